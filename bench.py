@@ -1,0 +1,260 @@
+#!/usr/bin/env python3
+"""bench.py -- frame-pair registrations/s of the CVO inner loop on MI355X.
+
+A "step" is one full align() (ref src/cvo.cpp:361-420: ~50 gradient-flow
+iterations, each = transform + flow sweep + step-size sweep over all
+target x source pairs) of BASELINE.json configs[1]: the seeded synthetic
+10k x 10k RGB-D cloud pair, from the reference object's initial state, with
+both clouds already resident in HBM.  One process per GPU; for N > 1 every rank
+registers its own pair (independent frame pairs: weak scaling, no data-path
+collective), and -- as a separately reported leg -- all ranks also run the
+target-sharded mode whose twist / step-coefficient partial sums are
+all-reduced with RCCL (BASELINE.json configs[3] scaled to fit the time budget).
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as ge  # noqa: E402
+
+FLOP_PER_PAIR = 8.0            # 3 sub + 3 mul + 2 add per pair test
+BYTES_PER_POINT = 32.0         # xyz 12 B + 5 features 20 B
+PEAK_F32_TFLOPS = 157.3        # MI355X_MICROARCH.md: FP32 vector = FP32 MFMA peak
+PEAK_HBM_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--points", type=int, default=10000, help="N = M of the synthetic pair")
+    ap.add_argument("--mode", default="cvo", choices=["cvo", "acvo"])
+    ap.add_argument("--cpu-seconds", type=float, default=15.0,
+                    help="budget of the cpu_baseline leg (rank 0, N=1 only)")
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--sharded-points", type=int, default=40000)
+    ap.add_argument("--sharded-steps", type=int, default=2)
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+
+    pkg = ge.load_package()
+    capi = pkg.capi
+    acvo = args.mode == "acvo"
+    mode = capi.MODE_ACVO if acvo else capi.MODE_CVO
+    n = m = args.points
+    # every rank registers its own frame pair (seed + rank)
+    xf, ff, xm, fm = pkg.data.synthetic_pair(n, m, seed=pkg.data.SEED_CFG2 + rank, acvo=acvo)
+    stream = torch.cuda.current_stream().cuda_stream
+    ctx = capi.Context(mode=mode, device=local_rank, stream=stream)
+    ctx.set_fixed(xf, ff)
+    ctx.set_moving(xm, fm)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def one_step():
+        st = capi.init_state(ctx.params)
+        n_it, _ = ctx.align(st, trace_cap=0)
+        return n_it, st
+
+    for _ in range(args.warmup):
+        one_step()
+    ctx.set_profiling(True)
+    ctx.get_profile(reset=True)
+    barrier()
+    t0 = time.perf_counter()
+    iters = 0
+    last_state = None
+    for _ in range(args.steps):
+        n_it, last_state = one_step()
+        iters += n_it
+    barrier()
+    elapsed = time.perf_counter() - t0
+    prof = ctx.get_profile(reset=True)
+    ctx.set_profiling(False)
+
+    t_max = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    it_sum = torch.tensor([float(iters)], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
+        dist.all_reduce(it_sum, op=dist.ReduceOp.SUM)
+    elapsed = float(t_max.item())
+    total_regs = args.steps * world
+    value = total_regs / elapsed
+
+    # parity sanity inside the bench: the registration recovers the synthetic motion
+    T_est = np.array(last_state.transform, np.float64).reshape(4, 4)
+    rot_err, tr_err = pkg.data.rel_pose_error(np.linalg.inv(T_est), np.linalg.inv(pkg.data.gt_motion()))
+
+    sharded = None
+    if world > 1 and args.sharded_steps > 0:
+        sharded = sharded_leg(args, pkg, dist, torch, rank, world, local_rank, barrier)
+
+    out = None
+    if rank == 0:
+        launches = prof["flow_launches"] + prof["step_launches"]
+        sweep_ms = (prof["flow_ms"] + prof["step_ms"]) / max(launches, 1)
+        pairs = (prof["flow_pairs"] + prof["step_pairs"]) / max(launches, 1)
+        achieved = FLOP_PER_PAIR * pairs / (sweep_ms * 1e-3) / 1e12 if sweep_ms > 0 else 0.0
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                with open(tpath) as fh:
+                    traffic = json.load(fh).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        algo_bytes = BYTES_PER_POINT * (n + m)
+        out = {
+            "metric": "frame-pair registrations/sec",
+            "value": value,
+            "unit": "registrations/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed * 1e3 / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": "synthetic %dk x %dk RGB-D cloud pair (xyz + 5-dim colour), %s align() "
+                            "to convergence, dense all-pairs sweeps" % (n // 1000, m // 1000, args.mode),
+                "points_fixed": n, "points_moving": m, "mode": args.mode,
+                "pairs_per_sweep": float(n) * m,
+                "parallelism": "1 registration per GPU" if world > 1 else "single GPU",
+            },
+            "iterations_per_registration": float(it_sum.item()) / total_regs,
+            "ms_per_iteration": elapsed * 1e3 * world / max(float(it_sum.item()), 1.0),
+            "gt_motion_rel_err": {"rot": rot_err, "trans": tr_err},
+            "roofline": {
+                "kernel": "k_sweep<FLOW|STEP> (all-pairs distance test + compacted survivors)",
+                "bound": "mfma",
+                "pipe": "fp32 VALU issue (f32 MFMA peak == f32 vector peak on gfx950)",
+                "achieved": achieved,
+                "peak": PEAK_F32_TFLOPS,
+                "unit": "TFLOP/s",
+                "frac": achieved / PEAK_F32_TFLOPS,
+                "flop_per_launch": FLOP_PER_PAIR * pairs,
+                "avg_launch_us": sweep_ms * 1e3,
+                "launches": launches,
+                "traffic": traffic,
+            },
+            "roofline_hbm": {
+                "bound": "hbm",
+                "achieved": algo_bytes / (sweep_ms * 1e-3) / 1e9 if sweep_ms > 0 else 0.0,
+                "peak": PEAK_HBM_GBS,
+                "unit": "GB/s",
+                "frac": (algo_bytes / (sweep_ms * 1e-3) / 1e9 / PEAK_HBM_GBS) if sweep_ms > 0 else 0.0,
+                "algorithmic_bytes_per_launch": algo_bytes,
+            },
+        }
+        if sharded is not None:
+            out["sharded_allreduce"] = sharded
+        if world == 1 and not args.no_cpu:
+            out["cpu_baseline"] = cpu_baseline(args, pkg, xf, ff, xm, fm, acvo)
+        print(json.dumps(out), flush=True)
+    ctx.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return out
+
+
+def sharded_leg(args, pkg, dist, torch, rank, world, local_rank, barrier):
+    """Target rows sharded over the ranks; the 13 + 4 float64 partial sums are
+    all-reduced with RCCL inside the C-ABI twice per iteration."""
+    capi = pkg.capi
+    acvo = args.mode == "acvo"
+    n = m = args.sharded_points
+    xf, ff, xm, fm = pkg.data.synthetic_pair(n, m, seed=pkg.data.SEED_CFG4, acvo=acvo)
+    stream = torch.cuda.current_stream().cuda_stream
+    ctx = capi.Context(mode=capi.MODE_ACVO if acvo else capi.MODE_CVO, device=local_rank,
+                       stream=stream)
+    ctx.set_fixed(xf, ff)
+    ctx.set_moving(xm, fm)
+    lo, hi = capi.shard_range(n, rank, world)
+    slo, shi = capi.shard_range(m, rank, world)
+    ctx.set_shard(lo, hi, slo, shi)
+    uid = [capi.comm_unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(uid, src=0)
+    ctx.comm_init(uid[0], rank, world)
+    st = capi.init_state(ctx.params)
+    ctx.align(st, trace_cap=0)   # warm-up (also sets up the RCCL channels)
+    barrier()
+    t0 = time.perf_counter()
+    iters = 0
+    for _ in range(args.sharded_steps):
+        st = capi.init_state(ctx.params)
+        n_it, _ = ctx.align(st, trace_cap=0)
+        iters += n_it
+    barrier()
+    el = time.perf_counter() - t0
+    t = torch.tensor([el], dtype=torch.float64, device="cuda")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    el = float(t.item())
+    ctx.close()
+    return {"workload": "synthetic %dk x %dk, target rows sharded %d ways, RCCL all-reduce of "
+                        "13+4 float64 per iteration" % (n // 1000, m // 1000, world),
+            "scaling": "strong", "registrations_per_s": args.sharded_steps / el,
+            "ms_per_iteration": el * 1e3 / max(iters, 1), "iterations": iters / args.sharded_steps}
+
+
+def cpu_baseline(args, pkg, xf, ff, xm, fm, acvo):
+    """The oracle (kind "port": the reference cannot be built here) timed on the
+    host cores of this box on a bounded sample of the same workload."""
+    from oracle import pyoracle as po
+    p = po.default_params(po.MODE_ACVO if acvo else po.MODE_CVO)
+    po.set_threads(0)
+    cores = po.get_threads()
+    done, iters = 0, 0
+    t0 = time.perf_counter()
+    while True:
+        st = po.init_state(p)
+        n_it, _ = po.align(p, st, xf, ff, xm, fm, search=po.SEARCH_GRID, trace_cap=1)
+        done += 1
+        iters += n_it
+        el = time.perf_counter() - t0
+        if el >= args.cpu_seconds or done >= 50:
+            break
+    return {"value": done / el, "unit": "registrations/s", "cores": cores, "kind": "port",
+            "ms_per_iteration": el * 1e3 / iters,
+            "sample": "%d full registration(s) of the same %dk x %dk pair (%d iterations), "
+                      "uniform-grid radius search + CSR Gram matrix as the reference, OpenMP on %d "
+                      "threads, %.1f s" % (done, xf.shape[0] // 1000, xm.shape[0] // 1000, iters,
+                                          cores, el)}
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,316 @@
+"""ctypes binding of include/cvo_hip.h (csrc/libcvo_hip.so)."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libcvo_hip.so")
+_LIB = None
+
+MODE_CVO, MODE_ACVO = 0, 1
+FEAT_COLMAJOR, FEAT_ROWMAJOR = 0, 1
+
+# every symbol include/cvo_hip.h declares (tests check the library exports all)
+SYMBOLS = [
+    "cvo_hip_error_string", "cvo_hip_last_error", "cvo_hip_device_count",
+    "cvo_hip_default_params", "cvo_hip_init_state", "cvo_hip_create", "cvo_hip_destroy",
+    "cvo_hip_set_params", "cvo_hip_set_fixed", "cvo_hip_set_moving",
+    "cvo_hip_swap_moving_to_fixed", "cvo_hip_set_shard", "cvo_hip_shard_range",
+    "cvo_hip_comm_unique_id", "cvo_hip_comm_init", "cvo_hip_set_allreduce",
+    "cvo_hip_transform_pcd", "cvo_hip_flow", "cvo_hip_step_coeffs", "cvo_hip_pick_step",
+    "cvo_hip_exp_se3", "cvo_hip_dist_se3", "cvo_hip_align", "cvo_hip_function_inner_product",
+    "cvo_hip_set_profiling", "cvo_hip_get_profile", "cvo_hip_synchronize",
+]
+
+
+class Params(C.Structure):
+    _fields_ = [
+        ("mode", C.c_int32), ("max_iter", C.c_int32),
+        ("ell_init", C.c_float), ("ell_min", C.c_float), ("ell_max_init", C.c_float),
+        ("sigma", C.c_float), ("sp_thres", C.c_float), ("c_sp_thres", C.c_float),
+        ("c", C.c_float), ("d", C.c_float), ("c_ell", C.c_float), ("c_sigma", C.c_float),
+        ("min_step", C.c_float), ("eps", C.c_float), ("eps_2", C.c_float), ("pad_", C.c_float),
+        ("dl_step", C.c_double),
+    ]
+
+
+class State(C.Structure):
+    _fields_ = [
+        ("R", C.c_float * 9), ("T", C.c_float * 3),
+        ("ell", C.c_float), ("ell_max", C.c_float),
+        ("transform", C.c_float * 16), ("prev_transform", C.c_float * 16),
+        ("accum_transform", C.c_float * 16),
+        ("iter", C.c_int32), ("pad_", C.c_int32),
+    ]
+
+
+class Trace(C.Structure):
+    _fields_ = [
+        ("k", C.c_int32), ("exit_code", C.c_int32),
+        ("ell", C.c_float), ("step", C.c_float), ("dist", C.c_float), ("pad_", C.c_float),
+        ("omega", C.c_float * 3), ("v", C.c_float * 3),
+        ("omega_d", C.c_double * 3), ("v_d", C.c_double * 3),
+        ("bcde", C.c_double * 4), ("sum_a", C.c_double), ("dl", C.c_double),
+        ("nnz", C.c_int64), ("nnz_xx", C.c_int64), ("nnz_yy", C.c_int64),
+    ]
+
+
+class Profile(C.Structure):
+    _fields_ = [
+        ("flow_ms", C.c_double), ("flow_launches", C.c_int64), ("flow_pairs", C.c_double),
+        ("step_ms", C.c_double), ("step_launches", C.c_int64), ("step_pairs", C.c_double),
+        ("self_ms", C.c_double), ("self_launches", C.c_int64), ("self_pairs", C.c_double),
+    ]
+
+
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p)
+
+
+class CvoHipError(RuntimeError):
+    pass
+
+
+def lib():
+    """Loads csrc/libcvo_hip.so; raises (never falls back) if it is missing."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(LIB_PATH):
+        raise CvoHipError(
+            "%s not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(there is no CPU fallback)" % LIB_PATH)
+    try:  # share the process's HIP runtime with torch when torch is present
+        import torch  # noqa: F401
+    except Exception:  # pragma: no cover
+        pass
+    L = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    fp, dp, vp = C.POINTER(C.c_float), C.POINTER(C.c_double), C.c_void_p
+    L.cvo_hip_error_string.restype = C.c_char_p
+    L.cvo_hip_error_string.argtypes = [C.c_int]
+    L.cvo_hip_last_error.restype = C.c_char_p
+    L.cvo_hip_last_error.argtypes = [vp]
+    L.cvo_hip_device_count.argtypes = [C.POINTER(C.c_int)]
+    L.cvo_hip_default_params.argtypes = [C.c_int, C.POINTER(Params)]
+    L.cvo_hip_init_state.argtypes = [C.POINTER(Params), C.POINTER(State)]
+    L.cvo_hip_create.argtypes = [C.c_int, vp, C.POINTER(Params), C.POINTER(vp)]
+    L.cvo_hip_destroy.argtypes = [vp]
+    L.cvo_hip_set_params.argtypes = [vp, C.POINTER(Params)]
+    L.cvo_hip_set_fixed.argtypes = [vp, fp, fp, C.c_int, C.c_int]
+    L.cvo_hip_set_moving.argtypes = [vp, fp, fp, C.c_int, C.c_int]
+    L.cvo_hip_swap_moving_to_fixed.argtypes = [vp]
+    L.cvo_hip_set_shard.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int]
+    L.cvo_hip_shard_range.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int),
+                                      C.POINTER(C.c_int)]
+    L.cvo_hip_comm_unique_id.argtypes = [vp]
+    L.cvo_hip_comm_init.argtypes = [vp, vp, C.c_int, C.c_int]
+    L.cvo_hip_set_allreduce.argtypes = [vp, ALLREDUCE_FN, vp]
+    L.cvo_hip_transform_pcd.argtypes = [vp, fp, fp]
+    L.cvo_hip_flow.argtypes = [vp, C.c_float, dp]
+    L.cvo_hip_step_coeffs.argtypes = [vp, fp, fp, C.c_float, dp]
+    L.cvo_hip_pick_step.argtypes = [dp, C.c_float, fp]
+    L.cvo_hip_exp_se3.argtypes = [fp, fp, C.c_float, fp, fp]
+    L.cvo_hip_dist_se3.argtypes = [fp, fp, C.c_float, fp]
+    L.cvo_hip_align.argtypes = [vp, C.POINTER(State), C.POINTER(Trace), C.c_int,
+                                C.POINTER(C.c_int)]
+    L.cvo_hip_function_inner_product.argtypes = [vp, C.c_float, fp]
+    L.cvo_hip_set_profiling.argtypes = [vp, C.c_int]
+    L.cvo_hip_get_profile.argtypes = [vp, C.POINTER(Profile), C.c_int]
+    L.cvo_hip_synchronize.argtypes = [vp]
+    for name in SYMBOLS:   # raises AttributeError if the library lacks a declared symbol
+        if name not in ("cvo_hip_error_string", "cvo_hip_last_error"):
+            getattr(L, name).restype = C.c_int
+    _LIB = L
+    return L
+
+
+def check(status, ctx=None, what=""):
+    if status == 0:
+        return
+    L = lib()
+    msg = L.cvo_hip_error_string(status).decode()
+    if ctx:
+        detail = L.cvo_hip_last_error(ctx).decode()
+        if detail:
+            msg += " (%s)" % detail
+    raise CvoHipError("%s: %s [%d]" % (what or "cvo_hip", msg, status))
+
+
+def device_count():
+    n = C.c_int(0)
+    check(lib().cvo_hip_device_count(C.byref(n)))
+    return n.value
+
+
+def default_params(mode=MODE_CVO):
+    p = Params()
+    check(lib().cvo_hip_default_params(mode, C.byref(p)), what="default_params")
+    return p
+
+
+def init_state(p):
+    s = State()
+    check(lib().cvo_hip_init_state(C.byref(p), C.byref(s)), what="init_state")
+    return s
+
+
+def f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def fptr(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def dptr(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def trace_to_dict(t):
+    return dict(k=t.k, exit_code=t.exit_code, ell=t.ell, step=t.step, dist=t.dist,
+                omega=list(t.omega), v=list(t.v), omega_d=list(t.omega_d), v_d=list(t.v_d),
+                bcde=list(t.bcde), sum_a=t.sum_a, dl=t.dl, nnz=t.nnz, nnz_xx=t.nnz_xx,
+                nnz_yy=t.nnz_yy)
+
+
+def pick_step(bcde, min_step=0.2):
+    b = np.ascontiguousarray(bcde, dtype=np.float64)
+    out = C.c_float()
+    check(lib().cvo_hip_pick_step(dptr(b), np.float32(min_step), C.byref(out)))
+    return out.value
+
+
+def exp_se3(omega, v, dt):
+    omega, v = f32(omega), f32(v)
+    dR, dT = np.zeros(9, np.float32), np.zeros(3, np.float32)
+    check(lib().cvo_hip_exp_se3(fptr(omega), fptr(v), np.float32(dt), fptr(dR), fptr(dT)))
+    return dR.reshape(3, 3), dT
+
+
+def dist_se3(omega, v, dt):
+    omega, v = f32(omega), f32(v)
+    out = C.c_float()
+    check(lib().cvo_hip_dist_se3(fptr(omega), fptr(v), np.float32(dt), C.byref(out)))
+    return out.value
+
+
+def shard_range(n, rank, world):
+    lo, hi = C.c_int(), C.c_int()
+    check(lib().cvo_hip_shard_range(n, rank, world, C.byref(lo), C.byref(hi)))
+    return lo.value, hi.value
+
+
+class Context:
+    """Owns one cvo_hip_ctx (one device + one HIP stream)."""
+
+    def __init__(self, params=None, mode=MODE_CVO, device=0, stream=None):
+        self._L = lib()
+        self.params = params if params is not None else default_params(mode)
+        self._ctx = C.c_void_p()
+        self._cb = None
+        check(self._L.cvo_hip_create(device, C.c_void_p(stream or 0), C.byref(self.params),
+                                     C.byref(self._ctx)), what="cvo_hip_create")
+        self.n_fixed = 0
+        self.n_moving = 0
+
+    def close(self):
+        if self._ctx:
+            self._L.cvo_hip_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, st, what):
+        check(st, self._ctx, what)
+
+    def set_params(self, params):
+        self.params = params
+        self._chk(self._L.cvo_hip_set_params(self._ctx, C.byref(params)), "set_params")
+
+    def set_fixed(self, xyz, feat, layout=FEAT_ROWMAJOR):
+        xyz, feat = f32(xyz), f32(feat)
+        self.n_fixed = xyz.shape[0]
+        self._chk(self._L.cvo_hip_set_fixed(self._ctx, fptr(xyz), fptr(feat), xyz.shape[0], layout),
+                  "set_fixed")
+
+    def set_moving(self, xyz, feat, layout=FEAT_ROWMAJOR):
+        xyz, feat = f32(xyz), f32(feat)
+        self.n_moving = xyz.shape[0]
+        self._chk(self._L.cvo_hip_set_moving(self._ctx, fptr(xyz), fptr(feat), xyz.shape[0],
+                                             layout), "set_moving")
+
+    def swap_moving_to_fixed(self):
+        self._chk(self._L.cvo_hip_swap_moving_to_fixed(self._ctx), "swap")
+        self.n_fixed, self.n_moving = self.n_moving, 0
+
+    def set_shard(self, row_lo, row_hi, srow_lo, srow_hi):
+        self._chk(self._L.cvo_hip_set_shard(self._ctx, row_lo, row_hi, srow_lo, srow_hi),
+                  "set_shard")
+
+    def comm_init(self, id_bytes, rank, world):
+        buf = C.create_string_buffer(bytes(id_bytes), 128)
+        self._chk(self._L.cvo_hip_comm_init(self._ctx, buf, rank, world), "comm_init")
+
+    def set_allreduce(self, fn):
+        """fn(dev_ptr:int, count:int, stream:int) -> None ; sums in place over ranks."""
+        def _cb(_user, buf, count, stream):
+            try:
+                fn(int(buf or 0), int(count), int(stream or 0))
+                return 0
+            except Exception:  # pragma: no cover
+                import traceback
+                traceback.print_exc()
+                return -1
+        self._cb = ALLREDUCE_FN(_cb)
+        self._chk(self._L.cvo_hip_set_allreduce(self._ctx, self._cb, None), "set_allreduce")
+
+    def transform_pcd(self, R, T):
+        R, T = f32(R).reshape(9), f32(T).reshape(3)
+        self._chk(self._L.cvo_hip_transform_pcd(self._ctx, fptr(R), fptr(T)), "transform_pcd")
+
+    def flow(self, ell):
+        out = np.zeros(13)
+        self._chk(self._L.cvo_hip_flow(self._ctx, np.float32(ell), dptr(out)), "flow")
+        return out
+
+    def step_coeffs(self, omega, v, ell):
+        omega, v = f32(omega), f32(v)
+        out = np.zeros(4)
+        self._chk(self._L.cvo_hip_step_coeffs(self._ctx, fptr(omega), fptr(v), np.float32(ell),
+                                              dptr(out)), "step_coeffs")
+        return out
+
+    def align(self, state, trace_cap=2000):
+        tr = (Trace * trace_cap)() if trace_cap > 0 else None
+        n_it = C.c_int(0)
+        self._chk(self._L.cvo_hip_align(self._ctx, C.byref(state), tr, trace_cap, C.byref(n_it)),
+                  "align")
+        n = n_it.value
+        return n, [trace_to_dict(tr[i]) for i in range(min(n, trace_cap))]
+
+    def function_inner_product(self, ell):
+        out = C.c_float()
+        self._chk(self._L.cvo_hip_function_inner_product(self._ctx, np.float32(ell), C.byref(out)),
+                  "function_inner_product")
+        return out.value
+
+    def set_profiling(self, enable=True):
+        self._chk(self._L.cvo_hip_set_profiling(self._ctx, int(bool(enable))), "set_profiling")
+
+    def get_profile(self, reset=False):
+        p = Profile()
+        self._chk(self._L.cvo_hip_get_profile(self._ctx, C.byref(p), int(reset)), "get_profile")
+        return {k: getattr(p, k) for k, _ in Profile._fields_}
+
+    def synchronize(self):
+        self._chk(self._L.cvo_hip_synchronize(self._ctx), "synchronize")
+
+
+def comm_unique_id():
+    buf = C.create_string_buffer(128)
+    check(lib().cvo_hip_comm_unique_id(buf), what="comm_unique_id")
+    return buf.raw

@@ -1,0 +1,138 @@
+// cvo_class.cpp -- C++ registration objects over the C-ABI (see include/cvo.hpp).
+#include "cvo.hpp"
+
+#include <cmath>
+#include <cstring>
+#include <iostream>
+#include <stdexcept>
+
+namespace cvo_hip {
+
+Affine3f::Affine3f()
+{
+    std::memset(m, 0, sizeof(m));
+    m[0] = m[5] = m[10] = m[15] = 1.0f;
+}
+
+void Affine3f::translation(float t[3]) const
+{
+    t[0] = m[3]; t[1] = m[7]; t[2] = m[11];
+}
+
+void Affine3f::linear(float r[9]) const
+{
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) r[3 * i + j] = m[4 * i + j];
+}
+
+void Affine3f::quaternion(float q[4]) const
+{   // Eigen's quaternion-from-matrix (Shoemake), float
+    const float m00 = m[0], m11 = m[5], m22 = m[10];
+    float t = m00 + m11 + m22;
+    float x, y, z, w;
+    if (t > 0.0f) {
+        t = std::sqrt(t + 1.0f);
+        w = 0.5f * t;
+        t = 0.5f / t;
+        x = (m[9] - m[6]) * t;
+        y = (m[2] - m[8]) * t;
+        z = (m[4] - m[1]) * t;
+    } else {
+        int i = 0;
+        if (m11 > m00) i = 1;
+        if (m22 > m[5 * i]) i = 2;
+        const int j = (i + 1) % 3, k = (j + 1) % 3;
+        t = std::sqrt(m[5 * i] - m[5 * j] - m[5 * k] + 1.0f);
+        float qv[3];
+        qv[i] = 0.5f * t;
+        t = 0.5f / t;
+        w = (m[4 * k + j] - m[4 * j + k]) * t;
+        qv[j] = (m[4 * j + i] + m[4 * i + j]) * t;
+        qv[k] = (m[4 * k + i] + m[4 * i + k]) * t;
+        x = qv[0]; y = qv[1]; z = qv[2];
+    }
+    q[0] = x; q[1] = y; q[2] = z; q[3] = w;
+}
+
+registration::registration(int mode, int device, void *stream)
+    : init(false), iter(0), ctx_(nullptr), have_moving_(false), n_iter_(0)
+{
+    check(cvo_hip_default_params(mode, &params_), "cvo_hip_default_params");
+    check(cvo_hip_init_state(&params_, &state_), "cvo_hip_init_state");
+    check(cvo_hip_create(device, stream, &params_, &ctx_), "cvo_hip_create");
+}
+
+registration::~registration() { cvo_hip_destroy(ctx_); }
+
+void registration::check(int status, const char *what)
+{
+    if (status == CVO_HIP_OK) return;
+    std::string msg = std::string(what) + ": " + cvo_hip_error_string(status);
+    if (ctx_) msg += std::string(" (") + cvo_hip_last_error(ctx_) + ")";
+    throw std::runtime_error(msg);
+}
+
+void registration::publish()
+{
+    std::memcpy(transform.m, state_.transform, sizeof(transform.m));
+    std::memcpy(prev_transform.m, state_.prev_transform, sizeof(prev_transform.m));
+    std::memcpy(accum_transform.m, state_.accum_transform, sizeof(accum_transform.m));
+    iter = state_.iter;
+}
+
+void registration::set_pcd(const point_cloud_view &pc)
+{   // ref src/cvo.cpp:319-357
+    if (init == false) {
+        std::cout << "initializing cvo..." << std::endl;
+        check(cvo_hip_set_fixed(ctx_, pc.positions, pc.features, pc.num_points, pc.feat_layout),
+              "cvo_hip_set_fixed");
+        std::cout << "first pcd generated!" << std::endl;
+        init = true;
+        return;
+    }
+    check(cvo_hip_set_moving(ctx_, pc.positions, pc.features, pc.num_points, pc.feat_layout),
+          "cvo_hip_set_moving");
+    have_moving_ = true;
+}
+
+void registration::align()
+{   // ref src/cvo.cpp:361-420; the moving cloud becomes the fixed one (:417)
+    if (!have_moving_) throw std::runtime_error("align(): set_pcd() must precede each align()");
+    check(cvo_hip_align(ctx_, &state_, nullptr, 0, &n_iter_), "cvo_hip_align");
+    check(cvo_hip_swap_moving_to_fixed(ctx_), "cvo_hip_swap_moving_to_fixed");
+    have_moving_ = false;
+    publish();
+}
+
+void registration::run_cvo(const point_cloud_view &pc)
+{   // ref src/cvo.cpp:422-435
+    if (init == false) {
+        set_pcd(pc);
+    } else {
+        set_pcd(pc);
+        align();
+        std::cout << "Total iterations: " << iter << std::endl;
+        std::cout << "RKHS-SE(3) Object Transformation Estimate: \n";
+        for (int r = 0; r < 4; ++r)
+            std::cout << transform.m[4 * r] << " " << transform.m[4 * r + 1] << " "
+                      << transform.m[4 * r + 2] << " " << transform.m[4 * r + 3] << std::endl;
+    }
+}
+
+}   // namespace cvo_hip
+
+namespace acvo {
+
+float acvo::function_inner_product(const cvo_hip::point_cloud_view &cloud_b)
+{
+    check(cvo_hip_set_moving(ctx_, cloud_b.positions, cloud_b.features, cloud_b.num_points,
+                             cloud_b.feat_layout),
+          "cvo_hip_set_moving");
+    have_moving_ = true;
+    float out = 0.0f;
+    check(cvo_hip_function_inner_product(ctx_, state_.ell, &out),
+          "cvo_hip_function_inner_product");
+    return out;
+}
+
+}   // namespace acvo

@@ -1,0 +1,80 @@
+"""Python mirror of the reference's registration objects.
+
+``Cvo`` ~ cvo::cvo (ref cpp/rkhs_registration/include/cvo.hpp:55-193),
+``Acvo`` ~ acvo::acvo (ref include/adaptive_cvo.hpp:57-196): same members
+(init, iter, transform, prev_transform, accum_transform) and methods
+(set_pcd, align, run_cvo), the point cloud arriving as arrays instead of
+cv::Mat images (the image front end is outside this back end).
+All computation goes through the HIP C-ABI; nothing here has a CPU path.
+"""
+import numpy as np
+
+from . import capi
+
+
+class _Registration:
+    MODE = capi.MODE_CVO
+
+    def __init__(self, device=0, stream=None, params=None):
+        self.params = params if params is not None else capi.default_params(self.MODE)
+        self.ctx = capi.Context(self.params, device=device, stream=stream)
+        self.state = capi.init_state(self.params)
+        self.init = False
+        self.iter = 0
+        self.transform = np.eye(4, dtype=np.float32)
+        self.prev_transform = np.eye(4, dtype=np.float32)
+        self.accum_transform = np.eye(4, dtype=np.float32)
+        self.num_iterations = 0
+        self.trace = []
+        self._have_moving = False
+
+    def _publish(self):
+        s = self.state
+        self.transform = np.array(s.transform, np.float32).reshape(4, 4)
+        self.prev_transform = np.array(s.prev_transform, np.float32).reshape(4, 4)
+        self.accum_transform = np.array(s.accum_transform, np.float32).reshape(4, 4)
+        self.iter = int(s.iter)
+
+    def set_pcd(self, positions, features, layout=capi.FEAT_ROWMAJOR):
+        """ref src/cvo.cpp:319-357 (tail: hand the clouds to the back end)."""
+        if not self.init:
+            self.ctx.set_fixed(positions, features, layout)
+            self.init = True
+            return
+        self.ctx.set_moving(positions, features, layout)
+        self._have_moving = True
+
+    def align(self, trace_cap=0):
+        """ref src/cvo.cpp:361-420."""
+        if not self._have_moving:
+            raise capi.CvoHipError("align(): set_pcd() must precede each align()")
+        self.num_iterations, self.trace = self.ctx.align(self.state, trace_cap=trace_cap)
+        self.ctx.swap_moving_to_fixed()   # ptr_fixed_pcd = std::move(ptr_moving_pcd)
+        self._have_moving = False
+        self._publish()
+
+    def run_cvo(self, positions, features, layout=capi.FEAT_ROWMAJOR, trace_cap=0):
+        """ref src/cvo.cpp:422-435."""
+        if not self.init:
+            self.set_pcd(positions, features, layout)
+        else:
+            self.set_pcd(positions, features, layout)
+            self.align(trace_cap=trace_cap)
+
+    def close(self):
+        self.ctx.close()
+
+
+class Cvo(_Registration):
+    MODE = capi.MODE_CVO
+
+
+class Acvo(_Registration):
+    MODE = capi.MODE_ACVO
+
+    def function_inner_product(self, positions, features, layout=capi.FEAT_ROWMAJOR):
+        """ref src/adaptive_cvo.cpp:385-439: statistic between the current fixed
+        cloud and the given cloud at the current length-scale."""
+        self.ctx.set_moving(positions, features, layout)
+        self._have_moving = True
+        return self.ctx.function_inner_product(self.state.ell)

@@ -1,0 +1,204 @@
+/*
+ * cvo_hip.h -- C-ABI of the MI355X (gfx950) back end for the CVO / Adaptive-CVO
+ * registration inner loop.
+ *
+ * This is the drop-in boundary: the four private calls
+ *     update_tf(); transform_pcd(); compute_flow(); compute_step_size();
+ * inside cvo::cvo::align() (ref cpp/rkhs_registration/src/cvo.cpp:366-377;
+ * acvo: src/adaptive_cvo.cpp:495-506) and the cloud hand-over at the tail of
+ * set_pcd() (ref src/cvo.cpp:344-356).  Plain pointers and sizes only; no
+ * Eigen, OpenCV or torch types cross it.  INTEGRATION.md shows the edits a
+ * maintainer of the reference makes to bind it.
+ *
+ * Conventions
+ *   - every function returns int: 0 = ok, <0 = cvo_hip_status (never throws);
+ *     cvo_hip_error_string() gives text, cvo_hip_last_error(ctx) detail.
+ *   - the caller owns all host arrays; the context owns all device memory.
+ *   - a context is bound to one device and one HIP stream and is NOT
+ *     thread-safe; distinct contexts are independent (batched mode = one
+ *     context per stream, ref SURVEY 8e).
+ *   - clouds: xyz is AoS n x 3 float32 (std::vector<Eigen::Vector3f>,
+ *     ref include/data_type.h:30,63); features n x 5 float32, either
+ *     column-major (Eigen::Matrix<float,Dynamic,5>, ref data_type.h:64) or
+ *     row-major, selected by feat_layout.
+ *   - matrices R (3x3) and the 4x4 transforms are ROW-major in this ABI.
+ */
+#ifndef CVO_HIP_H
+#define CVO_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CVO_HIP_NFEAT 5
+
+typedef enum cvo_hip_status {
+    CVO_HIP_OK = 0,
+    CVO_HIP_ERR_INVALID = -1,   /* bad argument / call order */
+    CVO_HIP_ERR_HIP = -2,       /* a HIP runtime call failed */
+    CVO_HIP_ERR_NOMEM = -3,
+    CVO_HIP_ERR_COMM = -4,      /* RCCL failure */
+    CVO_HIP_ERR_NODEVICE = -5   /* no usable gfx950 device */
+} cvo_hip_status;
+
+enum { CVO_HIP_MODE_CVO = 0, CVO_HIP_MODE_ACVO = 1 };
+enum { CVO_HIP_FEAT_COLMAJOR = 0, CVO_HIP_FEAT_ROWMAJOR = 1 };
+
+/* Hyper-parameters.  Defaults = the reference's constructor initialisers
+ * (ref src/cvo.cpp:18-48, src/adaptive_cvo.cpp:18-50). */
+typedef struct cvo_hip_params {
+    int32_t mode;        /* CVO_HIP_MODE_* */
+    int32_t max_iter;    /* MAX_ITER */
+    float ell_init;
+    float ell_min;
+    float ell_max_init;
+    float sigma;
+    float sp_thres;
+    float c_sp_thres;
+    float c;
+    float d;
+    float c_ell;
+    float c_sigma;
+    float min_step;
+    float eps;
+    float eps_2;
+    float pad_;
+    double dl_step;
+} cvo_hip_params;
+
+/* Per-object state the reference keeps in cvo::cvo members and carries from
+ * frame to frame (R, T, ell are never reset in cvo: SURVEY 8a quirks 1-4). */
+typedef struct cvo_hip_state {
+    float R[9];
+    float T[3];
+    float ell;
+    float ell_max;
+    float transform[16];        /* ref cvo.hpp:104 */
+    float prev_transform[16];   /* ref cvo.hpp:105 */
+    float accum_transform[16];  /* ref cvo.hpp:106 */
+    int32_t iter;               /* ref cvo.hpp:103 */
+    int32_t pad_;
+} cvo_hip_state;
+
+/* One record per executed iteration of align() (the parity artefact; the
+ * reference only prints, ref src/cvo.cpp:382,404). */
+typedef struct cvo_hip_trace {
+    int32_t k;
+    int32_t exit_code;   /* 0 continued, 1 break on twist norms, 2 break on se3 distance */
+    float ell;
+    float step;
+    float dist;
+    float pad_;
+    float omega[3];
+    float v[3];
+    double omega_d[3];
+    double v_d[3];
+    double bcde[4];
+    double sum_a;
+    double dl;
+    int64_t nnz;
+    int64_t nnz_xx;
+    int64_t nnz_yy;
+} cvo_hip_trace;
+
+/* Accumulated HIP-event timings of the two pair sweeps (profiling mode). */
+typedef struct cvo_hip_profile {
+    double flow_ms;        /* sum over launches of the flow sweep kernel */
+    int64_t flow_launches;
+    double flow_pairs;     /* pair tests executed by those launches */
+    double step_ms;
+    int64_t step_launches;
+    double step_pairs;
+    double self_ms;        /* acvo Axx/Ayy sweeps */
+    int64_t self_launches;
+    double self_pairs;
+} cvo_hip_profile;
+
+typedef struct cvo_hip_ctx cvo_hip_ctx;
+
+const char *cvo_hip_error_string(int status);
+const char *cvo_hip_last_error(const cvo_hip_ctx *ctx);
+int cvo_hip_device_count(int *count);
+
+/* ref src/cvo.cpp:18-48 / src/adaptive_cvo.cpp:18-50 (constructors). */
+int cvo_hip_default_params(int mode, cvo_hip_params *p);
+int cvo_hip_init_state(const cvo_hip_params *p, cvo_hip_state *s);
+
+/* stream: a hipStream_t (e.g. torch.cuda.current_stream().cuda_stream) or NULL
+ * to let the context create its own non-blocking stream. */
+int cvo_hip_create(int device, void *stream, const cvo_hip_params *p, cvo_hip_ctx **out);
+int cvo_hip_destroy(cvo_hip_ctx *ctx);
+int cvo_hip_set_params(cvo_hip_ctx *ctx, const cvo_hip_params *p);
+
+/* Cloud hand-over: tail of set_pcd() (ref src/cvo.cpp:344-356). */
+int cvo_hip_set_fixed(cvo_hip_ctx *ctx, const float *xyz, const float *feat, int n,
+                      int feat_layout);
+int cvo_hip_set_moving(cvo_hip_ctx *ctx, const float *xyz, const float *feat, int m,
+                       int feat_layout);
+/* ptr_fixed_pcd = std::move(ptr_moving_pcd) (ref src/cvo.cpp:417): device
+ * buffers are swapped, nothing is re-uploaded. */
+int cvo_hip_swap_moving_to_fixed(cvo_hip_ctx *ctx);
+
+/* Multi-GPU: this context owns target rows [row_lo,row_hi) of the fixed cloud
+ * (and rows [srow_lo,srow_hi) of the moving cloud for the acvo Ayy sweep).
+ * Default = everything. */
+int cvo_hip_set_shard(cvo_hip_ctx *ctx, int row_lo, int row_hi, int srow_lo, int srow_hi);
+/* Even contiguous split helper: rows of `n` owned by `rank` of `world`. */
+int cvo_hip_shard_range(int n, int rank, int world, int *lo, int *hi);
+
+/* RCCL all-reduce of the per-iteration partial sums (13 + 4 float64).
+ * id_bytes = the 128-byte ncclUniqueId made by cvo_hip_comm_unique_id() on
+ * rank 0 and shipped to the other ranks by the caller. */
+int cvo_hip_comm_unique_id(void *id_bytes_128);
+int cvo_hip_comm_init(cvo_hip_ctx *ctx, const void *id_bytes_128, int rank, int world);
+/* Alternative: caller-supplied reduction (buf is a DEVICE pointer valid on the
+ * context's stream; must be summed over ranks in place, stream-ordered). */
+typedef int (*cvo_hip_allreduce_fn)(void *user, double *dev_buf, int count, void *stream);
+int cvo_hip_set_allreduce(cvo_hip_ctx *ctx, cvo_hip_allreduce_fn fn, void *user);
+
+/* update_tf() + transform_pcd() (ref src/cvo.cpp:83-87,310-315). */
+int cvo_hip_transform_pcd(cvo_hip_ctx *ctx, const float R[9], const float T[3]);
+
+/* se_kernel() + compute_flow() (ref src/cvo.cpp:99-161,164-210) on the
+ * current transformed cloud: float64 sums of the per-pair float32 terms.
+ * out13 = { omega[3], v[3], sum_a, sum_a_d2 (acvo dl term), nnz(A),
+ *           sum_xx, nnz(Axx), sum_yy_tail, nnz(Ayy) }  (last four: acvo only,
+ * ref src/adaptive_cvo.cpp:154-272); already all-reduced if a communicator is
+ * attached. */
+int cvo_hip_flow(cvo_hip_ctx *ctx, float ell, double out13[13]);
+
+/* compute_step_size() coefficient sums (ref src/cvo.cpp:213-289). */
+int cvo_hip_step_coeffs(cvo_hip_ctx *ctx, const float omega[3], const float v[3], float ell,
+                        double bcde[4]);
+
+/* Root selection + clamps (ref src/cvo.cpp:291-307), Exp_SEK3
+ * (ref src/LieGroup.cpp:159-186) and dist_se3 (ref src/cvo.cpp:71-81): the O(1)
+ * host maths of the loop, exported for tests and for callers that drive the
+ * iteration themselves. */
+int cvo_hip_pick_step(const double bcde[4], float min_step, float *step);
+int cvo_hip_exp_se3(const float omega[3], const float v[3], float dt, float dR[9], float dT[3]);
+int cvo_hip_dist_se3(const float omega[3], const float v[3], float dt, float *dist);
+
+/* align() (ref src/cvo.cpp:361-420, src/adaptive_cvo.cpp:490-555): the whole
+ * gradient-flow loop on the clouds currently set.  Updates *state; writes at
+ * most trace_cap trace records if trace != NULL; *n_iter = loop bodies run. */
+int cvo_hip_align(cvo_hip_ctx *ctx, cvo_hip_state *state, cvo_hip_trace *trace,
+                  int trace_cap, int *n_iter);
+
+/* acvo::function_inner_product (ref src/adaptive_cvo.cpp:385-439) between the
+ * fixed and the (untransformed) moving cloud at length-scale ell. */
+int cvo_hip_function_inner_product(cvo_hip_ctx *ctx, float ell, float *out);
+
+/* Profiling: HIP events on the context's stream around every sweep launch. */
+int cvo_hip_set_profiling(cvo_hip_ctx *ctx, int enable);
+int cvo_hip_get_profile(cvo_hip_ctx *ctx, cvo_hip_profile *out, int reset);
+
+/* Blocks until everything queued on the context's stream has finished. */
+int cvo_hip_synchronize(cvo_hip_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CVO_HIP_H */

@@ -154,6 +154,7 @@ typedef struct kconsts {
     float sp;           /* keep iff a > sp */
     double ninv_2l2;    /* -1/(2 l^2)   (float64) */
     double ninv_2cl2;   /* -1/(2 c_l^2) (float64) */
+    int geom_only;      /* radius-set mode: keep every d2 < tau, value = d2 */
 } kconsts;
 
 static float logf_cr(float x) { return (float)log((double)x); }
@@ -161,6 +162,7 @@ static float logf_cr(float x) { return (float)log((double)x); }
 static void make_kconsts(const cvo_oracle_params *p, float ell, float c_sp, kconsts *k)
 {
     const float l = ell;
+    k->geom_only = 0;
     k->s2 = p->sigma * p->sigma;
     k->cs2 = p->c_sigma * p->c_sigma;
     k->sp = p->sp_thres;
@@ -186,6 +188,7 @@ void cvo_oracle_thresholds(const cvo_oracle_params *p, float ell, float tau[2])
  * float64 (one rounding apart from the reference's division). */
 static inline float pair_weight(const kconsts *kc, float d2, const float *fa, const float *fb)
 {
+    if (kc->geom_only) return d2 > 0.0f ? d2 : 1e-45f;   /* denormal marks d2 == 0 */
     const float d2c = d2_feat(fa, fb);
     if (!(d2c < kc->tau_c)) return 0.0f;
     const float k = (float)((double)kc->s2 * exp((double)d2 * kc->ninv_2l2));
@@ -502,6 +505,23 @@ int cvo_oracle_se_kernel(const cvo_oracle_params *p, float ell, float c_sp, cons
     kconsts kc;
     make_kconsts(p, ell, c_sp, &kc);
     return se_kernel_rows(&kc, xa, fa, 0, na, xb, fb, nb, search, row_ptr, col, val);
+}
+
+int cvo_oracle_radius_sets(const float *xa, int na, const float *xb, int nb, float tau,
+                            int search, int64_t **row_ptr, int32_t **col, float **d2)
+{
+    kconsts kc;
+    memset(&kc, 0, sizeof(kc));
+    kc.geom_only = 1;
+    kc.tau = tau;
+    /* features are not read in geom_only mode; pass the positions as dummies */
+    const int rc = se_kernel_rows(&kc, xa, xa, 0, na, xb, xb, nb, search, row_ptr, col, d2);
+    if (rc == 0) {
+        const int64_t nnz = (*row_ptr)[na];
+        for (int64_t q = 0; q < nnz; ++q)
+            if ((*d2)[q] == 1e-45f) (*d2)[q] = 0.0f;
+    }
+    return rc;
 }
 
 void cvo_oracle_free(void *p) { free(p); }

@@ -121,6 +121,12 @@ int cvo_oracle_se_kernel(const cvo_oracle_params *p, float ell, float c_sp,
                          int64_t **row_ptr, int32_t **col, float **val);
 void cvo_oracle_free(void *p);
 
+/* The purely geometric neighbour sets of se_kernel: for every row point a_i
+ * all b_j with d2(a_i,b_j) < tau (strict), columns ascending, value = d2.
+ * This is what nanoflann's radiusSearch returns (ref cvo.cpp:110-125). */
+int cvo_oracle_radius_sets(const float *xa, int na, const float *xb, int nb, float tau,
+                           int search, int64_t **row_ptr, int32_t **col, float **d2);
+
 /* compute_flow on a CSR A.  omega_d/v_d are the float64 sums (already scaled by
  * 1/c, 1/d per pair as the reference does); sum_a = sum of A values;
  * sum_a_d2 = sum of (1/ell^3 * A_ij) * ||y_j - x_i||^2 (acvo dl term). */

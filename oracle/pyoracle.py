@@ -80,6 +80,10 @@ def lib():
             C.POINTER(fp)]
         L.cvo_oracle_se_kernel.restype = C.c_int
         L.cvo_oracle_free.argtypes = [C.c_void_p]
+        L.cvo_oracle_radius_sets.argtypes = [
+            fp, C.c_int, fp, C.c_int, C.c_float, C.c_int,
+            C.POINTER(C.POINTER(C.c_int64)), C.POINTER(C.POINTER(C.c_int32)), C.POINTER(fp)]
+        L.cvo_oracle_radius_sets.restype = C.c_int
         L.cvo_oracle_flow.argtypes = [
             C.POINTER(Params), C.c_float, fp, C.c_int, fp, C.c_int,
             C.POINTER(C.c_int64), C.POINTER(C.c_int32), fp, dp, dp, dp, dp]
@@ -185,6 +189,26 @@ def se_kernel(p, ell, xa, fa, xb, fb, search=SEARCH_DENSE, c_sp=None):
                                     C.byref(rp), C.byref(col), C.byref(val))
     if rc != 0:
         raise MemoryError("cvo_oracle_se_kernel failed")
+    na = xa.shape[0]
+    row_ptr = np.ctypeslib.as_array(rp, shape=(na + 1,)).copy()
+    nnz = int(row_ptr[-1])
+    cols = np.ctypeslib.as_array(col, shape=(max(nnz, 1),))[:nnz].copy()
+    vals = np.ctypeslib.as_array(val, shape=(max(nnz, 1),))[:nnz].copy()
+    for q in (rp, col, val):
+        lib().cvo_oracle_free(q)
+    return row_ptr, cols, vals
+
+
+def radius_sets(xa, xb, tau, search=SEARCH_DENSE):
+    """CSR (row_ptr, col ascending, d2) of all pairs with d2 < tau."""
+    xa, xb = _f32(xa), _f32(xb)
+    rp = C.POINTER(C.c_int64)()
+    col = C.POINTER(C.c_int32)()
+    val = C.POINTER(C.c_float)()
+    rc = lib().cvo_oracle_radius_sets(_fp(xa), xa.shape[0], _fp(xb), xb.shape[0], np.float32(tau),
+                                      search, C.byref(rp), C.byref(col), C.byref(val))
+    if rc != 0:
+        raise MemoryError("cvo_oracle_radius_sets failed")
     na = xa.shape[0]
     row_ptr = np.ctypeslib.as_array(rp, shape=(na + 1,)).copy()
     nnz = int(row_ptr[-1])

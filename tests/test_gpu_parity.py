@@ -1,0 +1,160 @@
+"""-m gpu: the HIP path (through the C-ABI) against the CPU oracle.
+
+Tolerances.  Per-pair float32 terms are bit-identical by construction
+(DESIGN.md "Arithmetic contract"); only the float64 summation order differs,
+so sums agree to ~1e-12 of the sum of absolute terms, the float32-rounded
+twist and step are expected to be IDENTICAL, and align() must take the same
+number of iterations and land on the same transform (north_star: <= 1e-4
+relative rotation / translation error; asserted here at 1e-6).
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+SUM_RTOL = 1e-11   # float64 sums, relative to the largest |component|
+
+
+def _ctx(pkg, mode, xf, ff, xm, fm):
+    import torch
+    c = pkg.capi.Context(mode=mode, device=0, stream=torch.cuda.current_stream().cuda_stream)
+    c.set_fixed(xf, ff)
+    c.set_moving(xm, fm)
+    return c
+
+
+def _close(a, b, rtol=SUM_RTOL):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    scale = max(np.abs(b).max(), 1e-300)
+    return np.abs(a - b).max() <= rtol * scale
+
+
+def _small_motion():
+    R = np.eye(3, dtype=np.float32)
+    th = 0.01
+    R[0, 0], R[0, 1], R[1, 0], R[1, 1] = np.cos(th), -np.sin(th), np.sin(th), np.cos(th)
+    return R, np.array([0.002, -0.001, 0.003], np.float32)
+
+
+@pytest.mark.parametrize("n,m", [(3000, 3000), (1000, 1500), (257, 63), (64, 1), (1, 700)])
+@pytest.mark.parametrize("ell", [0.15, 0.06])
+def test_flow_and_step_match_oracle(pkg, po, n, m, ell):
+    xf, ff, xm, fm = pkg.data.synthetic_pair(n, m, seed=11)
+    R, T = _small_motion()
+    c = _ctx(pkg, pkg.capi.MODE_CVO, xf, ff, xm, fm)
+    c.transform_pcd(R, T)
+    out = c.flow(ell)
+    p = po.default_params(po.MODE_CVO)
+    y = po.transform(R, T, xm)
+    csr = po.se_kernel(p, ell, xf, ff, y, fm, search=po.SEARCH_GRID)
+    om, v, sa, sad2 = po.flow(p, ell, xf, y, csr)
+    assert int(out[8]) == int(csr[0][-1])                 # nnz(A) exact
+    assert _close(out[0:3], om) and _close(out[3:6], v)
+    assert _close([out[6]], [sa]) and _close([out[7]], [sad2])
+    omega, vv = om.astype(np.float32), v.astype(np.float32)
+    assert np.array_equal(out[0:3].astype(np.float32), omega)   # float32 twist identical
+    bcde = c.step_coeffs(omega, vv, ell)
+    ref = po.step_coeffs(ell, omega, vv, xf, y, csr)
+    assert _close(bcde, ref, 1e-10)
+    assert pkg.capi.pick_step(bcde) == po.pick_step(ref)
+    c.close()
+
+
+def test_flow_matches_oracle_on_tum_pair(pkg, po, desk):
+    xf, ff = desk["xyz0"][::5], pkg.data.cvo_features(desk["rgb0"][::5])
+    xm, fm = desk["xyz1"][::5], pkg.data.cvo_features(desk["rgb1"][::5])
+    c = _ctx(pkg, pkg.capi.MODE_CVO, xf, ff, xm, fm)
+    R, T = np.eye(3, dtype=np.float32), np.zeros(3, np.float32)
+    c.transform_pcd(R, T)
+    p = po.default_params(po.MODE_CVO)
+    for ell in (0.15, 0.10, 0.06, 0.03):
+        out = c.flow(ell)
+        csr = po.se_kernel(p, ell, xf, ff, xm, fm, search=po.SEARCH_GRID)
+        om, v, sa, _ = po.flow(p, ell, xf, xm, csr)
+        assert int(out[8]) == int(csr[0][-1])
+        assert _close(out[0:3], om) and _close(out[3:6], v) and _close([out[6]], [sa])
+    c.close()
+
+
+@pytest.mark.parametrize("n,m", [(1500, 1500), (900, 1300), (1300, 900)])
+def test_acvo_self_terms_match_oracle(pkg, po, n, m):
+    xf, ff, xm, fm = pkg.data.synthetic_pair(n, m, seed=5, acvo=True)
+    R, T = _small_motion()
+    c = _ctx(pkg, pkg.capi.MODE_ACVO, xf, ff, xm, fm)
+    c.transform_pcd(R, T)
+    ell = 0.1
+    out = c.flow(ell)
+    p = po.default_params(po.MODE_ACVO)
+    y = po.transform(R, T, xm)
+    A = po.se_kernel(p, ell, xf, ff, y, fm, search=po.SEARCH_GRID)
+    Axx = po.se_kernel(p, ell, xf, ff, xf, ff, search=po.SEARCH_GRID)
+    Ayy = po.se_kernel(p, ell, y, fm, y, fm, search=po.SEARCH_GRID)
+    assert (int(out[8]), int(out[10]), int(out[12])) == (int(A[0][-1]), int(Axx[0][-1]), int(Ayy[0][-1]))
+    # sum_xx over all rows; sum_yy only over rows >= n (reference quirk, acvo.cpp:213-265)
+    inv_l3 = np.float32(1) / (np.float32(ell) * np.float32(ell) * np.float32(ell))
+
+    def self_sum(X, csr, first):
+        rp, col, val = csr
+        rows = np.repeat(np.arange(X.shape[0]), np.diff(rp))
+        keep = rows >= first
+        e = (X[rows[keep]] - X[col[keep]]).astype(np.float32)
+        d2 = np.float32(0) + e[:, 0] * e[:, 0]
+        d2 = (e[:, 1].astype(np.float64) * e[:, 1] + d2).astype(np.float32)   # fma
+        d2 = (e[:, 2].astype(np.float64) * e[:, 2] + d2).astype(np.float32)
+        return float((((inv_l3 * val[keep]).astype(np.float32) * d2).astype(np.float32)).astype(np.float64).sum())
+    assert _close([out[9]], [self_sum(xf, Axx, 0)], 1e-9)
+    assert _close([out[11]], [self_sum(y, Ayy, n)], 1e-9) or (m <= n and out[11] == 0.0)
+    c.close()
+
+
+def _align_both(pkg, po, mode, xf, ff, xm, fm):
+    import torch
+    Reg = pkg.Cvo if mode == pkg.capi.MODE_CVO else pkg.Acvo
+    reg = Reg(device=0, stream=torch.cuda.current_stream().cuda_stream)
+    reg.run_cvo(xf, ff)
+    reg.run_cvo(xm, fm, trace_cap=2000)
+    p = po.default_params(mode)
+    st = po.init_state(p)
+    n_or, tr_or = po.align(p, st, xf, ff, xm, fm, search=po.SEARCH_GRID)
+    return reg, n_or, tr_or, po.state_matrices(st)
+
+
+@pytest.mark.parametrize("mode_name", ["cvo", "acvo"])
+def test_align_matches_oracle_synthetic(pkg, po, mode_name):
+    mode = pkg.capi.MODE_CVO if mode_name == "cvo" else pkg.capi.MODE_ACVO
+    xf, ff, xm, fm = pkg.data.synthetic_pair(2000, 2000, seed=7, acvo=(mode_name == "acvo"))
+    reg, n_or, tr_or, (T_or, P_or, A_or) = _align_both(pkg, po, mode, xf, ff, xm, fm)
+    assert reg.num_iterations == n_or
+    assert reg.iter == tr_or[-1]["k"]
+    for a, b in zip(reg.trace, tr_or):
+        assert a["nnz"] == b["nnz"] and a["ell"] == b["ell"]
+        assert a["omega"] == b["omega"] and a["v"] == b["v"] and a["step"] == b["step"]
+    rot, tr = pkg.data.rel_pose_error(reg.transform, T_or)
+    assert rot <= 1e-6 and tr <= 1e-6
+    assert np.allclose(reg.accum_transform, A_or, rtol=0, atol=1e-7)
+    reg.close()
+
+
+def test_align_matches_oracle_tum_pair(pkg, po, desk):
+    xf, ff = desk["xyz0"][::5], pkg.data.cvo_features(desk["rgb0"][::5])
+    xm, fm = desk["xyz1"][::5], pkg.data.cvo_features(desk["rgb1"][::5])
+    reg, n_or, tr_or, (T_or, _, _) = _align_both(pkg, po, pkg.capi.MODE_CVO, xf, ff, xm, fm)
+    assert reg.num_iterations == n_or
+    rot, tr = pkg.data.rel_pose_error(reg.transform, T_or)
+    assert rot <= 1e-6 and tr <= 1e-6
+    reg.close()
+
+
+def test_empty_gram_matrix_breaks_at_once(pkg):
+    """Clouds 10 m apart: A is empty, omega = v = 0, break A at k = 0 with
+    step = min_step."""
+    import torch
+    xf, ff, xm, fm = pkg.data.synthetic_pair(500, 400, seed=3)
+    xm = xm + np.float32(10.0)
+    reg = pkg.Cvo(device=0, stream=torch.cuda.current_stream().cuda_stream)
+    reg.run_cvo(xf, ff)
+    reg.run_cvo(xm, fm, trace_cap=10)
+    assert reg.num_iterations == 1 and reg.trace[0]["exit_code"] == 1
+    assert reg.trace[0]["nnz"] == 0 and reg.trace[0]["step"] == np.float32(0.2)
+    assert np.array_equal(reg.transform, np.eye(4, dtype=np.float32))
+    reg.close()
