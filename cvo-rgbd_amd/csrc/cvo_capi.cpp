@@ -2,6 +2,12 @@
 // kernel orchestration and the align() loop of cvo::cvo / acvo::acvo
 // (ref src/cvo.cpp:361-420, src/adaptive_cvo.cpp:490-555) on one MI355X.
 //
+// The loop is device-resident: registration state (R, T, ell, twist, partial
+// sums, trace) lives in HBM, the O(1) maths between the sweeps runs in the
+// k_post_* kernels, and the host only enqueues batches of iterations and
+// polls a `done` word through pinned memory.  After convergence the remaining
+// queued kernels return at once.
+//
 // There is no CPU fallback in this library: every entry point that computes
 // needs a gfx950 device and fails with CVO_HIP_ERR_NODEVICE / _HIP otherwise.
 #include "cvo_hip.h"
@@ -10,21 +16,23 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstddef>
 #include <cstdio>
 #include <cstring>
+#include <new>
 #include <string>
 #include <vector>
 
 #include "cvo_comm.h"
 #include "cvo_device.h"
-#include "se3_host.hpp"
+#include "se3_math.hpp"
 
 using namespace cvo_dev;
 
 namespace {
 
 struct Cloud {
-    float4 *pos = nullptr;   // original positions
+    float4 *pos = nullptr;
     float *feat = nullptr;
     int n = 0;
     int cap = 0;
@@ -36,6 +44,20 @@ struct EventPair {
     double pairs;
 };
 
+struct SweepPlan {
+    dim3 grid;
+    int jt = 0;
+    int nblocks = 0;
+};
+
+struct PartialBuf {
+    double *p = nullptr;
+    size_t cap = 0;   // doubles
+};
+
+constexpr int kBatch = 8;        // iterations enqueued between two polls
+constexpr int kPollSlots = 4;
+
 }   // namespace
 
 struct cvo_hip_ctx {
@@ -43,17 +65,16 @@ struct cvo_hip_ctx {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     cvo_hip_params prm{};
+    DevParams dprm{};
     Cloud fixed, moving;
-    float4 *moving_tf = nullptr;   // transformed moving cloud (cloud_y)
-    int moving_tf_cap = 0;
-    float *taylor = nullptr;
-    int taylor_cap = 0;
-    double *partials = nullptr;
-    size_t partials_cap = 0;       // in doubles
-    double *totals = nullptr;      // device [32]
-    double *totals_host = nullptr; // pinned [32]
+    DevState *st = nullptr;          // device
+    DevState *st_host = nullptr;     // pinned [kPollSlots + 1]
+    hipEvent_t poll_ev[kPollSlots]{};
+    PartialBuf part_flow, part_xx, part_yy, part_step;
+    cvo_hip_trace *trace_dev = nullptr;
+    int trace_dev_cap = 0;
     bool have_tf = false;
-    int row_lo = 0, row_hi = -1, srow_lo = 0, srow_hi = -1;   // -1 = whole cloud
+    int row_lo = 0, row_hi = -1, srow_lo = 0, srow_hi = -1;
     bool sharded = false;
     cvo_comm *comm = nullptr;
     cvo_hip_allreduce_fn user_allreduce = nullptr;
@@ -81,15 +102,32 @@ int fail(cvo_hip_ctx *ctx, int code, const char *msg)
     return code;
 }
 
-int ensure_f4(cvo_hip_ctx *ctx, float4 **p, int *cap, int n)
+DevParams make_dev_params(const cvo_hip_params &p)
 {
-    if (n <= *cap) return CVO_HIP_OK;
-    if (*p) HIP_TRY(ctx, hipFree(*p));
-    *p = nullptr;
-    *cap = 0;
-    HIP_TRY(ctx, hipMalloc((void **)p, (size_t)n * sizeof(float4)));
-    *cap = n;
-    return CVO_HIP_OK;
+    DevParams d{};
+    d.mode = p.mode;
+    d.max_iter = p.max_iter;
+    d.ell_init = p.ell_init;
+    d.ell_min = p.ell_min;
+    d.ell_max_init = p.ell_max_init;
+    d.sp = p.sp_thres;
+    d.c_sp = (p.mode == CVO_HIP_MODE_ACVO) ? p.c_sp_thres : p.sp_thres;
+    d.c = p.c;
+    d.d = p.d;
+    d.c_ell = p.c_ell;
+    d.min_step = p.min_step;
+    d.eps = p.eps;
+    d.eps_2 = p.eps_2;
+    const float s2 = p.sigma * p.sigma;
+    const float cs2 = p.c_sigma * p.c_sigma;
+    // `log(sp_thres/s2)` is the float overload in the reference (ref cvo.cpp:102)
+    d.log_sp_s2 = (float)std::log((double)(p.sp_thres / s2));
+    d.tau_c = (float)(-2.0 * p.c_ell * p.c_ell *
+                      (double)(float)std::log((double)(d.c_sp / p.c_sigma / p.c_sigma)));
+    d.s2_d = (double)s2;
+    d.cs2_d = (double)cs2;
+    d.dl_step = p.dl_step;
+    return d;
 }
 
 int upload_cloud(cvo_hip_ctx *ctx, Cloud &c, const float *xyz, const float *feat, int n,
@@ -128,69 +166,33 @@ int upload_cloud(cvo_hip_ctx *ctx, Cloud &c, const float *xyz, const float *feat
     return CVO_HIP_OK;
 }
 
-KernConsts make_kconsts(const cvo_hip_params &p, float ell, float c_sp)
-{
-    KernConsts k{};
-    const float l = ell;
-    const float s2 = p.sigma * p.sigma;
-    const float cs2 = p.c_sigma * p.c_sigma;
-    k.tau = cvo_host::d2_threshold(l, p.sp_thres, s2);
-    k.tau_c = cvo_host::d2c_threshold(p.c_ell, c_sp, p.c_sigma);
-    k.sp = p.sp_thres;
-    k.inv_c = 1 / p.c;
-    k.inv_d = 1 / p.d;
-    const float ell_3 = l * l * l;
-    k.inv_l3 = 1 / ell_3;
-    const float temp_coef = (float)(1 / (2.0 * l * l));
-    k.cb = (float)(-2.0 * temp_coef);
-    k.cg = -temp_coef;
-    k.cd = (float)(2.0 * temp_coef);
-    k.s2_d = (double)s2;
-    k.cs2_d = (double)cs2;
-    k.ninv_2l2 = -1.0 / (2.0 * l * l);
-    k.ninv_2cl2 = -1.0 / (2.0 * p.c_ell * p.c_ell);
-    return k;
-}
-
 // Chunk length so that the grid has enough workgroups to fill 256 CUs a few
 // times over while each block still amortises its prologue/epilogue.
-int pick_jt(int nrows, int nb)
-{
-    const int tiles = std::max(1, (nrows + rows_per_tile() - 1) / rows_per_tile());
-    const int want_blocks = 2048;
-    int chunks = std::max(1, want_blocks / tiles);
-    int jt = (nb + chunks - 1) / chunks;
-    jt = std::max(jt, 64);
-    jt = std::min(jt, 2048);
-    jt = (jt + 3) & ~3;
-    return jt;
-}
-
-struct SweepPlan {
-    dim3 grid;
-    int jt;
-    int nblocks;
-};
-
 SweepPlan plan_sweep(int nrows, int nb)
 {
     SweepPlan p{};
-    p.jt = pick_jt(nrows, nb);
-    const int chunks = std::max(1, (nb + p.jt - 1) / p.jt);
-    const int tiles = std::max(1, (nrows + rows_per_tile() - 1) / rows_per_tile());
+    const int tiles = std::max(1, (nrows + ROWS_PER_TILE - 1) / ROWS_PER_TILE);
+    const int want_blocks = 2048;
+    const int chunks_want = std::max(1, want_blocks / tiles);
+    int jt = (nb + chunks_want - 1) / chunks_want;
+    jt = std::max(jt, 64);
+    jt = std::min(jt, 2048);
+    jt = (jt + 3) & ~3;
+    p.jt = jt;
+    const int chunks = std::max(1, (nb + jt - 1) / jt);
     p.grid = dim3(chunks, tiles);
     p.nblocks = chunks * tiles;
     return p;
 }
 
-int ensure_partials(cvo_hip_ctx *ctx, size_t doubles)
+int ensure_partials(cvo_hip_ctx *ctx, PartialBuf &b, size_t doubles)
 {
-    if (doubles <= ctx->partials_cap) return CVO_HIP_OK;
-    if (ctx->partials) HIP_TRY(ctx, hipFree(ctx->partials));
-    ctx->partials = nullptr;
-    ctx->partials_cap = 0;
-    HIP_TRY(ctx, hipMalloc((void **)&ctx->partials, doubles * sizeof(double)));
-    ctx->partials_cap = doubles;
+    if (doubles <= b.cap) return CVO_HIP_OK;
+    if (b.p) HIP_TRY(ctx, hipFree(b.p));
+    b.p = nullptr;
+    b.cap = 0;
+    HIP_TRY(ctx, hipMalloc((void **)&b.p, doubles * sizeof(double)));
+    b.cap = doubles;
     return CVO_HIP_OK;
 }
 
@@ -204,28 +206,30 @@ void shard_ranges(const cvo_hip_ctx *ctx, int &rlo, int &rhi, int &slo, int &shi
     slo = std::min(slo, shi);
 }
 
-// Launch one sweep + its finalize; totals land in ctx->totals[off .. off+nacc).
-int run_sweep(cvo_hip_ctx *ctx, int mode, const float4 *pos_a, const float *feat_a, int row_lo,
-              int row_hi, const float4 *pos_b, const float *feat_b, int nb, int first_counted,
-              const KernConsts &kc, int nacc, int off)
+// One sweep launch (with optional HIP-event bracket).  Empty row ranges or
+// column sets still launch nothing and leave nblocks = 0 (the post kernel then
+// reduces zero blocks to 0.0).
+int enqueue_sweep(cvo_hip_ctx *ctx, int mode, PartialBuf &pb, const float4 *pos_a,
+                  const float *feat_a, int row_lo, int row_hi, int tf_a, const float4 *pos_b,
+                  const float *feat_b, int nb, int tf_b, int first_counted, int check_done,
+                  int *nblocks_out)
 {
     const int nrows = row_hi - row_lo;
-    if (nrows <= 0 || nb <= 0) {
-        HIP_TRY(ctx, hipMemsetAsync(ctx->totals + off, 0, nacc * sizeof(double), ctx->stream));
-        return CVO_HIP_OK;
-    }
+    *nblocks_out = 0;
+    if (nrows <= 0 || nb <= 0) return CVO_HIP_OK;
     const SweepPlan pl = plan_sweep(nrows, nb);
-    int rc = ensure_partials(ctx, (size_t)pl.nblocks * NACC_MAX);
+    int rc = ensure_partials(ctx, pb, (size_t)pl.nblocks * NACC_MAX);
     if (rc) return rc;
     SweepArgs a{};
     a.pos_a = pos_a; a.feat_a = feat_a;
     a.pos_b = pos_b; a.feat_b = feat_b;
-    a.taylor = ctx->taylor;
-    a.partials = ctx->partials;
+    a.partials = pb.p;
+    a.st = ctx->st;
     a.row_lo = row_lo; a.row_hi = row_hi;
     a.nb = nb; a.jt = pl.jt;
     a.first_counted = first_counted;
-    a.kc = kc;
+    a.tf_a = tf_a; a.tf_b = tf_b;
+    a.check_done = check_done;
     EventPair ev{};
     if (ctx->profiling) {
         HIP_TRY(ctx, hipEventCreate(&ev.a));
@@ -240,8 +244,7 @@ int run_sweep(cvo_hip_ctx *ctx, int mode, const float4 *pos_a, const float *feat
         ctx->events.push_back(ev);
     }
     HIP_TRY(ctx, hipGetLastError());
-    launch_finalize(ctx->partials, pl.nblocks, nacc, ctx->totals + off, ctx->stream);
-    HIP_TRY(ctx, hipGetLastError());
+    *nblocks_out = pl.nblocks;
     return CVO_HIP_OK;
 }
 
@@ -265,103 +268,120 @@ int drain_events(cvo_hip_ctx *ctx)
     return CVO_HIP_OK;
 }
 
-// all-reduce `count` doubles at ctx->totals+off over ranks (no-op single rank)
+bool multi_rank(const cvo_hip_ctx *ctx) { return ctx->comm || ctx->user_allreduce; }
+
+// all-reduce `count` doubles of st->red starting at `off` over the ranks
 int reduce_over_ranks(cvo_hip_ctx *ctx, int off, int count)
 {
+    double *buf = reinterpret_cast<double *>(reinterpret_cast<char *>(ctx->st) +
+                                             offsetof(DevState, red)) + off;
     if (ctx->comm) {
-        if (cvo_comm_allreduce(ctx->comm, ctx->totals + off, count, ctx->stream) != 0)
+        if (cvo_comm_allreduce(ctx->comm, buf, count, ctx->stream) != 0)
             return fail(ctx, CVO_HIP_ERR_COMM, cvo_comm_last_error(ctx->comm));
     } else if (ctx->user_allreduce) {
-        if (ctx->user_allreduce(ctx->user_allreduce_arg, ctx->totals + off, count,
-                                (void *)ctx->stream) != 0)
+        if (ctx->user_allreduce(ctx->user_allreduce_arg, buf, count, (void *)ctx->stream) != 0)
             return fail(ctx, CVO_HIP_ERR_COMM, "user all-reduce failed");
     }
     return CVO_HIP_OK;
 }
 
-int fetch_totals(cvo_hip_ctx *ctx, int off, int count, double *out)
+// flow side of one iteration: sweeps + reduction (+ all-reduce) (+ maths)
+int enqueue_flow(cvo_hip_ctx *ctx, bool tf_moving, int check_done, bool do_math,
+                 cvo_hip_trace *trace, int trace_cap)
 {
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->totals_host + off, ctx->totals + off, count * sizeof(double),
-                                hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    std::memcpy(out, ctx->totals_host + off, count * sizeof(double));
-    return CVO_HIP_OK;
-}
-
-int flow_impl(cvo_hip_ctx *ctx, float ell, double out13[13])
-{
-    if (!ctx->have_tf) return fail(ctx, CVO_HIP_ERR_INVALID, "transform_pcd not called");
     const bool acvo = ctx->prm.mode == CVO_HIP_MODE_ACVO;
-    const KernConsts kc =
-        make_kconsts(ctx->prm, ell, acvo ? ctx->prm.c_sp_thres : ctx->prm.sp_thres);
     int rlo, rhi, slo, shi;
     shard_ranges(ctx, rlo, rhi, slo, shi);
-    int rc = run_sweep(ctx, SWEEP_FLOW, ctx->fixed.pos, ctx->fixed.feat, rlo, rhi, ctx->moving_tf,
-                       ctx->moving.feat, ctx->moving.n, 0, kc, NACC_FLOW, 0);
+    PostFlowArgs pa{};
+    pa.st = ctx->st;
+    pa.prm = ctx->dprm;
+    pa.trace = trace; pa.trace_cap = trace_cap;
+    pa.check_done = check_done;
+    int rc = enqueue_sweep(ctx, SWEEP_FLOW, ctx->part_flow, ctx->fixed.pos, ctx->fixed.feat, rlo,
+                           rhi, 0, ctx->moving.pos, ctx->moving.feat, ctx->moving.n,
+                           tf_moving ? 1 : 0, 0, check_done, &pa.nb_flow);
     if (rc) return rc;
     if (acvo) {
         // Axx rows of this shard vs all of x; Ayy rows of this shard vs all of y
-        rc = run_sweep(ctx, SWEEP_SELF, ctx->fixed.pos, ctx->fixed.feat, rlo, rhi, ctx->fixed.pos,
-                       ctx->fixed.feat, ctx->fixed.n, 0, kc, NACC_SELF, 9);
+        rc = enqueue_sweep(ctx, SWEEP_SELF, ctx->part_xx, ctx->fixed.pos, ctx->fixed.feat, rlo, rhi,
+                           0, ctx->fixed.pos, ctx->fixed.feat, ctx->fixed.n, 0, 0, check_done,
+                           &pa.nb_xx);
         if (rc) return rc;
-        rc = run_sweep(ctx, SWEEP_SELF, ctx->moving_tf, ctx->moving.feat, slo, shi, ctx->moving_tf,
-                       ctx->moving.feat, ctx->moving.n, ctx->fixed.n, kc, NACC_SELF, 11);
+        rc = enqueue_sweep(ctx, SWEEP_SELF, ctx->part_yy, ctx->moving.pos, ctx->moving.feat, slo,
+                           shi, 1, ctx->moving.pos, ctx->moving.feat, ctx->moving.n, 1,
+                           ctx->fixed.n, check_done, &pa.nb_yy);
         if (rc) return rc;
-    } else {
-        HIP_TRY(ctx, hipMemsetAsync(ctx->totals + 9, 0, 4 * sizeof(double), ctx->stream));
     }
-    rc = reduce_over_ranks(ctx, 0, 13);
-    if (rc) return rc;
-    return fetch_totals(ctx, 0, 13, out13);
+    pa.part_flow = ctx->part_flow.p;
+    pa.part_xx = ctx->part_xx.p;
+    pa.part_yy = ctx->part_yy.p;
+    if (multi_rank(ctx)) {
+        pa.flags = POST_REDUCE;
+        launch_post_flow(pa, ctx->stream);
+        rc = reduce_over_ranks(ctx, RED_FLOW, RED_STEP - RED_FLOW);
+        if (rc) return rc;
+        if (do_math) {
+            pa.flags = POST_MATH;
+            launch_post_flow(pa, ctx->stream);
+        }
+    } else {
+        pa.flags = POST_REDUCE | (do_math ? POST_MATH : 0);
+        launch_post_flow(pa, ctx->stream);
+    }
+    HIP_TRY(ctx, hipGetLastError());
+    return CVO_HIP_OK;
 }
 
-int step_impl(cvo_hip_ctx *ctx, const float omega[3], const float v[3], float ell, double bcde[4])
+int enqueue_step(cvo_hip_ctx *ctx, int check_done, bool do_math, cvo_hip_trace *trace,
+                 int trace_cap)
 {
-    if (!ctx->have_tf) return fail(ctx, CVO_HIP_ERR_INVALID, "transform_pcd not called");
-    const bool acvo = ctx->prm.mode == CVO_HIP_MODE_ACVO;
-    const KernConsts kc =
-        make_kconsts(ctx->prm, ell, acvo ? ctx->prm.c_sp_thres : ctx->prm.sp_thres);
-    const int m = ctx->moving.n;
-    if (m > ctx->taylor_cap) {
-        if (ctx->taylor) HIP_TRY(ctx, hipFree(ctx->taylor));
-        ctx->taylor = nullptr; ctx->taylor_cap = 0;
-        HIP_TRY(ctx, hipMalloc((void **)&ctx->taylor, (size_t)m * TAYLOR_STRIDE * sizeof(float)));
-        ctx->taylor_cap = m;
-    }
-    const cvo_host::XiConsts xc = cvo_host::make_xi_consts(omega, v);
-    TaylorArgs ta{};
-    ta.pos = ctx->moving_tf; ta.taylor = ctx->taylor; ta.n = m;
-    std::memcpy(ta.omega, xc.omega, sizeof(ta.omega));
-    std::memcpy(ta.v, xc.v, sizeof(ta.v));
-    std::memcpy(ta.W2, xc.W2, sizeof(ta.W2));
-    std::memcpy(ta.W3, xc.W3, sizeof(ta.W3));
-    std::memcpy(ta.W4, xc.W4, sizeof(ta.W4));
-    std::memcpy(ta.u2, xc.u2, sizeof(ta.u2));
-    std::memcpy(ta.u3, xc.u3, sizeof(ta.u3));
-    std::memcpy(ta.u4, xc.u4, sizeof(ta.u4));
-    launch_taylor(ta, ctx->stream);
-    HIP_TRY(ctx, hipGetLastError());
     int rlo, rhi, slo, shi;
     shard_ranges(ctx, rlo, rhi, slo, shi);
-    int rc = run_sweep(ctx, SWEEP_STEP, ctx->fixed.pos, ctx->fixed.feat, rlo, rhi, ctx->moving_tf,
-                       ctx->moving.feat, m, 0, kc, NACC_STEP, 16);
+    PostStepArgs pa{};
+    pa.st = ctx->st;
+    pa.prm = ctx->dprm;
+    pa.trace = trace; pa.trace_cap = trace_cap;
+    pa.check_done = check_done;
+    int rc = enqueue_sweep(ctx, SWEEP_STEP, ctx->part_step, ctx->fixed.pos, ctx->fixed.feat, rlo,
+                           rhi, 0, ctx->moving.pos, ctx->moving.feat, ctx->moving.n, 1, 0,
+                           check_done, &pa.nb_step);
     if (rc) return rc;
-    rc = reduce_over_ranks(ctx, 16, 4);
-    if (rc) return rc;
-    return fetch_totals(ctx, 16, 4, bcde);
+    pa.part_step = ctx->part_step.p;
+    if (multi_rank(ctx)) {
+        pa.flags = POST_REDUCE;
+        launch_post_step(pa, ctx->stream);
+        rc = reduce_over_ranks(ctx, RED_STEP, RED_N - RED_STEP);
+        if (rc) return rc;
+        if (do_math) {
+            pa.flags = POST_MATH;
+            launch_post_step(pa, ctx->stream);
+        }
+    } else {
+        pa.flags = POST_REDUCE | (do_math ? POST_MATH : 0);
+        launch_post_step(pa, ctx->stream);
+    }
+    HIP_TRY(ctx, hipGetLastError());
+    return CVO_HIP_OK;
 }
 
-int transform_impl(cvo_hip_ctx *ctx, const float R[9], const float T[3])
+// host -> device copy of a few DevState fields through pinned staging slot 0
+int push_state_fields(cvo_hip_ctx *ctx, size_t off, size_t bytes)
 {
-    const int m = ctx->moving.n;
-    int rc = ensure_f4(ctx, &ctx->moving_tf, &ctx->moving_tf_cap, std::max(m, 1));
-    if (rc) return rc;
-    TransformArgs ta{};
-    ta.src = ctx->moving.pos; ta.dst = ctx->moving_tf; ta.n = m;
-    cvo_host::inverse_tf(R, T, ta.Rt, ta.t);
-    launch_transform(ta, ctx->stream);
-    HIP_TRY(ctx, hipGetLastError());
-    ctx->have_tf = true;
+    HIP_TRY(ctx, hipMemcpyAsync(reinterpret_cast<char *>(ctx->st) + off,
+                                reinterpret_cast<char *>(&ctx->st_host[kPollSlots]) + off, bytes,
+                                hipMemcpyHostToDevice, ctx->stream));
+    return CVO_HIP_OK;
+}
+
+int fetch_red(cvo_hip_ctx *ctx, int off, int count, double *out)
+{
+    DevState *h = &ctx->st_host[0];
+    HIP_TRY(ctx, hipMemcpyAsync(h->red + off,
+                                reinterpret_cast<char *>(ctx->st) + offsetof(DevState, red) +
+                                    off * sizeof(double),
+                                count * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    std::memcpy(out, h->red + off, count * sizeof(double));
     return CVO_HIP_OK;
 }
 
@@ -450,6 +470,7 @@ int cvo_hip_create(int device, void *stream, const cvo_hip_params *p, cvo_hip_ct
     if (!ctx) return CVO_HIP_ERR_NOMEM;
     ctx->device = device;
     ctx->prm = *p;
+    ctx->dprm = make_dev_params(*p);
     auto bail = [&](int code) {
         cvo_hip_destroy(ctx);
         return code;
@@ -462,13 +483,16 @@ int cvo_hip_create(int device, void *stream, const cvo_hip_params *p, cvo_hip_ct
             return bail(CVO_HIP_ERR_HIP);
         ctx->own_stream = true;
     }
-    if (hipMalloc((void **)&ctx->totals, 32 * sizeof(double)) != hipSuccess)
+    if (hipMalloc((void **)&ctx->st, sizeof(DevState)) != hipSuccess) return bail(CVO_HIP_ERR_NOMEM);
+    if (hipHostMalloc((void **)&ctx->st_host, (kPollSlots + 1) * sizeof(DevState),
+                      hipHostMallocDefault) != hipSuccess)
         return bail(CVO_HIP_ERR_NOMEM);
-    if (hipHostMalloc((void **)&ctx->totals_host, 32 * sizeof(double), hipHostMallocDefault) !=
-        hipSuccess)
-        return bail(CVO_HIP_ERR_NOMEM);
-    if (hipMemsetAsync(ctx->totals, 0, 32 * sizeof(double), ctx->stream) != hipSuccess)
+    std::memset(ctx->st_host, 0, (kPollSlots + 1) * sizeof(DevState));
+    if (hipMemsetAsync(ctx->st, 0, sizeof(DevState), ctx->stream) != hipSuccess)
         return bail(CVO_HIP_ERR_HIP);
+    for (int i = 0; i < kPollSlots; ++i)
+        if (hipEventCreateWithFlags(&ctx->poll_ev[i], hipEventDisableTiming) != hipSuccess)
+            return bail(CVO_HIP_ERR_HIP);
     *out = ctx;
     return CVO_HIP_OK;
 }
@@ -479,12 +503,15 @@ int cvo_hip_destroy(cvo_hip_ctx *ctx)
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     for (auto &ev : ctx->events) { hipEventDestroy(ev.a); hipEventDestroy(ev.b); }
+    for (int i = 0; i < kPollSlots; ++i)
+        if (ctx->poll_ev[i]) hipEventDestroy(ctx->poll_ev[i]);
     if (ctx->comm) cvo_comm_destroy(ctx->comm);
     for (void *p : {(void *)ctx->fixed.pos, (void *)ctx->fixed.feat, (void *)ctx->moving.pos,
-                    (void *)ctx->moving.feat, (void *)ctx->moving_tf, (void *)ctx->taylor,
-                    (void *)ctx->partials, (void *)ctx->totals})
+                    (void *)ctx->moving.feat, (void *)ctx->st, (void *)ctx->part_flow.p,
+                    (void *)ctx->part_xx.p, (void *)ctx->part_yy.p, (void *)ctx->part_step.p,
+                    (void *)ctx->trace_dev})
         if (p) (void)hipFree(p);
-    if (ctx->totals_host) (void)hipHostFree(ctx->totals_host);
+    if (ctx->st_host) (void)hipHostFree(ctx->st_host);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return CVO_HIP_OK;
@@ -494,6 +521,7 @@ int cvo_hip_set_params(cvo_hip_ctx *ctx, const cvo_hip_params *p)
 {
     if (!ctx || !p) return CVO_HIP_ERR_INVALID;
     ctx->prm = *p;
+    ctx->dprm = make_dev_params(*p);
     return CVO_HIP_OK;
 }
 
@@ -568,14 +596,35 @@ int cvo_hip_transform_pcd(cvo_hip_ctx *ctx, const float R[9], const float T[3])
 {
     if (!ctx || !R || !T) return CVO_HIP_ERR_INVALID;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    return transform_impl(ctx, R, T);
+    // update_tf(): the sweeps apply [Rt|t] while staging the moving cloud
+    DevState *h = &ctx->st_host[kPollSlots];
+    std::memcpy(h->R, R, sizeof(h->R));
+    std::memcpy(h->T, T, sizeof(h->T));
+    cvo_math::inverse_tf(R, T, h->Rt, h->t);
+    h->done = 0;
+    int rc = push_state_fields(ctx, offsetof(DevState, R), offsetof(DevState, ell) - offsetof(DevState, R));
+    if (rc) return rc;
+    rc = push_state_fields(ctx, offsetof(DevState, Rt), offsetof(DevState, used_Rt) - offsetof(DevState, Rt));
+    if (rc) return rc;
+    rc = push_state_fields(ctx, offsetof(DevState, done), sizeof(int32_t));
+    if (rc) return rc;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->have_tf = true;
+    return CVO_HIP_OK;
 }
 
 int cvo_hip_flow(cvo_hip_ctx *ctx, float ell, double out13[13])
 {
     if (!ctx || !out13) return CVO_HIP_ERR_INVALID;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    int rc = flow_impl(ctx, ell, out13);
+    if (!ctx->have_tf) return fail(ctx, CVO_HIP_ERR_INVALID, "transform_pcd not called");
+    DevState *h = &ctx->st_host[kPollSlots];
+    h->kc = make_kconsts(ctx->dprm, ell);
+    int rc = push_state_fields(ctx, offsetof(DevState, kc), sizeof(KernConsts));
+    if (rc) return rc;
+    rc = enqueue_flow(ctx, true, 0, false, nullptr, 0);
+    if (rc) return rc;
+    rc = fetch_red(ctx, RED_FLOW, 13, out13);
     if (!rc && ctx->profiling) rc = drain_events(ctx);
     return rc;
 }
@@ -585,7 +634,16 @@ int cvo_hip_step_coeffs(cvo_hip_ctx *ctx, const float omega[3], const float v[3]
 {
     if (!ctx || !omega || !v || !bcde) return CVO_HIP_ERR_INVALID;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    int rc = step_impl(ctx, omega, v, ell, bcde);
+    if (!ctx->have_tf) return fail(ctx, CVO_HIP_ERR_INVALID, "transform_pcd not called");
+    DevState *h = &ctx->st_host[kPollSlots];
+    h->kc = make_kconsts(ctx->dprm, ell);
+    h->xi = cvo_math::make_xi_consts(omega, v);
+    int rc = push_state_fields(ctx, offsetof(DevState, kc),
+                               offsetof(DevState, omega) - offsetof(DevState, kc));
+    if (rc) return rc;
+    rc = enqueue_step(ctx, 0, false, nullptr, 0);
+    if (rc) return rc;
+    rc = fetch_red(ctx, RED_STEP, 4, bcde);
     if (!rc && ctx->profiling) rc = drain_events(ctx);
     return rc;
 }
@@ -593,21 +651,21 @@ int cvo_hip_step_coeffs(cvo_hip_ctx *ctx, const float omega[3], const float v[3]
 int cvo_hip_pick_step(const double bcde[4], float min_step, float *step)
 {
     if (!bcde || !step) return CVO_HIP_ERR_INVALID;
-    *step = cvo_host::pick_step(bcde, min_step);
+    *step = cvo_math::pick_step(bcde, min_step);
     return CVO_HIP_OK;
 }
 
 int cvo_hip_exp_se3(const float omega[3], const float v[3], float dt, float dR[9], float dT[3])
 {
     if (!omega || !v || !dR || !dT) return CVO_HIP_ERR_INVALID;
-    cvo_host::exp_se3(omega, v, dt, dR, dT);
+    cvo_math::exp_se3(omega, v, dt, dR, dT);
     return CVO_HIP_OK;
 }
 
 int cvo_hip_dist_se3(const float omega[3], const float v[3], float dt, float *dist)
 {
     if (!omega || !v || !dist) return CVO_HIP_ERR_INVALID;
-    *dist = cvo_host::dist_se3(omega, v, dt);
+    *dist = cvo_math::dist_se3(omega, v, dt);
     return CVO_HIP_OK;
 }
 
@@ -622,101 +680,83 @@ int cvo_hip_align(cvo_hip_ctx *ctx, cvo_hip_state *s, cvo_hip_trace *trace, int 
         s->ell = p.ell_init;
         s->ell_max = p.ell_max_init;
     }
-    int executed = 0;
-    float Rt[9], t[3];
-    for (int k = 0; k < p.max_iter; ++k) {
-        cvo_hip_trace tr{};
-        tr.k = k;
-        tr.ell = s->ell;
-        tr.dist = std::nanf("");
-        // update_tf(); transform_pcd();
-        cvo_host::inverse_tf(s->R, s->T, Rt, t);
-        cvo_host::tf_to_mat4(Rt, t, s->transform);
-        int rc = transform_impl(ctx, s->R, s->T);
-        if (rc) return rc;
-        // compute_flow();
-        double red[13];
-        rc = flow_impl(ctx, s->ell, red);
-        if (rc) return rc;
-        float omega[3], v[3];
-        for (int q = 0; q < 3; ++q) {
-            tr.omega_d[q] = red[q];
-            tr.v_d[q] = red[3 + q];
-            tr.omega[q] = omega[q] = (float)red[q];
-            tr.v[q] = v[q] = (float)red[3 + q];
-        }
-        tr.sum_a = red[6];
-        tr.nnz = (int64_t)red[8];
-        double dl = 0.0;
-        if (acvo) {
-            tr.nnz_xx = (int64_t)red[10];
-            tr.nnz_yy = (int64_t)red[12];
-            const double num = (red[11] - 2.0 * red[7]) + red[9];
-            dl = num / (double)(tr.nnz_xx + tr.nnz_yy - 2 * tr.nnz);
-            tr.dl = dl;
-        }
-        // compute_step_size();
-        double bcde[4];
-        rc = step_impl(ctx, omega, v, s->ell, bcde);
-        if (rc) return rc;
-        std::memcpy(tr.bcde, bcde, sizeof(bcde));
-        const float step = cvo_host::pick_step(bcde, p.min_step);
-        tr.step = step;
-        executed = k + 1;
-
-        bool brk;
-        if (acvo) {   // omega.cast<double>().norm() (ref src/adaptive_cvo.cpp:509)
-            const double nw = std::sqrt((double)omega[0] * omega[0] +
-                                        ((double)omega[1] * omega[1] + (double)omega[2] * omega[2]));
-            const double nv = std::sqrt((double)v[0] * v[0] +
-                                        ((double)v[1] * v[1] + (double)v[2] * v[2]));
-            brk = nw < (double)p.eps && nv < (double)p.eps;
-        } else {
-            brk = cvo_host::norm_fixed3(omega) < p.eps && cvo_host::norm_fixed3(v) < p.eps;
-        }
-        if (brk) {
-            s->iter = k;
-            tr.exit_code = 1;
-            if (trace && k < trace_cap) trace[k] = tr;
-            break;
-        }
-        float dR[9], dT[3], RdT[3];
-        cvo_host::exp_se3(omega, v, step, dR, dT);
-        cvo_host::Mat3 R{}, dRm{};
-        std::memcpy(R.m, s->R, sizeof(R.m));
-        std::memcpy(dRm.m, dR, sizeof(dRm.m));
-        cvo_host::mul(R, dT, RdT);
-        for (int q = 0; q < 3; ++q) s->T[q] = RdT[q] + s->T[q];   // T = R*dT + T
-        const cvo_host::Mat3 Rn = cvo_host::mul(R, dRm);            // R = R*dR
-        std::memcpy(s->R, Rn.m, sizeof(Rn.m));
-
-        const float dist = cvo_host::dist_se3(omega, v, step);
-        tr.dist = dist;
-        if (dist < p.eps_2) {
-            s->iter = k;
-            tr.exit_code = 2;
-            if (trace && k < trace_cap) trace[k] = tr;
-            break;
-        }
-        if (acvo) {   // ref src/adaptive_cvo.cpp:538-545
-            s->ell = (float)((double)s->ell + p.dl_step * dl);
-            if (s->ell >= s->ell_max) {
-                s->ell = (float)(s->ell_max * 0.7);
-                s->ell_max = (float)(s->ell_max * 0.7);
-            }
-            s->ell = (s->ell < p.ell_min) ? p.ell_min : s->ell;
-        } else {      // ref src/cvo.cpp:408-410
-            s->ell = (k > 2) ? (float)0.10 : s->ell;
-            s->ell = (k > 9) ? (float)0.06 : s->ell;
-            s->ell = (k > 19) ? (float)0.03 : s->ell;
-        }
-        if (trace && k < trace_cap) trace[k] = tr;
+    if (!trace) trace_cap = 0;
+    if (trace_cap > p.max_iter) trace_cap = p.max_iter;
+    if (trace_cap > ctx->trace_dev_cap) {
+        if (ctx->trace_dev) HIP_TRY(ctx, hipFree(ctx->trace_dev));
+        ctx->trace_dev = nullptr; ctx->trace_dev_cap = 0;
+        HIP_TRY(ctx, hipMalloc((void **)&ctx->trace_dev, (size_t)trace_cap * sizeof(cvo_hip_trace)));
+        ctx->trace_dev_cap = trace_cap;
     }
-    // ref src/cvo.cpp:413-415
+    if (trace_cap > 0)
+        HIP_TRY(ctx, hipMemsetAsync(ctx->trace_dev, 0, (size_t)trace_cap * sizeof(cvo_hip_trace),
+                                    ctx->stream));
+
+    // initial device state
+    DevState *h = &ctx->st_host[kPollSlots];
+    std::memset(h, 0, sizeof(*h));
+    std::memcpy(h->R, s->R, sizeof(h->R));
+    std::memcpy(h->T, s->T, sizeof(h->T));
+    h->ell = s->ell;
+    h->ell_max = s->ell_max;
+    h->iter = s->iter;
+    if (p.max_iter <= 0) h->done = 3;
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->st, h, sizeof(DevState), hipMemcpyHostToDevice, ctx->stream));
+    launch_prepare(ctx->st, ctx->dprm, ctx->stream);
+    HIP_TRY(ctx, hipGetLastError());
+    ctx->have_tf = true;
+
+    // enqueue batches of iterations; poll `done` one batch behind
+    int enq = 0;          // iterations enqueued
+    int batches = 0;
+    bool done = p.max_iter <= 0;
+    int rc = CVO_HIP_OK;
+    while (!done) {
+        const int nb = std::min(kBatch, p.max_iter - enq);
+        for (int q = 0; q < nb && !rc; ++q) {
+            rc = enqueue_flow(ctx, true, 1, true, ctx->trace_dev, trace_cap);
+            if (!rc) rc = enqueue_step(ctx, 1, true, ctx->trace_dev, trace_cap);
+        }
+        if (rc) break;
+        enq += nb;
+        const int slot = batches % kPollSlots;
+        HIP_TRY(ctx, hipMemcpyAsync(&ctx->st_host[slot], ctx->st, sizeof(DevState),
+                                    hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipEventRecord(ctx->poll_ev[slot], ctx->stream));
+        ++batches;
+        if (batches >= 2) {   // look at the batch before the one just enqueued
+            const int prev = (batches - 2) % kPollSlots;
+            HIP_TRY(ctx, hipEventSynchronize(ctx->poll_ev[prev]));
+            if (ctx->st_host[prev].done != 0) done = true;
+        }
+        if (enq >= p.max_iter) done = true;
+    }
+    // everything still queued either runs or returns at once; fetch the end state
+    HIP_TRY(ctx, hipMemcpyAsync(&ctx->st_host[0], ctx->st, sizeof(DevState), hipMemcpyDeviceToHost,
+                                ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (rc) return rc;
+    const DevState &f = ctx->st_host[0];
+    if (f.done == 0) return fail(ctx, CVO_HIP_ERR_INVALID, "align loop ended without a verdict");
+    const int executed = f.n_exec;
+    if (trace_cap > 0 && executed > 0)
+        HIP_TRY(ctx, hipMemcpy(trace, ctx->trace_dev,
+                               (size_t)std::min(executed, trace_cap) * sizeof(cvo_hip_trace),
+                               hipMemcpyDeviceToHost));
+
+    // ref src/cvo.cpp:413-415: accumulate the transform computed at the TOP of
+    // the last executed iteration, then refresh `transform` from the final R,T
+    if (executed > 0) cvo_math::tf_to_mat4(f.used_Rt, f.used_t, s->transform);
+    std::memcpy(s->R, f.R, sizeof(s->R));
+    std::memcpy(s->T, f.T, sizeof(s->T));
+    s->ell = f.ell;
+    s->ell_max = f.ell_max;
+    s->iter = f.iter;
     std::memcpy(s->prev_transform, s->transform, sizeof(s->transform));
-    cvo_host::mat4_mul(s->accum_transform, s->transform, s->accum_transform);
-    cvo_host::inverse_tf(s->R, s->T, Rt, t);
-    cvo_host::tf_to_mat4(Rt, t, s->transform);
+    cvo_math::mat4_mul(s->accum_transform, s->transform, s->accum_transform);
+    float Rt[9], t[3];
+    cvo_math::inverse_tf(s->R, s->T, Rt, t);
+    cvo_math::tf_to_mat4(Rt, t, s->transform);
     if (n_iter) *n_iter = executed;
     if (ctx->profiling) return drain_events(ctx);
     return CVO_HIP_OK;
@@ -727,16 +767,36 @@ int cvo_hip_function_inner_product(cvo_hip_ctx *ctx, float ell, float *out)
     if (!ctx || !out) return CVO_HIP_ERR_INVALID;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     // untransformed positions, colour cut with sp_thres (ref acvo.cpp:391-392)
-    const KernConsts kc = make_kconsts(ctx->prm, ell, ctx->prm.sp_thres);
+    DevParams dp = ctx->dprm;
+    if (ctx->prm.mode == CVO_HIP_MODE_ACVO) {
+        dp.c_sp = ctx->prm.sp_thres;
+        dp.tau_c = (float)(-2.0 * ctx->prm.c_ell * ctx->prm.c_ell *
+                           (double)(float)std::log((double)(dp.c_sp / ctx->prm.c_sigma / ctx->prm.c_sigma)));
+    }
+    DevState *h = &ctx->st_host[kPollSlots];
+    h->kc = make_kconsts(dp, ell);
+    h->done = 0;
+    int rc = push_state_fields(ctx, offsetof(DevState, kc), sizeof(KernConsts));
+    if (rc) return rc;
+    rc = push_state_fields(ctx, offsetof(DevState, done), sizeof(int32_t));
+    if (rc) return rc;
     int rlo, rhi, slo, shi;
     shard_ranges(ctx, rlo, rhi, slo, shi);
-    int rc = run_sweep(ctx, SWEEP_FLOW, ctx->fixed.pos, ctx->fixed.feat, rlo, rhi, ctx->moving.pos,
-                       ctx->moving.feat, ctx->moving.n, 0, kc, NACC_FLOW, 0);
+    PostFlowArgs pa{};
+    pa.st = ctx->st;
+    pa.prm = ctx->dprm;
+    pa.prm.mode = CVO_HIP_MODE_CVO;   // no self terms here
+    pa.flags = POST_REDUCE;
+    rc = enqueue_sweep(ctx, SWEEP_FLOW, ctx->part_flow, ctx->fixed.pos, ctx->fixed.feat, rlo, rhi, 0,
+                       ctx->moving.pos, ctx->moving.feat, ctx->moving.n, 0, 0, 0, &pa.nb_flow);
     if (rc) return rc;
-    rc = reduce_over_ranks(ctx, 0, 9);
+    pa.part_flow = ctx->part_flow.p;
+    launch_post_flow(pa, ctx->stream);
+    HIP_TRY(ctx, hipGetLastError());
+    rc = reduce_over_ranks(ctx, RED_FLOW, 9);
     if (rc) return rc;
     double red[9];
-    rc = fetch_totals(ctx, 0, 9, red);
+    rc = fetch_red(ctx, RED_FLOW, 9, red);
     if (rc) return rc;
     *out = (float)(red[6] / red[8]);
     if (ctx->profiling) return drain_events(ctx);

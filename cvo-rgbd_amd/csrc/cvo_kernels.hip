@@ -1,19 +1,25 @@
 // cvo_kernels.hip -- gfx950 (MI355X, CDNA4) kernels for the CVO inner loop.
 //
-//   k_transform : transform_pcd            (ref src/cvo.cpp:310-315)
-//   k_sweep     : se_kernel fused with the consumer of A:
-//                   SWEEP_FLOW  compute_flow          (ref src/cvo.cpp:99-210)
-//                   SWEEP_STEP  compute_step_size      (ref src/cvo.cpp:249-289)
+//   k_sweep     : transform_pcd + se_kernel fused with the consumer of A
+//                   SWEEP_FLOW  compute_flow          (ref src/cvo.cpp:99-210,310-315)
+//                   SWEEP_STEP  compute_step_size      (ref src/cvo.cpp:213-289)
 //                   SWEEP_SELF  acvo Axx / Ayy terms   (ref src/adaptive_cvo.cpp:156-265)
-//   k_taylor    : per-source-point Taylor vectors      (ref src/cvo.cpp:226-238)
-//   k_finalize  : fixed-order float64 reduction of the per-block partials
+//   k_post_flow : fixed-order float64 reduction of the block partials, then the
+//                 O(1) maths that follows compute_flow (twist, dl, Taylor consts)
+//   k_post_step : same for compute_step_size: cubic, break tests, Exp_SEK3,
+//                 R/T update, length-scale update (ref src/cvo.cpp:291-307,380-410)
+//   k_prepare   : inverse transform + kernel constants from (R, T, ell)
+//
+// The whole align() loop is device-resident: the state lives in a DevState in
+// HBM, every kernel starts by reading it (and returns at once when the
+// registration has converged), so the host only enqueues launches and polls.
 //
 // The Gram matrix A is never materialised: every sweep re-tests all
-// target x source pairs (dense, wave64: one target row per lane and
-// ROWS_PER_LANE rows per thread, the source chunk broadcast from LDS), and
-// the rare survivors of the distance test are compacted through a per-wave
-// LDS queue so that the expensive part (two float64 exponentials, the colour
-// distance, the accumulations) always runs on full wavefronts.
+// target x source pairs (dense, wave64: ROWS_PER_LANE target rows per lane, the
+// source chunk broadcast from LDS), and the rare survivors of the distance
+// test are compacted through a per-wave LDS queue so that the expensive part
+// (colour distance, two float64 exponentials, float64 accumulation) always
+// runs on full wavefronts.
 //
 // Arithmetic contract: compiled with -ffp-contract=off; every FMA
 // below is an explicit __builtin_fmaf.  Per-pair terms are float32 in the
@@ -22,81 +28,28 @@
 
 namespace cvo_dev {
 
-constexpr int ROWS_PER_LANE = 4;
-
-int rows_per_tile() { return BLOCK * ROWS_PER_LANE; }
-
 __device__ __forceinline__ float4 nan4()
 {
     const float q = __builtin_nanf("");
     return make_float4(q, q, q, q);
 }
 
-// ---------------------------------------------------------------------------
-__global__ void __launch_bounds__(BLOCK) k_transform(const TransformArgs a)
+// Eigen: transform.linear()*p + translation, coefficient order, no FMA
+__device__ __forceinline__ float4 apply_tf(const float *Rt, const float *t, const float4 p)
 {
-    const int j = blockIdx.x * BLOCK + threadIdx.x;
-    if (j >= a.n) return;
-    const float4 p = a.src[j];
     float4 o;
-    // Eigen: transform.linear()*p + translation, coefficient order, no FMA
-    o.x = ((a.Rt[0] * p.x + a.Rt[1] * p.y) + a.Rt[2] * p.z) + a.t[0];
-    o.y = ((a.Rt[3] * p.x + a.Rt[4] * p.y) + a.Rt[5] * p.z) + a.t[1];
-    o.z = ((a.Rt[6] * p.x + a.Rt[7] * p.y) + a.Rt[8] * p.z) + a.t[2];
+    o.x = ((Rt[0] * p.x + Rt[1] * p.y) + Rt[2] * p.z) + t[0];
+    o.y = ((Rt[3] * p.x + Rt[4] * p.y) + Rt[5] * p.z) + t[1];
+    o.z = ((Rt[6] * p.x + Rt[7] * p.y) + Rt[8] * p.z) + t[2];
     o.w = 0.0f;
-    a.dst[j] = o;
+    return o;
 }
 
-void launch_transform(const TransformArgs &a, hipStream_t s)
-{
-    if (a.n <= 0) return;
-    hipLaunchKernelGGL(k_transform, dim3((a.n + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s, a);
-}
-
-// ---------------------------------------------------------------------------
-// taylor row layout (16 floats):
-//   [0..2] xiz  [3..5] xi2z  [6..8] xi3z  [9..11] xi4z
-//   [12] normxiz2  [13] xiz_dot_xi2z  [14] epsil_const  [15] 0
 __device__ __forceinline__ float mv_row(const float *m, float x, float y, float z)
 {
     return (m[0] * x + m[1] * y) + m[2] * z;
 }
 
-__global__ void __launch_bounds__(BLOCK) k_taylor(const TaylorArgs a)
-{
-    const int j = blockIdx.x * BLOCK + threadIdx.x;
-    if (j >= a.n) return;
-    const float4 p = a.pos[j];
-    float xiz[3], xi2z[3], xi3z[3], xi4z[3];
-    // omega x y + v
-    xiz[0] = (a.omega[1] * p.z - a.omega[2] * p.y) + a.v[0];
-    xiz[1] = (a.omega[2] * p.x - a.omega[0] * p.z) + a.v[1];
-    xiz[2] = (a.omega[0] * p.y - a.omega[1] * p.x) + a.v[2];
-#pragma unroll
-    for (int r = 0; r < 3; ++r) {
-        xi2z[r] = mv_row(a.W2 + 3 * r, p.x, p.y, p.z) + a.u2[r];
-        xi3z[r] = mv_row(a.W3 + 3 * r, p.x, p.y, p.z) + a.u3[r];
-        xi4z[r] = mv_row(a.W4 + 3 * r, p.x, p.y, p.z) + a.u4[r];
-    }
-    const float normxiz2 = (xiz[0] * xiz[0] + xiz[1] * xiz[1]) + xiz[2] * xiz[2];
-    const float xz12 = -((xiz[0] * xi2z[0] + xiz[1] * xi2z[1]) + xiz[2] * xi2z[2]);
-    const float eps_c = ((xi2z[0] * xi2z[0] + xi2z[1] * xi2z[1]) + xi2z[2] * xi2z[2]) +
-                        2 * ((xiz[0] * xi3z[0] + xiz[1] * xi3z[1]) + xiz[2] * xi3z[2]);
-    float4 *out = reinterpret_cast<float4 *>(a.taylor + (size_t)j * TAYLOR_STRIDE);
-    out[0] = make_float4(xiz[0], xiz[1], xiz[2], xi2z[0]);
-    out[1] = make_float4(xi2z[1], xi2z[2], xi3z[0], xi3z[1]);
-    out[2] = make_float4(xi3z[2], xi4z[0], xi4z[1], xi4z[2]);
-    out[3] = make_float4(normxiz2, xz12, eps_c, 0.0f);
-}
-
-void launch_taylor(const TaylorArgs &a, hipStream_t s)
-{
-    if (a.n <= 0) return;
-    hipLaunchKernelGGL(k_taylor, dim3((a.n + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s, a);
-}
-
-// ---------------------------------------------------------------------------
-// pair weight for a pair that passed d2 < tau; 0 if dropped
 __device__ __forceinline__ float d2_feat(const float4 fa0, const float fa4, const float4 fb0,
                                          const float fb4)
 {
@@ -110,6 +63,7 @@ __device__ __forceinline__ float d2_feat(const float4 fa0, const float fa4, cons
     return r;
 }
 
+// pair weight for a pair that passed d2 < tau; 0 if dropped (ref cvo.cpp:143-153)
 __device__ __forceinline__ float pair_weight(const KernConsts &kc, float d2, const float *feat_a,
                                              int i, const float *feat_b, int j)
 {
@@ -132,13 +86,13 @@ template <> struct NAcc<SWEEP_SELF> { static constexpr int n = NACC_SELF; };
 
 // One compacted candidate: full evaluation of the pair and accumulation.
 template <int MODE>
-__device__ __forceinline__ void process_pair(const SweepArgs &a, int i, int j, const float4 xi,
-                                             const float4 yj, double *acc)
+__device__ __forceinline__ void process_pair(const SweepArgs &a, const KernConsts &kc, int i,
+                                             int j, const float4 xi, const float4 yj, double *acc)
 {
     const float e0 = xi.x - yj.x, e1 = xi.y - yj.y, e2 = xi.z - yj.z;
     const float d2 = __builtin_fmaf(e2, e2, __builtin_fmaf(e1, e1, e0 * e0));
-    if (!(d2 < a.kc.tau)) return;   // also rejects NaN padding
-    const float w = pair_weight(a.kc, d2, a.feat_a, i, a.feat_b, j);
+    if (!(d2 < kc.tau)) return;   // also rejects NaN padding
+    const float w = pair_weight(kc, d2, a.feat_a, i, a.feat_b, j);
     if (!(w > 0.0f)) return;
     if (MODE == SWEEP_FLOW) {
         // cross(x_i, y_j), y_j - x_i ; (1/c * A_ij) * cross  (ref cvo.cpp:191-198)
@@ -146,7 +100,7 @@ __device__ __forceinline__ void process_pair(const SweepArgs &a, int i, int j, c
         const float c1 = xi.z * yj.x - xi.x * yj.z;
         const float c2 = xi.x * yj.y - xi.y * yj.x;
         const float f0 = yj.x - xi.x, f1 = yj.y - xi.y, f2 = yj.z - xi.z;
-        const float ac = a.kc.inv_c * w, ad = a.kc.inv_d * w;
+        const float ac = kc.inv_c * w, ad = kc.inv_d * w;
         acc[0] += (double)(ac * c0);
         acc[1] += (double)(ac * c1);
         acc[2] += (double)(ac * c2);
@@ -154,20 +108,34 @@ __device__ __forceinline__ void process_pair(const SweepArgs &a, int i, int j, c
         acc[4] += (double)(ad * f1);
         acc[5] += (double)(ad * f2);
         acc[6] += (double)w;
-        acc[7] += (double)((a.kc.inv_l3 * w) * d2);
+        acc[7] += (double)((kc.inv_l3 * w) * d2);
         acc[8] += 1.0;
     } else if (MODE == SWEEP_STEP) {
-        const float4 *t = reinterpret_cast<const float4 *>(a.taylor + (size_t)j * TAYLOR_STRIDE);
-        const float4 t0 = t[0], t1 = t[1], t2 = t[2], t3 = t[3];
-        // diff_xy = x_i - y_j is e0,e1,e2
-        const float cb = a.kc.cb, cg = a.kc.cg, cd = a.kc.cd;
-        const float beta = ((cb * t0.x) * e0 + (cb * t0.y) * e1) + (cb * t0.z) * e2;
-        const float g_dot = ((2.0f * t0.w) * e0 + (2.0f * t1.x) * e1) + (2.0f * t1.y) * e2;
-        const float gamma = cg * (t3.x + g_dot);
-        const float d_dot = ((-t1.z) * e0 + (-t1.w) * e1) + (-t2.x) * e2;
-        const float delta = cd * (t3.y + d_dot);
-        const float e_dot = ((2.0f * t2.y) * e0 + (2.0f * t2.z) * e1) + (2.0f * t2.w) * e2;
-        const float epsil = cg * (t3.z + e_dot);
+        // Taylor vectors of y_j (ref cvo.cpp:226-238), evaluated for survivors only
+        const cvo_math::XiConsts &xc = a.st->xi;
+        float xiz[3], xi2z[3], xi3z[3], xi4z[3];
+        xiz[0] = (xc.omega[1] * yj.z - xc.omega[2] * yj.y) + xc.v[0];
+        xiz[1] = (xc.omega[2] * yj.x - xc.omega[0] * yj.z) + xc.v[1];
+        xiz[2] = (xc.omega[0] * yj.y - xc.omega[1] * yj.x) + xc.v[2];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            xi2z[r] = mv_row(xc.W2 + 3 * r, yj.x, yj.y, yj.z) + xc.u2[r];
+            xi3z[r] = mv_row(xc.W3 + 3 * r, yj.x, yj.y, yj.z) + xc.u3[r];
+            xi4z[r] = mv_row(xc.W4 + 3 * r, yj.x, yj.y, yj.z) + xc.u4[r];
+        }
+        const float normxiz2 = (xiz[0] * xiz[0] + xiz[1] * xiz[1]) + xiz[2] * xiz[2];
+        const float xz12 = -((xiz[0] * xi2z[0] + xiz[1] * xi2z[1]) + xiz[2] * xi2z[2]);
+        const float eps_c = ((xi2z[0] * xi2z[0] + xi2z[1] * xi2z[1]) + xi2z[2] * xi2z[2]) +
+                            2 * ((xiz[0] * xi3z[0] + xiz[1] * xi3z[1]) + xiz[2] * xi3z[2]);
+        // diff_xy = x_i - y_j is (e0,e1,e2); ref cvo.cpp:256-280
+        const float cb = kc.cb, cg = kc.cg, cd = kc.cd;
+        const float beta = ((cb * xiz[0]) * e0 + (cb * xiz[1]) * e1) + (cb * xiz[2]) * e2;
+        const float g_dot = ((2.0f * xi2z[0]) * e0 + (2.0f * xi2z[1]) * e1) + (2.0f * xi2z[2]) * e2;
+        const float gamma = cg * (normxiz2 + g_dot);
+        const float d_dot = ((-xi3z[0]) * e0 + (-xi3z[1]) * e1) + (-xi3z[2]) * e2;
+        const float delta = cd * (xz12 + d_dot);
+        const float e_dot = ((2.0f * xi4z[0]) * e0 + (2.0f * xi4z[1]) * e1) + (2.0f * xi4z[2]) * e2;
+        const float epsil = cg * (eps_c + e_dot);
         const double A = (double)w;
         const double b = (double)beta, g = (double)gamma;
         acc[0] += (double)(w * beta);
@@ -176,7 +144,7 @@ __device__ __forceinline__ void process_pair(const SweepArgs &a, int i, int j, c
         acc[3] += A * ((((double)(epsil + beta * delta) + 0.5 * b * b * g) + 0.5 * g * g) +
                        1 / 24.0 * b * b * b * b);
     } else {
-        if (i >= a.first_counted) acc[0] += (double)((a.kc.inv_l3 * w) * d2);
+        if (i >= a.first_counted) acc[0] += (double)((kc.inv_l3 * w) * d2);
         acc[1] += 1.0;
     }
 }
@@ -185,26 +153,38 @@ template <int MODE>
 __global__ void __launch_bounds__(BLOCK) k_sweep(const SweepArgs a)
 {
     constexpr int NACC = NAcc<MODE>::n;
+    if (a.check_done && a.st->done != 0) return;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float4 *ypos = reinterpret_cast<float4 *>(smem);                         // [jt]
-    unsigned *queue = reinterpret_cast<unsigned *>(smem + (size_t)a.jt * 16); // [4][QCAP]
-    double *red = reinterpret_cast<double *>(smem + (size_t)a.jt * 16 + 4 * QCAP * 4); // [4][NACC]
+    float4 *ypos = reinterpret_cast<float4 *>(smem);                                     // [jt]
+    unsigned *queue = reinterpret_cast<unsigned *>(smem + (size_t)a.jt * 16);            // [4][QCAP]
+    double *red = reinterpret_cast<double *>(smem + (size_t)a.jt * 16 + 4 * QCAP * 4);  // [4][NACC]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wid = tid >> 6;
-    const int row0 = a.row_lo + blockIdx.y * (BLOCK * ROWS_PER_LANE);
+    const int row0 = a.row_lo + blockIdx.y * ROWS_PER_TILE;
     const int j0 = blockIdx.x * a.jt;
     const int jn = min(a.jt, a.nb - j0);
+    const KernConsts kc = a.st->kc;
+    const float *Rt = a.st->Rt;
+    const float *tt = a.st->t;
 
     float x0[ROWS_PER_LANE], x1[ROWS_PER_LANE], x2[ROWS_PER_LANE];
 #pragma unroll
     for (int r = 0; r < ROWS_PER_LANE; ++r) {
         const int i = row0 + r * BLOCK + tid;
-        const float4 p = (i < a.row_hi) ? a.pos_a[i] : nan4();
+        float4 p = nan4();
+        if (i < a.row_hi) {
+            p = a.pos_a[i];
+            if (a.tf_a) p = apply_tf(Rt, tt, p);
+        }
         x0[r] = p.x; x1[r] = p.y; x2[r] = p.z;
     }
-    for (int t = tid; t < jn; t += BLOCK) ypos[t] = a.pos_b[j0 + t];
+    for (int t = tid; t < jn; t += BLOCK) {
+        float4 p = a.pos_b[j0 + t];
+        if (a.tf_b) p = apply_tf(Rt, tt, p);
+        ypos[t] = p;
+    }
     __syncthreads();
 
     double acc[NACC];
@@ -213,7 +193,7 @@ __global__ void __launch_bounds__(BLOCK) k_sweep(const SweepArgs a)
 
     unsigned *q = queue + wid * QCAP;
     int qn = 0;   // wave-uniform
-    const float tau = a.kc.tau;
+    const float tau = kc.tau;
 
     for (int jj = 0; jj < jn; ++jj) {
         const float4 y = ypos[jj];   // LDS broadcast
@@ -237,7 +217,9 @@ __global__ void __launch_bounds__(BLOCK) k_sweep(const SweepArgs a)
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                     const unsigned e = q[qn + lane];
                     const int il = (int)(e >> 16), cj = (int)(e & 0xffffu);
-                    process_pair<MODE>(a, row0 + il, j0 + cj, a.pos_a[row0 + il], ypos[cj], acc);
+                    float4 xi = a.pos_a[row0 + il];
+                    if (a.tf_a) xi = apply_tf(Rt, tt, xi);
+                    process_pair<MODE>(a, kc, row0 + il, j0 + cj, xi, ypos[cj], acc);
                     __builtin_amdgcn_wave_barrier();
                 }
             }
@@ -250,7 +232,9 @@ __global__ void __launch_bounds__(BLOCK) k_sweep(const SweepArgs a)
         if (lane < qn) {
             const unsigned e = q[lane];
             const int il = (int)(e >> 16), cj = (int)(e & 0xffffu);
-            process_pair<MODE>(a, row0 + il, j0 + cj, a.pos_a[row0 + il], ypos[cj], acc);
+            float4 xi = a.pos_a[row0 + il];
+            if (a.tf_a) xi = apply_tf(Rt, tt, xi);
+            process_pair<MODE>(a, kc, row0 + il, j0 + cj, xi, ypos[cj], acc);
         }
     }
 
@@ -287,29 +271,190 @@ void launch_sweep(int mode, const SweepArgs &a, dim3 grid, hipStream_t s)
 }
 
 // ---------------------------------------------------------------------------
-// totals[k] = sum over blocks of partials[b][k], fixed order: thread t adds
-// blocks t, t+256, ... then a binary tree over the 256 threads.
-__global__ void __launch_bounds__(BLOCK) k_finalize(const double *partials, int nblocks, int nacc,
-                                                    double *totals)
+// Fixed-order reduction of partials[nblocks][NACC] by one 256-thread block:
+// thread t adds blocks t, t+256, ...; xor butterfly inside each wave; the four
+// wave sums are added in wave order.  Result broadcast to all threads via LDS.
+template <int NACC>
+__device__ void block_reduce_partials(const double *part, int nblocks, double *sh /*[4*NACC_MAX]*/,
+                                      double *out /*[NACC], thread 0 writes*/)
 {
-    __shared__ double sh[BLOCK];
-    for (int k = 0; k < nacc; ++k) {
-        double s = 0.0;
-        for (int b = threadIdx.x; b < nblocks; b += BLOCK) s += partials[(size_t)b * nacc + k];
-        sh[threadIdx.x] = s;
-        __syncthreads();
-        for (int off = BLOCK / 2; off >= 1; off >>= 1) {
-            if ((int)threadIdx.x < off) sh[threadIdx.x] += sh[threadIdx.x + off];
-            __syncthreads();
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    double s[NACC];
+#pragma unroll
+    for (int k = 0; k < NACC; ++k) s[k] = 0.0;
+    for (int b = tid; b < nblocks; b += BLOCK) {
+#pragma unroll
+        for (int k = 0; k < NACC; ++k) s[k] += part[(size_t)b * NACC + k];
+    }
+#pragma unroll
+    for (int k = 0; k < NACC; ++k) {
+        double v = s[k];
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+        if (lane == 0) sh[wid * NACC_MAX + k] = v;
+    }
+    __syncthreads();
+    if (tid == 0) {
+#pragma unroll
+        for (int k = 0; k < NACC; ++k)
+            out[k] = ((sh[k] + sh[NACC_MAX + k]) + sh[2 * NACC_MAX + k]) + sh[3 * NACC_MAX + k];
+    }
+    __syncthreads();
+}
+
+__global__ void __launch_bounds__(BLOCK) k_post_flow(const PostFlowArgs a)
+{
+    __shared__ double sh[4 * NACC_MAX];
+    DevState *st = a.st;
+    if (a.check_done && st->done != 0) return;
+    if (a.flags & POST_REDUCE) {
+        block_reduce_partials<NACC_FLOW>(a.part_flow, a.nb_flow, sh, st->red + RED_FLOW);
+        if (a.prm.mode == CVO_HIP_MODE_ACVO) {
+            block_reduce_partials<NACC_SELF>(a.part_xx, a.nb_xx, sh, st->red + RED_XX);
+            block_reduce_partials<NACC_SELF>(a.part_yy, a.nb_yy, sh, st->red + RED_YY);
+        } else if (threadIdx.x == 0) {
+            st->red[RED_XX] = st->red[RED_XX + 1] = st->red[RED_YY] = st->red[RED_YY + 1] = 0.0;
         }
-        if (threadIdx.x == 0) totals[k] = sh[0];
-        __syncthreads();
+    }
+    if ((a.flags & POST_MATH) && threadIdx.x == 0) {
+        const double *red = st->red;
+        float omega[3], v[3];
+        for (int q = 0; q < 3; ++q) {
+            omega[q] = (float)red[q];        // omega = double_omega.cast<float>()
+            v[q] = (float)red[3 + q];
+            st->omega[q] = omega[q];
+            st->v[q] = v[q];
+        }
+        st->xi = cvo_math::make_xi_consts(omega, v);
+        double dl = 0.0;
+        const long long nnz = (long long)red[8];
+        long long nnz_xx = 0, nnz_yy = 0;
+        if (a.prm.mode == CVO_HIP_MODE_ACVO) {   // ref src/adaptive_cvo.cpp:222-231,271
+            nnz_xx = (long long)red[RED_XX + 1];
+            nnz_yy = (long long)red[RED_YY + 1];
+            const double num = (red[RED_YY] - 2.0 * red[7]) + red[RED_XX];
+            dl = num / (double)(nnz_xx + nnz_yy - 2 * nnz);
+        }
+        st->dl = dl;
+        if (a.trace && st->k < a.trace_cap) {
+            cvo_hip_trace &tr = a.trace[st->k];
+            tr.k = st->k;
+            tr.exit_code = 0;
+            tr.ell = st->ell;
+            for (int q = 0; q < 3; ++q) {
+                tr.omega[q] = omega[q]; tr.v[q] = v[q];
+                tr.omega_d[q] = red[q]; tr.v_d[q] = red[3 + q];
+            }
+            tr.sum_a = red[6];
+            tr.dl = dl;
+            tr.nnz = nnz; tr.nnz_xx = nnz_xx; tr.nnz_yy = nnz_yy;
+        }
     }
 }
 
-void launch_finalize(const double *partials, int nblocks, int nacc, double *totals, hipStream_t s)
+__global__ void __launch_bounds__(BLOCK) k_post_step(const PostStepArgs a)
 {
-    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(BLOCK), 0, s, partials, nblocks, nacc, totals);
+    __shared__ double sh[4 * NACC_MAX];
+    DevState *st = a.st;
+    if (a.check_done && st->done != 0) return;
+    if (a.flags & POST_REDUCE)
+        block_reduce_partials<NACC_STEP>(a.part_step, a.nb_step, sh, st->red + RED_STEP);
+    if (!((a.flags & POST_MATH) && threadIdx.x == 0)) return;
+
+    const DevParams &p = a.prm;
+    const bool acvo = p.mode == CVO_HIP_MODE_ACVO;
+    const int k = st->k;
+    double bcde[4];
+    for (int q = 0; q < 4; ++q) bcde[q] = st->red[RED_STEP + q];
+    const float step = cvo_math::pick_step(bcde, p.min_step);
+    float omega[3], v[3];
+    for (int q = 0; q < 3; ++q) { omega[q] = st->omega[q]; v[q] = st->v[q]; }
+    cvo_hip_trace *tr = (a.trace && k < a.trace_cap) ? &a.trace[k] : nullptr;
+    if (tr) {
+        for (int q = 0; q < 4; ++q) tr->bcde[q] = bcde[q];
+        tr->step = step;
+        tr->dist = __builtin_nanf("");
+    }
+    st->n_exec = k + 1;
+    for (int q = 0; q < 9; ++q) st->used_Rt[q] = st->Rt[q];
+    for (int q = 0; q < 3; ++q) st->used_t[q] = st->t[q];
+
+    // break A: both twist norms below eps (ref cvo.cpp:380 float norms,
+    // adaptive_cvo.cpp:509 double norms of the float vectors)
+    bool brk;
+    if (acvo) {
+        const double nw = sqrt((double)omega[0] * omega[0] +
+                               ((double)omega[1] * omega[1] + (double)omega[2] * omega[2]));
+        const double nv = sqrt((double)v[0] * v[0] + ((double)v[1] * v[1] + (double)v[2] * v[2]));
+        brk = nw < (double)p.eps && nv < (double)p.eps;
+    } else {
+        brk = cvo_math::norm_fixed3(omega) < p.eps && cvo_math::norm_fixed3(v) < p.eps;
+    }
+    if (brk) {
+        st->iter = k;
+        st->done = 1;
+        if (tr) tr->exit_code = 1;
+        return;
+    }
+    // integrate: T = R*dT + T ; R = R*dR  (ref cvo.cpp:391-399)
+    float dR[9], dT[3], RdT[3];
+    cvo_math::exp_se3(omega, v, step, dR, dT);
+    cvo_math::Mat3 R, dRm;
+    for (int q = 0; q < 9; ++q) { R.m[q] = st->R[q]; dRm.m[q] = dR[q]; }
+    cvo_math::mulv(R, dT, RdT);
+    for (int q = 0; q < 3; ++q) st->T[q] = RdT[q] + st->T[q];
+    const cvo_math::Mat3 Rn = cvo_math::mul(R, dRm);
+    for (int q = 0; q < 9; ++q) st->R[q] = Rn.m[q];
+
+    const float dist = cvo_math::dist_se3(omega, v, step);
+    if (tr) tr->dist = dist;
+    if (dist < p.eps_2) {   // break B
+        st->iter = k;
+        st->done = 2;
+        if (tr) tr->exit_code = 2;
+        return;
+    }
+    // length-scale update
+    float ell = st->ell;
+    if (acvo) {   // ref src/adaptive_cvo.cpp:538-545
+        ell = (float)((double)ell + p.dl_step * st->dl);
+        if (ell >= st->ell_max) {
+            ell = (float)(st->ell_max * 0.7);
+            st->ell_max = (float)(st->ell_max * 0.7);
+        }
+        ell = (ell < p.ell_min) ? p.ell_min : ell;
+    } else {      // ref src/cvo.cpp:408-410
+        ell = (k > 2) ? (float)0.10 : ell;
+        ell = (k > 9) ? (float)0.06 : ell;
+        ell = (k > 19) ? (float)0.03 : ell;
+    }
+    st->ell = ell;
+    st->k = k + 1;
+    if (k + 1 >= p.max_iter) {
+        st->done = 3;   // MAX_ITER exhausted: `iter` keeps its stale value
+        return;
+    }
+    prepare_iteration(st, p);
+}
+
+__global__ void k_prepare(DevState *st, const DevParams prm)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) prepare_iteration(st, prm);
+}
+
+void launch_prepare(DevState *st, const DevParams &prm, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_prepare, dim3(1), dim3(64), 0, s, st, prm);
+}
+
+void launch_post_flow(const PostFlowArgs &a, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_post_flow, dim3(1), dim3(BLOCK), 0, s, a);
+}
+
+void launch_post_step(const PostStepArgs &a, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_post_step, dim3(1), dim3(BLOCK), 0, s, a);
 }
 
 }   // namespace cvo_dev

@@ -1,0 +1,286 @@
+// se3_math.hpp -- the O(1) mathematics of one align() iteration, written once
+// for host and device (the device-resident loop runs it in k_post_flow /
+// k_post_step; the C-ABI exports the same functions for host callers).
+//
+//   inverse transform         ref src/cvo.cpp:83-87
+//   kernel thresholds         ref src/cvo.cpp:102-103
+//   step-size cubic           ref src/cvo.cpp:53-69,291-307
+//   Exp_SEK3 (K = 1)          ref src/LieGroup.cpp:159-186
+//   dist_se3                  ref src/cvo.cpp:71-81
+//   length-scale schedules    ref src/cvo.cpp:408-410, src/adaptive_cvo.cpp:538-545
+//
+// Arithmetic contract: float32 expressions in Eigen's coefficient
+// order with NO contraction (-ffp-contract=off on host and device); anything
+// transcendental is computed in float64 from +,-,*,/,sqrt,floor only (so that
+// CPU and GPU agree bit for bit) and rounded once to float32.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <math.h>
+#include <string.h>
+
+#define CVO_HD __host__ __device__ inline
+
+namespace cvo_math {
+
+struct Mat3 {
+    float m[9];   // row-major
+};
+
+CVO_HD float at(const Mat3 &a, int r, int c) { return a.m[3 * r + c]; }
+
+CVO_HD Mat3 identity3()
+{
+    Mat3 I;
+    for (int k = 0; k < 9; ++k) I.m[k] = 0.0f;
+    I.m[0] = I.m[4] = I.m[8] = 1.0f;
+    return I;
+}
+
+CVO_HD Mat3 mul(const Mat3 &a, const Mat3 &b)
+{
+    Mat3 o;
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c)
+            o.m[3 * r + c] = (at(a, r, 0) * at(b, 0, c) + at(a, r, 1) * at(b, 1, c)) + at(a, r, 2) * at(b, 2, c);
+    return o;
+}
+
+CVO_HD void mulv(const Mat3 &a, const float x[3], float out[3])
+{
+    float t[3];
+    for (int r = 0; r < 3; ++r) t[r] = (at(a, r, 0) * x[0] + at(a, r, 1) * x[1]) + at(a, r, 2) * x[2];
+    for (int r = 0; r < 3; ++r) out[r] = t[r];
+}
+
+CVO_HD Mat3 skew(const float w[3])
+{ // ref src/LieGroup.cpp:20-27
+    Mat3 M;
+    M.m[0] = 0.0f;  M.m[1] = -w[2]; M.m[2] = w[1];
+    M.m[3] = w[2];  M.m[4] = 0.0f;  M.m[5] = -w[0];
+    M.m[6] = -w[1]; M.m[7] = w[0];  M.m[8] = 0.0f;
+    return M;
+}
+
+// Vector3f::squaredNorm() (fixed size 3, non-vectorised unrolled redux)
+CVO_HD float sqnorm_fixed3(const float a[3]) { return a[0] * a[0] + (a[1] * a[1] + a[2] * a[2]); }
+CVO_HD float norm_fixed3(const float a[3]) { return sqrtf(sqnorm_fixed3(a)); }
+
+// [Rt | t] = [R^T | -R^T T]
+CVO_HD void inverse_tf(const float R[9], const float T[3], float Rt[9], float t[3])
+{
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) Rt[3 * r + c] = R[3 * c + r];
+    for (int r = 0; r < 3; ++r)
+        t[r] = ((-Rt[3 * r]) * T[0] + (-Rt[3 * r + 1]) * T[1]) + (-Rt[3 * r + 2]) * T[2];
+}
+
+CVO_HD void tf_to_mat4(const float Rt[9], const float t[3], float m[16])
+{
+    for (int k = 0; k < 16; ++k) m[k] = 0.0f;
+    for (int r = 0; r < 3; ++r) {
+        for (int c = 0; c < 3; ++c) m[4 * r + c] = Rt[3 * r + c];
+        m[4 * r + 3] = t[r];
+    }
+    m[15] = 1.0f;
+}
+
+CVO_HD void mat4_mul(const float a[16], const float b[16], float out[16])
+{
+    float t[16];
+    for (int r = 0; r < 4; ++r)
+        for (int c = 0; c < 4; ++c)
+            t[4 * r + c] = ((a[4 * r] * b[c] + a[4 * r + 1] * b[4 + c]) + a[4 * r + 2] * b[8 + c]) +
+                           a[4 * r + 3] * b[12 + c];
+    for (int k = 0; k < 16; ++k) out[k] = t[k];
+}
+
+// ---------------------------------------------------------------------------
+// sin / cos in float64 from basic operations only (bit-reproducible on CPU
+// and GPU): Cody-Waite reduction by pi/2, Taylor polynomials on [-pi/4, pi/4].
+// Absolute error < 1e-16 for |x| < 1e5; callers round the result to float32.
+// ---------------------------------------------------------------------------
+CVO_HD void sincos_det(double x, double *s_out, double *c_out)
+{
+    const double two_over_pi = 0.63661977236758134308;
+    const double pio2_hi = 1.57079632673412561417e+00;   // first 33 bits of pi/2
+    const double pio2_lo = 6.07710050650619224932e-11;   // pi/2 - pio2_hi
+    const double kd = floor(x * two_over_pi + 0.5);
+    const double r = (x - kd * pio2_hi) - kd * pio2_lo;
+    const double r2 = r * r;
+    // sin r = r (1 - r2/6 (1 - r2/20 (1 - r2/42 (...))))  nested Taylor, degree 19
+    double ps = 1.0;
+    ps = 1.0 - r2 / (18.0 * 19.0) * ps;
+    ps = 1.0 - r2 / (16.0 * 17.0) * ps;
+    ps = 1.0 - r2 / (14.0 * 15.0) * ps;
+    ps = 1.0 - r2 / (12.0 * 13.0) * ps;
+    ps = 1.0 - r2 / (10.0 * 11.0) * ps;
+    ps = 1.0 - r2 / (8.0 * 9.0) * ps;
+    ps = 1.0 - r2 / (6.0 * 7.0) * ps;
+    ps = 1.0 - r2 / (4.0 * 5.0) * ps;
+    ps = 1.0 - r2 / (2.0 * 3.0) * ps;
+    const double sr = r * ps;
+    double pc = 1.0;
+    pc = 1.0 - r2 / (17.0 * 18.0) * pc;
+    pc = 1.0 - r2 / (15.0 * 16.0) * pc;
+    pc = 1.0 - r2 / (13.0 * 14.0) * pc;
+    pc = 1.0 - r2 / (11.0 * 12.0) * pc;
+    pc = 1.0 - r2 / (9.0 * 10.0) * pc;
+    pc = 1.0 - r2 / (7.0 * 8.0) * pc;
+    pc = 1.0 - r2 / (5.0 * 6.0) * pc;
+    pc = 1.0 - r2 / (3.0 * 4.0) * pc;
+    pc = 1.0 - r2 / (1.0 * 2.0) * pc;
+    const double cr = pc;
+    // quadrant = kd mod 4 (kd may be negative)
+    const double q4 = kd - 4.0 * floor(kd * 0.25);
+    double s, c;
+    if (q4 == 0.0) { s = sr; c = cr; }
+    else if (q4 == 1.0) { s = cr; c = -sr; }
+    else if (q4 == 2.0) { s = -sr; c = -cr; }
+    else { s = -cr; c = sr; }
+    *s_out = s;
+    *c_out = c;
+}
+
+// ---------------------------------------------------------------------------
+// Smallest positive real root of 4E s^3 + 3D s^2 + 2C s + B, else min_step;
+// clamp to 0.8.  The float coefficients and the float division by the leading
+// one are the reference's (VectorXf p_coef, companion-matrix first row); the
+// roots themselves are bracketed between the stationary points of the monic
+// cubic and bisected to adjacent float64 values (the reference runs a float
+// QR eigen-solve and accepts eigenvalues with imag()==0), then rounded.
+// ---------------------------------------------------------------------------
+CVO_HD double cubic_eval(double a, double b, double c, double s) { return ((s + a) * s + b) * s + c; }
+
+CVO_HD double bisect_root(double a, double b, double c, double lo, double hi, bool increasing)
+{ // precondition: sign change over [lo,hi] in the stated direction
+    for (int it = 0; it < 1200; ++it) {
+        const double mid = lo + (hi - lo) * 0.5;
+        if (!(mid > lo && mid < hi)) break;
+        const double f = cubic_eval(a, b, c, mid);
+        const bool go_right = increasing ? (f < 0.0) : (f > 0.0);
+        if (go_right) lo = mid; else hi = mid;
+    }
+    return hi;
+}
+
+CVO_HD float pick_step(const double bcde[4], float min_step)
+{
+    const float c3 = (float)(4.0 * (float)bcde[3]);
+    const float c2 = (float)(3.0 * (float)bcde[2]);
+    const float c1 = (float)(2.0 * (float)bcde[1]);
+    const float c0 = (float)bcde[0];
+    bool found = false;
+    double root = 0.0;
+    const bool finite = (c3 == c3) && (c2 == c2) && (c1 == c1) && (c0 == c0) &&
+                        fabsf(c3) <= 3.0e38f && fabsf(c2) <= 3.0e38f && fabsf(c1) <= 3.0e38f &&
+                        fabsf(c0) <= 3.0e38f;
+    if (c3 != 0.0f && finite) {
+        const float qa = c2 / c3, qb = c1 / c3, qc = c0 / c3;
+        const bool qfinite = fabsf(qa) <= 3.0e38f && fabsf(qb) <= 3.0e38f && fabsf(qc) <= 3.0e38f;
+        if (qfinite) {
+            const double a = (double)qa, b = (double)qb, c = (double)qc;
+            double M = fabs(a);
+            if (fabs(b) > M) M = fabs(b);
+            if (fabs(c) > M) M = fabs(c);
+            const double U = 1.0 + M;   // Cauchy bound: every root has |s| < U
+            const double f0 = c;        // f(0)
+            const double disc = a * a - 3.0 * b;
+            if (!(disc > 0.0)) {
+                // monotone increasing: one real root, positive iff f(0) < 0
+                if (f0 < 0.0) { root = bisect_root(a, b, c, 0.0, U, true); found = true; }
+            } else {
+                const double sq = sqrt(disc);
+                const double s1 = (-a - sq) / 3.0;   // local maximum
+                const double s2 = (-a + sq) / 3.0;   // local minimum
+                // (0, s1): increasing
+                if (!found && s1 > 0.0 && f0 < 0.0) {
+                    const double f1 = cubic_eval(a, b, c, s1);
+                    if (f1 >= 0.0) { root = bisect_root(a, b, c, 0.0, s1, true); found = true; }
+                }
+                // (max(0,s1), s2): decreasing
+                if (!found && s2 > 0.0) {
+                    const double lo = s1 > 0.0 ? s1 : 0.0;
+                    const double fl = cubic_eval(a, b, c, lo);
+                    const double f2 = cubic_eval(a, b, c, s2);
+                    if (fl > 0.0 && f2 <= 0.0) { root = bisect_root(a, b, c, lo, s2, false); found = true; }
+                }
+                // (max(0,s2), U): increasing
+                if (!found) {
+                    const double lo = s2 > 0.0 ? s2 : 0.0;
+                    const double fl = cubic_eval(a, b, c, lo);
+                    if (fl < 0.0) { root = bisect_root(a, b, c, lo, U, true); found = true; }
+                }
+            }
+        }
+    }
+    float step = min_step;
+    if (found) {
+        const float r = (float)root;
+        if (r > 0.0f) step = r;
+    }
+    step = ((double)step > 0.8) ? (float)0.8 : step;
+    return step;
+}
+
+// Exp_SEK3 with K = 1: dR (row-major) and dT = Jl * v.
+CVO_HD void exp_se3(const float w[3], const float v[3], float dt, float dR[9], float dT[3])
+{
+    const float TOLERANCE = 1e-6f;
+    const float theta = norm_fixed3(w);
+    const Mat3 I = identity3();
+    Mat3 R = I, Jl = I;   // small-angle branch: R = I, Jl = I (not dt*I)
+    if (!(theta < TOLERANCE)) {
+        const Mat3 A = skew(w);
+        const float theta2 = theta * theta;
+        double sd, cd;
+        sincos_det((double)(dt * theta), &sd, &cd);
+        const float stheta = (float)sd;
+        const float ctheta = (float)cd;
+        const float oneMinusCosTheta2 = (1 - ctheta) / theta2;
+        const Mat3 A2 = mul(A, A);
+        const float s1 = stheta / theta;
+        const float j3 = (dt * theta - stheta) / (theta2 * theta);
+        for (int k = 0; k < 9; ++k) {
+            R.m[k] = (I.m[k] + s1 * A.m[k]) + oneMinusCosTheta2 * A2.m[k];
+            Jl.m[k] = (dt * I.m[k] + oneMinusCosTheta2 * A.m[k]) + j3 * A2.m[k];
+        }
+    }
+    for (int k = 0; k < 9; ++k) dR[k] = R.m[k];
+    mulv(Jl, v, dT);
+}
+
+// ||logm([dR dT; 0 1])||_F for the increment produced by exp_se3(w, v, dt).
+CVO_HD float dist_se3(const float w[3], const float v[3], float dt)
+{
+    const double w2 = (double)w[0] * w[0] + (double)w[1] * w[1] + (double)w[2] * w[2];
+    const double v2 = (double)v[0] * v[0] + (double)v[1] * v[1] + (double)v[2] * v[2];
+    if (norm_fixed3(w) < 1e-6f) return (float)sqrt(v2);
+    return (float)((double)dt * sqrt(2.0 * w2 + v2));
+}
+
+// Constants of the per-point Taylor vectors in compute_step_size
+// (ref src/cvo.cpp:226-238): omega_hat powers are left-associated products.
+struct XiConsts {
+    float omega[3], v[3];
+    float W2[9], W3[9], W4[9];
+    float u2[3], u3[3], u4[3];
+};
+
+CVO_HD XiConsts make_xi_consts(const float omega[3], const float v[3])
+{
+    XiConsts c;
+    for (int k = 0; k < 3; ++k) { c.omega[k] = omega[k]; c.v[k] = v[k]; }
+    const Mat3 W = skew(omega);
+    const Mat3 W2 = mul(W, W);
+    const Mat3 W3 = mul(W2, W);
+    const Mat3 W4 = mul(W3, W);
+    for (int k = 0; k < 9; ++k) { c.W2[k] = W2.m[k]; c.W3[k] = W3.m[k]; c.W4[k] = W4.m[k]; }
+    mulv(W, v, c.u2);
+    mulv(W2, v, c.u3);
+    mulv(W3, v, c.u4);
+    return c;
+}
+
+}   // namespace cvo_math

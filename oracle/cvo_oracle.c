@@ -708,58 +708,82 @@ void cvo_oracle_step_coeffs(float ell, const float omega[3], const float v[3], c
     step_rows(ell, omega, v, x, 0, n, y, m, row_ptr, col, val, bcde);
 }
 
-/* roots of c3 s^3 + c2 s^2 + c1 s + c0 -> smallest positive real root.
- * ref src/cvo.cpp:53-69,291-307 solves the float companion matrix with Eigen's
- * EigenSolver and accepts roots with imag()==0; here: float coefficients as
- * the reference forms them, closed-form real roots in float64, rounded to
- * float.  Returns min_step if there is no positive real root or the cubic is
- * degenerate (0/0 -> NaN eigenvalues in the reference). */
+/* Smallest positive real root of 4E s^3 + 3D s^2 + 2C s + B, else min_step,
+ * clamped to 0.8.  ref src/cvo.cpp:53-69,291-307 solves the float companion
+ * matrix with Eigen's EigenSolver and accepts roots with imag()==0; here: the
+ * float coefficients and the float division by the leading one exactly as the
+ * reference forms them, then the real roots of the monic cubic are bracketed
+ * between its stationary points and bisected to adjacent float64 values
+ * (only +,-,*,/,sqrt: bit-reproducible on any IEEE machine), rounded to float.
+ * Degenerate cubics (0/0 -> NaN eigenvalues in the reference) give min_step. */
+static double cubic_eval(double a, double b, double c, double s)
+{
+    return ((s + a) * s + b) * s + c;
+}
+
+static double bisect_root(double a, double b, double c, double lo, double hi, int increasing)
+{
+    for (int it = 0; it < 1200; ++it) {
+        const double mid = lo + (hi - lo) * 0.5;
+        if (!(mid > lo && mid < hi)) break;
+        const double f = cubic_eval(a, b, c, mid);
+        const int go_right = increasing ? (f < 0.0) : (f > 0.0);
+        if (go_right) lo = mid; else hi = mid;
+    }
+    return hi;
+}
+
 float cvo_oracle_pick_step(const double bcde[4], float min_step)
 {
     const float c3 = (float)(4.0 * (float)bcde[3]);
     const float c2 = (float)(3.0 * (float)bcde[2]);
     const float c1 = (float)(2.0 * (float)bcde[1]);
     const float c0 = (float)bcde[0];
-    float best = INFINITY;
-    if (c3 != 0.0f && isfinite(c3) && isfinite(c2) && isfinite(c1) && isfinite(c0)) {
+    int found = 0;
+    double root = 0.0;
+    const int finite = (c3 == c3) && (c2 == c2) && (c1 == c1) && (c0 == c0) &&
+                       fabsf(c3) <= 3.0e38f && fabsf(c2) <= 3.0e38f && fabsf(c1) <= 3.0e38f &&
+                       fabsf(c0) <= 3.0e38f;
+    if (c3 != 0.0f && finite) {
         /* companion-matrix first row: -(coef/coef(0)) in float */
-        const double a = (double)(c2 / c3), b = (double)(c1 / c3), c = (double)(c0 / c3);
-        const double Q = (a * a - 3.0 * b) / 9.0;
-        const double Rr = (2.0 * a * a * a - 9.0 * a * b + 27.0 * c) / 54.0;
-        double roots[3];
-        int nr = 0;
-        if (Rr * Rr < Q * Q * Q) {
-            const double sq = sqrt(Q);
-            double ct = Rr / (sq * sq * sq);
-            if (ct > 1.0) ct = 1.0;
-            if (ct < -1.0) ct = -1.0;
-            const double th = acos(ct);
-            const double two_pi = 6.283185307179586476925286766559;
-            roots[0] = -2.0 * sq * cos(th / 3.0) - a / 3.0;
-            roots[1] = -2.0 * sq * cos((th + two_pi) / 3.0) - a / 3.0;
-            roots[2] = -2.0 * sq * cos((th - two_pi) / 3.0) - a / 3.0;
-            nr = 3;
-        } else {
-            const double s = sqrt(Rr * Rr - Q * Q * Q);
-            double A = -cbrt(fabs(Rr) + s);
-            if (Rr < 0) A = -A;
-            const double Bq = (A != 0.0) ? Q / A : 0.0;
-            roots[0] = (A + Bq) - a / 3.0;
-            nr = 1;
-        }
-        for (int i = 0; i < nr; ++i) {
-            /* two Newton polish steps on the monic cubic */
-            double s = roots[i];
-            for (int it = 0; it < 2; ++it) {
-                const double f = ((s + a) * s + b) * s + c;
-                const double fp = (3.0 * s + 2.0 * a) * s + b;
-                if (fp != 0.0 && isfinite(f / fp)) s -= f / fp;
+        const float qa = c2 / c3, qb = c1 / c3, qc = c0 / c3;
+        if (fabsf(qa) <= 3.0e38f && fabsf(qb) <= 3.0e38f && fabsf(qc) <= 3.0e38f) {
+            const double a = (double)qa, b = (double)qb, c = (double)qc;
+            double M = fabs(a);
+            if (fabs(b) > M) M = fabs(b);
+            if (fabs(c) > M) M = fabs(c);
+            const double U = 1.0 + M;   /* Cauchy bound */
+            const double f0 = c;
+            const double disc = a * a - 3.0 * b;
+            if (!(disc > 0.0)) {
+                if (f0 < 0.0) { root = bisect_root(a, b, c, 0.0, U, 1); found = 1; }
+            } else {
+                const double sq = sqrt(disc);
+                const double s1 = (-a - sq) / 3.0;   /* local maximum */
+                const double s2 = (-a + sq) / 3.0;   /* local minimum */
+                if (!found && s1 > 0.0 && f0 < 0.0) {
+                    const double f1 = cubic_eval(a, b, c, s1);
+                    if (f1 >= 0.0) { root = bisect_root(a, b, c, 0.0, s1, 1); found = 1; }
+                }
+                if (!found && s2 > 0.0) {
+                    const double lo = s1 > 0.0 ? s1 : 0.0;
+                    const double fl = cubic_eval(a, b, c, lo);
+                    const double f2 = cubic_eval(a, b, c, s2);
+                    if (fl > 0.0 && f2 <= 0.0) { root = bisect_root(a, b, c, lo, s2, 0); found = 1; }
+                }
+                if (!found) {
+                    const double lo = s2 > 0.0 ? s2 : 0.0;
+                    const double fl = cubic_eval(a, b, c, lo);
+                    if (fl < 0.0) { root = bisect_root(a, b, c, lo, U, 1); found = 1; }
+                }
             }
-            const float r = (float)s;
-            if (r > 0 && r < best) best = r;
         }
     }
-    float step = (best == INFINITY) ? min_step : best;
+    float step = min_step;
+    if (found) {
+        const float r = (float)root;
+        if (r > 0.0f) step = r;
+    }
     step = step > 0.8 ? (float)0.8 : step;   /* ref cvo.cpp:307 */
     return step;
 }
@@ -767,8 +791,50 @@ float cvo_oracle_pick_step(const double bcde[4], float min_step)
 /* ------------------------------------------------------------------------ */
 /* Exp_SEK3 (ref src/LieGroup.cpp:159-186), K = 1                            */
 /* ------------------------------------------------------------------------ */
-static float sinf_cr(float x) { return (float)sin((double)x); }
-static float cosf_cr(float x) { return (float)cos((double)x); }
+/* sin / cos in float64 from +,-,*,/,floor only (Cody-Waite reduction by pi/2,
+ * nested Taylor polynomials on [-pi/4, pi/4]); |error| < 1e-16 for |x| < 1e5.
+ * The reference calls float sin/cos (std:: overloads); rounding an accurate
+ * float64 value to float is the correctly-rounded float result except with
+ * probability ~1e-8, and it is bit-reproducible across CPU and GPU. */
+static void sincos_det(double x, double *s_out, double *c_out)
+{
+    const double two_over_pi = 0.63661977236758134308;
+    const double pio2_hi = 1.57079632673412561417e+00;
+    const double pio2_lo = 6.07710050650619224932e-11;
+    const double kd = floor(x * two_over_pi + 0.5);
+    const double r = (x - kd * pio2_hi) - kd * pio2_lo;
+    const double r2 = r * r;
+    double ps = 1.0;
+    ps = 1.0 - r2 / (18.0 * 19.0) * ps;
+    ps = 1.0 - r2 / (16.0 * 17.0) * ps;
+    ps = 1.0 - r2 / (14.0 * 15.0) * ps;
+    ps = 1.0 - r2 / (12.0 * 13.0) * ps;
+    ps = 1.0 - r2 / (10.0 * 11.0) * ps;
+    ps = 1.0 - r2 / (8.0 * 9.0) * ps;
+    ps = 1.0 - r2 / (6.0 * 7.0) * ps;
+    ps = 1.0 - r2 / (4.0 * 5.0) * ps;
+    ps = 1.0 - r2 / (2.0 * 3.0) * ps;
+    const double sr = r * ps;
+    double pc = 1.0;
+    pc = 1.0 - r2 / (17.0 * 18.0) * pc;
+    pc = 1.0 - r2 / (15.0 * 16.0) * pc;
+    pc = 1.0 - r2 / (13.0 * 14.0) * pc;
+    pc = 1.0 - r2 / (11.0 * 12.0) * pc;
+    pc = 1.0 - r2 / (9.0 * 10.0) * pc;
+    pc = 1.0 - r2 / (7.0 * 8.0) * pc;
+    pc = 1.0 - r2 / (5.0 * 6.0) * pc;
+    pc = 1.0 - r2 / (3.0 * 4.0) * pc;
+    pc = 1.0 - r2 / (1.0 * 2.0) * pc;
+    const double cr = pc;
+    const double q4 = kd - 4.0 * floor(kd * 0.25);
+    double sn, cs;
+    if (q4 == 0.0) { sn = sr; cs = cr; }
+    else if (q4 == 1.0) { sn = cr; cs = -sr; }
+    else if (q4 == 2.0) { sn = -sr; cs = -cr; }
+    else { sn = -cr; cs = sr; }
+    *s_out = sn;
+    *c_out = cs;
+}
 
 void cvo_oracle_exp_se3(const float omega[3], const float v[3], float dt, float dR[9],
                         float dT[3])
@@ -784,8 +850,10 @@ void cvo_oracle_exp_se3(const float omega[3], const float v[3], float dt, float 
         float A[9], A2[9];
         skew3(omega, A);
         const float theta2 = theta * theta;
-        const float stheta = sinf_cr(dt * theta);
-        const float ctheta = cosf_cr(dt * theta);
+        double sd, cd;
+        sincos_det((double)(dt * theta), &sd, &cd);
+        const float stheta = (float)sd;
+        const float ctheta = (float)cd;
         const float omc = (1 - ctheta) / theta2;
         matmul3(A, A, A2);
         const float s1 = stheta / theta;

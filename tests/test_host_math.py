@@ -1,0 +1,106 @@
+"""CPU: the O(1) host mathematics -- oracle vs independent references (scipy /
+numpy) and product (libcvo_hip.so host functions) vs oracle, bit for bit."""
+import numpy as np
+import pytest
+from scipy.linalg import expm, logm
+
+
+def _rand_twists(n, seed, scale_w=1.0, scale_v=1.0):
+    rng = np.random.default_rng(seed)
+    return (rng.normal(0, scale_w, (n, 3)).astype(np.float32),
+            rng.normal(0, scale_v, (n, 3)).astype(np.float32),
+            rng.uniform(1e-4, 0.8, n).astype(np.float32))
+
+
+def test_exp_se3_matches_matrix_exponential(po):
+    W, V, DT = _rand_twists(50, 1, 1.5, 1.0)
+    for w, v, dt in zip(W, V, DT):
+        dR, dT = po.exp_se3(w, v, dt)
+        xi = np.zeros((4, 4))
+        xi[:3, :3] = np.array([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]], np.float64)
+        xi[:3, 3] = v
+        E = expm(float(dt) * xi)
+        assert np.allclose(dR, E[:3, :3], atol=3e-6)
+        assert np.allclose(dT, E[:3, 3], atol=3e-6 * max(1.0, np.abs(v).max()))
+
+
+def test_exp_se3_small_angle_quirk(po):
+    """theta < 1e-6: R = I and Jl = I, so dT = v un-scaled by dt (Lie.cpp:168-170)."""
+    w = np.array([1e-8, -2e-8, 1e-8], np.float32)
+    v = np.array([0.3, -0.2, 0.1], np.float32)
+    dR, dT = po.exp_se3(w, v, 0.25)
+    assert np.array_equal(dR, np.eye(3, dtype=np.float32)) and np.array_equal(dT, v)
+    assert po.dist_se3(w, v, 0.25) == pytest.approx(float(np.linalg.norm(v)), rel=1e-6)
+
+
+def test_dist_se3_matches_matrix_log(po):
+    """Closed form vs ||logm([dR dT;0 1])||_F (ref cvo.cpp:71-81)."""
+    W, V, DT = _rand_twists(40, 2, 0.5, 0.5)
+    for w, v, dt in zip(W, V, DT):
+        dR, dT = po.exp_se3(w, v, dt)
+        M = np.eye(4)
+        M[:3, :3], M[:3, 3] = dR, dT
+        ref = np.linalg.norm(np.real(logm(M)))
+        assert po.dist_se3(w, v, dt) == pytest.approx(ref, rel=2e-5, abs=1e-7)
+
+
+def test_pick_step_matches_numpy_roots(po):
+    rng = np.random.default_rng(3)
+    n_checked = 0
+    for _ in range(400):
+        bcde = rng.normal(0, 1, 4) * 10.0 ** rng.integers(-3, 4, 4)
+        c = np.array([4.0 * np.float32(bcde[3]), 3.0 * np.float32(bcde[2]),
+                      2.0 * np.float32(bcde[1]), np.float32(bcde[0])], np.float32).astype(np.float64)
+        mon = np.array([1.0, np.float32(c[1] / c[0]), np.float32(c[2] / c[0]), np.float32(c[3] / c[0])],
+                       np.float64)
+        r = np.roots(mon)
+        real = r[np.abs(r.imag) < 1e-9 * np.maximum(1.0, np.abs(r.real))].real
+        cplx = r[np.abs(r.imag) >= 1e-9 * np.maximum(1.0, np.abs(r.real))]
+        if len(cplx) and np.min(np.abs(cplx.imag) / np.maximum(1.0, np.abs(cplx.real))) < 1e-5:
+            continue   # nearly a double root: classification is ill-conditioned
+        pos = real[real > 0]
+        want = np.float32(pos.min()) if len(pos) else np.float32(0.2)
+        want = np.float32(0.8) if want > 0.8 else want
+        got = po.pick_step(bcde)
+        assert got == pytest.approx(float(want), rel=1e-5), (bcde, r)
+        n_checked += 1
+    assert n_checked > 300
+
+
+def test_pick_step_degenerate(po):
+    assert po.pick_step([0.0, 0.0, 0.0, 0.0]) == pytest.approx(0.2)       # empty A: 0/0
+    assert po.pick_step([np.nan, 1.0, 1.0, 1.0]) == pytest.approx(0.2)
+    assert po.pick_step([1.0, 1.0, 1.0, 0.0]) == pytest.approx(0.2)       # E = 0: division by 0
+    assert po.pick_step([-100.0, 0.0, 0.0, 1.0]) == pytest.approx(0.8)     # root 2.92 -> clamp
+
+
+def test_product_host_math_is_bitwise_the_oracle(pkg, po):
+    """cvo_hip_pick_step / exp_se3 / dist_se3 (se3_math.hpp, the same code the
+    device-resident loop runs) against the oracle's C restatement."""
+    capi = pkg.capi
+    rng = np.random.default_rng(4)
+    for _ in range(2000):
+        bcde = rng.normal(0, 1, 4) * 10.0 ** rng.integers(-6, 7, 4)
+        assert np.float32(capi.pick_step(bcde)).view(np.uint32) == np.float32(po.pick_step(bcde)).view(np.uint32)
+    W, V, DT = _rand_twists(2000, 5, 3.0, 2.0)
+    W[:50] *= 1e-7   # exercise the small-angle branch
+    for w, v, dt in zip(W, V, DT):
+        a, b = capi.exp_se3(w, v, dt), po.exp_se3(w, v, dt)
+        assert np.array_equal(a[0].view(np.uint32), b[0].view(np.uint32))
+        assert np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32))
+        assert np.float32(capi.dist_se3(w, v, dt)).view(np.uint32) == np.float32(po.dist_se3(w, v, dt)).view(np.uint32)
+
+
+def test_sincos_det_is_the_rounded_libm_value(po):
+    """exp_se3 with omega along z: dR[1,0] = sin(dt*theta) for theta = |w|."""
+    rng = np.random.default_rng(6)
+    bad = 0
+    for _ in range(3000):
+        th = np.float32(rng.uniform(0.01, 40.0))
+        dt = np.float32(rng.uniform(0.001, 0.8))
+        dR, _ = po.exp_se3(np.array([0, 0, th], np.float32), np.zeros(3, np.float32), dt)
+        x = np.float32(dt * th)
+        s1 = np.float32(np.float32(np.sin(np.float64(x))) / th)   # stheta/theta
+        want = np.float32(s1 * th)
+        bad += int(dR[1, 0] != want)
+    assert bad == 0
