@@ -32,27 +32,34 @@ using namespace cvo_dev;
 namespace {
 
 struct Cloud {
-    float4 *pos = nullptr;
-    float *feat = nullptr;
+    float4 *pos = nullptr;   // Morton-sorted; .w = index in the caller's cloud (int bits)
+    float *feat = nullptr;   // same order
     int n = 0;
     int cap = 0;
+    float lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};   // bounding box
 };
 
 struct EventPair {
     hipEvent_t a, b;
     int kind;      // SweepMode
+    int iter_tag;  // align() iteration the launch belongs to, -1 outside align()
     double pairs;
 };
 
-struct SweepPlan {
+struct FilterPlan {
     dim3 grid;
     int jt = 0;
-    int nblocks = 0;
 };
 
-struct PartialBuf {
-    double *p = nullptr;
-    size_t cap = 0;   // doubles
+struct DevBuf {   // a growable device array
+    void *p = nullptr;
+    size_t bytes = 0;
+};
+
+struct CandList {
+    DevBuf cand;   // uint2[cap]
+    DevBuf aval;   // float[cap]   (LIST_XY only)
+    uint32_t cap = 0;
 };
 
 constexpr int kBatch = 8;        // iterations enqueued between two polls
@@ -70,7 +77,8 @@ struct cvo_hip_ctx {
     DevState *st = nullptr;          // device
     DevState *st_host = nullptr;     // pinned [kPollSlots + 1]
     hipEvent_t poll_ev[kPollSlots]{};
-    PartialBuf part_flow, part_xx, part_yy, part_step;
+    DevBuf part_flow, part_xx, part_yy, part_step;   // [PROC_BLOCKS][NACC_MAX] float64
+    CandList lists[LIST_N];
     cvo_hip_trace *trace_dev = nullptr;
     int trace_dev_cap = 0;
     bool have_tf = false;
@@ -80,6 +88,7 @@ struct cvo_hip_ctx {
     cvo_hip_allreduce_fn user_allreduce = nullptr;
     void *user_allreduce_arg = nullptr;
     bool profiling = false;
+    int iter_tag = -1;
     std::vector<EventPair> events;
     cvo_hip_profile prof{};
     std::string err;
@@ -145,16 +154,56 @@ int upload_cloud(cvo_hip_ctx *ctx, Cloud &c, const float *xyz, const float *feat
         c.cap = n;
     }
     c.n = n;
+    for (int a = 0; a < 3; ++a) { c.lo[a] = 0.0f; c.hi[a] = 0.0f; }
     if (n == 0) return CVO_HIP_OK;
+    // Bounding box, then a Morton (Z-order) permutation: consecutive device
+    // points are spatial neighbours, so a wave's 64 rows and a 16-column MFMA
+    // tile are compact patches and most (wave, tile) steps see no candidate.
+    // All sums over pairs are order-independent (float64 accumulators).
+    for (int a = 0; a < 3; ++a) { c.lo[a] = INFINITY; c.hi[a] = -INFINITY; }
+    for (int i = 0; i < n; ++i)
+        for (int a = 0; a < 3; ++a) {
+            const float v = xyz[3 * (size_t)i + a];
+            if (v < c.lo[a]) c.lo[a] = v;
+            if (v > c.hi[a]) c.hi[a] = v;
+        }
+    std::vector<std::pair<uint32_t, int>> order((size_t)n);
+    {
+        float inv[3];
+        for (int a = 0; a < 3; ++a) {
+            const float ext = c.hi[a] - c.lo[a];
+            inv[a] = (ext > 0.0f && std::isfinite(ext)) ? 1023.0f / ext : 0.0f;
+        }
+        auto spread = [](uint32_t v) {   // 10 bits -> every third bit
+            v &= 1023u;
+            v = (v | (v << 16)) & 0x030000FFu;
+            v = (v | (v << 8)) & 0x0300F00Fu;
+            v = (v | (v << 4)) & 0x030C30C3u;
+            v = (v | (v << 2)) & 0x09249249u;
+            return v;
+        };
+        for (int i = 0; i < n; ++i) {
+            uint32_t q[3];
+            for (int a = 0; a < 3; ++a) {
+                float f = (xyz[3 * (size_t)i + a] - c.lo[a]) * inv[a];
+                if (!(f >= 0.0f)) f = 0.0f;   // also catches NaN
+                if (f > 1023.0f) f = 1023.0f;
+                q[a] = (uint32_t)f;
+            }
+            order[(size_t)i] = {spread(q[0]) | (spread(q[1]) << 1) | (spread(q[2]) << 2), i};
+        }
+        std::sort(order.begin(), order.end());
+    }
     // pack on the host into the device layout, one copy each
     std::vector<float> hp((size_t)n * 4), hf((size_t)n * FEAT_STRIDE, 0.0f);
-    for (int i = 0; i < n; ++i) {
-        hp[4 * (size_t)i + 0] = xyz[3 * (size_t)i + 0];
-        hp[4 * (size_t)i + 1] = xyz[3 * (size_t)i + 1];
-        hp[4 * (size_t)i + 2] = xyz[3 * (size_t)i + 2];
-        hp[4 * (size_t)i + 3] = 0.0f;
+    for (int s = 0; s < n; ++s) {
+        const int i = order[(size_t)s].second;
+        hp[4 * (size_t)s + 0] = xyz[3 * (size_t)i + 0];
+        hp[4 * (size_t)s + 1] = xyz[3 * (size_t)i + 1];
+        hp[4 * (size_t)s + 2] = xyz[3 * (size_t)i + 2];
+        std::memcpy(&hp[4 * (size_t)s + 3], &i, sizeof(int));   // caller's index
         for (int f = 0; f < CVO_HIP_NFEAT; ++f)
-            hf[(size_t)i * FEAT_STRIDE + f] = (layout == CVO_HIP_FEAT_COLMAJOR)
+            hf[(size_t)s * FEAT_STRIDE + f] = (layout == CVO_HIP_FEAT_COLMAJOR)
                                                   ? feat[(size_t)f * n + i]
                                                   : feat[(size_t)i * CVO_HIP_NFEAT + f];
     }
@@ -166,33 +215,60 @@ int upload_cloud(cvo_hip_ctx *ctx, Cloud &c, const float *xyz, const float *feat
     return CVO_HIP_OK;
 }
 
-// Chunk length so that the grid has enough workgroups to fill 256 CUs a few
-// times over while each block still amortises its prologue/epilogue.
-SweepPlan plan_sweep(int nrows, int nb)
+// Filter grid: 256 rows per block; the column chunk is sized so that about
+// four 256-thread blocks per CU are resident while every block still amortises
+// its staging over many MFMA column tiles.
+FilterPlan plan_filter(int nrows, int nb)
 {
-    SweepPlan p{};
+    FilterPlan p{};
     const int tiles = std::max(1, (nrows + ROWS_PER_TILE - 1) / ROWS_PER_TILE);
-    const int want_blocks = 2048;
-    const int chunks_want = std::max(1, want_blocks / tiles);
+    const int want_blocks = 1024;
+    const int chunks_want = std::max(1, (want_blocks + tiles / 2) / tiles);
     int jt = (nb + chunks_want - 1) / chunks_want;
     jt = std::max(jt, 64);
     jt = std::min(jt, 2048);
-    jt = (jt + 3) & ~3;
+    jt = (jt + 15) & ~15;           // whole MFMA column tiles
     p.jt = jt;
     const int chunks = std::max(1, (nb + jt - 1) / jt);
     p.grid = dim3(chunks, tiles);
-    p.nblocks = chunks * tiles;
     return p;
 }
 
-int ensure_partials(cvo_hip_ctx *ctx, PartialBuf &b, size_t doubles)
+int ensure_buf(cvo_hip_ctx *ctx, DevBuf &b, size_t bytes)
 {
-    if (doubles <= b.cap) return CVO_HIP_OK;
+    if (bytes <= b.bytes) return CVO_HIP_OK;
     if (b.p) HIP_TRY(ctx, hipFree(b.p));
     b.p = nullptr;
-    b.cap = 0;
-    HIP_TRY(ctx, hipMalloc((void **)&b.p, doubles * sizeof(double)));
-    b.cap = doubles;
+    b.bytes = 0;
+    if (hipMalloc(&b.p, bytes) != hipSuccess) {
+        b.p = nullptr;
+        return fail(ctx, CVO_HIP_ERR_NOMEM, "hipMalloc failed (candidate list / partials)");
+    }
+    b.bytes = bytes;
+    return CVO_HIP_OK;
+}
+
+// Candidate-list capacity: never more than all pairs; by default room for 4 %
+// of them (the filter passes ~1.5 % at the widest length-scale on surface-like
+// clouds) and at least 1 Mi entries.  align() grows it on demand.
+int ensure_list(cvo_hip_ctx *ctx, int list, int nrows, int nb, uint32_t at_least)
+{
+    CandList &L = ctx->lists[list];
+    const double all = (double)std::max(nrows, 0) * (double)std::max(nb, 0);
+    double want = std::max(all * 0.04, 1048576.0);
+    want = std::max(want, (double)at_least);
+    want = std::min(want, std::max(all, 64.0));
+    want = std::min(want, 4.0e9);
+    // NSUB equal sub-lists; each must hold at least one full wave flush
+    const uint32_t cap = std::max<uint32_t>(((uint32_t)want + NSUB - 1) / NSUB, 128u) * NSUB;
+    if (cap <= L.cap) return CVO_HIP_OK;
+    int rc = ensure_buf(ctx, L.cand, (size_t)cap * sizeof(uint2));
+    if (rc) return rc;
+    if (list == LIST_XY) {
+        rc = ensure_buf(ctx, L.aval, (size_t)cap * sizeof(float));
+        if (rc) return rc;
+    }
+    L.cap = cap;
     return CVO_HIP_OK;
 }
 
@@ -206,58 +282,101 @@ void shard_ranges(const cvo_hip_ctx *ctx, int &rlo, int &rhi, int &slo, int &shi
     slo = std::min(slo, shi);
 }
 
-// One sweep launch (with optional HIP-event bracket).  Empty row ranges or
-// column sets still launch nothing and leave nblocks = 0 (the post kernel then
-// reduces zero blocks to 0.0).
-int enqueue_sweep(cvo_hip_ctx *ctx, int mode, PartialBuf &pb, const float4 *pos_a,
-                  const float *feat_a, int row_lo, int row_hi, int tf_a, const float4 *pos_b,
-                  const float *feat_b, int nb, int tf_b, int first_counted, int check_done,
-                  int *nblocks_out)
+// Geometry of the MFMA pre-filter: coordinates relative to the centre of the
+// fixed cloud's bounding box; radii from the farthest bounding-box corners.
+void fill_filter_geometry(const cvo_hip_ctx *ctx, DevState *h)
+{
+    const Cloud &cf = ctx->fixed.n > 0 ? ctx->fixed : ctx->moving;
+    for (int a = 0; a < 3; ++a) h->center[a] = 0.5f * (cf.lo[a] + cf.hi[a]);
+    auto radius = [&](const Cloud &c) {
+        if (c.n <= 0) return 0.0f;
+        double r2 = 0.0;
+        for (int a = 0; a < 3; ++a) {
+            const double d = std::max(std::fabs((double)c.lo[a] - h->center[a]),
+                                      std::fabs((double)c.hi[a] - h->center[a]));
+            r2 += d * d;
+        }
+        return (float)(std::sqrt(r2) * 1.0001 + 1e-6);
+    };
+    h->xmax = radius(ctx->fixed);
+    h->y0max = radius(ctx->moving);
+}
+
+// The dense all-pairs filter of one list (with optional HIP-event bracket: this
+// is the kernel the roofline is quoted on).
+int enqueue_filter(cvo_hip_ctx *ctx, int list, const float4 *pos_a, int row_lo, int row_hi,
+                   int tf_a, const float4 *pos_b, int nb, int tf_b, int check_done)
 {
     const int nrows = row_hi - row_lo;
-    *nblocks_out = 0;
     if (nrows <= 0 || nb <= 0) return CVO_HIP_OK;
-    const SweepPlan pl = plan_sweep(nrows, nb);
-    int rc = ensure_partials(ctx, pb, (size_t)pl.nblocks * NACC_MAX);
+    int rc = ensure_list(ctx, list, nrows, nb, 0);
     if (rc) return rc;
-    SweepArgs a{};
-    a.pos_a = pos_a; a.feat_a = feat_a;
-    a.pos_b = pos_b; a.feat_b = feat_b;
-    a.partials = pb.p;
+    const FilterPlan pl = plan_filter(nrows, nb);
+    FilterArgs a{};
+    a.pos_a = pos_a; a.pos_b = pos_b;
     a.st = ctx->st;
+    a.cand = (uint2 *)ctx->lists[list].cand.p;
+    a.subcap = ctx->lists[list].cap / NSUB;
+    a.list = list;
     a.row_lo = row_lo; a.row_hi = row_hi;
     a.nb = nb; a.jt = pl.jt;
-    a.first_counted = first_counted;
     a.tf_a = tf_a; a.tf_b = tf_b;
     a.check_done = check_done;
     EventPair ev{};
     if (ctx->profiling) {
         HIP_TRY(ctx, hipEventCreate(&ev.a));
         HIP_TRY(ctx, hipEventCreate(&ev.b));
-        ev.kind = mode;
+        ev.kind = list;
+        ev.iter_tag = ctx->iter_tag;
         ev.pairs = (double)nrows * (double)nb;
         HIP_TRY(ctx, hipEventRecord(ev.a, ctx->stream));
     }
-    launch_sweep(mode, a, pl.grid, ctx->stream);
+    launch_filter(a, pl.grid, ctx->stream);
     if (ctx->profiling) {
         HIP_TRY(ctx, hipEventRecord(ev.b, ctx->stream));
         ctx->events.push_back(ev);
     }
     HIP_TRY(ctx, hipGetLastError());
-    *nblocks_out = pl.nblocks;
     return CVO_HIP_OK;
 }
 
-int drain_events(cvo_hip_ctx *ctx)
+int enqueue_process(cvo_hip_ctx *ctx, int mode, int list, DevBuf &part, const float4 *pos_a,
+                    const float *feat_a, int tf_a, const float4 *pos_b, const float *feat_b,
+                    int tf_b, int first_counted, int check_done)
+{
+    int rc = ensure_buf(ctx, part, (size_t)PROC_BLOCKS * NACC_MAX * sizeof(double));
+    if (rc) return rc;
+    rc = ensure_list(ctx, list, 0, 0, 64);   // an (empty) list object must exist
+    if (rc) return rc;
+    ProcessArgs a{};
+    a.pos_a = pos_a; a.feat_a = feat_a;
+    a.pos_b = pos_b; a.feat_b = feat_b;
+    a.cand = (const uint2 *)ctx->lists[list].cand.p;
+    a.aval = (float *)ctx->lists[LIST_XY].aval.p;
+    a.partials = (double *)part.p;
+    a.st = ctx->st;
+    a.subcap = ctx->lists[list].cap / NSUB;
+    a.list = list;
+    a.first_counted = first_counted;
+    a.tf_a = tf_a; a.tf_b = tf_b;
+    a.check_done = check_done;
+    launch_process(mode, a, ctx->stream);
+    HIP_TRY(ctx, hipGetLastError());
+    return CVO_HIP_OK;
+}
+
+// n_exec >= 0: launches tagged with an iteration >= n_exec were queued past
+// convergence and returned at once; they are not sweeps and are not counted.
+int drain_events(cvo_hip_ctx *ctx, int n_exec = -1)
 {
     for (auto &ev : ctx->events) {
         float ms = 0.f;
         HIP_TRY(ctx, hipEventSynchronize(ev.b));
         HIP_TRY(ctx, hipEventElapsedTime(&ms, ev.a, ev.b));
-        if (ev.kind == SWEEP_FLOW) {
+        if (n_exec >= 0 && ev.iter_tag >= n_exec) {
+            // skipped launch
+        } else if (ev.kind == LIST_XY) {
             ctx->prof.flow_ms += ms; ctx->prof.flow_launches++; ctx->prof.flow_pairs += ev.pairs;
-        } else if (ev.kind == SWEEP_STEP) {
-            ctx->prof.step_ms += ms; ctx->prof.step_launches++; ctx->prof.step_pairs += ev.pairs;
         } else {
             ctx->prof.self_ms += ms; ctx->prof.self_launches++; ctx->prof.self_pairs += ev.pairs;
         }
@@ -285,36 +404,45 @@ int reduce_over_ranks(cvo_hip_ctx *ctx, int off, int count)
     return CVO_HIP_OK;
 }
 
-// flow side of one iteration: sweeps + reduction (+ all-reduce) (+ maths)
+// flow side of one iteration: dense filter(s) -> candidate list(s) -> exact
+// evaluation -> reduction (+ all-reduce) (+ the O(1) maths)
 int enqueue_flow(cvo_hip_ctx *ctx, bool tf_moving, int check_done, bool do_math,
                  cvo_hip_trace *trace, int trace_cap)
 {
     const bool acvo = ctx->prm.mode == CVO_HIP_MODE_ACVO;
+    const int tfm = tf_moving ? 1 : 0;
     int rlo, rhi, slo, shi;
     shard_ranges(ctx, rlo, rhi, slo, shi);
+    int rc = enqueue_filter(ctx, LIST_XY, ctx->fixed.pos, rlo, rhi, 0, ctx->moving.pos,
+                            ctx->moving.n, tfm, check_done);
+    if (rc) return rc;
+    rc = enqueue_process(ctx, PROC_FLOW, LIST_XY, ctx->part_flow, ctx->fixed.pos, ctx->fixed.feat,
+                         0, ctx->moving.pos, ctx->moving.feat, tfm, 0, check_done);
+    if (rc) return rc;
+    if (acvo) {
+        // Axx rows of this shard vs all of x; Ayy rows of this shard vs all of y
+        rc = enqueue_filter(ctx, LIST_XX, ctx->fixed.pos, rlo, rhi, 0, ctx->fixed.pos, ctx->fixed.n,
+                            0, check_done);
+        if (rc) return rc;
+        rc = enqueue_process(ctx, PROC_SELF, LIST_XX, ctx->part_xx, ctx->fixed.pos, ctx->fixed.feat,
+                             0, ctx->fixed.pos, ctx->fixed.feat, 0, 0, check_done);
+        if (rc) return rc;
+        rc = enqueue_filter(ctx, LIST_YY, ctx->moving.pos, slo, shi, tfm, ctx->moving.pos,
+                            ctx->moving.n, tfm, check_done);
+        if (rc) return rc;
+        rc = enqueue_process(ctx, PROC_SELF, LIST_YY, ctx->part_yy, ctx->moving.pos,
+                             ctx->moving.feat, tfm, ctx->moving.pos, ctx->moving.feat, tfm,
+                             ctx->fixed.n, check_done);
+        if (rc) return rc;
+    }
     PostFlowArgs pa{};
     pa.st = ctx->st;
     pa.prm = ctx->dprm;
     pa.trace = trace; pa.trace_cap = trace_cap;
     pa.check_done = check_done;
-    int rc = enqueue_sweep(ctx, SWEEP_FLOW, ctx->part_flow, ctx->fixed.pos, ctx->fixed.feat, rlo,
-                           rhi, 0, ctx->moving.pos, ctx->moving.feat, ctx->moving.n,
-                           tf_moving ? 1 : 0, 0, check_done, &pa.nb_flow);
-    if (rc) return rc;
-    if (acvo) {
-        // Axx rows of this shard vs all of x; Ayy rows of this shard vs all of y
-        rc = enqueue_sweep(ctx, SWEEP_SELF, ctx->part_xx, ctx->fixed.pos, ctx->fixed.feat, rlo, rhi,
-                           0, ctx->fixed.pos, ctx->fixed.feat, ctx->fixed.n, 0, 0, check_done,
-                           &pa.nb_xx);
-        if (rc) return rc;
-        rc = enqueue_sweep(ctx, SWEEP_SELF, ctx->part_yy, ctx->moving.pos, ctx->moving.feat, slo,
-                           shi, 1, ctx->moving.pos, ctx->moving.feat, ctx->moving.n, 1,
-                           ctx->fixed.n, check_done, &pa.nb_yy);
-        if (rc) return rc;
-    }
-    pa.part_flow = ctx->part_flow.p;
-    pa.part_xx = ctx->part_xx.p;
-    pa.part_yy = ctx->part_yy.p;
+    pa.part_flow = (const double *)ctx->part_flow.p;
+    pa.part_xx = (const double *)ctx->part_xx.p;
+    pa.part_yy = (const double *)ctx->part_yy.p;
     if (multi_rank(ctx)) {
         pa.flags = POST_REDUCE;
         launch_post_flow(pa, ctx->stream);
@@ -332,21 +460,20 @@ int enqueue_flow(cvo_hip_ctx *ctx, bool tf_moving, int check_done, bool do_math,
     return CVO_HIP_OK;
 }
 
+// step-size side: streams the xy list again with the weights PROC_FLOW kept
 int enqueue_step(cvo_hip_ctx *ctx, int check_done, bool do_math, cvo_hip_trace *trace,
                  int trace_cap)
 {
-    int rlo, rhi, slo, shi;
-    shard_ranges(ctx, rlo, rhi, slo, shi);
+    int rc = enqueue_process(ctx, PROC_STEP, LIST_XY, ctx->part_step, ctx->fixed.pos,
+                             ctx->fixed.feat, 0, ctx->moving.pos, ctx->moving.feat, 1, 0,
+                             check_done);
+    if (rc) return rc;
     PostStepArgs pa{};
     pa.st = ctx->st;
     pa.prm = ctx->dprm;
     pa.trace = trace; pa.trace_cap = trace_cap;
     pa.check_done = check_done;
-    int rc = enqueue_sweep(ctx, SWEEP_STEP, ctx->part_step, ctx->fixed.pos, ctx->fixed.feat, rlo,
-                           rhi, 0, ctx->moving.pos, ctx->moving.feat, ctx->moving.n, 1, 0,
-                           check_done, &pa.nb_step);
-    if (rc) return rc;
-    pa.part_step = ctx->part_step.p;
+    pa.part_step = (const double *)ctx->part_step.p;
     if (multi_rank(ctx)) {
         pa.flags = POST_REDUCE;
         launch_post_step(pa, ctx->stream);
@@ -361,6 +488,38 @@ int enqueue_step(cvo_hip_ctx *ctx, int check_done, bool do_math, cvo_hip_trace *
         launch_post_step(pa, ctx->stream);
     }
     HIP_TRY(ctx, hipGetLastError());
+    return CVO_HIP_OK;
+}
+
+// Low-level entry points run one list at a time and cannot resume: grow the
+// lists until nothing overflows.  Returns 1 if the caller must redo its launches.
+int check_overflow_and_grow(cvo_hip_ctx *ctx, bool *redo)
+{
+    DevState *h = &ctx->st_host[0];
+    HIP_TRY(ctx, hipMemcpyAsync(h->cnt, reinterpret_cast<char *>(ctx->st) + offsetof(DevState, cnt),
+                                sizeof(DevState) - offsetof(DevState, cnt), hipMemcpyDeviceToHost,
+                                ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    *redo = false;
+    for (int l = 0; l < LIST_N; ++l)
+        if (h->cnt[2 * l + 1]) {
+            uint32_t worst = 0;
+            for (int q = 0; q < NSUB; ++q) worst = std::max(worst, h->sub[l][q]);
+            const double need = std::max((double)worst * NSUB, (double)ctx->lists[l].cap);
+            const double grown = std::min(4.0e9, need * 1.25 + 1024.0);
+            int rc = ensure_list(ctx, l, 1 << 30, 4, (uint32_t)grown);
+            if (rc) return rc;
+            *redo = true;
+        }
+    return CVO_HIP_OK;
+}
+
+int zero_counters(cvo_hip_ctx *ctx)
+{
+    HIP_TRY(ctx, hipMemsetAsync(reinterpret_cast<char *>(ctx->st) + offsetof(DevState, cnt), 0,
+                                sizeof(uint32_t) * 2 * LIST_N, ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(reinterpret_cast<char *>(ctx->st) + offsetof(DevState, sub), 0,
+                                sizeof(uint32_t) * LIST_N * NSUB, ctx->stream));
     return CVO_HIP_OK;
 }
 
@@ -507,9 +666,10 @@ int cvo_hip_destroy(cvo_hip_ctx *ctx)
         if (ctx->poll_ev[i]) hipEventDestroy(ctx->poll_ev[i]);
     if (ctx->comm) cvo_comm_destroy(ctx->comm);
     for (void *p : {(void *)ctx->fixed.pos, (void *)ctx->fixed.feat, (void *)ctx->moving.pos,
-                    (void *)ctx->moving.feat, (void *)ctx->st, (void *)ctx->part_flow.p,
-                    (void *)ctx->part_xx.p, (void *)ctx->part_yy.p, (void *)ctx->part_step.p,
-                    (void *)ctx->trace_dev})
+                    (void *)ctx->moving.feat, (void *)ctx->st, ctx->part_flow.p, ctx->part_xx.p,
+                    ctx->part_yy.p, ctx->part_step.p, (void *)ctx->trace_dev,
+                    ctx->lists[0].cand.p, ctx->lists[0].aval.p, ctx->lists[1].cand.p,
+                    ctx->lists[1].aval.p, ctx->lists[2].cand.p, ctx->lists[2].aval.p})
         if (p) (void)hipFree(p);
     if (ctx->st_host) (void)hipHostFree(ctx->st_host);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -602,6 +762,7 @@ int cvo_hip_transform_pcd(cvo_hip_ctx *ctx, const float R[9], const float T[3])
     std::memcpy(h->T, T, sizeof(h->T));
     cvo_math::inverse_tf(R, T, h->Rt, h->t);
     h->done = 0;
+    fill_filter_geometry(ctx, h);
     int rc = push_state_fields(ctx, offsetof(DevState, R), offsetof(DevState, ell) - offsetof(DevState, R));
     if (rc) return rc;
     rc = push_state_fields(ctx, offsetof(DevState, Rt), offsetof(DevState, used_Rt) - offsetof(DevState, Rt));
@@ -620,10 +781,17 @@ int cvo_hip_flow(cvo_hip_ctx *ctx, float ell, double out13[13])
     if (!ctx->have_tf) return fail(ctx, CVO_HIP_ERR_INVALID, "transform_pcd not called");
     DevState *h = &ctx->st_host[kPollSlots];
     h->kc = make_kconsts(ctx->dprm, ell);
-    int rc = push_state_fields(ctx, offsetof(DevState, kc), sizeof(KernConsts));
+    fill_filter_geometry(ctx, h);
+    compute_filter_bounds(h, false);
+    int rc = push_state_fields(ctx, offsetof(DevState, kc),
+                               offsetof(DevState, xi) - offsetof(DevState, kc));
     if (rc) return rc;
-    rc = enqueue_flow(ctx, true, 0, false, nullptr, 0);
-    if (rc) return rc;
+    for (bool redo = true; redo;) {
+        rc = zero_counters(ctx);
+        if (!rc) rc = enqueue_flow(ctx, true, 0, false, nullptr, 0);
+        if (!rc) rc = check_overflow_and_grow(ctx, &redo);
+        if (rc) return rc;
+    }
     rc = fetch_red(ctx, RED_FLOW, 13, out13);
     if (!rc && ctx->profiling) rc = drain_events(ctx);
     return rc;
@@ -637,10 +805,25 @@ int cvo_hip_step_coeffs(cvo_hip_ctx *ctx, const float omega[3], const float v[3]
     if (!ctx->have_tf) return fail(ctx, CVO_HIP_ERR_INVALID, "transform_pcd not called");
     DevState *h = &ctx->st_host[kPollSlots];
     h->kc = make_kconsts(ctx->dprm, ell);
+    fill_filter_geometry(ctx, h);
+    compute_filter_bounds(h, false);
     h->xi = cvo_math::make_xi_consts(omega, v);
     int rc = push_state_fields(ctx, offsetof(DevState, kc),
                                offsetof(DevState, omega) - offsetof(DevState, kc));
     if (rc) return rc;
+    // stand-alone call: rebuild A (filter + PROC_FLOW records the kept weights),
+    // then stream it for the coefficient sums
+    int rlo, rhi, slo, shi;
+    shard_ranges(ctx, rlo, rhi, slo, shi);
+    for (bool redo = true; redo;) {
+        rc = zero_counters(ctx);
+        if (!rc) rc = enqueue_filter(ctx, LIST_XY, ctx->fixed.pos, rlo, rhi, 0, ctx->moving.pos,
+                                     ctx->moving.n, 1, 0);
+        if (!rc) rc = enqueue_process(ctx, PROC_FLOW, LIST_XY, ctx->part_flow, ctx->fixed.pos,
+                                      ctx->fixed.feat, 0, ctx->moving.pos, ctx->moving.feat, 1, 0, 0);
+        if (!rc) rc = check_overflow_and_grow(ctx, &redo);
+        if (rc) return rc;
+    }
     rc = enqueue_step(ctx, 0, false, nullptr, 0);
     if (rc) return rc;
     rc = fetch_red(ctx, RED_STEP, 4, bcde);
@@ -700,45 +883,77 @@ int cvo_hip_align(cvo_hip_ctx *ctx, cvo_hip_state *s, cvo_hip_trace *trace, int 
     h->ell = s->ell;
     h->ell_max = s->ell_max;
     h->iter = s->iter;
+    fill_filter_geometry(ctx, h);
     if (p.max_iter <= 0) h->done = 3;
     HIP_TRY(ctx, hipMemcpyAsync(ctx->st, h, sizeof(DevState), hipMemcpyHostToDevice, ctx->stream));
     launch_prepare(ctx->st, ctx->dprm, ctx->stream);
     HIP_TRY(ctx, hipGetLastError());
     ctx->have_tf = true;
 
-    // enqueue batches of iterations; poll `done` one batch behind
-    int enq = 0;          // iterations enqueued
-    int batches = 0;
-    bool done = p.max_iter <= 0;
+    // Enqueue batches of iterations; poll `done` one batch behind.  A candidate
+    // list that overflows parks the loop with NEED_BIGGER_LIST before any state
+    // was changed: enlarge it and resume from the same iteration.
     int rc = CVO_HIP_OK;
-    while (!done) {
-        const int nb = std::min(kBatch, p.max_iter - enq);
-        for (int q = 0; q < nb && !rc; ++q) {
-            rc = enqueue_flow(ctx, true, 1, true, ctx->trace_dev, trace_cap);
-            if (!rc) rc = enqueue_step(ctx, 1, true, ctx->trace_dev, trace_cap);
+    int executed = 0;
+    for (;;) {
+        int enq = 0;          // iterations enqueued in this round
+        int batches = 0;
+        bool stop = p.max_iter <= 0;
+        while (!stop) {
+            const int nb = std::min(kBatch, std::max(1, p.max_iter - enq));
+            for (int q = 0; q < nb && !rc; ++q) {
+                ctx->iter_tag = enq + q;
+                rc = enqueue_flow(ctx, true, 1, true, ctx->trace_dev, trace_cap);
+                if (!rc) rc = enqueue_step(ctx, 1, true, ctx->trace_dev, trace_cap);
+            }
+            ctx->iter_tag = -1;
+            if (rc) break;
+            enq += nb;
+            const int slot = batches % kPollSlots;
+            HIP_TRY(ctx, hipMemcpyAsync(&ctx->st_host[slot], ctx->st, DEVSTATE_HEAD_BYTES,
+                                        hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(ctx, hipEventRecord(ctx->poll_ev[slot], ctx->stream));
+            ++batches;
+            if (batches >= 2) {   // look at the batch before the one just enqueued
+                const int prev = (batches - 2) % kPollSlots;
+                HIP_TRY(ctx, hipEventSynchronize(ctx->poll_ev[prev]));
+                if (ctx->st_host[prev].done != 0) stop = true;
+            }
+            if (enq >= p.max_iter + kBatch) stop = true;   // cannot happen: done is set by then
         }
-        if (rc) break;
-        enq += nb;
-        const int slot = batches % kPollSlots;
-        HIP_TRY(ctx, hipMemcpyAsync(&ctx->st_host[slot], ctx->st, sizeof(DevState),
+        // everything still queued either runs or returns at once; fetch the state
+        HIP_TRY(ctx, hipMemcpyAsync(&ctx->st_host[0], ctx->st, sizeof(DevState),
                                     hipMemcpyDeviceToHost, ctx->stream));
-        HIP_TRY(ctx, hipEventRecord(ctx->poll_ev[slot], ctx->stream));
-        ++batches;
-        if (batches >= 2) {   // look at the batch before the one just enqueued
-            const int prev = (batches - 2) % kPollSlots;
-            HIP_TRY(ctx, hipEventSynchronize(ctx->poll_ev[prev]));
-            if (ctx->st_host[prev].done != 0) done = true;
-        }
-        if (enq >= p.max_iter) done = true;
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        if (rc) break;
+        const DevState &cur = ctx->st_host[0];
+        if (cur.done != NEED_BIGGER_LIST) break;
+        // profiling: the launches of this round past the parked iteration did nothing
+        if (ctx->profiling) { rc = drain_events(ctx, cur.k - executed + 1); if (rc) break; }
+        executed = cur.k;
+        for (int l = 0; l < LIST_N && !rc; ++l)
+            if (cur.cnt[2 * l + 1]) {
+                double tot = 0.0;   // appended so far; hashing is uniform, so scale by the worst sub-list
+                uint32_t worst = 0;
+                for (int q = 0; q < NSUB; ++q) { tot += cur.sub[l][q]; worst = std::max(worst, cur.sub[l][q]); }
+                const double grown = std::min(4.0e9, std::max((double)worst * NSUB, (double)ctx->lists[l].cap) * 1.5 + 1024.0);
+                rc = ensure_list(ctx, l, 1 << 30, 4, (uint32_t)grown);
+            }
+        if (rc) break;
+        int32_t zero = 0;
+        HIP_TRY(ctx, hipMemcpyAsync(reinterpret_cast<char *>(ctx->st) + offsetof(DevState, done), &zero,
+                                    sizeof(zero), hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        launch_prepare(ctx->st, ctx->dprm, ctx->stream);   // idempotent; re-zeroes the counters
+        HIP_TRY(ctx, hipGetLastError());
     }
-    // everything still queued either runs or returns at once; fetch the end state
-    HIP_TRY(ctx, hipMemcpyAsync(&ctx->st_host[0], ctx->st, sizeof(DevState), hipMemcpyDeviceToHost,
-                                ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->have_tf = false;   // the low-level entry points need their own transform_pcd()
     if (rc) return rc;
     const DevState &f = ctx->st_host[0];
-    if (f.done == 0) return fail(ctx, CVO_HIP_ERR_INVALID, "align loop ended without a verdict");
-    const int executed = f.n_exec;
+    if (f.done == 0 || f.done == NEED_BIGGER_LIST)
+        return fail(ctx, CVO_HIP_ERR_INVALID, "align loop ended without a verdict");
+    const int tag_base = executed;   // iteration tags restart at 0 after a resume
+    executed = f.n_exec;
     if (trace_cap > 0 && executed > 0)
         HIP_TRY(ctx, hipMemcpy(trace, ctx->trace_dev,
                                (size_t)std::min(executed, trace_cap) * sizeof(cvo_hip_trace),
@@ -758,7 +973,7 @@ int cvo_hip_align(cvo_hip_ctx *ctx, cvo_hip_state *s, cvo_hip_trace *trace, int 
     cvo_math::inverse_tf(s->R, s->T, Rt, t);
     cvo_math::tf_to_mat4(Rt, t, s->transform);
     if (n_iter) *n_iter = executed;
-    if (ctx->profiling) return drain_events(ctx);
+    if (ctx->profiling) return drain_events(ctx, executed - tag_base);
     return CVO_HIP_OK;
 }
 
@@ -775,8 +990,11 @@ int cvo_hip_function_inner_product(cvo_hip_ctx *ctx, float ell, float *out)
     }
     DevState *h = &ctx->st_host[kPollSlots];
     h->kc = make_kconsts(dp, ell);
+    fill_filter_geometry(ctx, h);
+    compute_filter_bounds(h, true);
     h->done = 0;
-    int rc = push_state_fields(ctx, offsetof(DevState, kc), sizeof(KernConsts));
+    int rc = push_state_fields(ctx, offsetof(DevState, kc),
+                               offsetof(DevState, xi) - offsetof(DevState, kc));
     if (rc) return rc;
     rc = push_state_fields(ctx, offsetof(DevState, done), sizeof(int32_t));
     if (rc) return rc;
@@ -787,10 +1005,16 @@ int cvo_hip_function_inner_product(cvo_hip_ctx *ctx, float ell, float *out)
     pa.prm = ctx->dprm;
     pa.prm.mode = CVO_HIP_MODE_CVO;   // no self terms here
     pa.flags = POST_REDUCE;
-    rc = enqueue_sweep(ctx, SWEEP_FLOW, ctx->part_flow, ctx->fixed.pos, ctx->fixed.feat, rlo, rhi, 0,
-                       ctx->moving.pos, ctx->moving.feat, ctx->moving.n, 0, 0, 0, &pa.nb_flow);
-    if (rc) return rc;
-    pa.part_flow = ctx->part_flow.p;
+    for (bool redo = true; redo;) {
+        rc = zero_counters(ctx);
+        if (!rc) rc = enqueue_filter(ctx, LIST_XY, ctx->fixed.pos, rlo, rhi, 0, ctx->moving.pos,
+                                     ctx->moving.n, 0, 0);
+        if (!rc) rc = enqueue_process(ctx, PROC_FLOW, LIST_XY, ctx->part_flow, ctx->fixed.pos,
+                                      ctx->fixed.feat, 0, ctx->moving.pos, ctx->moving.feat, 0, 0, 0);
+        if (!rc) rc = check_overflow_and_grow(ctx, &redo);
+        if (rc) return rc;
+    }
+    pa.part_flow = (const double *)ctx->part_flow.p;
     launch_post_flow(pa, ctx->stream);
     HIP_TRY(ctx, hipGetLastError());
     rc = reduce_over_ranks(ctx, RED_FLOW, 9);

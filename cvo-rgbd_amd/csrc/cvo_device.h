@@ -3,6 +3,7 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+#include <stddef.h>
 #include <stdint.h>
 
 #include "cvo_hip.h"
@@ -11,20 +12,37 @@
 namespace cvo_dev {
 
 // Device cloud layout (DESIGN.md "Data layout in HBM"):
-//   pos  : float4 per point (x, y, z, 0)        16 B, one global_load_dwordx4
-//   feat : 8 floats per point (f0..f4, 0, 0, 0) 32 B, two dwordx4 loads
-// Algorithmic bytes per point are 12 + 20 = 32 B; the padding is
-// free here: a sweep reads each cloud once and reuses it ~N-fold on chip.
+//   pos  : float4 per point (x, y, z, caller's index as int bits)  16 B
+//   feat : 8 floats per point (f0..f4, 0, 0, 0)                    32 B
+// both in Morton order.  Algorithmic bytes per point are 12 + 20 = 32 B
+// (SURVEY 8d); the padding is free: a sweep reads each cloud once and reuses it
+// ~N-fold on chip.
 constexpr int FEAT_STRIDE = 8;
 
-// Sweep geometry: a block of 256 threads owns ROWS_PER_LANE x 256 target rows
-// and one chunk of `jt` source columns.
+// Filter geometry: a block of 256 threads = 4 waves; every wave owns
+// TILES_PER_WAVE MFMA row tiles of 16 target rows, the block one chunk of `jt`
+// source columns (a multiple of 16: one MFMA column tile per group).
 constexpr int BLOCK = 256;
-constexpr int ROWS_PER_LANE = 4;
-constexpr int ROWS_PER_TILE = BLOCK * ROWS_PER_LANE;
-constexpr int QCAP = 128;           // per-wave candidate queue entries
+constexpr int TILES_PER_WAVE = 4;
+constexpr int ROWS_PER_WAVE = 16 * TILES_PER_WAVE;
+constexpr int ROWS_PER_TILE = 4 * ROWS_PER_WAVE;   // rows per block
+// Candidates are staged in a per-wave LDS queue and leave for HBM in chunks of
+// CHUNK entries: one returning atomic per chunk, and the reservation for the
+// next chunk is issued one chunk ahead so that its ~2 us round trip is hidden.
+constexpr int CHUNK = 256;   // entries per HBM reservation
+constexpr int QCAP = CHUNK + 64;    // per-wave candidate queue entries
+constexpr uint32_t HOLE = 0xffffffffu;   // row id of an unused slot of a reserved chunk
+constexpr float PAD_BIG = 1.0e30f;  // filter value of padded rows / columns
+constexpr int PROC_BLOCKS = 1024;   // grid of the candidate-list kernels
+// A candidate list is NSUB independent sub-lists (own counter, own slice of the
+// buffer): one hot atomic counter saturates near 90 appends/us on this chip
+// (MI355X_MICROARCH "dequeue"), 256 of them do not.  Waves scatter their
+// 64-entry flushes over the sub-lists round-robin, which also balances them.
+constexpr int NSUB = 256;
+constexpr int PROC_PARTS = PROC_BLOCKS / NSUB;   // blocks cooperating on one sub-list
 
-enum SweepMode { SWEEP_FLOW = 0, SWEEP_STEP = 1, SWEEP_SELF = 2 };
+enum ProcMode { PROC_FLOW = 0, PROC_STEP = 1, PROC_SELF = 2 };
+enum ListId { LIST_XY = 0, LIST_XX = 1, LIST_YY = 2, LIST_N = 3 };
 
 // float64 partial sums a block emits per mode
 constexpr int NACC_FLOW = 9;   // omega[3] v[3] sum_a sum_a_d2 nnz
@@ -37,6 +55,9 @@ constexpr int NACC_MAX = 9;
 //   red[9] sum_xx  [10] nnz_xx  [11] sum_yy_tail  [12] nnz_yy
 //   red[13..16] B C D E
 constexpr int RED_FLOW = 0, RED_XX = 9, RED_YY = 11, RED_STEP = 13, RED_N = 17;
+
+// DevState::done values
+enum { RUNNING = 0, DONE_BREAK_A = 1, DONE_BREAK_B = 2, DONE_MAX_ITER = 3, NEED_BIGGER_LIST = 4 };
 
 struct KernConsts {
     float tau;        // d2 < tau
@@ -73,29 +94,59 @@ struct DevState {
     float Rt[9], t[3];          // inverse transform of the current iteration
     float used_Rt[9], used_t[3]; // the one the last EXECUTED iteration used
     KernConsts kc;              // kernel constants of the current iteration
-    cvo_math::XiConsts xi;      // twist constants for the step-size sweep
+    // MFMA pre-filter (DESIGN.md "Conservative filter"): coordinates are taken
+    // relative to `center`; a pair can only pass the exact test if its filter
+    // value is below tauf[sel] = tau + rounding margin (sel = ListId)
+    float center[3];
+    float xmax, y0max;          // max |x - center|, max |y0 - center| (bbox bounds)
+    float tauf[3];
+    cvo_math::XiConsts xi;      // twist constants for the step-size pass
     float omega[3], v[3];
     double dl;
     double red[RED_N];
+    // candidate lists: cnt[2*l] = unused, cnt[2*l+1] = overflow flag of list l
+    uint32_t cnt[2 * LIST_N];
     int32_t k;                  // iteration about to run / running
-    int32_t done;               // 0 running, 1 break A, 2 break B, 3 MAX_ITER exhausted
+    int32_t done;               // RUNNING, DONE_*, NEED_BIGGER_LIST
     int32_t iter;               // the reference's `iter` member
     int32_t n_exec;             // loop bodies executed
+    // entries appended to every sub-list (kept last: the host polls only the
+    // part of the state in front of it)
+    uint32_t sub[LIST_N][NSUB];
 };
+constexpr size_t DEVSTATE_HEAD_BYTES = offsetof(DevState, sub);
 
-struct SweepArgs {
-    const float4 *pos_a;   // rows (targets)
-    const float *feat_a;
-    const float4 *pos_b;   // columns (sources; transformed on the fly if tf_b)
-    const float *feat_b;
-    double *partials;      // [gridDim.y * gridDim.x][nacc]
-    const DevState *st;    // Rt, t, kc, xi, done
-    int row_lo, row_hi;    // rows processed
-    int nb;                // columns
-    int jt;                // columns per chunk
-    int first_counted;     // SWEEP_SELF: rows below contribute 0 to the sum
+// Dense pair filter: rows [row_lo,row_hi) of cloud a against all of cloud b.
+struct FilterArgs {
+    const float4 *pos_a;
+    const float4 *pos_b;
+    DevState *st;          // Rt, t, center, tauf, done; cnt[] is appended to
+    uint2 *cand;           // candidate list (row, column) in device order
+    uint32_t subcap;       // capacity of each of its NSUB sub-lists
+    int list;              // ListId: selects tauf[] and cnt[]
+    int row_lo, row_hi;
+    int nb;
+    int jt;                // columns per block chunk (multiple of 16)
     int tf_a, tf_b;        // apply [Rt|t] to the row / column cloud while staging
     int check_done;        // return at once when st->done != 0
+    long long *dbg;        // probe only (tools/microbench): per-block phase clocks, else null
+};
+
+// Exact evaluation of a candidate list.
+struct ProcessArgs {
+    const float4 *pos_a;
+    const float *feat_a;
+    const float4 *pos_b;
+    const float *feat_b;
+    const uint2 *cand;
+    float *aval;           // PROC_FLOW writes the kept weight (0 = dropped), PROC_STEP reads it
+    double *partials;      // [PROC_BLOCKS][nacc]
+    const DevState *st;
+    uint32_t subcap;
+    int list;
+    int first_counted;     // PROC_SELF: rows whose caller index is below contribute 0 to the sum
+    int tf_a, tf_b;
+    int check_done;
 };
 
 // k_post flags
@@ -103,9 +154,9 @@ enum { POST_REDUCE = 1, POST_MATH = 2 };
 
 struct PostFlowArgs {
     DevState *st;
-    const double *part_flow; int nb_flow;
-    const double *part_xx;   int nb_xx;
-    const double *part_yy;   int nb_yy;
+    const double *part_flow;
+    const double *part_xx;
+    const double *part_yy;
     cvo_hip_trace *trace; int trace_cap;
     int flags;
     int check_done;
@@ -114,7 +165,7 @@ struct PostFlowArgs {
 
 struct PostStepArgs {
     DevState *st;
-    const double *part_step; int nb_step;
+    const double *part_step;
     cvo_hip_trace *trace; int trace_cap;
     int flags;
     int check_done;
@@ -144,15 +195,51 @@ CVO_HD KernConsts make_kconsts(const DevParams &p, float ell)
     return k;
 }
 
+// Conservative thresholds of the MFMA pre-filter.  The filter evaluates
+// q = (|x'|^2 - tauf) + sum_k x'_k (-2 y'_k) + |y'|^2 in float32 with
+// x' = x - center, y' = y - center.  All its rounding errors together are below
+// 8 u S (u = 2^-24, S = (max|x'| + max|y'|)^2); tauf = tau + 16 u S
+// keeps a factor two in hand, so every pair with d2 < tau has q < 0.
+// `identity` = the moving cloud is used untransformed (function_inner_product).
+CVO_HD void compute_filter_bounds(DevState *s, bool identity)
+{
+    float ymax = s->y0max;
+    if (!identity) {
+        // |R^T (p - T) - c| = |(p - c) - (T + R c - c)| <= |p - c| + |T + (R - I) c|
+        const float *R = s->R, *c = s->center;
+        double sh2 = 0.0;
+        for (int r = 0; r < 3; ++r) {
+            const double rc = (double)R[3 * r] * c[0] + (double)R[3 * r + 1] * c[1] +
+                              (double)R[3 * r + 2] * c[2];
+            const double d = (double)s->T[r] + rc - (double)c[r];
+            sh2 += d * d;
+        }
+        ymax = (float)(((double)s->y0max + sqrt(sh2)) * 1.0001 + 1e-6);
+    }
+    const double u16 = 16.0 / 16777216.0;
+    const double sxy = ((double)s->xmax + ymax) * ((double)s->xmax + ymax);
+    const double sxx = 4.0 * (double)s->xmax * s->xmax;
+    const double syy = 4.0 * (double)ymax * ymax;
+    const double tau = (double)s->kc.tau;
+    s->tauf[LIST_XY] = (float)((tau + u16 * sxy) * 1.000001 + 1e-12);
+    s->tauf[LIST_XX] = (float)((tau + u16 * sxx) * 1.000001 + 1e-12);
+    s->tauf[LIST_YY] = (float)((tau + u16 * syy) * 1.000001 + 1e-12);
+}
+
 // Everything an iteration needs that derives from (R, T, ell).
 CVO_HD void prepare_iteration(DevState *s, const DevParams &p)
 {
     cvo_math::inverse_tf(s->R, s->T, s->Rt, s->t);
     s->kc = make_kconsts(p, s->ell);
+    compute_filter_bounds(s, false);
+    for (int q = 0; q < 2 * LIST_N; ++q) s->cnt[q] = 0u;
+    // (the per-sub-list counters are zeroed by all threads of the calling kernel)
 }
 
+size_t filter_smem_bytes(int jt);
 void launch_prepare(DevState *st, const DevParams &prm, hipStream_t s);
-void launch_sweep(int mode, const SweepArgs &a, dim3 grid, hipStream_t s);
+void launch_filter(const FilterArgs &a, dim3 grid, hipStream_t s);
+void launch_process(int mode, const ProcessArgs &a, hipStream_t s);
 void launch_post_flow(const PostFlowArgs &a, hipStream_t s);
 void launch_post_step(const PostStepArgs &a, hipStream_t s);
 

@@ -1,9 +1,14 @@
 // cvo_kernels.hip -- gfx950 (MI355X, CDNA4) kernels for the CVO inner loop.
 //
-//   k_sweep     : transform_pcd + se_kernel fused with the consumer of A
-//                   SWEEP_FLOW  compute_flow          (ref src/cvo.cpp:99-210,310-315)
-//                   SWEEP_STEP  compute_step_size      (ref src/cvo.cpp:213-289)
-//                   SWEEP_SELF  acvo Axx / Ayy terms   (ref src/adaptive_cvo.cpp:156-265)
+//   k_filter    : transform_pcd + the neighbour search of se_kernel
+//                 (ref src/cvo.cpp:310-315,110-125): ALL target x source pairs
+//                 are tested on the matrix cores (f32 MFMA, K = 4) against a
+//                 conservative squared-distance bound; survivors are appended
+//                 to a candidate list in HBM.
+//   k_process   : exact evaluation of the candidate list
+//                   PROC_FLOW  rest of se_kernel + compute_flow (ref cvo.cpp:126-210)
+//                   PROC_STEP  compute_step_size sums          (ref cvo.cpp:213-289)
+//                   PROC_SELF  acvo Axx / Ayy terms   (ref adaptive_cvo.cpp:156-265)
 //   k_post_flow : fixed-order float64 reduction of the block partials, then the
 //                 O(1) maths that follows compute_flow (twist, dl, Taylor consts)
 //   k_post_step : same for compute_step_size: cubic, break tests, Exp_SEK3,
@@ -14,25 +19,23 @@
 // HBM, every kernel starts by reading it (and returns at once when the
 // registration has converged), so the host only enqueues launches and polls.
 //
-// The Gram matrix A is never materialised: every sweep re-tests all
-// target x source pairs (dense, wave64: ROWS_PER_LANE target rows per lane, the
-// source chunk broadcast from LDS), and the rare survivors of the distance
-// test are compacted through a per-wave LDS queue so that the expensive part
-// (colour distance, two float64 exponentials, float64 accumulation) always
-// runs on full wavefronts.
+// Why a list.  The reference builds a sparse Gram matrix A once per iteration
+// and uses it twice (flow, step size).  Here the dense filter plays the kd-tree
+// and the candidate list plays A: it is consumed by PROC_FLOW (which also
+// records every kept weight) and again by PROC_STEP, so the all-pairs work is
+// done once per iteration, and the expensive per-survivor arithmetic (colour
+// distance, two float64 exponentials, float64 accumulation) runs perfectly
+// load-balanced on full wavefronts no matter how the survivors cluster.
 //
 // Arithmetic contract: compiled with -ffp-contract=off; every FMA
 // below is an explicit __builtin_fmaf.  Per-pair terms are float32 in the
-// reference's operation order, accumulated in float64.
+// reference's operation order, accumulated in float64.  The MFMA filter only
+// decides which pairs are LOOKED AT; it never decides membership in A.
 #include "cvo_device.h"
 
 namespace cvo_dev {
 
-__device__ __forceinline__ float4 nan4()
-{
-    const float q = __builtin_nanf("");
-    return make_float4(q, q, q, q);
-}
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // Eigen: transform.linear()*p + translation, coefficient order, no FMA
 __device__ __forceinline__ float4 apply_tf(const float *Rt, const float *t, const float4 p)
@@ -41,7 +44,7 @@ __device__ __forceinline__ float4 apply_tf(const float *Rt, const float *t, cons
     o.x = ((Rt[0] * p.x + Rt[1] * p.y) + Rt[2] * p.z) + t[0];
     o.y = ((Rt[3] * p.x + Rt[4] * p.y) + Rt[5] * p.z) + t[1];
     o.z = ((Rt[6] * p.x + Rt[7] * p.y) + Rt[8] * p.z) + t[2];
-    o.w = 0.0f;
+    o.w = p.w;   // caller's index bits ride along
     return o;
 }
 
@@ -50,6 +53,209 @@ __device__ __forceinline__ float mv_row(const float *m, float x, float y, float 
     return (m[0] * x + m[1] * y) + m[2] * z;
 }
 
+// ---------------------------------------------------------------------------
+// k_filter
+// ---------------------------------------------------------------------------
+// LDS carve of one filter block (all 16-byte aligned):
+//   bop   [jt/16][64] float : MFMA B operands of the column chunk, per group of
+//                             16 columns k-major: [-2y'0 x16][-2y'1 x16][-2y'2 x16][|y'|^2 x16]
+//   xrow  [ROWS_PER_TILE] float4 : (x'0, x'1, x'2, |x'|^2) of the block's rows
+//   queue [4][QCAP] u32     : per-wave candidate queues
+size_t filter_smem_bytes(int jt) { return (size_t)jt * 16 + ROWS_PER_TILE * 16 + 4 * QCAP * 4; }
+
+// write queue entries q[0..n) to slots [base, base+padto) of sub-list `sub`
+// (slots n..padto become holes); n, padto, sub, base are wave-uniform
+__device__ __forceinline__ void write_chunk(const unsigned *q, int n, int padto, int lane, int row0,
+                                            int j0, unsigned sub, unsigned base, const FilterArgs &a)
+{
+    if (base + (unsigned)padto <= a.subcap) {
+        uint2 *dst = a.cand + (size_t)sub * a.subcap + base;
+        for (int t = lane; t < padto; t += 64) {
+            uint2 v = make_uint2(HOLE, HOLE);
+            if (t < n) {
+                const unsigned e = q[t];
+                v = make_uint2((unsigned)row0 + (e >> 16), (unsigned)j0 + (e & 0xffffu));
+            }
+            dst[t] = v;
+        }
+    } else if (lane == 0) {
+        atomicOr(&a.st->cnt[2 * a.list + 1], 1u);   // overflow: the host grows the list and resumes
+    }
+}
+
+__global__ void __launch_bounds__(BLOCK) k_filter(const FilterArgs a)
+{
+    const long long t_start = a.dbg ? (long long)__builtin_readcyclecounter() : 0;
+    const long long w_start = a.dbg ? (long long)wall_clock64() : 0;
+    if (a.check_done && a.st->done != 0) return;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *bop = reinterpret_cast<float *>(smem);
+    float4 *xrow = reinterpret_cast<float4 *>(smem + (size_t)a.jt * 16);
+    unsigned *queue = reinterpret_cast<unsigned *>(smem + (size_t)a.jt * 16 + ROWS_PER_TILE * 16);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wid = tid >> 6;
+    const int row0 = a.row_lo + blockIdx.y * ROWS_PER_TILE;
+    const int j0 = blockIdx.x * a.jt;
+    const int jn = min(a.jt, a.nb - j0);
+    const int ngroups = (jn + 15) >> 4;
+    const float *Rt = a.st->Rt;
+    const float *tt = a.st->t;
+    const float cx = a.st->center[0], cy = a.st->center[1], cz = a.st->center[2];
+    const float tauf = a.st->tauf[a.list];
+
+    // ---- prologue.  Every global load is issued before anything waits on one
+    // (clamped addresses instead of control flow), so the block pays ONE memory
+    // round trip for its 256 rows and its column chunk, not one per load.
+    const int i_row = row0 + tid;
+    float4 prow = a.pos_a[min(i_row, a.row_hi - 1)];
+    const int ncol = ngroups * 16;
+    for (int t0 = 0; t0 < ncol; t0 += 2 * BLOCK) {
+        const int ta = t0 + tid, tb = t0 + BLOCK + tid;
+        float4 pa = a.pos_b[j0 + min(ta, jn - 1)];
+        float4 pb = a.pos_b[j0 + min(tb, jn - 1)];
+        if (a.tf_b) { pa = apply_tf(Rt, tt, pa); pb = apply_tf(Rt, tt, pb); }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int t = u ? tb : ta;
+            const float4 p = u ? pb : pa;
+            if (t < ncol) {
+                // MFMA B operands of column t: [-2y'0, -2y'1, -2y'2, |y'|^2]
+                const float ax = p.x - cx, ay = p.y - cy, az = p.z - cz;
+                const bool real = t < jn;
+                float *g = bop + (t >> 4) * 64 + (t & 15);
+                g[0] = real ? -2.0f * ax : 0.0f;
+                g[16] = real ? -2.0f * ay : 0.0f;
+                g[32] = real ? -2.0f * az : 0.0f;
+                g[48] = real ? __builtin_fmaf(az, az, __builtin_fmaf(ay, ay, ax * ax)) : PAD_BIG;
+            }
+        }
+    }
+    {   // the block's rows: (x'0, x'1, x'2, |x'|^2) into LDS, one row per thread
+        if (a.tf_a) prow = apply_tf(Rt, tt, prow);
+        const float ax = prow.x - cx, ay = prow.y - cy, az = prow.z - cz;
+        const bool real = i_row < a.row_hi;
+        xrow[tid] = real ? make_float4(ax, ay, az, __builtin_fmaf(az, az, __builtin_fmaf(ay, ay, ax * ax)))
+                         : make_float4(0.0f, 0.0f, 0.0f, PAD_BIG);
+    }
+    __syncthreads();
+    // MFMA A operands: lane l holds A[row = l&15][k = l>>4] of each 16-row tile,
+    // k = 3 multiplies |y'|^2 by one.  C operands: lane l holds rows (l>>4)*4 + r:
+    // |x'|^2 - tauf, so that D = C + A.B is the filter value itself.
+    const int kk = lane >> 4;
+    float areg[TILES_PER_WAVE];
+    f32x4 creg[TILES_PER_WAVE];
+#pragma unroll
+    for (int t = 0; t < TILES_PER_WAVE; ++t) {
+        const float *xr = reinterpret_cast<const float *>(xrow + wid * ROWS_PER_WAVE + t * 16);
+        areg[t] = (kk == 3) ? 1.0f : xr[(lane & 15) * 4 + kk];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) creg[t][r] = xr[(kk * 4 + r) * 4 + 3] - tauf;
+    }
+
+    unsigned *q = queue + wid * QCAP;
+    int qn = 0;   // wave-uniform
+    // this wave's flushes walk round-robin over the sub-lists
+    unsigned sub = ((blockIdx.y * gridDim.x + blockIdx.x) * 4u + (unsigned)wid) * 37u;
+    int have_next = 0;            // wave-uniform: a chunk slot is reserved ahead
+    unsigned next_base = 0;       // its offset (valid in lane 0 once the atomic returns)
+    unsigned next_sub = 0;        // ... in this sub-list
+
+    const long long t_loop = a.dbg ? (long long)__builtin_readcyclecounter() : 0;
+    float bnext = bop[lane];
+    for (int g = 0; g < ngroups; ++g) {
+        const float b = bnext;
+        if (g + 1 < ngroups) bnext = bop[(g + 1) * 64 + lane];   // prefetch the next column tile
+        f32x4 d[TILES_PER_WAVE];
+#pragma unroll
+        for (int t = 0; t < TILES_PER_WAVE; ++t)
+            d[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[t], b, creg[t], 0, 0, 0);
+        // any filter value negative?  OR of the sign bits
+        int orall = 0;
+#pragma unroll
+        for (int t = 0; t < TILES_PER_WAVE; ++t)
+            orall |= (__float_as_int(d[t][0]) | __float_as_int(d[t][1])) |
+                     (__float_as_int(d[t][2]) | __float_as_int(d[t][3]));
+        if (__ballot(orall < 0) == 0ull) continue;
+        // queue every (row, column) whose filter value is negative
+#pragma unroll
+        for (int t = 0; t < TILES_PER_WAVE; ++t) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const bool pass = d[t][r] < 0.0f;
+                const unsigned long long m = __ballot(pass);
+                if (m) {
+                    if (pass) {
+                        const unsigned below = __builtin_amdgcn_mbcnt_hi(
+                            (unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+                        const unsigned rl = (unsigned)(wid * ROWS_PER_WAVE + t * 16 + kk * 4 + r);
+                        q[qn + below] = (rl << 16) | (unsigned)(g * 16 + (lane & 15));
+                    }
+                    qn += __popcll(m);
+                    if (qn >= CHUNK) {
+                        // a full chunk leaves for HBM: into the slot reserved one
+                        // chunk ago (or reserved now, the first time), and the
+                        // next slot is reserved at once so its atomic is in flight
+                        // while the queue refills
+                        qn -= CHUNK;
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                        unsigned base, csub;
+                        if (have_next) {
+                            base = __builtin_amdgcn_readfirstlane(next_base);
+                            csub = next_sub;
+                        } else {
+                            csub = (sub++) & (NSUB - 1);
+                            unsigned b0 = 0;
+                            if (lane == 0) b0 = atomicAdd(&a.st->sub[a.list][csub], (unsigned)CHUNK);
+                            base = __builtin_amdgcn_readfirstlane(b0);
+                        }
+                        next_sub = (sub++) & (NSUB - 1);
+                        if (lane == 0) next_base = atomicAdd(&a.st->sub[a.list][next_sub], (unsigned)CHUNK);
+                        have_next = 1;
+                        write_chunk(q + qn, CHUNK, CHUNK, lane, row0, j0, csub, base, a);
+                        __builtin_amdgcn_wave_barrier();
+                    }
+                }
+            }
+        }
+    }
+    const long long t_tail = a.dbg ? (long long)__builtin_readcyclecounter() : 0;
+    // the tail: into the slot already reserved (padding it with holes), or into
+    // an exactly-sized reservation if this wave never filled a chunk
+    if (have_next || qn > 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (have_next) {
+            write_chunk(q, qn, CHUNK, lane, row0, j0, next_sub,
+                        __builtin_amdgcn_readfirstlane(next_base), a);
+        } else {
+            const unsigned csub = sub & (NSUB - 1);
+            unsigned b0 = 0;
+            if (lane == 0) b0 = atomicAdd(&a.st->sub[a.list][csub], (unsigned)qn);
+            write_chunk(q, qn, qn, lane, row0, j0, csub, __builtin_amdgcn_readfirstlane(b0), a);
+        }
+    }
+    if (a.dbg && lane == 0) {   // probe: start, prologue end, loop end, exit clocks of every wave
+        long long *o = a.dbg + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 4 + wid) * 8;
+        o[6] = w_start; o[7] = (long long)wall_clock64();   // 100 MHz constant clock
+        o[0] = t_start; o[1] = t_loop; o[2] = t_tail; o[3] = (long long)__builtin_readcyclecounter();
+        o[4] = __builtin_amdgcn_s_getreg((31 << 11) | 4);    // HW_ID: wave slot, SIMD, CU, SE
+        o[5] = __builtin_amdgcn_s_getreg((31 << 11) | 20);   // XCC_ID
+    }
+}
+
+void launch_filter(const FilterArgs &a, dim3 grid, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_filter, grid, dim3(BLOCK), filter_smem_bytes(a.jt), s, a);
+}
+
+// ---------------------------------------------------------------------------
+// k_process
+// ---------------------------------------------------------------------------
 __device__ __forceinline__ float d2_feat(const float4 fa0, const float fa4, const float4 fb0,
                                          const float fb4)
 {
@@ -65,7 +271,7 @@ __device__ __forceinline__ float d2_feat(const float4 fa0, const float fa4, cons
 
 // pair weight for a pair that passed d2 < tau; 0 if dropped (ref cvo.cpp:143-153)
 __device__ __forceinline__ float pair_weight(const KernConsts &kc, float d2, const float *feat_a,
-                                             int i, const float *feat_b, int j)
+                                             unsigned i, const float *feat_b, unsigned j)
 {
     const float4 fa0 = *reinterpret_cast<const float4 *>(feat_a + (size_t)i * FEAT_STRIDE);
     const float fa4 = feat_a[(size_t)i * FEAT_STRIDE + 4];
@@ -80,166 +286,109 @@ __device__ __forceinline__ float pair_weight(const KernConsts &kc, float d2, con
 }
 
 template <int MODE> struct NAcc;
-template <> struct NAcc<SWEEP_FLOW> { static constexpr int n = NACC_FLOW; };
-template <> struct NAcc<SWEEP_STEP> { static constexpr int n = NACC_STEP; };
-template <> struct NAcc<SWEEP_SELF> { static constexpr int n = NACC_SELF; };
-
-// One compacted candidate: full evaluation of the pair and accumulation.
-template <int MODE>
-__device__ __forceinline__ void process_pair(const SweepArgs &a, const KernConsts &kc, int i,
-                                             int j, const float4 xi, const float4 yj, double *acc)
-{
-    const float e0 = xi.x - yj.x, e1 = xi.y - yj.y, e2 = xi.z - yj.z;
-    const float d2 = __builtin_fmaf(e2, e2, __builtin_fmaf(e1, e1, e0 * e0));
-    if (!(d2 < kc.tau)) return;   // also rejects NaN padding
-    const float w = pair_weight(kc, d2, a.feat_a, i, a.feat_b, j);
-    if (!(w > 0.0f)) return;
-    if (MODE == SWEEP_FLOW) {
-        // cross(x_i, y_j), y_j - x_i ; (1/c * A_ij) * cross  (ref cvo.cpp:191-198)
-        const float c0 = xi.y * yj.z - xi.z * yj.y;
-        const float c1 = xi.z * yj.x - xi.x * yj.z;
-        const float c2 = xi.x * yj.y - xi.y * yj.x;
-        const float f0 = yj.x - xi.x, f1 = yj.y - xi.y, f2 = yj.z - xi.z;
-        const float ac = kc.inv_c * w, ad = kc.inv_d * w;
-        acc[0] += (double)(ac * c0);
-        acc[1] += (double)(ac * c1);
-        acc[2] += (double)(ac * c2);
-        acc[3] += (double)(ad * f0);
-        acc[4] += (double)(ad * f1);
-        acc[5] += (double)(ad * f2);
-        acc[6] += (double)w;
-        acc[7] += (double)((kc.inv_l3 * w) * d2);
-        acc[8] += 1.0;
-    } else if (MODE == SWEEP_STEP) {
-        // Taylor vectors of y_j (ref cvo.cpp:226-238), evaluated for survivors only
-        const cvo_math::XiConsts &xc = a.st->xi;
-        float xiz[3], xi2z[3], xi3z[3], xi4z[3];
-        xiz[0] = (xc.omega[1] * yj.z - xc.omega[2] * yj.y) + xc.v[0];
-        xiz[1] = (xc.omega[2] * yj.x - xc.omega[0] * yj.z) + xc.v[1];
-        xiz[2] = (xc.omega[0] * yj.y - xc.omega[1] * yj.x) + xc.v[2];
-#pragma unroll
-        for (int r = 0; r < 3; ++r) {
-            xi2z[r] = mv_row(xc.W2 + 3 * r, yj.x, yj.y, yj.z) + xc.u2[r];
-            xi3z[r] = mv_row(xc.W3 + 3 * r, yj.x, yj.y, yj.z) + xc.u3[r];
-            xi4z[r] = mv_row(xc.W4 + 3 * r, yj.x, yj.y, yj.z) + xc.u4[r];
-        }
-        const float normxiz2 = (xiz[0] * xiz[0] + xiz[1] * xiz[1]) + xiz[2] * xiz[2];
-        const float xz12 = -((xiz[0] * xi2z[0] + xiz[1] * xi2z[1]) + xiz[2] * xi2z[2]);
-        const float eps_c = ((xi2z[0] * xi2z[0] + xi2z[1] * xi2z[1]) + xi2z[2] * xi2z[2]) +
-                            2 * ((xiz[0] * xi3z[0] + xiz[1] * xi3z[1]) + xiz[2] * xi3z[2]);
-        // diff_xy = x_i - y_j is (e0,e1,e2); ref cvo.cpp:256-280
-        const float cb = kc.cb, cg = kc.cg, cd = kc.cd;
-        const float beta = ((cb * xiz[0]) * e0 + (cb * xiz[1]) * e1) + (cb * xiz[2]) * e2;
-        const float g_dot = ((2.0f * xi2z[0]) * e0 + (2.0f * xi2z[1]) * e1) + (2.0f * xi2z[2]) * e2;
-        const float gamma = cg * (normxiz2 + g_dot);
-        const float d_dot = ((-xi3z[0]) * e0 + (-xi3z[1]) * e1) + (-xi3z[2]) * e2;
-        const float delta = cd * (xz12 + d_dot);
-        const float e_dot = ((2.0f * xi4z[0]) * e0 + (2.0f * xi4z[1]) * e1) + (2.0f * xi4z[2]) * e2;
-        const float epsil = cg * (eps_c + e_dot);
-        const double A = (double)w;
-        const double b = (double)beta, g = (double)gamma;
-        acc[0] += (double)(w * beta);
-        acc[1] += A * (g + (double)(beta * beta) / 2.0);
-        acc[2] += A * ((double)(delta + beta * gamma) + (double)(beta * beta * beta) / 6.0);
-        acc[3] += A * ((((double)(epsil + beta * delta) + 0.5 * b * b * g) + 0.5 * g * g) +
-                       1 / 24.0 * b * b * b * b);
-    } else {
-        if (i >= a.first_counted) acc[0] += (double)((kc.inv_l3 * w) * d2);
-        acc[1] += 1.0;
-    }
-}
+template <> struct NAcc<PROC_FLOW> { static constexpr int n = NACC_FLOW; };
+template <> struct NAcc<PROC_STEP> { static constexpr int n = NACC_STEP; };
+template <> struct NAcc<PROC_SELF> { static constexpr int n = NACC_SELF; };
 
 template <int MODE>
-__global__ void __launch_bounds__(BLOCK) k_sweep(const SweepArgs a)
+__global__ void __launch_bounds__(BLOCK) k_process(const ProcessArgs a)
 {
     constexpr int NACC = NAcc<MODE>::n;
     if (a.check_done && a.st->done != 0) return;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    float4 *ypos = reinterpret_cast<float4 *>(smem);                                     // [jt]
-    unsigned *queue = reinterpret_cast<unsigned *>(smem + (size_t)a.jt * 16);            // [4][QCAP]
-    double *red = reinterpret_cast<double *>(smem + (size_t)a.jt * 16 + 4 * QCAP * 4);  // [4][NACC]
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wid = tid >> 6;
-    const int row0 = a.row_lo + blockIdx.y * ROWS_PER_TILE;
-    const int j0 = blockIdx.x * a.jt;
-    const int jn = min(a.jt, a.nb - j0);
+    __shared__ double red[4 * NACC_MAX];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const KernConsts kc = a.st->kc;
     const float *Rt = a.st->Rt;
     const float *tt = a.st->t;
-
-    float x0[ROWS_PER_LANE], x1[ROWS_PER_LANE], x2[ROWS_PER_LANE];
-#pragma unroll
-    for (int r = 0; r < ROWS_PER_LANE; ++r) {
-        const int i = row0 + r * BLOCK + tid;
-        float4 p = nan4();
-        if (i < a.row_hi) {
-            p = a.pos_a[i];
-            if (a.tf_a) p = apply_tf(Rt, tt, p);
-        }
-        x0[r] = p.x; x1[r] = p.y; x2[r] = p.z;
-    }
-    for (int t = tid; t < jn; t += BLOCK) {
-        float4 p = a.pos_b[j0 + t];
-        if (a.tf_b) p = apply_tf(Rt, tt, p);
-        ypos[t] = p;
-    }
-    __syncthreads();
+    // PROC_PARTS blocks share one sub-list
+    const unsigned sub = blockIdx.x & (NSUB - 1), part = blockIdx.x / NSUB;
+    unsigned n = a.st->sub[a.list][sub];
+    if (n > a.subcap) n = a.subcap;   // overflowed list: the iteration is redone anyway
+    const size_t sbase = (size_t)sub * a.subcap;
 
     double acc[NACC];
 #pragma unroll
     for (int k = 0; k < NACC; ++k) acc[k] = 0.0;
 
-    unsigned *q = queue + wid * QCAP;
-    int qn = 0;   // wave-uniform
-    const float tau = kc.tau;
-
-    for (int jj = 0; jj < jn; ++jj) {
-        const float4 y = ypos[jj];   // LDS broadcast
+    for (unsigned off = part * BLOCK + tid; off < n; off += PROC_PARTS * BLOCK) {
+        const size_t idx = sbase + off;
+        const uint2 e = a.cand[idx];
+        if (e.x == HOLE) continue;   // unused slot of a reserved chunk
+        float4 xi = a.pos_a[e.x];
+        if (a.tf_a) xi = apply_tf(Rt, tt, xi);
+        float4 yj = a.pos_b[e.y];
+        if (a.tf_b) yj = apply_tf(Rt, tt, yj);
+        const float e0 = xi.x - yj.x, e1 = xi.y - yj.y, e2 = xi.z - yj.z;
+        float w;
+        float d2 = 0.0f;
+        if (MODE == PROC_STEP) {
+            w = a.aval[idx];     // kept weight recorded by PROC_FLOW, 0 = not in A
+        } else {
+            // the exact membership test of se_kernel (ref cvo.cpp:125-152)
+            d2 = __builtin_fmaf(e2, e2, __builtin_fmaf(e1, e1, e0 * e0));
+            w = (d2 < kc.tau) ? pair_weight(kc, d2, a.feat_a, e.x, a.feat_b, e.y) : 0.0f;
+            if (MODE == PROC_FLOW) a.aval[idx] = w;
+        }
+        if (!(w > 0.0f)) continue;
+        if (MODE == PROC_FLOW) {
+            // cross(x_i, y_j), y_j - x_i ; (1/c * A_ij) * cross  (ref cvo.cpp:191-198)
+            const float c0 = xi.y * yj.z - xi.z * yj.y;
+            const float c1 = xi.z * yj.x - xi.x * yj.z;
+            const float c2 = xi.x * yj.y - xi.y * yj.x;
+            const float f0 = yj.x - xi.x, f1 = yj.y - xi.y, f2 = yj.z - xi.z;
+            const float ac = kc.inv_c * w, ad = kc.inv_d * w;
+            acc[0] += (double)(ac * c0);
+            acc[1] += (double)(ac * c1);
+            acc[2] += (double)(ac * c2);
+            acc[3] += (double)(ad * f0);
+            acc[4] += (double)(ad * f1);
+            acc[5] += (double)(ad * f2);
+            acc[6] += (double)w;
+            acc[7] += (double)((kc.inv_l3 * w) * d2);
+            acc[8] += 1.0;
+        } else if (MODE == PROC_STEP) {
+            // Taylor vectors of y_j (ref cvo.cpp:226-238), for members of A only
+            const cvo_math::XiConsts &xc = a.st->xi;
+            float xiz[3], xi2z[3], xi3z[3], xi4z[3];
+            xiz[0] = (xc.omega[1] * yj.z - xc.omega[2] * yj.y) + xc.v[0];
+            xiz[1] = (xc.omega[2] * yj.x - xc.omega[0] * yj.z) + xc.v[1];
+            xiz[2] = (xc.omega[0] * yj.y - xc.omega[1] * yj.x) + xc.v[2];
 #pragma unroll
-        for (int r = 0; r < ROWS_PER_LANE; ++r) {
-            const float e0 = x0[r] - y.x, e1 = x1[r] - y.y, e2 = x2[r] - y.z;
-            const float d2 = __builtin_fmaf(e2, e2, __builtin_fmaf(e1, e1, e0 * e0));
-            const bool pass = d2 < tau;
-            const unsigned long long m = __ballot(pass);
-            if (m) {
-                if (pass) {
-                    const unsigned below = __builtin_amdgcn_mbcnt_hi(
-                        (unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-                    q[qn + below] = ((unsigned)(r * BLOCK + tid) << 16) | (unsigned)jj;
-                }
-                qn += __popcll(m);
-                if (qn >= 64) {
-                    qn -= 64;
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                    const unsigned e = q[qn + lane];
-                    const int il = (int)(e >> 16), cj = (int)(e & 0xffffu);
-                    float4 xi = a.pos_a[row0 + il];
-                    if (a.tf_a) xi = apply_tf(Rt, tt, xi);
-                    process_pair<MODE>(a, kc, row0 + il, j0 + cj, xi, ypos[cj], acc);
-                    __builtin_amdgcn_wave_barrier();
-                }
+            for (int r = 0; r < 3; ++r) {
+                xi2z[r] = mv_row(xc.W2 + 3 * r, yj.x, yj.y, yj.z) + xc.u2[r];
+                xi3z[r] = mv_row(xc.W3 + 3 * r, yj.x, yj.y, yj.z) + xc.u3[r];
+                xi4z[r] = mv_row(xc.W4 + 3 * r, yj.x, yj.y, yj.z) + xc.u4[r];
             }
-        }
-    }
-    if (qn > 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        if (lane < qn) {
-            const unsigned e = q[lane];
-            const int il = (int)(e >> 16), cj = (int)(e & 0xffffu);
-            float4 xi = a.pos_a[row0 + il];
-            if (a.tf_a) xi = apply_tf(Rt, tt, xi);
-            process_pair<MODE>(a, kc, row0 + il, j0 + cj, xi, ypos[cj], acc);
+            const float normxiz2 = (xiz[0] * xiz[0] + xiz[1] * xiz[1]) + xiz[2] * xiz[2];
+            const float xz12 = -((xiz[0] * xi2z[0] + xiz[1] * xi2z[1]) + xiz[2] * xi2z[2]);
+            const float eps_c = ((xi2z[0] * xi2z[0] + xi2z[1] * xi2z[1]) + xi2z[2] * xi2z[2]) +
+                                2 * ((xiz[0] * xi3z[0] + xiz[1] * xi3z[1]) + xiz[2] * xi3z[2]);
+            // diff_xy = x_i - y_j is (e0,e1,e2); ref cvo.cpp:256-280
+            const float cb = kc.cb, cg = kc.cg, cd = kc.cd;
+            const float beta = ((cb * xiz[0]) * e0 + (cb * xiz[1]) * e1) + (cb * xiz[2]) * e2;
+            const float g_dot =
+                ((2.0f * xi2z[0]) * e0 + (2.0f * xi2z[1]) * e1) + (2.0f * xi2z[2]) * e2;
+            const float gamma = cg * (normxiz2 + g_dot);
+            const float d_dot = ((-xi3z[0]) * e0 + (-xi3z[1]) * e1) + (-xi3z[2]) * e2;
+            const float delta = cd * (xz12 + d_dot);
+            const float e_dot =
+                ((2.0f * xi4z[0]) * e0 + (2.0f * xi4z[1]) * e1) + (2.0f * xi4z[2]) * e2;
+            const float epsil = cg * (eps_c + e_dot);
+            const double A = (double)w;
+            const double b = (double)beta, g = (double)gamma;
+            acc[0] += (double)(w * beta);
+            acc[1] += A * (g + (double)(beta * beta) / 2.0);
+            acc[2] += A * ((double)(delta + beta * gamma) + (double)(beta * beta * beta) / 6.0);
+            acc[3] += A * ((((double)(epsil + beta * delta) + 0.5 * b * b * g) + 0.5 * g * g) +
+                           1 / 24.0 * b * b * b * b);
+        } else {
+            if (__float_as_int(xi.w) >= a.first_counted)
+                acc[0] += (double)((kc.inv_l3 * w) * d2);
+            acc[1] += 1.0;
         }
     }
 
-    // wave reduction (xor butterfly: every lane ends with the same float64 sum,
-    // order fixed by the lane ids => deterministic), then 4 waves in order
+    // block reduction: xor butterfly inside each wave, then the 4 waves in order
 #pragma unroll
     for (int k = 0; k < NACC; ++k) {
         double s = acc[k];
@@ -250,22 +399,21 @@ __global__ void __launch_bounds__(BLOCK) k_sweep(const SweepArgs a)
     __syncthreads();
     if (tid < NACC) {
         const double s = ((red[tid] + red[NACC + tid]) + red[2 * NACC + tid]) + red[3 * NACC + tid];
-        a.partials[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * NACC + tid] = s;
+        a.partials[(size_t)blockIdx.x * NACC + tid] = s;
     }
 }
 
-void launch_sweep(int mode, const SweepArgs &a, dim3 grid, hipStream_t s)
+void launch_process(int mode, const ProcessArgs &a, hipStream_t s)
 {
-    const size_t smem = (size_t)a.jt * 16 + 4 * QCAP * 4 + 4 * NACC_MAX * sizeof(double);
     switch (mode) {
-    case SWEEP_FLOW:
-        hipLaunchKernelGGL(k_sweep<SWEEP_FLOW>, grid, dim3(BLOCK), smem, s, a);
+    case PROC_FLOW:
+        hipLaunchKernelGGL(k_process<PROC_FLOW>, dim3(PROC_BLOCKS), dim3(BLOCK), 0, s, a);
         break;
-    case SWEEP_STEP:
-        hipLaunchKernelGGL(k_sweep<SWEEP_STEP>, grid, dim3(BLOCK), smem, s, a);
+    case PROC_STEP:
+        hipLaunchKernelGGL(k_process<PROC_STEP>, dim3(PROC_BLOCKS), dim3(BLOCK), 0, s, a);
         break;
     default:
-        hipLaunchKernelGGL(k_sweep<SWEEP_SELF>, grid, dim3(BLOCK), smem, s, a);
+        hipLaunchKernelGGL(k_process<PROC_SELF>, dim3(PROC_BLOCKS), dim3(BLOCK), 0, s, a);
         break;
     }
 }
@@ -273,7 +421,7 @@ void launch_sweep(int mode, const SweepArgs &a, dim3 grid, hipStream_t s)
 // ---------------------------------------------------------------------------
 // Fixed-order reduction of partials[nblocks][NACC] by one 256-thread block:
 // thread t adds blocks t, t+256, ...; xor butterfly inside each wave; the four
-// wave sums are added in wave order.  Result broadcast to all threads via LDS.
+// wave sums are added in wave order.
 template <int NACC>
 __device__ void block_reduce_partials(const double *part, int nblocks, double *sh /*[4*NACC_MAX]*/,
                                       double *out /*[NACC], thread 0 writes*/)
@@ -307,16 +455,28 @@ __global__ void __launch_bounds__(BLOCK) k_post_flow(const PostFlowArgs a)
     __shared__ double sh[4 * NACC_MAX];
     DevState *st = a.st;
     if (a.check_done && st->done != 0) return;
+    const bool acvo = a.prm.mode == CVO_HIP_MODE_ACVO;
     if (a.flags & POST_REDUCE) {
-        block_reduce_partials<NACC_FLOW>(a.part_flow, a.nb_flow, sh, st->red + RED_FLOW);
-        if (a.prm.mode == CVO_HIP_MODE_ACVO) {
-            block_reduce_partials<NACC_SELF>(a.part_xx, a.nb_xx, sh, st->red + RED_XX);
-            block_reduce_partials<NACC_SELF>(a.part_yy, a.nb_yy, sh, st->red + RED_YY);
+        block_reduce_partials<NACC_FLOW>(a.part_flow, PROC_BLOCKS, sh, st->red + RED_FLOW);
+        if (acvo) {
+            block_reduce_partials<NACC_SELF>(a.part_xx, PROC_BLOCKS, sh, st->red + RED_XX);
+            block_reduce_partials<NACC_SELF>(a.part_yy, PROC_BLOCKS, sh, st->red + RED_YY);
         } else if (threadIdx.x == 0) {
             st->red[RED_XX] = st->red[RED_XX + 1] = st->red[RED_YY] = st->red[RED_YY + 1] = 0.0;
         }
+        // a candidate list overflowed on this rank: poison nnz so that, after the
+        // all-reduce, EVERY rank takes the same "grow the list and redo" exit
+        if (threadIdx.x == 0 &&
+            (st->cnt[2 * LIST_XY + 1] | st->cnt[2 * LIST_XX + 1] | st->cnt[2 * LIST_YY + 1]))
+            st->red[8] = __builtin_nan("");
     }
     if ((a.flags & POST_MATH) && threadIdx.x == 0) {
+        // nothing of an overflowed iteration is usable; the host enlarges the
+        // list and resumes from the same (untouched) state
+        if (st->red[8] != st->red[8]) {
+            st->done = NEED_BIGGER_LIST;
+            return;
+        }
         const double *red = st->red;
         float omega[3], v[3];
         for (int q = 0; q < 3; ++q) {
@@ -329,7 +489,7 @@ __global__ void __launch_bounds__(BLOCK) k_post_flow(const PostFlowArgs a)
         double dl = 0.0;
         const long long nnz = (long long)red[8];
         long long nnz_xx = 0, nnz_yy = 0;
-        if (a.prm.mode == CVO_HIP_MODE_ACVO) {   // ref src/adaptive_cvo.cpp:222-231,271
+        if (acvo) {   // ref src/adaptive_cvo.cpp:222-231,271
             nnz_xx = (long long)red[RED_XX + 1];
             nnz_yy = (long long)red[RED_YY + 1];
             const double num = (red[RED_YY] - 2.0 * red[7]) + red[RED_XX];
@@ -358,8 +518,11 @@ __global__ void __launch_bounds__(BLOCK) k_post_step(const PostStepArgs a)
     DevState *st = a.st;
     if (a.check_done && st->done != 0) return;
     if (a.flags & POST_REDUCE)
-        block_reduce_partials<NACC_STEP>(a.part_step, a.nb_step, sh, st->red + RED_STEP);
-    if (!((a.flags & POST_MATH) && threadIdx.x == 0)) return;
+        block_reduce_partials<NACC_STEP>(a.part_step, PROC_BLOCKS, sh, st->red + RED_STEP);
+    if (!(a.flags & POST_MATH)) return;
+    // the lists of this iteration have been consumed: empty them for the next one
+    for (int q = threadIdx.x; q < LIST_N * NSUB; q += BLOCK) (&st->sub[0][0])[q] = 0u;
+    if (threadIdx.x != 0) return;
 
     const DevParams &p = a.prm;
     const bool acvo = p.mode == CVO_HIP_MODE_ACVO;
@@ -392,7 +555,7 @@ __global__ void __launch_bounds__(BLOCK) k_post_step(const PostStepArgs a)
     }
     if (brk) {
         st->iter = k;
-        st->done = 1;
+        st->done = DONE_BREAK_A;
         if (tr) tr->exit_code = 1;
         return;
     }
@@ -410,7 +573,7 @@ __global__ void __launch_bounds__(BLOCK) k_post_step(const PostStepArgs a)
     if (tr) tr->dist = dist;
     if (dist < p.eps_2) {   // break B
         st->iter = k;
-        st->done = 2;
+        st->done = DONE_BREAK_B;
         if (tr) tr->exit_code = 2;
         return;
     }
@@ -431,7 +594,7 @@ __global__ void __launch_bounds__(BLOCK) k_post_step(const PostStepArgs a)
     st->ell = ell;
     st->k = k + 1;
     if (k + 1 >= p.max_iter) {
-        st->done = 3;   // MAX_ITER exhausted: `iter` keeps its stale value
+        st->done = DONE_MAX_ITER;   // `iter` keeps its stale value
         return;
     }
     prepare_iteration(st, p);
@@ -439,12 +602,13 @@ __global__ void __launch_bounds__(BLOCK) k_post_step(const PostStepArgs a)
 
 __global__ void k_prepare(DevState *st, const DevParams prm)
 {
-    if (threadIdx.x == 0 && blockIdx.x == 0) prepare_iteration(st, prm);
+    for (int q = threadIdx.x; q < LIST_N * NSUB; q += BLOCK) (&st->sub[0][0])[q] = 0u;
+    if (threadIdx.x == 0) prepare_iteration(st, prm);
 }
 
 void launch_prepare(DevState *st, const DevParams &prm, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_prepare, dim3(1), dim3(64), 0, s, st, prm);
+    hipLaunchKernelGGL(k_prepare, dim3(1), dim3(BLOCK), 0, s, st, prm);
 }
 
 void launch_post_flow(const PostFlowArgs &a, hipStream_t s)

@@ -724,6 +724,7 @@ static double cubic_eval(double a, double b, double c, double s)
 static double bisect_root(double a, double b, double c, double lo, double hi, int increasing)
 {
     for (int it = 0; it < 1200; ++it) {
+        if ((float)lo == (float)hi) break;   // the root's float value is decided
         const double mid = lo + (hi - lo) * 0.5;
         if (!(mid > lo && mid < hi)) break;
         const double f = cubic_eval(a, b, c, mid);
@@ -805,26 +806,26 @@ static void sincos_det(double x, double *s_out, double *c_out)
     const double r = (x - kd * pio2_hi) - kd * pio2_lo;
     const double r2 = r * r;
     double ps = 1.0;
-    ps = 1.0 - r2 / (18.0 * 19.0) * ps;
-    ps = 1.0 - r2 / (16.0 * 17.0) * ps;
-    ps = 1.0 - r2 / (14.0 * 15.0) * ps;
-    ps = 1.0 - r2 / (12.0 * 13.0) * ps;
-    ps = 1.0 - r2 / (10.0 * 11.0) * ps;
-    ps = 1.0 - r2 / (8.0 * 9.0) * ps;
-    ps = 1.0 - r2 / (6.0 * 7.0) * ps;
-    ps = 1.0 - r2 / (4.0 * 5.0) * ps;
-    ps = 1.0 - r2 / (2.0 * 3.0) * ps;
+    ps = 1.0 - r2 * (1.0 / (18.0 * 19.0)) * ps;
+    ps = 1.0 - r2 * (1.0 / (16.0 * 17.0)) * ps;
+    ps = 1.0 - r2 * (1.0 / (14.0 * 15.0)) * ps;
+    ps = 1.0 - r2 * (1.0 / (12.0 * 13.0)) * ps;
+    ps = 1.0 - r2 * (1.0 / (10.0 * 11.0)) * ps;
+    ps = 1.0 - r2 * (1.0 / (8.0 * 9.0)) * ps;
+    ps = 1.0 - r2 * (1.0 / (6.0 * 7.0)) * ps;
+    ps = 1.0 - r2 * (1.0 / (4.0 * 5.0)) * ps;
+    ps = 1.0 - r2 * (1.0 / (2.0 * 3.0)) * ps;
     const double sr = r * ps;
     double pc = 1.0;
-    pc = 1.0 - r2 / (17.0 * 18.0) * pc;
-    pc = 1.0 - r2 / (15.0 * 16.0) * pc;
-    pc = 1.0 - r2 / (13.0 * 14.0) * pc;
-    pc = 1.0 - r2 / (11.0 * 12.0) * pc;
-    pc = 1.0 - r2 / (9.0 * 10.0) * pc;
-    pc = 1.0 - r2 / (7.0 * 8.0) * pc;
-    pc = 1.0 - r2 / (5.0 * 6.0) * pc;
-    pc = 1.0 - r2 / (3.0 * 4.0) * pc;
-    pc = 1.0 - r2 / (1.0 * 2.0) * pc;
+    pc = 1.0 - r2 * (1.0 / (17.0 * 18.0)) * pc;
+    pc = 1.0 - r2 * (1.0 / (15.0 * 16.0)) * pc;
+    pc = 1.0 - r2 * (1.0 / (13.0 * 14.0)) * pc;
+    pc = 1.0 - r2 * (1.0 / (11.0 * 12.0)) * pc;
+    pc = 1.0 - r2 * (1.0 / (9.0 * 10.0)) * pc;
+    pc = 1.0 - r2 * (1.0 / (7.0 * 8.0)) * pc;
+    pc = 1.0 - r2 * (1.0 / (5.0 * 6.0)) * pc;
+    pc = 1.0 - r2 * (1.0 / (3.0 * 4.0)) * pc;
+    pc = 1.0 - r2 * (1.0 / (1.0 * 2.0)) * pc;
     const double cr = pc;
     const double q4 = kd - 4.0 * floor(kd * 0.25);
     double sn, cs;

@@ -1,0 +1,117 @@
+// filter_probe.hip -- where does a k_filter block spend its time?
+// Includes the production kernel source and runs it on a synthetic cloud pair
+// with per-wave s_memtime stamps (FilterArgs::dbg).
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -I../../include
+//        -I../../cvo-rgbd_amd/csrc filter_probe.hip -o filter_probe
+#include "../../cvo-rgbd_amd/csrc/cvo_kernels.hip"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <random>
+#include <vector>
+
+using namespace cvo_dev;
+
+int main(int argc, char **argv)
+{
+    const int n = argc > 1 ? atoi(argv[1]) : 10000;
+    const float ell = argc > 2 ? atof(argv[2]) : 0.03f;
+    const int jt = argc > 3 ? atoi(argv[3]) : 400;
+    std::mt19937 rng(1);
+    std::uniform_real_distribution<float> U(-0.78f, 0.78f);
+    std::vector<float4> ha(n), hb(n);
+    auto surf = [&](float x, float y) { return 1.3f + 0.25f * sinf(2.1f * x + 0.3f) * cosf(1.7f * y) + 0.15f * sinf(4.3f * y); };
+    for (auto *v : {&ha, &hb}) {
+        for (int i = 0; i < n; ++i) { float x = U(rng), y = U(rng); (*v)[i] = make_float4(x, y, surf(x, y), 0.f); }
+        // crude spatial sort (by cell) so that tiles are compact like the Morton order
+        std::sort(v->begin(), v->end(), [](const float4 &p, const float4 &q) {
+            int cp = (int)((p.x + 0.8f) * 10) * 16 + (int)((p.y + 0.8f) * 10), cq = (int)((q.x + 0.8f) * 10) * 16 + (int)((q.y + 0.8f) * 10);
+            return cp < cq; });
+    }
+    float4 *da, *db; DevState *st; uint2 *cand; long long *dbg;
+    hipMalloc(&da, n * sizeof(float4)); hipMalloc(&db, n * sizeof(float4));
+    hipMemcpy(da, ha.data(), n * sizeof(float4), hipMemcpyHostToDevice);
+    hipMemcpy(db, hb.data(), n * sizeof(float4), hipMemcpyHostToDevice);
+    DevState h{}; h.R[0] = h.R[4] = h.R[8] = 1.f; h.ell = ell; h.center[2] = 1.3f; h.xmax = h.y0max = 1.3f;
+    DevParams prm{}; prm.c = prm.d = 7.f; prm.c_ell = 200.f; prm.log_sp_s2 = logf(0.8f); prm.tau_c = 1e9f;
+    prepare_iteration(&h, prm);
+    hipMalloc(&st, sizeof(DevState)); hipMemcpy(st, &h, sizeof(h), hipMemcpyHostToDevice);
+    const uint32_t subcap = 1u << 16;
+    hipMalloc(&cand, (size_t)subcap * NSUB * sizeof(uint2));
+    const int tiles = (n + ROWS_PER_TILE - 1) / ROWS_PER_TILE, chunks = (n + jt - 1) / jt;
+    const size_t nw = (size_t)tiles * chunks * 4;
+    hipMalloc(&dbg, nw * 8 * sizeof(long long));
+    FilterArgs a{}; a.pos_a = da; a.pos_b = db; a.st = st; a.cand = cand; a.subcap = subcap; a.list = LIST_XY;
+    a.row_lo = 0; a.row_hi = n; a.nb = n; a.jt = jt; a.tf_a = 0; a.tf_b = 1; a.check_done = 1; a.dbg = dbg;
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int rep = 0; rep < 3; ++rep) {
+        hipMemset(&st->sub[0][0], 0, sizeof(h.sub)); hipMemset(st->cnt, 0, sizeof(h.cnt));
+        hipDeviceSynchronize();
+        hipEventRecord(e0);
+        launch_filter(a, dim3(chunks, tiles), 0);
+        hipEventRecord(e1);
+        hipDeviceSynchronize();
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        std::vector<long long> hd(nw * 8);
+        hipMemcpy(hd.data(), dbg, hd.size() * sizeof(long long), hipMemcpyDeviceToHost);
+        hipMemcpy(&h, st, sizeof(h), hipMemcpyDeviceToHost);
+        unsigned long long tot = 0; for (int q = 0; q < NSUB; ++q) tot += h.sub[0][q];
+        long long tmin = hd[0], tmax = 0; double pro = 0, loop = 0, tail = 0, life = 0;
+        for (size_t w = 0; w < nw; ++w) {
+            const long long *o = &hd[w * 8];
+            tmin = std::min(tmin, o[0]); tmax = std::max(tmax, o[3]);
+            pro += o[1] - o[0]; loop += o[2] - o[1]; tail += o[3] - o[2]; life += o[3] - o[0];
+        }
+        // when did waves start relative to the first one?
+        std::vector<long long> starts(nw); for (size_t w = 0; w < nw; ++w) starts[w] = hd[w * 8] - tmin;
+        std::sort(starts.begin(), starts.end());
+        if (rep == 2) {   // census: concurrency per CU from the stamps (clocks agree inside an XCD)
+            struct W { long long s, e; int cu; };
+            std::vector<W> ws(nw);
+            for (size_t w = 0; w < nw; ++w) {
+                const long long *o = &hd[w * 8];
+                const int hw = (int)o[4], xcc = (int)o[5] & 15;
+                const int cu = (hw >> 8) & 15, sh = (hw >> 12) & 1, se = (hw >> 13) & 7;
+                ws[w] = {o[0], o[3], ((xcc * 8 + se) * 2 + sh) * 16 + cu};
+            }
+            int maxcu = 0; for (auto &w : ws) maxcu = std::max(maxcu, w.cu);
+            std::vector<int> cnt(maxcu + 1, 0), peak(maxcu + 1, 0);
+            std::vector<long long> first(maxcu + 1, (long long)9e18), last(maxcu + 1, 0);
+            for (auto &w : ws) { cnt[w.cu]++; first[w.cu] = std::min(first[w.cu], w.s); last[w.cu] = std::max(last[w.cu], w.e); }
+            for (int c = 0; c <= maxcu; ++c) {
+                if (!cnt[c]) continue;
+                std::vector<std::pair<long long,int>> ev;
+                for (auto &w : ws) if (w.cu == c) { ev.push_back({w.s, 1}); ev.push_back({w.e, -1}); }
+                std::sort(ev.begin(), ev.end());
+                int cur = 0; for (auto &e : ev) { cur += e.second; peak[c] = std::max(peak[c], cur); }
+            }
+            {   // per XCD: when do waves start / end relative to the first start on that XCD
+                for (int x = 0; x < 8; ++x) {
+                    std::vector<long long> st_, en_;
+                    for (size_t w = 0; w < nw; ++w) { const long long *o = &hd[w * 8]; if (((int)o[5] & 15) == x) { st_.push_back(o[0]); en_.push_back(o[3]); } }
+                    if (st_.empty()) continue;
+                    std::sort(st_.begin(), st_.end()); std::sort(en_.begin(), en_.end());
+                    const long long t0 = st_[0];
+                    printf("xcd %d: %zu waves; start p50 %lld p90 %lld max %lld | end min %lld p50 %lld max %lld ticks\n", x, st_.size(),
+                           st_[st_.size() / 2] - t0, st_[st_.size() * 9 / 10] - t0, st_.back() - t0, en_[0] - t0, en_[en_.size() / 2] - t0, en_.back() - t0);
+                }
+            }
+            {   double dm = 0, dw = 0; long long wmin = (long long)9e18, wmax = 0;
+                for (size_t w = 0; w < nw; ++w) { const long long *o = &hd[w * 8]; dm += o[3] - o[0]; dw += o[7] - o[6]; wmin = std::min(wmin, o[6]); wmax = std::max(wmax, o[7]); }
+                std::vector<long long> ws_, we_; for (size_t w = 0; w < nw; ++w) { ws_.push_back(hd[w * 8 + 6] - wmin); we_.push_back(hd[w * 8 + 7] - wmin); }
+                std::sort(ws_.begin(), ws_.end()); std::sort(we_.begin(), we_.end());
+                printf("wave START (10 ns units): p10 %lld p50 %lld p90 %lld max %lld | wave END: min %lld p10 %lld p50 %lld p90 %lld max %lld\n",
+                       ws_[nw / 10], ws_[nw / 2], ws_[nw * 9 / 10], ws_[nw - 1], we_[0], we_[nw / 10], we_[nw / 2], we_[nw * 9 / 10], we_[nw - 1]);
+                printf("shader clock during the kernel: %.0f MHz; first wave start -> last wave end: %.2f us (100 MHz wall clock)\n", dm / dw * 100.0, (wmax - wmin) / 100.0);
+            }
+            int used = 0; double avgw = 0, avgpeak = 0, avgspan = 0;
+            for (int c = 0; c <= maxcu; ++c) if (cnt[c]) { used++; avgw += cnt[c]; avgpeak += peak[c]; avgspan += last[c] - first[c]; }
+            printf("census: %d CU ids used, waves/CU avg %.1f, peak concurrent waves/CU avg %.1f, CU busy span avg %.0f ticks\n", used, avgw / used, avgpeak / used, avgspan / used);
+        }
+        printf("n %d ell %.2f jt %d grid %dx%d: kernel %.1f us, first start -> last exit %lld ticks, per wave: prologue %.0f loop %.0f tail %.0f life %.0f ticks; start p50 %lld p90 %lld max %lld; candidates %llu ovf %u\n",
+               n, ell, jt, chunks, tiles, ms * 1e3, tmax - tmin, pro / nw, loop / nw, tail / nw, life / nw,
+               starts[nw / 2], starts[nw * 9 / 10], starts[nw - 1], tot, h.cnt[1]);
+    }
+    return 0;
+}
