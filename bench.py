@@ -122,9 +122,11 @@ def main():
 
     out = None
     if rank == 0:
-        launches = prof["flow_launches"] + prof["step_launches"]
-        sweep_ms = (prof["flow_ms"] + prof["step_ms"]) / max(launches, 1)
-        pairs = (prof["flow_pairs"] + prof["step_pairs"]) / max(launches, 1)
+        # the dominant kernel: k_filter on the (fixed x moving) pair set, one launch
+        # per executed iteration, bracketed by HIP events on the context's stream
+        launches = prof["flow_launches"]
+        sweep_ms = prof["flow_ms"] / max(launches, 1)
+        pairs = prof["flow_pairs"] / max(launches, 1)
         achieved = FLOP_PER_PAIR * pairs / (sweep_ms * 1e-3) / 1e12 if sweep_ms > 0 else 0.0
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
@@ -159,9 +161,9 @@ def main():
             "ms_per_iteration": elapsed * 1e3 * world / max(float(it_sum.item()), 1.0),
             "gt_motion_rel_err": {"rot": rot_err, "trans": tr_err},
             "roofline": {
-                "kernel": "k_sweep<FLOW|STEP> (all-pairs distance test + compacted survivors)",
+                "kernel": "cvo_dev::k_filter (all target x source pair tests, v_mfma_f32_16x16x4_f32)",
                 "bound": "mfma",
-                "pipe": "fp32 VALU issue (f32 MFMA peak == f32 vector peak on gfx950)",
+                "pipe": "f32 MFMA issue (f32 MFMA peak == f32 vector peak on gfx950)",
                 "achieved": achieved,
                 "peak": PEAK_F32_TFLOPS,
                 "unit": "TFLOP/s",
@@ -236,8 +238,24 @@ def cpu_baseline(args, pkg, xf, ff, xm, fm, acvo):
     host cores of this box on a bounded sample of the same workload."""
     from oracle import pyoracle as po
     p = po.default_params(po.MODE_ACVO if acvo else po.MODE_CVO)
+    # the restatement's OpenMP regions are short: more threads than it can feed
+    # make it slower, so calibrate the thread count on one registration each
     po.set_threads(0)
-    cores = po.get_threads()
+    ncpu = po.get_threads()
+    best, cores = None, 1
+    for nt in sorted({1, 8, 16, 32, 64, ncpu}):
+        if nt > ncpu:
+            continue
+        po.set_threads(nt)
+        t0 = time.perf_counter()
+        st = po.init_state(p)
+        po.align(p, st, xf, ff, xm, fm, search=po.SEARCH_GRID, trace_cap=1)
+        dt = time.perf_counter() - t0
+        if best is None or dt < best:
+            best, cores = dt, nt
+        if dt > 4 * best:
+            break
+    po.set_threads(cores)
     done, iters = 0, 0
     t0 = time.perf_counter()
     while True:

@@ -1,0 +1,75 @@
+"""CPU: the C-ABI library loads and exports every symbol include/cvo_hip.h
+declares (no device compute is attempted without a GPU)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "cvo_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    names = set(re.findall(r"\b(cvo_hip_[a-z0-9_]+)\s*\(", text))
+    names -= {"cvo_hip_allreduce_fn"}
+    return sorted(names)
+
+
+def test_header_and_binding_agree(pkg):
+    assert sorted(pkg.capi.SYMBOLS) == _declared_symbols()
+
+
+def test_library_exports_every_declared_symbol(pkg):
+    assert os.path.exists(pkg.capi.LIB_PATH), "run __graft_entry__.build() first"
+    lib = ctypes.CDLL(pkg.capi.LIB_PATH)
+    for name in _declared_symbols():
+        assert hasattr(lib, name), "libcvo_hip.so does not export %s" % name
+
+
+def test_params_and_state_defaults(pkg):
+    """Constructor initialisers of the reference (cvo.cpp:18-48, adaptive_cvo.cpp:18-50)."""
+    capi = pkg.capi
+    p = capi.default_params(capi.MODE_CVO)
+    assert (p.max_iter, p.c, p.d) == (2000, 7.0, 7.0)
+    assert p.ell_init == pytest.approx(0.15) and p.sp_thres == pytest.approx(8e-3)
+    assert p.c_ell == 200.0 and p.eps == pytest.approx(5e-5) and p.eps_2 == pytest.approx(1e-5)
+    q = capi.default_params(capi.MODE_ACVO)
+    assert q.ell_init == pytest.approx(0.1) and q.ell_min == pytest.approx(0.0391)
+    assert q.sp_thres == pytest.approx(8.315e-3) and q.c_ell == 0.5 and q.dl_step == 0.3
+    s = capi.init_state(p)
+    assert list(s.R) == [1, 0, 0, 0, 1, 0, 0, 0, 1] and list(s.T) == [0, 0, 0]
+    assert s.ell == p.ell_init and list(s.accum_transform)[::5] == [1, 1, 1, 1]
+
+
+def test_error_strings_and_argument_checks(pkg):
+    capi = pkg.capi
+    L = capi.lib()
+    assert L.cvo_hip_error_string(0) == b"ok"
+    assert b"invalid" in L.cvo_hip_error_string(-1)
+    assert L.cvo_hip_default_params(7, ctypes.byref(capi.Params())) == -1
+    assert capi.shard_range(10, 0, 3) == (0, 3) and capi.shard_range(10, 2, 3) == (6, 10)
+
+
+def test_no_cpu_fallback(pkg):
+    """Without a visible GPU, creating a context must fail loudly."""
+    capi = pkg.capi
+    if capi.device_count() > 0:
+        pytest.skip("a GPU is visible")
+    with pytest.raises(capi.CvoHipError):
+        capi.Context(mode=capi.MODE_CVO)
+
+
+def test_product_does_not_import_the_oracle():
+    """The oracle is test infrastructure: nothing under the product package or
+    include/ may mention it."""
+    bad = []
+    for base in ("cvo-rgbd_amd", "include"):
+        for dp, _, files in os.walk(os.path.join(ROOT, base)):
+            for f in files:
+                if f.endswith((".py", ".cpp", ".hip", ".h", ".hpp")) or f == "Makefile":
+                    txt = open(os.path.join(dp, f), errors="ignore").read()
+                    if re.search(r"(^|[^A-Za-z_])(import oracle|from oracle|liboracle|cvo_oracle)", txt):
+                        bad.append(os.path.join(dp, f))
+    assert not bad, bad

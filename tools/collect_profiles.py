@@ -1,0 +1,70 @@
+#!/usr/bin/env python3
+"""Copies the judged summaries of a gpurun profile run (tools/gpu_profile.sh) from
+gpurun_out/<tag>/ into profiles/ and derives profiles/pmc_traffic.json
+(HBM bytes per k_filter launch, corrected as MI355X_MICROARCH.md prescribes)."""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+src = os.path.join(ROOT, "gpurun_out", tag)
+dst = os.path.join(ROOT, "profiles")
+os.makedirs(dst, exist_ok=True)
+
+
+def one(pattern):
+    g = glob.glob(os.path.join(src, pattern))
+    return g[0] if g else None
+
+
+for pat, name in (("bench.json", "%s_bench.json"), ("stats/*kernel_stats.csv", "%s_kernel_stats.csv")):
+    f = one(pat)
+    if f:
+        shutil.copy(f, os.path.join(dst, name % tag))
+
+
+def counters(pattern):
+    f = one(pattern)
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    if not f:
+        return agg
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"].split("(")[0].replace("cvo_dev::", "").replace("void ", "")
+        agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    return agg
+
+
+summary = {}
+for pat in ("pmc_fetch/*counter_collection.csv", "pmc_write/*counter_collection.csv",
+            "pmc_sq/*counter_collection.csv", "pmc_lds/*counter_collection.csv"):
+    for k, d in counters(pat).items():
+        for c, v in d.items():
+            # launches queued past convergence return at once: keep the executed ones
+            vv = sorted(v)
+            real = [x for x in vv if x > 0.05 * vv[-1]] if vv[-1] > 0 else vv
+            summary.setdefault(k, {})[c] = {"launches": len(v), "executed": len(real),
+                                            "avg": sum(real) / max(len(real), 1), "max": vv[-1]}
+with open(os.path.join(dst, "%s_pmc_summary.json" % tag), "w") as fh:
+    json.dump(summary, fh, indent=1, sort_keys=True)
+
+kf = summary.get("k_filter", {})
+if "FETCH_SIZE" in kf:
+    fetch_kb = kf["FETCH_SIZE"]["avg"]
+    write_kb = kf.get("WRITE_SIZE", {}).get("avg", 0.0)
+    traffic = {
+        "kernel": "cvo_dev::k_filter",
+        "FETCH_SIZE_KB_per_launch": fetch_kb,
+        "WRITE_SIZE_KB_per_launch": write_kb,
+        "note": "FETCH_SIZE is reported in KB and, on gfx950, at 1/2 of the bytes of wide coalesced "
+                "reads (MI355X_MICROARCH.md, HBM): doubled here; WRITE_SIZE taken as is",
+        "hbm_bytes_per_launch": 2.0 * fetch_kb * 1024.0 + write_kb * 1024.0,
+    }
+    with open(os.path.join(dst, "pmc_traffic.json"), "w") as fh:
+        json.dump(traffic, fh, indent=1)
+    print(traffic)
+print("profiles written:", sorted(os.listdir(dst)))

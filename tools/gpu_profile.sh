@@ -1,6 +1,7 @@
 #!/bin/bash
-# Runs on the GPU box (via gpurun): bench + rocprofv3 kernel stats + PMC traffic.
-# Outputs under gpurun_out/<tag>/ ; copy what should be judged into profiles/.
+# Runs on the GPU box (via gpurun): bench + rocprofv3 kernel stats + PMC passes.
+# Outputs under gpurun_out/<tag>/ ; tools/collect_profiles.py copies the summaries
+# that should be judged into profiles/.
 TAG=${1:-r01}
 ROOTDIR=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOTDIR/gpurun_out/$TAG
@@ -9,9 +10,12 @@ cd $ROOTDIR
 python bench.py --steps 20 --warmup 3 > $OUT/bench.json 2> $OUT/bench.err
 tail -1 $OUT/bench.json
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d $OUT/stats -o stats -- python $ROOTDIR/bench.py --steps 5 --warmup 1 --no-cpu > $OUT/stats.log 2>&1
-rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc_fetch -o fetch -- python $ROOTDIR/bench.py --steps 2 --warmup 1 --no-cpu > $OUT/pmc_fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE -d $OUT/pmc_write -o write -- python $ROOTDIR/bench.py --steps 2 --warmup 1 --no-cpu > $OUT/pmc_write.log 2>&1
-rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY -d $OUT/pmc_sq -o sq -- python $ROOTDIR/bench.py --steps 2 --warmup 1 --no-cpu > $OUT/pmc_sq.log 2>&1
-find $OUT -name "*.csv" | head -20
-find $OUT -name "*kernel_stats*" -exec head -12 {} \;
+B="python $ROOTDIR/bench.py --steps 5 --warmup 1 --no-cpu"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o stats -- $B > $OUT/stats.log 2>&1
+# PMC passes: counters only (gpurun refuses --pmc together with the trace domains)
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o fetch -- $B > $OUT/pmc_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o write -- $B > $OUT/pmc_write.log 2>&1
+rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_sq -o sq -- $B > $OUT/pmc_sq.log 2>&1
+rocprofv3 --pmc SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU SQ_INSTS_VMEM SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS --output-format csv -d $OUT/pmc_lds -o lds -- $B > $OUT/pmc_lds.log 2>&1
+find $OUT -name "*.csv" | head -30
+head -12 $OUT/stats/*kernel_stats.csv
