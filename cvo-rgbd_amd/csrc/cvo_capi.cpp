@@ -56,10 +56,9 @@ struct DevBuf {   // a growable device array
     size_t bytes = 0;
 };
 
-struct CandList {
-    DevBuf cand;   // uint2[cap]
-    DevBuf aval;   // float[cap]   (LIST_XY only)
-    uint32_t cap = 0;
+struct List {     // LIST_XY/XX/YY: TileEntry[cap] in a; LIST_KEPT: uint2[cap] in a, float[cap] in b
+    DevBuf a, b;
+    uint32_t cap = 0;   // entries, a multiple of NSUB
 };
 
 constexpr int kBatch = 8;        // iterations enqueued between two polls
@@ -78,7 +77,7 @@ struct cvo_hip_ctx {
     DevState *st_host = nullptr;     // pinned [kPollSlots + 1]
     hipEvent_t poll_ev[kPollSlots]{};
     DevBuf part_flow, part_xx, part_yy, part_step;   // [PROC_BLOCKS][NACC_MAX] float64
-    CandList lists[LIST_N];
+    List lists[LIST_N];
     cvo_hip_trace *trace_dev = nullptr;
     int trace_dev_cap = 0;
     bool have_tf = false;
@@ -248,26 +247,38 @@ int ensure_buf(cvo_hip_ctx *ctx, DevBuf &b, size_t bytes)
     return CVO_HIP_OK;
 }
 
-// Candidate-list capacity: never more than all pairs; by default room for 4 %
-// of them (the filter passes ~1.5 % at the widest length-scale on surface-like
-// clouds) and at least 1 Mi entries.  align() grows it on demand.
-int ensure_list(cvo_hip_ctx *ctx, int list, int nrows, int nb, uint32_t at_least)
+// List capacities (entries).  Tile lists: there are at most ceil(rows/16) *
+// ceil(cols/16) tiles; room for all of them (x2, the sub-lists fill unevenly)
+// when that is small, else a quarter.  Kept list: 4 % of all pairs (the widest
+// length-scale keeps ~1.2 % on surface-like clouds), at least 1 Mi.  align()
+// grows a list that overflows and redoes the iteration.
+int ensure_list(cvo_hip_ctx *ctx, int list, int nrows, int nb, double at_least)
 {
-    CandList &L = ctx->lists[list];
-    const double all = (double)std::max(nrows, 0) * (double)std::max(nb, 0);
-    double want = std::max(all * 0.04, 1048576.0);
-    want = std::max(want, (double)at_least);
-    want = std::min(want, std::max(all, 64.0));
-    want = std::min(want, 4.0e9);
-    // NSUB equal sub-lists; each must hold at least one full wave flush
-    const uint32_t cap = std::max<uint32_t>(((uint32_t)want + NSUB - 1) / NSUB, 128u) * NSUB;
-    if (cap <= L.cap) return CVO_HIP_OK;
-    int rc = ensure_buf(ctx, L.cand, (size_t)cap * sizeof(uint2));
-    if (rc) return rc;
-    if (list == LIST_XY) {
-        rc = ensure_buf(ctx, L.aval, (size_t)cap * sizeof(float));
-        if (rc) return rc;
+    List &L = ctx->lists[list];
+    double want;
+    uint32_t min_sub;
+    if (list == LIST_KEPT) {
+        const double all = (double)std::max(nrows, 0) * (double)std::max(nb, 0);
+        want = std::max(all * 0.04, 1048576.0);
+        want = std::min(want, std::max(all * 1.25, 1.0));
+        min_sub = KEPT_STAGE;
+    } else {
+        const double all = std::ceil(std::max(nrows, 0) / 16.0 + 1.0) * std::ceil(std::max(nb, 0) / 16.0 + 1.0);
+        want = (all * 2.0 * sizeof(TileEntry) <= 64.0e6) ? all * 2.0 : std::max(all * 0.25, 64.0e6 / sizeof(TileEntry));
+        min_sub = TILE_STAGE;
     }
+    want = std::max(want, at_least);
+    want = std::min(want, 4.0e9);
+    const uint32_t cap = std::max<uint32_t>((uint32_t)((want + NSUB - 1) / NSUB), min_sub) * NSUB;
+    if (cap <= L.cap) return CVO_HIP_OK;
+    int rc;
+    if (list == LIST_KEPT) {
+        rc = ensure_buf(ctx, L.a, (size_t)cap * sizeof(uint2));
+        if (!rc) rc = ensure_buf(ctx, L.b, (size_t)cap * sizeof(float));
+    } else {
+        rc = ensure_buf(ctx, L.a, (size_t)cap * sizeof(TileEntry));
+    }
+    if (rc) return rc;
     L.cap = cap;
     return CVO_HIP_OK;
 }
@@ -315,7 +326,7 @@ int enqueue_filter(cvo_hip_ctx *ctx, int list, const float4 *pos_a, int row_lo, 
     FilterArgs a{};
     a.pos_a = pos_a; a.pos_b = pos_b;
     a.st = ctx->st;
-    a.cand = (uint2 *)ctx->lists[list].cand.p;
+    a.tiles = (TileEntry *)ctx->lists[list].a.p;
     a.subcap = ctx->lists[list].cap / NSUB;
     a.list = list;
     a.row_lo = row_lo; a.row_hi = row_hi;
@@ -346,16 +357,23 @@ int enqueue_process(cvo_hip_ctx *ctx, int mode, int list, DevBuf &part, const fl
 {
     int rc = ensure_buf(ctx, part, (size_t)PROC_BLOCKS * NACC_MAX * sizeof(double));
     if (rc) return rc;
-    rc = ensure_list(ctx, list, 0, 0, 64);   // an (empty) list object must exist
+    rc = ensure_list(ctx, list, 0, 0, 0);   // an (empty) list object must exist
+    if (rc) return rc;
+    if (mode == PROC_FLOW)   // the kept list is sized from the pair set this pass evaluates
+        rc = ensure_list(ctx, LIST_KEPT, ctx->fixed.n, ctx->moving.n, 0);
+    else
+        rc = ensure_list(ctx, LIST_KEPT, 0, 0, 0);
     if (rc) return rc;
     ProcessArgs a{};
     a.pos_a = pos_a; a.feat_a = feat_a;
     a.pos_b = pos_b; a.feat_b = feat_b;
-    a.cand = (const uint2 *)ctx->lists[list].cand.p;
-    a.aval = (float *)ctx->lists[LIST_XY].aval.p;
+    a.tiles = (const TileEntry *)ctx->lists[list].a.p;
+    a.kept_ij = (uint2 *)ctx->lists[LIST_KEPT].a.p;
+    a.kept_a = (float *)ctx->lists[LIST_KEPT].b.p;
     a.partials = (double *)part.p;
     a.st = ctx->st;
     a.subcap = ctx->lists[list].cap / NSUB;
+    a.kept_subcap = ctx->lists[LIST_KEPT].cap / NSUB;
     a.list = list;
     a.first_counted = first_counted;
     a.tf_a = tf_a; a.tf_b = tf_b;
@@ -507,7 +525,7 @@ int check_overflow_and_grow(cvo_hip_ctx *ctx, bool *redo)
             for (int q = 0; q < NSUB; ++q) worst = std::max(worst, h->sub[l][q]);
             const double need = std::max((double)worst * NSUB, (double)ctx->lists[l].cap);
             const double grown = std::min(4.0e9, need * 1.25 + 1024.0);
-            int rc = ensure_list(ctx, l, 1 << 30, 4, (uint32_t)grown);
+            int rc = ensure_list(ctx, l, 0, 0, grown);
             if (rc) return rc;
             *redo = true;
         }
@@ -668,8 +686,8 @@ int cvo_hip_destroy(cvo_hip_ctx *ctx)
     for (void *p : {(void *)ctx->fixed.pos, (void *)ctx->fixed.feat, (void *)ctx->moving.pos,
                     (void *)ctx->moving.feat, (void *)ctx->st, ctx->part_flow.p, ctx->part_xx.p,
                     ctx->part_yy.p, ctx->part_step.p, (void *)ctx->trace_dev,
-                    ctx->lists[0].cand.p, ctx->lists[0].aval.p, ctx->lists[1].cand.p,
-                    ctx->lists[1].aval.p, ctx->lists[2].cand.p, ctx->lists[2].aval.p})
+                    ctx->lists[0].a.p, ctx->lists[1].a.p, ctx->lists[2].a.p, ctx->lists[3].a.p,
+                    ctx->lists[3].b.p})
         if (p) (void)hipFree(p);
     if (ctx->st_host) (void)hipHostFree(ctx->st_host);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -937,7 +955,7 @@ int cvo_hip_align(cvo_hip_ctx *ctx, cvo_hip_state *s, cvo_hip_trace *trace, int 
                 uint32_t worst = 0;
                 for (int q = 0; q < NSUB; ++q) { tot += cur.sub[l][q]; worst = std::max(worst, cur.sub[l][q]); }
                 const double grown = std::min(4.0e9, std::max((double)worst * NSUB, (double)ctx->lists[l].cap) * 1.5 + 1024.0);
-                rc = ensure_list(ctx, l, 1 << 30, 4, (uint32_t)grown);
+                rc = ensure_list(ctx, l, 0, 0, grown);
             }
         if (rc) break;
         int32_t zero = 0;

@@ -26,23 +26,39 @@ constexpr int BLOCK = 256;
 constexpr int TILES_PER_WAVE = 4;
 constexpr int ROWS_PER_WAVE = 16 * TILES_PER_WAVE;
 constexpr int ROWS_PER_TILE = 4 * ROWS_PER_WAVE;   // rows per block
-// Candidates are staged in a per-wave LDS queue and leave for HBM in chunks of
-// CHUNK entries: one returning atomic per chunk, and the reservation for the
-// next chunk is issued one chunk ahead so that its ~2 us round trip is hidden.
-constexpr int CHUNK = 256;   // entries per HBM reservation
-constexpr int QCAP = CHUNK + 64;    // per-wave candidate queue entries
-constexpr uint32_t HOLE = 0xffffffffu;   // row id of an unused slot of a reserved chunk
 constexpr float PAD_BIG = 1.0e30f;  // filter value of padded rows / columns
-constexpr int PROC_BLOCKS = 1024;   // grid of the candidate-list kernels
-// A candidate list is NSUB independent sub-lists (own counter, own slice of the
-// buffer): one hot atomic counter saturates near 90 appends/us on this chip
-// (MI355X_MICROARCH "dequeue"), 256 of them do not.  Waves scatter their
-// 64-entry flushes over the sub-lists round-robin, which also balances them.
+constexpr int PROC_BLOCKS = 1024;   // grid of the list kernels
+
+// Two kinds of lists live in HBM, both split into NSUB independent sub-lists
+// (own counter, own slice of the buffer): one hot atomic counter saturates near
+// 90 appends/us on this chip (MI355X_MICROARCH "dequeue"), 256 of them do not,
+// and scattering appends over them round-robin balances the consumers.
+//   tile list  : what k_filter emits.  One TileEntry per 16x16 pair tile that
+//                has at least one pair under the filter bound: the tile's first
+//                row / column and a 256-bit mask (4 ballots, one per MFMA result
+//                register: bit l of m[r] <-> row (l>>4)*4+r, column l&15).
+//   kept list  : what PROC_FLOW emits: the members of A as (i, j) + weight,
+//                i.e. the reference's triplets (ref src/cvo.cpp:152) in COO form;
+//                PROC_STEP streams it.
+// Producers stage their appends in LDS and reserve an exactly-sized slice with
+// one returning atomic when the stage is full or the wave ends: no holes.
 constexpr int NSUB = 256;
 constexpr int PROC_PARTS = PROC_BLOCKS / NSUB;   // blocks cooperating on one sub-list
+constexpr int TILE_STAGE = 64;      // TileEntry slots staged per wave in k_filter
+constexpr int KEPT_STAGE = 512;     // kept triplets staged per wave in PROC_FLOW
+constexpr int PAIR_QUEUE = 128;     // compaction queue of a k_process wave
+
+struct __attribute__((aligned(16))) TileEntry {
+    uint32_t row, col;    // first row / column of the tile (device order)
+    uint32_t npairs;      // popcount of the mask
+    uint32_t pad_;
+    uint64_t m[4];
+};
+static_assert(sizeof(TileEntry) == 48, "TileEntry is three 16-byte words");
 
 enum ProcMode { PROC_FLOW = 0, PROC_STEP = 1, PROC_SELF = 2 };
-enum ListId { LIST_XY = 0, LIST_XX = 1, LIST_YY = 2, LIST_N = 3 };
+// lists: three tile lists + the kept list
+enum ListId { LIST_XY = 0, LIST_XX = 1, LIST_YY = 2, LIST_KEPT = 3, LIST_N = 4 };
 
 // float64 partial sums a block emits per mode
 constexpr int NACC_FLOW = 9;   // omega[3] v[3] sum_a sum_a_d2 nnz
@@ -96,7 +112,7 @@ struct DevState {
     KernConsts kc;              // kernel constants of the current iteration
     // MFMA pre-filter (DESIGN.md "Conservative filter"): coordinates are taken
     // relative to `center`; a pair can only pass the exact test if its filter
-    // value is below tauf[sel] = tau + rounding margin (sel = ListId)
+    // value is below tauf[sel] = tau + rounding margin (sel = LIST_XY/XX/YY)
     float center[3];
     float xmax, y0max;          // max |x - center|, max |y0 - center| (bbox bounds)
     float tauf[3];
@@ -104,7 +120,7 @@ struct DevState {
     float omega[3], v[3];
     double dl;
     double red[RED_N];
-    // candidate lists: cnt[2*l] = unused, cnt[2*l+1] = overflow flag of list l
+    // lists: cnt[2*l] = unused, cnt[2*l+1] = overflow flag of list l
     uint32_t cnt[2 * LIST_N];
     int32_t k;                  // iteration about to run / running
     int32_t done;               // RUNNING, DONE_*, NEED_BIGGER_LIST
@@ -120,30 +136,33 @@ constexpr size_t DEVSTATE_HEAD_BYTES = offsetof(DevState, sub);
 struct FilterArgs {
     const float4 *pos_a;
     const float4 *pos_b;
-    DevState *st;          // Rt, t, center, tauf, done; cnt[] is appended to
-    uint2 *cand;           // candidate list (row, column) in device order
-    uint32_t subcap;       // capacity of each of its NSUB sub-lists
-    int list;              // ListId: selects tauf[] and cnt[]
+    DevState *st;          // Rt, t, center, tauf, done; sub[list][] is appended to
+    TileEntry *tiles;      // the tile list
+    uint32_t subcap;       // capacity (entries) of each of its NSUB sub-lists
+    int list;              // LIST_XY / LIST_XX / LIST_YY: selects tauf[] and sub[]
     int row_lo, row_hi;
     int nb;
     int jt;                // columns per block chunk (multiple of 16)
     int tf_a, tf_b;        // apply [Rt|t] to the row / column cloud while staging
     int check_done;        // return at once when st->done != 0
-    long long *dbg;        // probe only (tools/microbench): per-block phase clocks, else null
+    long long *dbg;        // probe only (tools/microbench): per-wave phase clocks, else null
 };
 
-// Exact evaluation of a candidate list.
+// Exact evaluation of a tile list (PROC_FLOW, PROC_SELF) or of the kept list (PROC_STEP).
 struct ProcessArgs {
     const float4 *pos_a;
     const float *feat_a;
     const float4 *pos_b;
     const float *feat_b;
-    const uint2 *cand;
-    float *aval;           // PROC_FLOW writes the kept weight (0 = dropped), PROC_STEP reads it
+    const TileEntry *tiles;
+    uint2 *kept_ij;        // kept list: PROC_FLOW appends, PROC_STEP reads
+    float *kept_a;
     double *partials;      // [PROC_BLOCKS][nacc]
-    const DevState *st;
-    uint32_t subcap;
-    int list;
+    DevState *st;
+    uint32_t subcap;       // of the tile list
+    uint32_t kept_subcap;  // of the kept list
+    int list;              // which tile list
+    int row_hi, nb;        // valid rows / columns (mask bits beyond are padding)
     int first_counted;     // PROC_SELF: rows whose caller index is below contribute 0 to the sum
     int tf_a, tf_b;
     int check_done;

@@ -3,9 +3,10 @@
 //   k_filter    : transform_pcd + the neighbour search of se_kernel
 //                 (ref src/cvo.cpp:310-315,110-125): ALL target x source pairs
 //                 are tested on the matrix cores (f32 MFMA, K = 4) against a
-//                 conservative squared-distance bound; survivors are appended
-//                 to a candidate list in HBM.
-//   k_process   : exact evaluation of the candidate list
+//                 conservative squared-distance bound; 16x16 tiles with
+//                 survivors are appended (with their 256-bit pair mask) to a
+//                 tile list in HBM.
+//   k_process   : exact evaluation of the tile list / of the kept list
 //                   PROC_FLOW  rest of se_kernel + compute_flow (ref cvo.cpp:126-210)
 //                   PROC_STEP  compute_step_size sums          (ref cvo.cpp:213-289)
 //                   PROC_SELF  acvo Axx / Ayy terms   (ref adaptive_cvo.cpp:156-265)
@@ -57,27 +58,26 @@ __device__ __forceinline__ float mv_row(const float *m, float x, float y, float 
 // k_filter
 // ---------------------------------------------------------------------------
 // LDS carve of one filter block (all 16-byte aligned):
-//   bop   [jt/16][64] float : MFMA B operands of the column chunk, per group of
-//                             16 columns k-major: [-2y'0 x16][-2y'1 x16][-2y'2 x16][|y'|^2 x16]
+//   bop   [jt/16][64] float      : MFMA B operands of the column chunk, per group of
+//                                  16 columns k-major: [-2y'0 x16][-2y'1 x16][-2y'2 x16][|y'|^2 x16]
 //   xrow  [ROWS_PER_TILE] float4 : (x'0, x'1, x'2, |x'|^2) of the block's rows
-//   queue [4][QCAP] u32     : per-wave candidate queues
-size_t filter_smem_bytes(int jt) { return (size_t)jt * 16 + ROWS_PER_TILE * 16 + 4 * QCAP * 4; }
-
-// write queue entries q[0..n) to slots [base, base+padto) of sub-list `sub`
-// (slots n..padto become holes); n, padto, sub, base are wave-uniform
-__device__ __forceinline__ void write_chunk(const unsigned *q, int n, int padto, int lane, int row0,
-                                            int j0, unsigned sub, unsigned base, const FilterArgs &a)
+//   stage [4][TILE_STAGE] TileEntry : per-wave staging of the tile entries
+size_t filter_smem_bytes(int jt)
 {
-    if (base + (unsigned)padto <= a.subcap) {
-        uint2 *dst = a.cand + (size_t)sub * a.subcap + base;
-        for (int t = lane; t < padto; t += 64) {
-            uint2 v = make_uint2(HOLE, HOLE);
-            if (t < n) {
-                const unsigned e = q[t];
-                v = make_uint2((unsigned)row0 + (e >> 16), (unsigned)j0 + (e & 0xffffu));
-            }
-            dst[t] = v;
-        }
+    return (size_t)jt * 16 + ROWS_PER_TILE * 16 + 4 * TILE_STAGE * sizeof(TileEntry);
+}
+
+// append the wave's `n` staged tile entries to sub-list `sub` (exact-size slice)
+__device__ __forceinline__ void flush_tiles(const TileEntry *stage, int n, int lane, unsigned sub,
+                                            const FilterArgs &a)
+{
+    unsigned base = 0;
+    if (lane == 0) base = atomicAdd(&a.st->sub[a.list][sub], (unsigned)n);
+    base = __builtin_amdgcn_readfirstlane(base);
+    if (base + (unsigned)n <= a.subcap) {
+        const uint4 *src = reinterpret_cast<const uint4 *>(stage);
+        uint4 *dst = reinterpret_cast<uint4 *>(a.tiles + (size_t)sub * a.subcap + base);
+        for (int w = lane; w < n * 3; w += 64) dst[w] = src[w];
     } else if (lane == 0) {
         atomicOr(&a.st->cnt[2 * a.list + 1], 1u);   // overflow: the host grows the list and resumes
     }
@@ -91,7 +91,8 @@ __global__ void __launch_bounds__(BLOCK) k_filter(const FilterArgs a)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float *bop = reinterpret_cast<float *>(smem);
     float4 *xrow = reinterpret_cast<float4 *>(smem + (size_t)a.jt * 16);
-    unsigned *queue = reinterpret_cast<unsigned *>(smem + (size_t)a.jt * 16 + ROWS_PER_TILE * 16);
+    TileEntry *stage_all =
+        reinterpret_cast<TileEntry *>(smem + (size_t)a.jt * 16 + ROWS_PER_TILE * 16);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -154,13 +155,11 @@ __global__ void __launch_bounds__(BLOCK) k_filter(const FilterArgs a)
         for (int r = 0; r < 4; ++r) creg[t][r] = xr[(kk * 4 + r) * 4 + 3] - tauf;
     }
 
-    unsigned *q = queue + wid * QCAP;
-    int qn = 0;   // wave-uniform
+    TileEntry *stage = stage_all + wid * TILE_STAGE;
+    int ne = 0;   // wave-uniform: staged tile entries
     // this wave's flushes walk round-robin over the sub-lists
     unsigned sub = ((blockIdx.y * gridDim.x + blockIdx.x) * 4u + (unsigned)wid) * 37u;
-    int have_next = 0;            // wave-uniform: a chunk slot is reserved ahead
-    unsigned next_base = 0;       // its offset (valid in lane 0 once the atomic returns)
-    unsigned next_sub = 0;        // ... in this sub-list
+    const unsigned rbase = (unsigned)(row0 + wid * ROWS_PER_WAVE);
 
     const long long t_loop = a.dbg ? (long long)__builtin_readcyclecounter() : 0;
     float bnext = bop[lane];
@@ -172,72 +171,43 @@ __global__ void __launch_bounds__(BLOCK) k_filter(const FilterArgs a)
         for (int t = 0; t < TILES_PER_WAVE; ++t)
             d[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[t], b, creg[t], 0, 0, 0);
         // any filter value negative?  OR of the sign bits
-        int orall = 0;
+        int ort[TILES_PER_WAVE];
 #pragma unroll
         for (int t = 0; t < TILES_PER_WAVE; ++t)
-            orall |= (__float_as_int(d[t][0]) | __float_as_int(d[t][1])) |
+            ort[t] = (__float_as_int(d[t][0]) | __float_as_int(d[t][1])) |
                      (__float_as_int(d[t][2]) | __float_as_int(d[t][3]));
-        if (__ballot(orall < 0) == 0ull) continue;
-        // queue every (row, column) whose filter value is negative
+        if (__ballot(((ort[0] | ort[1]) | (ort[2] | ort[3])) < 0) == 0ull) continue;
+        // a tile with survivors: its four ballots ARE the 256-bit pair mask
 #pragma unroll
         for (int t = 0; t < TILES_PER_WAVE; ++t) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const bool pass = d[t][r] < 0.0f;
-                const unsigned long long m = __ballot(pass);
-                if (m) {
-                    if (pass) {
-                        const unsigned below = __builtin_amdgcn_mbcnt_hi(
-                            (unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-                        const unsigned rl = (unsigned)(wid * ROWS_PER_WAVE + t * 16 + kk * 4 + r);
-                        q[qn + below] = (rl << 16) | (unsigned)(g * 16 + (lane & 15));
-                    }
-                    qn += __popcll(m);
-                    if (qn >= CHUNK) {
-                        // a full chunk leaves for HBM: into the slot reserved one
-                        // chunk ago (or reserved now, the first time), and the
-                        // next slot is reserved at once so its atomic is in flight
-                        // while the queue refills
-                        qn -= CHUNK;
-                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                        __builtin_amdgcn_wave_barrier();
-                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                        unsigned base, csub;
-                        if (have_next) {
-                            base = __builtin_amdgcn_readfirstlane(next_base);
-                            csub = next_sub;
-                        } else {
-                            csub = (sub++) & (NSUB - 1);
-                            unsigned b0 = 0;
-                            if (lane == 0) b0 = atomicAdd(&a.st->sub[a.list][csub], (unsigned)CHUNK);
-                            base = __builtin_amdgcn_readfirstlane(b0);
-                        }
-                        next_sub = (sub++) & (NSUB - 1);
-                        if (lane == 0) next_base = atomicAdd(&a.st->sub[a.list][next_sub], (unsigned)CHUNK);
-                        have_next = 1;
-                        write_chunk(q + qn, CHUNK, CHUNK, lane, row0, j0, csub, base, a);
-                        __builtin_amdgcn_wave_barrier();
-                    }
-                }
+            if (__ballot(ort[t] < 0) == 0ull) continue;
+            const unsigned long long m0 = __ballot(d[t][0] < 0.0f), m1 = __ballot(d[t][1] < 0.0f),
+                                     m2 = __ballot(d[t][2] < 0.0f), m3 = __ballot(d[t][3] < 0.0f);
+            if (lane == 0) {
+                TileEntry te;
+                te.row = rbase + (unsigned)t * 16u;
+                te.col = (unsigned)(j0 + g * 16);
+                te.npairs = (unsigned)(__popcll(m0) + __popcll(m1) + __popcll(m2) + __popcll(m3));
+                te.pad_ = 0u;
+                te.m[0] = m0; te.m[1] = m1; te.m[2] = m2; te.m[3] = m3;
+                stage[ne] = te;
+            }
+            if (++ne == TILE_STAGE) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                flush_tiles(stage, ne, lane, (sub++) & (NSUB - 1), a);
+                __builtin_amdgcn_wave_barrier();
+                ne = 0;
             }
         }
     }
     const long long t_tail = a.dbg ? (long long)__builtin_readcyclecounter() : 0;
-    // the tail: into the slot already reserved (padding it with holes), or into
-    // an exactly-sized reservation if this wave never filled a chunk
-    if (have_next || qn > 0) {
+    if (ne > 0) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        if (have_next) {
-            write_chunk(q, qn, CHUNK, lane, row0, j0, next_sub,
-                        __builtin_amdgcn_readfirstlane(next_base), a);
-        } else {
-            const unsigned csub = sub & (NSUB - 1);
-            unsigned b0 = 0;
-            if (lane == 0) b0 = atomicAdd(&a.st->sub[a.list][csub], (unsigned)qn);
-            write_chunk(q, qn, qn, lane, row0, j0, csub, __builtin_amdgcn_readfirstlane(b0), a);
-        }
+        flush_tiles(stage, ne, lane, sub & (NSUB - 1), a);
     }
     if (a.dbg && lane == 0) {   // probe: start, prologue end, loop end, exit clocks of every wave
         long long *o = a.dbg + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 4 + wid) * 8;
@@ -290,101 +260,200 @@ template <> struct NAcc<PROC_FLOW> { static constexpr int n = NACC_FLOW; };
 template <> struct NAcc<PROC_STEP> { static constexpr int n = NACC_STEP; };
 template <> struct NAcc<PROC_SELF> { static constexpr int n = NACC_SELF; };
 
+// One pair of the exact pass.  PROC_FLOW / PROC_SELF: membership test of
+// se_kernel (ref cvo.cpp:125-152) and the flow / self sums; returns the weight
+// (0 = not in A).  PROC_STEP: `w` is the recorded weight of a member of A.
+template <int MODE>
+__device__ __forceinline__ float eval_pair(const ProcessArgs &a, const KernConsts &kc, unsigned i,
+                                           unsigned j, float w, double *acc)
+{
+    const float *Rt = a.st->Rt;
+    const float *tt = a.st->t;
+    float4 xi = a.pos_a[i];
+    if (a.tf_a) xi = apply_tf(Rt, tt, xi);
+    float4 yj = a.pos_b[j];
+    if (a.tf_b) yj = apply_tf(Rt, tt, yj);
+    const float e0 = xi.x - yj.x, e1 = xi.y - yj.y, e2 = xi.z - yj.z;
+    float d2 = 0.0f;
+    if (MODE != PROC_STEP) {
+        d2 = __builtin_fmaf(e2, e2, __builtin_fmaf(e1, e1, e0 * e0));
+        w = (d2 < kc.tau) ? pair_weight(kc, d2, a.feat_a, i, a.feat_b, j) : 0.0f;
+    }
+    if (!(w > 0.0f)) return 0.0f;
+    if (MODE == PROC_FLOW) {
+        // cross(x_i, y_j), y_j - x_i ; (1/c * A_ij) * cross  (ref cvo.cpp:191-198)
+        const float c0 = xi.y * yj.z - xi.z * yj.y;
+        const float c1 = xi.z * yj.x - xi.x * yj.z;
+        const float c2 = xi.x * yj.y - xi.y * yj.x;
+        const float f0 = yj.x - xi.x, f1 = yj.y - xi.y, f2 = yj.z - xi.z;
+        const float ac = kc.inv_c * w, ad = kc.inv_d * w;
+        acc[0] += (double)(ac * c0);
+        acc[1] += (double)(ac * c1);
+        acc[2] += (double)(ac * c2);
+        acc[3] += (double)(ad * f0);
+        acc[4] += (double)(ad * f1);
+        acc[5] += (double)(ad * f2);
+        acc[6] += (double)w;
+        acc[7] += (double)((kc.inv_l3 * w) * d2);
+        acc[8] += 1.0;
+    } else if (MODE == PROC_STEP) {
+        // Taylor vectors of y_j (ref cvo.cpp:226-238), for members of A only
+        const cvo_math::XiConsts &xc = a.st->xi;
+        float xiz[3], xi2z[3], xi3z[3], xi4z[3];
+        xiz[0] = (xc.omega[1] * yj.z - xc.omega[2] * yj.y) + xc.v[0];
+        xiz[1] = (xc.omega[2] * yj.x - xc.omega[0] * yj.z) + xc.v[1];
+        xiz[2] = (xc.omega[0] * yj.y - xc.omega[1] * yj.x) + xc.v[2];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            xi2z[r] = mv_row(xc.W2 + 3 * r, yj.x, yj.y, yj.z) + xc.u2[r];
+            xi3z[r] = mv_row(xc.W3 + 3 * r, yj.x, yj.y, yj.z) + xc.u3[r];
+            xi4z[r] = mv_row(xc.W4 + 3 * r, yj.x, yj.y, yj.z) + xc.u4[r];
+        }
+        const float normxiz2 = (xiz[0] * xiz[0] + xiz[1] * xiz[1]) + xiz[2] * xiz[2];
+        const float xz12 = -((xiz[0] * xi2z[0] + xiz[1] * xi2z[1]) + xiz[2] * xi2z[2]);
+        const float eps_c = ((xi2z[0] * xi2z[0] + xi2z[1] * xi2z[1]) + xi2z[2] * xi2z[2]) +
+                            2 * ((xiz[0] * xi3z[0] + xiz[1] * xi3z[1]) + xiz[2] * xi3z[2]);
+        // diff_xy = x_i - y_j is (e0,e1,e2); ref cvo.cpp:256-280
+        const float cb = kc.cb, cg = kc.cg, cd = kc.cd;
+        const float beta = ((cb * xiz[0]) * e0 + (cb * xiz[1]) * e1) + (cb * xiz[2]) * e2;
+        const float g_dot = ((2.0f * xi2z[0]) * e0 + (2.0f * xi2z[1]) * e1) + (2.0f * xi2z[2]) * e2;
+        const float gamma = cg * (normxiz2 + g_dot);
+        const float d_dot = ((-xi3z[0]) * e0 + (-xi3z[1]) * e1) + (-xi3z[2]) * e2;
+        const float delta = cd * (xz12 + d_dot);
+        const float e_dot = ((2.0f * xi4z[0]) * e0 + (2.0f * xi4z[1]) * e1) + (2.0f * xi4z[2]) * e2;
+        const float epsil = cg * (eps_c + e_dot);
+        const double A = (double)w;
+        const double b = (double)beta, g = (double)gamma;
+        acc[0] += (double)(w * beta);
+        acc[1] += A * (g + (double)(beta * beta) / 2.0);
+        acc[2] += A * ((double)(delta + beta * gamma) + (double)(beta * beta * beta) / 6.0);
+        acc[3] += A * ((((double)(epsil + beta * delta) + 0.5 * b * b * g) + 0.5 * g * g) +
+                       1 / 24.0 * b * b * b * b);
+    } else {
+        if (__float_as_int(xi.w) >= a.first_counted) acc[0] += (double)((kc.inv_l3 * w) * d2);
+        acc[1] += 1.0;
+    }
+    return w;
+}
+
+// per-wave LDS of a PROC_FLOW / PROC_SELF block
+struct __attribute__((aligned(16))) ProcWaveLds {
+    uint2 pairq[PAIR_QUEUE];     // compaction queue of (row, column)
+    uint2 kept_ij[KEPT_STAGE];   // staged members of A (PROC_FLOW)
+    float kept_a[KEPT_STAGE];
+};
+
+// append the wave's `n` staged kept triplets to the kept list (exact-size slice)
+__device__ __forceinline__ void flush_kept(const ProcWaveLds *L, int n, int lane, unsigned sub,
+                                           const ProcessArgs &a)
+{
+    unsigned base = 0;
+    if (lane == 0) base = atomicAdd(&a.st->sub[LIST_KEPT][sub], (unsigned)n);
+    base = __builtin_amdgcn_readfirstlane(base);
+    if (base + (unsigned)n <= a.kept_subcap) {
+        const size_t o = (size_t)sub * a.kept_subcap + base;
+        for (int t = lane; t < n; t += 64) {
+            a.kept_ij[o + t] = L->kept_ij[t];
+            a.kept_a[o + t] = L->kept_a[t];
+        }
+    } else if (lane == 0) {
+        atomicOr(&a.st->cnt[2 * LIST_KEPT + 1], 1u);
+    }
+}
+
 template <int MODE>
 __global__ void __launch_bounds__(BLOCK) k_process(const ProcessArgs a)
 {
     constexpr int NACC = NAcc<MODE>::n;
     if (a.check_done && a.st->done != 0) return;
     __shared__ double red[4 * NACC_MAX];
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    __shared__ ProcWaveLds wl[(MODE == PROC_STEP) ? 1 : 4];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const KernConsts kc = a.st->kc;
-    const float *Rt = a.st->Rt;
-    const float *tt = a.st->t;
     // PROC_PARTS blocks share one sub-list
     const unsigned sub = blockIdx.x & (NSUB - 1), part = blockIdx.x / NSUB;
-    unsigned n = a.st->sub[a.list][sub];
-    if (n > a.subcap) n = a.subcap;   // overflowed list: the iteration is redone anyway
-    const size_t sbase = (size_t)sub * a.subcap;
 
     double acc[NACC];
 #pragma unroll
     for (int k = 0; k < NACC; ++k) acc[k] = 0.0;
 
-    for (unsigned off = part * BLOCK + tid; off < n; off += PROC_PARTS * BLOCK) {
-        const size_t idx = sbase + off;
-        const uint2 e = a.cand[idx];
-        if (e.x == HOLE) continue;   // unused slot of a reserved chunk
-        float4 xi = a.pos_a[e.x];
-        if (a.tf_a) xi = apply_tf(Rt, tt, xi);
-        float4 yj = a.pos_b[e.y];
-        if (a.tf_b) yj = apply_tf(Rt, tt, yj);
-        const float e0 = xi.x - yj.x, e1 = xi.y - yj.y, e2 = xi.z - yj.z;
-        float w;
-        float d2 = 0.0f;
-        if (MODE == PROC_STEP) {
-            w = a.aval[idx];     // kept weight recorded by PROC_FLOW, 0 = not in A
-        } else {
-            // the exact membership test of se_kernel (ref cvo.cpp:125-152)
-            d2 = __builtin_fmaf(e2, e2, __builtin_fmaf(e1, e1, e0 * e0));
-            w = (d2 < kc.tau) ? pair_weight(kc, d2, a.feat_a, e.x, a.feat_b, e.y) : 0.0f;
-            if (MODE == PROC_FLOW) a.aval[idx] = w;
+    if (MODE == PROC_STEP) {
+        // stream the members of A recorded by PROC_FLOW
+        unsigned n = a.st->sub[LIST_KEPT][sub];
+        if (n > a.kept_subcap) n = a.kept_subcap;
+        const size_t sbase = (size_t)sub * a.kept_subcap;
+        for (unsigned off = part * BLOCK + tid; off < n; off += PROC_PARTS * BLOCK) {
+            const uint2 e = a.kept_ij[sbase + off];
+            eval_pair<MODE>(a, kc, e.x, e.y, a.kept_a[sbase + off], acc);
         }
-        if (!(w > 0.0f)) continue;
-        if (MODE == PROC_FLOW) {
-            // cross(x_i, y_j), y_j - x_i ; (1/c * A_ij) * cross  (ref cvo.cpp:191-198)
-            const float c0 = xi.y * yj.z - xi.z * yj.y;
-            const float c1 = xi.z * yj.x - xi.x * yj.z;
-            const float c2 = xi.x * yj.y - xi.y * yj.x;
-            const float f0 = yj.x - xi.x, f1 = yj.y - xi.y, f2 = yj.z - xi.z;
-            const float ac = kc.inv_c * w, ad = kc.inv_d * w;
-            acc[0] += (double)(ac * c0);
-            acc[1] += (double)(ac * c1);
-            acc[2] += (double)(ac * c2);
-            acc[3] += (double)(ad * f0);
-            acc[4] += (double)(ad * f1);
-            acc[5] += (double)(ad * f2);
-            acc[6] += (double)w;
-            acc[7] += (double)((kc.inv_l3 * w) * d2);
-            acc[8] += 1.0;
-        } else if (MODE == PROC_STEP) {
-            // Taylor vectors of y_j (ref cvo.cpp:226-238), for members of A only
-            const cvo_math::XiConsts &xc = a.st->xi;
-            float xiz[3], xi2z[3], xi3z[3], xi4z[3];
-            xiz[0] = (xc.omega[1] * yj.z - xc.omega[2] * yj.y) + xc.v[0];
-            xiz[1] = (xc.omega[2] * yj.x - xc.omega[0] * yj.z) + xc.v[1];
-            xiz[2] = (xc.omega[0] * yj.y - xc.omega[1] * yj.x) + xc.v[2];
-#pragma unroll
-            for (int r = 0; r < 3; ++r) {
-                xi2z[r] = mv_row(xc.W2 + 3 * r, yj.x, yj.y, yj.z) + xc.u2[r];
-                xi3z[r] = mv_row(xc.W3 + 3 * r, yj.x, yj.y, yj.z) + xc.u3[r];
-                xi4z[r] = mv_row(xc.W4 + 3 * r, yj.x, yj.y, yj.z) + xc.u4[r];
+    } else {
+        ProcWaveLds *L = &wl[wid];
+        unsigned n = a.st->sub[a.list][sub];
+        if (n > a.subcap) n = a.subcap;   // overflowed list: the iteration is redone anyway
+        const TileEntry *tl = a.tiles + (size_t)sub * a.subcap;
+        int qn = 0;   // wave-uniform: queued pairs
+        int nk = 0;   // wave-uniform: staged kept triplets
+        unsigned ksub = (blockIdx.x * 4u + (unsigned)wid) * 37u;
+        // evaluate the queued pairs q[base .. base+cnt) (cnt <= 64, wave-uniform)
+        auto run_batch = [&](int base, int cnt) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            float w = 0.0f;
+            uint2 pr = make_uint2(0u, 0u);
+            if (lane < cnt) {
+                pr = L->pairq[base + lane];
+                w = eval_pair<MODE>(a, kc, pr.x, pr.y, 0.0f, acc);
             }
-            const float normxiz2 = (xiz[0] * xiz[0] + xiz[1] * xiz[1]) + xiz[2] * xiz[2];
-            const float xz12 = -((xiz[0] * xi2z[0] + xiz[1] * xi2z[1]) + xiz[2] * xi2z[2]);
-            const float eps_c = ((xi2z[0] * xi2z[0] + xi2z[1] * xi2z[1]) + xi2z[2] * xi2z[2]) +
-                                2 * ((xiz[0] * xi3z[0] + xiz[1] * xi3z[1]) + xiz[2] * xi3z[2]);
-            // diff_xy = x_i - y_j is (e0,e1,e2); ref cvo.cpp:256-280
-            const float cb = kc.cb, cg = kc.cg, cd = kc.cd;
-            const float beta = ((cb * xiz[0]) * e0 + (cb * xiz[1]) * e1) + (cb * xiz[2]) * e2;
-            const float g_dot =
-                ((2.0f * xi2z[0]) * e0 + (2.0f * xi2z[1]) * e1) + (2.0f * xi2z[2]) * e2;
-            const float gamma = cg * (normxiz2 + g_dot);
-            const float d_dot = ((-xi3z[0]) * e0 + (-xi3z[1]) * e1) + (-xi3z[2]) * e2;
-            const float delta = cd * (xz12 + d_dot);
-            const float e_dot =
-                ((2.0f * xi4z[0]) * e0 + (2.0f * xi4z[1]) * e1) + (2.0f * xi4z[2]) * e2;
-            const float epsil = cg * (eps_c + e_dot);
-            const double A = (double)w;
-            const double b = (double)beta, g = (double)gamma;
-            acc[0] += (double)(w * beta);
-            acc[1] += A * (g + (double)(beta * beta) / 2.0);
-            acc[2] += A * ((double)(delta + beta * gamma) + (double)(beta * beta * beta) / 6.0);
-            acc[3] += A * ((((double)(epsil + beta * delta) + 0.5 * b * b * g) + 0.5 * g * g) +
-                           1 / 24.0 * b * b * b * b);
-        } else {
-            if (__float_as_int(xi.w) >= a.first_counted)
-                acc[0] += (double)((kc.inv_l3 * w) * d2);
-            acc[1] += 1.0;
+            if (MODE == PROC_FLOW) {   // record the members of A
+                const unsigned long long km = __ballot(w > 0.0f);
+                if (w > 0.0f) {
+                    const unsigned below = __builtin_amdgcn_mbcnt_hi(
+                        (unsigned)(km >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)km, 0u));
+                    L->kept_ij[nk + below] = pr;
+                    L->kept_a[nk + below] = w;
+                }
+                nk += __popcll(km);
+                if (nk > KEPT_STAGE - 64) {
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    flush_kept(L, nk, lane, (ksub++) & (NSUB - 1), a);
+                    nk = 0;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        };
+        // the 4 * PROC_PARTS waves of this sub-list take its tile entries in turn
+        for (unsigned e = part * 4u + (unsigned)wid; e < n; e += 4u * PROC_PARTS) {
+            // expand the tile's 256-bit mask into the queue: bit l of m[r] is
+            // row (l>>4)*4 + r, column l&15 of the tile
+            const TileEntry *te = tl + e;
+            const unsigned trow = te->row, tcol = te->col;
+#pragma unroll 1
+            for (int r = 0; r < 4; ++r) {
+                const unsigned long long m = te->m[r];
+                if (m == 0ull) continue;
+                if ((m >> lane) & 1ull) {
+                    const unsigned below = __builtin_amdgcn_mbcnt_hi(
+                        (unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+                    L->pairq[qn + below] = make_uint2(trow + (unsigned)((lane >> 4) * 4 + r),
+                                                      tcol + (unsigned)(lane & 15));
+                }
+                qn += __popcll(m);
+                if (qn >= 64) {
+                    qn -= 64;
+                    run_batch(qn, 64);
+                }
+            }
+        }
+        if (qn > 0) run_batch(0, qn);
+        if (MODE == PROC_FLOW && nk > 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            flush_kept(L, nk, lane, ksub & (NSUB - 1), a);
         }
     }
 
@@ -467,7 +536,8 @@ __global__ void __launch_bounds__(BLOCK) k_post_flow(const PostFlowArgs a)
         // a candidate list overflowed on this rank: poison nnz so that, after the
         // all-reduce, EVERY rank takes the same "grow the list and redo" exit
         if (threadIdx.x == 0 &&
-            (st->cnt[2 * LIST_XY + 1] | st->cnt[2 * LIST_XX + 1] | st->cnt[2 * LIST_YY + 1]))
+            (st->cnt[2 * LIST_XY + 1] | st->cnt[2 * LIST_XX + 1] | st->cnt[2 * LIST_YY + 1] |
+             st->cnt[2 * LIST_KEPT + 1]))
             st->red[8] = __builtin_nan("");
     }
     if ((a.flags & POST_MATH) && threadIdx.x == 0) {

@@ -29,7 +29,7 @@ int main(int argc, char **argv)
             int cp = (int)((p.x + 0.8f) * 10) * 16 + (int)((p.y + 0.8f) * 10), cq = (int)((q.x + 0.8f) * 10) * 16 + (int)((q.y + 0.8f) * 10);
             return cp < cq; });
     }
-    float4 *da, *db; DevState *st; uint2 *cand; long long *dbg;
+    float4 *da, *db; DevState *st; TileEntry *cand; long long *dbg;
     hipMalloc(&da, n * sizeof(float4)); hipMalloc(&db, n * sizeof(float4));
     hipMemcpy(da, ha.data(), n * sizeof(float4), hipMemcpyHostToDevice);
     hipMemcpy(db, hb.data(), n * sizeof(float4), hipMemcpyHostToDevice);
@@ -37,12 +37,12 @@ int main(int argc, char **argv)
     DevParams prm{}; prm.c = prm.d = 7.f; prm.c_ell = 200.f; prm.log_sp_s2 = logf(0.8f); prm.tau_c = 1e9f;
     prepare_iteration(&h, prm);
     hipMalloc(&st, sizeof(DevState)); hipMemcpy(st, &h, sizeof(h), hipMemcpyHostToDevice);
-    const uint32_t subcap = 1u << 16;
-    hipMalloc(&cand, (size_t)subcap * NSUB * sizeof(uint2));
+    const uint32_t subcap = 1u << 12;
+    hipMalloc(&cand, (size_t)subcap * NSUB * sizeof(TileEntry));
     const int tiles = (n + ROWS_PER_TILE - 1) / ROWS_PER_TILE, chunks = (n + jt - 1) / jt;
     const size_t nw = (size_t)tiles * chunks * 4;
     hipMalloc(&dbg, nw * 8 * sizeof(long long));
-    FilterArgs a{}; a.pos_a = da; a.pos_b = db; a.st = st; a.cand = cand; a.subcap = subcap; a.list = LIST_XY;
+    FilterArgs a{}; a.pos_a = da; a.pos_b = db; a.st = st; a.tiles = cand; a.subcap = subcap; a.list = LIST_XY;
     a.row_lo = 0; a.row_hi = n; a.nb = n; a.jt = jt; a.tf_a = 0; a.tf_b = 1; a.check_done = 1; a.dbg = dbg;
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     for (int rep = 0; rep < 3; ++rep) {
@@ -104,6 +104,19 @@ int main(int argc, char **argv)
                 printf("wave START (10 ns units): p10 %lld p50 %lld p90 %lld max %lld | wave END: min %lld p10 %lld p50 %lld p90 %lld max %lld\n",
                        ws_[nw / 10], ws_[nw / 2], ws_[nw * 9 / 10], ws_[nw - 1], we_[0], we_[nw / 10], we_[nw / 2], we_[nw * 9 / 10], we_[nw - 1]);
                 printf("shader clock during the kernel: %.0f MHz; first wave start -> last wave end: %.2f us (100 MHz wall clock)\n", dm / dw * 100.0, (wmax - wmin) / 100.0);
+            }
+            {   std::vector<int> hist(40, 0); std::vector<double> spanby(40, 0);
+                for (int c = 0; c <= maxcu; ++c) if (cnt[c]) { hist[std::min(cnt[c], 39)]++; spanby[std::min(cnt[c], 39)] += last[c] - first[c]; }
+                printf("waves per CU histogram (waves: #CUs, avg busy ticks):");
+                for (int k = 0; k < 40; ++k) if (hist[k]) printf(" %d: %d, %.0f |", k, hist[k], spanby[k] / hist[k]);
+                printf("\n");
+            }
+            {   std::vector<long long> pl, ll, tl;
+                for (size_t w = 0; w < nw; ++w) { const long long *o = &hd[w * 8]; pl.push_back(o[1] - o[0]); ll.push_back(o[2] - o[1]); tl.push_back(o[3] - o[2]); }
+                std::sort(pl.begin(), pl.end()); std::sort(ll.begin(), ll.end()); std::sort(tl.begin(), tl.end());
+                auto pc = [&](std::vector<long long> &v, double f) { return v[(size_t)(f * (v.size() - 1))]; };
+                printf("prologue ticks p10 %lld p50 %lld p90 %lld max %lld | loop p10 %lld p50 %lld p90 %lld p99 %lld max %lld | tail p50 %lld p99 %lld max %lld\n",
+                       pc(pl, .1), pc(pl, .5), pc(pl, .9), pc(pl, 1), pc(ll, .1), pc(ll, .5), pc(ll, .9), pc(ll, .99), pc(ll, 1), pc(tl, .5), pc(tl, .99), pc(tl, 1));
             }
             int used = 0; double avgw = 0, avgpeak = 0, avgspan = 0;
             for (int c = 0; c <= maxcu; ++c) if (cnt[c]) { used++; avgw += cnt[c]; avgpeak += peak[c]; avgspan += last[c] - first[c]; }
