@@ -18,6 +18,7 @@
 #include <cmath>
 #include <cstddef>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -34,6 +35,7 @@ namespace {
 struct Cloud {
     float4 *pos = nullptr;   // Morton-sorted; .w = index in the caller's cloud (int bits)
     float *feat = nullptr;   // same order
+    float4 *seg = nullptr;   // bounding sphere (centre, radius) of every SEG consecutive points
     int n = 0;
     int cap = 0;
     float lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};   // bounding box
@@ -61,7 +63,7 @@ struct List {     // LIST_XY/XX/YY: TileEntry[cap] in a; LIST_KEPT: uint2[cap] i
     uint32_t cap = 0;   // entries, a multiple of NSUB
 };
 
-constexpr int kBatch = 8;        // iterations enqueued between two polls
+constexpr int kBatch = 4;        // iterations enqueued between two polls
 constexpr int kPollSlots = 4;
 
 }   // namespace
@@ -78,6 +80,7 @@ struct cvo_hip_ctx {
     hipEvent_t poll_ev[kPollSlots]{};
     DevBuf part_flow, part_xx, part_yy, part_step;   // [PROC_BLOCKS][NACC_MAX] float64
     List lists[LIST_N];
+    DevBuf kept_cnt;                 // uint32[PROC_WAVES]
     cvo_hip_trace *trace_dev = nullptr;
     int trace_dev_cap = 0;
     bool have_tf = false;
@@ -87,6 +90,7 @@ struct cvo_hip_ctx {
     cvo_hip_allreduce_fn user_allreduce = nullptr;
     void *user_allreduce_arg = nullptr;
     bool profiling = false;
+    long long *post_dbg = nullptr;   // CVO_HIP_POST_DEBUG diagnostics
     int iter_tag = -1;
     std::vector<EventPair> events;
     cvo_hip_profile prof{};
@@ -147,9 +151,11 @@ int upload_cloud(cvo_hip_ctx *ctx, Cloud &c, const float *xyz, const float *feat
     if (n > c.cap) {
         if (c.pos) HIP_TRY(ctx, hipFree(c.pos));
         if (c.feat) HIP_TRY(ctx, hipFree(c.feat));
-        c.pos = nullptr; c.feat = nullptr; c.cap = 0;
+        if (c.seg) HIP_TRY(ctx, hipFree(c.seg));
+        c.pos = nullptr; c.feat = nullptr; c.seg = nullptr; c.cap = 0;
         HIP_TRY(ctx, hipMalloc((void **)&c.pos, (size_t)n * sizeof(float4)));
         HIP_TRY(ctx, hipMalloc((void **)&c.feat, (size_t)n * FEAT_STRIDE * sizeof(float)));
+        HIP_TRY(ctx, hipMalloc((void **)&c.seg, (size_t)((n + SEG - 1) / SEG) * sizeof(float4)));
         c.cap = n;
     }
     c.n = n;
@@ -206,6 +212,33 @@ int upload_cloud(cvo_hip_ctx *ctx, Cloud &c, const float *xyz, const float *feat
                                                   ? feat[(size_t)f * n + i]
                                                   : feat[(size_t)i * CVO_HIP_NFEAT + f];
     }
+    // bounding spheres of the Morton runs (culling in k_filter): centre of the
+    // run's bounding box, radius = farthest point, inflated against rounding
+    const int nseg = (n + SEG - 1) / SEG;
+    std::vector<float> hs((size_t)nseg * 4);
+    for (int g = 0; g < nseg; ++g) {
+        const int s0 = g * SEG, s1 = std::min(n, s0 + SEG);
+        float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+        for (int q = s0; q < s1; ++q)
+            for (int a = 0; a < 3; ++a) {
+                lo[a] = std::min(lo[a], hp[4 * (size_t)q + a]);
+                hi[a] = std::max(hi[a], hp[4 * (size_t)q + a]);
+            }
+        double cc[3], r2 = 0.0;
+        for (int a = 0; a < 3; ++a) cc[a] = 0.5 * ((double)lo[a] + hi[a]);
+        for (int a = 0; a < 3; ++a) hs[4 * (size_t)g + a] = (float)cc[a];
+        for (int q = s0; q < s1; ++q) {
+            double d2 = 0.0;
+            for (int a = 0; a < 3; ++a) {
+                const double d = (double)hp[4 * (size_t)q + a] - (double)hs[4 * (size_t)g + a];
+                d2 += d * d;
+            }
+            r2 = std::max(r2, d2);
+        }
+        hs[4 * (size_t)g + 3] = (float)(std::sqrt(r2) * 1.00001 + 1e-6);
+    }
+    HIP_TRY(ctx, hipMemcpyAsync(c.seg, hs.data(), hs.size() * sizeof(float), hipMemcpyHostToDevice,
+                                ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(c.pos, hp.data(), hp.size() * sizeof(float), hipMemcpyHostToDevice,
                                 ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(c.feat, hf.data(), hf.size() * sizeof(float),
@@ -221,12 +254,14 @@ FilterPlan plan_filter(int nrows, int nb)
 {
     FilterPlan p{};
     const int tiles = std::max(1, (nrows + ROWS_PER_TILE - 1) / ROWS_PER_TILE);
-    const int want_blocks = 1024;
+    // many small blocks: most are culled at once (bounding spheres), the others
+    // should be short so that the few dense ones do not become a tail
+    const int want_blocks = 4096;
     const int chunks_want = std::max(1, (want_blocks + tiles / 2) / tiles);
     int jt = (nb + chunks_want - 1) / chunks_want;
     jt = std::max(jt, 64);
     jt = std::min(jt, 2048);
-    jt = (jt + 15) & ~15;           // whole MFMA column tiles
+    jt = (jt + SEG - 1) & ~(SEG - 1);   // whole bounding-sphere segments (4 MFMA column tiles)
     p.jt = jt;
     const int chunks = std::max(1, (nb + jt - 1) / jt);
     p.grid = dim3(chunks, tiles);
@@ -261,7 +296,7 @@ int ensure_list(cvo_hip_ctx *ctx, int list, int nrows, int nb, double at_least)
         const double all = (double)std::max(nrows, 0) * (double)std::max(nb, 0);
         want = std::max(all * 0.04, 1048576.0);
         want = std::min(want, std::max(all * 1.25, 1.0));
-        min_sub = KEPT_STAGE;
+        min_sub = 64 * (PROC_WAVES / NSUB);   // every PROC_FLOW wave's slice holds >= 64 entries
     } else {
         const double all = std::ceil(std::max(nrows, 0) / 16.0 + 1.0) * std::ceil(std::max(nb, 0) / 16.0 + 1.0);
         want = (all * 2.0 * sizeof(TileEntry) <= 64.0e6) ? all * 2.0 : std::max(all * 0.25, 64.0e6 / sizeof(TileEntry));
@@ -315,9 +350,11 @@ void fill_filter_geometry(const cvo_hip_ctx *ctx, DevState *h)
 
 // The dense all-pairs filter of one list (with optional HIP-event bracket: this
 // is the kernel the roofline is quoted on).
-int enqueue_filter(cvo_hip_ctx *ctx, int list, const float4 *pos_a, int row_lo, int row_hi,
-                   int tf_a, const float4 *pos_b, int nb, int tf_b, int check_done)
+int enqueue_filter(cvo_hip_ctx *ctx, int list, const Cloud &ca, int row_lo, int row_hi, int tf_a,
+                   const Cloud &cb, int tf_b, int check_done)
 {
+    const float4 *pos_a = ca.pos, *pos_b = cb.pos;
+    const int nb = cb.n;
     const int nrows = row_hi - row_lo;
     if (nrows <= 0 || nb <= 0) return CVO_HIP_OK;
     int rc = ensure_list(ctx, list, nrows, nb, 0);
@@ -325,6 +362,7 @@ int enqueue_filter(cvo_hip_ctx *ctx, int list, const float4 *pos_a, int row_lo, 
     const FilterPlan pl = plan_filter(nrows, nb);
     FilterArgs a{};
     a.pos_a = pos_a; a.pos_b = pos_b;
+    a.seg_a = ca.seg; a.seg_b = cb.seg;
     a.st = ctx->st;
     a.tiles = (TileEntry *)ctx->lists[list].a.p;
     a.subcap = ctx->lists[list].cap / NSUB;
@@ -355,10 +393,15 @@ int enqueue_process(cvo_hip_ctx *ctx, int mode, int list, DevBuf &part, const fl
                     const float *feat_a, int tf_a, const float4 *pos_b, const float *feat_b,
                     int tf_b, int first_counted, int check_done)
 {
-    int rc = ensure_buf(ctx, part, (size_t)PROC_BLOCKS * NACC_MAX * sizeof(double));
+    int rc = ensure_buf(ctx, part, (size_t)PROC_WAVES * NACC_MAX * sizeof(double));
     if (rc) return rc;
     rc = ensure_list(ctx, list, 0, 0, 0);   // an (empty) list object must exist
     if (rc) return rc;
+    if (!ctx->kept_cnt.p) {
+        rc = ensure_buf(ctx, ctx->kept_cnt, PROC_WAVES * sizeof(uint32_t));
+        if (rc) return rc;
+        HIP_TRY(ctx, hipMemsetAsync(ctx->kept_cnt.p, 0, PROC_WAVES * sizeof(uint32_t), ctx->stream));
+    }
     if (mode == PROC_FLOW)   // the kept list is sized from the pair set this pass evaluates
         rc = ensure_list(ctx, LIST_KEPT, ctx->fixed.n, ctx->moving.n, 0);
     else
@@ -370,10 +413,11 @@ int enqueue_process(cvo_hip_ctx *ctx, int mode, int list, DevBuf &part, const fl
     a.tiles = (const TileEntry *)ctx->lists[list].a.p;
     a.kept_ij = (uint2 *)ctx->lists[LIST_KEPT].a.p;
     a.kept_a = (float *)ctx->lists[LIST_KEPT].b.p;
+    a.kept_cnt = (uint32_t *)ctx->kept_cnt.p;
     a.partials = (double *)part.p;
     a.st = ctx->st;
     a.subcap = ctx->lists[list].cap / NSUB;
-    a.kept_subcap = ctx->lists[LIST_KEPT].cap / NSUB;
+    a.kept_wcap = ctx->lists[LIST_KEPT].cap / PROC_WAVES;
     a.list = list;
     a.first_counted = first_counted;
     a.tf_a = tf_a; a.tf_b = tf_b;
@@ -431,22 +475,19 @@ int enqueue_flow(cvo_hip_ctx *ctx, bool tf_moving, int check_done, bool do_math,
     const int tfm = tf_moving ? 1 : 0;
     int rlo, rhi, slo, shi;
     shard_ranges(ctx, rlo, rhi, slo, shi);
-    int rc = enqueue_filter(ctx, LIST_XY, ctx->fixed.pos, rlo, rhi, 0, ctx->moving.pos,
-                            ctx->moving.n, tfm, check_done);
+    int rc = enqueue_filter(ctx, LIST_XY, ctx->fixed, rlo, rhi, 0, ctx->moving, tfm, check_done);
     if (rc) return rc;
     rc = enqueue_process(ctx, PROC_FLOW, LIST_XY, ctx->part_flow, ctx->fixed.pos, ctx->fixed.feat,
                          0, ctx->moving.pos, ctx->moving.feat, tfm, 0, check_done);
     if (rc) return rc;
     if (acvo) {
         // Axx rows of this shard vs all of x; Ayy rows of this shard vs all of y
-        rc = enqueue_filter(ctx, LIST_XX, ctx->fixed.pos, rlo, rhi, 0, ctx->fixed.pos, ctx->fixed.n,
-                            0, check_done);
+        rc = enqueue_filter(ctx, LIST_XX, ctx->fixed, rlo, rhi, 0, ctx->fixed, 0, check_done);
         if (rc) return rc;
         rc = enqueue_process(ctx, PROC_SELF, LIST_XX, ctx->part_xx, ctx->fixed.pos, ctx->fixed.feat,
                              0, ctx->fixed.pos, ctx->fixed.feat, 0, 0, check_done);
         if (rc) return rc;
-        rc = enqueue_filter(ctx, LIST_YY, ctx->moving.pos, slo, shi, tfm, ctx->moving.pos,
-                            ctx->moving.n, tfm, check_done);
+        rc = enqueue_filter(ctx, LIST_YY, ctx->moving, slo, shi, tfm, ctx->moving, tfm, check_done);
         if (rc) return rc;
         rc = enqueue_process(ctx, PROC_SELF, LIST_YY, ctx->part_yy, ctx->moving.pos,
                              ctx->moving.feat, tfm, ctx->moving.pos, ctx->moving.feat, tfm,
@@ -492,6 +533,7 @@ int enqueue_step(cvo_hip_ctx *ctx, int check_done, bool do_math, cvo_hip_trace *
     pa.trace = trace; pa.trace_cap = trace_cap;
     pa.check_done = check_done;
     pa.part_step = (const double *)ctx->part_step.p;
+    pa.dbg = ctx->post_dbg;
     if (multi_rank(ctx)) {
         pa.flags = POST_REDUCE;
         launch_post_step(pa, ctx->stream);
@@ -670,6 +712,10 @@ int cvo_hip_create(int device, void *stream, const cvo_hip_params *p, cvo_hip_ct
     for (int i = 0; i < kPollSlots; ++i)
         if (hipEventCreateWithFlags(&ctx->poll_ev[i], hipEventDisableTiming) != hipSuccess)
             return bail(CVO_HIP_ERR_HIP);
+    if (getenv("CVO_HIP_POST_DEBUG")) {
+        if (hipMalloc((void **)&ctx->post_dbg, 8 * sizeof(long long)) != hipSuccess) return bail(CVO_HIP_ERR_NOMEM);
+        (void)hipMemset(ctx->post_dbg, 0, 8 * sizeof(long long));
+    }
     *out = ctx;
     return CVO_HIP_OK;
 }
@@ -683,11 +729,19 @@ int cvo_hip_destroy(cvo_hip_ctx *ctx)
     for (int i = 0; i < kPollSlots; ++i)
         if (ctx->poll_ev[i]) hipEventDestroy(ctx->poll_ev[i]);
     if (ctx->comm) cvo_comm_destroy(ctx->comm);
+    if (ctx->post_dbg) {
+        long long h[8];
+        if (hipMemcpy(h, ctx->post_dbg, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess && h[0] > 0)
+            fprintf(stderr, "[cvo_hip] k_post_step over %lld launches, avg ticks: state load %.0f, reduce %.0f, "
+                    "cubic %.0f, exp+update %.0f, prepare %.0f\n", h[0], (double)h[1] / h[0], (double)h[2] / h[0],
+                    (double)h[3] / h[0], (double)h[4] / h[0], (double)h[5] / h[0]);
+        (void)hipFree(ctx->post_dbg);
+    }
     for (void *p : {(void *)ctx->fixed.pos, (void *)ctx->fixed.feat, (void *)ctx->moving.pos,
-                    (void *)ctx->moving.feat, (void *)ctx->st, ctx->part_flow.p, ctx->part_xx.p,
+                    (void *)ctx->moving.feat, (void *)ctx->fixed.seg, (void *)ctx->moving.seg, (void *)ctx->st, ctx->part_flow.p, ctx->part_xx.p,
                     ctx->part_yy.p, ctx->part_step.p, (void *)ctx->trace_dev,
                     ctx->lists[0].a.p, ctx->lists[1].a.p, ctx->lists[2].a.p, ctx->lists[3].a.p,
-                    ctx->lists[3].b.p})
+                    ctx->lists[3].b.p, ctx->kept_cnt.p})
         if (p) (void)hipFree(p);
     if (ctx->st_host) (void)hipHostFree(ctx->st_host);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -835,8 +889,7 @@ int cvo_hip_step_coeffs(cvo_hip_ctx *ctx, const float omega[3], const float v[3]
     shard_ranges(ctx, rlo, rhi, slo, shi);
     for (bool redo = true; redo;) {
         rc = zero_counters(ctx);
-        if (!rc) rc = enqueue_filter(ctx, LIST_XY, ctx->fixed.pos, rlo, rhi, 0, ctx->moving.pos,
-                                     ctx->moving.n, 1, 0);
+        if (!rc) rc = enqueue_filter(ctx, LIST_XY, ctx->fixed, rlo, rhi, 0, ctx->moving, 1, 0);
         if (!rc) rc = enqueue_process(ctx, PROC_FLOW, LIST_XY, ctx->part_flow, ctx->fixed.pos,
                                       ctx->fixed.feat, 0, ctx->moving.pos, ctx->moving.feat, 1, 0, 0);
         if (!rc) rc = check_overflow_and_grow(ctx, &redo);
@@ -1025,8 +1078,7 @@ int cvo_hip_function_inner_product(cvo_hip_ctx *ctx, float ell, float *out)
     pa.flags = POST_REDUCE;
     for (bool redo = true; redo;) {
         rc = zero_counters(ctx);
-        if (!rc) rc = enqueue_filter(ctx, LIST_XY, ctx->fixed.pos, rlo, rhi, 0, ctx->moving.pos,
-                                     ctx->moving.n, 0, 0);
+        if (!rc) rc = enqueue_filter(ctx, LIST_XY, ctx->fixed, rlo, rhi, 0, ctx->moving, 0, 0);
         if (!rc) rc = enqueue_process(ctx, PROC_FLOW, LIST_XY, ctx->part_flow, ctx->fixed.pos,
                                       ctx->fixed.feat, 0, ctx->moving.pos, ctx->moving.feat, 0, 0, 0);
         if (!rc) rc = check_overflow_and_grow(ctx, &redo);

@@ -28,33 +28,33 @@ constexpr int ROWS_PER_WAVE = 16 * TILES_PER_WAVE;
 constexpr int ROWS_PER_TILE = 4 * ROWS_PER_WAVE;   // rows per block
 constexpr float PAD_BIG = 1.0e30f;  // filter value of padded rows / columns
 constexpr int PROC_BLOCKS = 1024;   // grid of the list kernels
+constexpr int PROC_WAVES = PROC_BLOCKS * 4;
 
 // Two kinds of lists live in HBM, both split into NSUB independent sub-lists
 // (own counter, own slice of the buffer): one hot atomic counter saturates near
 // 90 appends/us on this chip (MI355X_MICROARCH "dequeue"), 256 of them do not,
 // and scattering appends over them round-robin balances the consumers.
-//   tile list  : what k_filter emits.  One TileEntry per 16x16 pair tile that
-//                has at least one pair under the filter bound: the tile's first
-//                row / column and a 256-bit mask (4 ballots, one per MFMA result
-//                register: bit l of m[r] <-> row (l>>4)*4+r, column l&15).
+//   tile list  : what k_filter emits.  One TileEntry per MFMA result register
+//                of a 16x16 pair tile that has at least one pair under the
+//                filter bound: the tile's first row / column, the register r
+//                and the wave ballot: bit l <-> row (l>>4)*4 + r, column l&15.
+//                At most 64 pairs per entry = one full wavefront of exact work.
 //   kept list  : what PROC_FLOW emits: the members of A as (i, j) + weight,
 //                i.e. the reference's triplets (ref src/cvo.cpp:152) in COO form;
-//                PROC_STEP streams it.
-// Producers stage their appends in LDS and reserve an exactly-sized slice with
-// one returning atomic when the stage is full or the wave ends: no holes.
+//                PROC_STEP streams it.  It needs no atomics: wave w of PROC_FLOW
+//                owns slice w (kept_cap / PROC_WAVES entries) and records its count;
+//                wave w of PROC_STEP reads slice w back.
+// k_filter stages its appends in LDS and reserves an exactly-sized slice of a
+// sub-list with one returning atomic when the stage is full or the wave ends.
 constexpr int NSUB = 256;
 constexpr int PROC_PARTS = PROC_BLOCKS / NSUB;   // blocks cooperating on one sub-list
-constexpr int TILE_STAGE = 64;      // TileEntry slots staged per wave in k_filter
-constexpr int KEPT_STAGE = 512;     // kept triplets staged per wave in PROC_FLOW
+constexpr int TILE_STAGE = 128;     // TileEntry slots staged per wave in k_filter
 constexpr int PAIR_QUEUE = 128;     // compaction queue of a k_process wave
+constexpr int SEG = 64;             // points per bounding-sphere segment (= rows of a filter wave)
+constexpr int MAX_CSEG = 32;        // column segments of a filter block (jt <= 2048)
 
-struct __attribute__((aligned(16))) TileEntry {
-    uint32_t row, col;    // first row / column of the tile (device order)
-    uint32_t npairs;      // popcount of the mask
-    uint32_t pad_;
-    uint64_t m[4];
-};
-static_assert(sizeof(TileEntry) == 48, "TileEntry is three 16-byte words");
+// x = first row of the tile, y = first column | r << 30, z/w = the 64-bit mask
+typedef uint4 TileEntry;
 
 enum ProcMode { PROC_FLOW = 0, PROC_STEP = 1, PROC_SELF = 2 };
 // lists: three tile lists + the kept list
@@ -136,13 +136,15 @@ constexpr size_t DEVSTATE_HEAD_BYTES = offsetof(DevState, sub);
 struct FilterArgs {
     const float4 *pos_a;
     const float4 *pos_b;
+    const float4 *seg_a;   // bounding spheres (centre, radius) of every SEG device points
+    const float4 *seg_b;   // ... of the ORIGINAL positions; centres are moved with [Rt|t]
     DevState *st;          // Rt, t, center, tauf, done; sub[list][] is appended to
     TileEntry *tiles;      // the tile list
     uint32_t subcap;       // capacity (entries) of each of its NSUB sub-lists
     int list;              // LIST_XY / LIST_XX / LIST_YY: selects tauf[] and sub[]
     int row_lo, row_hi;
     int nb;
-    int jt;                // columns per block chunk (multiple of 16)
+    int jt;                // columns per block chunk (multiple of SEG)
     int tf_a, tf_b;        // apply [Rt|t] to the row / column cloud while staging
     int check_done;        // return at once when st->done != 0
     long long *dbg;        // probe only (tools/microbench): per-wave phase clocks, else null
@@ -155,12 +157,13 @@ struct ProcessArgs {
     const float4 *pos_b;
     const float *feat_b;
     const TileEntry *tiles;
-    uint2 *kept_ij;        // kept list: PROC_FLOW appends, PROC_STEP reads
+    uint2 *kept_ij;        // kept list: PROC_FLOW writes, PROC_STEP reads
     float *kept_a;
+    uint32_t *kept_cnt;    // [PROC_WAVES] members recorded by each PROC_FLOW wave
     double *partials;      // [PROC_BLOCKS][nacc]
     DevState *st;
     uint32_t subcap;       // of the tile list
-    uint32_t kept_subcap;  // of the kept list
+    uint32_t kept_wcap;    // kept-list slice of one wave (entries)
     int list;              // which tile list
     int row_hi, nb;        // valid rows / columns (mask bits beyond are padding)
     int first_counted;     // PROC_SELF: rows whose caller index is below contribute 0 to the sum
@@ -188,6 +191,7 @@ struct PostStepArgs {
     cvo_hip_trace *trace; int trace_cap;
     int flags;
     int check_done;
+    long long *dbg;        // diagnostics only (CVO_HIP_POST_DEBUG): phase clocks of thread 0
     DevParams prm;
 };
 

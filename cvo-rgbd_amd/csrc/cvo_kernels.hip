@@ -62,9 +62,21 @@ __device__ __forceinline__ float mv_row(const float *m, float x, float y, float 
 //                                  16 columns k-major: [-2y'0 x16][-2y'1 x16][-2y'2 x16][|y'|^2 x16]
 //   xrow  [ROWS_PER_TILE] float4 : (x'0, x'1, x'2, |x'|^2) of the block's rows
 //   stage [4][TILE_STAGE] TileEntry : per-wave staging of the tile entries
+//   near  [4][MAX_CSEG] u32      : which (wave, column segment) pairs can hold a pair
 size_t filter_smem_bytes(int jt)
 {
-    return (size_t)jt * 16 + ROWS_PER_TILE * 16 + 4 * TILE_STAGE * sizeof(TileEntry);
+    return (size_t)jt * 16 + ROWS_PER_TILE * 16 + 4 * TILE_STAGE * sizeof(TileEntry) +
+           4 * MAX_CSEG * 4;
+}
+
+// Can a point of sphere a be within sqrt(tauf) of a point of sphere b?
+// Conservative against float32 rounding (relative and absolute slack).
+__device__ __forceinline__ bool spheres_near(const float4 sa, const float4 sb, float reach)
+{
+    const float ex = sa.x - sb.x, ey = sa.y - sb.y, ez = sa.z - sb.z;
+    const float d2 = __builtin_fmaf(ez, ez, __builtin_fmaf(ey, ey, ex * ex));
+    const float rr = (sa.w + sb.w + reach) * 1.00001f + 1e-5f;
+    return d2 * 0.99999f <= rr * rr;
 }
 
 // append the wave's `n` staged tile entries to sub-list `sub` (exact-size slice)
@@ -77,7 +89,7 @@ __device__ __forceinline__ void flush_tiles(const TileEntry *stage, int n, int l
     if (base + (unsigned)n <= a.subcap) {
         const uint4 *src = reinterpret_cast<const uint4 *>(stage);
         uint4 *dst = reinterpret_cast<uint4 *>(a.tiles + (size_t)sub * a.subcap + base);
-        for (int w = lane; w < n * 3; w += 64) dst[w] = src[w];
+        for (int w = lane; w < n; w += 64) dst[w] = src[w];
     } else if (lane == 0) {
         atomicOr(&a.st->cnt[2 * a.list + 1], 1u);   // overflow: the host grows the list and resumes
     }
@@ -87,12 +99,16 @@ __global__ void __launch_bounds__(BLOCK) k_filter(const FilterArgs a)
 {
     const long long t_start = a.dbg ? (long long)__builtin_readcyclecounter() : 0;
     const long long w_start = a.dbg ? (long long)wall_clock64() : 0;
-    if (a.check_done && a.st->done != 0) return;
+    // first round trip: the loop-control word, the state constants and this
+    // thread's bounding spheres are all fetched before anything waits
+    const int done_word = a.check_done ? a.st->done : 0;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float *bop = reinterpret_cast<float *>(smem);
     float4 *xrow = reinterpret_cast<float4 *>(smem + (size_t)a.jt * 16);
     TileEntry *stage_all =
         reinterpret_cast<TileEntry *>(smem + (size_t)a.jt * 16 + ROWS_PER_TILE * 16);
+    unsigned *nearf = reinterpret_cast<unsigned *>(smem + (size_t)a.jt * 16 + ROWS_PER_TILE * 16 +
+                                                   4 * TILE_STAGE * sizeof(TileEntry));
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -105,6 +121,48 @@ __global__ void __launch_bounds__(BLOCK) k_filter(const FilterArgs a)
     const float *tt = a.st->t;
     const float cx = a.st->center[0], cy = a.st->center[1], cz = a.st->center[2];
     const float tauf = a.st->tauf[a.list];
+
+    // ---- culling.  The clouds are in Morton order, so the 64 rows of a wave and
+    // every run of 64 columns are compact patches with precomputed bounding
+    // spheres (rigid motion moves a sphere's centre, not its radius).  A (wave,
+    // column segment) pair whose spheres are more than sqrt(tauf) apart cannot
+    // hold a pair with d2 < tau; a block with no near pair at all exits here.
+    const int ncseg = (jn + SEG - 1) / SEG;
+    {
+        bool near = false;
+        {
+            // thread -> (wave w, column segment u); clamped so that every thread can
+            // load unconditionally (the rows of a wave touch at most two segments)
+            const int tcl = min(tid, 4 * ncseg - 1);
+            const int w = tcl / ncseg, u = tcl - w * ncseg;
+            const int r_first = row0 + w * ROWS_PER_WAVE;
+            const int r_last = min(r_first + ROWS_PER_WAVE, a.row_hi) - 1;
+            const int last_seg = (a.row_hi - 1) >> 6;
+            const int sg0 = min(r_first >> 6, last_seg), sg1 = min(max(r_last, r_first) >> 6, last_seg);
+            float4 sb = a.seg_b[(j0 >> 6) + u];
+            float4 sa0 = a.seg_a[sg0], sa1 = a.seg_a[sg1];
+            if (done_word != 0) return;   // first wait: everything above is in flight
+            if (tid < 4 * ncseg && r_first < a.row_hi) {
+                const float reach = sqrtf(tauf);
+                if (a.tf_b) { const float r = sb.w; sb = apply_tf(Rt, tt, sb); sb.w = r; }
+                if (a.tf_a) {
+                    float r = sa0.w; sa0 = apply_tf(Rt, tt, sa0); sa0.w = r;
+                    r = sa1.w; sa1 = apply_tf(Rt, tt, sa1); sa1.w = r;
+                }
+                near = spheres_near(sa0, sb, reach) || spheres_near(sa1, sb, reach);
+            }
+            if (tid < 4 * ncseg) nearf[w * MAX_CSEG + u] = near ? 1u : 0u;
+        }
+        if (!__syncthreads_or(near ? 1 : 0)) {
+            if (a.dbg && lane == 0) {   // probe: a culled block
+                long long *o = a.dbg + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 4 + wid) * 8;
+                const long long now = (long long)__builtin_readcyclecounter();
+                o[0] = t_start; o[1] = now; o[2] = now; o[3] = now; o[4] = -1; o[5] = 0;
+                o[6] = w_start; o[7] = (long long)wall_clock64();
+            }
+            return;
+        }
+    }
 
     // ---- prologue.  Every global load is issued before anything waits on one
     // (clamped addresses instead of control flow), so the block pays ONE memory
@@ -162,10 +220,10 @@ __global__ void __launch_bounds__(BLOCK) k_filter(const FilterArgs a)
     const unsigned rbase = (unsigned)(row0 + wid * ROWS_PER_WAVE);
 
     const long long t_loop = a.dbg ? (long long)__builtin_readcyclecounter() : 0;
-    float bnext = bop[lane];
+    const unsigned *mynear = nearf + wid * MAX_CSEG;
     for (int g = 0; g < ngroups; ++g) {
-        const float b = bnext;
-        if (g + 1 < ngroups) bnext = bop[(g + 1) * 64 + lane];   // prefetch the next column tile
+        if ((g & 3) == 0 && mynear[g >> 2] == 0u) { g += 3; continue; }   // culled column segment
+        const float b = bop[g * 64 + lane];
         f32x4 d[TILES_PER_WAVE];
 #pragma unroll
         for (int t = 0; t < TILES_PER_WAVE; ++t)
@@ -177,29 +235,34 @@ __global__ void __launch_bounds__(BLOCK) k_filter(const FilterArgs a)
             ort[t] = (__float_as_int(d[t][0]) | __float_as_int(d[t][1])) |
                      (__float_as_int(d[t][2]) | __float_as_int(d[t][3]));
         if (__ballot(((ort[0] | ort[1]) | (ort[2] | ort[3])) < 0) == 0ull) continue;
-        // a tile with survivors: its four ballots ARE the 256-bit pair mask
+        // Every result register with survivors becomes one entry: its ballot IS the
+        // pair mask.  All 16 ballots are taken, lane k (< 16) adopts mask k, and the
+        // lanes with a non-empty mask write their entries in one LDS store.
+        unsigned mlo = 0u, mhi = 0u;
 #pragma unroll
         for (int t = 0; t < TILES_PER_WAVE; ++t) {
-            if (__ballot(ort[t] < 0) == 0ull) continue;
-            const unsigned long long m0 = __ballot(d[t][0] < 0.0f), m1 = __ballot(d[t][1] < 0.0f),
-                                     m2 = __ballot(d[t][2] < 0.0f), m3 = __ballot(d[t][3] < 0.0f);
-            if (lane == 0) {
-                TileEntry te;
-                te.row = rbase + (unsigned)t * 16u;
-                te.col = (unsigned)(j0 + g * 16);
-                te.npairs = (unsigned)(__popcll(m0) + __popcll(m1) + __popcll(m2) + __popcll(m3));
-                te.pad_ = 0u;
-                te.m[0] = m0; te.m[1] = m1; te.m[2] = m2; te.m[3] = m3;
-                stage[ne] = te;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const unsigned long long m = __ballot(d[t][r] < 0.0f);
+                if (lane == t * 4 + r) { mlo = (unsigned)m; mhi = (unsigned)(m >> 32); }
             }
-            if (++ne == TILE_STAGE) {
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                flush_tiles(stage, ne, lane, (sub++) & (NSUB - 1), a);
-                __builtin_amdgcn_wave_barrier();
-                ne = 0;
-            }
+        }
+        const bool has = (mlo | mhi) != 0u;   // only lanes < 16 can be true
+        const unsigned long long nz = __ballot(has);
+        if (has) {
+            const unsigned below = __builtin_amdgcn_mbcnt_lo((unsigned)nz, 0u);
+            stage[ne + below] = make_uint4(rbase + (unsigned)(lane >> 2) * 16u,
+                                           (unsigned)(j0 + g * 16) | ((unsigned)(lane & 3) << 30),
+                                           mlo, mhi);
+        }
+        ne += __popcll(nz);
+        if (ne > TILE_STAGE - 16) {   // no room for another full group: flush (rare)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            flush_tiles(stage, ne, lane, (sub++) & (NSUB - 1), a);
+            __builtin_amdgcn_wave_barrier();
+            ne = 0;
         }
     }
     const long long t_tail = a.dbg ? (long long)__builtin_readcyclecounter() : 0;
@@ -240,13 +303,9 @@ __device__ __forceinline__ float d2_feat(const float4 fa0, const float fa4, cons
 }
 
 // pair weight for a pair that passed d2 < tau; 0 if dropped (ref cvo.cpp:143-153)
-__device__ __forceinline__ float pair_weight(const KernConsts &kc, float d2, const float *feat_a,
-                                             unsigned i, const float *feat_b, unsigned j)
+__device__ __forceinline__ float pair_weight(const KernConsts &kc, float d2, const float4 fa0,
+                                             const float fa4, const float4 fb0, const float fb4)
 {
-    const float4 fa0 = *reinterpret_cast<const float4 *>(feat_a + (size_t)i * FEAT_STRIDE);
-    const float fa4 = feat_a[(size_t)i * FEAT_STRIDE + 4];
-    const float4 fb0 = *reinterpret_cast<const float4 *>(feat_b + (size_t)j * FEAT_STRIDE);
-    const float fb4 = feat_b[(size_t)j * FEAT_STRIDE + 4];
     const float d2c = d2_feat(fa0, fa4, fb0, fb4);
     if (!(d2c < kc.tau_c)) return 0.0f;
     const float k = (float)(kc.s2_d * exp((double)d2 * kc.ninv_2l2));
@@ -272,12 +331,22 @@ __device__ __forceinline__ float eval_pair(const ProcessArgs &a, const KernConst
     float4 xi = a.pos_a[i];
     if (a.tf_a) xi = apply_tf(Rt, tt, xi);
     float4 yj = a.pos_b[j];
+    // the features are fetched together with the positions (one memory round
+    // trip per pair instead of two); ~97 % of the filtered pairs need them
+    float4 fa0 = make_float4(0.f, 0.f, 0.f, 0.f), fb0 = fa0;
+    float fa4 = 0.f, fb4 = 0.f;
+    if (MODE != PROC_STEP) {
+        fa0 = *reinterpret_cast<const float4 *>(a.feat_a + (size_t)i * FEAT_STRIDE);
+        fa4 = a.feat_a[(size_t)i * FEAT_STRIDE + 4];
+        fb0 = *reinterpret_cast<const float4 *>(a.feat_b + (size_t)j * FEAT_STRIDE);
+        fb4 = a.feat_b[(size_t)j * FEAT_STRIDE + 4];
+    }
     if (a.tf_b) yj = apply_tf(Rt, tt, yj);
     const float e0 = xi.x - yj.x, e1 = xi.y - yj.y, e2 = xi.z - yj.z;
     float d2 = 0.0f;
     if (MODE != PROC_STEP) {
         d2 = __builtin_fmaf(e2, e2, __builtin_fmaf(e1, e1, e0 * e0));
-        w = (d2 < kc.tau) ? pair_weight(kc, d2, a.feat_a, i, a.feat_b, j) : 0.0f;
+        w = (d2 < kc.tau) ? pair_weight(kc, d2, fa0, fa4, fb0, fb4) : 0.0f;
     }
     if (!(w > 0.0f)) return 0.0f;
     if (MODE == PROC_FLOW) {
@@ -336,65 +405,53 @@ __device__ __forceinline__ float eval_pair(const ProcessArgs &a, const KernConst
     return w;
 }
 
-// per-wave LDS of a PROC_FLOW / PROC_SELF block
-struct __attribute__((aligned(16))) ProcWaveLds {
-    uint2 pairq[PAIR_QUEUE];     // compaction queue of (row, column)
-    uint2 kept_ij[KEPT_STAGE];   // staged members of A (PROC_FLOW)
-    float kept_a[KEPT_STAGE];
-};
-
-// append the wave's `n` staged kept triplets to the kept list (exact-size slice)
-__device__ __forceinline__ void flush_kept(const ProcWaveLds *L, int n, int lane, unsigned sub,
-                                           const ProcessArgs &a)
-{
-    unsigned base = 0;
-    if (lane == 0) base = atomicAdd(&a.st->sub[LIST_KEPT][sub], (unsigned)n);
-    base = __builtin_amdgcn_readfirstlane(base);
-    if (base + (unsigned)n <= a.kept_subcap) {
-        const size_t o = (size_t)sub * a.kept_subcap + base;
-        for (int t = lane; t < n; t += 64) {
-            a.kept_ij[o + t] = L->kept_ij[t];
-            a.kept_a[o + t] = L->kept_a[t];
-        }
-    } else if (lane == 0) {
-        atomicOr(&a.st->cnt[2 * LIST_KEPT + 1], 1u);
-    }
-}
-
 template <int MODE>
 __global__ void __launch_bounds__(BLOCK) k_process(const ProcessArgs a)
 {
     constexpr int NACC = NAcc<MODE>::n;
-    if (a.check_done && a.st->done != 0) return;
     __shared__ double red[4 * NACC_MAX];
-    __shared__ ProcWaveLds wl[(MODE == PROC_STEP) ? 1 : 4];
+    __shared__ uint2 pairq_all[(MODE == PROC_STEP) ? 1 : 4 * PAIR_QUEUE];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned wave = blockIdx.x * 4u + (unsigned)wid;   // 0 .. PROC_WAVES-1
+    // first round trip: loop-control word, kernel constants, list sizes
+    const int done_word = a.check_done ? a.st->done : 0;
     const KernConsts kc = a.st->kc;
-    // PROC_PARTS blocks share one sub-list
-    const unsigned sub = blockIdx.x & (NSUB - 1), part = blockIdx.x / NSUB;
 
     double acc[NACC];
 #pragma unroll
     for (int k = 0; k < NACC; ++k) acc[k] = 0.0;
 
     if (MODE == PROC_STEP) {
-        // stream the members of A recorded by PROC_FLOW
-        unsigned n = a.st->sub[LIST_KEPT][sub];
-        if (n > a.kept_subcap) n = a.kept_subcap;
-        const size_t sbase = (size_t)sub * a.kept_subcap;
-        for (unsigned off = part * BLOCK + tid; off < n; off += PROC_PARTS * BLOCK) {
-            const uint2 e = a.kept_ij[sbase + off];
-            eval_pair<MODE>(a, kc, e.x, e.y, a.kept_a[sbase + off], acc);
+        // stream the members of A that wave `wave` of PROC_FLOW recorded
+        const size_t base = (size_t)wave * a.kept_wcap;
+        unsigned n = a.kept_cnt[wave];
+        // the first entries are fetched together with the count
+        uint2 e = a.kept_ij[base + lane];
+        float w = a.kept_a[base + lane];
+        if (done_word != 0) return;
+        if (n > a.kept_wcap) n = a.kept_wcap;
+        for (unsigned off = lane; off < n; off += 64) {
+            if (off >= 64) { e = a.kept_ij[base + off]; w = a.kept_a[base + off]; }
+            eval_pair<MODE>(a, kc, e.x, e.y, w, acc);
         }
     } else {
-        ProcWaveLds *L = &wl[wid];
+        // PROC_PARTS blocks share one sub-list of the tile list
+        const unsigned sub = blockIdx.x & (NSUB - 1), part = blockIdx.x / NSUB;
         unsigned n = a.st->sub[a.list][sub];
-        if (n > a.subcap) n = a.subcap;   // overflowed list: the iteration is redone anyway
         const TileEntry *tl = a.tiles + (size_t)sub * a.subcap;
+        // The 4 * PROC_PARTS waves of this sub-list take its entries in turn, 64 at
+        // a time: lane l fetches the wave's l-th entry of the round (one memory
+        // round trip per 64 entries, the first one together with the count).
+        const unsigned stride = 4u * PROC_PARTS;
+        const unsigned e0 = part * 4u + (unsigned)wid;
+        TileEntry mine = tl[min(e0 + (unsigned)lane * stride, a.subcap - 1)];
+        if (done_word != 0) return;
+        if (n > a.subcap) n = a.subcap;   // overflowed list: the iteration is redone anyway
+        uint2 *pairq = pairq_all + wid * PAIR_QUEUE;
         int qn = 0;   // wave-uniform: queued pairs
-        int nk = 0;   // wave-uniform: staged kept triplets
-        unsigned ksub = (blockIdx.x * 4u + (unsigned)wid) * 37u;
+        unsigned nk = 0;   // wave-uniform: members of A recorded so far
+        const size_t kbase = (size_t)wave * a.kept_wcap;
         // evaluate the queued pairs q[base .. base+cnt) (cnt <= 64, wave-uniform)
         auto run_batch = [&](int base, int cnt) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -403,43 +460,42 @@ __global__ void __launch_bounds__(BLOCK) k_process(const ProcessArgs a)
             float w = 0.0f;
             uint2 pr = make_uint2(0u, 0u);
             if (lane < cnt) {
-                pr = L->pairq[base + lane];
+                pr = pairq[base + lane];
                 w = eval_pair<MODE>(a, kc, pr.x, pr.y, 0.0f, acc);
             }
-            if (MODE == PROC_FLOW) {   // record the members of A
+            if (MODE == PROC_FLOW) {   // record the members of A in this wave's slice
                 const unsigned long long km = __ballot(w > 0.0f);
-                if (w > 0.0f) {
-                    const unsigned below = __builtin_amdgcn_mbcnt_hi(
-                        (unsigned)(km >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)km, 0u));
-                    L->kept_ij[nk + below] = pr;
-                    L->kept_a[nk + below] = w;
+                const unsigned add = (unsigned)__popcll(km);
+                if (nk + add <= a.kept_wcap) {
+                    if (w > 0.0f) {
+                        const unsigned below = __builtin_amdgcn_mbcnt_hi(
+                            (unsigned)(km >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)km, 0u));
+                        a.kept_ij[kbase + nk + below] = pr;
+                        a.kept_a[kbase + nk + below] = w;
+                    }
+                } else if (lane == 0) {
+                    atomicOr(&a.st->cnt[2 * LIST_KEPT + 1], 1u);   // slice full: grow and redo
                 }
-                nk += __popcll(km);
-                if (nk > KEPT_STAGE - 64) {
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                    flush_kept(L, nk, lane, (ksub++) & (NSUB - 1), a);
-                    nk = 0;
-                }
+                nk += add;
             }
             __builtin_amdgcn_wave_barrier();
         };
-        // the 4 * PROC_PARTS waves of this sub-list take its tile entries in turn
-        for (unsigned e = part * 4u + (unsigned)wid; e < n; e += 4u * PROC_PARTS) {
-            // expand the tile's 256-bit mask into the queue: bit l of m[r] is
-            // row (l>>4)*4 + r, column l&15 of the tile
-            const TileEntry *te = tl + e;
-            const unsigned trow = te->row, tcol = te->col;
-#pragma unroll 1
-            for (int r = 0; r < 4; ++r) {
-                const unsigned long long m = te->m[r];
-                if (m == 0ull) continue;
+        for (unsigned eb = e0; eb < n; eb += 64u * stride) {
+            if (eb != e0) mine = tl[min(eb + (unsigned)lane * stride, a.subcap - 1)];
+            const unsigned left = (n - eb + stride - 1) / stride;   // entries of this round
+            const int cnt = (int)(left < 64u ? left : 64u);
+            for (int k = 0; k < cnt; ++k) {
+                // broadcast lane k's entry and expand its mask into the queue:
+                // bit l is row (l>>4)*4 + r, column l&15 of the tile
+                const unsigned tx = __shfl(mine.x, k, 64), ty = __shfl(mine.y, k, 64);
+                const unsigned long long m = (unsigned long long)__shfl(mine.z, k, 64) |
+                                             ((unsigned long long)__shfl(mine.w, k, 64) << 32);
+                const unsigned r = ty >> 30, tcol = ty & 0x3fffffffu;
                 if ((m >> lane) & 1ull) {
                     const unsigned below = __builtin_amdgcn_mbcnt_hi(
                         (unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-                    L->pairq[qn + below] = make_uint2(trow + (unsigned)((lane >> 4) * 4 + r),
-                                                      tcol + (unsigned)(lane & 15));
+                    pairq[qn + below] =
+                        make_uint2(tx + (unsigned)(lane >> 4) * 4u + r, tcol + (unsigned)(lane & 15));
                 }
                 qn += __popcll(m);
                 if (qn >= 64) {
@@ -449,12 +505,7 @@ __global__ void __launch_bounds__(BLOCK) k_process(const ProcessArgs a)
             }
         }
         if (qn > 0) run_batch(0, qn);
-        if (MODE == PROC_FLOW && nk > 0) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            flush_kept(L, nk, lane, ksub & (NSUB - 1), a);
-        }
+        if (MODE == PROC_FLOW && lane == 0) a.kept_cnt[wave] = nk;
     }
 
     // block reduction: xor butterfly inside each wave, then the 4 waves in order
@@ -491,7 +542,7 @@ void launch_process(int mode, const ProcessArgs &a, hipStream_t s)
 // Fixed-order reduction of partials[nblocks][NACC] by one 256-thread block:
 // thread t adds blocks t, t+256, ...; xor butterfly inside each wave; the four
 // wave sums are added in wave order.
-template <int NACC>
+template <int NACC, int NPART = PROC_BLOCKS>
 __device__ void block_reduce_partials(const double *part, int nblocks, double *sh /*[4*NACC_MAX]*/,
                                       double *out /*[NACC], thread 0 writes*/)
 {
@@ -499,9 +550,14 @@ __device__ void block_reduce_partials(const double *part, int nblocks, double *s
     double s[NACC];
 #pragma unroll
     for (int k = 0; k < NACC; ++k) s[k] = 0.0;
-    for (int b = tid; b < nblocks; b += BLOCK) {
+    // nblocks == PROC_BLOCKS: a fixed trip count, fully unrolled, so that all the
+    // loads are in flight together (one memory round trip, not one per step)
+    static_assert(NPART % BLOCK == 0, "partials per thread must be whole");
 #pragma unroll
-        for (int k = 0; k < NACC; ++k) s[k] += part[(size_t)b * NACC + k];
+    for (int u = 0; u < NPART / BLOCK; ++u) {
+        const int b = tid + u * BLOCK;
+#pragma unroll
+        for (int k = 0; k < NACC; ++k) s[k] += (b < nblocks) ? part[(size_t)b * NACC + k] : 0.0;
     }
 #pragma unroll
     for (int k = 0; k < NACC; ++k) {
@@ -519,10 +575,59 @@ __device__ void block_reduce_partials(const double *part, int nblocks, double *s
     __syncthreads();
 }
 
+// The head of DevState (everything in front of the sub-list counters) moves
+// between HBM and LDS cooperatively: the O(1) maths then pays LDS latency per
+// field instead of one memory round trip per dependent access.
+__device__ __forceinline__ void state_head_to_lds(const DevState *g, DevState *l)
+{
+    const uint32_t *src = reinterpret_cast<const uint32_t *>(g);
+    uint32_t *dst = reinterpret_cast<uint32_t *>(l);
+    for (int q = threadIdx.x; q < (int)(DEVSTATE_HEAD_BYTES / 4); q += BLOCK) dst[q] = src[q];
+    __syncthreads();
+}
+
+__device__ __forceinline__ void state_head_from_lds(const DevState *l, DevState *g)
+{
+    const uint32_t *src = reinterpret_cast<const uint32_t *>(l);
+    uint32_t *dst = reinterpret_cast<uint32_t *>(g);
+    for (int q = threadIdx.x; q < (int)(DEVSTATE_HEAD_BYTES / 4); q += BLOCK) dst[q] = src[q];
+}
+
+__device__ void post_step_math(DevState *st, const PostStepArgs &a);
+
+// cvo_math::section_root with one lane per interior point (all 64 lanes of a
+// wave must call it with the same bracket): same arithmetic per point, same
+// selection rule (lowest lane whose point is not left of the root).
+__device__ __forceinline__ double section_root_wave(const cvo_math::CubicBracket &B, int lane)
+{
+    double lo = B.lo, hi = B.hi;
+    for (int round = 0; round < 64; ++round) {
+        if ((float)lo == (float)hi) break;
+        const double w = hi - lo;
+        const double x = cvo_math::section_point(lo, w, lane);
+        const bool inside = x > lo && x < hi;
+        const double f = cvo_math::cubic_eval(B.a, B.b, B.c, x);
+        const bool go_right = inside && (B.increasing ? (f < 0.0) : (f > 0.0));
+        const unsigned long long gm = __ballot(go_right), im = __ballot(inside);
+        const int first = (~gm == 0ull) ? 64 : (int)__builtin_ctzll(~gm);   // serial loop's break index
+        double nlo = lo, nhi = hi;
+        if (first > 0) nlo = __shfl(x, first - 1, 64);
+        if (first < 64 && ((im >> first) & 1ull)) nhi = __shfl(x, first, 64);
+        if (nlo == lo && nhi == hi) break;
+        lo = nlo;
+        hi = nhi;
+    }
+    return hi;
+}
+
 __global__ void __launch_bounds__(BLOCK) k_post_flow(const PostFlowArgs a)
 {
     __shared__ double sh[4 * NACC_MAX];
-    DevState *st = a.st;
+    __shared__ __attribute__((aligned(16))) DevState s_st;
+    // One round trip: every thread fetches a word of the state's head into LDS;
+    // the maths below runs on that copy and the head is written back at the end.
+    state_head_to_lds(a.st, &s_st);
+    DevState *st = &s_st;
     if (a.check_done && st->done != 0) return;
     const bool acvo = a.prm.mode == CVO_HIP_MODE_ACVO;
     if (a.flags & POST_REDUCE) {
@@ -543,10 +648,8 @@ __global__ void __launch_bounds__(BLOCK) k_post_flow(const PostFlowArgs a)
     if ((a.flags & POST_MATH) && threadIdx.x == 0) {
         // nothing of an overflowed iteration is usable; the host enlarges the
         // list and resumes from the same (untouched) state
-        if (st->red[8] != st->red[8]) {
-            st->done = NEED_BIGGER_LIST;
-            return;
-        }
+        const bool overflow = st->red[8] != st->red[8];
+        if (overflow) st->done = NEED_BIGGER_LIST;
         const double *red = st->red;
         float omega[3], v[3];
         for (int q = 0; q < 3; ++q) {
@@ -555,7 +658,7 @@ __global__ void __launch_bounds__(BLOCK) k_post_flow(const PostFlowArgs a)
             st->omega[q] = omega[q];
             st->v[q] = v[q];
         }
-        st->xi = cvo_math::make_xi_consts(omega, v);
+        if (!overflow) st->xi = cvo_math::make_xi_consts(omega, v);
         double dl = 0.0;
         const long long nnz = (long long)red[8];
         long long nnz_xx = 0, nnz_yy = 0;
@@ -566,7 +669,7 @@ __global__ void __launch_bounds__(BLOCK) k_post_flow(const PostFlowArgs a)
             dl = num / (double)(nnz_xx + nnz_yy - 2 * nnz);
         }
         st->dl = dl;
-        if (a.trace && st->k < a.trace_cap) {
+        if (!overflow && a.trace && st->k < a.trace_cap) {
             cvo_hip_trace &tr = a.trace[st->k];
             tr.k = st->k;
             tr.exit_code = 0;
@@ -580,26 +683,47 @@ __global__ void __launch_bounds__(BLOCK) k_post_flow(const PostFlowArgs a)
             tr.nnz = nnz; tr.nnz_xx = nnz_xx; tr.nnz_yy = nnz_yy;
         }
     }
+    __syncthreads();
+    state_head_from_lds(&s_st, a.st);
 }
 
 __global__ void __launch_bounds__(BLOCK) k_post_step(const PostStepArgs a)
 {
     __shared__ double sh[4 * NACC_MAX];
-    DevState *st = a.st;
+    __shared__ __attribute__((aligned(16))) DevState s_st;
+    const long long c0 = a.dbg ? (long long)__builtin_readcyclecounter() : 0;
+    state_head_to_lds(a.st, &s_st);   // one round trip, see k_post_flow
+    DevState *st = &s_st;
     if (a.check_done && st->done != 0) return;
+    const long long c1 = a.dbg ? (long long)__builtin_readcyclecounter() : 0;
     if (a.flags & POST_REDUCE)
         block_reduce_partials<NACC_STEP>(a.part_step, PROC_BLOCKS, sh, st->red + RED_STEP);
-    if (!(a.flags & POST_MATH)) return;
-    // the lists of this iteration have been consumed: empty them for the next one
-    for (int q = threadIdx.x; q < LIST_N * NSUB; q += BLOCK) (&st->sub[0][0])[q] = 0u;
-    if (threadIdx.x != 0) return;
+    if (a.dbg && threadIdx.x == 0) {
+        a.dbg[0] += 1; a.dbg[1] += c1 - c0; a.dbg[2] += (long long)__builtin_readcyclecounter() - c1;
+    }
+    if (a.flags & POST_MATH) {
+        // the lists of this iteration have been consumed: empty them for the next one
+        for (int q = threadIdx.x; q < LIST_N * NSUB; q += BLOCK) (&a.st->sub[0][0])[q] = 0u;
+        if (threadIdx.x < 64) post_step_math(st, a);   // wave 0: the cubic uses all its lanes
+    }
+    __syncthreads();
+    state_head_from_lds(&s_st, a.st);
+}
+
+__device__ void post_step_math(DevState *st, const PostStepArgs &a)
+{
 
     const DevParams &p = a.prm;
     const bool acvo = p.mode == CVO_HIP_MODE_ACVO;
     const int k = st->k;
     double bcde[4];
     for (int q = 0; q < 4; ++q) bcde[q] = st->red[RED_STEP + q];
-    const float step = cvo_math::pick_step(bcde, p.min_step);
+    const long long c2 = a.dbg ? (long long)__builtin_readcyclecounter() : 0;
+    const cvo_math::CubicBracket cb = cvo_math::cubic_bracket(bcde);
+    const float step = cvo_math::finish_step(
+        cb.found, cb.found ? section_root_wave(cb, (int)threadIdx.x) : 0.0, p.min_step);
+    if (threadIdx.x != 0) return;   // the rest is scalar work
+    if (a.dbg) a.dbg[3] += (long long)__builtin_readcyclecounter() - c2;
     float omega[3], v[3];
     for (int q = 0; q < 3; ++q) { omega[q] = st->omega[q]; v[q] = st->v[q]; }
     cvo_hip_trace *tr = (a.trace && k < a.trace_cap) ? &a.trace[k] : nullptr;
@@ -630,6 +754,7 @@ __global__ void __launch_bounds__(BLOCK) k_post_step(const PostStepArgs a)
         return;
     }
     // integrate: T = R*dT + T ; R = R*dR  (ref cvo.cpp:391-399)
+    const long long c3 = a.dbg ? (long long)__builtin_readcyclecounter() : 0;
     float dR[9], dT[3], RdT[3];
     cvo_math::exp_se3(omega, v, step, dR, dT);
     cvo_math::Mat3 R, dRm;
@@ -667,7 +792,9 @@ __global__ void __launch_bounds__(BLOCK) k_post_step(const PostStepArgs a)
         st->done = DONE_MAX_ITER;   // `iter` keeps its stale value
         return;
     }
+    const long long c4 = a.dbg ? (long long)__builtin_readcyclecounter() : 0;
     prepare_iteration(st, p);
+    if (a.dbg) { a.dbg[4] += c4 - c3; a.dbg[5] += (long long)__builtin_readcyclecounter() - c4; }
 }
 
 __global__ void k_prepare(DevState *st, const DevParams prm)

@@ -148,74 +148,112 @@ CVO_HD void sincos_det(double x, double *s_out, double *c_out)
 // clamp to 0.8.  The float coefficients and the float division by the leading
 // one are the reference's (VectorXf p_coef, companion-matrix first row); the
 // roots themselves are bracketed between the stationary points of the monic
-// cubic and bisected to adjacent float64 values (the reference runs a float
-// QR eigen-solve and accepts eigenvalues with imag()==0), then rounded.
+// cubic and refined in float64 until their float32 value is decided (the
+// reference runs a float QR eigen-solve and accepts eigenvalues with imag()==0).
 // ---------------------------------------------------------------------------
 CVO_HD double cubic_eval(double a, double b, double c, double s) { return ((s + a) * s + b) * s + c; }
 
-CVO_HD double bisect_root(double a, double b, double c, double lo, double hi, bool increasing)
-{ // precondition: sign change over [lo,hi] in the stated direction
-    for (int it = 0; it < 1200; ++it) {
-        if ((float)lo == (float)hi) break;   // the root's float value is decided
-        const double mid = lo + (hi - lo) * 0.5;
-        if (!(mid > lo && mid < hi)) break;
-        const double f = cubic_eval(a, b, c, mid);
-        const bool go_right = increasing ? (f < 0.0) : (f > 0.0);
-        if (go_right) lo = mid; else hi = mid;
-    }
-    return hi;
-}
+// A bracket [lo,hi] of the monic cubic s^3 + a s^2 + b s + c that holds its
+// smallest positive real root (sign change in the stated direction), if any.
+struct CubicBracket {
+    double a, b, c, lo, hi;
+    bool found, increasing;
+};
 
-CVO_HD float pick_step(const double bcde[4], float min_step)
+CVO_HD CubicBracket cubic_bracket(const double bcde[4])
 {
+    CubicBracket B;
+    B.a = B.b = B.c = B.lo = B.hi = 0.0;
+    B.found = false;
+    B.increasing = true;
     const float c3 = (float)(4.0 * (float)bcde[3]);
     const float c2 = (float)(3.0 * (float)bcde[2]);
     const float c1 = (float)(2.0 * (float)bcde[1]);
     const float c0 = (float)bcde[0];
-    bool found = false;
-    double root = 0.0;
     const bool finite = (c3 == c3) && (c2 == c2) && (c1 == c1) && (c0 == c0) &&
                         fabsf(c3) <= 3.0e38f && fabsf(c2) <= 3.0e38f && fabsf(c1) <= 3.0e38f &&
                         fabsf(c0) <= 3.0e38f;
-    if (c3 != 0.0f && finite) {
-        const float qa = c2 / c3, qb = c1 / c3, qc = c0 / c3;
-        const bool qfinite = fabsf(qa) <= 3.0e38f && fabsf(qb) <= 3.0e38f && fabsf(qc) <= 3.0e38f;
-        if (qfinite) {
-            const double a = (double)qa, b = (double)qb, c = (double)qc;
-            double M = fabs(a);
-            if (fabs(b) > M) M = fabs(b);
-            if (fabs(c) > M) M = fabs(c);
-            const double U = 1.0 + M;   // Cauchy bound: every root has |s| < U
-            const double f0 = c;        // f(0)
-            const double disc = a * a - 3.0 * b;
-            if (!(disc > 0.0)) {
-                // monotone increasing: one real root, positive iff f(0) < 0
-                if (f0 < 0.0) { root = bisect_root(a, b, c, 0.0, U, true); found = true; }
-            } else {
-                const double sq = sqrt(disc);
-                const double s1 = (-a - sq) / 3.0;   // local maximum
-                const double s2 = (-a + sq) / 3.0;   // local minimum
-                // (0, s1): increasing
-                if (!found && s1 > 0.0 && f0 < 0.0) {
-                    const double f1 = cubic_eval(a, b, c, s1);
-                    if (f1 >= 0.0) { root = bisect_root(a, b, c, 0.0, s1, true); found = true; }
-                }
-                // (max(0,s1), s2): decreasing
-                if (!found && s2 > 0.0) {
-                    const double lo = s1 > 0.0 ? s1 : 0.0;
-                    const double fl = cubic_eval(a, b, c, lo);
-                    const double f2 = cubic_eval(a, b, c, s2);
-                    if (fl > 0.0 && f2 <= 0.0) { root = bisect_root(a, b, c, lo, s2, false); found = true; }
-                }
-                // (max(0,s2), U): increasing
-                if (!found) {
-                    const double lo = s2 > 0.0 ? s2 : 0.0;
-                    const double fl = cubic_eval(a, b, c, lo);
-                    if (fl < 0.0) { root = bisect_root(a, b, c, lo, U, true); found = true; }
-                }
-            }
-        }
+    if (!(c3 != 0.0f && finite)) return B;
+    const float qa = c2 / c3, qb = c1 / c3, qc = c0 / c3;
+    if (!(fabsf(qa) <= 3.0e38f && fabsf(qb) <= 3.0e38f && fabsf(qc) <= 3.0e38f)) return B;
+    const double a = (double)qa, b = (double)qb, c = (double)qc;
+    B.a = a; B.b = b; B.c = c;
+    double M = fabs(a);
+    if (fabs(b) > M) M = fabs(b);
+    if (fabs(c) > M) M = fabs(c);
+    const double U = 1.0 + M;   // Cauchy bound: every root has |s| < U
+    const double f0 = c;        // f(0)
+    const double disc = a * a - 3.0 * b;
+    if (!(disc > 0.0)) {
+        // monotone increasing: one real root, positive iff f(0) < 0
+        if (f0 < 0.0) { B.lo = 0.0; B.hi = U; B.increasing = true; B.found = true; }
+        return B;
     }
+    const double sq = sqrt(disc);
+    const double s1 = (-a - sq) / 3.0;   // local maximum
+    const double s2 = (-a + sq) / 3.0;   // local minimum
+    // (0, s1): increasing
+    if (s1 > 0.0 && f0 < 0.0) {
+        const double f1 = cubic_eval(a, b, c, s1);
+        if (f1 >= 0.0) { B.lo = 0.0; B.hi = s1; B.increasing = true; B.found = true; return B; }
+    }
+    // (max(0,s1), s2): decreasing
+    if (s2 > 0.0) {
+        const double lo = s1 > 0.0 ? s1 : 0.0;
+        const double fl = cubic_eval(a, b, c, lo);
+        const double f2 = cubic_eval(a, b, c, s2);
+        if (fl > 0.0 && f2 <= 0.0) { B.lo = lo; B.hi = s2; B.increasing = false; B.found = true; return B; }
+    }
+    // (max(0,s2), U): increasing
+    {
+        const double lo = s2 > 0.0 ? s2 : 0.0;
+        const double fl = cubic_eval(a, b, c, lo);
+        if (fl < 0.0) { B.lo = lo; B.hi = U; B.increasing = true; B.found = true; }
+    }
+    return B;
+}
+
+// Refinement by 64-way sectioning: every round evaluates the cubic at the 64
+// interior points lo + (hi-lo)(l+1)/65 and keeps the sub-interval where the sign
+// changes, until both ends round to the same float32.  Serial form (host, oracle,
+// a lone device thread); k_post_step runs the same rounds with one lane per
+// point (section_root_wave in cvo_kernels.hip) -- identical arithmetic per point,
+// hence identical results.
+constexpr int SECTIONS = 64;
+
+CVO_HD double section_point(double lo, double w, int l)
+{
+    return lo + w * ((double)(l + 1) * (1.0 / 65.0));
+}
+
+CVO_HD double section_root(const CubicBracket &B)
+{
+    double lo = B.lo, hi = B.hi;
+    for (int round = 0; round < 64; ++round) {
+        if ((float)lo == (float)hi) break;   // the root's float value is decided
+        const double w = hi - lo;
+        double nlo = lo, nhi = hi;
+        for (int l = 0; l < SECTIONS; ++l) {
+            const double x = section_point(lo, w, l);
+            const bool inside = x > lo && x < hi;
+            const double f = cubic_eval(B.a, B.b, B.c, x);
+            const bool go_right = inside && (B.increasing ? (f < 0.0) : (f > 0.0));
+            if (!go_right) {
+                if (inside) nhi = x;
+                break;
+            }
+            nlo = x;
+        }
+        if (nlo == lo && nhi == hi) break;   // no representable point left in between
+        lo = nlo;
+        hi = nhi;
+    }
+    return hi;
+}
+
+// min_step if there is no positive real root, clamp to 0.8 (ref cvo.cpp:298-307)
+CVO_HD float finish_step(bool found, double root, float min_step)
+{
     float step = min_step;
     if (found) {
         const float r = (float)root;
@@ -223,6 +261,12 @@ CVO_HD float pick_step(const double bcde[4], float min_step)
     }
     step = ((double)step > 0.8) ? (float)0.8 : step;
     return step;
+}
+
+CVO_HD float pick_step(const double bcde[4], float min_step)
+{
+    const CubicBracket B = cubic_bracket(bcde);
+    return finish_step(B.found, B.found ? section_root(B) : 0.0, min_step);
 }
 
 // Exp_SEK3 with K = 1: dR (row-major) and dT = Jl * v.

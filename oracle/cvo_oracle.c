@@ -713,76 +713,101 @@ void cvo_oracle_step_coeffs(float ell, const float omega[3], const float v[3], c
  * matrix with Eigen's EigenSolver and accepts roots with imag()==0; here: the
  * float coefficients and the float division by the leading one exactly as the
  * reference forms them, then the real roots of the monic cubic are bracketed
- * between its stationary points and bisected to adjacent float64 values
- * (only +,-,*,/,sqrt: bit-reproducible on any IEEE machine), rounded to float.
+ * between its stationary points and refined by 64-way sectioning in float64
+ * until its float value is decided (only +,-,*,/,sqrt: bit-reproducible).
  * Degenerate cubics (0/0 -> NaN eigenvalues in the reference) give min_step. */
 static double cubic_eval(double a, double b, double c, double s)
 {
     return ((s + a) * s + b) * s + c;
 }
 
-static double bisect_root(double a, double b, double c, double lo, double hi, int increasing)
+typedef struct cubic_bracket {
+    double a, b, c, lo, hi;
+    int found, increasing;
+} cubic_bracket;
+
+static cubic_bracket make_bracket(const double bcde[4])
 {
-    for (int it = 0; it < 1200; ++it) {
-        if ((float)lo == (float)hi) break;   // the root's float value is decided
-        const double mid = lo + (hi - lo) * 0.5;
-        if (!(mid > lo && mid < hi)) break;
-        const double f = cubic_eval(a, b, c, mid);
-        const int go_right = increasing ? (f < 0.0) : (f > 0.0);
-        if (go_right) lo = mid; else hi = mid;
+    cubic_bracket B;
+    memset(&B, 0, sizeof(B));
+    B.increasing = 1;
+    const float c3 = (float)(4.0 * (float)bcde[3]);
+    const float c2 = (float)(3.0 * (float)bcde[2]);
+    const float c1 = (float)(2.0 * (float)bcde[1]);
+    const float c0 = (float)bcde[0];
+    const int finite = (c3 == c3) && (c2 == c2) && (c1 == c1) && (c0 == c0) &&
+                       fabsf(c3) <= 3.0e38f && fabsf(c2) <= 3.0e38f && fabsf(c1) <= 3.0e38f &&
+                       fabsf(c0) <= 3.0e38f;
+    if (!(c3 != 0.0f && finite)) return B;
+    /* companion-matrix first row: -(coef/coef(0)) in float */
+    const float qa = c2 / c3, qb = c1 / c3, qc = c0 / c3;
+    if (!(fabsf(qa) <= 3.0e38f && fabsf(qb) <= 3.0e38f && fabsf(qc) <= 3.0e38f)) return B;
+    const double a = (double)qa, b = (double)qb, c = (double)qc;
+    B.a = a; B.b = b; B.c = c;
+    double M = fabs(a);
+    if (fabs(b) > M) M = fabs(b);
+    if (fabs(c) > M) M = fabs(c);
+    const double U = 1.0 + M;   /* Cauchy bound */
+    const double f0 = c;
+    const double disc = a * a - 3.0 * b;
+    if (!(disc > 0.0)) {
+        if (f0 < 0.0) { B.lo = 0.0; B.hi = U; B.increasing = 1; B.found = 1; }
+        return B;
+    }
+    const double sq = sqrt(disc);
+    const double s1 = (-a - sq) / 3.0;   /* local maximum */
+    const double s2 = (-a + sq) / 3.0;   /* local minimum */
+    if (s1 > 0.0 && f0 < 0.0) {
+        const double f1 = cubic_eval(a, b, c, s1);
+        if (f1 >= 0.0) { B.lo = 0.0; B.hi = s1; B.increasing = 1; B.found = 1; return B; }
+    }
+    if (s2 > 0.0) {
+        const double lo = s1 > 0.0 ? s1 : 0.0;
+        const double fl = cubic_eval(a, b, c, lo);
+        const double f2 = cubic_eval(a, b, c, s2);
+        if (fl > 0.0 && f2 <= 0.0) { B.lo = lo; B.hi = s2; B.increasing = 0; B.found = 1; return B; }
+    }
+    {
+        const double lo = s2 > 0.0 ? s2 : 0.0;
+        const double fl = cubic_eval(a, b, c, lo);
+        if (fl < 0.0) { B.lo = lo; B.hi = U; B.increasing = 1; B.found = 1; }
+    }
+    return B;
+}
+
+/* 64-way sectioning until both ends round to the same float (see header comment
+ * above; the GPU runs the same rounds with one lane per interior point). */
+static double section_root(const cubic_bracket *B)
+{
+    double lo = B->lo, hi = B->hi;
+    for (int round = 0; round < 64; ++round) {
+        if ((float)lo == (float)hi) break;
+        const double w = hi - lo;
+        double nlo = lo, nhi = hi;
+        for (int l = 0; l < 64; ++l) {
+            const double x = lo + w * ((double)(l + 1) * (1.0 / 65.0));
+            const int inside = x > lo && x < hi;
+            const double f = cubic_eval(B->a, B->b, B->c, x);
+            const int go_right = inside && (B->increasing ? (f < 0.0) : (f > 0.0));
+            if (!go_right) {
+                if (inside) nhi = x;
+                break;
+            }
+            nlo = x;
+        }
+        if (nlo == lo && nhi == hi) break;
+        lo = nlo;
+        hi = nhi;
     }
     return hi;
 }
 
 float cvo_oracle_pick_step(const double bcde[4], float min_step)
 {
-    const float c3 = (float)(4.0 * (float)bcde[3]);
-    const float c2 = (float)(3.0 * (float)bcde[2]);
-    const float c1 = (float)(2.0 * (float)bcde[1]);
-    const float c0 = (float)bcde[0];
-    int found = 0;
-    double root = 0.0;
-    const int finite = (c3 == c3) && (c2 == c2) && (c1 == c1) && (c0 == c0) &&
-                       fabsf(c3) <= 3.0e38f && fabsf(c2) <= 3.0e38f && fabsf(c1) <= 3.0e38f &&
-                       fabsf(c0) <= 3.0e38f;
-    if (c3 != 0.0f && finite) {
-        /* companion-matrix first row: -(coef/coef(0)) in float */
-        const float qa = c2 / c3, qb = c1 / c3, qc = c0 / c3;
-        if (fabsf(qa) <= 3.0e38f && fabsf(qb) <= 3.0e38f && fabsf(qc) <= 3.0e38f) {
-            const double a = (double)qa, b = (double)qb, c = (double)qc;
-            double M = fabs(a);
-            if (fabs(b) > M) M = fabs(b);
-            if (fabs(c) > M) M = fabs(c);
-            const double U = 1.0 + M;   /* Cauchy bound */
-            const double f0 = c;
-            const double disc = a * a - 3.0 * b;
-            if (!(disc > 0.0)) {
-                if (f0 < 0.0) { root = bisect_root(a, b, c, 0.0, U, 1); found = 1; }
-            } else {
-                const double sq = sqrt(disc);
-                const double s1 = (-a - sq) / 3.0;   /* local maximum */
-                const double s2 = (-a + sq) / 3.0;   /* local minimum */
-                if (!found && s1 > 0.0 && f0 < 0.0) {
-                    const double f1 = cubic_eval(a, b, c, s1);
-                    if (f1 >= 0.0) { root = bisect_root(a, b, c, 0.0, s1, 1); found = 1; }
-                }
-                if (!found && s2 > 0.0) {
-                    const double lo = s1 > 0.0 ? s1 : 0.0;
-                    const double fl = cubic_eval(a, b, c, lo);
-                    const double f2 = cubic_eval(a, b, c, s2);
-                    if (fl > 0.0 && f2 <= 0.0) { root = bisect_root(a, b, c, lo, s2, 0); found = 1; }
-                }
-                if (!found) {
-                    const double lo = s2 > 0.0 ? s2 : 0.0;
-                    const double fl = cubic_eval(a, b, c, lo);
-                    if (fl < 0.0) { root = bisect_root(a, b, c, lo, U, 1); found = 1; }
-                }
-            }
-        }
-    }
+    const cubic_bracket B = make_bracket(bcde);
     float step = min_step;
-    if (found) {
-        const float r = (float)root;
+    if (B.found) {
+        const float r = (float)section_root(&B);
         if (r > 0.0f) step = r;
     }
     step = step > 0.8 ? (float)0.8 : step;   /* ref cvo.cpp:307 */

@@ -26,9 +26,28 @@ int main(int argc, char **argv)
         for (int i = 0; i < n; ++i) { float x = U(rng), y = U(rng); (*v)[i] = make_float4(x, y, surf(x, y), 0.f); }
         // crude spatial sort (by cell) so that tiles are compact like the Morton order
         std::sort(v->begin(), v->end(), [](const float4 &p, const float4 &q) {
-            int cp = (int)((p.x + 0.8f) * 10) * 16 + (int)((p.y + 0.8f) * 10), cq = (int)((q.x + 0.8f) * 10) * 16 + (int)((q.y + 0.8f) * 10);
+            auto mort = [](float x, float y) { unsigned a = (unsigned)((x + 0.8f) * 600.f), b = (unsigned)((y + 0.8f) * 600.f), m = 0; for (int k = 0; k < 10; ++k) m |= ((a >> k) & 1u) << (2 * k) | ((b >> k) & 1u) << (2 * k + 1); return m; }; unsigned cp = mort(p.x, p.y), cq = mort(q.x, q.y);
             return cp < cq; });
     }
+    auto spheres = [&](const std::vector<float4> &v) {
+        std::vector<float4> sp((v.size() + SEG - 1) / SEG);
+        for (size_t g = 0; g < sp.size(); ++g) {
+            const size_t s0 = g * SEG, s1 = std::min(v.size(), s0 + SEG);
+            float lo[3] = {1e30f, 1e30f, 1e30f}, hi[3] = {-1e30f, -1e30f, -1e30f};
+            for (size_t q = s0; q < s1; ++q) { const float p[3] = {v[q].x, v[q].y, v[q].z};
+                for (int a = 0; a < 3; ++a) { lo[a] = std::min(lo[a], p[a]); hi[a] = std::max(hi[a], p[a]); } }
+            const float c[3] = {0.5f * (lo[0] + hi[0]), 0.5f * (lo[1] + hi[1]), 0.5f * (lo[2] + hi[2])};
+            double r2 = 0; for (size_t q = s0; q < s1; ++q) { double d = 0; const float p[3] = {v[q].x, v[q].y, v[q].z};
+                for (int a = 0; a < 3; ++a) d += ((double)p[a] - c[a]) * ((double)p[a] - c[a]); r2 = std::max(r2, d); }
+            sp[g] = make_float4(c[0], c[1], c[2], (float)(sqrt(r2) * 1.00001 + 1e-6));
+        }
+        return sp; };
+    const std::vector<float4> sa = spheres(ha), sb = spheres(hb);
+    float4 *dsa, *dsb;
+    hipMalloc(&dsa, sa.size() * sizeof(float4)); hipMalloc(&dsb, sb.size() * sizeof(float4));
+    hipMemcpy(dsa, sa.data(), sa.size() * sizeof(float4), hipMemcpyHostToDevice);
+    hipMemcpy(dsb, sb.data(), sb.size() * sizeof(float4), hipMemcpyHostToDevice);
+    { double rs = 0; for (auto &q : sa) rs += q.w; printf("mean segment radius %.3f m\n", rs / sa.size()); }
     float4 *da, *db; DevState *st; TileEntry *cand; long long *dbg;
     hipMalloc(&da, n * sizeof(float4)); hipMalloc(&db, n * sizeof(float4));
     hipMemcpy(da, ha.data(), n * sizeof(float4), hipMemcpyHostToDevice);
@@ -42,21 +61,31 @@ int main(int argc, char **argv)
     const int tiles = (n + ROWS_PER_TILE - 1) / ROWS_PER_TILE, chunks = (n + jt - 1) / jt;
     const size_t nw = (size_t)tiles * chunks * 4;
     hipMalloc(&dbg, nw * 8 * sizeof(long long));
-    FilterArgs a{}; a.pos_a = da; a.pos_b = db; a.st = st; a.tiles = cand; a.subcap = subcap; a.list = LIST_XY;
+    FilterArgs a{}; a.pos_a = da; a.pos_b = db; a.seg_a = dsa; a.seg_b = dsb; a.st = st; a.tiles = cand; a.subcap = subcap; a.list = LIST_XY;
     a.row_lo = 0; a.row_hi = n; a.nb = n; a.jt = jt; a.tf_a = 0; a.tf_b = 1; a.check_done = 1; a.dbg = dbg;
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     for (int rep = 0; rep < 3; ++rep) {
-        hipMemset(&st->sub[0][0], 0, sizeof(h.sub)); hipMemset(st->cnt, 0, sizeof(h.cnt));
+        hipMemset(&st->sub[0][0], 0, sizeof(h.sub)); hipMemset(st->cnt, 0, sizeof(h.cnt)); hipMemset(dbg, 0, nw * 8 * sizeof(long long));
         hipDeviceSynchronize();
         hipEventRecord(e0);
         launch_filter(a, dim3(chunks, tiles), 0);
         hipEventRecord(e1);
         hipDeviceSynchronize();
         float ms; hipEventElapsedTime(&ms, e0, e1);
-        std::vector<long long> hd(nw * 8);
+        std::vector<long long> hd(nw * 8); size_t nw_live = nw;
         hipMemcpy(hd.data(), dbg, hd.size() * sizeof(long long), hipMemcpyDeviceToHost);
         hipMemcpy(&h, st, sizeof(h), hipMemcpyDeviceToHost);
         unsigned long long tot = 0; for (int q = 0; q < NSUB; ++q) tot += h.sub[0][q];
+        size_t culled = 0; double clife = 0;
+        for (size_t w = 0; w < nw; ++w) if (hd[w * 8 + 4] == -1) { culled++; clife += hd[w * 8 + 3] - hd[w * 8]; }
+        printf("culled waves %zu of %zu (avg life %.0f ticks)\n", culled, (size_t)nw, culled ? clife / culled : 0.0);
+        {   size_t k = 0;   // keep only the surviving waves for the statistics below
+            for (size_t w = 0; w < nw; ++w) if (hd[w * 8 + 4] != -1) { for (int q = 0; q < 8; ++q) hd[k * 8 + q] = hd[w * 8 + q]; ++k; }
+            nw_live = k; }
+        if (nw_live == 0) continue;
+        const size_t nw_outer = nw; (void)nw_outer;
+        {
+        const size_t nw = nw_live;
         long long tmin = hd[0], tmax = 0; double pro = 0, loop = 0, tail = 0, life = 0;
         for (size_t w = 0; w < nw; ++w) {
             const long long *o = &hd[w * 8];
@@ -125,6 +154,7 @@ int main(int argc, char **argv)
         printf("n %d ell %.2f jt %d grid %dx%d: kernel %.1f us, first start -> last exit %lld ticks, per wave: prologue %.0f loop %.0f tail %.0f life %.0f ticks; start p50 %lld p90 %lld max %lld; candidates %llu ovf %u\n",
                n, ell, jt, chunks, tiles, ms * 1e3, tmax - tmin, pro / nw, loop / nw, tail / nw, life / nw,
                starts[nw / 2], starts[nw * 9 / 10], starts[nw - 1], tot, h.cnt[1]);
+        }
     }
     return 0;
 }
