@@ -302,6 +302,12 @@ int ensure_list(cvo_hip_ctx *ctx, int list, int nrows, int nb, double at_least)
         want = (all * 2.0 * sizeof(TileEntry) <= 64.0e6) ? all * 2.0 : std::max(all * 0.25, 64.0e6 / sizeof(TileEntry));
         min_sub = TILE_STAGE;
     }
+    if (at_least <= 0.0) {   // test hook: start from a tiny list to exercise the grow-and-redo path
+        if (const char *e = getenv("CVO_HIP_LIST_INIT")) {
+            const double v = atof(e);
+            if (v > 0.0) want = v;
+        }
+    }
     want = std::max(want, at_least);
     want = std::min(want, 4.0e9);
     const uint32_t cap = std::max<uint32_t>((uint32_t)((want + NSUB - 1) / NSUB), min_sub) * NSUB;

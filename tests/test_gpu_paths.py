@@ -1,0 +1,190 @@
+"""-m gpu: the less-travelled paths of the HIP library against the oracle:
+row sharding, the RCCL hook (world size 1), list overflow + resume,
+function_inner_product, frame-to-frame state carry-over, full-size clouds."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _stream():
+    import torch
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ctx(pkg, mode, xf, ff, xm, fm):
+    c = pkg.capi.Context(mode=mode, device=0, stream=_stream())
+    c.set_fixed(xf, ff)
+    c.set_moving(xm, fm)
+    return c
+
+
+def _motion():
+    th = 0.012
+    R = np.array([[np.cos(th), -np.sin(th), 0], [np.sin(th), np.cos(th), 0], [0, 0, 1]], np.float32)
+    return R, np.array([0.003, -0.002, 0.004], np.float32)
+
+
+@pytest.mark.parametrize("mode_name", ["cvo", "acvo"])
+def test_row_shards_add_up_to_the_whole(pkg, mode_name):
+    """Target rows split over two contexts: partial flow / step sums add up
+    (sums over independent pairs)."""
+    capi = pkg.capi
+    mode = capi.MODE_CVO if mode_name == "cvo" else capi.MODE_ACVO
+    n, m = 1800, 2100
+    xf, ff, xm, fm = pkg.data.synthetic_pair(n, m, seed=17, acvo=(mode_name == "acvo"))
+    R, T = _motion()
+    ell = 0.1
+    full = _ctx(pkg, mode, xf, ff, xm, fm)
+    full.transform_pcd(R, T)
+    f_full = full.flow(ell)
+    om, v = f_full[0:3].astype(np.float32), f_full[3:6].astype(np.float32)
+    s_full = full.step_coeffs(om, v, ell)
+    parts_f, parts_s = np.zeros(13), np.zeros(4)
+    for rank in range(2):
+        c = _ctx(pkg, mode, xf, ff, xm, fm)
+        lo, hi = capi.shard_range(n, rank, 2)
+        slo, shi = capi.shard_range(m, rank, 2)
+        c.set_shard(lo, hi, slo, shi)
+        c.transform_pcd(R, T)
+        parts_f += c.flow(ell)
+        parts_s += c.step_coeffs(om, v, ell)
+        c.close()
+    for k in (8, 10, 12):
+        assert int(parts_f[k]) == int(f_full[k])           # nnz(A), nnz(Axx), nnz(Ayy)
+    assert np.allclose(parts_f, f_full, rtol=1e-11, atol=1e-13)
+    assert np.allclose(parts_s, s_full, rtol=1e-10, atol=1e-12)
+    full.close()
+
+
+def _oracle_align(po, mode, clouds, carry=True):
+    p = po.default_params(mode)
+    s = po.init_state(p)
+    its = []
+    for k in range(1, len(clouds)):
+        n_it, _ = po.align(p, s, *clouds[k - 1], *clouds[k], search=po.SEARCH_GRID)
+        its.append(n_it)
+    return its, po.state_matrices(s)
+
+
+def test_rccl_world_size_one_and_user_hook(pkg, po):
+    """cvo_hip_comm_init with a one-rank communicator and a caller-supplied
+    all-reduce hook (identity for one rank) run the reduce -> all-reduce -> maths
+    split of the post kernels and must not change the result."""
+    capi = pkg.capi
+    xf, ff, xm, fm = pkg.data.synthetic_pair(1500, 1500, seed=23)
+    its, (T_or, _, _) = _oracle_align(po, po.MODE_CVO, [(xf, ff), (xm, fm)])
+    for variant in ("rccl", "hook"):
+        c = _ctx(pkg, capi.MODE_CVO, xf, ff, xm, fm)
+        lo, hi = capi.shard_range(1500, 0, 1)
+        c.set_shard(lo, hi, lo, hi)
+        calls = [0]
+        if variant == "rccl":
+            c.comm_init(capi.comm_unique_id(), 0, 1)
+        else:
+            def hook(ptr, count, stream):
+                assert ptr != 0 and count in (13, 4)
+                calls[0] += 1
+            c.set_allreduce(hook)
+        st = capi.init_state(c.params)
+        n_it, _ = c.align(st, trace_cap=0)
+        assert n_it == its[0]
+        T = np.array(st.transform, np.float32).reshape(4, 4)
+        rot, tra = pkg.data.rel_pose_error(T, T_or)
+        assert rot <= 1e-6 and tra <= 1e-6
+        if variant == "hook":
+            assert calls[0] >= 2 * n_it
+        c.close()
+
+
+@pytest.mark.parametrize("mode_name", ["cvo", "acvo"])
+def test_list_overflow_grows_and_resumes(pkg, po, mode_name, monkeypatch):
+    """Start from absurdly small lists: the loop must park with NEED_BIGGER_LIST,
+    the host must grow the list and resume from the same iteration, and the
+    result must still be the oracle's."""
+    capi = pkg.capi
+    mode = capi.MODE_CVO if mode_name == "cvo" else capi.MODE_ACVO
+    xf, ff, xm, fm = pkg.data.synthetic_pair(2000, 2000, seed=7, acvo=(mode_name == "acvo"))
+    its, (T_or, _, _) = _oracle_align(po, mode, [(xf, ff), (xm, fm)])
+    monkeypatch.setenv("CVO_HIP_LIST_INIT", "1")      # -> the minimum capacity of every list
+    c = _ctx(pkg, mode, xf, ff, xm, fm)
+    st = capi.init_state(c.params)
+    n_it, tr = c.align(st, trace_cap=2000)
+    monkeypatch.delenv("CVO_HIP_LIST_INIT")
+    assert n_it == its[0] and len(tr) == n_it
+    T = np.array(st.transform, np.float32).reshape(4, 4)
+    rot, tra = pkg.data.rel_pose_error(T, T_or)
+    assert rot <= 1e-6 and tra <= 1e-6
+    c.close()
+
+
+def test_function_inner_product_matches_oracle(pkg, po):
+    xf, ff, xm, fm = pkg.data.synthetic_pair(1200, 1400, seed=29, acvo=True)
+    import torch
+    reg = pkg.Acvo(device=0, stream=_stream())
+    reg.run_cvo(xf, ff)
+    got = reg.function_inner_product(xm, fm)
+    p = po.default_params(po.MODE_ACVO)
+    want = po.function_inner_product(p, p.ell_init, xf, ff, xm, fm)
+    assert got == pytest.approx(want, rel=1e-6)
+    reg.close()
+
+
+@pytest.mark.parametrize("mode_name", ["cvo", "acvo"])
+def test_sequence_with_state_carry_over(pkg, po, desk, mode_name):
+    """BASELINE configs[2] as far as the tree allows: the five shipped fr1/desk
+    clouds streamed through one registration object (every 5th point; cvo keeps
+    ell/R/T between frames, acvo resets ell): same per-pair iteration counts and
+    the same accumulated trajectory as the oracle."""
+    capi = pkg.capi
+    acvo = mode_name == "acvo"
+    mode = capi.MODE_ACVO if acvo else capi.MODE_CVO
+    feats = pkg.data.acvo_features if acvo else pkg.data.cvo_features
+    clouds = [(desk["xyz%d" % k][::5], feats(desk["rgb%d" % k][::5])) for k in range(5)]
+    its_or, (T_or, P_or, A_or) = _oracle_align(po, mode, clouds)
+    Reg = pkg.Acvo if acvo else pkg.Cvo
+    reg = Reg(device=0, stream=_stream())
+    its = []
+    for xyz, f in clouds:
+        reg.run_cvo(xyz, f)
+        if reg.num_iterations:
+            its.append(reg.num_iterations)
+    assert its == its_or
+    rot, tra = pkg.data.rel_pose_error(reg.accum_transform, A_or)
+    assert rot <= 1e-5 and tra <= 1e-5
+    assert np.allclose(reg.prev_transform, P_or, atol=1e-7)
+    reg.close()
+
+
+def test_full_size_tum_pair(pkg, po, desk):
+    """15 849 x 17 067 points (the shipped clouds as they are)."""
+    xf, ff = desk["xyz0"], pkg.data.cvo_features(desk["rgb0"])
+    xm, fm = desk["xyz1"], pkg.data.cvo_features(desk["rgb1"])
+    po.set_threads(16)
+    its, (T_or, _, _) = _oracle_align(po, po.MODE_CVO, [(xf, ff), (xm, fm)])
+    po.set_threads(0)
+    reg = pkg.Cvo(device=0, stream=_stream())
+    reg.run_cvo(xf, ff)
+    reg.run_cvo(xm, fm)
+    assert reg.num_iterations == its[0]
+    rot, tra = pkg.data.rel_pose_error(reg.transform, T_or)
+    assert rot <= 1e-6 and tra <= 1e-6
+    reg.close()
+
+
+def test_column_major_features_are_the_reference_layout(pkg, po):
+    """Eigen::Matrix<float,Dynamic,5> is column-major (ref data_type.h:64)."""
+    capi = pkg.capi
+    xf, ff, xm, fm = pkg.data.synthetic_pair(900, 800, seed=31)
+    R, T = _motion()
+    a = _ctx(pkg, capi.MODE_CVO, xf, ff, xm, fm)
+    b = capi.Context(mode=capi.MODE_CVO, device=0, stream=_stream())
+    b.set_fixed(xf, np.ascontiguousarray(ff.T), layout=capi.FEAT_COLMAJOR)
+    b.set_moving(xm, np.ascontiguousarray(fm.T), layout=capi.FEAT_COLMAJOR)
+    for c in (a, b):
+        c.transform_pcd(R, T)
+    assert np.array_equal(a.flow(0.1), b.flow(0.1))
+    a.close()
+    b.close()
