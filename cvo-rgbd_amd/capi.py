@@ -19,7 +19,8 @@ SYMBOLS = [
     "cvo_hip_swap_moving_to_fixed", "cvo_hip_set_shard", "cvo_hip_shard_range",
     "cvo_hip_comm_unique_id", "cvo_hip_comm_init", "cvo_hip_set_allreduce",
     "cvo_hip_transform_pcd", "cvo_hip_flow", "cvo_hip_step_coeffs", "cvo_hip_pick_step",
-    "cvo_hip_exp_se3", "cvo_hip_dist_se3", "cvo_hip_align", "cvo_hip_function_inner_product",
+    "cvo_hip_exp_se3", "cvo_hip_dist_se3", "cvo_hip_align", "cvo_hip_align_many",
+    "cvo_hip_function_inner_product",
     "cvo_hip_set_profiling", "cvo_hip_get_profile", "cvo_hip_synchronize",
 ]
 
@@ -113,6 +114,8 @@ def lib():
     L.cvo_hip_dist_se3.argtypes = [fp, fp, C.c_float, fp]
     L.cvo_hip_align.argtypes = [vp, C.POINTER(State), C.POINTER(Trace), C.c_int,
                                 C.POINTER(C.c_int)]
+    L.cvo_hip_align_many.argtypes = [C.POINTER(vp), C.POINTER(C.POINTER(State)), C.POINTER(C.c_int),
+                                     C.c_int]
     L.cvo_hip_function_inner_product.argtypes = [vp, C.c_float, fp]
     L.cvo_hip_set_profiling.argtypes = [vp, C.c_int]
     L.cvo_hip_get_profile.argtypes = [vp, C.POINTER(Profile), C.c_int]
@@ -308,6 +311,17 @@ class Context:
 
     def synchronize(self):
         self._chk(self._L.cvo_hip_synchronize(self._ctx), "synchronize")
+
+
+def align_many(contexts, states):
+    """Batched mode: all registrations in flight at once (one context + stream
+    each).  Returns the list of iteration counts; `states` are updated in place."""
+    n = len(contexts)
+    arr_c = (C.c_void_p * n)(*[c._ctx for c in contexts])
+    arr_s = (C.POINTER(State) * n)(*[C.pointer(s) for s in states])
+    its = (C.c_int * n)()
+    check(lib().cvo_hip_align_many(arr_c, arr_s, its, n), what="align_many")
+    return list(its)
 
 
 def comm_unique_id():

@@ -17,6 +17,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstddef>
+#include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -64,6 +65,16 @@ struct List {     // LIST_XY/XX/YY: TileEntry[cap] in a; LIST_KEPT: uint2[cap] i
 };
 
 constexpr int kBatch = 4;        // iterations enqueued between two polls
+
+// A captured batch of kBatch iterations (hipGraph): one hipGraphLaunch instead
+// of 5-9 kernel launches per iteration.  Valid for exactly the kernel arguments
+// in `key` (cloud / list / partial / trace pointers, sizes, shard, parameters).
+struct GraphEntry {
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    std::vector<uint64_t> key;
+    uint64_t stamp = 0;
+};
 constexpr int kPollSlots = 4;
 
 }   // namespace
@@ -91,6 +102,10 @@ struct cvo_hip_ctx {
     void *user_allreduce_arg = nullptr;
     bool profiling = false;
     long long *post_dbg = nullptr;   // CVO_HIP_POST_DEBUG diagnostics
+    std::vector<GraphEntry> graphs;  // small LRU cache (the clouds ping-pong between two buffers)
+    uint64_t graph_clock = 0;
+    bool warm = false;               // every device buffer of the loop has been allocated
+    bool use_graphs = true;
     int iter_tag = -1;
     std::vector<EventPair> events;
     cvo_hip_profile prof{};
@@ -580,6 +595,112 @@ int check_overflow_and_grow(cvo_hip_ctx *ctx, bool *redo)
     return CVO_HIP_OK;
 }
 
+// Allocate (or grow) every device buffer the loop will touch for the clouds
+// that are set, so that no allocation can happen inside a graph capture.
+int prepare_buffers(cvo_hip_ctx *ctx)
+{
+    const bool acvo = ctx->prm.mode == CVO_HIP_MODE_ACVO;
+    int rlo, rhi, slo, shi;
+    shard_ranges(ctx, rlo, rhi, slo, shi);
+    int rc = ensure_list(ctx, LIST_XY, rhi - rlo, ctx->moving.n, 0);
+    if (!rc) rc = ensure_list(ctx, LIST_KEPT, ctx->fixed.n, ctx->moving.n, 0);
+    if (!rc && acvo) rc = ensure_list(ctx, LIST_XX, rhi - rlo, ctx->fixed.n, 0);
+    if (!rc && acvo) rc = ensure_list(ctx, LIST_YY, shi - slo, ctx->moving.n, 0);
+    for (DevBuf *b : {&ctx->part_flow, &ctx->part_xx, &ctx->part_yy, &ctx->part_step})
+        if (!rc) rc = ensure_buf(ctx, *b, (size_t)PROC_WAVES * NACC_MAX * sizeof(double));
+    if (!rc && !ctx->kept_cnt.p) {
+        rc = ensure_buf(ctx, ctx->kept_cnt, PROC_WAVES * sizeof(uint32_t));
+        if (!rc) HIP_TRY(ctx, hipMemsetAsync(ctx->kept_cnt.p, 0, PROC_WAVES * sizeof(uint32_t), ctx->stream));
+    }
+    if (!rc) ctx->warm = true;
+    return rc;
+}
+
+int enqueue_iterations(cvo_hip_ctx *ctx, int count, int tag0, int trace_cap)
+{
+    int rc = CVO_HIP_OK;
+    for (int q = 0; q < count && !rc; ++q) {
+        ctx->iter_tag = tag0 >= 0 ? tag0 + q : -1;
+        rc = enqueue_flow(ctx, true, 1, true, ctx->trace_dev, trace_cap);
+        if (!rc) rc = enqueue_step(ctx, 1, true, ctx->trace_dev, trace_cap);
+    }
+    ctx->iter_tag = -1;
+    return rc;
+}
+
+std::vector<uint64_t> graph_key(const cvo_hip_ctx *ctx, int trace_cap)
+{
+    std::vector<uint64_t> k;
+    auto P = [&](const void *p) { k.push_back((uint64_t)(uintptr_t)p); };
+    auto I = [&](uint64_t v) { k.push_back(v); };
+    P(ctx->fixed.pos); P(ctx->fixed.feat); P(ctx->fixed.seg); I(ctx->fixed.n);
+    P(ctx->moving.pos); P(ctx->moving.feat); P(ctx->moving.seg); I(ctx->moving.n);
+    for (int l = 0; l < LIST_N; ++l) { P(ctx->lists[l].a.p); P(ctx->lists[l].b.p); I(ctx->lists[l].cap); }
+    P(ctx->kept_cnt.p); P(ctx->part_flow.p); P(ctx->part_xx.p); P(ctx->part_yy.p); P(ctx->part_step.p);
+    P(ctx->trace_dev); I((uint64_t)trace_cap); P(ctx->st); P(ctx->post_dbg);
+    I(ctx->sharded); I((uint64_t)ctx->row_lo); I((uint64_t)ctx->row_hi);
+    I((uint64_t)ctx->srow_lo); I((uint64_t)ctx->srow_hi);
+    uint64_t h = 1469598103934665603ull;   // FNV-1a over the by-value parameter block
+    const unsigned char *b = reinterpret_cast<const unsigned char *>(&ctx->dprm);
+    for (size_t i = 0; i < sizeof(DevParams); ++i) { h ^= b[i]; h *= 1099511628211ull; }
+    I(h);
+    return k;
+}
+
+void drop_graphs(cvo_hip_ctx *ctx)
+{
+    for (auto &g : ctx->graphs) {
+        if (g.exec) (void)hipGraphExecDestroy(g.exec);
+        if (g.graph) (void)hipGraphDestroy(g.graph);
+    }
+    ctx->graphs.clear();
+}
+
+// Launch one batch of kBatch iterations: through a cached graph when possible
+// (single rank, no per-launch HIP events, buffers already allocated), else eagerly.
+int launch_batch(cvo_hip_ctx *ctx, int tag0, int trace_cap)
+{
+    const bool graphable = ctx->use_graphs && ctx->warm && !ctx->profiling && !multi_rank(ctx);
+    if (!graphable) {
+        const int rc = enqueue_iterations(ctx, kBatch, tag0, trace_cap);
+        if (!rc) ctx->warm = true;
+        return rc;
+    }
+    const std::vector<uint64_t> key = graph_key(ctx, trace_cap);
+    GraphEntry *hit = nullptr;
+    for (auto &g : ctx->graphs)
+        if (g.key == key) { hit = &g; break; }
+    if (!hit) {
+        if (ctx->graphs.size() >= 4) {   // evict the least recently used entry
+            size_t lru = 0;
+            for (size_t i = 1; i < ctx->graphs.size(); ++i)
+                if (ctx->graphs[i].stamp < ctx->graphs[lru].stamp) lru = i;
+            if (ctx->graphs[lru].exec) (void)hipGraphExecDestroy(ctx->graphs[lru].exec);
+            if (ctx->graphs[lru].graph) (void)hipGraphDestroy(ctx->graphs[lru].graph);
+            ctx->graphs.erase(ctx->graphs.begin() + lru);
+        }
+        GraphEntry g;
+        g.key = key;
+        HIP_TRY(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeRelaxed));
+        const int rc = enqueue_iterations(ctx, kBatch, -1, trace_cap);
+        const hipError_t e = hipStreamEndCapture(ctx->stream, &g.graph);
+        if (rc) { if (g.graph) (void)hipGraphDestroy(g.graph); return rc; }
+        if (e != hipSuccess) { ctx->err = "hipStreamEndCapture failed"; return CVO_HIP_ERR_HIP; }
+        if (graph_key(ctx, trace_cap) != key) {
+            // something was (re)allocated while capturing: the capture is unusable
+            (void)hipGraphDestroy(g.graph);
+            ctx->use_graphs = false;
+            return enqueue_iterations(ctx, kBatch, tag0, trace_cap);
+        }
+        HIP_TRY(ctx, hipGraphInstantiate(&g.exec, g.graph, nullptr, nullptr, 0));
+        ctx->graphs.push_back(g);
+        hit = &ctx->graphs.back();
+    }
+    hit->stamp = ++ctx->graph_clock;
+    HIP_TRY(ctx, hipGraphLaunch(hit->exec, ctx->stream));
+    return CVO_HIP_OK;
+}
+
 int zero_counters(cvo_hip_ctx *ctx)
 {
     HIP_TRY(ctx, hipMemsetAsync(reinterpret_cast<char *>(ctx->st) + offsetof(DevState, cnt), 0,
@@ -718,6 +839,7 @@ int cvo_hip_create(int device, void *stream, const cvo_hip_params *p, cvo_hip_ct
     for (int i = 0; i < kPollSlots; ++i)
         if (hipEventCreateWithFlags(&ctx->poll_ev[i], hipEventDisableTiming) != hipSuccess)
             return bail(CVO_HIP_ERR_HIP);
+    if (getenv("CVO_HIP_NO_GRAPH")) ctx->use_graphs = false;
     if (getenv("CVO_HIP_POST_DEBUG")) {
         if (hipMalloc((void **)&ctx->post_dbg, 8 * sizeof(long long)) != hipSuccess) return bail(CVO_HIP_ERR_NOMEM);
         (void)hipMemset(ctx->post_dbg, 0, 8 * sizeof(long long));
@@ -735,6 +857,7 @@ int cvo_hip_destroy(cvo_hip_ctx *ctx)
     for (int i = 0; i < kPollSlots; ++i)
         if (ctx->poll_ev[i]) hipEventDestroy(ctx->poll_ev[i]);
     if (ctx->comm) cvo_comm_destroy(ctx->comm);
+    drop_graphs(ctx);
     if (ctx->post_dbg) {
         long long h[8];
         if (hipMemcpy(h, ctx->post_dbg, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess && h[0] > 0)
@@ -929,29 +1052,45 @@ int cvo_hip_dist_se3(const float omega[3], const float v[3], float dt, float *di
     return CVO_HIP_OK;
 }
 
-int cvo_hip_align(cvo_hip_ctx *ctx, cvo_hip_state *s, cvo_hip_trace *trace, int trace_cap,
-                  int *n_iter)
+// ---- align() as a resumable job, so that one host thread can keep many
+// ---- registrations (one context + stream each) in flight: cvo_hip_align_many
+namespace {
+
+struct AlignJob {
+    cvo_hip_ctx *ctx = nullptr;
+    cvo_hip_state *s = nullptr;
+    cvo_hip_trace *trace = nullptr;
+    int trace_cap = 0;
+    int *n_iter = nullptr;
+    int enq = 0;            // iterations enqueued in this round
+    int batches = 0;        // batches enqueued in this round
+    int checked = 0;        // batches whose poll copy has been looked at
+    int executed_base = 0;  // iterations completed before this round (after a list grew)
+    int phase = 0;          // 0 enqueueing/polling, 1 waiting for the final state, 2 finished
+    int rc = CVO_HIP_OK;
+};
+
+int job_begin(AlignJob &j)
 {
-    if (!ctx || !s) return CVO_HIP_ERR_INVALID;
+    cvo_hip_ctx *ctx = j.ctx;
+    cvo_hip_state *s = j.s;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const cvo_hip_params &p = ctx->prm;
-    const bool acvo = p.mode == CVO_HIP_MODE_ACVO;
-    if (acvo) {   // tail of acvo::set_pcd (ref src/adaptive_cvo.cpp:476-478)
+    if (p.mode == CVO_HIP_MODE_ACVO) {   // tail of acvo::set_pcd (ref src/adaptive_cvo.cpp:476-478)
         s->ell = p.ell_init;
         s->ell_max = p.ell_max_init;
     }
-    if (!trace) trace_cap = 0;
-    if (trace_cap > p.max_iter) trace_cap = p.max_iter;
-    if (trace_cap > ctx->trace_dev_cap) {
+    if (!j.trace) j.trace_cap = 0;
+    if (j.trace_cap > p.max_iter) j.trace_cap = p.max_iter;
+    if (j.trace_cap > ctx->trace_dev_cap) {
         if (ctx->trace_dev) HIP_TRY(ctx, hipFree(ctx->trace_dev));
         ctx->trace_dev = nullptr; ctx->trace_dev_cap = 0;
-        HIP_TRY(ctx, hipMalloc((void **)&ctx->trace_dev, (size_t)trace_cap * sizeof(cvo_hip_trace)));
-        ctx->trace_dev_cap = trace_cap;
+        HIP_TRY(ctx, hipMalloc((void **)&ctx->trace_dev, (size_t)j.trace_cap * sizeof(cvo_hip_trace)));
+        ctx->trace_dev_cap = j.trace_cap;
     }
-    if (trace_cap > 0)
-        HIP_TRY(ctx, hipMemsetAsync(ctx->trace_dev, 0, (size_t)trace_cap * sizeof(cvo_hip_trace),
+    if (j.trace_cap > 0)
+        HIP_TRY(ctx, hipMemsetAsync(ctx->trace_dev, 0, (size_t)j.trace_cap * sizeof(cvo_hip_trace),
                                     ctx->stream));
-
     // initial device state
     DevState *h = &ctx->st_host[kPollSlots];
     std::memset(h, 0, sizeof(*h));
@@ -961,83 +1100,40 @@ int cvo_hip_align(cvo_hip_ctx *ctx, cvo_hip_state *s, cvo_hip_trace *trace, int 
     h->ell_max = s->ell_max;
     h->iter = s->iter;
     fill_filter_geometry(ctx, h);
-    if (p.max_iter <= 0) h->done = 3;
+    if (p.max_iter <= 0) h->done = DONE_MAX_ITER;
     HIP_TRY(ctx, hipMemcpyAsync(ctx->st, h, sizeof(DevState), hipMemcpyHostToDevice, ctx->stream));
     launch_prepare(ctx->st, ctx->dprm, ctx->stream);
     HIP_TRY(ctx, hipGetLastError());
     ctx->have_tf = true;
-
-    // Enqueue batches of iterations; poll `done` one batch behind.  A candidate
-    // list that overflows parks the loop with NEED_BIGGER_LIST before any state
-    // was changed: enlarge it and resume from the same iteration.
-    int rc = CVO_HIP_OK;
-    int executed = 0;
-    for (;;) {
-        int enq = 0;          // iterations enqueued in this round
-        int batches = 0;
-        bool stop = p.max_iter <= 0;
-        while (!stop) {
-            const int nb = std::min(kBatch, std::max(1, p.max_iter - enq));
-            for (int q = 0; q < nb && !rc; ++q) {
-                ctx->iter_tag = enq + q;
-                rc = enqueue_flow(ctx, true, 1, true, ctx->trace_dev, trace_cap);
-                if (!rc) rc = enqueue_step(ctx, 1, true, ctx->trace_dev, trace_cap);
-            }
-            ctx->iter_tag = -1;
-            if (rc) break;
-            enq += nb;
-            const int slot = batches % kPollSlots;
-            HIP_TRY(ctx, hipMemcpyAsync(&ctx->st_host[slot], ctx->st, DEVSTATE_HEAD_BYTES,
-                                        hipMemcpyDeviceToHost, ctx->stream));
-            HIP_TRY(ctx, hipEventRecord(ctx->poll_ev[slot], ctx->stream));
-            ++batches;
-            if (batches >= 2) {   // look at the batch before the one just enqueued
-                const int prev = (batches - 2) % kPollSlots;
-                HIP_TRY(ctx, hipEventSynchronize(ctx->poll_ev[prev]));
-                if (ctx->st_host[prev].done != 0) stop = true;
-            }
-            if (enq >= p.max_iter + kBatch) stop = true;   // cannot happen: done is set by then
-        }
-        // everything still queued either runs or returns at once; fetch the state
-        HIP_TRY(ctx, hipMemcpyAsync(&ctx->st_host[0], ctx->st, sizeof(DevState),
-                                    hipMemcpyDeviceToHost, ctx->stream));
-        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-        if (rc) break;
-        const DevState &cur = ctx->st_host[0];
-        if (cur.done != NEED_BIGGER_LIST) break;
-        // profiling: the launches of this round past the parked iteration did nothing
-        if (ctx->profiling) { rc = drain_events(ctx, cur.k - executed + 1); if (rc) break; }
-        executed = cur.k;
-        for (int l = 0; l < LIST_N && !rc; ++l)
-            if (cur.cnt[2 * l + 1]) {
-                double tot = 0.0;   // appended so far; hashing is uniform, so scale by the worst sub-list
-                uint32_t worst = 0;
-                for (int q = 0; q < NSUB; ++q) { tot += cur.sub[l][q]; worst = std::max(worst, cur.sub[l][q]); }
-                const double grown = std::min(4.0e9, std::max((double)worst * NSUB, (double)ctx->lists[l].cap) * 1.5 + 1024.0);
-                rc = ensure_list(ctx, l, 0, 0, grown);
-            }
-        if (rc) break;
-        int32_t zero = 0;
-        HIP_TRY(ctx, hipMemcpyAsync(reinterpret_cast<char *>(ctx->st) + offsetof(DevState, done), &zero,
-                                    sizeof(zero), hipMemcpyHostToDevice, ctx->stream));
-        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-        launch_prepare(ctx->st, ctx->dprm, ctx->stream);   // idempotent; re-zeroes the counters
-        HIP_TRY(ctx, hipGetLastError());
+    const int prc = prepare_buffers(ctx);
+    if (prc) return prc;
+    j.enq = j.batches = j.checked = 0;
+    j.executed_base = 0;
+    j.phase = p.max_iter <= 0 ? 1 : 0;
+    if (j.phase == 1) {
+        HIP_TRY(ctx, hipMemcpyAsync(&ctx->st_host[0], ctx->st, sizeof(DevState), hipMemcpyDeviceToHost,
+                                    ctx->stream));
+        HIP_TRY(ctx, hipEventRecord(ctx->poll_ev[0], ctx->stream));
     }
-    ctx->have_tf = false;   // the low-level entry points need their own transform_pcd()
-    if (rc) return rc;
-    const DevState &f = ctx->st_host[0];
-    if (f.done == 0 || f.done == NEED_BIGGER_LIST)
-        return fail(ctx, CVO_HIP_ERR_INVALID, "align loop ended without a verdict");
-    const int tag_base = executed;   // iteration tags restart at 0 after a resume
-    executed = f.n_exec;
-    if (trace_cap > 0 && executed > 0)
-        HIP_TRY(ctx, hipMemcpy(trace, ctx->trace_dev,
-                               (size_t)std::min(executed, trace_cap) * sizeof(cvo_hip_trace),
-                               hipMemcpyDeviceToHost));
+    return CVO_HIP_OK;
+}
 
-    // ref src/cvo.cpp:413-415: accumulate the transform computed at the TOP of
-    // the last executed iteration, then refresh `transform` from the final R,T
+// ref src/cvo.cpp:413-415 and the trace / state hand-back
+int job_finish(AlignJob &j)
+{
+    cvo_hip_ctx *ctx = j.ctx;
+    cvo_hip_state *s = j.s;
+    const DevState &f = ctx->st_host[0];
+    ctx->have_tf = false;   // the low-level entry points need their own transform_pcd()
+    if (f.done == RUNNING || f.done == NEED_BIGGER_LIST)
+        return fail(ctx, CVO_HIP_ERR_INVALID, "align loop ended without a verdict");
+    const int executed = f.n_exec;
+    if (j.trace_cap > 0 && executed > 0)
+        HIP_TRY(ctx, hipMemcpy(j.trace, ctx->trace_dev,
+                               (size_t)std::min(executed, j.trace_cap) * sizeof(cvo_hip_trace),
+                               hipMemcpyDeviceToHost));
+    // accumulate the transform computed at the TOP of the last executed
+    // iteration, then refresh `transform` from the final R,T
     if (executed > 0) cvo_math::tf_to_mat4(f.used_Rt, f.used_t, s->transform);
     std::memcpy(s->R, f.R, sizeof(s->R));
     std::memcpy(s->T, f.T, sizeof(s->T));
@@ -1049,9 +1145,136 @@ int cvo_hip_align(cvo_hip_ctx *ctx, cvo_hip_state *s, cvo_hip_trace *trace, int 
     float Rt[9], t[3];
     cvo_math::inverse_tf(s->R, s->T, Rt, t);
     cvo_math::tf_to_mat4(Rt, t, s->transform);
-    if (n_iter) *n_iter = executed;
-    if (ctx->profiling) return drain_events(ctx, executed - tag_base);
+    if (j.n_iter) *j.n_iter = executed;
+    if (ctx->profiling) return drain_events(ctx, executed - j.executed_base);
     return CVO_HIP_OK;
+}
+
+// Advance a job without (block = false) or with (block = true) waiting on the
+// GPU.  Returns 1 when the job has finished (j.rc holds its status), else 0.
+// At most two batches are in flight; `done` is looked at one batch behind; a
+// list that overflows parks the loop with NEED_BIGGER_LIST before any state was
+// changed: enlarge it and resume from the same iteration.
+int job_pump(AlignJob &j, bool block)
+{
+    cvo_hip_ctx *ctx = j.ctx;
+    if (j.phase == 2) return 1;
+    auto finish_with = [&](int rc) { j.rc = rc; j.phase = 2; return 1; };
+    if (hipSetDevice(ctx->device) != hipSuccess) return finish_with(CVO_HIP_ERR_HIP);
+    if (j.phase == 0) {
+        bool stop = false;
+        while (j.batches - j.checked < 2) {   // keep two batches queued
+            int rc = launch_batch(ctx, j.enq, j.trace_cap);
+            if (rc) return finish_with(rc);
+            j.enq += kBatch;
+            const int slot = j.batches % kPollSlots;
+            if (hipMemcpyAsync(&ctx->st_host[slot], ctx->st, DEVSTATE_HEAD_BYTES, hipMemcpyDeviceToHost,
+                               ctx->stream) != hipSuccess ||
+                hipEventRecord(ctx->poll_ev[slot], ctx->stream) != hipSuccess)
+                return finish_with(fail(ctx, CVO_HIP_ERR_HIP, "poll copy failed"));
+            ++j.batches;
+        }
+        // look at the oldest batch not yet examined
+        const int slot = j.checked % kPollSlots;
+        hipError_t q = block ? hipEventSynchronize(ctx->poll_ev[slot]) : hipEventQuery(ctx->poll_ev[slot]);
+        if (q == hipErrorNotReady) return 0;
+        if (q != hipSuccess) return finish_with(fail(ctx, CVO_HIP_ERR_HIP, "poll event failed"));
+        ++j.checked;
+        if (ctx->st_host[slot].done != RUNNING) stop = true;
+        if (j.enq >= ctx->prm.max_iter + 2 * kBatch) stop = true;   // cannot happen: done is set by then
+        if (!stop) return 0;
+        // everything still queued either runs or returns at once; fetch the full state
+        if (hipMemcpyAsync(&ctx->st_host[0], ctx->st, sizeof(DevState), hipMemcpyDeviceToHost,
+                           ctx->stream) != hipSuccess ||
+            hipEventRecord(ctx->poll_ev[0], ctx->stream) != hipSuccess)
+            return finish_with(fail(ctx, CVO_HIP_ERR_HIP, "state copy failed"));
+        j.phase = 1;
+    }
+    // phase 1: wait for the final state
+    hipError_t q = block ? hipEventSynchronize(ctx->poll_ev[0]) : hipEventQuery(ctx->poll_ev[0]);
+    if (q == hipErrorNotReady) return 0;
+    if (q != hipSuccess) return finish_with(fail(ctx, CVO_HIP_ERR_HIP, "state event failed"));
+    const DevState &cur = ctx->st_host[0];
+    if (cur.done != NEED_BIGGER_LIST) return finish_with(job_finish(j));
+    // grow the overflowed list(s) and resume from the parked iteration
+    int rc = CVO_HIP_OK;
+    if (ctx->profiling) rc = drain_events(ctx, cur.k - j.executed_base + 1);
+    j.executed_base = cur.k;
+    for (int l = 0; l < LIST_N && !rc; ++l)
+        if (cur.cnt[2 * l + 1]) {
+            uint32_t worst = 0;   // appends are spread evenly: scale by the fullest sub-list
+            for (int qq = 0; qq < NSUB; ++qq) worst = std::max(worst, cur.sub[l][qq]);
+            const double grown =
+                std::min(4.0e9, std::max((double)worst * NSUB, (double)ctx->lists[l].cap) * 1.5 + 1024.0);
+            rc = ensure_list(ctx, l, 0, 0, grown);
+        }
+    if (rc) return finish_with(rc);
+    int32_t zero = 0;
+    if (hipMemcpyAsync(reinterpret_cast<char *>(ctx->st) + offsetof(DevState, done), &zero, sizeof(zero),
+                       hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+        hipStreamSynchronize(ctx->stream) != hipSuccess)
+        return finish_with(fail(ctx, CVO_HIP_ERR_HIP, "resume failed"));
+    launch_prepare(ctx->st, ctx->dprm, ctx->stream);   // idempotent; re-zeroes the counters
+    if (hipGetLastError() != hipSuccess) return finish_with(fail(ctx, CVO_HIP_ERR_HIP, "resume failed"));
+    j.enq = j.batches = j.checked = 0;
+    j.phase = 0;
+    return 0;
+}
+
+}   // namespace
+
+int cvo_hip_align(cvo_hip_ctx *ctx, cvo_hip_state *s, cvo_hip_trace *trace, int trace_cap,
+                  int *n_iter)
+{
+    if (!ctx || !s) return CVO_HIP_ERR_INVALID;
+    AlignJob j;
+    j.ctx = ctx; j.s = s; j.trace = trace; j.trace_cap = trace_cap; j.n_iter = n_iter;
+    int rc = job_begin(j);
+    if (rc) return rc;
+    while (!job_pump(j, true)) {}
+    return j.rc;
+}
+
+int cvo_hip_align_many(cvo_hip_ctx **ctxs, cvo_hip_state **states, int *n_iters, int count)
+{
+    if (count < 0 || (count > 0 && (!ctxs || !states))) return CVO_HIP_ERR_INVALID;
+    std::vector<AlignJob> jobs((size_t)count);
+    for (int i = 0; i < count; ++i) {
+        if (!ctxs[i] || !states[i]) return CVO_HIP_ERR_INVALID;
+        for (int k = 0; k < i; ++k)
+            if (ctxs[k] == ctxs[i]) return CVO_HIP_ERR_INVALID;   // one job per context
+        jobs[i].ctx = ctxs[i];
+        jobs[i].s = states[i];
+        jobs[i].n_iter = n_iters ? &n_iters[i] : nullptr;
+    }
+    int first_err = CVO_HIP_OK;
+    for (int i = 0; i < count; ++i) {
+        const int rc = job_begin(jobs[i]);
+        if (rc) { jobs[i].rc = rc; jobs[i].phase = 2; if (!first_err) first_err = rc; }
+    }
+    // round-robin: every pass tops up each registration's queue and looks at its
+    // poll word without blocking; when nobody moved, block on the oldest job
+    for (;;) {
+        int live = 0, moved = 0, first_live = -1;
+        for (int i = 0; i < count; ++i) {
+            if (jobs[i].phase == 2) continue;
+            const int before_phase = jobs[i].phase, before_checked = jobs[i].checked;
+            if (job_pump(jobs[i], false)) {
+                if (jobs[i].rc && !first_err) first_err = jobs[i].rc;
+                ++moved;
+                continue;
+            }
+            ++live;
+            if (first_live < 0) first_live = i;
+            if (jobs[i].phase != before_phase || jobs[i].checked != before_checked) ++moved;
+        }
+        if (live == 0) break;
+        if (!moved) {
+            if (job_pump(jobs[first_live], true) && jobs[first_live].rc && !first_err)
+                first_err = jobs[first_live].rc;
+        }
+    }
+    return first_err;
 }
 
 int cvo_hip_function_inner_product(cvo_hip_ctx *ctx, float ell, float *out)

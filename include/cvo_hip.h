@@ -187,6 +187,13 @@ int cvo_hip_dist_se3(const float omega[3], const float v[3], float dt, float *di
 int cvo_hip_align(cvo_hip_ctx *ctx, cvo_hip_state *state, cvo_hip_trace *trace,
                   int trace_cap, int *n_iter);
 
+/* Batched mode (BASELINE configs[4], ref SURVEY 8e): `count` independent
+ * registrations, one context (= one device stream) each, driven concurrently by
+ * the calling thread.  Equivalent to calling cvo_hip_align(ctxs[i], states[i],
+ * NULL, 0, &n_iters[i]) for every i, but with all of them in flight at once.
+ * Returns the first non-zero status, 0 if all succeeded. */
+int cvo_hip_align_many(cvo_hip_ctx **ctxs, cvo_hip_state **states, int *n_iters, int count);
+
 /* acvo::function_inner_product (ref src/adaptive_cvo.cpp:385-439) between the
  * fixed and the (untransformed) moving cloud at length-scale ell. */
 int cvo_hip_function_inner_product(cvo_hip_ctx *ctx, float ell, float *out);

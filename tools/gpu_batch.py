@@ -1,0 +1,33 @@
+#!/usr/bin/env python3
+"""Throughput probe: B independent registrations in flight through
+cvo_hip_align_many (one context + one HIP stream each, one host thread)."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+import __graft_entry__ as ge
+
+pkg = ge.load_package()
+capi = pkg.capi
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
+reps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+for B in (1, 2, 4, 8, 16):
+    ctxs, streams = [], []
+    for b in range(B):
+        s = torch.cuda.Stream()
+        xf, ff, xm, fm = pkg.data.synthetic_pair(n, n, seed=pkg.data.SEED_CFG2)
+        c = capi.Context(mode=capi.MODE_CVO, device=0, stream=s.cuda_stream)
+        c.set_fixed(xf, ff); c.set_moving(xm, fm)
+        ctxs.append(c); streams.append(s)
+    def step():
+        states = [capi.init_state(c.params) for c in ctxs]
+        return capi.align_many(ctxs, states), states
+    its, _ = step()
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    for _ in range(reps):
+        its, states = step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t
+    print("B %2d: %.1f registrations/s (%.2f ms per batch, iters %s)" % (B, B * reps / dt, dt * 1e3 / reps, its[:3]))
+    for c in ctxs: c.close()
