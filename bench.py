@@ -1,15 +1,20 @@
 #!/usr/bin/env python3
 """bench.py -- frame-pair registrations/s of the CVO inner loop on MI355X.
 
-A "step" is one full align() (ref src/cvo.cpp:361-420: ~50 gradient-flow
-iterations, each = transform + flow sweep + step-size sweep over all
-target x source pairs) of BASELINE.json configs[1]: the seeded synthetic
-10k x 10k RGB-D cloud pair, from the reference object's initial state, with
-both clouds already resident in HBM.  One process per GPU; for N > 1 every rank
-registers its own pair (independent frame pairs: weak scaling, no data-path
-collective), and -- as a separately reported leg -- all ranks also run the
-target-sharded mode whose twist / step-coefficient partial sums are
-all-reduced with RCCL (BASELINE.json configs[3] scaled to fit the time budget).
+A "step" is one pass of the hot path over one BATCH of synthetic input: `--batch`
+(default 4) independent frame pairs of BASELINE.json configs[1] -- the seeded
+synthetic 10k x 10k RGB-D cloud pair -- each run through a full align()
+(ref src/cvo.cpp:361-420: ~50 gradient-flow iterations, each = transform +
+all-pairs neighbour filter + flow pass + step-size pass) from the reference
+object's initial state, all clouds already resident in HBM, all registrations
+of the batch in flight at once (one context + one HIP stream each,
+cvo_hip_align_many).  `value` = registrations completed per second; the
+single-registration latency (batch of one) is measured in the same run and
+reported as `single_stream`.  One process per GPU; for N > 1 every rank runs its
+own batches (independent frame pairs: weak scaling, no data-path collective),
+and -- as a separately reported leg -- all ranks also run the target-sharded
+mode whose twist / step-coefficient partial sums are all-reduced with RCCL
+(BASELINE.json configs[3] scaled to fit the time budget).
 
 Prints ONE JSON line on rank 0.
 """
@@ -37,6 +42,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--points", type=int, default=10000, help="N = M of the synthetic pair")
+    ap.add_argument("--batch", type=int, default=4, help="frame pairs in flight per step")
     ap.add_argument("--mode", default="cvo", choices=["cvo", "acvo"])
     ap.add_argument("--cpu-seconds", type=float, default=15.0,
                     help="budget of the cpu_baseline leg (rank 0, N=1 only)")
@@ -70,36 +76,65 @@ def main():
     acvo = args.mode == "acvo"
     mode = capi.MODE_ACVO if acvo else capi.MODE_CVO
     n = m = args.points
-    # every rank registers its own frame pair (seed + rank)
-    xf, ff, xm, fm = pkg.data.synthetic_pair(n, m, seed=pkg.data.SEED_CFG2 + rank, acvo=acvo)
-    stream = torch.cuda.current_stream().cuda_stream
-    ctx = capi.Context(mode=mode, device=local_rank, stream=stream)
-    ctx.set_fixed(xf, ff)
-    ctx.set_moving(xm, fm)
+    # every rank registers its own frame pairs: `batch` contexts, one stream each
+    # (all pairs are the configs[1] pair itself: identical work per registration)
+    xf, ff, xm, fm = pkg.data.synthetic_pair(n, m, seed=pkg.data.SEED_CFG2, acvo=acvo)
+    B = max(1, args.batch)
+    streams = [torch.cuda.Stream() for _ in range(B)]
+    ctxs = []
+    for b in range(B):
+        c = capi.Context(mode=mode, device=local_rank, stream=streams[b].cuda_stream)
+        c.set_fixed(xf, ff)
+        c.set_moving(xm, fm)
+        ctxs.append(c)
+    ctx = ctxs[0]
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    def one_step():
-        st = capi.init_state(ctx.params)
-        n_it, _ = ctx.align(st, trace_cap=0)
-        return n_it, st
+    def one_step(cs):
+        states = [capi.init_state(c.params) for c in cs]
+        its = capi.align_many(cs, states)
+        return its, states
 
     for _ in range(args.warmup):
-        one_step()
-    ctx.set_profiling(True)
-    ctx.get_profile(reset=True)
+        one_step(ctxs)
     barrier()
     t0 = time.perf_counter()
     iters = 0
     last_state = None
     for _ in range(args.steps):
-        n_it, last_state = one_step()
-        iters += n_it
+        its, states = one_step(ctxs)
+        iters += sum(its)
+        last_state = states[0]
     barrier()
     elapsed = time.perf_counter() - t0
+
+    # the same pair, one registration at a time (latency view), same run
+    for _ in range(2):
+        one_step(ctxs[:1])
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    it1 = 0
+    n1 = max(5, args.steps)
+    for _ in range(n1):
+        its, _ = one_step(ctxs[:1])
+        it1 += its[0]
+    torch.cuda.synchronize()
+    el1 = time.perf_counter() - t1
+    single = {"registrations_per_s": n1 / el1, "ms_per_registration": el1 * 1e3 / n1,
+              "ms_per_iteration": el1 * 1e3 / max(it1, 1)}
+
+    # roofline leg: HIP events on context 0's own stream around every k_filter launch,
+    # one registration in flight so that a launch has the device to itself (a kernel
+    # duration measured while B streams share the CUs is not a roofline input)
+    ctx.set_profiling(True)
+    ctx.get_profile(reset=True)
+    for _ in range(max(3, args.steps // 4)):
+        one_step(ctxs[:1])
+    torch.cuda.synchronize()
     prof = ctx.get_profile(reset=True)
     ctx.set_profiling(False)
 
@@ -109,7 +144,7 @@ def main():
         dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
         dist.all_reduce(it_sum, op=dist.ReduceOp.SUM)
     elapsed = float(t_max.item())
-    total_regs = args.steps * world
+    total_regs = args.steps * world * B
     value = total_regs / elapsed
 
     # parity sanity inside the bench: the registration recovers the synthetic motion
@@ -152,13 +187,16 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": "synthetic %dk x %dk RGB-D cloud pair (xyz + 5-dim colour), %s align() "
-                            "to convergence, dense all-pairs sweeps" % (n // 1000, m // 1000, args.mode),
+                            "to convergence; a step = a batch of %d such registrations in flight"
+                            % (n // 1000, m // 1000, args.mode, B),
                 "points_fixed": n, "points_moving": m, "mode": args.mode,
                 "pairs_per_sweep": float(n) * m,
-                "parallelism": "1 registration per GPU" if world > 1 else "single GPU",
+                "batch": B,
+                "parallelism": "%d independent registrations in flight per GPU (one HIP stream each)" % B,
             },
             "iterations_per_registration": float(it_sum.item()) / total_regs,
             "ms_per_iteration": elapsed * 1e3 * world / max(float(it_sum.item()), 1.0),
+            "single_stream": single,
             "gt_motion_rel_err": {"rot": rot_err, "trans": tr_err},
             "roofline": {
                 "kernel": "cvo_dev::k_filter (all target x source pair tests, v_mfma_f32_16x16x4_f32)",
@@ -171,6 +209,8 @@ def main():
                 "flop_per_launch": FLOP_PER_PAIR * pairs,
                 "avg_launch_us": sweep_ms * 1e3,
                 "launches": launches,
+                "measured": "HIP events on the launching stream, every k_filter launch of %d "
+                            "single-stream registrations of the same run" % max(3, args.steps // 4),
                 "traffic": traffic,
             },
             "roofline_hbm": {
@@ -187,7 +227,8 @@ def main():
         if world == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(args, pkg, xf, ff, xm, fm, acvo)
         print(json.dumps(out), flush=True)
-    ctx.close()
+    for c in ctxs:
+        c.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

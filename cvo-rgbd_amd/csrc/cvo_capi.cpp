@@ -399,13 +399,11 @@ int enqueue_filter(cvo_hip_ctx *ctx, int list, const Cloud &ca, int row_lo, int 
         ev.kind = list;
         ev.iter_tag = ctx->iter_tag;
         ev.pairs = (double)nrows * (double)nb;
-        HIP_TRY(ctx, hipEventRecord(ev.a, ctx->stream));
     }
-    launch_filter(a, pl.grid, ctx->stream);
-    if (ctx->profiling) {
-        HIP_TRY(ctx, hipEventRecord(ev.b, ctx->stream));
-        ctx->events.push_back(ev);
-    }
+    // profiling: the two events are attached to the dispatch itself (kernel begin /
+    // end timestamps, what rocprofv3's kernel trace reports), not recorded around it
+    launch_filter(a, pl.grid, ctx->stream, ev.a, ev.b);
+    if (ctx->profiling) ctx->events.push_back(ev);
     HIP_TRY(ctx, hipGetLastError());
     return CVO_HIP_OK;
 }

@@ -3,6 +3,7 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stddef.h>
 #include <stdint.h>
 
@@ -261,7 +262,8 @@ CVO_HD void prepare_iteration(DevState *s, const DevParams &p)
 
 size_t filter_smem_bytes(int jt);
 void launch_prepare(DevState *st, const DevParams &prm, hipStream_t s);
-void launch_filter(const FilterArgs &a, dim3 grid, hipStream_t s);
+void launch_filter(const FilterArgs &a, dim3 grid, hipStream_t s, hipEvent_t ev_start = nullptr,
+                   hipEvent_t ev_stop = nullptr);
 void launch_process(int mode, const ProcessArgs &a, hipStream_t s);
 void launch_post_flow(const PostFlowArgs &a, hipStream_t s);
 void launch_post_step(const PostStepArgs &a, hipStream_t s);

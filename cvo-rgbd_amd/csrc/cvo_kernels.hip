@@ -281,9 +281,14 @@ __global__ void __launch_bounds__(BLOCK) k_filter(const FilterArgs a)
     }
 }
 
-void launch_filter(const FilterArgs &a, dim3 grid, hipStream_t s)
+void launch_filter(const FilterArgs &a, dim3 grid, hipStream_t s, hipEvent_t ev_start,
+                   hipEvent_t ev_stop)
 {
-    hipLaunchKernelGGL(k_filter, grid, dim3(BLOCK), filter_smem_bytes(a.jt), s, a);
+    if (ev_start && ev_stop)   // the events take the dispatch packet's own begin / end timestamps
+        hipExtLaunchKernelGGL(k_filter, grid, dim3(BLOCK), filter_smem_bytes(a.jt), s, ev_start,
+                              ev_stop, 0, a);
+    else
+        hipLaunchKernelGGL(k_filter, grid, dim3(BLOCK), filter_smem_bytes(a.jt), s, a);
 }
 
 // ---------------------------------------------------------------------------

@@ -188,3 +188,46 @@ def test_column_major_features_are_the_reference_layout(pkg, po):
     assert np.array_equal(a.flow(0.1), b.flow(0.1))
     a.close()
     b.close()
+
+
+@pytest.mark.parametrize("mode_name", ["cvo", "acvo"])
+def test_align_many_equals_one_by_one(pkg, mode_name):
+    """Batched mode (BASELINE configs[4]): several registrations in flight, one
+    context + stream each, give exactly what align() gives one at a time."""
+    import torch
+    capi = pkg.capi
+    acvo = mode_name == "acvo"
+    mode = capi.MODE_ACVO if acvo else capi.MODE_CVO
+    sizes = [(1500, 1700), (2500, 2300), (900, 3100), (2000, 2000), (64, 50)]
+    streams = [torch.cuda.Stream() for _ in sizes]
+    clouds = [pkg.data.synthetic_pair(n, m, seed=40 + i, acvo=acvo) for i, (n, m) in enumerate(sizes)]
+    ctxs = []
+    for s, (xf, ff, xm, fm) in zip(streams, clouds):
+        c = capi.Context(mode=mode, device=0, stream=s.cuda_stream)
+        c.set_fixed(xf, ff)
+        c.set_moving(xm, fm)
+        ctxs.append(c)
+    ref_states, ref_iters = [], []
+    for c in ctxs:
+        st = capi.init_state(c.params)
+        n_it, _ = c.align(st, trace_cap=0)
+        ref_states.append(st)
+        ref_iters.append(n_it)
+    for _ in range(2):   # twice: the second pass reuses cached graphs and warmed lists
+        states = [capi.init_state(c.params) for c in ctxs]
+        iters = capi.align_many(ctxs, states)
+        assert list(iters) == ref_iters
+        for a, b in zip(states, ref_states):
+            assert bytes(a) == bytes(b)
+    # the batch carries frame-to-frame state exactly like align()
+    states2 = [capi.init_state(c.params) for c in ctxs]
+    capi.align_many(ctxs, states2)
+    it_a = capi.align_many(ctxs, states2)
+    for c, st in zip(ctxs, ref_states):
+        n_it, _ = c.align(st, trace_cap=0)
+    assert [s.iter for s in states2] == [s.iter for s in ref_states]
+    for a, b in zip(states2, ref_states):
+        assert bytes(a) == bytes(b)
+    assert len(it_a) == len(ctxs)
+    for c in ctxs:
+        c.close()

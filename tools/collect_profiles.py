@@ -22,7 +22,8 @@ def one(pattern):
     return g[0] if g else None
 
 
-for pat, name in (("bench.json", "%s_bench.json"), ("stats/*kernel_stats.csv", "%s_kernel_stats.csv")):
+for pat, name in (("bench.json", "%s_bench.json"), ("stats/*kernel_stats.csv", "%s_kernel_stats.csv"),
+                  ("stats_batch/*kernel_stats.csv", "%s_kernel_stats_batch4.csv")):
     f = one(pat)
     if f:
         shutil.copy(f, os.path.join(dst, name % tag))
@@ -51,6 +52,23 @@ for pat in ("pmc_fetch/*counter_collection.csv", "pmc_write/*counter_collection.
                                             "avg": sum(real) / max(len(real), 1), "max": vv[-1]}
 with open(os.path.join(dst, "%s_pmc_summary.json" % tag), "w") as fh:
     json.dump(summary, fh, indent=1, sort_keys=True)
+
+# kernel durations over the launches that did work (the ones queued past convergence
+# return after their first load: well under 0.4 x the median), from the kernel trace of the --batch 1 run
+tr = one("stats/*kernel_trace.csv")
+if tr:
+    dur = collections.defaultdict(list)
+    for r in csv.DictReader(open(tr)):
+        k = r["Kernel_Name"].split("(")[0].replace("cvo_dev::", "").replace("void ", "")
+        dur[k].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+    live = {}
+    for k, v in dur.items():
+        med = sorted(v)[len(v) // 2]
+        lv = [x for x in v if x > 0.4 * med]
+        live[k] = {"launches": len(v), "avg_us": sum(v) / len(v), "live_launches": len(lv),
+                   "live_avg_us": sum(lv) / max(len(lv), 1), "total_us": sum(v)}
+    with open(os.path.join(dst, "%s_kernel_live.json" % tag), "w") as fh:
+        json.dump(live, fh, indent=1, sort_keys=True)
 
 kf = summary.get("k_filter", {})
 if "FETCH_SIZE" in kf:

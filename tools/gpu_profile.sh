@@ -10,7 +10,9 @@ cd $ROOTDIR
 python bench.py --steps 20 --warmup 3 > $OUT/bench.json 2> $OUT/bench.err
 tail -1 $OUT/bench.json
 cd /tmp && export TMPDIR=/tmp
-B="python $ROOTDIR/bench.py --steps 5 --warmup 1 --no-cpu"
+# kernel durations are only meaningful with one registration in flight: --batch 1
+B="python $ROOTDIR/bench.py --batch 1 --steps 5 --warmup 1 --no-cpu"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_batch -o stats -- python $ROOTDIR/bench.py --steps 5 --warmup 1 --no-cpu > $OUT/stats_batch.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o stats -- $B > $OUT/stats.log 2>&1
 # PMC passes: counters only (gpurun refuses --pmc together with the trace domains)
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o fetch -- $B > $OUT/pmc_fetch.log 2>&1

@@ -36,3 +36,13 @@ for rep in range(3):
     rot, tr = pkg.data.rel_pose_error(np.linalg.inv(reg.transform.astype(np.float64)), np.linalg.inv(pkg.data.gt_motion()))
     reg.close()
 print("final transform vs ground truth motion (rel rot err, rel trans err):", rot, tr)
+
+# cloud hand-over cost (host Morton sort + H2D), the PCIe-inclusive part of a frame
+ctx = pkg.capi.Context(mode=pkg.capi.MODE_CVO, device=0, stream=torch.cuda.current_stream().cuda_stream)
+for rep in range(3):
+    t = time.time()
+    ctx.set_moving(xm, fm)
+    ctx.synchronize()
+    dt = time.time() - t
+print("set_moving (%d points, sort + upload): %.3f ms" % (n, dt * 1e3))
+ctx.close()
