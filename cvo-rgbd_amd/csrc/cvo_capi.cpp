@@ -154,6 +154,12 @@ DevParams make_dev_params(const cvo_hip_params &p)
     d.s2_d = (double)s2;
     d.cs2_d = (double)cs2;
     d.dl_step = p.dl_step;
+    // tile-list re-use (cvo_device.h plan_lists); CVO_HIP_LIST_MARGIN=0 rebuilds every iteration
+    d.list_margin = 0.15f;
+    if (const char *e = getenv("CVO_HIP_LIST_MARGIN")) {
+        const double m = atof(e);
+        d.list_margin = (m >= 0.0 && m <= 4.0) ? (float)m : d.list_margin;
+    }
     return d;
 }
 
@@ -448,13 +454,18 @@ int enqueue_process(cvo_hip_ctx *ctx, int mode, int list, DevBuf &part, const fl
 
 // n_exec >= 0: launches tagged with an iteration >= n_exec were queued past
 // convergence and returned at once; they are not sweeps and are not counted.
-int drain_events(cvo_hip_ctx *ctx, int n_exec = -1)
+// Inside align() a launch whose list is re-used returns at once as well: `fin`
+// (the final state) tells which iterations rebuilt which list.
+int drain_events(cvo_hip_ctx *ctx, int n_exec = -1, const DevState *fin = nullptr)
 {
     for (auto &ev : ctx->events) {
         float ms = 0.f;
         HIP_TRY(ctx, hipEventSynchronize(ev.b));
         HIP_TRY(ctx, hipEventElapsedTime(&ms, ev.a, ev.b));
-        if (n_exec >= 0 && ev.iter_tag >= n_exec) {
+        bool live = !(n_exec >= 0 && ev.iter_tag >= n_exec);
+        if (live && fin && ev.iter_tag >= 0 && ev.kind >= 0 && ev.kind < 3)
+            live = (fin->built[ev.kind][(ev.iter_tag >> 5) & 63] >> (ev.iter_tag & 31)) & 1u;
+        if (!live) {
             // skipped launch
         } else if (ev.kind == LIST_XY) {
             ctx->prof.flow_ms += ms; ctx->prof.flow_launches++; ctx->prof.flow_pairs += ev.pairs;
@@ -1144,7 +1155,7 @@ int job_finish(AlignJob &j)
     cvo_math::inverse_tf(s->R, s->T, Rt, t);
     cvo_math::tf_to_mat4(Rt, t, s->transform);
     if (j.n_iter) *j.n_iter = executed;
-    if (ctx->profiling) return drain_events(ctx, executed - j.executed_base);
+    if (ctx->profiling) return drain_events(ctx, executed, &f);
     return CVO_HIP_OK;
 }
 
@@ -1162,7 +1173,7 @@ int job_pump(AlignJob &j, bool block)
     if (j.phase == 0) {
         bool stop = false;
         while (j.batches - j.checked < 2) {   // keep two batches queued
-            int rc = launch_batch(ctx, j.enq, j.trace_cap);
+            int rc = launch_batch(ctx, j.executed_base + j.enq, j.trace_cap);
             if (rc) return finish_with(rc);
             j.enq += kBatch;
             const int slot = j.batches % kPollSlots;
@@ -1196,7 +1207,7 @@ int job_pump(AlignJob &j, bool block)
     if (cur.done != NEED_BIGGER_LIST) return finish_with(job_finish(j));
     // grow the overflowed list(s) and resume from the parked iteration
     int rc = CVO_HIP_OK;
-    if (ctx->profiling) rc = drain_events(ctx, cur.k - j.executed_base + 1);
+    if (ctx->profiling) rc = drain_events(ctx, cur.k + 1, &cur);
     j.executed_base = cur.k;
     for (int l = 0; l < LIST_N && !rc; ++l)
         if (cur.cnt[2 * l + 1]) {

@@ -100,7 +100,8 @@ struct DevParams {
     float min_step, eps, eps_2;
     float log_sp_s2;     // (float)log(sp/s2): tau = (float)(-2.0*l*l*log_sp_s2)
     float tau_c;         // (float)(-2.0*c_ell*c_ell*(float)log(c_sp/c_sigma/c_sigma))
-    float pad_;
+    float list_margin;   // tile lists are built (1 + list_margin) wider than needed and re-used
+                         // while they provably still hold every pair; 0 = rebuild every iteration
     double s2_d, cs2_d, dl_step;
 };
 
@@ -117,6 +118,12 @@ struct DevState {
     float center[3];
     float xmax, y0max;          // max |x - center|, max |y0 - center| (bbox bounds)
     float tauf[3];
+    // Tile-list re-use (plan_lists): list l was built with every pair closer than
+    // list_r[l]; the xy list with the moving cloud at [list_Rt | list_t].
+    float list_r[3];
+    int32_t list_ok[3];         // list l holds a build of this align()
+    int32_t reuse[3];           // this iteration consumes list l as it is: k_filter returns at once
+    float list_Rt[9], list_t[3];
     cvo_math::XiConsts xi;      // twist constants for the step-size pass
     float omega[3], v[3];
     double dl;
@@ -130,6 +137,9 @@ struct DevState {
     // entries appended to every sub-list (kept last: the host polls only the
     // part of the state in front of it)
     uint32_t sub[LIST_N][NSUB];
+    // bit k of built[l]: iteration k (mod 2048) rebuilt list l (profiling: which
+    // k_filter launches did the work)
+    uint32_t built[3][64];
 };
 constexpr size_t DEVSTATE_HEAD_BYTES = offsetof(DevState, sub);
 
@@ -250,12 +260,66 @@ CVO_HD void compute_filter_bounds(DevState *s, bool identity)
     s->tauf[LIST_YY] = (float)((tau + u16 * syy) * 1.000001 + 1e-12);
 }
 
-// Everything an iteration needs that derives from (R, T, ell).
+// Tile-list re-use.  k_filter is conservative and membership in A is decided by
+// the exact test of k_process, so a list stays valid for as long as it is a
+// superset of {pairs with d2 < tau}.  A list is therefore built for the radius
+// list_r = (1 + margin) * sqrt(tau) and kept while
+//     sqrt(tau_now) + (how far any moving point has travelled since the build) <= list_r
+// (triangle inequality; the xx / yy lists of acvo are rigid: only tau matters).
+// The travel of y = Rt y0 + t is bounded by |dRt|_2 max|y0 - c| + |dRt c + dt| with
+// |dRt|_2 = |dRt|_F / sqrt(2) for a difference of rotations.  A list much wider
+// than needed (after ell dropped) is rebuilt as well.  All slack terms are far
+// above the float32 rounding of the coordinates and of d2 (<= ~1e-5 m here) and
+// far below the margin (>= 1 mm at ell_min): decisions change performance only.
+constexpr double LIST_LOOSE = 1.3;
+CVO_HD void plan_lists(DevState *s, const DevParams &p)
+{
+    const double r_now = sqrt((double)s->kc.tau);
+    const double ymax = (double)s->y0max;
+    const double slack = 1.0e-4 * (1.0 + (double)s->xmax + ymax);
+    const double margin = (double)p.list_margin;
+    double travel = 0.0;
+    if (s->list_ok[LIST_XY]) {
+        double f2 = 0.0, c2 = 0.0;
+        for (int r = 0; r < 3; ++r) {
+            double dc = (double)s->t[r] - (double)s->list_t[r];
+            for (int q = 0; q < 3; ++q) {
+                const double d = (double)s->Rt[3 * r + q] - (double)s->list_Rt[3 * r + q];
+                f2 += d * d;
+                dc += d * (double)s->center[q];
+            }
+            c2 += dc * dc;
+        }
+        travel = sqrt(0.5 * f2) * 1.001 * ymax + sqrt(c2);
+    }
+    for (int l = 0; l < 3; ++l) {
+        const double need = (r_now + (l == LIST_XY ? travel : 0.0)) * 1.0001 + slack;
+        const double lr = (double)s->list_r[l];
+        const bool keep = margin > 0.0 && s->list_ok[l] && need <= lr &&
+                          lr <= LIST_LOOSE * (1.0 + margin) * (r_now * 1.0001 + slack);
+        s->reuse[l] = keep ? 1 : 0;
+        if (keep) continue;
+        const double rb = (r_now * 1.0001 + slack) * (1.0 + margin);
+        s->list_r[l] = (float)(rb * 1.000001);   // rounded up: the list holds at least this radius
+        s->list_ok[l] = 1;
+        if (margin > 0.0)   // tauf of compute_filter_bounds is tau + rounding slack: widen tau
+            s->tauf[l] = (float)(((double)s->list_r[l] * (double)s->list_r[l] +
+                                  ((double)s->tauf[l] - (double)s->kc.tau)) * 1.000001 + 1e-12);
+        if (l == LIST_XY) {
+            for (int q = 0; q < 9; ++q) s->list_Rt[q] = s->Rt[q];
+            for (int q = 0; q < 3; ++q) s->list_t[q] = s->t[q];
+        }
+    }
+}
+
+// Everything an iteration needs that derives from (R, T, ell).  The caller logs
+// the lists that are rebuilt (reuse[l] == 0) in DevState::built.
 CVO_HD void prepare_iteration(DevState *s, const DevParams &p)
 {
     cvo_math::inverse_tf(s->R, s->T, s->Rt, s->t);
     s->kc = make_kconsts(p, s->ell);
     compute_filter_bounds(s, false);
+    plan_lists(s, p);
     for (int q = 0; q < 2 * LIST_N; ++q) s->cnt[q] = 0u;
     // (the per-sub-list counters are zeroed by all threads of the calling kernel)
 }

@@ -101,7 +101,8 @@ __global__ void __launch_bounds__(BLOCK) k_filter(const FilterArgs a)
     const long long w_start = a.dbg ? (long long)wall_clock64() : 0;
     // first round trip: the loop-control word, the state constants and this
     // thread's bounding spheres are all fetched before anything waits
-    const int done_word = a.check_done ? a.st->done : 0;
+    // (inside align() a list that is still valid is consumed again: nothing to do)
+    const int done_word = a.check_done ? (a.st->done | a.st->reuse[a.list]) : 0;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float *bop = reinterpret_cast<float *>(smem);
     float4 *xrow = reinterpret_cast<float4 *>(smem + (size_t)a.jt * 16);
@@ -707,9 +708,17 @@ __global__ void __launch_bounds__(BLOCK) k_post_step(const PostStepArgs a)
         a.dbg[0] += 1; a.dbg[1] += c1 - c0; a.dbg[2] += (long long)__builtin_readcyclecounter() - c1;
     }
     if (a.flags & POST_MATH) {
-        // the lists of this iteration have been consumed: empty them for the next one
-        for (int q = threadIdx.x; q < LIST_N * NSUB; q += BLOCK) (&a.st->sub[0][0])[q] = 0u;
         if (threadIdx.x < 64) post_step_math(st, a);   // wave 0: the cubic uses all its lanes
+        __syncthreads();
+        // the tile lists the next iteration rebuilds are emptied; the others are kept
+        if (st->done == RUNNING) {
+            for (int l = 0; l < 3; ++l) {
+                if (st->reuse[l]) continue;
+                for (int q = threadIdx.x; q < NSUB; q += BLOCK) a.st->sub[l][q] = 0u;
+                if (threadIdx.x == 0)
+                    atomicOr(&a.st->built[l][(st->k >> 5) & 63], 1u << (st->k & 31));
+            }
+        }
     }
     __syncthreads();
     state_head_from_lds(&s_st, a.st);
@@ -802,10 +811,18 @@ __device__ void post_step_math(DevState *st, const PostStepArgs &a)
     if (a.dbg) { a.dbg[4] += c4 - c3; a.dbg[5] += (long long)__builtin_readcyclecounter() - c4; }
 }
 
+// First iteration of an align() (or of its resumption after a list grew): no
+// list is valid, everything is rebuilt.
 __global__ void k_prepare(DevState *st, const DevParams prm)
 {
     for (int q = threadIdx.x; q < LIST_N * NSUB; q += BLOCK) (&st->sub[0][0])[q] = 0u;
-    if (threadIdx.x == 0) prepare_iteration(st, prm);
+    if (threadIdx.x == 0) {
+        for (int l = 0; l < 3; ++l) {
+            st->list_ok[l] = 0;
+            atomicOr(&st->built[l][(st->k >> 5) & 63], 1u << (st->k & 31));
+        }
+        prepare_iteration(st, prm);
+    }
 }
 
 void launch_prepare(DevState *st, const DevParams &prm, hipStream_t s)
