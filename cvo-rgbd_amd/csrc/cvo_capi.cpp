@@ -77,6 +77,17 @@ struct GraphEntry {
 };
 constexpr int kPollSlots = 4;
 
+// One kernel launch of an iteration, recorded instead of launched (fused mode:
+// the launches of several registrations are merged slot by slot).
+struct RecOp {
+    enum Kind { FILTER, PROCESS, POST_FLOW, POST_STEP } kind;
+    int mode = 0;   // PROCESS: ProcMode
+    FilterArgs f{};
+    ProcessArgs p{};
+    PostFlowArgs pf{};
+    PostStepArgs ps{};
+};
+
 }   // namespace
 
 struct cvo_hip_ctx {
@@ -87,7 +98,9 @@ struct cvo_hip_ctx {
     DevParams dprm{};
     Cloud fixed, moving;
     DevState *st = nullptr;          // device
-    DevState *st_host = nullptr;     // pinned [kPollSlots + 1]
+    DevState *st_host = nullptr;     // pinned [kPollSlots + 2]
+    int32_t *done_mirror = nullptr;  // pinned (in the last slot): the post kernels copy `done` here
+    std::vector<RecOp> *rec = nullptr;   // not null: record launches instead of issuing them
     hipEvent_t poll_ev[kPollSlots]{};
     DevBuf part_flow, part_xx, part_yy, part_step;   // [PROC_BLOCKS][NACC_MAX] float64
     List lists[LIST_N];
@@ -398,6 +411,12 @@ int enqueue_filter(cvo_hip_ctx *ctx, int list, const Cloud &ca, int row_lo, int 
     a.nb = nb; a.jt = pl.jt;
     a.tf_a = tf_a; a.tf_b = tf_b;
     a.check_done = check_done;
+    a.gx = (int)pl.grid.x; a.gy = (int)pl.grid.y;
+    if (ctx->rec) {
+        RecOp op; op.kind = RecOp::FILTER; op.f = a;
+        ctx->rec->push_back(op);
+        return CVO_HIP_OK;
+    }
     EventPair ev{};
     if (ctx->profiling) {
         HIP_TRY(ctx, hipEventCreate(&ev.a));
@@ -447,9 +466,34 @@ int enqueue_process(cvo_hip_ctx *ctx, int mode, int list, DevBuf &part, const fl
     a.first_counted = first_counted;
     a.tf_a = tf_a; a.tf_b = tf_b;
     a.check_done = check_done;
+    if (ctx->rec) {
+        RecOp op; op.kind = RecOp::PROCESS; op.mode = mode; op.p = a;
+        ctx->rec->push_back(op);
+        return CVO_HIP_OK;
+    }
     launch_process(mode, a, ctx->stream);
     HIP_TRY(ctx, hipGetLastError());
     return CVO_HIP_OK;
+}
+
+void emit_post_flow(cvo_hip_ctx *ctx, const PostFlowArgs &pa)
+{
+    if (ctx->rec) {
+        RecOp op; op.kind = RecOp::POST_FLOW; op.pf = pa;
+        ctx->rec->push_back(op);
+    } else {
+        launch_post_flow(pa, ctx->stream);
+    }
+}
+
+void emit_post_step(cvo_hip_ctx *ctx, const PostStepArgs &pa)
+{
+    if (ctx->rec) {
+        RecOp op; op.kind = RecOp::POST_STEP; op.ps = pa;
+        ctx->rec->push_back(op);
+    } else {
+        launch_post_step(pa, ctx->stream);
+    }
 }
 
 // n_exec >= 0: launches tagged with an iteration >= n_exec were queued past
@@ -529,21 +573,22 @@ int enqueue_flow(cvo_hip_ctx *ctx, bool tf_moving, int check_done, bool do_math,
     pa.prm = ctx->dprm;
     pa.trace = trace; pa.trace_cap = trace_cap;
     pa.check_done = check_done;
+    pa.done_mirror = ctx->done_mirror;
     pa.part_flow = (const double *)ctx->part_flow.p;
     pa.part_xx = (const double *)ctx->part_xx.p;
     pa.part_yy = (const double *)ctx->part_yy.p;
     if (multi_rank(ctx)) {
         pa.flags = POST_REDUCE;
-        launch_post_flow(pa, ctx->stream);
+        emit_post_flow(ctx, pa);
         rc = reduce_over_ranks(ctx, RED_FLOW, RED_STEP - RED_FLOW);
         if (rc) return rc;
         if (do_math) {
             pa.flags = POST_MATH;
-            launch_post_flow(pa, ctx->stream);
+            emit_post_flow(ctx, pa);
         }
     } else {
         pa.flags = POST_REDUCE | (do_math ? POST_MATH : 0);
-        launch_post_flow(pa, ctx->stream);
+        emit_post_flow(ctx, pa);
     }
     HIP_TRY(ctx, hipGetLastError());
     return CVO_HIP_OK;
@@ -562,20 +607,21 @@ int enqueue_step(cvo_hip_ctx *ctx, int check_done, bool do_math, cvo_hip_trace *
     pa.prm = ctx->dprm;
     pa.trace = trace; pa.trace_cap = trace_cap;
     pa.check_done = check_done;
+    pa.done_mirror = ctx->done_mirror;
     pa.part_step = (const double *)ctx->part_step.p;
     pa.dbg = ctx->post_dbg;
     if (multi_rank(ctx)) {
         pa.flags = POST_REDUCE;
-        launch_post_step(pa, ctx->stream);
+        emit_post_step(ctx, pa);
         rc = reduce_over_ranks(ctx, RED_STEP, RED_N - RED_STEP);
         if (rc) return rc;
         if (do_math) {
             pa.flags = POST_MATH;
-            launch_post_step(pa, ctx->stream);
+            emit_post_step(ctx, pa);
         }
     } else {
         pa.flags = POST_REDUCE | (do_math ? POST_MATH : 0);
-        launch_post_step(pa, ctx->stream);
+        emit_post_step(ctx, pa);
     }
     HIP_TRY(ctx, hipGetLastError());
     return CVO_HIP_OK;
@@ -839,7 +885,7 @@ int cvo_hip_create(int device, void *stream, const cvo_hip_params *p, cvo_hip_ct
         ctx->own_stream = true;
     }
     if (hipMalloc((void **)&ctx->st, sizeof(DevState)) != hipSuccess) return bail(CVO_HIP_ERR_NOMEM);
-    if (hipHostMalloc((void **)&ctx->st_host, (kPollSlots + 1) * sizeof(DevState),
+    if (hipHostMalloc((void **)&ctx->st_host, (kPollSlots + 2) * sizeof(DevState),
                       hipHostMallocDefault) != hipSuccess)
         return bail(CVO_HIP_ERR_NOMEM);
     std::memset(ctx->st_host, 0, (kPollSlots + 1) * sizeof(DevState));
@@ -848,6 +894,8 @@ int cvo_hip_create(int device, void *stream, const cvo_hip_params *p, cvo_hip_ct
     for (int i = 0; i < kPollSlots; ++i)
         if (hipEventCreateWithFlags(&ctx->poll_ev[i], hipEventDisableTiming) != hipSuccess)
             return bail(CVO_HIP_ERR_HIP);
+    ctx->done_mirror = reinterpret_cast<int32_t *>(&ctx->st_host[kPollSlots + 1]);
+    *ctx->done_mirror = 0;
     if (getenv("CVO_HIP_NO_GRAPH")) ctx->use_graphs = false;
     if (getenv("CVO_HIP_POST_DEBUG")) {
         if (hipMalloc((void **)&ctx->post_dbg, 8 * sizeof(long long)) != hipSuccess) return bail(CVO_HIP_ERR_NOMEM);
@@ -1089,6 +1137,7 @@ int job_begin(AlignJob &j)
         s->ell = p.ell_init;
         s->ell_max = p.ell_max_init;
     }
+    *ctx->done_mirror = 0;
     if (!j.trace) j.trace_cap = 0;
     if (j.trace_cap > p.max_iter) j.trace_cap = p.max_iter;
     if (j.trace_cap > ctx->trace_dev_cap) {
@@ -1230,6 +1279,141 @@ int job_pump(AlignJob &j, bool block)
     return 0;
 }
 
+// ---------------------------------------------------------------------------
+// Fused mode: up to MAXG registrations advance through ONE sequence of launches
+// (blockIdx.z = registration).  All members run the same launch sequence (same
+// mode, single rank, no per-launch events) on the leader's stream; a member
+// that has stopped keeps returning at its first load until it is dropped from
+// the launches at the next poll.
+bool fusable(const cvo_hip_ctx *c) { return !c->profiling && !multi_rank(c); }
+
+// issue one iteration of all members, slot by slot
+void launch_fused(const std::vector<std::vector<RecOp>> &ops, hipStream_t s)
+{
+    const int n = (int)ops.size();
+    const size_t slots = ops[0].size();
+    FilterArgs f[MAXG]; ProcessArgs p[MAXG]; PostFlowArgs pf[MAXG]; PostStepArgs ps[MAXG];
+    for (size_t q = 0; q < slots; ++q) {
+        switch (ops[0][q].kind) {
+        case RecOp::FILTER:
+            for (int i = 0; i < n; ++i) f[i] = ops[i][q].f;
+            launch_filter_group(f, n, s);
+            break;
+        case RecOp::PROCESS:
+            for (int i = 0; i < n; ++i) p[i] = ops[i][q].p;
+            launch_process_group(ops[0][q].mode, p, n, s);
+            break;
+        case RecOp::POST_FLOW:
+            for (int i = 0; i < n; ++i) pf[i] = ops[i][q].pf;
+            launch_post_flow_group(pf, n, s);
+            break;
+        case RecOp::POST_STEP:
+            for (int i = 0; i < n; ++i) ps[i] = ops[i][q].ps;
+            launch_post_step_group(ps, n, s);
+            break;
+        }
+    }
+}
+
+// jobs: begun (job_begin) and in phase 0, all fusable, same device and mode, <= MAXG
+void run_fused(std::vector<AlignJob *> &jobs)
+{
+    if (jobs.empty()) return;
+    cvo_hip_ctx *lead = jobs[0]->ctx;
+    hipStream_t s = lead->stream;
+    auto fail_all = [&](std::vector<AlignJob *> &v, const char *msg) {
+        for (AlignJob *j : v) { j->rc = fail(j->ctx, CVO_HIP_ERR_HIP, msg); j->phase = 2; }
+        v.clear();
+    };
+    if (hipSetDevice(lead->device) != hipSuccess) return fail_all(jobs, "hipSetDevice failed");
+    // the members' uploads and initial states were queued on their own streams
+    for (AlignJob *j : jobs)
+        if (hipStreamSynchronize(j->ctx->stream) != hipSuccess) return fail_all(jobs, "stream sync failed");
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    if (hipEventCreateWithFlags(&ev[0], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ev[1], hipEventDisableTiming) != hipSuccess)
+        return fail_all(jobs, "hipEventCreate failed");
+    std::vector<AlignJob *> live = jobs;
+    std::vector<std::vector<RecOp>> ops;
+    while (!live.empty()) {
+        // (re)record the launch arguments of the current members
+        ops.assign(live.size(), {});
+        bool bad = false;
+        for (size_t i = 0; i < live.size() && !bad; ++i) {
+            cvo_hip_ctx *c = live[i]->ctx;
+            c->rec = &ops[i];
+            const int rc = enqueue_iterations(c, 1, -1, 0);
+            c->rec = nullptr;
+            if (rc || ops[i].size() != ops[0].size()) bad = true;
+        }
+        if (bad) { fail_all(live, "fused launch recording failed"); break; }
+        int max_iter = 0;
+        for (AlignJob *j : live) max_iter = std::max(max_iter, j->ctx->prm.max_iter);
+        bool changed = false;
+        for (int b = 0; !changed; ++b) {
+            for (int q = 0; q < kBatch; ++q) launch_fused(ops, s);
+            if (hipGetLastError() != hipSuccess || hipEventRecord(ev[b & 1], s) != hipSuccess) {
+                fail_all(live, "fused launch failed");
+                break;
+            }
+            if (b >= 1) {   // look at the state one batch behind
+                if (hipEventSynchronize(ev[(b - 1) & 1]) != hipSuccess) {
+                    fail_all(live, "fused poll failed");
+                    break;
+                }
+                for (AlignJob *j : live)
+                    if (*(volatile int32_t *)j->ctx->done_mirror != RUNNING) changed = true;
+            }
+            if ((b + 1) * kBatch > max_iter + 3 * kBatch) changed = true;   // cannot happen
+        }
+        if (live.empty()) break;
+        // somebody stopped: drain the queue, hand the finished members back
+        if (hipStreamSynchronize(s) != hipSuccess) { fail_all(live, "stream sync failed"); break; }
+        std::vector<AlignJob *> stopped, next;
+        for (AlignJob *j : live)
+            (*(volatile int32_t *)j->ctx->done_mirror != RUNNING ? stopped : next).push_back(j);
+        if (stopped.empty()) { fail_all(live, "align loop ended without a verdict"); break; }
+        for (AlignJob *j : stopped)
+            if (hipMemcpyAsync(&j->ctx->st_host[0], j->ctx->st, sizeof(DevState), hipMemcpyDeviceToHost,
+                               s) != hipSuccess)
+                j->rc = fail(j->ctx, CVO_HIP_ERR_HIP, "state copy failed");
+        if (hipStreamSynchronize(s) != hipSuccess) { fail_all(live, "stream sync failed"); break; }
+        for (AlignJob *j : stopped) {
+            cvo_hip_ctx *c = j->ctx;
+            if (j->rc) { j->phase = 2; continue; }
+            const DevState &cur = c->st_host[0];
+            if (cur.done != NEED_BIGGER_LIST) {
+                j->rc = job_finish(*j);
+                j->phase = 2;
+                continue;
+            }
+            // grow the overflowed list(s); the member resumes from the parked iteration
+            int rc = CVO_HIP_OK;
+            for (int l = 0; l < LIST_N && !rc; ++l)
+                if (cur.cnt[2 * l + 1]) {
+                    uint32_t worst = 0;
+                    for (int qq = 0; qq < NSUB; ++qq) worst = std::max(worst, cur.sub[l][qq]);
+                    const double grown = std::min(
+                        4.0e9, std::max((double)worst * NSUB, (double)c->lists[l].cap) * 1.5 + 1024.0);
+                    rc = ensure_list(c, l, 0, 0, grown);
+                }
+            int32_t zero = 0;
+            if (!rc && (hipMemcpyAsync(reinterpret_cast<char *>(c->st) + offsetof(DevState, done), &zero,
+                                       sizeof(zero), hipMemcpyHostToDevice, s) != hipSuccess ||
+                        hipStreamSynchronize(s) != hipSuccess))
+                rc = fail(c, CVO_HIP_ERR_HIP, "resume failed");
+            if (rc) { j->rc = rc; j->phase = 2; continue; }
+            *c->done_mirror = 0;
+            j->executed_base = cur.k;
+            launch_prepare(c->st, c->dprm, s);
+            next.push_back(j);
+        }
+        live.swap(next);
+    }
+    (void)hipEventDestroy(ev[0]);
+    (void)hipEventDestroy(ev[1]);
+}
+
 }   // namespace
 
 int cvo_hip_align(cvo_hip_ctx *ctx, cvo_hip_state *s, cvo_hip_trace *trace, int trace_cap,
@@ -1260,6 +1444,26 @@ int cvo_hip_align_many(cvo_hip_ctx **ctxs, cvo_hip_state **states, int *n_iters,
     for (int i = 0; i < count; ++i) {
         const int rc = job_begin(jobs[i]);
         if (rc) { jobs[i].rc = rc; jobs[i].phase = 2; if (!first_err) first_err = rc; }
+    }
+    // fused groups: same device, same mode, nothing that needs its own launches
+    static const bool no_fuse = getenv("CVO_HIP_NO_FUSE") != nullptr;
+    if (!no_fuse && count > 1) {
+        std::vector<char> taken((size_t)count, 0);
+        for (int i = 0; i < count; ++i) {
+            if (taken[i] || jobs[i].phase != 0 || !fusable(jobs[i].ctx)) continue;
+            std::vector<AlignJob *> grp;
+            for (int k = i; k < count && (int)grp.size() < MAXG; ++k)
+                if (!taken[k] && jobs[k].phase == 0 && fusable(jobs[k].ctx) &&
+                    jobs[k].ctx->device == jobs[i].ctx->device &&
+                    jobs[k].ctx->prm.mode == jobs[i].ctx->prm.mode) {
+                    grp.push_back(&jobs[k]);
+                    taken[k] = 1;
+                }
+            if (grp.size() < 2) { taken[i] = 0; for (AlignJob *j : grp) taken[j - &jobs[0]] = 0; continue; }
+            run_fused(grp);
+        }
+        for (int i = 0; i < count; ++i)
+            if (jobs[i].phase == 2 && jobs[i].rc && !first_err) first_err = jobs[i].rc;
     }
     // round-robin: every pass tops up each registration's queue and looks at its
     // poll word without blocking; when nobody moved, block on the oldest job

@@ -143,6 +143,12 @@ struct DevState {
 };
 constexpr size_t DEVSTATE_HEAD_BYTES = offsetof(DevState, sub);
 
+// Fused launches: one launch can serve up to MAXG independent registrations
+// (blockIdx.z selects the argument block).  Every hot kernel here is latency-
+// bound at 10k x 10k, so G registrations per launch cost little more than one.
+constexpr int MAXG = 16;
+template <class A> struct Grp { A a[MAXG]; };
+
 // Dense pair filter: rows [row_lo,row_hi) of cloud a against all of cloud b.
 struct FilterArgs {
     const float4 *pos_a;
@@ -158,6 +164,7 @@ struct FilterArgs {
     int jt;                // columns per block chunk (multiple of SEG)
     int tf_a, tf_b;        // apply [Rt|t] to the row / column cloud while staging
     int check_done;        // return at once when st->done != 0
+    int gx, gy;            // this registration's own grid (a fused launch may be larger)
     long long *dbg;        // probe only (tools/microbench): per-wave phase clocks, else null
 };
 
@@ -193,6 +200,7 @@ struct PostFlowArgs {
     cvo_hip_trace *trace; int trace_cap;
     int flags;
     int check_done;
+    int32_t *done_mirror;  // optional host-visible copy of st->done once the loop has stopped
     DevParams prm;
 };
 
@@ -203,6 +211,7 @@ struct PostStepArgs {
     int flags;
     int check_done;
     long long *dbg;        // diagnostics only (CVO_HIP_POST_DEBUG): phase clocks of thread 0
+    int32_t *done_mirror;  // see PostFlowArgs
     DevParams prm;
 };
 
@@ -331,5 +340,10 @@ void launch_filter(const FilterArgs &a, dim3 grid, hipStream_t s, hipEvent_t ev_
 void launch_process(int mode, const ProcessArgs &a, hipStream_t s);
 void launch_post_flow(const PostFlowArgs &a, hipStream_t s);
 void launch_post_step(const PostStepArgs &a, hipStream_t s);
+// fused: n <= MAXG argument blocks, one launch (FilterArgs::gx/gy must be set)
+void launch_filter_group(const FilterArgs *a, int n, hipStream_t s);
+void launch_process_group(int mode, const ProcessArgs *a, int n, hipStream_t s);
+void launch_post_flow_group(const PostFlowArgs *a, int n, hipStream_t s);
+void launch_post_step_group(const PostStepArgs *a, int n, hipStream_t s);
 
 }   // namespace cvo_dev

@@ -32,6 +32,8 @@
 // below is an explicit __builtin_fmaf.  Per-pair terms are float32 in the
 // reference's operation order, accumulated in float64.  The MFMA filter only
 // decides which pairs are LOOKED AT; it never decides membership in A.
+#include <algorithm>
+
 #include "cvo_device.h"
 
 namespace cvo_dev {
@@ -95,8 +97,10 @@ __device__ __forceinline__ void flush_tiles(const TileEntry *stage, int n, int l
     }
 }
 
-__global__ void __launch_bounds__(BLOCK) k_filter(const FilterArgs a)
+__global__ void __launch_bounds__(BLOCK) k_filter(const Grp<FilterArgs> grp)
 {
+    const FilterArgs &a = grp.a[blockIdx.z];
+    if ((int)blockIdx.x >= a.gx || (int)blockIdx.y >= a.gy) return;   // fused launch: not ours
     const long long t_start = a.dbg ? (long long)__builtin_readcyclecounter() : 0;
     const long long w_start = a.dbg ? (long long)wall_clock64() : 0;
     // first round trip: the loop-control word, the state constants and this
@@ -156,7 +160,7 @@ __global__ void __launch_bounds__(BLOCK) k_filter(const FilterArgs a)
         }
         if (!__syncthreads_or(near ? 1 : 0)) {
             if (a.dbg && lane == 0) {   // probe: a culled block
-                long long *o = a.dbg + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 4 + wid) * 8;
+                long long *o = a.dbg + ((size_t)(blockIdx.y * a.gx + blockIdx.x) * 4 + wid) * 8;
                 const long long now = (long long)__builtin_readcyclecounter();
                 o[0] = t_start; o[1] = now; o[2] = now; o[3] = now; o[4] = -1; o[5] = 0;
                 o[6] = w_start; o[7] = (long long)wall_clock64();
@@ -217,7 +221,7 @@ __global__ void __launch_bounds__(BLOCK) k_filter(const FilterArgs a)
     TileEntry *stage = stage_all + wid * TILE_STAGE;
     int ne = 0;   // wave-uniform: staged tile entries
     // this wave's flushes walk round-robin over the sub-lists
-    unsigned sub = ((blockIdx.y * gridDim.x + blockIdx.x) * 4u + (unsigned)wid) * 37u;
+    unsigned sub = ((blockIdx.y * a.gx + blockIdx.x) * 4u + (unsigned)wid) * 37u;
     const unsigned rbase = (unsigned)(row0 + wid * ROWS_PER_WAVE);
 
     const long long t_loop = a.dbg ? (long long)__builtin_readcyclecounter() : 0;
@@ -274,7 +278,7 @@ __global__ void __launch_bounds__(BLOCK) k_filter(const FilterArgs a)
         flush_tiles(stage, ne, lane, sub & (NSUB - 1), a);
     }
     if (a.dbg && lane == 0) {   // probe: start, prologue end, loop end, exit clocks of every wave
-        long long *o = a.dbg + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 4 + wid) * 8;
+        long long *o = a.dbg + ((size_t)(blockIdx.y * a.gx + blockIdx.x) * 4 + wid) * 8;
         o[6] = w_start; o[7] = (long long)wall_clock64();   // 100 MHz constant clock
         o[0] = t_start; o[1] = t_loop; o[2] = t_tail; o[3] = (long long)__builtin_readcyclecounter();
         o[4] = __builtin_amdgcn_s_getreg((31 << 11) | 4);    // HW_ID: wave slot, SIMD, CU, SE
@@ -285,11 +289,29 @@ __global__ void __launch_bounds__(BLOCK) k_filter(const FilterArgs a)
 void launch_filter(const FilterArgs &a, dim3 grid, hipStream_t s, hipEvent_t ev_start,
                    hipEvent_t ev_stop)
 {
+    Grp<FilterArgs> g;
+    g.a[0] = a;
+    g.a[0].gx = (int)grid.x; g.a[0].gy = (int)grid.y;
+    grid.z = 1;
     if (ev_start && ev_stop)   // the events take the dispatch packet's own begin / end timestamps
         hipExtLaunchKernelGGL(k_filter, grid, dim3(BLOCK), filter_smem_bytes(a.jt), s, ev_start,
-                              ev_stop, 0, a);
+                              ev_stop, 0, g);
     else
-        hipLaunchKernelGGL(k_filter, grid, dim3(BLOCK), filter_smem_bytes(a.jt), s, a);
+        hipLaunchKernelGGL(k_filter, grid, dim3(BLOCK), filter_smem_bytes(a.jt), s, g);
+}
+
+void launch_filter_group(const FilterArgs *a, int n, hipStream_t s)
+{
+    Grp<FilterArgs> g;
+    dim3 grid(1, 1, (unsigned)n);
+    int jt = 0;
+    for (int i = 0; i < n; ++i) {
+        g.a[i] = a[i];
+        grid.x = std::max(grid.x, (unsigned)a[i].gx);
+        grid.y = std::max(grid.y, (unsigned)a[i].gy);
+        jt = std::max(jt, a[i].jt);
+    }
+    hipLaunchKernelGGL(k_filter, grid, dim3(BLOCK), filter_smem_bytes(jt), s, g);
 }
 
 // ---------------------------------------------------------------------------
@@ -318,6 +340,100 @@ __device__ __forceinline__ float pair_weight(const KernConsts &kc, float d2, con
     const float ck = (float)(kc.cs2_d * exp((double)d2c * kc.ninv_2cl2));
     const float a = ck * k;
     return a > kc.sp ? a : 0.0f;
+}
+
+
+// ---------------------------------------------------------------------------
+// Wave-wide float64 sums of N per-lane values, written to dst[0..N).
+//
+// A butterfly per value costs 6 exchanges (12 ds_bpermute for a double), and the
+// LDS pipe -- not the VALU -- was what the list kernels waited on.  This is a
+// reduce-scatter instead: at the level with lane mask OFF the lower lane of each
+// pair keeps the first half of the values and the upper lane the second half,
+// each adding what its partner held of its own half, so the number of live
+// values halves per level (9 -> 5 -> 3 -> 2 -> 1: 13 exchanges instead of 54).
+// Levels 32 and 16 use gfx950's v_permlane32_swap / v_permlane16_swap, levels 8,
+// 4, 2, 1 DPP moves (row_mirror, row_half_mirror, quad_perm: partners l^15, l^7,
+// l^2, l^1 -- the masks 32,16,15,7,2,1 are independent, so every level joins two
+// disjoint halves): nothing goes through the LDS crossbar.  The order of the
+// additions is fixed: results are reproducible.
+template <int CTRL> __device__ __forceinline__ double dpp_mov_f64(double x)
+{
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+
+template <int OFF> __device__ __forceinline__ double wave_xchg(double x)
+{
+    if constexpr (OFF == 8) return dpp_mov_f64<0x140>(x);        // row_mirror
+    else if constexpr (OFF == 4) return dpp_mov_f64<0x141>(x);   // row_half_mirror
+    else if constexpr (OFF == 2) return dpp_mov_f64<0x4E>(x);    // quad_perm [2,3,0,1]
+    else if constexpr (OFF == 1) return dpp_mov_f64<0xB1>(x);    // quad_perm [1,0,3,2]
+    else return __shfl_xor(x, OFF, 64);
+}
+
+template <int N, int OFF> struct WaveRS {
+    static constexpr int H = (N + 1) / 2;
+    static __device__ __forceinline__ void run(double *v, int lane)
+    {
+        if constexpr (N > 1) {
+            const bool upper = (lane & OFF) != 0;
+#pragma unroll
+            for (int q = 0; q < H; ++q) {
+                const double hi = (q + H < N) ? v[q + H] : 0.0;
+                if constexpr (OFF >= 16) {
+                    // gfx950 v_permlane{32,16}_swap: the upper half (odd rows) of the
+                    // first operand trades places with the lower half (even rows) of
+                    // the second, so {kept, received} come out without any select
+                    const unsigned xl = (unsigned)__double2loint(v[q]), xh = (unsigned)__double2hiint(v[q]);
+                    const unsigned yl = (unsigned)__double2loint(hi), yh = (unsigned)__double2hiint(hi);
+                    double k0, k1;
+                    if constexpr (OFF == 32) {
+                        const auto rl = __builtin_amdgcn_permlane32_swap(xl, yl, false, false);
+                        const auto rh = __builtin_amdgcn_permlane32_swap(xh, yh, false, false);
+                        k0 = __hiloint2double((int)rh[0], (int)rl[0]);
+                        k1 = __hiloint2double((int)rh[1], (int)rl[1]);
+                    } else {
+                        const auto rl = __builtin_amdgcn_permlane16_swap(xl, yl, false, false);
+                        const auto rh = __builtin_amdgcn_permlane16_swap(xh, yh, false, false);
+                        k0 = __hiloint2double((int)rh[0], (int)rl[0]);
+                        k1 = __hiloint2double((int)rh[1], (int)rl[1]);
+                    }
+                    v[q] = k0 + k1;
+                } else {
+                    const double send = upper ? v[q] : hi;
+                    const double keep = upper ? hi : v[q];
+                    v[q] = keep + wave_xchg<OFF>(send);
+                }
+            }
+        } else {
+            v[0] += wave_xchg<OFF>(v[0]);
+        }
+        if constexpr (OFF > 1) WaveRS<(N > 1 ? H : 1), OFF / 2>::run(v, lane);
+    }
+    // which of the N sums this lane ends up holding in v[0] (-1: none / a duplicate)
+    static __device__ __forceinline__ int slot(int lane)
+    {
+        int p = 0;
+        if constexpr (OFF > 1) p = WaveRS<(N > 1 ? H : 1), OFF / 2>::slot(lane);
+        if (p < 0) return -1;
+        if constexpr (N > 1) {
+            p += (lane & OFF) ? H : 0;
+            return p < N ? p : -1;
+        } else {
+            return (lane & OFF) ? -1 : p;   // plain butterfly level: one writer per pair
+        }
+    }
+};
+
+template <int N>
+__device__ __forceinline__ void wave_sums(double (&v)[N], int lane, double *dst)
+{
+    WaveRS<N, 32>::run(v, lane);
+    const int p = WaveRS<N, 32>::slot(lane);
+    if (p >= 0) dst[p] = v[0];
 }
 
 template <int MODE> struct NAcc;
@@ -412,8 +528,9 @@ __device__ __forceinline__ float eval_pair(const ProcessArgs &a, const KernConst
 }
 
 template <int MODE>
-__global__ void __launch_bounds__(BLOCK) k_process(const ProcessArgs a)
+__global__ void __launch_bounds__(BLOCK) k_process(const Grp<ProcessArgs> grp)
 {
+    const ProcessArgs &a = grp.a[blockIdx.z];
     constexpr int NACC = NAcc<MODE>::n;
     __shared__ double red[4 * NACC_MAX];
     __shared__ uint2 pairq_all[(MODE == PROC_STEP) ? 1 : 4 * PAIR_QUEUE];
@@ -493,9 +610,11 @@ __global__ void __launch_bounds__(BLOCK) k_process(const ProcessArgs a)
             for (int k = 0; k < cnt; ++k) {
                 // broadcast lane k's entry and expand its mask into the queue:
                 // bit l is row (l>>4)*4 + r, column l&15 of the tile
-                const unsigned tx = __shfl(mine.x, k, 64), ty = __shfl(mine.y, k, 64);
-                const unsigned long long m = (unsigned long long)__shfl(mine.z, k, 64) |
-                                             ((unsigned long long)__shfl(mine.w, k, 64) << 32);
+                const unsigned tx = (unsigned)__builtin_amdgcn_readlane((int)mine.x, k);
+                const unsigned ty = (unsigned)__builtin_amdgcn_readlane((int)mine.y, k);
+                const unsigned long long m =
+                    (unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)mine.z, k) |
+                    ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)mine.w, k) << 32);
                 const unsigned r = ty >> 30, tcol = ty & 0x3fffffffu;
                 if ((m >> lane) & 1ull) {
                     const unsigned below = __builtin_amdgcn_mbcnt_hi(
@@ -514,14 +633,8 @@ __global__ void __launch_bounds__(BLOCK) k_process(const ProcessArgs a)
         if (MODE == PROC_FLOW && lane == 0) a.kept_cnt[wave] = nk;
     }
 
-    // block reduction: xor butterfly inside each wave, then the 4 waves in order
-#pragma unroll
-    for (int k = 0; k < NACC; ++k) {
-        double s = acc[k];
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
-        if (lane == 0) red[wid * NACC + k] = s;
-    }
+    // block reduction: reduce-scatter inside each wave, then the 4 waves in order
+    wave_sums<NACC>(acc, lane, red + wid * NACC);
     __syncthreads();
     if (tid < NACC) {
         const double s = ((red[tid] + red[NACC + tid]) + red[2 * NACC + tid]) + red[3 * NACC + tid];
@@ -529,19 +642,27 @@ __global__ void __launch_bounds__(BLOCK) k_process(const ProcessArgs a)
     }
 }
 
-void launch_process(int mode, const ProcessArgs &a, hipStream_t s)
+void launch_process_group(int mode, const ProcessArgs *a, int n, hipStream_t s)
 {
+    Grp<ProcessArgs> g;
+    for (int i = 0; i < n; ++i) g.a[i] = a[i];
+    const dim3 grid(PROC_BLOCKS, 1, (unsigned)n);
     switch (mode) {
     case PROC_FLOW:
-        hipLaunchKernelGGL(k_process<PROC_FLOW>, dim3(PROC_BLOCKS), dim3(BLOCK), 0, s, a);
+        hipLaunchKernelGGL(k_process<PROC_FLOW>, grid, dim3(BLOCK), 0, s, g);
         break;
     case PROC_STEP:
-        hipLaunchKernelGGL(k_process<PROC_STEP>, dim3(PROC_BLOCKS), dim3(BLOCK), 0, s, a);
+        hipLaunchKernelGGL(k_process<PROC_STEP>, grid, dim3(BLOCK), 0, s, g);
         break;
     default:
-        hipLaunchKernelGGL(k_process<PROC_SELF>, dim3(PROC_BLOCKS), dim3(BLOCK), 0, s, a);
+        hipLaunchKernelGGL(k_process<PROC_SELF>, grid, dim3(BLOCK), 0, s, g);
         break;
     }
+}
+
+void launch_process(int mode, const ProcessArgs &a, hipStream_t s)
+{
+    launch_process_group(mode, &a, 1, s);
 }
 
 // ---------------------------------------------------------------------------
@@ -565,13 +686,7 @@ __device__ void block_reduce_partials(const double *part, int nblocks, double *s
 #pragma unroll
         for (int k = 0; k < NACC; ++k) s[k] += (b < nblocks) ? part[(size_t)b * NACC + k] : 0.0;
     }
-#pragma unroll
-    for (int k = 0; k < NACC; ++k) {
-        double v = s[k];
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
-        if (lane == 0) sh[wid * NACC_MAX + k] = v;
-    }
+    wave_sums<NACC>(s, lane, sh + wid * NACC_MAX);
     __syncthreads();
     if (tid == 0) {
 #pragma unroll
@@ -626,8 +741,9 @@ __device__ __forceinline__ double section_root_wave(const cvo_math::CubicBracket
     return hi;
 }
 
-__global__ void __launch_bounds__(BLOCK) k_post_flow(const PostFlowArgs a)
+__global__ void __launch_bounds__(BLOCK) k_post_flow(const Grp<PostFlowArgs> grp)
 {
+    const PostFlowArgs &a = grp.a[blockIdx.z];
     __shared__ double sh[4 * NACC_MAX];
     __shared__ __attribute__((aligned(16))) DevState s_st;
     // One round trip: every thread fetches a word of the state's head into LDS;
@@ -690,11 +806,13 @@ __global__ void __launch_bounds__(BLOCK) k_post_flow(const PostFlowArgs a)
         }
     }
     __syncthreads();
+    if (threadIdx.x == 0 && a.done_mirror && s_st.done != RUNNING) *a.done_mirror = s_st.done;
     state_head_from_lds(&s_st, a.st);
 }
 
-__global__ void __launch_bounds__(BLOCK) k_post_step(const PostStepArgs a)
+__global__ void __launch_bounds__(BLOCK) k_post_step(const Grp<PostStepArgs> grp)
 {
+    const PostStepArgs &a = grp.a[blockIdx.z];
     __shared__ double sh[4 * NACC_MAX];
     __shared__ __attribute__((aligned(16))) DevState s_st;
     const long long c0 = a.dbg ? (long long)__builtin_readcyclecounter() : 0;
@@ -721,6 +839,7 @@ __global__ void __launch_bounds__(BLOCK) k_post_step(const PostStepArgs a)
         }
     }
     __syncthreads();
+    if (threadIdx.x == 0 && a.done_mirror && s_st.done != RUNNING) *a.done_mirror = s_st.done;
     state_head_from_lds(&s_st, a.st);
 }
 
@@ -830,14 +949,21 @@ void launch_prepare(DevState *st, const DevParams &prm, hipStream_t s)
     hipLaunchKernelGGL(k_prepare, dim3(1), dim3(BLOCK), 0, s, st, prm);
 }
 
-void launch_post_flow(const PostFlowArgs &a, hipStream_t s)
+void launch_post_flow_group(const PostFlowArgs *a, int n, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_post_flow, dim3(1), dim3(BLOCK), 0, s, a);
+    Grp<PostFlowArgs> g;
+    for (int i = 0; i < n; ++i) g.a[i] = a[i];
+    hipLaunchKernelGGL(k_post_flow, dim3(1, 1, (unsigned)n), dim3(BLOCK), 0, s, g);
 }
 
-void launch_post_step(const PostStepArgs &a, hipStream_t s)
+void launch_post_step_group(const PostStepArgs *a, int n, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_post_step, dim3(1), dim3(BLOCK), 0, s, a);
+    Grp<PostStepArgs> g;
+    for (int i = 0; i < n; ++i) g.a[i] = a[i];
+    hipLaunchKernelGGL(k_post_step, dim3(1, 1, (unsigned)n), dim3(BLOCK), 0, s, g);
 }
+
+void launch_post_flow(const PostFlowArgs &a, hipStream_t s) { launch_post_flow_group(&a, 1, s); }
+void launch_post_step(const PostStepArgs &a, hipStream_t s) { launch_post_step_group(&a, 1, s); }
 
 }   // namespace cvo_dev

@@ -11,7 +11,8 @@ pkg = ge.load_package()
 capi = pkg.capi
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
-for B in (1, 2, 4, 8, 16):
+BS = [int(x) for x in sys.argv[3].split(",")] if len(sys.argv) > 3 else [1, 2, 4, 8, 16]
+for B in BS:
     ctxs, streams = [], []
     for b in range(B):
         s = torch.cuda.Stream()
