@@ -101,6 +101,7 @@ struct cvo_hip_ctx {
     DevState *st_host = nullptr;     // pinned [kPollSlots + 2]
     int32_t *done_mirror = nullptr;  // pinned (in the last slot): the post kernels copy `done` here
     std::vector<RecOp> *rec = nullptr;   // not null: record launches instead of issuing them
+    int proc_blocks = PROC_BLOCKS;       // blocks of the list kernels (fewer in fused launches)
     hipEvent_t poll_ev[kPollSlots]{};
     DevBuf part_flow, part_xx, part_yy, part_step;   // [PROC_BLOCKS][NACC_MAX] float64
     List lists[LIST_N];
@@ -461,7 +462,8 @@ int enqueue_process(cvo_hip_ctx *ctx, int mode, int list, DevBuf &part, const fl
     a.partials = (double *)part.p;
     a.st = ctx->st;
     a.subcap = ctx->lists[list].cap / NSUB;
-    a.kept_wcap = ctx->lists[LIST_KEPT].cap / PROC_WAVES;
+    a.nblk = ctx->proc_blocks;
+    a.kept_wcap = ctx->lists[LIST_KEPT].cap / (uint32_t)(4 * ctx->proc_blocks);
     a.list = list;
     a.first_counted = first_counted;
     a.tf_a = tf_a; a.tf_b = tf_b;
@@ -574,6 +576,7 @@ int enqueue_flow(cvo_hip_ctx *ctx, bool tf_moving, int check_done, bool do_math,
     pa.trace = trace; pa.trace_cap = trace_cap;
     pa.check_done = check_done;
     pa.done_mirror = ctx->done_mirror;
+    pa.nblk = ctx->proc_blocks;
     pa.part_flow = (const double *)ctx->part_flow.p;
     pa.part_xx = (const double *)ctx->part_xx.p;
     pa.part_yy = (const double *)ctx->part_yy.p;
@@ -608,6 +611,7 @@ int enqueue_step(cvo_hip_ctx *ctx, int check_done, bool do_math, cvo_hip_trace *
     pa.trace = trace; pa.trace_cap = trace_cap;
     pa.check_done = check_done;
     pa.done_mirror = ctx->done_mirror;
+    pa.nblk = ctx->proc_blocks;
     pa.part_step = (const double *)ctx->part_step.p;
     pa.dbg = ctx->post_dbg;
     if (multi_rank(ctx)) {
@@ -1336,13 +1340,23 @@ void run_fused(std::vector<AlignJob *> &jobs)
     std::vector<AlignJob *> live = jobs;
     std::vector<std::vector<RecOp>> ops;
     while (!live.empty()) {
-        // (re)record the launch arguments of the current members
+        // (re)record the launch arguments of the current members; the list kernels
+        // get fewer blocks per registration the more registrations share a launch
+        const int G = (int)live.size();
+        static const int budget = [] {   // blocks of a whole fused launch (tuning knob)
+            const char *e = getenv("CVO_HIP_PROC_BUDGET");
+            const int v = e ? atoi(e) : 4096;
+            return v >= NSUB ? v : 4096;
+        }();
+        const int nblk = std::min(PROC_BLOCKS, std::max(NSUB, (budget / G) / NSUB * NSUB));
         ops.assign(live.size(), {});
         bool bad = false;
         for (size_t i = 0; i < live.size() && !bad; ++i) {
             cvo_hip_ctx *c = live[i]->ctx;
             c->rec = &ops[i];
+            c->proc_blocks = nblk;
             const int rc = enqueue_iterations(c, 1, -1, 0);
+            c->proc_blocks = PROC_BLOCKS;
             c->rec = nullptr;
             if (rc || ops[i].size() != ops[0].size()) bad = true;
         }
@@ -1517,6 +1531,7 @@ int cvo_hip_function_inner_product(cvo_hip_ctx *ctx, float ell, float *out)
     pa.st = ctx->st;
     pa.prm = ctx->dprm;
     pa.prm.mode = CVO_HIP_MODE_CVO;   // no self terms here
+    pa.nblk = ctx->proc_blocks;
     pa.flags = POST_REDUCE;
     for (bool redo = true; redo;) {
         rc = zero_counters(ctx);

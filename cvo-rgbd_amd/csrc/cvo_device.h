@@ -28,7 +28,7 @@ constexpr int TILES_PER_WAVE = 4;
 constexpr int ROWS_PER_WAVE = 16 * TILES_PER_WAVE;
 constexpr int ROWS_PER_TILE = 4 * ROWS_PER_WAVE;   // rows per block
 constexpr float PAD_BIG = 1.0e30f;  // filter value of padded rows / columns
-constexpr int PROC_BLOCKS = 1024;   // grid of the list kernels
+constexpr int PROC_BLOCKS = 1024;   // largest grid of the list kernels (ProcessArgs::nblk, a multiple of NSUB)
 constexpr int PROC_WAVES = PROC_BLOCKS * 4;
 
 // Two kinds of lists live in HBM, both split into NSUB independent sub-lists
@@ -48,7 +48,7 @@ constexpr int PROC_WAVES = PROC_BLOCKS * 4;
 // k_filter stages its appends in LDS and reserves an exactly-sized slice of a
 // sub-list with one returning atomic when the stage is full or the wave ends.
 constexpr int NSUB = 256;
-constexpr int PROC_PARTS = PROC_BLOCKS / NSUB;   // blocks cooperating on one sub-list
+constexpr int PROC_PARTS = PROC_BLOCKS / NSUB;   // most blocks cooperating on one sub-list
 constexpr int TILE_STAGE = 128;     // TileEntry slots staged per wave in k_filter
 constexpr int PAIR_QUEUE = 128;     // compaction queue of a k_process wave
 constexpr int SEG = 64;             // points per bounding-sphere segment (= rows of a filter wave)
@@ -182,6 +182,7 @@ struct ProcessArgs {
     DevState *st;
     uint32_t subcap;       // of the tile list
     uint32_t kept_wcap;    // kept-list slice of one wave (entries)
+    int nblk;              // blocks of this launch for this registration (NSUB .. PROC_BLOCKS)
     int list;              // which tile list
     int row_hi, nb;        // valid rows / columns (mask bits beyond are padding)
     int first_counted;     // PROC_SELF: rows whose caller index is below contribute 0 to the sum
@@ -201,6 +202,7 @@ struct PostFlowArgs {
     int flags;
     int check_done;
     int32_t *done_mirror;  // optional host-visible copy of st->done once the loop has stopped
+    int nblk;              // rows of the partial-sum arrays (= ProcessArgs::nblk of the producers)
     DevParams prm;
 };
 
@@ -212,6 +214,7 @@ struct PostStepArgs {
     int check_done;
     long long *dbg;        // diagnostics only (CVO_HIP_POST_DEBUG): phase clocks of thread 0
     int32_t *done_mirror;  // see PostFlowArgs
+    int nblk;
     DevParams prm;
 };
 

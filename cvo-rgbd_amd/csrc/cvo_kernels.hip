@@ -33,6 +33,7 @@
 // reference's operation order, accumulated in float64.  The MFMA filter only
 // decides which pairs are LOOKED AT; it never decides membership in A.
 #include <algorithm>
+#include <cstdlib>
 
 #include "cvo_device.h"
 
@@ -99,8 +100,13 @@ __device__ __forceinline__ void flush_tiles(const TileEntry *stage, int n, int l
 
 __global__ void __launch_bounds__(BLOCK) k_filter(const Grp<FilterArgs> grp)
 {
+    // Persistent blocks: the (column chunk, row tile) items of this registration's
+    // a.gx x a.gy work grid are dealt round-robin to the gridDim.x blocks of the
+    // launch, so that a launch that has nothing to do (list re-used, loop finished)
+    // costs a few hundred blocks, not thousands.
     const FilterArgs &a = grp.a[blockIdx.z];
-    if ((int)blockIdx.x >= a.gx || (int)blockIdx.y >= a.gy) return;   // fused launch: not ours
+    const int nitems = a.gx * a.gy;
+    if ((int)blockIdx.x >= nitems) return;
     const long long t_start = a.dbg ? (long long)__builtin_readcyclecounter() : 0;
     const long long w_start = a.dbg ? (long long)wall_clock64() : 0;
     // first round trip: the loop-control word, the state constants and this
@@ -118,14 +124,16 @@ __global__ void __launch_bounds__(BLOCK) k_filter(const Grp<FilterArgs> grp)
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wid = tid >> 6;
-    const int row0 = a.row_lo + blockIdx.y * ROWS_PER_TILE;
-    const int j0 = blockIdx.x * a.jt;
-    const int jn = min(a.jt, a.nb - j0);
-    const int ngroups = (jn + 15) >> 4;
     const float *Rt = a.st->Rt;
     const float *tt = a.st->t;
     const float cx = a.st->center[0], cy = a.st->center[1], cz = a.st->center[2];
     const float tauf = a.st->tauf[a.list];
+    for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
+    const int bx = item % a.gx, by = item / a.gx;
+    const int row0 = a.row_lo + by * ROWS_PER_TILE;
+    const int j0 = bx * a.jt;
+    const int jn = min(a.jt, a.nb - j0);
+    const int ngroups = (jn + 15) >> 4;
 
     // ---- culling.  The clouds are in Morton order, so the 64 rows of a wave and
     // every run of 64 columns are compact patches with precomputed bounding
@@ -160,12 +168,12 @@ __global__ void __launch_bounds__(BLOCK) k_filter(const Grp<FilterArgs> grp)
         }
         if (!__syncthreads_or(near ? 1 : 0)) {
             if (a.dbg && lane == 0) {   // probe: a culled block
-                long long *o = a.dbg + ((size_t)(blockIdx.y * a.gx + blockIdx.x) * 4 + wid) * 8;
+                long long *o = a.dbg + ((size_t)(by * a.gx + bx) * 4 + wid) * 8;
                 const long long now = (long long)__builtin_readcyclecounter();
                 o[0] = t_start; o[1] = now; o[2] = now; o[3] = now; o[4] = -1; o[5] = 0;
                 o[6] = w_start; o[7] = (long long)wall_clock64();
             }
-            return;
+            continue;   // (the barrier above already separates this item's LDS use from the next)
         }
     }
 
@@ -221,7 +229,7 @@ __global__ void __launch_bounds__(BLOCK) k_filter(const Grp<FilterArgs> grp)
     TileEntry *stage = stage_all + wid * TILE_STAGE;
     int ne = 0;   // wave-uniform: staged tile entries
     // this wave's flushes walk round-robin over the sub-lists
-    unsigned sub = ((blockIdx.y * a.gx + blockIdx.x) * 4u + (unsigned)wid) * 37u;
+    unsigned sub = ((by * a.gx + bx) * 4u + (unsigned)wid) * 37u;
     const unsigned rbase = (unsigned)(row0 + wid * ROWS_PER_WAVE);
 
     const long long t_loop = a.dbg ? (long long)__builtin_readcyclecounter() : 0;
@@ -278,12 +286,25 @@ __global__ void __launch_bounds__(BLOCK) k_filter(const Grp<FilterArgs> grp)
         flush_tiles(stage, ne, lane, sub & (NSUB - 1), a);
     }
     if (a.dbg && lane == 0) {   // probe: start, prologue end, loop end, exit clocks of every wave
-        long long *o = a.dbg + ((size_t)(blockIdx.y * a.gx + blockIdx.x) * 4 + wid) * 8;
+        long long *o = a.dbg + ((size_t)(by * a.gx + bx) * 4 + wid) * 8;
         o[6] = w_start; o[7] = (long long)wall_clock64();   // 100 MHz constant clock
         o[0] = t_start; o[1] = t_loop; o[2] = t_tail; o[3] = (long long)__builtin_readcyclecounter();
         o[4] = __builtin_amdgcn_s_getreg((31 << 11) | 4);    // HW_ID: wave slot, SIMD, CU, SE
         o[5] = __builtin_amdgcn_s_getreg((31 << 11) | 20);   // XCC_ID
     }
+    __syncthreads();   // the next item re-uses the LDS staging areas
+    }   // item loop
+}
+
+// blocks of one registration's filter launch (persistent, see k_filter)
+static long long filter_blocks_max()
+{
+    static const long long v = [] {
+        const char *e = getenv("CVO_HIP_FILTER_BLOCKS");
+        const long long q = e ? atoll(e) : 1024;
+        return q >= 1 ? q : 1024;
+    }();
+    return v;
 }
 
 void launch_filter(const FilterArgs &a, dim3 grid, hipStream_t s, hipEvent_t ev_start,
@@ -292,7 +313,7 @@ void launch_filter(const FilterArgs &a, dim3 grid, hipStream_t s, hipEvent_t ev_
     Grp<FilterArgs> g;
     g.a[0] = a;
     g.a[0].gx = (int)grid.x; g.a[0].gy = (int)grid.y;
-    grid.z = 1;
+    grid = dim3((unsigned)std::min<long long>((long long)grid.x * grid.y, filter_blocks_max()), 1, 1);
     if (ev_start && ev_stop)   // the events take the dispatch packet's own begin / end timestamps
         hipExtLaunchKernelGGL(k_filter, grid, dim3(BLOCK), filter_smem_bytes(a.jt), s, ev_start,
                               ev_stop, 0, g);
@@ -305,10 +326,11 @@ void launch_filter_group(const FilterArgs *a, int n, hipStream_t s)
     Grp<FilterArgs> g;
     dim3 grid(1, 1, (unsigned)n);
     int jt = 0;
+    // the launch as a whole gets about as many blocks as a single registration would
+    const long long cap = std::max<long long>(64, filter_blocks_max() / n);
     for (int i = 0; i < n; ++i) {
         g.a[i] = a[i];
-        grid.x = std::max(grid.x, (unsigned)a[i].gx);
-        grid.y = std::max(grid.y, (unsigned)a[i].gy);
+        grid.x = std::max(grid.x, (unsigned)std::min<long long>((long long)a[i].gx * a[i].gy, cap));
         jt = std::max(jt, a[i].jt);
     }
     hipLaunchKernelGGL(k_filter, grid, dim3(BLOCK), filter_smem_bytes(jt), s, g);
@@ -531,6 +553,7 @@ template <int MODE>
 __global__ void __launch_bounds__(BLOCK) k_process(const Grp<ProcessArgs> grp)
 {
     const ProcessArgs &a = grp.a[blockIdx.z];
+    if ((int)blockIdx.x >= a.nblk) return;
     constexpr int NACC = NAcc<MODE>::n;
     __shared__ double red[4 * NACC_MAX];
     __shared__ uint2 pairq_all[(MODE == PROC_STEP) ? 1 : 4 * PAIR_QUEUE];
@@ -559,14 +582,14 @@ __global__ void __launch_bounds__(BLOCK) k_process(const Grp<ProcessArgs> grp)
             eval_pair<MODE>(a, kc, e.x, e.y, w, acc);
         }
     } else {
-        // PROC_PARTS blocks share one sub-list of the tile list
+        // nblk / NSUB blocks share one sub-list of the tile list
         const unsigned sub = blockIdx.x & (NSUB - 1), part = blockIdx.x / NSUB;
         unsigned n = a.st->sub[a.list][sub];
         const TileEntry *tl = a.tiles + (size_t)sub * a.subcap;
-        // The 4 * PROC_PARTS waves of this sub-list take its entries in turn, 64 at
+        // The 4 * nblk / NSUB waves of this sub-list take its entries in turn, 64 at
         // a time: lane l fetches the wave's l-th entry of the round (one memory
         // round trip per 64 entries, the first one together with the count).
-        const unsigned stride = 4u * PROC_PARTS;
+        const unsigned stride = 4u * (unsigned)(a.nblk / NSUB);
         const unsigned e0 = part * 4u + (unsigned)wid;
         TileEntry mine = tl[min(e0 + (unsigned)lane * stride, a.subcap - 1)];
         if (done_word != 0) return;
@@ -646,7 +669,9 @@ void launch_process_group(int mode, const ProcessArgs *a, int n, hipStream_t s)
 {
     Grp<ProcessArgs> g;
     for (int i = 0; i < n; ++i) g.a[i] = a[i];
-    const dim3 grid(PROC_BLOCKS, 1, (unsigned)n);
+    int nblk = NSUB;
+    for (int i = 0; i < n; ++i) nblk = std::max(nblk, a[i].nblk);
+    const dim3 grid((unsigned)nblk, 1, (unsigned)n);
     switch (mode) {
     case PROC_FLOW:
         hipLaunchKernelGGL(k_process<PROC_FLOW>, grid, dim3(BLOCK), 0, s, g);
@@ -753,10 +778,10 @@ __global__ void __launch_bounds__(BLOCK) k_post_flow(const Grp<PostFlowArgs> grp
     if (a.check_done && st->done != 0) return;
     const bool acvo = a.prm.mode == CVO_HIP_MODE_ACVO;
     if (a.flags & POST_REDUCE) {
-        block_reduce_partials<NACC_FLOW>(a.part_flow, PROC_BLOCKS, sh, st->red + RED_FLOW);
+        block_reduce_partials<NACC_FLOW>(a.part_flow, a.nblk, sh, st->red + RED_FLOW);
         if (acvo) {
-            block_reduce_partials<NACC_SELF>(a.part_xx, PROC_BLOCKS, sh, st->red + RED_XX);
-            block_reduce_partials<NACC_SELF>(a.part_yy, PROC_BLOCKS, sh, st->red + RED_YY);
+            block_reduce_partials<NACC_SELF>(a.part_xx, a.nblk, sh, st->red + RED_XX);
+            block_reduce_partials<NACC_SELF>(a.part_yy, a.nblk, sh, st->red + RED_YY);
         } else if (threadIdx.x == 0) {
             st->red[RED_XX] = st->red[RED_XX + 1] = st->red[RED_YY] = st->red[RED_YY + 1] = 0.0;
         }
@@ -821,7 +846,7 @@ __global__ void __launch_bounds__(BLOCK) k_post_step(const Grp<PostStepArgs> grp
     if (a.check_done && st->done != 0) return;
     const long long c1 = a.dbg ? (long long)__builtin_readcyclecounter() : 0;
     if (a.flags & POST_REDUCE)
-        block_reduce_partials<NACC_STEP>(a.part_step, PROC_BLOCKS, sh, st->red + RED_STEP);
+        block_reduce_partials<NACC_STEP>(a.part_step, a.nblk, sh, st->red + RED_STEP);
     if (a.dbg && threadIdx.x == 0) {
         a.dbg[0] += 1; a.dbg[1] += c1 - c0; a.dbg[2] += (long long)__builtin_readcyclecounter() - c1;
     }
