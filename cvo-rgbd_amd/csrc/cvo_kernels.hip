@@ -65,11 +65,12 @@ __device__ __forceinline__ float mv_row(const float *m, float x, float y, float 
 //                                  16 columns k-major: [-2y'0 x16][-2y'1 x16][-2y'2 x16][|y'|^2 x16]
 //   xrow  [ROWS_PER_TILE] float4 : (x'0, x'1, x'2, |x'|^2) of the block's rows
 //   stage [4][TILE_STAGE] TileEntry : per-wave staging of the tile entries
-//   near  [4][MAX_CSEG] u32      : which (wave, column segment) pairs can hold a pair
+//   near  [FILTER_KMAX][4] u32   : per (item, wave): the column segments that can hold a pair
+constexpr int FILTER_KMAX = 64;   // items culled per pass
 size_t filter_smem_bytes(int jt)
 {
     return (size_t)jt * 16 + ROWS_PER_TILE * 16 + 4 * TILE_STAGE * sizeof(TileEntry) +
-           4 * MAX_CSEG * 4;
+           FILTER_KMAX * 4 * 4;
 }
 
 // Can a point of sphere a be within sqrt(tauf) of a point of sphere b?
@@ -98,7 +99,8 @@ __device__ __forceinline__ void flush_tiles(const TileEntry *stage, int n, int l
     }
 }
 
-__global__ void __launch_bounds__(BLOCK) k_filter(const Grp<FilterArgs> grp)
+__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(6, 8)))
+k_filter(const Grp<FilterArgs> grp)
 {
     // Persistent blocks: the (column chunk, row tile) items of this registration's
     // a.gx x a.gy work grid are dealt round-robin to the gridDim.x blocks of the
@@ -118,8 +120,8 @@ __global__ void __launch_bounds__(BLOCK) k_filter(const Grp<FilterArgs> grp)
     float4 *xrow = reinterpret_cast<float4 *>(smem + (size_t)a.jt * 16);
     TileEntry *stage_all =
         reinterpret_cast<TileEntry *>(smem + (size_t)a.jt * 16 + ROWS_PER_TILE * 16);
-    unsigned *nearf = reinterpret_cast<unsigned *>(smem + (size_t)a.jt * 16 + ROWS_PER_TILE * 16 +
-                                                   4 * TILE_STAGE * sizeof(TileEntry));
+    unsigned *nearmask = reinterpret_cast<unsigned *>(smem + (size_t)a.jt * 16 + ROWS_PER_TILE * 16 +
+                                                      4 * TILE_STAGE * sizeof(TileEntry));
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -128,54 +130,59 @@ __global__ void __launch_bounds__(BLOCK) k_filter(const Grp<FilterArgs> grp)
     const float *tt = a.st->t;
     const float cx = a.st->center[0], cy = a.st->center[1], cz = a.st->center[2];
     const float tauf = a.st->tauf[a.list];
-    for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
+    // ---- culling, for all the items of this block at once.  The clouds are in
+    // Morton order, so the 64 rows of a wave and every run of 64 columns are
+    // compact patches with precomputed bounding spheres (rigid motion moves a
+    // sphere's centre, not its radius).  A (wave, column segment) pair whose
+    // spheres are more than sqrt(tauf) apart cannot hold a pair with d2 < tau.
+    // One thread per (item, wave, segment) test, all loads in flight together: the
+    // items that hold nothing cost no round trip of their own.
+    const int k_all = (nitems - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int ncf = a.jt / SEG;   // column segments of a full item
+    const float reach = sqrtf(tauf);
+    for (int k0 = 0; k0 < k_all; k0 += FILTER_KMAX) {
+    const int kn = min(FILTER_KMAX, k_all - k0);
+    for (int q = tid; q < FILTER_KMAX * 4; q += BLOCK) nearmask[q] = 0u;
+    __syncthreads();
+    for (int t = tid; t < kn * 4 * ncf; t += BLOCK) {
+        const int k = t / (4 * ncf), rem = t - k * 4 * ncf;
+        const int w = rem / ncf, u = rem - w * ncf;
+        const int item = (int)blockIdx.x + (k0 + k) * (int)gridDim.x;
+        const int bx = item % a.gx, by = item / a.gx;
+        const int row0 = a.row_lo + by * ROWS_PER_TILE;
+        const int j0 = bx * a.jt;
+        const int ncseg = (min(a.jt, a.nb - j0) + SEG - 1) / SEG;
+        // clamped so that every thread can load unconditionally (the rows of a
+        // wave touch at most two segments)
+        const int r_first = row0 + w * ROWS_PER_WAVE;
+        const int r_last = min(r_first + ROWS_PER_WAVE, a.row_hi) - 1;
+        const int last_seg = (a.row_hi - 1) >> 6;
+        const int sg0 = min(r_first >> 6, last_seg), sg1 = min(max(r_last, r_first) >> 6, last_seg);
+        float4 sb = a.seg_b[(j0 >> 6) + min(u, ncseg - 1)];
+        float4 sa0 = a.seg_a[sg0], sa1 = a.seg_a[sg1];
+        if (done_word != 0) return;   // first wait: everything above is in flight
+        if (u < ncseg && r_first < a.row_hi) {
+            if (a.tf_b) { const float r = sb.w; sb = apply_tf(Rt, tt, sb); sb.w = r; }
+            if (a.tf_a) {
+                float r = sa0.w; sa0 = apply_tf(Rt, tt, sa0); sa0.w = r;
+                r = sa1.w; sa1 = apply_tf(Rt, tt, sa1); sa1.w = r;
+            }
+            if (spheres_near(sa0, sb, reach) || spheres_near(sa1, sb, reach))
+                atomicOr(&nearmask[k * 4 + w], 1u << u);
+        }
+    }
+    if (done_word != 0) return;
+    __syncthreads();
+    for (int k = 0; k < kn; ++k) {
+    if ((nearmask[k * 4] | nearmask[k * 4 + 1] | nearmask[k * 4 + 2] | nearmask[k * 4 + 3]) == 0u)
+        continue;   // nothing near in this item
+    const int item = (int)blockIdx.x + (k0 + k) * (int)gridDim.x;
     const int bx = item % a.gx, by = item / a.gx;
     const int row0 = a.row_lo + by * ROWS_PER_TILE;
     const int j0 = bx * a.jt;
     const int jn = min(a.jt, a.nb - j0);
     const int ngroups = (jn + 15) >> 4;
-
-    // ---- culling.  The clouds are in Morton order, so the 64 rows of a wave and
-    // every run of 64 columns are compact patches with precomputed bounding
-    // spheres (rigid motion moves a sphere's centre, not its radius).  A (wave,
-    // column segment) pair whose spheres are more than sqrt(tauf) apart cannot
-    // hold a pair with d2 < tau; a block with no near pair at all exits here.
-    const int ncseg = (jn + SEG - 1) / SEG;
-    {
-        bool near = false;
-        {
-            // thread -> (wave w, column segment u); clamped so that every thread can
-            // load unconditionally (the rows of a wave touch at most two segments)
-            const int tcl = min(tid, 4 * ncseg - 1);
-            const int w = tcl / ncseg, u = tcl - w * ncseg;
-            const int r_first = row0 + w * ROWS_PER_WAVE;
-            const int r_last = min(r_first + ROWS_PER_WAVE, a.row_hi) - 1;
-            const int last_seg = (a.row_hi - 1) >> 6;
-            const int sg0 = min(r_first >> 6, last_seg), sg1 = min(max(r_last, r_first) >> 6, last_seg);
-            float4 sb = a.seg_b[(j0 >> 6) + u];
-            float4 sa0 = a.seg_a[sg0], sa1 = a.seg_a[sg1];
-            if (done_word != 0) return;   // first wait: everything above is in flight
-            if (tid < 4 * ncseg && r_first < a.row_hi) {
-                const float reach = sqrtf(tauf);
-                if (a.tf_b) { const float r = sb.w; sb = apply_tf(Rt, tt, sb); sb.w = r; }
-                if (a.tf_a) {
-                    float r = sa0.w; sa0 = apply_tf(Rt, tt, sa0); sa0.w = r;
-                    r = sa1.w; sa1 = apply_tf(Rt, tt, sa1); sa1.w = r;
-                }
-                near = spheres_near(sa0, sb, reach) || spheres_near(sa1, sb, reach);
-            }
-            if (tid < 4 * ncseg) nearf[w * MAX_CSEG + u] = near ? 1u : 0u;
-        }
-        if (!__syncthreads_or(near ? 1 : 0)) {
-            if (a.dbg && lane == 0) {   // probe: a culled block
-                long long *o = a.dbg + ((size_t)(by * a.gx + bx) * 4 + wid) * 8;
-                const long long now = (long long)__builtin_readcyclecounter();
-                o[0] = t_start; o[1] = now; o[2] = now; o[3] = now; o[4] = -1; o[5] = 0;
-                o[6] = w_start; o[7] = (long long)wall_clock64();
-            }
-            continue;   // (the barrier above already separates this item's LDS use from the next)
-        }
-    }
+    const unsigned mynear = nearmask[k * 4 + wid];
 
     // ---- prologue.  Every global load is issued before anything waits on one
     // (clamped addresses instead of control flow), so the block pays ONE memory
@@ -233,9 +240,8 @@ __global__ void __launch_bounds__(BLOCK) k_filter(const Grp<FilterArgs> grp)
     const unsigned rbase = (unsigned)(row0 + wid * ROWS_PER_WAVE);
 
     const long long t_loop = a.dbg ? (long long)__builtin_readcyclecounter() : 0;
-    const unsigned *mynear = nearf + wid * MAX_CSEG;
     for (int g = 0; g < ngroups; ++g) {
-        if ((g & 3) == 0 && mynear[g >> 2] == 0u) { g += 3; continue; }   // culled column segment
+        if ((g & 3) == 0 && ((mynear >> (g >> 2)) & 1u) == 0u) { g += 3; continue; }   // culled segment
         const float b = bop[g * 64 + lane];
         f32x4 d[TILES_PER_WAVE];
 #pragma unroll
@@ -293,7 +299,9 @@ __global__ void __launch_bounds__(BLOCK) k_filter(const Grp<FilterArgs> grp)
         o[5] = __builtin_amdgcn_s_getreg((31 << 11) | 20);   // XCC_ID
     }
     __syncthreads();   // the next item re-uses the LDS staging areas
-    }   // item loop
+    }   // live items
+    __syncthreads();
+    }   // chunks of FILTER_KMAX items
 }
 
 // blocks of one registration's filter launch (persistent, see k_filter)
@@ -301,8 +309,8 @@ static long long filter_blocks_max()
 {
     static const long long v = [] {
         const char *e = getenv("CVO_HIP_FILTER_BLOCKS");
-        const long long q = e ? atoll(e) : 1024;
-        return q >= 1 ? q : 1024;
+        const long long q = e ? atoll(e) : 2048;
+        return q >= 1 ? q : 2048;
     }();
     return v;
 }
@@ -327,7 +335,7 @@ void launch_filter_group(const FilterArgs *a, int n, hipStream_t s)
     dim3 grid(1, 1, (unsigned)n);
     int jt = 0;
     // the launch as a whole gets about as many blocks as a single registration would
-    const long long cap = std::max<long long>(64, filter_blocks_max() / n);
+    const long long cap = std::max<long long>(64, filter_blocks_max() / (2 * n));
     for (int i = 0; i < n; ++i) {
         g.a[i] = a[i];
         grid.x = std::max(grid.x, (unsigned)std::min<long long>((long long)a[i].gx * a[i].gy, cap));
