@@ -2,13 +2,13 @@
 """bench.py -- frame-pair registrations/s of the CVO inner loop on MI355X.
 
 A "step" is one pass of the hot path over one BATCH of synthetic input: `--batch`
-(default 4) independent frame pairs of BASELINE.json configs[1] -- the seeded
+(default 16) independent frame pairs of BASELINE.json configs[1] -- the seeded
 synthetic 10k x 10k RGB-D cloud pair -- each run through a full align()
 (ref src/cvo.cpp:361-420: ~50 gradient-flow iterations, each = transform +
 all-pairs neighbour filter + flow pass + step-size pass) from the reference
 object's initial state, all clouds already resident in HBM, all registrations
-of the batch in flight at once (one context + one HIP stream each,
-cvo_hip_align_many).  `value` = registrations completed per second; the
+of the batch in flight at once (cvo_hip_align_many: the registrations of a batch
+share every kernel launch, blockIdx.z = registration).  `value` = registrations completed per second; the
 single-registration latency (batch of one) is measured in the same run and
 reported as `single_stream`.  One process per GPU; for N > 1 every rank runs its
 own batches (independent frame pairs: weak scaling, no data-path collective),
@@ -42,7 +42,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--points", type=int, default=10000, help="N = M of the synthetic pair")
-    ap.add_argument("--batch", type=int, default=4, help="frame pairs in flight per step")
+    ap.add_argument("--batch", type=int, default=16, help="frame pairs in flight per step")
     ap.add_argument("--mode", default="cvo", choices=["cvo", "acvo"])
     ap.add_argument("--cpu-seconds", type=float, default=15.0,
                     help="budget of the cpu_baseline leg (rank 0, N=1 only)")
@@ -172,6 +172,14 @@ def main():
             except Exception:
                 traffic = None
         algo_bytes = BYTES_PER_POINT * (n + m)
+        iters_per_reg = float(it_sum.item()) / total_regs
+        # two all-pairs sweeps (flow, step size) per iteration, 8 flop per
+        # pair test.  The path culls tile pairs, re-uses its neighbour lists across
+        # iterations and evaluates the step-size sweep on the members of A only, so this
+        # is an EQUIVALENT rate (work the reference's dense formulation would do / time).
+        sweep_flop_per_iter = 2.0 * FLOP_PER_PAIR * float(n) * m
+        equiv_batched = sweep_flop_per_iter * float(it_sum.item()) / elapsed / 1e12
+        equiv_single = sweep_flop_per_iter / (single["ms_per_iteration"] * 1e-3) / 1e12
         out = {
             "metric": "frame-pair registrations/sec",
             "value": value,
@@ -192,9 +200,15 @@ def main():
                 "points_fixed": n, "points_moving": m, "mode": args.mode,
                 "pairs_per_sweep": float(n) * m,
                 "batch": B,
-                "parallelism": "%d independent registrations in flight per GPU (one HIP stream each)" % B,
+                "parallelism": "%d independent registrations in flight per GPU, fused into shared "
+                               "kernel launches (blockIdx.z = registration)" % B,
             },
-            "iterations_per_registration": float(it_sum.item()) / total_regs,
+            "iterations_per_registration": iters_per_reg,
+            "equivalent_sweep_rate": {
+                "definition": "2 sweeps x 8 flop x N x M per iteration / time (SURVEY 8d b); exceeds the "
+                              "f32 peak because most pair tests are proven unnecessary, not executed",
+                "batched_TFLOPs": equiv_batched, "single_stream_TFLOPs": equiv_single,
+                "peak_TFLOPs": PEAK_F32_TFLOPS},
             "ms_per_iteration": elapsed * 1e3 * world / max(float(it_sum.item()), 1.0),
             "single_stream": single,
             "gt_motion_rel_err": {"rot": rot_err, "trans": tr_err},
@@ -209,6 +223,10 @@ def main():
                 "flop_per_launch": FLOP_PER_PAIR * pairs,
                 "avg_launch_us": sweep_ms * 1e3,
                 "launches": launches,
+                "launches_note": "k_filter does work only in the iterations that rebuild the tile list "
+                                 "(%.1f of %.1f iterations per registration here); the other launches "
+                                 "return at once and are not counted" % (
+                                     launches / float(max(3, args.steps // 4)), iters_per_reg),
                 "measured": "HIP events on the launching stream, every k_filter launch of %d "
                             "single-stream registrations of the same run" % max(3, args.steps // 4),
                 "traffic": traffic,

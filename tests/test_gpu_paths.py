@@ -231,3 +231,67 @@ def test_align_many_equals_one_by_one(pkg, mode_name):
     assert len(it_a) == len(ctxs)
     for c in ctxs:
         c.close()
+
+
+@pytest.mark.parametrize("mode_name", ["cvo", "acvo"])
+def test_list_reuse_changes_nothing(pkg, monkeypatch, mode_name):
+    """The tile lists are built 15 % wide and re-used while they provably hold
+    every pair (cvo_device.h plan_lists): a performance decision only.  With
+    re-use switched off (every iteration rebuilds its lists at the exact radius)
+    the registration is the same bit for bit, trace included."""
+    capi = pkg.capi
+    acvo = mode_name == "acvo"
+    mode = capi.MODE_ACVO if acvo else capi.MODE_CVO
+    xf, ff, xm, fm = pkg.data.synthetic_pair(3000, 2800, seed=61, acvo=acvo)
+    runs = []
+    for margin in ("0", None, "0.4"):
+        if margin is None:
+            monkeypatch.delenv("CVO_HIP_LIST_MARGIN", raising=False)
+        else:
+            monkeypatch.setenv("CVO_HIP_LIST_MARGIN", margin)
+        c = _ctx(pkg, mode, xf, ff, xm, fm)
+        c.set_profiling(True)
+        st = capi.init_state(c.params)
+        n_it, tr = c.align(st, trace_cap=2000)
+        prof = c.get_profile(reset=True)
+        runs.append((n_it, bytes(st), [(t["nnz"], t["step"], tuple(t["omega"]), tuple(t["v"])) for t in tr],
+                     prof["flow_launches"]))
+        c.close()
+    monkeypatch.delenv("CVO_HIP_LIST_MARGIN", raising=False)
+    assert runs[0][0] == runs[1][0] == runs[2][0]
+    assert runs[0][1] == runs[1][1] == runs[2][1]
+    assert runs[0][2] == runs[1][2] == runs[2][2]
+    # no re-use: one list build per iteration (+ one per iteration redone after a list grew)
+    assert runs[0][0] <= runs[0][3] <= runs[0][0] + 3
+    assert runs[1][3] < runs[0][3] // 2        # re-use: far fewer builds
+
+
+def test_fused_batch_with_list_overflow(pkg, monkeypatch):
+    """Fused launches (several registrations per kernel launch) where the lists of
+    every member start at their minimum capacity: each member parks, grows its
+    list and rejoins the batch; results equal the one-by-one registrations."""
+    import torch
+    capi = pkg.capi
+    sizes = [(1800, 1700), (2200, 2500), (1500, 1500)]
+    clouds = [pkg.data.synthetic_pair(n, m, seed=70 + i) for i, (n, m) in enumerate(sizes)]
+    ref = []
+    for xf, ff, xm, fm in clouds:
+        c = _ctx(pkg, capi.MODE_CVO, xf, ff, xm, fm)
+        st = capi.init_state(c.params)
+        n_it, _ = c.align(st, trace_cap=0)
+        ref.append((n_it, bytes(st)))
+        c.close()
+    monkeypatch.setenv("CVO_HIP_LIST_INIT", "1")
+    streams = [torch.cuda.Stream() for _ in sizes]
+    ctxs = []
+    for s, (xf, ff, xm, fm) in zip(streams, clouds):
+        c = capi.Context(mode=capi.MODE_CVO, device=0, stream=s.cuda_stream)
+        c.set_fixed(xf, ff)
+        c.set_moving(xm, fm)
+        ctxs.append(c)
+    states = [capi.init_state(c.params) for c in ctxs]
+    its = capi.align_many(ctxs, states)
+    monkeypatch.delenv("CVO_HIP_LIST_INIT")
+    assert [(i, bytes(s)) for i, s in zip(its, states)] == ref
+    for c in ctxs:
+        c.close()

@@ -77,10 +77,10 @@ int main(int argc, char **argv)
         hipMemcpy(&h, st, sizeof(h), hipMemcpyDeviceToHost);
         unsigned long long tot = 0; for (int q = 0; q < NSUB; ++q) tot += h.sub[0][q];
         size_t culled = 0; double clife = 0;
-        for (size_t w = 0; w < nw; ++w) if (hd[w * 8 + 4] == -1) { culled++; clife += hd[w * 8 + 3] - hd[w * 8]; }
+        for (size_t w = 0; w < nw; ++w) if (hd[w * 8 + 3] == 0) { culled++; }
         printf("culled waves %zu of %zu (avg life %.0f ticks)\n", culled, (size_t)nw, culled ? clife / culled : 0.0);
         {   size_t k = 0;   // keep only the surviving waves for the statistics below
-            for (size_t w = 0; w < nw; ++w) if (hd[w * 8 + 4] != -1) { for (int q = 0; q < 8; ++q) hd[k * 8 + q] = hd[w * 8 + q]; ++k; }
+            for (size_t w = 0; w < nw; ++w) if (hd[w * 8 + 3] != 0) { for (int q = 0; q < 8; ++q) hd[k * 8 + q] = hd[w * 8 + q]; ++k; }
             nw_live = k; }
         if (nw_live == 0) continue;
         const size_t nw_outer = nw; (void)nw_outer;
