@@ -63,8 +63,11 @@ if tr:
         dur[k].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
     live = {}
     for k, v in dur.items():
-        med = sorted(v)[len(v) // 2]
-        lv = [x for x in v if x > 0.4 * med]
+        sv = sorted(v)
+        # k_filter works only in the iterations that rebuild the tile list (most of its
+        # launches return at once): its executed launches are the long ones
+        ref = sv[int(0.99 * (len(sv) - 1))] if k == "k_filter" else sv[len(sv) // 2]
+        lv = [x for x in v if x > 0.4 * ref]
         live[k] = {"launches": len(v), "avg_us": sum(v) / len(v), "live_launches": len(lv),
                    "live_avg_us": sum(lv) / max(len(lv), 1), "total_us": sum(v)}
     with open(os.path.join(dst, "%s_kernel_live.json" % tag), "w") as fh:
