@@ -2,13 +2,14 @@
 """bench.py -- frame-pair registrations/s of the CVO inner loop on MI355X.
 
 A "step" is one pass of the hot path over one BATCH of synthetic input: `--batch`
-(default 16) independent frame pairs of BASELINE.json configs[1] -- the seeded
+(default 32) independent frame pairs of BASELINE.json configs[1] -- the seeded
 synthetic 10k x 10k RGB-D cloud pair -- each run through a full align()
 (ref src/cvo.cpp:361-420: ~50 gradient-flow iterations, each = transform +
 all-pairs neighbour filter + flow pass + step-size pass) from the reference
 object's initial state, all clouds already resident in HBM, all registrations
-of the batch in flight at once (cvo_hip_align_many: the registrations of a batch
-share every kernel launch, blockIdx.z = registration).  `value` = registrations completed per second; the
+of the batch in flight at once (cvo_hip_align_many: groups of up to 16
+registrations share every kernel launch, blockIdx.z = registration; the groups
+run on their own streams and fill each other's bubbles).  `value` = registrations completed per second; the
 single-registration latency (batch of one) is measured in the same run and
 reported as `single_stream`.  One process per GPU; for N > 1 every rank runs its
 own batches (independent frame pairs: weak scaling, no data-path collective),
@@ -42,7 +43,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--points", type=int, default=10000, help="N = M of the synthetic pair")
-    ap.add_argument("--batch", type=int, default=16, help="frame pairs in flight per step")
+    ap.add_argument("--batch", type=int, default=32, help="frame pairs in flight per step")
     ap.add_argument("--mode", default="cvo", choices=["cvo", "acvo"])
     ap.add_argument("--cpu-seconds", type=float, default=15.0,
                     help="budget of the cpu_baseline leg (rank 0, N=1 only)")
@@ -200,8 +201,8 @@ def main():
                 "points_fixed": n, "points_moving": m, "mode": args.mode,
                 "pairs_per_sweep": float(n) * m,
                 "batch": B,
-                "parallelism": "%d independent registrations in flight per GPU, fused into shared "
-                               "kernel launches (blockIdx.z = registration)" % B,
+                "parallelism": "%d independent registrations in flight per GPU, fused in groups of <= 16 into "
+                               "shared kernel launches (blockIdx.z = registration), one stream per group" % B,
             },
             "iterations_per_registration": iters_per_reg,
             "equivalent_sweep_rate": {

@@ -23,6 +23,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <memory>
 #include <vector>
 
 #include "cvo_comm.h"
@@ -1319,79 +1320,113 @@ void launch_fused(const std::vector<std::vector<RecOp>> &ops, hipStream_t s)
     }
 }
 
-// jobs: begun (job_begin) and in phase 0, all fusable, same device and mode, <= MAXG
-void run_fused(std::vector<AlignJob *> &jobs)
+// Streams of the fused groups: a few per device, created on first use and kept
+// for the life of the process.
+hipStream_t group_stream(int device, int slot)
 {
-    if (jobs.empty()) return;
-    cvo_hip_ctx *lead = jobs[0]->ctx;
-    hipStream_t s = lead->stream;
-    auto fail_all = [&](std::vector<AlignJob *> &v, const char *msg) {
-        for (AlignJob *j : v) { j->rc = fail(j->ctx, CVO_HIP_ERR_HIP, msg); j->phase = 2; }
-        v.clear();
-    };
-    if (hipSetDevice(lead->device) != hipSuccess) return fail_all(jobs, "hipSetDevice failed");
-    // the members' uploads and initial states were queued on their own streams
-    for (AlignJob *j : jobs)
-        if (hipStreamSynchronize(j->ctx->stream) != hipSuccess) return fail_all(jobs, "stream sync failed");
-    hipEvent_t ev[2] = {nullptr, nullptr};
-    if (hipEventCreateWithFlags(&ev[0], hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&ev[1], hipEventDisableTiming) != hipSuccess)
-        return fail_all(jobs, "hipEventCreate failed");
-    std::vector<AlignJob *> live = jobs;
+    constexpr int kDev = 16, kSlots = 4;
+    static hipStream_t pool[kDev][kSlots] = {};
+    if (device < 0 || device >= kDev) return nullptr;
+    slot = ((slot % kSlots) + kSlots) % kSlots;
+    if (!pool[device][slot] &&
+        hipStreamCreateWithFlags(&pool[device][slot], hipStreamNonBlocking) != hipSuccess)
+        pool[device][slot] = nullptr;
+    return pool[device][slot];
+}
+
+// A fused group as a resumable state machine, so that one host thread can keep
+// several groups (each on its own stream) in flight: while one group sits in its
+// single-block post kernels or between two kernels, the other one has the GPU.
+// Members: begun (job_begin), in phase 0, fusable, same device and mode, <= MAXG.
+struct FusedRun {
+    std::vector<AlignJob *> live;
     std::vector<std::vector<RecOp>> ops;
-    while (!live.empty()) {
-        // (re)record the launch arguments of the current members; the list kernels
-        // get fewer blocks per registration the more registrations share a launch
-        const int G = (int)live.size();
+    hipStream_t s = nullptr;
+    int device = 0;
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    int b = 0;          // batches launched since the arguments were recorded
+    int max_iter = 0;
+    enum { RECORD, LAUNCH, WAIT, SETTLE, DONE } state = RECORD;
+
+    void fail_all(const char *msg)
+    {
+        for (AlignJob *j : live) { j->rc = fail(j->ctx, CVO_HIP_ERR_HIP, msg); j->phase = 2; }
+        live.clear();
+        state = DONE;
+    }
+
+    // slot: index of this group among the groups in flight; groups use library-owned
+    // streams (the members' streams may well share a hardware queue)
+    void start(const std::vector<AlignJob *> &jobs, int slot)
+    {
+        live = jobs;
+        device = jobs[0]->ctx->device;
+        if (hipSetDevice(device) != hipSuccess) return fail_all("hipSetDevice failed");
+        s = group_stream(device, slot);
+        if (!s) s = jobs[0]->ctx->stream;
+        // the members' uploads and initial states were queued on their own streams
+        for (AlignJob *j : live)
+            if (hipStreamSynchronize(j->ctx->stream) != hipSuccess) return fail_all("stream sync failed");
+        if (hipEventCreateWithFlags(&ev[0], hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&ev[1], hipEventDisableTiming) != hipSuccess)
+            return fail_all("hipEventCreate failed");
+        state = RECORD;
+    }
+
+    ~FusedRun()
+    {
+        if (ev[0]) (void)hipEventDestroy(ev[0]);
+        if (ev[1]) (void)hipEventDestroy(ev[1]);
+    }
+
+    bool stopped_any() const
+    {
+        for (AlignJob *j : live)
+            if (*(volatile int32_t *)j->ctx->done_mirror != RUNNING) return true;
+        return false;
+    }
+
+    // (re)record the launch arguments of the current members; the list kernels get
+    // fewer blocks per registration the more registrations share a launch
+    void record()
+    {
         static const int budget = [] {   // blocks of a whole fused launch (tuning knob)
             const char *e = getenv("CVO_HIP_PROC_BUDGET");
             const int v = e ? atoi(e) : 4096;
             return v >= NSUB ? v : 4096;
         }();
+        const int G = (int)live.size();
         const int nblk = std::min(PROC_BLOCKS, std::max(NSUB, (budget / G) / NSUB * NSUB));
         ops.assign(live.size(), {});
-        bool bad = false;
-        for (size_t i = 0; i < live.size() && !bad; ++i) {
+        for (size_t i = 0; i < live.size(); ++i) {
             cvo_hip_ctx *c = live[i]->ctx;
             c->rec = &ops[i];
             c->proc_blocks = nblk;
             const int rc = enqueue_iterations(c, 1, -1, 0);
             c->proc_blocks = PROC_BLOCKS;
             c->rec = nullptr;
-            if (rc || ops[i].size() != ops[0].size()) bad = true;
+            if (rc || ops[i].size() != ops[0].size()) return fail_all("fused launch recording failed");
         }
-        if (bad) { fail_all(live, "fused launch recording failed"); break; }
-        int max_iter = 0;
+        max_iter = 0;
         for (AlignJob *j : live) max_iter = std::max(max_iter, j->ctx->prm.max_iter);
-        bool changed = false;
-        for (int b = 0; !changed; ++b) {
-            for (int q = 0; q < kBatch; ++q) launch_fused(ops, s);
-            if (hipGetLastError() != hipSuccess || hipEventRecord(ev[b & 1], s) != hipSuccess) {
-                fail_all(live, "fused launch failed");
-                break;
-            }
-            if (b >= 1) {   // look at the state one batch behind
-                if (hipEventSynchronize(ev[(b - 1) & 1]) != hipSuccess) {
-                    fail_all(live, "fused poll failed");
-                    break;
-                }
-                for (AlignJob *j : live)
-                    if (*(volatile int32_t *)j->ctx->done_mirror != RUNNING) changed = true;
-            }
-            if ((b + 1) * kBatch > max_iter + 3 * kBatch) changed = true;   // cannot happen
-        }
-        if (live.empty()) break;
-        // somebody stopped: drain the queue, hand the finished members back
-        if (hipStreamSynchronize(s) != hipSuccess) { fail_all(live, "stream sync failed"); break; }
+        b = 0;
+        state = LAUNCH;
+    }
+
+    // somebody stopped: drain the queue, hand the finished members back, let the
+    // ones whose list overflowed grow it and rejoin
+    void settle()
+    {
+        if (hipStreamSynchronize(s) != hipSuccess) return fail_all("stream sync failed");
         std::vector<AlignJob *> stopped, next;
         for (AlignJob *j : live)
             (*(volatile int32_t *)j->ctx->done_mirror != RUNNING ? stopped : next).push_back(j);
-        if (stopped.empty()) { fail_all(live, "align loop ended without a verdict"); break; }
+        if (stopped.empty()) return fail_all("align loop ended without a verdict");
         for (AlignJob *j : stopped)
             if (hipMemcpyAsync(&j->ctx->st_host[0], j->ctx->st, sizeof(DevState), hipMemcpyDeviceToHost,
                                s) != hipSuccess)
                 j->rc = fail(j->ctx, CVO_HIP_ERR_HIP, "state copy failed");
-        if (hipStreamSynchronize(s) != hipSuccess) { fail_all(live, "stream sync failed"); break; }
+        if (hipStreamSynchronize(s) != hipSuccess) return fail_all("stream sync failed");
         for (AlignJob *j : stopped) {
             cvo_hip_ctx *c = j->ctx;
             if (j->rc) { j->phase = 2; continue; }
@@ -1401,7 +1436,6 @@ void run_fused(std::vector<AlignJob *> &jobs)
                 j->phase = 2;
                 continue;
             }
-            // grow the overflowed list(s); the member resumes from the parked iteration
             int rc = CVO_HIP_OK;
             for (int l = 0; l < LIST_N && !rc; ++l)
                 if (cur.cnt[2 * l + 1]) {
@@ -1423,10 +1457,44 @@ void run_fused(std::vector<AlignJob *> &jobs)
             next.push_back(j);
         }
         live.swap(next);
+        state = live.empty() ? DONE : RECORD;
     }
-    (void)hipEventDestroy(ev[0]);
-    (void)hipEventDestroy(ev[1]);
-}
+
+    // Advance as far as possible without (block = false) or with waiting on the GPU.
+    // Returns true if anything moved.
+    bool pump(bool block)
+    {
+        bool moved = false;
+        for (;;) {
+            if (state == DONE) return moved;
+            if (hipSetDevice(device) != hipSuccess) { fail_all("hipSetDevice failed"); return true; }
+            if (state == RECORD) { record(); moved = true; continue; }
+            if (state == LAUNCH) {
+                for (int q = 0; q < kBatch; ++q) launch_fused(ops, s);
+                if (hipGetLastError() != hipSuccess || hipEventRecord(ev[b & 1], s) != hipSuccess) {
+                    fail_all("fused launch failed");
+                    return true;
+                }
+                ++b;
+                moved = true;
+                if ((b + 1) * kBatch > max_iter + 4 * kBatch) { state = SETTLE; continue; }   // cannot happen
+                state = b >= 2 ? WAIT : LAUNCH;   // keep two batches queued, look one batch behind
+                continue;
+            }
+            if (state == WAIT) {
+                hipEvent_t e = ev[b & 1];   // batch b - 2: the older of the two in flight
+                const hipError_t q = block ? hipEventSynchronize(e) : hipEventQuery(e);
+                if (q == hipErrorNotReady) return moved;
+                if (q != hipSuccess) { fail_all("fused poll failed"); return true; }
+                moved = true;
+                block = false;   // waited once: the caller decides whom to wait for next
+                state = stopped_any() ? SETTLE : LAUNCH;
+                continue;
+            }
+            if (state == SETTLE) { settle(); moved = true; continue; }
+        }
+    }
+};
 
 }   // namespace
 
@@ -1459,22 +1527,53 @@ int cvo_hip_align_many(cvo_hip_ctx **ctxs, cvo_hip_state **states, int *n_iters,
         const int rc = job_begin(jobs[i]);
         if (rc) { jobs[i].rc = rc; jobs[i].phase = 2; if (!first_err) first_err = rc; }
     }
-    // fused groups: same device, same mode, nothing that needs its own launches
+    // fused groups: same device, same mode, nothing that needs its own launches;
+    // each group runs on its leader's stream, all groups are in flight together
     static const bool no_fuse = getenv("CVO_HIP_NO_FUSE") != nullptr;
     if (!no_fuse && count > 1) {
         std::vector<char> taken((size_t)count, 0);
+        std::vector<std::unique_ptr<FusedRun>> runs;
+        static const int gmax = [] {
+            const char *e = getenv("CVO_HIP_GROUP");
+            const int v = e ? atoi(e) : MAXG;
+            return std::min(MAXG, std::max(2, v));
+        }();
         for (int i = 0; i < count; ++i) {
             if (taken[i] || jobs[i].phase != 0 || !fusable(jobs[i].ctx)) continue;
-            std::vector<AlignJob *> grp;
-            for (int k = i; k < count && (int)grp.size() < MAXG; ++k)
+            std::vector<AlignJob *> cand;
+            for (int k = i; k < count; ++k)
                 if (!taken[k] && jobs[k].phase == 0 && fusable(jobs[k].ctx) &&
                     jobs[k].ctx->device == jobs[i].ctx->device &&
-                    jobs[k].ctx->prm.mode == jobs[i].ctx->prm.mode) {
-                    grp.push_back(&jobs[k]);
-                    taken[k] = 1;
-                }
-            if (grp.size() < 2) { taken[i] = 0; for (AlignJob *j : grp) taken[j - &jobs[0]] = 0; continue; }
-            run_fused(grp);
+                    jobs[k].ctx->prm.mode == jobs[i].ctx->prm.mode)
+                    cand.push_back(&jobs[k]);
+            if (cand.size() < 2) continue;
+            // split evenly into the fewest groups of at most gmax members, but at least
+            // two when there are enough members: two groups fill each other's bubbles
+            // (single-block post kernels, kernel boundaries)
+            size_t ngroups = (cand.size() + gmax - 1) / gmax;
+            if (ngroups < 2 && cand.size() >= 8) ngroups = 2;
+            size_t at = 0;
+            for (size_t g = 0; g < ngroups; ++g) {
+                const size_t take = (cand.size() - at + (ngroups - g) - 1) / (ngroups - g);
+                std::vector<AlignJob *> grp(cand.begin() + at, cand.begin() + at + take);
+                at += take;
+                for (AlignJob *j : grp) taken[j - &jobs[0]] = 1;
+                if (grp.size() < 2) { taken[grp[0] - &jobs[0]] = 0; continue; }
+                runs.emplace_back(new FusedRun());
+                runs.back()->start(grp, (int)runs.size() - 1);
+            }
+        }
+        for (;;) {
+            bool any_live = false, moved = false;
+            for (auto &r : runs) {
+                if (r->state == FusedRun::DONE) continue;
+                if (r->pump(false)) moved = true;
+                if (r->state != FusedRun::DONE) any_live = true;
+            }
+            if (!any_live) break;
+            if (!moved)   // everybody waits for the GPU: block on the first live group
+                for (auto &r : runs)
+                    if (r->state != FusedRun::DONE) { r->pump(true); break; }
         }
         for (int i = 0; i < count; ++i)
             if (jobs[i].phase == 2 && jobs[i].rc && !first_err) first_err = jobs[i].rc;

@@ -23,7 +23,7 @@ def one(pattern):
 
 
 for pat, name in (("bench.json", "%s_bench.json"), ("stats/*kernel_stats.csv", "%s_kernel_stats.csv"),
-                  ("stats_batch/*kernel_stats.csv", "%s_kernel_stats_batch16.csv")):
+                  ("stats_batch/*kernel_stats.csv", "%s_kernel_stats_batch32.csv")):
     f = one(pat)
     if f:
         shutil.copy(f, os.path.join(dst, name % tag))
