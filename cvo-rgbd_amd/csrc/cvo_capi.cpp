@@ -77,6 +77,7 @@ struct GraphEntry {
     uint64_t stamp = 0;
 };
 constexpr int kPollSlots = 4;
+constexpr int kProcStepTwist = 100;   // RecOp::mode of a k_step_twist launch
 
 // One kernel launch of an iteration, recorded instead of launched (fused mode:
 // the launches of several registrations are merged slot by slot).
@@ -103,6 +104,10 @@ struct cvo_hip_ctx {
     int32_t *done_mirror = nullptr;  // pinned (in the last slot): the post kernels copy `done` here
     std::vector<RecOp> *rec = nullptr;   // not null: record launches instead of issuing them
     int proc_blocks = PROC_BLOCKS;       // blocks of the list kernels (fewer in fused launches)
+    bool merge_twist = false;            // inside align(): k_step_twist replaces k_post_flow + PROC_STEP
+    bool allow_merge = true;
+    cvo_hip_trace *cur_trace = nullptr;  // trace buffer of the iterations being enqueued
+    int cur_trace_cap = 0;
     hipEvent_t poll_ev[kPollSlots]{};
     DevBuf part_flow, part_xx, part_yy, part_step;   // [PROC_BLOCKS][NACC_MAX] float64
     List lists[LIST_N];
@@ -469,12 +474,22 @@ int enqueue_process(cvo_hip_ctx *ctx, int mode, int list, DevBuf &part, const fl
     a.first_counted = first_counted;
     a.tf_a = tf_a; a.tf_b = tf_b;
     a.check_done = check_done;
+    const bool twist = mode == PROC_STEP && ctx->merge_twist;
+    if (twist) {
+        a.flow_part = (const double *)ctx->part_flow.p;
+        a.xx_part = (const double *)ctx->part_xx.p;
+        a.yy_part = (const double *)ctx->part_yy.p;
+        a.trace = ctx->cur_trace; a.trace_cap = ctx->cur_trace_cap;
+        a.acvo = ctx->prm.mode == CVO_HIP_MODE_ACVO;
+        a.done_mirror = ctx->done_mirror;
+    }
     if (ctx->rec) {
-        RecOp op; op.kind = RecOp::PROCESS; op.mode = mode; op.p = a;
+        RecOp op; op.kind = RecOp::PROCESS; op.mode = twist ? kProcStepTwist : mode; op.p = a;
         ctx->rec->push_back(op);
         return CVO_HIP_OK;
     }
-    launch_process(mode, a, ctx->stream);
+    if (twist) launch_step_twist_group(&a, 1, ctx->stream);
+    else launch_process(mode, a, ctx->stream);
     HIP_TRY(ctx, hipGetLastError());
     return CVO_HIP_OK;
 }
@@ -571,6 +586,7 @@ int enqueue_flow(cvo_hip_ctx *ctx, bool tf_moving, int check_done, bool do_math,
                              ctx->fixed.n, check_done);
         if (rc) return rc;
     }
+    if (ctx->merge_twist) return CVO_HIP_OK;   // k_step_twist does the rest of compute_flow
     PostFlowArgs pa{};
     pa.st = ctx->st;
     pa.prm = ctx->dprm;
@@ -612,7 +628,7 @@ int enqueue_step(cvo_hip_ctx *ctx, int check_done, bool do_math, cvo_hip_trace *
     pa.trace = trace; pa.trace_cap = trace_cap;
     pa.check_done = check_done;
     pa.done_mirror = ctx->done_mirror;
-    pa.nblk = ctx->proc_blocks;
+    pa.nblk = ctx->merge_twist ? ctx->proc_blocks / STEP_TWIST_ROWS_DIV : ctx->proc_blocks;
     pa.part_step = (const double *)ctx->part_step.p;
     pa.dbg = ctx->post_dbg;
     if (multi_rank(ctx)) {
@@ -679,11 +695,15 @@ int prepare_buffers(cvo_hip_ctx *ctx)
 int enqueue_iterations(cvo_hip_ctx *ctx, int count, int tag0, int trace_cap)
 {
     int rc = CVO_HIP_OK;
+    ctx->merge_twist = ctx->allow_merge && !multi_rank(ctx);
+    ctx->cur_trace = ctx->trace_dev;
+    ctx->cur_trace_cap = trace_cap;
     for (int q = 0; q < count && !rc; ++q) {
         ctx->iter_tag = tag0 >= 0 ? tag0 + q : -1;
         rc = enqueue_flow(ctx, true, 1, true, ctx->trace_dev, trace_cap);
         if (!rc) rc = enqueue_step(ctx, 1, true, ctx->trace_dev, trace_cap);
     }
+    ctx->merge_twist = false;
     ctx->iter_tag = -1;
     return rc;
 }
@@ -902,6 +922,7 @@ int cvo_hip_create(int device, void *stream, const cvo_hip_params *p, cvo_hip_ct
     ctx->done_mirror = reinterpret_cast<int32_t *>(&ctx->st_host[kPollSlots + 1]);
     *ctx->done_mirror = 0;
     if (getenv("CVO_HIP_NO_GRAPH")) ctx->use_graphs = false;
+    if (getenv("CVO_HIP_NO_MERGE")) ctx->allow_merge = false;
     if (getenv("CVO_HIP_POST_DEBUG")) {
         if (hipMalloc((void **)&ctx->post_dbg, 8 * sizeof(long long)) != hipSuccess) return bail(CVO_HIP_ERR_NOMEM);
         (void)hipMemset(ctx->post_dbg, 0, 8 * sizeof(long long));
@@ -1306,7 +1327,8 @@ void launch_fused(const std::vector<std::vector<RecOp>> &ops, hipStream_t s)
             break;
         case RecOp::PROCESS:
             for (int i = 0; i < n; ++i) p[i] = ops[i][q].p;
-            launch_process_group(ops[0][q].mode, p, n, s);
+            if (ops[0][q].mode == kProcStepTwist) launch_step_twist_group(p, n, s);
+            else launch_process_group(ops[0][q].mode, p, n, s);
             break;
         case RecOp::POST_FLOW:
             for (int i = 0; i < n; ++i) pf[i] = ops[i][q].pf;
@@ -1402,7 +1424,13 @@ struct FusedRun {
             cvo_hip_ctx *c = live[i]->ctx;
             c->rec = &ops[i];
             c->proc_blocks = nblk;
+            // k_step_twist pays for the saved launch with a prologue in every block:
+            // a gain while launches are latency-bound, a loss once the GPU is full
+            const bool allow = c->allow_merge;
+            static const int merge_max = [] { const char *e = getenv("CVO_HIP_MERGE_MAXG"); return e ? atoi(e) : 2; }();
+            if (G > merge_max) c->allow_merge = false;
             const int rc = enqueue_iterations(c, 1, -1, 0);
+            c->allow_merge = allow;
             c->proc_blocks = PROC_BLOCKS;
             c->rec = nullptr;
             if (rc || ops[i].size() != ops[0].size()) return fail_all("fused launch recording failed");

@@ -178,11 +178,18 @@ struct ProcessArgs {
     uint2 *kept_ij;        // kept list: PROC_FLOW writes, PROC_STEP reads
     float *kept_a;
     uint32_t *kept_cnt;    // [PROC_WAVES] members recorded by each PROC_FLOW wave
-    double *partials;      // [PROC_BLOCKS][nacc]
+    double *partials;      // [nacc][nblk] (k_step_twist: [nacc][nblk / 4])
     DevState *st;
     uint32_t subcap;       // of the tile list
     uint32_t kept_wcap;    // kept-list slice of one wave (entries)
     int nblk;              // blocks of this launch for this registration (NSUB .. PROC_BLOCKS)
+    // k_step_twist only (PROC_STEP with the tail of compute_flow in front):
+    const double *flow_part;   // [nblk][NACC_FLOW] partial sums of PROC_FLOW
+    const double *xx_part;     // acvo: [nblk][NACC_SELF]
+    const double *yy_part;
+    cvo_hip_trace *trace; int trace_cap;
+    int acvo;
+    int32_t *done_mirror;
     int list;              // which tile list
     int row_hi, nb;        // valid rows / columns (mask bits beyond are padding)
     int first_counted;     // PROC_SELF: rows whose caller index is below contribute 0 to the sum
@@ -348,5 +355,7 @@ void launch_filter_group(const FilterArgs *a, int n, hipStream_t s);
 void launch_process_group(int mode, const ProcessArgs *a, int n, hipStream_t s);
 void launch_post_flow_group(const PostFlowArgs *a, int n, hipStream_t s);
 void launch_post_step_group(const PostStepArgs *a, int n, hipStream_t s);
+void launch_step_twist_group(const ProcessArgs *a, int n, hipStream_t s);
+constexpr int STEP_TWIST_ROWS_DIV = 4;   // k_step_twist writes nblk / 4 partial rows
 
 }   // namespace cvo_dev

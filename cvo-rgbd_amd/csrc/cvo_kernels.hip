@@ -476,7 +476,8 @@ template <> struct NAcc<PROC_SELF> { static constexpr int n = NACC_SELF; };
 // (0 = not in A).  PROC_STEP: `w` is the recorded weight of a member of A.
 template <int MODE>
 __device__ __forceinline__ float eval_pair(const ProcessArgs &a, const KernConsts &kc, unsigned i,
-                                           unsigned j, float w, double *acc)
+                                           unsigned j, float w, double *acc,
+                                           const cvo_math::XiConsts &xc)
 {
     const float *Rt = a.st->Rt;
     const float *tt = a.st->t;
@@ -519,7 +520,6 @@ __device__ __forceinline__ float eval_pair(const ProcessArgs &a, const KernConst
         acc[8] += 1.0;
     } else if (MODE == PROC_STEP) {
         // Taylor vectors of y_j (ref cvo.cpp:226-238), for members of A only
-        const cvo_math::XiConsts &xc = a.st->xi;
         float xiz[3], xi2z[3], xi3z[3], xi4z[3];
         xiz[0] = (xc.omega[1] * yj.z - xc.omega[2] * yj.y) + xc.v[0];
         xiz[1] = (xc.omega[2] * yj.x - xc.omega[0] * yj.z) + xc.v[1];
@@ -587,7 +587,7 @@ __global__ void __launch_bounds__(BLOCK) k_process(const Grp<ProcessArgs> grp)
         if (n > a.kept_wcap) n = a.kept_wcap;
         for (unsigned off = lane; off < n; off += 64) {
             if (off >= 64) { e = a.kept_ij[base + off]; w = a.kept_a[base + off]; }
-            eval_pair<MODE>(a, kc, e.x, e.y, w, acc);
+            eval_pair<MODE>(a, kc, e.x, e.y, w, acc, a.st->xi);
         }
     } else {
         // nblk / NSUB blocks share one sub-list of the tile list
@@ -615,7 +615,7 @@ __global__ void __launch_bounds__(BLOCK) k_process(const Grp<ProcessArgs> grp)
             uint2 pr = make_uint2(0u, 0u);
             if (lane < cnt) {
                 pr = pairq[base + lane];
-                w = eval_pair<MODE>(a, kc, pr.x, pr.y, 0.0f, acc);
+                w = eval_pair<MODE>(a, kc, pr.x, pr.y, 0.0f, acc, a.st->xi);   // (xi: PROC_STEP only)
             }
             if (MODE == PROC_FLOW) {   // record the members of A in this wave's slice
                 const unsigned long long km = __ballot(w > 0.0f);
@@ -669,8 +669,158 @@ __global__ void __launch_bounds__(BLOCK) k_process(const Grp<ProcessArgs> grp)
     __syncthreads();
     if (tid < NACC) {
         const double s = ((red[tid] + red[NACC + tid]) + red[2 * NACC + tid]) + red[3 * NACC + tid];
-        a.partials[(size_t)blockIdx.x * NACC + tid] = s;
+        a.partials[(size_t)tid * a.nblk + blockIdx.x] = s;   // [value][block]: coalesced for the readers
     }
+}
+
+// ---------------------------------------------------------------------------
+// k_step_twist = the tail of compute_flow (what k_post_flow does) + PROC_STEP in one
+// launch: every block reduces the PROC_FLOW partial sums itself -- 1024 threads, one
+// partial row each, the same fixed order in every block, so all blocks hold the same
+// twist -- and goes on to stream its slices of the kept list.  One launch, one kernel
+// boundary and one single-block bubble less per iteration.  Block 0 also leaves the
+// twist, dl and the trace record in the state for k_post_step.  Single-rank align()
+// only: with ranks to sum over, k_post_flow and PROC_STEP stay separate launches.
+constexpr int STEP_BLOCK = 1024;
+constexpr int STEP_WAVES = STEP_BLOCK / 64;
+
+__global__ void __launch_bounds__(STEP_BLOCK) k_step_twist(const Grp<ProcessArgs> grp)
+{
+    const ProcessArgs &a = grp.a[blockIdx.z];
+    const int nfat = a.nblk / (STEP_BLOCK / BLOCK);   // blocks of this registration
+    if ((int)blockIdx.x >= nfat) return;
+    constexpr int NACC = NACC_STEP;
+    __shared__ double sh[STEP_WAVES * NACC_MAX];
+    __shared__ double tot[NACC_MAX + 4];
+    __shared__ cvo_math::XiConsts s_xi;
+    __shared__ int s_overflow;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned wave = blockIdx.x * (unsigned)STEP_WAVES + (unsigned)wid;   // = the PROC_FLOW wave
+    // first round trip: loop control, constants, this thread's PROC_FLOW partial row,
+    // the wave's first kept entries
+    const int done_word = a.check_done ? a.st->done : 0;
+    const KernConsts kc = a.st->kc;
+    const unsigned ovf = a.st->cnt[2 * LIST_XY + 1] | a.st->cnt[2 * LIST_XX + 1] |
+                         a.st->cnt[2 * LIST_YY + 1] | a.st->cnt[2 * LIST_KEPT + 1];
+    double pf[NACC_FLOW];
+#pragma unroll
+    for (int k = 0; k < NACC_FLOW; ++k)
+        pf[k] = (tid < a.nblk) ? a.flow_part[(size_t)k * a.nblk + tid] : 0.0;
+    const size_t base = (size_t)wave * a.kept_wcap;
+    unsigned n = a.kept_cnt[wave];
+    uint2 e = a.kept_ij[base + lane];
+    float w = a.kept_a[base + lane];
+    if (done_word != 0) return;
+
+    // ---- the twist (ref cvo.cpp:201-209) from the partial sums
+    wave_sums<NACC_FLOW>(pf, lane, sh + wid * NACC_MAX);
+    __syncthreads();
+    if (tid < NACC_FLOW) {
+        double t = 0.0;
+#pragma unroll
+        for (int q = 0; q < STEP_WAVES; ++q) t += sh[q * NACC_MAX + tid];
+        tot[tid] = t;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        float omega[3], v[3];
+        for (int q = 0; q < 3; ++q) { omega[q] = (float)tot[q]; v[q] = (float)tot[3 + q]; }
+        s_xi = cvo_math::make_xi_consts(omega, v);
+        s_overflow = ovf != 0u;
+    }
+    // acvo: block 0 also needs the Axx / Ayy sums for dl (ref adaptive_cvo.cpp:222-231,271)
+    if (blockIdx.x == 0 && a.acvo && wid < 2) {
+        const double *part = wid == 0 ? a.xx_part : a.yy_part;
+        double ps[NACC_SELF] = {0.0, 0.0};
+        for (int b = lane; b < a.nblk; b += 64) {
+            ps[0] += part[b];
+            ps[1] += part[(size_t)a.nblk + b];
+        }
+        wave_sums<NACC_SELF>(ps, lane, tot + NACC_FLOW + 2 * wid);   // tot[9..10] xx, tot[11..12] yy
+    }
+    __syncthreads();
+    const bool overflow = s_overflow != 0;
+    if (blockIdx.x == 0 && tid == 0) {
+        DevState *st = a.st;
+        // nothing of an overflowed iteration is usable; the host enlarges the list
+        // and resumes from the same (untouched) state
+        if (overflow) {
+            st->done = NEED_BIGGER_LIST;
+            if (a.done_mirror) *a.done_mirror = NEED_BIGGER_LIST;
+        } else {
+            for (int q = 0; q < NACC_FLOW; ++q) st->red[RED_FLOW + q] = tot[q];
+            for (int q = 0; q < 4; ++q) st->red[RED_XX + q] = a.acvo ? tot[NACC_FLOW + q] : 0.0;
+            for (int q = 0; q < 3; ++q) { st->omega[q] = s_xi.omega[q]; st->v[q] = s_xi.v[q]; }
+            st->xi = s_xi;
+            double dl = 0.0;
+            const long long nnz = (long long)tot[8];
+            long long nnz_xx = 0, nnz_yy = 0;
+            if (a.acvo) {
+                nnz_xx = (long long)tot[NACC_FLOW + 1];
+                nnz_yy = (long long)tot[NACC_FLOW + 3];
+                const double num = (tot[NACC_FLOW + 2] - 2.0 * tot[7]) + tot[NACC_FLOW];
+                dl = num / (double)(nnz_xx + nnz_yy - 2 * nnz);
+            }
+            st->dl = dl;
+            if (a.trace && st->k < a.trace_cap) {
+                cvo_hip_trace &tr = a.trace[st->k];
+                tr.k = st->k;
+                tr.exit_code = 0;
+                tr.ell = st->ell;
+                for (int q = 0; q < 3; ++q) {
+                    tr.omega[q] = s_xi.omega[q]; tr.v[q] = s_xi.v[q];
+                    tr.omega_d[q] = tot[q]; tr.v_d[q] = tot[3 + q];
+                }
+                tr.sum_a = tot[6];
+                tr.dl = dl;
+                tr.nnz = nnz; tr.nnz_xx = nnz_xx; tr.nnz_yy = nnz_yy;
+            }
+        }
+    }
+    if (overflow) return;
+    // the constants are the same for every lane: keep them in scalar registers
+    cvo_math::XiConsts xc;
+    {
+        auto uni = [](float x) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(x))); };
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            xc.omega[q] = uni(s_xi.omega[q]); xc.v[q] = uni(s_xi.v[q]);
+            xc.u2[q] = uni(s_xi.u2[q]); xc.u3[q] = uni(s_xi.u3[q]); xc.u4[q] = uni(s_xi.u4[q]);
+        }
+#pragma unroll
+        for (int q = 0; q < 9; ++q) {
+            xc.W2[q] = uni(s_xi.W2[q]); xc.W3[q] = uni(s_xi.W3[q]); xc.W4[q] = uni(s_xi.W4[q]);
+        }
+    }
+
+    // ---- compute_step_size sums over this wave's slice of the kept list
+    double acc[NACC];
+#pragma unroll
+    for (int k = 0; k < NACC; ++k) acc[k] = 0.0;
+    if (n > a.kept_wcap) n = a.kept_wcap;
+    for (unsigned off = lane; off < n; off += 64) {
+        if (off >= 64) { e = a.kept_ij[base + off]; w = a.kept_a[base + off]; }
+        eval_pair<PROC_STEP>(a, kc, e.x, e.y, w, acc, xc);
+    }
+    __syncthreads();   // sh is re-used
+    wave_sums<NACC>(acc, lane, sh + wid * NACC);
+    __syncthreads();
+    if (tid < NACC) {
+        double t = 0.0;
+#pragma unroll
+        for (int q = 0; q < STEP_WAVES; ++q) t += sh[q * NACC + tid];
+        a.partials[(size_t)tid * nfat + blockIdx.x] = t;
+    }
+}
+
+void launch_step_twist_group(const ProcessArgs *a, int n, hipStream_t s)
+{
+    Grp<ProcessArgs> g;
+    int nblk = NSUB;
+    for (int i = 0; i < n; ++i) { g.a[i] = a[i]; nblk = std::max(nblk, a[i].nblk); }
+    const dim3 grid((unsigned)(nblk / (STEP_BLOCK / BLOCK)), 1, (unsigned)n);
+    hipLaunchKernelGGL(k_step_twist, grid, dim3(STEP_BLOCK), 0, s, g);
 }
 
 void launch_process_group(int mode, const ProcessArgs *a, int n, hipStream_t s)
@@ -699,7 +849,7 @@ void launch_process(int mode, const ProcessArgs &a, hipStream_t s)
 }
 
 // ---------------------------------------------------------------------------
-// Fixed-order reduction of partials[nblocks][NACC] by one 256-thread block:
+// Fixed-order reduction of partials[NACC][nblocks] by one 256-thread block:
 // thread t adds blocks t, t+256, ...; xor butterfly inside each wave; the four
 // wave sums are added in wave order.
 template <int NACC, int NPART = PROC_BLOCKS>
@@ -717,7 +867,7 @@ __device__ void block_reduce_partials(const double *part, int nblocks, double *s
     for (int u = 0; u < NPART / BLOCK; ++u) {
         const int b = tid + u * BLOCK;
 #pragma unroll
-        for (int k = 0; k < NACC; ++k) s[k] += (b < nblocks) ? part[(size_t)b * NACC + k] : 0.0;
+        for (int k = 0; k < NACC; ++k) s[k] += (b < nblocks) ? part[(size_t)k * nblocks + b] : 0.0;
     }
     wave_sums<NACC>(s, lane, sh + wid * NACC_MAX);
     __syncthreads();
