@@ -567,25 +567,47 @@ int enqueue_flow(cvo_hip_ctx *ctx, bool tf_moving, int check_done, bool do_math,
     const int tfm = tf_moving ? 1 : 0;
     int rlo, rhi, slo, shi;
     shard_ranges(ctx, rlo, rhi, slo, shi);
+    // acvo on its own stream: the three filters share one launch and so do the two
+    // self passes (the argument blocks are recorded, then issued as groups)
+    const bool group_lists = acvo && !ctx->rec && !ctx->profiling;
+    std::vector<RecOp> local;
+    if (group_lists) ctx->rec = &local;
     int rc = enqueue_filter(ctx, LIST_XY, ctx->fixed, rlo, rhi, 0, ctx->moving, tfm, check_done);
-    if (rc) return rc;
-    rc = enqueue_process(ctx, PROC_FLOW, LIST_XY, ctx->part_flow, ctx->fixed.pos, ctx->fixed.feat,
-                         0, ctx->moving.pos, ctx->moving.feat, tfm, 0, check_done);
-    if (rc) return rc;
-    if (acvo) {
+    if (!rc)
+        rc = enqueue_process(ctx, PROC_FLOW, LIST_XY, ctx->part_flow, ctx->fixed.pos, ctx->fixed.feat,
+                             0, ctx->moving.pos, ctx->moving.feat, tfm, 0, check_done);
+    if (!rc && acvo) {
         // Axx rows of this shard vs all of x; Ayy rows of this shard vs all of y
         rc = enqueue_filter(ctx, LIST_XX, ctx->fixed, rlo, rhi, 0, ctx->fixed, 0, check_done);
-        if (rc) return rc;
-        rc = enqueue_process(ctx, PROC_SELF, LIST_XX, ctx->part_xx, ctx->fixed.pos, ctx->fixed.feat,
-                             0, ctx->fixed.pos, ctx->fixed.feat, 0, 0, check_done);
-        if (rc) return rc;
-        rc = enqueue_filter(ctx, LIST_YY, ctx->moving, slo, shi, tfm, ctx->moving, tfm, check_done);
-        if (rc) return rc;
-        rc = enqueue_process(ctx, PROC_SELF, LIST_YY, ctx->part_yy, ctx->moving.pos,
-                             ctx->moving.feat, tfm, ctx->moving.pos, ctx->moving.feat, tfm,
-                             ctx->fixed.n, check_done);
-        if (rc) return rc;
+        if (!rc)
+            rc = enqueue_process(ctx, PROC_SELF, LIST_XX, ctx->part_xx, ctx->fixed.pos,
+                                 ctx->fixed.feat, 0, ctx->fixed.pos, ctx->fixed.feat, 0, 0, check_done);
+        if (!rc)
+            rc = enqueue_filter(ctx, LIST_YY, ctx->moving, slo, shi, tfm, ctx->moving, tfm, check_done);
+        if (!rc)
+            rc = enqueue_process(ctx, PROC_SELF, LIST_YY, ctx->part_yy, ctx->moving.pos,
+                                 ctx->moving.feat, tfm, ctx->moving.pos, ctx->moving.feat, tfm,
+                                 ctx->fixed.n, check_done);
     }
+    if (group_lists) {
+        ctx->rec = nullptr;
+        if (!rc) {
+            FilterArgs f[3];
+            ProcessArgs flow{}, self[2];
+            int nf = 0, ns = 0;
+            bool have_flow = false;
+            for (const RecOp &op : local) {
+                if (op.kind == RecOp::FILTER && nf < 3) f[nf++] = op.f;
+                else if (op.kind == RecOp::PROCESS && op.mode == PROC_FLOW) { flow = op.p; have_flow = true; }
+                else if (op.kind == RecOp::PROCESS && op.mode == PROC_SELF && ns < 2) self[ns++] = op.p;
+            }
+            if (nf) launch_filter_group(f, nf, ctx->stream);
+            if (have_flow) launch_process_group(PROC_FLOW, &flow, 1, ctx->stream);
+            if (ns) launch_process_group(PROC_SELF, self, ns, ctx->stream);
+            HIP_TRY(ctx, hipGetLastError());
+        }
+    }
+    if (rc) return rc;
     if (ctx->merge_twist) return CVO_HIP_OK;   // k_step_twist does the rest of compute_flow
     PostFlowArgs pa{};
     pa.st = ctx->st;
