@@ -11,7 +11,7 @@ csrc/libcvo_hip.so), ``capi`` (ctypes binding of that ABI), ``registration``
 trajectory writer).  There is no CPU fallback: without the built library and a
 HIP device every compute call raises.
 """
-from . import capi, data, registration  # noqa: F401
+from . import capi, data, registration, trajectory  # noqa: F401
 from .registration import Acvo, Cvo  # noqa: F401
 
-__all__ = ["capi", "data", "registration", "Cvo", "Acvo"]
+__all__ = ["capi", "data", "registration", "trajectory", "Cvo", "Acvo"]

@@ -61,6 +61,23 @@ class _Registration:
             self.set_pcd(positions, features, layout)
             self.align(trace_cap=trace_cap)
 
+    def run_sequence(self, frames, writer=None, trace_cap=0):
+        """The loop of the reference's drivers (ref src/cvo_main.cpp:36-66): every
+        frame goes through run_cvo(); from the second frame on a pose line of
+        `accum_transform` is appended to `writer` (a trajectory.TrajectoryWriter).
+        `frames` yields (name, positions, features).  Returns the per-pair
+        iteration counts."""
+        iters = []
+        for name, positions, features in frames:
+            first = not self.init
+            self.run_cvo(positions, features, trace_cap=trace_cap)
+            if first:
+                continue
+            iters.append(self.num_iterations)
+            if writer is not None:
+                writer.append(name, self.accum_transform)
+        return iters
+
     def close(self):
         self.ctx.close()
 

@@ -295,3 +295,37 @@ def test_fused_batch_with_list_overflow(pkg, monkeypatch):
     assert [(i, bytes(s)) for i, s in zip(its, states)] == ref
     for c in ctxs:
         c.close()
+
+
+def test_sequence_to_trajectory_file(pkg, po, desk, tmp_path):
+    """SURVEY 8 f1 end to end: the five shipped fr1/desk clouds through
+    run_sequence() with the reference's pose-file writer, read back and scored
+    with the TUM relative pose error against the mocap ground truth that ships
+    with the reference (tests/golden/trajectory_inputs.npz)."""
+    tj = pkg.trajectory
+    stamps = [str(s) for s in desk["stamps"]]
+    clouds = [(stamps[k], desk["xyz%d" % k][::5], pkg.data.cvo_features(desk["rgb%d" % k][::5]))
+              for k in range(5)]
+    path = str(tmp_path / "cvo_poses_qt.txt")
+    reg = pkg.Cvo(device=0, stream=_stream())
+    with tj.TrajectoryWriter(path) as w:
+        iters = reg.run_sequence(clouds, writer=w)
+    assert len(iters) == 4 and w.lines == 4           # no line for the first frame (ref cvo_main.cpp:56)
+    est = tj.read_trajectory(path, matrices=True)
+    assert sorted(est) == [float(s) for s in stamps[1:]]
+    last = est[float(stamps[-1])]
+    assert np.allclose(last, reg.accum_transform, atol=5e-6)   # %g keeps 6 significant digits
+    # the same sequence through the oracle gives the same file
+    its_or, (_, _, A_or) = _oracle_align(po, po.MODE_CVO, [(x, f) for _, x, f in clouds])
+    assert iters == its_or
+    assert np.allclose(last, A_or, atol=5e-6)
+    # scored against mocap: frame-to-frame drift of a few mm / tenths of a degree
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "trajectory_inputs.npz"))
+    gt = {float(r[0]): tj.pose_matrix(r[1:4], r[4:8]) for r in z["gt"]}
+    est[float(stamps[0])] = np.eye(4)                  # the first frame is the origin
+    # accum_transform IS the camera pose in the first frame's coordinates (what the
+    # reference feeds the TUM tools): 2.6 mm / 6 mrad per frame on these four pairs
+    rows, st = tj.relative_pose_error(gt, est, delta=1, delta_unit="f")
+    assert len(rows) >= 3
+    assert st["translational"]["rmse"] < 0.005 and st["rotational"]["rmse"] < 0.01
+    reg.close()
