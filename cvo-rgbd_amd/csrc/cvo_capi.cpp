@@ -1391,6 +1391,17 @@ struct FusedRun {
     int b = 0;          // batches launched since the arguments were recorded
     int max_iter = 0;
     enum { RECORD, LAUNCH, WAIT, SETTLE, DONE } state = RECORD;
+    hipGraph_t graph = nullptr;        // kBatch fused iterations, captured once per membership
+    hipGraphExec_t gexec = nullptr;
+    bool use_graph = true;             // (measured: a gain with <= 2 groups in flight, a loss with 4)
+
+    void drop_graph()
+    {
+        if (gexec) (void)hipGraphExecDestroy(gexec);
+        if (graph) (void)hipGraphDestroy(graph);
+        gexec = nullptr;
+        graph = nullptr;
+    }
 
     void fail_all(const char *msg)
     {
@@ -1419,6 +1430,7 @@ struct FusedRun {
 
     ~FusedRun()
     {
+        drop_graph();
         if (ev[0]) (void)hipEventDestroy(ev[0]);
         if (ev[1]) (void)hipEventDestroy(ev[1]);
     }
@@ -1461,6 +1473,17 @@ struct FusedRun {
         for (AlignJob *j : live) max_iter = std::max(max_iter, j->ctx->prm.max_iter);
         b = 0;
         state = LAUNCH;
+        // one graph launch per batch instead of 5-9 kernel launches per iteration: with
+        // several groups in flight the launching thread is the next bottleneck
+        drop_graph();
+        static const bool no_graph = getenv("CVO_HIP_NO_GRAPH") != nullptr;
+        if (use_graph && !no_graph && hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed) == hipSuccess) {
+            for (int q = 0; q < kBatch; ++q) launch_fused(ops, s);
+            const hipError_t e = hipStreamEndCapture(s, &graph);
+            if (e != hipSuccess || !graph || hipGraphInstantiate(&gexec, graph, nullptr, nullptr, 0) != hipSuccess)
+                drop_graph();
+            (void)hipGetLastError();
+        }
     }
 
     // somebody stopped: drain the queue, hand the finished members back, let the
@@ -1520,7 +1543,11 @@ struct FusedRun {
             if (hipSetDevice(device) != hipSuccess) { fail_all("hipSetDevice failed"); return true; }
             if (state == RECORD) { record(); moved = true; continue; }
             if (state == LAUNCH) {
-                for (int q = 0; q < kBatch; ++q) launch_fused(ops, s);
+                if (gexec) {
+                    if (hipGraphLaunch(gexec, s) != hipSuccess) { fail_all("fused graph launch failed"); return true; }
+                } else {
+                    for (int q = 0; q < kBatch; ++q) launch_fused(ops, s);
+                }
                 if (hipGetLastError() != hipSuccess || hipEventRecord(ev[b & 1], s) != hipSuccess) {
                     fail_all("fused launch failed");
                     return true;
@@ -1613,6 +1640,7 @@ int cvo_hip_align_many(cvo_hip_ctx **ctxs, cvo_hip_state **states, int *n_iters,
                 runs.back()->start(grp, (int)runs.size() - 1);
             }
         }
+        for (auto &r : runs) r->use_graph = runs.size() <= 2;
         for (;;) {
             bool any_live = false, moved = false;
             for (auto &r : runs) {
