@@ -329,3 +329,41 @@ def test_sequence_to_trajectory_file(pkg, po, desk, tmp_path):
     assert len(rows) >= 3
     assert st["translational"]["rmse"] < 0.005 and st["rotational"]["rmse"] < 0.01
     reg.close()
+
+
+def test_align_many_mixed_bag(pkg):
+    """One call, members that cannot share launches: both modes, a profiling
+    context, a tiny cloud, a registration that stops at once (max_iter = 1) and
+    more members than one launch group holds -- all equal to one-by-one."""
+    import torch
+    capi = pkg.capi
+    specs = []
+    for i in range(20):
+        acvo = i % 3 == 1
+        n, m = (40, 33) if i == 5 else (700 + 37 * i, 650 + 29 * i)
+        specs.append((acvo, n, m))
+    ctxs, ref = [], []
+    keep = []
+    for i, (acvo, n, m) in enumerate(specs):
+        xf, ff, xm, fm = pkg.data.synthetic_pair(n, m, seed=90 + i, acvo=acvo)
+        s = torch.cuda.Stream()
+        keep.append(s)
+        prm = capi.default_params(capi.MODE_ACVO if acvo else capi.MODE_CVO)
+        if i == 7:
+            prm.max_iter = 1
+        c = capi.Context(mode=prm.mode, device=0, stream=s.cuda_stream, params=prm)
+        c.set_fixed(xf, ff)
+        c.set_moving(xm, fm)
+        if i == 9:
+            c.set_profiling(True)
+        st = capi.init_state(c.params)
+        n_it, _ = c.align(st, trace_cap=0)
+        ref.append((n_it, bytes(st)))
+        ctxs.append(c)
+    states = [capi.init_state(c.params) for c in ctxs]
+    its = capi.align_many(ctxs, states)
+    got = [(i, bytes(s)) for i, s in zip(its, states)]
+    assert got == ref
+    assert ref[7][0] == 1
+    for c in ctxs:
+        c.close()
