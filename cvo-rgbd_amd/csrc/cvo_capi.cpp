@@ -24,6 +24,7 @@
 #include <new>
 #include <string>
 #include <memory>
+#include <mutex>
 #include <vector>
 
 #include "cvo_comm.h"
@@ -534,8 +535,8 @@ int drain_events(cvo_hip_ctx *ctx, int n_exec = -1, const DevState *fin = nullpt
         } else {
             ctx->prof.self_ms += ms; ctx->prof.self_launches++; ctx->prof.self_pairs += ev.pairs;
         }
-        hipEventDestroy(ev.a);
-        hipEventDestroy(ev.b);
+        (void)hipEventDestroy(ev.a);
+        (void)hipEventDestroy(ev.b);
     }
     ctx->events.clear();
     return CVO_HIP_OK;
@@ -958,9 +959,9 @@ int cvo_hip_destroy(cvo_hip_ctx *ctx)
     if (!ctx) return CVO_HIP_OK;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-    for (auto &ev : ctx->events) { hipEventDestroy(ev.a); hipEventDestroy(ev.b); }
+    for (auto &ev : ctx->events) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
     for (int i = 0; i < kPollSlots; ++i)
-        if (ctx->poll_ev[i]) hipEventDestroy(ctx->poll_ev[i]);
+        if (ctx->poll_ev[i]) (void)hipEventDestroy(ctx->poll_ev[i]);
     if (ctx->comm) cvo_comm_destroy(ctx->comm);
     drop_graphs(ctx);
     if (ctx->post_dbg) {
@@ -1370,6 +1371,8 @@ hipStream_t group_stream(int device, int slot)
 {
     constexpr int kDev = 16, kSlots = 4;
     static hipStream_t pool[kDev][kSlots] = {};
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lock(mu);
     if (device < 0 || device >= kDev) return nullptr;
     slot = ((slot % kSlots) + kSlots) % kSlots;
     if (!pool[device][slot] &&

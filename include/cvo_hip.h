@@ -188,10 +188,14 @@ int cvo_hip_align(cvo_hip_ctx *ctx, cvo_hip_state *state, cvo_hip_trace *trace,
                   int trace_cap, int *n_iter);
 
 /* Batched mode (BASELINE configs[4], ref SURVEY 8e): `count` independent
- * registrations, one context (= one device stream) each, driven concurrently by
- * the calling thread.  Equivalent to calling cvo_hip_align(ctxs[i], states[i],
- * NULL, 0, &n_iters[i]) for every i, but with all of them in flight at once.
- * Returns the first non-zero status, 0 if all succeeded. */
+ * registrations, one context each, driven concurrently by the calling thread.
+ * Equivalent to calling cvo_hip_align(ctxs[i], states[i], NULL, 0, &n_iters[i])
+ * for every i -- bit for bit -- but with all of them in flight at once: contexts
+ * of the same device and mode share their kernel launches in groups of up to 16
+ * (one grid slice per registration) on streams owned by the library; contexts
+ * that profile or are sharded over ranks run on their own streams.  All the
+ * contexts' streams are idle when the call returns.  Returns the first
+ * non-zero status, 0 if all succeeded. */
 int cvo_hip_align_many(cvo_hip_ctx **ctxs, cvo_hip_state **states, int *n_iters, int count);
 
 /* acvo::function_inner_product (ref src/adaptive_cvo.cpp:385-439) between the
