@@ -93,6 +93,37 @@ def read_pcd_ascii(path):
     return xyz, rgb
 
 
+def pc_range_filter(xyz, rgb, max_range=4.0, min_range=0.8):
+    """ref util/pcRangeFilter.m:5-12: drop the points whose range (float32
+    norm) is above max_range or below min_range."""
+    xyz = np.asarray(xyz, np.float32)
+    r = np.sqrt((xyz * xyz).sum(1, dtype=np.float32))
+    keep = ~((r > np.float32(max_range)) | (r < np.float32(min_range)))
+    return xyz[keep], np.asarray(rgb)[keep]
+
+
+def grid_average(xyz, rgb, grid_size=0.05):
+    """Box-grid downsampling in the manner of MATLAB's
+    pcdownsample(cloud, 'gridAverage', grid_size) (ref data/rgbd_dataset/
+    rgbddataset_rkhs.m:36-39,58): one point per occupied voxel = the mean
+    location and the mean colour (rounded to uint8) of its points.  Voxels are
+    anchored at the cloud's minimum corner; MATLAB's own anchoring is not
+    documented ("f2"), so the output is equivalent, not identical.
+    Voxels come out in lexicographic (x, y, z) index order."""
+    x = np.asarray(xyz, np.float64)
+    c = np.asarray(rgb, np.float64)
+    idx = np.floor((x - x.min(0)) / float(grid_size)).astype(np.int64)
+    span = idx.max(0) + 1
+    key = (idx[:, 0] * span[1] + idx[:, 1]) * span[2] + idx[:, 2]
+    _, inv = np.unique(key, return_inverse=True)
+    inv = inv.ravel()
+    n = int(inv.max()) + 1
+    cnt = np.bincount(inv, minlength=n).astype(np.float64)
+    loc = np.stack([np.bincount(inv, weights=x[:, k], minlength=n) / cnt for k in range(3)], 1)
+    col = np.stack([np.bincount(inv, weights=c[:, k], minlength=n) / cnt for k in range(c.shape[1])], 1)
+    return loc.astype(np.float32), np.clip(np.floor(col + 0.5), 0, 255).astype(np.uint8)
+
+
 def cvo_features(rgb, dx=None, dy=None):
     """cvo feature type 1: raw B, G, R, dx, dy (ref src/pcd_generator.cpp:359-380)."""
     n = rgb.shape[0]
