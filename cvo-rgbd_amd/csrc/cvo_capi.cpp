@@ -36,8 +36,8 @@ using namespace cvo_dev;
 namespace {
 
 struct Cloud {
-    float4 *pos = nullptr;   // Morton-sorted; .w = index in the caller's cloud (int bits)
-    float *feat = nullptr;   // same order
+    float4 *pos = nullptr;   // Morton-sorted; .w = the 5th feature
+    float *feat = nullptr;   // same order: f0..f4, index in the caller's cloud (int bits), 2 pad
     float4 *seg = nullptr;   // bounding sphere (centre, radius) of every SEG consecutive points
     int n = 0;
     int cap = 0;
@@ -248,11 +248,15 @@ int upload_cloud(cvo_hip_ctx *ctx, Cloud &c, const float *xyz, const float *feat
         hp[4 * (size_t)s + 0] = xyz[3 * (size_t)i + 0];
         hp[4 * (size_t)s + 1] = xyz[3 * (size_t)i + 1];
         hp[4 * (size_t)s + 2] = xyz[3 * (size_t)i + 2];
-        std::memcpy(&hp[4 * (size_t)s + 3], &i, sizeof(int));   // caller's index
         for (int f = 0; f < CVO_HIP_NFEAT; ++f)
             hf[(size_t)s * FEAT_STRIDE + f] = (layout == CVO_HIP_FEAT_COLMAJOR)
                                                   ? feat[(size_t)f * n + i]
                                                   : feat[(size_t)i * CVO_HIP_NFEAT + f];
+        // the 5th feature rides in pos.w: a pair then costs four 16-byte gathers (two
+        // positions, two feature quads) -- the list kernels are bound by L1 request
+        // rate -- and the caller's index (acvo Ayy rule only) moves to feat[5]
+        hp[4 * (size_t)s + 3] = hf[(size_t)s * FEAT_STRIDE + 4];
+        std::memcpy(&hf[(size_t)s * FEAT_STRIDE + FEAT_INDEX_SLOT], &i, sizeof(int));
     }
     // bounding spheres of the Morton runs (culling in k_filter): centre of the
     // run's bounding box, radius = farthest point, inflated against rounding

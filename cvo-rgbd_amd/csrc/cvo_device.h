@@ -18,7 +18,8 @@ namespace cvo_dev {
 // both in Morton order.  Algorithmic bytes per point are 12 + 20 = 32 B
 // (SURVEY 8d); the padding is free: a sweep reads each cloud once and reuses it
 // ~N-fold on chip.
-constexpr int FEAT_STRIDE = 8;
+constexpr int FEAT_STRIDE = 8;       // floats per point in `feat`: f0..f4, caller index bits, 2 pad
+constexpr int FEAT_INDEX_SLOT = 5;   // (f4 is also kept in pos.w, which is what the kernels read)
 
 // Filter geometry: a block of 256 threads = 4 waves; every wave owns
 // TILES_PER_WAVE MFMA row tiles of 16 target rows, the block one chunk of `jt`

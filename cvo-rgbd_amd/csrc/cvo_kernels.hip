@@ -48,7 +48,7 @@ __device__ __forceinline__ float4 apply_tf(const float *Rt, const float *t, cons
     o.x = ((Rt[0] * p.x + Rt[1] * p.y) + Rt[2] * p.z) + t[0];
     o.y = ((Rt[3] * p.x + Rt[4] * p.y) + Rt[5] * p.z) + t[1];
     o.z = ((Rt[6] * p.x + Rt[7] * p.y) + Rt[8] * p.z) + t[2];
-    o.w = p.w;   // caller's index bits ride along
+    o.w = p.w;   // the point's 5th feature rides along
     return o;
 }
 
@@ -360,14 +360,58 @@ __device__ __forceinline__ float d2_feat(const float4 fa0, const float fa4, cons
     return r;
 }
 
+// ---------------------------------------------------------------------------
+// exp(x) for the kernel weights, x <= 0 (ref cvo.cpp:149-150 calls the double
+// overload of exp).  2^(k/64) table + degree-5 polynomial on |r| <= ln2/128, the
+// scheme of every libm: at most one ulp from glibc's exp (differs from it in the
+// last bit for 25 % of the arguments) and -- what the arithmetic contract needs --
+// the float32 value of sigma^2 exp(x) was the same for all of 2*10^8 random
+// arguments in [-6, 0].  14 float64 operations instead of ~30 in the device libm;
+// the two exp are the largest single item of the per-pair work.
+__device__ const double c_exp2_64[64] = {
+    0x1.0000000000000p+0, 0x1.02c9a3e778061p+0, 0x1.059b0d3158574p+0, 0x1.0874518759bc8p+0,
+    0x1.0b5586cf9890fp+0, 0x1.0e3ec32d3d1a2p+0, 0x1.11301d0125b51p+0, 0x1.1429aaea92de0p+0,
+    0x1.172b83c7d517bp+0, 0x1.1a35beb6fcb75p+0, 0x1.1d4873168b9aap+0, 0x1.2063b88628cd6p+0,
+    0x1.2387a6e756238p+0, 0x1.26b4565e27cddp+0, 0x1.29e9df51fdee1p+0, 0x1.2d285a6e4030bp+0,
+    0x1.306fe0a31b715p+0, 0x1.33c08b26416ffp+0, 0x1.371a7373aa9cbp+0, 0x1.3a7db34e59ff7p+0,
+    0x1.3dea64c123422p+0, 0x1.4160a21f72e2ap+0, 0x1.44e086061892dp+0, 0x1.486a2b5c13cd0p+0,
+    0x1.4bfdad5362a27p+0, 0x1.4f9b2769d2ca7p+0, 0x1.5342b569d4f82p+0, 0x1.56f4736b527dap+0,
+    0x1.5ab07dd485429p+0, 0x1.5e76f15ad2148p+0, 0x1.6247eb03a5585p+0, 0x1.6623882552225p+0,
+    0x1.6a09e667f3bcdp+0, 0x1.6dfb23c651a2fp+0, 0x1.71f75e8ec5f74p+0, 0x1.75feb564267c9p+0,
+    0x1.7a11473eb0187p+0, 0x1.7e2f336cf4e62p+0, 0x1.82589994cce13p+0, 0x1.868d99b4492edp+0,
+    0x1.8ace5422aa0dbp+0, 0x1.8f1ae99157736p+0, 0x1.93737b0cdc5e5p+0, 0x1.97d829fde4e50p+0,
+    0x1.9c49182a3f090p+0, 0x1.a0c667b5de565p+0, 0x1.a5503b23e255dp+0, 0x1.a9e6b5579fdbfp+0,
+    0x1.ae89f995ad3adp+0, 0x1.b33a2b84f15fbp+0, 0x1.b7f76f2fb5e47p+0, 0x1.bcc1e904bc1d2p+0,
+    0x1.c199bdd85529cp+0, 0x1.c67f12e57d14bp+0, 0x1.cb720dcef9069p+0, 0x1.d072d4a07897cp+0,
+    0x1.d5818dcfba487p+0, 0x1.da9e603db3285p+0, 0x1.dfc97337b9b5fp+0, 0x1.e502ee78b3ff6p+0,
+    0x1.ea4afa2a490dap+0, 0x1.efa1bee615a27p+0, 0x1.f50765b6e4540p+0, 0x1.fa7c1819e90d8p+0,
+};
+
+__device__ __forceinline__ double exp_neg(double x, const double *tab /* LDS copy of c_exp2_64 */)
+{
+    const double kd = __builtin_rint(x * 0x1.71547652b82fep+6);          // x * 64/ln2
+    const int k = (int)kd;
+    double r = __builtin_fma(-kd, 0x1.62e42fee00000p-7, x);              // ln2/64, high part (exact product)
+    r = __builtin_fma(-kd, 0x1.a39ef35793c76p-39, r);                    // low part
+    double p = 1.0 / 120.0;
+    p = __builtin_fma(p, r, 1.0 / 24.0);
+    p = __builtin_fma(p, r, 1.0 / 6.0);
+    p = __builtin_fma(p, r, 0.5);
+    p = __builtin_fma(p, r, 1.0);
+    p = p * r;
+    const double s = tab[k & 63];
+    return __builtin_ldexp(__builtin_fma(s, p, s), k >> 6);
+}
+
 // pair weight for a pair that passed d2 < tau; 0 if dropped (ref cvo.cpp:143-153)
 __device__ __forceinline__ float pair_weight(const KernConsts &kc, float d2, const float4 fa0,
-                                             const float fa4, const float4 fb0, const float fb4)
+                                             const float fa4, const float4 fb0, const float fb4,
+                                             const double *etab)
 {
     const float d2c = d2_feat(fa0, fa4, fb0, fb4);
     if (!(d2c < kc.tau_c)) return 0.0f;
-    const float k = (float)(kc.s2_d * exp((double)d2 * kc.ninv_2l2));
-    const float ck = (float)(kc.cs2_d * exp((double)d2c * kc.ninv_2cl2));
+    const float k = (float)(kc.s2_d * exp_neg((double)d2 * kc.ninv_2l2, etab));
+    const float ck = (float)(kc.cs2_d * exp_neg((double)d2c * kc.ninv_2cl2, etab));
     const float a = ck * k;
     return a > kc.sp ? a : 0.0f;
 }
@@ -477,7 +521,7 @@ template <> struct NAcc<PROC_SELF> { static constexpr int n = NACC_SELF; };
 template <int MODE>
 __device__ __forceinline__ float eval_pair(const ProcessArgs &a, const KernConsts &kc, unsigned i,
                                            unsigned j, float w, double *acc,
-                                           const cvo_math::XiConsts &xc)
+                                           const cvo_math::XiConsts &xc, const double *etab = nullptr)
 {
     const float *Rt = a.st->Rt;
     const float *tt = a.st->t;
@@ -488,18 +532,21 @@ __device__ __forceinline__ float eval_pair(const ProcessArgs &a, const KernConst
     // trip per pair instead of two); ~97 % of the filtered pairs need them
     float4 fa0 = make_float4(0.f, 0.f, 0.f, 0.f), fb0 = fa0;
     float fa4 = 0.f, fb4 = 0.f;
+    int row_index = 0;
     if (MODE != PROC_STEP) {
         fa0 = *reinterpret_cast<const float4 *>(a.feat_a + (size_t)i * FEAT_STRIDE);
-        fa4 = a.feat_a[(size_t)i * FEAT_STRIDE + 4];
         fb0 = *reinterpret_cast<const float4 *>(a.feat_b + (size_t)j * FEAT_STRIDE);
-        fb4 = a.feat_b[(size_t)j * FEAT_STRIDE + 4];
+        fa4 = xi.w;   // the 5th feature travels in pos.w
+        fb4 = yj.w;
+        if (MODE == PROC_SELF)   // the caller's index of the row (acvo Ayy rule)
+            row_index = __float_as_int(a.feat_a[(size_t)i * FEAT_STRIDE + FEAT_INDEX_SLOT]);
     }
     if (a.tf_b) yj = apply_tf(Rt, tt, yj);
     const float e0 = xi.x - yj.x, e1 = xi.y - yj.y, e2 = xi.z - yj.z;
     float d2 = 0.0f;
     if (MODE != PROC_STEP) {
         d2 = __builtin_fmaf(e2, e2, __builtin_fmaf(e1, e1, e0 * e0));
-        w = (d2 < kc.tau) ? pair_weight(kc, d2, fa0, fa4, fb0, fb4) : 0.0f;
+        w = (d2 < kc.tau) ? pair_weight(kc, d2, fa0, fa4, fb0, fb4, etab) : 0.0f;
     }
     if (!(w > 0.0f)) return 0.0f;
     if (MODE == PROC_FLOW) {
@@ -551,7 +598,7 @@ __device__ __forceinline__ float eval_pair(const ProcessArgs &a, const KernConst
         acc[3] += A * ((((double)(epsil + beta * delta) + 0.5 * b * b * g) + 0.5 * g * g) +
                        1 / 24.0 * b * b * b * b);
     } else {
-        if (__float_as_int(xi.w) >= a.first_counted) acc[0] += (double)((kc.inv_l3 * w) * d2);
+        if (row_index >= a.first_counted) acc[0] += (double)((kc.inv_l3 * w) * d2);
         acc[1] += 1.0;
     }
     return w;
@@ -565,6 +612,10 @@ __global__ void __launch_bounds__(BLOCK) k_process(const Grp<ProcessArgs> grp)
     constexpr int NACC = NAcc<MODE>::n;
     __shared__ double red[4 * NACC_MAX];
     __shared__ uint2 pairq_all[(MODE == PROC_STEP) ? 1 : 4 * PAIR_QUEUE];
+    // every wave keeps its own copy of the exp table (no block barrier needed)
+    __shared__ double s_etab_all[(MODE == PROC_STEP) ? 1 : 4 * 64];
+    if (MODE != PROC_STEP) s_etab_all[threadIdx.x] = c_exp2_64[threadIdx.x & 63];
+    const double *s_etab = s_etab_all + ((MODE == PROC_STEP) ? 0 : (threadIdx.x >> 6) * 64);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const unsigned wave = blockIdx.x * 4u + (unsigned)wid;   // 0 .. PROC_WAVES-1
@@ -615,7 +666,7 @@ __global__ void __launch_bounds__(BLOCK) k_process(const Grp<ProcessArgs> grp)
             uint2 pr = make_uint2(0u, 0u);
             if (lane < cnt) {
                 pr = pairq[base + lane];
-                w = eval_pair<MODE>(a, kc, pr.x, pr.y, 0.0f, acc, a.st->xi);   // (xi: PROC_STEP only)
+                w = eval_pair<MODE>(a, kc, pr.x, pr.y, 0.0f, acc, a.st->xi, s_etab);   // (xi: PROC_STEP only)
             }
             if (MODE == PROC_FLOW) {   // record the members of A in this wave's slice
                 const unsigned long long km = __ballot(w > 0.0f);
