@@ -236,6 +236,14 @@ k_filter(const Grp<FilterArgs> grp)
     TileEntry *stage = stage_all + wid * TILE_STAGE;
     int ne = 0;   // wave-uniform: staged tile entries
     // this wave's flushes walk round-robin over the sub-lists
+    // XCD-aware sub-list choice: the 256 sub-lists are consumed by the list kernels'
+    // blocks b = sub (mod 256), and workgroups go round-robin to the 8 XCDs, so
+    // sub-list s is read on XCD s % 8.  Rows are in Morton order: the 8 eighths of
+    // the row range are compact regions; a wave's entries go to the 32 sub-lists of
+    // ITS region (round-robin inside), so that each XCD's L2 serves one region of
+    // both clouds instead of all of them (matters from ~50k points on).
+    const unsigned region =
+        (unsigned)(((long long)(row0 + wid * ROWS_PER_WAVE - a.row_lo) * 8) / max(a.row_hi - a.row_lo, 1)) & 7u;
     unsigned sub = ((by * a.gx + bx) * 4u + (unsigned)wid) * 37u;
     const unsigned rbase = (unsigned)(row0 + wid * ROWS_PER_WAVE);
 
@@ -279,7 +287,7 @@ k_filter(const Grp<FilterArgs> grp)
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            flush_tiles(stage, ne, lane, (sub++) & (NSUB - 1), a);
+            flush_tiles(stage, ne, lane, (((sub++) & 31u) << 3) | region, a);
             __builtin_amdgcn_wave_barrier();
             ne = 0;
         }
@@ -289,7 +297,7 @@ k_filter(const Grp<FilterArgs> grp)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        flush_tiles(stage, ne, lane, sub & (NSUB - 1), a);
+        flush_tiles(stage, ne, lane, ((sub & 31u) << 3) | region, a);
     }
     if (a.dbg && lane == 0) {   // probe: start, prologue end, loop end, exit clocks of every wave
         long long *o = a.dbg + ((size_t)(by * a.gx + bx) * 4 + wid) * 8;
@@ -747,7 +755,11 @@ __global__ void __launch_bounds__(STEP_BLOCK) k_step_twist(const Grp<ProcessArgs
     __shared__ int s_overflow;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const unsigned wave = blockIdx.x * (unsigned)STEP_WAVES + (unsigned)wid;   // = the PROC_FLOW wave
+    // this wave streams the kept slice of one PROC_FLOW wave; the 16 of a block are
+    // taken from PROC_FLOW blocks that ran on the same XCD (block id mod 8), whose
+    // rows and columns belong to one region of the clouds (see k_filter)
+    const unsigned fb = (blockIdx.x & 7u) + 8u * ((blockIdx.x >> 3) * 4u + ((unsigned)wid >> 2));
+    const unsigned wave = fb * 4u + ((unsigned)wid & 3u);
     // first round trip: loop control, constants, this thread's PROC_FLOW partial row,
     // the wave's first kept entries
     const int done_word = a.check_done ? a.st->done : 0;
