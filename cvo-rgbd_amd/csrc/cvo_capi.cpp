@@ -1455,11 +1455,13 @@ struct FusedRun {
     {
         static const int budget = [] {   // blocks of a whole fused launch (tuning knob)
             const char *e = getenv("CVO_HIP_PROC_BUDGET");
-            const int v = e ? atoi(e) : 4096;
-            return v >= NSUB ? v : 4096;
+            const int v = e ? atoi(e) : 2048;
+            return v >= 64 ? v : 2048;
         }();
         const int G = (int)live.size();
-        const int nblk = std::min(PROC_BLOCKS, std::max(NSUB, (budget / G) / NSUB * NSUB));
+        // (a multiple of 32 that divides or is a multiple of NSUB: 64, 128, 256, 512, 1024)
+        int nblk = 64;
+        while (nblk < PROC_BLOCKS && nblk * 2 <= budget / G) nblk *= 2;
         ops.assign(live.size(), {});
         for (size_t i = 0; i < live.size(); ++i) {
             cvo_hip_ctx *c = live[i]->ctx;

@@ -649,18 +649,22 @@ __global__ void __launch_bounds__(BLOCK) k_process(const Grp<ProcessArgs> grp)
             eval_pair<MODE>(a, kc, e.x, e.y, w, acc, a.st->xi);
         }
     } else {
-        // nblk / NSUB blocks share one sub-list of the tile list
-        const unsigned sub = blockIdx.x & (NSUB - 1), part = blockIdx.x / NSUB;
+        // nblk >= NSUB: nblk / NSUB blocks share one sub-list of the tile list;
+        // nblk < NSUB (many registrations per launch): a block takes NSUB / nblk
+        // sub-lists, one after the other (sub-list s stays on XCD s % 8 either way)
+        const bool shared = a.nblk >= NSUB;
+        const unsigned nsl = shared ? 1u : (unsigned)(NSUB / a.nblk);
+        const unsigned part = shared ? blockIdx.x / NSUB : 0u;
+        unsigned sub = blockIdx.x & (NSUB - 1);
         unsigned n = a.st->sub[a.list][sub];
         const TileEntry *tl = a.tiles + (size_t)sub * a.subcap;
-        // The 4 * nblk / NSUB waves of this sub-list take its entries in turn, 64 at
-        // a time: lane l fetches the wave's l-th entry of the round (one memory
-        // round trip per 64 entries, the first one together with the count).
-        const unsigned stride = 4u * (unsigned)(a.nblk / NSUB);
+        // The waves of a sub-list take its entries in turn, 64 at a time: lane l
+        // fetches the wave's l-th entry of the round (one memory round trip per 64
+        // entries, the first one together with the count).
+        const unsigned stride = shared ? 4u * (unsigned)(a.nblk / NSUB) : 4u;
         const unsigned e0 = part * 4u + (unsigned)wid;
         TileEntry mine = tl[min(e0 + (unsigned)lane * stride, a.subcap - 1)];
         if (done_word != 0) return;
-        if (n > a.subcap) n = a.subcap;   // overflowed list: the iteration is redone anyway
         uint2 *pairq = pairq_all + wid * PAIR_QUEUE;
         int qn = 0;   // wave-uniform: queued pairs
         unsigned nk = 0;   // wave-uniform: members of A recorded so far
@@ -693,6 +697,18 @@ __global__ void __launch_bounds__(BLOCK) k_process(const Grp<ProcessArgs> grp)
             }
             __builtin_amdgcn_wave_barrier();
         };
+        for (unsigned sl = 0; sl < nsl; ++sl) {
+        // the next sub-list's size and first entries are requested before this one is worked on
+        unsigned n_next = 0;
+        TileEntry mine_next = mine;
+        const TileEntry *tl_next = tl;
+        if (sl + 1 < nsl) {
+            const unsigned sub_next = sub + (unsigned)a.nblk;
+            n_next = a.st->sub[a.list][sub_next];
+            tl_next = a.tiles + (size_t)sub_next * a.subcap;
+            mine_next = tl_next[min(e0 + (unsigned)lane * stride, a.subcap - 1)];
+        }
+        if (n > a.subcap) n = a.subcap;   // overflowed list: the iteration is redone anyway
         for (unsigned eb = e0; eb < n; eb += 64u * stride) {
             if (eb != e0) mine = tl[min(eb + (unsigned)lane * stride, a.subcap - 1)];
             const unsigned left = (n - eb + stride - 1) / stride;   // entries of this round
@@ -719,6 +735,8 @@ __global__ void __launch_bounds__(BLOCK) k_process(const Grp<ProcessArgs> grp)
                 }
             }
         }
+        sub += (unsigned)a.nblk; n = n_next; tl = tl_next; mine = mine_next;
+        }   // sub-lists of this block
         if (qn > 0) run_batch(0, qn);
         if (MODE == PROC_FLOW && lane == 0) a.kept_cnt[wave] = nk;
     }
@@ -880,7 +898,7 @@ __global__ void __launch_bounds__(STEP_BLOCK) k_step_twist(const Grp<ProcessArgs
 void launch_step_twist_group(const ProcessArgs *a, int n, hipStream_t s)
 {
     Grp<ProcessArgs> g;
-    int nblk = NSUB;
+    int nblk = 32;
     for (int i = 0; i < n; ++i) { g.a[i] = a[i]; nblk = std::max(nblk, a[i].nblk); }
     const dim3 grid((unsigned)(nblk / (STEP_BLOCK / BLOCK)), 1, (unsigned)n);
     hipLaunchKernelGGL(k_step_twist, grid, dim3(STEP_BLOCK), 0, s, g);
@@ -890,7 +908,7 @@ void launch_process_group(int mode, const ProcessArgs *a, int n, hipStream_t s)
 {
     Grp<ProcessArgs> g;
     for (int i = 0; i < n; ++i) g.a[i] = a[i];
-    int nblk = NSUB;
+    int nblk = 1;
     for (int i = 0; i < n; ++i) nblk = std::max(nblk, a[i].nblk);
     const dim3 grid((unsigned)nblk, 1, (unsigned)n);
     switch (mode) {
