@@ -5,6 +5,8 @@
 #include <cstring>
 #include <iostream>
 #include <stdexcept>
+#include <string>
+#include <vector>
 
 namespace cvo_hip {
 
@@ -102,6 +104,34 @@ void registration::align()
     check(cvo_hip_swap_moving_to_fixed(ctx_), "cvo_hip_swap_moving_to_fixed");
     have_moving_ = false;
     publish();
+}
+
+void registration::align_many(registration *const *objects, int count)
+{
+    std::vector<cvo_hip_ctx *> ctxs((size_t)count);
+    std::vector<cvo_hip_state *> states((size_t)count);
+    std::vector<int> iters((size_t)count, 0);
+    for (int i = 0; i < count; ++i) {
+        if (!objects[i] || !objects[i]->have_moving_)
+            throw std::runtime_error("align_many(): set_pcd() must precede align() for every object");
+        ctxs[(size_t)i] = objects[i]->ctx_;
+        states[(size_t)i] = &objects[i]->state_;
+    }
+    const int rc = cvo_hip_align_many(ctxs.data(), states.data(), iters.data(), count);
+    if (rc != CVO_HIP_OK) {
+        for (int i = 0; i < count; ++i) {
+            const char *d = cvo_hip_last_error(ctxs[(size_t)i]);
+            if (d && d[0]) throw std::runtime_error(std::string("cvo_hip_align_many: ") + d);
+        }
+        throw std::runtime_error(std::string("cvo_hip_align_many: ") + cvo_hip_error_string(rc));
+    }
+    for (int i = 0; i < count; ++i) {
+        registration *o = objects[i];
+        o->n_iter_ = iters[(size_t)i];
+        o->check(cvo_hip_swap_moving_to_fixed(o->ctx_), "cvo_hip_swap_moving_to_fixed");
+        o->have_moving_ = false;
+        o->publish();
+    }
 }
 
 void registration::run_cvo(const point_cloud_view &pc)

@@ -64,6 +64,10 @@ class registration {
     void set_pcd(const point_cloud_view &pc);
     void align();
     void run_cvo(const point_cloud_view &pc);
+    // Batched mode: align() of `count` objects (each with its moving cloud set) in
+    // one call, their kernel launches shared (cvo_hip_align_many).  The result of
+    // every object is what its own align() would have given.
+    static void align_many(registration *const *objects, int count);
 
     int num_iterations() const { return n_iter_; }   // loop bodies executed by the last align()
     cvo_hip_ctx *context() { return ctx_; }

@@ -367,3 +367,60 @@ def test_align_many_mixed_bag(pkg):
     assert ref[7][0] == 1
     for c in ctxs:
         c.close()
+
+
+@pytest.mark.parametrize("mode_name", ["cvo", "acvo"])
+def test_cpp_objects_match_python_objects(pkg, tmp_path, mode_name):
+    """include/cvo.hpp (cvo::cvo / acvo::acvo with the reference's members and
+    methods) compiled with g++ against libcvo_hip.so and driven like the
+    reference's main(): same iteration counts and transforms as the Python mirror,
+    both frame after frame and through registration::align_many."""
+    import subprocess
+    import struct
+    acvo = mode_name == "acvo"
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "cvo_class_demo")
+    lib = os.path.join(root, "cvo-rgbd_amd", "csrc")
+    subprocess.run(["g++", "-std=c++17", "-O1", "-I", os.path.join(root, "include"),
+                    os.path.join(root, "tests", "cpp", "cvo_class_demo.cpp"), "-L", lib, "-lcvo_hip",
+                    "-Wl,-rpath," + lib, "-o", exe], check=True)
+    frames = []
+    for k in range(3):
+        xf, ff, xm, fm = pkg.data.synthetic_pair(1500 + 100 * k, 1400, seed=200 + k, acvo=acvo)
+        frames.append((xf if k % 2 == 0 else xm[:1400 + 50 * k], ff if k % 2 == 0 else fm[:1400 + 50 * k]))
+    path = str(tmp_path / "frames.bin")
+    with open(path, "wb") as fh:
+        fh.write(struct.pack("<i", len(frames)))
+        for x, f in frames:
+            fh.write(struct.pack("<i", len(x)))
+            fh.write(np.ascontiguousarray(x, np.float32).tobytes())
+            fh.write(np.ascontiguousarray(f, np.float32).tobytes())
+    out = subprocess.run([exe, path, mode_name], check=True, capture_output=True, text=True).stdout
+    lines = out.strip().split("\n")
+    Reg = pkg.Acvo if acvo else pkg.Cvo
+    reg = Reg(device=0, stream=_stream())
+    want_seq, want_pairs = [], []
+    for x, f in frames:
+        first = not reg.init
+        reg.run_cvo(x, f)
+        if not first:
+            want_seq.append((reg.iter, reg.num_iterations, reg.transform.copy(), reg.accum_transform.copy()))
+    reg.close()
+    for k in range(1, len(frames)):
+        r2 = Reg(device=0, stream=_stream())
+        r2.run_cvo(*frames[k - 1])
+        r2.run_cvo(*frames[k])
+        want_pairs.append((r2.num_iterations, r2.transform.copy()))
+        r2.close()
+    it = iter(lines)
+    for w_iter, w_n, w_T, w_A in want_seq:
+        tag = next(it).split()
+        assert tag[0] == "iter" and int(tag[1]) == w_iter and int(tag[3]) == w_n
+        T = np.array(next(it).split()[1:], np.float32).reshape(4, 4)
+        A = np.array(next(it).split()[1:], np.float32).reshape(4, 4)
+        assert np.array_equal(T, w_T.astype(np.float32)) and np.array_equal(A, w_A.astype(np.float32))
+    for w_n, w_T in want_pairs:
+        tag = next(it).split()
+        assert tag[0] == "many" and int(tag[2]) == w_n
+        T = np.array(next(it).split()[1:], np.float32).reshape(4, 4)
+        assert np.array_equal(T, w_T.astype(np.float32))
