@@ -7,6 +7,8 @@ twist and step are expected to be IDENTICAL, and align() must take the same
 number of iterations and land on the same transform (north_star: <= 1e-4
 relative rotation / translation error; asserted here at 1e-6).
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -158,3 +160,17 @@ def test_empty_gram_matrix_breaks_at_once(pkg):
     assert reg.trace[0]["nnz"] == 0 and reg.trace[0]["step"] == np.float32(0.2)
     assert np.array_equal(reg.transform, np.eye(4, dtype=np.float32))
     reg.close()
+
+
+def test_random_soak_bit_parity(pkg):
+    """tools/gpu_soak.py in small: random sizes / seeds / motions / modes, every
+    registration equal to the oracle's bit for bit, alone and through
+    align_many.  (The full soak -- 1500 cases up to 6000 points -- had no
+    mismatch either: DESIGN.md section 2.)"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "gpu_soak.py"), "40", "2000"],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "40 cases, 0 mismatches vs oracle, 0 align_many differences" in r.stdout
