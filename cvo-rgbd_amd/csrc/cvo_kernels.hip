@@ -107,8 +107,15 @@ k_filter(const Grp<FilterArgs> grp)
     // launch, so that a launch that has nothing to do (list re-used, loop finished)
     // costs a few hundred blocks, not thousands.
     const FilterArgs &a = grp.a[blockIdx.z];
-    const int nitems = a.gx * a.gy;
-    if ((int)blockIdx.x >= nitems) return;
+    // XCD-aware dealing: block b runs on XCD b % 8 (workgroups go round-robin to the
+    // XCDs) and takes items of the row tiles of region b % 8 only (the 8 eighths of
+    // the row-tile range; rows are in Morton order), the same regions whose tile
+    // entries that XCD's list-kernel blocks consume: every XCD's L2 holds one region
+    // of the clouds for the whole iteration instead of all of them.
+    const int reg = (int)(blockIdx.x & 7u), slot = (int)(blockIdx.x >> 3), nslot = (int)(gridDim.x >> 3);
+    const int by_lo = (reg * a.gy + 7) / 8, by_hi = ((reg + 1) * a.gy + 7) / 8;   // tiles of this region
+    const int nitems = (by_hi - by_lo) * a.gx;
+    if (slot >= nitems) return;
     const long long t_start = a.dbg ? (long long)__builtin_readcyclecounter() : 0;
     const long long w_start = a.dbg ? (long long)wall_clock64() : 0;
     // first round trip: the loop-control word, the state constants and this
@@ -137,7 +144,7 @@ k_filter(const Grp<FilterArgs> grp)
     // spheres are more than sqrt(tauf) apart cannot hold a pair with d2 < tau.
     // One thread per (item, wave, segment) test, all loads in flight together: the
     // items that hold nothing cost no round trip of their own.
-    const int k_all = (nitems - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int k_all = (nitems - slot + nslot - 1) / nslot;
     const int ncf = a.jt / SEG;   // column segments of a full item
     const float reach = sqrtf(tauf);
     for (int k0 = 0; k0 < k_all; k0 += FILTER_KMAX) {
@@ -147,8 +154,8 @@ k_filter(const Grp<FilterArgs> grp)
     for (int t = tid; t < kn * 4 * ncf; t += BLOCK) {
         const int k = t / (4 * ncf), rem = t - k * 4 * ncf;
         const int w = rem / ncf, u = rem - w * ncf;
-        const int item = (int)blockIdx.x + (k0 + k) * (int)gridDim.x;
-        const int bx = item % a.gx, by = item / a.gx;
+        const int item = slot + (k0 + k) * nslot;
+        const int bx = item % a.gx, by = by_lo + item / a.gx;
         const int row0 = a.row_lo + by * ROWS_PER_TILE;
         const int j0 = bx * a.jt;
         const int ncseg = (min(a.jt, a.nb - j0) + SEG - 1) / SEG;
@@ -176,8 +183,8 @@ k_filter(const Grp<FilterArgs> grp)
     for (int k = 0; k < kn; ++k) {
     if ((nearmask[k * 4] | nearmask[k * 4 + 1] | nearmask[k * 4 + 2] | nearmask[k * 4 + 3]) == 0u)
         continue;   // nothing near in this item
-    const int item = (int)blockIdx.x + (k0 + k) * (int)gridDim.x;
-    const int bx = item % a.gx, by = item / a.gx;
+    const int item = slot + (k0 + k) * nslot;
+    const int bx = item % a.gx, by = by_lo + item / a.gx;
     const int row0 = a.row_lo + by * ROWS_PER_TILE;
     const int j0 = bx * a.jt;
     const int jn = min(a.jt, a.nb - j0);
@@ -323,13 +330,22 @@ static long long filter_blocks_max()
     return v;
 }
 
+// grid.x of one registration: a multiple of 8 (one eighth of the blocks per XCD /
+// row region), enough for the largest region's items up to the cap
+static unsigned filter_grid_x(long long nitems, long long cap)
+{
+    const long long per_region = (nitems + 7) / 8 + 1;   // regions differ by at most one row tile
+    const long long want = std::min<long long>(per_region * 8, std::max<long long>(cap, 8));
+    return (unsigned)((want + 7) / 8 * 8);
+}
+
 void launch_filter(const FilterArgs &a, dim3 grid, hipStream_t s, hipEvent_t ev_start,
                    hipEvent_t ev_stop)
 {
     Grp<FilterArgs> g;
     g.a[0] = a;
     g.a[0].gx = (int)grid.x; g.a[0].gy = (int)grid.y;
-    grid = dim3((unsigned)std::min<long long>((long long)grid.x * grid.y, filter_blocks_max()), 1, 1);
+    grid = dim3(filter_grid_x((long long)grid.x * grid.y, filter_blocks_max()), 1, 1);
     if (ev_start && ev_stop)   // the events take the dispatch packet's own begin / end timestamps
         hipExtLaunchKernelGGL(k_filter, grid, dim3(BLOCK), filter_smem_bytes(a.jt), s, ev_start,
                               ev_stop, 0, g);
@@ -346,7 +362,7 @@ void launch_filter_group(const FilterArgs *a, int n, hipStream_t s)
     const long long cap = std::max<long long>(64, filter_blocks_max() / (2 * n));
     for (int i = 0; i < n; ++i) {
         g.a[i] = a[i];
-        grid.x = std::max(grid.x, (unsigned)std::min<long long>((long long)a[i].gx * a[i].gy, cap));
+        grid.x = std::max(grid.x, filter_grid_x((long long)a[i].gx * a[i].gy, cap));
         jt = std::max(jt, a[i].jt);
     }
     hipLaunchKernelGGL(k_filter, grid, dim3(BLOCK), filter_smem_bytes(jt), s, g);
