@@ -105,6 +105,10 @@ struct cvo_hip_ctx {
     int32_t *done_mirror = nullptr;  // pinned (in the last slot): the post kernels copy `done` here
     std::vector<RecOp> *rec = nullptr;   // not null: record launches instead of issuing them
     int proc_blocks = PROC_BLOCKS;       // blocks of the list kernels (fewer in fused launches)
+    void *upload_stage = nullptr;        // pinned staging of upload_cloud (pos | feat | seg)
+    size_t upload_stage_bytes = 0;
+    std::vector<uint32_t> sort_keys[2];  // radix-sort scratch of upload_cloud
+    std::vector<int> sort_idx[2];
     bool merge_twist = false;            // inside align(): k_step_twist replaces k_post_flow + PROC_STEP
     bool allow_merge = true;
     cvo_hip_trace *cur_trace = nullptr;  // trace buffer of the iterations being enqueued
@@ -214,7 +218,11 @@ int upload_cloud(cvo_hip_ctx *ctx, Cloud &c, const float *xyz, const float *feat
             if (v < c.lo[a]) c.lo[a] = v;
             if (v > c.hi[a]) c.hi[a] = v;
         }
-    std::vector<std::pair<uint32_t, int>> order((size_t)n);
+    // keys, then a stable LSD radix sort (3 passes of 10 bits): the same permutation
+    // as sorting (key, index) pairs, in a fraction of the time
+    std::vector<uint32_t> *keys = ctx->sort_keys;
+    std::vector<int> *idx = ctx->sort_idx;
+    for (int q = 0; q < 2; ++q) { keys[q].resize((size_t)n); idx[q].resize((size_t)n); }
     {
         float inv[3];
         for (int a = 0; a < 3; ++a) {
@@ -237,31 +245,61 @@ int upload_cloud(cvo_hip_ctx *ctx, Cloud &c, const float *xyz, const float *feat
                 if (f > 1023.0f) f = 1023.0f;
                 q[a] = (uint32_t)f;
             }
-            order[(size_t)i] = {spread(q[0]) | (spread(q[1]) << 1) | (spread(q[2]) << 2), i};
+            keys[0][(size_t)i] = spread(q[0]) | (spread(q[1]) << 1) | (spread(q[2]) << 2);
+            idx[0][(size_t)i] = i;
         }
-        std::sort(order.begin(), order.end());
+        int src = 0;
+        for (int pass = 0; pass < 3; ++pass) {
+            uint32_t hist[1025] = {0};
+            const int sh = 10 * pass;
+            for (int i = 0; i < n; ++i) hist[((keys[src][(size_t)i] >> sh) & 1023u) + 1]++;
+            for (int q = 0; q < 1024; ++q) hist[q + 1] += hist[q];
+            for (int i = 0; i < n; ++i) {
+                const uint32_t k = keys[src][(size_t)i];
+                const uint32_t d = hist[(k >> sh) & 1023u]++;
+                keys[src ^ 1][d] = k;
+                idx[src ^ 1][d] = idx[src][(size_t)i];
+            }
+            src ^= 1;
+        }
+        if (src != 0) idx[0].swap(idx[1]);
     }
-    // pack on the host into the device layout, one copy each
-    std::vector<float> hp((size_t)n * 4), hf((size_t)n * FEAT_STRIDE, 0.0f);
+    const std::vector<int> &order = idx[0];
+    // pack on the host into the device layout (pinned staging, kept by the context)
+    const int nseg_ = (n + SEG - 1) / SEG;
+    const size_t bytes_pos = (size_t)n * 4 * sizeof(float), bytes_feat = (size_t)n * FEAT_STRIDE * sizeof(float),
+                 bytes_seg = (size_t)nseg_ * 4 * sizeof(float);
+    if (bytes_pos + bytes_feat + bytes_seg > ctx->upload_stage_bytes) {
+        if (ctx->upload_stage) (void)hipHostFree(ctx->upload_stage);
+        ctx->upload_stage = nullptr;
+        ctx->upload_stage_bytes = 0;
+        const size_t want = (bytes_pos + bytes_feat + bytes_seg) * 5 / 4 + 4096;
+        if (hipHostMalloc(&ctx->upload_stage, want, hipHostMallocDefault) != hipSuccess)
+            return fail(ctx, CVO_HIP_ERR_NOMEM, "hipHostMalloc(upload staging) failed");
+        ctx->upload_stage_bytes = want;
+    }
+    float *hp = reinterpret_cast<float *>(ctx->upload_stage);
+    float *hf = hp + (size_t)n * 4;
+    float *hs = hf + (size_t)n * FEAT_STRIDE;
     for (int s = 0; s < n; ++s) {
-        const int i = order[(size_t)s].second;
+        const int i = order[(size_t)s];
         hp[4 * (size_t)s + 0] = xyz[3 * (size_t)i + 0];
         hp[4 * (size_t)s + 1] = xyz[3 * (size_t)i + 1];
         hp[4 * (size_t)s + 2] = xyz[3 * (size_t)i + 2];
+        float *f8 = hf + (size_t)s * FEAT_STRIDE;
         for (int f = 0; f < CVO_HIP_NFEAT; ++f)
-            hf[(size_t)s * FEAT_STRIDE + f] = (layout == CVO_HIP_FEAT_COLMAJOR)
-                                                  ? feat[(size_t)f * n + i]
-                                                  : feat[(size_t)i * CVO_HIP_NFEAT + f];
+            f8[f] = (layout == CVO_HIP_FEAT_COLMAJOR) ? feat[(size_t)f * n + i]
+                                                      : feat[(size_t)i * CVO_HIP_NFEAT + f];
         // the 5th feature rides in pos.w: a pair then costs four 16-byte gathers (two
         // positions, two feature quads) -- the list kernels are bound by L1 request
         // rate -- and the caller's index (acvo Ayy rule only) moves to feat[5]
-        hp[4 * (size_t)s + 3] = hf[(size_t)s * FEAT_STRIDE + 4];
-        std::memcpy(&hf[(size_t)s * FEAT_STRIDE + FEAT_INDEX_SLOT], &i, sizeof(int));
+        hp[4 * (size_t)s + 3] = f8[4];
+        std::memcpy(&f8[FEAT_INDEX_SLOT], &i, sizeof(int));
+        f8[6] = f8[7] = 0.0f;
     }
     // bounding spheres of the Morton runs (culling in k_filter): centre of the
     // run's bounding box, radius = farthest point, inflated against rounding
-    const int nseg = (n + SEG - 1) / SEG;
-    std::vector<float> hs((size_t)nseg * 4);
+    const int nseg = nseg_;
     for (int g = 0; g < nseg; ++g) {
         const int s0 = g * SEG, s1 = std::min(n, s0 + SEG);
         float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
@@ -283,13 +321,10 @@ int upload_cloud(cvo_hip_ctx *ctx, Cloud &c, const float *xyz, const float *feat
         }
         hs[4 * (size_t)g + 3] = (float)(std::sqrt(r2) * 1.00001 + 1e-6);
     }
-    HIP_TRY(ctx, hipMemcpyAsync(c.seg, hs.data(), hs.size() * sizeof(float), hipMemcpyHostToDevice,
-                                ctx->stream));
-    HIP_TRY(ctx, hipMemcpyAsync(c.pos, hp.data(), hp.size() * sizeof(float), hipMemcpyHostToDevice,
-                                ctx->stream));
-    HIP_TRY(ctx, hipMemcpyAsync(c.feat, hf.data(), hf.size() * sizeof(float),
-                                hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));   // host staging buffers die here
+    HIP_TRY(ctx, hipMemcpyAsync(c.seg, hs, bytes_seg, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(c.pos, hp, bytes_pos, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(c.feat, hf, bytes_feat, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));   // the staging buffer is re-used by the next upload
     return CVO_HIP_OK;
 }
 
@@ -983,6 +1018,7 @@ int cvo_hip_destroy(cvo_hip_ctx *ctx)
                     ctx->lists[3].b.p, ctx->kept_cnt.p})
         if (p) (void)hipFree(p);
     if (ctx->st_host) (void)hipHostFree(ctx->st_host);
+    if (ctx->upload_stage) (void)hipHostFree(ctx->upload_stage);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return CVO_HIP_OK;
