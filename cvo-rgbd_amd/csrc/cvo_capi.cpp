@@ -1315,10 +1315,16 @@ int job_pump(AlignJob &j, bool block)
             if (rc) return finish_with(rc);
             j.enq += kBatch;
             const int slot = j.batches % kPollSlots;
-            if (hipMemcpyAsync(&ctx->st_host[slot], ctx->st, DEVSTATE_HEAD_BYTES, hipMemcpyDeviceToHost,
-                               ctx->stream) != hipSuccess ||
-                hipEventRecord(ctx->poll_ev[slot], ctx->stream) != hipSuccess)
+            // Single rank: the post kernels mirror `done` into pinned memory, an event
+            // per batch is all the polling needs.  With ranks to stay in step with, the
+            // state is copied in stream order instead: every rank must see `done` at the
+            // same batch, or their all-reduce counts would differ.
+            if (multi_rank(ctx) &&
+                hipMemcpyAsync(&ctx->st_host[slot], ctx->st, DEVSTATE_HEAD_BYTES, hipMemcpyDeviceToHost,
+                               ctx->stream) != hipSuccess)
                 return finish_with(fail(ctx, CVO_HIP_ERR_HIP, "poll copy failed"));
+            if (hipEventRecord(ctx->poll_ev[slot], ctx->stream) != hipSuccess)
+                return finish_with(fail(ctx, CVO_HIP_ERR_HIP, "poll event failed"));
             ++j.batches;
         }
         // look at the oldest batch not yet examined
@@ -1327,7 +1333,9 @@ int job_pump(AlignJob &j, bool block)
         if (q == hipErrorNotReady) return 0;
         if (q != hipSuccess) return finish_with(fail(ctx, CVO_HIP_ERR_HIP, "poll event failed"));
         ++j.checked;
-        if (ctx->st_host[slot].done != RUNNING) stop = true;
+        if (multi_rank(ctx) ? ctx->st_host[slot].done != RUNNING
+                            : *(volatile int32_t *)ctx->done_mirror != RUNNING)
+            stop = true;
         if (j.enq >= ctx->prm.max_iter + 2 * kBatch) stop = true;   // cannot happen: done is set by then
         if (!stop) return 0;
         // everything still queued either runs or returns at once; fetch the full state
@@ -1361,6 +1369,7 @@ int job_pump(AlignJob &j, bool block)
                        hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
         hipStreamSynchronize(ctx->stream) != hipSuccess)
         return finish_with(fail(ctx, CVO_HIP_ERR_HIP, "resume failed"));
+    *ctx->done_mirror = 0;   // (the stream is idle: nothing can be writing it)
     launch_prepare(ctx->st, ctx->dprm, ctx->stream);   // idempotent; re-zeroes the counters
     if (hipGetLastError() != hipSuccess) return finish_with(fail(ctx, CVO_HIP_ERR_HIP, "resume failed"));
     j.enq = j.batches = j.checked = 0;
