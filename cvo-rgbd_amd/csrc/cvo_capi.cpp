@@ -1128,6 +1128,7 @@ int cvo_hip_flow(cvo_hip_ctx *ctx, float ell, double out13[13])
     if (!ctx->have_tf) return fail(ctx, CVO_HIP_ERR_INVALID, "transform_pcd not called");
     DevState *h = &ctx->st_host[kPollSlots];
     h->kc = make_kconsts(ctx->dprm, ell);
+    h->kc_ell = -1.0f;   // (never equal to an ell: prepare_iteration recomputes)
     fill_filter_geometry(ctx, h);
     compute_filter_bounds(h, false);
     int rc = push_state_fields(ctx, offsetof(DevState, kc),
@@ -1152,6 +1153,7 @@ int cvo_hip_step_coeffs(cvo_hip_ctx *ctx, const float omega[3], const float v[3]
     if (!ctx->have_tf) return fail(ctx, CVO_HIP_ERR_INVALID, "transform_pcd not called");
     DevState *h = &ctx->st_host[kPollSlots];
     h->kc = make_kconsts(ctx->dprm, ell);
+    h->kc_ell = -1.0f;   // (never equal to an ell: prepare_iteration recomputes)
     fill_filter_geometry(ctx, h);
     compute_filter_bounds(h, false);
     h->xi = cvo_math::make_xi_consts(omega, v);
@@ -1748,6 +1750,7 @@ int cvo_hip_function_inner_product(cvo_hip_ctx *ctx, float ell, float *out)
     }
     DevState *h = &ctx->st_host[kPollSlots];
     h->kc = make_kconsts(dp, ell);
+    h->kc_ell = -1.0f;   // (never equal to an ell: prepare_iteration recomputes)
     fill_filter_geometry(ctx, h);
     compute_filter_bounds(h, true);
     h->done = 0;

@@ -113,6 +113,7 @@ struct DevState {
     float Rt[9], t[3];          // inverse transform of the current iteration
     float used_Rt[9], used_t[3]; // the one the last EXECUTED iteration used
     KernConsts kc;              // kernel constants of the current iteration
+    float kc_ell, kc_pad_;      // the ell they were made for (they depend on nothing else)
     // MFMA pre-filter (DESIGN.md "Conservative filter"): coordinates are taken
     // relative to `center`; a pair can only pass the exact test if its filter
     // value is below tauf[sel] = tau + rounding margin (sel = LIST_XY/XX/YY)
@@ -337,7 +338,10 @@ CVO_HD void plan_lists(DevState *s, const DevParams &p)
 CVO_HD void prepare_iteration(DevState *s, const DevParams &p)
 {
     cvo_math::inverse_tf(s->R, s->T, s->Rt, s->t);
-    s->kc = make_kconsts(p, s->ell);
+    if (!(s->kc_ell == s->ell)) {   // three float64 divisions and a log-scaled threshold: only when ell moved
+        s->kc = make_kconsts(p, s->ell);
+        s->kc_ell = s->ell;
+    }
     compute_filter_bounds(s, false);
     plan_lists(s, p);
     for (int q = 0; q < 2 * LIST_N; ++q) s->cnt[q] = 0u;
