@@ -79,6 +79,7 @@ struct GraphEntry {
 };
 constexpr int kPollSlots = 4;
 constexpr int kProcStepTwist = 100;   // RecOp::mode of a k_step_twist launch
+constexpr int kFlowBuild = 101;       // RecOp::mode of a k_flow_build launch (RecOp::f = the build's arguments)
 
 // One kernel launch of an iteration, recorded instead of launched (fused mode:
 // the launches of several registrations are merged slot by slot).
@@ -109,6 +110,15 @@ struct cvo_hip_ctx {
     size_t upload_stage_bytes = 0;
     std::vector<uint32_t> sort_keys[2];  // radix-sort scratch of upload_cloud
     std::vector<int> sort_idx[2];
+    // asynchronous xy builds (cvo_device.h plan_xy_async): the k_filter blocks of the xy
+    // list ride in the launch of the flow pass of the same slot (k_flow_build) and fill
+    // the idle one of two buffers
+    FilterArgs xy_build{};               // argument block of those filter blocks (this slot)
+    bool have_xy_build = false;
+    bool allow_async = true;
+    bool crowded = false;                // set by align_many: many registrations share the launches
+    bool use_async = false;              // decided per align(): single rank, not profiling
+    bool in_loop = false;                // enqueueing iterations of align()
     bool merge_twist = false;            // inside align(): k_step_twist replaces k_post_flow + PROC_STEP
     bool allow_merge = true;
     cvo_hip_trace *cur_trace = nullptr;  // trace buffer of the iterations being enqueued
@@ -180,6 +190,11 @@ DevParams make_dev_params(const cvo_hip_params &p)
     d.cs2_d = (double)cs2;
     d.dl_step = p.dl_step;
     // tile-list re-use (cvo_device.h plan_lists); CVO_HIP_LIST_MARGIN=0 rebuilds every iteration
+    d.build_at = 0.5f;
+    if (const char *e = getenv("CVO_HIP_BUILD_AT")) {
+        const double m = atof(e);
+        d.build_at = (m > 0.0 && m < 1.0) ? (float)m : d.build_at;
+    }
     d.list_margin = 0.15f;
     if (const char *e = getenv("CVO_HIP_LIST_MARGIN")) {
         const double m = atof(e);
@@ -435,6 +450,9 @@ void fill_filter_geometry(const cvo_hip_ctx *ctx, DevState *h)
     h->y0max = radius(ctx->moving);
 }
 
+bool multi_rank(const cvo_hip_ctx *ctx);
+DevParams loop_params(const cvo_hip_ctx *ctx);
+
 // The dense all-pairs filter of one list (with optional HIP-event bracket: this
 // is the kernel the roofline is quoted on).
 int enqueue_filter(cvo_hip_ctx *ctx, int list, const Cloud &ca, int row_lo, int row_hi, int tf_a,
@@ -459,6 +477,18 @@ int enqueue_filter(cvo_hip_ctx *ctx, int list, const Cloud &ca, int row_lo, int 
     a.tf_a = tf_a; a.tf_b = tf_b;
     a.check_done = check_done;
     a.gx = (int)pl.grid.x; a.gy = (int)pl.grid.y;
+    const bool side = list == LIST_XY && ctx->in_loop && ctx->use_async;
+    if (side) {   // build beside the flow pass, into the buffer the plan step named
+        rc = ensure_list(ctx, LIST_XYB, 0, 0, (double)ctx->lists[LIST_XY].cap);
+        if (rc) return rc;
+        a.async_xy = 1;
+        a.tiles_b = (TileEntry *)ctx->lists[LIST_XYB].a.p;
+    }
+    if (side) {   // no launch of its own: rides with the flow pass (enqueue_process)
+        ctx->xy_build = a;
+        ctx->have_xy_build = true;
+        return CVO_HIP_OK;
+    }
     if (ctx->rec) {
         RecOp op; op.kind = RecOp::FILTER; op.f = a;
         ctx->rec->push_back(op);
@@ -514,6 +544,10 @@ int enqueue_process(cvo_hip_ctx *ctx, int mode, int list, DevBuf &part, const fl
     a.first_counted = first_counted;
     a.tf_a = tf_a; a.tf_b = tf_b;
     a.check_done = check_done;
+    if (ctx->in_loop && ctx->use_async) {
+        a.async_xy = 1;
+        a.tiles_b = (const TileEntry *)ctx->lists[LIST_XYB].a.p;
+    }
     const bool twist = mode == PROC_STEP && ctx->merge_twist;
     if (twist) {
         a.flow_part = (const double *)ctx->part_flow.p;
@@ -523,12 +557,17 @@ int enqueue_process(cvo_hip_ctx *ctx, int mode, int list, DevBuf &part, const fl
         a.acvo = ctx->prm.mode == CVO_HIP_MODE_ACVO;
         a.done_mirror = ctx->done_mirror;
     }
+    const bool build = mode == PROC_FLOW && ctx->have_xy_build;
+    ctx->have_xy_build = ctx->have_xy_build && mode != PROC_FLOW;
     if (ctx->rec) {
-        RecOp op; op.kind = RecOp::PROCESS; op.mode = twist ? kProcStepTwist : mode; op.p = a;
+        RecOp op; op.kind = RecOp::PROCESS; op.mode = twist ? kProcStepTwist : (build ? kFlowBuild : mode);
+        op.p = a;
+        if (build) op.f = ctx->xy_build;
         ctx->rec->push_back(op);
         return CVO_HIP_OK;
     }
     if (twist) launch_step_twist_group(&a, 1, ctx->stream);
+    else if (build) launch_flow_build_group(&a, &ctx->xy_build, 1, ctx->stream);
     else launch_process(mode, a, ctx->stream);
     HIP_TRY(ctx, hipGetLastError());
     return CVO_HIP_OK;
@@ -583,6 +622,14 @@ int drain_events(cvo_hip_ctx *ctx, int n_exec = -1, const DevState *fin = nullpt
 
 bool multi_rank(const cvo_hip_ctx *ctx) { return ctx->comm || ctx->user_allreduce; }
 
+// the parameter block of the kernels of align(): the context's, plus the mode of this run
+DevParams loop_params(const cvo_hip_ctx *ctx)
+{
+    DevParams dp = ctx->dprm;
+    dp.async_xy = ctx->use_async ? 1 : 0;
+    return dp;
+}
+
 // all-reduce `count` doubles of st->red starting at `off` over the ranks
 int reduce_over_ranks(cvo_hip_ctx *ctx, int off, int count)
 {
@@ -632,17 +679,21 @@ int enqueue_flow(cvo_hip_ctx *ctx, bool tf_moving, int check_done, bool do_math,
     if (group_lists) {
         ctx->rec = nullptr;
         if (!rc) {
-            FilterArgs f[3];
+            FilterArgs f[3], build{};
             ProcessArgs flow{}, self[2];
             int nf = 0, ns = 0;
-            bool have_flow = false;
+            bool have_flow = false, have_build = false;
             for (const RecOp &op : local) {
                 if (op.kind == RecOp::FILTER && nf < 3) f[nf++] = op.f;
-                else if (op.kind == RecOp::PROCESS && op.mode == PROC_FLOW) { flow = op.p; have_flow = true; }
+                else if (op.kind == RecOp::PROCESS && (op.mode == PROC_FLOW || op.mode == kFlowBuild)) {
+                    flow = op.p; have_flow = true;
+                    if (op.mode == kFlowBuild) { build = op.f; have_build = true; }
+                }
                 else if (op.kind == RecOp::PROCESS && op.mode == PROC_SELF && ns < 2) self[ns++] = op.p;
             }
             if (nf) launch_filter_group(f, nf, ctx->stream);
-            if (have_flow) launch_process_group(PROC_FLOW, &flow, 1, ctx->stream);
+            if (have_flow && have_build) launch_flow_build_group(&flow, &build, 1, ctx->stream);
+            else if (have_flow) launch_process_group(PROC_FLOW, &flow, 1, ctx->stream);
             if (ns) launch_process_group(PROC_SELF, self, ns, ctx->stream);
             HIP_TRY(ctx, hipGetLastError());
         }
@@ -651,7 +702,7 @@ int enqueue_flow(cvo_hip_ctx *ctx, bool tf_moving, int check_done, bool do_math,
     if (ctx->merge_twist) return CVO_HIP_OK;   // k_step_twist does the rest of compute_flow
     PostFlowArgs pa{};
     pa.st = ctx->st;
-    pa.prm = ctx->dprm;
+    pa.prm = ctx->in_loop ? loop_params(ctx) : ctx->dprm;
     pa.trace = trace; pa.trace_cap = trace_cap;
     pa.check_done = check_done;
     pa.done_mirror = ctx->done_mirror;
@@ -686,7 +737,7 @@ int enqueue_step(cvo_hip_ctx *ctx, int check_done, bool do_math, cvo_hip_trace *
     if (rc) return rc;
     PostStepArgs pa{};
     pa.st = ctx->st;
-    pa.prm = ctx->dprm;
+    pa.prm = ctx->in_loop ? loop_params(ctx) : ctx->dprm;
     pa.trace = trace; pa.trace_cap = trace_cap;
     pa.check_done = check_done;
     pa.done_mirror = ctx->done_mirror;
@@ -741,6 +792,7 @@ int prepare_buffers(cvo_hip_ctx *ctx)
     int rlo, rhi, slo, shi;
     shard_ranges(ctx, rlo, rhi, slo, shi);
     int rc = ensure_list(ctx, LIST_XY, rhi - rlo, ctx->moving.n, 0);
+    if (!rc) rc = ensure_list(ctx, LIST_XYB, 0, 0, (double)ctx->lists[LIST_XY].cap);   // second xy buffer
     if (!rc) rc = ensure_list(ctx, LIST_KEPT, ctx->fixed.n, ctx->moving.n, 0);
     if (!rc && acvo) rc = ensure_list(ctx, LIST_XX, rhi - rlo, ctx->fixed.n, 0);
     if (!rc && acvo) rc = ensure_list(ctx, LIST_YY, shi - slo, ctx->moving.n, 0);
@@ -758,6 +810,7 @@ int enqueue_iterations(cvo_hip_ctx *ctx, int count, int tag0, int trace_cap)
 {
     int rc = CVO_HIP_OK;
     ctx->merge_twist = ctx->allow_merge && !multi_rank(ctx);
+    ctx->in_loop = true;
     ctx->cur_trace = ctx->trace_dev;
     ctx->cur_trace_cap = trace_cap;
     for (int q = 0; q < count && !rc; ++q) {
@@ -766,6 +819,7 @@ int enqueue_iterations(cvo_hip_ctx *ctx, int count, int tag0, int trace_cap)
         if (!rc) rc = enqueue_step(ctx, 1, true, ctx->trace_dev, trace_cap);
     }
     ctx->merge_twist = false;
+    ctx->in_loop = false;
     ctx->iter_tag = -1;
     return rc;
 }
@@ -780,6 +834,7 @@ std::vector<uint64_t> graph_key(const cvo_hip_ctx *ctx, int trace_cap)
     for (int l = 0; l < LIST_N; ++l) { P(ctx->lists[l].a.p); P(ctx->lists[l].b.p); I(ctx->lists[l].cap); }
     P(ctx->kept_cnt.p); P(ctx->part_flow.p); P(ctx->part_xx.p); P(ctx->part_yy.p); P(ctx->part_step.p);
     P(ctx->trace_dev); I((uint64_t)trace_cap); P(ctx->st); P(ctx->post_dbg);
+    I(ctx->use_async);
     I(ctx->sharded); I((uint64_t)ctx->row_lo); I((uint64_t)ctx->row_hi);
     I((uint64_t)ctx->srow_lo); I((uint64_t)ctx->srow_hi);
     uint64_t h = 1469598103934665603ull;   // FNV-1a over the by-value parameter block
@@ -985,6 +1040,7 @@ int cvo_hip_create(int device, void *stream, const cvo_hip_params *p, cvo_hip_ct
     *ctx->done_mirror = 0;
     if (getenv("CVO_HIP_NO_GRAPH")) ctx->use_graphs = false;
     if (getenv("CVO_HIP_NO_MERGE")) ctx->allow_merge = false;
+    if (getenv("CVO_HIP_NO_ASYNC")) ctx->allow_async = false;
     if (getenv("CVO_HIP_POST_DEBUG")) {
         if (hipMalloc((void **)&ctx->post_dbg, 8 * sizeof(long long)) != hipSuccess) return bail(CVO_HIP_ERR_NOMEM);
         (void)hipMemset(ctx->post_dbg, 0, 8 * sizeof(long long));
@@ -1251,7 +1307,10 @@ int job_begin(AlignJob &j)
     fill_filter_geometry(ctx, h);
     if (p.max_iter <= 0) h->done = DONE_MAX_ITER;
     HIP_TRY(ctx, hipMemcpyAsync(ctx->st, h, sizeof(DevState), hipMemcpyHostToDevice, ctx->stream));
-    launch_prepare(ctx->st, ctx->dprm, ctx->stream);
+    // (from ~20k x 20k on a build is too long to hide beside one flow pass)
+    ctx->use_async = ctx->allow_async && !ctx->crowded && !ctx->profiling && !multi_rank(ctx) &&
+                     (double)ctx->fixed.n * (double)ctx->moving.n <= 2.0e8;
+    launch_prepare(ctx->st, loop_params(ctx), ctx->stream);
     HIP_TRY(ctx, hipGetLastError());
     ctx->have_tf = true;
     const int prc = prepare_buffers(ctx);
@@ -1338,7 +1397,8 @@ int job_pump(AlignJob &j, bool block)
         if (multi_rank(ctx) ? ctx->st_host[slot].done != RUNNING
                             : *(volatile int32_t *)ctx->done_mirror != RUNNING)
             stop = true;
-        if (j.enq >= ctx->prm.max_iter + 2 * kBatch) stop = true;   // cannot happen: done is set by then
+        // (slots, not iterations: asynchronous builds add a stall slot now and then)
+        if (j.enq >= (ctx->use_async ? 2 : 1) * ctx->prm.max_iter + 4 * kBatch) stop = true;   // cannot happen
         if (!stop) return 0;
         // everything still queued either runs or returns at once; fetch the full state
         if (hipMemcpyAsync(&ctx->st_host[0], ctx->st, sizeof(DevState), hipMemcpyDeviceToHost,
@@ -1365,6 +1425,11 @@ int job_pump(AlignJob &j, bool block)
                 std::min(4.0e9, std::max((double)worst * NSUB, (double)ctx->lists[l].cap) * 1.5 + 1024.0);
             rc = ensure_list(ctx, l, 0, 0, grown);
         }
+    if (!rc) {   // the two xy buffers share one capacity
+        const double both = (double)std::max(ctx->lists[LIST_XY].cap, ctx->lists[LIST_XYB].cap);
+        rc = ensure_list(ctx, LIST_XY, 0, 0, both);
+        if (!rc) rc = ensure_list(ctx, LIST_XYB, 0, 0, both);
+    }
     if (rc) return finish_with(rc);
     int32_t zero = 0;
     if (hipMemcpyAsync(reinterpret_cast<char *>(ctx->st) + offsetof(DevState, done), &zero, sizeof(zero),
@@ -1372,7 +1437,7 @@ int job_pump(AlignJob &j, bool block)
         hipStreamSynchronize(ctx->stream) != hipSuccess)
         return finish_with(fail(ctx, CVO_HIP_ERR_HIP, "resume failed"));
     *ctx->done_mirror = 0;   // (the stream is idle: nothing can be writing it)
-    launch_prepare(ctx->st, ctx->dprm, ctx->stream);   // idempotent; re-zeroes the counters
+    launch_prepare(ctx->st, loop_params(ctx), ctx->stream);   // idempotent; re-zeroes the counters
     if (hipGetLastError() != hipSuccess) return finish_with(fail(ctx, CVO_HIP_ERR_HIP, "resume failed"));
     j.enq = j.batches = j.checked = 0;
     j.phase = 0;
@@ -1401,8 +1466,14 @@ void launch_fused(const std::vector<std::vector<RecOp>> &ops, hipStream_t s)
             break;
         case RecOp::PROCESS:
             for (int i = 0; i < n; ++i) p[i] = ops[i][q].p;
-            if (ops[0][q].mode == kProcStepTwist) launch_step_twist_group(p, n, s);
-            else launch_process_group(ops[0][q].mode, p, n, s);
+            if (ops[0][q].mode == kProcStepTwist) {
+                launch_step_twist_group(p, n, s);
+            } else if (ops[0][q].mode == kFlowBuild) {
+                for (int i = 0; i < n; ++i) f[i] = ops[i][q].f;
+                launch_flow_build_group(p, f, n, s);
+            } else {
+                launch_process_group(ops[0][q].mode, p, n, s);
+            }
             break;
         case RecOp::POST_FLOW:
             for (int i = 0; i < n; ++i) pf[i] = ops[i][q].pf;
@@ -1574,6 +1645,11 @@ struct FusedRun {
                         4.0e9, std::max((double)worst * NSUB, (double)c->lists[l].cap) * 1.5 + 1024.0);
                     rc = ensure_list(c, l, 0, 0, grown);
                 }
+            if (!rc) {   // the two xy buffers share one capacity
+                const double both = (double)std::max(c->lists[LIST_XY].cap, c->lists[LIST_XYB].cap);
+                rc = ensure_list(c, LIST_XY, 0, 0, both);
+                if (!rc) rc = ensure_list(c, LIST_XYB, 0, 0, both);
+            }
             int32_t zero = 0;
             if (!rc && (hipMemcpyAsync(reinterpret_cast<char *>(c->st) + offsetof(DevState, done), &zero,
                                        sizeof(zero), hipMemcpyHostToDevice, s) != hipSuccess ||
@@ -1582,7 +1658,7 @@ struct FusedRun {
             if (rc) { j->rc = rc; j->phase = 2; continue; }
             *c->done_mirror = 0;
             j->executed_base = cur.k;
-            launch_prepare(c->st, c->dprm, s);
+            launch_prepare(c->st, loop_params(c), s);
             next.push_back(j);
         }
         live.swap(next);
@@ -1656,8 +1732,21 @@ int cvo_hip_align_many(cvo_hip_ctx **ctxs, cvo_hip_state **states, int *n_iters,
         jobs[i].n_iter = n_iters ? &n_iters[i] : nullptr;
     }
     int first_err = CVO_HIP_OK;
+    // Asynchronous xy builds shorten the launch chain of a registration; once the GPU is
+    // shared by many registrations the chain no longer matters and the extra builds cost
+    // more than they save: members of large fused groups keep the synchronous scheme.
+    static const bool no_fuse_env = getenv("CVO_HIP_NO_FUSE") != nullptr;
+    for (int i = 0; i < count; ++i) {
+        int peers = 0;
+        for (int k = 0; k < count; ++k)
+            if (fusable(jobs[k].ctx) && jobs[k].ctx->device == jobs[i].ctx->device &&
+                jobs[k].ctx->prm.mode == jobs[i].ctx->prm.mode)
+                ++peers;
+        jobs[i].ctx->crowded = !no_fuse_env && fusable(jobs[i].ctx) && peers > 2;
+    }
     for (int i = 0; i < count; ++i) {
         const int rc = job_begin(jobs[i]);
+        jobs[i].ctx->crowded = false;
         if (rc) { jobs[i].rc = rc; jobs[i].phase = 2; if (!first_err) first_err = rc; }
     }
     // fused groups: same device, same mode, nothing that needs its own launches;

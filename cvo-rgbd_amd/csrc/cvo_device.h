@@ -60,7 +60,8 @@ typedef uint4 TileEntry;
 
 enum ProcMode { PROC_FLOW = 0, PROC_STEP = 1, PROC_SELF = 2 };
 // lists: three tile lists + the kept list
-enum ListId { LIST_XY = 0, LIST_XX = 1, LIST_YY = 2, LIST_KEPT = 3, LIST_N = 4 };
+// LIST_XYB: the second buffer of the xy tile list (asynchronous builds, see plan_xy_async)
+enum ListId { LIST_XY = 0, LIST_XX = 1, LIST_YY = 2, LIST_KEPT = 3, LIST_XYB = 4, LIST_N = 5 };
 
 // float64 partial sums a block emits per mode
 constexpr int NACC_FLOW = 9;   // omega[3] v[3] sum_a sum_a_d2 nnz
@@ -103,6 +104,8 @@ struct DevParams {
     float tau_c;         // (float)(-2.0*c_ell*c_ell*(float)log(c_sp/c_sigma/c_sigma))
     float list_margin;   // tile lists are built (1 + list_margin) wider than needed and re-used
                          // while they provably still hold every pair; 0 = rebuild every iteration
+    int32_t async_xy;    // the xy list is double-buffered and built concurrently (plan_xy_async)
+    float build_at;      // ... a new build is scheduled when this fraction of the margin in use is gone
     double s2_d, cs2_d, dl_step;
 };
 
@@ -126,6 +129,14 @@ struct DevState {
     int32_t list_ok[3];         // list l holds a build of this align()
     int32_t reuse[3];           // this iteration consumes list l as it is: k_filter returns at once
     float list_Rt[9], list_t[3];
+    // Asynchronous xy builds (DevParams::async_xy): two buffers; FLOW consumes
+    // `xy_active`; the k_filter launch of the coming slot builds `xy_target` (-1: none)
+    // at that slot's transform; `stall`: no buffer is valid, the coming slot only builds.
+    int32_t xy_active, xy_target, stall, xy_fail;
+    int32_t xy_ok[2];
+    float xy_r[2];
+    float tauf_build, xy_pad_;
+    float xy_Rt[2][9], xy_t[2][3];
     cvo_math::XiConsts xi;      // twist constants for the step-size pass
     float omega[3], v[3];
     double dl;
@@ -159,6 +170,8 @@ struct FilterArgs {
     const float4 *seg_b;   // ... of the ORIGINAL positions; centres are moved with [Rt|t]
     DevState *st;          // Rt, t, center, tauf, done; sub[list][] is appended to
     TileEntry *tiles;      // the tile list
+    TileEntry *tiles_b;    // async xy: the second buffer (same capacity); st->xy_target picks
+    int async_xy;
     uint32_t subcap;       // capacity (entries) of each of its NSUB sub-lists
     int list;              // LIST_XY / LIST_XX / LIST_YY: selects tauf[] and sub[]
     int row_lo, row_hi;
@@ -177,6 +190,8 @@ struct ProcessArgs {
     const float4 *pos_b;
     const float *feat_b;
     const TileEntry *tiles;
+    const TileEntry *tiles_b;   // async xy: second buffer; st->xy_active picks (PROC_FLOW)
+    int async_xy;               // also: every kernel of the slot returns at once when st->stall
     uint2 *kept_ij;        // kept list: PROC_FLOW writes, PROC_STEP reads
     float *kept_a;
     uint32_t *kept_cnt;    // [PROC_WAVES] members recorded by each PROC_FLOW wave
@@ -314,6 +329,7 @@ CVO_HD void plan_lists(DevState *s, const DevParams &p)
         travel = sqrt(0.5 * f2) * 1.001 * ymax + sqrt(c2);
     }
     for (int l = 0; l < 3; ++l) {
+        if (l == LIST_XY && p.async_xy) continue;   // planned by plan_xy_async
         const double need = (r_now + (l == LIST_XY ? travel : 0.0)) * 1.0001 + slack;
         const double lr = (double)s->list_r[l];
         const bool keep = margin > 0.0 && s->list_ok[l] && need <= lr &&
@@ -333,6 +349,71 @@ CVO_HD void plan_lists(DevState *s, const DevParams &p)
     }
 }
 
+// Asynchronous xy builds.  A build needs A transform near the current one, not
+// the next one: the k_filter launch of slot s runs beside k_process<FLOW> of slot
+// s (other stream), builds the idle buffer at slot s's transform, and the plan
+// step at the end of the slot switches to it if it holds every pair for the NEW
+// transform.  The filter is then off the launch chain (3 dependent launches per
+// iteration instead of 4) and never waited for.  A build is scheduled when half
+// the margin of the list in use is gone (the new one is usable one slot later) or
+// the list is too wide; if no buffer is valid (first slot, a jump) the coming slot
+// is a STALL: nothing but the build runs, the iteration is executed one slot later.
+CVO_HD double xy_travel(const DevState *s, int b)
+{
+    double f2 = 0.0, c2 = 0.0;
+    for (int r = 0; r < 3; ++r) {
+        double dc = (double)s->t[r] - (double)s->xy_t[b][r];
+        for (int q = 0; q < 3; ++q) {
+            const double d = (double)s->Rt[3 * r + q] - (double)s->xy_Rt[b][3 * r + q];
+            f2 += d * d;
+            dc += d * (double)s->center[q];
+        }
+        c2 += dc * dc;
+    }
+    return sqrt(0.5 * f2) * 1.001 * (double)s->y0max + sqrt(c2);
+}
+
+CVO_HD void plan_xy_async(DevState *s, const DevParams &p)
+{
+    const double r_now = sqrt((double)s->kc.tau);
+    const double slack = 1.0e-4 * (1.0 + (double)s->xmax + (double)s->y0max);
+    const double margin = (double)p.list_margin;
+    const double r0 = r_now * 1.0001 + slack;   // radius needed with no travel
+    const int fresh = s->xy_target;
+    if (fresh >= 0) s->xy_ok[fresh] = s->xy_fail ? 0 : 1;   // the build of the slot that just ended
+    double need[2];
+    bool valid[2];
+    for (int b = 0; b < 2; ++b) {
+        need[b] = s->xy_ok[b] ? (r_now + xy_travel(s, b)) * 1.0001 + slack : 0.0;
+        valid[b] = s->xy_ok[b] && need[b] <= (double)s->xy_r[b];
+    }
+    int use = -1;
+    if (fresh >= 0 && valid[fresh]) use = fresh;
+    else if (valid[s->xy_active]) use = s->xy_active;
+    else if (valid[1 - s->xy_active]) use = 1 - s->xy_active;
+    s->stall = use < 0 ? 1 : 0;
+    if (use >= 0) s->xy_active = use;
+    bool build = use < 0 || !(margin > 0.0);
+    if (!build) {
+        const double lr = (double)s->xy_r[use];
+        if (need[use] - r0 > (double)p.build_at * (lr - r0)) build = true;   // most of the margin is gone
+        if (lr > LIST_LOOSE * (1.0 + margin) * r0) build = true;             // far wider than needed
+    }
+    s->xy_target = -1;
+    if (build) {
+        const int tgt = use < 0 ? 0 : 1 - use;
+        s->xy_target = tgt;
+        s->xy_ok[tgt] = 0;
+        s->xy_r[tgt] = (float)(r0 * (1.0 + margin) * 1.000001);   // rounded up
+        // tauf[LIST_XY] of compute_filter_bounds is tau + rounding slack: widen tau
+        s->tauf_build = (float)(((double)s->xy_r[tgt] * (double)s->xy_r[tgt] +
+                                 ((double)s->tauf[LIST_XY] - (double)s->kc.tau)) * 1.000001 + 1e-12);
+        for (int q = 0; q < 9; ++q) s->xy_Rt[tgt][q] = s->Rt[q];
+        for (int q = 0; q < 3; ++q) s->xy_t[tgt][q] = s->t[q];
+    }
+    s->xy_fail = 0;
+}
+
 // Everything an iteration needs that derives from (R, T, ell).  The caller logs
 // the lists that are rebuilt (reuse[l] == 0) in DevState::built.
 CVO_HD void prepare_iteration(DevState *s, const DevParams &p)
@@ -344,6 +425,7 @@ CVO_HD void prepare_iteration(DevState *s, const DevParams &p)
     }
     compute_filter_bounds(s, false);
     plan_lists(s, p);
+    if (p.async_xy) plan_xy_async(s, p);
     for (int q = 0; q < 2 * LIST_N; ++q) s->cnt[q] = 0u;
     // (the per-sub-list counters are zeroed by all threads of the calling kernel)
 }
@@ -361,6 +443,7 @@ void launch_process_group(int mode, const ProcessArgs *a, int n, hipStream_t s);
 void launch_post_flow_group(const PostFlowArgs *a, int n, hipStream_t s);
 void launch_post_step_group(const PostStepArgs *a, int n, hipStream_t s);
 void launch_step_twist_group(const ProcessArgs *a, int n, hipStream_t s);
+void launch_flow_build_group(const ProcessArgs *a, const FilterArgs *f, int n, hipStream_t s);
 constexpr int STEP_TWIST_ROWS_DIV = 4;   // k_step_twist writes nblk / 4 partial rows
 
 }   // namespace cvo_dev

@@ -85,34 +85,32 @@ __device__ __forceinline__ bool spheres_near(const float4 sa, const float4 sb, f
 
 // append the wave's `n` staged tile entries to sub-list `sub` (exact-size slice)
 __device__ __forceinline__ void flush_tiles(const TileEntry *stage, int n, int lane, unsigned sub,
-                                            const FilterArgs &a)
+                                            const FilterArgs &a, int list, TileEntry *tiles)
 {
     unsigned base = 0;
-    if (lane == 0) base = atomicAdd(&a.st->sub[a.list][sub], (unsigned)n);
+    if (lane == 0) base = atomicAdd(&a.st->sub[list][sub], (unsigned)n);
     base = __builtin_amdgcn_readfirstlane(base);
     if (base + (unsigned)n <= a.subcap) {
         const uint4 *src = reinterpret_cast<const uint4 *>(stage);
-        uint4 *dst = reinterpret_cast<uint4 *>(a.tiles + (size_t)sub * a.subcap + base);
+        uint4 *dst = reinterpret_cast<uint4 *>(tiles + (size_t)sub * a.subcap + base);
         for (int w = lane; w < n; w += 64) dst[w] = src[w];
     } else if (lane == 0) {
-        atomicOr(&a.st->cnt[2 * a.list + 1], 1u);   // overflow: the host grows the list and resumes
+        atomicOr(&a.st->cnt[2 * list + 1], 1u);   // overflow: the host grows the list and resumes
     }
 }
 
-__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(6, 8)))
-k_filter(const Grp<FilterArgs> grp)
+__device__ __forceinline__ void filter_body(const FilterArgs &a, const unsigned bid, const unsigned nblocks)
 {
     // Persistent blocks: the (column chunk, row tile) items of this registration's
     // a.gx x a.gy work grid are dealt round-robin to the gridDim.x blocks of the
     // launch, so that a launch that has nothing to do (list re-used, loop finished)
     // costs a few hundred blocks, not thousands.
-    const FilterArgs &a = grp.a[blockIdx.z];
     // XCD-aware dealing: block b runs on XCD b % 8 (workgroups go round-robin to the
     // XCDs) and takes items of the row tiles of region b % 8 only (the 8 eighths of
     // the row-tile range; rows are in Morton order), the same regions whose tile
     // entries that XCD's list-kernel blocks consume: every XCD's L2 holds one region
     // of the clouds for the whole iteration instead of all of them.
-    const int reg = (int)(blockIdx.x & 7u), slot = (int)(blockIdx.x >> 3), nslot = (int)(gridDim.x >> 3);
+    const int reg = (int)(bid & 7u), slot = (int)(bid >> 3), nslot = (int)(nblocks >> 3);
     const int by_lo = (reg * a.gy + 7) / 8, by_hi = ((reg + 1) * a.gy + 7) / 8;   // tiles of this region
     const int nitems = (by_hi - by_lo) * a.gx;
     if (slot >= nitems) return;
@@ -121,7 +119,11 @@ k_filter(const Grp<FilterArgs> grp)
     // first round trip: the loop-control word, the state constants and this
     // thread's bounding spheres are all fetched before anything waits
     // (inside align() a list that is still valid is consumed again: nothing to do)
-    const int done_word = a.check_done ? (a.st->done | a.st->reuse[a.list]) : 0;
+    // (async xy: this launch builds the buffer the plan step scheduled, if any)
+    const int target = a.async_xy ? a.st->xy_target : 0;
+    const int done_word = a.check_done ? (a.st->done | (a.async_xy ? (target < 0) : a.st->reuse[a.list])) : 0;
+    const int out_list = (a.async_xy && target == 1) ? LIST_XYB : a.list;
+    TileEntry *out_tiles = (a.async_xy && target == 1) ? a.tiles_b : a.tiles;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float *bop = reinterpret_cast<float *>(smem);
     float4 *xrow = reinterpret_cast<float4 *>(smem + (size_t)a.jt * 16);
@@ -136,7 +138,7 @@ k_filter(const Grp<FilterArgs> grp)
     const float *Rt = a.st->Rt;
     const float *tt = a.st->t;
     const float cx = a.st->center[0], cy = a.st->center[1], cz = a.st->center[2];
-    const float tauf = a.st->tauf[a.list];
+    const float tauf = a.async_xy ? a.st->tauf_build : a.st->tauf[a.list];
     // ---- culling, for all the items of this block at once.  The clouds are in
     // Morton order, so the 64 rows of a wave and every run of 64 columns are
     // compact patches with precomputed bounding spheres (rigid motion moves a
@@ -294,7 +296,7 @@ k_filter(const Grp<FilterArgs> grp)
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            flush_tiles(stage, ne, lane, (((sub++) & 31u) << 3) | region, a);
+            flush_tiles(stage, ne, lane, (((sub++) & 31u) << 3) | region, a, out_list, out_tiles);
             __builtin_amdgcn_wave_barrier();
             ne = 0;
         }
@@ -304,7 +306,7 @@ k_filter(const Grp<FilterArgs> grp)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        flush_tiles(stage, ne, lane, ((sub & 31u) << 3) | region, a);
+        flush_tiles(stage, ne, lane, ((sub & 31u) << 3) | region, a, out_list, out_tiles);
     }
     if (a.dbg && lane == 0) {   // probe: start, prologue end, loop end, exit clocks of every wave
         long long *o = a.dbg + ((size_t)(by * a.gx + bx) * 4 + wid) * 8;
@@ -317,6 +319,12 @@ k_filter(const Grp<FilterArgs> grp)
     }   // live items
     __syncthreads();
     }   // chunks of FILTER_KMAX items
+}
+
+__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(6, 8)))
+k_filter(const Grp<FilterArgs> grp)
+{
+    filter_body(grp.a[blockIdx.z], blockIdx.x, gridDim.x);
 }
 
 // blocks of one registration's filter launch (persistent, see k_filter)
@@ -629,10 +637,9 @@ __device__ __forceinline__ float eval_pair(const ProcessArgs &a, const KernConst
 }
 
 template <int MODE>
-__global__ void __launch_bounds__(BLOCK) k_process(const Grp<ProcessArgs> grp)
+__device__ __forceinline__ void process_body(const ProcessArgs &a, const unsigned bid)
 {
-    const ProcessArgs &a = grp.a[blockIdx.z];
-    if ((int)blockIdx.x >= a.nblk) return;
+    if ((int)bid >= a.nblk) return;
     constexpr int NACC = NAcc<MODE>::n;
     __shared__ double red[4 * NACC_MAX];
     __shared__ uint2 pairq_all[(MODE == PROC_STEP) ? 1 : 4 * PAIR_QUEUE];
@@ -642,10 +649,14 @@ __global__ void __launch_bounds__(BLOCK) k_process(const Grp<ProcessArgs> grp)
     const double *s_etab = s_etab_all + ((MODE == PROC_STEP) ? 0 : (threadIdx.x >> 6) * 64);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const unsigned wave = blockIdx.x * 4u + (unsigned)wid;   // 0 .. PROC_WAVES-1
+    const unsigned wave = bid * 4u + (unsigned)wid;   // 0 .. PROC_WAVES-1
     // first round trip: loop-control word, kernel constants, list sizes
-    const int done_word = a.check_done ? a.st->done : 0;
+    // (async xy: a stall slot only builds; PROC_FLOW reads the buffer in use)
+    const int done_word = a.check_done ? (a.st->done | (a.async_xy ? a.st->stall : 0)) : 0;
     const KernConsts kc = a.st->kc;
+    const bool second = MODE == PROC_FLOW && a.async_xy && a.st->xy_active == 1;
+    const int in_list = second ? (int)LIST_XYB : a.list;
+    const TileEntry *in_tiles = second ? a.tiles_b : a.tiles;
 
     double acc[NACC];
 #pragma unroll
@@ -670,10 +681,10 @@ __global__ void __launch_bounds__(BLOCK) k_process(const Grp<ProcessArgs> grp)
         // sub-lists, one after the other (sub-list s stays on XCD s % 8 either way)
         const bool shared = a.nblk >= NSUB;
         const unsigned nsl = shared ? 1u : (unsigned)(NSUB / a.nblk);
-        const unsigned part = shared ? blockIdx.x / NSUB : 0u;
-        unsigned sub = blockIdx.x & (NSUB - 1);
-        unsigned n = a.st->sub[a.list][sub];
-        const TileEntry *tl = a.tiles + (size_t)sub * a.subcap;
+        const unsigned part = shared ? bid / NSUB : 0u;
+        unsigned sub = bid & (NSUB - 1);
+        unsigned n = a.st->sub[in_list][sub];
+        const TileEntry *tl = in_tiles + (size_t)sub * a.subcap;
         // The waves of a sub-list take its entries in turn, 64 at a time: lane l
         // fetches the wave's l-th entry of the round (one memory round trip per 64
         // entries, the first one together with the count).
@@ -720,8 +731,8 @@ __global__ void __launch_bounds__(BLOCK) k_process(const Grp<ProcessArgs> grp)
         const TileEntry *tl_next = tl;
         if (sl + 1 < nsl) {
             const unsigned sub_next = sub + (unsigned)a.nblk;
-            n_next = a.st->sub[a.list][sub_next];
-            tl_next = a.tiles + (size_t)sub_next * a.subcap;
+            n_next = a.st->sub[in_list][sub_next];
+            tl_next = in_tiles + (size_t)sub_next * a.subcap;
             mine_next = tl_next[min(e0 + (unsigned)lane * stride, a.subcap - 1)];
         }
         if (n > a.subcap) n = a.subcap;   // overflowed list: the iteration is redone anyway
@@ -762,8 +773,53 @@ __global__ void __launch_bounds__(BLOCK) k_process(const Grp<ProcessArgs> grp)
     __syncthreads();
     if (tid < NACC) {
         const double s = ((red[tid] + red[NACC + tid]) + red[2 * NACC + tid]) + red[3 * NACC + tid];
-        a.partials[(size_t)tid * a.nblk + blockIdx.x] = s;   // [value][block]: coalesced for the readers
+        a.partials[(size_t)tid * a.nblk + bid] = s;   // [value][block]: coalesced for the readers
     }
+}
+
+template <int MODE>
+__global__ void __launch_bounds__(BLOCK) k_process(const Grp<ProcessArgs> grp)
+{
+    process_body<MODE>(grp.a[blockIdx.z], blockIdx.x);
+}
+
+// ---------------------------------------------------------------------------
+// k_flow_build = k_process<PROC_FLOW> and the asynchronous xy build in one launch:
+// blocks [0, np) run the flow pass of this slot on the buffer in use, blocks
+// [np, np + nfb) are k_filter blocks that build the idle buffer at this slot's
+// transform when the plan step asked for it (cvo_device.h plan_xy_async) and return
+// after their first load otherwise.  The filter is off the launch chain: three
+// dependent launches per iteration, and builds that nobody waits for.
+struct BuildExtra {          // what a filter block needs beyond the flow pass's arguments
+    const float4 *seg_a, *seg_b;
+    int row_lo, row_hi, nb, jt, gx, gy;
+};
+
+__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(6, 8)))
+k_flow_build(const Grp<ProcessArgs> gp, const Grp<BuildExtra> gx, const int np, const int nfb)
+{
+    const ProcessArgs &a = gp.a[blockIdx.z];
+    if ((int)blockIdx.x < np) {
+        process_body<PROC_FLOW>(a, blockIdx.x);
+        return;
+    }
+    const BuildExtra &x = gx.a[blockIdx.z];
+    FilterArgs f;
+    f.pos_a = a.pos_a; f.pos_b = a.pos_b;
+    f.seg_a = x.seg_a; f.seg_b = x.seg_b;
+    f.st = a.st;
+    f.tiles = const_cast<TileEntry *>(a.tiles);
+    f.tiles_b = const_cast<TileEntry *>(a.tiles_b);
+    f.async_xy = 1;
+    f.subcap = a.subcap;
+    f.list = LIST_XY;
+    f.row_lo = x.row_lo; f.row_hi = x.row_hi;
+    f.nb = x.nb; f.jt = x.jt;
+    f.tf_a = a.tf_a; f.tf_b = a.tf_b;
+    f.check_done = a.check_done;
+    f.gx = x.gx; f.gy = x.gy;
+    f.dbg = nullptr;
+    filter_body(f, blockIdx.x - (unsigned)np, (unsigned)nfb);
 }
 
 // ---------------------------------------------------------------------------
@@ -796,9 +852,10 @@ __global__ void __launch_bounds__(STEP_BLOCK) k_step_twist(const Grp<ProcessArgs
     const unsigned wave = fb * 4u + ((unsigned)wid & 3u);
     // first round trip: loop control, constants, this thread's PROC_FLOW partial row,
     // the wave's first kept entries
-    const int done_word = a.check_done ? a.st->done : 0;
+    const int done_word = a.check_done ? (a.st->done | (a.async_xy ? a.st->stall : 0)) : 0;
     const KernConsts kc = a.st->kc;
-    const unsigned ovf = a.st->cnt[2 * LIST_XY + 1] | a.st->cnt[2 * LIST_XX + 1] |
+    // (async xy: the buffer being built beside this launch is k_post_step's business)
+    const unsigned ovf = (a.async_xy ? 0u : a.st->cnt[2 * LIST_XY + 1]) | a.st->cnt[2 * LIST_XX + 1] |
                          a.st->cnt[2 * LIST_YY + 1] | a.st->cnt[2 * LIST_KEPT + 1];
     double pf[NACC_FLOW];
 #pragma unroll
@@ -920,6 +977,27 @@ void launch_step_twist_group(const ProcessArgs *a, int n, hipStream_t s)
     hipLaunchKernelGGL(k_step_twist, grid, dim3(STEP_BLOCK), 0, s, g);
 }
 
+// flow pass + asynchronous xy build: f[i] is the k_filter argument block of a[i]
+void launch_flow_build_group(const ProcessArgs *a, const FilterArgs *f, int n, hipStream_t s)
+{
+    Grp<ProcessArgs> gp;
+    Grp<BuildExtra> gx;
+    int np = 8, jt = 0;
+    unsigned nfb = 8;
+    static const long long fb_div = [] { const char *e = getenv("CVO_HIP_BUILD_DIV"); return e ? std::max(1LL, atoll(e)) : 2LL; }();
+    // fewer filter blocks than a stand-alone k_filter launch gets: nobody waits for a build
+    const long long cap = std::max<long long>(64, 2 * filter_blocks_max() / (fb_div * n));
+    for (int i = 0; i < n; ++i) {
+        gp.a[i] = a[i];
+        gx.a[i] = BuildExtra{f[i].seg_a, f[i].seg_b, f[i].row_lo, f[i].row_hi, f[i].nb, f[i].jt, f[i].gx, f[i].gy};
+        np = std::max(np, a[i].nblk);
+        nfb = std::max(nfb, filter_grid_x((long long)f[i].gx * f[i].gy, cap));
+        jt = std::max(jt, f[i].jt);
+    }
+    const dim3 grid((unsigned)np + nfb, 1, (unsigned)n);
+    hipLaunchKernelGGL(k_flow_build, grid, dim3(BLOCK), filter_smem_bytes(jt), s, gp, gx, np, (int)nfb);
+}
+
 void launch_process_group(int mode, const ProcessArgs *a, int n, hipStream_t s)
 {
     Grp<ProcessArgs> g;
@@ -1030,7 +1108,7 @@ __global__ void __launch_bounds__(BLOCK) k_post_flow(const Grp<PostFlowArgs> grp
     // the maths below runs on that copy and the head is written back at the end.
     state_head_to_lds(a.st, &s_st);
     DevState *st = &s_st;
-    if (a.check_done && st->done != 0) return;
+    if (a.check_done && (st->done != 0 || (a.prm.async_xy && st->stall))) return;
     const bool acvo = a.prm.mode == CVO_HIP_MODE_ACVO;
     if (a.flags & POST_REDUCE) {
         block_reduce_partials<NACC_FLOW>(a.part_flow, a.nblk, sh, st->red + RED_FLOW);
@@ -1043,8 +1121,8 @@ __global__ void __launch_bounds__(BLOCK) k_post_flow(const Grp<PostFlowArgs> grp
         // a candidate list overflowed on this rank: poison nnz so that, after the
         // all-reduce, EVERY rank takes the same "grow the list and redo" exit
         if (threadIdx.x == 0 &&
-            (st->cnt[2 * LIST_XY + 1] | st->cnt[2 * LIST_XX + 1] | st->cnt[2 * LIST_YY + 1] |
-             st->cnt[2 * LIST_KEPT + 1]))
+            ((a.prm.async_xy ? 0u : st->cnt[2 * LIST_XY + 1]) | st->cnt[2 * LIST_XX + 1] |
+             st->cnt[2 * LIST_YY + 1] | st->cnt[2 * LIST_KEPT + 1]))
             st->red[8] = __builtin_nan("");
     }
     if ((a.flags & POST_MATH) && threadIdx.x == 0) {
@@ -1099,22 +1177,45 @@ __global__ void __launch_bounds__(BLOCK) k_post_step(const Grp<PostStepArgs> grp
     state_head_to_lds(a.st, &s_st);   // one round trip, see k_post_flow
     DevState *st = &s_st;
     if (a.check_done && st->done != 0) return;
+    // async xy: a stall slot executed no iteration (only the plan below runs); the
+    // list that was built beside this slot may have overflowed
+    const bool async = a.prm.async_xy != 0;
+    const bool stalled = async && st->stall != 0;
+    const int built_list = (async && st->xy_target >= 0) ? (st->xy_target ? (int)LIST_XYB : (int)LIST_XY) : -1;
+    const bool built_failed = built_list >= 0 && st->cnt[2 * built_list + 1] != 0u;
+    __syncthreads();   // (everybody has read the flags before thread 0 changes the state)
+    if (threadIdx.x == 0) st->xy_fail = built_failed ? 1 : 0;
     const long long c1 = a.dbg ? (long long)__builtin_readcyclecounter() : 0;
-    if (a.flags & POST_REDUCE)
+    if ((a.flags & POST_REDUCE) && !stalled)
         block_reduce_partials<NACC_STEP>(a.part_step, a.nblk, sh, st->red + RED_STEP);
     if (a.dbg && threadIdx.x == 0) {
         a.dbg[0] += 1; a.dbg[1] += c1 - c0; a.dbg[2] += (long long)__builtin_readcyclecounter() - c1;
     }
     if (a.flags & POST_MATH) {
-        if (threadIdx.x < 64) post_step_math(st, a);   // wave 0: the cubic uses all its lanes
+        if (stalled) {
+            if (threadIdx.x == 0) prepare_iteration(st, a.prm);   // the state did not move: plan only
+        } else if (threadIdx.x < 64) {
+            post_step_math(st, a);   // wave 0: the cubic uses all its lanes
+        }
         __syncthreads();
-        // the tile lists the next iteration rebuilds are emptied; the others are kept
+        // the tile lists the next slot rebuilds are emptied; the others are kept
         if (st->done == RUNNING) {
             for (int l = 0; l < 3; ++l) {
-                if (st->reuse[l]) continue;
+                if (st->reuse[l] || (async && l == LIST_XY)) continue;
                 for (int q = threadIdx.x; q < NSUB; q += BLOCK) a.st->sub[l][q] = 0u;
                 if (threadIdx.x == 0)
                     atomicOr(&a.st->built[l][(st->k >> 5) & 63], 1u << (st->k & 31));
+            }
+            if (async && st->xy_target >= 0) {
+                const int l = st->xy_target ? (int)LIST_XYB : (int)LIST_XY;
+                for (int q = threadIdx.x; q < NSUB; q += BLOCK) a.st->sub[l][q] = 0u;
+            }
+            __syncthreads();
+            // the list built beside this slot overflowed: the iteration itself was fine
+            // and is kept; park so that the host enlarges the buffers
+            if (threadIdx.x == 0 && built_failed) {
+                st->done = NEED_BIGGER_LIST;
+                st->cnt[2 * built_list + 1] = 1u;   // (prepare_iteration cleared the flags)
             }
         }
     }
@@ -1220,6 +1321,11 @@ __global__ void k_prepare(DevState *st, const DevParams prm)
             st->list_ok[l] = 0;
             atomicOr(&st->built[l][(st->k >> 5) & 63], 1u << (st->k & 31));
         }
+        st->xy_ok[0] = st->xy_ok[1] = 0;   // async xy: the first slot only builds
+        st->xy_active = 0;
+        st->xy_target = -1;
+        st->xy_fail = 0;
+        st->stall = 0;
         prepare_iteration(st, prm);
     }
 }
