@@ -984,7 +984,7 @@ void launch_flow_build_group(const ProcessArgs *a, const FilterArgs *f, int n, h
     Grp<BuildExtra> gx;
     int np = 8, jt = 0;
     unsigned nfb = 8;
-    static const long long fb_div = [] { const char *e = getenv("CVO_HIP_BUILD_DIV"); return e ? std::max(1LL, atoll(e)) : 2LL; }();
+    static const long long fb_div = [] { const char *e = getenv("CVO_HIP_BUILD_DIV"); return e ? std::max(1LL, atoll(e)) : 4LL; }();
     // fewer filter blocks than a stand-alone k_filter launch gets: nobody waits for a build
     const long long cap = std::max<long long>(64, 2 * filter_blocks_max() / (fb_div * n));
     for (int i = 0; i < n; ++i) {
