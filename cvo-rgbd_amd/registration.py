@@ -63,18 +63,18 @@ class _Registration:
 
     def run_sequence(self, frames, writer=None, trace_cap=0):
         """The loop of the reference's drivers (ref src/cvo_main.cpp:36-66): every
-        frame goes through run_cvo(); from the second frame on a pose line of
-        `accum_transform` is appended to `writer` (a trajectory.TrajectoryWriter).
-        `frames` yields (name, positions, features).  Returns the per-pair
-        iteration counts."""
+        frame goes through run_cvo() and then gets a pose line of `accum_transform`
+        in `writer` (a trajectory.TrajectoryWriter) -- the first frame too (the
+        identity): `init` is already true after the first run_cvo()
+        (ref cvo_main.cpp:52,58).  `frames` yields (name,
+        positions, features).  Returns the per-pair iteration counts."""
         iters = []
         for name, positions, features in frames:
             first = not self.init
             self.run_cvo(positions, features, trace_cap=trace_cap)
-            if first:
-                continue
-            iters.append(self.num_iterations)
-            if writer is not None:
+            if not first:
+                iters.append(self.num_iterations)
+            if writer is not None and self.init:
                 writer.append(name, self.accum_transform)
         return iters
 

@@ -29,9 +29,9 @@ from . import data as _data
 
 class TrajectoryWriter:
     """Pose lines as the reference's drivers write them (ref cvo_main.cpp:58-65):
-    one line per frame AFTER the first, the frame's name (its RGB time stamp)
-    followed by translation and unit quaternion (x y z w) of `accum_transform`,
-    `%g`-formatted like a default std::ostream."""
+    one line per frame (the first one carries the identity), the frame's name (its
+    RGB time stamp) followed by translation and unit quaternion (x y z w) of
+    `accum_transform`, `%g`-formatted like a default std::ostream."""
 
     def __init__(self, target):
         self._own = isinstance(target, str)

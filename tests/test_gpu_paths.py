@@ -310,9 +310,10 @@ def test_sequence_to_trajectory_file(pkg, po, desk, tmp_path):
     reg = pkg.Cvo(device=0, stream=_stream())
     with tj.TrajectoryWriter(path) as w:
         iters = reg.run_sequence(clouds, writer=w)
-    assert len(iters) == 4 and w.lines == 4           # no line for the first frame (ref cvo_main.cpp:56)
+    assert len(iters) == 4 and w.lines == 5           # the first frame gets a line too (quirk 13)
     est = tj.read_trajectory(path, matrices=True)
-    assert sorted(est) == [float(s) for s in stamps[1:]]
+    assert sorted(est) == [float(s) for s in stamps]
+    assert np.array_equal(est[float(stamps[0])], np.eye(4))
     last = est[float(stamps[-1])]
     assert np.allclose(last, reg.accum_transform, atol=5e-6)   # %g keeps 6 significant digits
     # the same sequence through the oracle gives the same file
@@ -322,7 +323,6 @@ def test_sequence_to_trajectory_file(pkg, po, desk, tmp_path):
     # scored against mocap: frame-to-frame drift of a few mm / tenths of a degree
     z = np.load(os.path.join(os.path.dirname(__file__), "golden", "trajectory_inputs.npz"))
     gt = {float(r[0]): tj.pose_matrix(r[1:4], r[4:8]) for r in z["gt"]}
-    est[float(stamps[0])] = np.eye(4)                  # the first frame is the origin
     # accum_transform IS the camera pose in the first frame's coordinates (what the
     # reference feeds the TUM tools): 2.6 mm / 6 mrad per frame on these four pairs
     rows, st = tj.relative_pose_error(gt, est, delta=1, delta_unit="f")
