@@ -106,6 +106,8 @@ struct cvo_hip_ctx {
     int32_t *done_mirror = nullptr;  // pinned (in the last slot): the post kernels copy `done` here
     std::vector<RecOp> *rec = nullptr;   // not null: record launches instead of issuing them
     int proc_blocks = PROC_BLOCKS;       // blocks of the list kernels (fewer in fused launches)
+    int proc_blocks_default = PROC_BLOCKS;
+    bool proc_blocks_forced = false;     // CVO_HIP_PROC_BLOCKS
     void *upload_stage = nullptr;        // pinned staging of upload_cloud (pos | feat | seg)
     size_t upload_stage_bytes = 0;
     std::vector<uint32_t> sort_keys[2];  // radix-sort scratch of upload_cloud
@@ -834,7 +836,7 @@ std::vector<uint64_t> graph_key(const cvo_hip_ctx *ctx, int trace_cap)
     for (int l = 0; l < LIST_N; ++l) { P(ctx->lists[l].a.p); P(ctx->lists[l].b.p); I(ctx->lists[l].cap); }
     P(ctx->kept_cnt.p); P(ctx->part_flow.p); P(ctx->part_xx.p); P(ctx->part_yy.p); P(ctx->part_step.p);
     P(ctx->trace_dev); I((uint64_t)trace_cap); P(ctx->st); P(ctx->post_dbg);
-    I(ctx->use_async);
+    I(ctx->use_async); I((uint64_t)ctx->proc_blocks);
     I(ctx->sharded); I((uint64_t)ctx->row_lo); I((uint64_t)ctx->row_hi);
     I((uint64_t)ctx->srow_lo); I((uint64_t)ctx->srow_hi);
     uint64_t h = 1469598103934665603ull;   // FNV-1a over the by-value parameter block
@@ -1041,6 +1043,13 @@ int cvo_hip_create(int device, void *stream, const cvo_hip_params *p, cvo_hip_ct
     if (getenv("CVO_HIP_NO_GRAPH")) ctx->use_graphs = false;
     if (getenv("CVO_HIP_NO_MERGE")) ctx->allow_merge = false;
     if (getenv("CVO_HIP_NO_ASYNC")) ctx->allow_async = false;
+    if (const char *e = getenv("CVO_HIP_PROC_BLOCKS")) {   // list-kernel blocks of a lone registration
+        const int v = atoi(e);
+        if (v == 64 || v == 128 || v == 256 || v == 512 || v == 1024) {
+            ctx->proc_blocks = ctx->proc_blocks_default = v;
+            ctx->proc_blocks_forced = true;
+        }
+    }
     if (getenv("CVO_HIP_POST_DEBUG")) {
         if (hipMalloc((void **)&ctx->post_dbg, 8 * sizeof(long long)) != hipSuccess) return bail(CVO_HIP_ERR_NOMEM);
         (void)hipMemset(ctx->post_dbg, 0, 8 * sizeof(long long));
@@ -1307,6 +1316,11 @@ int job_begin(AlignJob &j)
     fill_filter_geometry(ctx, h);
     if (p.max_iter <= 0) h->done = DONE_MAX_ITER;
     HIP_TRY(ctx, hipMemcpyAsync(ctx->st, h, sizeof(DevState), hipMemcpyHostToDevice, ctx->stream));
+    // small clouds (the ~3k-point clouds of the reference's front end): 2048 waves do
+    // (measured 3k x 3k: 2.11 ms with 512 blocks, 2.19 with 1024; 10k x 10k the other way round)
+    if (!ctx->proc_blocks_forced)
+        ctx->proc_blocks = ctx->proc_blocks_default =
+            ((double)ctx->fixed.n * (double)ctx->moving.n <= 2.5e7) ? PROC_BLOCKS / 2 : PROC_BLOCKS;
     // (from ~20k x 20k on a build is too long to hide beside one flow pass)
     ctx->use_async = ctx->allow_async && !ctx->crowded && !ctx->profiling && !multi_rank(ctx) &&
                      (double)ctx->fixed.n * (double)ctx->moving.n <= 2.0e8;
@@ -1592,7 +1606,7 @@ struct FusedRun {
             if (G > merge_max) c->allow_merge = false;
             const int rc = enqueue_iterations(c, 1, -1, 0);
             c->allow_merge = allow;
-            c->proc_blocks = PROC_BLOCKS;
+            c->proc_blocks = c->proc_blocks_default;
             c->rec = nullptr;
             if (rc || ops[i].size() != ops[0].size()) return fail_all("fused launch recording failed");
         }
