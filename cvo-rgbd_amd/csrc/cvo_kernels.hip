@@ -1183,6 +1183,10 @@ __global__ void __launch_bounds__(BLOCK) k_post_step(const Grp<PostStepArgs> grp
     const bool stalled = async && st->stall != 0;
     const int built_list = (async && st->xy_target >= 0) ? (st->xy_target ? (int)LIST_XYB : (int)LIST_XY) : -1;
     const bool built_failed = built_list >= 0 && st->cnt[2 * built_list + 1] != 0u;
+    // (a stall slot runs no k_step_twist / k_post_flow, which is where an overflow of the
+    // xx / yy lists is normally caught: lists built in a stall slot are checked here)
+    const bool xx_failed = stalled && st->cnt[2 * LIST_XX + 1] != 0u;
+    const bool yy_failed = stalled && st->cnt[2 * LIST_YY + 1] != 0u;
     __syncthreads();   // (everybody has read the flags before thread 0 changes the state)
     if (threadIdx.x == 0) st->xy_fail = built_failed ? 1 : 0;
     const long long c1 = a.dbg ? (long long)__builtin_readcyclecounter() : 0;
@@ -1213,9 +1217,12 @@ __global__ void __launch_bounds__(BLOCK) k_post_step(const Grp<PostStepArgs> grp
             __syncthreads();
             // the list built beside this slot overflowed: the iteration itself was fine
             // and is kept; park so that the host enlarges the buffers
-            if (threadIdx.x == 0 && built_failed) {
+            if (threadIdx.x == 0 && (built_failed || xx_failed || yy_failed)) {
                 st->done = NEED_BIGGER_LIST;
-                st->cnt[2 * built_list + 1] = 1u;   // (prepare_iteration cleared the flags)
+                // (prepare_iteration cleared the flags: the host needs them to know what to grow)
+                if (built_failed) st->cnt[2 * built_list + 1] = 1u;
+                if (xx_failed) st->cnt[2 * LIST_XX + 1] = 1u;
+                if (yy_failed) st->cnt[2 * LIST_YY + 1] = 1u;
             }
         }
     }

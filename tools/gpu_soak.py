@@ -32,11 +32,53 @@ for case in range(n_cases):
     xm = (xm.astype(np.float64) @ R.T + rng.normal(size=3) * 0.004).astype(np.float32)
     mode = po.MODE_ACVO if acvo else po.MODE_CVO
     p = po.default_params(mode)
+    gp = capi.default_params(capi.MODE_ACVO if acvo else capi.MODE_CVO)
+    if case % 3 == 2:   # every third case: perturbed hyper-parameters (wider / narrower kernels, ...)
+        scale = float(rng.uniform(0.6, 1.8))
+        for q in (p, gp):
+            q.ell_init = np.float32(q.ell_init * scale)
+            q.ell_max_init = np.float32(q.ell_max_init * scale)
+            q.sp_thres = np.float32(q.sp_thres * (0.35 if case % 2 else 1.1))
+            q.c_sp_thres = np.float32(q.c_sp_thres * (0.5 if case % 2 else 1.05))
+            q.c = np.float32(7.0 * (1.0 + 0.3 * (case % 5)))
+            q.max_iter = 60 + case % 40
+            if acvo and not os.environ.get("SOAK_KEEP_DL"):
+                q.dl_step = 0.3 * (0.5 + (case % 4) * 0.4)
+    only = os.environ.get("SOAK_ONLY")
+    if only is not None and int(only) != case:
+        continue
+    if only is not None:   # one case under the microscope: the sums of the first flow pass
+        c = capi.Context(mode=capi.MODE_ACVO if acvo else capi.MODE_CVO, device=0,
+                         stream=torch.cuda.current_stream().cuda_stream, params=gp)
+        c.set_fixed(xf, ff); c.set_moving(xm, fm)
+        c.transform_pcd(np.eye(3, dtype=np.float32), np.zeros(3, np.float32))
+        g13 = c.flow(float(gp.ell_init))
+        ell0 = float(p.ell_init)
+        o13 = np.zeros(13)
+        csr = po.se_kernel(p, ell0, xf, ff, xm, fm, search=po.SEARCH_GRID)
+        om, v, sa, sad2 = po.flow(p, ell0, xf, xm, csr)
+        o13[0:3], o13[3:6], o13[6], o13[7], o13[8] = om, v, sa, sad2, len(csr[1])
+        l3 = np.float32(1.0) / (np.float32(ell0) * np.float32(ell0) * np.float32(ell0))
+        for base, (xa, fa) in ((9, (xf, ff)), (11, (xm, fm))):
+            rp, col, val = po.se_kernel(p, ell0, xa, fa, xa, fa, search=po.SEARCH_GRID)
+            rows = np.repeat(np.arange(len(xa)), np.diff(rp))
+            d = xa[rows].astype(np.float32) - xa[col].astype(np.float32)
+            d2 = (d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2]
+            terms = ((l3 * val) * d2).astype(np.float64)
+            if base == 11:
+                terms = terms[rows >= len(xf)]       # acvo Ayy row rule (quirk 5)
+            o13[base], o13[base + 1] = terms.sum(), len(col)
+        names = ["w0", "w1", "w2", "v0", "v1", "v2", "sum_a", "sum_a_d2", "nnz", "sum_xx", "nnz_xx", "sum_yy", "nnz_yy"]
+        print("params", {k: getattr(gp, k) for k, _ in gp._fields_ if k not in ("pad_",)})
+        for k in range(13):
+            print("   %-9s gpu %.12g   oracle %s" % (names[k], g13[k], ("%.12g" % o13[k]) if o13 is not None else "n/a"))
+        c.close()
     s = po.init_state(p)
     n_or, _ = po.align(p, s, xf, ff, xm, fm, search=po.SEARCH_GRID)
     st_or = bytes(s)
     strm = torch.cuda.Stream(); streams.append(strm)
-    c = capi.Context(mode=capi.MODE_ACVO if acvo else capi.MODE_CVO, device=0, stream=strm.cuda_stream)
+    c = capi.Context(mode=capi.MODE_ACVO if acvo else capi.MODE_CVO, device=0, stream=strm.cuda_stream,
+                     params=gp)
     c.set_fixed(xf, ff); c.set_moving(xm, fm)
     st = capi.init_state(c.params)
     n_it, _ = c.align(st, trace_cap=0)
@@ -47,6 +89,23 @@ for case in range(n_cases):
     exact = np.array_equal(np.array(st.transform), np.array(s.transform))
     if not (same_iter and rot <= 1e-6 and tra <= 1e-6):
         bad += 1
+        if os.environ.get("SOAK_TRACE"):
+            s2 = po.init_state(p)
+            _, tr_o = po.align(p, s2, xf, ff, xm, fm, search=po.SEARCH_GRID, trace_cap=300)
+            st2 = capi.init_state(c.params)
+            _, tr_g = c.align(st2, trace_cap=300)
+            for k, (a, b) in enumerate(zip(tr_o, tr_g)):
+                same = (a["nnz"] == b["nnz"] and a["step"] == b["step"] and tuple(a["omega"]) == tuple(b["omega"])
+                        and a["ell"] == b["ell"])
+                if not same:
+                    print("  first divergence at iteration", k)
+                    for key in ("nnz", "nnz_xx", "nnz_yy", "ell", "step", "omega", "v", "dl", "sum_a", "bcde"):
+                        print("   ", key, a.get(key), "|", b.get(key))
+                    if k > 0:
+                        print("    previous iteration:")
+                        for key in ("nnz", "nnz_xx", "nnz_yy", "ell", "dl", "sum_a"):
+                            print("      ", key, tr_o[k-1].get(key), "|", tr_g[k-1].get(key))
+                    break
         print("MISMATCH case %d acvo %d n %d m %d seed %d: iters %d vs %d, rel err %.2e %.2e" % (
             case, acvo, n, m, seed, n_it, n_or, rot, tra))
     elif not exact:
