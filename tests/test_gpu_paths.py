@@ -424,3 +424,40 @@ def test_cpp_objects_match_python_objects(pkg, tmp_path, mode_name):
         assert tag[0] == "many" and int(tag[2]) == w_n
         T = np.array(next(it).split()[1:], np.float32).reshape(4, 4)
         assert np.array_equal(T, w_T.astype(np.float32))
+
+
+@pytest.mark.parametrize("mode_name", ["cvo", "acvo"])
+def test_align_many_pair_uses_async_builds(pkg, po, mode_name):
+    """Two registrations per call share their launches AND keep the asynchronous
+    list builds (k_flow_build with two argument blocks): equal to the oracle and
+    to one-by-one, also with wide kernels that overflow the first tile lists."""
+    import torch
+    capi = pkg.capi
+    acvo = mode_name == "acvo"
+    mode = capi.MODE_ACVO if acvo else capi.MODE_CVO
+    omode = po.MODE_ACVO if acvo else po.MODE_CVO
+    ctxs, want, keep = [], [], []
+    for i, (n, m) in enumerate([(2600, 2400), (1900, 3100)]):
+        xf, ff, xm, fm = pkg.data.synthetic_pair(n, m, seed=300 + i, acvo=acvo)
+        gp, p = capi.default_params(mode), po.default_params(omode)
+        for q in (gp, p):   # wide kernel: dense tile lists
+            q.sp_thres = np.float32(q.sp_thres * 0.35)
+            q.c_sp_thres = np.float32(q.c_sp_thres * 0.5)
+            q.max_iter = 70
+        s = po.init_state(p)
+        n_or, _ = po.align(p, s, xf, ff, xm, fm, search=po.SEARCH_GRID)
+        want.append((n_or, np.array(s.transform), np.array(s.R), s.ell))
+        strm = torch.cuda.Stream()
+        keep.append(strm)
+        c = capi.Context(mode=mode, device=0, stream=strm.cuda_stream, params=gp)
+        c.set_fixed(xf, ff)
+        c.set_moving(xm, fm)
+        ctxs.append(c)
+    states = [capi.init_state(c.params) for c in ctxs]
+    its = capi.align_many(ctxs, states)
+    for it, st, (n_or, T_or, R_or, ell_or) in zip(its, states, want):
+        assert it == n_or
+        assert np.array_equal(np.array(st.transform), T_or) and np.array_equal(np.array(st.R), R_or)
+        assert st.ell == ell_or
+    for c in ctxs:
+        c.close()
