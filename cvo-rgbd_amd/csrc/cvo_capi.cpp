@@ -397,7 +397,9 @@ int ensure_list(cvo_hip_ctx *ctx, int list, int nrows, int nb, double at_least)
         min_sub = 64 * (PROC_WAVES / NSUB);   // every PROC_FLOW wave's slice holds >= 64 entries
     } else {
         const double all = std::ceil(std::max(nrows, 0) / 16.0 + 1.0) * std::ceil(std::max(nb, 0) / 16.0 + 1.0);
-        want = (all * 2.0 * sizeof(TileEntry) <= 64.0e6) ? all * 2.0 : std::max(all * 0.25, 64.0e6 / sizeof(TileEntry));
+        // (a 16 x 16 tile yields up to four entries, one per MFMA result register: 4 x all
+        // can never overflow; beyond 64 MB start from a quarter of the tiles and grow on demand)
+        want = (all * 4.0 * sizeof(TileEntry) <= 64.0e6) ? all * 4.0 : std::max(all * 0.25, 64.0e6 / sizeof(TileEntry));
         min_sub = TILE_STAGE;
     }
     if (at_least <= 0.0) {   // test hook: start from a tiny list to exercise the grow-and-redo path
