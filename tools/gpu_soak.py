@@ -30,6 +30,30 @@ for case in range(n_cases):
     K = np.array([[0, -ang[2], ang[1]], [ang[2], 0, -ang[0]], [-ang[1], ang[0], 0]])
     R = np.eye(3) + np.sin(th) / th * K + (1 - np.cos(th)) / th**2 * K @ K
     xm = (xm.astype(np.float64) @ R.T + rng.normal(size=3) * 0.004).astype(np.float32)
+    if os.environ.get("SOAK_DEGENERATE"):   # hostile inputs, one kind per case
+        kind = case % 8
+        if kind == 0:      # identical clouds: converged at once
+            xm, fm = xf.copy(), ff.copy()
+        elif kind == 1:    # a handful of points
+            k1, k2 = int(rng.integers(1, 20)), int(rng.integers(1, 20))
+            xf, ff, xm, fm = xf[:k1], ff[:k1], xm[:k2], fm[:k2]
+        elif kind == 2:    # a large motion: lists die young, stall slots
+            xm = (xm.astype(np.float64) + np.array([0.05, -0.04, 0.06])).astype(np.float32)
+        elif kind == 3:    # nothing in reach: empty A
+            xm = (xm.astype(np.float64) + 50.0).astype(np.float32)
+        elif kind == 4:    # everything in one small blob: dense tiles, overflowing lists
+            xf = (xf.astype(np.float64) * 0.08 + np.array([0.0, 0.0, 1.2])).astype(np.float32)
+            xm = (xm.astype(np.float64) * 0.08 + np.array([0.0, 0.0, 1.2])).astype(np.float32)
+        elif kind == 5:    # far from the origin: the rounding slack of the MFMA filter
+            off = np.array([80.0, -120.0, 60.0])
+            xf = (xf.astype(np.float64) + off).astype(np.float32)
+            xm = (xm.astype(np.float64) + off).astype(np.float32)
+        elif kind == 6:    # duplicated points
+            xf = np.concatenate([xf, xf[: len(xf) // 3]]); ff = np.concatenate([ff, ff[: len(ff) // 3]])
+            xm = np.concatenate([xm, xm[: len(xm) // 2]]); fm = np.concatenate([fm, fm[: len(fm) // 2]])
+        else:              # very unequal sizes
+            xm, fm = xm[: max(8, len(xm) // 40)], fm[: max(8, len(fm) // 40)]
+        n, m = len(xf), len(xm)
     mode = po.MODE_ACVO if acvo else po.MODE_CVO
     p = po.default_params(mode)
     gp = capi.default_params(capi.MODE_ACVO if acvo else capi.MODE_CVO)
