@@ -1080,10 +1080,12 @@ int cvo_hip_destroy(cvo_hip_ctx *ctx)
     }
     for (void *p : {(void *)ctx->fixed.pos, (void *)ctx->fixed.feat, (void *)ctx->moving.pos,
                     (void *)ctx->moving.feat, (void *)ctx->fixed.seg, (void *)ctx->moving.seg, (void *)ctx->st, ctx->part_flow.p, ctx->part_xx.p,
-                    ctx->part_yy.p, ctx->part_step.p, (void *)ctx->trace_dev,
-                    ctx->lists[0].a.p, ctx->lists[1].a.p, ctx->lists[2].a.p, ctx->lists[3].a.p,
-                    ctx->lists[3].b.p, ctx->kept_cnt.p})
+                    ctx->part_yy.p, ctx->part_step.p, (void *)ctx->trace_dev, ctx->kept_cnt.p})
         if (p) (void)hipFree(p);
+    for (int l = 0; l < LIST_N; ++l) {
+        if (ctx->lists[l].a.p) (void)hipFree(ctx->lists[l].a.p);
+        if (ctx->lists[l].b.p) (void)hipFree(ctx->lists[l].b.p);
+    }
     if (ctx->st_host) (void)hipHostFree(ctx->st_host);
     if (ctx->upload_stage) (void)hipHostFree(ctx->upload_stage);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);

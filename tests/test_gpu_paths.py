@@ -461,3 +461,26 @@ def test_align_many_pair_uses_async_builds(pkg, po, mode_name):
         assert st.ell == ell_or
     for c in ctxs:
         c.close()
+
+
+def test_contexts_give_their_memory_back(pkg):
+    """create / register / destroy in a loop: device memory in use returns to where
+    it was (every list buffer, both xy buffers included, is freed)."""
+    import torch
+    capi = pkg.capi
+    xf, ff, xm, fm = pkg.data.synthetic_pair(4000, 4000, seed=5)
+
+    def cycle():
+        c = _ctx(pkg, capi.MODE_CVO, xf, ff, xm, fm)
+        st = capi.init_state(c.params)
+        c.align(st, trace_cap=0)
+        c.close()
+
+    cycle()
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    for _ in range(12):
+        cycle()
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info()
+    assert free0 - free1 < 8 * 1024 * 1024, "device memory leaked: %d bytes" % (free0 - free1)
