@@ -1760,7 +1760,8 @@ int cvo_hip_align_many(cvo_hip_ctx **ctxs, cvo_hip_state **states, int *n_iters,
             if (fusable(jobs[k].ctx) && jobs[k].ctx->device == jobs[i].ctx->device &&
                 jobs[k].ctx->prm.mode == jobs[i].ctx->prm.mode)
                 ++peers;
-        jobs[i].ctx->crowded = !no_fuse_env && fusable(jobs[i].ctx) && peers > 2;
+        static const int crowd = [] { const char *e = getenv("CVO_HIP_CROWD"); return e ? atoi(e) : 2; }();
+        jobs[i].ctx->crowded = !no_fuse_env && fusable(jobs[i].ctx) && peers > crowd;
     }
     for (int i = 0; i < count; ++i) {
         const int rc = job_begin(jobs[i]);
