@@ -695,9 +695,13 @@ int enqueue_flow(cvo_hip_ctx *ctx, bool tf_moving, int check_done, bool do_math,
                 }
                 else if (op.kind == RecOp::PROCESS && op.mode == PROC_SELF && ns < 2) self[ns++] = op.p;
             }
-            if (nf) launch_filter_group(f, nf, ctx->stream);
-            if (have_flow && have_build) launch_flow_build_group(&flow, &build, 1, ctx->stream);
-            else if (have_flow) launch_process_group(PROC_FLOW, &flow, 1, ctx->stream);
+            if (have_flow && have_build && nf == 2) {   // everything that filters rides with the flow pass
+                launch_flow_build3(flow, build, f[0], f[1], ctx->stream);
+            } else {
+                if (nf) launch_filter_group(f, nf, ctx->stream);
+                if (have_flow && have_build) launch_flow_build_group(&flow, &build, 1, ctx->stream);
+                else if (have_flow) launch_process_group(PROC_FLOW, &flow, 1, ctx->stream);
+            }
             if (ns) launch_process_group(PROC_SELF, self, ns, ctx->stream);
             HIP_TRY(ctx, hipGetLastError());
         }

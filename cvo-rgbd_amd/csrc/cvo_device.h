@@ -444,6 +444,8 @@ void launch_post_flow_group(const PostFlowArgs *a, int n, hipStream_t s);
 void launch_post_step_group(const PostStepArgs *a, int n, hipStream_t s);
 void launch_step_twist_group(const ProcessArgs *a, int n, hipStream_t s);
 void launch_flow_build_group(const ProcessArgs *a, const FilterArgs *f, int n, hipStream_t s);
+void launch_flow_build3(const ProcessArgs &flow, const FilterArgs &xy, const FilterArgs &xx,
+                        const FilterArgs &yy, hipStream_t s);
 constexpr int STEP_TWIST_ROWS_DIV = 4;   // k_step_twist writes nblk / 4 partial rows
 
 }   // namespace cvo_dev

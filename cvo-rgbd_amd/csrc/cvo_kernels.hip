@@ -998,6 +998,36 @@ void launch_flow_build_group(const ProcessArgs *a, const FilterArgs *f, int n, h
     hipLaunchKernelGGL(k_flow_build, grid, dim3(BLOCK), filter_smem_bytes(jt), s, gp, gx, np, (int)nfb);
 }
 
+// acvo, one registration: the flow pass, the asynchronous xy build AND the xx / yy
+// filters (synchronous lists, consumed by the PROC_SELF launch that follows) in one
+// launch -- no k_filter launch of its own is left in an acvo iteration.
+__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(6, 8)))
+k_flow_build3(const ProcessArgs flow, const FilterArgs f0, const FilterArgs f1, const FilterArgs f2,
+              const int np, const int n0, const int n1, const int n2)
+{
+    int b = (int)blockIdx.x;
+    if (b < np) { process_body<PROC_FLOW>(flow, (unsigned)b); return; }
+    b -= np;
+    if (b < n0) { filter_body(f0, (unsigned)b, (unsigned)n0); return; }
+    b -= n0;
+    if (b < n1) { filter_body(f1, (unsigned)b, (unsigned)n1); return; }
+    b -= n1;
+    filter_body(f2, (unsigned)b, (unsigned)n2);
+}
+
+void launch_flow_build3(const ProcessArgs &flow, const FilterArgs &xy, const FilterArgs &xx,
+                        const FilterArgs &yy, hipStream_t s)
+{
+    const long long cap = std::max<long long>(64, filter_blocks_max() / 2);
+    const int np = std::max(8, flow.nblk);
+    const int n0 = (int)filter_grid_x((long long)xy.gx * xy.gy, cap);
+    const int n1 = (int)filter_grid_x((long long)xx.gx * xx.gy, cap);
+    const int n2 = (int)filter_grid_x((long long)yy.gx * yy.gy, cap);
+    const int jt = std::max(xy.jt, std::max(xx.jt, yy.jt));
+    hipLaunchKernelGGL(k_flow_build3, dim3((unsigned)(np + n0 + n1 + n2)), dim3(BLOCK), filter_smem_bytes(jt), s,
+                       flow, xy, xx, yy, np, n0, n1, n2);
+}
+
 void launch_process_group(int mode, const ProcessArgs *a, int n, hipStream_t s)
 {
     Grp<ProcessArgs> g;

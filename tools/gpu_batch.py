@@ -12,12 +12,13 @@ capi = pkg.capi
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 BS = [int(x) for x in sys.argv[3].split(",")] if len(sys.argv) > 3 else [1, 2, 4, 8, 16]
+ACVO = len(sys.argv) > 4 and sys.argv[4] == "acvo"
 for B in BS:
     ctxs, streams = [], []
     for b in range(B):
         s = torch.cuda.Stream()
-        xf, ff, xm, fm = pkg.data.synthetic_pair(n, n, seed=pkg.data.SEED_CFG2)
-        c = capi.Context(mode=capi.MODE_CVO, device=0, stream=s.cuda_stream)
+        xf, ff, xm, fm = pkg.data.synthetic_pair(n, n, seed=pkg.data.SEED_CFG2, acvo=ACVO)
+        c = capi.Context(mode=capi.MODE_ACVO if ACVO else capi.MODE_CVO, device=0, stream=s.cuda_stream)
         c.set_fixed(xf, ff); c.set_moving(xm, fm)
         ctxs.append(c); streams.append(s)
     def step():
