@@ -80,6 +80,7 @@ struct GraphEntry {
 constexpr int kPollSlots = 4;
 constexpr int kProcStepTwist = 100;   // RecOp::mode of a k_step_twist launch
 constexpr int kFlowBuild = 101;       // RecOp::mode of a k_flow_build launch (RecOp::f = the build's arguments)
+constexpr int kFilterAhead = 102;     // RecOp::mode of an xx / yy filter that builds ahead (rides in the flow launch)
 
 // One kernel launch of an iteration, recorded instead of launched (fused mode:
 // the launches of several registrations are merged slot by slot).
@@ -119,6 +120,9 @@ struct cvo_hip_ctx {
     bool have_xy_build = false;
     bool allow_async = true;
     bool crowded = false;                // set by align_many: many registrations share the launches
+    bool lone = true;                    // this registration has its launches to itself
+    bool allow_async_self = true;
+    bool use_async_self = false;         // acvo, lone: self lists built ahead, PROC_SELF in the flow launch
     bool use_async = false;              // decided per align(): single rank, not profiling
     bool in_loop = false;                // enqueueing iterations of align()
     bool merge_twist = false;            // inside align(): k_step_twist replaces k_post_flow + PROC_STEP
@@ -493,6 +497,17 @@ int enqueue_filter(cvo_hip_ctx *ctx, int list, const Cloud &ca, int row_lo, int 
         ctx->have_xy_build = true;
         return CVO_HIP_OK;
     }
+    const bool ahead = (list == LIST_XX || list == LIST_YY) && ctx->in_loop && ctx->use_async_self && ctx->rec;
+    if (ahead) {   // built ahead into the idle buffer, by filter blocks of the flow launch
+        const int other = list == LIST_XX ? LIST_XXB : LIST_YYB;
+        rc = ensure_list(ctx, other, 0, 0, (double)ctx->lists[list].cap);
+        if (rc) return rc;
+        a.async_xy = list == LIST_XX ? 2 : 3;
+        a.tiles_b = (TileEntry *)ctx->lists[other].a.p;
+        RecOp op; op.kind = RecOp::FILTER; op.mode = kFilterAhead; op.f = a;
+        ctx->rec->push_back(op);
+        return CVO_HIP_OK;
+    }
     if (ctx->rec) {
         RecOp op; op.kind = RecOp::FILTER; op.f = a;
         ctx->rec->push_back(op);
@@ -551,6 +566,10 @@ int enqueue_process(cvo_hip_ctx *ctx, int mode, int list, DevBuf &part, const fl
     if (ctx->in_loop && ctx->use_async) {
         a.async_xy = 1;
         a.tiles_b = (const TileEntry *)ctx->lists[LIST_XYB].a.p;
+    }
+    if (mode == PROC_SELF && ctx->in_loop && ctx->use_async_self) {
+        a.async_self = list == LIST_XX ? 1 : 2;
+        a.tiles_b = (const TileEntry *)ctx->lists[list == LIST_XX ? LIST_XXB : LIST_YYB].a.p;
     }
     const bool twist = mode == PROC_STEP && ctx->merge_twist;
     if (twist) {
@@ -631,6 +650,7 @@ DevParams loop_params(const cvo_hip_ctx *ctx)
 {
     DevParams dp = ctx->dprm;
     dp.async_xy = ctx->use_async ? 1 : 0;
+    dp.async_self = ctx->use_async_self ? 1 : 0;
     return dp;
 }
 
@@ -683,19 +703,24 @@ int enqueue_flow(cvo_hip_ctx *ctx, bool tf_moving, int check_done, bool do_math,
     if (group_lists) {
         ctx->rec = nullptr;
         if (!rc) {
-            FilterArgs f[3], build{};
+            FilterArgs f[3], build{}, ahead[2];
             ProcessArgs flow{}, self[2];
-            int nf = 0, ns = 0;
+            int nf = 0, ns = 0, na = 0;
             bool have_flow = false, have_build = false;
             for (const RecOp &op : local) {
-                if (op.kind == RecOp::FILTER && nf < 3) f[nf++] = op.f;
+                if (op.kind == RecOp::FILTER && op.mode == kFilterAhead && na < 2) ahead[na++] = op.f;
+                else if (op.kind == RecOp::FILTER && nf < 3) f[nf++] = op.f;
                 else if (op.kind == RecOp::PROCESS && (op.mode == PROC_FLOW || op.mode == kFlowBuild)) {
                     flow = op.p; have_flow = true;
                     if (op.mode == kFlowBuild) { build = op.f; have_build = true; }
                 }
                 else if (op.kind == RecOp::PROCESS && op.mode == PROC_SELF && ns < 2) self[ns++] = op.p;
             }
-            if (have_flow && have_build && nf == 2) {   // everything that filters rides with the flow pass
+            if (have_flow && have_build && na == 2 && ns == 2) {
+                // everything but the step-size pass in one launch (self lists built ahead)
+                launch_flow_build6(flow, self[0], self[1], build, ahead[0], ahead[1], ctx->stream);
+                ns = 0;
+            } else if (have_flow && have_build && nf == 2) {   // everything that filters rides with the flow pass
                 launch_flow_build3(flow, build, f[0], f[1], ctx->stream);
             } else {
                 if (nf) launch_filter_group(f, nf, ctx->stream);
@@ -804,6 +829,8 @@ int prepare_buffers(cvo_hip_ctx *ctx)
     if (!rc) rc = ensure_list(ctx, LIST_KEPT, ctx->fixed.n, ctx->moving.n, 0);
     if (!rc && acvo) rc = ensure_list(ctx, LIST_XX, rhi - rlo, ctx->fixed.n, 0);
     if (!rc && acvo) rc = ensure_list(ctx, LIST_YY, shi - slo, ctx->moving.n, 0);
+    if (!rc && acvo) rc = ensure_list(ctx, LIST_XXB, 0, 0, (double)ctx->lists[LIST_XX].cap);
+    if (!rc && acvo) rc = ensure_list(ctx, LIST_YYB, 0, 0, (double)ctx->lists[LIST_YY].cap);
     for (DevBuf *b : {&ctx->part_flow, &ctx->part_xx, &ctx->part_yy, &ctx->part_step})
         if (!rc) rc = ensure_buf(ctx, *b, (size_t)PROC_WAVES * NACC_MAX * sizeof(double));
     if (!rc && !ctx->kept_cnt.p) {
@@ -1049,6 +1076,7 @@ int cvo_hip_create(int device, void *stream, const cvo_hip_params *p, cvo_hip_ct
     if (getenv("CVO_HIP_NO_GRAPH")) ctx->use_graphs = false;
     if (getenv("CVO_HIP_NO_MERGE")) ctx->allow_merge = false;
     if (getenv("CVO_HIP_NO_ASYNC")) ctx->allow_async = false;
+    if (getenv("CVO_HIP_NO_ASYNC_SELF")) ctx->allow_async_self = false;
     if (const char *e = getenv("CVO_HIP_PROC_BLOCKS")) {   // list-kernel blocks of a lone registration
         const int v = atoi(e);
         if (v == 64 || v == 128 || v == 256 || v == 512 || v == 1024) {
@@ -1329,9 +1357,11 @@ int job_begin(AlignJob &j)
     if (!ctx->proc_blocks_forced)
         ctx->proc_blocks = ctx->proc_blocks_default =
             ((double)ctx->fixed.n * (double)ctx->moving.n <= 2.5e7) ? PROC_BLOCKS / 2 : PROC_BLOCKS;
-    // (from ~20k x 20k on a build is too long to hide beside one flow pass)
+    // (use_async_self below; from ~20k x 20k on a build is too long to hide beside one flow pass)
     ctx->use_async = ctx->allow_async && !ctx->crowded && !ctx->profiling && !multi_rank(ctx) &&
                      (double)ctx->fixed.n * (double)ctx->moving.n <= 2.0e8;
+    ctx->use_async_self = ctx->use_async && ctx->allow_async_self && ctx->lone &&
+                          ctx->prm.mode == CVO_HIP_MODE_ACVO;
     launch_prepare(ctx->st, loop_params(ctx), ctx->stream);
     HIP_TRY(ctx, hipGetLastError());
     ctx->have_tf = true;
@@ -1447,10 +1477,12 @@ int job_pump(AlignJob &j, bool block)
                 std::min(4.0e9, std::max((double)worst * NSUB, (double)ctx->lists[l].cap) * 1.5 + 1024.0);
             rc = ensure_list(ctx, l, 0, 0, grown);
         }
-    if (!rc) {   // the two xy buffers share one capacity
-        const double both = (double)std::max(ctx->lists[LIST_XY].cap, ctx->lists[LIST_XYB].cap);
-        rc = ensure_list(ctx, LIST_XY, 0, 0, both);
-        if (!rc) rc = ensure_list(ctx, LIST_XYB, 0, 0, both);
+    for (int q = 0; q < 3 && !rc; ++q) {   // the two buffers of a list share one capacity
+        const int la = q == 0 ? LIST_XY : (q == 1 ? LIST_XX : LIST_YY), lb = q == 0 ? LIST_XYB : (q == 1 ? LIST_XXB : LIST_YYB);
+        if (!ctx->lists[la].cap && !ctx->lists[lb].cap) continue;
+        const double both = (double)std::max(ctx->lists[la].cap, ctx->lists[lb].cap);
+        rc = ensure_list(ctx, la, 0, 0, both);
+        if (!rc && ctx->lists[lb].cap) rc = ensure_list(ctx, lb, 0, 0, both);
     }
     if (rc) return finish_with(rc);
     int32_t zero = 0;
@@ -1667,10 +1699,12 @@ struct FusedRun {
                         4.0e9, std::max((double)worst * NSUB, (double)c->lists[l].cap) * 1.5 + 1024.0);
                     rc = ensure_list(c, l, 0, 0, grown);
                 }
-            if (!rc) {   // the two xy buffers share one capacity
-                const double both = (double)std::max(c->lists[LIST_XY].cap, c->lists[LIST_XYB].cap);
-                rc = ensure_list(c, LIST_XY, 0, 0, both);
-                if (!rc) rc = ensure_list(c, LIST_XYB, 0, 0, both);
+            for (int q = 0; q < 3 && !rc; ++q) {   // the two buffers of a list share one capacity
+                const int la = q == 0 ? LIST_XY : (q == 1 ? LIST_XX : LIST_YY), lb = q == 0 ? LIST_XYB : (q == 1 ? LIST_XXB : LIST_YYB);
+                if (!c->lists[la].cap && !c->lists[lb].cap) continue;
+                const double both = (double)std::max(c->lists[la].cap, c->lists[lb].cap);
+                rc = ensure_list(c, la, 0, 0, both);
+                if (!rc && c->lists[lb].cap) rc = ensure_list(c, lb, 0, 0, both);
             }
             int32_t zero = 0;
             if (!rc && (hipMemcpyAsync(reinterpret_cast<char *>(c->st) + offsetof(DevState, done), &zero,
@@ -1766,10 +1800,12 @@ int cvo_hip_align_many(cvo_hip_ctx **ctxs, cvo_hip_state **states, int *n_iters,
                 ++peers;
         static const int crowd = [] { const char *e = getenv("CVO_HIP_CROWD"); return e ? atoi(e) : 2; }();
         jobs[i].ctx->crowded = !no_fuse_env && fusable(jobs[i].ctx) && peers > crowd;
+        jobs[i].ctx->lone = no_fuse_env || !fusable(jobs[i].ctx) || peers < 2 || count < 2;
     }
     for (int i = 0; i < count; ++i) {
         const int rc = job_begin(jobs[i]);
         jobs[i].ctx->crowded = false;
+        jobs[i].ctx->lone = true;
         if (rc) { jobs[i].rc = rc; jobs[i].phase = 2; if (!first_err) first_err = rc; }
     }
     // fused groups: same device, same mode, nothing that needs its own launches;

@@ -61,7 +61,11 @@ typedef uint4 TileEntry;
 enum ProcMode { PROC_FLOW = 0, PROC_STEP = 1, PROC_SELF = 2 };
 // lists: three tile lists + the kept list
 // LIST_XYB: the second buffer of the xy tile list (asynchronous builds, see plan_xy_async)
-enum ListId { LIST_XY = 0, LIST_XX = 1, LIST_YY = 2, LIST_KEPT = 3, LIST_XYB = 4, LIST_N = 5 };
+// LIST_XXB / LIST_YYB: second buffers of the acvo self lists (plan_self_async)
+enum ListId { LIST_XY = 0, LIST_XX = 1, LIST_YY = 2, LIST_KEPT = 3, LIST_XYB = 4, LIST_XXB = 5, LIST_YYB = 6,
+              LIST_N = 7 };
+// list id of buffer `buf` of self list l (0: xx, 1: yy)
+CVO_HD int self_list_id(int l, int buf) { return buf ? LIST_XXB + l : LIST_XX + l; }
 
 // float64 partial sums a block emits per mode
 constexpr int NACC_FLOW = 9;   // omega[3] v[3] sum_a sum_a_d2 nnz
@@ -106,6 +110,8 @@ struct DevParams {
                          // while they provably still hold every pair; 0 = rebuild every iteration
     int32_t async_xy;    // the xy list is double-buffered and built concurrently (plan_xy_async)
     float build_at;      // ... a new build is scheduled when this fraction of the margin in use is gone
+    int32_t async_self;  // acvo: the xx / yy lists are double-buffered too and PROC_SELF rides in the flow launch
+    int32_t pad3_;
     double s2_d, cs2_d, dl_step;
 };
 
@@ -137,6 +143,11 @@ struct DevState {
     float xy_r[2];
     float tauf_build, xy_pad_;
     float xy_Rt[2][9], xy_t[2][3];
+    // the same for the two self lists of acvo (rigid: only the radius matters), [l][buffer]
+    int32_t sf_active[2], sf_target[2], sf_fail[2];
+    int32_t sf_ok[2][2];
+    float sf_r[2][2];
+    float sf_tauf_build[2];
     cvo_math::XiConsts xi;      // twist constants for the step-size pass
     float omega[3], v[3];
     double dl;
@@ -170,8 +181,8 @@ struct FilterArgs {
     const float4 *seg_b;   // ... of the ORIGINAL positions; centres are moved with [Rt|t]
     DevState *st;          // Rt, t, center, tauf, done; sub[list][] is appended to
     TileEntry *tiles;      // the tile list
-    TileEntry *tiles_b;    // async xy: the second buffer (same capacity); st->xy_target picks
-    int async_xy;
+    TileEntry *tiles_b;    // async: the second buffer (same capacity); st->xy_target / sf_target picks
+    int async_xy;          // 1: the asynchronous xy build; 2, 3: the asynchronous xx / yy build
     uint32_t subcap;       // capacity (entries) of each of its NSUB sub-lists
     int list;              // LIST_XY / LIST_XX / LIST_YY: selects tauf[] and sub[]
     int row_lo, row_hi;
@@ -190,8 +201,9 @@ struct ProcessArgs {
     const float4 *pos_b;
     const float *feat_b;
     const TileEntry *tiles;
-    const TileEntry *tiles_b;   // async xy: second buffer; st->xy_active picks (PROC_FLOW)
+    const TileEntry *tiles_b;   // async: second buffer; st->xy_active (PROC_FLOW) / sf_active (PROC_SELF) picks
     int async_xy;               // also: every kernel of the slot returns at once when st->stall
+    int async_self;             // PROC_SELF: 1 xx, 2 yy double-buffered
     uint2 *kept_ij;        // kept list: PROC_FLOW writes, PROC_STEP reads
     float *kept_a;
     uint32_t *kept_cnt;    // [PROC_WAVES] members recorded by each PROC_FLOW wave
@@ -330,6 +342,7 @@ CVO_HD void plan_lists(DevState *s, const DevParams &p)
     }
     for (int l = 0; l < 3; ++l) {
         if (l == LIST_XY && p.async_xy) continue;   // planned by plan_xy_async
+        if (l != LIST_XY && p.async_self) continue; // planned by plan_self_async
         const double need = (r_now + (l == LIST_XY ? travel : 0.0)) * 1.0001 + slack;
         const double lr = (double)s->list_r[l];
         const bool keep = margin > 0.0 && s->list_ok[l] && need <= lr &&
@@ -414,6 +427,48 @@ CVO_HD void plan_xy_async(DevState *s, const DevParams &p)
     s->xy_fail = 0;
 }
 
+// The acvo self lists the same way (PROC_SELF then rides in the flow launch and needs
+// its lists built BEFORE that launch).  They are rigid -- the pair distances do not
+// depend on the transform -- so only ell ages them: a list built for radius
+// (1 + margin) r serves until r_now outgrows it; the next one is built ahead when
+// half of that room is gone or ell has dropped far below.
+CVO_HD void plan_self_async(DevState *s, const DevParams &p)
+{
+    const double r_now = sqrt((double)s->kc.tau);
+    const double slack = 1.0e-4 * (1.0 + (double)s->xmax + (double)s->y0max);
+    const double margin = (double)p.list_margin;
+    const double r0 = r_now * 1.0001 + slack;
+    for (int l = 0; l < 2; ++l) {
+        const int fresh = s->sf_target[l];
+        if (fresh >= 0) s->sf_ok[l][fresh] = s->sf_fail[l] ? 0 : 1;
+        bool valid[2];
+        for (int b = 0; b < 2; ++b) valid[b] = s->sf_ok[l][b] && r0 <= (double)s->sf_r[l][b];
+        int use = -1;
+        if (fresh >= 0 && valid[fresh]) use = fresh;
+        else if (valid[s->sf_active[l]]) use = s->sf_active[l];
+        else if (valid[1 - s->sf_active[l]]) use = 1 - s->sf_active[l];
+        if (use < 0) s->stall = 1;
+        else s->sf_active[l] = use;
+        bool build = use < 0 || !(margin > 0.0);
+        if (!build) {
+            const double lr = (double)s->sf_r[l][use];
+            const double built_for = lr / (1.0 + margin);              // the radius it was built around
+            if (r0 > built_for + (double)p.build_at * (lr - built_for)) build = true;
+            if (lr > LIST_LOOSE * (1.0 + margin) * r0) build = true;
+        }
+        s->sf_target[l] = -1;
+        if (build) {
+            const int tgt = use < 0 ? 0 : 1 - use;
+            s->sf_target[l] = tgt;
+            s->sf_ok[l][tgt] = 0;
+            s->sf_r[l][tgt] = (float)(r0 * (1.0 + margin) * 1.000001);
+            s->sf_tauf_build[l] = (float)(((double)s->sf_r[l][tgt] * (double)s->sf_r[l][tgt] +
+                                           ((double)s->tauf[LIST_XX + l] - (double)s->kc.tau)) * 1.000001 + 1e-12);
+        }
+        s->sf_fail[l] = 0;
+    }
+}
+
 // Everything an iteration needs that derives from (R, T, ell).  The caller logs
 // the lists that are rebuilt (reuse[l] == 0) in DevState::built.
 CVO_HD void prepare_iteration(DevState *s, const DevParams &p)
@@ -426,6 +481,7 @@ CVO_HD void prepare_iteration(DevState *s, const DevParams &p)
     compute_filter_bounds(s, false);
     plan_lists(s, p);
     if (p.async_xy) plan_xy_async(s, p);
+    if (p.async_self) plan_self_async(s, p);   // (after the xy plan: it may add a stall)
     for (int q = 0; q < 2 * LIST_N; ++q) s->cnt[q] = 0u;
     // (the per-sub-list counters are zeroed by all threads of the calling kernel)
 }
@@ -446,6 +502,8 @@ void launch_step_twist_group(const ProcessArgs *a, int n, hipStream_t s);
 void launch_flow_build_group(const ProcessArgs *a, const FilterArgs *f, int n, hipStream_t s);
 void launch_flow_build3(const ProcessArgs &flow, const FilterArgs &xy, const FilterArgs &xx,
                         const FilterArgs &yy, hipStream_t s);
+void launch_flow_build6(const ProcessArgs &flow, const ProcessArgs &sxx, const ProcessArgs &syy,
+                        const FilterArgs &xy, const FilterArgs &xx, const FilterArgs &yy, hipStream_t s);
 constexpr int STEP_TWIST_ROWS_DIV = 4;   // k_step_twist writes nblk / 4 partial rows
 
 }   // namespace cvo_dev

@@ -120,10 +120,12 @@ __device__ __forceinline__ void filter_body(const FilterArgs &a, const unsigned 
     // thread's bounding spheres are all fetched before anything waits
     // (inside align() a list that is still valid is consumed again: nothing to do)
     // (async xy: this launch builds the buffer the plan step scheduled, if any)
-    const int target = a.async_xy ? a.st->xy_target : 0;
-    const int done_word = a.check_done ? (a.st->done | (a.async_xy ? (target < 0) : a.st->reuse[a.list])) : 0;
-    const int out_list = (a.async_xy && target == 1) ? LIST_XYB : a.list;
-    TileEntry *out_tiles = (a.async_xy && target == 1) ? a.tiles_b : a.tiles;
+    const int kind = a.async_xy;   // 0: synchronous list; 1: xy, 2: xx, 3: yy built ahead into the idle buffer
+    const int target = kind == 1 ? a.st->xy_target : (kind >= 2 ? a.st->sf_target[kind - 2] : 0);
+    const int done_word = a.check_done ? (a.st->done | (kind ? (target < 0) : a.st->reuse[a.list])) : 0;
+    const int out_list = kind == 1 ? (target == 1 ? (int)LIST_XYB : (int)LIST_XY)
+                                   : (kind >= 2 ? self_list_id(kind - 2, target == 1 ? 1 : 0) : a.list);
+    TileEntry *out_tiles = (kind && target == 1) ? a.tiles_b : a.tiles;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float *bop = reinterpret_cast<float *>(smem);
     float4 *xrow = reinterpret_cast<float4 *>(smem + (size_t)a.jt * 16);
@@ -138,7 +140,8 @@ __device__ __forceinline__ void filter_body(const FilterArgs &a, const unsigned 
     const float *Rt = a.st->Rt;
     const float *tt = a.st->t;
     const float cx = a.st->center[0], cy = a.st->center[1], cz = a.st->center[2];
-    const float tauf = a.async_xy ? a.st->tauf_build : a.st->tauf[a.list];
+    const float tauf = kind == 1 ? a.st->tauf_build
+                                 : (kind >= 2 ? a.st->sf_tauf_build[kind - 2] : a.st->tauf[a.list]);
     // ---- culling, for all the items of this block at once.  The clouds are in
     // Morton order, so the 64 rows of a wave and every run of 64 columns are
     // compact patches with precomputed bounding spheres (rigid motion moves a
@@ -636,15 +639,19 @@ __device__ __forceinline__ float eval_pair(const ProcessArgs &a, const KernConst
     return w;
 }
 
+// LDS of a list-kernel block: handed in, so that launches whose blocks play different
+// roles (flow pass, self passes, filter) overlay one allocation instead of adding them up
+constexpr int PROC_SMEM = 4 * NACC_MAX * 8 + 4 * PAIR_QUEUE * 8 + 4 * 64 * 8;
+
 template <int MODE>
-__device__ __forceinline__ void process_body(const ProcessArgs &a, const unsigned bid)
+__device__ __forceinline__ void process_body(const ProcessArgs &a, const unsigned bid, char *scratch)
 {
     if ((int)bid >= a.nblk) return;
     constexpr int NACC = NAcc<MODE>::n;
-    __shared__ double red[4 * NACC_MAX];
-    __shared__ uint2 pairq_all[(MODE == PROC_STEP) ? 1 : 4 * PAIR_QUEUE];
+    double *red = reinterpret_cast<double *>(scratch);
+    uint2 *pairq_all = reinterpret_cast<uint2 *>(scratch + 4 * NACC_MAX * 8);
     // every wave keeps its own copy of the exp table (no block barrier needed)
-    __shared__ double s_etab_all[(MODE == PROC_STEP) ? 1 : 4 * 64];
+    double *s_etab_all = reinterpret_cast<double *>(scratch + 4 * NACC_MAX * 8 + 4 * PAIR_QUEUE * 8);
     if (MODE != PROC_STEP) s_etab_all[threadIdx.x] = c_exp2_64[threadIdx.x & 63];
     const double *s_etab = s_etab_all + ((MODE == PROC_STEP) ? 0 : (threadIdx.x >> 6) * 64);
     const int tid = threadIdx.x, lane = tid & 63;
@@ -654,8 +661,9 @@ __device__ __forceinline__ void process_body(const ProcessArgs &a, const unsigne
     // (async xy: a stall slot only builds; PROC_FLOW reads the buffer in use)
     const int done_word = a.check_done ? (a.st->done | (a.async_xy ? a.st->stall : 0)) : 0;
     const KernConsts kc = a.st->kc;
-    const bool second = MODE == PROC_FLOW && a.async_xy && a.st->xy_active == 1;
-    const int in_list = second ? (int)LIST_XYB : a.list;
+    const bool second = (MODE == PROC_FLOW && a.async_xy && a.st->xy_active == 1) ||
+                        (MODE == PROC_SELF && a.async_self && a.st->sf_active[a.async_self - 1] == 1);
+    const int in_list = !second ? a.list : (MODE == PROC_FLOW ? (int)LIST_XYB : self_list_id(a.async_self - 1, 1));
     const TileEntry *in_tiles = second ? a.tiles_b : a.tiles;
 
     double acc[NACC];
@@ -780,7 +788,8 @@ __device__ __forceinline__ void process_body(const ProcessArgs &a, const unsigne
 template <int MODE>
 __global__ void __launch_bounds__(BLOCK) k_process(const Grp<ProcessArgs> grp)
 {
-    process_body<MODE>(grp.a[blockIdx.z], blockIdx.x);
+    __shared__ __attribute__((aligned(16))) char scratch[PROC_SMEM];
+    process_body<MODE>(grp.a[blockIdx.z], blockIdx.x, scratch);
 }
 
 // ---------------------------------------------------------------------------
@@ -798,9 +807,10 @@ struct BuildExtra {          // what a filter block needs beyond the flow pass's
 __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(6, 8)))
 k_flow_build(const Grp<ProcessArgs> gp, const Grp<BuildExtra> gx, const int np, const int nfb)
 {
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // (>= PROC_SMEM: the filter's carve is larger)
     const ProcessArgs &a = gp.a[blockIdx.z];
     if ((int)blockIdx.x < np) {
-        process_body<PROC_FLOW>(a, blockIdx.x);
+        process_body<PROC_FLOW>(a, blockIdx.x, smem);
         return;
     }
     const BuildExtra &x = gx.a[blockIdx.z];
@@ -1005,8 +1015,9 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(6, 8
 k_flow_build3(const ProcessArgs flow, const FilterArgs f0, const FilterArgs f1, const FilterArgs f2,
               const int np, const int n0, const int n1, const int n2)
 {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
     int b = (int)blockIdx.x;
-    if (b < np) { process_body<PROC_FLOW>(flow, (unsigned)b); return; }
+    if (b < np) { process_body<PROC_FLOW>(flow, (unsigned)b, smem); return; }
     b -= np;
     if (b < n0) { filter_body(f0, (unsigned)b, (unsigned)n0); return; }
     b -= n0;
@@ -1026,6 +1037,40 @@ void launch_flow_build3(const ProcessArgs &flow, const FilterArgs &xy, const Fil
     const int jt = std::max(xy.jt, std::max(xx.jt, yy.jt));
     hipLaunchKernelGGL(k_flow_build3, dim3((unsigned)(np + n0 + n1 + n2)), dim3(BLOCK), filter_smem_bytes(jt), s,
                        flow, xy, xx, yy, np, n0, n1, n2);
+}
+
+// acvo with the self lists built ahead as well (plan_self_async): flow pass, both self
+// passes and all three filters in ONE launch -- three dependent launches per iteration.
+__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(6, 8)))
+k_flow_build6(const ProcessArgs flow, const ProcessArgs sxx, const ProcessArgs syy, const FilterArgs f0,
+              const FilterArgs f1, const FilterArgs f2, const int np, const int n0, const int n1, const int n2)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int b = (int)blockIdx.x;
+    if (b < np) { process_body<PROC_FLOW>(flow, (unsigned)b, smem); return; }
+    b -= np;
+    if (b < np) { process_body<PROC_SELF>(sxx, (unsigned)b, smem); return; }
+    b -= np;
+    if (b < np) { process_body<PROC_SELF>(syy, (unsigned)b, smem); return; }
+    b -= np;
+    if (b < n0) { filter_body(f0, (unsigned)b, (unsigned)n0); return; }
+    b -= n0;
+    if (b < n1) { filter_body(f1, (unsigned)b, (unsigned)n1); return; }
+    b -= n1;
+    filter_body(f2, (unsigned)b, (unsigned)n2);
+}
+
+void launch_flow_build6(const ProcessArgs &flow, const ProcessArgs &sxx, const ProcessArgs &syy,
+                        const FilterArgs &xy, const FilterArgs &xx, const FilterArgs &yy, hipStream_t s)
+{
+    const long long cap = std::max<long long>(64, filter_blocks_max() / 2);
+    const int np = std::max(8, flow.nblk);
+    const int n0 = (int)filter_grid_x((long long)xy.gx * xy.gy, cap);
+    const int n1 = (int)filter_grid_x((long long)xx.gx * xx.gy, cap);
+    const int n2 = (int)filter_grid_x((long long)yy.gx * yy.gy, cap);
+    const int jt = std::max(xy.jt, std::max(xx.jt, yy.jt));
+    hipLaunchKernelGGL(k_flow_build6, dim3((unsigned)(3 * np + n0 + n1 + n2)), dim3(BLOCK),
+                       filter_smem_bytes(jt), s, flow, sxx, syy, xy, xx, yy, np, n0, n1, n2);
 }
 
 void launch_process_group(int mode, const ProcessArgs *a, int n, hipStream_t s)
@@ -1215,10 +1260,22 @@ __global__ void __launch_bounds__(BLOCK) k_post_step(const Grp<PostStepArgs> grp
     const bool built_failed = built_list >= 0 && st->cnt[2 * built_list + 1] != 0u;
     // (a stall slot runs no k_step_twist / k_post_flow, which is where an overflow of the
     // xx / yy lists is normally caught: lists built in a stall slot are checked here)
-    const bool xx_failed = stalled && st->cnt[2 * LIST_XX + 1] != 0u;
-    const bool yy_failed = stalled && st->cnt[2 * LIST_YY + 1] != 0u;
+    const bool aself = a.prm.async_self != 0;
+    int sf_list[2] = {-1, -1};   // the self lists built beside this slot
+    if (aself)
+        for (int l = 0; l < 2; ++l)
+            if (st->sf_target[l] >= 0) sf_list[l] = self_list_id(l, st->sf_target[l]);
+    const bool xx_failed = aself ? (sf_list[0] >= 0 && st->cnt[2 * sf_list[0] + 1] != 0u)
+                                 : (stalled && st->cnt[2 * LIST_XX + 1] != 0u);
+    const bool yy_failed = aself ? (sf_list[1] >= 0 && st->cnt[2 * sf_list[1] + 1] != 0u)
+                                 : (stalled && st->cnt[2 * LIST_YY + 1] != 0u);
+    const int xx_flag = aself ? sf_list[0] : (int)LIST_XX, yy_flag = aself ? sf_list[1] : (int)LIST_YY;
     __syncthreads();   // (everybody has read the flags before thread 0 changes the state)
-    if (threadIdx.x == 0) st->xy_fail = built_failed ? 1 : 0;
+    if (threadIdx.x == 0) {
+        st->xy_fail = built_failed ? 1 : 0;
+        st->sf_fail[0] = (aself && xx_failed) ? 1 : 0;
+        st->sf_fail[1] = (aself && yy_failed) ? 1 : 0;
+    }
     const long long c1 = a.dbg ? (long long)__builtin_readcyclecounter() : 0;
     if ((a.flags & POST_REDUCE) && !stalled)
         block_reduce_partials<NACC_STEP>(a.part_step, a.nblk, sh, st->red + RED_STEP);
@@ -1235,7 +1292,7 @@ __global__ void __launch_bounds__(BLOCK) k_post_step(const Grp<PostStepArgs> grp
         // the tile lists the next slot rebuilds are emptied; the others are kept
         if (st->done == RUNNING) {
             for (int l = 0; l < 3; ++l) {
-                if (st->reuse[l] || (async && l == LIST_XY)) continue;
+                if (st->reuse[l] || (async && l == LIST_XY) || (aself && l != LIST_XY)) continue;
                 for (int q = threadIdx.x; q < NSUB; q += BLOCK) a.st->sub[l][q] = 0u;
                 if (threadIdx.x == 0)
                     atomicOr(&a.st->built[l][(st->k >> 5) & 63], 1u << (st->k & 31));
@@ -1244,6 +1301,12 @@ __global__ void __launch_bounds__(BLOCK) k_post_step(const Grp<PostStepArgs> grp
                 const int l = st->xy_target ? (int)LIST_XYB : (int)LIST_XY;
                 for (int q = threadIdx.x; q < NSUB; q += BLOCK) a.st->sub[l][q] = 0u;
             }
+            if (aself)   // the self builds that start with the coming slot
+                for (int l = 0; l < 2; ++l)
+                    if (st->sf_target[l] >= 0) {
+                        const int id = self_list_id(l, st->sf_target[l]);
+                        for (int q = threadIdx.x; q < NSUB; q += BLOCK) a.st->sub[id][q] = 0u;
+                    }
             __syncthreads();
             // the list built beside this slot overflowed: the iteration itself was fine
             // and is kept; park so that the host enlarges the buffers
@@ -1251,8 +1314,8 @@ __global__ void __launch_bounds__(BLOCK) k_post_step(const Grp<PostStepArgs> grp
                 st->done = NEED_BIGGER_LIST;
                 // (prepare_iteration cleared the flags: the host needs them to know what to grow)
                 if (built_failed) st->cnt[2 * built_list + 1] = 1u;
-                if (xx_failed) st->cnt[2 * LIST_XX + 1] = 1u;
-                if (yy_failed) st->cnt[2 * LIST_YY + 1] = 1u;
+                if (xx_failed) st->cnt[2 * xx_flag + 1] = 1u;
+                if (yy_failed) st->cnt[2 * yy_flag + 1] = 1u;
             }
         }
     }
@@ -1357,6 +1420,10 @@ __global__ void k_prepare(DevState *st, const DevParams prm)
         for (int l = 0; l < 3; ++l) {
             st->list_ok[l] = 0;
             atomicOr(&st->built[l][(st->k >> 5) & 63], 1u << (st->k & 31));
+        }
+        for (int l = 0; l < 2; ++l) {      // async self lists: nothing built yet
+            st->sf_ok[l][0] = st->sf_ok[l][1] = 0;
+            st->sf_active[l] = 0; st->sf_target[l] = -1; st->sf_fail[l] = 0;
         }
         st->xy_ok[0] = st->xy_ok[1] = 0;   // async xy: the first slot only builds
         st->xy_active = 0;

@@ -5,7 +5,7 @@ ROOTDIR=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOTDIR/gpurun_out/trace_b$B
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o t -- python $ROOTDIR/tools/gpu_batch.py 10000 5 $B > $OUT/log.txt 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o t -- python $ROOTDIR/tools/gpu_batch.py ${N:-10000} 5 $B $MODE > $OUT/log.txt 2>&1
 tail -2 $OUT/log.txt
 python - <<PY
 import csv,collections,glob
