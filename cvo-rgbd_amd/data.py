@@ -204,3 +204,35 @@ def rel_pose_error(T_est, T_ref):
     dt = np.linalg.norm(T_est[:3, 3] - T_ref[:3, 3])
     ref_t = np.linalg.norm(T_ref[:3, 3])
     return ang / max(ref_ang, 1e-30), dt / max(ref_t, 1e-30)
+
+
+def synthetic_rgbd_frame(width=640, height=480, seed=0, texture=1.0, motion=(0.0, 0.0), holes=0.02):
+    """A synthetic RGB-D frame for the front end (SURVEY 8 f3 has no image data to
+    test on: the reference ships no frames): a smooth colour field with band-limited
+    texture of strength `texture` (0 = nearly flat, few gradients; 1 = desk-like;
+    3 = busy), shifted by `motion` pixels, and a slanted-plane depth map in TUM units
+    (5000 per metre) with a fraction `holes` of invalid (zero) pixels.
+    Returns (bgr h x w x 3 uint8, depth h x w uint16)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    y, x = np.mgrid[0:height, 0:width].astype(np.float64)
+    x = x + motion[0]
+    y = y + motion[1]
+    u, v = x / width, y / height
+    base = np.stack([120 + 70 * np.sin(5.0 * u + 1.0) * np.cos(3.0 * v),
+                     110 + 60 * np.cos(4.0 * v + 0.5),
+                     130 + 50 * np.sin(3.0 * u + 4.0 * v)], axis=-1)
+    tex = np.zeros((height, width))
+    for _ in range(24):   # a handful of oriented gratings and blobs
+        fx, fy = rng.uniform(-0.35, 0.35, 2)
+        ph = rng.uniform(0, 2 * np.pi)
+        cx, cy = rng.uniform(0, width), rng.uniform(0, height)
+        sig = rng.uniform(30, 160)
+        win = np.exp(-((x - cx) ** 2 + (y - cy) ** 2) / (2 * sig * sig))
+        tex += rng.uniform(4, 18) * win * np.sign(np.sin(fx * x + fy * y + ph))
+    img = base + texture * tex[..., None] * np.array([1.0, 0.8, 0.6])
+    img += rng.normal(0, 0.6 * min(texture, 1.0) + 0.05, img.shape)
+    bgr = np.clip(np.rint(img), 0, 255).astype(np.uint8)
+    z = 1.2 + 0.5 * u + 0.3 * v + 0.05 * np.sin(9 * u)
+    depth = np.clip(np.rint(z * 5000.0), 0, 65535).astype(np.uint16)
+    depth[rng.random((height, width)) < holes] = 0
+    return bgr, depth

@@ -60,3 +60,14 @@ def golden_json():
         with open(os.path.join(GOLDEN, name)) as fh:
             return json.load(fh)
     return load
+
+
+def low_texture_frame(pkg, seed=6, width=640, height=480):
+    """A nearly flat frame with a few low-contrast shapes: the selector keeps fewer than
+    num_want / 3 pixels, so the Canny top-up runs (ref src/pcd_generator.cpp:143-175)."""
+    bgr, dep = pkg.data.synthetic_rgbd_frame(width=width, height=height, seed=seed, texture=0.0, holes=0.01)
+    b = bgr.astype(np.int32)
+    b[height // 5:height * 3 // 5, width // 3:width * 2 // 5] += 10
+    b[height * 3 // 4:height * 4 // 5, width // 12:width * 11 // 12] -= 10
+    b[20:40, width - 140:width - 120] += 60
+    return np.clip(b, 0, 255).astype(np.uint8), dep

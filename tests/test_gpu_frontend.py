@@ -1,0 +1,177 @@
+"""GPU: the HIP front end (include/cvo_frontend.h) against its CPU
+restatement (oracle/frontend_oracle.c) on the same synthetic frames: every
+intermediate image and the cloud, bit for bit."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import low_texture_frame
+from oracle import pyoracle_fe as fo
+
+pytestmark = pytest.mark.gpu
+
+
+def _check_frame(pkg, gen, bgr, dep, seq, ftype, num_want=3000):
+    F = pkg.frontend
+    xyz, feat = gen.create_pointcloud(bgr, dep, seq, ftype)
+    ref = fo.create_pointcloud(bgr, dep, seq, ftype, num_want)
+    info = gen.info()
+    g = fo.gray(bgr)
+    assert np.array_equal(gen.read_stage(F.STAGE_GRAY), g)
+    assert np.array_equal(gen.read_stage(F.STAGE_HSV), fo.hsv(bgr))
+    _, dx0, dy0, ag = fo.pyramid(g)
+    assert np.array_equal(gen.read_stage(F.STAGE_DX0), dx0) and np.array_equal(gen.read_stage(F.STAGE_DY0), dy0)
+    for l, st in enumerate((F.STAGE_AG0, F.STAGE_AG1, F.STAGE_AG2)):
+        assert np.array_equal(gen.read_stage(st), ag[l]), "squared gradients, level %d" % l
+    assert np.array_equal(gen.read_stage(F.STAGE_THS), fo.thresholds(ag[0]))
+    assert np.array_equal(gen.read_stage(F.STAGE_MAP), ref["map"])
+    assert info["num_selected"] == ref["num_selected"]
+    assert info["num_points"] == len(ref["positions"]) == len(xyz)
+    assert np.array_equal(xyz.view(np.uint32), ref["positions"].view(np.uint32))
+    assert np.array_equal(feat.view(np.uint32), ref["features"].view(np.uint32))
+    return info
+
+
+@pytest.mark.parametrize("texture,seed", [(0.3, 11), (1.0, 12), (3.0, 13), (6.0, 14)])
+def test_vga_frames_match_the_oracle(pkg, texture, seed):
+    gen = pkg.frontend.PcdGenerator(640, 480)
+    bgr, dep = pkg.data.synthetic_rgbd_frame(seed=seed, texture=texture)
+    seen = []
+    for ftype in (pkg.frontend.FEATURES_RGB, pkg.frontend.FEATURES_HSV):
+        seen.append(_check_frame(pkg, gen, bgr, dep, 1, ftype))
+    assert seen[0]["num_selected"] == seen[1]["num_selected"]
+    gen.close()
+
+
+def test_both_selector_branches_are_exercised(pkg):
+    """sparse texture -> re-selection with a smaller potential; busy -> a larger one"""
+    gen = pkg.frontend.PcdGenerator(640, 480)
+    pots = {}
+    for texture, seed in ((0.3, 11), (6.0, 14)):
+        bgr, dep = pkg.data.synthetic_rgbd_frame(seed=seed, texture=texture)
+        gen.create_pointcloud(bgr, dep)
+        pots[texture] = gen.info()
+    assert pots[0.3]["reselected"] == 1 and pots[0.3]["pot_used"] < 3
+    assert pots[6.0]["pot_used"] >= 3
+    gen.close()
+
+
+@pytest.mark.parametrize("w,h", [(320, 256), (352, 300), (96, 64), (1280, 720)])
+def test_other_image_sizes(pkg, w, h):
+    gen = pkg.frontend.PcdGenerator(w, h, num_want=max(200, w * h // 100))
+    for seed in (1, 2):
+        bgr, dep = pkg.data.synthetic_rgbd_frame(width=w, height=h, seed=seed, texture=1.0)
+        _check_frame(pkg, gen, bgr, dep, 3, pkg.frontend.FEATURES_RGB, num_want=max(200, w * h // 100))
+    gen.close()
+
+
+def test_canny_top_up_matches(pkg):
+    gen = pkg.frontend.PcdGenerator(640, 480)
+    bgr, dep = low_texture_frame(pkg)
+    info = _check_frame(pkg, gen, bgr, dep, 1, pkg.frontend.FEATURES_RGB)
+    assert info["canny_used"] == 1 and info["num_selected"] < 1000
+    edges = fo.canny(fo.blur3(fo.gray(bgr)))
+    assert np.array_equal(gen.read_stage(pkg.frontend.STAGE_EDGES), edges)
+    # a normal frame afterwards on the same object: no top-up, still exact
+    bgr, dep = pkg.data.synthetic_rgbd_frame(seed=3, texture=1.0)
+    assert _check_frame(pkg, gen, bgr, dep, 1, pkg.frontend.FEATURES_HSV)["canny_used"] == 0
+    gen.close()
+
+
+def test_long_edge_chains_in_hysteresis(pkg):
+    """a spiral of weak edge pixels hanging off one strong pixel: many sweeps"""
+    h, w = 256, 256
+    bgr = np.full((h, w, 3), 90, np.uint8)
+    y, x = np.mgrid[0:h, 0:w]
+    r = np.hypot(x - 128, y - 128)
+    th = np.arctan2(y - 128, x - 128)
+    spiral = np.abs(((r / 14.0 - th / (2 * np.pi)) % 1.0) - 0.5) < 0.18
+    bgr[spiral] += 9
+    bgr[126:131, 126:131] = 200
+    dep = np.full((h, w), 6000, np.uint16)
+    gen = pkg.frontend.PcdGenerator(w, h, num_want=30000)
+    info = _check_frame(pkg, gen, bgr, dep, 1, pkg.frontend.FEATURES_RGB, num_want=30000)
+    assert info["canny_used"] == 1
+    edges = fo.canny(fo.blur3(fo.gray(bgr)))
+    assert np.count_nonzero(edges) > 2000
+    assert np.array_equal(gen.read_stage(pkg.frontend.STAGE_EDGES), edges)
+    gen.close()
+
+
+def test_argument_checks_and_capacity(pkg):
+    import ctypes as C
+    F = pkg.frontend
+    gen = F.PcdGenerator(640, 480)
+    with pytest.raises(ValueError):
+        gen.create_pointcloud(np.zeros((10, 10, 3), np.uint8), np.zeros((10, 10), np.uint16))
+    bgr, dep = pkg.data.synthetic_rgbd_frame(seed=1, texture=1.0)
+    pos = np.zeros((100, 3), np.float32); feat = np.zeros((100, 5), np.float32)
+    n = C.c_int(0)
+    fp = C.POINTER(C.c_float)
+    st = F.lib().cvo_fe_create_pointcloud(gen._h, bgr.ctypes.data_as(C.POINTER(C.c_uint8)), 640 * 3,
+                                          dep.ctypes.data_as(C.POINTER(C.c_uint16)), 640 * 2, 1, 1,
+                                          pos.ctypes.data_as(fp), feat.ctypes.data_as(fp), 100, C.byref(n))
+    assert st == -1 and n.value > 100 and b"capacity" in F.lib().cvo_fe_last_error(gen._h)
+    ref = fo.create_pointcloud(bgr, dep, 1, 1)
+    assert np.array_equal(pos, ref["positions"][:100])      # the first `capacity` points are delivered
+    st = F.lib().cvo_fe_create_pointcloud(gen._h, bgr.ctypes.data_as(C.POINTER(C.c_uint8)), 640,
+                                          dep.ctypes.data_as(C.POINTER(C.c_uint16)), 640 * 2, 1, 1,
+                                          pos.ctypes.data_as(fp), feat.ctypes.data_as(fp), 100, C.byref(n))
+    assert st == -1                                        # stride shorter than a row
+    h = C.c_void_p()
+    assert F.lib().cvo_fe_create(0, None, 8, 8, C.byref(h)) == -1
+    gen.close()
+
+
+def test_padded_rows(pkg):
+    """img_stride / depth_stride larger than a row (cv::Mat::step of a sub-image)"""
+    import ctypes as C
+    F = pkg.frontend
+    w, h = 320, 256
+    bgr, dep = pkg.data.synthetic_rgbd_frame(width=w, height=h, seed=8, texture=1.0)
+    big = np.zeros((h, w * 3 + 24), np.uint8); big[:, :w * 3] = bgr.reshape(h, -1)
+    bigd = np.zeros((h, w + 6), np.uint16); bigd[:, :w] = dep
+    gen = F.PcdGenerator(w, h)
+    pos = np.zeros((gen.capacity, 3), np.float32); feat = np.zeros((gen.capacity, 5), np.float32)
+    n = C.c_int(0)
+    fp = C.POINTER(C.c_float)
+    st = F.lib().cvo_fe_create_pointcloud(gen._h, big.ctypes.data_as(C.POINTER(C.c_uint8)), big.strides[0],
+                                          bigd.ctypes.data_as(C.POINTER(C.c_uint16)), bigd.strides[0], 2, 0,
+                                          pos.ctypes.data_as(fp), feat.ctypes.data_as(fp), gen.capacity, C.byref(n))
+    assert st == 0
+    ref = fo.create_pointcloud(bgr, dep, 2, 0)
+    assert n.value == len(ref["positions"]) and np.array_equal(pos[:n.value], ref["positions"])
+    assert np.array_equal(feat[:n.value], ref["features"])
+    gen.close()
+
+
+def test_directory_run_feeds_the_registration(pkg, tmp_path):
+    """ref src/cvo_main.cpp:20-66: PNG pair -> front end -> run_cvo -> pose line; the result
+    is the one the registration gives on the oracle's clouds of the same frames"""
+    Image = pytest.importorskip("PIL.Image")
+    os.makedirs(tmp_path / "rgb"); os.makedirs(tmp_path / "depth")
+    lines, frames = [], []
+    for k in range(3):
+        bgr, dep = pkg.data.synthetic_rgbd_frame(seed=21, texture=1.0, motion=(1.5 * k, 0.75 * k))
+        frames.append((bgr, dep))
+        stamp = "%.6f" % (1305031453.0 + k / 30.0)
+        Image.fromarray(bgr[:, :, ::-1]).save(tmp_path / "rgb" / (stamp + ".png"))
+        Image.fromarray(dep).save(tmp_path / "depth" / (stamp + ".png"))
+        lines.append("%s rgb/%s.png %s depth/%s.png" % (stamp, stamp, stamp, stamp))
+    (tmp_path / "assoc.txt").write_text("\n".join(lines) + "\n")
+    for cls, ftype in ((pkg.Cvo, 1), (pkg.Acvo, 0)):
+        reg = cls()
+        out = tmp_path / ("poses_%d.txt" % ftype)
+        with pkg.trajectory.TrajectoryWriter(str(out)) as wr:
+            assert pkg.frontend.run_directory(reg, str(tmp_path), 1, writer=wr) == 3
+        assert len(open(out).read().strip().split("\n")) == 3
+        ref = cls()
+        for bgr, dep in frames:
+            r = fo.create_pointcloud(bgr, dep, 1, ftype)
+            ref.run_cvo(r["positions"], r["features"])
+        assert np.array_equal(reg.accum_transform, ref.accum_transform)
+        assert reg.num_iterations == ref.num_iterations > 0
+        # the image moved by ~(1.5, 0.75) px per frame at ~1.5 m: a few millimetres
+        assert 1e-4 < np.linalg.norm(reg.accum_transform[:3, 3]) < 0.05
+        reg.close(); ref.close()
