@@ -33,7 +33,7 @@ struct FeCtrl {
     int do_sub;         // the map is sub-sampled
     int char_th;        // ... with this threshold on the random bytes
     int num_have;       // pixels chosen by the pass that counts
-    int removed;        // pixels the sub-sampling dropped
+    int in_map;         // pixels in the map when the cloud was emitted
     int pad2_[2];
     int num_points;     // selected pixels with depth
     int changed;        // hysteresis sweep flag
@@ -93,14 +93,22 @@ __device__ __forceinline__ int block_base(const int *cnt, int b)
     return s;
 }
 
-// load_image: cv::cvtColor RGB2GRAY and RGB2HSV on 8-bit data, channel 0 taken as R
-// (ref src/pcd_generator.cpp:389-390), OpenCV's fixed-point definitions; level 0 of
-// the pyramid is the grey image as float (ref :53-61).
-__global__ void __launch_bounds__(FE_BLOCK) k_fe_convert(const uint8_t *img, int np, const int *sdiv,
-                                                         const int *hdiv, uint8_t *gray, uint32_t *hsv, float *I0)
+// Level 0 in one pass.  load_image: cv::cvtColor RGB2GRAY and RGB2HSV on 8-bit data,
+// channel 0 taken as R (ref src/pcd_generator.cpp:389-390), OpenCV's fixed-point
+// definitions; the grey image as float is level 0 of the pyramid (ref :53-61); its
+// central differences on the flattened image for idx in [w, w*(h-1)) (ref :95-113; the
+// rest is zero here).  The four neighbours' grey values are recomputed from the colour
+// image instead of waiting for another launch.
+__global__ void __launch_bounds__(FE_BLOCK) k_fe_level0(const uint8_t *img, int w, int h, const int *sdiv,
+                                                        const int *hdiv, uint8_t *gray, uint32_t *hsv, float *I0,
+                                                        float *ag, float *dx_out, float *dy_out)
 {
     const int i = blockIdx.x * FE_BLOCK + threadIdx.x;
+    const int np = w * h;
     if (i >= np) return;
+    auto grey = [&](int j) {
+        return (img[3 * j] * 4899 + img[3 * j + 1] * 9617 + img[3 * j + 2] * 1868 + (1 << 13)) >> 14;
+    };
     const int r = img[3 * i], g = img[3 * i + 1], b = img[3 * i + 2];
     const int gr = (r * 4899 + g * 9617 + b * 1868 + (1 << 13)) >> 14;
     gray[i] = (uint8_t)gr;
@@ -114,35 +122,38 @@ __global__ void __launch_bounds__(FE_BLOCK) k_fe_convert(const uint8_t *img, int
     hh += hh < 0 ? 180 : 0;
     hh = min(max(hh, 0), 255);
     hsv[i] = (uint32_t)hh | ((uint32_t)s << 8) | ((uint32_t)v << 16);
+    float dx = 0.0f, dy = 0.0f, a = 0.0f;
+    if (i >= w && i < w * (h - 1)) {
+        dx = 0.5f * ((float)grey(i + 1) - (float)grey(i - 1));
+        dy = 0.5f * ((float)grey(i + w) - (float)grey(i - w));
+        a = dx * dx + dy * dy;
+    }
+    ag[i] = a;
+    dx_out[i] = dx;
+    dy_out[i] = dy;
 }
 
-// make_pyramid, down-sampling (ref src/pcd_generator.cpp:79-93)
-__global__ void __launch_bounds__(FE_BLOCK) k_fe_down(const float *prev, int pw, float *cur, int wl, int hl)
+// Level l > 0 in one pass: the 2x2 mean of level l-1 (ref src/pcd_generator.cpp:79-93)
+// and its squared gradient magnitude (ref :95-113); the neighbours' means are recomputed.
+__global__ void __launch_bounds__(FE_BLOCK) k_fe_level(const float *prev, int pw, float *cur, int wl, int hl, float *ag)
 {
     const int i = blockIdx.x * FE_BLOCK + threadIdx.x;
     if (i >= wl * hl) return;
-    const int y = i / wl, x = i - y * wl;
-    const float *p = prev + 2 * x + 2 * y * pw;
-    cur[i] = 0.25f * (((p[0] + p[1]) + p[pw]) + p[pw + 1]);
-}
-
-// make_pyramid, gradients (ref src/pcd_generator.cpp:95-113): central differences on
-// the flattened image for idx in [wl, wl*(hl-1)); the rest is zero here
-__global__ void __launch_bounds__(FE_BLOCK) k_fe_grad(const float *I, int wl, int hl, float *ag, float *dx_out,
-                                                      float *dy_out)
-{
-    const int idx = blockIdx.x * FE_BLOCK + threadIdx.x;
-    if (idx >= wl * hl) return;
-    float dx = 0.0f, dy = 0.0f, a = 0.0f;
-    if (idx >= wl && idx < wl * (hl - 1)) {
-        dx = 0.5f * (I[idx + 1] - I[idx - 1]);
-        dy = 0.5f * (I[idx + wl] - I[idx - wl]);
+    auto mean = [&](int j) {
+        const int y = j / wl, x = j - y * wl;
+        const float *p = prev + 2 * x + 2 * y * pw;
+        return 0.25f * (((p[0] + p[1]) + p[pw]) + p[pw + 1]);
+    };
+    cur[i] = mean(i);
+    float a = 0.0f;
+    if (i >= wl && i < wl * (hl - 1)) {
+        float dx = 0.5f * (mean(i + 1) - mean(i - 1));
+        float dy = 0.5f * (mean(i + wl) - mean(i - wl));
         if (!isfinite(dx)) dx = 0.0f;
         if (!isfinite(dy)) dy = 0.0f;
         a = dx * dx + dy * dy;
     }
-    ag[idx] = a;
-    if (dx_out) { dx_out[idx] = dx; dy_out[idx] = dy; }
+    ag[i] = a;
 }
 
 // PixelSelector::makeHists, first half (ref thirdparty/PixelSelector2.cpp:70-104): one
@@ -372,12 +383,17 @@ __global__ void __launch_bounds__(FE_BLOCK) k_fe_count(const float *map, const u
                                                        const FeCtrl *c, int *cnt)
 {
     if (MODE == 0 && !c->do_sub) return;
-    __shared__ int s_w[FE_BLOCK / 64];
-    const int f = fe_flags<MODE>(map, depth, np, blockIdx.x * FE_CHUNK + 4 * threadIdx.x);
+    __shared__ int s_w[2][FE_BLOCK / 64];
+    const int i0 = blockIdx.x * FE_CHUNK + 4 * threadIdx.x;
+    const int f = fe_flags<MODE>(map, depth, np, i0);
     const int v = wave_sum(__popc(f));
-    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = v;
+    // MODE 1 also counts the pixels in the map, with or without depth (cnt[gridDim.x + b]):
+    // their total is the selector's result (num_selected)
+    const int u = MODE == 1 ? wave_sum(__popc(fe_flags<0>(map, depth, np, i0))) : 0;
+    if ((threadIdx.x & 63) == 0) { s_w[0][threadIdx.x >> 6] = v; s_w[1][threadIdx.x >> 6] = u; }
     __syncthreads();
-    if (threadIdx.x == 0) cnt[blockIdx.x] = (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]);
+    if (threadIdx.x == 0) cnt[blockIdx.x] = (s_w[0][0] + s_w[0][1]) + (s_w[0][2] + s_w[0][3]);
+    if (MODE == 1 && threadIdx.x == 1) cnt[gridDim.x + blockIdx.x] = (s_w[1][0] + s_w[1][1]) + (s_w[1][2] + s_w[1][3]);
 }
 
 // makeMaps, sub-sampling (ref thirdparty/PixelSelector2.cpp:209-226): the rn-th chosen
@@ -391,15 +407,13 @@ __global__ void __launch_bounds__(FE_BLOCK) k_fe_subsample(float *map, int np, c
     int total;
     int rn = block_base(cnt, blockIdx.x) + block_excl_scan(__popc(f), &total);
     const int th = c->char_th;
-    int removed = 0;
 #pragma unroll
     for (int q = 0; q < 4; ++q)
         if (f & (1 << q)) {
-            if ((int)pattern[rn] > th) { map[i0 + q] = 0.0f; removed++; }
+            if ((int)pattern[rn] > th) map[i0 + q] = 0.0f;
             rn++;
         }
-    removed = wave_sum(removed);
-    if ((threadIdx.x & 63) == 0 && removed) atomicAdd(&c->removed, removed);
+    // (num_selected = what is left: counted by the next pass, k_fe_count<1>)
 }
 
 struct EmitArgs {
@@ -423,6 +437,10 @@ __global__ void __launch_bounds__(FE_BLOCK) k_fe_emit(const EmitArgs a)
     int total;
     int idx = block_base(a.cnt, blockIdx.x) + block_excl_scan(__popc(f), &total);
     if (blockIdx.x == a.nblocks - 1 && threadIdx.x == FE_BLOCK - 1) a.ctrl->num_points = idx + __popc(f);
+    if (blockIdx.x == 0) {   // (uniform per block) the size of the map
+        const int in_map = block_base(a.cnt + a.nblocks, a.nblocks);
+        if (threadIdx.x == 0) a.ctrl->in_map = in_map;
+    }
 #pragma unroll
     for (int q = 0; q < 4; ++q)
         if (f & (1 << q)) {
@@ -790,7 +808,7 @@ int cvo_fe_create(int device, void *stream, int width, int height, cvo_fe_ctx **
     ok = ok && dev_alloc(&ctx->pos, (size_t)ctx->cap * 3) == hipSuccess;
     ok = ok && dev_alloc(&ctx->feat, (size_t)ctx->cap * 5) == hipSuccess;
     ok = ok && dev_alloc(&ctx->sdiv, 256) == hipSuccess && dev_alloc(&ctx->hdiv, 256) == hipSuccess;
-    ok = ok && dev_alloc(&ctx->cnt, (size_t)ctx->nchunks) == hipSuccess && dev_alloc(&ctx->mag, np) == hipSuccess;
+    ok = ok && dev_alloc(&ctx->cnt, 2 * (size_t)ctx->nchunks) == hipSuccess && dev_alloc(&ctx->mag, np) == hipSuccess;
     ok = ok && dev_alloc(&ctx->grad, np) == hipSuccess && dev_alloc(&ctx->ctrl, 1) == hipSuccess;
     ok = ok && dev_alloc(&ctx->blk_cnt, 3 * ((size_t)((width + 3) / 4) * ((height + 3) / 4) / 4 + 2)) == hipSuccess;
     ok = ok && pin_alloc(&ctx->h_img, np * 3) == hipSuccess && pin_alloc(&ctx->h_depth, np) == hipSuccess;
@@ -836,11 +854,16 @@ int cvo_fe_create_pointcloud(cvo_fe_ctx *ctx, const uint8_t *img, size_t img_str
         return fail(ctx, CVO_HIP_ERR_INVALID, "create_pointcloud: bad argument");
     FE_HIP(hipSetDevice(ctx->device));
     hipStream_t s = ctx->stream;
-    for (int y = 0; y < h; ++y) {
-        std::memcpy(ctx->h_img + (size_t)y * w * 3, img + (size_t)y * img_stride, (size_t)w * 3);
-        std::memcpy(ctx->h_depth + (size_t)y * w, (const uint8_t *)depth + (size_t)y * depth_stride, (size_t)w * 2);
-    }
+    // pinned staging; the depth rows are staged while the colour image is on its way
+    if (img_stride == (size_t)w * 3) std::memcpy(ctx->h_img, img, (size_t)np * 3);
+    else
+        for (int y = 0; y < h; ++y)
+            std::memcpy(ctx->h_img + (size_t)y * w * 3, img + (size_t)y * img_stride, (size_t)w * 3);
     FE_HIP(hipMemcpyAsync(ctx->img, ctx->h_img, (size_t)np * 3, hipMemcpyHostToDevice, s));
+    if (depth_stride == (size_t)w * 2) std::memcpy(ctx->h_depth, depth, (size_t)np * 2);
+    else
+        for (int y = 0; y < h; ++y)
+            std::memcpy(ctx->h_depth + (size_t)y * w, (const uint8_t *)depth + (size_t)y * depth_stride, (size_t)w * 2);
     FE_HIP(hipMemcpyAsync(ctx->depth, ctx->h_depth, (size_t)np * 2, hipMemcpyHostToDevice, s));
     FeCtrl c0{};
     c0.pot[0] = 3;   // a selector starts every frame at potential 3 (ref PixelSelector2.cpp:39)
@@ -848,16 +871,11 @@ int cvo_fe_create_pointcloud(cvo_fe_ctx *ctx, const uint8_t *img, size_t img_str
     FE_HIP(hipMemcpyAsync(ctx->ctrl, ctx->h_ctrl, sizeof(FeCtrl), hipMemcpyHostToDevice, s));
 
     const FeDims &d = ctx->d;
-    hipLaunchKernelGGL(k_fe_convert, dim3(blocks(np)), dim3(FE_BLOCK), 0, s, ctx->img, np, ctx->sdiv, ctx->hdiv,
-                       ctx->gray, ctx->hsv, ctx->I[0]);
-    for (int l = 0; l < FE_LEVELS; ++l) {
-        const int nl = d.wl[l] * d.hl[l];
-        if (l > 0)
-            hipLaunchKernelGGL(k_fe_down, dim3(blocks(nl)), dim3(FE_BLOCK), 0, s, ctx->I[l - 1], d.wl[l - 1], ctx->I[l],
-                               d.wl[l], d.hl[l]);
-        hipLaunchKernelGGL(k_fe_grad, dim3(blocks(nl)), dim3(FE_BLOCK), 0, s, ctx->I[l], d.wl[l], d.hl[l], ctx->ag[l],
-                           l == 0 ? ctx->dx0 : nullptr, l == 0 ? ctx->dy0 : nullptr);
-    }
+    hipLaunchKernelGGL(k_fe_level0, dim3(blocks(np)), dim3(FE_BLOCK), 0, s, ctx->img, w, h, ctx->sdiv, ctx->hdiv,
+                       ctx->gray, ctx->hsv, ctx->I[0], ctx->ag[0], ctx->dx0, ctx->dy0);
+    for (int l = 1; l < FE_LEVELS; ++l)
+        hipLaunchKernelGGL(k_fe_level, dim3(blocks(d.wl[l] * d.hl[l])), dim3(FE_BLOCK), 0, s, ctx->I[l - 1],
+                           d.wl[l - 1], ctx->I[l], d.wl[l], d.hl[l], ctx->ag[l]);
     const int ncell = d.w32 * d.h32;
     hipLaunchKernelGGL(k_fe_hist, dim3(ncell), dim3(FE_BLOCK), 0, s, ctx->ag[0], w, h, d.w32, ctx->ths);
     hipLaunchKernelGGL(k_fe_smooth, dim3(blocks(ncell)), dim3(FE_BLOCK), 0, s, ctx->ths, d.w32, d.h32, ctx->ths_s);
@@ -879,7 +897,7 @@ int cvo_fe_create_pointcloud(cvo_fe_ctx *ctx, const uint8_t *img, size_t img_str
     int rc = run_emit(ctx, dataset_seq, feature_type);
     if (rc) return rc;
     // ref src/pcd_generator.cpp:141-144: fewer than a third of what was asked for?
-    const int num_selected = ctx->h_ctrl->num_have - ctx->h_ctrl->removed;
+    const int num_selected = ctx->h_ctrl->in_map;   // (before any top-up: that is what the reference tests)
     const bool canny = num_selected < ctx->num_want / 3;
     if (canny) {
         rc = run_canny(ctx);

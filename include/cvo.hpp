@@ -5,9 +5,10 @@
 // Same public surface: members init, iter, transform, prev_transform,
 // accum_transform; methods set_pcd(), align(), run_cvo(); acvo additionally
 // function_inner_product().  The reference's set_pcd()/run_cvo() take
-// cv::Mat RGB/depth images and run the pcd_generator front end (OpenCV + DSO
-// pixel selector, SURVEY 8 f3 -- outside this back end); here they take the
-// point_cloud the front end produces (positions + 5 features,
+// cv::Mat RGB/depth images and run the pcd_generator front end; here they take
+// either an image_view pair (plain pointers in place of cv::Mat; the front end
+// then runs on the GPU behind cvo_frontend.h) or directly the
+// point_cloud a front end produced (positions + 5 features,
 // ref include/data_type.h:59-71).  State carry-over between frames follows
 // the reference object exactly (ell and R,T are not reset in cvo; acvo resets
 // ell per pair): SURVEY 8a quirks 1-4, 10, 13.
@@ -18,9 +19,19 @@
 
 #include <string>
 
+#include "cvo_frontend.h"
 #include "cvo_hip.h"
 
 namespace cvo_hip {
+
+// Stand-in for the cv::Mat arguments of set_pcd() / run_cvo(): what cv::imread gives
+// -- rows x cols pixels, `step` bytes per row; the colour image 3 bytes per pixel in
+// file (B, G, R) order, the depth image one uint16 per pixel.
+struct image_view {
+    const void *data;
+    int rows, cols;
+    size_t step;
+};
 
 // Stand-in for Eigen::Affine3f: 4x4 row-major, matrix()(r,c) access.
 struct Affine3f {
@@ -64,6 +75,14 @@ class registration {
     void set_pcd(const point_cloud_view &pc);
     void align();
     void run_cvo(const point_cloud_view &pc);
+    // The reference's own signatures (ref include/cvo.hpp:171-192): images in, the front
+    // end (pcd_generator) runs first -- on the GPU.  The two paths are dead parameters
+    // there too (ref src/cvo.cpp:332,341).
+    void set_pcd(const int dataset_seq, const image_view &RGB_img, const image_view &dep_img,
+                 const std::string &pcd_pth = std::string(), const std::string &pcd_dso_pth = std::string());
+    void run_cvo(const int dataset_seq, const image_view &RGB_img, const image_view &dep_img,
+                 const std::string &pcd_pth = std::string(), const std::string &pcd_dso_pth = std::string());
+    int num_points_last_frame() const { return fe_points_; }
     // Batched mode: align() of `count` objects (each with its moving cloud set) in
     // one call, their kernel launches shared (cvo_hip_align_many).  The result of
     // every object is what its own align() would have given.
@@ -79,8 +98,13 @@ class registration {
     cvo_hip_state state_;
     bool have_moving_;
     int n_iter_;
+    cvo_fe_ctx *fe_;           // front end, created with the first image (its size is fixed then)
+    int fe_w_, fe_h_, fe_points_;
+    float *fe_pos_, *fe_feat_; // the cloud of the last frame (host)
+    int device_;
     void check(int status, const char *what);
     void publish();
+    point_cloud_view make_cloud(int dataset_seq, const image_view &rgb, const image_view &dep);
 };
 
 }   // namespace cvo_hip

@@ -175,3 +175,42 @@ def test_directory_run_feeds_the_registration(pkg, tmp_path):
         # the image moved by ~(1.5, 0.75) px per frame at ~1.5 m: a few millimetres
         assert 1e-4 < np.linalg.norm(reg.accum_transform[:3, 3]) < 0.05
         reg.close(); ref.close()
+
+
+@pytest.mark.parametrize("mode_name", ["cvo", "acvo"])
+def test_cpp_objects_take_images(pkg, tmp_path, mode_name):
+    """include/cvo.hpp: run_cvo(dataset_seq, RGB_img, dep_img, ...) as the reference's
+    drivers call it (ref src/cvo_main.cpp:52-64): the pose lines equal the Python path's"""
+    import io
+    import struct
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "cvo_image_demo")
+    lib = os.path.join(root, "cvo-rgbd_amd", "csrc")
+    subprocess.run(["g++", "-std=c++17", "-O1", "-I", os.path.join(root, "include"),
+                    os.path.join(root, "tests", "cpp", "cvo_image_demo.cpp"), "-L", lib, "-lcvo_hip",
+                    "-Wl,-rpath," + lib, "-o", exe], check=True)
+    w, h = 640, 480
+    frames = [pkg.data.synthetic_rgbd_frame(seed=31, texture=1.0, motion=(1.2 * k, -0.6 * k)) for k in range(3)]
+    names = ["1305031453.%06d" % (359684 + 33333 * k) for k in range(3)]
+    path = str(tmp_path / "frames.bin")
+    with open(path, "wb") as fh:
+        fh.write(struct.pack("<iii", len(frames), w, h))
+        for name, (bgr, dep) in zip(names, frames):
+            fh.write(name.encode().ljust(32, b"\0"))
+            fh.write(bgr.tobytes()); fh.write(dep.tobytes())
+    out = subprocess.run([exe, path, mode_name, "1"], check=True, capture_output=True, text=True).stdout
+    reg = (pkg.Acvo if mode_name == "acvo" else pkg.Cvo)()
+    gen = pkg.frontend.PcdGenerator(w, h)
+    buf = io.StringIO()
+    wr = pkg.trajectory.TrajectoryWriter(buf)
+    ftype = pkg.frontend.FEATURES_HSV if mode_name == "acvo" else pkg.frontend.FEATURES_RGB
+    for name, (bgr, dep) in zip(names, frames):
+        xyz, feat = gen.create_pointcloud(bgr, dep, 1, ftype)
+        reg.run_cvo(xyz, feat)
+        wr.append(name, reg.accum_transform)
+    want = buf.getvalue().strip().split("\n")
+    got = out.strip().split("\n")
+    assert got[:3] == want
+    assert got[3] == "points_last_frame %d iterations %d" % (len(xyz), reg.num_iterations)
+    reg.close(); gen.close()
