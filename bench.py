@@ -255,6 +255,11 @@ def main():
             out["sharded_allreduce"] = sharded
         if world == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(args, pkg, xf, ff, xm, fm, acvo)
+        if world == 1:
+            try:
+                out["frontend"] = frontend_leg(args, pkg)
+            except Exception as e:   # the headline line must survive a side leg
+                out["frontend"] = {"error": repr(e)}
         print(json.dumps(out), flush=True)
     for c in ctxs:
         c.close()
@@ -262,6 +267,31 @@ def main():
         if world > 1:
             dist.barrier()
         dist.destroy_process_group()
+    return out
+
+
+def frontend_leg(args, pkg, frames=100):
+    """Side leg (not part of `value`): the RGB-D front end on synthetic VGA
+    frames, host images in / host cloud out (PCIe inclusive), and its CPU restatement
+    (oracle, one thread) on the same frames."""
+    imgs = [pkg.data.synthetic_rgbd_frame(seed=100 + k, texture=1.0) for k in range(4)]
+    gen = pkg.frontend.PcdGenerator(640, 480)
+    for bgr, dep in imgs:
+        gen.create_pointcloud(bgr, dep)
+    t0 = time.perf_counter()
+    for k in range(frames):
+        xyz, _ = gen.create_pointcloud(*imgs[k % 4])
+    dt = (time.perf_counter() - t0) / frames
+    out = {"frames_per_s": 1.0 / dt, "ms_per_frame": dt * 1e3, "image": "640x480 synthetic, texture 1.0",
+           "points": int(len(xyz)), "includes": "staging + PCIe in, kernels, cloud out"}
+    gen.close()
+    if not args.no_cpu:
+        from oracle import pyoracle_fe as fo
+        t0 = time.perf_counter()
+        for k in range(4):
+            fo.create_pointcloud(*imgs[k])
+        out["cpu_ms_per_frame"] = (time.perf_counter() - t0) / 4 * 1e3
+        out["cpu_kind"] = "port, 1 thread"
     return out
 
 
