@@ -48,6 +48,7 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=15.0,
                     help="budget of the cpu_baseline leg (rank 0, N=1 only)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-frontend", action="store_true", help="skip the RGB-D front end side leg")
     ap.add_argument("--sharded-points", type=int, default=40000)
     ap.add_argument("--sharded-steps", type=int, default=2)
     ap.add_argument("--force-sharded-leg", action="store_true",
@@ -255,7 +256,10 @@ def main():
             out["sharded_allreduce"] = sharded
         if world == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(args, pkg, xf, ff, xm, fm, acvo)
-        if world == 1:
+        if world == 1 and not args.no_frontend:
+            for c in ctxs:   # (dozens of idle streams slow every other stream's submissions down)
+                c.close()
+            ctxs = []
             try:
                 out["frontend"] = frontend_leg(args, pkg)
             except Exception as e:   # the headline line must survive a side leg

@@ -23,7 +23,8 @@ def one(pattern):
 
 
 for pat, name in (("bench.json", "%s_bench.json"), ("stats/*kernel_stats.csv", "%s_kernel_stats.csv"),
-                  ("stats_batch/*kernel_stats.csv", "%s_kernel_stats_batch32.csv")):
+                  ("stats_batch/*kernel_stats.csv", "%s_kernel_stats_batch32.csv"),
+                  ("stats_fe/*kernel_stats.csv", "%s_kernel_stats_frontend.csv")):
     f = one(pat)
     if f:
         shutil.copy(f, os.path.join(dst, name % tag))

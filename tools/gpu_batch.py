@@ -13,6 +13,8 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 BS = [int(x) for x in sys.argv[3].split(",")] if len(sys.argv) > 3 else [1, 2, 4, 8, 16]
 ACVO = len(sys.argv) > 4 and sys.argv[4] == "acvo"
+IDLE = int(os.environ.get("IDLE_STREAMS", "0"))   # experiment: streams that exist but are never used
+idle = [torch.cuda.Stream() for _ in range(IDLE)]
 for B in BS:
     ctxs, streams = [], []
     for b in range(B):
