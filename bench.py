@@ -288,6 +288,23 @@ def frontend_leg(args, pkg, frames=100):
     dt = (time.perf_counter() - t0) / frames
     out = {"frames_per_s": 1.0 / dt, "ms_per_frame": dt * 1e3, "image": "640x480 synthetic, texture 1.0",
            "points": int(len(xyz)), "includes": "staging + PCIe in, kernels, cloud out"}
+    # the reference's driver loop end to end (ref src/cvo_main.cpp:36-66) on a synthetic
+    # sequence: image pair -> front end -> run_cvo -> pose
+    seq = [("%d" % k,) + pkg.data.synthetic_rgbd_frame(seed=77, texture=1.0, motion=(1.5 * k, 0.7 * k))
+           for k in range(12)]
+    stream = {}
+    for name, cls in (("cvo", pkg.Cvo), ("acvo", pkg.Acvo)):
+        reg = cls()
+        pkg.frontend.run_frames(reg, seq[:3], 1, generator=gen)   # warm-up
+        reg.close()
+        reg = cls()
+        t0 = time.perf_counter()
+        pkg.frontend.run_frames(reg, seq * 3, 1, generator=gen)
+        dt = (time.perf_counter() - t0) / (3 * len(seq))
+        reg.close()
+        stream[name] = {"frames_per_s": 1.0 / dt, "ms_per_frame": dt * 1e3}
+    out["stream"] = stream
+    out["stream_note"] = "36 synthetic VGA frames (12, three times over), ~3k points each, decoded images in host memory, one frame at a time"
     gen.close()
     if not args.no_cpu:
         from oracle import pyoracle_fe as fo

@@ -659,6 +659,9 @@ struct cvo_fe_ctx {
     FeCtrl *h_ctrl = nullptr;
     float *h_pos = nullptr, *h_feat = nullptr;
     cvo_fe_info info{};
+    int copied = 0;            // points of the cloud already on their way to h_pos / h_feat
+    bool pending = false;      // a frame was submitted and not collected yet
+    int p_seq = 0, p_ftype = 0;
     std::string err;
 };
 
@@ -719,7 +722,10 @@ int run_emit(cvo_fe_ctx *ctx, int dataset_seq, int feature_type)
     cvo_fe_camera(dataset_seq, e.cam);
     hipLaunchKernelGGL(k_fe_emit, dim3(ctx->nchunks), dim3(FE_BLOCK), 0, s, e);
     FE_HIP(hipMemcpyAsync(ctx->h_ctrl, ctx->ctrl, sizeof(FeCtrl), hipMemcpyDeviceToHost, s));
-    FE_HIP(hipStreamSynchronize(s));
+    // the cloud follows optimistically (its size is not known yet): enough for any normal frame
+    ctx->copied = std::min(ctx->cap, std::max(4096, 2 * ctx->num_want));
+    FE_HIP(hipMemcpyAsync(ctx->h_pos, ctx->pos, (size_t)ctx->copied * 3 * sizeof(float), hipMemcpyDeviceToHost, s));
+    FE_HIP(hipMemcpyAsync(ctx->h_feat, ctx->feat, (size_t)ctx->copied * 5 * sizeof(float), hipMemcpyDeviceToHost, s));
     return CVO_HIP_OK;
 }
 
@@ -842,16 +848,15 @@ int cvo_fe_set_num_want(cvo_fe_ctx *ctx, int num_want)
     return CVO_HIP_OK;
 }
 
-int cvo_fe_create_pointcloud(cvo_fe_ctx *ctx, const uint8_t *img, size_t img_stride, const uint16_t *depth,
-                             size_t depth_stride, int dataset_seq, int feature_type, float *positions,
-                             float *features, int capacity, int *num_points)
+int cvo_fe_submit(cvo_fe_ctx *ctx, const uint8_t *img, size_t img_stride, const uint16_t *depth,
+                  size_t depth_stride, int dataset_seq, int feature_type)
 {
     if (!ctx) return CVO_HIP_ERR_INVALID;
     const int w = ctx->d.w, h = ctx->d.h, np = ctx->np;
-    if (!img || !depth || !num_points || capacity < 0 || (capacity > 0 && (!positions || !features)) ||
-        img_stride < (size_t)w * 3 || depth_stride < (size_t)w * 2 ||
+    if (!img || !depth || img_stride < (size_t)w * 3 || depth_stride < (size_t)w * 2 ||
         (feature_type != CVO_FE_FEATURES_HSV && feature_type != CVO_FE_FEATURES_RGB))
-        return fail(ctx, CVO_HIP_ERR_INVALID, "create_pointcloud: bad argument");
+        return fail(ctx, CVO_HIP_ERR_INVALID, "submit: bad argument");
+    if (ctx->pending) return fail(ctx, CVO_HIP_ERR_INVALID, "submit: the previous frame was not collected");
     FE_HIP(hipSetDevice(ctx->device));
     hipStream_t s = ctx->stream;
     // pinned staging; the depth rows are staged while the colour image is on its way
@@ -893,16 +898,35 @@ int cvo_fe_create_pointcloud(cvo_fe_ctx *ctx, const uint8_t *img, size_t img_str
                        ctx->ctrl);
     FE_HIP(hipGetLastError());
     // the cloud is emitted at once; a frame that needs the edge top-up (rare: a nearly
-    // texture-free image) is noticed when the control block arrives and emitted again
-    int rc = run_emit(ctx, dataset_seq, feature_type);
+    // texture-free image) is noticed at collect(), when the control block has arrived, and
+    // emitted again
+    const int rc = run_emit(ctx, dataset_seq, feature_type);
     if (rc) return rc;
+    ctx->pending = true;
+    ctx->p_seq = dataset_seq;
+    ctx->p_ftype = feature_type;
+    return CVO_HIP_OK;
+}
+
+int cvo_fe_collect(cvo_fe_ctx *ctx, float *positions, float *features, int capacity, int *num_points)
+{
+    if (!ctx) return CVO_HIP_ERR_INVALID;
+    if (!num_points || capacity < 0 || (capacity > 0 && (!positions || !features)))
+        return fail(ctx, CVO_HIP_ERR_INVALID, "collect: bad argument");
+    if (!ctx->pending) return fail(ctx, CVO_HIP_ERR_INVALID, "collect: no frame was submitted");
+    ctx->pending = false;
+    FE_HIP(hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    FE_HIP(hipStreamSynchronize(s));
+    int rc = CVO_HIP_OK;
     // ref src/pcd_generator.cpp:141-144: fewer than a third of what was asked for?
     const int num_selected = ctx->h_ctrl->in_map;   // (before any top-up: that is what the reference tests)
     const bool canny = num_selected < ctx->num_want / 3;
     if (canny) {
         rc = run_canny(ctx);
-        if (!rc) rc = run_emit(ctx, dataset_seq, feature_type);
+        if (!rc) rc = run_emit(ctx, ctx->p_seq, ctx->p_ftype);
         if (rc) return rc;
+        FE_HIP(hipStreamSynchronize(s));
     }
     const FeCtrl &c = *ctx->h_ctrl;
     ctx->info.num_selected = num_selected;
@@ -912,15 +936,30 @@ int cvo_fe_create_pointcloud(cvo_fe_ctx *ctx, const uint8_t *img, size_t img_str
     ctx->info.num_points = c.num_points;
     *num_points = c.num_points;
     const int ncopy = std::min(std::min(c.num_points, capacity), ctx->cap);
-    if (ncopy > 0) {
-        FE_HIP(hipMemcpyAsync(ctx->h_pos, ctx->pos, (size_t)ncopy * 3 * sizeof(float), hipMemcpyDeviceToHost, s));
-        FE_HIP(hipMemcpyAsync(ctx->h_feat, ctx->feat, (size_t)ncopy * 5 * sizeof(float), hipMemcpyDeviceToHost, s));
+    if (ncopy > ctx->copied) {   // an unusually large cloud: fetch the rest
+        const size_t from = (size_t)ctx->copied, more = (size_t)(ncopy - ctx->copied);
+        FE_HIP(hipMemcpyAsync(ctx->h_pos + from * 3, ctx->pos + from * 3, more * 3 * sizeof(float), hipMemcpyDeviceToHost, s));
+        FE_HIP(hipMemcpyAsync(ctx->h_feat + from * 5, ctx->feat + from * 5, more * 5 * sizeof(float), hipMemcpyDeviceToHost, s));
         FE_HIP(hipStreamSynchronize(s));
+    }
+    if (ncopy > 0) {
         std::memcpy(positions, ctx->h_pos, (size_t)ncopy * 3 * sizeof(float));
         std::memcpy(features, ctx->h_feat, (size_t)ncopy * 5 * sizeof(float));
     }
     if (c.num_points > ncopy) return fail(ctx, CVO_HIP_ERR_INVALID, "create_pointcloud: more points than capacity");
     return CVO_HIP_OK;
+}
+
+int cvo_fe_create_pointcloud(cvo_fe_ctx *ctx, const uint8_t *img, size_t img_stride, const uint16_t *depth,
+                             size_t depth_stride, int dataset_seq, int feature_type, float *positions,
+                             float *features, int capacity, int *num_points)
+{
+    if (!ctx) return CVO_HIP_ERR_INVALID;
+    if (!num_points || capacity < 0 || (capacity > 0 && (!positions || !features)))
+        return fail(ctx, CVO_HIP_ERR_INVALID, "create_pointcloud: bad argument");
+    const int rc = cvo_fe_submit(ctx, img, img_stride, depth, depth_stride, dataset_seq, feature_type);
+    if (rc) return rc;
+    return cvo_fe_collect(ctx, positions, features, capacity, num_points);
 }
 
 int cvo_fe_get_info(const cvo_fe_ctx *ctx, cvo_fe_info *out)

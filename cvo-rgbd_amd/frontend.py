@@ -27,7 +27,7 @@ FEATURES_HSV, FEATURES_RGB = 0, 1
  STAGE_EDGES) = range(10)
 
 SYMBOLS = ("cvo_fe_create", "cvo_fe_destroy", "cvo_fe_last_error", "cvo_fe_set_num_want",
-           "cvo_fe_create_pointcloud", "cvo_fe_get_info", "cvo_fe_read_stage", "cvo_fe_random_pattern",
+           "cvo_fe_create_pointcloud", "cvo_fe_submit", "cvo_fe_collect", "cvo_fe_get_info", "cvo_fe_read_stage", "cvo_fe_random_pattern",
            "cvo_fe_camera")
 
 
@@ -52,6 +52,8 @@ def lib():
         L.cvo_fe_set_num_want.argtypes = [vp, C.c_int]
         L.cvo_fe_create_pointcloud.argtypes = [vp, u8p, C.c_size_t, u16p, C.c_size_t, C.c_int, C.c_int, fp, fp,
                                                C.c_int, C.POINTER(C.c_int)]
+        L.cvo_fe_submit.argtypes = [vp, u8p, C.c_size_t, u16p, C.c_size_t, C.c_int, C.c_int]
+        L.cvo_fe_collect.argtypes = [vp, fp, fp, C.c_int, C.POINTER(C.c_int)]
         L.cvo_fe_get_info.argtypes = [vp, C.POINTER(Info)]
         L.cvo_fe_read_stage.argtypes = [vp, C.c_int, vp, C.c_size_t]
         L.cvo_fe_random_pattern.argtypes = [C.c_int, u8p]
@@ -117,6 +119,25 @@ class PcdGenerator:
         self._chk(st, "create_pointcloud")
         return self._pos[:n.value].copy(), self._feat[:n.value].copy()
 
+    def submit(self, bgr, depth, dataset_seq=1, feature_type=FEATURES_RGB):
+        """First half of create_pointcloud: stage the images, enqueue everything, return."""
+        bgr = np.ascontiguousarray(bgr, np.uint8)
+        depth = np.ascontiguousarray(depth, np.uint16)
+        if bgr.shape != (self.height, self.width, 3) or depth.shape != (self.height, self.width):
+            raise ValueError("expected a %dx%dx3 uint8 image and a %dx%d uint16 depth map"
+                             % (self.height, self.width, self.height, self.width))
+        self._chk(lib().cvo_fe_submit(self._h, bgr.ctypes.data_as(C.POINTER(C.c_uint8)), self.width * 3,
+                                      depth.ctypes.data_as(C.POINTER(C.c_uint16)), self.width * 2,
+                                      int(dataset_seq), int(feature_type)), "submit")
+
+    def collect(self):
+        """Second half: wait for the submitted frame and return its cloud."""
+        n = C.c_int(0)
+        self._chk(lib().cvo_fe_collect(self._h, self._pos.ctypes.data_as(C.POINTER(C.c_float)),
+                                       self._feat.ctypes.data_as(C.POINTER(C.c_float)), self.capacity, C.byref(n)),
+                  "collect")
+        return self._pos[:n.value].copy(), self._feat[:n.value].copy()
+
     def info(self):
         out = Info()
         self._chk(lib().cvo_fe_get_info(self._h, C.byref(out)), "get_info")
@@ -173,6 +194,38 @@ def load_img(rgb_path, depth_path):
     return np.ascontiguousarray(rgb[:, :, ::-1]), np.ascontiguousarray(dep)
 
 
+def run_frames(registration, frames, dataset_seq, writer=None, generator=None, prefetch=False):
+    """The driver loop on decoded frames: `frames` yields (name, bgr, depth).  With
+    `prefetch` frame k+1 is in the front end while frame k is being registered (the
+    results are the same either way).  Off by default: measured on MI355X it wins 3 % when
+    the two streams share a hardware queue and loses up to 40 % when they do not (the front
+    end's launches then cut into the registration's latency-bound launch chain).
+    Returns the number of frames."""
+    ftype = FEATURES_HSV if registration.params.mode == capi.MODE_ACVO else FEATURES_RGB
+    gen = generator
+    it = iter(frames)
+    count = 0
+    cur = next(it, None)
+    if cur is None:
+        return 0
+    if gen is None:
+        gen = PcdGenerator(cur[1].shape[1], cur[1].shape[0])
+    gen.submit(cur[1], cur[2], dataset_seq, ftype)
+    while cur is not None:
+        xyz, feat = gen.collect()
+        nxt = next(it, None)
+        if nxt is not None and prefetch:
+            gen.submit(nxt[1], nxt[2], dataset_seq, ftype)
+        registration.run_cvo(xyz, feat)
+        if writer is not None and registration.init:
+            writer.append(cur[0], registration.accum_transform)
+        if nxt is not None and not prefetch:
+            gen.submit(nxt[1], nxt[2], dataset_seq, ftype)
+        count += 1
+        cur = nxt
+    return count
+
+
 def run_directory(registration, folder, dataset_seq, writer=None, assoc="assoc.txt", limit=None,
                   generator=None):
     """The reference's main loop (ref src/cvo_main.cpp:20-66, adaptive_cvo_main.cpp): every
@@ -182,14 +235,10 @@ def run_directory(registration, folder, dataset_seq, writer=None, assoc="assoc.t
     names, rgbs, deps = load_file_name(os.path.join(folder, assoc))
     if limit is not None:
         names, rgbs, deps = names[:limit], rgbs[:limit], deps[:limit]
-    ftype = FEATURES_HSV if registration.params.mode == capi.MODE_ACVO else FEATURES_RGB
-    gen = generator
-    for name, r, d in zip(names, rgbs, deps):
-        bgr, depth = load_img(os.path.join(folder, r), os.path.join(folder, d))
-        if gen is None:
-            gen = PcdGenerator(bgr.shape[1], bgr.shape[0])
-        xyz, feat = gen.create_pointcloud(bgr, depth, dataset_seq, ftype)
-        registration.run_cvo(xyz, feat)
-        if writer is not None and registration.init:
-            writer.append(name, registration.accum_transform)
-    return len(names)
+
+    def decoded():
+        for name, r, d in zip(names, rgbs, deps):
+            bgr, depth = load_img(os.path.join(folder, r), os.path.join(folder, d))
+            yield name, bgr, depth
+
+    return run_frames(registration, decoded(), dataset_seq, writer=writer, generator=generator)

@@ -78,7 +78,16 @@ int cvo_fe_create_pointcloud(cvo_fe_ctx *ctx, const uint8_t *img, size_t img_str
                              size_t depth_stride, int dataset_seq, int feature_type, float *positions,
                              float *features, int capacity, int *num_points);
 
-/* what the last create_pointcloud did */
+/* The same in two halves, for callers that have other work while the GPU is busy (the
+ * drivers register frame k while frame k+1 is in the front end): submit() stages the
+ * images, enqueues every kernel and the copies back and returns; collect() waits, runs the
+ * rare edge top-up if the frame needs it, and delivers the cloud.  One frame in flight per
+ * context; the image buffers may be re-used as soon as submit() returns. */
+int cvo_fe_submit(cvo_fe_ctx *ctx, const uint8_t *img, size_t img_stride, const uint16_t *depth,
+                  size_t depth_stride, int dataset_seq, int feature_type);
+int cvo_fe_collect(cvo_fe_ctx *ctx, float *positions, float *features, int capacity, int *num_points);
+
+/* what the last create_pointcloud / collect did */
 int cvo_fe_get_info(const cvo_fe_ctx *ctx, cvo_fe_info *out);
 /* copy an intermediate image of the last create_pointcloud to host memory */
 int cvo_fe_read_stage(cvo_fe_ctx *ctx, int stage, void *out, size_t bytes);

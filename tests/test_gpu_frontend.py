@@ -214,3 +214,37 @@ def test_cpp_objects_take_images(pkg, tmp_path, mode_name):
     assert got[:3] == want
     assert got[3] == "points_last_frame %d iterations %d" % (len(xyz), reg.num_iterations)
     reg.close(); gen.close()
+
+
+def test_submit_collect_and_prefetched_stream(pkg):
+    """cvo_fe_submit / cvo_fe_collect: same cloud as the one-call form; one frame in flight;
+    the driver loop with prefetch gives the poses of the plain loop"""
+    import io
+    F = pkg.frontend
+    gen = F.PcdGenerator(640, 480)
+    frames = [("%d.0" % k,) + pkg.data.synthetic_rgbd_frame(seed=41, texture=1.0, motion=(1.0 * k, 0.5 * k))
+              for k in range(4)]
+    xyz, feat = gen.create_pointcloud(frames[0][1], frames[0][2], 1, F.FEATURES_HSV)
+    gen.submit(frames[0][1], frames[0][2], 1, F.FEATURES_HSV)
+    with pytest.raises(pkg.capi.CvoHipError):
+        gen.submit(frames[1][1], frames[1][2], 1, F.FEATURES_HSV)     # one frame in flight
+    x2, f2 = gen.collect()
+    assert np.array_equal(xyz, x2) and np.array_equal(feat, f2)
+    with pytest.raises(pkg.capi.CvoHipError):
+        gen.collect()                                                  # nothing submitted
+    # a frame that needs the top-up, through the split form
+    bgr, dep = low_texture_frame(pkg)
+    gen.submit(bgr, dep, 1, F.FEATURES_RGB)
+    x3, f3 = gen.collect()
+    ref = fo.create_pointcloud(bgr, dep, 1, 1)
+    assert gen.info()["canny_used"] == 1 and np.array_equal(x3, ref["positions"]) and np.array_equal(f3, ref["features"])
+    poses = []
+    for prefetch in (True, False):
+        reg = pkg.Acvo()
+        buf = io.StringIO()
+        assert F.run_frames(reg, frames, 1, writer=pkg.trajectory.TrajectoryWriter(buf), generator=gen,
+                            prefetch=prefetch) == 4
+        poses.append(buf.getvalue())
+        reg.close()
+    assert poses[0] == poses[1] and len(poses[0].strip().split("\n")) == 4
+    gen.close()
