@@ -13,6 +13,6 @@ behind include/cvo_frontend.h).  There is no CPU fallback: without the built lib
 HIP device every compute call raises.
 """
 from . import capi, data, frontend, registration, trajectory  # noqa: F401
-from .registration import Acvo, Cvo  # noqa: F401
+from .registration import Acvo, Cvo, RkhsMatlab  # noqa: F401
 
-__all__ = ["capi", "data", "frontend", "registration", "trajectory", "Cvo", "Acvo"]
+__all__ = ["capi", "data", "frontend", "registration", "trajectory", "Cvo", "Acvo", "RkhsMatlab"]

@@ -8,7 +8,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libcvo_hip.so")
 _LIB = None
 
-MODE_CVO, MODE_ACVO = 0, 1
+MODE_CVO, MODE_ACVO, MODE_MATLAB = 0, 1, 2   # MATLAB: default_params() only (mode CVO + color_scale)
 FEAT_COLMAJOR, FEAT_ROWMAJOR = 0, 1
 
 # every symbol include/cvo_hip.h declares (tests check the library exports all)
@@ -31,7 +31,7 @@ class Params(C.Structure):
         ("ell_init", C.c_float), ("ell_min", C.c_float), ("ell_max_init", C.c_float),
         ("sigma", C.c_float), ("sp_thres", C.c_float), ("c_sp_thres", C.c_float),
         ("c", C.c_float), ("d", C.c_float), ("c_ell", C.c_float), ("c_sigma", C.c_float),
-        ("min_step", C.c_float), ("eps", C.c_float), ("eps_2", C.c_float), ("pad_", C.c_float),
+        ("min_step", C.c_float), ("eps", C.c_float), ("eps_2", C.c_float), ("color_scale", C.c_float),
         ("dl_step", C.c_double),
     ]
 

@@ -195,6 +195,7 @@ DevParams make_dev_params(const cvo_hip_params &p)
     d.s2_d = (double)s2;
     d.cs2_d = (double)cs2;
     d.dl_step = p.dl_step;
+    d.color_scale = p.color_scale;
     // tile-list re-use (cvo_device.h plan_lists); CVO_HIP_LIST_MARGIN=0 rebuilds every iteration
     d.build_at = 0.5f;
     if (const char *e = getenv("CVO_HIP_BUILD_AT")) {
@@ -563,6 +564,7 @@ int enqueue_process(cvo_hip_ctx *ctx, int mode, int list, DevBuf &part, const fl
     a.first_counted = first_counted;
     a.tf_a = tf_a; a.tf_b = tf_b;
     a.check_done = check_done;
+    a.weight = ctx->prm.color_scale > 0.0f ? 1 : 0;   // the MATLAB object's weight: its own instantiation
     if (ctx->in_loop && ctx->use_async) {
         a.async_xy = 1;
         a.tiles_b = (const TileEntry *)ctx->lists[LIST_XYB].a.p;
@@ -994,9 +996,10 @@ int cvo_hip_device_count(int *count)
 
 int cvo_hip_default_params(int mode, cvo_hip_params *p)
 {
-    if (!p || (mode != CVO_HIP_MODE_CVO && mode != CVO_HIP_MODE_ACVO)) return CVO_HIP_ERR_INVALID;
+    if (!p || (mode != CVO_HIP_MODE_CVO && mode != CVO_HIP_MODE_ACVO && mode != CVO_HIP_MODE_MATLAB))
+        return CVO_HIP_ERR_INVALID;
     std::memset(p, 0, sizeof(*p));
-    p->mode = mode;
+    p->mode = mode == CVO_HIP_MODE_MATLAB ? CVO_HIP_MODE_CVO : mode;
     p->max_iter = 2000;
     p->sigma = 0.1f;
     p->c = 7.0f;
@@ -1021,6 +1024,13 @@ int cvo_hip_default_params(int mode, cvo_hip_params *p)
         p->c_sp_thres = 8e-3f;
         p->c_ell = 200.0f;
         p->dl_step = 0.0;
+    }
+    if (mode == CVO_HIP_MODE_MATLAB) {   // ref rkhs_se3_registration.m:10-28
+        p->sp_thres = 1e-3f;
+        p->c_sp_thres = 1e-3f;
+        p->eps = 5e-4f;
+        p->eps_2 = 1e-4f;
+        p->color_scale = 1e-5f;
     }
     return CVO_HIP_OK;
 }
@@ -1358,7 +1368,9 @@ int job_begin(AlignJob &j)
         ctx->proc_blocks = ctx->proc_blocks_default =
             ((double)ctx->fixed.n * (double)ctx->moving.n <= 2.5e7) ? PROC_BLOCKS / 2 : PROC_BLOCKS;
     // (use_async_self below; from ~20k x 20k on a build is too long to hide beside one flow pass)
+    // (the MATLAB weight exists as a classic k_process launch only)
     ctx->use_async = ctx->allow_async && !ctx->crowded && !ctx->profiling && !multi_rank(ctx) &&
+                     !(ctx->prm.color_scale > 0.0f) &&
                      (double)ctx->fixed.n * (double)ctx->moving.n <= 2.0e8;
     ctx->use_async_self = ctx->use_async && ctx->allow_async_self && ctx->lone &&
                           ctx->prm.mode == CVO_HIP_MODE_ACVO;
@@ -1504,7 +1516,7 @@ int job_pump(AlignJob &j, bool block)
 // mode, single rank, no per-launch events) on the leader's stream; a member
 // that has stopped keeps returning at its first load until it is dropped from
 // the launches at the next poll.
-bool fusable(const cvo_hip_ctx *c) { return !c->profiling && !multi_rank(c); }
+bool fusable(const cvo_hip_ctx *c) { return !c->profiling && !multi_rank(c) && !(c->prm.color_scale > 0.0f); }
 
 // issue one iteration of all members, slot by slot
 void launch_fused(const std::vector<std::vector<RecOp>> &ops, hipStream_t s)

@@ -90,7 +90,7 @@ struct KernConsts {
     float inv_d;      // 1/d
     float inv_l3;     // 1/(ell*ell*ell)
     float cb, cg, cd; // step-size scalings: -2t, -t, 2t with t = 1/(2 l^2)
-    float pad_;
+    float cscale;     // > 0: MATLAB weight (linear colour inner product, threshold on K only)
     double s2_d;      // (double)(sigma*sigma)
     double cs2_d;     // (double)(c_sigma*c_sigma)
     double ninv_2l2;  // -1/(2 l^2)
@@ -111,7 +111,7 @@ struct DevParams {
     int32_t async_xy;    // the xy list is double-buffered and built concurrently (plan_xy_async)
     float build_at;      // ... a new build is scheduled when this fraction of the margin in use is gone
     int32_t async_self;  // acvo: the xx / yy lists are double-buffered too and PROC_SELF rides in the flow launch
-    int32_t pad3_;
+    float color_scale;   // cvo_hip_params::color_scale
     double s2_d, cs2_d, dl_step;
 };
 
@@ -224,6 +224,7 @@ struct ProcessArgs {
     int first_counted;     // PROC_SELF: rows whose caller index is below contribute 0 to the sum
     int tf_a, tf_b;
     int check_done;
+    int weight;            // PROC_FLOW: 0 the C++ pair weight, 1 the MATLAB object's (classic launches only)
 };
 
 // k_post flags
@@ -269,7 +270,10 @@ CVO_HD KernConsts make_kconsts(const DevParams &p, float ell)
     k.cb = (float)(-2.0 * temp_coef);
     k.cg = -temp_coef;
     k.cd = (float)(2.0 * temp_coef);
-    k.pad_ = 0.0f;
+    k.cscale = p.color_scale;
+    // MATLAB keeps K >= sp (ref rkhs_se3_registration.m:70): the radius is widened by 1e-5 so
+    // that the exact test on K in pair_weight decides, not the rounding of tau
+    if (k.cscale > 0.0f) k.tau = (float)((double)k.tau * 1.00001);
     k.s2_d = p.s2_d;
     k.cs2_d = p.cs2_d;
     k.ninv_2l2 = -1.0 / (2.0 * l * l);

@@ -438,11 +438,22 @@ __device__ __forceinline__ double exp_neg(double x, const double *tab /* LDS cop
     return __builtin_ldexp(__builtin_fma(s, p, s), k >> 6);
 }
 
-// pair weight for a pair that passed d2 < tau; 0 if dropped (ref cvo.cpp:143-153)
+// pair weight for a pair that passed d2 < tau; 0 if dropped.
+// WEIGHT 0: the C++ objects' (ref cvo.cpp:143-153).  WEIGHT 1: the MATLAB object's (SURVEY 8
+// a9, ref rkhs_se3_registration.m:40-73,125-127): linear colour inner product, threshold on
+// K alone -- a separate instantiation (k_process<PROC_FLOW, 1>), so that the kernels of the
+// main path carry nothing of it (a run-time branch here cost them 6 %).
+template <int WEIGHT>
 __device__ __forceinline__ float pair_weight(const KernConsts &kc, float d2, const float4 fa0,
                                              const float fa4, const float4 fb0, const float fb4,
                                              const double *etab)
 {
+    if (WEIGHT == 1) {
+        const float km = (float)(kc.s2_d * exp_neg((double)d2 * kc.ninv_2l2, etab));
+        if (!(km >= kc.sp)) return 0.0f;
+        const float ci = kc.cscale * ((fa0.x * fb0.x + fa0.y * fb0.y) + fa0.z * fb0.z);
+        return ci * km;
+    }
     const float d2c = d2_feat(fa0, fa4, fb0, fb4);
     if (!(d2c < kc.tau_c)) return 0.0f;
     const float k = (float)(kc.s2_d * exp_neg((double)d2 * kc.ninv_2l2, etab));
@@ -553,7 +564,7 @@ template <> struct NAcc<PROC_SELF> { static constexpr int n = NACC_SELF; };
 // One pair of the exact pass.  PROC_FLOW / PROC_SELF: membership test of
 // se_kernel (ref cvo.cpp:125-152) and the flow / self sums; returns the weight
 // (0 = not in A).  PROC_STEP: `w` is the recorded weight of a member of A.
-template <int MODE>
+template <int MODE, int WEIGHT = 0>
 __device__ __forceinline__ float eval_pair(const ProcessArgs &a, const KernConsts &kc, unsigned i,
                                            unsigned j, float w, double *acc,
                                            const cvo_math::XiConsts &xc, const double *etab = nullptr)
@@ -581,7 +592,7 @@ __device__ __forceinline__ float eval_pair(const ProcessArgs &a, const KernConst
     float d2 = 0.0f;
     if (MODE != PROC_STEP) {
         d2 = __builtin_fmaf(e2, e2, __builtin_fmaf(e1, e1, e0 * e0));
-        w = (d2 < kc.tau) ? pair_weight(kc, d2, fa0, fa4, fb0, fb4, etab) : 0.0f;
+        w = (d2 < kc.tau) ? pair_weight<WEIGHT>(kc, d2, fa0, fa4, fb0, fb4, etab) : 0.0f;
     }
     if (!(w > 0.0f)) return 0.0f;
     if (MODE == PROC_FLOW) {
@@ -643,7 +654,7 @@ __device__ __forceinline__ float eval_pair(const ProcessArgs &a, const KernConst
 // roles (flow pass, self passes, filter) overlay one allocation instead of adding them up
 constexpr int PROC_SMEM = 4 * NACC_MAX * 8 + 4 * PAIR_QUEUE * 8 + 4 * 64 * 8;
 
-template <int MODE>
+template <int MODE, int WEIGHT = 0>
 __device__ __forceinline__ void process_body(const ProcessArgs &a, const unsigned bid, char *scratch)
 {
     if ((int)bid >= a.nblk) return;
@@ -713,7 +724,7 @@ __device__ __forceinline__ void process_body(const ProcessArgs &a, const unsigne
             uint2 pr = make_uint2(0u, 0u);
             if (lane < cnt) {
                 pr = pairq[base + lane];
-                w = eval_pair<MODE>(a, kc, pr.x, pr.y, 0.0f, acc, a.st->xi, s_etab);   // (xi: PROC_STEP only)
+                w = eval_pair<MODE, WEIGHT>(a, kc, pr.x, pr.y, 0.0f, acc, a.st->xi, s_etab);   // (xi: PROC_STEP only)
             }
             if (MODE == PROC_FLOW) {   // record the members of A in this wave's slice
                 const unsigned long long km = __ballot(w > 0.0f);
@@ -785,11 +796,11 @@ __device__ __forceinline__ void process_body(const ProcessArgs &a, const unsigne
     }
 }
 
-template <int MODE>
+template <int MODE, int WEIGHT = 0>
 __global__ void __launch_bounds__(BLOCK) k_process(const Grp<ProcessArgs> grp)
 {
     __shared__ __attribute__((aligned(16))) char scratch[PROC_SMEM];
-    process_body<MODE>(grp.a[blockIdx.z], blockIdx.x, scratch);
+    process_body<MODE, WEIGHT>(grp.a[blockIdx.z], blockIdx.x, scratch);
 }
 
 // ---------------------------------------------------------------------------
@@ -1082,7 +1093,8 @@ void launch_process_group(int mode, const ProcessArgs *a, int n, hipStream_t s)
     const dim3 grid((unsigned)nblk, 1, (unsigned)n);
     switch (mode) {
     case PROC_FLOW:
-        hipLaunchKernelGGL(k_process<PROC_FLOW>, grid, dim3(BLOCK), 0, s, g);
+        if (a[0].weight == 1) hipLaunchKernelGGL((k_process<PROC_FLOW, 1>), grid, dim3(BLOCK), 0, s, g);
+        else hipLaunchKernelGGL(k_process<PROC_FLOW>, grid, dim3(BLOCK), 0, s, g);
         break;
     case PROC_STEP:
         hipLaunchKernelGGL(k_process<PROC_STEP>, grid, dim3(BLOCK), 0, s, g);

@@ -86,6 +86,37 @@ class Cvo(_Registration):
     MODE = capi.MODE_CVO
 
 
+class RkhsMatlab(_Registration):
+    """The reference's MATLAB registration object (ref matlab/@rkhs_se3_registration/
+    rkhs_se3_registration.m) on the same HIP kernels: linear colour inner
+    product CI = 1e-5 <c_i, c_j>, squared-exponential kernel thresholded at 1e-3 on K
+    alone, eps 5e-4 / 1e-4 (:10-28,40-73,125-127).  Unlike the C++ objects it starts every
+    pair from R = I, T = 0, ell = 0.15 (:112-114).  Arithmetic is this library's float32
+    per-pair contract, not MATLAB's float64: results agree with a float64 restatement
+    (oracle/matlab_dense.py) to ~1e-5."""
+    MODE = capi.MODE_MATLAB
+
+    @staticmethod
+    def features(rgb):
+        """n x 3 colour bytes -> the n x 5 feature rows the kernels read (channels 0..2)."""
+        f = np.zeros((len(rgb), 5), np.float32)
+        f[:, :3] = np.asarray(rgb, np.float32)
+        return f
+
+    def register(self, fixed_xyz, fixed_rgb, moving_xyz, moving_rgb):
+        """One pair as rgbddataset_rkhs.m drives the object (ref :30-75): returns the 4 x 4
+        `tform` = [R' -R'T; 0 1] and the number of iterations."""
+        self.state = capi.init_state(self.params)
+        self.ctx.set_fixed(np.ascontiguousarray(fixed_xyz, np.float32), self.features(fixed_rgb))
+        self.ctx.set_moving(np.ascontiguousarray(moving_xyz, np.float32), self.features(moving_rgb))
+        self.init = True
+        self._have_moving = True
+        self.num_iterations, self.trace = self.ctx.align(self.state, trace_cap=0)
+        self._have_moving = False
+        self._publish()
+        return self.transform.copy(), self.num_iterations
+
+
 class Acvo(_Registration):
     MODE = capi.MODE_ACVO
 

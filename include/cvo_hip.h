@@ -43,7 +43,10 @@ typedef enum cvo_hip_status {
     CVO_HIP_ERR_NODEVICE = -5   /* no usable gfx950 device */
 } cvo_hip_status;
 
-enum { CVO_HIP_MODE_CVO = 0, CVO_HIP_MODE_ACVO = 1 };
+/* CVO_HIP_MODE_MATLAB is accepted by cvo_hip_default_params() only: it returns mode = CVO with
+ * the constants of the reference's MATLAB object and color_scale > 0 (SURVEY 8 a9,
+ * ref matlab/@rkhs_se3_registration/rkhs_se3_registration.m:10-28). */
+enum { CVO_HIP_MODE_CVO = 0, CVO_HIP_MODE_ACVO = 1, CVO_HIP_MODE_MATLAB = 2 };
 enum { CVO_HIP_FEAT_COLMAJOR = 0, CVO_HIP_FEAT_ROWMAJOR = 1 };
 
 /* Hyper-parameters.  Defaults = the reference's constructor initialisers
@@ -64,7 +67,10 @@ typedef struct cvo_hip_params {
     float min_step;
     float eps;
     float eps_2;
-    float pad_;
+    float color_scale;   /* 0: the C++ pair weight (ref src/cvo.cpp:143-153).  > 0: the MATLAB object's:
+                          * a = color_scale * <c_i, c_j> * K with K = sigma^2 exp(-d2 / 2 ell^2) kept iff
+                          * K >= sp_thres, c = features 0..2 -- linear colour inner product, no colour
+                          * cut-off (ref rkhs_se3_registration.m:40-73,125-127) */
     double dl_step;
 } cvo_hip_params;
 

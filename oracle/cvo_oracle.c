@@ -38,7 +38,7 @@ static int nthreads(void) { return cvo_oracle_get_threads(); }
 void cvo_oracle_default_params(int mode, cvo_oracle_params *p)
 {
     memset(p, 0, sizeof(*p));
-    p->mode = mode;
+    p->mode = mode == CVO_ORACLE_MODE_MATLAB ? CVO_ORACLE_MODE_CVO : mode;
     p->max_iter = 2000;
     p->sigma = 0.1f;
     p->c = 7.0f;
@@ -63,6 +63,13 @@ void cvo_oracle_default_params(int mode, cvo_oracle_params *p)
         p->c_sp_thres = 8e-3f; /* cvo.cpp:103 uses sp_thres for the colour cut */
         p->c_ell = 200.0f;
         p->dl_step = 0.0;
+    }
+    if (mode == CVO_ORACLE_MODE_MATLAB) {   /* ref rkhs_se3_registration.m:10-28 */
+        p->sp_thres = 1e-3f;
+        p->c_sp_thres = 1e-3f;
+        p->eps = 5e-4f;
+        p->eps_2 = 1e-4f;
+        p->color_scale = 1e-5f;
     }
 }
 
@@ -155,6 +162,7 @@ typedef struct kconsts {
     double ninv_2l2;    /* -1/(2 l^2)   (float64) */
     double ninv_2cl2;   /* -1/(2 c_l^2) (float64) */
     int geom_only;      /* radius-set mode: keep every d2 < tau, value = d2 */
+    float cscale;       /* > 0: MATLAB weight (linear colour inner product, threshold on K) */
 } kconsts;
 
 static float logf_cr(float x) { return (float)log((double)x); }
@@ -173,6 +181,10 @@ static void make_kconsts(const cvo_oracle_params *p, float ell, float c_sp, kcon
                        (double)logf_cr(c_sp / p->c_sigma / p->c_sigma));
     k->ninv_2l2 = -1.0 / (2.0 * l * l);
     k->ninv_2cl2 = -1.0 / (2.0 * p->c_ell * p->c_ell);
+    k->cscale = p->color_scale;
+    /* MATLAB keeps K >= sp (ref rkhs_se3_registration.m:70): the radius is widened by 1e-5 so
+     * that the exact test on K below decides, not the rounding of tau */
+    if (k->cscale > 0.0f) k->tau = (float)((double)k->tau * 1.00001);
 }
 
 void cvo_oracle_thresholds(const cvo_oracle_params *p, float ell, float tau[2])
@@ -189,6 +201,12 @@ void cvo_oracle_thresholds(const cvo_oracle_params *p, float ell, float tau[2])
 static inline float pair_weight(const kconsts *kc, float d2, const float *fa, const float *fb)
 {
     if (kc->geom_only) return d2 > 0.0f ? d2 : 1e-45f;   /* denormal marks d2 == 0 */
+    if (kc->cscale > 0.0f) {   /* ref rkhs_se3_registration.m:40-53,55-73,125-127 */
+        const float k = (float)((double)kc->s2 * exp((double)d2 * kc->ninv_2l2));
+        if (!(k >= kc->sp)) return 0.0f;
+        const float ci = kc->cscale * ((fa[0] * fb[0] + fa[1] * fb[1]) + fa[2] * fb[2]);
+        return ci * k;
+    }
     const float d2c = d2_feat(fa, fb);
     if (!(d2c < kc->tau_c)) return 0.0f;
     const float k = (float)((double)kc->s2 * exp((double)d2 * kc->ninv_2l2));

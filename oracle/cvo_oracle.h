@@ -41,7 +41,10 @@ extern "C" {
 
 #define CVO_ORACLE_NFEAT 5
 
-enum { CVO_ORACLE_MODE_CVO = 0, CVO_ORACLE_MODE_ACVO = 1 };
+/* MODE_MATLAB is accepted by cvo_oracle_default_params() only: it returns mode = CVO with the
+ * MATLAB object's constants and color_scale > 0 (ref matlab/@rkhs_se3_registration/
+ * rkhs_se3_registration.m:10-28). */
+enum { CVO_ORACLE_MODE_CVO = 0, CVO_ORACLE_MODE_ACVO = 1, CVO_ORACLE_MODE_MATLAB = 2 };
 enum { CVO_ORACLE_SEARCH_DENSE = 0, CVO_ORACLE_SEARCH_GRID = 1 };
 
 /* Hyper-parameters: cvo.cpp:18-48, adaptive_cvo.cpp:18-50. */
@@ -61,7 +64,9 @@ typedef struct cvo_oracle_params {
     float min_step;        /* 0.2 */
     float eps;             /* 5e-5 */
     float eps_2;           /* 1e-5 */
-    float pad_;
+    float color_scale;     /* 0: the C++ weight.  > 0: the MATLAB object's weight
+                            * a = color_scale * <c_i, c_j> * K, K = s2 exp(-d2/2l^2) kept iff K >= sp
+                            * (ref rkhs_se3_registration.m:40-73,125-127), c = features 0..2 */
     double dl_step;        /* acvo 0.3 */
 } cvo_oracle_params;
 

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
 _REF = None
 
-MODE_CVO, MODE_ACVO = 0, 1
+MODE_CVO, MODE_ACVO, MODE_MATLAB = 0, 1, 2
 SEARCH_DENSE, SEARCH_GRID = 0, 1
 
 
@@ -23,7 +23,7 @@ class Params(C.Structure):
         ("ell_init", C.c_float), ("ell_min", C.c_float), ("ell_max_init", C.c_float),
         ("sigma", C.c_float), ("sp_thres", C.c_float), ("c_sp_thres", C.c_float),
         ("c", C.c_float), ("d", C.c_float), ("c_ell", C.c_float), ("c_sigma", C.c_float),
-        ("min_step", C.c_float), ("eps", C.c_float), ("eps_2", C.c_float), ("pad_", C.c_float),
+        ("min_step", C.c_float), ("eps", C.c_float), ("eps_2", C.c_float), ("color_scale", C.c_float),
         ("dl_step", C.c_double),
     ]
 

@@ -119,3 +119,34 @@ def test_matlab_dense_variant_close_to_recorded_run(pkg, desk):
     assert np.abs(T - G).max() < 5e-3
     # and far closer to it than the identity is
     assert np.abs(T - G).max() < 0.2 * np.abs(np.eye(4) - G).max()
+
+
+def _matlab_features(rgb):
+    f = np.zeros((len(rgb), 5), np.float32)
+    f[:, :3] = np.asarray(rgb, np.float32)
+    return f
+
+
+def test_matlab_weight_in_the_c_restatement_tracks_float64(pkg, desk):
+    """the MATLAB object's pair weight (linear colour inner product, threshold
+    on K only) as a variant of the C restatement (float32 per pair) against the float64
+    numpy restatement of the whole MATLAB object: same iteration count, transform within
+    1e-4 -- on the range-filtered, grid-averaged shipped pair and on a synthetic one."""
+    from oracle import matlab_dense
+    from oracle import pyoracle as po
+    p = po.default_params(po.MODE_MATLAB)
+    assert p.mode == po.MODE_CVO and p.color_scale == np.float32(1e-5) and p.sp_thres == np.float32(1e-3)
+    f = pkg.data.grid_average(*pkg.data.pc_range_filter(desk["xyz0"], desk["rgb0"]))
+    m = pkg.data.grid_average(*pkg.data.pc_range_filter(desk["xyz1"], desk["rgb1"]))
+    xf, _, xm, _ = pkg.data.synthetic_pair(900, 800, seed=17)
+    rng = np.random.default_rng(3)
+    cf = rng.integers(0, 256, (900, 3)).astype(np.uint8)
+    cm = rng.integers(0, 256, (800, 3)).astype(np.uint8)
+    for (fx, fc, mx, mc) in ((f[0], f[1], m[0], m[1]), (xf, cf, xm, cm)):
+        T64, k64 = matlab_dense.align(fx, fc, mx, mc)
+        st = po.init_state(p)
+        n, _ = po.align(p, st, fx, _matlab_features(fc), mx, _matlab_features(mc), search=po.SEARCH_DENSE)
+        T32 = po.state_matrices(st)[0]
+        # matlab_dense counts the iteration that breaks; the C loop reports executed bodies
+        assert abs(n - k64) <= 1
+        assert np.abs(T32 - T64).max() < 1e-4

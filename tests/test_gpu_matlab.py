@@ -1,0 +1,69 @@
+"""GPU: the MATLAB object's pair weight (linear colour inner product,
+threshold on K only; ref matlab/@rkhs_se3_registration/rkhs_se3_registration.m) on the
+HIP kernels -- bit for bit against the C restatement with the same weight, within 1e-4
+of the float64 restatement of the whole MATLAB object, and (soft) near the transform the
+reference's MATLAB run recorded."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import matlab_dense
+from oracle import pyoracle as po
+
+pytestmark = pytest.mark.gpu
+
+
+def _prepared(pkg, desk, a, b):
+    f = pkg.data.grid_average(*pkg.data.pc_range_filter(desk["xyz%d" % a], desk["rgb%d" % a]))
+    m = pkg.data.grid_average(*pkg.data.pc_range_filter(desk["xyz%d" % b], desk["rgb%d" % b]))
+    return f[0], f[1], m[0], m[1]
+
+
+def _oracle(fx, fc, mx, mc):
+    p = po.default_params(po.MODE_MATLAB)
+    st = po.init_state(p)
+    feat = lambda c: np.concatenate([np.asarray(c, np.float32), np.zeros((len(c), 2), np.float32)], axis=1)
+    n, _ = po.align(p, st, fx, feat(fc), mx, feat(mc), search=po.SEARCH_DENSE)
+    return n, st
+
+
+def test_defaults(pkg):
+    p = pkg.capi.default_params(pkg.capi.MODE_MATLAB)
+    assert p.mode == pkg.capi.MODE_CVO and p.color_scale == np.float32(1e-5)
+    assert p.sp_thres == np.float32(1e-3) and p.eps == np.float32(5e-4) and p.eps_2 == np.float32(1e-4)
+    assert pkg.capi.default_params(pkg.capi.MODE_CVO).color_scale == 0.0
+
+
+def test_shipped_pairs_match_restatements(pkg, desk):
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "matlab_transforms.json")))
+    reg = pkg.RkhsMatlab()
+    for a in range(3):
+        fx, fc, mx, mc = _prepared(pkg, desk, a, a + 1)
+        T, n = reg.register(fx, fc, mx, mc)
+        n_or, st = _oracle(fx, fc, mx, mc)
+        assert n == n_or
+        assert np.array_equal(T, po.state_matrices(st)[0])          # bit for bit vs the C restatement
+        T64, k64 = matlab_dense.align(fx, fc, mx, mc)
+        assert abs(n - k64) <= 1 and np.abs(T - T64).max() < 1e-4  # float64 restatement of the object
+        G = np.array(gold["matlab"][a + 1])
+        assert np.abs(T - G).max() < 6e-3                           # soft: the recorded MATLAB run
+    reg.close()
+
+
+@pytest.mark.parametrize("n,m,seed", [(900, 800, 17), (3000, 2500, 18), (6000, 6000, 19)])
+def test_synthetic_pairs_bit_identical(pkg, n, m, seed):
+    xf, _, xm, _ = pkg.data.synthetic_pair(n, m, seed=seed)
+    rng = np.random.default_rng(seed)
+    cf = rng.integers(0, 256, (n, 3)).astype(np.uint8)
+    cm = rng.integers(0, 256, (m, 3)).astype(np.uint8)
+    reg = pkg.RkhsMatlab()
+    T, it = reg.register(xf, cf, xm, cm)
+    n_or, st = _oracle(xf, cf, xm, cm)
+    assert it == n_or and np.array_equal(T, po.state_matrices(st)[0])
+    assert list(reg.state.R) == list(st.R) and list(reg.state.T) == list(st.T) and reg.state.ell == st.ell
+    # every pair starts from scratch (ref rkhs_se3_registration.m:112-114): same call, same result
+    T2, it2 = reg.register(xf, cf, xm, cm)
+    assert it2 == it and np.array_equal(T2, T)
+    reg.close()

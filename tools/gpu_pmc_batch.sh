@@ -24,5 +24,5 @@ for f in sorted(glob.glob("$OUT/p*/*counter_collection.csv")):
         agg[(k,r.get('Grid_Size','') )][r['Counter_Name']].append(float(r['Counter_Value']))
     for k,d in sorted(agg.items()):
         if 'rocclr' in k[0] or 'prepare' in k[0]: continue
-        print(k, {c: round(sorted(v)[len(v)//2],1) for c,v in d.items()}, "n", len(next(iter(d.values()))))
+        print(k, "p50", {c: round(sorted(v)[len(v)//2],1) for c,v in d.items()}, "p90", {c: round(sorted(v)[(len(v)*9)//10],1) for c,v in d.items()}, "n", len(next(iter(d.values()))))
 PY
