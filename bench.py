@@ -254,8 +254,6 @@ def main():
         }
         if sharded is not None:
             out["sharded_allreduce"] = sharded
-        if world == 1 and not args.no_cpu:
-            out["cpu_baseline"] = cpu_baseline(args, pkg, xf, ff, xm, fm, acvo)
         if world == 1 and not args.no_frontend:
             for c in ctxs:   # (dozens of idle streams slow every other stream's submissions down)
                 c.close()
@@ -264,6 +262,10 @@ def main():
                 out["frontend"] = frontend_leg(args, pkg)
             except Exception as e:   # the headline line must survive a side leg
                 out["frontend"] = {"error": repr(e)}
+        # (last: the OpenMP team of the CPU leg keeps spinning for a while after its last
+        # parallel region and would slow the host side of everything timed after it)
+        if world == 1 and not args.no_cpu:
+            out["cpu_baseline"] = cpu_baseline(args, pkg, xf, ff, xm, fm, acvo)
         print(json.dumps(out), flush=True)
     for c in ctxs:
         c.close()
@@ -294,17 +296,21 @@ def frontend_leg(args, pkg, frames=100):
            for k in range(12)]
     stream = {}
     for name, cls in (("cvo", pkg.Cvo), ("acvo", pkg.Acvo)):
-        reg = cls()
-        pkg.frontend.run_frames(reg, seq[:3], 1, generator=gen)   # warm-up
-        reg.close()
-        reg = cls()
-        t0 = time.perf_counter()
-        pkg.frontend.run_frames(reg, seq * 3, 1, generator=gen)
-        dt = (time.perf_counter() - t0) / (3 * len(seq))
-        reg.close()
-        stream[name] = {"frames_per_s": 1.0 / dt, "ms_per_frame": dt * 1e3}
+        passes = []
+        for _ in range(3):   # three passes on fresh objects, the median one is reported
+            reg = cls()
+            pkg.frontend.run_frames(reg, seq[:3], 1, generator=gen)   # warm-up
+            reg.close()
+            reg = cls()
+            t0 = time.perf_counter()
+            pkg.frontend.run_frames(reg, seq * 3, 1, generator=gen)
+            passes.append((time.perf_counter() - t0) / (3 * len(seq)))
+            reg.close()
+        dt = sorted(passes)[1]
+        stream[name] = {"frames_per_s": 1.0 / dt, "ms_per_frame": dt * 1e3,
+                        "passes_ms_per_frame": [round(v * 1e3, 3) for v in passes]}
     out["stream"] = stream
-    out["stream_note"] = "36 synthetic VGA frames (12, three times over), ~3k points each, decoded images in host memory, one frame at a time"
+    out["stream_note"] = "36 synthetic VGA frames (12, three times over), ~3k points each, decoded images in host memory, one frame at a time; median of 3 passes"
     gen.close()
     if not args.no_cpu:
         from oracle import pyoracle_fe as fo
