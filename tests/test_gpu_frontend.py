@@ -248,3 +248,22 @@ def test_submit_collect_and_prefetched_stream(pkg):
         reg.close()
     assert poses[0] == poses[1] and len(poses[0].strip().split("\n")) == 4
     gen.close()
+
+
+def test_empty_and_saturated_frames(pkg):
+    """no depth at all, a constant image, a maximally busy (random) image"""
+    gen = pkg.frontend.PcdGenerator(640, 480)
+    bgr, dep = pkg.data.synthetic_rgbd_frame(seed=9, texture=1.0)
+    info = _check_frame(pkg, gen, bgr, np.zeros_like(dep), 1, pkg.frontend.FEATURES_RGB)
+    assert info["num_points"] == 0 and info["num_selected"] > 2000
+    flat = np.full_like(bgr, 77)
+    info = _check_frame(pkg, gen, flat, dep, 1, pkg.frontend.FEATURES_HSV)
+    assert info["num_points"] == 0 and info["num_selected"] == 0 and info["canny_used"] == 1
+    rng = np.random.default_rng(1)
+    noise = rng.integers(0, 256, bgr.shape, dtype=np.uint8)
+    info = _check_frame(pkg, gen, noise, dep, 1, pkg.frontend.FEATURES_RGB)
+    assert info["reselected"] == 1 and info["pot_used"] > 3 and 2000 < info["num_selected"] < 4500
+    black = np.zeros_like(bgr); white = np.full_like(bgr, 255)
+    _check_frame(pkg, gen, black, dep, 1, pkg.frontend.FEATURES_HSV)
+    _check_frame(pkg, gen, white, dep, 1, pkg.frontend.FEATURES_HSV)
+    gen.close()
