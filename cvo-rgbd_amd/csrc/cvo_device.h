@@ -324,14 +324,13 @@ CVO_HD void compute_filter_bounds(DevState *s, bool identity)
 // above the float32 rounding of the coordinates and of d2 (<= ~1e-5 m here) and
 // far below the margin (>= 1 mm at ell_min): decisions change performance only.
 constexpr double LIST_LOOSE = 1.3;
-CVO_HD void plan_lists(DevState *s, const DevParams &p)
+CVO_HD void plan_lists(DevState *s, const DevParams &p, const double r_now)
 {
-    const double r_now = sqrt((double)s->kc.tau);
     const double ymax = (double)s->y0max;
     const double slack = 1.0e-4 * (1.0 + (double)s->xmax + ymax);
     const double margin = (double)p.list_margin;
     double travel = 0.0;
-    if (s->list_ok[LIST_XY]) {
+    if (s->list_ok[LIST_XY] && !p.async_xy) {
         double f2 = 0.0, c2 = 0.0;
         for (int r = 0; r < 3; ++r) {
             double dc = (double)s->t[r] - (double)s->list_t[r];
@@ -347,6 +346,8 @@ CVO_HD void plan_lists(DevState *s, const DevParams &p)
     for (int l = 0; l < 3; ++l) {
         if (l == LIST_XY && p.async_xy) continue;   // planned by plan_xy_async
         if (l != LIST_XY && p.async_self) continue; // planned by plan_self_async
+        if (l == LIST_XY && p.async_xy) continue;   // planned by plan_xy_async (and tauf[XY] must stay
+                                                    // tau + rounding slack: tauf_build is made from it)
         const double need = (r_now + (l == LIST_XY ? travel : 0.0)) * 1.0001 + slack;
         const double lr = (double)s->list_r[l];
         const bool keep = margin > 0.0 && s->list_ok[l] && need <= lr &&
@@ -390,9 +391,8 @@ CVO_HD double xy_travel(const DevState *s, int b)
     return sqrt(0.5 * f2) * 1.001 * (double)s->y0max + sqrt(c2);
 }
 
-CVO_HD void plan_xy_async(DevState *s, const DevParams &p)
+CVO_HD void plan_xy_async(DevState *s, const DevParams &p, const double r_now)
 {
-    const double r_now = sqrt((double)s->kc.tau);
     const double slack = 1.0e-4 * (1.0 + (double)s->xmax + (double)s->y0max);
     const double margin = (double)p.list_margin;
     const double r0 = r_now * 1.0001 + slack;   // radius needed with no travel
@@ -436,9 +436,8 @@ CVO_HD void plan_xy_async(DevState *s, const DevParams &p)
 // depend on the transform -- so only ell ages them: a list built for radius
 // (1 + margin) r serves until r_now outgrows it; the next one is built ahead when
 // half of that room is gone or ell has dropped far below.
-CVO_HD void plan_self_async(DevState *s, const DevParams &p)
+CVO_HD void plan_self_async(DevState *s, const DevParams &p, const double r_now)
 {
-    const double r_now = sqrt((double)s->kc.tau);
     const double slack = 1.0e-4 * (1.0 + (double)s->xmax + (double)s->y0max);
     const double margin = (double)p.list_margin;
     const double r0 = r_now * 1.0001 + slack;
@@ -483,9 +482,10 @@ CVO_HD void prepare_iteration(DevState *s, const DevParams &p)
         s->kc_ell = s->ell;
     }
     compute_filter_bounds(s, false);
-    plan_lists(s, p);
-    if (p.async_xy) plan_xy_async(s, p);
-    if (p.async_self) plan_self_async(s, p);   // (after the xy plan: it may add a stall)
+    const double r_now = sqrt((double)s->kc.tau);
+    plan_lists(s, p, r_now);
+    if (p.async_xy) plan_xy_async(s, p, r_now);
+    if (p.async_self) plan_self_async(s, p, r_now);   // (after the xy plan: it may add a stall)
     for (int q = 0; q < 2 * LIST_N; ++q) s->cnt[q] = 0u;
     // (the per-sub-list counters are zeroed by all threads of the calling kernel)
 }

@@ -1114,12 +1114,12 @@ void launch_process(int mode, const ProcessArgs &a, hipStream_t s)
 // Fixed-order reduction of partials[NACC][nblocks] by one 256-thread block:
 // thread t adds blocks t, t+256, ...; xor butterfly inside each wave; the four
 // wave sums are added in wave order.
+// (two halves, so that a caller can have the loads in flight while it waits for
+// something else: thread_load_partials only issues them and adds in a fixed order)
 template <int NACC, int NPART = PROC_BLOCKS>
-__device__ void block_reduce_partials(const double *part, int nblocks, double *sh /*[4*NACC_MAX]*/,
-                                      double *out /*[NACC], thread 0 writes*/)
+__device__ __forceinline__ void thread_load_partials(const double *part, int nblocks, double (&s)[NACC])
 {
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    double s[NACC];
+    const int tid = threadIdx.x;
 #pragma unroll
     for (int k = 0; k < NACC; ++k) s[k] = 0.0;
     // nblocks == PROC_BLOCKS: a fixed trip count, fully unrolled, so that all the
@@ -1131,6 +1131,13 @@ __device__ void block_reduce_partials(const double *part, int nblocks, double *s
 #pragma unroll
         for (int k = 0; k < NACC; ++k) s[k] += (b < nblocks) ? part[(size_t)k * nblocks + b] : 0.0;
     }
+}
+
+template <int NACC>
+__device__ __forceinline__ void block_finish_partials(double (&s)[NACC], double *sh /*[4*NACC_MAX]*/,
+                                                      double *out /*[NACC], thread 0 writes*/)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     wave_sums<NACC>(s, lane, sh + wid * NACC_MAX);
     __syncthreads();
     if (tid == 0) {
@@ -1139,6 +1146,15 @@ __device__ void block_reduce_partials(const double *part, int nblocks, double *s
             out[k] = ((sh[k] + sh[NACC_MAX + k]) + sh[2 * NACC_MAX + k]) + sh[3 * NACC_MAX + k];
     }
     __syncthreads();
+}
+
+template <int NACC, int NPART = PROC_BLOCKS>
+__device__ void block_reduce_partials(const double *part, int nblocks, double *sh /*[4*NACC_MAX]*/,
+                                      double *out /*[NACC], thread 0 writes*/)
+{
+    double s[NACC];
+    thread_load_partials<NACC, NPART>(part, nblocks, s);
+    block_finish_partials<NACC>(s, sh, out);
 }
 
 // The head of DevState (everything in front of the sub-list counters) moves
@@ -1164,6 +1180,12 @@ __device__ void post_step_math(DevState *st, const PostStepArgs &a);
 // cvo_math::section_root with one lane per interior point (all 64 lanes of a
 // wave must call it with the same bracket): same arithmetic per point, same
 // selection rule (lowest lane whose point is not left of the root).
+__device__ __forceinline__ double readlane_f64(double x, int l)
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(x), l), hi = __builtin_amdgcn_readlane(__double2hiint(x), l);
+    return __hiloint2double(hi, lo);
+}
+
 __device__ __forceinline__ double section_root_wave(const cvo_math::CubicBracket &B, int lane)
 {
     double lo = B.lo, hi = B.hi;
@@ -1177,8 +1199,9 @@ __device__ __forceinline__ double section_root_wave(const cvo_math::CubicBracket
         const unsigned long long gm = __ballot(go_right), im = __ballot(inside);
         const int first = (~gm == 0ull) ? 64 : (int)__builtin_ctzll(~gm);   // serial loop's break index
         double nlo = lo, nhi = hi;
-        if (first > 0) nlo = __shfl(x, first - 1, 64);
-        if (first < 64 && ((im >> first) & 1ull)) nhi = __shfl(x, first, 64);
+        // (`first` is wave-uniform: v_readlane instead of a trip through the LDS crossbar)
+        if (first > 0) nlo = readlane_f64(x, first - 1);
+        if (first < 64 && ((im >> first) & 1ull)) nhi = readlane_f64(x, first);
         if (nlo == lo && nhi == hi) break;
         lo = nlo;
         hi = nhi;
@@ -1261,7 +1284,10 @@ __global__ void __launch_bounds__(BLOCK) k_post_step(const Grp<PostStepArgs> grp
     __shared__ double sh[4 * NACC_MAX];
     __shared__ __attribute__((aligned(16))) DevState s_st;
     const long long c0 = a.dbg ? (long long)__builtin_readcyclecounter() : 0;
-    state_head_to_lds(a.st, &s_st);   // one round trip, see k_post_flow
+    // the step partials are requested together with the state's head: one round trip for both
+    double sp[NACC_STEP];
+    if (a.flags & POST_REDUCE) thread_load_partials<NACC_STEP>(a.part_step, a.nblk, sp);
+    state_head_to_lds(a.st, &s_st);   // (see k_post_flow)
     DevState *st = &s_st;
     if (a.check_done && st->done != 0) return;
     // async xy: a stall slot executed no iteration (only the plan below runs); the
@@ -1289,8 +1315,7 @@ __global__ void __launch_bounds__(BLOCK) k_post_step(const Grp<PostStepArgs> grp
         st->sf_fail[1] = (aself && yy_failed) ? 1 : 0;
     }
     const long long c1 = a.dbg ? (long long)__builtin_readcyclecounter() : 0;
-    if ((a.flags & POST_REDUCE) && !stalled)
-        block_reduce_partials<NACC_STEP>(a.part_step, a.nblk, sh, st->red + RED_STEP);
+    if ((a.flags & POST_REDUCE) && !stalled) block_finish_partials<NACC_STEP>(sp, sh, st->red + RED_STEP);
     if (a.dbg && threadIdx.x == 0) {
         a.dbg[0] += 1; a.dbg[1] += c1 - c0; a.dbg[2] += (long long)__builtin_readcyclecounter() - c1;
     }
