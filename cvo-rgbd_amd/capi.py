@@ -16,6 +16,7 @@ SYMBOLS = [
     "cvo_hip_error_string", "cvo_hip_last_error", "cvo_hip_device_count",
     "cvo_hip_default_params", "cvo_hip_init_state", "cvo_hip_create", "cvo_hip_destroy",
     "cvo_hip_set_params", "cvo_hip_set_fixed", "cvo_hip_set_moving",
+    "cvo_hip_set_fixed_device", "cvo_hip_set_moving_device",
     "cvo_hip_swap_moving_to_fixed", "cvo_hip_set_shard", "cvo_hip_shard_range",
     "cvo_hip_comm_unique_id", "cvo_hip_comm_init", "cvo_hip_set_allreduce",
     "cvo_hip_transform_pcd", "cvo_hip_flow", "cvo_hip_step_coeffs", "cvo_hip_pick_step",
@@ -99,6 +100,8 @@ def lib():
     L.cvo_hip_set_params.argtypes = [vp, C.POINTER(Params)]
     L.cvo_hip_set_fixed.argtypes = [vp, fp, fp, C.c_int, C.c_int]
     L.cvo_hip_set_moving.argtypes = [vp, fp, fp, C.c_int, C.c_int]
+    L.cvo_hip_set_fixed_device.argtypes = [vp, vp, vp, C.c_int, C.c_int]
+    L.cvo_hip_set_moving_device.argtypes = [vp, vp, vp, C.c_int, C.c_int]
     L.cvo_hip_swap_moving_to_fixed.argtypes = [vp]
     L.cvo_hip_set_shard.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int]
     L.cvo_hip_shard_range.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int),
@@ -245,6 +248,15 @@ class Context:
         self.n_moving = xyz.shape[0]
         self._chk(self._L.cvo_hip_set_moving(self._ctx, fptr(xyz), fptr(feat), xyz.shape[0],
                                              layout), "set_moving")
+
+    def set_fixed_device(self, d_xyz, d_feat, n, layout=FEAT_ROWMAJOR):
+        """The cloud is already in device memory (addresses as integers)."""
+        self.n_fixed = int(n)
+        self._chk(self._L.cvo_hip_set_fixed_device(self._ctx, d_xyz, d_feat, int(n), layout), "set_fixed_device")
+
+    def set_moving_device(self, d_xyz, d_feat, m, layout=FEAT_ROWMAJOR):
+        self.n_moving = int(m)
+        self._chk(self._L.cvo_hip_set_moving_device(self._ctx, d_xyz, d_feat, int(m), layout), "set_moving_device")
 
     def swap_moving_to_fixed(self):
         self._chk(self._L.cvo_hip_swap_moving_to_fixed(self._ctx), "swap")

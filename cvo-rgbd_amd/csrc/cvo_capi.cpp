@@ -28,6 +28,7 @@
 #include <vector>
 
 #include "cvo_comm.h"
+#include "cvo_cloud.h"
 #include "cvo_device.h"
 #include "se3_math.hpp"
 
@@ -111,8 +112,10 @@ struct cvo_hip_ctx {
     bool proc_blocks_forced = false;     // CVO_HIP_PROC_BLOCKS
     void *upload_stage = nullptr;        // pinned staging of upload_cloud (pos | feat | seg)
     size_t upload_stage_bytes = 0;
-    std::vector<uint32_t> sort_keys[2];  // radix-sort scratch of upload_cloud
-    std::vector<int> sort_idx[2];
+    DevBuf raw_xyz, raw_feat;            // upload_cloud: the caller's arrays as they came
+    DevBuf sort_keys[2], sort_idx[2], sort_tmp;   // ... scratch of the device-side Morton sort
+    float *bbox_dev = nullptr;           // [6] device, bounding box of a cloud handed over in device memory
+    float *bbox_host = nullptr;          // [6] pinned
     // asynchronous xy builds (cvo_device.h plan_xy_async): the k_filter blocks of the xy
     // list ride in the launch of the flow pass of the same slot (k_flow_build) and fill
     // the idle one of two buffers
@@ -210,8 +213,14 @@ DevParams make_dev_params(const cvo_hip_params &p)
     return d;
 }
 
+int ensure_buf(cvo_hip_ctx *ctx, DevBuf &b, size_t bytes);
+
+// The cloud into the kernels' layout (cvo_cloud.hip): Morton order -- consecutive device
+// points are spatial neighbours, so a wave's 64 rows and a 16-column MFMA tile are compact
+// patches and most (wave, tile) steps see no candidate -- packed rows, bounding spheres
+// of the 64-point runs.  `on_device`: xyz / feat are device pointers (same device).
 int upload_cloud(cvo_hip_ctx *ctx, Cloud &c, const float *xyz, const float *feat, int n,
-                 int layout)
+                 int layout, bool on_device = false)
 {
     if (n < 0 || (n > 0 && (!xyz || !feat))) return fail(ctx, CVO_HIP_ERR_INVALID, "null cloud");
     if (layout != CVO_HIP_FEAT_COLMAJOR && layout != CVO_HIP_FEAT_ROWMAJOR)
@@ -229,124 +238,64 @@ int upload_cloud(cvo_hip_ctx *ctx, Cloud &c, const float *xyz, const float *feat
     c.n = n;
     for (int a = 0; a < 3; ++a) { c.lo[a] = 0.0f; c.hi[a] = 0.0f; }
     if (n == 0) return CVO_HIP_OK;
-    // Bounding box, then a Morton (Z-order) permutation: consecutive device
-    // points are spatial neighbours, so a wave's 64 rows and a 16-column MFMA
-    // tile are compact patches and most (wave, tile) steps see no candidate.
-    // All sums over pairs are order-independent (float64 accumulators).
-    for (int a = 0; a < 3; ++a) { c.lo[a] = INFINITY; c.hi[a] = -INFINITY; }
-    for (int i = 0; i < n; ++i)
-        for (int a = 0; a < 3; ++a) {
-            const float v = xyz[3 * (size_t)i + a];
-            if (v < c.lo[a]) c.lo[a] = v;
-            if (v > c.hi[a]) c.hi[a] = v;
-        }
-    // keys, then a stable LSD radix sort (3 passes of 10 bits): the same permutation
-    // as sorting (key, index) pairs, in a fraction of the time
-    std::vector<uint32_t> *keys = ctx->sort_keys;
-    std::vector<int> *idx = ctx->sort_idx;
-    for (int q = 0; q < 2; ++q) { keys[q].resize((size_t)n); idx[q].resize((size_t)n); }
-    {
-        float inv[3];
-        for (int a = 0; a < 3; ++a) {
-            const float ext = c.hi[a] - c.lo[a];
-            inv[a] = (ext > 0.0f && std::isfinite(ext)) ? 1023.0f / ext : 0.0f;
-        }
-        auto spread = [](uint32_t v) {   // 10 bits -> every third bit
-            v &= 1023u;
-            v = (v | (v << 16)) & 0x030000FFu;
-            v = (v | (v << 8)) & 0x0300F00Fu;
-            v = (v | (v << 4)) & 0x030C30C3u;
-            v = (v | (v << 2)) & 0x09249249u;
-            return v;
-        };
-        for (int i = 0; i < n; ++i) {
-            uint32_t q[3];
+    const size_t bytes_xyz = (size_t)n * 3 * sizeof(float), bytes_feat = (size_t)n * CVO_HIP_NFEAT * sizeof(float);
+    if (!ctx->bbox_host) {
+        HIP_TRY(ctx, hipHostMalloc((void **)&ctx->bbox_host, 6 * sizeof(float), hipHostMallocDefault));
+        HIP_TRY(ctx, hipMalloc((void **)&ctx->bbox_dev, 6 * sizeof(float)));
+    }
+    const float *d_xyz = xyz, *d_feat = feat;
+    if (on_device) {
+        // the bounding box comes back to the host: the filter geometry of align() is made from it
+        HIP_TRY(ctx, cloud_bbox_device(xyz, n, ctx->bbox_dev, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->bbox_host, ctx->bbox_dev, 6 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        for (int a = 0; a < 3; ++a) { c.lo[a] = ctx->bbox_host[a]; c.hi[a] = ctx->bbox_host[3 + a]; }
+    } else {
+        for (int a = 0; a < 3; ++a) { c.lo[a] = INFINITY; c.hi[a] = -INFINITY; }
+        for (int i = 0; i < n; ++i)
             for (int a = 0; a < 3; ++a) {
-                float f = (xyz[3 * (size_t)i + a] - c.lo[a]) * inv[a];
-                if (!(f >= 0.0f)) f = 0.0f;   // also catches NaN
-                if (f > 1023.0f) f = 1023.0f;
-                q[a] = (uint32_t)f;
+                const float v = xyz[3 * (size_t)i + a];
+                if (v < c.lo[a]) c.lo[a] = v;
+                if (v > c.hi[a]) c.hi[a] = v;
             }
-            keys[0][(size_t)i] = spread(q[0]) | (spread(q[1]) << 1) | (spread(q[2]) << 2);
-            idx[0][(size_t)i] = i;
+        // the arrays as they are, through pinned staging kept by the context
+        if (bytes_xyz + bytes_feat > ctx->upload_stage_bytes) {
+            if (ctx->upload_stage) (void)hipHostFree(ctx->upload_stage);
+            ctx->upload_stage = nullptr;
+            ctx->upload_stage_bytes = 0;
+            const size_t want = (bytes_xyz + bytes_feat) * 5 / 4 + 4096;
+            if (hipHostMalloc(&ctx->upload_stage, want, hipHostMallocDefault) != hipSuccess)
+                return fail(ctx, CVO_HIP_ERR_NOMEM, "hipHostMalloc(upload staging) failed");
+            ctx->upload_stage_bytes = want;
         }
-        int src = 0;
-        for (int pass = 0; pass < 3; ++pass) {
-            uint32_t hist[1025] = {0};
-            const int sh = 10 * pass;
-            for (int i = 0; i < n; ++i) hist[((keys[src][(size_t)i] >> sh) & 1023u) + 1]++;
-            for (int q = 0; q < 1024; ++q) hist[q + 1] += hist[q];
-            for (int i = 0; i < n; ++i) {
-                const uint32_t k = keys[src][(size_t)i];
-                const uint32_t d = hist[(k >> sh) & 1023u]++;
-                keys[src ^ 1][d] = k;
-                idx[src ^ 1][d] = idx[src][(size_t)i];
-            }
-            src ^= 1;
-        }
-        if (src != 0) idx[0].swap(idx[1]);
+        int rc = ensure_buf(ctx, ctx->raw_xyz, bytes_xyz);
+        if (!rc) rc = ensure_buf(ctx, ctx->raw_feat, bytes_feat);
+        if (rc) return rc;
+        char *hs = reinterpret_cast<char *>(ctx->upload_stage);
+        std::memcpy(hs, xyz, bytes_xyz);
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->raw_xyz.p, hs, bytes_xyz, hipMemcpyHostToDevice, ctx->stream));
+        std::memcpy(hs + bytes_xyz, feat, bytes_feat);
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->raw_feat.p, hs + bytes_xyz, bytes_feat, hipMemcpyHostToDevice, ctx->stream));
+        d_xyz = (const float *)ctx->raw_xyz.p;
+        d_feat = (const float *)ctx->raw_feat.p;
     }
-    const std::vector<int> &order = idx[0];
-    // pack on the host into the device layout (pinned staging, kept by the context)
-    const int nseg_ = (n + SEG - 1) / SEG;
-    const size_t bytes_pos = (size_t)n * 4 * sizeof(float), bytes_feat = (size_t)n * FEAT_STRIDE * sizeof(float),
-                 bytes_seg = (size_t)nseg_ * 4 * sizeof(float);
-    if (bytes_pos + bytes_feat + bytes_seg > ctx->upload_stage_bytes) {
-        if (ctx->upload_stage) (void)hipHostFree(ctx->upload_stage);
-        ctx->upload_stage = nullptr;
-        ctx->upload_stage_bytes = 0;
-        const size_t want = (bytes_pos + bytes_feat + bytes_seg) * 5 / 4 + 4096;
-        if (hipHostMalloc(&ctx->upload_stage, want, hipHostMallocDefault) != hipSuccess)
-            return fail(ctx, CVO_HIP_ERR_NOMEM, "hipHostMalloc(upload staging) failed");
-        ctx->upload_stage_bytes = want;
+    int rc = CVO_HIP_OK;
+    for (int q = 0; q < 2 && !rc; ++q) {
+        rc = ensure_buf(ctx, ctx->sort_keys[q], (size_t)n * sizeof(uint32_t));
+        if (!rc) rc = ensure_buf(ctx, ctx->sort_idx[q], (size_t)n * sizeof(int));
     }
-    float *hp = reinterpret_cast<float *>(ctx->upload_stage);
-    float *hf = hp + (size_t)n * 4;
-    float *hs = hf + (size_t)n * FEAT_STRIDE;
-    for (int s = 0; s < n; ++s) {
-        const int i = order[(size_t)s];
-        hp[4 * (size_t)s + 0] = xyz[3 * (size_t)i + 0];
-        hp[4 * (size_t)s + 1] = xyz[3 * (size_t)i + 1];
-        hp[4 * (size_t)s + 2] = xyz[3 * (size_t)i + 2];
-        float *f8 = hf + (size_t)s * FEAT_STRIDE;
-        for (int f = 0; f < CVO_HIP_NFEAT; ++f)
-            f8[f] = (layout == CVO_HIP_FEAT_COLMAJOR) ? feat[(size_t)f * n + i]
-                                                      : feat[(size_t)i * CVO_HIP_NFEAT + f];
-        // the 5th feature rides in pos.w: a pair then costs four 16-byte gathers (two
-        // positions, two feature quads) -- the list kernels are bound by L1 request
-        // rate -- and the caller's index (acvo Ayy rule only) moves to feat[5]
-        hp[4 * (size_t)s + 3] = f8[4];
-        std::memcpy(&f8[FEAT_INDEX_SLOT], &i, sizeof(int));
-        f8[6] = f8[7] = 0.0f;
-    }
-    // bounding spheres of the Morton runs (culling in k_filter): centre of the
-    // run's bounding box, radius = farthest point, inflated against rounding
-    const int nseg = nseg_;
-    for (int g = 0; g < nseg; ++g) {
-        const int s0 = g * SEG, s1 = std::min(n, s0 + SEG);
-        float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
-        for (int q = s0; q < s1; ++q)
-            for (int a = 0; a < 3; ++a) {
-                lo[a] = std::min(lo[a], hp[4 * (size_t)q + a]);
-                hi[a] = std::max(hi[a], hp[4 * (size_t)q + a]);
-            }
-        double cc[3], r2 = 0.0;
-        for (int a = 0; a < 3; ++a) cc[a] = 0.5 * ((double)lo[a] + hi[a]);
-        for (int a = 0; a < 3; ++a) hs[4 * (size_t)g + a] = (float)cc[a];
-        for (int q = s0; q < s1; ++q) {
-            double d2 = 0.0;
-            for (int a = 0; a < 3; ++a) {
-                const double d = (double)hp[4 * (size_t)q + a] - (double)hs[4 * (size_t)g + a];
-                d2 += d * d;
-            }
-            r2 = std::max(r2, d2);
-        }
-        hs[4 * (size_t)g + 3] = (float)(std::sqrt(r2) * 1.00001 + 1e-6);
-    }
-    HIP_TRY(ctx, hipMemcpyAsync(c.seg, hs, bytes_seg, hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(ctx, hipMemcpyAsync(c.pos, hp, bytes_pos, hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(ctx, hipMemcpyAsync(c.feat, hf, bytes_feat, hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));   // the staging buffer is re-used by the next upload
+    const size_t tmp = cloud_sort_scratch_bytes(n);
+    if (!rc) rc = ensure_buf(ctx, ctx->sort_tmp, tmp);
+    if (rc) return rc;
+    CloudPrep cp{};
+    cp.xyz = d_xyz; cp.feat = d_feat; cp.n = n; cp.colmajor = layout == CVO_HIP_FEAT_COLMAJOR ? 1 : 0;
+    for (int a = 0; a < 3; ++a) { cp.lo[a] = c.lo[a]; cp.hi[a] = c.hi[a]; }
+    for (int q = 0; q < 2; ++q) { cp.keys[q] = (uint32_t *)ctx->sort_keys[q].p; cp.idx[q] = (int *)ctx->sort_idx[q].p; }
+    cp.scratch = ctx->sort_tmp.p; cp.scratch_bytes = tmp;
+    cp.pos = c.pos; cp.feat8 = c.feat; cp.seg = c.seg;
+    HIP_TRY(ctx, cloud_prepare_device(cp, ctx->stream));
+    // (the staging buffer, or the caller's device arrays, may be re-used once this returns)
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return CVO_HIP_OK;
 }
 
@@ -1130,6 +1079,11 @@ int cvo_hip_destroy(cvo_hip_ctx *ctx)
     }
     if (ctx->st_host) (void)hipHostFree(ctx->st_host);
     if (ctx->upload_stage) (void)hipHostFree(ctx->upload_stage);
+    for (DevBuf *b : {&ctx->raw_xyz, &ctx->raw_feat, &ctx->sort_keys[0], &ctx->sort_keys[1], &ctx->sort_idx[0],
+                      &ctx->sort_idx[1], &ctx->sort_tmp})
+        if (b->p) (void)hipFree(b->p);
+    if (ctx->bbox_dev) (void)hipFree(ctx->bbox_dev);
+    if (ctx->bbox_host) (void)hipHostFree(ctx->bbox_host);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return CVO_HIP_OK;
@@ -1156,6 +1110,21 @@ int cvo_hip_set_moving(cvo_hip_ctx *ctx, const float *xyz, const float *feat, in
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     ctx->have_tf = false;
     return upload_cloud(ctx, ctx->moving, xyz, feat, m, layout);
+}
+
+int cvo_hip_set_fixed_device(cvo_hip_ctx *ctx, const float *d_xyz, const float *d_feat, int n, int layout)
+{
+    if (!ctx) return CVO_HIP_ERR_INVALID;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return upload_cloud(ctx, ctx->fixed, d_xyz, d_feat, n, layout, true);
+}
+
+int cvo_hip_set_moving_device(cvo_hip_ctx *ctx, const float *d_xyz, const float *d_feat, int m, int layout)
+{
+    if (!ctx) return CVO_HIP_ERR_INVALID;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    ctx->have_tf = false;
+    return upload_cloud(ctx, ctx->moving, d_xyz, d_feat, m, layout, true);
 }
 
 int cvo_hip_swap_moving_to_fixed(cvo_hip_ctx *ctx)

@@ -58,7 +58,7 @@ void Affine3f::quaternion(float q[4]) const
 
 registration::registration(int mode, int device, void *stream)
     : init(false), iter(0), ctx_(nullptr), have_moving_(false), n_iter_(0), fe_(nullptr), fe_w_(0), fe_h_(0),
-      fe_points_(0), fe_pos_(nullptr), fe_feat_(nullptr), device_(device)
+      fe_points_(0), device_(device)
 {
     check(cvo_hip_default_params(mode, &params_), "cvo_hip_default_params");
     check(cvo_hip_init_state(&params_, &state_), "cvo_hip_init_state");
@@ -68,15 +68,14 @@ registration::registration(int mode, int device, void *stream)
 registration::~registration()
 {
     if (fe_) cvo_fe_destroy(fe_);
-    delete[] fe_pos_;
-    delete[] fe_feat_;
     cvo_hip_destroy(ctx_);
 }
 
 // pcd_generator::load_image + create_pointcloud (ref src/cvo.cpp:321-341): cvo asks for
 // the raw colour features (type 1), acvo for the HSV ones (type 0, ref
-// src/adaptive_cvo.cpp:451,462)
-point_cloud_view registration::make_cloud(int dataset_seq, const image_view &rgb, const image_view &dep)
+// src/adaptive_cvo.cpp:451,462).  The cloud never leaves the device: the front end's
+// output arrays go straight into cvo_hip_set_*_device.
+void registration::cloud_from_images(int dataset_seq, const image_view &rgb, const image_view &dep)
 {
     if (!rgb.data || !dep.data || rgb.rows != dep.rows || rgb.cols != dep.cols)
         throw std::runtime_error("set_pcd(): colour and depth image must have the same size");
@@ -84,36 +83,49 @@ point_cloud_view registration::make_cloud(int dataset_seq, const image_view &rgb
         const int rc = cvo_fe_create(device_, nullptr, rgb.cols, rgb.rows, &fe_);
         if (rc != CVO_HIP_OK) throw std::runtime_error(std::string("cvo_fe_create: ") + cvo_hip_error_string(rc));
         fe_w_ = rgb.cols; fe_h_ = rgb.rows;
-        const size_t cap = (size_t)fe_w_ * fe_h_ / 4;
-        fe_pos_ = new float[cap * 3];
-        fe_feat_ = new float[cap * 5];
     }
     if (rgb.cols != fe_w_ || rgb.rows != fe_h_)
         throw std::runtime_error("set_pcd(): the image size changed within a sequence");
     const int ftype = params_.mode == CVO_HIP_MODE_ACVO ? CVO_FE_FEATURES_HSV : CVO_FE_FEATURES_RGB;
-    const int rc = cvo_fe_create_pointcloud(fe_, (const uint8_t *)rgb.data, rgb.step, (const uint16_t *)dep.data,
-                                            dep.step, dataset_seq, ftype, fe_pos_, fe_feat_, fe_w_ * fe_h_ / 4,
-                                            &fe_points_);
+    int rc = cvo_fe_submit(fe_, (const uint8_t *)rgb.data, rgb.step, (const uint16_t *)dep.data, dep.step,
+                           dataset_seq, ftype);
+    const float *d_pos = nullptr, *d_feat = nullptr;
+    if (rc == CVO_HIP_OK) rc = cvo_fe_collect_device(fe_, &d_pos, &d_feat, &fe_points_);
     if (rc != CVO_HIP_OK)
-        throw std::runtime_error(std::string("cvo_fe_create_pointcloud: ") + cvo_hip_error_string(rc) + " (" +
+        throw std::runtime_error(std::string("front end: ") + cvo_hip_error_string(rc) + " (" +
                                  cvo_fe_last_error(fe_) + ")");
-    return point_cloud_view{fe_points_, fe_pos_, fe_feat_, CVO_HIP_FEAT_ROWMAJOR};
+    if (init == false) {   // ref src/cvo.cpp:325-334
+        std::cout << "initializing cvo..." << std::endl;
+        check(cvo_hip_set_fixed_device(ctx_, d_pos, d_feat, fe_points_, CVO_HIP_FEAT_ROWMAJOR),
+              "cvo_hip_set_fixed_device");
+        std::cout << "first pcd generated!" << std::endl;
+        init = true;
+        return;
+    }
+    check(cvo_hip_set_moving_device(ctx_, d_pos, d_feat, fe_points_, CVO_HIP_FEAT_ROWMAJOR),
+          "cvo_hip_set_moving_device");
+    have_moving_ = true;
+    std::cout << "num moving: " << fe_points_ << std::endl;   // ref src/cvo.cpp:343-347
 }
 
 void registration::set_pcd(const int dataset_seq, const image_view &RGB_img, const image_view &dep_img,
                            const std::string &, const std::string &)
 {
-    const bool first = !init;
-    set_pcd(make_cloud(dataset_seq, RGB_img, dep_img));
-    if (!first) {   // ref src/cvo.cpp:343-347
-        std::cout << "num moving: " << fe_points_ << std::endl;
-    }
+    cloud_from_images(dataset_seq, RGB_img, dep_img);
 }
 
 void registration::run_cvo(const int dataset_seq, const image_view &RGB_img, const image_view &dep_img,
                            const std::string &, const std::string &)
 {   // ref src/cvo.cpp:422-435
-    run_cvo(make_cloud(dataset_seq, RGB_img, dep_img));
+    const bool first = !init;
+    cloud_from_images(dataset_seq, RGB_img, dep_img);
+    if (first) return;
+    align();
+    std::cout << "Total iterations: " << iter << std::endl;
+    std::cout << "RKHS-SE(3) Object Transformation Estimate: \n";
+    for (int r = 0; r < 4; ++r)
+        std::cout << transform.m[4 * r] << " " << transform.m[4 * r + 1] << " " << transform.m[4 * r + 2] << " "
+                  << transform.m[4 * r + 3] << std::endl;
 }
 
 void registration::check(int status, const char *what)

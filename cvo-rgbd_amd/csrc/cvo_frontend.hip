@@ -908,11 +908,31 @@ int cvo_fe_submit(cvo_fe_ctx *ctx, const uint8_t *img, size_t img_stride, const 
     return CVO_HIP_OK;
 }
 
+namespace {
+int collect_impl(cvo_fe_ctx *ctx, float *positions, float *features, int capacity, int *num_points, bool to_host);
+}
+
 int cvo_fe_collect(cvo_fe_ctx *ctx, float *positions, float *features, int capacity, int *num_points)
 {
     if (!ctx) return CVO_HIP_ERR_INVALID;
     if (!num_points || capacity < 0 || (capacity > 0 && (!positions || !features)))
         return fail(ctx, CVO_HIP_ERR_INVALID, "collect: bad argument");
+    return collect_impl(ctx, positions, features, capacity, num_points, true);
+}
+
+int cvo_fe_collect_device(cvo_fe_ctx *ctx, const float **d_positions, const float **d_features, int *num_points)
+{
+    if (!ctx) return CVO_HIP_ERR_INVALID;
+    if (!d_positions || !d_features || !num_points) return fail(ctx, CVO_HIP_ERR_INVALID, "collect_device: bad argument");
+    const int rc = collect_impl(ctx, nullptr, nullptr, ctx->cap, num_points, false);
+    *d_positions = ctx->pos;
+    *d_features = ctx->feat;
+    return rc;
+}
+
+namespace {
+int collect_impl(cvo_fe_ctx *ctx, float *positions, float *features, int capacity, int *num_points, bool to_host)
+{
     if (!ctx->pending) return fail(ctx, CVO_HIP_ERR_INVALID, "collect: no frame was submitted");
     ctx->pending = false;
     FE_HIP(hipSetDevice(ctx->device));
@@ -936,19 +956,21 @@ int cvo_fe_collect(cvo_fe_ctx *ctx, float *positions, float *features, int capac
     ctx->info.num_points = c.num_points;
     *num_points = c.num_points;
     const int ncopy = std::min(std::min(c.num_points, capacity), ctx->cap);
-    if (ncopy > ctx->copied) {   // an unusually large cloud: fetch the rest
+    if (to_host && ncopy > ctx->copied) {   // an unusually large cloud: fetch the rest
         const size_t from = (size_t)ctx->copied, more = (size_t)(ncopy - ctx->copied);
         FE_HIP(hipMemcpyAsync(ctx->h_pos + from * 3, ctx->pos + from * 3, more * 3 * sizeof(float), hipMemcpyDeviceToHost, s));
         FE_HIP(hipMemcpyAsync(ctx->h_feat + from * 5, ctx->feat + from * 5, more * 5 * sizeof(float), hipMemcpyDeviceToHost, s));
         FE_HIP(hipStreamSynchronize(s));
     }
-    if (ncopy > 0) {
+    if (to_host && ncopy > 0) {
         std::memcpy(positions, ctx->h_pos, (size_t)ncopy * 3 * sizeof(float));
         std::memcpy(features, ctx->h_feat, (size_t)ncopy * 5 * sizeof(float));
     }
     if (c.num_points > ncopy) return fail(ctx, CVO_HIP_ERR_INVALID, "create_pointcloud: more points than capacity");
     return CVO_HIP_OK;
 }
+
+}   // namespace
 
 int cvo_fe_create_pointcloud(cvo_fe_ctx *ctx, const uint8_t *img, size_t img_stride, const uint16_t *depth,
                              size_t depth_stride, int dataset_seq, int feature_type, float *positions,

@@ -27,7 +27,7 @@ FEATURES_HSV, FEATURES_RGB = 0, 1
  STAGE_EDGES) = range(10)
 
 SYMBOLS = ("cvo_fe_create", "cvo_fe_destroy", "cvo_fe_last_error", "cvo_fe_set_num_want",
-           "cvo_fe_create_pointcloud", "cvo_fe_submit", "cvo_fe_collect", "cvo_fe_get_info", "cvo_fe_read_stage", "cvo_fe_random_pattern",
+           "cvo_fe_create_pointcloud", "cvo_fe_submit", "cvo_fe_collect", "cvo_fe_collect_device", "cvo_fe_get_info", "cvo_fe_read_stage", "cvo_fe_random_pattern",
            "cvo_fe_camera")
 
 
@@ -54,6 +54,7 @@ def lib():
                                                C.c_int, C.POINTER(C.c_int)]
         L.cvo_fe_submit.argtypes = [vp, u8p, C.c_size_t, u16p, C.c_size_t, C.c_int, C.c_int]
         L.cvo_fe_collect.argtypes = [vp, fp, fp, C.c_int, C.POINTER(C.c_int)]
+        L.cvo_fe_collect_device.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(C.c_int)]
         L.cvo_fe_get_info.argtypes = [vp, C.POINTER(Info)]
         L.cvo_fe_read_stage.argtypes = [vp, C.c_int, vp, C.c_size_t]
         L.cvo_fe_random_pattern.argtypes = [C.c_int, u8p]
@@ -138,6 +139,13 @@ class PcdGenerator:
                   "collect")
         return self._pos[:n.value].copy(), self._feat[:n.value].copy()
 
+    def collect_device(self):
+        """collect() without the copy to the host: (device address of the positions, of the
+        features, number of points); valid until the next submit on this object."""
+        dp, df, n = C.c_void_p(), C.c_void_p(), C.c_int(0)
+        self._chk(lib().cvo_fe_collect_device(self._h, C.byref(dp), C.byref(df), C.byref(n)), "collect_device")
+        return dp.value, df.value, n.value
+
     def info(self):
         out = Info()
         self._chk(lib().cvo_fe_get_info(self._h, C.byref(out)), "get_info")
@@ -194,12 +202,14 @@ def load_img(rgb_path, depth_path):
     return np.ascontiguousarray(rgb[:, :, ::-1]), np.ascontiguousarray(dep)
 
 
-def run_frames(registration, frames, dataset_seq, writer=None, generator=None, prefetch=False):
+def run_frames(registration, frames, dataset_seq, writer=None, generator=None, prefetch=False, device=True):
     """The driver loop on decoded frames: `frames` yields (name, bgr, depth).  With
     `prefetch` frame k+1 is in the front end while frame k is being registered (the
     results are the same either way).  Off by default: measured on MI355X it wins 3 % when
     the two streams share a hardware queue and loses up to 40 % when they do not (the front
     end's launches then cut into the registration's latency-bound launch chain).
+    `device`: the cloud goes from the front end to the registration in device memory
+    (cvo_fe_collect_device -> cvo_hip_set_*_device) instead of through host arrays.
     Returns the number of frames."""
     ftype = FEATURES_HSV if registration.params.mode == capi.MODE_ACVO else FEATURES_RGB
     gen = generator
@@ -212,14 +222,20 @@ def run_frames(registration, frames, dataset_seq, writer=None, generator=None, p
         gen = PcdGenerator(cur[1].shape[1], cur[1].shape[0])
     gen.submit(cur[1], cur[2], dataset_seq, ftype)
     while cur is not None:
-        xyz, feat = gen.collect()
-        nxt = next(it, None)
-        if nxt is not None and prefetch:
-            gen.submit(nxt[1], nxt[2], dataset_seq, ftype)
-        registration.run_cvo(xyz, feat)
+        if device:
+            d_xyz, d_feat, npts = gen.collect_device()
+            nxt = next(it, None)
+            # (the device cloud is consumed before the next frame may overwrite it: no prefetch)
+            registration.run_cvo_device(d_xyz, d_feat, npts)
+        else:
+            xyz, feat = gen.collect()
+            nxt = next(it, None)
+            if nxt is not None and prefetch:
+                gen.submit(nxt[1], nxt[2], dataset_seq, ftype)
+            registration.run_cvo(xyz, feat)
         if writer is not None and registration.init:
             writer.append(cur[0], registration.accum_transform)
-        if nxt is not None and not prefetch:
+        if nxt is not None and (device or not prefetch):
             gen.submit(nxt[1], nxt[2], dataset_seq, ftype)
         count += 1
         cur = nxt

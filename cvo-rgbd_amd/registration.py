@@ -44,6 +44,21 @@ class _Registration:
         self.ctx.set_moving(positions, features, layout)
         self._have_moving = True
 
+    def set_pcd_device(self, d_positions, d_features, n, layout=capi.FEAT_ROWMAJOR):
+        """set_pcd with the cloud already in device memory (e.g. PcdGenerator.collect_device)."""
+        if not self.init:
+            self.ctx.set_fixed_device(d_positions, d_features, n, layout)
+            self.init = True
+            return
+        self.ctx.set_moving_device(d_positions, d_features, n, layout)
+        self._have_moving = True
+
+    def run_cvo_device(self, d_positions, d_features, n, layout=capi.FEAT_ROWMAJOR, trace_cap=0):
+        first = not self.init
+        self.set_pcd_device(d_positions, d_features, n, layout)
+        if not first:
+            self.align(trace_cap=trace_cap)
+
     def align(self, trace_cap=0):
         """ref src/cvo.cpp:361-420."""
         if not self._have_moving:

@@ -100,11 +100,10 @@ class registration {
     int n_iter_;
     cvo_fe_ctx *fe_;           // front end, created with the first image (its size is fixed then)
     int fe_w_, fe_h_, fe_points_;
-    float *fe_pos_, *fe_feat_; // the cloud of the last frame (host)
     int device_;
     void check(int status, const char *what);
     void publish();
-    point_cloud_view make_cloud(int dataset_seq, const image_view &rgb, const image_view &dep);
+    void cloud_from_images(int dataset_seq, const image_view &rgb, const image_view &dep);
 };
 
 }   // namespace cvo_hip

@@ -87,6 +87,11 @@ int cvo_fe_submit(cvo_fe_ctx *ctx, const uint8_t *img, size_t img_stride, const 
                   size_t depth_stride, int dataset_seq, int feature_type);
 int cvo_fe_collect(cvo_fe_ctx *ctx, float *positions, float *features, int capacity, int *num_points);
 
+/* collect() without the copy to the host: the cloud stays in device memory (positions
+ * n x 3, features n x 5 row-major, floats) for cvo_hip_set_fixed_device / _set_moving_device.
+ * The pointers are valid until the next submit() / create_pointcloud() on this context. */
+int cvo_fe_collect_device(cvo_fe_ctx *ctx, const float **d_positions, const float **d_features, int *num_points);
+
 /* what the last create_pointcloud / collect did */
 int cvo_fe_get_info(const cvo_fe_ctx *ctx, cvo_fe_info *out);
 /* copy an intermediate image of the last create_pointcloud to host memory */

@@ -145,6 +145,13 @@ int cvo_hip_set_moving(cvo_hip_ctx *ctx, const float *xyz, const float *feat, in
                        int feat_layout);
 /* ptr_fixed_pcd = std::move(ptr_moving_pcd) (ref src/cvo.cpp:417): device
  * buffers are swapped, nothing is re-uploaded. */
+/* The same with the cloud already in device memory (same device as the context), e.g. as
+ * the front end leaves it (cvo_fe_device_cloud, cvo_frontend.h): nothing but the bounding
+ * box (24 bytes) crosses PCIe.  The arrays may be re-used when the call returns. */
+int cvo_hip_set_fixed_device(cvo_hip_ctx *ctx, const float *d_xyz, const float *d_feat, int n,
+                             int feat_layout);
+int cvo_hip_set_moving_device(cvo_hip_ctx *ctx, const float *d_xyz, const float *d_feat, int m,
+                              int feat_layout);
 int cvo_hip_swap_moving_to_fixed(cvo_hip_ctx *ctx);
 
 /* Multi-GPU: this context owns target rows [row_lo,row_hi) of the fixed cloud

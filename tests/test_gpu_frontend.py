@@ -239,14 +239,15 @@ def test_submit_collect_and_prefetched_stream(pkg):
     ref = fo.create_pointcloud(bgr, dep, 1, 1)
     assert gen.info()["canny_used"] == 1 and np.array_equal(x3, ref["positions"]) and np.array_equal(f3, ref["features"])
     poses = []
-    for prefetch in (True, False):
+    for prefetch, device in ((True, False), (False, False), (False, True)):
         reg = pkg.Acvo()
         buf = io.StringIO()
         assert F.run_frames(reg, frames, 1, writer=pkg.trajectory.TrajectoryWriter(buf), generator=gen,
-                            prefetch=prefetch) == 4
+                            prefetch=prefetch, device=device) == 4
         poses.append(buf.getvalue())
         reg.close()
-    assert poses[0] == poses[1] and len(poses[0].strip().split("\n")) == 4
+    # prefetched, serial, and with the cloud handed over in device memory: the same poses
+    assert poses[0] == poses[1] == poses[2] and len(poses[0].strip().split("\n")) == 4
     gen.close()
 
 

@@ -484,3 +484,30 @@ def test_contexts_give_their_memory_back(pkg):
     torch.cuda.synchronize()
     free1, _ = torch.cuda.mem_get_info()
     assert free0 - free1 < 8 * 1024 * 1024, "device memory leaked: %d bytes" % (free0 - free1)
+
+
+@pytest.mark.parametrize("n", [1, 63, 64, 65, 1000, 10000, 50000])
+def test_cloud_in_device_memory_equals_host_hand_over(pkg, n):
+    """cvo_hip_set_*_device: the cloud prepared from device arrays gives the registration the
+    host hand-over gives (both layouts); the device-side Morton sort handles run boundaries"""
+    import torch
+    capi = pkg.capi
+    xf, ff, xm, fm = pkg.data.synthetic_pair(n, max(1, n - 3), seed=300 + n % 97)
+    results = []
+    for how in ("host", "device", "device_colmajor"):
+        c = capi.Context(mode=capi.MODE_CVO, device=0)
+        if how == "host":
+            c.set_fixed(xf, ff); c.set_moving(xm, fm)
+        else:
+            col = how.endswith("colmajor")
+            t = [torch.from_numpy(np.ascontiguousarray(a.T if (col and a.shape[1] == 5) else a)).cuda()
+                 for a in (xf, ff, xm, fm)]
+            lay = capi.FEAT_COLMAJOR if col else capi.FEAT_ROWMAJOR
+            torch.cuda.synchronize()
+            c.set_fixed_device(t[0].data_ptr(), t[1].data_ptr(), len(xf), lay)
+            c.set_moving_device(t[2].data_ptr(), t[3].data_ptr(), len(xm), lay)
+        st = capi.init_state(c.params)
+        it, _ = c.align(st, trace_cap=0)
+        results.append((it, bytes(st)))
+        c.close()
+    assert results[0] == results[1] == results[2]

@@ -14,14 +14,15 @@ base = [("%d" % k,) + pkg.data.synthetic_rgbd_frame(seed=77, texture=1.0, motion
 seq = [base[(k % 22) if (k % 22) < 12 else 22 - (k % 22)] for k in range(n)]   # forth and back
 gen = pkg.frontend.PcdGenerator(640, 480)
 for rep in range(3):
-    for prefetch in (True, False):
+  for DEV in (False, True):
+    for prefetch in ((True, False) if not DEV else (False,)):
         reg = cls()
-        pkg.frontend.run_frames(reg, seq[:3], 1, generator=gen, prefetch=prefetch)
+        pkg.frontend.run_frames(reg, seq[:3], 1, generator=gen, prefetch=prefetch, device=DEV)
         reg.close()
         reg = cls()
         t0 = time.perf_counter()
-        pkg.frontend.run_frames(reg, seq, 1, generator=gen, prefetch=prefetch)
+        pkg.frontend.run_frames(reg, seq, 1, generator=gen, prefetch=prefetch, device=DEV)
         dt = (time.perf_counter() - t0) / len(seq)
-        print("%s prefetch=%d: %.3f ms per frame (%.0f frames/s), last pair %d iterations" % (
-            mode, prefetch, dt * 1e3, 1 / dt, reg.num_iterations))
+        print("%s prefetch=%d device=%s: %.3f ms per frame (%.0f frames/s), last pair %d iterations" % (
+            mode, prefetch, DEV, dt * 1e3, 1 / dt, reg.num_iterations))
         reg.close()
