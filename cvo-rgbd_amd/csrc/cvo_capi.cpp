@@ -40,7 +40,9 @@ struct Cloud {
     float4 *pos = nullptr;   // Morton-sorted; .w = the 5th feature
     float *feat = nullptr;   // same order: f0..f4, index in the caller's cloud (int bits), 2 pad
     float4 *seg = nullptr;   // bounding sphere (centre, radius) of every SEG consecutive points
-    int n = 0;
+    int n = 0;               // points, as the caller counts them
+    int np = 0;              // rows of the device arrays: n padded to CLOUD_PAD (cvo_cloud.h); what kernels get
+    int pad_axis = 0;        // where the padding rows are parked (the two clouds of a pair differ)
     int cap = 0;
     float lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};   // bounding box
 };
@@ -148,6 +150,8 @@ struct cvo_hip_ctx {
     long long *post_dbg = nullptr;   // CVO_HIP_POST_DEBUG diagnostics
     std::vector<GraphEntry> graphs;  // small LRU cache (the clouds ping-pong between two buffers)
     uint64_t graph_clock = 0;
+    long long graph_hits = 0, graph_misses = 0;   // CVO_HIP_GRAPH_DEBUG diagnostics
+    int graph_fail = 0;                           // consecutive captures spoilt by an allocation
     bool warm = false;               // every device buffer of the loop has been allocated
     bool use_graphs = true;
     int iter_tag = -1;
@@ -222,20 +226,24 @@ int ensure_buf(cvo_hip_ctx *ctx, DevBuf &b, size_t bytes);
 int upload_cloud(cvo_hip_ctx *ctx, Cloud &c, const float *xyz, const float *feat, int n,
                  int layout, bool on_device = false)
 {
+    const int np = cloud_padded(n);
+    const Cloud &other = (&c == &ctx->fixed) ? ctx->moving : ctx->fixed;
     if (n < 0 || (n > 0 && (!xyz || !feat))) return fail(ctx, CVO_HIP_ERR_INVALID, "null cloud");
     if (layout != CVO_HIP_FEAT_COLMAJOR && layout != CVO_HIP_FEAT_ROWMAJOR)
         return fail(ctx, CVO_HIP_ERR_INVALID, "bad feat_layout");
-    if (n > c.cap) {
+    if (np > c.cap) {
         if (c.pos) HIP_TRY(ctx, hipFree(c.pos));
         if (c.feat) HIP_TRY(ctx, hipFree(c.feat));
         if (c.seg) HIP_TRY(ctx, hipFree(c.seg));
         c.pos = nullptr; c.feat = nullptr; c.seg = nullptr; c.cap = 0;
-        HIP_TRY(ctx, hipMalloc((void **)&c.pos, (size_t)n * sizeof(float4)));
-        HIP_TRY(ctx, hipMalloc((void **)&c.feat, (size_t)n * FEAT_STRIDE * sizeof(float)));
-        HIP_TRY(ctx, hipMalloc((void **)&c.seg, (size_t)((n + SEG - 1) / SEG) * sizeof(float4)));
-        c.cap = n;
+        HIP_TRY(ctx, hipMalloc((void **)&c.pos, (size_t)np * sizeof(float4)));
+        HIP_TRY(ctx, hipMalloc((void **)&c.feat, (size_t)np * FEAT_STRIDE * sizeof(float)));
+        HIP_TRY(ctx, hipMalloc((void **)&c.seg, (size_t)((np + SEG - 1) / SEG) * sizeof(float4)));
+        c.cap = np;
     }
     c.n = n;
+    c.np = np;
+    c.pad_axis = (other.n > 0) ? 1 - other.pad_axis : 0;
     for (int a = 0; a < 3; ++a) { c.lo[a] = 0.0f; c.hi[a] = 0.0f; }
     if (n == 0) return CVO_HIP_OK;
     const size_t bytes_xyz = (size_t)n * 3 * sizeof(float), bytes_feat = (size_t)n * CVO_HIP_NFEAT * sizeof(float);
@@ -288,6 +296,7 @@ int upload_cloud(cvo_hip_ctx *ctx, Cloud &c, const float *xyz, const float *feat
     if (!rc) rc = ensure_buf(ctx, ctx->sort_tmp, tmp);
     if (rc) return rc;
     CloudPrep cp{};
+    cp.np = np; cp.pad_axis = c.pad_axis;
     cp.xyz = d_xyz; cp.feat = d_feat; cp.n = n; cp.colmajor = layout == CVO_HIP_FEAT_COLMAJOR ? 1 : 0;
     for (int a = 0; a < 3; ++a) { cp.lo[a] = c.lo[a]; cp.hi[a] = c.hi[a]; }
     for (int q = 0; q < 2; ++q) { cp.keys[q] = (uint32_t *)ctx->sort_keys[q].p; cp.idx[q] = (int *)ctx->sort_idx[q].p; }
@@ -381,9 +390,9 @@ int ensure_list(cvo_hip_ctx *ctx, int list, int nrows, int nb, double at_least)
 void shard_ranges(const cvo_hip_ctx *ctx, int &rlo, int &rhi, int &slo, int &shi)
 {
     rlo = ctx->sharded ? ctx->row_lo : 0;
-    rhi = ctx->sharded ? std::min(ctx->row_hi, ctx->fixed.n) : ctx->fixed.n;
+    rhi = ctx->sharded ? std::min(ctx->row_hi, ctx->fixed.n) : ctx->fixed.np;   // (padding rows are inert)
     slo = ctx->sharded ? ctx->srow_lo : 0;
-    shi = ctx->sharded ? std::min(ctx->srow_hi, ctx->moving.n) : ctx->moving.n;
+    shi = ctx->sharded ? std::min(ctx->srow_hi, ctx->moving.n) : ctx->moving.np;
     rlo = std::min(rlo, rhi);
     slo = std::min(slo, shi);
 }
@@ -393,6 +402,7 @@ void shard_ranges(const cvo_hip_ctx *ctx, int &rlo, int &rhi, int &slo, int &shi
 void fill_filter_geometry(const cvo_hip_ctx *ctx, DevState *h)
 {
     const Cloud &cf = ctx->fixed.n > 0 ? ctx->fixed : ctx->moving;
+    h->n_fixed = ctx->fixed.n;
     for (int a = 0; a < 3; ++a) h->center[a] = 0.5f * (cf.lo[a] + cf.hi[a]);
     auto radius = [&](const Cloud &c) {
         if (c.n <= 0) return 0.0f;
@@ -417,7 +427,7 @@ int enqueue_filter(cvo_hip_ctx *ctx, int list, const Cloud &ca, int row_lo, int 
                    const Cloud &cb, int tf_b, int check_done)
 {
     const float4 *pos_a = ca.pos, *pos_b = cb.pos;
-    const int nb = cb.n;
+    const int nb = cb.np;
     const int nrows = row_hi - row_lo;
     if (nrows <= 0 || nb <= 0) return CVO_HIP_OK;
     int rc = ensure_list(ctx, list, nrows, nb, 0);
@@ -493,7 +503,7 @@ int enqueue_process(cvo_hip_ctx *ctx, int mode, int list, DevBuf &part, const fl
         HIP_TRY(ctx, hipMemsetAsync(ctx->kept_cnt.p, 0, PROC_WAVES * sizeof(uint32_t), ctx->stream));
     }
     if (mode == PROC_FLOW)   // the kept list is sized from the pair set this pass evaluates
-        rc = ensure_list(ctx, LIST_KEPT, ctx->fixed.n, ctx->moving.n, 0);
+        rc = ensure_list(ctx, LIST_KEPT, ctx->fixed.np, ctx->moving.np, 0);
     else
         rc = ensure_list(ctx, LIST_KEPT, 0, 0, 0);
     if (rc) return rc;
@@ -649,7 +659,7 @@ int enqueue_flow(cvo_hip_ctx *ctx, bool tf_moving, int check_done, bool do_math,
         if (!rc)
             rc = enqueue_process(ctx, PROC_SELF, LIST_YY, ctx->part_yy, ctx->moving.pos,
                                  ctx->moving.feat, tfm, ctx->moving.pos, ctx->moving.feat, tfm,
-                                 ctx->fixed.n, check_done);
+                                 1 /* rows below st->n_fixed do not count */, check_done);
     }
     if (group_lists) {
         ctx->rec = nullptr;
@@ -775,11 +785,12 @@ int prepare_buffers(cvo_hip_ctx *ctx)
     const bool acvo = ctx->prm.mode == CVO_HIP_MODE_ACVO;
     int rlo, rhi, slo, shi;
     shard_ranges(ctx, rlo, rhi, slo, shi);
-    int rc = ensure_list(ctx, LIST_XY, rhi - rlo, ctx->moving.n, 0);
+    // (padded sizes, the ones enqueue_filter sees: the capacities must not move while a batch is captured)
+    int rc = ensure_list(ctx, LIST_XY, rhi - rlo, ctx->moving.np, 0);
     if (!rc) rc = ensure_list(ctx, LIST_XYB, 0, 0, (double)ctx->lists[LIST_XY].cap);   // second xy buffer
-    if (!rc) rc = ensure_list(ctx, LIST_KEPT, ctx->fixed.n, ctx->moving.n, 0);
-    if (!rc && acvo) rc = ensure_list(ctx, LIST_XX, rhi - rlo, ctx->fixed.n, 0);
-    if (!rc && acvo) rc = ensure_list(ctx, LIST_YY, shi - slo, ctx->moving.n, 0);
+    if (!rc) rc = ensure_list(ctx, LIST_KEPT, ctx->fixed.np, ctx->moving.np, 0);
+    if (!rc && acvo) rc = ensure_list(ctx, LIST_XX, rhi - rlo, ctx->fixed.np, 0);
+    if (!rc && acvo) rc = ensure_list(ctx, LIST_YY, shi - slo, ctx->moving.np, 0);
     if (!rc && acvo) rc = ensure_list(ctx, LIST_XXB, 0, 0, (double)ctx->lists[LIST_XX].cap);
     if (!rc && acvo) rc = ensure_list(ctx, LIST_YYB, 0, 0, (double)ctx->lists[LIST_YY].cap);
     for (DevBuf *b : {&ctx->part_flow, &ctx->part_xx, &ctx->part_yy, &ctx->part_step})
@@ -815,8 +826,9 @@ std::vector<uint64_t> graph_key(const cvo_hip_ctx *ctx, int trace_cap)
     std::vector<uint64_t> k;
     auto P = [&](const void *p) { k.push_back((uint64_t)(uintptr_t)p); };
     auto I = [&](uint64_t v) { k.push_back(v); };
-    P(ctx->fixed.pos); P(ctx->fixed.feat); P(ctx->fixed.seg); I(ctx->fixed.n);
-    P(ctx->moving.pos); P(ctx->moving.feat); P(ctx->moving.seg); I(ctx->moving.n);
+    // (padded sizes: a stream of frames whose clouds differ by a few points re-uses one graph)
+    P(ctx->fixed.pos); P(ctx->fixed.feat); P(ctx->fixed.seg); I(ctx->fixed.np);
+    P(ctx->moving.pos); P(ctx->moving.feat); P(ctx->moving.seg); I(ctx->moving.np);
     for (int l = 0; l < LIST_N; ++l) { P(ctx->lists[l].a.p); P(ctx->lists[l].b.p); I(ctx->lists[l].cap); }
     P(ctx->kept_cnt.p); P(ctx->part_flow.p); P(ctx->part_xx.p); P(ctx->part_yy.p); P(ctx->part_step.p);
     P(ctx->trace_dev); I((uint64_t)trace_cap); P(ctx->st); P(ctx->post_dbg);
@@ -853,6 +865,7 @@ int launch_batch(cvo_hip_ctx *ctx, int tag0, int trace_cap)
     GraphEntry *hit = nullptr;
     for (auto &g : ctx->graphs)
         if (g.key == key) { hit = &g; break; }
+    if (hit) ++ctx->graph_hits; else ++ctx->graph_misses;
     if (!hit) {
         if (ctx->graphs.size() >= 4) {   // evict the least recently used entry
             size_t lru = 0;
@@ -871,11 +884,17 @@ int launch_batch(cvo_hip_ctx *ctx, int tag0, int trace_cap)
         if (e != hipSuccess) { ctx->err = "hipStreamEndCapture failed"; return CVO_HIP_ERR_HIP; }
         if (graph_key(ctx, trace_cap) != key) {
             // something was (re)allocated while capturing: the capture is unusable
+            if (getenv("CVO_HIP_GRAPH_DEBUG")) {
+                const std::vector<uint64_t> k2 = graph_key(ctx, trace_cap);
+                for (size_t q = 0; q < key.size(); ++q)
+                    if (key[q] != k2[q]) fprintf(stderr, "[cvo_hip] graph key element %zu changed during capture\n", q);
+            }
             (void)hipGraphDestroy(g.graph);
-            ctx->use_graphs = false;
+            if (++ctx->graph_fail >= 8) ctx->use_graphs = false;   // (a buffer grew: normally a one-off)
             return enqueue_iterations(ctx, kBatch, tag0, trace_cap);
         }
         HIP_TRY(ctx, hipGraphInstantiate(&g.exec, g.graph, nullptr, nullptr, 0));
+        ctx->graph_fail = 0;
         ctx->graphs.push_back(g);
         hit = &ctx->graphs.back();
     }
@@ -1060,6 +1079,8 @@ int cvo_hip_destroy(cvo_hip_ctx *ctx)
     for (int i = 0; i < kPollSlots; ++i)
         if (ctx->poll_ev[i]) (void)hipEventDestroy(ctx->poll_ev[i]);
     if (ctx->comm) cvo_comm_destroy(ctx->comm);
+    if (getenv("CVO_HIP_GRAPH_DEBUG"))
+        fprintf(stderr, "[cvo_hip] graph cache: %lld hits, %lld captures\n", ctx->graph_hits, ctx->graph_misses);
     drop_graphs(ctx);
     if (ctx->post_dbg) {
         long long h[8];
@@ -1132,6 +1153,7 @@ int cvo_hip_swap_moving_to_fixed(cvo_hip_ctx *ctx)
     if (!ctx) return CVO_HIP_ERR_INVALID;
     std::swap(ctx->fixed, ctx->moving);
     ctx->moving.n = 0;
+    ctx->moving.np = 0;
     ctx->have_tf = false;
     return CVO_HIP_OK;
 }

@@ -10,6 +10,8 @@ struct CloudPrep {
     const float *xyz;    // device: n x 3 as the caller gave them
     const float *feat;   // device: n x 5, row- or column-major
     int n, colmajor;
+    int np;              // rows of the device arrays: n rounded up to CLOUD_PAD, the tail is padding
+    int pad_axis;        // 0 / 1: which way the padding rows are parked (differs between the two clouds of a pair)
     float lo[3], hi[3];  // bounding box of xyz
     uint32_t *keys[2];   // device scratch, n each
     int *idx[2];
@@ -19,6 +21,13 @@ struct CloudPrep {
     float *feat8;        // out: n x FEAT_STRIDE
     float4 *seg;         // out: bounding spheres of the SEG-point runs
 };
+
+// Device clouds are padded to a multiple of CLOUD_PAD rows: kernel arguments (and captured
+// graphs) then change only when a cloud crosses a bucket, not with every frame of a stream.
+// Padding rows are parked ~10 km away, 16 m apart, with NaN features: the filter never lists
+// them, and if it did the exact test would drop them.
+constexpr int CLOUD_PAD = 256;
+inline int cloud_padded(int n) { return n <= 0 ? 0 : (n + CLOUD_PAD - 1) / CLOUD_PAD * CLOUD_PAD; }
 
 size_t cloud_sort_scratch_bytes(int n);
 // bbox6 (device): min xyz, max xyz

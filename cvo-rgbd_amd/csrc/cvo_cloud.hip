@@ -137,6 +137,25 @@ __global__ void __launch_bounds__(CB) k_cloud_seg(const float4 *pos, int n, int 
     if (lane == 0) seg[g] = make_float4(c[0], c[1], c[2], (float)(sqrt(d2) * 1.00001 + 1e-6));
 }
 
+// padding rows [n, np): parked far away along `axis`, 16 m apart; NaN features
+__global__ void __launch_bounds__(CB) k_cloud_pad(float4 *pos, float *feat8, float4 *seg, int n, int np, float bx,
+                                                  float by, float bz, int axis)
+{
+    const int q = n + blockIdx.x * CB + threadIdx.x;
+    if (q >= np) return;
+    const float nanv = __int_as_float(0x7fc00000);
+    const float off = 1.0e4f + 16.0f * (float)(q - n);
+    const float4 p = axis ? make_float4(bx, by + off, bz, nanv) : make_float4(bx + off, by, bz, nanv);
+    pos[q] = p;
+    float4 *o = reinterpret_cast<float4 *>(feat8 + (size_t)q * FEAT_STRIDE);
+    o[0] = make_float4(nanv, nanv, nanv, nanv);
+    o[1] = make_float4(nanv, __int_as_float(-1), 0.0f, 0.0f);
+    // runs that hold nothing but padding get a sphere of their own (the last real run keeps the
+    // sphere of its real points: k_cloud_seg)
+    if ((q & (SEG - 1)) == 0 && q >= ((n + SEG - 1) / SEG) * SEG)
+        seg[q / SEG] = make_float4(p.x + (axis ? 0.0f : 8.0f * SEG), p.y + (axis ? 8.0f * SEG : 0.0f), p.z, 8.5f * SEG);
+}
+
 }   // namespace
 
 size_t cloud_sort_scratch_bytes(int n)
@@ -174,6 +193,9 @@ hipError_t cloud_prepare_device(const CloudPrep &c, hipStream_t s)
     hipLaunchKernelGGL(k_cloud_pack, dim3(nb), dim3(CB), 0, s, c.xyz, c.feat, n, c.colmajor, c.idx[1], c.pos, c.feat8);
     const int nseg = (n + SEG - 1) / SEG;
     hipLaunchKernelGGL(k_cloud_seg, dim3((nseg + CB / 64 - 1) / (CB / 64)), dim3(CB), 0, s, c.pos, n, nseg, c.seg);
+    if (c.np > n)
+        hipLaunchKernelGGL(k_cloud_pad, dim3((c.np - n + CB - 1) / CB), dim3(CB), 0, s, c.pos, c.feat8, c.seg, n, c.np,
+                           0.5f * (c.lo[0] + c.hi[0]), 0.5f * (c.lo[1] + c.hi[1]), 0.5f * (c.lo[2] + c.hi[2]), c.pad_axis);
     return hipGetLastError();
 }
 

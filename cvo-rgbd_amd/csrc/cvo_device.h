@@ -129,6 +129,8 @@ struct DevState {
     float center[3];
     float xmax, y0max;          // max |x - center|, max |y0 - center| (bbox bounds)
     float tauf[3];
+    int32_t n_fixed;            // points of the fixed cloud as the caller counts them (acvo Ayy rule);
+    int32_t n_rsv_;             // kernel arguments only carry the padded sizes (cvo_cloud.h)
     // Tile-list re-use (plan_lists): list l was built with every pair closer than
     // list_r[l]; the xy list with the moving cloud at [list_Rt | list_t].
     float list_r[3];
@@ -221,7 +223,7 @@ struct ProcessArgs {
     int32_t *done_mirror;
     int list;              // which tile list
     int row_hi, nb;        // valid rows / columns (mask bits beyond are padding)
-    int first_counted;     // PROC_SELF: rows whose caller index is below contribute 0 to the sum
+    int first_counted;     // PROC_SELF: 1 = rows whose caller index is below st->n_fixed contribute 0 to the sum
     int tf_a, tf_b;
     int check_done;
     int weight;            // PROC_FLOW: 0 the C++ pair weight, 1 the MATLAB object's (classic launches only)

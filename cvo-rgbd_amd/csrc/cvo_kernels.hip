@@ -567,7 +567,8 @@ template <> struct NAcc<PROC_SELF> { static constexpr int n = NACC_SELF; };
 template <int MODE, int WEIGHT = 0>
 __device__ __forceinline__ float eval_pair(const ProcessArgs &a, const KernConsts &kc, unsigned i,
                                            unsigned j, float w, double *acc,
-                                           const cvo_math::XiConsts &xc, const double *etab = nullptr)
+                                           const cvo_math::XiConsts &xc, const double *etab = nullptr,
+                                           const int first_counted = 0)
 {
     const float *Rt = a.st->Rt;
     const float *tt = a.st->t;
@@ -644,7 +645,7 @@ __device__ __forceinline__ float eval_pair(const ProcessArgs &a, const KernConst
         acc[3] += A * ((((double)(epsil + beta * delta) + 0.5 * b * b * g) + 0.5 * g * g) +
                        1 / 24.0 * b * b * b * b);
     } else {
-        if (row_index >= a.first_counted) acc[0] += (double)((kc.inv_l3 * w) * d2);
+        if (row_index >= first_counted) acc[0] += (double)((kc.inv_l3 * w) * d2);
         acc[1] += 1.0;
     }
     return w;
@@ -672,6 +673,9 @@ __device__ __forceinline__ void process_body(const ProcessArgs &a, const unsigne
     // (async xy: a stall slot only builds; PROC_FLOW reads the buffer in use)
     const int done_word = a.check_done ? (a.st->done | (a.async_xy ? a.st->stall : 0)) : 0;
     const KernConsts kc = a.st->kc;
+    // (acvo Ayy rule, SURVEY 8a quirk 5: the caller's count of fixed points lives in the state, so
+    // that the kernel arguments -- and with them a captured graph -- do not depend on it)
+    const int first_counted = (MODE == PROC_SELF && a.first_counted) ? a.st->n_fixed : 0;
     const bool second = (MODE == PROC_FLOW && a.async_xy && a.st->xy_active == 1) ||
                         (MODE == PROC_SELF && a.async_self && a.st->sf_active[a.async_self - 1] == 1);
     const int in_list = !second ? a.list : (MODE == PROC_FLOW ? (int)LIST_XYB : self_list_id(a.async_self - 1, 1));
@@ -724,7 +728,7 @@ __device__ __forceinline__ void process_body(const ProcessArgs &a, const unsigne
             uint2 pr = make_uint2(0u, 0u);
             if (lane < cnt) {
                 pr = pairq[base + lane];
-                w = eval_pair<MODE, WEIGHT>(a, kc, pr.x, pr.y, 0.0f, acc, a.st->xi, s_etab);   // (xi: PROC_STEP only)
+                w = eval_pair<MODE, WEIGHT>(a, kc, pr.x, pr.y, 0.0f, acc, a.st->xi, s_etab, first_counted);   // (xi: PROC_STEP only)
             }
             if (MODE == PROC_FLOW) {   // record the members of A in this wave's slice
                 const unsigned long long km = __ballot(w > 0.0f);
