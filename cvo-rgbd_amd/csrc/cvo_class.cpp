@@ -83,6 +83,7 @@ void registration::cloud_from_images(int dataset_seq, const image_view &rgb, con
         const int rc = cvo_fe_create(device_, nullptr, rgb.cols, rgb.rows, &fe_);
         if (rc != CVO_HIP_OK) throw std::runtime_error(std::string("cvo_fe_create: ") + cvo_hip_error_string(rc));
         fe_w_ = rgb.cols; fe_h_ = rgb.rows;
+        cvo_fe_set_device_output(fe_, 1);
     }
     if (rgb.cols != fe_w_ || rgb.rows != fe_h_)
         throw std::runtime_error("set_pcd(): the image size changed within a sequence");

@@ -661,6 +661,7 @@ struct cvo_fe_ctx {
     cvo_fe_info info{};
     int copied = 0;            // points of the cloud already on their way to h_pos / h_feat
     bool pending = false;      // a frame was submitted and not collected yet
+    bool device_output = false;   // collect_device() will be used: no copy of the cloud to the host
     int p_seq = 0, p_ftype = 0;
     std::string err;
 };
@@ -723,6 +724,9 @@ int run_emit(cvo_fe_ctx *ctx, int dataset_seq, int feature_type)
     hipLaunchKernelGGL(k_fe_emit, dim3(ctx->nchunks), dim3(FE_BLOCK), 0, s, e);
     FE_HIP(hipMemcpyAsync(ctx->h_ctrl, ctx->ctrl, sizeof(FeCtrl), hipMemcpyDeviceToHost, s));
     // the cloud follows optimistically (its size is not known yet): enough for any normal frame
+    // (not when the consumer takes it from device memory: cvo_fe_set_device_output)
+    ctx->copied = 0;
+    if (ctx->device_output) return CVO_HIP_OK;
     ctx->copied = std::min(ctx->cap, std::max(4096, 2 * ctx->num_want));
     FE_HIP(hipMemcpyAsync(ctx->h_pos, ctx->pos, (size_t)ctx->copied * 3 * sizeof(float), hipMemcpyDeviceToHost, s));
     FE_HIP(hipMemcpyAsync(ctx->h_feat, ctx->feat, (size_t)ctx->copied * 5 * sizeof(float), hipMemcpyDeviceToHost, s));
@@ -838,6 +842,14 @@ int cvo_fe_create(int device, void *stream, int width, int height, cvo_fe_ctx **
         hipMemset(ctx->edges, 0, np) != hipSuccess || hipMemset(ctx->map, 0, np * sizeof(float)) != hipSuccess)
         return bail(CVO_HIP_ERR_HIP);
     *out = ctx;
+    return CVO_HIP_OK;
+}
+
+int cvo_fe_set_device_output(cvo_fe_ctx *ctx, int on)
+{
+    if (!ctx) return CVO_HIP_ERR_INVALID;
+    if (ctx->pending) return fail(ctx, CVO_HIP_ERR_INVALID, "set_device_output: a frame is in flight");
+    ctx->device_output = on != 0;
     return CVO_HIP_OK;
 }
 

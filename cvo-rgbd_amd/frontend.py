@@ -27,7 +27,7 @@ FEATURES_HSV, FEATURES_RGB = 0, 1
  STAGE_EDGES) = range(10)
 
 SYMBOLS = ("cvo_fe_create", "cvo_fe_destroy", "cvo_fe_last_error", "cvo_fe_set_num_want",
-           "cvo_fe_create_pointcloud", "cvo_fe_submit", "cvo_fe_collect", "cvo_fe_collect_device", "cvo_fe_get_info", "cvo_fe_read_stage", "cvo_fe_random_pattern",
+           "cvo_fe_create_pointcloud", "cvo_fe_submit", "cvo_fe_collect", "cvo_fe_collect_device", "cvo_fe_set_device_output", "cvo_fe_get_info", "cvo_fe_read_stage", "cvo_fe_random_pattern",
            "cvo_fe_camera")
 
 
@@ -55,6 +55,7 @@ def lib():
         L.cvo_fe_submit.argtypes = [vp, u8p, C.c_size_t, u16p, C.c_size_t, C.c_int, C.c_int]
         L.cvo_fe_collect.argtypes = [vp, fp, fp, C.c_int, C.POINTER(C.c_int)]
         L.cvo_fe_collect_device.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(C.c_int)]
+        L.cvo_fe_set_device_output.argtypes = [vp, C.c_int]
         L.cvo_fe_get_info.argtypes = [vp, C.POINTER(Info)]
         L.cvo_fe_read_stage.argtypes = [vp, C.c_int, vp, C.c_size_t]
         L.cvo_fe_random_pattern.argtypes = [C.c_int, u8p]
@@ -146,6 +147,10 @@ class PcdGenerator:
         self._chk(lib().cvo_fe_collect_device(self._h, C.byref(dp), C.byref(df), C.byref(n)), "collect_device")
         return dp.value, df.value, n.value
 
+    def set_device_output(self, on=True):
+        """The following frames are taken with collect_device(): no copy of the cloud to the host."""
+        self._chk(lib().cvo_fe_set_device_output(self._h, 1 if on else 0), "set_device_output")
+
     def info(self):
         out = Info()
         self._chk(lib().cvo_fe_get_info(self._h, C.byref(out)), "get_info")
@@ -220,6 +225,7 @@ def run_frames(registration, frames, dataset_seq, writer=None, generator=None, p
         return 0
     if gen is None:
         gen = PcdGenerator(cur[1].shape[1], cur[1].shape[0])
+    gen.set_device_output(device)
     gen.submit(cur[1], cur[2], dataset_seq, ftype)
     while cur is not None:
         if device:

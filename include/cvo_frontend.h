@@ -92,6 +92,10 @@ int cvo_fe_collect(cvo_fe_ctx *ctx, float *positions, float *features, int capac
  * The pointers are valid until the next submit() / create_pointcloud() on this context. */
 int cvo_fe_collect_device(cvo_fe_ctx *ctx, const float **d_positions, const float **d_features, int *num_points);
 
+/* 1: the following frames are collected with cvo_fe_collect_device(): submit() then does not
+ * start the (optimistic) copy of the cloud to the host.  cvo_fe_collect() still works. */
+int cvo_fe_set_device_output(cvo_fe_ctx *ctx, int on);
+
 /* what the last create_pointcloud / collect did */
 int cvo_fe_get_info(const cvo_fe_ctx *ctx, cvo_fe_info *out);
 /* copy an intermediate image of the last create_pointcloud to host memory */
