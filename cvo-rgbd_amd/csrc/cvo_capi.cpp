@@ -254,10 +254,9 @@ int upload_cloud(cvo_hip_ctx *ctx, Cloud &c, const float *xyz, const float *feat
     const float *d_xyz = xyz, *d_feat = feat;
     if (on_device) {
         // the bounding box comes back to the host: the filter geometry of align() is made from it
+        // (it is waited for at the end, together with the preparation: one synchronisation)
         HIP_TRY(ctx, cloud_bbox_device(xyz, n, ctx->bbox_dev, ctx->stream));
         HIP_TRY(ctx, hipMemcpyAsync(ctx->bbox_host, ctx->bbox_dev, 6 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
-        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-        for (int a = 0; a < 3; ++a) { c.lo[a] = ctx->bbox_host[a]; c.hi[a] = ctx->bbox_host[3 + a]; }
     } else {
         for (int a = 0; a < 3; ++a) { c.lo[a] = INFINITY; c.hi[a] = -INFINITY; }
         for (int i = 0; i < n; ++i)
@@ -286,6 +285,8 @@ int upload_cloud(cvo_hip_ctx *ctx, Cloud &c, const float *xyz, const float *feat
         HIP_TRY(ctx, hipMemcpyAsync(ctx->raw_feat.p, hs + bytes_xyz, bytes_feat, hipMemcpyHostToDevice, ctx->stream));
         d_xyz = (const float *)ctx->raw_xyz.p;
         d_feat = (const float *)ctx->raw_feat.p;
+        for (int a = 0; a < 3; ++a) { ctx->bbox_host[a] = c.lo[a]; ctx->bbox_host[3 + a] = c.hi[a]; }
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->bbox_dev, ctx->bbox_host, 6 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
     }
     int rc = CVO_HIP_OK;
     for (int q = 0; q < 2 && !rc; ++q) {
@@ -298,13 +299,15 @@ int upload_cloud(cvo_hip_ctx *ctx, Cloud &c, const float *xyz, const float *feat
     CloudPrep cp{};
     cp.np = np; cp.pad_axis = c.pad_axis;
     cp.xyz = d_xyz; cp.feat = d_feat; cp.n = n; cp.colmajor = layout == CVO_HIP_FEAT_COLMAJOR ? 1 : 0;
-    for (int a = 0; a < 3; ++a) { cp.lo[a] = c.lo[a]; cp.hi[a] = c.hi[a]; }
+    cp.bbox = ctx->bbox_dev;
     for (int q = 0; q < 2; ++q) { cp.keys[q] = (uint32_t *)ctx->sort_keys[q].p; cp.idx[q] = (int *)ctx->sort_idx[q].p; }
     cp.scratch = ctx->sort_tmp.p; cp.scratch_bytes = tmp;
     cp.pos = c.pos; cp.feat8 = c.feat; cp.seg = c.seg;
     HIP_TRY(ctx, cloud_prepare_device(cp, ctx->stream));
     // (the staging buffer, or the caller's device arrays, may be re-used once this returns)
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (on_device)
+        for (int a = 0; a < 3; ++a) { c.lo[a] = ctx->bbox_host[a]; c.hi[a] = ctx->bbox_host[3 + a]; }
     return CVO_HIP_OK;
 }
 

@@ -12,7 +12,7 @@ struct CloudPrep {
     int n, colmajor;
     int np;              // rows of the device arrays: n rounded up to CLOUD_PAD, the tail is padding
     int pad_axis;        // 0 / 1: which way the padding rows are parked (differs between the two clouds of a pair)
-    float lo[3], hi[3];  // bounding box of xyz
+    const float *bbox;   // device: bounding box of xyz (min xyz, max xyz)
     uint32_t *keys[2];   // device scratch, n each
     int *idx[2];
     void *scratch;       // rocPRIM temporary storage

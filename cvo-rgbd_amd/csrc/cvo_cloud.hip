@@ -65,18 +65,21 @@ __global__ void __launch_bounds__(1024) k_cloud_bbox(const float *xyz, int n, fl
     }
 }
 
-struct KeyArgs { float lo[3], inv[3]; };
 
 // 30-bit Morton key of every point (10 bits per axis of the bounding box) and the
 // identity permutation
-__global__ void __launch_bounds__(CB) k_cloud_keys(const float *xyz, int n, const KeyArgs k, uint32_t *keys, int *idx)
+__global__ void __launch_bounds__(CB) k_cloud_keys(const float *xyz, int n, const float *bbox, uint32_t *keys, int *idx)
 {
     const int i = blockIdx.x * CB + threadIdx.x;
     if (i >= n) return;
     uint32_t q[3];
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
-        float f = (xyz[3 * (size_t)i + a] - k.lo[a]) * k.inv[a];
+        // (the box is read from device memory: a cloud that arrives in device memory is prepared
+        // without the host having to see its box first)
+        const float lo = bbox[a], ext = bbox[3 + a] - lo;
+        const float inv = (ext > 0.0f && ext <= 3.4e38f) ? 1023.0f / ext : 0.0f;   // (finite extent)
+        float f = (xyz[3 * (size_t)i + a] - lo) * inv;
         if (!(f >= 0.0f)) f = 0.0f;   // also catches NaN
         if (f > 1023.0f) f = 1023.0f;
         q[a] = (uint32_t)f;
@@ -138,11 +141,12 @@ __global__ void __launch_bounds__(CB) k_cloud_seg(const float4 *pos, int n, int 
 }
 
 // padding rows [n, np): parked far away along `axis`, 16 m apart; NaN features
-__global__ void __launch_bounds__(CB) k_cloud_pad(float4 *pos, float *feat8, float4 *seg, int n, int np, float bx,
-                                                  float by, float bz, int axis)
+__global__ void __launch_bounds__(CB) k_cloud_pad(float4 *pos, float *feat8, float4 *seg, int n, int np,
+                                                  const float *bbox, int axis)
 {
     const int q = n + blockIdx.x * CB + threadIdx.x;
     if (q >= np) return;
+    const float bx = 0.5f * (bbox[0] + bbox[3]), by = 0.5f * (bbox[1] + bbox[4]), bz = 0.5f * (bbox[2] + bbox[5]);
     const float nanv = __int_as_float(0x7fc00000);
     const float off = 1.0e4f + 16.0f * (float)(q - n);
     const float4 p = axis ? make_float4(bx, by + off, bz, nanv) : make_float4(bx + off, by, bz, nanv);
@@ -177,14 +181,8 @@ hipError_t cloud_prepare_device(const CloudPrep &c, hipStream_t s)
 {
     const int n = c.n;
     if (n <= 0) return hipSuccess;
-    KeyArgs k;
-    for (int a = 0; a < 3; ++a) {
-        const float ext = c.hi[a] - c.lo[a];
-        k.lo[a] = c.lo[a];
-        k.inv[a] = (ext > 0.0f && ext <= 3.4e38f) ? 1023.0f / ext : 0.0f;   // (finite extent)
-    }
     const int nb = (n + CB - 1) / CB;
-    hipLaunchKernelGGL(k_cloud_keys, dim3(nb), dim3(CB), 0, s, c.xyz, n, k, c.keys[0], c.idx[0]);
+    hipLaunchKernelGGL(k_cloud_keys, dim3(nb), dim3(CB), 0, s, c.xyz, n, c.bbox, c.keys[0], c.idx[0]);
     size_t bytes = c.scratch_bytes;
     // stable LSD radix sort over the 30 key bits: the permutation of sorting (key, index) pairs
     hipError_t e = rocprim::radix_sort_pairs(c.scratch, bytes, c.keys[0], c.keys[1], c.idx[0], c.idx[1], (size_t)n,
@@ -195,7 +193,7 @@ hipError_t cloud_prepare_device(const CloudPrep &c, hipStream_t s)
     hipLaunchKernelGGL(k_cloud_seg, dim3((nseg + CB / 64 - 1) / (CB / 64)), dim3(CB), 0, s, c.pos, n, nseg, c.seg);
     if (c.np > n)
         hipLaunchKernelGGL(k_cloud_pad, dim3((c.np - n + CB - 1) / CB), dim3(CB), 0, s, c.pos, c.feat8, c.seg, n, c.np,
-                           0.5f * (c.lo[0] + c.hi[0]), 0.5f * (c.lo[1] + c.hi[1]), 0.5f * (c.lo[2] + c.hi[2]), c.pad_axis);
+                           c.bbox, c.pad_axis);
     return hipGetLastError();
 }
 
