@@ -22,7 +22,7 @@ SYMBOLS = [
     "cvo_hip_transform_pcd", "cvo_hip_flow", "cvo_hip_step_coeffs", "cvo_hip_pick_step",
     "cvo_hip_exp_se3", "cvo_hip_dist_se3", "cvo_hip_align", "cvo_hip_align_many",
     "cvo_hip_function_inner_product",
-    "cvo_hip_set_profiling", "cvo_hip_get_profile", "cvo_hip_synchronize",
+    "cvo_hip_set_profiling", "cvo_hip_get_profile", "cvo_hip_get_graph_stats", "cvo_hip_synchronize",
 ]
 
 
@@ -122,6 +122,7 @@ def lib():
     L.cvo_hip_function_inner_product.argtypes = [vp, C.c_float, fp]
     L.cvo_hip_set_profiling.argtypes = [vp, C.c_int]
     L.cvo_hip_get_profile.argtypes = [vp, C.POINTER(Profile), C.c_int]
+    L.cvo_hip_get_graph_stats.argtypes = [vp, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]
     L.cvo_hip_synchronize.argtypes = [vp]
     for name in SYMBOLS:   # raises AttributeError if the library lacks a declared symbol
         if name not in ("cvo_hip_error_string", "cvo_hip_last_error"):
@@ -320,6 +321,12 @@ class Context:
         p = Profile()
         self._chk(self._L.cvo_hip_get_profile(self._ctx, C.byref(p), int(reset)), "get_profile")
         return {k: getattr(p, k) for k, _ in Profile._fields_}
+
+    def graph_stats(self):
+        """(batches launched from a cached graph, batches captured)."""
+        a, b = C.c_longlong(0), C.c_longlong(0)
+        self._chk(self._L.cvo_hip_get_graph_stats(self._ctx, C.byref(a), C.byref(b)), "graph_stats")
+        return a.value, b.value
 
     def synchronize(self):
         self._chk(self._L.cvo_hip_synchronize(self._ctx), "synchronize")

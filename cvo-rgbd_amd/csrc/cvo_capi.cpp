@@ -150,7 +150,7 @@ struct cvo_hip_ctx {
     long long *post_dbg = nullptr;   // CVO_HIP_POST_DEBUG diagnostics
     std::vector<GraphEntry> graphs;  // small LRU cache (the clouds ping-pong between two buffers)
     uint64_t graph_clock = 0;
-    long long graph_hits = 0, graph_misses = 0;   // CVO_HIP_GRAPH_DEBUG diagnostics
+    long long graph_hits = 0, graph_misses = 0;   // cvo_hip_get_graph_stats / CVO_HIP_GRAPH_DEBUG
     int graph_fail = 0;                           // consecutive captures spoilt by an allocation
     bool warm = false;               // every device buffer of the loop has been allocated
     bool use_graphs = true;
@@ -1956,6 +1956,14 @@ int cvo_hip_get_profile(cvo_hip_ctx *ctx, cvo_hip_profile *out, int reset)
     if (rc) return rc;
     *out = ctx->prof;
     if (reset) ctx->prof = cvo_hip_profile{};
+    return CVO_HIP_OK;
+}
+
+int cvo_hip_get_graph_stats(const cvo_hip_ctx *ctx, long long *launches_from_cache, long long *captures)
+{
+    if (!ctx || !launches_from_cache || !captures) return CVO_HIP_ERR_INVALID;
+    *launches_from_cache = ctx->graph_hits;
+    *captures = ctx->graph_misses;
     return CVO_HIP_OK;
 }
 

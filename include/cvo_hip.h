@@ -220,6 +220,9 @@ int cvo_hip_set_profiling(cvo_hip_ctx *ctx, int enable);
 int cvo_hip_get_profile(cvo_hip_ctx *ctx, cvo_hip_profile *out, int reset);
 
 /* Blocks until everything queued on the context's stream has finished. */
+/* Diagnostics: batches of align() launched from a cached hipGraph / batches that had to be
+ * captured first (a stream of frames should capture a handful of times, not per frame). */
+int cvo_hip_get_graph_stats(const cvo_hip_ctx *ctx, long long *launches_from_cache, long long *captures);
 int cvo_hip_synchronize(cvo_hip_ctx *ctx);
 
 #ifdef __cplusplus
