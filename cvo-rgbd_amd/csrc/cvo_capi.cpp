@@ -1620,11 +1620,22 @@ struct FusedRun {
         if (ev[1]) (void)hipEventDestroy(ev[1]);
     }
 
-    bool stopped_any() const
+    // Is it time to drain the queue and re-form the group?  A member that has finished costs
+    // next to nothing while it stays (its blocks return at their first load); taking it out
+    // costs a drained queue, new launch arguments and a new graph.  So the group is re-formed
+    // when half of it has finished (16 -> 8 -> 4 ...: a handful of times, not once per member),
+    // at once for a member that waits for a bigger list, and of course when all are through.
+    bool should_settle() const
     {
-        for (AlignJob *j : live)
-            if (*(volatile int32_t *)j->ctx->done_mirror != RUNNING) return true;
-        return false;
+        static const bool eager = getenv("CVO_HIP_SETTLE_EAGER") != nullptr;
+        size_t stopped = 0;
+        for (AlignJob *j : live) {
+            const int32_t d = *(volatile int32_t *)j->ctx->done_mirror;
+            if (d == NEED_BIGGER_LIST) return true;
+            if (d != RUNNING) ++stopped;
+        }
+        if (eager) return stopped > 0;
+        return stopped > 0 && (2 * stopped >= live.size() || stopped == live.size());
     }
 
     // (re)record the launch arguments of the current members; the list kernels get
@@ -1759,7 +1770,7 @@ struct FusedRun {
                 if (q != hipSuccess) { fail_all("fused poll failed"); return true; }
                 moved = true;
                 block = false;   // waited once: the caller decides whom to wait for next
-                state = stopped_any() ? SETTLE : LAUNCH;
+                state = should_settle() ? SETTLE : LAUNCH;
                 continue;
             }
             if (state == SETTLE) { settle(); moved = true; continue; }

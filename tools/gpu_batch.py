@@ -19,7 +19,7 @@ for B in BS:
     ctxs, streams = [], []
     for b in range(B):
         s = torch.cuda.Stream()
-        xf, ff, xm, fm = pkg.data.synthetic_pair(n, n, seed=pkg.data.SEED_CFG2, acvo=ACVO)
+        xf, ff, xm, fm = pkg.data.synthetic_pair(n, n, seed=(1000 + b) if os.environ.get("DISTINCT") else pkg.data.SEED_CFG2, acvo=ACVO)
         c = capi.Context(mode=capi.MODE_ACVO if ACVO else capi.MODE_CVO, device=0, stream=s.cuda_stream)
         c.set_fixed(xf, ff); c.set_moving(xm, fm)
         ctxs.append(c); streams.append(s)
