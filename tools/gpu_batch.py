@@ -33,5 +33,5 @@ for B in BS:
         its, states = step()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t
-    print("B %2d: %.1f registrations/s (%.2f ms per batch, iters %s)" % (B, B * reps / dt, dt * 1e3 / reps, its[:3]))
+    print("B %2d: %.1f registrations/s (%.2f ms per batch, iters %s, mean %.1f, %.2f us per registration-iteration)" % (B, B * reps / dt, dt * 1e3 / reps, its[:3], float(np.mean(its)), dt * 1e6 / reps / max(1, int(np.sum(its)))))
     for c in ctxs: c.close()
