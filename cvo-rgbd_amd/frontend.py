@@ -208,14 +208,13 @@ def load_img(rgb_path, depth_path):
 
 
 def run_frames(registration, frames, dataset_seq, writer=None, generator=None, prefetch=False, device=True):
-    """The driver loop on decoded frames: `frames` yields (name, bgr, depth).  With
-    `prefetch` frame k+1 is in the front end while frame k is being registered (the
-    results are the same either way).  Off by default: measured on MI355X it wins 3 % when
-    the two streams share a hardware queue and loses up to 40 % when they do not (the front
-    end's launches then cut into the registration's latency-bound launch chain).
+    """The driver loop on decoded frames: `frames` yields (name, bgr, depth).
     `device`: the cloud goes from the front end to the registration in device memory
     (cvo_fe_collect_device -> cvo_hip_set_*_device) instead of through host arrays.
-    Returns the number of frames."""
+    `prefetch`: frame k+1 is in the front end (its own, low-priority stream) while frame k
+    is being registered; the results are the same either way.  Off by default: measured on
+    MI355X it is worth +4-5 % per frame in a process that has little else on the GPU's queues
+    and -5 % in one that has (bench.py, after the batched legs).  Returns the number of frames."""
     ftype = FEATURES_HSV if registration.params.mode == capi.MODE_ACVO else FEATURES_RGB
     gen = generator
     it = iter(frames)
@@ -231,8 +230,12 @@ def run_frames(registration, frames, dataset_seq, writer=None, generator=None, p
         if device:
             d_xyz, d_feat, npts = gen.collect_device()
             nxt = next(it, None)
-            # (the device cloud is consumed before the next frame may overwrite it: no prefetch)
-            registration.run_cvo_device(d_xyz, d_feat, npts)
+            first = not registration.init
+            registration.set_pcd_device(d_xyz, d_feat, npts)   # (consumed: the next frame may overwrite it)
+            if nxt is not None and prefetch:
+                gen.submit(nxt[1], nxt[2], dataset_seq, ftype)
+            if not first:
+                registration.align()
         else:
             xyz, feat = gen.collect()
             nxt = next(it, None)
@@ -241,7 +244,7 @@ def run_frames(registration, frames, dataset_seq, writer=None, generator=None, p
             registration.run_cvo(xyz, feat)
         if writer is not None and registration.init:
             writer.append(cur[0], registration.accum_transform)
-        if nxt is not None and (device or not prefetch):
+        if nxt is not None and not prefetch:
             gen.submit(nxt[1], nxt[2], dataset_seq, ftype)
         count += 1
         cur = nxt

@@ -239,7 +239,7 @@ def test_submit_collect_and_prefetched_stream(pkg):
     ref = fo.create_pointcloud(bgr, dep, 1, 1)
     assert gen.info()["canny_used"] == 1 and np.array_equal(x3, ref["positions"]) and np.array_equal(f3, ref["features"])
     poses = []
-    for prefetch, device in ((True, False), (False, False), (False, True)):
+    for prefetch, device in ((True, False), (False, False), (False, True), (True, True)):
         reg = pkg.Acvo()
         buf = io.StringIO()
         assert F.run_frames(reg, frames, 1, writer=pkg.trajectory.TrajectoryWriter(buf), generator=gen,
@@ -247,7 +247,7 @@ def test_submit_collect_and_prefetched_stream(pkg):
         poses.append(buf.getvalue())
         reg.close()
     # prefetched, serial, and with the cloud handed over in device memory: the same poses
-    assert poses[0] == poses[1] == poses[2] and len(poses[0].strip().split("\n")) == 4
+    assert poses[0] == poses[1] == poses[2] == poses[3] and len(poses[0].strip().split("\n")) == 4
     gen.close()
 
 

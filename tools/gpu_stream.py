@@ -15,7 +15,7 @@ seq = [base[(k % 22) if (k % 22) < 12 else 22 - (k % 22)] for k in range(n)]   #
 gen = pkg.frontend.PcdGenerator(640, 480)
 for rep in range(3):
   for DEV in (False, True):
-    for prefetch in ((True, False) if not DEV else (False,)):
+    for prefetch in (True, False):
         reg = cls()
         pkg.frontend.run_frames(reg, seq[:3], 1, generator=gen, prefetch=prefetch, device=DEV)
         reg.close()
