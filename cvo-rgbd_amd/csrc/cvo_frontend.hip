@@ -16,6 +16,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <vector>
 
 #include "cvo_frontend.h"
 
@@ -636,6 +637,12 @@ const float kCameras[6][5] = {{1000.0f, 616.368f, 616.745f, 319.935f, 243.639f},
 
 }   // namespace
 
+struct FeGraph {
+    uint64_t key = 0;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+};
+
 struct cvo_fe_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -659,6 +666,7 @@ struct cvo_fe_ctx {
     FeCtrl *h_ctrl = nullptr;
     float *h_pos = nullptr, *h_feat = nullptr;
     cvo_fe_info info{};
+    std::vector<FeGraph> graphs;   // one frame's device work, captured per (camera, features, ...)
     int copied = 0;            // points of the cloud already on their way to h_pos / h_feat
     bool pending = false;      // a frame was submitted and not collected yet
     bool device_output = false;   // collect_device() will be used: no copy of the cloud to the host
@@ -766,6 +774,10 @@ int cvo_fe_destroy(cvo_fe_ctx *ctx)
                    ctx->mag, ctx->grad, ctx->ctrl, ctx->blk_cnt};
     for (void *p : dev)
         if (p) (void)hipFree(p);
+    for (auto &g : ctx->graphs) {
+        if (g.exec) (void)hipGraphExecDestroy(g.exec);
+        if (g.graph) (void)hipGraphDestroy(g.graph);
+    }
     void *pin[] = {ctx->h_img, ctx->h_depth, ctx->h_ctrl, ctx->h_pos, ctx->h_feat};
     for (void *p : pin)
         if (p) (void)hipHostFree(p);
@@ -866,6 +878,10 @@ int cvo_fe_set_num_want(cvo_fe_ctx *ctx, int num_want)
     return CVO_HIP_OK;
 }
 
+namespace {
+int enqueue_frame(cvo_fe_ctx *ctx, int dataset_seq, int feature_type);
+}
+
 int cvo_fe_submit(cvo_fe_ctx *ctx, const uint8_t *img, size_t img_stride, const uint16_t *depth,
                   size_t depth_stride, int dataset_seq, int feature_type)
 {
@@ -882,15 +898,61 @@ int cvo_fe_submit(cvo_fe_ctx *ctx, const uint8_t *img, size_t img_stride, const 
     else
         for (int y = 0; y < h; ++y)
             std::memcpy(ctx->h_img + (size_t)y * w * 3, img + (size_t)y * img_stride, (size_t)w * 3);
-    FE_HIP(hipMemcpyAsync(ctx->img, ctx->h_img, (size_t)np * 3, hipMemcpyHostToDevice, s));
     if (depth_stride == (size_t)w * 2) std::memcpy(ctx->h_depth, depth, (size_t)np * 2);
     else
         for (int y = 0; y < h; ++y)
             std::memcpy(ctx->h_depth + (size_t)y * w, (const uint8_t *)depth + (size_t)y * depth_stride, (size_t)w * 2);
-    FE_HIP(hipMemcpyAsync(ctx->depth, ctx->h_depth, (size_t)np * 2, hipMemcpyHostToDevice, s));
     FeCtrl c0{};
     c0.pot[0] = 3;   // a selector starts every frame at potential 3 (ref PixelSelector2.cpp:39)
     *ctx->h_ctrl = c0;
+    // Everything from here to the copies back is the same sequence for every frame (fixed
+    // buffers, fixed pinned staging): captured once per (camera, feature type, num_want,
+    // output mode) and launched as one hipGraph -- 3 copies in, 11 kernels, the copies out.
+    static const bool no_graph = getenv("CVO_FE_NO_GRAPH") != nullptr;
+    const uint64_t key = ((uint64_t)(uint32_t)dataset_seq << 40) ^ ((uint64_t)feature_type << 36) ^
+                         ((uint64_t)ctx->device_output << 32) ^ (uint64_t)(uint32_t)ctx->num_want;
+    int rc = CVO_HIP_OK;
+    FeGraph *g = nullptr;
+    for (auto &e : ctx->graphs)
+        if (e.key == key) g = &e;
+    if (!no_graph && !g && ctx->graphs.size() < 8) {
+        FeGraph ng;
+        ng.key = key;
+        if (hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed) == hipSuccess) {
+            rc = enqueue_frame(ctx, dataset_seq, feature_type);
+            const hipError_t e = hipStreamEndCapture(s, &ng.graph);
+            if (!rc && e == hipSuccess && ng.graph &&
+                hipGraphInstantiate(&ng.exec, ng.graph, nullptr, nullptr, 0) == hipSuccess) {
+                ctx->graphs.push_back(ng);
+                g = &ctx->graphs.back();
+            } else {
+                if (ng.graph) (void)hipGraphDestroy(ng.graph);
+                (void)hipGetLastError();
+                rc = CVO_HIP_OK;
+            }
+        }
+    }
+    ctx->copied = ctx->device_output ? 0 : std::min(ctx->cap, std::max(4096, 2 * ctx->num_want));
+    if (g) {
+        FE_HIP(hipGraphLaunch(g->exec, s));
+    } else {
+        rc = enqueue_frame(ctx, dataset_seq, feature_type);
+        if (rc) return rc;
+    }
+    ctx->pending = true;
+    ctx->p_seq = dataset_seq;
+    ctx->p_ftype = feature_type;
+    return CVO_HIP_OK;
+}
+
+namespace {
+// one frame's device work, in stream order (also what a captured graph holds)
+int enqueue_frame(cvo_fe_ctx *ctx, int dataset_seq, int feature_type)
+{
+    const int w = ctx->d.w, h = ctx->d.h, np = ctx->np;
+    hipStream_t s = ctx->stream;
+    FE_HIP(hipMemcpyAsync(ctx->img, ctx->h_img, (size_t)np * 3, hipMemcpyHostToDevice, s));
+    FE_HIP(hipMemcpyAsync(ctx->depth, ctx->h_depth, (size_t)np * 2, hipMemcpyHostToDevice, s));
     FE_HIP(hipMemcpyAsync(ctx->ctrl, ctx->h_ctrl, sizeof(FeCtrl), hipMemcpyHostToDevice, s));
 
     const FeDims &d = ctx->d;
@@ -918,15 +980,9 @@ int cvo_fe_submit(cvo_fe_ctx *ctx, const uint8_t *img, size_t img_stride, const 
     // the cloud is emitted at once; a frame that needs the edge top-up (rare: a nearly
     // texture-free image) is noticed at collect(), when the control block has arrived, and
     // emitted again
-    const int rc = run_emit(ctx, dataset_seq, feature_type);
-    if (rc) return rc;
-    ctx->pending = true;
-    ctx->p_seq = dataset_seq;
-    ctx->p_ftype = feature_type;
-    return CVO_HIP_OK;
+    return run_emit(ctx, dataset_seq, feature_type);
 }
 
-namespace {
 int collect_impl(cvo_fe_ctx *ctx, float *positions, float *features, int capacity, int *num_points, bool to_host);
 }
 
