@@ -819,7 +819,7 @@ int cvo_fe_create(int device, void *stream, int width, int height, cvo_fe_ctx **
     const size_t np = (size_t)width * height;
     ctx->np = (int)np;
     ctx->nchunks = (int)((np + FE_CHUNK - 1) / FE_CHUNK);
-    ctx->cap = (int)(np / 4);
+    ctx->cap = (int)np;   // (a selection can never hold more points than the image has pixels)
     bool ok = true;
     ok = ok && dev_alloc(&ctx->img, np * 3) == hipSuccess && dev_alloc(&ctx->gray, np) == hipSuccess;
     ok = ok && dev_alloc(&ctx->pattern, np) == hipSuccess && dev_alloc(&ctx->tmp8, np) == hipSuccess;

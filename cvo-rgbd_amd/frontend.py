@@ -94,7 +94,7 @@ class PcdGenerator:
             capi.check(st, what="cvo_fe_create (the front end needs a gfx950 device: no CPU path)")
         self.num_want = int(num_want)
         self._chk(lib().cvo_fe_set_num_want(self._h, self.num_want), "set_num_want")
-        self.capacity = self.width * self.height // 4
+        self.capacity = self.width * self.height   # (upper bound of any selection)
         self._pos = np.empty((self.capacity, 3), np.float32)
         self._feat = np.empty((self.capacity, 5), np.float32)
 

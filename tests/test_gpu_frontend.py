@@ -268,3 +268,14 @@ def test_empty_and_saturated_frames(pkg):
     _check_frame(pkg, gen, black, dep, 1, pkg.frontend.FEATURES_HSV)
     _check_frame(pkg, gen, white, dep, 1, pkg.frontend.FEATURES_HSV)
     gen.close()
+
+
+def test_front_end_soak(pkg):
+    """tools/gpu_soak_fe.py, 40 random frames: sizes, textures, densities, cameras, feature types"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "gpu_soak_fe.py"), "40"],
+                         capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert " 0 mismatches" in out.stdout
