@@ -680,6 +680,11 @@ __device__ __forceinline__ void process_body(const ProcessArgs &a, const unsigne
                         (MODE == PROC_SELF && a.async_self && a.st->sf_active[a.async_self - 1] == 1);
     const int in_list = !second ? a.list : (MODE == PROC_FLOW ? (int)LIST_XYB : self_list_id(a.async_self - 1, 1));
     const TileEntry *in_tiles = second ? a.tiles_b : a.tiles;
+    // A list that overflowed while it was built holds counters past what was written (an
+    // append that does not fit is dropped, its count stays): entries from memory nobody
+    // initialised would be taken for row / column numbers.  The iteration is redone with a
+    // larger list anyway: consume nothing of it.  (Same for the kept list of PROC_STEP.)
+    const unsigned list_bad = a.st->cnt[2 * (MODE == PROC_STEP ? (int)LIST_KEPT : in_list) + 1];
 
     double acc[NACC];
 #pragma unroll
@@ -694,6 +699,7 @@ __device__ __forceinline__ void process_body(const ProcessArgs &a, const unsigne
         float w = a.kept_a[base + lane];
         if (done_word != 0) return;
         if (n > a.kept_wcap) n = a.kept_wcap;
+        if (list_bad) n = 0;
         for (unsigned off = lane; off < n; off += 64) {
             if (off >= 64) { e = a.kept_ij[base + off]; w = a.kept_a[base + off]; }
             eval_pair<MODE>(a, kc, e.x, e.y, w, acc, a.st->xi);
@@ -706,7 +712,7 @@ __device__ __forceinline__ void process_body(const ProcessArgs &a, const unsigne
         const unsigned nsl = shared ? 1u : (unsigned)(NSUB / a.nblk);
         const unsigned part = shared ? bid / NSUB : 0u;
         unsigned sub = bid & (NSUB - 1);
-        unsigned n = a.st->sub[in_list][sub];
+        unsigned n = list_bad ? 0u : a.st->sub[in_list][sub];
         const TileEntry *tl = in_tiles + (size_t)sub * a.subcap;
         // The waves of a sub-list take its entries in turn, 64 at a time: lane l
         // fetches the wave's l-th entry of the round (one memory round trip per 64
@@ -754,7 +760,7 @@ __device__ __forceinline__ void process_body(const ProcessArgs &a, const unsigne
         const TileEntry *tl_next = tl;
         if (sl + 1 < nsl) {
             const unsigned sub_next = sub + (unsigned)a.nblk;
-            n_next = a.st->sub[in_list][sub_next];
+            n_next = list_bad ? 0u : a.st->sub[in_list][sub_next];
             tl_next = in_tiles + (size_t)sub_next * a.subcap;
             mine_next = tl_next[min(e0 + (unsigned)lane * stride, a.subcap - 1)];
         }

@@ -67,3 +67,17 @@ def test_synthetic_pairs_bit_identical(pkg, n, m, seed):
     T2, it2 = reg.register(xf, cf, xm, cm)
     assert it2 == it and np.array_equal(T2, T)
     reg.close()
+
+
+def test_matlab_weight_soak(pkg):
+    """tools/gpu_soak.py with the MATLAB weight: random clouds, perturbed thresholds; dense
+    small clouds overflow their first tile lists here (the grow-and-redo path: a consumer
+    must not read entries an overflowed list never received)"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SOAK_MATLAB="1")
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "gpu_soak.py"), "120", "2500"],
+                         capture_output=True, text=True, env=env)
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-1500:]
+    assert "120 cases, 0 mismatches" in out.stdout

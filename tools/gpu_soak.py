@@ -68,6 +68,17 @@ for case in range(n_cases):
             q.max_iter = 60 + case % 40
             if acvo and not os.environ.get("SOAK_KEEP_DL"):
                 q.dl_step = 0.3 * (0.5 + (case % 4) * 0.4)
+    if os.environ.get("SOAK_MATLAB") and not acvo:
+        # the MATLAB object's weight: colour bytes in features 0..2, K-only threshold
+        p = po.default_params(po.MODE_MATLAB)
+        gp = capi.default_params(capi.MODE_MATLAB)
+        for f in (ff, fm):
+            f[:, :3] = rng.integers(0, 256, (len(f), 3)).astype(np.float32)
+            f[:, 3:] = 0.0
+        if case % 3 == 2:
+            for q in (p, gp):
+                q.sp_thres = np.float32(q.sp_thres * (2.0 if case % 2 else 0.6))
+                q.max_iter = 40 + case % 40
     only = os.environ.get("SOAK_ONLY")
     if only is not None and int(only) != case:
         continue
@@ -97,6 +108,8 @@ for case in range(n_cases):
         for k in range(13):
             print("   %-9s gpu %.12g   oracle %s" % (names[k], g13[k], ("%.12g" % o13[k]) if o13 is not None else "n/a"))
         c.close()
+    if os.environ.get("SOAK_VERBOSE"):
+        print("case", case, "acvo", acvo, "n", len(xf), "m", len(xm), flush=True)
     s = po.init_state(p)
     n_or, _ = po.align(p, s, xf, ff, xm, fm, search=po.SEARCH_GRID)
     st_or = bytes(s)
