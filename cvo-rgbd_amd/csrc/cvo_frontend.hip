@@ -960,7 +960,9 @@ int enqueue_frame(cvo_fe_ctx *ctx, int dataset_seq, int feature_type)
                        ctx->gray, ctx->hsv, ctx->I[0], ctx->ag[0], ctx->dx0, ctx->dy0);
     for (int l = 1; l < FE_LEVELS; ++l)
         hipLaunchKernelGGL(k_fe_level, dim3(blocks(d.wl[l] * d.hl[l])), dim3(FE_BLOCK), 0, s, ctx->I[l - 1],
-                           d.wl[l - 1], ctx->I[l], d.wl[l], d.hl[l], ctx->ag[l]);
+                           2 * d.wl[l] /* the reference's row stride of the level above, also when
+                                           that level is one pixel wider (ref src/pcd_generator.cpp:82) */,
+                           ctx->I[l], d.wl[l], d.hl[l], ctx->ag[l]);
     const int ncell = d.w32 * d.h32;
     hipLaunchKernelGGL(k_fe_hist, dim3(ncell), dim3(FE_BLOCK), 0, s, ctx->ag[0], w, h, d.w32, ctx->ths);
     hipLaunchKernelGGL(k_fe_smooth, dim3(blocks(ncell)), dim3(FE_BLOCK), 0, s, ctx->ths, d.w32, d.h32, ctx->ths_s);

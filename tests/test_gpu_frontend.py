@@ -57,7 +57,7 @@ def test_both_selector_branches_are_exercised(pkg):
     gen.close()
 
 
-@pytest.mark.parametrize("w,h", [(320, 256), (352, 300), (96, 64), (1280, 720)])
+@pytest.mark.parametrize("w,h", [(320, 256), (352, 300), (96, 64), (1280, 720), (333, 251), (127, 193)])
 def test_other_image_sizes(pkg, w, h):
     gen = pkg.frontend.PcdGenerator(w, h, num_want=max(200, w * h // 100))
     for seed in (1, 2):
