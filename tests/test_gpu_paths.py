@@ -513,18 +513,19 @@ def test_cloud_in_device_memory_equals_host_hand_over(pkg, n):
     assert results[0] == results[1] == results[2]
 
 
-def test_stream_of_varying_clouds_reuses_its_captured_batches(pkg):
+@pytest.mark.parametrize("lo,span,max_captures", [(2900, 120, 4), (3030, 90, 10)])
+def test_stream_of_varying_clouds_reuses_its_captured_batches(pkg, lo, span, max_captures):
     """Frames of a real stream differ by a few points each: the device arrays are padded to
     256-row buckets and sizes stay out of the kernel arguments, so the loop's captured
     batches (hipGraph) are re-used from frame to frame -- and the results are those of
     fresh objects."""
     rng = np.random.default_rng(4)
-    base = pkg.data.synthetic_pair(3100, 3100, seed=77, acvo=True)
+    base = pkg.data.synthetic_pair(3200, 3200, seed=77, acvo=True)
     frames = []
     for k in range(10):
-        n = 2900 + int(rng.integers(0, 120))
+        n = lo + int(rng.integers(0, span))   # (the second range straddles a 256-row bucket: 3072)
         src = base[0:2] if k % 2 == 0 else base[2:4]
-        sel = np.sort(rng.choice(3100, n, replace=False))
+        sel = np.sort(rng.choice(3200, n, replace=False))
         frames.append((src[0][sel], src[1][sel]))
     reg = pkg.Acvo()
     got = []
@@ -535,7 +536,7 @@ def test_stream_of_varying_clouds_reuses_its_captured_batches(pkg):
             got.append((reg.num_iterations, reg.transform.copy()))
     hits, captures = reg.ctx.graph_stats()
     reg.close()
-    assert captures <= 4 and hits > 10 * captures
+    assert captures <= max_captures and hits > 3 * captures
     # each pair on fresh objects (acvo resets ell per pair, but R, T carry over: replay the chain)
     ref = pkg.Acvo()
     want = []
