@@ -12,7 +12,7 @@ pkg = ge.load_package()
 F = pkg.frontend
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 rng = np.random.default_rng(2024)
-sizes = [(640, 480), (320, 240), (352, 288), (160, 128), (800, 600), (96, 64), (333, 251), (65, 64), (127, 193)]
+sizes = [(640, 480), (320, 240), (352, 288), (160, 128), (800, 600), (96, 64), (333, 251), (65, 64), (127, 193), (64, 64), (1024, 64)]
 gens = {}
 bad = 0
 stats = {"reselected": 0, "canny": 0, "points": 0}
@@ -20,7 +20,7 @@ t0 = time.time()
 for case in range(n_cases):
     w, h = sizes[int(rng.integers(0, len(sizes)))]
     tex = float(rng.choice([0.0, 0.05, 0.2, 0.5, 1.0, 2.0, 4.0, 8.0]))
-    want = int(rng.choice([300, 1000, 3000, 8000]))
+    want = int(rng.choice([1, 30, 300, 1000, 3000, 8000, w * h]))
     holes = float(rng.choice([0.0, 0.02, 0.3]))
     seq = int(rng.integers(0, 7))
     ftype = int(rng.integers(0, 2))
