@@ -177,6 +177,20 @@ def main():
                     traffic = json.load(fh).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
+        # which kernels the time of the batched run goes to, from the committed rocprofv3 summary of
+        # this same command (profiles/, refreshed by tools/gpu_profile.sh): informational
+        shares = None
+        spath = os.path.join(ROOT, "profiles", "r01_kernel_stats_batch32.csv")
+        if os.path.exists(spath):
+            try:
+                import csv
+                rows = [r for r in csv.DictReader(open(spath)) if "cvo_dev::" in r["Name"]]
+                tot = sum(float(r["TotalDurationNs"]) for r in rows)
+                top = sorted(rows, key=lambda r: -float(r["TotalDurationNs"]))[:5]
+                shares = {r["Name"].replace("void ", "").replace("cvo_dev::", "").split("(")[0]:
+                          round(float(r["TotalDurationNs"]) / tot, 3) for r in top}
+            except Exception:
+                shares = None
         algo_bytes = BYTES_PER_POINT * (n + m)
         iters_per_reg = float(it_sum.item()) / total_regs
         # two all-pairs sweeps (flow, step size) per iteration, 8 flop per
@@ -218,6 +232,7 @@ def main():
             "ms_per_iteration": elapsed * 1e3 * world / max(float(it_sum.item()), 1.0),
             "single_stream": single,
             "gt_motion_rel_err": {"rot": rot_err, "trans": tr_err},
+            "kernel_time_shares_batched": shares,
             "roofline": {
                 "kernel": "cvo_dev::k_filter (all target x source pair tests, v_mfma_f32_16x16x4_f32)",
                 "bound": "mfma",
