@@ -29,6 +29,7 @@
 
 #include "cvo_comm.h"
 #include "cvo_cloud.h"
+#include "cvo_lock.h"
 #include "cvo_device.h"
 #include "se3_math.hpp"
 
@@ -880,11 +881,30 @@ int launch_batch(cvo_hip_ctx *ctx, int tag0, int trace_cap)
         }
         GraphEntry g;
         g.key = key;
-        HIP_TRY(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeRelaxed));
-        const int rc = enqueue_iterations(ctx, kBatch, -1, trace_cap);
-        const hipError_t e = hipStreamEndCapture(ctx->stream, &g.graph);
-        if (rc) { if (g.graph) (void)hipGraphDestroy(g.graph); return rc; }
-        if (e != hipSuccess) { ctx->err = "hipStreamEndCapture failed"; return CVO_HIP_ERR_HIP; }
+        // A capture can be spoilt from outside: another host thread working on ITS context (an
+        // allocation, a synchronisation) invalidates every capture in progress in this runtime,
+        // relaxed mode or not.  Nothing has been launched then: the batch goes out eagerly and
+        // the next one tries again.
+        int rc;
+        hipError_t e;
+        {
+            cvo_lock::Capture alone;   // (no other thread of this library is inside the runtime)
+            if (!alone.ok || hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeRelaxed) != hipSuccess) {
+                (void)hipGetLastError();
+                rc = -1;
+                e = hipErrorUnknown;
+            } else {
+                rc = enqueue_iterations(ctx, kBatch, -1, trace_cap);
+                e = hipStreamEndCapture(ctx->stream, &g.graph);
+            }
+        }
+        if (rc || e != hipSuccess || !g.graph) {
+            if (g.graph) (void)hipGraphDestroy(g.graph);
+            (void)hipGetLastError();
+            ctx->err.clear();
+            if (++ctx->graph_fail >= 64) ctx->use_graphs = false;
+            return enqueue_iterations(ctx, kBatch, tag0, trace_cap);
+        }
         if (graph_key(ctx, trace_cap) != key) {
             // something was (re)allocated while capturing: the capture is unusable
             if (getenv("CVO_HIP_GRAPH_DEBUG")) {
@@ -893,10 +913,15 @@ int launch_batch(cvo_hip_ctx *ctx, int tag0, int trace_cap)
                     if (key[q] != k2[q]) fprintf(stderr, "[cvo_hip] graph key element %zu changed during capture\n", q);
             }
             (void)hipGraphDestroy(g.graph);
-            if (++ctx->graph_fail >= 8) ctx->use_graphs = false;   // (a buffer grew: normally a one-off)
+            if (++ctx->graph_fail >= 64) ctx->use_graphs = false;   // (a buffer grew: normally a one-off)
             return enqueue_iterations(ctx, kBatch, tag0, trace_cap);
         }
-        HIP_TRY(ctx, hipGraphInstantiate(&g.exec, g.graph, nullptr, nullptr, 0));
+        if (hipGraphInstantiate(&g.exec, g.graph, nullptr, nullptr, 0) != hipSuccess) {
+            (void)hipGraphDestroy(g.graph);
+            (void)hipGetLastError();
+            if (++ctx->graph_fail >= 64) ctx->use_graphs = false;
+            return enqueue_iterations(ctx, kBatch, tag0, trace_cap);
+        }
         ctx->graph_fail = 0;
         ctx->graphs.push_back(g);
         hit = &ctx->graphs.back();
@@ -1020,6 +1045,7 @@ int cvo_hip_init_state(const cvo_hip_params *p, cvo_hip_state *s)
 
 int cvo_hip_create(int device, void *stream, const cvo_hip_params *p, cvo_hip_ctx **out)
 {
+    cvo_lock::Api api_guard;
     if (!p || !out) return CVO_HIP_ERR_INVALID;
     *out = nullptr;
     int n = 0;
@@ -1075,6 +1101,7 @@ int cvo_hip_create(int device, void *stream, const cvo_hip_params *p, cvo_hip_ct
 
 int cvo_hip_destroy(cvo_hip_ctx *ctx)
 {
+    cvo_lock::Api api_guard;
     if (!ctx) return CVO_HIP_OK;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
@@ -1123,6 +1150,7 @@ int cvo_hip_set_params(cvo_hip_ctx *ctx, const cvo_hip_params *p)
 
 int cvo_hip_set_fixed(cvo_hip_ctx *ctx, const float *xyz, const float *feat, int n, int layout)
 {
+    cvo_lock::Api api_guard;
     if (!ctx) return CVO_HIP_ERR_INVALID;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     return upload_cloud(ctx, ctx->fixed, xyz, feat, n, layout);
@@ -1130,6 +1158,7 @@ int cvo_hip_set_fixed(cvo_hip_ctx *ctx, const float *xyz, const float *feat, int
 
 int cvo_hip_set_moving(cvo_hip_ctx *ctx, const float *xyz, const float *feat, int m, int layout)
 {
+    cvo_lock::Api api_guard;
     if (!ctx) return CVO_HIP_ERR_INVALID;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     ctx->have_tf = false;
@@ -1138,6 +1167,7 @@ int cvo_hip_set_moving(cvo_hip_ctx *ctx, const float *xyz, const float *feat, in
 
 int cvo_hip_set_fixed_device(cvo_hip_ctx *ctx, const float *d_xyz, const float *d_feat, int n, int layout)
 {
+    cvo_lock::Api api_guard;
     if (!ctx) return CVO_HIP_ERR_INVALID;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     return upload_cloud(ctx, ctx->fixed, d_xyz, d_feat, n, layout, true);
@@ -1145,6 +1175,7 @@ int cvo_hip_set_fixed_device(cvo_hip_ctx *ctx, const float *d_xyz, const float *
 
 int cvo_hip_set_moving_device(cvo_hip_ctx *ctx, const float *d_xyz, const float *d_feat, int m, int layout)
 {
+    cvo_lock::Api api_guard;
     if (!ctx) return CVO_HIP_ERR_INVALID;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     ctx->have_tf = false;
@@ -1187,6 +1218,7 @@ int cvo_hip_comm_unique_id(void *id_bytes_128)
 
 int cvo_hip_comm_init(cvo_hip_ctx *ctx, const void *id_bytes_128, int rank, int world)
 {
+    cvo_lock::Api api_guard;
     if (!ctx || !id_bytes_128 || world <= 0 || rank < 0 || rank >= world)
         return CVO_HIP_ERR_INVALID;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -1206,6 +1238,7 @@ int cvo_hip_set_allreduce(cvo_hip_ctx *ctx, cvo_hip_allreduce_fn fn, void *user)
 
 int cvo_hip_transform_pcd(cvo_hip_ctx *ctx, const float R[9], const float T[3])
 {
+    cvo_lock::Api api_guard;
     if (!ctx || !R || !T) return CVO_HIP_ERR_INVALID;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     // update_tf(): the sweeps apply [Rt|t] while staging the moving cloud
@@ -1228,6 +1261,7 @@ int cvo_hip_transform_pcd(cvo_hip_ctx *ctx, const float R[9], const float T[3])
 
 int cvo_hip_flow(cvo_hip_ctx *ctx, float ell, double out13[13])
 {
+    cvo_lock::Api api_guard;
     if (!ctx || !out13) return CVO_HIP_ERR_INVALID;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (!ctx->have_tf) return fail(ctx, CVO_HIP_ERR_INVALID, "transform_pcd not called");
@@ -1253,6 +1287,7 @@ int cvo_hip_flow(cvo_hip_ctx *ctx, float ell, double out13[13])
 int cvo_hip_step_coeffs(cvo_hip_ctx *ctx, const float omega[3], const float v[3], float ell,
                         double bcde[4])
 {
+    cvo_lock::Api api_guard;
     if (!ctx || !omega || !v || !bcde) return CVO_HIP_ERR_INVALID;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (!ctx->have_tf) return fail(ctx, CVO_HIP_ERR_INVALID, "transform_pcd not called");
@@ -1675,9 +1710,15 @@ struct FusedRun {
         // several groups in flight the launching thread is the next bottleneck
         drop_graph();
         static const bool no_graph = getenv("CVO_HIP_NO_GRAPH") != nullptr;
-        if (use_graph && !no_graph && hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed) == hipSuccess) {
-            for (int q = 0; q < kBatch; ++q) launch_fused(ops, s);
-            const hipError_t e = hipStreamEndCapture(s, &graph);
+        if (use_graph && !no_graph) {
+            hipError_t e = hipErrorUnknown;
+            {
+                cvo_lock::Capture alone;
+                if (alone.ok && hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed) == hipSuccess) {
+                    for (int q = 0; q < kBatch; ++q) launch_fused(ops, s);
+                    e = hipStreamEndCapture(s, &graph);
+                }
+            }
             if (e != hipSuccess || !graph || hipGraphInstantiate(&gexec, graph, nullptr, nullptr, 0) != hipSuccess)
                 drop_graph();
             (void)hipGetLastError();
@@ -1783,6 +1824,7 @@ struct FusedRun {
 int cvo_hip_align(cvo_hip_ctx *ctx, cvo_hip_state *s, cvo_hip_trace *trace, int trace_cap,
                   int *n_iter)
 {
+    cvo_lock::Api api_guard;
     if (!ctx || !s) return CVO_HIP_ERR_INVALID;
     AlignJob j;
     j.ctx = ctx; j.s = s; j.trace = trace; j.trace_cap = trace_cap; j.n_iter = n_iter;
@@ -1794,6 +1836,7 @@ int cvo_hip_align(cvo_hip_ctx *ctx, cvo_hip_state *s, cvo_hip_trace *trace, int 
 
 int cvo_hip_align_many(cvo_hip_ctx **ctxs, cvo_hip_state **states, int *n_iters, int count)
 {
+    cvo_lock::Api api_guard;
     if (count < 0 || (count > 0 && (!ctxs || !states))) return CVO_HIP_ERR_INVALID;
     std::vector<AlignJob> jobs((size_t)count);
     for (int i = 0; i < count; ++i) {
@@ -1904,6 +1947,7 @@ int cvo_hip_align_many(cvo_hip_ctx **ctxs, cvo_hip_state **states, int *n_iters,
 
 int cvo_hip_function_inner_product(cvo_hip_ctx *ctx, float ell, float *out)
 {
+    cvo_lock::Api api_guard;
     if (!ctx || !out) return CVO_HIP_ERR_INVALID;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     // untransformed positions, colour cut with sp_thres (ref acvo.cpp:391-392)
@@ -1962,6 +2006,7 @@ int cvo_hip_set_profiling(cvo_hip_ctx *ctx, int enable)
 
 int cvo_hip_get_profile(cvo_hip_ctx *ctx, cvo_hip_profile *out, int reset)
 {
+    cvo_lock::Api api_guard;
     if (!ctx || !out) return CVO_HIP_ERR_INVALID;
     int rc = drain_events(ctx);
     if (rc) return rc;
@@ -1980,6 +2025,7 @@ int cvo_hip_get_graph_stats(const cvo_hip_ctx *ctx, long long *launches_from_cac
 
 int cvo_hip_synchronize(cvo_hip_ctx *ctx)
 {
+    cvo_lock::Api api_guard;
     if (!ctx) return CVO_HIP_ERR_INVALID;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return CVO_HIP_OK;

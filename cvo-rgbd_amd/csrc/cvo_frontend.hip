@@ -19,6 +19,7 @@
 #include <vector>
 
 #include "cvo_frontend.h"
+#include "cvo_lock.h"
 
 namespace {
 
@@ -765,6 +766,7 @@ const char *cvo_fe_last_error(const cvo_fe_ctx *ctx) { return ctx ? ctx->err.c_s
 
 int cvo_fe_destroy(cvo_fe_ctx *ctx)
 {
+    cvo_lock::Api api_guard;
     if (!ctx) return CVO_HIP_ERR_INVALID;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
@@ -788,6 +790,7 @@ int cvo_fe_destroy(cvo_fe_ctx *ctx)
 
 int cvo_fe_create(int device, void *stream, int width, int height, cvo_fe_ctx **out)
 {
+    cvo_lock::Api api_guard;
     if (!out || width < 64 || height < 64 || (long long)width * height > (1ll << 26)) return CVO_HIP_ERR_INVALID;
     *out = nullptr;
     int ndev = 0;
@@ -885,6 +888,7 @@ int enqueue_frame(cvo_fe_ctx *ctx, int dataset_seq, int feature_type);
 int cvo_fe_submit(cvo_fe_ctx *ctx, const uint8_t *img, size_t img_stride, const uint16_t *depth,
                   size_t depth_stride, int dataset_seq, int feature_type)
 {
+    cvo_lock::Api api_guard;
     if (!ctx) return CVO_HIP_ERR_INVALID;
     const int w = ctx->d.w, h = ctx->d.h, np = ctx->np;
     if (!img || !depth || img_stride < (size_t)w * 3 || depth_stride < (size_t)w * 2 ||
@@ -918,7 +922,8 @@ int cvo_fe_submit(cvo_fe_ctx *ctx, const uint8_t *img, size_t img_stride, const 
     if (!no_graph && !g && ctx->graphs.size() < 8) {
         FeGraph ng;
         ng.key = key;
-        if (hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed) == hipSuccess) {
+        cvo_lock::Capture alone;   // (see cvo_lock.h)
+        if (alone.ok && hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed) == hipSuccess) {
             rc = enqueue_frame(ctx, dataset_seq, feature_type);
             const hipError_t e = hipStreamEndCapture(s, &ng.graph);
             if (!rc && e == hipSuccess && ng.graph &&
@@ -990,6 +995,7 @@ int collect_impl(cvo_fe_ctx *ctx, float *positions, float *features, int capacit
 
 int cvo_fe_collect(cvo_fe_ctx *ctx, float *positions, float *features, int capacity, int *num_points)
 {
+    cvo_lock::Api api_guard;
     if (!ctx) return CVO_HIP_ERR_INVALID;
     if (!num_points || capacity < 0 || (capacity > 0 && (!positions || !features)))
         return fail(ctx, CVO_HIP_ERR_INVALID, "collect: bad argument");
@@ -998,6 +1004,7 @@ int cvo_fe_collect(cvo_fe_ctx *ctx, float *positions, float *features, int capac
 
 int cvo_fe_collect_device(cvo_fe_ctx *ctx, const float **d_positions, const float **d_features, int *num_points)
 {
+    cvo_lock::Api api_guard;
     if (!ctx) return CVO_HIP_ERR_INVALID;
     if (!d_positions || !d_features || !num_points) return fail(ctx, CVO_HIP_ERR_INVALID, "collect_device: bad argument");
     const int rc = collect_impl(ctx, nullptr, nullptr, ctx->cap, num_points, false);
@@ -1052,6 +1059,7 @@ int cvo_fe_create_pointcloud(cvo_fe_ctx *ctx, const uint8_t *img, size_t img_str
                              size_t depth_stride, int dataset_seq, int feature_type, float *positions,
                              float *features, int capacity, int *num_points)
 {
+    cvo_lock::Api api_guard;
     if (!ctx) return CVO_HIP_ERR_INVALID;
     if (!num_points || capacity < 0 || (capacity > 0 && (!positions || !features)))
         return fail(ctx, CVO_HIP_ERR_INVALID, "create_pointcloud: bad argument");
@@ -1069,6 +1077,7 @@ int cvo_fe_get_info(const cvo_fe_ctx *ctx, cvo_fe_info *out)
 
 int cvo_fe_read_stage(cvo_fe_ctx *ctx, int stage, void *out, size_t bytes)
 {
+    cvo_lock::Api api_guard;
     if (!ctx || !out) return CVO_HIP_ERR_INVALID;
     const FeDims &d = ctx->d;
     const size_t np = (size_t)ctx->np;

@@ -548,3 +548,39 @@ def test_stream_of_varying_clouds_reuses_its_captured_batches(pkg, lo, span, max
     ref.close()
     assert [g[0] for g in got] == [w[0] for w in want]
     assert all(np.array_equal(g[1], w[1]) for g, w in zip(got, want))
+
+
+def test_contexts_on_concurrent_host_threads(pkg):
+    """Independent contexts are used from several host threads at once (one object per
+    sequence, several sequences per process: SURVEY 8b threading): same results as one
+    after the other.  Front end objects included."""
+    import threading
+    capi = pkg.capi
+    pairs = [pkg.data.synthetic_pair(1500 + 100 * k, 1400 + 50 * k, seed=500 + k, acvo=(k % 2 == 1)) for k in range(6)]
+    frames = [pkg.data.synthetic_rgbd_frame(width=320, height=256, seed=600 + k, texture=1.0) for k in range(6)]
+
+    def work(k, out):
+        acvo = k % 2 == 1
+        c = capi.Context(mode=capi.MODE_ACVO if acvo else capi.MODE_CVO, device=0)
+        gen = pkg.frontend.PcdGenerator(320, 256)
+        res = []
+        for rep in range(4):
+            xf, ff, xm, fm = pairs[k]
+            c.set_fixed(xf, ff); c.set_moving(xm, fm)
+            st = capi.init_state(c.params)
+            it, _ = c.align(st, trace_cap=0)
+            xyz, feat = gen.create_pointcloud(*frames[k])
+            res.append((it, bytes(st), xyz.tobytes(), feat.tobytes()))
+        c.close(); gen.close()
+        out[k] = res
+
+    serial, threaded = {}, {}
+    for k in range(6):
+        work(k, serial)
+    ts = [threading.Thread(target=work, args=(k, threaded)) for k in range(6)]
+    for t in ts: t.start()
+    for t in ts: t.join()
+    assert sorted(threaded) == list(range(6))
+    for k in range(6):
+        assert threaded[k] == serial[k], "context %d differs when run beside others" % k
+        assert all(r == serial[k][0] for r in serial[k])
