@@ -191,6 +191,16 @@ def main():
                           round(float(r["TotalDurationNs"]) / tot, 3) for r in top}
             except Exception:
                 shares = None
+        # the same kernel's duration in the committed rocprofv3 kernel trace of this command
+        # (executed launches only): HIP events read 2-5 us more (the event pair's own handling)
+        rocprof_us = None
+        lpath = os.path.join(ROOT, "profiles", "r01_kernel_live.json")
+        if os.path.exists(lpath):
+            try:
+                with open(lpath) as fh:
+                    rocprof_us = json.load(fh).get("k_filter", {}).get("live_avg_us")
+            except Exception:
+                rocprof_us = None
         algo_bytes = BYTES_PER_POINT * (n + m)
         iters_per_reg = float(it_sum.item()) / total_regs
         # two all-pairs sweeps (flow, step size) per iteration, 8 flop per
@@ -243,6 +253,9 @@ def main():
                 "frac": achieved / PEAK_F32_TFLOPS,
                 "flop_per_launch": FLOP_PER_PAIR * pairs,
                 "avg_launch_us": sweep_ms * 1e3,
+                "rocprofv3_avg_launch_us": rocprof_us,
+                "frac_at_rocprofv3_duration": (FLOP_PER_PAIR * pairs / (rocprof_us * 1e-6) / 1e12 / PEAK_F32_TFLOPS)
+                if rocprof_us else None,
                 "launches": launches,
                 "launches_note": "k_filter does work only in the iterations that rebuild the tile list "
                                  "(%.1f of %.1f iterations per registration here); the other launches "
