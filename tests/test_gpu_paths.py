@@ -584,3 +584,64 @@ def test_contexts_on_concurrent_host_threads(pkg):
     for k in range(6):
         assert threaded[k] == serial[k], "context %d differs when run beside others" % k
         assert all(r == serial[k][0] for r in serial[k])
+
+
+@pytest.mark.parametrize("mode_name", ["cvo", "acvo"])
+def test_two_ranks_on_one_gpu_through_the_allreduce_hook(pkg, po, mode_name):
+    """The target-sharded path with a REAL second rank: two contexts on this GPU, each with
+    half of the fixed rows (and of the moving rows for the acvo Ayy sum), driven from two host
+    threads; the all-reduce hook sums the 13 + 4 float64 partials of the two ranks in rank
+    order through host memory.  Both ranks must stay in lock step bit for bit and land on the
+    unsharded result (1e-6; same iteration count)."""
+    import ctypes
+    import threading
+    capi = pkg.capi
+    acvo = mode_name == "acvo"
+    mode = capi.MODE_ACVO if acvo else capi.MODE_CVO
+    n, m = 2600, 2300
+    xf, ff, xm, fm = pkg.data.synthetic_pair(n, m, seed=61, acvo=acvo)
+    ref = _ctx(pkg, mode, xf, ff, xm, fm)
+    st_ref = capi.init_state(ref.params)
+    it_ref, _ = ref.align(st_ref, trace_cap=0)
+    ref.close()
+    hip = ctypes.CDLL("libamdhip64.so")
+    hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+    hip.hipStreamSynchronize.argtypes = [ctypes.c_void_p]
+    barrier = threading.Barrier(2)
+    box = [None, None]
+    out = {}
+    calls = [0, 0]
+
+    def rank(r):
+        c = _ctx(pkg, mode, xf, ff, xm, fm)
+        lo, hi = capi.shard_range(n, r, 2)
+        slo, shi = capi.shard_range(m, r, 2)
+        c.set_shard(lo, hi, slo, shi)
+
+        def hook(ptr, count, stream):
+            calls[r] += 1
+            hip.hipStreamSynchronize(stream)
+            mine = np.zeros(count, np.float64)
+            assert hip.hipMemcpy(mine.ctypes.data, ptr, count * 8, 2) == 0      # device -> host
+            box[r] = mine
+            barrier.wait()
+            total = box[0] + box[1]                                             # rank order
+            barrier.wait()
+            assert hip.hipMemcpy(ptr, total.ctypes.data, count * 8, 1) == 0     # host -> device
+
+        c.set_allreduce(hook)
+        st = capi.init_state(c.params)
+        it, _ = c.align(st, trace_cap=0)
+        out[r] = (it, bytes(st), np.array(st.transform, np.float32).reshape(4, 4))
+        c.close()
+
+    ts = [threading.Thread(target=rank, args=(r,)) for r in (0, 1)]
+    for t in ts: t.start()
+    for t in ts: t.join(timeout=120)
+    assert sorted(out) == [0, 1], "a rank did not finish"
+    assert out[0][0] == out[1][0] == it_ref
+    assert out[0][1] == out[1][1]                       # lock step, bit for bit
+    assert calls[0] == calls[1] >= 2 * it_ref
+    T_ref = np.array(st_ref.transform, np.float32).reshape(4, 4)
+    rot, tra = pkg.data.rel_pose_error(out[0][2], T_ref)
+    assert rot <= 1e-6 and tra <= 1e-6
