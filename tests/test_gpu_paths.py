@@ -586,8 +586,8 @@ def test_contexts_on_concurrent_host_threads(pkg):
         assert all(r == serial[k][0] for r in serial[k])
 
 
-@pytest.mark.parametrize("mode_name", ["cvo", "acvo"])
-def test_two_ranks_on_one_gpu_through_the_allreduce_hook(pkg, po, mode_name):
+@pytest.mark.parametrize("mode_name,n,m", [("cvo", 2600, 2300), ("acvo", 2600, 2300), ("acvo", 1500, 2400)])
+def test_two_ranks_on_one_gpu_through_the_allreduce_hook(pkg, po, mode_name, n, m):
     """The target-sharded path with a REAL second rank: two contexts on this GPU, each with
     half of the fixed rows (and of the moving rows for the acvo Ayy sum), driven from two host
     threads; the all-reduce hook sums the 13 + 4 float64 partials of the two ranks in rank
@@ -598,8 +598,7 @@ def test_two_ranks_on_one_gpu_through_the_allreduce_hook(pkg, po, mode_name):
     capi = pkg.capi
     acvo = mode_name == "acvo"
     mode = capi.MODE_ACVO if acvo else capi.MODE_CVO
-    n, m = 2600, 2300
-    xf, ff, xm, fm = pkg.data.synthetic_pair(n, m, seed=61, acvo=acvo)
+    xf, ff, xm, fm = pkg.data.synthetic_pair(n, m, seed=61, acvo=acvo)   # (m > n: the acvo Ayy tail rows)
     ref = _ctx(pkg, mode, xf, ff, xm, fm)
     st_ref = capi.init_state(ref.params)
     it_ref, _ = ref.align(st_ref, trace_cap=0)
