@@ -253,19 +253,7 @@ int upload_cloud(cvo_hip_ctx *ctx, Cloud &c, const float *xyz, const float *feat
         HIP_TRY(ctx, hipMalloc((void **)&ctx->bbox_dev, 6 * sizeof(float)));
     }
     const float *d_xyz = xyz, *d_feat = feat;
-    if (on_device) {
-        // the bounding box comes back to the host: the filter geometry of align() is made from it
-        // (it is waited for at the end, together with the preparation: one synchronisation)
-        HIP_TRY(ctx, cloud_bbox_device(xyz, n, ctx->bbox_dev, ctx->stream));
-        HIP_TRY(ctx, hipMemcpyAsync(ctx->bbox_host, ctx->bbox_dev, 6 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
-    } else {
-        for (int a = 0; a < 3; ++a) { c.lo[a] = INFINITY; c.hi[a] = -INFINITY; }
-        for (int i = 0; i < n; ++i)
-            for (int a = 0; a < 3; ++a) {
-                const float v = xyz[3 * (size_t)i + a];
-                if (v < c.lo[a]) c.lo[a] = v;
-                if (v > c.hi[a]) c.hi[a] = v;
-            }
+    if (!on_device) {
         // the arrays as they are, through pinned staging kept by the context
         if (bytes_xyz + bytes_feat > ctx->upload_stage_bytes) {
             if (ctx->upload_stage) (void)hipHostFree(ctx->upload_stage);
@@ -276,9 +264,9 @@ int upload_cloud(cvo_hip_ctx *ctx, Cloud &c, const float *xyz, const float *feat
                 return fail(ctx, CVO_HIP_ERR_NOMEM, "hipHostMalloc(upload staging) failed");
             ctx->upload_stage_bytes = want;
         }
-        int rc = ensure_buf(ctx, ctx->raw_xyz, bytes_xyz);
-        if (!rc) rc = ensure_buf(ctx, ctx->raw_feat, bytes_feat);
-        if (rc) return rc;
+        int rcb = ensure_buf(ctx, ctx->raw_xyz, bytes_xyz);
+        if (!rcb) rcb = ensure_buf(ctx, ctx->raw_feat, bytes_feat);
+        if (rcb) return rcb;
         char *hs = reinterpret_cast<char *>(ctx->upload_stage);
         std::memcpy(hs, xyz, bytes_xyz);
         HIP_TRY(ctx, hipMemcpyAsync(ctx->raw_xyz.p, hs, bytes_xyz, hipMemcpyHostToDevice, ctx->stream));
@@ -286,9 +274,12 @@ int upload_cloud(cvo_hip_ctx *ctx, Cloud &c, const float *xyz, const float *feat
         HIP_TRY(ctx, hipMemcpyAsync(ctx->raw_feat.p, hs + bytes_xyz, bytes_feat, hipMemcpyHostToDevice, ctx->stream));
         d_xyz = (const float *)ctx->raw_xyz.p;
         d_feat = (const float *)ctx->raw_feat.p;
-        for (int a = 0; a < 3; ++a) { ctx->bbox_host[a] = c.lo[a]; ctx->bbox_host[3 + a] = c.hi[a]; }
-        HIP_TRY(ctx, hipMemcpyAsync(ctx->bbox_dev, ctx->bbox_host, 6 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
     }
+    // From here on the cloud is in device memory either way.  Its bounding box is made there too
+    // and comes back to the host (the filter geometry of align() is made from it) together
+    // with the end of the preparation: one synchronisation.
+    HIP_TRY(ctx, cloud_bbox_device(d_xyz, n, ctx->bbox_dev, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->bbox_host, ctx->bbox_dev, 6 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
     int rc = CVO_HIP_OK;
     for (int q = 0; q < 2 && !rc; ++q) {
         rc = ensure_buf(ctx, ctx->sort_keys[q], (size_t)n * sizeof(uint32_t));
@@ -307,8 +298,7 @@ int upload_cloud(cvo_hip_ctx *ctx, Cloud &c, const float *xyz, const float *feat
     HIP_TRY(ctx, cloud_prepare_device(cp, ctx->stream));
     // (the staging buffer, or the caller's device arrays, may be re-used once this returns)
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    if (on_device)
-        for (int a = 0; a < 3; ++a) { c.lo[a] = ctx->bbox_host[a]; c.hi[a] = ctx->bbox_host[3 + a]; }
+    for (int a = 0; a < 3; ++a) { c.lo[a] = ctx->bbox_host[a]; c.hi[a] = ctx->bbox_host[3 + a]; }
     return CVO_HIP_OK;
 }
 
