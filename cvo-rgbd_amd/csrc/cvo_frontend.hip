@@ -866,6 +866,14 @@ int cvo_fe_create(int device, void *stream, int width, int height, cvo_fe_ctx **
     return CVO_HIP_OK;
 }
 
+int cvo_fe_host_buffers(cvo_fe_ctx *ctx, uint8_t **img, uint16_t **depth)
+{
+    if (!ctx || !img || !depth) return CVO_HIP_ERR_INVALID;
+    *img = ctx->h_img;
+    *depth = ctx->h_depth;
+    return CVO_HIP_OK;
+}
+
 int cvo_fe_set_device_output(cvo_fe_ctx *ctx, int on)
 {
     if (!ctx) return CVO_HIP_ERR_INVALID;
@@ -898,11 +906,14 @@ int cvo_fe_submit(cvo_fe_ctx *ctx, const uint8_t *img, size_t img_stride, const 
     FE_HIP(hipSetDevice(ctx->device));
     hipStream_t s = ctx->stream;
     // pinned staging; the depth rows are staged while the colour image is on its way
-    if (img_stride == (size_t)w * 3) std::memcpy(ctx->h_img, img, (size_t)np * 3);
+    if (img == ctx->h_img && img_stride == (size_t)w * 3) {
+        // (the caller decoded into the staging image itself: cvo_fe_host_buffers)
+    } else if (img_stride == (size_t)w * 3) std::memcpy(ctx->h_img, img, (size_t)np * 3);
     else
         for (int y = 0; y < h; ++y)
             std::memcpy(ctx->h_img + (size_t)y * w * 3, img + (size_t)y * img_stride, (size_t)w * 3);
-    if (depth_stride == (size_t)w * 2) std::memcpy(ctx->h_depth, depth, (size_t)np * 2);
+    if (depth == ctx->h_depth && depth_stride == (size_t)w * 2) {
+    } else if (depth_stride == (size_t)w * 2) std::memcpy(ctx->h_depth, depth, (size_t)np * 2);
     else
         for (int y = 0; y < h; ++y)
             std::memcpy(ctx->h_depth + (size_t)y * w, (const uint8_t *)depth + (size_t)y * depth_stride, (size_t)w * 2);

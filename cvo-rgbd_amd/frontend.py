@@ -27,7 +27,7 @@ FEATURES_HSV, FEATURES_RGB = 0, 1
  STAGE_EDGES) = range(10)
 
 SYMBOLS = ("cvo_fe_create", "cvo_fe_destroy", "cvo_fe_last_error", "cvo_fe_set_num_want",
-           "cvo_fe_create_pointcloud", "cvo_fe_submit", "cvo_fe_collect", "cvo_fe_collect_device", "cvo_fe_set_device_output", "cvo_fe_get_info", "cvo_fe_read_stage", "cvo_fe_random_pattern",
+           "cvo_fe_create_pointcloud", "cvo_fe_submit", "cvo_fe_collect", "cvo_fe_collect_device", "cvo_fe_set_device_output", "cvo_fe_host_buffers", "cvo_fe_get_info", "cvo_fe_read_stage", "cvo_fe_random_pattern",
            "cvo_fe_camera")
 
 
@@ -56,6 +56,7 @@ def lib():
         L.cvo_fe_collect.argtypes = [vp, fp, fp, C.c_int, C.POINTER(C.c_int)]
         L.cvo_fe_collect_device.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(C.c_int)]
         L.cvo_fe_set_device_output.argtypes = [vp, C.c_int]
+        L.cvo_fe_host_buffers.argtypes = [vp, C.POINTER(u8p), C.POINTER(u16p)]
         L.cvo_fe_get_info.argtypes = [vp, C.POINTER(Info)]
         L.cvo_fe_read_stage.argtypes = [vp, C.c_int, vp, C.c_size_t]
         L.cvo_fe_random_pattern.argtypes = [C.c_int, u8p]
@@ -146,6 +147,15 @@ class PcdGenerator:
         dp, df, n = C.c_void_p(), C.c_void_p(), C.c_int(0)
         self._chk(lib().cvo_fe_collect_device(self._h, C.byref(dp), C.byref(df), C.byref(n)), "collect_device")
         return dp.value, df.value, n.value
+
+    def host_buffers(self):
+        """numpy views of the context's pinned staging images (h x w x 3 uint8, h x w uint16): fill
+        them in place and pass them to submit() / create_pointcloud() to save a copy."""
+        pi, pd = C.POINTER(C.c_uint8)(), C.POINTER(C.c_uint16)()
+        self._chk(lib().cvo_fe_host_buffers(self._h, C.byref(pi), C.byref(pd)), "host_buffers")
+        img = np.ctypeslib.as_array(pi, shape=(self.height, self.width, 3))
+        dep = np.ctypeslib.as_array(pd, shape=(self.height, self.width))
+        return img, dep
 
     def set_device_output(self, on=True):
         """The following frames are taken with collect_device(): no copy of the cloud to the host."""

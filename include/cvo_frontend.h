@@ -78,6 +78,13 @@ int cvo_fe_create_pointcloud(cvo_fe_ctx *ctx, const uint8_t *img, size_t img_str
                              size_t depth_stride, int dataset_seq, int feature_type, float *positions,
                              float *features, int capacity, int *num_points);
 
+/* The context's own pinned staging images (width*3 bytes per colour row, width uint16 per
+ * depth row, no padding): a decoder that writes straight into them -- e.g. a cv::Mat header
+ * over the pointer handed to cv::imdecode -- saves the copy that submit() / create_pointcloud()
+ * otherwise make; pass these same pointers (and the dense strides) to them.  They may be
+ * refilled once the frame has been collected. */
+int cvo_fe_host_buffers(cvo_fe_ctx *ctx, uint8_t **img, uint16_t **depth);
+
 /* The same in two halves, for callers that have other work while the GPU is busy (the
  * drivers register frame k while frame k+1 is in the front end): submit() stages the
  * images, enqueues every kernel and the copies back and returns; collect() waits, runs the

@@ -279,3 +279,19 @@ def test_front_end_soak(pkg):
                          capture_output=True, text=True)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert " 0 mismatches" in out.stdout
+
+
+def test_decoding_straight_into_the_staging_images(pkg):
+    """cvo_fe_host_buffers: frames written in place into the pinned staging images give the
+    same clouds as frames handed over from ordinary arrays"""
+    gen = pkg.frontend.PcdGenerator(640, 480)
+    img, dep = gen.host_buffers()
+    assert img.shape == (480, 640, 3) and dep.shape == (480, 640)
+    for seed in (51, 52, 53):
+        bgr, depth = pkg.data.synthetic_rgbd_frame(seed=seed, texture=1.0)
+        want = gen.create_pointcloud(bgr, depth, 1, pkg.frontend.FEATURES_HSV)
+        img[...] = bgr
+        dep[...] = depth
+        got = gen.create_pointcloud(img, dep, 1, pkg.frontend.FEATURES_HSV)
+        assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+    gen.close()

@@ -20,6 +20,13 @@ for k in range(n):
     xyz, feat = gen.create_pointcloud(bgr, dep)
 dt = (time.perf_counter() - t0) / n
 print("front end: %.3f ms per frame (%.0f frames/s), %d points, info %s" % (dt * 1e3, 1 / dt, len(xyz), gen.info()))
+img, dep = gen.host_buffers()
+img[...] = frames[0][0]; dep[...] = frames[0][1]
+t0 = time.perf_counter()
+for k in range(n):
+    gen.create_pointcloud(img, dep)
+dz = (time.perf_counter() - t0) / n
+print("front end, frame already in the staging images: %.3f ms per frame (%.0f frames/s)" % (dz * 1e3, 1 / dz))
 t0 = time.perf_counter()
 for k in range(8):
     fo.create_pointcloud(*frames[k])
