@@ -13,7 +13,7 @@ pkg = ge.load_package()
 capi = pkg.capi
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 max_pts = int(sys.argv[2]) if len(sys.argv) > 2 else 3000
-rng = np.random.default_rng(12345)
+rng = np.random.default_rng(int(os.environ.get("SOAK_SEED", "12345")))
 po.set_threads(16)
 bad = 0
 t0 = time.time()

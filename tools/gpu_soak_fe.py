@@ -11,7 +11,7 @@ from oracle import pyoracle_fe as fo
 pkg = ge.load_package()
 F = pkg.frontend
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
-rng = np.random.default_rng(2024)
+rng = np.random.default_rng(int(os.environ.get("SOAK_SEED", "2024")))
 sizes = [(640, 480), (320, 240), (352, 288), (160, 128), (800, 600), (96, 64), (333, 251), (65, 64), (127, 193), (64, 64), (1024, 64), (1920, 1080)]
 gens = {}
 bad = 0
