@@ -17,8 +17,9 @@ namespace cvo_lock {
 
 inline std::shared_mutex &mutex()
 {
-    static std::shared_mutex m;
-    return m;
+    // (never destroyed: contexts may be closed from finalisers that run after static destructors)
+    static std::shared_mutex *m = new std::shared_mutex;
+    return *m;
 }
 
 inline int &depth()
