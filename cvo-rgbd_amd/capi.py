@@ -21,8 +21,8 @@ SYMBOLS = [
     "cvo_hip_comm_unique_id", "cvo_hip_comm_init", "cvo_hip_set_allreduce",
     "cvo_hip_transform_pcd", "cvo_hip_flow", "cvo_hip_step_coeffs", "cvo_hip_pick_step",
     "cvo_hip_exp_se3", "cvo_hip_dist_se3", "cvo_hip_align", "cvo_hip_align_many",
-    "cvo_hip_function_inner_product",
-    "cvo_hip_set_profiling", "cvo_hip_get_profile", "cvo_hip_get_graph_stats", "cvo_hip_synchronize",
+    "cvo_hip_function_inner_product", "cvo_hip_function_inner_product_clouds",
+    "cvo_hip_set_graph_capture", "cvo_hip_set_profiling", "cvo_hip_get_profile", "cvo_hip_get_graph_stats", "cvo_hip_synchronize",
 ]
 
 
@@ -120,6 +120,9 @@ def lib():
     L.cvo_hip_align_many.argtypes = [C.POINTER(vp), C.POINTER(C.POINTER(State)), C.POINTER(C.c_int),
                                      C.c_int]
     L.cvo_hip_function_inner_product.argtypes = [vp, C.c_float, fp]
+    L.cvo_hip_function_inner_product_clouds.argtypes = [vp, C.c_float, fp, fp, C.c_int, fp, fp, C.c_int,
+                                                        C.c_int, fp]
+    L.cvo_hip_set_graph_capture.argtypes = [vp, C.c_int]
     L.cvo_hip_set_profiling.argtypes = [vp, C.c_int]
     L.cvo_hip_get_profile.argtypes = [vp, C.POINTER(Profile), C.c_int]
     L.cvo_hip_get_graph_stats.argtypes = [vp, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]
@@ -210,7 +213,9 @@ def shard_range(n, rank, world):
 class Context:
     """Owns one cvo_hip_ctx (one device + one HIP stream)."""
 
-    def __init__(self, params=None, mode=MODE_CVO, device=0, stream=None):
+    def __init__(self, params=None, mode=MODE_CVO, device=0, stream=None, graph_capture=None):
+        """graph_capture: None = the library's default (hipGraphs on a stream the context
+        creates itself, eager launches on a caller's stream); True / False = cvo_hip_set_graph_capture."""
         self._L = lib()
         self.params = params if params is not None else default_params(mode)
         self._ctx = C.c_void_p()
@@ -219,6 +224,11 @@ class Context:
                                      C.byref(self._ctx)), what="cvo_hip_create")
         self.n_fixed = 0
         self.n_moving = 0
+        if graph_capture is not None:
+            self.set_graph_capture(graph_capture)
+
+    def set_graph_capture(self, enable=True):
+        self._chk(self._L.cvo_hip_set_graph_capture(self._ctx, int(bool(enable))), "set_graph_capture")
 
     def close(self):
         if self._ctx:
@@ -312,6 +322,14 @@ class Context:
         out = C.c_float()
         self._chk(self._L.cvo_hip_function_inner_product(self._ctx, np.float32(ell), C.byref(out)),
                   "function_inner_product")
+        return out.value
+
+    def function_inner_product_clouds(self, ell, xyz_a, feat_a, xyz_b, feat_b, layout=FEAT_ROWMAJOR):
+        xyz_a, feat_a, xyz_b, feat_b = f32(xyz_a), f32(feat_a), f32(xyz_b), f32(feat_b)
+        out = C.c_float()
+        self._chk(self._L.cvo_hip_function_inner_product_clouds(
+            self._ctx, np.float32(ell), fptr(xyz_a), fptr(feat_a), xyz_a.shape[0], fptr(xyz_b), fptr(feat_b),
+            xyz_b.shape[0], layout, C.byref(out)), "function_inner_product_clouds")
         return out.value
 
     def set_profiling(self, enable=True):

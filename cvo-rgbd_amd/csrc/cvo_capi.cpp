@@ -106,6 +106,7 @@ struct cvo_hip_ctx {
     cvo_hip_params prm{};
     DevParams dprm{};
     Cloud fixed, moving;
+    Cloud scratch_a, scratch_b;      // cvo_hip_function_inner_product_clouds: never the registration's clouds
     DevState *st = nullptr;          // device
     DevState *st_host = nullptr;     // pinned [kPollSlots + 2]
     int32_t *done_mirror = nullptr;  // pinned (in the last slot): the post kernels copy `done` here
@@ -176,6 +177,34 @@ int fail(cvo_hip_ctx *ctx, int code, const char *msg)
 {
     if (ctx) ctx->err = msg;
     return code;
+}
+
+// Parameters the kernels can work with: a known mode, finite values, positive kernel scales
+// and thresholds (log of a non-positive quotient would make NaN radii and NaN twists that
+// only surface as "align loop ended without a verdict").  Returns nullptr if fine.
+const char *params_problem(const cvo_hip_params &p)
+{
+    if (p.mode != CVO_HIP_MODE_CVO && p.mode != CVO_HIP_MODE_ACVO)
+        return "params.mode must be CVO_HIP_MODE_CVO or CVO_HIP_MODE_ACVO (MATLAB: default_params() returns mode CVO)";
+    if (p.max_iter < 0) return "params.max_iter < 0";
+    const float pos[] = {p.ell_init, p.sigma, p.sp_thres, p.c, p.d, p.c_ell, p.c_sigma};
+    const char *pos_name[] = {"ell_init", "sigma", "sp_thres", "c", "d", "c_ell", "c_sigma"};
+    static thread_local char msg[96];
+    for (int i = 0; i < 7; ++i)
+        if (!(pos[i] > 0.0f) || !std::isfinite(pos[i])) {
+            snprintf(msg, sizeof(msg), "params.%s must be positive and finite", pos_name[i]);
+            return msg;
+        }
+    if (p.mode == CVO_HIP_MODE_ACVO && (!(p.c_sp_thres > 0.0f) || !std::isfinite(p.c_sp_thres)))
+        return "params.c_sp_thres must be positive and finite";
+    if (p.mode == CVO_HIP_MODE_ACVO && (!(p.ell_max_init > 0.0f) || !std::isfinite(p.ell_max_init) ||
+                                        !(p.ell_min >= 0.0f) || !std::isfinite(p.dl_step)))
+        return "params.ell_max_init / ell_min / dl_step out of range";
+    const float fin[] = {p.min_step, p.eps, p.eps_2, p.color_scale, p.ell_min};
+    for (float v : fin)
+        if (!std::isfinite(v)) return "params: min_step, eps, eps_2, color_scale, ell_min must be finite";
+    if (p.color_scale < 0.0f) return "params.color_scale < 0";
+    return nullptr;
 }
 
 DevParams make_dev_params(const cvo_hip_params &p)
@@ -1038,6 +1067,7 @@ int cvo_hip_create(int device, void *stream, const cvo_hip_params *p, cvo_hip_ct
     cvo_lock::Api api_guard;
     if (!p || !out) return CVO_HIP_ERR_INVALID;
     *out = nullptr;
+    if (params_problem(*p)) return CVO_HIP_ERR_INVALID;   // (no context to hold the text: see cvo_hip_set_params)
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n)
         return CVO_HIP_ERR_NODEVICE;
@@ -1070,6 +1100,14 @@ int cvo_hip_create(int device, void *stream, const cvo_hip_params *p, cvo_hip_ct
             return bail(CVO_HIP_ERR_HIP);
     ctx->done_mirror = reinterpret_cast<int32_t *>(&ctx->st_host[kPollSlots + 1]);
     *ctx->done_mirror = 0;
+    // Stream capture is a process-wide affair in this runtime (cvo_lock.h): the library's own
+    // entry points keep out of each other's captures, but HIP work of OTHER code in the process
+    // (torch on another thread, say) cannot be kept out and would fail with "previous error
+    // during capture".  So batches are captured into hipGraphs by default only on a stream the
+    // library created itself; with a caller-supplied stream the caller opts in
+    // (cvo_hip_set_graph_capture, or CVO_HIP_GRAPH=1) once it knows no other thread of the
+    // process uses HIP while an align() is being set up.  CVO_HIP_NO_GRAPH=1 forbids captures.
+    ctx->use_graphs = ctx->own_stream || getenv("CVO_HIP_GRAPH") != nullptr;
     if (getenv("CVO_HIP_NO_GRAPH")) ctx->use_graphs = false;
     if (getenv("CVO_HIP_NO_MERGE")) ctx->allow_merge = false;
     if (getenv("CVO_HIP_NO_ASYNC")) ctx->allow_async = false;
@@ -1111,7 +1149,9 @@ int cvo_hip_destroy(cvo_hip_ctx *ctx)
         (void)hipFree(ctx->post_dbg);
     }
     for (void *p : {(void *)ctx->fixed.pos, (void *)ctx->fixed.feat, (void *)ctx->moving.pos,
-                    (void *)ctx->moving.feat, (void *)ctx->fixed.seg, (void *)ctx->moving.seg, (void *)ctx->st, ctx->part_flow.p, ctx->part_xx.p,
+                    (void *)ctx->moving.feat, (void *)ctx->fixed.seg, (void *)ctx->moving.seg,
+                    (void *)ctx->scratch_a.pos, (void *)ctx->scratch_a.feat, (void *)ctx->scratch_a.seg,
+                    (void *)ctx->scratch_b.pos, (void *)ctx->scratch_b.feat, (void *)ctx->scratch_b.seg, (void *)ctx->st, ctx->part_flow.p, ctx->part_xx.p,
                     ctx->part_yy.p, ctx->part_step.p, (void *)ctx->trace_dev, ctx->kept_cnt.p})
         if (p) (void)hipFree(p);
     for (int l = 0; l < LIST_N; ++l) {
@@ -1132,7 +1172,10 @@ int cvo_hip_destroy(cvo_hip_ctx *ctx)
 
 int cvo_hip_set_params(cvo_hip_ctx *ctx, const cvo_hip_params *p)
 {
+    cvo_lock::Api api_guard;
     if (!ctx || !p) return CVO_HIP_ERR_INVALID;
+    if (const char *why = params_problem(*p)) return fail(ctx, CVO_HIP_ERR_INVALID, why);
+    drop_graphs(ctx);   // (captured batches hold the parameter block by value)
     ctx->prm = *p;
     ctx->dprm = make_dev_params(*p);
     return CVO_HIP_OK;
@@ -1174,6 +1217,7 @@ int cvo_hip_set_moving_device(cvo_hip_ctx *ctx, const float *d_xyz, const float 
 
 int cvo_hip_swap_moving_to_fixed(cvo_hip_ctx *ctx)
 {
+    cvo_lock::Api api_guard;
     if (!ctx) return CVO_HIP_ERR_INVALID;
     std::swap(ctx->fixed, ctx->moving);
     ctx->moving.n = 0;
@@ -1192,6 +1236,7 @@ int cvo_hip_shard_range(int n, int rank, int world, int *lo, int *hi)
 
 int cvo_hip_set_shard(cvo_hip_ctx *ctx, int row_lo, int row_hi, int srow_lo, int srow_hi)
 {
+    cvo_lock::Api api_guard;
     if (!ctx || row_lo < 0 || row_hi < row_lo || srow_lo < 0 || srow_hi < srow_lo)
         return CVO_HIP_ERR_INVALID;
     ctx->row_lo = row_lo; ctx->row_hi = row_hi;
@@ -1220,6 +1265,7 @@ int cvo_hip_comm_init(cvo_hip_ctx *ctx, const void *id_bytes_128, int rank, int 
 
 int cvo_hip_set_allreduce(cvo_hip_ctx *ctx, cvo_hip_allreduce_fn fn, void *user)
 {
+    cvo_lock::Api api_guard;
     if (!ctx) return CVO_HIP_ERR_INVALID;
     ctx->user_allreduce = fn;
     ctx->user_allreduce_arg = user;
@@ -1894,7 +1940,11 @@ int cvo_hip_align_many(cvo_hip_ctx **ctxs, cvo_hip_state **states, int *n_iters,
                 runs.back()->start(grp, (int)runs.size() - 1);
             }
         }
-        for (auto &r : runs) r->use_graph = runs.size() <= 2;
+        for (auto &r : runs) {
+            r->use_graph = runs.size() <= 2;
+            for (AlignJob *j : r->live)   // (capture policy: cvo_hip_set_graph_capture)
+                if (!j->ctx->use_graphs) r->use_graph = false;
+        }
         for (;;) {
             bool any_live = false, moved = false;
             for (auto &r : runs) {
@@ -1942,6 +1992,9 @@ int cvo_hip_function_inner_product(cvo_hip_ctx *ctx, float ell, float *out)
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     // untransformed positions, colour cut with sp_thres (ref acvo.cpp:391-392)
     DevParams dp = ctx->dprm;
+    // the spatial threshold is written log(sp_thres/sigma/sigma) here (ref acvo.cpp:391): two
+    // float divisions, not the division by the float product s2 of se_kernel (ref :100)
+    dp.log_sp_s2 = (float)std::log((double)(ctx->prm.sp_thres / ctx->prm.sigma / ctx->prm.sigma));
     if (ctx->prm.mode == CVO_HIP_MODE_ACVO) {
         dp.c_sp = ctx->prm.sp_thres;
         dp.tau_c = (float)(-2.0 * ctx->prm.c_ell * ctx->prm.c_ell *
@@ -1987,8 +2040,40 @@ int cvo_hip_function_inner_product(cvo_hip_ctx *ctx, float ell, float *out)
     return CVO_HIP_OK;
 }
 
+int cvo_hip_function_inner_product_clouds(cvo_hip_ctx *ctx, float ell, const float *xyz_a, const float *feat_a,
+                                          int na, const float *xyz_b, const float *feat_b, int nb,
+                                          int feat_layout, float *out)
+{
+    cvo_lock::Api api_guard;
+    if (!ctx || !out) return CVO_HIP_ERR_INVALID;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    // the two clouds go to buffers of their own: the registration's fixed / moving clouds, a
+    // pending set_pcd() and the transform handed to the low-level calls stay as they are
+    // (the reference's function reads its two arguments and `ell`, nothing else: acvo.cpp:385)
+    const bool had_tf = ctx->have_tf;
+    std::swap(ctx->fixed, ctx->scratch_a);
+    std::swap(ctx->moving, ctx->scratch_b);
+    int rc = upload_cloud(ctx, ctx->fixed, xyz_a, feat_a, na, feat_layout);
+    if (!rc) rc = upload_cloud(ctx, ctx->moving, xyz_b, feat_b, nb, feat_layout);
+    if (!rc) rc = cvo_hip_function_inner_product(ctx, ell, out);
+    std::swap(ctx->fixed, ctx->scratch_a);
+    std::swap(ctx->moving, ctx->scratch_b);
+    ctx->have_tf = had_tf;
+    return rc;
+}
+
+int cvo_hip_set_graph_capture(cvo_hip_ctx *ctx, int enable)
+{
+    cvo_lock::Api api_guard;
+    if (!ctx) return CVO_HIP_ERR_INVALID;
+    ctx->use_graphs = enable != 0 && getenv("CVO_HIP_NO_GRAPH") == nullptr;
+    if (!ctx->use_graphs) drop_graphs(ctx);
+    return CVO_HIP_OK;
+}
+
 int cvo_hip_set_profiling(cvo_hip_ctx *ctx, int enable)
 {
+    cvo_lock::Api api_guard;
     if (!ctx) return CVO_HIP_ERR_INVALID;
     ctx->profiling = enable != 0;
     return CVO_HIP_OK;

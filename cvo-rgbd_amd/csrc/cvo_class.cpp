@@ -216,15 +216,16 @@ void registration::run_cvo(const point_cloud_view &pc)
 
 namespace acvo {
 
-float acvo::function_inner_product(const cvo_hip::point_cloud_view &cloud_b)
-{
-    check(cvo_hip_set_moving(ctx_, cloud_b.positions, cloud_b.features, cloud_b.num_points,
-                             cloud_b.feat_layout),
-          "cvo_hip_set_moving");
-    have_moving_ = true;
+float acvo::function_inner_product(const cvo_hip::point_cloud_view *cloud_a,
+                                   const cvo_hip::point_cloud_view *cloud_b)
+{   // ref src/adaptive_cvo.cpp:385-439: two arbitrary clouds and the current ell; nothing else is read
+    if (!cloud_a || !cloud_b || cloud_a->feat_layout != cloud_b->feat_layout)
+        check(CVO_HIP_ERR_INVALID, "function_inner_product");
     float out = 0.0f;
-    check(cvo_hip_function_inner_product(ctx_, state_.ell, &out),
-          "cvo_hip_function_inner_product");
+    check(cvo_hip_function_inner_product_clouds(ctx_, state_.ell, cloud_a->positions, cloud_a->features,
+                                                cloud_a->num_points, cloud_b->positions, cloud_b->features,
+                                                cloud_b->num_points, cloud_a->feat_layout, &out),
+          "cvo_hip_function_inner_product_clouds");
     return out;
 }
 

@@ -15,9 +15,9 @@ from . import capi
 class _Registration:
     MODE = capi.MODE_CVO
 
-    def __init__(self, device=0, stream=None, params=None):
+    def __init__(self, device=0, stream=None, params=None, graph_capture=None):
         self.params = params if params is not None else capi.default_params(self.MODE)
-        self.ctx = capi.Context(self.params, device=device, stream=stream)
+        self.ctx = capi.Context(self.params, device=device, stream=stream, graph_capture=graph_capture)
         self.state = capi.init_state(self.params)
         self.init = False
         self.iter = 0
@@ -135,9 +135,9 @@ class RkhsMatlab(_Registration):
 class Acvo(_Registration):
     MODE = capi.MODE_ACVO
 
-    def function_inner_product(self, positions, features, layout=capi.FEAT_ROWMAJOR):
-        """ref src/adaptive_cvo.cpp:385-439: statistic between the current fixed
-        cloud and the given cloud at the current length-scale."""
-        self.ctx.set_moving(positions, features, layout)
-        self._have_moving = True
-        return self.ctx.function_inner_product(self.state.ell)
+    def function_inner_product(self, cloud_a, cloud_b, layout=capi.FEAT_ROWMAJOR):
+        """ref include/adaptive_cvo.hpp:179, src/adaptive_cvo.cpp:385-439: the statistic between
+        two arbitrary clouds -- (positions, features) each -- at the current length-scale.
+        Registration state is untouched (a pending set_pcd() stays pending)."""
+        return self.ctx.function_inner_product_clouds(self.state.ell, cloud_a[0], cloud_a[1],
+                                                      cloud_b[0], cloud_b[1], layout)

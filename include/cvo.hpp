@@ -121,9 +121,10 @@ class acvo : public cvo_hip::registration {
   public:
     explicit acvo(int device = 0, void *stream = nullptr)
         : cvo_hip::registration(CVO_HIP_MODE_ACVO, device, stream) {}
-    // ref src/adaptive_cvo.cpp:385-439 (public, never called in the tree):
-    // inner product between the current fixed cloud and `cloud_b` at the
-    // current length-scale.
-    float function_inner_product(const cvo_hip::point_cloud_view &cloud_b);
+    // ref include/adaptive_cvo.hpp:179, src/adaptive_cvo.cpp:385-439 (public, never called in
+    // the tree): the inner-product statistic of two arbitrary clouds at the current
+    // length-scale.  Reads nothing else and changes nothing: a pending set_pcd() stays pending.
+    float function_inner_product(const cvo_hip::point_cloud_view *cloud_a,
+                                 const cvo_hip::point_cloud_view *cloud_b);
 };
 }   // namespace acvo

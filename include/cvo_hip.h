@@ -214,6 +214,24 @@ int cvo_hip_align_many(cvo_hip_ctx **ctxs, cvo_hip_state **states, int *n_iters,
 /* acvo::function_inner_product (ref src/adaptive_cvo.cpp:385-439) between the
  * fixed and the (untransformed) moving cloud at length-scale ell. */
 int cvo_hip_function_inner_product(cvo_hip_ctx *ctx, float ell, float *out);
+/* The reference's own signature -- float function_inner_product(point_cloud* cloud_a,
+ * point_cloud* cloud_b) (ref include/adaptive_cvo.hpp:179): any two clouds (host arrays), the
+ * statistic at length-scale `ell`.  Registration state is not touched: the clouds go to
+ * buffers of their own, a pending set_moving() stays pending. */
+int cvo_hip_function_inner_product_clouds(cvo_hip_ctx *ctx, float ell, const float *xyz_a,
+                                          const float *feat_a, int na, const float *xyz_b,
+                                          const float *feat_b, int nb, int feat_layout, float *out);
+
+/* hipGraph capture of the loop's batches of iterations.  A stream capture is a process-wide
+ * affair in the HIP runtime: while one thread captures, HIP calls of any other thread fail
+ * ("previous error during capture") and spoil the capture.  The library serialises its own
+ * entry points against its captures; it cannot do that for other HIP users in the process.
+ * Default: ON for a context that created its own stream (cvo_hip_create(stream = NULL)), OFF
+ * for a caller-supplied stream -- eager launches, same results, a few per cent slower.  Enable
+ * it when no other thread of the process issues HIP work while align() runs (or set
+ * CVO_HIP_GRAPH=1); CVO_HIP_NO_GRAPH=1 disables every capture of the library.
+ * cvo_hip_align_many() captures its shared launches only if every member context allows it. */
+int cvo_hip_set_graph_capture(cvo_hip_ctx *ctx, int enable);
 
 /* Profiling: HIP events on the context's stream around every sweep launch. */
 int cvo_hip_set_profiling(cvo_hip_ctx *ctx, int enable);

@@ -167,7 +167,11 @@ typedef struct kconsts {
 
 static float logf_cr(float x) { return (float)log((double)x); }
 
-static void make_kconsts(const cvo_oracle_params *p, float ell, float c_sp, kconsts *k)
+/* fip: function_inner_product writes the spatial threshold as log(sp_thres/sigma/sigma)
+ * (ref src/adaptive_cvo.cpp:391) -- two float divisions -- where se_kernel divides by the
+ * float product s2 once (ref src/cvo.cpp:102, src/adaptive_cvo.cpp:100): the float quotients
+ * differ in the last bit (0.8315 vs 0.83149993 with the acvo constants). */
+static void make_kconsts_ex(const cvo_oracle_params *p, float ell, float c_sp, int fip, kconsts *k)
 {
     const float l = ell;
     k->geom_only = 0;
@@ -176,7 +180,8 @@ static void make_kconsts(const cvo_oracle_params *p, float ell, float c_sp, kcon
     k->sp = p->sp_thres;
     /* ref src/cvo.cpp:102-103: float = -2.0*l*l*log(sp/s2): float log (std::log
      * overload), the rest in double, stored as float. */
-    k->tau = (float)(-2.0 * l * l * (double)logf_cr(p->sp_thres / k->s2));
+    k->tau = (float)(-2.0 * l * l * (double)logf_cr(fip ? p->sp_thres / p->sigma / p->sigma
+                                                        : p->sp_thres / k->s2));
     k->tau_c = (float)(-2.0 * p->c_ell * p->c_ell *
                        (double)logf_cr(c_sp / p->c_sigma / p->c_sigma));
     k->ninv_2l2 = -1.0 / (2.0 * l * l);
@@ -185,6 +190,11 @@ static void make_kconsts(const cvo_oracle_params *p, float ell, float c_sp, kcon
     /* MATLAB keeps K >= sp (ref rkhs_se3_registration.m:70): the radius is widened by 1e-5 so
      * that the exact test on K below decides, not the rounding of tau */
     if (k->cscale > 0.0f) k->tau = (float)((double)k->tau * 1.00001);
+}
+
+static void make_kconsts(const cvo_oracle_params *p, float ell, float c_sp, kconsts *k)
+{
+    make_kconsts_ex(p, ell, c_sp, 0, k);
 }
 
 void cvo_oracle_thresholds(const cvo_oracle_params *p, float ell, float tau[2])
@@ -932,8 +942,9 @@ float cvo_oracle_function_inner_product(const cvo_oracle_params *p, float ell, c
     int64_t *rp = NULL;
     int32_t *col = NULL;
     float *val = NULL;
-    if (cvo_oracle_se_kernel(p, ell, p->sp_thres, xa, fa, na, xb, fb, nb, search, &rp, &col,
-                             &val))
+    kconsts kc;
+    make_kconsts_ex(p, ell, p->sp_thres, 1, &kc);   /* ref acvo.cpp:391-392: its own threshold lines */
+    if (se_kernel_rows(&kc, xa, fa, 0, na, xb, fb, nb, search, &rp, &col, &val))
         return NAN;
     double sum_a = 0;
     const int64_t nnz = rp[na];

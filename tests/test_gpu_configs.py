@@ -1,0 +1,149 @@
+"""-m gpu: every BASELINE.json config at its stated size, HIP (through the C-ABI)
+against the CPU oracle.
+
+configs[0]  TUM fr1/desk pair decimated to ~3k x 3k        -> tests/test_gpu_parity.py (tum pair)
+configs[1]  synthetic 10k x 10k, seed 20190402, cvo + acvo -> here, per-iteration trace equality
+configs[2]  fr1/desk streamed (the 5 shipped clouds)       -> tests/test_gpu_paths.py (carry-over)
+configs[3]  synthetic 200k x 200k, seed 20191001, sharded  -> here: one iteration of flow / step
+            coefficients against the oracle at ell = 0.15 and 0.03, and a whole align()
+            two-rank-sharded (device mailboxes) against the unsharded run
+configs[4]  8 concurrent 20k x 20k per GPU, seeds 1000 + i -> here, one align_many call
+
+Tolerances as in tests/test_gpu_parity.py: float32 quantities identical, float64 sums
+1e-11 relative, transforms 1e-6 (north_star: 1e-4).  ref src/cvo.cpp:361-420.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+SUM_RTOL = 1e-11
+
+
+def _close(a, b, rtol=SUM_RTOL):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return np.abs(a - b).max() <= rtol * max(np.abs(b).max(), 1e-300)
+
+
+def _stream():
+    import torch
+    return torch.cuda.current_stream().cuda_stream
+
+
+@pytest.mark.parametrize("mode_name", ["cvo", "acvo"])
+def test_config1_10k_x_10k_trace_equals_oracle(pkg, po, mode_name):
+    """BASELINE configs[1]: the pair bench.py times.  Every iteration's nnz, ell, float32 twist
+    and step equal the oracle's; same iteration count; same transform."""
+    acvo = mode_name == "acvo"
+    mode = pkg.capi.MODE_ACVO if acvo else pkg.capi.MODE_CVO
+    xf, ff, xm, fm = pkg.data.synthetic_pair(10000, 10000, seed=pkg.data.SEED_CFG2, acvo=acvo)
+    reg = (pkg.Acvo if acvo else pkg.Cvo)(device=0, stream=_stream())
+    reg.run_cvo(xf, ff)
+    reg.run_cvo(xm, fm, trace_cap=2000)
+    p = po.default_params(mode)
+    st = po.init_state(p)
+    n_or, tr_or = po.align(p, st, xf, ff, xm, fm, search=po.SEARCH_GRID)
+    T_or, _, A_or = po.state_matrices(st)
+    assert reg.num_iterations == n_or
+    assert len(reg.trace) == len(tr_or)
+    for a, b in zip(reg.trace, tr_or):
+        assert a["nnz"] == b["nnz"] and a["ell"] == b["ell"]
+        assert a["nnz_xx"] == b["nnz_xx"] and a["nnz_yy"] == b["nnz_yy"]
+        assert a["omega"] == b["omega"] and a["v"] == b["v"] and a["step"] == b["step"]
+        assert _close(a["omega_d"], b["omega_d"]) and _close(a["v_d"], b["v_d"])
+        assert _close(a["bcde"], b["bcde"], 1e-9)
+    rot, tr = pkg.data.rel_pose_error(reg.transform, T_or)
+    assert rot <= 1e-6 and tr <= 1e-6
+    assert np.array_equal(np.array(reg.state.R), np.array(st.R))
+    assert np.array_equal(np.array(reg.state.T), np.array(st.T))
+    assert np.allclose(reg.accum_transform, A_or, rtol=0, atol=1e-7)
+    reg.close()
+
+
+@pytest.mark.parametrize("mode_name", ["cvo", "acvo"])
+def test_config4_eight_concurrent_20k_x_20k(pkg, po, mode_name):
+    """BASELINE configs[4], per GPU: 8 registrations of 20k x 20k (seeds 1000 + i) in flight
+    through ONE cvo_hip_align_many call; each equals the oracle's registration of its pair."""
+    import torch
+    capi = pkg.capi
+    acvo = mode_name == "acvo"
+    mode = capi.MODE_ACVO if acvo else capi.MODE_CVO
+    pairs = [pkg.data.synthetic_pair(20000, 20000, seed=pkg.data.SEED_CFG5_BASE + i, acvo=acvo) for i in range(8)]
+    streams = [torch.cuda.Stream() for _ in pairs]
+    ctxs = []
+    for (xf, ff, xm, fm), s in zip(pairs, streams):
+        c = capi.Context(mode=mode, device=0, stream=s.cuda_stream)
+        c.set_fixed(xf, ff)
+        c.set_moving(xm, fm)
+        ctxs.append(c)
+    states = [capi.init_state(c.params) for c in ctxs]
+    its = capi.align_many(ctxs, states)
+    p = po.default_params(mode)
+    for i, (xf, ff, xm, fm) in enumerate(pairs):
+        st = po.init_state(p)
+        n_or, _ = po.align(p, st, xf, ff, xm, fm, search=po.SEARCH_GRID, trace_cap=1)
+        assert its[i] == n_or, "pair %d" % i
+        assert np.array_equal(np.array(states[i].R), np.array(st.R)), "pair %d" % i
+        assert np.array_equal(np.array(states[i].T), np.array(st.T)), "pair %d" % i
+        assert states[i].iter == st.iter and states[i].ell == st.ell
+        rot, tr = pkg.data.rel_pose_error(np.array(states[i].transform, np.float32).reshape(4, 4),
+                                          po.state_matrices(st)[0])
+        assert rot <= 1e-6 and tr <= 1e-6
+    for c in ctxs:
+        c.close()
+
+
+@pytest.fixture(scope="module")
+def cfg3(pkg):
+    return pkg.data.synthetic_pair(200000, 200000, seed=pkg.data.SEED_CFG4)
+
+
+@pytest.mark.parametrize("ell", [0.03, 0.15])
+def test_config3_200k_x_200k_one_iteration(pkg, po, cfg3, ell):
+    """BASELINE configs[3] at full size (4e10 pairs per sweep): nnz(A) exact, float64 flow sums
+    and step coefficients against the oracle, float32 twist identical -- at the widest and the
+    narrowest length-scale of the cvo schedule (4.6e8 and 1.4e7 members of A)."""
+    xf, ff, xm, fm = cfg3
+    c = pkg.capi.Context(mode=pkg.capi.MODE_CVO, device=0, stream=_stream())
+    c.set_fixed(xf, ff)
+    c.set_moving(xm, fm)
+    R, T = np.eye(3, dtype=np.float32), np.zeros(3, np.float32)
+    c.transform_pcd(R, T)
+    out = c.flow(ell)
+    p = po.default_params(po.MODE_CVO)
+    csr = po.se_kernel(p, ell, xf, ff, xm, fm, search=po.SEARCH_GRID)
+    om, v, sa, sad2 = po.flow(p, ell, xf, xm, csr)
+    assert int(out[8]) == int(csr[0][-1])
+    assert _close(out[0:3], om) and _close(out[3:6], v)
+    assert _close([out[6]], [sa]) and _close([out[7]], [sad2])
+    omega, vv = om.astype(np.float32), v.astype(np.float32)
+    assert np.array_equal(out[0:3].astype(np.float32), omega)
+    assert np.array_equal(out[3:6].astype(np.float32), vv)
+    bcde = c.step_coeffs(omega, vv, ell)
+    ref = po.step_coeffs(ell, omega, vv, xf, xm, csr)
+    del csr
+    assert _close(bcde, ref, 1e-10)
+    assert pkg.capi.pick_step(bcde) == po.pick_step(ref)
+    c.close()
+
+
+def test_config3_200k_x_200k_two_ranks_equal_one(pkg, cfg3):
+    """BASELINE configs[3]: a whole align() with the target rows split over two ranks -- two
+    contexts on this GPU, their 13 + 4 float64 partial sums exchanged through device-memory
+    mailboxes inside the launch chain (the xGMI peer-store all-reduce of SURVEY 8e, here with
+    both mailboxes on one device) -- against the unsharded run: same iteration count, both
+    ranks bit-identical, transform within 1e-6."""
+    from helpers import align_two_ranks_mailbox
+    capi = pkg.capi
+    xf, ff, xm, fm = cfg3
+    ref = capi.Context(mode=capi.MODE_CVO, device=0, stream=_stream())
+    ref.set_fixed(xf, ff)
+    ref.set_moving(xm, fm)
+    st_ref = capi.init_state(ref.params)
+    it_ref, _ = ref.align(st_ref, trace_cap=0)
+    ref.close()
+    out = align_two_ranks_mailbox(pkg, capi.MODE_CVO, xf, ff, xm, fm)
+    assert out[0][0] == out[1][0] == it_ref
+    assert out[0][1] == out[1][1]
+    rot, tra = pkg.data.rel_pose_error(out[0][2], np.array(st_ref.transform, np.float32).reshape(4, 4))
+    assert rot <= 1e-6 and tra <= 1e-6

@@ -121,15 +121,28 @@ def test_list_overflow_grows_and_resumes(pkg, po, mode_name, monkeypatch):
 
 
 def test_function_inner_product_matches_oracle(pkg, po):
+    """ref src/adaptive_cvo.cpp:385-439: two arbitrary clouds and the current ell.  The statistic
+    equals the oracle's (float32 result of float64 sums: identical up to the summation order),
+    and the call leaves the registration alone: a pending set_pcd() stays pending and the
+    align() that follows is the one that would have run without the call in between."""
     xf, ff, xm, fm = pkg.data.synthetic_pair(1200, 1400, seed=29, acvo=True)
-    import torch
+    xa, fa, xb, fb = pkg.data.synthetic_pair(900, 1100, seed=31, acvo=True)
+    p = po.default_params(po.MODE_ACVO)
+    ref = pkg.Acvo(device=0, stream=_stream())
+    ref.run_cvo(xf, ff)
+    ref.run_cvo(xm, fm)
     reg = pkg.Acvo(device=0, stream=_stream())
     reg.run_cvo(xf, ff)
-    got = reg.function_inner_product(xm, fm)
-    p = po.default_params(po.MODE_ACVO)
-    want = po.function_inner_product(p, p.ell_init, xf, ff, xm, fm)
-    assert got == pytest.approx(want, rel=1e-6)
+    got = reg.function_inner_product((xf, ff), (xm, fm))
+    assert got == pytest.approx(po.function_inner_product(p, p.ell_init, xf, ff, xm, fm), rel=1e-6)
+    reg.set_pcd(xm, fm)                                    # pending moving cloud ...
+    got2 = reg.function_inner_product((xa, fa), (xb, fb))  # ... survives a call on two other clouds
+    assert got2 == pytest.approx(po.function_inner_product(p, p.ell_init, xa, fa, xb, fb), rel=1e-6)
+    reg.align()
+    assert reg.num_iterations == ref.num_iterations
+    assert np.array_equal(reg.transform, ref.transform)
     reg.close()
+    ref.close()
 
 
 @pytest.mark.parametrize("mode_name", ["cvo", "acvo"])

@@ -104,3 +104,59 @@ def test_sincos_det_is_the_rounded_libm_value(po):
         want = np.float32(s1 * th)
         bad += int(dR[1, 0] != want)
     assert bad == 0
+
+
+def _reference_root_rule(bcde, min_step=np.float32(0.2)):
+    """ref src/cvo.cpp:53-69,291-307 literally, in float32: p_coef = (4E, 3D, 2C, B) as floats,
+    companion matrix with first row -(coef/coef(0)).segment(1,3), ITS FLOAT32 EIGENVALUES
+    (LAPACK sgeev here, Eigen's float EigenSolver there), the smallest one with real > 0 and
+    imag == 0 EXACTLY, else min_step; clamp to 0.8."""
+    B, C, D, E = [np.float32(x) for x in bcde]
+    coef = np.array([np.float32(4.0 * float(E)), np.float32(3.0 * float(D)), np.float32(2.0 * float(C)), B],
+                    np.float32)
+    M = np.zeros((3, 3), np.float32)
+    M[1, 0] = M[2, 1] = 1
+    with np.errstate(all="ignore"):
+        M[0, :] = -(coef / coef[0])[1:4]
+    if not np.all(np.isfinite(M)):
+        return float(min_step)
+    fmax = np.float32(np.finfo(np.float32).max)
+    t = fmax
+    for z in np.linalg.eigvals(M):      # complex64
+        if z.real > 0 and z.real < t and z.imag == 0:
+            t = np.float32(z.real)
+    step = min_step if t == fmax else t
+    return float(np.float32(0.8) if float(step) > 0.8 else step)
+
+
+def test_sectioning_root_vs_float32_companion_eigenvalues(po, pkg):
+    """The restatement brackets and sections the cubic in float64 where the reference runs a
+    float32 eigen-solve of the companion matrix and keeps eigenvalues whose imaginary part is
+    exactly zero.  On the step-size coefficients that registrations actually produce (every
+    iteration of five oracle registrations, both modes) the two rules must give the same step;
+    on random coefficients -- including nearly double roots, where a float32 eigen-solve may
+    return a conjugate pair for two close real roots -- the disagreement rate is reported and
+    bounded."""
+    po.set_threads(4)
+    cases = []
+    for mode, seed, n in [(0, 7, 1500), (1, 7, 1500), (0, 11, 1200), (1, 5, 1200), (0, 23, 900)]:
+        xf, ff, xm, fm = pkg.data.synthetic_pair(n, n, seed=seed, acvo=(mode == 1))
+        p = po.default_params(mode)
+        st = po.init_state(p)
+        _, tr = po.align(p, st, xf, ff, xm, fm)
+        cases += [t["bcde"] for t in tr]
+    assert len(cases) > 200
+    worst = 0.0
+    for b in cases:
+        got, want = po.pick_step(b), _reference_root_rule(b)
+        worst = max(worst, abs(got - want) / max(abs(want), 1e-30))
+    assert worst <= 2e-6, "registration coefficients: sectioning and float32 eigen-solve differ by %g" % worst
+    rng = np.random.default_rng(8)
+    n_rand, n_diff = 2000, 0
+    for _ in range(n_rand):
+        b = rng.normal(0, 1, 4) * 10.0 ** rng.integers(-3, 4, 4)
+        got, want = po.pick_step(b), _reference_root_rule(b)
+        if abs(got - want) > 1e-4 * max(abs(want), 1e-30):
+            n_diff += 1
+    print("random coefficients: %d of %d steps differ by more than 1e-4 relative" % (n_diff, n_rand))
+    assert n_diff <= n_rand // 50
