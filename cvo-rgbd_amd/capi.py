@@ -19,6 +19,7 @@ SYMBOLS = [
     "cvo_hip_set_fixed_device", "cvo_hip_set_moving_device",
     "cvo_hip_swap_moving_to_fixed", "cvo_hip_set_shard", "cvo_hip_shard_range",
     "cvo_hip_comm_unique_id", "cvo_hip_comm_init", "cvo_hip_set_allreduce",
+    "cvo_hip_mailbox_create", "cvo_hip_mailbox_connect",
     "cvo_hip_transform_pcd", "cvo_hip_flow", "cvo_hip_step_coeffs", "cvo_hip_pick_step",
     "cvo_hip_exp_se3", "cvo_hip_dist_se3", "cvo_hip_align", "cvo_hip_align_many",
     "cvo_hip_function_inner_product", "cvo_hip_function_inner_product_clouds",
@@ -63,6 +64,7 @@ class Profile(C.Structure):
         ("flow_ms", C.c_double), ("flow_launches", C.c_int64), ("flow_pairs", C.c_double),
         ("step_ms", C.c_double), ("step_launches", C.c_int64), ("step_pairs", C.c_double),
         ("self_ms", C.c_double), ("self_launches", C.c_int64), ("self_pairs", C.c_double),
+        ("proc_flow_ms", C.c_double), ("proc_flow_launches", C.c_int64),
     ]
 
 
@@ -109,6 +111,8 @@ def lib():
     L.cvo_hip_comm_unique_id.argtypes = [vp]
     L.cvo_hip_comm_init.argtypes = [vp, vp, C.c_int, C.c_int]
     L.cvo_hip_set_allreduce.argtypes = [vp, ALLREDUCE_FN, vp]
+    L.cvo_hip_mailbox_create.argtypes = [vp, C.c_int, C.c_int, vp, C.POINTER(vp)]
+    L.cvo_hip_mailbox_connect.argtypes = [vp, vp, C.POINTER(vp)]
     L.cvo_hip_transform_pcd.argtypes = [vp, fp, fp]
     L.cvo_hip_flow.argtypes = [vp, C.c_float, dp]
     L.cvo_hip_step_coeffs.argtypes = [vp, fp, fp, C.c_float, dp]
@@ -280,6 +284,24 @@ class Context:
     def comm_init(self, id_bytes, rank, world):
         buf = C.create_string_buffer(bytes(id_bytes), 128)
         self._chk(self._L.cvo_hip_comm_init(self._ctx, buf, rank, world), "comm_init")
+
+    def mailbox_create(self, rank, world):
+        """-> (64-byte IPC handle, device pointer) of this rank's mailbox."""
+        buf = C.create_string_buffer(64)
+        ptr = C.c_void_p()
+        self._chk(self._L.cvo_hip_mailbox_create(self._ctx, rank, world, buf, C.byref(ptr)), "mailbox_create")
+        self._mail_world = world
+        return buf.raw, ptr.value
+
+    def mailbox_connect(self, handles=None, ptrs=None):
+        """handles: the ranks' IPC handles in rank order (one process per GPU) -- or ptrs: their
+        device pointers (ranks inside one process)."""
+        if ptrs is not None:
+            arr = (C.c_void_p * len(ptrs))(*ptrs)
+            self._chk(self._L.cvo_hip_mailbox_connect(self._ctx, None, arr), "mailbox_connect")
+        else:
+            blob = C.create_string_buffer(b"".join(bytes(h) for h in handles), 64 * len(handles))
+            self._chk(self._L.cvo_hip_mailbox_connect(self._ctx, blob, None), "mailbox_connect")
 
     def set_allreduce(self, fn):
         """fn(dev_ptr:int, count:int, stream:int) -> None ; sums in place over ranks."""

@@ -82,6 +82,7 @@ struct GraphEntry {
     uint64_t stamp = 0;
 };
 constexpr int kPollSlots = 4;
+constexpr int kEvProcFlow = 10, kEvProcStep = 11;   // EventPair::kind of the list kernels (0..2: k_filter of list l)
 constexpr int kProcStepTwist = 100;   // RecOp::mode of a k_step_twist launch
 constexpr int kFlowBuild = 101;       // RecOp::mode of a k_flow_build launch (RecOp::f = the build's arguments)
 constexpr int kFilterAhead = 102;     // RecOp::mode of an xx / yy filter that builds ahead (rides in the flow launch)
@@ -146,6 +147,11 @@ struct cvo_hip_ctx {
     int row_lo = 0, row_hi = -1, srow_lo = 0, srow_hi = -1;
     bool sharded = false;
     cvo_comm *comm = nullptr;
+    // mailbox all-reduce (cvo_device.h Mailbox / CommTable)
+    Mailbox *mailbox = nullptr;          // this rank's own, device memory (uncached where the runtime offers it)
+    CommTable *comm_table = nullptr;     // device copy; not null = connected: the post kernels exchange
+    void *mail_opened[MAX_WORLD] = {};   // peers' mailboxes opened from IPC handles (closed at destroy)
+    int mail_rank = 0, mail_world = 0;
     cvo_hip_allreduce_fn user_allreduce = nullptr;
     void *user_allreduce_arg = nullptr;
     bool profiling = false;
@@ -573,9 +579,19 @@ int enqueue_process(cvo_hip_ctx *ctx, int mode, int list, DevBuf &part, const fl
         ctx->rec->push_back(op);
         return CVO_HIP_OK;
     }
-    if (twist) launch_step_twist_group(&a, 1, ctx->stream);
+    EventPair ev{};
+    const bool timed = ctx->profiling && !build && (mode == PROC_FLOW || mode == PROC_STEP);
+    if (timed) {
+        HIP_TRY(ctx, hipEventCreate(&ev.a));
+        HIP_TRY(ctx, hipEventCreate(&ev.b));
+        ev.kind = mode == PROC_FLOW ? kEvProcFlow : kEvProcStep;
+        ev.iter_tag = ctx->iter_tag;
+        ev.pairs = 0.0;
+    }
+    if (twist) launch_step_twist_group(&a, 1, ctx->stream, ev.a, ev.b);
     else if (build) launch_flow_build_group(&a, &ctx->xy_build, 1, ctx->stream);
-    else launch_process(mode, a, ctx->stream);
+    else launch_process(mode, a, ctx->stream, ev.a, ev.b);
+    if (timed) ctx->events.push_back(ev);
     HIP_TRY(ctx, hipGetLastError());
     return CVO_HIP_OK;
 }
@@ -615,6 +631,10 @@ int drain_events(cvo_hip_ctx *ctx, int n_exec = -1, const DevState *fin = nullpt
             live = (fin->built[ev.kind][(ev.iter_tag >> 5) & 63] >> (ev.iter_tag & 31)) & 1u;
         if (!live) {
             // skipped launch
+        } else if (ev.kind == kEvProcFlow) {
+            ctx->prof.proc_flow_ms += ms; ctx->prof.proc_flow_launches++;
+        } else if (ev.kind == kEvProcStep) {
+            ctx->prof.step_ms += ms; ctx->prof.step_launches++;
         } else if (ev.kind == LIST_XY) {
             ctx->prof.flow_ms += ms; ctx->prof.flow_launches++; ctx->prof.flow_pairs += ev.pairs;
         } else {
@@ -627,7 +647,11 @@ int drain_events(cvo_hip_ctx *ctx, int n_exec = -1, const DevState *fin = nullpt
     return CVO_HIP_OK;
 }
 
-bool multi_rank(const cvo_hip_ctx *ctx) { return ctx->comm || ctx->user_allreduce; }
+// Sums over ranks: either between the kernels (RCCL / the caller's hook: a stream-level
+// all-reduce, two extra launches per reduction and no graph capture) or inside the post
+// kernels through the mailboxes (nothing for the host to do).
+bool host_reduce(const cvo_hip_ctx *ctx) { return !ctx->comm_table && (ctx->comm || ctx->user_allreduce); }
+bool multi_rank(const cvo_hip_ctx *ctx) { return ctx->comm_table || ctx->comm || ctx->user_allreduce; }
 
 // the parameter block of the kernels of align(): the context's, plus the mode of this run
 DevParams loop_params(const cvo_hip_ctx *ctx)
@@ -643,6 +667,7 @@ int reduce_over_ranks(cvo_hip_ctx *ctx, int off, int count)
 {
     double *buf = reinterpret_cast<double *>(reinterpret_cast<char *>(ctx->st) +
                                              offsetof(DevState, red)) + off;
+    if (ctx->comm_table) return CVO_HIP_OK;   // exchanged inside the post kernel already
     if (ctx->comm) {
         if (cvo_comm_allreduce(ctx->comm, buf, count, ctx->stream) != 0)
             return fail(ctx, CVO_HIP_ERR_COMM, cvo_comm_last_error(ctx->comm));
@@ -727,7 +752,8 @@ int enqueue_flow(cvo_hip_ctx *ctx, bool tf_moving, int check_done, bool do_math,
     pa.part_flow = (const double *)ctx->part_flow.p;
     pa.part_xx = (const double *)ctx->part_xx.p;
     pa.part_yy = (const double *)ctx->part_yy.p;
-    if (multi_rank(ctx)) {
+    pa.comm = ctx->comm_table;
+    if (host_reduce(ctx)) {
         pa.flags = POST_REDUCE;
         emit_post_flow(ctx, pa);
         rc = reduce_over_ranks(ctx, RED_FLOW, RED_STEP - RED_FLOW);
@@ -761,7 +787,8 @@ int enqueue_step(cvo_hip_ctx *ctx, int check_done, bool do_math, cvo_hip_trace *
     pa.nblk = ctx->merge_twist ? ctx->proc_blocks / STEP_TWIST_ROWS_DIV : ctx->proc_blocks;
     pa.part_step = (const double *)ctx->part_step.p;
     pa.dbg = ctx->post_dbg;
-    if (multi_rank(ctx)) {
+    pa.comm = ctx->comm_table;
+    if (host_reduce(ctx)) {
         pa.flags = POST_REDUCE;
         emit_post_step(ctx, pa);
         rc = reduce_over_ranks(ctx, RED_STEP, RED_N - RED_STEP);
@@ -854,7 +881,7 @@ std::vector<uint64_t> graph_key(const cvo_hip_ctx *ctx, int trace_cap)
     P(ctx->moving.pos); P(ctx->moving.feat); P(ctx->moving.seg); I(ctx->moving.np);
     for (int l = 0; l < LIST_N; ++l) { P(ctx->lists[l].a.p); P(ctx->lists[l].b.p); I(ctx->lists[l].cap); }
     P(ctx->kept_cnt.p); P(ctx->part_flow.p); P(ctx->part_xx.p); P(ctx->part_yy.p); P(ctx->part_step.p);
-    P(ctx->trace_dev); I((uint64_t)trace_cap); P(ctx->st); P(ctx->post_dbg);
+    P(ctx->trace_dev); I((uint64_t)trace_cap); P(ctx->st); P(ctx->post_dbg); P(ctx->comm_table);
     I(ctx->use_async); I((uint64_t)ctx->proc_blocks);
     I(ctx->sharded); I((uint64_t)ctx->row_lo); I((uint64_t)ctx->row_hi);
     I((uint64_t)ctx->srow_lo); I((uint64_t)ctx->srow_hi);
@@ -878,7 +905,7 @@ void drop_graphs(cvo_hip_ctx *ctx)
 // (single rank, no per-launch HIP events, buffers already allocated), else eagerly.
 int launch_batch(cvo_hip_ctx *ctx, int tag0, int trace_cap)
 {
-    const bool graphable = ctx->use_graphs && ctx->warm && !ctx->profiling && !multi_rank(ctx);
+    const bool graphable = ctx->use_graphs && ctx->warm && !ctx->profiling && !host_reduce(ctx);
     if (!graphable) {
         const int rc = enqueue_iterations(ctx, kBatch, tag0, trace_cap);
         if (!rc) ctx->warm = true;
@@ -1137,6 +1164,10 @@ int cvo_hip_destroy(cvo_hip_ctx *ctx)
     for (int i = 0; i < kPollSlots; ++i)
         if (ctx->poll_ev[i]) (void)hipEventDestroy(ctx->poll_ev[i]);
     if (ctx->comm) cvo_comm_destroy(ctx->comm);
+    for (void *q : ctx->mail_opened)
+        if (q) (void)hipIpcCloseMemHandle(q);
+    if (ctx->comm_table) (void)hipFree(ctx->comm_table);
+    if (ctx->mailbox) (void)hipFree(ctx->mailbox);
     if (getenv("CVO_HIP_GRAPH_DEBUG"))
         fprintf(stderr, "[cvo_hip] graph cache: %lld hits, %lld captures\n", ctx->graph_hits, ctx->graph_misses);
     drop_graphs(ctx);
@@ -1263,6 +1294,99 @@ int cvo_hip_comm_init(cvo_hip_ctx *ctx, const void *id_bytes_128, int rank, int 
     return CVO_HIP_OK;
 }
 
+int cvo_hip_mailbox_create(cvo_hip_ctx *ctx, int rank, int world, void *ipc_handle_64, void **dev_ptr)
+{
+    cvo_lock::Api api_guard;
+    if (!ctx || world < 1 || world > MAX_WORLD || rank < 0 || rank >= world) return CVO_HIP_ERR_INVALID;
+    static_assert(sizeof(hipIpcMemHandle_t) <= CVO_HIP_MAILBOX_HANDLE_BYTES, "IPC handle size");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->comm_table) { HIP_TRY(ctx, hipFree(ctx->comm_table)); ctx->comm_table = nullptr; }
+    for (void *&q : ctx->mail_opened)
+        if (q) { (void)hipIpcCloseMemHandle(q); q = nullptr; }
+    if (!ctx->mailbox) {
+        // peers write into it while this rank's kernel polls it: memory that no cache of this
+        // device holds back -- uncached where the runtime offers it, else fine-grained, else plain
+        // (polls and payload reads are system-scope loads either way)
+        void *p = nullptr;
+        if (hipExtMallocWithFlags(&p, sizeof(Mailbox), hipDeviceMallocUncached) != hipSuccess) {
+            (void)hipGetLastError();
+            p = nullptr;
+            if (hipExtMallocWithFlags(&p, sizeof(Mailbox), hipDeviceMallocFinegrained) != hipSuccess) {
+                (void)hipGetLastError();
+                p = nullptr;
+                if (hipMalloc(&p, sizeof(Mailbox)) != hipSuccess)
+                    return fail(ctx, CVO_HIP_ERR_NOMEM, "hipMalloc(mailbox) failed");
+            }
+        }
+        ctx->mailbox = (Mailbox *)p;
+    }
+    // sequence numbers restart with a new set of peers: empty the slots and the counter
+    HIP_TRY(ctx, hipMemset(ctx->mailbox, 0, sizeof(Mailbox)));
+    HIP_TRY(ctx, hipMemset(reinterpret_cast<char *>(ctx->st) + offsetof(DevState, mail_seq), 0, sizeof(unsigned long long)));
+    ctx->mail_rank = rank;
+    ctx->mail_world = world;
+    if (ipc_handle_64) {
+        std::memset(ipc_handle_64, 0, CVO_HIP_MAILBOX_HANDLE_BYTES);
+        hipIpcMemHandle_t h;
+        if (hipIpcGetMemHandle(&h, ctx->mailbox) != hipSuccess) {
+            (void)hipGetLastError();
+            return fail(ctx, CVO_HIP_ERR_COMM, "hipIpcGetMemHandle(mailbox) failed (HSA_ENABLE_IPC_MODE_LEGACY=0 set?)");
+        }
+        std::memcpy(ipc_handle_64, &h, sizeof(h));
+    }
+    if (dev_ptr) *dev_ptr = ctx->mailbox;
+    return CVO_HIP_OK;
+}
+
+int cvo_hip_mailbox_connect(cvo_hip_ctx *ctx, const void *ipc_handles, void *const *dev_ptrs)
+{
+    cvo_lock::Api api_guard;
+    if (!ctx || !ctx->mailbox || ctx->mail_world < 1 || (!ipc_handles && !dev_ptrs && ctx->mail_world > 1))
+        return CVO_HIP_ERR_INVALID;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    CommTable t{};
+    t.rank = ctx->mail_rank;
+    t.world = ctx->mail_world;
+    double secs = 5.0;
+    if (const char *e = getenv("CVO_HIP_MAILBOX_TIMEOUT_S")) { const double v = atof(e); if (v > 0.0) secs = v; }
+    t.timeout_ticks = (long long)(secs * 1.0e8);   // wall_clock64(): 100 MHz
+    for (int r = 0; r < t.world; ++r) {
+        if (r == t.rank) { t.peer[r] = ctx->mailbox; continue; }
+        void *p = nullptr;
+        if (dev_ptrs) {
+            p = dev_ptrs[r];   // same process: a pointer this device can reach (peer access enabled by the owner of the devices)
+            hipPointerAttribute_t at{};
+            if (p && hipPointerGetAttributes(&at, p) == hipSuccess && at.device != ctx->device) {
+                const hipError_t e = hipDeviceEnablePeerAccess(at.device, 0);
+                if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) {
+                    (void)hipGetLastError();
+                    return fail(ctx, CVO_HIP_ERR_COMM, "hipDeviceEnablePeerAccess failed");
+                }
+            }
+            (void)hipGetLastError();
+        } else {
+            hipIpcMemHandle_t h;
+            std::memcpy(&h, reinterpret_cast<const char *>(ipc_handles) + (size_t)r * CVO_HIP_MAILBOX_HANDLE_BYTES, sizeof(h));
+            if (hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess) != hipSuccess) {
+                (void)hipGetLastError();
+                return fail(ctx, CVO_HIP_ERR_COMM, "hipIpcOpenMemHandle(peer mailbox) failed");
+            }
+            ctx->mail_opened[r] = p;
+        }
+        if (!p) return fail(ctx, CVO_HIP_ERR_INVALID, "null peer mailbox");
+        t.peer[r] = (Mailbox *)p;
+    }
+    CommTable *d = nullptr;
+    HIP_TRY(ctx, hipMalloc((void **)&d, sizeof(CommTable)));
+    if (hipMemcpy(d, &t, sizeof(t), hipMemcpyHostToDevice) != hipSuccess) {
+        (void)hipFree(d);
+        return fail(ctx, CVO_HIP_ERR_HIP, "hipMemcpy(comm table) failed");
+    }
+    ctx->comm_table = d;
+    return CVO_HIP_OK;
+}
+
 int cvo_hip_set_allreduce(cvo_hip_ctx *ctx, cvo_hip_allreduce_fn fn, void *user)
 {
     cvo_lock::Api api_guard;
@@ -1314,6 +1438,15 @@ int cvo_hip_flow(cvo_hip_ctx *ctx, float ell, double out13[13])
         if (!rc) rc = enqueue_flow(ctx, true, 0, false, nullptr, 0);
         if (!rc) rc = check_overflow_and_grow(ctx, &redo);
         if (rc) return rc;
+        if (multi_rank(ctx)) {
+            // a list that overflowed on ANY rank poisoned nnz before the sums went over the
+            // ranks: every rank sees the NaN and redoes the pass (the one that overflowed with
+            // a larger list), so that all of them run the same number of exchanges
+            double nnz = 0.0;
+            rc = fetch_red(ctx, RED_FLOW + 8, 1, &nnz);
+            if (rc) return rc;
+            if (nnz != nnz) redo = true;
+        }
     }
     rc = fetch_red(ctx, RED_FLOW, 13, out13);
     if (!rc && ctx->profiling) rc = drain_events(ctx);
@@ -1426,7 +1559,8 @@ int job_begin(AlignJob &j)
     h->iter = s->iter;
     fill_filter_geometry(ctx, h);
     if (p.max_iter <= 0) h->done = DONE_MAX_ITER;
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->st, h, sizeof(DevState), hipMemcpyHostToDevice, ctx->stream));
+    // (everything but the mailbox sequence number, which lives as long as the context)
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->st, h, DEVSTATE_INIT_BYTES, hipMemcpyHostToDevice, ctx->stream));
     // small clouds (the ~3k-point clouds of the reference's front end): 2048 waves do
     // (measured 3k x 3k: 2.11 ms with 512 blocks, 2.19 with 1024; 10k x 10k the other way round)
     if (!ctx->proc_blocks_forced)
@@ -1462,6 +1596,8 @@ int job_finish(AlignJob &j)
     cvo_hip_state *s = j.s;
     const DevState &f = ctx->st_host[0];
     ctx->have_tf = false;   // the low-level entry points need their own transform_pcd()
+    if (f.done == DONE_COMM_ERROR)
+        return fail(ctx, CVO_HIP_ERR_COMM, "mailbox all-reduce timed out: a peer rank never delivered its partial sums");
     if (f.done == RUNNING || f.done == NEED_BIGGER_LIST)
         return fail(ctx, CVO_HIP_ERR_INVALID, "align loop ended without a verdict");
     const int executed = f.n_exec;
@@ -1509,7 +1645,7 @@ int job_pump(AlignJob &j, bool block)
             // per batch is all the polling needs.  With ranks to stay in step with, the
             // state is copied in stream order instead: every rank must see `done` at the
             // same batch, or their all-reduce counts would differ.
-            if (multi_rank(ctx) &&
+            if (host_reduce(ctx) &&
                 hipMemcpyAsync(&ctx->st_host[slot], ctx->st, DEVSTATE_HEAD_BYTES, hipMemcpyDeviceToHost,
                                ctx->stream) != hipSuccess)
                 return finish_with(fail(ctx, CVO_HIP_ERR_HIP, "poll copy failed"));
@@ -1523,8 +1659,10 @@ int job_pump(AlignJob &j, bool block)
         if (q == hipErrorNotReady) return 0;
         if (q != hipSuccess) return finish_with(fail(ctx, CVO_HIP_ERR_HIP, "poll event failed"));
         ++j.checked;
-        if (multi_rank(ctx) ? ctx->st_host[slot].done != RUNNING
-                            : *(volatile int32_t *)ctx->done_mirror != RUNNING)
+        // (mailboxes: a rank that sees `done` one batch after its peers only queues kernels that
+        // return at their first load -- no exchange is left half done)
+        if (host_reduce(ctx) ? ctx->st_host[slot].done != RUNNING
+                             : *(volatile int32_t *)ctx->done_mirror != RUNNING)
             stop = true;
         // (slots, not iterations: asynchronous builds add a stall slot now and then)
         if (j.enq >= (ctx->use_async ? 2 : 1) * ctx->prm.max_iter + 4 * kBatch) stop = true;   // cannot happen
@@ -2019,6 +2157,7 @@ int cvo_hip_function_inner_product(cvo_hip_ctx *ctx, float ell, float *out)
     pa.prm.mode = CVO_HIP_MODE_CVO;   // no self terms here
     pa.nblk = ctx->proc_blocks;
     pa.flags = POST_REDUCE;
+    pa.comm = ctx->comm_table;
     for (bool redo = true; redo;) {
         rc = zero_counters(ctx);
         if (!rc) rc = enqueue_filter(ctx, LIST_XY, ctx->fixed, rlo, rhi, 0, ctx->moving, 0, 0);

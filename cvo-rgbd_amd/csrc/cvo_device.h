@@ -80,7 +80,30 @@ constexpr int NACC_MAX = 9;
 constexpr int RED_FLOW = 0, RED_XX = 9, RED_YY = 11, RED_STEP = 13, RED_N = 17;
 
 // DevState::done values
-enum { RUNNING = 0, DONE_BREAK_A = 1, DONE_BREAK_B = 2, DONE_MAX_ITER = 3, NEED_BIGGER_LIST = 4 };
+enum { RUNNING = 0, DONE_BREAK_A = 1, DONE_BREAK_B = 2, DONE_MAX_ITER = 3, NEED_BIGGER_LIST = 4,
+       DONE_COMM_ERROR = 5 };
+
+// Peer-to-peer mailbox all-reduce: every rank owns one Mailbox in ITS OWN device
+// memory with one slot per sender (two generations: a sender may be one exchange ahead of
+// the slowest reader, never two).  An exchange = every rank stores its partial sums and then
+// the sequence number into slot[seq & 1][my rank] of EVERY rank's mailbox (peer stores over
+// xGMI, own store locally), then polls the slots of its own mailbox -- local memory, no
+// remote reads -- until all carry `seq`, and adds them up in rank order: every rank gets the
+// same bits whatever the arrival order.  It runs inside the post kernels: no collective
+// launch, no stream-level synchronisation, two one-way link latencies per iteration.
+constexpr int MAX_WORLD = 16;
+constexpr int MAIL_VALS = 14;      // >= the 13 flow-side sums
+struct alignas(128) MailSlot {
+    double v[MAIL_VALS];
+    unsigned long long seq;
+    unsigned long long pad_;
+};
+struct Mailbox { MailSlot slot[2][MAX_WORLD]; };
+struct CommTable {
+    Mailbox *peer[MAX_WORLD];      // peer[rank] = this rank's own mailbox
+    int rank, world;
+    long long timeout_ticks;       // of the 100 MHz wall clock
+};
 
 struct KernConsts {
     float tau;        // d2 < tau
@@ -166,7 +189,12 @@ struct DevState {
     // bit k of built[l]: iteration k (mod 2048) rebuilt list l (profiling: which
     // k_filter launches did the work)
     uint32_t built[3][64];
+    // exchanges done through the mailboxes since the context was created (never reset: the
+    // sequence numbers of successive align() calls must keep alternating between the two
+    // slot generations) -- kept last, align() re-initialises everything in front of it
+    unsigned long long mail_seq;
 };
+constexpr size_t DEVSTATE_INIT_BYTES = offsetof(DevState, mail_seq);
 constexpr size_t DEVSTATE_HEAD_BYTES = offsetof(DevState, sub);
 
 // Fused launches: one launch can serve up to MAXG independent registrations
@@ -242,6 +270,7 @@ struct PostFlowArgs {
     int check_done;
     int32_t *done_mirror;  // optional host-visible copy of st->done once the loop has stopped
     int nblk;              // rows of the partial-sum arrays (= ProcessArgs::nblk of the producers)
+    const CommTable *comm; // not null: the reduced sums are exchanged with the other ranks (mailboxes)
     DevParams prm;
 };
 
@@ -254,6 +283,7 @@ struct PostStepArgs {
     long long *dbg;        // diagnostics only (CVO_HIP_POST_DEBUG): phase clocks of thread 0
     int32_t *done_mirror;  // see PostFlowArgs
     int nblk;
+    const CommTable *comm; // see PostFlowArgs
     DevParams prm;
 };
 
@@ -496,15 +526,18 @@ size_t filter_smem_bytes(int jt);
 void launch_prepare(DevState *st, const DevParams &prm, hipStream_t s);
 void launch_filter(const FilterArgs &a, dim3 grid, hipStream_t s, hipEvent_t ev_start = nullptr,
                    hipEvent_t ev_stop = nullptr);
-void launch_process(int mode, const ProcessArgs &a, hipStream_t s);
+void launch_process(int mode, const ProcessArgs &a, hipStream_t s, hipEvent_t ev_start = nullptr,
+                    hipEvent_t ev_stop = nullptr);
 void launch_post_flow(const PostFlowArgs &a, hipStream_t s);
 void launch_post_step(const PostStepArgs &a, hipStream_t s);
 // fused: n <= MAXG argument blocks, one launch (FilterArgs::gx/gy must be set)
 void launch_filter_group(const FilterArgs *a, int n, hipStream_t s);
-void launch_process_group(int mode, const ProcessArgs *a, int n, hipStream_t s);
+void launch_process_group(int mode, const ProcessArgs *a, int n, hipStream_t s, hipEvent_t ev_start = nullptr,
+                          hipEvent_t ev_stop = nullptr);
 void launch_post_flow_group(const PostFlowArgs *a, int n, hipStream_t s);
 void launch_post_step_group(const PostStepArgs *a, int n, hipStream_t s);
-void launch_step_twist_group(const ProcessArgs *a, int n, hipStream_t s);
+void launch_step_twist_group(const ProcessArgs *a, int n, hipStream_t s, hipEvent_t ev_start = nullptr,
+                             hipEvent_t ev_stop = nullptr);
 void launch_flow_build_group(const ProcessArgs *a, const FilterArgs *f, int n, hipStream_t s);
 void launch_flow_build3(const ProcessArgs &flow, const FilterArgs &xy, const FilterArgs &xx,
                         const FilterArgs &yy, hipStream_t s);

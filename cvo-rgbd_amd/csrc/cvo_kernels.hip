@@ -999,13 +999,14 @@ __global__ void __launch_bounds__(STEP_BLOCK) k_step_twist(const Grp<ProcessArgs
     }
 }
 
-void launch_step_twist_group(const ProcessArgs *a, int n, hipStream_t s)
+void launch_step_twist_group(const ProcessArgs *a, int n, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop)
 {
     Grp<ProcessArgs> g;
     int nblk = 32;
     for (int i = 0; i < n; ++i) { g.a[i] = a[i]; nblk = std::max(nblk, a[i].nblk); }
     const dim3 grid((unsigned)(nblk / (STEP_BLOCK / BLOCK)), 1, (unsigned)n);
-    hipLaunchKernelGGL(k_step_twist, grid, dim3(STEP_BLOCK), 0, s, g);
+    if (ev_start && ev_stop) hipExtLaunchKernelGGL(k_step_twist, grid, dim3(STEP_BLOCK), 0, s, ev_start, ev_stop, 0, g);
+    else hipLaunchKernelGGL(k_step_twist, grid, dim3(STEP_BLOCK), 0, s, g);
 }
 
 // flow pass + asynchronous xy build: f[i] is the k_filter argument block of a[i]
@@ -1094,13 +1095,24 @@ void launch_flow_build6(const ProcessArgs &flow, const ProcessArgs &sxx, const P
                        filter_smem_bytes(jt), s, flow, sxx, syy, xy, xx, yy, np, n0, n1, n2);
 }
 
-void launch_process_group(int mode, const ProcessArgs *a, int n, hipStream_t s)
+void launch_process_group(int mode, const ProcessArgs *a, int n, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop)
 {
     Grp<ProcessArgs> g;
     for (int i = 0; i < n; ++i) g.a[i] = a[i];
     int nblk = 1;
     for (int i = 0; i < n; ++i) nblk = std::max(nblk, a[i].nblk);
     const dim3 grid((unsigned)nblk, 1, (unsigned)n);
+    if (ev_start && ev_stop) {   // profiling: the events take the dispatch's own begin / end timestamps
+        if (mode == PROC_FLOW && a[0].weight == 1)
+            hipExtLaunchKernelGGL((k_process<PROC_FLOW, 1>), grid, dim3(BLOCK), 0, s, ev_start, ev_stop, 0, g);
+        else if (mode == PROC_FLOW)
+            hipExtLaunchKernelGGL(k_process<PROC_FLOW>, grid, dim3(BLOCK), 0, s, ev_start, ev_stop, 0, g);
+        else if (mode == PROC_STEP)
+            hipExtLaunchKernelGGL(k_process<PROC_STEP>, grid, dim3(BLOCK), 0, s, ev_start, ev_stop, 0, g);
+        else
+            hipExtLaunchKernelGGL(k_process<PROC_SELF>, grid, dim3(BLOCK), 0, s, ev_start, ev_stop, 0, g);
+        return;
+    }
     switch (mode) {
     case PROC_FLOW:
         if (a[0].weight == 1) hipLaunchKernelGGL((k_process<PROC_FLOW, 1>), grid, dim3(BLOCK), 0, s, g);
@@ -1115,9 +1127,9 @@ void launch_process_group(int mode, const ProcessArgs *a, int n, hipStream_t s)
     }
 }
 
-void launch_process(int mode, const ProcessArgs &a, hipStream_t s)
+void launch_process(int mode, const ProcessArgs &a, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop)
 {
-    launch_process_group(mode, &a, 1, s);
+    launch_process_group(mode, &a, 1, s, ev_start, ev_stop);
 }
 
 // ---------------------------------------------------------------------------
@@ -1219,6 +1231,59 @@ __device__ __forceinline__ double section_root_wave(const cvo_math::CubicBracket
     return hi;
 }
 
+// ---------------------------------------------------------------------------
+// Mailbox all-reduce over the ranks (cvo_device.h: Mailbox, CommTable), called by
+// a whole block between its reduction and its O(1) maths: vals[0..count) (LDS or global,
+// written before the call) are replaced by their sums over all ranks, added in rank order.
+// Lane r of wave 0 serves rank r: it stores this rank's values and then the sequence number
+// into rank r's mailbox (system-scope stores: peer memory over xGMI), polls this rank's own
+// slot of sender r and copies it out.  The poll is bounded (CommTable::timeout_ticks): a
+// peer that never shows up ends the registration with DONE_COMM_ERROR instead of hanging
+// the GPU.  Returns false on a time-out (block-uniform).
+__device__ bool mailbox_allreduce(const CommTable &ct, DevState *gst, double *vals, int count,
+                                  double *sh /*[MAX_WORLD * MAIL_VALS]*/, int *sh_fail)
+{
+    __syncthreads();
+    const int lane = threadIdx.x;
+    if (lane < 64) {
+        const unsigned long long seq = gst->mail_seq + 1ull;
+        const int gen = (int)(seq & 1ull);
+        bool ok = true;
+        if (lane < ct.world) {
+            MailSlot *dst = &ct.peer[lane]->slot[gen][ct.rank];
+            for (int i = 0; i < count; ++i)
+                __hip_atomic_store(&dst->v[i], vals[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the flag must not overtake the write-back)
+            __hip_atomic_store(&dst->seq, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            const MailSlot *src = &ct.peer[ct.rank]->slot[gen][lane];
+            const long long t0 = (long long)wall_clock64();
+            while (__hip_atomic_load(&src->seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != seq) {
+                if ((long long)wall_clock64() - t0 > ct.timeout_ticks) { ok = false; break; }
+                __builtin_amdgcn_s_sleep(8);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+            for (int i = 0; i < count; ++i)
+                sh[lane * MAIL_VALS + i] = __hip_atomic_load(&src->v[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        const bool all_ok = __ballot(!ok) == 0ull;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (lane < count && all_ok) {
+            double t = 0.0;
+            for (int r = 0; r < ct.world; ++r) t += sh[r * MAIL_VALS + lane];   // rank order, on every rank
+            vals[lane] = t;
+        }
+        if (lane == 0) {
+            gst->mail_seq = seq;
+            *sh_fail = all_ok ? 0 : 1;
+        }
+    }
+    __syncthreads();
+    return *sh_fail == 0;
+}
+
 __global__ void __launch_bounds__(BLOCK) k_post_flow(const Grp<PostFlowArgs> grp)
 {
     const PostFlowArgs &a = grp.a[blockIdx.z];
@@ -1245,7 +1310,14 @@ __global__ void __launch_bounds__(BLOCK) k_post_flow(const Grp<PostFlowArgs> grp
              st->cnt[2 * LIST_YY + 1] | st->cnt[2 * LIST_KEPT + 1]))
             st->red[8] = __builtin_nan("");
     }
-    if ((a.flags & POST_MATH) && threadIdx.x == 0) {
+    bool comm_ok = true;
+    if (a.comm) {
+        __shared__ double sh_mail[MAX_WORLD * MAIL_VALS];
+        __shared__ int sh_fail;
+        comm_ok = mailbox_allreduce(*a.comm, a.st, st->red + RED_FLOW, RED_STEP - RED_FLOW, sh_mail, &sh_fail);
+        if (!comm_ok && threadIdx.x == 0) st->done = DONE_COMM_ERROR;
+    }
+    if ((a.flags & POST_MATH) && comm_ok && threadIdx.x == 0) {
         // nothing of an overflowed iteration is usable; the host enlarges the
         // list and resumes from the same (untouched) state
         const bool overflow = st->red[8] != st->red[8];
@@ -1329,7 +1401,14 @@ __global__ void __launch_bounds__(BLOCK) k_post_step(const Grp<PostStepArgs> grp
     if (a.dbg && threadIdx.x == 0) {
         a.dbg[0] += 1; a.dbg[1] += c1 - c0; a.dbg[2] += (long long)__builtin_readcyclecounter() - c1;
     }
-    if (a.flags & POST_MATH) {
+    bool comm_ok = true;
+    if (a.comm && !stalled) {
+        __shared__ double sh_mail[MAX_WORLD * MAIL_VALS];
+        __shared__ int sh_fail;
+        comm_ok = mailbox_allreduce(*a.comm, a.st, st->red + RED_STEP, RED_N - RED_STEP, sh_mail, &sh_fail);
+        if (!comm_ok && threadIdx.x == 0) st->done = DONE_COMM_ERROR;
+    }
+    if ((a.flags & POST_MATH) && comm_ok) {
         if (stalled) {
             if (threadIdx.x == 0) prepare_iteration(st, a.prm);   // the state did not move: plan only
         } else if (threadIdx.x < 64) {

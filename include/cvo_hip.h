@@ -109,17 +109,22 @@ typedef struct cvo_hip_trace {
     int64_t nnz_yy;
 } cvo_hip_trace;
 
-/* Accumulated HIP-event timings of the two pair sweeps (profiling mode). */
+/* Accumulated HIP-event timings (profiling mode: one registration at a time, eager launches,
+ * an event pair attached to each dispatch = the kernel's own begin / end timestamps).  Only
+ * launches that did work are counted (not the ones queued past convergence, not a k_filter
+ * whose list was re-used). */
 typedef struct cvo_hip_profile {
-    double flow_ms;        /* sum over launches of the flow sweep kernel */
+    double flow_ms;        /* k_filter on the (fixed x moving) pair set: the all-pairs test */
     int64_t flow_launches;
-    double flow_pairs;     /* pair tests executed by those launches */
-    double step_ms;
+    double flow_pairs;     /* pair tests those launches stand for (rows x padded columns) */
+    double step_ms;        /* the step-size pass over the members of A (k_step_twist / k_process<PROC_STEP>) */
     int64_t step_launches;
     double step_pairs;
-    double self_ms;        /* acvo Axx/Ayy sweeps */
+    double self_ms;        /* acvo: k_filter on (x, x) and (y, y) */
     int64_t self_launches;
     double self_pairs;
+    double proc_flow_ms;   /* k_process<PROC_FLOW>: exact test + flow sums over the candidate list */
+    int64_t proc_flow_launches;
 } cvo_hip_profile;
 
 typedef struct cvo_hip_ctx cvo_hip_ctx;
@@ -170,6 +175,27 @@ int cvo_hip_comm_init(cvo_hip_ctx *ctx, const void *id_bytes_128, int rank, int 
  * context's stream; must be summed over ranks in place, stream-ordered). */
 typedef int (*cvo_hip_allreduce_fn)(void *user, double *dev_buf, int count, void *stream);
 int cvo_hip_set_allreduce(cvo_hip_ctx *ctx, cvo_hip_allreduce_fn fn, void *user);
+
+/* Peer-to-peer mailbox all-reduce (preferred over RCCL for these <= 104-byte messages): every
+ * rank owns a 4 KB mailbox in its own device memory; per reduction each rank stores its partial
+ * sums + a sequence number into every rank's mailbox (peer stores over xGMI), polls its OWN
+ * mailbox and adds the world's partials in rank order -- inside the kernels that reduce the
+ * block partials, so an iteration has no collective launch and no stream-level wait, results
+ * are bitwise the same on every rank, and batches of iterations are still captured as hipGraphs.
+ * Replaces the mutex-guarded sums of ref src/cvo.cpp:201-204,283-288 and
+ * src/adaptive_cvo.cpp:234-238 across GPUs.
+ *   1. every rank: cvo_hip_mailbox_create(ctx, rank, world, handle, &ptr)    (world <= 16)
+ *   2. the caller ships the 64-byte IPC handles (one process per GPU, e.g. with
+ *      torch.distributed.all_gather_object) or the raw pointers (ranks in one process)
+ *   3. every rank: cvo_hip_mailbox_connect(ctx, handles (world x 64 bytes, rank order), NULL)
+ *      or (ctx, NULL, ptrs (world device pointers)); after it cvo_hip_align / _flow /
+ *      _step_coeffs / _function_inner_product all-reduce through the mailboxes.
+ * All ranks must issue the same sequence of those calls (SPMD).  A peer that does not show up
+ * within CVO_HIP_MAILBOX_TIMEOUT_S (default 5 s) ends the call with CVO_HIP_ERR_COMM.  Nobody may
+ * destroy its context while a peer can still be inside such a call. */
+#define CVO_HIP_MAILBOX_HANDLE_BYTES 64
+int cvo_hip_mailbox_create(cvo_hip_ctx *ctx, int rank, int world, void *ipc_handle_64, void **dev_ptr);
+int cvo_hip_mailbox_connect(cvo_hip_ctx *ctx, const void *ipc_handles, void *const *dev_ptrs);
 
 /* update_tf() + transform_pcd() (ref src/cvo.cpp:83-87,310-315). */
 int cvo_hip_transform_pcd(cvo_hip_ctx *ctx, const float R[9], const float T[3]);

@@ -657,3 +657,41 @@ def test_two_ranks_on_one_gpu_through_the_allreduce_hook(pkg, po, mode_name, n, 
     T_ref = np.array(st_ref.transform, np.float32).reshape(4, 4)
     rot, tra = pkg.data.rel_pose_error(out[0][2], T_ref)
     assert rot <= 1e-6 and tra <= 1e-6
+
+
+@pytest.mark.parametrize("mode_name,n,m,world", [("cvo", 2600, 2300, 2), ("acvo", 1500, 2400, 2), ("cvo", 5000, 5000, 4)])
+def test_ranks_on_one_gpu_through_device_mailboxes(pkg, mode_name, n, m, world):
+    """The peer-store all-reduce of SURVEY 8e (cvo_hip_mailbox_*): `world` contexts on this GPU,
+    each with its share of the fixed rows, exchange their 13 + 4 float64 partial sums through
+    mailboxes in DEVICE memory from inside the post kernels -- the code path that runs over
+    xGMI between GPUs; here every peer store lands on the same device.  All ranks stay in lock
+    step bit for bit and land on the unsharded result (same iteration count, 1e-6)."""
+    from helpers import align_two_ranks
+    capi = pkg.capi
+    acvo = mode_name == "acvo"
+    mode = capi.MODE_ACVO if acvo else capi.MODE_CVO
+    xf, ff, xm, fm = pkg.data.synthetic_pair(n, m, seed=61, acvo=acvo)
+    ref = _ctx(pkg, mode, xf, ff, xm, fm)
+    st_ref = capi.init_state(ref.params)
+    it_ref, _ = ref.align(st_ref, trace_cap=0)
+    ref.close()
+    out = align_two_ranks(pkg, mode, xf, ff, xm, fm, exchange="mailbox", world=world, timeout=120)
+    T_ref = np.array(st_ref.transform, np.float32).reshape(4, 4)
+    for r in range(world):
+        assert out[r][0] == it_ref
+        assert out[r][1] == out[0][1]                   # lock step, bit for bit
+    rot, tra = pkg.data.rel_pose_error(out[0][2], T_ref)
+    assert rot <= 1e-6 and tra <= 1e-6
+
+
+@pytest.mark.parametrize("mode_name", ["cvo", "acvo"])
+def test_ranks_in_separate_processes_through_ipc_mailboxes(mode_name):
+    """One process per rank, mailboxes opened from IPC handles (tools/gpu_mailbox_ipc.py): the
+    set-up bench.py's sharded leg uses on a multi-GPU node, here with both ranks on GPU 0."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "gpu_mailbox_ipc.py"), "2", "3000", mode_name],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "mailbox ipc world 2: OK" in r.stdout

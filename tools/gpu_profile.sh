@@ -2,7 +2,7 @@
 # Runs on the GPU box (via gpurun): bench + rocprofv3 kernel stats + PMC passes.
 # Outputs under gpurun_out/<tag>/ ; tools/collect_profiles.py copies the summaries
 # that should be judged into profiles/.
-TAG=${1:-r01}
+TAG=${1:-r02}
 ROOTDIR=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOTDIR/gpurun_out/$TAG
 mkdir -p $OUT
@@ -11,8 +11,8 @@ python bench.py --steps 20 --warmup 3 > $OUT/bench.json 2> $OUT/bench.err
 tail -1 $OUT/bench.json
 cd /tmp && export TMPDIR=/tmp
 # kernel durations are only meaningful with one registration in flight: --batch 1
-B="python $ROOTDIR/bench.py --batch 1 --steps 5 --warmup 1 --no-cpu --no-frontend"
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_batch -o stats -- python $ROOTDIR/bench.py --steps 5 --warmup 1 --no-cpu --no-frontend > $OUT/stats_batch.log 2>&1
+B="python $ROOTDIR/bench.py --batch 1 --steps 5 --warmup 1 --no-cpu --no-side-legs"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_batch -o stats -- python $ROOTDIR/bench.py --steps 5 --warmup 1 --no-cpu --no-side-legs > $OUT/stats_batch.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o stats -- $B > $OUT/stats.log 2>&1
 # PMC passes: counters only (gpurun refuses --pmc together with the trace domains)
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o fetch -- $B > $OUT/pmc_fetch.log 2>&1
