@@ -24,6 +24,7 @@
 #include <new>
 #include <string>
 #include <memory>
+#include <deque>
 #include <mutex>
 #include <vector>
 
@@ -72,14 +73,86 @@ struct List {     // LIST_XY/XX/YY: TileEntry[cap] in a; LIST_KEPT: uint2[cap] i
 
 constexpr int kBatch = 6;        // iterations enqueued between two polls (measured: 4 -> 556, 6 -> 572, 8 -> 566, 12 -> 549 reg/s)
 
-// A captured batch of kBatch iterations (hipGraph): one hipGraphLaunch instead
-// of 5-9 kernel launches per iteration.  Valid for exactly the kernel arguments
-// in `key` (cloud / list / partial / trace pointers, sizes, shard, parameters).
-struct GraphEntry {
+// The kernels of the loop read their argument blocks from a table of Slots in device memory
+// (cvo_device.h "Argument tables"): one slot for a registration on its own (cvo_hip_align), up
+// to MAXG for a fused group (cvo_hip_align_many).  The host keeps an image of what it last sent
+// per slot and sends a slot again only when its image changed -- through a small ring of
+// pinned staging buffers, ordered on the stream that runs the loop.
+constexpr int kStage = 8;
+struct TableBuf {
+    Slot *dev = nullptr;
+    int nslots = 0;
+    std::vector<Slot> image;          // what the device holds (after the queued copies)
+    Slot *stage = nullptr;            // pinned [kStage]
+    hipEvent_t stage_ev[kStage] = {};
+    bool stage_used[kStage] = {};
+    int next = 0;
+
+    int init(int n)
+    {
+        if (dev) return 0;
+        if (hipMalloc((void **)&dev, (size_t)n * sizeof(Slot)) != hipSuccess) { dev = nullptr; return -1; }
+        if (hipMemset(dev, 0, (size_t)n * sizeof(Slot)) != hipSuccess) return -1;
+        if (hipHostMalloc((void **)&stage, kStage * sizeof(Slot), hipHostMallocDefault) != hipSuccess) return -1;
+        for (int i = 0; i < kStage; ++i)
+            if (hipEventCreateWithFlags(&stage_ev[i], hipEventDisableTiming) != hipSuccess) return -1;
+        nslots = n;
+        image.assign((size_t)n, Slot{});
+        return 0;
+    }
+    void destroy()
+    {
+        for (int i = 0; i < kStage; ++i)
+            if (stage_ev[i]) (void)hipEventDestroy(stage_ev[i]);
+        if (stage) (void)hipHostFree(stage);
+        if (dev) (void)hipFree(dev);
+        dev = nullptr; stage = nullptr; nslots = 0;
+        image.clear();
+    }
+    // slot z := want, as far as its first `nq` argument blocks go (no-op for what the device
+    // already holds; a change of `active` alone is a 16-byte copy); ordered on s
+    int send(int z, const Slot &want, hipStream_t s, int nq = MAX_OPS)
+    {
+        Slot &img = image[(size_t)z];
+        const size_t head = offsetof(Slot, op);
+        const size_t bytes = head + (size_t)nq * sizeof(OpArgs);
+        const bool ops_same = std::memcmp(img.op, want.op, (size_t)nq * sizeof(OpArgs)) == 0;
+        if (ops_same && std::memcmp(&img, &want, head) == 0) return 0;
+        const size_t n = ops_same ? head : bytes;
+        const int b = next;
+        next = (next + 1) % kStage;
+        if (stage_used[b] && hipEventSynchronize(stage_ev[b]) != hipSuccess) return -1;   // (kStage copies ago)
+        std::memcpy(&stage[b], &want, n);
+        if (hipMemcpyAsync(&dev[z], &stage[b], n, hipMemcpyHostToDevice, s) != hipSuccess) return -1;
+        if (hipEventRecord(stage_ev[b], s) != hipSuccess) return -1;
+        stage_used[b] = true;
+        std::memcpy(&img, &want, n);
+        return 0;
+    }
+};
+
+// A captured batch of kBatch iterations of a launch plan (hipGraph).  It depends on the table's
+// address and on the plan -- kernels, grids, LDS sizes -- not on any argument: one capture
+// serves every frame pair (and every membership of a fused group) of the same shape.
+struct PlanGraph {
+    std::vector<TLaunch> plan;
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
-    std::vector<uint64_t> key;
     uint64_t stamp = 0;
+};
+struct PlanCache {
+    std::vector<PlanGraph> graphs;
+    uint64_t clock = 0;
+    long long hits = 0, captures = 0;
+    int fails = 0;
+    void drop()
+    {
+        for (auto &g : graphs) {
+            if (g.exec) (void)hipGraphExecDestroy(g.exec);
+            if (g.graph) (void)hipGraphDestroy(g.graph);
+        }
+        graphs.clear();
+    }
 };
 constexpr int kPollSlots = 4;
 constexpr int kEvProcFlow = 10, kEvProcStep = 11;   // EventPair::kind of the list kernels (0..2: k_filter of list l)
@@ -156,10 +229,10 @@ struct cvo_hip_ctx {
     void *user_allreduce_arg = nullptr;
     bool profiling = false;
     long long *post_dbg = nullptr;   // CVO_HIP_POST_DEBUG diagnostics
-    std::vector<GraphEntry> graphs;  // small LRU cache (the clouds ping-pong between two buffers)
-    uint64_t graph_clock = 0;
-    long long graph_hits = 0, graph_misses = 0;   // cvo_hip_get_graph_stats / CVO_HIP_GRAPH_DEBUG
-    int graph_fail = 0;                           // consecutive captures spoilt by an allocation
+    TableBuf table;                  // this registration's own argument table (one slot): cvo_hip_align
+    PlanCache plans;                 // ... and the batches captured for it
+    std::vector<TLaunch> plan;       // launches of one iteration of the align() in progress
+    hipStream_t loop_stream = nullptr;   // stream the align() in progress runs on (a fused group's, else `stream`)
     bool warm = false;               // every device buffer of the loop has been allocated
     bool use_graphs = true;
     int iter_tag = -1;
@@ -449,6 +522,7 @@ void fill_filter_geometry(const cvo_hip_ctx *ctx, DevState *h)
 
 bool multi_rank(const cvo_hip_ctx *ctx);
 DevParams loop_params(const cvo_hip_ctx *ctx);
+hipStream_t loop_stream(const cvo_hip_ctx *ctx);
 
 // The dense all-pairs filter of one list (with optional HIP-event bracket: this
 // is the kernel the roofline is quoted on).
@@ -847,7 +921,7 @@ int prepare_buffers(cvo_hip_ctx *ctx)
         if (!rc) rc = ensure_buf(ctx, *b, (size_t)PROC_WAVES * NACC_MAX * sizeof(double));
     if (!rc && !ctx->kept_cnt.p) {
         rc = ensure_buf(ctx, ctx->kept_cnt, PROC_WAVES * sizeof(uint32_t));
-        if (!rc) HIP_TRY(ctx, hipMemsetAsync(ctx->kept_cnt.p, 0, PROC_WAVES * sizeof(uint32_t), ctx->stream));
+        if (!rc) HIP_TRY(ctx, hipMemsetAsync(ctx->kept_cnt.p, 0, PROC_WAVES * sizeof(uint32_t), loop_stream(ctx)));
     }
     if (!rc) ctx->warm = true;
     return rc;
@@ -871,109 +945,293 @@ int enqueue_iterations(cvo_hip_ctx *ctx, int count, int tag0, int trace_cap)
     return rc;
 }
 
-std::vector<uint64_t> graph_key(const cvo_hip_ctx *ctx, int trace_cap)
-{
-    std::vector<uint64_t> k;
-    auto P = [&](const void *p) { k.push_back((uint64_t)(uintptr_t)p); };
-    auto I = [&](uint64_t v) { k.push_back(v); };
-    // (padded sizes: a stream of frames whose clouds differ by a few points re-uses one graph)
-    P(ctx->fixed.pos); P(ctx->fixed.feat); P(ctx->fixed.seg); I(ctx->fixed.np);
-    P(ctx->moving.pos); P(ctx->moving.feat); P(ctx->moving.seg); I(ctx->moving.np);
-    for (int l = 0; l < LIST_N; ++l) { P(ctx->lists[l].a.p); P(ctx->lists[l].b.p); I(ctx->lists[l].cap); }
-    P(ctx->kept_cnt.p); P(ctx->part_flow.p); P(ctx->part_xx.p); P(ctx->part_yy.p); P(ctx->part_step.p);
-    P(ctx->trace_dev); I((uint64_t)trace_cap); P(ctx->st); P(ctx->post_dbg); P(ctx->comm_table);
-    I(ctx->use_async); I((uint64_t)ctx->proc_blocks);
-    I(ctx->sharded); I((uint64_t)ctx->row_lo); I((uint64_t)ctx->row_hi);
-    I((uint64_t)ctx->srow_lo); I((uint64_t)ctx->srow_hi);
-    uint64_t h = 1469598103934665603ull;   // FNV-1a over the by-value parameter block
-    const unsigned char *b = reinterpret_cast<const unsigned char *>(&ctx->dprm);
-    for (size_t i = 0; i < sizeof(DevParams); ++i) { h ^= b[i]; h *= 1099511628211ull; }
-    I(h);
-    return k;
+void drop_graphs(cvo_hip_ctx *ctx) { ctx->plans.drop(); }
+
+// ---------------------------------------------------------------------------
+// From the recorded launches of one iteration (RecOp) to a launch plan + the slot contents.
+bool merged_w4()
+{   // merged launches: 4 waves per SIMD, nothing spilled (default) or 6 with a few spills (profiles/ has the A/B)
+    static const bool v = [] { const char *e = getenv("CVO_HIP_MERGED_WAVES"); return !(e && atoi(e) == 6); }();
+    return v;
 }
 
-void drop_graphs(cvo_hip_ctx *ctx)
+TLaunch mk_launch(int kernel, int q, unsigned gx, unsigned gz, unsigned smem = 0)
 {
-    for (auto &g : ctx->graphs) {
-        if (g.exec) (void)hipGraphExecDestroy(g.exec);
-        if (g.graph) (void)hipGraphDestroy(g.graph);
+    TLaunch l{};
+    l.kernel = kernel; l.q = q; l.gx = gx; l.gz = gz; l.smem = smem;
+    l.merged_w4 = merged_w4() ? 1 : 0;
+    return l;
+}
+
+long long filter_items(const FilterArgs &f) { return (long long)f.gx * f.gy; }
+
+// One registration with the launches to itself: the flow side of an iteration is merged into
+// as few launches as its scheme allows (what enqueue_flow does for eager launches):
+//   flow pass + xy build + both self passes + both self builds      -> kt_flow_build6
+//   flow pass + xy build + xx / yy filters (self passes afterwards) -> kt_flow_build3, kt_self2
+//   flow pass + xy build                                            -> kt_flow_build
+//   synchronous lists                                               -> kt_filter(_group), kt_process, kt_self2
+bool plan_lone(const std::vector<RecOp> &ops, Slot &slot, std::vector<TLaunch> &plan)
+{
+    plan.clear();
+    std::memset(&slot, 0, sizeof(slot));
+    slot.active = 1;
+    const long long fbmax = filter_blocks_cap();
+    FilterArgs f[3], build{}, ahead[2];
+    ProcessArgs flow{}, self[2];
+    int nf = 0, ns = 0, na = 0;
+    bool have_flow = false, have_build = false;
+    size_t at = 0;
+    for (; at < ops.size(); ++at) {   // the flow side: up to the first post / step launch
+        const RecOp &op = ops[at];
+        if (op.kind == RecOp::FILTER && op.mode == kFilterAhead && na < 2) ahead[na++] = op.f;
+        else if (op.kind == RecOp::FILTER && nf < 3) f[nf++] = op.f;
+        else if (op.kind == RecOp::PROCESS && (op.mode == PROC_FLOW || op.mode == kFlowBuild)) {
+            flow = op.p; have_flow = true;
+            if (op.mode == kFlowBuild) { build = op.f; have_build = true; }
+        } else if (op.kind == RecOp::PROCESS && op.mode == PROC_SELF && ns < 2) self[ns++] = op.p;
+        else break;
     }
-    ctx->graphs.clear();
+    int q = 0;
+    auto smem_of = [](int jt) { return (unsigned)filter_smem_bytes(jt); };
+    if (have_flow && have_build && ((na == 2 && ns == 2) || nf == 2)) {
+        const bool six = na == 2 && ns == 2;
+        OpArgs &o = slot.op[q];
+        o.p = flow; o.f = build;
+        o.f2[0] = six ? ahead[0] : f[0];
+        o.f2[1] = six ? ahead[1] : f[1];
+        if (six) { o.p2[0] = self[0]; o.p2[1] = self[1]; }
+        const long long cap = std::max<long long>(64, fbmax / 2);
+        o.np = std::max(8, flow.nblk);
+        o.n0 = (int)filter_grid_cap(filter_items(o.f), cap);
+        o.n1 = (int)filter_grid_cap(filter_items(o.f2[0]), cap);
+        o.n2 = (int)filter_grid_cap(filter_items(o.f2[1]), cap);
+        const int jt = std::max(o.f.jt, std::max(o.f2[0].jt, o.f2[1].jt));
+        plan.push_back(mk_launch(six ? TK_FLOW_BUILD6 : TK_FLOW_BUILD3, q,
+                                 (unsigned)((six ? 3 : 1) * o.np + o.n0 + o.n1 + o.n2), 1, smem_of(jt)));
+        ++q;
+        if (six) ns = 0;
+        nf = 0;
+    } else {
+        if (nf == 3) {
+            OpArgs &o = slot.op[q];
+            o.f = f[0]; o.f2[0] = f[1]; o.f2[1] = f[2];
+            const long long cap = std::max<long long>(64, fbmax / (2 * 3));
+            unsigned gx = 1; int jt = 0;
+            for (int i = 0; i < 3; ++i) { gx = std::max(gx, filter_grid_cap(filter_items(f[i]), cap)); jt = std::max(jt, f[i].jt); }
+            plan.push_back(mk_launch(TK_FILTER_GROUP, q, gx, 1, smem_of(jt)));
+            ++q;
+        } else {
+            for (int i = 0; i < nf; ++i) {
+                slot.op[q].f = f[i];
+                plan.push_back(mk_launch(TK_FILTER, q, filter_grid_cap(filter_items(f[i]), fbmax), 1, smem_of(f[i].jt)));
+                ++q;
+            }
+        }
+        if (have_flow && have_build) {
+            OpArgs &o = slot.op[q];
+            o.p = flow; o.f = build;
+            static const long long fb_div = [] { const char *e = getenv("CVO_HIP_BUILD_DIV"); return e ? std::max(1LL, atoll(e)) : 4LL; }();
+            const long long cap = std::max<long long>(64, 2 * fbmax / fb_div);
+            o.np = std::max(8, flow.nblk);
+            o.n0 = (int)std::max(8u, filter_grid_cap(filter_items(build), cap));
+            plan.push_back(mk_launch(TK_FLOW_BUILD, q, (unsigned)(o.np + o.n0), 1, smem_of(build.jt)));
+            ++q;
+        } else if (have_flow) {
+            slot.op[q].p = flow;
+            plan.push_back(mk_launch(flow.weight == 1 ? TK_FLOW_MATLAB : TK_FLOW, q, (unsigned)std::max(1, flow.nblk), 1));
+            ++q;
+        }
+    }
+    if (ns == 2) {
+        slot.op[q].p2[0] = self[0]; slot.op[q].p2[1] = self[1];
+        plan.push_back(mk_launch(TK_SELF2, q, (unsigned)std::max(self[0].nblk, self[1].nblk), 1));
+        ++q;
+    } else if (ns == 1) {
+        slot.op[q].p = self[0];
+        plan.push_back(mk_launch(TK_SELF, q, (unsigned)self[0].nblk, 1));
+        ++q;
+    }
+    for (; at < ops.size(); ++at) {   // the rest, one launch each
+        if (q >= MAX_OPS) return false;
+        const RecOp &op = ops[at];
+        OpArgs &o = slot.op[q];
+        if (op.kind == RecOp::POST_FLOW) { o.pf = op.pf; plan.push_back(mk_launch(TK_POST_FLOW, q, 1, 1)); }
+        else if (op.kind == RecOp::POST_STEP) { o.ps = op.ps; plan.push_back(mk_launch(TK_POST_STEP, q, 1, 1)); }
+        else if (op.kind == RecOp::PROCESS && op.mode == kProcStepTwist) {
+            o.p = op.p;
+            plan.push_back(mk_launch(TK_STEP_TWIST, q, (unsigned)std::max(8, std::max(32, op.p.nblk) / 4), 1));
+        } else if (op.kind == RecOp::PROCESS && op.mode == PROC_STEP) {
+            o.p = op.p;
+            plan.push_back(mk_launch(TK_STEP, q, (unsigned)std::max(1, op.p.nblk), 1));
+        } else return false;
+        ++q;
+    }
+    return q <= MAX_OPS;
 }
 
-// Launch one batch of kBatch iterations: through a cached graph when possible
-// (single rank, no per-launch HIP events, buffers already allocated), else eagerly.
+// A fused group: one launch per recorded launch, blockIdx.z = slot.  `ops[i]` = member i's
+// recorded iteration (all of the same shape), `slots[i]` its slot image; geometry = what
+// serves every member (zdim slots share the launch).
+bool plan_fused(const std::vector<const std::vector<RecOp> *> &ops, const std::vector<Slot *> &slots, int zdim,
+                std::vector<TLaunch> &plan)
+{
+    plan.clear();
+    if (ops.empty()) return true;
+    const size_t nq = ops[0]->size();
+    if (nq > (size_t)MAX_OPS) return false;
+    for (const auto *o : ops)
+        if (o->size() != nq) return false;
+    const long long fbmax = filter_blocks_cap();
+    static const long long fb_div = [] { const char *e = getenv("CVO_HIP_BUILD_DIV"); return e ? std::max(1LL, atoll(e)) : 4LL; }();
+    for (size_t q = 0; q < nq; ++q) {
+        const RecOp &first = (*ops[0])[q];
+        for (const auto *o : ops)
+            if ((*o)[q].kind != first.kind || (*o)[q].mode != first.mode) return false;
+        unsigned gx = 1, smem = 0;
+        int kernel = -1, np = 8;
+        unsigned nfb = 8;
+        for (size_t i = 0; i < ops.size(); ++i) {
+            const RecOp &op = (*ops[i])[q];
+            OpArgs &o = slots[i]->op[q];
+            switch (op.kind) {
+            case RecOp::FILTER: {
+                o.f = op.f;
+                kernel = TK_FILTER;
+                const long long cap = std::max<long long>(64, fbmax / (2 * zdim));
+                gx = std::max(gx, filter_grid_cap(filter_items(op.f), cap));
+                smem = std::max(smem, (unsigned)filter_smem_bytes(op.f.jt));
+                break;
+            }
+            case RecOp::PROCESS:
+                o.p = op.p;
+                if (op.mode == kProcStepTwist) {
+                    kernel = TK_STEP_TWIST;
+                    gx = std::max(gx, (unsigned)(std::max(32, op.p.nblk) / 4));
+                } else if (op.mode == kFlowBuild) {
+                    kernel = TK_FLOW_BUILD;
+                    o.f = op.f;
+                    const long long cap = std::max<long long>(64, 2 * fbmax / (fb_div * zdim));
+                    np = std::max(np, op.p.nblk);
+                    nfb = std::max(nfb, filter_grid_cap(filter_items(op.f), cap));
+                    smem = std::max(smem, (unsigned)filter_smem_bytes(op.f.jt));
+                } else {
+                    kernel = op.mode == PROC_FLOW ? (op.p.weight == 1 ? TK_FLOW_MATLAB : TK_FLOW)
+                                                  : (op.mode == PROC_STEP ? TK_STEP : TK_SELF);
+                    gx = std::max(gx, (unsigned)op.p.nblk);
+                }
+                break;
+            case RecOp::POST_FLOW: o.pf = op.pf; kernel = TK_POST_FLOW; break;
+            case RecOp::POST_STEP: o.ps = op.ps; kernel = TK_POST_STEP; break;
+            }
+        }
+        if (kernel == TK_FLOW_BUILD) {
+            gx = (unsigned)np + nfb;
+            for (Slot *sl : slots) { sl->op[q].np = np; sl->op[q].n0 = (int)nfb; }
+        }
+        plan.push_back(mk_launch(kernel, (int)q, gx, (unsigned)zdim, smem));
+    }
+    return true;
+}
+
+bool same_plan(const std::vector<TLaunch> &a, const std::vector<TLaunch> &b)
+{
+    return a.size() == b.size() && (a.empty() || std::memcmp(a.data(), b.data(), a.size() * sizeof(TLaunch)) == 0);
+}
+
+void launch_plan_eager(const Slot *tab, const std::vector<TLaunch> &plan, int iterations, hipStream_t s)
+{
+    for (int k = 0; k < iterations; ++k)
+        for (const TLaunch &l : plan) launch_table(tab, l, s);
+}
+
+// kBatch iterations of `plan` on table `tab`: through a cached graph when allowed, else eagerly.
+int run_plan(const Slot *tab, PlanCache &cache, const std::vector<TLaunch> &plan, hipStream_t s, bool use_graph)
+{
+    if (!use_graph || cache.fails >= 64) {
+        launch_plan_eager(tab, plan, kBatch, s);
+        return hipGetLastError() == hipSuccess ? CVO_HIP_OK : CVO_HIP_ERR_HIP;
+    }
+    PlanGraph *hit = nullptr;
+    for (auto &g : cache.graphs)
+        if (same_plan(g.plan, plan)) { hit = &g; break; }
+    if (hit) ++cache.hits;
+    if (!hit) {
+        ++cache.captures;
+        if (cache.graphs.size() >= 12) {   // evict the least recently used entry
+            size_t lru = 0;
+            for (size_t i = 1; i < cache.graphs.size(); ++i)
+                if (cache.graphs[i].stamp < cache.graphs[lru].stamp) lru = i;
+            if (cache.graphs[lru].exec) (void)hipGraphExecDestroy(cache.graphs[lru].exec);
+            if (cache.graphs[lru].graph) (void)hipGraphDestroy(cache.graphs[lru].graph);
+            cache.graphs.erase(cache.graphs.begin() + lru);
+        }
+        PlanGraph g;
+        g.plan = plan;
+        // A capture can be spoilt from outside (another thread's HIP work: cvo_lock.h).  Nothing
+        // has been launched then: the batch goes out eagerly and the next one tries again.
+        hipError_t e = hipErrorUnknown;
+        {
+            cvo_lock::Capture alone;   // (no other thread of this library is inside the runtime)
+            if (alone.ok && hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed) == hipSuccess) {
+                launch_plan_eager(tab, plan, kBatch, s);
+                e = hipStreamEndCapture(s, &g.graph);
+            }
+        }
+        if (e != hipSuccess || !g.graph || hipGraphInstantiate(&g.exec, g.graph, nullptr, nullptr, 0) != hipSuccess) {
+            if (g.graph) (void)hipGraphDestroy(g.graph);
+            (void)hipGetLastError();
+            ++cache.fails;
+            launch_plan_eager(tab, plan, kBatch, s);
+            return hipGetLastError() == hipSuccess ? CVO_HIP_OK : CVO_HIP_ERR_HIP;
+        }
+        cache.fails = 0;
+        cache.graphs.push_back(g);
+        hit = &cache.graphs.back();
+    }
+    hit->stamp = ++cache.clock;
+    return hipGraphLaunch(hit->exec, s) == hipSuccess ? CVO_HIP_OK : CVO_HIP_ERR_HIP;
+}
+
+hipStream_t loop_stream(const cvo_hip_ctx *ctx) { return ctx->loop_stream ? ctx->loop_stream : ctx->stream; }
+
+// Record the launches of ONE iteration of this context's align() (nothing is launched).
+int record_iteration(cvo_hip_ctx *ctx, std::vector<RecOp> &ops, int trace_cap)
+{
+    ops.clear();
+    ctx->rec = &ops;
+    const int rc = enqueue_iterations(ctx, 1, -1, trace_cap);
+    ctx->rec = nullptr;
+    return rc;
+}
+
+// The registration on its own table: (re)make its plan and slot, send the slot if it changed.
+// Called when an align() begins and when it resumes after a list grew (the arguments only
+// change then: buffers, sizes, parameters, trace).
+int prepare_lone_plan(cvo_hip_ctx *ctx, int trace_cap)
+{
+    if (ctx->table.init(1) != 0) return fail(ctx, CVO_HIP_ERR_NOMEM, "argument table allocation failed");
+    std::vector<RecOp> ops;
+    int rc = record_iteration(ctx, ops, trace_cap);
+    if (rc) return rc;
+    Slot slot;
+    if (!plan_lone(ops, slot, ctx->plan)) return fail(ctx, CVO_HIP_ERR_INVALID, "launch plan does not fit the argument table");
+    if (ctx->table.send(0, slot, loop_stream(ctx)) != 0) return fail(ctx, CVO_HIP_ERR_HIP, "argument table upload failed");
+    return CVO_HIP_OK;
+}
+
+// Launch one batch of kBatch iterations: through the context's table (graph or eager table
+// launches); profiling and the stream-level all-reduces (RCCL, caller's hook) keep the
+// classic by-value launches -- they need their own launches / host calls in between.
 int launch_batch(cvo_hip_ctx *ctx, int tag0, int trace_cap)
 {
-    const bool graphable = ctx->use_graphs && ctx->warm && !ctx->profiling && !host_reduce(ctx);
-    if (!graphable) {
+    if (ctx->profiling || host_reduce(ctx)) {
         const int rc = enqueue_iterations(ctx, kBatch, tag0, trace_cap);
         if (!rc) ctx->warm = true;
         return rc;
     }
-    const std::vector<uint64_t> key = graph_key(ctx, trace_cap);
-    GraphEntry *hit = nullptr;
-    for (auto &g : ctx->graphs)
-        if (g.key == key) { hit = &g; break; }
-    if (hit) ++ctx->graph_hits; else ++ctx->graph_misses;
-    if (!hit) {
-        if (ctx->graphs.size() >= 4) {   // evict the least recently used entry
-            size_t lru = 0;
-            for (size_t i = 1; i < ctx->graphs.size(); ++i)
-                if (ctx->graphs[i].stamp < ctx->graphs[lru].stamp) lru = i;
-            if (ctx->graphs[lru].exec) (void)hipGraphExecDestroy(ctx->graphs[lru].exec);
-            if (ctx->graphs[lru].graph) (void)hipGraphDestroy(ctx->graphs[lru].graph);
-            ctx->graphs.erase(ctx->graphs.begin() + lru);
-        }
-        GraphEntry g;
-        g.key = key;
-        // A capture can be spoilt from outside: another host thread working on ITS context (an
-        // allocation, a synchronisation) invalidates every capture in progress in this runtime,
-        // relaxed mode or not.  Nothing has been launched then: the batch goes out eagerly and
-        // the next one tries again.
-        int rc;
-        hipError_t e;
-        {
-            cvo_lock::Capture alone;   // (no other thread of this library is inside the runtime)
-            if (!alone.ok || hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeRelaxed) != hipSuccess) {
-                (void)hipGetLastError();
-                rc = -1;
-                e = hipErrorUnknown;
-            } else {
-                rc = enqueue_iterations(ctx, kBatch, -1, trace_cap);
-                e = hipStreamEndCapture(ctx->stream, &g.graph);
-            }
-        }
-        if (rc || e != hipSuccess || !g.graph) {
-            if (g.graph) (void)hipGraphDestroy(g.graph);
-            (void)hipGetLastError();
-            ctx->err.clear();
-            if (++ctx->graph_fail >= 64) ctx->use_graphs = false;
-            return enqueue_iterations(ctx, kBatch, tag0, trace_cap);
-        }
-        if (graph_key(ctx, trace_cap) != key) {
-            // something was (re)allocated while capturing: the capture is unusable
-            if (getenv("CVO_HIP_GRAPH_DEBUG")) {
-                const std::vector<uint64_t> k2 = graph_key(ctx, trace_cap);
-                for (size_t q = 0; q < key.size(); ++q)
-                    if (key[q] != k2[q]) fprintf(stderr, "[cvo_hip] graph key element %zu changed during capture\n", q);
-            }
-            (void)hipGraphDestroy(g.graph);
-            if (++ctx->graph_fail >= 64) ctx->use_graphs = false;   // (a buffer grew: normally a one-off)
-            return enqueue_iterations(ctx, kBatch, tag0, trace_cap);
-        }
-        if (hipGraphInstantiate(&g.exec, g.graph, nullptr, nullptr, 0) != hipSuccess) {
-            (void)hipGraphDestroy(g.graph);
-            (void)hipGetLastError();
-            if (++ctx->graph_fail >= 64) ctx->use_graphs = false;
-            return enqueue_iterations(ctx, kBatch, tag0, trace_cap);
-        }
-        ctx->graph_fail = 0;
-        ctx->graphs.push_back(g);
-        hit = &ctx->graphs.back();
-    }
-    hit->stamp = ++ctx->graph_clock;
-    HIP_TRY(ctx, hipGraphLaunch(hit->exec, ctx->stream));
+    const int rc = run_plan(ctx->table.dev, ctx->plans, ctx->plan, loop_stream(ctx), ctx->use_graphs);
+    if (rc) return fail(ctx, rc, "launching a batch of iterations failed");
     return CVO_HIP_OK;
 }
 
@@ -1169,8 +1427,9 @@ int cvo_hip_destroy(cvo_hip_ctx *ctx)
     if (ctx->comm_table) (void)hipFree(ctx->comm_table);
     if (ctx->mailbox) (void)hipFree(ctx->mailbox);
     if (getenv("CVO_HIP_GRAPH_DEBUG"))
-        fprintf(stderr, "[cvo_hip] graph cache: %lld hits, %lld captures\n", ctx->graph_hits, ctx->graph_misses);
+        fprintf(stderr, "[cvo_hip] graph cache: %lld hits, %lld captures\n", ctx->plans.hits, ctx->plans.captures);
     drop_graphs(ctx);
+    ctx->table.destroy();
     if (ctx->post_dbg) {
         long long h[8];
         if (hipMemcpy(h, ctx->post_dbg, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess && h[0] > 0)
@@ -1525,6 +1784,7 @@ struct AlignJob {
     int executed_base = 0;  // iterations completed before this round (after a list grew)
     int phase = 0;          // 0 enqueueing/polling, 1 waiting for the final state, 2 finished
     int rc = CVO_HIP_OK;
+    bool in_group = false;  // runs in a fused group (on the group's stream and table)
 };
 
 int job_begin(AlignJob &j)
@@ -1548,7 +1808,7 @@ int job_begin(AlignJob &j)
     }
     if (j.trace_cap > 0)
         HIP_TRY(ctx, hipMemsetAsync(ctx->trace_dev, 0, (size_t)j.trace_cap * sizeof(cvo_hip_trace),
-                                    ctx->stream));
+                                    loop_stream(ctx)));
     // initial device state
     DevState *h = &ctx->st_host[kPollSlots];
     std::memset(h, 0, sizeof(*h));
@@ -1560,7 +1820,7 @@ int job_begin(AlignJob &j)
     fill_filter_geometry(ctx, h);
     if (p.max_iter <= 0) h->done = DONE_MAX_ITER;
     // (everything but the mailbox sequence number, which lives as long as the context)
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->st, h, DEVSTATE_INIT_BYTES, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->st, h, DEVSTATE_INIT_BYTES, hipMemcpyHostToDevice, loop_stream(ctx)));
     // small clouds (the ~3k-point clouds of the reference's front end): 2048 waves do
     // (measured 3k x 3k: 2.11 ms with 512 blocks, 2.19 with 1024; 10k x 10k the other way round)
     if (!ctx->proc_blocks_forced)
@@ -1573,18 +1833,23 @@ int job_begin(AlignJob &j)
                      (double)ctx->fixed.n * (double)ctx->moving.n <= 2.0e8;
     ctx->use_async_self = ctx->use_async && ctx->allow_async_self && ctx->lone &&
                           ctx->prm.mode == CVO_HIP_MODE_ACVO;
-    launch_prepare(ctx->st, loop_params(ctx), ctx->stream);
+    launch_prepare(ctx->st, loop_params(ctx), loop_stream(ctx));
     HIP_TRY(ctx, hipGetLastError());
     ctx->have_tf = true;
     const int prc = prepare_buffers(ctx);
     if (prc) return prc;
+    // (a member of a fused group is planned by the group: its slot is one of many)
+    if (!j.in_group && !ctx->profiling && !host_reduce(ctx)) {
+        const int rc2 = prepare_lone_plan(ctx, j.trace_cap);
+        if (rc2) return rc2;
+    }
     j.enq = j.batches = j.checked = 0;
     j.executed_base = 0;
     j.phase = p.max_iter <= 0 ? 1 : 0;
     if (j.phase == 1) {
         HIP_TRY(ctx, hipMemcpyAsync(&ctx->st_host[0], ctx->st, sizeof(DevState), hipMemcpyDeviceToHost,
-                                    ctx->stream));
-        HIP_TRY(ctx, hipEventRecord(ctx->poll_ev[0], ctx->stream));
+                                    loop_stream(ctx)));
+        HIP_TRY(ctx, hipEventRecord(ctx->poll_ev[0], loop_stream(ctx)));
     }
     return CVO_HIP_OK;
 }
@@ -1708,6 +1973,10 @@ int job_pump(AlignJob &j, bool block)
     *ctx->done_mirror = 0;   // (the stream is idle: nothing can be writing it)
     launch_prepare(ctx->st, loop_params(ctx), ctx->stream);   // idempotent; re-zeroes the counters
     if (hipGetLastError() != hipSuccess) return finish_with(fail(ctx, CVO_HIP_ERR_HIP, "resume failed"));
+    if (!ctx->profiling && !host_reduce(ctx)) {   // the lists moved: new arguments
+        rc = prepare_lone_plan(ctx, j.trace_cap);
+        if (rc) return finish_with(rc);
+    }
     j.enq = j.batches = j.checked = 0;
     j.phase = 0;
     return 0;
@@ -1721,277 +1990,326 @@ int job_pump(AlignJob &j, bool block)
 // the launches at the next poll.
 bool fusable(const cvo_hip_ctx *c) { return !c->profiling && !multi_rank(c) && !(c->prm.color_scale > 0.0f); }
 
-// issue one iteration of all members, slot by slot
-void launch_fused(const std::vector<std::vector<RecOp>> &ops, hipStream_t s)
-{
-    const int n = (int)ops.size();
-    const size_t slots = ops[0].size();
-    FilterArgs f[MAXG]; ProcessArgs p[MAXG]; PostFlowArgs pf[MAXG]; PostStepArgs ps[MAXG];
-    for (size_t q = 0; q < slots; ++q) {
-        switch (ops[0][q].kind) {
-        case RecOp::FILTER:
-            for (int i = 0; i < n; ++i) f[i] = ops[i][q].f;
-            launch_filter_group(f, n, s);
-            break;
-        case RecOp::PROCESS:
-            for (int i = 0; i < n; ++i) p[i] = ops[i][q].p;
-            if (ops[0][q].mode == kProcStepTwist) {
-                launch_step_twist_group(p, n, s);
-            } else if (ops[0][q].mode == kFlowBuild) {
-                for (int i = 0; i < n; ++i) f[i] = ops[i][q].f;
-                launch_flow_build_group(p, f, n, s);
-            } else {
-                launch_process_group(ops[0][q].mode, p, n, s);
-            }
-            break;
-        case RecOp::POST_FLOW:
-            for (int i = 0; i < n; ++i) pf[i] = ops[i][q].pf;
-            launch_post_flow_group(pf, n, s);
-            break;
-        case RecOp::POST_STEP:
-            for (int i = 0; i < n; ++i) ps[i] = ops[i][q].ps;
-            launch_post_step_group(ps, n, s);
-            break;
-        }
-    }
-}
-
-// Streams of the fused groups: a few per device, created on first use and kept
-// for the life of the process.
-hipStream_t group_stream(int device, int slot)
-{
-    constexpr int kDev = 16, kSlots = 4;
-    static hipStream_t pool[kDev][kSlots] = {};
-    static std::mutex mu;
-    std::lock_guard<std::mutex> lock(mu);
-    if (device < 0 || device >= kDev) return nullptr;
-    slot = ((slot % kSlots) + kSlots) % kSlots;
-    if (!pool[device][slot] &&
-        hipStreamCreateWithFlags(&pool[device][slot], hipStreamNonBlocking) != hipSuccess)
-        pool[device][slot] = nullptr;
-    return pool[device][slot];
-}
-
-// A fused group as a resumable state machine, so that one host thread can keep
-// several groups (each on its own stream) in flight: while one group sits in its
-// single-block post kernels or between two kernels, the other one has the GPU.
-// Members: begun (job_begin), in phase 0, fusable, same device and mode, <= MAXG.
-struct FusedRun {
-    std::vector<AlignJob *> live;
-    std::vector<std::vector<RecOp>> ops;
-    hipStream_t s = nullptr;
+// A fused group as a long-lived engine: a stream, a table of MAXG slots and the batches
+// captured for it, all of which outlive the cvo_hip_align_many call that uses them.
+// Registrations enter a free slot and leave it when they stop -- by stream-ordered copies into
+// the table, between two batches of iterations: nothing is drained, nothing is captured again
+// (continuous batching).  Slots are kept packed at the low end; the launches serve
+// zdim = 1, 2, 4, 8 or 16 slots, the list kernels getting more blocks per registration the
+// fewer share the launch.  One host thread keeps several engines in flight: while one group
+// sits in its single-block post kernels or between two kernels, the other one has the GPU.
+struct Engine {
     int device = 0;
-    hipEvent_t ev[2] = {nullptr, nullptr};
-    int b = 0;          // batches launched since the arguments were recorded
-    int max_iter = 0;
-    enum { RECORD, LAUNCH, WAIT, SETTLE, DONE } state = RECORD;
-    hipGraph_t graph = nullptr;        // kBatch fused iterations, captured once per membership
-    hipGraphExec_t gexec = nullptr;
-    bool use_graph = true;             // (measured: a gain with <= 2 groups in flight, a loss with 4)
+    hipStream_t s = nullptr;
+    TableBuf tab;
+    PlanCache plans;
+    bool in_use = false;
 
-    void drop_graph()
+    // state of the call in progress
+    AlignJob *member[MAXG] = {};
+    std::vector<RecOp> ops[MAXG];
+    Slot slot[MAXG];
+    struct Retire { hipEvent_t ev = nullptr; std::vector<AlignJob *> jobs; };
+    std::vector<Retire> retiring;          // their final state is on its way to the host
+    hipEvent_t ev[4] = {};
+    long long launched = 0, checked = 0;   // batches
+    int zdim = 0;
+    bool crowded = true, use_graph = true, dirty = true, failed = false;
+    std::vector<TLaunch> plan;
+
+    int create(int dev)
     {
-        if (gexec) (void)hipGraphExecDestroy(gexec);
-        if (graph) (void)hipGraphDestroy(graph);
-        gexec = nullptr;
-        graph = nullptr;
+        device = dev;
+        if (hipSetDevice(dev) != hipSuccess) return -1;
+        if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) return -1;
+        if (tab.init(MAXG) != 0) return -1;
+        for (auto &e : ev)
+            if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return -1;
+        return 0;
     }
 
-    void fail_all(const char *msg)
-    {
-        for (AlignJob *j : live) { j->rc = fail(j->ctx, CVO_HIP_ERR_HIP, msg); j->phase = 2; }
-        live.clear();
-        state = DONE;
-    }
+    int live() const { int n = 0; for (AlignJob *j : member) n += j != nullptr; return n; }
+    bool idle() const { return live() == 0 && retiring.empty() && launched == checked; }
 
-    // slot: index of this group among the groups in flight; groups use library-owned
-    // streams (the members' streams may well share a hardware queue)
-    void start(const std::vector<AlignJob *> &jobs, int slot)
-    {
-        live = jobs;
-        device = jobs[0]->ctx->device;
-        if (hipSetDevice(device) != hipSuccess) return fail_all("hipSetDevice failed");
-        s = group_stream(device, slot);
-        if (!s) s = jobs[0]->ctx->stream;
-        // the members' uploads and initial states were queued on their own streams
-        for (AlignJob *j : live)
-            if (hipStreamSynchronize(j->ctx->stream) != hipSuccess) return fail_all("stream sync failed");
-        if (hipEventCreateWithFlags(&ev[0], hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&ev[1], hipEventDisableTiming) != hipSuccess)
-            return fail_all("hipEventCreate failed");
-        state = RECORD;
-    }
-
-    ~FusedRun()
-    {
-        drop_graph();
-        if (ev[0]) (void)hipEventDestroy(ev[0]);
-        if (ev[1]) (void)hipEventDestroy(ev[1]);
-    }
-
-    // Is it time to drain the queue and re-form the group?  A member that has finished costs
-    // next to nothing while it stays (its blocks return at their first load); taking it out
-    // costs a drained queue, new launch arguments and a new graph.  So the group is re-formed
-    // when half of it has finished (16 -> 8 -> 4 ...: a handful of times, not once per member),
-    // at once for a member that waits for a bigger list, and of course when all are through.
-    bool should_settle() const
-    {
-        static const bool eager = getenv("CVO_HIP_SETTLE_EAGER") != nullptr;
-        size_t stopped = 0;
-        for (AlignJob *j : live) {
-            const int32_t d = *(volatile int32_t *)j->ctx->done_mirror;
-            if (d == NEED_BIGGER_LIST) return true;
-            if (d != RUNNING) ++stopped;
-        }
-        if (eager) return stopped > 0;
-        return stopped > 0 && (2 * stopped >= live.size() || stopped == live.size());
-    }
-
-    // (re)record the launch arguments of the current members; the list kernels get
-    // fewer blocks per registration the more registrations share a launch
-    void record()
+    static int nblk_for(int z)
     {
         static const int budget = [] {   // blocks of a whole fused launch (tuning knob)
             const char *e = getenv("CVO_HIP_PROC_BUDGET");
             const int v = e ? atoi(e) : 2048;
             return v >= 64 ? v : 2048;
         }();
-        const int G = (int)live.size();
         // (a multiple of 32 that divides or is a multiple of NSUB: 64, 128, 256, 512, 1024)
         int nblk = 64;
-        while (nblk < PROC_BLOCKS && nblk * 2 <= budget / G) nblk *= 2;
-        ops.assign(live.size(), {});
-        for (size_t i = 0; i < live.size(); ++i) {
-            cvo_hip_ctx *c = live[i]->ctx;
-            c->rec = &ops[i];
-            c->proc_blocks = nblk;
-            // k_step_twist pays for the saved launch with a prologue in every block:
-            // a gain while launches are latency-bound, a loss once the GPU is full
-            const bool allow = c->allow_merge;
-            static const int merge_max = [] { const char *e = getenv("CVO_HIP_MERGE_MAXG"); return e ? atoi(e) : 2; }();
-            if (G > merge_max) c->allow_merge = false;
-            const int rc = enqueue_iterations(c, 1, -1, 0);
-            c->allow_merge = allow;
-            c->proc_blocks = c->proc_blocks_default;
-            c->rec = nullptr;
-            if (rc || ops[i].size() != ops[0].size()) return fail_all("fused launch recording failed");
-        }
-        max_iter = 0;
-        for (AlignJob *j : live) max_iter = std::max(max_iter, j->ctx->prm.max_iter);
-        b = 0;
-        state = LAUNCH;
-        // one graph launch per batch instead of 5-9 kernel launches per iteration: with
-        // several groups in flight the launching thread is the next bottleneck
-        drop_graph();
-        static const bool no_graph = getenv("CVO_HIP_NO_GRAPH") != nullptr;
-        if (use_graph && !no_graph) {
-            hipError_t e = hipErrorUnknown;
-            {
-                cvo_lock::Capture alone;
-                if (alone.ok && hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed) == hipSuccess) {
-                    for (int q = 0; q < kBatch; ++q) launch_fused(ops, s);
-                    e = hipStreamEndCapture(s, &graph);
-                }
-            }
-            if (e != hipSuccess || !graph || hipGraphInstantiate(&gexec, graph, nullptr, nullptr, 0) != hipSuccess)
-                drop_graph();
-            (void)hipGetLastError();
-        }
+        while (nblk < PROC_BLOCKS && nblk * 2 <= budget / std::max(1, z)) nblk *= 2;
+        return nblk;
     }
 
-    // somebody stopped: drain the queue, hand the finished members back, let the
-    // ones whose list overflowed grow it and rejoin
-    void settle()
+    void finish_job(AlignJob *j, int rc)
     {
-        if (hipStreamSynchronize(s) != hipSuccess) return fail_all("stream sync failed");
-        std::vector<AlignJob *> stopped, next;
-        for (AlignJob *j : live)
-            (*(volatile int32_t *)j->ctx->done_mirror != RUNNING ? stopped : next).push_back(j);
-        if (stopped.empty()) return fail_all("align loop ended without a verdict");
-        for (AlignJob *j : stopped)
-            if (hipMemcpyAsync(&j->ctx->st_host[0], j->ctx->st, sizeof(DevState), hipMemcpyDeviceToHost,
-                               s) != hipSuccess)
-                j->rc = fail(j->ctx, CVO_HIP_ERR_HIP, "state copy failed");
-        if (hipStreamSynchronize(s) != hipSuccess) return fail_all("stream sync failed");
-        for (AlignJob *j : stopped) {
-            cvo_hip_ctx *c = j->ctx;
-            if (j->rc) { j->phase = 2; continue; }
-            const DevState &cur = c->st_host[0];
-            if (cur.done != NEED_BIGGER_LIST) {
-                j->rc = job_finish(*j);
-                j->phase = 2;
-                continue;
-            }
-            int rc = CVO_HIP_OK;
-            for (int l = 0; l < LIST_N && !rc; ++l)
-                if (cur.cnt[2 * l + 1]) {
-                    uint32_t worst = 0;
-                    for (int qq = 0; qq < NSUB; ++qq) worst = std::max(worst, cur.sub[l][qq]);
-                    const double grown = std::min(
-                        4.0e9, std::max((double)worst * NSUB, (double)c->lists[l].cap) * 1.5 + 1024.0);
-                    rc = ensure_list(c, l, 0, 0, grown);
-                }
-            for (int q = 0; q < 3 && !rc; ++q) {   // the two buffers of a list share one capacity
-                const int la = q == 0 ? LIST_XY : (q == 1 ? LIST_XX : LIST_YY), lb = q == 0 ? LIST_XYB : (q == 1 ? LIST_XXB : LIST_YYB);
-                if (!c->lists[la].cap && !c->lists[lb].cap) continue;
-                const double both = (double)std::max(c->lists[la].cap, c->lists[lb].cap);
-                rc = ensure_list(c, la, 0, 0, both);
-                if (!rc && c->lists[lb].cap) rc = ensure_list(c, lb, 0, 0, both);
-            }
-            int32_t zero = 0;
-            if (!rc && (hipMemcpyAsync(reinterpret_cast<char *>(c->st) + offsetof(DevState, done), &zero,
-                                       sizeof(zero), hipMemcpyHostToDevice, s) != hipSuccess ||
-                        hipStreamSynchronize(s) != hipSuccess))
-                rc = fail(c, CVO_HIP_ERR_HIP, "resume failed");
-            if (rc) { j->rc = rc; j->phase = 2; continue; }
-            *c->done_mirror = 0;
-            j->executed_base = cur.k;
-            launch_prepare(c->st, loop_params(c), s);
-            next.push_back(j);
-        }
-        live.swap(next);
-        state = live.empty() ? DONE : RECORD;
+        j->rc = rc;
+        j->phase = 2;
+        j->in_group = false;
+        j->ctx->loop_stream = nullptr;
+        j->ctx->crowded = false;
+        j->ctx->lone = true;
+        j->ctx->proc_blocks = j->ctx->proc_blocks_default;
     }
 
-    // Advance as far as possible without (block = false) or with waiting on the GPU.
-    // Returns true if anything moved.
-    bool pump(bool block)
+    void fail_all(const char *msg, std::deque<AlignJob *> &pending)
+    {
+        failed = true;
+        (void)hipStreamSynchronize(s);
+        for (AlignJob *&j : member)
+            if (j) { finish_job(j, fail(j->ctx, CVO_HIP_ERR_HIP, msg)); j = nullptr; }
+        for (auto &r : retiring) {
+            for (AlignJob *j : r.jobs) finish_job(j, fail(j->ctx, CVO_HIP_ERR_HIP, msg));
+            if (r.ev) (void)hipEventDestroy(r.ev);
+        }
+        retiring.clear();
+        for (AlignJob *j : pending) { j->rc = fail(j->ctx, CVO_HIP_ERR_HIP, msg); j->phase = 2; }
+        pending.clear();
+        for (int z = 0; z < MAXG; ++z) { slot[z].active = 0; (void)tab.send(z, slot[z], s, 0); }
+        (void)hipStreamSynchronize(s);
+        launched = checked = 0;
+    }
+
+    // a job takes slot z: its align() begins (or resumes after its lists grew) on this stream
+    int insert(AlignJob *j, int z)
+    {
+        cvo_hip_ctx *c = j->ctx;
+        c->loop_stream = s;
+        c->crowded = crowded;
+        c->lone = false;
+        j->in_group = true;
+        int rc = CVO_HIP_OK;
+        if (j->phase == 3) {   // resuming: the state is where the overflow parked it
+            int32_t zero = 0;
+            std::memcpy(&c->st_host[kPollSlots].done, &zero, sizeof(zero));
+            if (hipMemcpyAsync(reinterpret_cast<char *>(c->st) + offsetof(DevState, done), &c->st_host[kPollSlots].done,
+                               sizeof(zero), hipMemcpyHostToDevice, s) != hipSuccess)
+                rc = fail(c, CVO_HIP_ERR_HIP, "resume failed");
+            *c->done_mirror = 0;
+            launch_prepare(c->st, loop_params(c), s);
+            j->phase = 0;
+        } else {
+            rc = job_begin(*j);
+        }
+        if (rc) { finish_job(j, rc); return rc; }
+        if (j->phase != 0) {   // max_iter <= 0: nothing to run; the state copy is already queued
+            Retire r;
+            if (hipEventCreateWithFlags(&r.ev, hipEventDisableTiming) != hipSuccess || hipEventRecord(r.ev, s) != hipSuccess) {
+                finish_job(j, fail(c, CVO_HIP_ERR_HIP, "event failed"));
+                return CVO_HIP_ERR_HIP;
+            }
+            r.jobs.push_back(j);
+            retiring.push_back(r);
+            return CVO_HIP_OK;
+        }
+        member[z] = j;
+        ops[z].clear();
+        dirty = true;
+        return CVO_HIP_OK;
+    }
+
+    // membership changed: pack the members into the low slots, pick zdim, (re)record what needs
+    // it, make the plan, send the slots that changed
+    int replan()
+    {
+        int n = 0;
+        for (int z = 0; z < MAXG; ++z)
+            if (member[z]) {
+                if (z != n) {
+                    member[n] = member[z]; member[z] = nullptr;
+                    ops[n].swap(ops[z]); ops[z].clear();
+                }
+                ++n;
+            }
+        int zd = 1;
+        while (zd < n) zd *= 2;
+        const bool regeom = zd != zdim;
+        zdim = zd;
+        const int nblk = nblk_for(zdim);
+        static const int merge_max = [] { const char *e = getenv("CVO_HIP_MERGE_MAXG"); return e ? atoi(e) : 2; }();
+        std::vector<const std::vector<RecOp> *> po;
+        std::vector<Slot *> ps;
+        for (int z = 0; z < n; ++z) {
+            cvo_hip_ctx *c = member[z]->ctx;
+            if (regeom || ops[z].empty()) {
+                c->proc_blocks = nblk;
+                // k_step_twist pays for the saved launch with a prologue in every block:
+                // a gain while launches are latency-bound, a loss once the GPU is full
+                const bool allow = c->allow_merge;
+                if (zdim > merge_max) c->allow_merge = false;
+                const int rc = record_iteration(c, ops[z], 0);
+                c->allow_merge = allow;
+                if (rc) return rc;
+            }
+            std::memset(&slot[z], 0, sizeof(Slot));
+            slot[z].active = 1;
+            po.push_back(&ops[z]);
+            ps.push_back(&slot[z]);
+        }
+        for (int z = n; z < MAXG; ++z) slot[z].active = 0;
+        if (!plan_fused(po, ps, zdim, plan)) return CVO_HIP_ERR_INVALID;
+        const int nq = n ? (int)ops[0].size() : 0;
+        for (int z = 0; z < MAXG; ++z)
+            if (tab.send(z, slot[z], s, z < n ? nq : 0) != 0) return CVO_HIP_ERR_HIP;
+        dirty = false;
+        return CVO_HIP_OK;
+    }
+
+    // members whose loop has stopped leave their slots; their final state starts for the host
+    void collect_stopped()
+    {
+        Retire r;
+        for (int z = 0; z < MAXG; ++z) {
+            AlignJob *j = member[z];
+            if (!j || *(volatile int32_t *)j->ctx->done_mirror == RUNNING) continue;
+            if (hipMemcpyAsync(&j->ctx->st_host[0], j->ctx->st, sizeof(DevState), hipMemcpyDeviceToHost, s) != hipSuccess) {
+                finish_job(j, fail(j->ctx, CVO_HIP_ERR_HIP, "state copy failed"));
+            } else {
+                r.jobs.push_back(j);
+            }
+            member[z] = nullptr;
+            ops[z].clear();
+            dirty = true;
+        }
+        if (r.jobs.empty()) return;
+        if (hipEventCreateWithFlags(&r.ev, hipEventDisableTiming) != hipSuccess || hipEventRecord(r.ev, s) != hipSuccess) {
+            for (AlignJob *j : r.jobs) finish_job(j, fail(j->ctx, CVO_HIP_ERR_HIP, "event failed"));
+            if (r.ev) (void)hipEventDestroy(r.ev);
+            return;
+        }
+        retiring.push_back(r);
+    }
+
+    // final states that have arrived: hand the registration back, or -- a list overflowed --
+    // enlarge it and queue the registration again (it resumes at the iteration it parked at)
+    bool finish_arrived(std::deque<AlignJob *> &pending, bool block)
     {
         bool moved = false;
-        for (;;) {
-            if (state == DONE) return moved;
-            if (hipSetDevice(device) != hipSuccess) { fail_all("hipSetDevice failed"); return true; }
-            if (state == RECORD) { record(); moved = true; continue; }
-            if (state == LAUNCH) {
-                if (gexec) {
-                    if (hipGraphLaunch(gexec, s) != hipSuccess) { fail_all("fused graph launch failed"); return true; }
-                } else {
-                    for (int q = 0; q < kBatch; ++q) launch_fused(ops, s);
+        while (!retiring.empty()) {
+            Retire &r = retiring.front();
+            const hipError_t q = block ? hipEventSynchronize(r.ev) : hipEventQuery(r.ev);
+            if (q == hipErrorNotReady) break;
+            block = false;
+            for (AlignJob *j : r.jobs) {
+                cvo_hip_ctx *c = j->ctx;
+                const DevState &cur = c->st_host[0];
+                if (q != hipSuccess) { finish_job(j, fail(c, CVO_HIP_ERR_HIP, "state event failed")); continue; }
+                if (cur.done != NEED_BIGGER_LIST) { finish_job(j, job_finish(*j)); continue; }
+                int rc = CVO_HIP_OK;
+                for (int l = 0; l < LIST_N && !rc; ++l)
+                    if (cur.cnt[2 * l + 1]) {
+                        uint32_t worst = 0;
+                        for (int qq = 0; qq < NSUB; ++qq) worst = std::max(worst, cur.sub[l][qq]);
+                        const double grown = std::min(
+                            4.0e9, std::max((double)worst * NSUB, (double)c->lists[l].cap) * 1.5 + 1024.0);
+                        rc = ensure_list(c, l, 0, 0, grown);
+                    }
+                for (int qq = 0; qq < 3 && !rc; ++qq) {   // the two buffers of a list share one capacity
+                    const int la = qq == 0 ? LIST_XY : (qq == 1 ? LIST_XX : LIST_YY), lb = qq == 0 ? LIST_XYB : (qq == 1 ? LIST_XXB : LIST_YYB);
+                    if (!c->lists[la].cap && !c->lists[lb].cap) continue;
+                    const double both = (double)std::max(c->lists[la].cap, c->lists[lb].cap);
+                    rc = ensure_list(c, la, 0, 0, both);
+                    if (!rc && c->lists[lb].cap) rc = ensure_list(c, lb, 0, 0, both);
                 }
-                if (hipGetLastError() != hipSuccess || hipEventRecord(ev[b & 1], s) != hipSuccess) {
-                    fail_all("fused launch failed");
-                    return true;
-                }
-                ++b;
-                moved = true;
-                if ((b + 1) * kBatch > max_iter + 4 * kBatch) { state = SETTLE; continue; }   // cannot happen
-                state = b >= 2 ? WAIT : LAUNCH;   // keep two batches queued, look one batch behind
-                continue;
+                if (rc) { finish_job(j, rc); continue; }
+                j->executed_base = cur.k;
+                j->phase = 3;   // resume
+                pending.push_front(j);
             }
-            if (state == WAIT) {
-                hipEvent_t e = ev[b & 1];   // batch b - 2: the older of the two in flight
-                const hipError_t q = block ? hipEventSynchronize(e) : hipEventQuery(e);
-                if (q == hipErrorNotReady) return moved;
-                if (q != hipSuccess) { fail_all("fused poll failed"); return true; }
-                moved = true;
-                block = false;   // waited once: the caller decides whom to wait for next
-                state = should_settle() ? SETTLE : LAUNCH;
-                continue;
+            (void)hipEventDestroy(r.ev);
+            retiring.erase(retiring.begin());
+            moved = true;
+        }
+        return moved;
+    }
+
+    // Advance as far as possible without waiting on the GPU.  `want` = how many members this
+    // engine should hold at most right now.  Returns true if anything moved.
+    bool pump(std::deque<AlignJob *> &pending, int want)
+    {
+        if (failed) return false;
+        if (hipSetDevice(device) != hipSuccess) { fail_all("hipSetDevice failed", pending); return true; }
+        bool moved = false;
+        // batches that have completed: look for members that stopped
+        while (checked < launched) {
+            const hipError_t q = hipEventQuery(ev[checked % 4]);
+            if (q == hipErrorNotReady) break;
+            if (q != hipSuccess) { fail_all("fused poll failed", pending); return true; }
+            ++checked;
+            collect_stopped();
+            moved = true;
+        }
+        if (finish_arrived(pending, false)) moved = true;
+        // free slots take the next registrations
+        while (!pending.empty() && live() < std::min(want, (int)MAXG)) {
+            AlignJob *j = pending.front();
+            pending.pop_front();
+            int z = 0;
+            while (member[z]) ++z;
+            insert(j, z);
+            moved = true;
+        }
+        // keep two batches queued, look one batch behind
+        while (live() > 0 && launched - checked < 2) {
+            if (dirty) {
+                const int rc = replan();
+                if (rc) { fail_all("fused launch recording failed", pending); return true; }
             }
-            if (state == SETTLE) { settle(); moved = true; continue; }
+            if (run_plan(tab.dev, plans, plan, s, use_graph) != CVO_HIP_OK ||
+                hipEventRecord(ev[launched % 4], s) != hipSuccess) {
+                fail_all("fused launch failed", pending);
+                return true;
+            }
+            ++launched;
+            moved = true;
+        }
+        if (live() == 0 && dirty && launched == checked) {   // the last members left: empty the table
+            if (replan() != CVO_HIP_OK) { fail_all("table update failed", pending); return true; }
+        }
+        return moved;
+    }
+
+    // block until the oldest thing in flight has completed
+    void wait_oldest(std::deque<AlignJob *> &pending)
+    {
+        if (checked < launched) {
+            if (hipEventSynchronize(ev[checked % 4]) != hipSuccess) fail_all("fused poll failed", pending);
+        } else if (!retiring.empty()) {
+            (void)hipEventSynchronize(retiring.front().ev);
         }
     }
 };
+
+// engines live for the life of the process (like their streams); a call borrows them
+std::mutex *engine_mutex()
+{
+    static std::mutex *mu = new std::mutex;   // (never destroyed: see cvo_lock.h)
+    return mu;
+}
+
+Engine *engine_checkout(int device)
+{
+    static std::vector<Engine *> *all = new std::vector<Engine *>();
+    std::lock_guard<std::mutex> lock(*engine_mutex());
+    for (Engine *e : *all)
+        if (!e->in_use && e->device == device && !e->failed) { e->in_use = true; return e; }
+    Engine *e = new (std::nothrow) Engine();
+    if (!e) return nullptr;
+    if (e->create(device) != 0) { (void)hipGetLastError(); delete e; return nullptr; }
+    e->in_use = true;
+    all->push_back(e);
+    return e;
+}
+
+void engine_release(Engine *e)
+{
+    std::lock_guard<std::mutex> lock(*engine_mutex());
+    e->launched = e->checked = 0;
+    e->in_use = false;
+}
 
 }   // namespace
 
@@ -2022,81 +2340,80 @@ int cvo_hip_align_many(cvo_hip_ctx **ctxs, cvo_hip_state **states, int *n_iters,
         jobs[i].n_iter = n_iters ? &n_iters[i] : nullptr;
     }
     int first_err = CVO_HIP_OK;
-    // Asynchronous xy builds shorten the launch chain of a registration; once the GPU is
-    // shared by many registrations the chain no longer matters and the extra builds cost
-    // more than they save: members of large fused groups keep the synchronous scheme.
-    static const bool no_fuse_env = getenv("CVO_HIP_NO_FUSE") != nullptr;
-    for (int i = 0; i < count; ++i) {
-        int peers = 0;
-        for (int k = 0; k < count; ++k)
-            if (fusable(jobs[k].ctx) && jobs[k].ctx->device == jobs[i].ctx->device &&
-                jobs[k].ctx->prm.mode == jobs[i].ctx->prm.mode)
-                ++peers;
-        static const int crowd = [] { const char *e = getenv("CVO_HIP_CROWD"); return e ? atoi(e) : 2; }();
-        jobs[i].ctx->crowded = !no_fuse_env && fusable(jobs[i].ctx) && peers > crowd;
-        jobs[i].ctx->lone = no_fuse_env || !fusable(jobs[i].ctx) || peers < 2 || count < 2;
-    }
-    for (int i = 0; i < count; ++i) {
-        const int rc = job_begin(jobs[i]);
-        jobs[i].ctx->crowded = false;
-        jobs[i].ctx->lone = true;
-        if (rc) { jobs[i].rc = rc; jobs[i].phase = 2; if (!first_err) first_err = rc; }
-    }
-    // fused groups: same device, same mode, nothing that needs its own launches;
-    // each group runs on its leader's stream, all groups are in flight together
+    std::vector<char> taken((size_t)count, 0);
+    // fused groups: same device, same mode, nothing that needs its own launches.  The jobs of
+    // a class wait in one queue; one or two engines (two from 8 jobs on: two groups fill each
+    // other's bubbles -- single-block post kernels, kernel boundaries) take them into their
+    // slots as slots become free.
     static const bool no_fuse = getenv("CVO_HIP_NO_FUSE") != nullptr;
     if (!no_fuse && count > 1) {
-        std::vector<char> taken((size_t)count, 0);
-        std::vector<std::unique_ptr<FusedRun>> runs;
         static const int gmax = [] {
             const char *e = getenv("CVO_HIP_GROUP");
             const int v = e ? atoi(e) : MAXG;
-            return std::min(MAXG, std::max(2, v));
+            return std::min((int)MAXG, std::max(2, v));
         }();
         for (int i = 0; i < count; ++i) {
             if (taken[i] || jobs[i].phase != 0 || !fusable(jobs[i].ctx)) continue;
-            std::vector<AlignJob *> cand;
+            std::deque<AlignJob *> pending;
             for (int k = i; k < count; ++k)
                 if (!taken[k] && jobs[k].phase == 0 && fusable(jobs[k].ctx) &&
                     jobs[k].ctx->device == jobs[i].ctx->device &&
                     jobs[k].ctx->prm.mode == jobs[i].ctx->prm.mode)
-                    cand.push_back(&jobs[k]);
-            if (cand.size() < 2) continue;
-            // split evenly into the fewest groups of at most gmax members, but at least
-            // two when there are enough members: two groups fill each other's bubbles
-            // (single-block post kernels, kernel boundaries)
-            size_t ngroups = (cand.size() + gmax - 1) / gmax;
-            if (ngroups < 2 && cand.size() >= 8) ngroups = 2;
-            size_t at = 0;
+                    pending.push_back(&jobs[k]);
+            if (pending.size() < 2) continue;
+            for (AlignJob *j : pending) taken[j - &jobs[0]] = 1;
+            const size_t total = pending.size();
+            size_t ngroups = (total + gmax - 1) / gmax;
+            if (ngroups < 2 && total >= 8) ngroups = 2;
+            ngroups = std::min<size_t>(ngroups, 2);
+            bool graphs_ok = true;   // (capture policy: cvo_hip_set_graph_capture)
+            for (AlignJob *j : pending) graphs_ok = graphs_ok && j->ctx->use_graphs;
+            // Asynchronous xy builds shorten the launch chain of a registration; once the GPU is
+            // shared by many registrations the chain no longer matters and the extra builds cost
+            // more than they save: members of large groups keep the synchronous scheme.
+            static const int crowd = [] { const char *e = getenv("CVO_HIP_CROWD"); return e ? atoi(e) : 2; }();
+            std::vector<Engine *> engines;
             for (size_t g = 0; g < ngroups; ++g) {
-                const size_t take = (cand.size() - at + (ngroups - g) - 1) / (ngroups - g);
-                std::vector<AlignJob *> grp(cand.begin() + at, cand.begin() + at + take);
-                at += take;
-                for (AlignJob *j : grp) taken[j - &jobs[0]] = 1;
-                if (grp.size() < 2) { taken[grp[0] - &jobs[0]] = 0; continue; }
-                runs.emplace_back(new FusedRun());
-                runs.back()->start(grp, (int)runs.size() - 1);
+                Engine *e = engine_checkout(jobs[i].ctx->device);
+                if (!e) break;
+                e->crowded = (int)total > crowd;
+                e->use_graph = graphs_ok;
+                e->zdim = 0;
+                e->dirty = true;
+                engines.push_back(e);
             }
-        }
-        for (auto &r : runs) {
-            r->use_graph = runs.size() <= 2;
-            for (AlignJob *j : r->live)   // (capture policy: cvo_hip_set_graph_capture)
-                if (!j->ctx->use_graphs) r->use_graph = false;
-        }
-        for (;;) {
-            bool any_live = false, moved = false;
-            for (auto &r : runs) {
-                if (r->state == FusedRun::DONE) continue;
-                if (r->pump(false)) moved = true;
-                if (r->state != FusedRun::DONE) any_live = true;
+            if (engines.empty()) {   // no engine to be had: the jobs run on their own below
+                for (AlignJob *j : pending) taken[j - &jobs[0]] = 0;
+                continue;
             }
-            if (!any_live) break;
-            if (!moved)   // everybody waits for the GPU: block on the first live group
-                for (auto &r : runs)
-                    if (r->state != FusedRun::DONE) { r->pump(true); break; }
+            // the first fill is even (16 + 16 of 32, 4 + 4 of 8); later a free slot takes the next job
+            const int share = std::min<int>(gmax, (int)((total + engines.size() - 1) / engines.size()));
+            for (;;) {
+                bool any = false, moved = false;
+                for (Engine *e : engines) {
+                    if (e->pump(pending, share)) moved = true;
+                    if (!e->idle()) any = true;
+                }
+                if (!any && pending.empty()) break;
+                bool alive = false;
+                for (Engine *e : engines) alive = alive || !e->failed;
+                if (!alive) break;
+                if (!moved)   // everybody waits for the GPU: block on the oldest thing in flight
+                    for (Engine *e : engines)
+                        if (!e->idle() && !e->failed) { e->wait_oldest(pending); break; }
+            }
+            for (Engine *e : engines) engine_release(e);
         }
         for (int i = 0; i < count; ++i)
             if (jobs[i].phase == 2 && jobs[i].rc && !first_err) first_err = jobs[i].rc;
+    }
+    // the others run on their own streams and tables
+    for (int i = 0; i < count; ++i) {
+        if (taken[i] || jobs[i].phase == 2) continue;
+        jobs[i].ctx->crowded = false;
+        jobs[i].ctx->lone = true;
+        const int rc = job_begin(jobs[i]);
+        if (rc) { jobs[i].rc = rc; jobs[i].phase = 2; if (!first_err) first_err = rc; }
     }
     // round-robin: every pass tops up each registration's queue and looks at its
     // poll word without blocking; when nobody moved, block on the oldest job
@@ -2232,8 +2549,8 @@ int cvo_hip_get_profile(cvo_hip_ctx *ctx, cvo_hip_profile *out, int reset)
 int cvo_hip_get_graph_stats(const cvo_hip_ctx *ctx, long long *launches_from_cache, long long *captures)
 {
     if (!ctx || !launches_from_cache || !captures) return CVO_HIP_ERR_INVALID;
-    *launches_from_cache = ctx->graph_hits;
-    *captures = ctx->graph_misses;
+    *launches_from_cache = ctx->plans.hits;
+    *captures = ctx->plans.captures;
     return CVO_HIP_OK;
 }
 

@@ -287,6 +287,34 @@ struct PostStepArgs {
     DevParams prm;
 };
 
+// ---------------------------------------------------------------------------
+// Argument tables.  The kernels of the align() loop do not take their argument blocks by
+// value: they take a pointer to an array of Slots in device memory and blockIdx.z selects the
+// slot; op[q] holds the arguments of the q-th launch of an iteration.  What this buys:
+//   * a captured batch of iterations (hipGraph) depends on the launch geometry only, not on
+//     any buffer address: it is captured once per table and shape and then serves every
+//     frame pair and every membership of a fused group -- a registration enters or leaves a
+//     running group by a stream-ordered copy into the table (continuous batching), no
+//     drained queue, no new capture;
+//   * the merged launches (flow pass + self passes + list builds in one grid) read only the
+//     fields of the role a block plays, when it needs them: no scalar-register spills.
+// An empty slot (active == 0) costs one scalar load per block.
+constexpr int MAX_OPS = 10;   // launches of one iteration (9 for acvo in a fused group: 3 filters, flow, 2 selfs, post, step, post)
+struct OpArgs {
+    FilterArgs f;             // FILTER; the xy build riding in a flow launch
+    FilterArgs f2[2];         // merged acvo launches: the xx / yy filters
+    ProcessArgs p;            // PROCESS; the flow pass of a merged launch
+    ProcessArgs p2[2];        // merged acvo launch: the two self passes
+    PostFlowArgs pf;
+    PostStepArgs ps;
+    int np, n0, n1, n2;       // merged launches: blocks of the roles
+};
+struct Slot {
+    int active;
+    int pad_[3];
+    OpArgs op[MAX_OPS];
+};
+
 CVO_HD KernConsts make_kconsts(const DevParams &p, float ell)
 {
     KernConsts k;
@@ -544,5 +572,20 @@ void launch_flow_build3(const ProcessArgs &flow, const FilterArgs &xy, const Fil
 void launch_flow_build6(const ProcessArgs &flow, const ProcessArgs &sxx, const ProcessArgs &syy,
                         const FilterArgs &xy, const FilterArgs &xx, const FilterArgs &yy, hipStream_t s);
 constexpr int STEP_TWIST_ROWS_DIV = 4;   // k_step_twist writes nblk / 4 partial rows
+
+// One launch of an iteration through a table: which kernel, its geometry, which op[] it reads.
+enum TKernel { TK_FILTER = 0, TK_FILTER_GROUP, TK_FLOW, TK_FLOW_MATLAB, TK_STEP, TK_SELF, TK_SELF2, TK_STEP_TWIST,
+               TK_FLOW_BUILD, TK_FLOW_BUILD3, TK_FLOW_BUILD6, TK_POST_FLOW, TK_POST_STEP };
+struct TLaunch {
+    int kernel;          // TKernel
+    int q;               // op index in the slots
+    unsigned gx, gz;     // grid.x, grid.z (= slots served)
+    unsigned smem;       // dynamic LDS bytes
+    int merged_w4;       // merged launches: the 4-waves-per-SIMD build (no register spills)
+};
+void launch_table(const Slot *tab, const TLaunch &l, hipStream_t s);
+// geometry helpers shared with the host (what the by-value launchers compute from their arguments)
+unsigned filter_grid_cap(long long nitems, long long cap);
+long long filter_blocks_cap();
 
 }   // namespace cvo_dev

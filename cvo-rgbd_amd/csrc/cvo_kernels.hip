@@ -114,8 +114,10 @@ __device__ __forceinline__ void filter_body(const FilterArgs &a, const unsigned 
     const int by_lo = (reg * a.gy + 7) / 8, by_hi = ((reg + 1) * a.gy + 7) / 8;   // tiles of this region
     const int nitems = (by_hi - by_lo) * a.gx;
     if (slot >= nitems) return;
+#ifdef CVO_FILTER_PROBE   // tools/microbench/filter_probe.hip: per-wave phase clocks (costs ~10 scalar registers)
     const long long t_start = a.dbg ? (long long)__builtin_readcyclecounter() : 0;
     const long long w_start = a.dbg ? (long long)wall_clock64() : 0;
+#endif
     // first round trip: the loop-control word, the state constants and this
     // thread's bounding spheres are all fetched before anything waits
     // (inside align() a list that is still valid is consumed again: nothing to do)
@@ -259,7 +261,9 @@ __device__ __forceinline__ void filter_body(const FilterArgs &a, const unsigned 
     unsigned sub = ((by * a.gx + bx) * 4u + (unsigned)wid) * 37u;
     const unsigned rbase = (unsigned)(row0 + wid * ROWS_PER_WAVE);
 
+#ifdef CVO_FILTER_PROBE
     const long long t_loop = a.dbg ? (long long)__builtin_readcyclecounter() : 0;
+#endif
     for (int g = 0; g < ngroups; ++g) {
         if ((g & 3) == 0 && ((mynear >> (g >> 2)) & 1u) == 0u) { g += 3; continue; }   // culled segment
         const float b = bop[g * 64 + lane];
@@ -304,13 +308,16 @@ __device__ __forceinline__ void filter_body(const FilterArgs &a, const unsigned 
             ne = 0;
         }
     }
+#ifdef CVO_FILTER_PROBE
     const long long t_tail = a.dbg ? (long long)__builtin_readcyclecounter() : 0;
+#endif
     if (ne > 0) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         flush_tiles(stage, ne, lane, ((sub & 31u) << 3) | region, a, out_list, out_tiles);
     }
+#ifdef CVO_FILTER_PROBE
     if (a.dbg && lane == 0) {   // probe: start, prologue end, loop end, exit clocks of every wave
         long long *o = a.dbg + ((size_t)(by * a.gx + bx) * 4 + wid) * 8;
         o[6] = w_start; o[7] = (long long)wall_clock64();   // 100 MHz constant clock
@@ -318,6 +325,7 @@ __device__ __forceinline__ void filter_body(const FilterArgs &a, const unsigned 
         o[4] = __builtin_amdgcn_s_getreg((31 << 11) | 4);    // HW_ID: wave slot, SIMD, CU, SE
         o[5] = __builtin_amdgcn_s_getreg((31 << 11) | 20);   // XCC_ID
     }
+#endif
     __syncthreads();   // the next item re-uses the LDS staging areas
     }   // live items
     __syncthreads();
@@ -864,9 +872,8 @@ k_flow_build(const Grp<ProcessArgs> gp, const Grp<BuildExtra> gx, const int np, 
 constexpr int STEP_BLOCK = 1024;
 constexpr int STEP_WAVES = STEP_BLOCK / 64;
 
-__global__ void __launch_bounds__(STEP_BLOCK) k_step_twist(const Grp<ProcessArgs> grp)
+__device__ __forceinline__ void step_twist_body(const ProcessArgs &a)
 {
-    const ProcessArgs &a = grp.a[blockIdx.z];
     const int nfat = a.nblk / (STEP_BLOCK / BLOCK);   // blocks of this registration
     if ((int)blockIdx.x >= nfat) return;
     constexpr int NACC = NACC_STEP;
@@ -997,6 +1004,11 @@ __global__ void __launch_bounds__(STEP_BLOCK) k_step_twist(const Grp<ProcessArgs
         for (int q = 0; q < STEP_WAVES; ++q) t += sh[q * NACC + tid];
         a.partials[(size_t)tid * nfat + blockIdx.x] = t;
     }
+}
+
+__global__ void __launch_bounds__(STEP_BLOCK) k_step_twist(const Grp<ProcessArgs> grp)
+{
+    step_twist_body(grp.a[blockIdx.z]);
 }
 
 void launch_step_twist_group(const ProcessArgs *a, int n, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop)
@@ -1284,9 +1296,8 @@ __device__ bool mailbox_allreduce(const CommTable &ct, DevState *gst, double *va
     return *sh_fail == 0;
 }
 
-__global__ void __launch_bounds__(BLOCK) k_post_flow(const Grp<PostFlowArgs> grp)
+__device__ __forceinline__ void post_flow_body(const PostFlowArgs &a)
 {
-    const PostFlowArgs &a = grp.a[blockIdx.z];
     __shared__ double sh[4 * NACC_MAX];
     __shared__ __attribute__((aligned(16))) DevState s_st;
     // One round trip: every thread fetches a word of the state's head into LDS;
@@ -1360,9 +1371,13 @@ __global__ void __launch_bounds__(BLOCK) k_post_flow(const Grp<PostFlowArgs> grp
     state_head_from_lds(&s_st, a.st);
 }
 
-__global__ void __launch_bounds__(BLOCK) k_post_step(const Grp<PostStepArgs> grp)
+__global__ void __launch_bounds__(BLOCK) k_post_flow(const Grp<PostFlowArgs> grp)
 {
-    const PostStepArgs &a = grp.a[blockIdx.z];
+    post_flow_body(grp.a[blockIdx.z]);
+}
+
+__device__ __forceinline__ void post_step_body(const PostStepArgs &a)
+{
     __shared__ double sh[4 * NACC_MAX];
     __shared__ __attribute__((aligned(16))) DevState s_st;
     const long long c0 = a.dbg ? (long long)__builtin_readcyclecounter() : 0;
@@ -1448,6 +1463,11 @@ __global__ void __launch_bounds__(BLOCK) k_post_step(const Grp<PostStepArgs> grp
     __syncthreads();
     if (threadIdx.x == 0 && a.done_mirror && s_st.done != RUNNING) *a.done_mirror = s_st.done;
     state_head_from_lds(&s_st, a.st);
+}
+
+__global__ void __launch_bounds__(BLOCK) k_post_step(const Grp<PostStepArgs> grp)
+{
+    post_step_body(grp.a[blockIdx.z]);
 }
 
 __device__ void post_step_math(DevState *st, const PostStepArgs &a)
@@ -1577,6 +1597,163 @@ void launch_post_step_group(const PostStepArgs *a, int n, hipStream_t s)
     Grp<PostStepArgs> g;
     for (int i = 0; i < n; ++i) g.a[i] = a[i];
     hipLaunchKernelGGL(k_post_step, dim3(1, 1, (unsigned)n), dim3(BLOCK), 0, s, g);
+}
+
+// ---------------------------------------------------------------------------
+// The same kernels reading their arguments from a table of Slots in device memory
+// (cvo_device.h "Argument tables"): blockIdx.z = slot, op[q] = this launch's arguments.
+// These are the kernels of the align() loop; the by-value forms above serve the low-level
+// entry points and the profiling mode.
+// The table is read through the CONSTANT address space: nothing writes it while a kernel runs
+// (the host updates it with stream-ordered copies between launches), so its fields are scalar,
+// invariant loads the compiler may issue late or repeat -- exactly what kernel arguments are.
+// (Through a plain global pointer the same kernels need ~30 more vector registers.)
+typedef const __attribute__((address_space(4))) Slot *CSlot;
+#define CVO_SLOT(tab)                          \
+    CSlot cs = (CSlot)(tab) + blockIdx.z;      \
+    if (cs->active == 0) return
+#define CVO_ARG(T, field) (*(const T *)(&cs->field))
+// which of the three filter argument blocks of op[q]: 0 the xy list, 1 / 2 the xx / yy lists
+#define CVO_FILTER_ROLE(role) (*(const FilterArgs *)((role) == 0 ? &cs->op[q].f : &cs->op[q].f2[(role) - 1]))
+
+__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(6, 8)))
+kt_filter(const Slot *__restrict__ tab, const int q)
+{
+    CVO_SLOT(tab);
+    filter_body(CVO_ARG(FilterArgs, op[q].f), blockIdx.x, gridDim.x);
+}
+
+// acvo, synchronous lists, one registration: the three filters in one launch (blockIdx.y = list)
+__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(6, 8)))
+kt_filter_group(const Slot *__restrict__ tab, const int q)
+{
+    CVO_SLOT(tab);
+    filter_body(CVO_FILTER_ROLE((int)blockIdx.y), blockIdx.x, gridDim.x);
+}
+
+template <int MODE, int WEIGHT = 0>
+__global__ void __launch_bounds__(BLOCK) kt_process(const Slot *__restrict__ tab, const int q)
+{
+    __shared__ __attribute__((aligned(16))) char scratch[PROC_SMEM];
+    CVO_SLOT(tab);
+    process_body<MODE, WEIGHT>(CVO_ARG(ProcessArgs, op[q].p), blockIdx.x, scratch);
+}
+
+// acvo, one registration: both self passes in one launch (blockIdx.y = xx / yy)
+__global__ void __launch_bounds__(BLOCK) kt_self2(const Slot *__restrict__ tab, const int q)
+{
+    __shared__ __attribute__((aligned(16))) char scratch[PROC_SMEM];
+    CVO_SLOT(tab);
+    process_body<PROC_SELF>(CVO_ARG(ProcessArgs, op[q].p2[blockIdx.y]), blockIdx.x, scratch);
+}
+
+__global__ void __launch_bounds__(STEP_BLOCK) kt_step_twist(const Slot *__restrict__ tab, const int q)
+{
+    CVO_SLOT(tab);
+    step_twist_body(CVO_ARG(ProcessArgs, op[q].p));
+}
+
+__global__ void __launch_bounds__(BLOCK) kt_post_flow(const Slot *__restrict__ tab, const int q)
+{
+    CVO_SLOT(tab);
+    post_flow_body(CVO_ARG(PostFlowArgs, op[q].pf));
+}
+
+__global__ void __launch_bounds__(BLOCK) kt_post_step(const Slot *__restrict__ tab, const int q)
+{
+    CVO_SLOT(tab);
+    post_step_body(CVO_ARG(PostStepArgs, op[q].ps));
+}
+
+// The merged launches (see k_flow_build, k_flow_build3, k_flow_build6): a block reads the
+// argument block of the role it plays.  Two builds each: 6 waves per SIMD (<= 80 registers: a few
+// spilled) and 4 (all in registers); CVO_HIP_MERGED_WAVES picks, profiles/ has the A/B.
+#define CVO_MERGED_KERNELS(SUFFIX, WAVES)                                                                  \
+    __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WAVES, 8)))               \
+    kt_flow_build##SUFFIX(const Slot *__restrict__ tab, const int q)                                       \
+    {                                                                                                      \
+        extern __shared__ __attribute__((aligned(16))) char smem[];                                        \
+        CVO_SLOT(tab);                                                                                     \
+        const int np = cs->op[q].np;                                                                       \
+        if ((int)blockIdx.x < np) {                                                                        \
+            process_body<PROC_FLOW>(CVO_ARG(ProcessArgs, op[q].p), blockIdx.x, smem);                      \
+            return;                                                                                        \
+        }                                                                                                  \
+        filter_body(CVO_ARG(FilterArgs, op[q].f), blockIdx.x - (unsigned)np, (unsigned)cs->op[q].n0);      \
+    }                                                                                                      \
+    __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WAVES, 8)))               \
+    kt_flow_build3##SUFFIX(const Slot *__restrict__ tab, const int q)                                      \
+    {                                                                                                      \
+        extern __shared__ __attribute__((aligned(16))) char smem[];                                        \
+        CVO_SLOT(tab);                                                                                     \
+        int b = (int)blockIdx.x;                                                                           \
+        const int np = cs->op[q].np, n0 = cs->op[q].n0, n1 = cs->op[q].n1, n2 = cs->op[q].n2;             \
+        if (b < np) {                                                                                      \
+            process_body<PROC_FLOW>(CVO_ARG(ProcessArgs, op[q].p), (unsigned)b, smem);                     \
+            return;                                                                                        \
+        }                                                                                                  \
+        b -= np;                                                                                           \
+        const int role = b < n0 ? 0 : (b < n0 + n1 ? 1 : 2);                                               \
+        filter_body(CVO_FILTER_ROLE(role), (unsigned)(b - (role == 0 ? 0 : (role == 1 ? n0 : n0 + n1))),   \
+                    (unsigned)(role == 0 ? n0 : (role == 1 ? n1 : n2)));                                   \
+    }                                                                                                      \
+    __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WAVES, 8)))               \
+    kt_flow_build6##SUFFIX(const Slot *__restrict__ tab, const int q)                                      \
+    {                                                                                                      \
+        extern __shared__ __attribute__((aligned(16))) char smem[];                                        \
+        CVO_SLOT(tab);                                                                                     \
+        int b = (int)blockIdx.x;                                                                           \
+        const int np = cs->op[q].np;                                                                       \
+        if (b < np) {                                                                                      \
+            process_body<PROC_FLOW>(CVO_ARG(ProcessArgs, op[q].p), (unsigned)b, smem);                     \
+            return;                                                                                        \
+        }                                                                                                  \
+        b -= np;                                                                                           \
+        if (b < 2 * np) {                                                                                  \
+            const int w = b >= np ? 1 : 0;                                                                 \
+            process_body<PROC_SELF>(CVO_ARG(ProcessArgs, op[q].p2[w]), (unsigned)(b - w * np), smem);      \
+            return;                                                                                        \
+        }                                                                                                  \
+        b -= 2 * np;                                                                                       \
+        const int n0 = cs->op[q].n0, n1 = cs->op[q].n1;                                                    \
+        const int role = b < n0 ? 0 : (b < n0 + n1 ? 1 : 2);                                               \
+        filter_body(CVO_FILTER_ROLE(role), (unsigned)(b - (role == 0 ? 0 : (role == 1 ? n0 : n0 + n1))),   \
+                    (unsigned)(role == 0 ? n0 : (role == 1 ? n1 : cs->op[q].n2)));                         \
+    }
+CVO_MERGED_KERNELS(_w6, 6)
+CVO_MERGED_KERNELS(_w4, 4)
+
+unsigned filter_grid_cap(long long nitems, long long cap) { return filter_grid_x(nitems, cap); }
+long long filter_blocks_cap() { return filter_blocks_max(); }
+
+void launch_table(const Slot *tab, const TLaunch &l, hipStream_t s)
+{
+    const dim3 g(l.gx, 1, l.gz);
+    switch (l.kernel) {
+    case TK_FILTER: hipLaunchKernelGGL(kt_filter, g, dim3(BLOCK), l.smem, s, tab, l.q); break;
+    case TK_FILTER_GROUP: hipLaunchKernelGGL(kt_filter_group, dim3(l.gx, 3, l.gz), dim3(BLOCK), l.smem, s, tab, l.q); break;
+    case TK_FLOW: hipLaunchKernelGGL(kt_process<PROC_FLOW>, g, dim3(BLOCK), 0, s, tab, l.q); break;
+    case TK_FLOW_MATLAB: hipLaunchKernelGGL((kt_process<PROC_FLOW, 1>), g, dim3(BLOCK), 0, s, tab, l.q); break;
+    case TK_STEP: hipLaunchKernelGGL(kt_process<PROC_STEP>, g, dim3(BLOCK), 0, s, tab, l.q); break;
+    case TK_SELF: hipLaunchKernelGGL(kt_process<PROC_SELF>, g, dim3(BLOCK), 0, s, tab, l.q); break;
+    case TK_SELF2: hipLaunchKernelGGL(kt_self2, dim3(l.gx, 2, l.gz), dim3(BLOCK), 0, s, tab, l.q); break;
+    case TK_STEP_TWIST: hipLaunchKernelGGL(kt_step_twist, g, dim3(STEP_BLOCK), 0, s, tab, l.q); break;
+    case TK_FLOW_BUILD:
+        if (l.merged_w4) hipLaunchKernelGGL(kt_flow_build_w4, g, dim3(BLOCK), l.smem, s, tab, l.q);
+        else hipLaunchKernelGGL(kt_flow_build_w6, g, dim3(BLOCK), l.smem, s, tab, l.q);
+        break;
+    case TK_FLOW_BUILD3:
+        if (l.merged_w4) hipLaunchKernelGGL(kt_flow_build3_w4, g, dim3(BLOCK), l.smem, s, tab, l.q);
+        else hipLaunchKernelGGL(kt_flow_build3_w6, g, dim3(BLOCK), l.smem, s, tab, l.q);
+        break;
+    case TK_FLOW_BUILD6:
+        if (l.merged_w4) hipLaunchKernelGGL(kt_flow_build6_w4, g, dim3(BLOCK), l.smem, s, tab, l.q);
+        else hipLaunchKernelGGL(kt_flow_build6_w6, g, dim3(BLOCK), l.smem, s, tab, l.q);
+        break;
+    case TK_POST_FLOW: hipLaunchKernelGGL(kt_post_flow, g, dim3(BLOCK), 0, s, tab, l.q); break;
+    case TK_POST_STEP: hipLaunchKernelGGL(kt_post_step, g, dim3(BLOCK), 0, s, tab, l.q); break;
+    default: break;
+    }
 }
 
 void launch_post_flow(const PostFlowArgs &a, hipStream_t s) { launch_post_flow_group(&a, 1, s); }

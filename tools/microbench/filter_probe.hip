@@ -3,6 +3,7 @@
 // with per-wave s_memtime stamps (FilterArgs::dbg).
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -I../../include
 //        -I../../cvo-rgbd_amd/csrc filter_probe.hip -o filter_probe
+#define CVO_FILTER_PROBE 1
 #include "../../cvo-rgbd_amd/csrc/cvo_kernels.hip"
 
 #include <algorithm>
