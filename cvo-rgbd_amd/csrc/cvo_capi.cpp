@@ -78,12 +78,12 @@ constexpr int kBatch = 6;        // iterations enqueued between two polls (measu
 // to MAXG for a fused group (cvo_hip_align_many).  The host keeps an image of what it last sent
 // per slot and sends a slot again only when its image changed -- through a small ring of
 // pinned staging buffers, ordered on the stream that runs the loop.
-constexpr int kStage = 8;
+constexpr int kStage = 4;
 struct TableBuf {
     Slot *dev = nullptr;
     int nslots = 0;
     std::vector<Slot> image;          // what the device holds (after the queued copies)
-    Slot *stage = nullptr;            // pinned [kStage]
+    Slot *stage = nullptr;            // pinned [kStage][nslots]
     hipEvent_t stage_ev[kStage] = {};
     bool stage_used[kStage] = {};
     int next = 0;
@@ -93,7 +93,7 @@ struct TableBuf {
         if (dev) return 0;
         if (hipMalloc((void **)&dev, (size_t)n * sizeof(Slot)) != hipSuccess) { dev = nullptr; return -1; }
         if (hipMemset(dev, 0, (size_t)n * sizeof(Slot)) != hipSuccess) return -1;
-        if (hipHostMalloc((void **)&stage, kStage * sizeof(Slot), hipHostMallocDefault) != hipSuccess) return -1;
+        if (hipHostMalloc((void **)&stage, (size_t)kStage * n * sizeof(Slot), hipHostMallocDefault) != hipSuccess) return -1;
         for (int i = 0; i < kStage; ++i)
             if (hipEventCreateWithFlags(&stage_ev[i], hipEventDisableTiming) != hipSuccess) return -1;
         nslots = n;
@@ -109,24 +109,34 @@ struct TableBuf {
         dev = nullptr; stage = nullptr; nslots = 0;
         image.clear();
     }
-    // slot z := want, as far as its first `nq` argument blocks go (no-op for what the device
-    // already holds; a change of `active` alone is a 16-byte copy); ordered on s
-    int send(int z, const Slot &want, hipStream_t s, int nq = MAX_OPS)
+    // Make the device hold want[0 .. nslots): as far as the first `nq` argument blocks of the
+    // ACTIVE slots and every slot's `active` flag go.  Whatever differs travels in ONE copy (the
+    // span from the first to the last slot that changed), ordered on s -- every copy is a stop of
+    // its own between two batches of the stream.
+    int sync(const Slot *want, hipStream_t s, int nq = MAX_OPS)
     {
-        Slot &img = image[(size_t)z];
         const size_t head = offsetof(Slot, op);
-        const size_t bytes = head + (size_t)nq * sizeof(OpArgs);
-        const bool ops_same = std::memcmp(img.op, want.op, (size_t)nq * sizeof(OpArgs)) == 0;
-        if (ops_same && std::memcmp(&img, &want, head) == 0) return 0;
-        const size_t n = ops_same ? head : bytes;
+        int lo = nslots, hi = -1;
+        for (int z = 0; z < nslots; ++z) {
+            const Slot &img = image[(size_t)z];
+            bool same = std::memcmp(&img, &want[z], head) == 0;
+            if (same && want[z].active) same = std::memcmp(img.op, want[z].op, (size_t)nq * sizeof(OpArgs)) == 0;
+            if (!same) { lo = std::min(lo, z); hi = z; }
+        }
+        if (hi < 0) return 0;
         const int b = next;
         next = (next + 1) % kStage;
         if (stage_used[b] && hipEventSynchronize(stage_ev[b]) != hipSuccess) return -1;   // (kStage copies ago)
-        std::memcpy(&stage[b], &want, n);
-        if (hipMemcpyAsync(&dev[z], &stage[b], n, hipMemcpyHostToDevice, s) != hipSuccess) return -1;
+        Slot *st = stage + (size_t)b * nslots;
+        const size_t n = (size_t)(hi - lo + 1);
+        for (int z = lo; z <= hi; ++z) {
+            if (want[z].active) image[(size_t)z] = want[z];
+            else image[(size_t)z].active = 0;   // (its argument blocks stay what they were: nobody reads them)
+            st[z] = image[(size_t)z];
+        }
+        if (hipMemcpyAsync(&dev[lo], &st[lo], n * sizeof(Slot), hipMemcpyHostToDevice, s) != hipSuccess) return -1;
         if (hipEventRecord(stage_ev[b], s) != hipSuccess) return -1;
         stage_used[b] = true;
-        std::memcpy(&img, &want, n);
         return 0;
     }
 };
@@ -995,32 +1005,36 @@ bool plan_lone(const std::vector<RecOp> &ops, Slot &slot, std::vector<TLaunch> &
     int q = 0;
     auto smem_of = [](int jt) { return (unsigned)filter_smem_bytes(jt); };
     if (have_flow && have_build && ((na == 2 && ns == 2) || nf == 2)) {
+        // (op[q]: flow pass + xy build; op[q + 1], op[q + 2]: the xx / yy filters and, `six`, the self passes)
         const bool six = na == 2 && ns == 2;
         OpArgs &o = slot.op[q];
         o.p = flow; o.f = build;
-        o.f2[0] = six ? ahead[0] : f[0];
-        o.f2[1] = six ? ahead[1] : f[1];
-        if (six) { o.p2[0] = self[0]; o.p2[1] = self[1]; }
+        for (int w = 0; w < 2; ++w) {
+            slot.op[q + 1 + w].f = six ? ahead[w] : f[w];
+            if (six) slot.op[q + 1 + w].p = self[w];
+        }
         const long long cap = std::max<long long>(64, fbmax / 2);
         o.np = std::max(8, flow.nblk);
         o.n0 = (int)filter_grid_cap(filter_items(o.f), cap);
-        o.n1 = (int)filter_grid_cap(filter_items(o.f2[0]), cap);
-        o.n2 = (int)filter_grid_cap(filter_items(o.f2[1]), cap);
-        const int jt = std::max(o.f.jt, std::max(o.f2[0].jt, o.f2[1].jt));
+        o.n1 = (int)filter_grid_cap(filter_items(slot.op[q + 1].f), cap);
+        o.n2 = (int)filter_grid_cap(filter_items(slot.op[q + 2].f), cap);
+        const int jt = std::max(o.f.jt, std::max(slot.op[q + 1].f.jt, slot.op[q + 2].f.jt));
         plan.push_back(mk_launch(six ? TK_FLOW_BUILD6 : TK_FLOW_BUILD3, q,
                                  (unsigned)((six ? 3 : 1) * o.np + o.n0 + o.n1 + o.n2), 1, smem_of(jt)));
-        ++q;
+        q += 3;
         if (six) ns = 0;
         nf = 0;
     } else {
         if (nf == 3) {
-            OpArgs &o = slot.op[q];
-            o.f = f[0]; o.f2[0] = f[1]; o.f2[1] = f[2];
             const long long cap = std::max<long long>(64, fbmax / (2 * 3));
             unsigned gx = 1; int jt = 0;
-            for (int i = 0; i < 3; ++i) { gx = std::max(gx, filter_grid_cap(filter_items(f[i]), cap)); jt = std::max(jt, f[i].jt); }
+            for (int i = 0; i < 3; ++i) {
+                slot.op[q + i].f = f[i];
+                gx = std::max(gx, filter_grid_cap(filter_items(f[i]), cap));
+                jt = std::max(jt, f[i].jt);
+            }
             plan.push_back(mk_launch(TK_FILTER_GROUP, q, gx, 1, smem_of(jt)));
-            ++q;
+            q += 3;
         } else {
             for (int i = 0; i < nf; ++i) {
                 slot.op[q].f = f[i];
@@ -1044,9 +1058,9 @@ bool plan_lone(const std::vector<RecOp> &ops, Slot &slot, std::vector<TLaunch> &
         }
     }
     if (ns == 2) {
-        slot.op[q].p2[0] = self[0]; slot.op[q].p2[1] = self[1];
+        slot.op[q].p = self[0]; slot.op[q + 1].p = self[1];
         plan.push_back(mk_launch(TK_SELF2, q, (unsigned)std::max(self[0].nblk, self[1].nblk), 1));
-        ++q;
+        q += 2;
     } else if (ns == 1) {
         slot.op[q].p = self[0];
         plan.push_back(mk_launch(TK_SELF, q, (unsigned)self[0].nblk, 1));
@@ -1216,7 +1230,7 @@ int prepare_lone_plan(cvo_hip_ctx *ctx, int trace_cap)
     if (rc) return rc;
     Slot slot;
     if (!plan_lone(ops, slot, ctx->plan)) return fail(ctx, CVO_HIP_ERR_INVALID, "launch plan does not fit the argument table");
-    if (ctx->table.send(0, slot, loop_stream(ctx)) != 0) return fail(ctx, CVO_HIP_ERR_HIP, "argument table upload failed");
+    if (ctx->table.sync(&slot, loop_stream(ctx)) != 0) return fail(ctx, CVO_HIP_ERR_HIP, "argument table upload failed");
     return CVO_HIP_OK;
 }
 
@@ -2016,6 +2030,9 @@ struct Engine {
     int zdim = 0;
     bool crowded = true, use_graph = true, dirty = true, failed = false;
     std::vector<TLaunch> plan;
+    // diagnostics (CVO_HIP_ENGINE_DEBUG)
+    long long n_batches[5] = {}, n_replans = 0, n_inserts = 0, n_sends = 0;
+    double t_replan = 0, t_insert = 0, t_launch = 0, t_finish = 0;
 
     int create(int dev)
     {
@@ -2068,7 +2085,8 @@ struct Engine {
         retiring.clear();
         for (AlignJob *j : pending) { j->rc = fail(j->ctx, CVO_HIP_ERR_HIP, msg); j->phase = 2; }
         pending.clear();
-        for (int z = 0; z < MAXG; ++z) { slot[z].active = 0; (void)tab.send(z, slot[z], s, 0); }
+        for (int z = 0; z < MAXG; ++z) slot[z].active = 0;
+        (void)tab.sync(slot, s, 0);
         (void)hipStreamSynchronize(s);
         launched = checked = 0;
     }
@@ -2111,28 +2129,29 @@ struct Engine {
         return CVO_HIP_OK;
     }
 
-    // membership changed: pack the members into the low slots, pick zdim, (re)record what needs
-    // it, make the plan, send the slots that changed
+    // membership changed: pick zdim (1, 2, 4, 8, 16 >= the members), bring the members that sit
+    // above it down into free slots (the others stay where they are: a slot that moves is a slot
+    // that has to be sent again), (re)record what needs it, make the plan, send what changed
     int replan()
     {
         int n = 0;
-        for (int z = 0; z < MAXG; ++z)
-            if (member[z]) {
-                if (z != n) {
-                    member[n] = member[z]; member[z] = nullptr;
-                    ops[n].swap(ops[z]); ops[z].clear();
-                }
-                ++n;
-            }
+        for (int z = 0; z < MAXG; ++z) n += member[z] != nullptr;
         int zd = 1;
         while (zd < n) zd *= 2;
+        for (int z = MAXG - 1, hole = 0; z >= zd; --z) {
+            if (!member[z]) continue;
+            while (member[hole]) ++hole;
+            member[hole] = member[z]; member[z] = nullptr;
+            ops[hole].swap(ops[z]); ops[z].clear();
+        }
         const bool regeom = zd != zdim;
         zdim = zd;
         const int nblk = nblk_for(zdim);
         static const int merge_max = [] { const char *e = getenv("CVO_HIP_MERGE_MAXG"); return e ? atoi(e) : 2; }();
         std::vector<const std::vector<RecOp> *> po;
         std::vector<Slot *> ps;
-        for (int z = 0; z < n; ++z) {
+        for (int z = 0; z < MAXG; ++z) {
+            if (!member[z]) { slot[z].active = 0; continue; }
             cvo_hip_ctx *c = member[z]->ctx;
             if (regeom || ops[z].empty()) {
                 c->proc_blocks = nblk;
@@ -2149,11 +2168,10 @@ struct Engine {
             po.push_back(&ops[z]);
             ps.push_back(&slot[z]);
         }
-        for (int z = n; z < MAXG; ++z) slot[z].active = 0;
         if (!plan_fused(po, ps, zdim, plan)) return CVO_HIP_ERR_INVALID;
-        const int nq = n ? (int)ops[0].size() : 0;
-        for (int z = 0; z < MAXG; ++z)
-            if (tab.send(z, slot[z], s, z < n ? nq : 0) != 0) return CVO_HIP_ERR_HIP;
+        const int nq = po.empty() ? 0 : (int)po[0]->size();
+        if (tab.sync(slot, s, nq) != 0) return CVO_HIP_ERR_HIP;
+        ++n_replans;
         dirty = false;
         return CVO_HIP_OK;
     }
@@ -2264,6 +2282,7 @@ struct Engine {
                 return true;
             }
             ++launched;
+            ++n_batches[zdim >= 16 ? 4 : (zdim >= 8 ? 3 : (zdim >= 4 ? 2 : (zdim >= 2 ? 1 : 0)))];
             moved = true;
         }
         if (live() == 0 && dirty && launched == checked) {   // the last members left: empty the table
@@ -2307,6 +2326,13 @@ Engine *engine_checkout(int device)
 void engine_release(Engine *e)
 {
     std::lock_guard<std::mutex> lock(*engine_mutex());
+    static const bool dbg = getenv("CVO_HIP_ENGINE_DEBUG") != nullptr;
+    if (dbg)
+        fprintf(stderr, "[cvo_hip] engine %p: batches at zdim 1/2/4/8/16: %lld %lld %lld %lld %lld, replans %lld, "
+                "graph captures %lld hits %lld\n", (void *)e, e->n_batches[0], e->n_batches[1], e->n_batches[2],
+                e->n_batches[3], e->n_batches[4], e->n_replans, e->plans.captures, e->plans.hits);
+    for (long long &v : e->n_batches) v = 0;
+    e->n_replans = 0;
     e->launched = e->checked = 0;
     e->in_use = false;
 }

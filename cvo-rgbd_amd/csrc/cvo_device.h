@@ -301,14 +301,18 @@ struct PostStepArgs {
 // An empty slot (active == 0) costs one scalar load per block.
 constexpr int MAX_OPS = 10;   // launches of one iteration (9 for acvo in a fused group: 3 filters, flow, 2 selfs, post, step, post)
 struct OpArgs {
-    FilterArgs f;             // FILTER; the xy build riding in a flow launch
-    FilterArgs f2[2];         // merged acvo launches: the xx / yy filters
     ProcessArgs p;            // PROCESS; the flow pass of a merged launch
-    ProcessArgs p2[2];        // merged acvo launch: the two self passes
-    PostFlowArgs pf;
-    PostStepArgs ps;
+    FilterArgs f;             // FILTER; the xy build riding in a flow launch
+    union {
+        PostFlowArgs pf;
+        PostStepArgs ps;
+    };
     int np, n0, n1, n2;       // merged launches: blocks of the roles
 };
+// Merged launches of a registration on its own take the argument blocks of their further roles
+// from the NEXT entries: op[q + 1], op[q + 2] hold the xx / yy filters (kt_filter_group,
+// kt_flow_build3, kt_flow_build6: .f) and the two self passes (kt_flow_build6: .p; kt_self2:
+// op[q], op[q + 1]).
 struct Slot {
     int active;
     int pad_[3];

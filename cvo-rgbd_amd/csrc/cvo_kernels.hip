@@ -1613,8 +1613,8 @@ typedef const __attribute__((address_space(4))) Slot *CSlot;
     CSlot cs = (CSlot)(tab) + blockIdx.z;      \
     if (cs->active == 0) return
 #define CVO_ARG(T, field) (*(const T *)(&cs->field))
-// which of the three filter argument blocks of op[q]: 0 the xy list, 1 / 2 the xx / yy lists
-#define CVO_FILTER_ROLE(role) (*(const FilterArgs *)((role) == 0 ? &cs->op[q].f : &cs->op[q].f2[(role) - 1]))
+// the filter argument block of role 0 (the xy list), 1, 2 (the xx / yy lists): op[q], op[q + 1], op[q + 2]
+#define CVO_FILTER_ROLE(role) (*(const FilterArgs *)(&cs->op[q + (role)].f))
 
 __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(6, 8)))
 kt_filter(const Slot *__restrict__ tab, const int q)
@@ -1644,7 +1644,7 @@ __global__ void __launch_bounds__(BLOCK) kt_self2(const Slot *__restrict__ tab, 
 {
     __shared__ __attribute__((aligned(16))) char scratch[PROC_SMEM];
     CVO_SLOT(tab);
-    process_body<PROC_SELF>(CVO_ARG(ProcessArgs, op[q].p2[blockIdx.y]), blockIdx.x, scratch);
+    process_body<PROC_SELF>(CVO_ARG(ProcessArgs, op[q + blockIdx.y].p), blockIdx.x, scratch);
 }
 
 __global__ void __launch_bounds__(STEP_BLOCK) kt_step_twist(const Slot *__restrict__ tab, const int q)
@@ -1711,7 +1711,7 @@ __global__ void __launch_bounds__(BLOCK) kt_post_step(const Slot *__restrict__ t
         b -= np;                                                                                           \
         if (b < 2 * np) {                                                                                  \
             const int w = b >= np ? 1 : 0;                                                                 \
-            process_body<PROC_SELF>(CVO_ARG(ProcessArgs, op[q].p2[w]), (unsigned)(b - w * np), smem);      \
+            process_body<PROC_SELF>(CVO_ARG(ProcessArgs, op[q + 1 + w].p), (unsigned)(b - w * np), smem);   \
             return;                                                                                        \
         }                                                                                                  \
         b -= 2 * np;                                                                                       \
