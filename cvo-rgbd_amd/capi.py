@@ -23,7 +23,7 @@ SYMBOLS = [
     "cvo_hip_transform_pcd", "cvo_hip_flow", "cvo_hip_step_coeffs", "cvo_hip_pick_step",
     "cvo_hip_exp_se3", "cvo_hip_dist_se3", "cvo_hip_align", "cvo_hip_align_many",
     "cvo_hip_function_inner_product", "cvo_hip_function_inner_product_clouds",
-    "cvo_hip_set_graph_capture", "cvo_hip_set_profiling", "cvo_hip_get_profile", "cvo_hip_get_graph_stats", "cvo_hip_synchronize",
+    "cvo_hip_get_wave_load", "cvo_hip_set_graph_capture", "cvo_hip_set_profiling", "cvo_hip_get_profile", "cvo_hip_get_graph_stats", "cvo_hip_synchronize",
 ]
 
 
@@ -126,6 +126,7 @@ def lib():
     L.cvo_hip_function_inner_product.argtypes = [vp, C.c_float, fp]
     L.cvo_hip_function_inner_product_clouds.argtypes = [vp, C.c_float, fp, fp, C.c_int, fp, fp, C.c_int,
                                                         C.c_int, fp]
+    L.cvo_hip_get_wave_load.argtypes = [vp, C.POINTER(C.c_uint32), C.c_int, C.POINTER(C.c_int)]
     L.cvo_hip_set_graph_capture.argtypes = [vp, C.c_int]
     L.cvo_hip_set_profiling.argtypes = [vp, C.c_int]
     L.cvo_hip_get_profile.argtypes = [vp, C.POINTER(Profile), C.c_int]
@@ -353,6 +354,13 @@ class Context:
             self._ctx, np.float32(ell), fptr(xyz_a), fptr(feat_a), xyz_a.shape[0], fptr(xyz_b), fptr(feat_b),
             xyz_b.shape[0], layout, C.byref(out)), "function_inner_product_clouds")
         return out.value
+
+    def wave_load(self):
+        """members of A kept by every wave of the last flow pass (diagnostics)."""
+        buf = (C.c_uint32 * 4096)()
+        n = C.c_int(0)
+        self._chk(self._L.cvo_hip_get_wave_load(self._ctx, buf, 4096, C.byref(n)), "wave_load")
+        return np.array(buf[:n.value], np.int64)
 
     def set_profiling(self, enable=True):
         self._chk(self._L.cvo_hip_set_profiling(self._ctx, int(bool(enable))), "set_profiling")

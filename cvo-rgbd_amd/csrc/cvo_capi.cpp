@@ -2544,6 +2544,20 @@ int cvo_hip_function_inner_product_clouds(cvo_hip_ctx *ctx, float ell, const flo
     return rc;
 }
 
+int cvo_hip_get_wave_load(cvo_hip_ctx *ctx, uint32_t *members_per_wave, int capacity, int *waves)
+{
+    cvo_lock::Api api_guard;
+    if (!ctx || !members_per_wave || !waves || capacity < 0) return CVO_HIP_ERR_INVALID;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const int n = std::min(capacity, 4 * ctx->proc_blocks);
+    *waves = 0;
+    if (!ctx->kept_cnt.p || n <= 0) return CVO_HIP_OK;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipMemcpy(members_per_wave, ctx->kept_cnt.p, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    *waves = n;
+    return CVO_HIP_OK;
+}
+
 int cvo_hip_set_graph_capture(cvo_hip_ctx *ctx, int enable)
 {
     cvo_lock::Api api_guard;

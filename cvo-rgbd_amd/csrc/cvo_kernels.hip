@@ -83,20 +83,37 @@ __device__ __forceinline__ bool spheres_near(const float4 sa, const float4 sb, f
     return d2 * 0.99999f <= rr * rr;
 }
 
-// append the wave's `n` staged tile entries to sub-list `sub` (exact-size slice)
-__device__ __forceinline__ void flush_tiles(const TileEntry *stage, int n, int lane, unsigned sub,
+// Append the wave's `n` staged tile entries (n <= TILE_STAGE) to the 32 sub-lists of its row
+// region, DEALT one by one: entry k goes to sub-list ((k + rot) & 31) * 8 + region.  Whole
+// flushes to one sub-list each -- the first version -- left the sub-lists of a 10k x 10k pair with
+// 2.6 (ell = 0.15) to 4.9 (ell = 0.03) times the mean load on the fullest one (a few flushes of up
+// to 128 entries per sub-list: Poisson), and the list kernels run as long as their fullest
+// block.  Lane j < 32 reserves the exact room of sub-list j with one returning atomic (32
+// distinct addresses: one wave instruction, as before).
+__device__ __forceinline__ void flush_tiles(const TileEntry *stage, int n, int lane, unsigned rot, unsigned region,
                                             const FilterArgs &a, int list, TileEntry *tiles)
 {
-    unsigned base = 0;
-    if (lane == 0) base = atomicAdd(&a.st->sub[list][sub], (unsigned)n);
-    base = __builtin_amdgcn_readfirstlane(base);
-    if (base + (unsigned)n <= a.subcap) {
-        const uint4 *src = reinterpret_cast<const uint4 *>(stage);
-        uint4 *dst = reinterpret_cast<uint4 *>(tiles + (size_t)sub * a.subcap + base);
-        for (int w = lane; w < n; w += 64) dst[w] = src[w];
-    } else if (lane == 0) {
-        atomicOr(&a.st->cnt[2 * list + 1], 1u);   // overflow: the host grows the list and resumes
+    unsigned base = 0, cnt = 0;
+    if (lane < 32) {
+        const unsigned k0 = ((unsigned)lane - rot) & 31u;   // the first staged entry that goes to sub-list `lane`
+        cnt = k0 < (unsigned)n ? ((unsigned)n - 1u - k0) / 32u + 1u : 0u;
+        if (cnt) base = atomicAdd(&a.st->sub[list][((unsigned)lane << 3) | region], cnt);
     }
+    bool over = false;
+    static_assert(TILE_STAGE <= 128, "two entries per lane");
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        // (the shuffle runs with every lane enabled: a disabled source lane would read as zero)
+        const int k = lane + 64 * h;
+        const unsigned j = ((unsigned)k + rot) & 31u;
+        const unsigned pos = (unsigned)__shfl((int)base, (int)j, 64) + ((unsigned)k >> 5);
+        if (k < n) {
+            if (pos < a.subcap) tiles[(size_t)((j << 3) | region) * a.subcap + pos] = stage[k];
+            else over = true;
+        }
+    }
+    if (__ballot(over) != 0ull && lane == 0)
+        atomicOr(&a.st->cnt[2 * list + 1], 1u);   // overflow: the host grows the list and resumes
 }
 
 __device__ __forceinline__ void filter_body(const FilterArgs &a, const unsigned bid, const unsigned nblocks)
@@ -303,7 +320,8 @@ __device__ __forceinline__ void filter_body(const FilterArgs &a, const unsigned 
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            flush_tiles(stage, ne, lane, (((sub++) & 31u) << 3) | region, a, out_list, out_tiles);
+            flush_tiles(stage, ne, lane, sub, region, a, out_list, out_tiles);
+            sub += (unsigned)ne;
             __builtin_amdgcn_wave_barrier();
             ne = 0;
         }
@@ -315,7 +333,7 @@ __device__ __forceinline__ void filter_body(const FilterArgs &a, const unsigned 
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        flush_tiles(stage, ne, lane, ((sub & 31u) << 3) | region, a, out_list, out_tiles);
+        flush_tiles(stage, ne, lane, sub, region, a, out_list, out_tiles);
     }
 #ifdef CVO_FILTER_PROBE
     if (a.dbg && lane == 0) {   // probe: start, prologue end, loop end, exit clocks of every wave
@@ -1639,6 +1657,16 @@ __global__ void __launch_bounds__(BLOCK) kt_process(const Slot *__restrict__ tab
     process_body<MODE, WEIGHT>(CVO_ARG(ProcessArgs, op[q].p), blockIdx.x, scratch);
 }
 
+// the flow pass held to 64 vector registers: 8 waves per SIMD, so that the 2048 blocks of a full
+// fused launch are all resident at once (with 74 registers 1536 are: the launch takes two rounds)
+__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8)))
+kt_flow_w8(const Slot *__restrict__ tab, const int q)
+{
+    __shared__ __attribute__((aligned(16))) char scratch[PROC_SMEM];
+    CVO_SLOT(tab);
+    process_body<PROC_FLOW, 0>(CVO_ARG(ProcessArgs, op[q].p), blockIdx.x, scratch);
+}
+
 // acvo, one registration: both self passes in one launch (blockIdx.y = xx / yy)
 __global__ void __launch_bounds__(BLOCK) kt_self2(const Slot *__restrict__ tab, const int q)
 {
@@ -1732,7 +1760,12 @@ void launch_table(const Slot *tab, const TLaunch &l, hipStream_t s)
     switch (l.kernel) {
     case TK_FILTER: hipLaunchKernelGGL(kt_filter, g, dim3(BLOCK), l.smem, s, tab, l.q); break;
     case TK_FILTER_GROUP: hipLaunchKernelGGL(kt_filter_group, dim3(l.gx, 3, l.gz), dim3(BLOCK), l.smem, s, tab, l.q); break;
-    case TK_FLOW: hipLaunchKernelGGL(kt_process<PROC_FLOW>, g, dim3(BLOCK), 0, s, tab, l.q); break;
+    case TK_FLOW: {
+        static const bool w8 = [] { const char *e = getenv("CVO_HIP_FLOW_WAVES"); return e && atoi(e) == 8; }();
+        if (w8 && l.gz > 2) hipLaunchKernelGGL(kt_flow_w8, g, dim3(BLOCK), 0, s, tab, l.q);
+        else hipLaunchKernelGGL(kt_process<PROC_FLOW>, g, dim3(BLOCK), 0, s, tab, l.q);
+        break;
+    }
     case TK_FLOW_MATLAB: hipLaunchKernelGGL((kt_process<PROC_FLOW, 1>), g, dim3(BLOCK), 0, s, tab, l.q); break;
     case TK_STEP: hipLaunchKernelGGL(kt_process<PROC_STEP>, g, dim3(BLOCK), 0, s, tab, l.q); break;
     case TK_SELF: hipLaunchKernelGGL(kt_process<PROC_SELF>, g, dim3(BLOCK), 0, s, tab, l.q); break;

@@ -263,6 +263,11 @@ int cvo_hip_set_graph_capture(cvo_hip_ctx *ctx, int enable);
 int cvo_hip_set_profiling(cvo_hip_ctx *ctx, int enable);
 int cvo_hip_get_profile(cvo_hip_ctx *ctx, cvo_hip_profile *out, int reset);
 
+/* Diagnostics: how evenly the last flow pass (cvo_hip_flow / the last iteration of align) spread
+ * the members of A over its wavefronts: members_per_wave[w] = pairs kept by wave w (4 waves per
+ * block, blocks in launch order); *waves = entries written (<= capacity). */
+int cvo_hip_get_wave_load(cvo_hip_ctx *ctx, uint32_t *members_per_wave, int capacity, int *waves);
+
 /* Blocks until everything queued on the context's stream has finished. */
 /* Diagnostics: batches of align() launched from a cached hipGraph / batches that had to be
  * captured first (a stream of frames should capture a handful of times, not per frame). */
