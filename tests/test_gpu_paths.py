@@ -695,3 +695,37 @@ def test_ranks_in_separate_processes_through_ipc_mailboxes(mode_name):
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "mailbox ipc world 2: OK" in r.stdout
+
+
+@pytest.mark.parametrize("graphs", [True, False])
+def test_align_many_refills_its_slots_from_the_queue(pkg, monkeypatch, graphs):
+    """Continuous batching: 44 registrations of very different lengths (max_iter 3 ... 60, sizes
+    300 ... 2400) in ONE call -- more than the two engines hold (2 x 16 slots), so slots are
+    refilled from the queue while their neighbours keep running; a tiny list start size makes some
+    of them park for a bigger list and resume on the way.  Every result equals the registration
+    run on its own, bit for bit; with captured batches and with eager table launches."""
+    import torch
+    capi = pkg.capi
+    monkeypatch.setenv("CVO_HIP_LIST_INIT", "30000")
+    rng = np.random.default_rng(12)
+    ctxs, ref, keep = [], [], []
+    for i in range(44):
+        n, m = int(rng.integers(300, 2400)), int(rng.integers(300, 2400))
+        xf, ff, xm, fm = pkg.data.synthetic_pair(n, m, seed=300 + i)
+        prm = capi.default_params(capi.MODE_CVO)
+        prm.max_iter = int(rng.choice([3, 7, 13, 25, 60, 2000]))
+        s = torch.cuda.Stream()
+        keep.append(s)
+        c = capi.Context(mode=prm.mode, device=0, stream=s.cuda_stream, params=prm, graph_capture=graphs)
+        c.set_fixed(xf, ff)
+        c.set_moving(xm, fm)
+        st = capi.init_state(c.params)
+        n_it, _ = c.align(st, trace_cap=0)
+        ref.append((n_it, bytes(st)))
+        ctxs.append(c)
+    for _ in range(2):
+        states = [capi.init_state(c.params) for c in ctxs]
+        its = capi.align_many(ctxs, states)
+        assert [(i, bytes(s)) for i, s in zip(its, states)] == ref
+    for c in ctxs:
+        c.close()
