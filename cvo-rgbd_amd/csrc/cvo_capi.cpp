@@ -1074,7 +1074,21 @@ bool plan_lone(const std::vector<RecOp> &ops, Slot &slot, std::vector<TLaunch> &
         else if (op.kind == RecOp::POST_STEP) { o.ps = op.ps; plan.push_back(mk_launch(TK_POST_STEP, q, 1, 1)); }
         else if (op.kind == RecOp::PROCESS && op.mode == kProcStepTwist) {
             o.p = op.p;
-            plan.push_back(mk_launch(TK_STEP_TWIST, q, (unsigned)std::max(8, std::max(32, op.p.nblk) / 4), 1));
+            // CVO_HIP_TAIL=1: the post-step maths rides in the same launch (last block to deliver:
+            // kt_step_twist_post).  Off by default: measured 36.4 vs 33.3 us per iteration at 10k x 10k
+            // (26.3 vs 24.4 at 3k x 3k) -- the release fence of every block plus the acquire of the last
+            // one cost more than the kernel boundary and the launch they save (profiles/r02_ab.txt)
+            static const bool tail = getenv("CVO_HIP_TAIL") != nullptr;
+            const bool fuse = tail && at + 2 == ops.size() && ops[at + 1].kind == RecOp::POST_STEP &&
+                              ops[at + 1].ps.comm == nullptr && q + 1 < MAX_OPS;
+            plan.push_back(mk_launch(fuse ? TK_STEP_TWIST_POST : TK_STEP_TWIST, q,
+                                     (unsigned)std::max(8, std::max(32, op.p.nblk) / 4), 1));
+            if (fuse) {
+                slot.op[q + 1].ps = ops[at + 1].ps;
+                q += 2;
+                at += 1;
+                continue;
+            }
         } else if (op.kind == RecOp::PROCESS && op.mode == PROC_STEP) {
             o.p = op.p;
             plan.push_back(mk_launch(TK_STEP, q, (unsigned)std::max(1, op.p.nblk), 1));

@@ -153,7 +153,7 @@ struct DevState {
     float xmax, y0max;          // max |x - center|, max |y0 - center| (bbox bounds)
     float tauf[3];
     int32_t n_fixed;            // points of the fixed cloud as the caller counts them (acvo Ayy rule);
-    int32_t n_rsv_;             // kernel arguments only carry the padded sizes (cvo_cloud.h)
+    uint32_t step_ticket;       // blocks of kt_step_twist_post that have delivered their partial sums
     // Tile-list re-use (plan_lists): list l was built with every pair closer than
     // list_r[l]; the xy list with the moving cloud at [list_Rt | list_t].
     float list_r[3];
@@ -578,7 +578,7 @@ void launch_flow_build6(const ProcessArgs &flow, const ProcessArgs &sxx, const P
 constexpr int STEP_TWIST_ROWS_DIV = 4;   // k_step_twist writes nblk / 4 partial rows
 
 // One launch of an iteration through a table: which kernel, its geometry, which op[] it reads.
-enum TKernel { TK_FILTER = 0, TK_FILTER_GROUP, TK_FLOW, TK_FLOW_MATLAB, TK_STEP, TK_SELF, TK_SELF2, TK_STEP_TWIST,
+enum TKernel { TK_FILTER = 0, TK_FILTER_GROUP, TK_FLOW, TK_FLOW_MATLAB, TK_STEP, TK_SELF, TK_SELF2, TK_STEP_TWIST, TK_STEP_TWIST_POST,
                TK_FLOW_BUILD, TK_FLOW_BUILD3, TK_FLOW_BUILD6, TK_POST_FLOW, TK_POST_STEP };
 struct TLaunch {
     int kernel;          // TKernel

@@ -890,10 +890,12 @@ k_flow_build(const Grp<ProcessArgs> gp, const Grp<BuildExtra> gx, const int np, 
 constexpr int STEP_BLOCK = 1024;
 constexpr int STEP_WAVES = STEP_BLOCK / 64;
 
-__device__ __forceinline__ void step_twist_body(const ProcessArgs &a)
+// returns true if this block delivered a row of step partial sums (false: the registration has
+// stopped, the slot is a stall, a list overflowed, or the block is surplus)
+__device__ __forceinline__ bool step_twist_body(const ProcessArgs &a)
 {
     const int nfat = a.nblk / (STEP_BLOCK / BLOCK);   // blocks of this registration
-    if ((int)blockIdx.x >= nfat) return;
+    if ((int)blockIdx.x >= nfat) return false;
     constexpr int NACC = NACC_STEP;
     __shared__ double sh[STEP_WAVES * NACC_MAX];
     __shared__ double tot[NACC_MAX + 4];
@@ -921,7 +923,7 @@ __device__ __forceinline__ void step_twist_body(const ProcessArgs &a)
     unsigned n = a.kept_cnt[wave];
     uint2 e = a.kept_ij[base + lane];
     float w = a.kept_a[base + lane];
-    if (done_word != 0) return;
+    if (done_word != 0) return false;
 
     // ---- the twist (ref cvo.cpp:201-209) from the partial sums
     wave_sums<NACC_FLOW>(pf, lane, sh + wid * NACC_MAX);
@@ -988,7 +990,7 @@ __device__ __forceinline__ void step_twist_body(const ProcessArgs &a)
             }
         }
     }
-    if (overflow) return;
+    if (overflow) return false;
     // the constants are the same for every lane: keep them in scalar registers
     cvo_math::XiConsts xc;
     {
@@ -1022,6 +1024,7 @@ __device__ __forceinline__ void step_twist_body(const ProcessArgs &a)
         for (int q = 0; q < STEP_WAVES; ++q) t += sh[q * NACC + tid];
         a.partials[(size_t)tid * nfat + blockIdx.x] = t;
     }
+    return true;
 }
 
 __global__ void __launch_bounds__(STEP_BLOCK) k_step_twist(const Grp<ProcessArgs> grp)
@@ -1681,16 +1684,55 @@ __global__ void __launch_bounds__(STEP_BLOCK) kt_step_twist(const Slot *__restri
     step_twist_body(CVO_ARG(ProcessArgs, op[q].p));
 }
 
+// kt_step_twist + k_post_step in one launch (ref src/cvo.cpp:291-307,380-410 follow the sums of
+// :213-289 without a kernel boundary).  Every block delivers its row of step partial sums, then
+// draws a ticket (release fence + one atomic); the block that draws the last one acquires, lets
+// go of all but its first four waves and runs the post-step maths (op[q + 1].ps) on the spot:
+// two dependent launches per iteration instead of three.  A stall slot (asynchronous builds: no
+// iteration executed, no partials) leaves the plan step to block 0.
+__global__ void __launch_bounds__(STEP_BLOCK) kt_step_twist_post(const Slot *__restrict__ tab, const int q)
+{
+    CVO_SLOT(tab);
+    __shared__ int s_last;
+    const ProcessArgs &a = CVO_ARG(ProcessArgs, op[q].p);
+    const bool ran = step_twist_body(a);
+    DevState *st = a.st;
+    if (!ran) {
+        // (block-uniform; `done` and `stall` were written by the previous launch)
+        if (!(blockIdx.x == 0 && a.async_xy && st->done == 0 && st->stall != 0)) return;
+    } else {
+        __syncthreads();   // (the row of partials is on its way)
+        if (threadIdx.x == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const unsigned nfat = (unsigned)(a.nblk / (STEP_BLOCK / BLOCK));
+            const unsigned t = __hip_atomic_fetch_add(&st->step_ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_last = t == nfat - 1u;
+            if (s_last) __hip_atomic_store(&st->step_ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+        if (!s_last) return;
+    }
+    if (threadIdx.x >= BLOCK) return;   // (waves that have ended no longer count at the barriers below)
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    const PostStepArgs ps = CVO_ARG(PostStepArgs, op[q + 1].ps);
+    post_step_body(ps);
+}
+
 __global__ void __launch_bounds__(BLOCK) kt_post_flow(const Slot *__restrict__ tab, const int q)
 {
     CVO_SLOT(tab);
-    post_flow_body(CVO_ARG(PostFlowArgs, op[q].pf));
+    // (the post kernels are one long dependent chain on one lane: their arguments are fetched once,
+    // up front, instead of where the chain first needs them)
+    const PostFlowArgs a = CVO_ARG(PostFlowArgs, op[q].pf);
+    post_flow_body(a);
 }
 
 __global__ void __launch_bounds__(BLOCK) kt_post_step(const Slot *__restrict__ tab, const int q)
 {
     CVO_SLOT(tab);
-    post_step_body(CVO_ARG(PostStepArgs, op[q].ps));
+    const PostStepArgs a = CVO_ARG(PostStepArgs, op[q].ps);
+    post_step_body(a);
 }
 
 // The merged launches (see k_flow_build, k_flow_build3, k_flow_build6): a block reads the
@@ -1771,6 +1813,7 @@ void launch_table(const Slot *tab, const TLaunch &l, hipStream_t s)
     case TK_SELF: hipLaunchKernelGGL(kt_process<PROC_SELF>, g, dim3(BLOCK), 0, s, tab, l.q); break;
     case TK_SELF2: hipLaunchKernelGGL(kt_self2, dim3(l.gx, 2, l.gz), dim3(BLOCK), 0, s, tab, l.q); break;
     case TK_STEP_TWIST: hipLaunchKernelGGL(kt_step_twist, g, dim3(STEP_BLOCK), 0, s, tab, l.q); break;
+    case TK_STEP_TWIST_POST: hipLaunchKernelGGL(kt_step_twist_post, g, dim3(STEP_BLOCK), 0, s, tab, l.q); break;
     case TK_FLOW_BUILD:
         if (l.merged_w4) hipLaunchKernelGGL(kt_flow_build_w4, g, dim3(BLOCK), l.smem, s, tab, l.q);
         else hipLaunchKernelGGL(kt_flow_build_w6, g, dim3(BLOCK), l.smem, s, tab, l.q);
