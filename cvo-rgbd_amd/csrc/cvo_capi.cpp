@@ -323,7 +323,7 @@ DevParams make_dev_params(const cvo_hip_params &p)
     d.dl_step = p.dl_step;
     d.color_scale = p.color_scale;
     // tile-list re-use (cvo_device.h plan_lists); CVO_HIP_LIST_MARGIN=0 rebuilds every iteration
-    d.build_at = 0.5f;
+    d.build_at = 0.7f;   // (measured 0.3 / 0.5 / 0.7: 1.80 / 1.77 / 1.73 ms per 10k x 10k registration)
     if (const char *e = getenv("CVO_HIP_BUILD_AT")) {
         const double m = atof(e);
         d.build_at = (m > 0.0 && m < 1.0) ? (float)m : d.build_at;
@@ -741,6 +741,13 @@ bool multi_rank(const cvo_hip_ctx *ctx) { return ctx->comm_table || ctx->comm ||
 DevParams loop_params(const cvo_hip_ctx *ctx)
 {
     DevParams dp = ctx->dprm;
+    // Width of the lists: a wider list is rebuilt less often but costs every flow pass more
+    // candidates ((1 + margin)^2).  Measured (profiles/r02_ab.txt): up to ~14k points a side, where a
+    // build is a large part of an iteration, 25 % beats 15 % (32 distinct 10k x 10k pairs 2273 ->
+    // 2398 registrations/s, one at a time 1.77 -> 1.71 ms); at 20k x 20k it loses (917 -> 792).
+    const bool margin_set = getenv("CVO_HIP_LIST_MARGIN") != nullptr;   // (then make_dev_params took it)
+    if (!margin_set)
+        dp.list_margin = ((double)ctx->fixed.n * (double)ctx->moving.n <= 2.0e8) ? 0.25f : 0.15f;
     dp.async_xy = ctx->use_async ? 1 : 0;
     dp.async_self = ctx->use_async_self ? 1 : 0;
     return dp;

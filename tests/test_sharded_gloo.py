@@ -1,8 +1,19 @@
-"""CPU, world_size 2, gloo: the row-sharded registration (target rows split
-over ranks, 13 + 4 float64 partial sums all-reduced twice per iteration --
-SURVEY 8e) gives the single-rank result.  The sharding/reduction protocol is
-exercised with the oracle's kernels; the HIP library runs the same protocol
-with RCCL (cvo_hip_comm_init) and is covered on the GPU by -m gpu tests."""
+"""CPU, world_size 2, gloo: what a CPU box can legitimately cover of the target-sharded mode.
+
+Covered here: the sharding CONTRACT -- rows split with the product's own cvo_hip_shard_range
+(a host function of libcvo_hip.so, no GPU needed), 13 + 4 float64 partial sums summed over the
+ranks twice per iteration, every rank running the O(1) maths on the reduced sums --
+gives the single-rank iteration count, the global nnz in every iteration, a transform within
+1e-6, and ranks that stay bit-identical.  The kernels under the contract are the ORACLE's (the
+HIP kernels need a GPU): this test says nothing about the HIP library's own exchange.
+
+Covered on the GPU (-m gpu): the HIP library's row shards add up (test_row_shards_add_up_to_the_whole),
+its in-kernel mailbox all-reduce with 2 and 4 real ranks on one device and with one process per
+rank over IPC handles (test_ranks_on_one_gpu_through_device_mailboxes,
+test_ranks_in_separate_processes_through_ipc_mailboxes), the RCCL and hook paths
+(test_rccl_world_size_one_and_user_hook, test_two_ranks_on_one_gpu_through_the_allreduce_hook), and
+BASELINE configs[3] at full size (tests/test_gpu_configs.py).  Only an 8-GPU node can show the
+peer stores crossing xGMI."""
 import os
 import socket
 
