@@ -2,16 +2,16 @@
 """bench.py -- frame-pair registrations/s of the CVO inner loop on MI355X.
 
 A "step" is one pass of the hot path over one BATCH of synthetic input: `--batch`
-(default 32) independent, DISTINCT frame pairs of the BASELINE.json configs[1] shape --
+(default 64) independent, DISTINCT frame pairs of the BASELINE.json configs[1] shape --
 synthetic 10k x 10k RGB-D clouds; pair 0 is the configs[1] pair itself (seed 20190402),
 pair i >= 1 has seed 1000 + i -- each run through a full align()
 (ref src/cvo.cpp:361-420: 43-102 gradient-flow iterations, each = transform + all-pairs
 neighbour filter + flow pass + step-size pass) from the reference object's initial state,
 all clouds already resident in HBM, all registrations of the batch handed to ONE
-cvo_hip_align_many call (groups of up to 16 registrations share every kernel launch,
-blockIdx.z = registration; the groups run on their own streams and fill each other's
-bubbles).  `value` = registrations completed per second.  Side legs of the same run
-(rank 0, N = 1; none of them inside the timed region): the same batch size with 32 copies of
+cvo_hip_align_many call (three engines of 16 slots each share the GPU; a slot's registration
+is one blockIdx.z slice of every kernel launch of its engine; a slot that falls free takes
+the next pair of the batch -- continuous batching).  `value` = registrations completed per second.  Side legs of the same run
+(rank 0, N = 1; none of them inside the timed region): the same batch size with copies of
 ONE pair (`identical_pairs`), one registration at a time (`single_stream`), kernel
 durations by HIP events for the roofline objects, BASELINE configs[4] per GPU
 (`config4`: 8 concurrent 20k x 20k), the RGB-D front end, and the CPU oracle timed on
@@ -52,7 +52,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--points", type=int, default=10000, help="N = M of the synthetic pairs")
-    ap.add_argument("--batch", type=int, default=32, help="frame pairs in flight per step")
+    ap.add_argument("--batch", type=int, default=64, help="frame pairs handed to one align_many call per step")
     ap.add_argument("--identical", action="store_true",
                     help="the timed batch is `--batch` copies of the configs[1] pair (round-1 behaviour)")
     ap.add_argument("--mode", default="cvo", choices=["cvo", "acvo"])
@@ -176,8 +176,8 @@ def main():
                 "pairs_per_sweep": float(n) * m,
                 "batch": B, "distinct_pairs": not args.identical,
                 "iterations_per_registration_min_max": [int(min(last_its)), int(max(last_its))],
-                "parallelism": "%d independent registrations in flight per GPU, fused in groups of <= 16 into "
-                               "shared kernel launches (blockIdx.z = registration), one stream per group" % B,
+                "parallelism": "%d registrations per align_many call per GPU: up to 3 engines x 16 slots share their "
+                               "kernel launches (blockIdx.z = slot), slots refilled from the batch as registrations stop" % B,
                 "graph_capture": "opted in (single-threaded process; default is eager on a caller's stream)",
             },
             "iterations_per_registration": iters_per_reg,

@@ -71,7 +71,11 @@ struct List {     // LIST_XY/XX/YY: TileEntry[cap] in a; LIST_KEPT: uint2[cap] i
     uint32_t cap = 0;   // entries, a multiple of NSUB
 };
 
-constexpr int kBatch = 6;        // iterations enqueued between two polls (measured: 4 -> 556, 6 -> 572, 8 -> 566, 12 -> 549 reg/s)
+// iterations enqueued between two polls (measured, one registration: 4 -> 556, 6 -> 572, 8 -> 566, 12 -> 549 reg/s)
+// ... and in a fused group, where a batch boundary is also where a slot that fell free is noticed and
+// refilled: shorter (64 distinct pairs: 3 -> 2857, 4 -> 2917, 6 -> 2693, 8 -> 2621 registrations/s)
+static const int kEngineBatch = [] { const char *e = getenv("CVO_HIP_ENGINE_BATCH"); const int v = e ? atoi(e) : 4; return v >= 1 && v <= 64 ? v : 4; }();
+static const int kBatch = [] { const char *e = getenv("CVO_HIP_BATCH"); const int v = e ? atoi(e) : 6; return v >= 1 && v <= 64 ? v : 6; }();
 
 // The kernels of the loop read their argument blocks from a table of Slots in device memory
 // (cvo_device.h "Argument tables"): one slot for a registration on its own (cvo_hip_align), up
@@ -88,11 +92,13 @@ struct TableBuf {
     bool stage_used[kStage] = {};
     int next = 0;
 
-    int init(int n)
+    // (s: the stream every later copy into the table is ordered on -- the zero fill must be too:
+    // a non-blocking stream does not wait for the null stream's memset)
+    int init(int n, hipStream_t s)
     {
         if (dev) return 0;
         if (hipMalloc((void **)&dev, (size_t)n * sizeof(Slot)) != hipSuccess) { dev = nullptr; return -1; }
-        if (hipMemset(dev, 0, (size_t)n * sizeof(Slot)) != hipSuccess) return -1;
+        if (hipMemsetAsync(dev, 0, (size_t)n * sizeof(Slot), s) != hipSuccess) return -1;
         if (hipHostMalloc((void **)&stage, (size_t)kStage * n * sizeof(Slot), hipHostMallocDefault) != hipSuccess) return -1;
         for (int i = 0; i < kStage; ++i)
             if (hipEventCreateWithFlags(&stage_ev[i], hipEventDisableTiming) != hipSuccess) return -1;
@@ -146,6 +152,7 @@ struct TableBuf {
 // serves every frame pair (and every membership of a fused group) of the same shape.
 struct PlanGraph {
     std::vector<TLaunch> plan;
+    int iterations = 0;
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
     uint64_t stamp = 0;
@@ -1181,15 +1188,16 @@ void launch_plan_eager(const Slot *tab, const std::vector<TLaunch> &plan, int it
 }
 
 // kBatch iterations of `plan` on table `tab`: through a cached graph when allowed, else eagerly.
-int run_plan(const Slot *tab, PlanCache &cache, const std::vector<TLaunch> &plan, hipStream_t s, bool use_graph)
+int run_plan(const Slot *tab, PlanCache &cache, const std::vector<TLaunch> &plan, hipStream_t s, bool use_graph,
+             int iterations)
 {
     if (!use_graph || cache.fails >= 64) {
-        launch_plan_eager(tab, plan, kBatch, s);
+        launch_plan_eager(tab, plan, iterations, s);
         return hipGetLastError() == hipSuccess ? CVO_HIP_OK : CVO_HIP_ERR_HIP;
     }
     PlanGraph *hit = nullptr;
     for (auto &g : cache.graphs)
-        if (same_plan(g.plan, plan)) { hit = &g; break; }
+        if (g.iterations == iterations && same_plan(g.plan, plan)) { hit = &g; break; }
     if (hit) ++cache.hits;
     if (!hit) {
         ++cache.captures;
@@ -1203,13 +1211,14 @@ int run_plan(const Slot *tab, PlanCache &cache, const std::vector<TLaunch> &plan
         }
         PlanGraph g;
         g.plan = plan;
+        g.iterations = iterations;
         // A capture can be spoilt from outside (another thread's HIP work: cvo_lock.h).  Nothing
         // has been launched then: the batch goes out eagerly and the next one tries again.
         hipError_t e = hipErrorUnknown;
         {
             cvo_lock::Capture alone;   // (no other thread of this library is inside the runtime)
             if (alone.ok && hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed) == hipSuccess) {
-                launch_plan_eager(tab, plan, kBatch, s);
+                launch_plan_eager(tab, plan, iterations, s);
                 e = hipStreamEndCapture(s, &g.graph);
             }
         }
@@ -1217,7 +1226,7 @@ int run_plan(const Slot *tab, PlanCache &cache, const std::vector<TLaunch> &plan
             if (g.graph) (void)hipGraphDestroy(g.graph);
             (void)hipGetLastError();
             ++cache.fails;
-            launch_plan_eager(tab, plan, kBatch, s);
+            launch_plan_eager(tab, plan, iterations, s);
             return hipGetLastError() == hipSuccess ? CVO_HIP_OK : CVO_HIP_ERR_HIP;
         }
         cache.fails = 0;
@@ -1245,7 +1254,7 @@ int record_iteration(cvo_hip_ctx *ctx, std::vector<RecOp> &ops, int trace_cap)
 // change then: buffers, sizes, parameters, trace).
 int prepare_lone_plan(cvo_hip_ctx *ctx, int trace_cap)
 {
-    if (ctx->table.init(1) != 0) return fail(ctx, CVO_HIP_ERR_NOMEM, "argument table allocation failed");
+    if (ctx->table.init(1, loop_stream(ctx)) != 0) return fail(ctx, CVO_HIP_ERR_NOMEM, "argument table allocation failed");
     std::vector<RecOp> ops;
     int rc = record_iteration(ctx, ops, trace_cap);
     if (rc) return rc;
@@ -1265,7 +1274,7 @@ int launch_batch(cvo_hip_ctx *ctx, int tag0, int trace_cap)
         if (!rc) ctx->warm = true;
         return rc;
     }
-    const int rc = run_plan(ctx->table.dev, ctx->plans, ctx->plan, loop_stream(ctx), ctx->use_graphs);
+    const int rc = run_plan(ctx->table.dev, ctx->plans, ctx->plan, loop_stream(ctx), ctx->use_graphs, kBatch);
     if (rc) return fail(ctx, rc, "launching a batch of iterations failed");
     return CVO_HIP_OK;
 }
@@ -1618,6 +1627,7 @@ int cvo_hip_mailbox_create(cvo_hip_ctx *ctx, int rank, int world, void *ipc_hand
     // sequence numbers restart with a new set of peers: empty the slots and the counter
     HIP_TRY(ctx, hipMemset(ctx->mailbox, 0, sizeof(Mailbox)));
     HIP_TRY(ctx, hipMemset(reinterpret_cast<char *>(ctx->st) + offsetof(DevState, mail_seq), 0, sizeof(unsigned long long)));
+    HIP_TRY(ctx, hipDeviceSynchronize());   // (null-stream fills: the context's stream does not wait for them by itself)
     ctx->mail_rank = rank;
     ctx->mail_world = world;
     if (ipc_handle_64) {
@@ -2060,7 +2070,7 @@ struct Engine {
         device = dev;
         if (hipSetDevice(dev) != hipSuccess) return -1;
         if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) return -1;
-        if (tab.init(MAXG) != 0) return -1;
+        if (tab.init(MAXG, s) != 0) return -1;
         for (auto &e : ev)
             if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return -1;
         return 0;
@@ -2297,7 +2307,7 @@ struct Engine {
                 const int rc = replan();
                 if (rc) { fail_all("fused launch recording failed", pending); return true; }
             }
-            if (run_plan(tab.dev, plans, plan, s, use_graph) != CVO_HIP_OK ||
+            if (run_plan(tab.dev, plans, plan, s, use_graph, kEngineBatch) != CVO_HIP_OK ||
                 hipEventRecord(ev[launched % 4], s) != hipSuccess) {
                 fail_all("fused launch failed", pending);
                 return true;
@@ -2410,9 +2420,13 @@ int cvo_hip_align_many(cvo_hip_ctx **ctxs, cvo_hip_state **states, int *n_iters,
             if (pending.size() < 2) continue;
             for (AlignJob *j : pending) taken[j - &jobs[0]] = 1;
             const size_t total = pending.size();
-            size_t ngroups = (total + gmax - 1) / gmax;
-            if (ngroups < 2 && total >= 8) ngroups = 2;
-            ngroups = std::min<size_t>(ngroups, 2);
+            // how many engines share the GPU: one group alone leaves it idle in its single-block post
+            // kernels and at every kernel boundary; two fill each other's bubbles (32 pairs: 1409 ->
+            // 2410 registrations/s); a third pays once there are enough jobs to keep three groups
+            // well filled (64 distinct pairs: 2345 -> 2940; 32: 11 per group, no gain); four lose
+            static const size_t max_engines = [] { const char *e = getenv("CVO_HIP_ENGINES"); const int v = e ? atoi(e) : 3; return (size_t)std::max(1, std::min(v, 8)); }();
+            size_t ngroups = total >= 40 ? 3 : (total >= 8 ? 2 : 1);
+            ngroups = std::max<size_t>(1, std::min(ngroups, max_engines));
             bool graphs_ok = true;   // (capture policy: cvo_hip_set_graph_capture)
             for (AlignJob *j : pending) graphs_ok = graphs_ok && j->ctx->use_graphs;
             // Asynchronous xy builds shorten the launch chain of a registration; once the GPU is
