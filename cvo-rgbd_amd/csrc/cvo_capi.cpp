@@ -565,6 +565,8 @@ int enqueue_filter(cvo_hip_ctx *ctx, int list, const Cloud &ca, int row_lo, int 
     a.tf_a = tf_a; a.tf_b = tf_b;
     a.check_done = check_done;
     a.gx = (int)pl.grid.x; a.gy = (int)pl.grid.y;
+    static const int deal_shift = [] { const char *e = getenv("CVO_HIP_DEAL_SHIFT"); const int v = e ? atoi(e) : 2; return v >= 0 && v <= 7 ? v : 2; }();   // runs of 4: 64-byte stores
+    a.deal_shift = deal_shift;
     const bool side = list == LIST_XY && ctx->in_loop && ctx->use_async;
     if (side) {   // build beside the flow pass, into the buffer the plan step named
         rc = ensure_list(ctx, LIST_XYB, 0, 0, (double)ctx->lists[LIST_XY].cap);

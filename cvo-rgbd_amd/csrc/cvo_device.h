@@ -221,6 +221,7 @@ struct FilterArgs {
     int tf_a, tf_b;        // apply [Rt|t] to the row / column cloud while staging
     int check_done;        // return at once when st->done != 0
     int gx, gy;            // this registration's own grid (a fused launch may be larger)
+    int deal_shift;        // tile entries are dealt over the sub-lists in runs of 1 << deal_shift (flush_tiles)
     long long *dbg;        // probe only (tools/microbench): per-wave phase clocks, else null
 };
 

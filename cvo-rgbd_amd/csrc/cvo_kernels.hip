@@ -83,30 +83,33 @@ __device__ __forceinline__ bool spheres_near(const float4 sa, const float4 sb, f
     return d2 * 0.99999f <= rr * rr;
 }
 
-// Append the wave's `n` staged tile entries (n <= TILE_STAGE) to the 32 sub-lists of its row
-// region, DEALT one by one: entry k goes to sub-list ((k + rot) & 31) * 8 + region.  Whole
-// flushes to one sub-list each -- the first version -- left the sub-lists of a 10k x 10k pair with
-// 2.6 (ell = 0.15) to 4.9 (ell = 0.03) times the mean load on the fullest one (a few flushes of up
-// to 128 entries per sub-list: Poisson), and the list kernels run as long as their fullest
-// block.  Lane j < 32 reserves the exact room of sub-list j with one returning atomic (32
-// distinct addresses: one wave instruction, as before).
+// Append the wave's `n` staged tile entries (n <= TILE_STAGE = 128) to the 32 sub-lists of its row
+// region, DEALT in runs of L = 1 << a.deal_shift entries: run c (entries cL .. cL+L-1) goes to
+// sub-list ((c + rot) & 31) * 8 + region.  Whole flushes to one sub-list each -- the first
+// version -- left the sub-lists of a 10k x 10k pair with 2.6 (ell = 0.15) to 4.9 (ell = 0.03)
+// times the mean load on the fullest one (a few flushes of up to 128 entries per sub-list:
+// Poisson), and the list kernels run as long as their fullest block.  Lane j < 32 reserves
+// the room of sub-list j with one returning atomic (32 distinct addresses: one wave
+// instruction, as before).
 __device__ __forceinline__ void flush_tiles(const TileEntry *stage, int n, int lane, unsigned rot, unsigned region,
                                             const FilterArgs &a, int list, TileEntry *tiles)
 {
-    unsigned base = 0, cnt = 0;
+    static_assert(TILE_STAGE <= 128, "two entries per lane");
+    const int sh = a.deal_shift, L = 1 << sh;
+    unsigned base = 0;
     if (lane < 32) {
-        const unsigned k0 = ((unsigned)lane - rot) & 31u;   // the first staged entry that goes to sub-list `lane`
-        cnt = k0 < (unsigned)n ? ((unsigned)n - 1u - k0) / 32u + 1u : 0u;
-        if (cnt) base = atomicAdd(&a.st->sub[list][((unsigned)lane << 3) | region], cnt);
+        int cnt = 0;
+        for (int c = (int)(((unsigned)lane - rot) & 31u); (c << sh) < n; c += 32) cnt += min(n - (c << sh), L);
+        if (cnt) base = atomicAdd(&a.st->sub[list][((unsigned)lane << 3) | region], (unsigned)cnt);
     }
     bool over = false;
-    static_assert(TILE_STAGE <= 128, "two entries per lane");
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         // (the shuffle runs with every lane enabled: a disabled source lane would read as zero)
         const int k = lane + 64 * h;
-        const unsigned j = ((unsigned)k + rot) & 31u;
-        const unsigned pos = (unsigned)__shfl((int)base, (int)j, 64) + ((unsigned)k >> 5);
+        const unsigned c = (unsigned)k >> sh;
+        const unsigned j = (c + rot) & 31u;
+        const unsigned pos = (unsigned)__shfl((int)base, (int)j, 64) + ((c >> 5) << sh) + ((unsigned)k & (unsigned)(L - 1));
         if (k < n) {
             if (pos < a.subcap) tiles[(size_t)((j << 3) | region) * a.subcap + pos] = stage[k];
             else over = true;
@@ -321,7 +324,7 @@ __device__ __forceinline__ void filter_body(const FilterArgs &a, const unsigned 
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             flush_tiles(stage, ne, lane, sub, region, a, out_list, out_tiles);
-            sub += (unsigned)ne;
+            sub += (unsigned)((ne + (1 << a.deal_shift) - 1) >> a.deal_shift);
             __builtin_amdgcn_wave_barrier();
             ne = 0;
         }
@@ -876,6 +879,7 @@ k_flow_build(const Grp<ProcessArgs> gp, const Grp<BuildExtra> gx, const int np, 
     f.check_done = a.check_done;
     f.gx = x.gx; f.gy = x.gy;
     f.dbg = nullptr;
+    f.deal_shift = 2;
     filter_body(f, blockIdx.x - (unsigned)np, (unsigned)nfb);
 }
 
