@@ -108,7 +108,9 @@ def grid_average(xyz, rgb, grid_size=0.05):
     rgbddataset_rkhs.m:36-39,58): one point per occupied voxel = the mean
     location and the mean colour (rounded to uint8) of its points.  Voxels are
     anchored at the cloud's minimum corner; MATLAB's own anchoring is not
-    documented ("f2"), so the output is equivalent, not identical.
+    documented, and no anchoring reproduces the transforms its run recorded better
+    than 2.8e-3 (tools/search_grid_anchor.py, tests/golden/grid_anchor_residuals.json;
+    DESIGN.md section 2), so the output is equivalent, not identical.
     Voxels come out in lexicographic (x, y, z) index order."""
     x = np.asarray(xyz, np.float64)
     c = np.asarray(rgb, np.float64)

@@ -150,3 +150,20 @@ def test_matlab_weight_in_the_c_restatement_tracks_float64(pkg, desk):
         # matlab_dense counts the iteration that breaks; the C loop reports executed bodies
         assert abs(n - k64) <= 1
         assert np.abs(T32 - T64).max() < 1e-4
+
+
+def test_no_grid_anchoring_explains_the_recorded_matlab_run():
+    """tools/search_grid_anchor.py scanned 130 anchorings of the 0.05 m box grid; its table is a
+    committed fixture.  The claim DESIGN.md makes of it -- under every variant the worst of the four
+    shipped pairs is 2.8e-3 .. 7.3e-3 from the recorded transform (a single pair comes as close as
+    4e-4 under one anchoring and is off again for the next pair), none pins the run -- is checked
+    against the table."""
+    import json
+    import os
+    d = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "grid_anchor_residuals.json")))
+    rows = d["table"]
+    assert len(rows) >= 130 and all(len(r["residual_per_pair"]) == 4 for r in rows)
+    worst = [max(r["residual_per_pair"]) for r in rows]
+    assert abs(min(worst) - d["best_worst_pair_residual"]) < 1e-12 and 2.5e-3 < min(worst) < 3e-3
+    assert max(worst) < 8e-3
+    assert not any(max(r["residual_per_pair"]) < 1.5e-3 for r in rows)
