@@ -23,7 +23,7 @@ SYMBOLS = [
     "cvo_hip_transform_pcd", "cvo_hip_flow", "cvo_hip_step_coeffs", "cvo_hip_pick_step",
     "cvo_hip_exp_se3", "cvo_hip_dist_se3", "cvo_hip_align", "cvo_hip_align_many",
     "cvo_hip_function_inner_product", "cvo_hip_function_inner_product_clouds",
-    "cvo_hip_get_wave_load", "cvo_hip_set_graph_capture", "cvo_hip_set_profiling", "cvo_hip_get_profile", "cvo_hip_get_graph_stats", "cvo_hip_synchronize",
+    "cvo_hip_engine_profiling", "cvo_hip_get_engine_profile", "cvo_hip_get_wave_load", "cvo_hip_set_graph_capture", "cvo_hip_set_profiling", "cvo_hip_get_profile", "cvo_hip_get_graph_stats", "cvo_hip_synchronize",
 ]
 
 
@@ -126,6 +126,8 @@ def lib():
     L.cvo_hip_function_inner_product.argtypes = [vp, C.c_float, fp]
     L.cvo_hip_function_inner_product_clouds.argtypes = [vp, C.c_float, fp, fp, C.c_int, fp, fp, C.c_int,
                                                         C.c_int, fp]
+    L.cvo_hip_engine_profiling.argtypes = [C.c_int]
+    L.cvo_hip_get_engine_profile.argtypes = [dp, C.POINTER(C.c_longlong), dp, C.c_int]
     L.cvo_hip_get_wave_load.argtypes = [vp, C.POINTER(C.c_uint32), C.c_int, C.POINTER(C.c_int)]
     L.cvo_hip_set_graph_capture.argtypes = [vp, C.c_int]
     L.cvo_hip_set_profiling.argtypes = [vp, C.c_int]
@@ -389,6 +391,17 @@ def align_many(contexts, states):
     its = (C.c_int * n)()
     check(lib().cvo_hip_align_many(arr_c, arr_s, its, n), what="align_many")
     return list(its)
+
+
+def engine_profiling(enable=True):
+    check(lib().cvo_hip_engine_profiling(int(bool(enable))), what="engine_profiling")
+
+
+def engine_profile(reset=True):
+    """(kernel ms, launches, registrations served) of the fused groups' flow-pass launches."""
+    ms, n, regs = C.c_double(), C.c_longlong(), C.c_double()
+    check(lib().cvo_hip_get_engine_profile(C.byref(ms), C.byref(n), C.byref(regs), int(reset)), what="engine_profile")
+    return ms.value, n.value, regs.value
 
 
 def comm_unique_id():

@@ -2037,6 +2037,21 @@ int job_pump(AlignJob &j, bool block)
 // the launches at the next poll.
 bool fusable(const cvo_hip_ctx *c) { return !c->profiling && !multi_rank(c) && !(c->prm.color_scale > 0.0f); }
 
+// Engine profiling (cvo_hip_engine_profiling): while it is on, the engines launch eagerly and every
+// flow-pass launch (kt_process<PROC_FLOW>, the kernel with the largest share of a batched run)
+// carries a HIP event pair; the sums are read with cvo_hip_get_engine_profile.
+struct EngineProfile {
+    std::mutex mu;
+    bool on = false;
+    double flow_ms = 0.0, flow_slots = 0.0;
+    long long flow_launches = 0;
+};
+EngineProfile *engine_profile()
+{
+    static EngineProfile *p = new EngineProfile;
+    return p;
+}
+
 // A fused group as a long-lived engine: a stream, a table of MAXG slots and the batches
 // captured for it, all of which outlive the cvo_hip_align_many call that uses them.
 // Registrations enter a free slot and leave it when they stop -- by stream-ordered copies into
@@ -2063,6 +2078,8 @@ struct Engine {
     int zdim = 0;
     bool crowded = true, use_graph = true, dirty = true, failed = false;
     std::vector<TLaunch> plan;
+    struct FlowEv { hipEvent_t a, b; int live; };
+    std::vector<FlowEv> flow_ev;           // engine profiling: one pair per flow-pass launch
     // diagnostics (CVO_HIP_ENGINE_DEBUG)
     long long n_batches[5] = {}, n_replans = 0, n_inserts = 0, n_sends = 0;
     double t_replan = 0, t_insert = 0, t_launch = 0, t_finish = 0;
@@ -2309,7 +2326,25 @@ struct Engine {
                 const int rc = replan();
                 if (rc) { fail_all("fused launch recording failed", pending); return true; }
             }
-            if (run_plan(tab.dev, plans, plan, s, use_graph, kEngineBatch) != CVO_HIP_OK ||
+            int rc_launch = CVO_HIP_OK;
+            if (engine_profile()->on) {   // eager, the flow-pass launches bracketed by events
+                for (int k = 0; k < kEngineBatch; ++k)
+                    for (const TLaunch &l : plan) {
+                        if (l.kernel == TK_FLOW) {
+                            FlowEv fe{nullptr, nullptr, live()};
+                            if (hipEventCreate(&fe.a) == hipSuccess && hipEventCreate(&fe.b) == hipSuccess) {
+                                launch_table(tab.dev, l, s, fe.a, fe.b);
+                                flow_ev.push_back(fe);
+                                continue;
+                            }
+                        }
+                        launch_table(tab.dev, l, s);
+                    }
+                if (hipGetLastError() != hipSuccess) rc_launch = CVO_HIP_ERR_HIP;
+            } else {
+                rc_launch = run_plan(tab.dev, plans, plan, s, use_graph, kEngineBatch);
+            }
+            if (rc_launch != CVO_HIP_OK ||
                 hipEventRecord(ev[launched % 4], s) != hipSuccess) {
                 fail_all("fused launch failed", pending);
                 return true;
@@ -2358,6 +2393,19 @@ Engine *engine_checkout(int device)
 
 void engine_release(Engine *e)
 {
+    if (!e->flow_ev.empty()) {   // (the engine is idle: every event has completed)
+        EngineProfile *pr = engine_profile();
+        std::lock_guard<std::mutex> plock(pr->mu);
+        for (auto &fe : e->flow_ev) {
+            float ms = 0.f;
+            if (hipEventSynchronize(fe.b) == hipSuccess && hipEventElapsedTime(&ms, fe.a, fe.b) == hipSuccess) {
+                pr->flow_ms += ms; pr->flow_launches++; pr->flow_slots += fe.live;
+            }
+            (void)hipEventDestroy(fe.a);
+            (void)hipEventDestroy(fe.b);
+        }
+        e->flow_ev.clear();
+    }
     std::lock_guard<std::mutex> lock(*engine_mutex());
     static const bool dbg = getenv("CVO_HIP_ENGINE_DEBUG") != nullptr;
     if (dbg)
@@ -2579,6 +2627,24 @@ int cvo_hip_function_inner_product_clouds(cvo_hip_ctx *ctx, float ell, const flo
     std::swap(ctx->moving, ctx->scratch_b);
     ctx->have_tf = had_tf;
     return rc;
+}
+
+int cvo_hip_engine_profiling(int enable)
+{
+    EngineProfile *pr = engine_profile();
+    std::lock_guard<std::mutex> lock(pr->mu);
+    pr->on = enable != 0;
+    return CVO_HIP_OK;
+}
+
+int cvo_hip_get_engine_profile(double *flow_ms, long long *flow_launches, double *flow_registrations, int reset)
+{
+    if (!flow_ms || !flow_launches || !flow_registrations) return CVO_HIP_ERR_INVALID;
+    EngineProfile *pr = engine_profile();
+    std::lock_guard<std::mutex> lock(pr->mu);
+    *flow_ms = pr->flow_ms; *flow_launches = pr->flow_launches; *flow_registrations = pr->flow_slots;
+    if (reset) { pr->flow_ms = 0.0; pr->flow_launches = 0; pr->flow_slots = 0.0; }
+    return CVO_HIP_OK;
 }
 
 int cvo_hip_get_wave_load(cvo_hip_ctx *ctx, uint32_t *members_per_wave, int capacity, int *waves)

@@ -588,7 +588,8 @@ struct TLaunch {
     unsigned smem;       // dynamic LDS bytes
     int merged_w4;       // merged launches: the 4-waves-per-SIMD build (no register spills)
 };
-void launch_table(const Slot *tab, const TLaunch &l, hipStream_t s);
+void launch_table(const Slot *tab, const TLaunch &l, hipStream_t s, hipEvent_t ev_start = nullptr,
+                  hipEvent_t ev_stop = nullptr);
 // geometry helpers shared with the host (what the by-value launchers compute from their arguments)
 unsigned filter_grid_cap(long long nitems, long long cap);
 long long filter_blocks_cap();

@@ -1800,9 +1800,13 @@ CVO_MERGED_KERNELS(_w4, 4)
 unsigned filter_grid_cap(long long nitems, long long cap) { return filter_grid_x(nitems, cap); }
 long long filter_blocks_cap() { return filter_blocks_max(); }
 
-void launch_table(const Slot *tab, const TLaunch &l, hipStream_t s)
+void launch_table(const Slot *tab, const TLaunch &l, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop)
 {
     const dim3 g(l.gx, 1, l.gz);
+    if (ev_start && ev_stop && l.kernel == TK_FLOW) {   // engine profiling: the dispatch's own begin / end
+        hipExtLaunchKernelGGL(kt_process<PROC_FLOW>, g, dim3(BLOCK), 0, s, ev_start, ev_stop, 0, tab, l.q);
+        return;
+    }
     switch (l.kernel) {
     case TK_FILTER: hipLaunchKernelGGL(kt_filter, g, dim3(BLOCK), l.smem, s, tab, l.q); break;
     case TK_FILTER_GROUP: hipLaunchKernelGGL(kt_filter_group, dim3(l.gx, 3, l.gz), dim3(BLOCK), l.smem, s, tab, l.q); break;

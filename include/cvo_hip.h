@@ -263,6 +263,14 @@ int cvo_hip_set_graph_capture(cvo_hip_ctx *ctx, int enable);
 int cvo_hip_set_profiling(cvo_hip_ctx *ctx, int enable);
 int cvo_hip_get_profile(cvo_hip_ctx *ctx, cvo_hip_profile *out, int reset);
 
+/* Profiling of cvo_hip_align_many's shared launches (process-wide switch): while on, the fused groups
+ * launch eagerly and every flow-pass launch (kt_process<PROC_FLOW>: one launch serves up to 16
+ * registrations) carries a HIP event pair attached to the dispatch.  cvo_hip_get_engine_profile
+ * returns the summed kernel time, the launches and the registrations those launches served
+ * (sum over launches of the occupied slots); bench.py quotes its roofline on it. */
+int cvo_hip_engine_profiling(int enable);
+int cvo_hip_get_engine_profile(double *flow_ms, long long *flow_launches, double *flow_registrations, int reset);
+
 /* Diagnostics: how evenly the last flow pass (cvo_hip_flow / the last iteration of align) spread
  * the members of A over its wavefronts: members_per_wave[w] = pairs kept by wave w (4 waves per
  * block, blocks in launch order); *waves = entries written (<= capacity). */

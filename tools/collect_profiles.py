@@ -54,6 +54,21 @@ for pat in ("pmc_fetch/*counter_collection.csv", "pmc_write/*counter_collection.
 with open(os.path.join(dst, "%s_pmc_summary.json" % tag), "w") as fh:
     json.dump(summary, fh, indent=1, sort_keys=True)
 
+# the batched run (default --batch): FETCH_SIZE / WRITE_SIZE of the table kernels, per launch
+batch = {}
+for pat in ("pmc_fetch_b/*counter_collection.csv", "pmc_write_b/*counter_collection.csv"):
+    for k, d in counters(pat).items():
+        if not k.startswith("kt_"):
+            continue
+        for c, v in d.items():
+            vv = sorted(v)
+            real = [x for x in vv if x > 0.05 * vv[-1]] if vv[-1] > 0 else vv
+            batch.setdefault(k, {})[c] = {"launches": len(v), "executed": len(real),
+                                          "avg": sum(real) / max(len(real), 1), "max": vv[-1]}
+if batch:
+    with open(os.path.join(dst, "%s_pmc_batch.json" % tag), "w") as fh:
+        json.dump(batch, fh, indent=1, sort_keys=True)
+
 # kernel durations over the launches that did work (the ones queued past convergence
 # return after their first load: well under 0.4 x the median), from the kernel trace of the --batch 1 run
 tr = one("stats/*kernel_trace.csv")
