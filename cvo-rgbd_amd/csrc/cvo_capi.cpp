@@ -646,6 +646,8 @@ int enqueue_process(cvo_hip_ctx *ctx, int mode, int list, DevBuf &part, const fl
     a.tf_a = tf_a; a.tf_b = tf_b;
     a.check_done = check_done;
     a.weight = ctx->prm.color_scale > 0.0f ? 1 : 0;   // the MATLAB object's weight: its own instantiation
+    static const bool no_pack = getenv("CVO_HIP_NO_PACK") != nullptr;
+    a.kept_packed = (!no_pack && ctx->fixed.np <= 65536 && ctx->moving.np <= 65536) ? 1 : 0;
     if (ctx->in_loop && ctx->use_async) {
         a.async_xy = 1;
         a.tiles_b = (const TileEntry *)ctx->lists[LIST_XYB].a.p;

@@ -256,6 +256,9 @@ struct ProcessArgs {
     int tf_a, tf_b;
     int check_done;
     int weight;            // PROC_FLOW: 0 the C++ pair weight, 1 the MATLAB object's (classic launches only)
+    int kept_packed;       // both clouds have <= 65536 rows: a kept entry is 8 bytes (i | j << 16, weight bits)
+                           // in kept_ij alone instead of 8 + 4 -- the kept list is the largest HBM stream of a
+                           // batched run (written by every flow pass, read back by the step pass)
 };
 
 // k_post flags

@@ -724,14 +724,16 @@ __device__ __forceinline__ void process_body(const ProcessArgs &a, const unsigne
         const size_t base = (size_t)wave * a.kept_wcap;
         unsigned n = a.kept_cnt[wave];
         // the first entries are fetched together with the count
+        const bool packed = a.kept_packed != 0;
         uint2 e = a.kept_ij[base + lane];
-        float w = a.kept_a[base + lane];
+        float w = packed ? 0.0f : a.kept_a[base + lane];
         if (done_word != 0) return;
         if (n > a.kept_wcap) n = a.kept_wcap;
         if (list_bad) n = 0;
         for (unsigned off = lane; off < n; off += 64) {
-            if (off >= 64) { e = a.kept_ij[base + off]; w = a.kept_a[base + off]; }
-            eval_pair<MODE>(a, kc, e.x, e.y, w, acc, a.st->xi);
+            if (off >= 64) { e = a.kept_ij[base + off]; if (!packed) w = a.kept_a[base + off]; }
+            eval_pair<MODE>(a, kc, packed ? (e.x & 0xffffu) : e.x, packed ? (e.x >> 16) : e.y,
+                            packed ? __uint_as_float(e.y) : w, acc, a.st->xi);
         }
     } else {
         // nblk >= NSUB: nblk / NSUB blocks share one sub-list of the tile list;
@@ -772,8 +774,12 @@ __device__ __forceinline__ void process_body(const ProcessArgs &a, const unsigne
                     if (w > 0.0f) {
                         const unsigned below = __builtin_amdgcn_mbcnt_hi(
                             (unsigned)(km >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)km, 0u));
-                        a.kept_ij[kbase + nk + below] = pr;
-                        a.kept_a[kbase + nk + below] = w;
+                        if (a.kept_packed) {
+                            a.kept_ij[kbase + nk + below] = make_uint2(pr.x | (pr.y << 16), __float_as_uint(w));
+                        } else {
+                            a.kept_ij[kbase + nk + below] = pr;
+                            a.kept_a[kbase + nk + below] = w;
+                        }
                     }
                 } else if (lane == 0) {
                     atomicOr(&a.st->cnt[2 * LIST_KEPT + 1], 1u);   // slice full: grow and redo
@@ -925,8 +931,9 @@ __device__ __forceinline__ bool step_twist_body(const ProcessArgs &a)
         pf[k] = (tid < a.nblk) ? a.flow_part[(size_t)k * a.nblk + tid] : 0.0;
     const size_t base = (size_t)wave * a.kept_wcap;
     unsigned n = a.kept_cnt[wave];
+    const bool packed = a.kept_packed != 0;
     uint2 e = a.kept_ij[base + lane];
-    float w = a.kept_a[base + lane];
+    float w = packed ? 0.0f : a.kept_a[base + lane];
     if (done_word != 0) return false;
 
     // ---- the twist (ref cvo.cpp:201-209) from the partial sums
@@ -1016,8 +1023,9 @@ __device__ __forceinline__ bool step_twist_body(const ProcessArgs &a)
     for (int k = 0; k < NACC; ++k) acc[k] = 0.0;
     if (n > a.kept_wcap) n = a.kept_wcap;
     for (unsigned off = lane; off < n; off += 64) {
-        if (off >= 64) { e = a.kept_ij[base + off]; w = a.kept_a[base + off]; }
-        eval_pair<PROC_STEP>(a, kc, e.x, e.y, w, acc, xc);
+        if (off >= 64) { e = a.kept_ij[base + off]; if (!packed) w = a.kept_a[base + off]; }
+        eval_pair<PROC_STEP>(a, kc, packed ? (e.x & 0xffffu) : e.x, packed ? (e.x >> 16) : e.y,
+                             packed ? __uint_as_float(e.y) : w, acc, xc);
     }
     __syncthreads();   // sh is re-used
     wave_sums<NACC>(acc, lane, sh + wid * NACC);
