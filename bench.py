@@ -563,8 +563,23 @@ def sharded_leg(args, pkg, dist, torch, rank, world, local_rank, barrier):
             ctx.comm_init(uid[0], rank, world)
         return ctx
 
+    def agree(ok):
+        # every rank must take the same branch: the minimum of the ranks' verdicts
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device="cuda")
+        if world > 1:
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        return int(flag.item()) == 1
+
     def run(exchange):
-        ctx = make_ctx(exchange)
+        ctx, err = None, None
+        try:
+            ctx = make_ctx(exchange)
+        except Exception as exc:   # noqa: BLE001
+            err = exc
+        if not agree(err is None):   # (before anybody waits in an exchange for a rank that is not coming)
+            if ctx is not None:
+                ctx.close()
+            raise RuntimeError("setting up the %s exchange failed on a rank: %r" % (exchange, err))
         try:
             st = capi.init_state(ctx.params)
             ctx.align(st, trace_cap=0)   # warm-up (RCCL: also sets up the channels)
@@ -593,17 +608,13 @@ def sharded_leg(args, pkg, dist, torch, rank, world, local_rank, barrier):
     order = ["mailbox", "rccl"] if args.sharded_exchange == "mailbox" else ["rccl"]
     for ex in order:
         try:
-            # every rank must take the same branch: agree on success
-            ok = 1
+            ok = True
             try:
                 r = run(ex)
             except Exception as exc:   # noqa: BLE001
-                ok, r = 0, {"error": repr(exc)}
-            flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
-            if world > 1:
-                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                ok, r = False, {"error": repr(exc)}
             res[ex] = r
-            if int(flag.item()) == 1:
+            if agree(ok):
                 res["exchange"] = ex
                 res.update(r)
                 if ex == "mailbox" and world > 1 and "rccl" in order:
