@@ -565,8 +565,6 @@ int enqueue_filter(cvo_hip_ctx *ctx, int list, const Cloud &ca, int row_lo, int 
     a.tf_a = tf_a; a.tf_b = tf_b;
     a.check_done = check_done;
     a.gx = (int)pl.grid.x; a.gy = (int)pl.grid.y;
-    static const int deal_shift = [] { const char *e = getenv("CVO_HIP_DEAL_SHIFT"); const int v = e ? atoi(e) : 2; return v >= 0 && v <= 7 ? v : 2; }();   // runs of 4: 64-byte stores
-    a.deal_shift = deal_shift;
     const bool side = list == LIST_XY && ctx->in_loop && ctx->use_async;
     if (side) {   // build beside the flow pass, into the buffer the plan step named
         rc = ensure_list(ctx, LIST_XYB, 0, 0, (double)ctx->lists[LIST_XY].cap);
@@ -683,8 +681,10 @@ int enqueue_process(cvo_hip_ctx *ctx, int mode, int list, DevBuf &part, const fl
         ev.iter_tag = ctx->iter_tag;
         ev.pairs = 0.0;
     }
+    // (a build riding in the flow launch exists in the table path only: the asynchronous scheme is off
+    // whenever launches are issued by value -- profiling, stream-level all-reduces)
+    if (build) return fail(ctx, CVO_HIP_ERR_INVALID, "asynchronous build outside the table path");
     if (twist) launch_step_twist_group(&a, 1, ctx->stream, ev.a, ev.b);
-    else if (build) launch_flow_build_group(&a, &ctx->xy_build, 1, ctx->stream);
     else launch_process(mode, a, ctx->stream, ev.a, ev.b);
     if (timed) ctx->events.push_back(ev);
     HIP_TRY(ctx, hipGetLastError());
@@ -827,17 +827,10 @@ int enqueue_flow(cvo_hip_ctx *ctx, bool tf_moving, int check_done, bool do_math,
                 }
                 else if (op.kind == RecOp::PROCESS && op.mode == PROC_SELF && ns < 2) self[ns++] = op.p;
             }
-            if (have_flow && have_build && na == 2 && ns == 2) {
-                // everything but the step-size pass in one launch (self lists built ahead)
-                launch_flow_build6(flow, self[0], self[1], build, ahead[0], ahead[1], ctx->stream);
-                ns = 0;
-            } else if (have_flow && have_build && nf == 2) {   // everything that filters rides with the flow pass
-                launch_flow_build3(flow, build, f[0], f[1], ctx->stream);
-            } else {
-                if (nf) launch_filter_group(f, nf, ctx->stream);
-                if (have_flow && have_build) launch_flow_build_group(&flow, &build, 1, ctx->stream);
-                else if (have_flow) launch_process_group(PROC_FLOW, &flow, 1, ctx->stream);
-            }
+            // (eager by-value launches: synchronous lists only, see enqueue_process)
+            if (nf) launch_filter_group(f, nf, ctx->stream);
+            if (have_flow && !have_build) launch_process_group(PROC_FLOW, &flow, 1, ctx->stream);
+            else if (have_flow) rc = fail(ctx, CVO_HIP_ERR_INVALID, "asynchronous build outside the table path");
             if (ns) launch_process_group(PROC_SELF, self, ns, ctx->stream);
             HIP_TRY(ctx, hipGetLastError());
         }
@@ -977,17 +970,10 @@ void drop_graphs(cvo_hip_ctx *ctx) { ctx->plans.drop(); }
 
 // ---------------------------------------------------------------------------
 // From the recorded launches of one iteration (RecOp) to a launch plan + the slot contents.
-bool merged_w4()
-{   // merged launches: 4 waves per SIMD, nothing spilled (default) or 6 with a few spills (profiles/ has the A/B)
-    static const bool v = [] { const char *e = getenv("CVO_HIP_MERGED_WAVES"); return !(e && atoi(e) == 6); }();
-    return v;
-}
-
 TLaunch mk_launch(int kernel, int q, unsigned gx, unsigned gz, unsigned smem = 0)
 {
     TLaunch l{};
     l.kernel = kernel; l.q = q; l.gx = gx; l.gz = gz; l.smem = smem;
-    l.merged_w4 = merged_w4() ? 1 : 0;
     return l;
 }
 

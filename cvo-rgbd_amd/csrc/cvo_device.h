@@ -51,6 +51,7 @@ constexpr int PROC_WAVES = PROC_BLOCKS * 4;
 constexpr int NSUB = 256;
 constexpr int PROC_PARTS = PROC_BLOCKS / NSUB;   // most blocks cooperating on one sub-list
 constexpr int TILE_STAGE = 128;     // TileEntry slots staged per wave in k_filter
+constexpr int DEAL_SHIFT = 2;       // ... and dealt over the sub-lists of a region in runs of 1 << DEAL_SHIFT (flush_tiles)
 constexpr int PAIR_QUEUE = 128;     // compaction queue of a k_process wave
 constexpr int SEG = 64;             // points per bounding-sphere segment (= rows of a filter wave)
 constexpr int MAX_CSEG = 32;        // column segments of a filter block (jt <= 2048)
@@ -221,7 +222,6 @@ struct FilterArgs {
     int tf_a, tf_b;        // apply [Rt|t] to the row / column cloud while staging
     int check_done;        // return at once when st->done != 0
     int gx, gy;            // this registration's own grid (a fused launch may be larger)
-    int deal_shift;        // tile entries are dealt over the sub-lists in runs of 1 << deal_shift (flush_tiles)
     long long *dbg;        // probe only (tools/microbench): per-wave phase clocks, else null
 };
 
@@ -574,11 +574,6 @@ void launch_post_flow_group(const PostFlowArgs *a, int n, hipStream_t s);
 void launch_post_step_group(const PostStepArgs *a, int n, hipStream_t s);
 void launch_step_twist_group(const ProcessArgs *a, int n, hipStream_t s, hipEvent_t ev_start = nullptr,
                              hipEvent_t ev_stop = nullptr);
-void launch_flow_build_group(const ProcessArgs *a, const FilterArgs *f, int n, hipStream_t s);
-void launch_flow_build3(const ProcessArgs &flow, const FilterArgs &xy, const FilterArgs &xx,
-                        const FilterArgs &yy, hipStream_t s);
-void launch_flow_build6(const ProcessArgs &flow, const ProcessArgs &sxx, const ProcessArgs &syy,
-                        const FilterArgs &xy, const FilterArgs &xx, const FilterArgs &yy, hipStream_t s);
 constexpr int STEP_TWIST_ROWS_DIV = 4;   // k_step_twist writes nblk / 4 partial rows
 
 // One launch of an iteration through a table: which kernel, its geometry, which op[] it reads.
@@ -589,7 +584,6 @@ struct TLaunch {
     int q;               // op index in the slots
     unsigned gx, gz;     // grid.x, grid.z (= slots served)
     unsigned smem;       // dynamic LDS bytes
-    int merged_w4;       // merged launches: the 4-waves-per-SIMD build (no register spills)
 };
 void launch_table(const Slot *tab, const TLaunch &l, hipStream_t s, hipEvent_t ev_start = nullptr,
                   hipEvent_t ev_stop = nullptr);

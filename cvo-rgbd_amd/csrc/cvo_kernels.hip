@@ -84,7 +84,8 @@ __device__ __forceinline__ bool spheres_near(const float4 sa, const float4 sb, f
 }
 
 // Append the wave's `n` staged tile entries (n <= TILE_STAGE = 128) to the 32 sub-lists of its row
-// region, DEALT in runs of L = 1 << a.deal_shift entries: run c (entries cL .. cL+L-1) goes to
+// region, DEALT in runs of L = 1 << DEAL_SHIFT = 4 entries (64-byte stores; runs of 1, 2, 4 measured alike,
+// whole flushes 3 % slower: profiles/r02_ab.txt): run c (entries cL .. cL+L-1) goes to
 // sub-list ((c + rot) & 31) * 8 + region.  Whole flushes to one sub-list each -- the first
 // version -- left the sub-lists of a 10k x 10k pair with 2.6 (ell = 0.15) to 4.9 (ell = 0.03)
 // times the mean load on the fullest one (a few flushes of up to 128 entries per sub-list:
@@ -95,7 +96,7 @@ __device__ __forceinline__ void flush_tiles(const TileEntry *stage, int n, int l
                                             const FilterArgs &a, int list, TileEntry *tiles)
 {
     static_assert(TILE_STAGE <= 128, "two entries per lane");
-    const int sh = a.deal_shift, L = 1 << sh;
+    constexpr int sh = DEAL_SHIFT, L = 1 << sh;
     unsigned base = 0;
     if (lane < 32) {
         int cnt = 0;
@@ -324,7 +325,7 @@ __device__ __forceinline__ void filter_body(const FilterArgs &a, const unsigned 
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             flush_tiles(stage, ne, lane, sub, region, a, out_list, out_tiles);
-            sub += (unsigned)((ne + (1 << a.deal_shift) - 1) >> a.deal_shift);
+            sub += (unsigned)((ne + (1 << DEAL_SHIFT) - 1) >> DEAL_SHIFT);
             __builtin_amdgcn_wave_barrier();
             ne = 0;
         }
@@ -849,47 +850,6 @@ __global__ void __launch_bounds__(BLOCK) k_process(const Grp<ProcessArgs> grp)
 }
 
 // ---------------------------------------------------------------------------
-// k_flow_build = k_process<PROC_FLOW> and the asynchronous xy build in one launch:
-// blocks [0, np) run the flow pass of this slot on the buffer in use, blocks
-// [np, np + nfb) are k_filter blocks that build the idle buffer at this slot's
-// transform when the plan step asked for it (cvo_device.h plan_xy_async) and return
-// after their first load otherwise.  The filter is off the launch chain: three
-// dependent launches per iteration, and builds that nobody waits for.
-struct BuildExtra {          // what a filter block needs beyond the flow pass's arguments
-    const float4 *seg_a, *seg_b;
-    int row_lo, row_hi, nb, jt, gx, gy;
-};
-
-__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(6, 8)))
-k_flow_build(const Grp<ProcessArgs> gp, const Grp<BuildExtra> gx, const int np, const int nfb)
-{
-    extern __shared__ __attribute__((aligned(16))) char smem[];   // (>= PROC_SMEM: the filter's carve is larger)
-    const ProcessArgs &a = gp.a[blockIdx.z];
-    if ((int)blockIdx.x < np) {
-        process_body<PROC_FLOW>(a, blockIdx.x, smem);
-        return;
-    }
-    const BuildExtra &x = gx.a[blockIdx.z];
-    FilterArgs f;
-    f.pos_a = a.pos_a; f.pos_b = a.pos_b;
-    f.seg_a = x.seg_a; f.seg_b = x.seg_b;
-    f.st = a.st;
-    f.tiles = const_cast<TileEntry *>(a.tiles);
-    f.tiles_b = const_cast<TileEntry *>(a.tiles_b);
-    f.async_xy = 1;
-    f.subcap = a.subcap;
-    f.list = LIST_XY;
-    f.row_lo = x.row_lo; f.row_hi = x.row_hi;
-    f.nb = x.nb; f.jt = x.jt;
-    f.tf_a = a.tf_a; f.tf_b = a.tf_b;
-    f.check_done = a.check_done;
-    f.gx = x.gx; f.gy = x.gy;
-    f.dbg = nullptr;
-    f.deal_shift = 2;
-    filter_body(f, blockIdx.x - (unsigned)np, (unsigned)nfb);
-}
-
-// ---------------------------------------------------------------------------
 // k_step_twist = the tail of compute_flow (what k_post_flow does) + PROC_STEP in one
 // launch: every block reduces the PROC_FLOW partial sums itself -- 1024 threads, one
 // partial row each, the same fixed order in every block, so all blocks hold the same
@@ -1052,92 +1012,6 @@ void launch_step_twist_group(const ProcessArgs *a, int n, hipStream_t s, hipEven
     const dim3 grid((unsigned)(nblk / (STEP_BLOCK / BLOCK)), 1, (unsigned)n);
     if (ev_start && ev_stop) hipExtLaunchKernelGGL(k_step_twist, grid, dim3(STEP_BLOCK), 0, s, ev_start, ev_stop, 0, g);
     else hipLaunchKernelGGL(k_step_twist, grid, dim3(STEP_BLOCK), 0, s, g);
-}
-
-// flow pass + asynchronous xy build: f[i] is the k_filter argument block of a[i]
-void launch_flow_build_group(const ProcessArgs *a, const FilterArgs *f, int n, hipStream_t s)
-{
-    Grp<ProcessArgs> gp;
-    Grp<BuildExtra> gx;
-    int np = 8, jt = 0;
-    unsigned nfb = 8;
-    static const long long fb_div = [] { const char *e = getenv("CVO_HIP_BUILD_DIV"); return e ? std::max(1LL, atoll(e)) : 4LL; }();
-    // fewer filter blocks than a stand-alone k_filter launch gets: nobody waits for a build
-    const long long cap = std::max<long long>(64, 2 * filter_blocks_max() / (fb_div * n));
-    for (int i = 0; i < n; ++i) {
-        gp.a[i] = a[i];
-        gx.a[i] = BuildExtra{f[i].seg_a, f[i].seg_b, f[i].row_lo, f[i].row_hi, f[i].nb, f[i].jt, f[i].gx, f[i].gy};
-        np = std::max(np, a[i].nblk);
-        nfb = std::max(nfb, filter_grid_x((long long)f[i].gx * f[i].gy, cap));
-        jt = std::max(jt, f[i].jt);
-    }
-    const dim3 grid((unsigned)np + nfb, 1, (unsigned)n);
-    hipLaunchKernelGGL(k_flow_build, grid, dim3(BLOCK), filter_smem_bytes(jt), s, gp, gx, np, (int)nfb);
-}
-
-// acvo, one registration: the flow pass, the asynchronous xy build AND the xx / yy
-// filters (synchronous lists, consumed by the PROC_SELF launch that follows) in one
-// launch -- no k_filter launch of its own is left in an acvo iteration.
-__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(6, 8)))
-k_flow_build3(const ProcessArgs flow, const FilterArgs f0, const FilterArgs f1, const FilterArgs f2,
-              const int np, const int n0, const int n1, const int n2)
-{
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    int b = (int)blockIdx.x;
-    if (b < np) { process_body<PROC_FLOW>(flow, (unsigned)b, smem); return; }
-    b -= np;
-    if (b < n0) { filter_body(f0, (unsigned)b, (unsigned)n0); return; }
-    b -= n0;
-    if (b < n1) { filter_body(f1, (unsigned)b, (unsigned)n1); return; }
-    b -= n1;
-    filter_body(f2, (unsigned)b, (unsigned)n2);
-}
-
-void launch_flow_build3(const ProcessArgs &flow, const FilterArgs &xy, const FilterArgs &xx,
-                        const FilterArgs &yy, hipStream_t s)
-{
-    const long long cap = std::max<long long>(64, filter_blocks_max() / 2);
-    const int np = std::max(8, flow.nblk);
-    const int n0 = (int)filter_grid_x((long long)xy.gx * xy.gy, cap);
-    const int n1 = (int)filter_grid_x((long long)xx.gx * xx.gy, cap);
-    const int n2 = (int)filter_grid_x((long long)yy.gx * yy.gy, cap);
-    const int jt = std::max(xy.jt, std::max(xx.jt, yy.jt));
-    hipLaunchKernelGGL(k_flow_build3, dim3((unsigned)(np + n0 + n1 + n2)), dim3(BLOCK), filter_smem_bytes(jt), s,
-                       flow, xy, xx, yy, np, n0, n1, n2);
-}
-
-// acvo with the self lists built ahead as well (plan_self_async): flow pass, both self
-// passes and all three filters in ONE launch -- three dependent launches per iteration.
-__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(6, 8)))
-k_flow_build6(const ProcessArgs flow, const ProcessArgs sxx, const ProcessArgs syy, const FilterArgs f0,
-              const FilterArgs f1, const FilterArgs f2, const int np, const int n0, const int n1, const int n2)
-{
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    int b = (int)blockIdx.x;
-    if (b < np) { process_body<PROC_FLOW>(flow, (unsigned)b, smem); return; }
-    b -= np;
-    if (b < np) { process_body<PROC_SELF>(sxx, (unsigned)b, smem); return; }
-    b -= np;
-    if (b < np) { process_body<PROC_SELF>(syy, (unsigned)b, smem); return; }
-    b -= np;
-    if (b < n0) { filter_body(f0, (unsigned)b, (unsigned)n0); return; }
-    b -= n0;
-    if (b < n1) { filter_body(f1, (unsigned)b, (unsigned)n1); return; }
-    b -= n1;
-    filter_body(f2, (unsigned)b, (unsigned)n2);
-}
-
-void launch_flow_build6(const ProcessArgs &flow, const ProcessArgs &sxx, const ProcessArgs &syy,
-                        const FilterArgs &xy, const FilterArgs &xx, const FilterArgs &yy, hipStream_t s)
-{
-    const long long cap = std::max<long long>(64, filter_blocks_max() / 2);
-    const int np = std::max(8, flow.nblk);
-    const int n0 = (int)filter_grid_x((long long)xy.gx * xy.gy, cap);
-    const int n1 = (int)filter_grid_x((long long)xx.gx * xx.gy, cap);
-    const int n2 = (int)filter_grid_x((long long)yy.gx * yy.gy, cap);
-    const int jt = std::max(xy.jt, std::max(xx.jt, yy.jt));
-    hipLaunchKernelGGL(k_flow_build6, dim3((unsigned)(3 * np + n0 + n1 + n2)), dim3(BLOCK),
-                       filter_smem_bytes(jt), s, flow, sxx, syy, xy, xx, yy, np, n0, n1, n2);
 }
 
 void launch_process_group(int mode, const ProcessArgs *a, int n, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop)
@@ -1672,16 +1546,6 @@ __global__ void __launch_bounds__(BLOCK) kt_process(const Slot *__restrict__ tab
     process_body<MODE, WEIGHT>(CVO_ARG(ProcessArgs, op[q].p), blockIdx.x, scratch);
 }
 
-// the flow pass held to 64 vector registers: 8 waves per SIMD, so that the 2048 blocks of a full
-// fused launch are all resident at once (with 74 registers 1536 are: the launch takes two rounds)
-__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8)))
-kt_flow_w8(const Slot *__restrict__ tab, const int q)
-{
-    __shared__ __attribute__((aligned(16))) char scratch[PROC_SMEM];
-    CVO_SLOT(tab);
-    process_body<PROC_FLOW, 0>(CVO_ARG(ProcessArgs, op[q].p), blockIdx.x, scratch);
-}
-
 // acvo, one registration: both self passes in one launch (blockIdx.y = xx / yy)
 __global__ void __launch_bounds__(BLOCK) kt_self2(const Slot *__restrict__ tab, const int q)
 {
@@ -1747,9 +1611,20 @@ __global__ void __launch_bounds__(BLOCK) kt_post_step(const Slot *__restrict__ t
     post_step_body(a);
 }
 
-// The merged launches (see k_flow_build, k_flow_build3, k_flow_build6): a block reads the
-// argument block of the role it plays.  Two builds each: 6 waves per SIMD (<= 80 registers: a few
-// spilled) and 4 (all in registers); CVO_HIP_MERGED_WAVES picks, profiles/ has the A/B.
+// The merged launches of a registration with its launches to itself (asynchronous list builds,
+// cvo_device.h plan_xy_async / plan_self_async):
+//   kt_flow_build  : blocks [0, np) run the flow pass of this slot on the xy buffer in use, the
+//                    next n0 are k_filter blocks that build the idle buffer at this slot's
+//                    transform when the plan step asked for it (and return after their first
+//                    load otherwise): the filter is off the launch chain, three dependent
+//                    launches per iteration, builds that nobody waits for;
+//   kt_flow_build3 : acvo -- the same plus the xx / yy filters (synchronous lists, consumed by
+//                    the kt_self2 launch that follows): no k_filter launch of its own is left;
+//   kt_flow_build6 : acvo with the self lists built ahead as well -- flow pass, both self passes
+//                    and all three builds in ONE launch.
+// A block reads the argument block of the role it plays.  Built for 4 waves per SIMD: every vector
+// register in registers, no scratch (held to 6 waves -- 80 registers -- 8 to 12 of them spill and
+// a registration is 1.5 % slower, profiles/r02_ab.txt).
 #define CVO_MERGED_KERNELS(SUFFIX, WAVES)                                                                  \
     __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WAVES, 8)))               \
     kt_flow_build##SUFFIX(const Slot *__restrict__ tab, const int q)                                       \
@@ -1802,7 +1677,6 @@ __global__ void __launch_bounds__(BLOCK) kt_post_step(const Slot *__restrict__ t
         filter_body(CVO_FILTER_ROLE(role), (unsigned)(b - (role == 0 ? 0 : (role == 1 ? n0 : n0 + n1))),   \
                     (unsigned)(role == 0 ? n0 : (role == 1 ? n1 : cs->op[q].n2)));                         \
     }
-CVO_MERGED_KERNELS(_w6, 6)
 CVO_MERGED_KERNELS(_w4, 4)
 
 unsigned filter_grid_cap(long long nitems, long long cap) { return filter_grid_x(nitems, cap); }
@@ -1818,30 +1692,16 @@ void launch_table(const Slot *tab, const TLaunch &l, hipStream_t s, hipEvent_t e
     switch (l.kernel) {
     case TK_FILTER: hipLaunchKernelGGL(kt_filter, g, dim3(BLOCK), l.smem, s, tab, l.q); break;
     case TK_FILTER_GROUP: hipLaunchKernelGGL(kt_filter_group, dim3(l.gx, 3, l.gz), dim3(BLOCK), l.smem, s, tab, l.q); break;
-    case TK_FLOW: {
-        static const bool w8 = [] { const char *e = getenv("CVO_HIP_FLOW_WAVES"); return e && atoi(e) == 8; }();
-        if (w8 && l.gz > 2) hipLaunchKernelGGL(kt_flow_w8, g, dim3(BLOCK), 0, s, tab, l.q);
-        else hipLaunchKernelGGL(kt_process<PROC_FLOW>, g, dim3(BLOCK), 0, s, tab, l.q);
-        break;
-    }
+    case TK_FLOW: hipLaunchKernelGGL(kt_process<PROC_FLOW>, g, dim3(BLOCK), 0, s, tab, l.q); break;
     case TK_FLOW_MATLAB: hipLaunchKernelGGL((kt_process<PROC_FLOW, 1>), g, dim3(BLOCK), 0, s, tab, l.q); break;
     case TK_STEP: hipLaunchKernelGGL(kt_process<PROC_STEP>, g, dim3(BLOCK), 0, s, tab, l.q); break;
     case TK_SELF: hipLaunchKernelGGL(kt_process<PROC_SELF>, g, dim3(BLOCK), 0, s, tab, l.q); break;
     case TK_SELF2: hipLaunchKernelGGL(kt_self2, dim3(l.gx, 2, l.gz), dim3(BLOCK), 0, s, tab, l.q); break;
     case TK_STEP_TWIST: hipLaunchKernelGGL(kt_step_twist, g, dim3(STEP_BLOCK), 0, s, tab, l.q); break;
     case TK_STEP_TWIST_POST: hipLaunchKernelGGL(kt_step_twist_post, g, dim3(STEP_BLOCK), 0, s, tab, l.q); break;
-    case TK_FLOW_BUILD:
-        if (l.merged_w4) hipLaunchKernelGGL(kt_flow_build_w4, g, dim3(BLOCK), l.smem, s, tab, l.q);
-        else hipLaunchKernelGGL(kt_flow_build_w6, g, dim3(BLOCK), l.smem, s, tab, l.q);
-        break;
-    case TK_FLOW_BUILD3:
-        if (l.merged_w4) hipLaunchKernelGGL(kt_flow_build3_w4, g, dim3(BLOCK), l.smem, s, tab, l.q);
-        else hipLaunchKernelGGL(kt_flow_build3_w6, g, dim3(BLOCK), l.smem, s, tab, l.q);
-        break;
-    case TK_FLOW_BUILD6:
-        if (l.merged_w4) hipLaunchKernelGGL(kt_flow_build6_w4, g, dim3(BLOCK), l.smem, s, tab, l.q);
-        else hipLaunchKernelGGL(kt_flow_build6_w6, g, dim3(BLOCK), l.smem, s, tab, l.q);
-        break;
+    case TK_FLOW_BUILD: hipLaunchKernelGGL(kt_flow_build_w4, g, dim3(BLOCK), l.smem, s, tab, l.q); break;
+    case TK_FLOW_BUILD3: hipLaunchKernelGGL(kt_flow_build3_w4, g, dim3(BLOCK), l.smem, s, tab, l.q); break;
+    case TK_FLOW_BUILD6: hipLaunchKernelGGL(kt_flow_build6_w4, g, dim3(BLOCK), l.smem, s, tab, l.q); break;
     case TK_POST_FLOW: hipLaunchKernelGGL(kt_post_flow, g, dim3(BLOCK), 0, s, tab, l.q); break;
     case TK_POST_STEP: hipLaunchKernelGGL(kt_post_step, g, dim3(BLOCK), 0, s, tab, l.q); break;
     default: break;

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Timeline view of a rocprofv3 --kernel-trace CSV: per queue busy time and gaps, the union
 busy time of the device, and per (kernel, grid z) duration statistics.
-usage: trace_timeline.py <kernel_trace.csv> [skip_first_ms]"""
+usage: trace_timeline.py <kernel_trace.csv> [skip_first_ms | -keep_last_ms]"""
 import collections
 import csv
 import sys
@@ -17,7 +17,7 @@ for r in rows:
     z = r.get("Grid_Size_Z", r.get("Grid_Size", ""))
     ev.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), name, q, z))
 ev.sort()
-t0 = ev[0][0] + skip
+t0 = ev[0][0] + skip if skip >= 0 else ev[-1][1] + skip   # negative: keep the last |skip| ms
 ev = [e for e in ev if e[0] >= t0]
 span = (ev[-1][1] - ev[0][0]) / 1e3
 print("kernels %d, span %.1f us" % (len(ev), span))
