@@ -73,3 +73,38 @@ def test_product_does_not_import_the_oracle():
                     if re.search(r"(^|[^A-Za-z_])(import oracle|from oracle|liboracle|cvo_oracle)", txt):
                         bad.append(os.path.join(dp, f))
     assert not bad, bad
+
+
+def test_parameters_are_validated_before_anything_touches_a_device(pkg):
+    """cvo_hip_create refuses parameter blocks the kernels cannot work with -- an unknown mode
+    (MATLAB is a preset of default_params, not a mode of a context), kernel scales or thresholds
+    that are not positive, non-finite values -- with CVO_HIP_ERR_INVALID (-1), not with the
+    'no device' status a GPU-less box would otherwise give (-5): the check runs first.  (The
+    reference would take log() of a non-positive quotient and carry NaNs, ref src/cvo.cpp:102-103.)"""
+    capi = pkg.capi
+    L = capi.lib()
+
+    def create(p):
+        ctx = ctypes.c_void_p()
+        rc = L.cvo_hip_create(0, None, ctypes.byref(p), ctypes.byref(ctx))
+        if rc == 0:
+            L.cvo_hip_destroy(ctx)
+        return rc
+
+    good = capi.default_params(capi.MODE_CVO)
+    assert create(good) in (0, -5)                      # fine: a context, or no GPU here
+    for field, value in (("mode", 2), ("mode", 9), ("sigma", 0.0), ("c_sigma", -1.0), ("c", 0.0), ("d", 0.0),
+                         ("c_ell", 0.0), ("sp_thres", 0.0), ("sp_thres", -1e-3), ("ell_init", 0.0),
+                         ("max_iter", -1), ("eps", float("nan")), ("min_step", float("inf")),
+                         ("color_scale", -1.0)):
+        p = capi.default_params(capi.MODE_CVO)
+        setattr(p, field, value)
+        assert create(p) == -1, field
+    q = capi.default_params(capi.MODE_ACVO)
+    q.c_sp_thres = 0.0
+    assert create(q) == -1
+    q = capi.default_params(capi.MODE_ACVO)
+    q.dl_step = float("nan")
+    assert create(q) == -1
+    m = capi.default_params(capi.MODE_MATLAB)           # the MATLAB preset is a valid CVO-mode block
+    assert m.mode == capi.MODE_CVO and m.color_scale > 0 and create(m) in (0, -5)

@@ -729,3 +729,34 @@ def test_align_many_refills_its_slots_from_the_queue(pkg, monkeypatch, graphs):
         assert [(i, bytes(s)) for i, s in zip(its, states)] == ref
     for c in ctxs:
         c.close()
+
+
+def test_graph_capture_policy_and_parameter_errors(pkg):
+    """Captures are the default only on a stream the context created itself; on a caller's stream
+    the loop launches eagerly until the caller opts in (cvo_hip.h: cvo_hip_set_graph_capture) --
+    same result either way.  set_params refuses a bad block and says why."""
+    import torch
+    capi = pkg.capi
+    xf, ff, xm, fm = pkg.data.synthetic_pair(1800, 1700, seed=71)
+    results = []
+    for stream, opt_in in ((None, None), ("torch", None), ("torch", True), (None, False)):
+        s = torch.cuda.Stream() if stream else None
+        c = capi.Context(mode=capi.MODE_CVO, device=0, stream=s.cuda_stream if s else None, graph_capture=opt_in)
+        c.set_fixed(xf, ff)
+        c.set_moving(xm, fm)
+        for _ in range(2):
+            st = capi.init_state(c.params)
+            it, _ = c.align(st, trace_cap=0)
+        hits, captures = c.graph_stats()
+        expect_graphs = (stream is None and opt_in is not False) or opt_in is True
+        assert (captures > 0) == expect_graphs, (stream, opt_in, hits, captures)
+        if expect_graphs:
+            assert captures <= 2 and hits >= captures    # the second align() re-uses the first one's batches
+        results.append((it, bytes(st)))
+        if stream is None and opt_in is None:
+            bad = capi.default_params(capi.MODE_CVO)
+            bad.sigma = 0.0
+            with pytest.raises(capi.CvoHipError, match="sigma"):
+                c.set_params(bad)
+        c.close()
+    assert all(r == results[0] for r in results)
