@@ -1116,7 +1116,24 @@ bool plan_fused(const std::vector<const std::vector<RecOp> *> &ops, const std::v
         if (o->size() != nq) return false;
     const long long fbmax = filter_blocks_cap();
     static const long long fb_div = [] { const char *e = getenv("CVO_HIP_BUILD_DIV"); return e ? std::max(1LL, atoll(e)) : 4LL; }();
-    for (size_t q = 0; q < nq; ++q) {
+    // acvo, synchronous lists: filter xy, flow, filter xx, self, filter yy, self are recorded in the
+    // reference's order; the three filters are independent of the passes, so the slots hold them
+    // first -- three filters (one launch, blockIdx.y = list), flow, two self passes (one launch) --
+    // 6 launches per iteration instead of 9
+    std::vector<size_t> perm(nq);
+    for (size_t q = 0; q < nq; ++q) perm[q] = q;
+    static const bool regroup = getenv("CVO_HIP_NO_REGROUP") == nullptr;
+    {
+        const std::vector<RecOp> &r = *ops[0];
+        auto is_f = [&](size_t q) { return q < nq && r[q].kind == RecOp::FILTER && r[q].mode != kFilterAhead; };
+        auto is_p = [&](size_t q, int mode) { return q < nq && r[q].kind == RecOp::PROCESS && r[q].mode == mode; };
+        if (regroup && is_f(0) && is_p(1, PROC_FLOW) && is_f(2) && is_p(3, PROC_SELF) && is_f(4) && is_p(5, PROC_SELF)) {
+            const size_t order[6] = {0, 2, 4, 1, 3, 5};
+            for (size_t q = 0; q < 6; ++q) perm[q] = order[q];
+        }
+    }
+    for (size_t qs = 0; qs < nq; ++qs) {
+        const size_t q = perm[qs];   // recorded op q lives in slot entry qs
         const RecOp &first = (*ops[0])[q];
         for (const auto *o : ops)
             if ((*o)[q].kind != first.kind || (*o)[q].mode != first.mode) return false;
@@ -1125,7 +1142,7 @@ bool plan_fused(const std::vector<const std::vector<RecOp> *> &ops, const std::v
         unsigned nfb = 8;
         for (size_t i = 0; i < ops.size(); ++i) {
             const RecOp &op = (*ops[i])[q];
-            OpArgs &o = slots[i]->op[q];
+            OpArgs &o = slots[i]->op[qs];
             switch (op.kind) {
             case RecOp::FILTER: {
                 o.f = op.f;
@@ -1159,10 +1176,36 @@ bool plan_fused(const std::vector<const std::vector<RecOp> *> &ops, const std::v
         }
         if (kernel == TK_FLOW_BUILD) {
             gx = (unsigned)np + nfb;
-            for (Slot *sl : slots) { sl->op[q].np = np; sl->op[q].n0 = (int)nfb; }
+            for (Slot *sl : slots) { sl->op[qs].np = np; sl->op[qs].n0 = (int)nfb; }
         }
-        plan.push_back(mk_launch(kernel, (int)q, gx, (unsigned)zdim, smem));
+        plan.push_back(mk_launch(kernel, (int)qs, gx, (unsigned)zdim, smem));
     }
+    // three filters / two self passes in a row become one launch each
+    std::vector<TLaunch> merged;
+    for (size_t i = 0; i < plan.size(); ++i) {
+        auto run_of = [&](int kernel, size_t n) {
+            if (i + n > plan.size()) return false;
+            for (size_t k = 0; k < n; ++k)
+                if (plan[i + k].kernel != kernel || plan[i + k].q != plan[i].q + (int)k) return false;
+            return true;
+        };
+        if (run_of(TK_FILTER, 3)) {
+            TLaunch l = plan[i];
+            l.kernel = TK_FILTER_GROUP;
+            for (size_t k = 1; k < 3; ++k) { l.gx = std::max(l.gx, plan[i + k].gx); l.smem = std::max(l.smem, plan[i + k].smem); }
+            merged.push_back(l);
+            i += 2;
+        } else if (run_of(TK_SELF, 2)) {
+            TLaunch l = plan[i];
+            l.kernel = TK_SELF2;
+            l.gx = std::max(l.gx, plan[i + 1].gx);
+            merged.push_back(l);
+            i += 1;
+        } else {
+            merged.push_back(plan[i]);
+        }
+    }
+    plan.swap(merged);
     return true;
 }
 
