@@ -71,11 +71,13 @@ struct List {     // LIST_XY/XX/YY: TileEntry[cap] in a; LIST_KEPT: uint2[cap] i
     uint32_t cap = 0;   // entries, a multiple of NSUB
 };
 
-// iterations enqueued between two polls (measured, one registration: 4 -> 556, 6 -> 572, 8 -> 566, 12 -> 549 reg/s)
+// iterations per captured batch of a registration on its own (paced submission, job_pump: measured with the next
+// batch enqueued when the running one has finished -- 6 / 8 / 12 / 16 / 24: 643 / 644 / 632 / 625 / 600 reg/s at 10k x 10k,
+// 650 / 668 / 668 / 644 / 672 at 3k x 3k, acvo 388 / 393 / 376 / 392 / 380)
 // ... and in a fused group, where a batch boundary is also where a slot that fell free is noticed and
 // refilled: shorter (64 distinct pairs: 3 -> 2857, 4 -> 2917, 6 -> 2693, 8 -> 2621 registrations/s)
 static const int kEngineBatch = [] { const char *e = getenv("CVO_HIP_ENGINE_BATCH"); const int v = e ? atoi(e) : 4; return v >= 1 && v <= 64 ? v : 4; }();
-static const int kBatch = [] { const char *e = getenv("CVO_HIP_BATCH"); const int v = e ? atoi(e) : 6; return v >= 1 && v <= 64 ? v : 6; }();
+static const int kBatch = [] { const char *e = getenv("CVO_HIP_BATCH"); const int v = e ? atoi(e) : 8; return v >= 1 && v <= 64 ? v : 8; }();
 
 // The kernels of the loop read their argument blocks from a table of Slots in device memory
 // (cvo_device.h "Argument tables"): one slot for a registration on its own (cvo_hip_align), up
@@ -201,6 +203,7 @@ struct cvo_hip_ctx {
     DevState *st = nullptr;          // device
     DevState *st_host = nullptr;     // pinned [kPollSlots + 2]
     int32_t *done_mirror = nullptr;  // pinned (in the last slot): the post kernels copy `done` here
+    int32_t *progress_mirror = nullptr;   // pinned, next to it: slots the post-step kernel has completed
     std::vector<RecOp> *rec = nullptr;   // not null: record launches instead of issuing them
     int proc_blocks = PROC_BLOCKS;       // blocks of the list kernels (fewer in fused launches)
     int proc_blocks_default = PROC_BLOCKS;
@@ -879,6 +882,7 @@ int enqueue_step(cvo_hip_ctx *ctx, int check_done, bool do_math, cvo_hip_trace *
     pa.trace = trace; pa.trace_cap = trace_cap;
     pa.check_done = check_done;
     pa.done_mirror = ctx->done_mirror;
+    pa.progress_mirror = ctx->progress_mirror;
     pa.nblk = ctx->merge_twist ? ctx->proc_blocks / STEP_TWIST_ROWS_DIV : ctx->proc_blocks;
     pa.part_step = (const double *)ctx->part_step.p;
     pa.dbg = ctx->post_dbg;
@@ -1461,7 +1465,9 @@ int cvo_hip_create(int device, void *stream, const cvo_hip_params *p, cvo_hip_ct
         if (hipEventCreateWithFlags(&ctx->poll_ev[i], hipEventDisableTiming) != hipSuccess)
             return bail(CVO_HIP_ERR_HIP);
     ctx->done_mirror = reinterpret_cast<int32_t *>(&ctx->st_host[kPollSlots + 1]);
+    ctx->progress_mirror = ctx->done_mirror + 16;   // (its own cache line)
     *ctx->done_mirror = 0;
+    *ctx->progress_mirror = 0;
     // Stream capture is a process-wide affair in this runtime (cvo_lock.h): the library's own
     // entry points keep out of each other's captures, but HIP work of OTHER code in the process
     // (torch on another thread, say) cannot be kept out and would fail with "previous error
@@ -1876,6 +1882,7 @@ int job_begin(AlignJob &j)
         s->ell_max = p.ell_max_init;
     }
     *ctx->done_mirror = 0;
+    *ctx->progress_mirror = 0;
     if (!j.trace) j.trace_cap = 0;
     if (j.trace_cap > p.max_iter) j.trace_cap = p.max_iter;
     if (j.trace_cap > ctx->trace_dev_cap) {
@@ -1977,6 +1984,37 @@ int job_pump(AlignJob &j, bool block)
     if (j.phase == 2) return 1;
     auto finish_with = [&](int rc) { j.rc = rc; j.phase = 2; return 1; };
     if (hipSetDevice(ctx->device) != hipSuccess) return finish_with(CVO_HIP_ERR_HIP);
+    // Blocking caller, launches that need no host work in between: PACED mode.  The post-step
+    // kernel mirrors its slot count and `done` into pinned memory; this thread watches the two
+    // words and enqueues the next batch when the running one has finished -- not a whole batch
+    // ahead, which left a registration that converged with (on average) a batch and a half of
+    // queued launches to return one by one (~85 us of 1.7 ms, and the next frame's hand-over
+    // queues behind them).  The ~10 us the stream idles between two batches cost less than that
+    // (CVO_HIP_PACE_LEAD = slots of overlap, 0 / 1 / 2 / 3: 644 / 619 / 627 / 620 registrations/s at
+    // 10k x 10k, event-paced two batches ahead: 604).
+    static const bool no_pace = getenv("CVO_HIP_NO_PACE") != nullptr;
+    if (j.phase == 0 && block && !no_pace && !host_reduce(ctx) && !ctx->profiling) {
+        const int limit = (ctx->use_async ? 2 : 1) * ctx->prm.max_iter + 4 * kBatch;
+        for (;;) {
+            if (*(volatile int32_t *)ctx->done_mirror != RUNNING) break;
+            const int slots = *(volatile int32_t *)ctx->progress_mirror;
+            static const int lead = [] { const char *e = getenv("CVO_HIP_PACE_LEAD"); const int v = e ? atoi(e) : 0; return v >= 0 && v <= 64 ? v : 0; }();
+            if (j.enq - slots <= lead) {
+                if (j.enq >= limit) break;   // cannot happen
+                const int rc = launch_batch(ctx, j.executed_base + j.enq, j.trace_cap);
+                if (rc) return finish_with(rc);
+                j.enq += kBatch;
+                ++j.batches;
+            } else {
+                __builtin_ia32_pause();
+            }
+        }
+        if (hipMemcpyAsync(&ctx->st_host[0], ctx->st, sizeof(DevState), hipMemcpyDeviceToHost,
+                           ctx->stream) != hipSuccess ||
+            hipEventRecord(ctx->poll_ev[0], ctx->stream) != hipSuccess)
+            return finish_with(fail(ctx, CVO_HIP_ERR_HIP, "state copy failed"));
+        j.phase = 1;
+    }
     if (j.phase == 0) {
         bool stop = false;
         while (j.batches - j.checked < 2) {   // keep two batches queued
@@ -2049,6 +2087,10 @@ int job_pump(AlignJob &j, bool block)
         hipStreamSynchronize(ctx->stream) != hipSuccess)
         return finish_with(fail(ctx, CVO_HIP_ERR_HIP, "resume failed"));
     *ctx->done_mirror = 0;   // (the stream is idle: nothing can be writing it)
+    *ctx->progress_mirror = 0;
+    if (hipMemset(reinterpret_cast<char *>(ctx->st) + offsetof(DevState, n_slots), 0, sizeof(int32_t)) != hipSuccess ||
+        hipDeviceSynchronize() != hipSuccess)
+        return finish_with(fail(ctx, CVO_HIP_ERR_HIP, "resume failed"));
     launch_prepare(ctx->st, loop_params(ctx), ctx->stream);   // idempotent; re-zeroes the counters
     if (hipGetLastError() != hipSuccess) return finish_with(fail(ctx, CVO_HIP_ERR_HIP, "resume failed"));
     if (!ctx->profiling && !host_reduce(ctx)) {   // the lists moved: new arguments

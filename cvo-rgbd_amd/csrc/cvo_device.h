@@ -184,6 +184,7 @@ struct DevState {
     int32_t done;               // RUNNING, DONE_*, NEED_BIGGER_LIST
     int32_t iter;               // the reference's `iter` member
     int32_t n_exec;             // loop bodies executed
+    int32_t n_slots;            // post-step launches that did something (iterations + stall slots): the host paces its batches on it
     // entries appended to every sub-list (kept last: the host polls only the
     // part of the state in front of it)
     uint32_t sub[LIST_N][NSUB];
@@ -286,6 +287,8 @@ struct PostStepArgs {
     int check_done;
     long long *dbg;        // diagnostics only (CVO_HIP_POST_DEBUG): phase clocks of thread 0
     int32_t *done_mirror;  // see PostFlowArgs
+    int32_t *progress_mirror;   // optional host-visible copy of st->n_slots (pinned): lets the host enqueue the next
+                                // batch when the running one is down to its last slot instead of a whole batch ahead
     int nblk;
     const CommTable *comm; // see PostFlowArgs
     DevParams prm;

@@ -1368,7 +1368,14 @@ __device__ __forceinline__ void post_step_body(const PostStepArgs &a)
         }
     }
     __syncthreads();
-    if (threadIdx.x == 0 && a.done_mirror && s_st.done != RUNNING) *a.done_mirror = s_st.done;
+    if (threadIdx.x == 0) {
+        if (a.flags & POST_MATH) {
+            s_st.n_slots += 1;
+            if (a.progress_mirror) *a.progress_mirror = s_st.n_slots;
+        }
+        if (a.done_mirror && s_st.done != RUNNING) *a.done_mirror = s_st.done;
+    }
+    __syncthreads();
     state_head_from_lds(&s_st, a.st);
 }
 
