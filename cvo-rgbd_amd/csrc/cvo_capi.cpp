@@ -2393,8 +2393,9 @@ struct Engine {
             insert(j, z);
             moved = true;
         }
-        // keep two batches queued, look one batch behind
-        while (live() > 0 && launched - checked < 2) {
+        // batches kept queued per engine (the other engines fill the gap between two batches of this one)
+        static const long long depth = [] { const char *e = getenv("CVO_HIP_ENGINE_DEPTH"); const int v = e ? atoi(e) : 2; return (long long)(v >= 1 && v <= 3 ? v : 2); }();
+        while (live() > 0 && launched - checked < depth) {
             if (dirty) {
                 const int rc = replan();
                 if (rc) { fail_all("fused launch recording failed", pending); return true; }
