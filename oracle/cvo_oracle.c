@@ -32,6 +32,13 @@ int cvo_oracle_get_threads(void)
 
 static int nthreads(void) { return cvo_oracle_get_threads(); }
 
+/* Arithmetic variants for the deviation study (tests/test_oracle_variants.py): the places
+ * where this file fixes ONE of several readings the reference's compiled arithmetic admits.
+ * 0 = the contract the HIP path is held to. */
+static unsigned g_variant = 0;
+void cvo_oracle_set_variant(unsigned flags) { g_variant = flags; }
+unsigned cvo_oracle_get_variant(void) { return g_variant; }
+
 /* ------------------------------------------------------------------------ */
 /* parameters: ref src/cvo.cpp:18-48, src/adaptive_cvo.cpp:18-50             */
 /* ------------------------------------------------------------------------ */
@@ -138,6 +145,8 @@ static inline void cross3(const float *a, const float *b, float *out)
 static inline float d2_pos(const float *a, const float *b)
 {
     const float d0 = a[0] - b[0], d1 = a[1] - b[1], d2 = a[2] - b[2];
+    if (g_variant & CVO_ORACLE_VAR_D2_PLAIN)      /* no contraction: ((d0^2 + d1^2) + d2^2) */
+        return (d0 * d0 + d1 * d1) + d2 * d2;
     return fmaf(d2, d2, fmaf(d1, d1, d0 * d0));
 }
 
@@ -558,6 +567,69 @@ void cvo_oracle_free(void *p) { free(p); }
 /* compute_flow (ref src/cvo.cpp:164-210, src/adaptive_cvo.cpp:154-272)      */
 /* rows [r0,r1) of x; CSR is local to that row range                         */
 /* ------------------------------------------------------------------------ */
+/* The literal reading of ref src/cvo.cpp:197-198: per row i, `1/c*Ai` is a float row vector,
+ * `(1/c*Ai)*cross_xy` a FLOAT 1 x k by k x 3 product, cast to double only afterwards, and the
+ * rows are added in double in whatever order the TBB workers take the lock (here: row order).
+ * Eigen evaluates the product as three dot products; the order inside one is the compiler's:
+ *   ROWSUM_SEQ     one accumulator, plain multiply-add in column order;
+ *   ROWSUM_PACKET  eight lanes (AVX packets) of fused multiply-adds over columns j = l mod 8,
+ *                  a scalar tail, lanes reduced pairwise -- the shape of Eigen's vectorised redux.
+ * Deviation study only; the dl terms (acvo) keep the float64 per-pair sum. */
+static float rowdot_f32(const float *a, const float *b, int k, int packet)
+{
+    if (!packet) {
+        float s = 0;
+        for (int j = 0; j < k; ++j) s = s + a[j] * b[j];
+        return s;
+    }
+    float lane[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const int kv = k & ~7;
+    for (int j = 0; j < kv; j += 8)
+        for (int l = 0; l < 8; ++l) lane[l] = fmaf(a[j + l], b[j + l], lane[l]);
+    float s = ((lane[0] + lane[4]) + (lane[2] + lane[6])) + ((lane[1] + lane[5]) + (lane[3] + lane[7]));
+    for (int j = kv; j < k; ++j) s = fmaf(a[j], b[j], s);
+    return s;
+}
+
+static void flow_rows_f32(const cvo_oracle_params *p, float ell, const float *x, int r0, int r1,
+                          const float *y, const int64_t *row_ptr, const int32_t *col,
+                          const float *val, double out[8])
+{
+    const float inv_c = 1 / p->c, inv_d = 1 / p->d;
+    const float ell_3 = ell * ell * ell, inv_l3 = 1 / ell_3;
+    const int packet = (g_variant & CVO_ORACLE_VAR_ROWSUM_PACKET) != 0;
+    double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int64_t kmax = 1;
+    for (int ri = 0; ri < r1 - r0; ++ri)
+        if (row_ptr[ri + 1] - row_ptr[ri] > kmax) kmax = row_ptr[ri + 1] - row_ptr[ri];
+    float *buf = (float *)malloc((size_t)kmax * 8 * sizeof(float));
+    float *ac = buf, *ad = buf + kmax, *cr = buf + 2 * kmax, *df = buf + 5 * kmax;
+    for (int ri = 0; ri < r1 - r0; ++ri) {
+        const float *xi = x + 3 * (r0 + ri);
+        const int k = (int)(row_ptr[ri + 1] - row_ptr[ri]);
+        for (int j = 0; j < k; ++j) {
+            const int64_t q = row_ptr[ri] + j;
+            const float *yj = y + 3 * col[q];
+            float c3[3];
+            cross3(xi, yj, c3);
+            ac[j] = inv_c * val[q];
+            ad[j] = inv_d * val[q];
+            for (int a = 0; a < 3; ++a) {                 /* column-major k x 3 */
+                cr[a * kmax + j] = c3[a];
+                df[a * kmax + j] = yj[a] - xi[a];
+            }
+            acc[6] += (double)val[q];
+            acc[7] += (double)((inv_l3 * val[q]) * d2_pos(xi, yj));
+        }
+        for (int a = 0; a < 3; ++a) {
+            acc[a] += (double)rowdot_f32(ac, cr + a * kmax, k, packet);
+            acc[3 + a] += (double)rowdot_f32(ad, df + a * kmax, k, packet);
+        }
+    }
+    free(buf);
+    memcpy(out, acc, sizeof(acc));
+}
+
 static void flow_rows(const cvo_oracle_params *p, float ell, const float *x, int r0, int r1,
                       const float *y, const int64_t *row_ptr, const int32_t *col,
                       const float *val, double out[8])
@@ -567,6 +639,10 @@ static void flow_rows(const cvo_oracle_params *p, float ell, const float *x, int
     const float inv_l3 = 1 / ell_3;
     double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     const int nrows = r1 - r0;
+    if (g_variant & (CVO_ORACLE_VAR_ROWSUM_SEQ | CVO_ORACLE_VAR_ROWSUM_PACKET)) {
+        flow_rows_f32(p, ell, x, r0, r1, y, row_ptr, col, val, out);
+        return;
+    }
 #pragma omp parallel num_threads(nthreads())
     {
         double w[3] = {0, 0, 0}, vv[3] = {0, 0, 0}, sa = 0, sad2 = 0;

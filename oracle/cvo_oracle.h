@@ -109,6 +109,14 @@ void cvo_oracle_init_state(const cvo_oracle_params *p, cvo_oracle_state *s);
 void cvo_oracle_set_threads(int n);   /* 0 = OpenMP default */
 int  cvo_oracle_get_threads(void);
 
+/* Deviation study (tests/test_oracle_variants.py): re-run the oracle with another admissible
+ * reading of the reference's arithmetic.  0 = the contract (the default, what HIP is held to). */
+#define CVO_ORACLE_VAR_ROWSUM_SEQ    1u   /* flow: per-row FLOAT product, one accumulator (cvo.cpp:197-198) */
+#define CVO_ORACLE_VAR_ROWSUM_PACKET 2u   /* flow: per-row FLOAT product, 8-lane FMA redux */
+#define CVO_ORACLE_VAR_D2_PLAIN      4u   /* squared distance without FMA contraction */
+void cvo_oracle_set_variant(unsigned flags);
+unsigned cvo_oracle_get_variant(void);
+
 /* Thresholds (cvo.cpp:102-103): tau[0] = d2_thres, tau[1] = d2_c_thres. */
 void cvo_oracle_thresholds(const cvo_oracle_params *p, float ell, float tau[2]);
 

@@ -157,6 +157,15 @@ def set_threads(n):
     lib().cvo_oracle_set_threads(int(n))
 
 
+VAR_ROWSUM_SEQ, VAR_ROWSUM_PACKET, VAR_D2_PLAIN = 1, 2, 4
+
+
+def set_variant(flags):
+    """Deviation study only (tests/test_oracle_variants.py); 0 = the contract."""
+    lib().cvo_oracle_set_variant.argtypes = [C.c_uint]
+    lib().cvo_oracle_set_variant(int(flags))
+
+
 def get_threads():
     return lib().cvo_oracle_get_threads()
 
