@@ -29,9 +29,14 @@ for B in BS:
     its, _ = step()
     torch.cuda.synchronize()
     t = time.perf_counter()
+    per = []
     for _ in range(reps):
+        t1 = time.perf_counter()
         its, states = step()
+        per.append((time.perf_counter() - t1) * 1e3)   # (align_many returns with every registration finished)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t
+    if os.environ.get("PER_STEP"):
+        print("   per step ms:", " ".join("%.2f" % x for x in per))
     print("B %2d: %.1f registrations/s (%.2f ms per batch, iters %s, mean %.1f, %.2f us per registration-iteration)" % (B, B * reps / dt, dt * 1e3 / reps, its[:3], float(np.mean(its)), dt * 1e6 / reps / max(1, int(np.sum(its)))))
     for c in ctxs: c.close()
