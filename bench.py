@@ -8,7 +8,7 @@ pair i >= 1 has seed 1000 + i -- each run through a full align()
 (ref src/cvo.cpp:361-420: 43-102 gradient-flow iterations, each = transform + all-pairs
 neighbour filter + flow pass + step-size pass) from the reference object's initial state,
 all clouds already resident in HBM, all registrations of the batch handed to ONE
-cvo_hip_align_many call (three engines of 16 slots each share the GPU; a slot's registration
+cvo_hip_align_many call (three engines of up to 32 slots each share the GPU; a slot's registration
 is one blockIdx.z slice of every kernel launch of its engine; a slot that falls free takes
 the next pair of the batch -- continuous batching).  `value` = registrations completed per second.  Side legs of the same run
 (rank 0, N = 1; none of them inside the timed region): the same batch size with copies of
@@ -176,7 +176,7 @@ def main():
                 "pairs_per_sweep": float(n) * m,
                 "batch": B, "distinct_pairs": not args.identical,
                 "iterations_per_registration_min_max": [int(min(last_its)), int(max(last_its))],
-                "parallelism": "%d registrations per align_many call per GPU: up to 3 engines x 16 slots share their "
+                "parallelism": "%d registrations per align_many call per GPU: 3 engines x 21-22 of 32 slots share their "
                                "kernel launches (blockIdx.z = slot), slots refilled from the batch as registrations stop" % B,
                 "graph_capture": "opted in (single-threaded process; default is eager on a caller's stream)",
             },

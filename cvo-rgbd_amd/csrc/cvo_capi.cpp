@@ -2125,12 +2125,12 @@ EngineProfile *engine_profile()
     return p;
 }
 
-// A fused group as a long-lived engine: a stream, a table of MAXG slots and the batches
+// A fused group as a long-lived engine: a stream, a table of ENGINE_SLOTS slots and the batches
 // captured for it, all of which outlive the cvo_hip_align_many call that uses them.
 // Registrations enter a free slot and leave it when they stop -- by stream-ordered copies into
 // the table, between two batches of iterations: nothing is drained, nothing is captured again
 // (continuous batching).  Slots are kept packed at the low end; the launches serve
-// zdim = 1, 2, 4, 8 or 16 slots, the list kernels getting more blocks per registration the
+// zdim = 1, 2, 4, 8, 16, 24 or 32 slots, the list kernels getting more blocks per registration the
 // fewer share the launch.  One host thread keeps several engines in flight: while one group
 // sits in its single-block post kernels or between two kernels, the other one has the GPU.
 struct Engine {
@@ -2141,9 +2141,9 @@ struct Engine {
     bool in_use = false;
 
     // state of the call in progress
-    AlignJob *member[MAXG] = {};
-    std::vector<RecOp> ops[MAXG];
-    Slot slot[MAXG];
+    AlignJob *member[ENGINE_SLOTS] = {};
+    std::vector<RecOp> ops[ENGINE_SLOTS];
+    Slot slot[ENGINE_SLOTS];
     struct Retire { hipEvent_t ev = nullptr; std::vector<AlignJob *> jobs; };
     std::vector<Retire> retiring;          // their final state is on its way to the host
     hipEvent_t ev[4] = {};
@@ -2162,7 +2162,7 @@ struct Engine {
         device = dev;
         if (hipSetDevice(dev) != hipSuccess) return -1;
         if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) return -1;
-        if (tab.init(MAXG, s) != 0) return -1;
+        if (tab.init(ENGINE_SLOTS, s) != 0) return -1;
         for (auto &e : ev)
             if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return -1;
         return 0;
@@ -2180,7 +2180,7 @@ struct Engine {
         }();
         // (a multiple of 32 that divides or is a multiple of NSUB: 64, 128, 256, 512, 1024)
         int nblk = 64;
-        while (nblk < PROC_BLOCKS && nblk * 2 <= budget / std::max(1, z)) nblk *= 2;
+        while (nblk < PROC_BLOCKS && nblk * 2 <= (budget + z / 2) / std::max(1, z)) nblk *= 2;
         return nblk;
     }
 
@@ -2208,7 +2208,7 @@ struct Engine {
         retiring.clear();
         for (AlignJob *j : pending) { j->rc = fail(j->ctx, CVO_HIP_ERR_HIP, msg); j->phase = 2; }
         pending.clear();
-        for (int z = 0; z < MAXG; ++z) slot[z].active = 0;
+        for (int z = 0; z < ENGINE_SLOTS; ++z) slot[z].active = 0;
         (void)tab.sync(slot, s, 0);
         (void)hipStreamSynchronize(s);
         launched = checked = 0;
@@ -2252,16 +2252,17 @@ struct Engine {
         return CVO_HIP_OK;
     }
 
-    // membership changed: pick zdim (1, 2, 4, 8, 16 >= the members), bring the members that sit
+    // membership changed: pick zdim (1, 2, 4, 8, 16, 24, 32 >= the members), bring the members that sit
     // above it down into free slots (the others stay where they are: a slot that moves is a slot
     // that has to be sent again), (re)record what needs it, make the plan, send what changed
     int replan()
     {
         int n = 0;
-        for (int z = 0; z < MAXG; ++z) n += member[z] != nullptr;
+        for (int z = 0; z < ENGINE_SLOTS; ++z) n += member[z] != nullptr;
         int zd = 1;
         while (zd < n) zd *= 2;
-        for (int z = MAXG - 1, hole = 0; z >= zd; --z) {
+        if (n > 16 && n <= 24) zd = 24;   // (three engines sharing 64 registrations hold 21 or 22 each)
+        for (int z = ENGINE_SLOTS - 1, hole = 0; z >= zd; --z) {
             if (!member[z]) continue;
             while (member[hole]) ++hole;
             member[hole] = member[z]; member[z] = nullptr;
@@ -2273,7 +2274,7 @@ struct Engine {
         static const int merge_max = [] { const char *e = getenv("CVO_HIP_MERGE_MAXG"); return e ? atoi(e) : 2; }();
         std::vector<const std::vector<RecOp> *> po;
         std::vector<Slot *> ps;
-        for (int z = 0; z < MAXG; ++z) {
+        for (int z = 0; z < ENGINE_SLOTS; ++z) {
             if (!member[z]) { slot[z].active = 0; continue; }
             cvo_hip_ctx *c = member[z]->ctx;
             if (regeom || ops[z].empty()) {
@@ -2303,7 +2304,7 @@ struct Engine {
     void collect_stopped()
     {
         Retire r;
-        for (int z = 0; z < MAXG; ++z) {
+        for (int z = 0; z < ENGINE_SLOTS; ++z) {
             AlignJob *j = member[z];
             if (!j || *(volatile int32_t *)j->ctx->done_mirror == RUNNING) continue;
             if (hipMemcpyAsync(&j->ctx->st_host[0], j->ctx->st, sizeof(DevState), hipMemcpyDeviceToHost, s) != hipSuccess) {
@@ -2385,7 +2386,7 @@ struct Engine {
         }
         if (finish_arrived(pending, false)) moved = true;
         // free slots take the next registrations
-        while (!pending.empty() && live() < std::min(want, (int)MAXG)) {
+        while (!pending.empty() && live() < std::min(want, (int)ENGINE_SLOTS)) {
             AlignJob *j = pending.front();
             pending.pop_front();
             int z = 0;
@@ -2530,8 +2531,8 @@ int cvo_hip_align_many(cvo_hip_ctx **ctxs, cvo_hip_state **states, int *n_iters,
     if (!no_fuse && count > 1) {
         static const int gmax = [] {
             const char *e = getenv("CVO_HIP_GROUP");
-            const int v = e ? atoi(e) : MAXG;
-            return std::min((int)MAXG, std::max(2, v));
+            const int v = e ? atoi(e) : ENGINE_SLOTS;
+            return std::min((int)ENGINE_SLOTS, std::max(2, v));
         }();
         for (int i = 0; i < count; ++i) {
             if (taken[i] || jobs[i].phase != 0 || !fusable(jobs[i].ctx)) continue;
@@ -2545,12 +2546,15 @@ int cvo_hip_align_many(cvo_hip_ctx **ctxs, cvo_hip_state **states, int *n_iters,
             for (AlignJob *j : pending) taken[j - &jobs[0]] = 1;
             const size_t total = pending.size();
             // how many engines share the GPU: one group alone leaves it idle in its single-block post
-            // kernels and at every kernel boundary; two fill each other's bubbles (32 pairs: 1409 ->
-            // 2410 registrations/s); a third pays once there are enough jobs to keep three groups
-            // well filled (64 distinct pairs: 2345 -> 2940; 32: 11 per group, no gain); four lose
-            static const size_t max_engines = [] { const char *e = getenv("CVO_HIP_ENGINES"); const int v = e ? atoi(e) : 3; return (size_t)std::max(1, std::min(v, 8)); }();
-            size_t ngroups = total >= 40 ? 3 : (total >= 8 ? 2 : 1);
+            // kernels and at every kernel boundary; two fill each other's bubbles (32 pairs: 2079 ->
+            // 2428 registrations/s; three: 2273); a third pays once there are enough jobs to keep three
+            // groups well filled (64 distinct pairs in engines of 32 slots: 2 x 32 2897, 3 x 22 3149,
+            // 4 x 16 2822); a fourth when three tables cannot hold every job at once (128 pairs:
+            // 3 x 32 and 32 waiting 3297, 4 x 32 3644 -- the longest registration starts at once)
+            static const size_t max_engines = [] { const char *e = getenv("CVO_HIP_ENGINES"); const int v = e ? atoi(e) : 4; return (size_t)std::max(1, std::min(v, 8)); }();
+            size_t ngroups = total > 3 * ENGINE_SLOTS ? 4 : (total >= 40 ? 3 : (total >= 8 ? 2 : 1));
             ngroups = std::max<size_t>(1, std::min(ngroups, max_engines));
+            if (const char *e = getenv("CVO_HIP_ENGINES_FORCE")) ngroups = (size_t)std::max(1, std::min(atoi(e), 8));   // (tuning probe)
             bool graphs_ok = true;   // (capture policy: cvo_hip_set_graph_capture)
             for (AlignJob *j : pending) graphs_ok = graphs_ok && j->ctx->use_graphs;
             // Asynchronous xy builds shorten the launch chain of a registration; once the GPU is

@@ -204,6 +204,7 @@ constexpr size_t DEVSTATE_HEAD_BYTES = offsetof(DevState, sub);
 // bound at 10k x 10k, so G registrations per launch cost little more than one.
 constexpr int MAXG = 16;
 template <class A> struct Grp { A a[MAXG]; };
+constexpr int ENGINE_SLOTS = 32;   // slots of an engine's argument table (the by-value groups above stop at MAXG)
 
 // Dense pair filter: rows [row_lo,row_hi) of cloud a against all of cloud b.
 struct FilterArgs {

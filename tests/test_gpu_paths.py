@@ -697,19 +697,20 @@ def test_ranks_in_separate_processes_through_ipc_mailboxes(mode_name):
     assert "mailbox ipc world 2: OK" in r.stdout
 
 
-@pytest.mark.parametrize("graphs", [True, False])
-def test_align_many_refills_its_slots_from_the_queue(pkg, monkeypatch, graphs):
-    """Continuous batching: 44 registrations of very different lengths (max_iter 3 ... 60, sizes
-    300 ... 2400) in ONE call -- more than the two engines hold (2 x 16 slots), so slots are
-    refilled from the queue while their neighbours keep running; a tiny list start size makes some
-    of them park for a bigger list and resume on the way.  Every result equals the registration
-    run on its own, bit for bit; with captured batches and with eager table launches."""
+@pytest.mark.parametrize("graphs,jobs", [(True, 44), (False, 44), (True, 70), (True, 110)])
+def test_align_many_refills_its_slots_from_the_queue(pkg, monkeypatch, graphs, jobs):
+    """Continuous batching: 44 / 70 / 110 registrations of very different lengths (max_iter 3 ... 60,
+    sizes 300 ... 2400) in ONE call -- three engines of 15, of 24 (launches of 24 slots) and of 32
+    slots with 14 left in the queue -- so slots are refilled from the queue while their neighbours
+    keep running; a tiny list start size makes some of them park for a bigger list and resume on
+    the way.  Every result equals the registration run on its own, bit for bit; with captured
+    batches and with eager table launches."""
     import torch
     capi = pkg.capi
     monkeypatch.setenv("CVO_HIP_LIST_INIT", "30000")
     rng = np.random.default_rng(12)
     ctxs, ref, keep = [], [], []
-    for i in range(44):
+    for i in range(jobs):
         n, m = int(rng.integers(300, 2400)), int(rng.integers(300, 2400))
         xf, ff, xm, fm = pkg.data.synthetic_pair(n, m, seed=300 + i)
         prm = capi.default_params(capi.MODE_CVO)
