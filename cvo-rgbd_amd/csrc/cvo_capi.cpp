@@ -2156,7 +2156,7 @@ struct Engine {
     std::vector<FlowEv> flow_ev;           // engine profiling: one pair per flow-pass launch
     // diagnostics (CVO_HIP_ENGINE_DEBUG)
     long long n_batches[5] = {}, n_replans = 0, n_inserts = 0, n_sends = 0;
-    double t_replan = 0, t_insert = 0, t_launch = 0, t_finish = 0, t_wait = 0, t_collect = 0;
+    double t_replan = 0, t_insert = 0, t_launch = 0, t_finish = 0, t_wait = 0, t_collect = 0, t_idle_at = 0;
     static double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
     int create(int dev)
@@ -2582,6 +2582,7 @@ int cvo_hip_align_many(cvo_hip_ctx **ctxs, cvo_hip_state **states, int *n_iters,
                 e->crowded = (int)total > crowd;
                 e->use_graph = graphs_ok;
                 e->zdim = 0;
+                e->t_idle_at = 0;
                 e->dirty = true;
                 engines.push_back(e);
             }
@@ -2596,6 +2597,10 @@ int cvo_hip_align_many(cvo_hip_ctx **ctxs, cvo_hip_state **states, int *n_iters,
                 for (Engine *e : engines) {
                     if (e->pump(pending, share)) moved = true;
                     if (!e->idle()) any = true;
+                    else if (dbg_many && e->t_idle_at == 0) {
+                        e->t_idle_at = Engine::now_ms();
+                        fprintf(stderr, "[cvo_hip]   engine %p idle after %.2f ms\n", (void *)e, e->t_idle_at - t_many0);
+                    }
                 }
                 if (!any && pending.empty()) break;
                 bool alive = false;
