@@ -814,7 +814,7 @@ __device__ __forceinline__ void process_body(const ProcessArgs &a, const unsigne
                     (unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)mine.z, k) |
                     ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)mine.w, k) << 32);
                 const unsigned r = ty >> 30, tcol = ty & 0x3fffffffu;
-                if ((m >> lane) & 1ull) {
+                if (__builtin_amdgcn_inverse_ballot_w64(m)) {   // the mask IS the set of lanes that act: no per-lane test
                     const unsigned below = __builtin_amdgcn_mbcnt_hi(
                         (unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
                     pairq[qn + below] =

@@ -9,6 +9,8 @@ import __graft_entry__ as ge
 
 pkg = ge.load_package()
 capi = pkg.capi
+if os.environ.get("CVO_LIB"):   # A/B of two builds in one session: a second library next to the built one
+    capi.LIB_PATH = os.path.join(os.path.dirname(capi.LIB_PATH), os.environ["CVO_LIB"])
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 BS = [int(x) for x in sys.argv[3].split(",")] if len(sys.argv) > 3 else [1, 2, 4, 8, 16]
