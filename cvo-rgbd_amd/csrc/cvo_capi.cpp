@@ -222,6 +222,7 @@ struct cvo_hip_ctx {
     bool have_xy_build = false;
     bool allow_async = true;
     bool crowded = false;                // set by align_many: many registrations share the launches
+    DevBuf pos_bt;                       // crowded: the moving cloud under the iteration's transform (FilterArgs::pos_bt)
     bool lone = true;                    // this registration has its launches to itself
     bool allow_async_self = true;
     bool use_async_self = false;         // acvo, lone: self lists built ahead, PROC_SELF in the flow launch
@@ -545,6 +546,14 @@ bool multi_rank(const cvo_hip_ctx *ctx);
 DevParams loop_params(const cvo_hip_ctx *ctx);
 hipStream_t loop_stream(const cvo_hip_ctx *ctx);
 
+// Members of a crowded engine: the xy filter launch of an iteration (recorded, a launch of its
+// own there) also writes the transformed moving cloud, and the list passes read that.
+bool pre_transform(const cvo_hip_ctx *ctx)
+{
+    static const bool off = getenv("CVO_HIP_NO_PRETF") != nullptr;
+    return !off && ctx->crowded && ctx->rec && ctx->in_loop && !ctx->use_async;
+}
+
 // The dense all-pairs filter of one list (with optional HIP-event bracket: this
 // is the kernel the roofline is quoted on).
 int enqueue_filter(cvo_hip_ctx *ctx, int list, const Cloud &ca, int row_lo, int row_hi, int tf_a,
@@ -569,6 +578,11 @@ int enqueue_filter(cvo_hip_ctx *ctx, int list, const Cloud &ca, int row_lo, int 
     a.tf_a = tf_a; a.tf_b = tf_b;
     a.check_done = check_done;
     a.gx = (int)pl.grid.x; a.gy = (int)pl.grid.y;
+    if (pre_transform(ctx) && list == LIST_XY && tf_b && !tf_a && cb.pos == ctx->moving.pos) {
+        rc = ensure_buf(ctx, ctx->pos_bt, (size_t)cb.np * sizeof(float4));
+        if (rc) return rc;
+        a.pos_bt = (float4 *)ctx->pos_bt.p;
+    }
     const bool side = list == LIST_XY && ctx->in_loop && ctx->use_async;
     if (side) {   // build beside the flow pass, into the buffer the plan step named
         rc = ensure_list(ctx, LIST_XYB, 0, 0, (double)ctx->lists[LIST_XY].cap);
@@ -646,7 +660,12 @@ int enqueue_process(cvo_hip_ctx *ctx, int mode, int list, DevBuf &part, const fl
     a.list = list;
     a.first_counted = first_counted;
     a.tf_a = tf_a; a.tf_b = tf_b;
+    if (pre_transform(ctx) && ctx->pos_bt.p) {   // (written by this iteration's xy filter launch)
+        if (tf_b && pos_b == ctx->moving.pos) { a.pos_b = (const float4 *)ctx->pos_bt.p; a.tf_b = 0; }
+        if (tf_a && pos_a == ctx->moving.pos) { a.pos_a = (const float4 *)ctx->pos_bt.p; a.tf_a = 0; }   // acvo: the yy pass
+    }
     a.check_done = check_done;
+    a.need_d2 = (ctx->prm.mode == CVO_HIP_MODE_ACVO || !ctx->in_loop) ? 1 : 0;
     a.weight = ctx->prm.color_scale > 0.0f ? 1 : 0;   // the MATLAB object's weight: its own instantiation
     static const bool no_pack = getenv("CVO_HIP_NO_PACK") != nullptr;
     a.kept_packed = (!no_pack && ctx->fixed.np <= 65536 && ctx->moving.np <= 65536) ? 1 : 0;
@@ -1526,7 +1545,7 @@ int cvo_hip_destroy(cvo_hip_ctx *ctx)
                     (void *)ctx->moving.feat, (void *)ctx->fixed.seg, (void *)ctx->moving.seg,
                     (void *)ctx->scratch_a.pos, (void *)ctx->scratch_a.feat, (void *)ctx->scratch_a.seg,
                     (void *)ctx->scratch_b.pos, (void *)ctx->scratch_b.feat, (void *)ctx->scratch_b.seg, (void *)ctx->st, ctx->part_flow.p, ctx->part_xx.p,
-                    ctx->part_yy.p, ctx->part_step.p, (void *)ctx->trace_dev, ctx->kept_cnt.p})
+                    ctx->part_yy.p, ctx->part_step.p, (void *)ctx->trace_dev, ctx->kept_cnt.p, ctx->pos_bt.p})
         if (p) (void)hipFree(p);
     for (int l = 0; l < LIST_N; ++l) {
         if (ctx->lists[l].a.p) (void)hipFree(ctx->lists[l].a.p);
@@ -2181,7 +2200,8 @@ struct Engine {
             return v >= 64 ? v : 2048;
         }();
         // (a multiple of 32 that divides or is a multiple of NSUB: 64, 128, 256, 512, 1024)
-        int nblk = 64;
+        static const int nmin = [] { const char *e = getenv("CVO_HIP_PROC_MIN"); const int v = e ? atoi(e) : 64; return (v == 8 || v == 16 || v == 32) ? v : 64; }();
+        int nblk = nmin;
         while (nblk < PROC_BLOCKS && nblk * 2 <= (budget + z / 2) / std::max(1, z)) nblk *= 2;
         return nblk;
     }

@@ -225,6 +225,8 @@ struct FilterArgs {
     int check_done;        // return at once when st->done != 0
     int gx, gy;            // this registration's own grid (a fused launch may be larger)
     long long *dbg;        // probe only (tools/microbench): per-wave phase clocks, else null
+    float4 *pos_bt;        // crowded engines: this launch also leaves [Rt|t] pos_b (all nb rows, .w kept) here for
+                           // the list passes of the iteration, which then skip the transform per pair (else null)
 };
 
 // Exact evaluation of a tile list (PROC_FLOW, PROC_SELF) or of the kept list (PROC_STEP).
@@ -258,6 +260,7 @@ struct ProcessArgs {
     int tf_a, tf_b;
     int check_done;
     int weight;            // PROC_FLOW: 0 the C++ pair weight, 1 the MATLAB object's (classic launches only)
+    int need_d2;           // PROC_FLOW: accumulate sum (1/l^3 a) d2 (acvo's dl term; cvo_hip_flow reports it for both modes)
     int kept_packed;       // both clouds have <= 65536 rows: a kept entry is 8 bytes (i | j << 16, weight bits)
                            // in kept_ij alone instead of 8 + 4 -- the kept list is the largest HBM stream of a
                            // batched run (written by every flow pass, read back by the step pass)

@@ -120,6 +120,23 @@ __device__ __forceinline__ void flush_tiles(const TileEntry *stage, int n, int l
         atomicOr(&a.st->cnt[2 * list + 1], 1u);   // overflow: the host grows the list and resumes
 }
 
+// transform_pcd as a pass of its own (ref cvo.cpp:310-315), for the launches that many registrations
+// share: the moving cloud under the iteration's [Rt|t], once per point instead of once per pair in
+// the flow and step passes (18 VALU operations per 64 pairs in each).  Same arithmetic, same values.
+__device__ __forceinline__ void pretransform_body(const FilterArgs &a, const unsigned bid, const unsigned nblocks)
+{
+    if (!a.pos_bt) return;
+    if (a.check_done && a.st->done != 0) return;
+    const float *Rt = a.st->Rt;
+    const float *tt = a.st->t;
+    for (unsigned j = bid * BLOCK + threadIdx.x; j < (unsigned)a.nb; j += nblocks * BLOCK) {
+        const float4 y0 = a.pos_b[j];
+        float4 y = apply_tf(Rt, tt, y0);
+        y.w = y0.w;
+        a.pos_bt[j] = y;
+    }
+}
+
 __device__ __forceinline__ void filter_body(const FilterArgs &a, const unsigned bid, const unsigned nblocks)
 {
     // Persistent blocks: the (column chunk, row tile) items of this registration's
@@ -640,8 +657,8 @@ __device__ __forceinline__ float eval_pair(const ProcessArgs &a, const KernConst
         acc[4] += (double)(ad * f1);
         acc[5] += (double)(ad * f2);
         acc[6] += (double)w;
-        acc[7] += (double)((kc.inv_l3 * w) * d2);
-        acc[8] += 1.0;
+        if (a.need_d2) acc[7] += (double)((kc.inv_l3 * w) * d2);   // (the acvo dl term: nobody reads it inside a cvo loop)
+        // (acc[8], the number of members: counted per wave by the caller, not per pair here)
     } else if (MODE == PROC_STEP) {
         // Taylor vectors of y_j (ref cvo.cpp:226-238), for members of A only
         float xiz[3], xi2z[3], xi3z[3], xi4z[3];
@@ -676,7 +693,7 @@ __device__ __forceinline__ float eval_pair(const ProcessArgs &a, const KernConst
                        1 / 24.0 * b * b * b * b);
     } else {
         if (row_index >= first_counted) acc[0] += (double)((kc.inv_l3 * w) * d2);
-        acc[1] += 1.0;
+        // (acc[1], the number of members: counted per wave by the caller)
     }
     return w;
 }
@@ -768,6 +785,7 @@ __device__ __forceinline__ void process_body(const ProcessArgs &a, const unsigne
                 pr = pairq[base + lane];
                 w = eval_pair<MODE, WEIGHT>(a, kc, pr.x, pr.y, 0.0f, acc, a.st->xi, s_etab, first_counted);   // (xi: PROC_STEP only)
             }
+            if (MODE == PROC_SELF) nk += (unsigned)__popcll(__ballot(w > 0.0f));   // (scalar: the member count)
             if (MODE == PROC_FLOW) {   // record the members of A in this wave's slice
                 const unsigned long long km = __ballot(w > 0.0f);
                 const unsigned add = (unsigned)__popcll(km);
@@ -831,6 +849,8 @@ __device__ __forceinline__ void process_body(const ProcessArgs &a, const unsigne
         }   // sub-lists of this block
         if (qn > 0) run_batch(0, qn);
         if (MODE == PROC_FLOW && lane == 0) a.kept_cnt[wave] = nk;
+        // the member count of the wave joins the sums (one lane holds it; a slice that overflowed still counts)
+        if (lane == 0) acc[MODE == PROC_FLOW ? 8 : 1] = (double)nk;
     }
 
     // block reduction: reduce-scatter inside each wave, then the 4 waves in order
@@ -1534,6 +1554,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(6, 8
 kt_filter(const Slot *__restrict__ tab, const int q)
 {
     CVO_SLOT(tab);
+    pretransform_body(CVO_ARG(FilterArgs, op[q].f), blockIdx.x, gridDim.x);
     filter_body(CVO_ARG(FilterArgs, op[q].f), blockIdx.x, gridDim.x);
 }
 
@@ -1542,6 +1563,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(6, 8
 kt_filter_group(const Slot *__restrict__ tab, const int q)
 {
     CVO_SLOT(tab);
+    if (blockIdx.y == 0) pretransform_body(CVO_FILTER_ROLE(0), blockIdx.x, gridDim.x);
     filter_body(CVO_FILTER_ROLE((int)blockIdx.y), blockIdx.x, gridDim.x);
 }
 
