@@ -608,6 +608,18 @@ template <> struct NAcc<PROC_FLOW> { static constexpr int n = NACC_FLOW; };
 template <> struct NAcc<PROC_STEP> { static constexpr int n = NACC_STEP; };
 template <> struct NAcc<PROC_SELF> { static constexpr int n = NACC_SELF; };
 
+// x / 6.0, correctly rounded, in three operations instead of the division sequence (~12): with
+// c = RN(1/6), q0 = x c, r = x - 6 q0 (exact in one fma), the quotient is q0 + r / 6 exactly, and
+// RN(q0 + r c) differs from it by less than 2^-53 ulp -- while x / 6 = (x / 2) / 3 is never closer
+// than 1/6 ulp to a rounding boundary (thirds), so both round to the same double.  (Finite x.)
+__device__ __forceinline__ double div6(double x)
+{
+    const double c = 0x1.5555555555555p-3;
+    const double q0 = x * c;
+    const double r = __builtin_fma(-6.0, q0, x);
+    return __builtin_fma(r, c, q0);
+}
+
 // One pair of the exact pass.  PROC_FLOW / PROC_SELF: membership test of
 // se_kernel (ref cvo.cpp:125-152) and the flow / self sums; returns the weight
 // (0 = not in A).  PROC_STEP: `w` is the recorded weight of a member of A.
@@ -688,7 +700,7 @@ __device__ __forceinline__ float eval_pair(const ProcessArgs &a, const KernConst
         const double b = (double)beta, g = (double)gamma;
         acc[0] += (double)(w * beta);
         acc[1] += A * (g + (double)(beta * beta) / 2.0);
-        acc[2] += A * ((double)(delta + beta * gamma) + (double)(beta * beta * beta) / 6.0);
+        acc[2] += A * ((double)(delta + beta * gamma) + div6((double)(beta * beta * beta)));
         acc[3] += A * ((((double)(epsil + beta * delta) + 0.5 * b * b * g) + 0.5 * g * g) +
                        1 / 24.0 * b * b * b * b);
     } else {
