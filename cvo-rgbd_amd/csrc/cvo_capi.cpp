@@ -228,6 +228,7 @@ struct cvo_hip_ctx {
     bool use_async_self = false;         // acvo, lone: self lists built ahead, PROC_SELF in the flow launch
     bool use_async = false;              // decided per align(): single rank, not profiling
     bool in_loop = false;                // enqueueing iterations of align()
+    bool plan_recording = false;         // ... into the RecOp list a table plan is made of (record_iteration)
     bool merge_twist = false;            // inside align(): k_step_twist replaces k_post_flow + PROC_STEP
     bool allow_merge = true;
     cvo_hip_trace *cur_trace = nullptr;  // trace buffer of the iterations being enqueued
@@ -546,12 +547,13 @@ bool multi_rank(const cvo_hip_ctx *ctx);
 DevParams loop_params(const cvo_hip_ctx *ctx);
 hipStream_t loop_stream(const cvo_hip_ctx *ctx);
 
-// Members of a crowded engine: the xy filter launch of an iteration (recorded, a launch of its
-// own there) also writes the transformed moving cloud, and the list passes read that.
+// Wherever the xy filter of an iteration is a recorded launch of its own -- members of a crowded
+// engine, sharded and large registrations (no build riding in the flow launch) -- it also writes
+// the transformed moving cloud, and the list passes of the iteration read that.
 bool pre_transform(const cvo_hip_ctx *ctx)
 {
     static const bool off = getenv("CVO_HIP_NO_PRETF") != nullptr;
-    return !off && ctx->crowded && ctx->rec && ctx->in_loop && !ctx->use_async;
+    return !off && ctx->plan_recording && ctx->in_loop && !ctx->use_async;   // (a table plan: kt_filter / kt_filter_group)
 }
 
 // The dense all-pairs filter of one list (with optional HIP-event bracket: this
@@ -1301,7 +1303,9 @@ int record_iteration(cvo_hip_ctx *ctx, std::vector<RecOp> &ops, int trace_cap)
 {
     ops.clear();
     ctx->rec = &ops;
+    ctx->plan_recording = true;
     const int rc = enqueue_iterations(ctx, 1, -1, trace_cap);
+    ctx->plan_recording = false;
     ctx->rec = nullptr;
     return rc;
 }
