@@ -361,6 +361,8 @@ int upload_cloud(cvo_hip_ctx *ctx, Cloud &c, const float *xyz, const float *feat
     const int np = cloud_padded(n);
     const Cloud &other = (&c == &ctx->fixed) ? ctx->moving : ctx->fixed;
     if (n < 0 || (n > 0 && (!xyz || !feat))) return fail(ctx, CVO_HIP_ERR_INVALID, "null cloud");
+    if (n > (1 << 26))   // (the list kernels address a cloud through 32-bit byte offsets: 32 B per point)
+        return fail(ctx, CVO_HIP_ERR_INVALID, "cloud too large: at most 2^26 points");
     if (layout != CVO_HIP_FEAT_COLMAJOR && layout != CVO_HIP_FEAT_ROWMAJOR)
         return fail(ctx, CVO_HIP_ERR_INVALID, "bad feat_layout");
     if (np > c.cap) {

@@ -620,6 +620,13 @@ __device__ __forceinline__ double div6(double x)
     return __builtin_fma(r, c, q0);
 }
 
+// a 16-byte gather at a 32-bit byte offset from a wave-uniform base (clouds of < 2^27 points): the
+// address is scalar base + vector offset, one shift per gather instead of 64-bit address arithmetic
+__device__ __forceinline__ const float4 *gather16(const void *base, unsigned byte_off)
+{
+    return reinterpret_cast<const float4 *>(static_cast<const char *>(base) + byte_off);
+}
+
 // One pair of the exact pass.  PROC_FLOW / PROC_SELF: membership test of
 // se_kernel (ref cvo.cpp:125-152) and the flow / self sums; returns the weight
 // (0 = not in A).  PROC_STEP: `w` is the recorded weight of a member of A.
@@ -631,17 +638,17 @@ __device__ __forceinline__ float eval_pair(const ProcessArgs &a, const KernConst
 {
     const float *Rt = a.st->Rt;
     const float *tt = a.st->t;
-    float4 xi = a.pos_a[i];
+    float4 xi = *gather16(a.pos_a, i * 16u);
     if (a.tf_a) xi = apply_tf(Rt, tt, xi);
-    float4 yj = a.pos_b[j];
+    float4 yj = *gather16(a.pos_b, j * 16u);
     // the features are fetched together with the positions (one memory round
     // trip per pair instead of two); ~97 % of the filtered pairs need them
     float4 fa0 = make_float4(0.f, 0.f, 0.f, 0.f), fb0 = fa0;
     float fa4 = 0.f, fb4 = 0.f;
     int row_index = 0;
     if (MODE != PROC_STEP) {
-        fa0 = *reinterpret_cast<const float4 *>(a.feat_a + (size_t)i * FEAT_STRIDE);
-        fb0 = *reinterpret_cast<const float4 *>(a.feat_b + (size_t)j * FEAT_STRIDE);
+        fa0 = *gather16(a.feat_a, i * (unsigned)(FEAT_STRIDE * 4));
+        fb0 = *gather16(a.feat_b, j * (unsigned)(FEAT_STRIDE * 4));
         fa4 = xi.w;   // the 5th feature travels in pos.w
         fb4 = yj.w;
         if (MODE == PROC_SELF)   // the caller's index of the row (acvo Ayy rule)

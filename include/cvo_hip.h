@@ -143,7 +143,8 @@ int cvo_hip_create(int device, void *stream, const cvo_hip_params *p, cvo_hip_ct
 int cvo_hip_destroy(cvo_hip_ctx *ctx);
 int cvo_hip_set_params(cvo_hip_ctx *ctx, const cvo_hip_params *p);
 
-/* Cloud hand-over: tail of set_pcd() (ref src/cvo.cpp:344-356). */
+/* Cloud hand-over: tail of set_pcd() (ref src/cvo.cpp:344-356).  At most 2^26 points per cloud
+ * (CVO_HIP_ERR_INVALID beyond). */
 int cvo_hip_set_fixed(cvo_hip_ctx *ctx, const float *xyz, const float *feat, int n,
                       int feat_layout);
 int cvo_hip_set_moving(cvo_hip_ctx *ctx, const float *xyz, const float *feat, int m,
@@ -264,7 +265,7 @@ int cvo_hip_set_profiling(cvo_hip_ctx *ctx, int enable);
 int cvo_hip_get_profile(cvo_hip_ctx *ctx, cvo_hip_profile *out, int reset);
 
 /* Profiling of cvo_hip_align_many's shared launches (process-wide switch): while on, the fused groups
- * launch eagerly and every flow-pass launch (kt_process<PROC_FLOW>: one launch serves up to 16
+ * launch eagerly and every flow-pass launch (kt_process<PROC_FLOW>: one launch serves up to 32
  * registrations) carries a HIP event pair attached to the dispatch.  cvo_hip_get_engine_profile
  * returns the summed kernel time, the launches and the registrations those launches served
  * (sum over launches of the occupied slots); bench.py quotes its roofline on it. */
