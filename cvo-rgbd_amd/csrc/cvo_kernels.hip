@@ -1573,8 +1573,8 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(6, 8
 kt_filter(const Slot *__restrict__ tab, const int q)
 {
     CVO_SLOT(tab);
-    pretransform_body(CVO_ARG(FilterArgs, op[q].f), blockIdx.x, gridDim.x);
     filter_body(CVO_ARG(FilterArgs, op[q].f), blockIdx.x, gridDim.x);
+    pretransform_body(CVO_ARG(FilterArgs, op[q].f), blockIdx.x, gridDim.x);   // (after: nothing of it is live across the build)
 }
 
 // acvo, synchronous lists, one registration: the three filters in one launch (blockIdx.y = list)
@@ -1582,8 +1582,8 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(6, 8
 kt_filter_group(const Slot *__restrict__ tab, const int q)
 {
     CVO_SLOT(tab);
-    if (blockIdx.y == 0) pretransform_body(CVO_FILTER_ROLE(0), blockIdx.x, gridDim.x);
     filter_body(CVO_FILTER_ROLE((int)blockIdx.y), blockIdx.x, gridDim.x);
+    if (blockIdx.y == 0) pretransform_body(CVO_FILTER_ROLE(0), blockIdx.x, gridDim.x);
 }
 
 template <int MODE, int WEIGHT = 0>
