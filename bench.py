@@ -344,9 +344,21 @@ def roofline_legs(args, pkg, ctx, ctxs, one_step, n, m):
             return None
         return {"avg_launch_us": live[kernel].get("live_avg_us"), "source": live_src}
 
+    rocprof_batch = None   # rocprofv3's average of the same kernel over the same command (committed summary)
+    if os.path.exists(spath):
+        try:
+            import csv
+            for r in csv.DictReader(open(spath)):
+                if "kt_process<0, 0>" in r["Name"]:
+                    rocprof_batch = {"avg_launch_us": float(r["AverageNs"]) / 1e3, "launches": int(r["Calls"]),
+                                     "source": "committed profiles/%s_kernel_stats_batch32.csv" % PROFILE_TAG,
+                                     "note": "under the kernel trace a step takes ~1.4x as long and the engines' launches overlap "
+                                             "less: a launch has more of the GPU to itself and is shorter than in the timed run"}
+        except Exception:
+            rocprof_batch = None
     res = {"kernel_time_shares_batched": shares}
     # ---- the kernel that dominates the timed region: the flow pass.  In the timed region one launch of it
-    # (kt_process<PROC_FLOW>) serves the up to 16 registrations of an engine: measured on exactly those
+    # (kt_process<PROC_FLOW>) serves the up to 32 registrations of an engine: measured on exactly those
     # launches -- the batch once more with engine profiling on (eager launches, a HIP event pair attached
     # to every flow-pass dispatch of the engines' own streams).
     capi = pkg.capi
@@ -387,6 +399,9 @@ def roofline_legs(args, pkg, ctx, ctxs, one_step, n, m):
         "registrations_per_launch": regs_per_launch,
         "avg_launch_us": b_us, "launches": e_n if e_n > 0 else pf_n,
         "measured": how,
+        "rocprofv3": rocprof_batch,
+        "frac_at_rocprofv3_duration": (b_bytes / (rocprof_batch["avg_launch_us"] * 1e-6) / 1e9 / PEAK_HBM_GBS)
+                                      if rocprof_batch and rocprof_batch["avg_launch_us"] > 0 else None,
         "traffic": tr_batch["bytes_per_launch"] if tr_batch else None,
         "traffic_source": tr_batch["source"] if tr_batch else None,
         "traffic_note": "PMC FETCH_SIZE x 2 + WRITE_SIZE per launch of the batched run (launches of every occupancy averaged)",
@@ -405,9 +420,11 @@ def roofline_legs(args, pkg, ctx, ctxs, one_step, n, m):
                       "achieved_TFLOPs": flow_flop * regs_per_launch / (b_us * 1e-6) / 1e12 if b_us > 0 else 0.0,
                       "peak_TFLOPs": PEAK_F32_TFLOPS,
                       "frac": (flow_flop * regs_per_launch / (b_us * 1e-6) / 1e12 / PEAK_F32_TFLOPS) if b_us > 0 else 0.0},
-        "reading": "neither roof is near: a launch evaluates ~1e5-1e6 candidate pairs per registration behind a "
-                   "handful of dependent memory round trips (gathers through the tile list); sixteen registrations "
-                   "per launch amortise the latency, they do not remove it",
+        "reading": "the algorithmic bytes are the two clouds; what the pass does is evaluate ~1e5-1e6 candidate pairs per "
+                   "registration at ~135 vector instructions per 64 of them (float32 geometry, two float64 exp, nine float64 "
+                   "sums). The saturated resource of the batched run is VALU issue, not a memory roof: SQ_ACTIVE_INST_VALU "
+                   "over all kernels = ~78 % of the wall time at saturation, and idle instructions added to this kernel cost "
+                   "throughput in proportion (profiles/r02_ab.txt items 24-28, DESIGN 5)",
     }
     # ---- the all-pairs test: k_filter (f32 MFMA), launches that build a list
     kf_n = prof["flow_launches"]
