@@ -554,7 +554,7 @@ hipStream_t loop_stream(const cvo_hip_ctx *ctx);
 // the transformed moving cloud, and the list passes of the iteration read that.
 bool pre_transform(const cvo_hip_ctx *ctx)
 {
-    static const bool off = getenv("CVO_HIP_NO_PRETF") != nullptr;
+    const bool off = getenv("CVO_HIP_NO_PRETF") != nullptr;   // (read when a plan is recorded: tests switch it)
     return !off && ctx->plan_recording && ctx->in_loop && !ctx->use_async;   // (a table plan: kt_filter / kt_filter_group)
 }
 

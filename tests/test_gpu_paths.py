@@ -761,3 +761,54 @@ def test_graph_capture_policy_and_parameter_errors(pkg):
                 c.set_params(bad)
         c.close()
     assert all(r == results[0] for r in results)
+
+
+@pytest.mark.parametrize("mode_name", ["cvo", "acvo"])
+def test_transform_pass_changes_nothing(pkg, monkeypatch, mode_name):
+    """transform_pcd as a pass of its own (the xy filter launch writes [Rt|t] y for every point, the
+    list passes read it: plans whose xy filter is its own launch -- here a 16k x 15k pair, too large
+    for a build to ride in the flow launch -- and crowded engines) against the transform inside the
+    list passes, per pair (CVO_HIP_NO_PRETF): same iterations, same state, bit for bit; and the
+    engines' results against the registrations run on their own."""
+    import torch
+    capi = pkg.capi
+    acvo = mode_name == "acvo"
+    mode = capi.MODE_ACVO if acvo else capi.MODE_CVO
+    xf, ff, xm, fm = pkg.data.synthetic_pair(16000, 15000, seed=2024, acvo=acvo)
+    out = []
+    for off in (False, True):
+        if off:
+            monkeypatch.setenv("CVO_HIP_NO_PRETF", "1")
+        else:
+            monkeypatch.delenv("CVO_HIP_NO_PRETF", raising=False)
+        prm = capi.default_params(mode)
+        prm.max_iter = 40
+        c = capi.Context(mode=mode, device=0, params=prm)
+        c.set_fixed(xf, ff)
+        c.set_moving(xm, fm)
+        st = capi.init_state(c.params)
+        it, _ = c.align(st, trace_cap=0)
+        out.append((it, bytes(st)))
+        c.close()
+    assert out[0] == out[1]
+    pairs = [pkg.data.synthetic_pair(1500 + 100 * i, 1400 + 90 * i, seed=900 + i, acvo=acvo) for i in range(10)]
+    res = []
+    for off in (False, True):
+        if off:
+            monkeypatch.setenv("CVO_HIP_NO_PRETF", "1")
+        else:
+            monkeypatch.delenv("CVO_HIP_NO_PRETF", raising=False)
+        keep, ctxs = [], []
+        for xf, ff, xm, fm in pairs:
+            s = torch.cuda.Stream()
+            keep.append(s)
+            c = capi.Context(mode=mode, device=0, stream=s.cuda_stream)
+            c.set_fixed(xf, ff)
+            c.set_moving(xm, fm)
+            ctxs.append(c)
+        states = [capi.init_state(c.params) for c in ctxs]
+        its = capi.align_many(ctxs, states)
+        res.append([(i, bytes(s)) for i, s in zip(its, states)])
+        for c in ctxs:
+            c.close()
+    assert res[0] == res[1]
