@@ -509,6 +509,22 @@ __device__ __forceinline__ float pair_weight(const KernConsts &kc, float d2, con
     return a > kc.sp ? a : 0.0f;
 }
 
+// the two halves of pair_weight<0>, for the flow pass with a candidate list: ck is a function of the two
+// points' features alone (0 = the colour cut fails; a passing pair has ck > 0)
+__device__ __forceinline__ float colour_weight(const KernConsts &kc, const float4 fa0, const float fa4,
+                                               const float4 fb0, const float fb4, const double *etab)
+{
+    const float d2c = d2_feat(fa0, fa4, fb0, fb4);
+    if (!(d2c < kc.tau_c)) return 0.0f;
+    return (float)(kc.cs2_d * exp_neg((double)d2c * kc.ninv_2cl2, etab));
+}
+__device__ __forceinline__ float weight_from_ck(const KernConsts &kc, float d2, float ck, const double *etab)
+{
+    const float k = (float)(kc.s2_d * exp_neg((double)d2 * kc.ninv_2l2, etab));
+    const float a = ck * k;
+    return a > kc.sp ? a : 0.0f;
+}
+
 
 // ---------------------------------------------------------------------------
 // Wave-wide float64 sums of N per-lane values, written to dst[0..N).
@@ -630,11 +646,13 @@ __device__ __forceinline__ const float4 *gather16(const void *base, unsigned byt
 // One pair of the exact pass.  PROC_FLOW / PROC_SELF: membership test of
 // se_kernel (ref cvo.cpp:125-152) and the flow / self sums; returns the weight
 // (0 = not in A).  PROC_STEP: `w` is the recorded weight of a member of A.
-template <int MODE, int WEIGHT = 0>
+// CK (PROC_FLOW, WEIGHT 0): 0 as the reference writes it; 1 also hands the pair's colour weight out
+// through *ck_io (computed for every pair, inside tau or not); 2 takes it from *ck_io, no features read.
+template <int MODE, int WEIGHT = 0, int CK = 0>
 __device__ __forceinline__ float eval_pair(const ProcessArgs &a, const KernConsts &kc, unsigned i,
                                            unsigned j, float w, double *acc,
                                            const cvo_math::XiConsts &xc, const double *etab = nullptr,
-                                           const int first_counted = 0)
+                                           const int first_counted = 0, float *ck_io = nullptr)
 {
     const float *Rt = a.st->Rt;
     const float *tt = a.st->t;
@@ -646,7 +664,7 @@ __device__ __forceinline__ float eval_pair(const ProcessArgs &a, const KernConst
     float4 fa0 = make_float4(0.f, 0.f, 0.f, 0.f), fb0 = fa0;
     float fa4 = 0.f, fb4 = 0.f;
     int row_index = 0;
-    if (MODE != PROC_STEP) {
+    if (MODE != PROC_STEP && CK != 2) {
         fa0 = *gather16(a.feat_a, i * (unsigned)(FEAT_STRIDE * 4));
         fb0 = *gather16(a.feat_b, j * (unsigned)(FEAT_STRIDE * 4));
         fa4 = xi.w;   // the 5th feature travels in pos.w
@@ -659,7 +677,13 @@ __device__ __forceinline__ float eval_pair(const ProcessArgs &a, const KernConst
     float d2 = 0.0f;
     if (MODE != PROC_STEP) {
         d2 = __builtin_fmaf(e2, e2, __builtin_fmaf(e1, e1, e0 * e0));
-        w = (d2 < kc.tau) ? pair_weight<WEIGHT>(kc, d2, fa0, fa4, fb0, fb4, etab) : 0.0f;
+        if (CK == 0) {
+            w = (d2 < kc.tau) ? pair_weight<WEIGHT>(kc, d2, fa0, fa4, fb0, fb4, etab) : 0.0f;
+        } else {
+            const float ck = CK == 2 ? *ck_io : colour_weight(kc, fa0, fa4, fb0, fb4, etab);
+            if (CK == 1) *ck_io = ck;
+            w = (d2 < kc.tau && ck > 0.0f) ? weight_from_ck(kc, d2, ck, etab) : 0.0f;
+        }
     }
     if (!(w > 0.0f)) return 0.0f;
     if (MODE == PROC_FLOW) {
@@ -721,58 +745,16 @@ __device__ __forceinline__ float eval_pair(const ProcessArgs &a, const KernConst
 // roles (flow pass, self passes, filter) overlay one allocation instead of adding them up
 constexpr int PROC_SMEM = 4 * NACC_MAX * 8 + 4 * PAIR_QUEUE * 8 + 4 * 64 * 8;
 
-template <int MODE, int WEIGHT = 0>
-__device__ __forceinline__ void process_body(const ProcessArgs &a, const unsigned bid, char *scratch)
+// The tile list of one registration, expanded and evaluated by the block's four waves (PROC_FLOW,
+// PROC_SELF).  REC (PROC_FLOW): every candidate is recorded for the passes that follow (ProcessArgs::cand).
+// Returns false when the loop has stopped (nothing to reduce).
+template <int MODE, int WEIGHT, int REC>
+__device__ __forceinline__ bool expand_lists(const ProcessArgs &a, const KernConsts &kc, const unsigned bid, const int wid,
+                                             const int lane, const unsigned wave, const int done_word,
+                                             const unsigned list_bad, const int in_list, const TileEntry *in_tiles,
+                                             const int first_counted, const double *s_etab, uint2 *pairq_all,
+                                             double (&acc)[NAcc<MODE>::n])
 {
-    if ((int)bid >= a.nblk) return;
-    constexpr int NACC = NAcc<MODE>::n;
-    double *red = reinterpret_cast<double *>(scratch);
-    uint2 *pairq_all = reinterpret_cast<uint2 *>(scratch + 4 * NACC_MAX * 8);
-    // every wave keeps its own copy of the exp table (no block barrier needed)
-    double *s_etab_all = reinterpret_cast<double *>(scratch + 4 * NACC_MAX * 8 + 4 * PAIR_QUEUE * 8);
-    if (MODE != PROC_STEP) s_etab_all[threadIdx.x] = c_exp2_64[threadIdx.x & 63];
-    const double *s_etab = s_etab_all + ((MODE == PROC_STEP) ? 0 : (threadIdx.x >> 6) * 64);
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const unsigned wave = bid * 4u + (unsigned)wid;   // 0 .. PROC_WAVES-1
-    // first round trip: loop-control word, kernel constants, list sizes
-    // (async xy: a stall slot only builds; PROC_FLOW reads the buffer in use)
-    const int done_word = a.check_done ? (a.st->done | (a.async_xy ? a.st->stall : 0)) : 0;
-    const KernConsts kc = a.st->kc;
-    // (acvo Ayy rule, SURVEY 8a quirk 5: the caller's count of fixed points lives in the state, so
-    // that the kernel arguments -- and with them a captured graph -- do not depend on it)
-    const int first_counted = (MODE == PROC_SELF && a.first_counted) ? a.st->n_fixed : 0;
-    const bool second = (MODE == PROC_FLOW && a.async_xy && a.st->xy_active == 1) ||
-                        (MODE == PROC_SELF && a.async_self && a.st->sf_active[a.async_self - 1] == 1);
-    const int in_list = !second ? a.list : (MODE == PROC_FLOW ? (int)LIST_XYB : self_list_id(a.async_self - 1, 1));
-    const TileEntry *in_tiles = second ? a.tiles_b : a.tiles;
-    // A list that overflowed while it was built holds counters past what was written (an
-    // append that does not fit is dropped, its count stays): entries from memory nobody
-    // initialised would be taken for row / column numbers.  The iteration is redone with a
-    // larger list anyway: consume nothing of it.  (Same for the kept list of PROC_STEP.)
-    const unsigned list_bad = a.st->cnt[2 * (MODE == PROC_STEP ? (int)LIST_KEPT : in_list) + 1];
-
-    double acc[NACC];
-#pragma unroll
-    for (int k = 0; k < NACC; ++k) acc[k] = 0.0;
-
-    if (MODE == PROC_STEP) {
-        // stream the members of A that wave `wave` of PROC_FLOW recorded
-        const size_t base = (size_t)wave * a.kept_wcap;
-        unsigned n = a.kept_cnt[wave];
-        // the first entries are fetched together with the count
-        const bool packed = a.kept_packed != 0;
-        uint2 e = a.kept_ij[base + lane];
-        float w = packed ? 0.0f : a.kept_a[base + lane];
-        if (done_word != 0) return;
-        if (n > a.kept_wcap) n = a.kept_wcap;
-        if (list_bad) n = 0;
-        for (unsigned off = lane; off < n; off += 64) {
-            if (off >= 64) { e = a.kept_ij[base + off]; if (!packed) w = a.kept_a[base + off]; }
-            eval_pair<MODE>(a, kc, packed ? (e.x & 0xffffu) : e.x, packed ? (e.x >> 16) : e.y,
-                            packed ? __uint_as_float(e.y) : w, acc, a.st->xi);
-        }
-    } else {
         // nblk >= NSUB: nblk / NSUB blocks share one sub-list of the tile list;
         // nblk < NSUB (many registrations per launch): a block takes NSUB / nblk
         // sub-lists, one after the other (sub-list s stays on XCD s % 8 either way)
@@ -788,10 +770,11 @@ __device__ __forceinline__ void process_body(const ProcessArgs &a, const unsigne
         const unsigned stride = shared ? 4u * (unsigned)(a.nblk / NSUB) : 4u;
         const unsigned e0 = part * 4u + (unsigned)wid;
         TileEntry mine = tl[min(e0 + (unsigned)lane * stride, a.subcap - 1)];
-        if (done_word != 0) return;
+        if (done_word != 0) return false;
         uint2 *pairq = pairq_all + wid * PAIR_QUEUE;
         int qn = 0;   // wave-uniform: queued pairs
         unsigned nk = 0;   // wave-uniform: members of A recorded so far
+        unsigned co = 0;   // wave-uniform (REC): candidates recorded so far
         const size_t kbase = (size_t)wave * a.kept_wcap;
         // evaluate the queued pairs q[base .. base+cnt) (cnt <= 64, wave-uniform)
         auto run_batch = [&](int base, int cnt) {
@@ -800,9 +783,18 @@ __device__ __forceinline__ void process_body(const ProcessArgs &a, const unsigne
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             float w = 0.0f;
             uint2 pr = make_uint2(0u, 0u);
+            float ck = 0.0f;
             if (lane < cnt) {
                 pr = pairq[base + lane];
-                w = eval_pair<MODE, WEIGHT>(a, kc, pr.x, pr.y, 0.0f, acc, a.st->xi, s_etab, first_counted);   // (xi: PROC_STEP only)
+                w = eval_pair<MODE, WEIGHT, REC>(a, kc, pr.x, pr.y, 0.0f, acc, a.st->xi, s_etab, first_counted, &ck);   // (xi: PROC_STEP only)
+            }
+            if (REC) {   // every candidate goes on record, at the place the wave met it (its colour weight with it)
+                if (co + (unsigned)cnt <= a.kept_wcap) {
+                    if (lane < cnt) a.cand[kbase + co + lane] = make_uint2(pr.x | (pr.y << 16), __float_as_uint(ck));
+                } else if (lane == 0) {
+                    atomicOr(&a.st->cnt[2 * LIST_KEPT + 1], 1u);   // slice full: grow and redo
+                }
+                co += (unsigned)cnt;
             }
             if (MODE == PROC_SELF) nk += (unsigned)__popcll(__ballot(w > 0.0f));   // (scalar: the member count)
             if (MODE == PROC_FLOW) {   // record the members of A in this wave's slice
@@ -867,9 +859,116 @@ __device__ __forceinline__ void process_body(const ProcessArgs &a, const unsigne
         sub += (unsigned)a.nblk; n = n_next; tl = tl_next; mine = mine_next;
         }   // sub-lists of this block
         if (qn > 0) run_batch(0, qn);
-        if (MODE == PROC_FLOW && lane == 0) a.kept_cnt[wave] = nk;
+        if (MODE == PROC_FLOW && lane == 0) { a.kept_cnt[wave] = nk; if (REC) a.cand_cnt[wave] = co; }
         // the member count of the wave joins the sums (one lane holds it; a slice that overflowed still counts)
         if (lane == 0) acc[MODE == PROC_FLOW ? 8 : 1] = (double)nk;
+        return true;
+}
+
+// The candidate list of one registration, streamed by the wave that recorded it: lane l takes the
+// wave's l-th candidate of the round -- nothing to expand, full rounds but the last, the colour weight
+// read back with the pair -- and the members of A of THIS iteration go to the kept list as always.
+__device__ __forceinline__ bool stream_candidates(const ProcessArgs &a, const KernConsts &kc, const int lane,
+                                                  const unsigned wave, const int done_word, const double *s_etab,
+                                                  double (&acc)[NACC_FLOW])
+{
+    const size_t base = (size_t)wave * a.kept_wcap;
+    unsigned n = a.cand_cnt[wave];
+    uint2 e = a.cand[base + lane];
+    if (done_word != 0) return false;
+    if (n > a.kept_wcap) n = a.kept_wcap;
+    unsigned nk = 0;
+    for (unsigned b0 = 0; b0 < n; b0 += 64u) {
+        if (b0 != 0u) e = a.cand[base + min(b0 + (unsigned)lane, a.kept_wcap - 1u)];
+        float w = 0.0f;
+        if (b0 + (unsigned)lane < n) {
+            float ck = __uint_as_float(e.y);
+            w = eval_pair<PROC_FLOW, 0, 2>(a, kc, e.x & 0xffffu, e.x >> 16, 0.0f, acc, a.st->xi, s_etab, 0, &ck);
+        }
+        const unsigned long long km = __ballot(w > 0.0f);
+        if (w > 0.0f) {   // (members <= candidates <= the slice: it cannot overflow here)
+            const unsigned below = __builtin_amdgcn_mbcnt_hi((unsigned)(km >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)km, 0u));
+            a.kept_ij[base + nk + below] = make_uint2(e.x, __float_as_uint(w));
+        }
+        nk += (unsigned)__popcll(km);
+    }
+    if (lane == 0) { a.kept_cnt[wave] = nk; acc[8] = (double)nk; }
+    return true;
+}
+
+// (PROC_SELF instantiations never stream: the accumulator shapes differ)
+template <int MODE>
+__device__ __forceinline__ bool stream_candidates_if_flow(const ProcessArgs &a, const KernConsts &kc, const int lane,
+                                                          const unsigned wave, const int done_word, const double *s_etab,
+                                                          double (&acc)[NAcc<MODE>::n])
+{
+    if constexpr (MODE == PROC_FLOW) return stream_candidates(a, kc, lane, wave, done_word, s_etab, acc);
+    else return true;
+}
+
+
+// CAND false: the launch never keeps a candidate list (the merged launches of one registration on its
+// own, whose xy list is built beside the pass): that code is left out of the kernel
+template <int MODE, int WEIGHT = 0, bool CAND = true>
+__device__ __forceinline__ void process_body(const ProcessArgs &a, const unsigned bid, char *scratch)
+{
+    if ((int)bid >= a.nblk) return;
+    constexpr int NACC = NAcc<MODE>::n;
+    double *red = reinterpret_cast<double *>(scratch);
+    uint2 *pairq_all = reinterpret_cast<uint2 *>(scratch + 4 * NACC_MAX * 8);
+    // every wave keeps its own copy of the exp table (no block barrier needed)
+    double *s_etab_all = reinterpret_cast<double *>(scratch + 4 * NACC_MAX * 8 + 4 * PAIR_QUEUE * 8);
+    if (MODE != PROC_STEP) s_etab_all[threadIdx.x] = c_exp2_64[threadIdx.x & 63];
+    const double *s_etab = s_etab_all + ((MODE == PROC_STEP) ? 0 : (threadIdx.x >> 6) * 64);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned wave = bid * 4u + (unsigned)wid;   // 0 .. PROC_WAVES-1
+    // first round trip: loop-control word, kernel constants, list sizes
+    // (async xy: a stall slot only builds; PROC_FLOW reads the buffer in use)
+    const int done_word = a.check_done ? (a.st->done | (a.async_xy ? a.st->stall : 0)) : 0;
+    const KernConsts kc = a.st->kc;
+    // (acvo Ayy rule, SURVEY 8a quirk 5: the caller's count of fixed points lives in the state, so
+    // that the kernel arguments -- and with them a captured graph -- do not depend on it)
+    const int first_counted = (MODE == PROC_SELF && a.first_counted) ? a.st->n_fixed : 0;
+    const bool second = (MODE == PROC_FLOW && a.async_xy && a.st->xy_active == 1) ||
+                        (MODE == PROC_SELF && a.async_self && a.st->sf_active[a.async_self - 1] == 1);
+    const int in_list = !second ? a.list : (MODE == PROC_FLOW ? (int)LIST_XYB : self_list_id(a.async_self - 1, 1));
+    const TileEntry *in_tiles = second ? a.tiles_b : a.tiles;
+    // A list that overflowed while it was built holds counters past what was written (an
+    // append that does not fit is dropped, its count stays): entries from memory nobody
+    // initialised would be taken for row / column numbers.  The iteration is redone with a
+    // larger list anyway: consume nothing of it.  (Same for the kept list of PROC_STEP.)
+    const unsigned list_bad = a.st->cnt[2 * (MODE == PROC_STEP ? (int)LIST_KEPT : in_list) + 1];
+
+    double acc[NACC];
+#pragma unroll
+    for (int k = 0; k < NACC; ++k) acc[k] = 0.0;
+
+    if (MODE == PROC_STEP) {
+        // stream the members of A that wave `wave` of PROC_FLOW recorded
+        const size_t base = (size_t)wave * a.kept_wcap;
+        unsigned n = a.kept_cnt[wave];
+        // the first entries are fetched together with the count
+        const bool packed = a.kept_packed != 0;
+        uint2 e = a.kept_ij[base + lane];
+        float w = packed ? 0.0f : a.kept_a[base + lane];
+        if (done_word != 0) return;
+        if (n > a.kept_wcap) n = a.kept_wcap;
+        if (list_bad) n = 0;
+        for (unsigned off = lane; off < n; off += 64) {
+            if (off >= 64) { e = a.kept_ij[base + off]; if (!packed) w = a.kept_a[base + off]; }
+            eval_pair<MODE>(a, kc, packed ? (e.x & 0xffffu) : e.x, packed ? (e.x >> 16) : e.y,
+                            packed ? __uint_as_float(e.y) : w, acc, a.st->xi);
+        }
+    } else {
+        bool alive;
+        if (CAND && MODE == PROC_FLOW && WEIGHT == 0 && a.cand && a.kept_packed && !a.async_xy) {
+            if (a.st->ck_nblk == a.nblk) alive = stream_candidates_if_flow<MODE>(a, kc, lane, wave, done_word, s_etab, acc);
+            else alive = expand_lists<MODE, WEIGHT, (MODE == PROC_FLOW && WEIGHT == 0) ? 1 : 0>(a, kc, bid, wid, lane, wave, done_word, list_bad, in_list, in_tiles, first_counted, s_etab, pairq_all, acc);
+        } else {
+            alive = expand_lists<MODE, WEIGHT, 0>(a, kc, bid, wid, lane, wave, done_word, list_bad, in_list, in_tiles, first_counted, s_etab, pairq_all, acc);
+        }
+        if (!alive) return;
     }
 
     // block reduction: reduce-scatter inside each wave, then the 4 waves in order
@@ -1429,6 +1528,10 @@ __device__ void post_step_math(DevState *st, const PostStepArgs &a)
     const DevParams &p = a.prm;
     const bool acvo = p.mode == CVO_HIP_MODE_ACVO;
     const int k = st->k;
+    // (this iteration's flow pass has recorded or streamed the candidate list: it matches the tile list --
+    // until plan_lists, below, schedules a rebuild)
+    if (threadIdx.x == 0 && a.ck_nblk != 0 && st->cnt[2 * LIST_XY + 1] == 0u && st->cnt[2 * LIST_KEPT + 1] == 0u)
+        st->ck_nblk = a.ck_nblk;
     double bcde[4];
     for (int q = 0; q < 4; ++q) bcde[q] = st->red[RED_STEP + q];
     const long long c2 = a.dbg ? (long long)__builtin_readcyclecounter() : 0;
@@ -1681,7 +1784,7 @@ __global__ void __launch_bounds__(BLOCK) kt_post_step(const Slot *__restrict__ t
         CVO_SLOT(tab);                                                                                     \
         const int np = cs->op[q].np;                                                                       \
         if ((int)blockIdx.x < np) {                                                                        \
-            process_body<PROC_FLOW>(CVO_ARG(ProcessArgs, op[q].p), blockIdx.x, smem);                      \
+            process_body<PROC_FLOW, 0, false>(CVO_ARG(ProcessArgs, op[q].p), blockIdx.x, smem);                      \
             return;                                                                                        \
         }                                                                                                  \
         filter_body(CVO_ARG(FilterArgs, op[q].f), blockIdx.x - (unsigned)np, (unsigned)cs->op[q].n0);      \
@@ -1694,7 +1797,7 @@ __global__ void __launch_bounds__(BLOCK) kt_post_step(const Slot *__restrict__ t
         int b = (int)blockIdx.x;                                                                           \
         const int np = cs->op[q].np, n0 = cs->op[q].n0, n1 = cs->op[q].n1, n2 = cs->op[q].n2;             \
         if (b < np) {                                                                                      \
-            process_body<PROC_FLOW>(CVO_ARG(ProcessArgs, op[q].p), (unsigned)b, smem);                     \
+            process_body<PROC_FLOW, 0, false>(CVO_ARG(ProcessArgs, op[q].p), (unsigned)b, smem);                     \
             return;                                                                                        \
         }                                                                                                  \
         b -= np;                                                                                           \
@@ -1710,7 +1813,7 @@ __global__ void __launch_bounds__(BLOCK) kt_post_step(const Slot *__restrict__ t
         int b = (int)blockIdx.x;                                                                           \
         const int np = cs->op[q].np;                                                                       \
         if (b < np) {                                                                                      \
-            process_body<PROC_FLOW>(CVO_ARG(ProcessArgs, op[q].p), (unsigned)b, smem);                     \
+            process_body<PROC_FLOW, 0, false>(CVO_ARG(ProcessArgs, op[q].p), (unsigned)b, smem);                     \
             return;                                                                                        \
         }                                                                                                  \
         b -= np;                                                                                           \

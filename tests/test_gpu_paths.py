@@ -764,23 +764,30 @@ def test_graph_capture_policy_and_parameter_errors(pkg):
 
 
 @pytest.mark.parametrize("mode_name", ["cvo", "acvo"])
-def test_transform_pass_changes_nothing(pkg, monkeypatch, mode_name):
-    """transform_pcd as a pass of its own (the xy filter launch writes [Rt|t] y for every point, the
-    list passes read it: plans whose xy filter is its own launch -- here a 16k x 15k pair, too large
-    for a build to ride in the flow launch -- and crowded engines) against the transform inside the
-    list passes, per pair (CVO_HIP_NO_PRETF): same iterations, same state, bit for bit; and the
-    engines' results against the registrations run on their own."""
+def test_transform_pass_and_candidate_list_change_nothing(pkg, monkeypatch, mode_name):
+    """Two mechanisms of the plans whose xy filter is a launch of its own (a 16k x 15k pair, too large
+    for a build to ride in the flow launch; crowded engines), each against the plain form:
+    transform_pcd as a pass of its own (the filter launch writes [Rt|t] y for every point, the list
+    passes read it; CVO_HIP_NO_PRETF = the transform inside the list passes, per pair) and the
+    candidate list (the flow pass after a build records every pair of the tile list with its colour
+    weight, the passes over the same list stream the record; CVO_HIP_NO_CAND = expand the tile list
+    every time).  Same iterations, same state, bit for bit, in all three forms."""
     import torch
     capi = pkg.capi
     acvo = mode_name == "acvo"
     mode = capi.MODE_ACVO if acvo else capi.MODE_CVO
+    forms = ({}, {"CVO_HIP_NO_CAND": "1"}, {"CVO_HIP_NO_PRETF": "1"})
+
+    def set_form(env):
+        for k in ("CVO_HIP_NO_CAND", "CVO_HIP_NO_PRETF"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+
     xf, ff, xm, fm = pkg.data.synthetic_pair(16000, 15000, seed=2024, acvo=acvo)
     out = []
-    for off in (False, True):
-        if off:
-            monkeypatch.setenv("CVO_HIP_NO_PRETF", "1")
-        else:
-            monkeypatch.delenv("CVO_HIP_NO_PRETF", raising=False)
+    for env in forms:
+        set_form(env)
         prm = capi.default_params(mode)
         prm.max_iter = 40
         c = capi.Context(mode=mode, device=0, params=prm)
@@ -790,14 +797,11 @@ def test_transform_pass_changes_nothing(pkg, monkeypatch, mode_name):
         it, _ = c.align(st, trace_cap=0)
         out.append((it, bytes(st)))
         c.close()
-    assert out[0] == out[1]
+    assert out[0] == out[1] == out[2]
     pairs = [pkg.data.synthetic_pair(1500 + 100 * i, 1400 + 90 * i, seed=900 + i, acvo=acvo) for i in range(10)]
     res = []
-    for off in (False, True):
-        if off:
-            monkeypatch.setenv("CVO_HIP_NO_PRETF", "1")
-        else:
-            monkeypatch.delenv("CVO_HIP_NO_PRETF", raising=False)
+    for env in forms:
+        set_form(env)
         keep, ctxs = [], []
         for xf, ff, xm, fm in pairs:
             s = torch.cuda.Stream()
@@ -811,4 +815,4 @@ def test_transform_pass_changes_nothing(pkg, monkeypatch, mode_name):
         res.append([(i, bytes(s)) for i, s in zip(its, states)])
         for c in ctxs:
             c.close()
-    assert res[0] == res[1]
+    assert res[0] == res[1] == res[2]
