@@ -222,8 +222,8 @@ struct cvo_hip_ctx {
     bool have_xy_build = false;
     bool allow_async = true;
     bool crowded = false;                // set by align_many: many registrations share the launches
-    DevBuf cand, cand_cnt;               // the candidate list of the xy list (ProcessArgs::cand, cand_cnt)
-    int ck_nblk = 0;                     // recorded plan: the flow pass keeps a candidate list with this many blocks (0: no)
+    DevBuf cand[3], cand_cnt[3];         // the candidate lists of the xy / xx / yy tile lists (ProcessArgs::cand, cand_cnt)
+    int ck_nblk[3] = {0, 0, 0};          // recorded plan: the pass over list l keeps a candidate list with this many blocks (0: no)
     DevBuf pos_bt;                       // crowded: the moving cloud under the iteration's transform (FilterArgs::pos_bt)
     bool lone = true;                    // this registration has its launches to itself
     bool allow_async_self = true;
@@ -675,16 +675,18 @@ int enqueue_process(cvo_hip_ctx *ctx, int mode, int list, DevBuf &part, const fl
     a.weight = ctx->prm.color_scale > 0.0f ? 1 : 0;   // the MATLAB object's weight: its own instantiation
     static const bool no_pack = getenv("CVO_HIP_NO_PACK") != nullptr;
     a.kept_packed = (!no_pack && ctx->fixed.np <= 65536 && ctx->moving.np <= 65536) ? 1 : 0;
-    if (mode == PROC_FLOW && list == LIST_XY) {
+    if ((mode == PROC_FLOW && list == LIST_XY) || (mode == PROC_SELF && (list == LIST_XX || list == LIST_YY))) {
         const bool no_cand = getenv("CVO_HIP_NO_CAND") != nullptr;   // (read when a plan is recorded: tests switch it)
-        ctx->ck_nblk = 0;
-        if (!no_cand && pre_transform(ctx) && !(ctx->prm.color_scale > 0.0f) && a.kept_packed) {   // (the same plans: a synchronous xy list)
-            rc = ensure_buf(ctx, ctx->cand, (size_t)ctx->lists[LIST_KEPT].cap * sizeof(uint2));
-            if (!rc) rc = ensure_buf(ctx, ctx->cand_cnt, PROC_WAVES * sizeof(uint32_t));
+        const bool no_self = getenv("CVO_HIP_NO_CAND_SELF") != nullptr;
+        ctx->ck_nblk[list] = 0;
+        if (!no_cand && !(mode == PROC_SELF && no_self) && pre_transform(ctx) && !(ctx->prm.color_scale > 0.0f) &&
+            a.kept_packed) {   // (the same plans: synchronous lists)
+            rc = ensure_buf(ctx, ctx->cand[list], (size_t)ctx->lists[LIST_KEPT].cap * sizeof(uint2));
+            if (!rc) rc = ensure_buf(ctx, ctx->cand_cnt[list], PROC_WAVES * sizeof(uint32_t));
             if (rc) return rc;
-            a.cand = (uint2 *)ctx->cand.p;
-            a.cand_cnt = (uint32_t *)ctx->cand_cnt.p;
-            ctx->ck_nblk = a.nblk;
+            a.cand = (uint2 *)ctx->cand[list].p;
+            a.cand_cnt = (uint32_t *)ctx->cand_cnt[list].p;
+            ctx->ck_nblk[list] = a.nblk;
         }
     }
     if (ctx->in_loop && ctx->use_async) {
@@ -921,7 +923,7 @@ int enqueue_step(cvo_hip_ctx *ctx, int check_done, bool do_math, cvo_hip_trace *
     pa.check_done = check_done;
     pa.done_mirror = ctx->done_mirror;
     pa.progress_mirror = ctx->progress_mirror;
-    pa.ck_nblk = ctx->plan_recording ? ctx->ck_nblk : 0;
+    for (int l = 0; l < 3; ++l) pa.ck_nblk[l] = ctx->plan_recording ? ctx->ck_nblk[l] : 0;
     pa.nblk = ctx->merge_twist ? ctx->proc_blocks / STEP_TWIST_ROWS_DIV : ctx->proc_blocks;
     pa.part_step = (const double *)ctx->part_step.p;
     pa.dbg = ctx->post_dbg;
@@ -1321,6 +1323,7 @@ int record_iteration(cvo_hip_ctx *ctx, std::vector<RecOp> &ops, int trace_cap)
     ops.clear();
     ctx->rec = &ops;
     ctx->plan_recording = true;
+    for (int l = 0; l < 3; ++l) ctx->ck_nblk[l] = 0;   // (set again by the passes of this plan that keep a candidate list)
     const int rc = enqueue_iterations(ctx, 1, -1, trace_cap);
     ctx->plan_recording = false;
     ctx->rec = nullptr;
@@ -1566,7 +1569,8 @@ int cvo_hip_destroy(cvo_hip_ctx *ctx)
                     (void *)ctx->moving.feat, (void *)ctx->fixed.seg, (void *)ctx->moving.seg,
                     (void *)ctx->scratch_a.pos, (void *)ctx->scratch_a.feat, (void *)ctx->scratch_a.seg,
                     (void *)ctx->scratch_b.pos, (void *)ctx->scratch_b.feat, (void *)ctx->scratch_b.seg, (void *)ctx->st, ctx->part_flow.p, ctx->part_xx.p,
-                    ctx->part_yy.p, ctx->part_step.p, (void *)ctx->trace_dev, ctx->kept_cnt.p, ctx->pos_bt.p, ctx->cand.p, ctx->cand_cnt.p})
+                    ctx->part_yy.p, ctx->part_step.p, (void *)ctx->trace_dev, ctx->kept_cnt.p, ctx->pos_bt.p, ctx->cand[0].p, ctx->cand[1].p, ctx->cand[2].p, ctx->cand_cnt[0].p,
+                    ctx->cand_cnt[1].p, ctx->cand_cnt[2].p})
         if (p) (void)hipFree(p);
     for (int l = 0; l < LIST_N; ++l) {
         if (ctx->lists[l].a.p) (void)hipFree(ctx->lists[l].a.p);

@@ -160,7 +160,7 @@ struct DevState {
     float list_r[3];
     int32_t list_ok[3];         // list l holds a build of this align()
     int32_t reuse[3];           // this iteration consumes list l as it is: k_filter returns at once
-    int32_t ck_nblk;            // candidate list of the xy list (ProcessArgs::cand): recorded by a flow pass of this many
+    int32_t ck_nblk[3];         // candidate list of tile list l (ProcessArgs::cand): recorded by a pass of this many
                                 // blocks over the tile list as it stands; 0 = none (tile list rebuilt / to be rebuilt)
     float list_Rt[9], list_t[3];
     // Asynchronous xy builds (DevParams::async_xy): two buffers; FLOW consumes
@@ -265,8 +265,9 @@ struct ProcessArgs {
     uint2 *cand;           // PROC_FLOW over a synchronous xy list of clouds that pack (kept_packed): the CANDIDATE list --
                            // every pair of the tile list as (i | j << 16, its colour weight), wave by wave in the order
                            // the wave meets them.  The pass after a build expands the tile list and records it; the
-                           // passes over the same tile list (st->ck_nblk == nblk) stream the record instead: nothing to
-                           // expand, no feature gathers, no colour exp.  Null: no candidate list.
+                           // passes over the same tile list (st->ck_nblk[list] == nblk) stream the record instead: nothing to
+                           // expand, no feature gathers, no colour exp.  PROC_SELF (acvo's xx / yy lists) likewise,
+                           // the sign of the recorded weight = the row counts (Ayy rule).  Null: no candidate list.
     uint32_t *cand_cnt;    // [PROC_WAVES] candidates recorded by each wave
     int need_d2;           // PROC_FLOW: accumulate sum (1/l^3 a) d2 (acvo's dl term; cvo_hip_flow reports it for both modes)
     int kept_packed;       // both clouds have <= 65536 rows: a kept entry is 8 bytes (i | j << 16, weight bits)
@@ -299,8 +300,8 @@ struct PostStepArgs {
     int check_done;
     long long *dbg;        // diagnostics only (CVO_HIP_POST_DEBUG): phase clocks of thread 0
     int32_t *done_mirror;  // see PostFlowArgs
-    int ck_nblk;           // the flow pass of this iteration ran with ProcessArgs::cand and this many blocks: the candidate
-                           // list now matches the tile list (0: no candidate list)
+    int ck_nblk[3];        // the pass over tile list l of this iteration ran with ProcessArgs::cand and this many blocks:
+                           // its candidate list now matches the tile list (0: no candidate list)
     int32_t *progress_mirror;   // optional host-visible copy of st->n_slots (pinned): lets the host enqueue the next
                                 // batch when the running one is down to its last slot instead of a whole batch ahead
     int nblk;
@@ -439,7 +440,7 @@ CVO_HD void plan_lists(DevState *s, const DevParams &p, const double r_now)
                           lr <= LIST_LOOSE * (1.0 + margin) * (r_now * 1.0001 + slack);
         s->reuse[l] = keep ? 1 : 0;
         if (keep) continue;
-        if (l == LIST_XY) s->ck_nblk = 0;   // a new tile list: the candidate list recorded from the old one is void
+        s->ck_nblk[l] = 0;   // a new tile list: the candidate list recorded from the old one is void
         const double rb = (r_now * 1.0001 + slack) * (1.0 + margin);
         s->list_r[l] = (float)(rb * 1.000001);   // rounded up: the list holds at least this radius
         s->list_ok[l] = 1;

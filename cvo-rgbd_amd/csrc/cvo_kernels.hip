@@ -680,8 +680,10 @@ __device__ __forceinline__ float eval_pair(const ProcessArgs &a, const KernConst
         if (CK == 0) {
             w = (d2 < kc.tau) ? pair_weight<WEIGHT>(kc, d2, fa0, fa4, fb0, fb4, etab) : 0.0f;
         } else {
-            const float ck = CK == 2 ? *ck_io : colour_weight(kc, fa0, fa4, fb0, fb4, etab);
-            if (CK == 1) *ck_io = ck;
+            // (PROC_SELF: the sign of the recorded weight says whether the row counts -- acvo Ayy rule)
+            const float ck = CK == 2 ? __builtin_fabsf(*ck_io) : colour_weight(kc, fa0, fa4, fb0, fb4, etab);
+            if (CK == 2 && MODE == PROC_SELF) row_index = (*ck_io < 0.0f) ? -1 : 0;
+            if (CK == 1) *ck_io = (MODE == PROC_SELF && row_index < first_counted) ? -ck : ck;
             w = (d2 < kc.tau && ck > 0.0f) ? weight_from_ck(kc, d2, ck, etab) : 0.0f;
         }
     }
@@ -735,7 +737,7 @@ __device__ __forceinline__ float eval_pair(const ProcessArgs &a, const KernConst
         acc[3] += A * ((((double)(epsil + beta * delta) + 0.5 * b * b * g) + 0.5 * g * g) +
                        1 / 24.0 * b * b * b * b);
     } else {
-        if (row_index >= first_counted) acc[0] += (double)((kc.inv_l3 * w) * d2);
+        if (CK == 2 ? row_index >= 0 : row_index >= first_counted) acc[0] += (double)((kc.inv_l3 * w) * d2);
         // (acc[1], the number of members: counted per wave by the caller)
     }
     return w;
@@ -859,7 +861,8 @@ __device__ __forceinline__ bool expand_lists(const ProcessArgs &a, const KernCon
         sub += (unsigned)a.nblk; n = n_next; tl = tl_next; mine = mine_next;
         }   // sub-lists of this block
         if (qn > 0) run_batch(0, qn);
-        if (MODE == PROC_FLOW && lane == 0) { a.kept_cnt[wave] = nk; if (REC) a.cand_cnt[wave] = co; }
+        if (MODE == PROC_FLOW && lane == 0) a.kept_cnt[wave] = nk;
+        if (REC && lane == 0) a.cand_cnt[wave] = co;
         // the member count of the wave joins the sums (one lane holds it; a slice that overflowed still counts)
         if (lane == 0) acc[MODE == PROC_FLOW ? 8 : 1] = (double)nk;
         return true;
@@ -867,10 +870,11 @@ __device__ __forceinline__ bool expand_lists(const ProcessArgs &a, const KernCon
 
 // The candidate list of one registration, streamed by the wave that recorded it: lane l takes the
 // wave's l-th candidate of the round -- nothing to expand, full rounds but the last, the colour weight
-// read back with the pair -- and the members of A of THIS iteration go to the kept list as always.
+// read back with the pair.  PROC_FLOW: the members of A of THIS iteration go to the kept list as always.
+template <int MODE>
 __device__ __forceinline__ bool stream_candidates(const ProcessArgs &a, const KernConsts &kc, const int lane,
                                                   const unsigned wave, const int done_word, const double *s_etab,
-                                                  double (&acc)[NACC_FLOW])
+                                                  double (&acc)[NAcc<MODE>::n])
 {
     const size_t base = (size_t)wave * a.kept_wcap;
     unsigned n = a.cand_cnt[wave];
@@ -883,29 +887,21 @@ __device__ __forceinline__ bool stream_candidates(const ProcessArgs &a, const Ke
         float w = 0.0f;
         if (b0 + (unsigned)lane < n) {
             float ck = __uint_as_float(e.y);
-            w = eval_pair<PROC_FLOW, 0, 2>(a, kc, e.x & 0xffffu, e.x >> 16, 0.0f, acc, a.st->xi, s_etab, 0, &ck);
+            w = eval_pair<MODE, 0, 2>(a, kc, e.x & 0xffffu, e.x >> 16, 0.0f, acc, a.st->xi, s_etab, 0, &ck);
         }
         const unsigned long long km = __ballot(w > 0.0f);
-        if (w > 0.0f) {   // (members <= candidates <= the slice: it cannot overflow here)
+        if (MODE == PROC_FLOW && w > 0.0f) {   // (members <= candidates <= the slice: it cannot overflow here)
             const unsigned below = __builtin_amdgcn_mbcnt_hi((unsigned)(km >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)km, 0u));
             a.kept_ij[base + nk + below] = make_uint2(e.x, __float_as_uint(w));
         }
         nk += (unsigned)__popcll(km);
     }
-    if (lane == 0) { a.kept_cnt[wave] = nk; acc[8] = (double)nk; }
+    if (lane == 0) {
+        if (MODE == PROC_FLOW) a.kept_cnt[wave] = nk;
+        acc[MODE == PROC_FLOW ? 8 : 1] = (double)nk;
+    }
     return true;
 }
-
-// (PROC_SELF instantiations never stream: the accumulator shapes differ)
-template <int MODE>
-__device__ __forceinline__ bool stream_candidates_if_flow(const ProcessArgs &a, const KernConsts &kc, const int lane,
-                                                          const unsigned wave, const int done_word, const double *s_etab,
-                                                          double (&acc)[NAcc<MODE>::n])
-{
-    if constexpr (MODE == PROC_FLOW) return stream_candidates(a, kc, lane, wave, done_word, s_etab, acc);
-    else return true;
-}
-
 
 // CAND false: the launch never keeps a candidate list (the merged launches of one registration on its
 // own, whose xy list is built beside the pass): that code is left out of the kernel
@@ -962,9 +958,9 @@ __device__ __forceinline__ void process_body(const ProcessArgs &a, const unsigne
         }
     } else {
         bool alive;
-        if (CAND && MODE == PROC_FLOW && WEIGHT == 0 && a.cand && a.kept_packed && !a.async_xy) {
-            if (a.st->ck_nblk == a.nblk) alive = stream_candidates_if_flow<MODE>(a, kc, lane, wave, done_word, s_etab, acc);
-            else alive = expand_lists<MODE, WEIGHT, (MODE == PROC_FLOW && WEIGHT == 0) ? 1 : 0>(a, kc, bid, wid, lane, wave, done_word, list_bad, in_list, in_tiles, first_counted, s_etab, pairq_all, acc);
+        if (CAND && WEIGHT == 0 && a.cand && a.kept_packed && !a.async_xy && !a.async_self) {
+            if (a.st->ck_nblk[a.list] == a.nblk) alive = stream_candidates<MODE>(a, kc, lane, wave, done_word, s_etab, acc);
+            else alive = expand_lists<MODE, WEIGHT, WEIGHT == 0 ? 1 : 0>(a, kc, bid, wid, lane, wave, done_word, list_bad, in_list, in_tiles, first_counted, s_etab, pairq_all, acc);
         } else {
             alive = expand_lists<MODE, WEIGHT, 0>(a, kc, bid, wid, lane, wave, done_word, list_bad, in_list, in_tiles, first_counted, s_etab, pairq_all, acc);
         }
@@ -1530,8 +1526,9 @@ __device__ void post_step_math(DevState *st, const PostStepArgs &a)
     const int k = st->k;
     // (this iteration's flow pass has recorded or streamed the candidate list: it matches the tile list --
     // until plan_lists, below, schedules a rebuild)
-    if (threadIdx.x == 0 && a.ck_nblk != 0 && st->cnt[2 * LIST_XY + 1] == 0u && st->cnt[2 * LIST_KEPT + 1] == 0u)
-        st->ck_nblk = a.ck_nblk;
+    if (threadIdx.x == 0 && st->cnt[2 * LIST_KEPT + 1] == 0u)
+        for (int l = 0; l < 3; ++l)
+            if (a.ck_nblk[l] != 0 && st->cnt[2 * l + 1] == 0u) st->ck_nblk[l] = a.ck_nblk[l];
     double bcde[4];
     for (int q = 0; q < 4; ++q) bcde[q] = st->red[RED_STEP + q];
     const long long c2 = a.dbg ? (long long)__builtin_readcyclecounter() : 0;

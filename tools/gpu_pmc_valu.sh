@@ -8,7 +8,7 @@ cd /tmp && export TMPDIR=/tmp
 i=0
 for V in "$@"; do
   i=$((i+1))
-  env $V DISTINCT=1 CVO_HIP_GRAPH=1 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_INSTS_LDS GRBM_GUI_ACTIVE --output-format csv -d $OUT/v$i -o p -- python $ROOTDIR/tools/gpu_batch.py ${PMC_N:-10000} 1 ${PMC_B:-64} > $OUT/v$i.log 2>&1
+  env $V DISTINCT=1 CVO_HIP_GRAPH=1 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_INSTS_LDS GRBM_GUI_ACTIVE --output-format csv -d $OUT/v$i -o p -- python $ROOTDIR/tools/gpu_batch.py ${PMC_N:-10000} 1 ${PMC_B:-64} ${PMC_MODE:-} > $OUT/v$i.log 2>&1
   echo "== variant $i: $V"
   python - <<PY
 import csv,collections,glob
