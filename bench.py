@@ -61,6 +61,8 @@ def parse():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-frontend", action="store_true", help="skip the RGB-D front end side leg")
     ap.add_argument("--no-side-legs", action="store_true", help="timed region + roofline only (profiling runs)")
+    ap.add_argument("--saturation-batch", type=int, default=256,
+                    help="side leg: distinct pairs per call with the tail of a call amortised (0 = skip)")
     ap.add_argument("--sharded-points", type=int, default=200000)
     ap.add_argument("--sharded-steps", type=int, default=2)
     ap.add_argument("--sharded-timeout", type=int, default=240, help="watchdog of the sharded leg, seconds")
@@ -229,6 +231,11 @@ def main():
         for c in ctxs:   # (dozens of idle streams slow every other stream's submissions down)
             c.close()
         ctxs = []
+        if not args.no_side_legs and args.saturation_batch > B:
+            try:
+                out["saturation"] = saturation_leg(args, pkg, torch, mode, acvo, n, m)
+            except Exception as e:
+                out["saturation"] = {"error": repr(e)}
         if not args.no_side_legs:
             try:
                 out["config4"] = config4_leg(args, pkg, torch, mode, acvo)
@@ -475,6 +482,44 @@ def identical_leg(args, pkg, ctxs, pair0, one_step, torch):
     el = time.perf_counter() - t0
     return {"registrations_per_s": steps * len(ctxs) / el, "ms_per_step": el * 1e3 / steps,
             "iterations_per_registration": it / float(steps * len(ctxs)), "steps": steps}
+
+
+def saturation_leg(args, pkg, torch, mode, acvo, n, m):
+    """The same workload with `--saturation-batch` distinct pairs per align_many call (four engines of 32
+    slots, the others waiting in the queue): a step of 64 pairs ends with the few longest
+    registrations running almost alone; this is the rate with that tail amortised."""
+    capi = pkg.capi
+    count = args.saturation_batch
+    ctxs, streams = [], []
+    for i in range(count):
+        xf, ff, xm, fm = pkg.data.synthetic_pair(n, m, seed=pair_seed(pkg, i), acvo=acvo)
+        s = torch.cuda.Stream()
+        c = capi.Context(mode=mode, device=torch.cuda.current_device(), stream=s.cuda_stream, graph_capture=True)
+        c.set_fixed(xf, ff)
+        c.set_moving(xm, fm)
+        ctxs.append(c)
+        streams.append(s)
+
+    def step():
+        states = [capi.init_state(c.params) for c in ctxs]
+        return capi.align_many(ctxs, states)
+
+    # (making the pairs kept the GPU idle for seconds: warm up by wall time, not by a step count)
+    t_w = time.perf_counter()
+    while time.perf_counter() - t_w < 0.6:
+        step()
+    torch.cuda.synchronize()
+    steps, it = 4, 0
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        it += sum(step())
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    for c in ctxs:
+        c.close()
+    return {"workload": "%d distinct pairs per align_many call (pair i as in the timed region)" % count,
+            "registrations_per_s": steps * count / el, "ms_per_step": el * 1e3 / steps,
+            "iterations_per_registration": it / float(steps * count), "steps": steps}
 
 
 def config4_leg(args, pkg, torch, mode, acvo, count=8, points=20000):
