@@ -681,12 +681,17 @@ int enqueue_process(cvo_hip_ctx *ctx, int mode, int list, DevBuf &part, const fl
         ctx->ck_nblk[list] = 0;
         if (!no_cand && !(mode == PROC_SELF && no_self) && pre_transform(ctx) && !(ctx->prm.color_scale > 0.0f) &&
             a.kept_packed) {   // (the same plans: synchronous lists)
-            rc = ensure_buf(ctx, ctx->cand[list], (size_t)ctx->lists[LIST_KEPT].cap * sizeof(uint2));
-            if (!rc) rc = ensure_buf(ctx, ctx->cand_cnt[list], PROC_WAVES * sizeof(uint32_t));
-            if (rc) return rc;
-            a.cand = (uint2 *)ctx->cand[list].p;
-            a.cand_cnt = (uint32_t *)ctx->cand_cnt[list].p;
-            ctx->ck_nblk[list] = a.nblk;
+            // (an optimisation: if its memory cannot be had, the pass expands the tile list every time)
+            int rc_c = ensure_buf(ctx, ctx->cand[list], (size_t)ctx->lists[LIST_KEPT].cap * sizeof(uint2));
+            if (!rc_c) rc_c = ensure_buf(ctx, ctx->cand_cnt[list], PROC_WAVES * sizeof(uint32_t));
+            if (!rc_c) {
+                a.cand = (uint2 *)ctx->cand[list].p;
+                a.cand_cnt = (uint32_t *)ctx->cand_cnt[list].p;
+                ctx->ck_nblk[list] = a.nblk;
+            } else {
+                (void)hipGetLastError();
+                ctx->err = "";
+            }
         }
     }
     if (ctx->in_loop && ctx->use_async) {
