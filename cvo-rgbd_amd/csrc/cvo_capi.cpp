@@ -76,8 +76,12 @@ struct List {     // LIST_XY/XX/YY: TileEntry[cap] in a; LIST_KEPT: uint2[cap] i
 // batch enqueued when the running one has finished -- 6 / 8 / 12 / 16 / 24: 643 / 644 / 632 / 625 / 600 reg/s at 10k x 10k,
 // 650 / 668 / 668 / 644 / 672 at 3k x 3k, acvo 388 / 393 / 376 / 392 / 380)
 // ... and in a fused group, where a batch boundary is also where a slot that fell free is noticed and
-// refilled: shorter (64 distinct pairs: 3 -> 2857, 4 -> 2917, 6 -> 2693, 8 -> 2621 registrations/s)
-static const int kEngineBatch = [] { const char *e = getenv("CVO_HIP_ENGINE_BATCH"); const int v = e ? atoi(e) : 4; return v >= 1 && v <= 64 ? v : 4; }();
+// refilled.  With tables of 16 slots (a batch of 64 pairs = 48 in flight + 16 waiting for a slot) shorter was
+// better (3 -> 2857, 4 -> 2917, 6 -> 2693, 8 -> 2621 registrations/s); with tables of 32 a batch of 64 is in
+// flight at once and the iterations are cheaper (candidate lists): 4 / 8 / 10 / 12 / 16 / 24 per captured batch:
+// 256 pairs per call 3905 / 4188 / 4254 / 4248 / 4277 / 4105, 64 pairs 3604 / 3625 / - / 3650 / 3594 / 3571,
+// 32 pairs 2630 / 2734 / - / 2723 / 2453 / 2694, 8 x 20k 1022 / 1029 / 1028 / 1014 / 995 / 961 -> 10
+static const int kEngineBatch = [] { const char *e = getenv("CVO_HIP_ENGINE_BATCH"); const int v = e ? atoi(e) : 10; return v >= 1 && v <= 64 ? v : 10; }();
 static const int kBatch = [] { const char *e = getenv("CVO_HIP_BATCH"); const int v = e ? atoi(e) : 8; return v >= 1 && v <= 64 ? v : 8; }();
 
 // The kernels of the loop read their argument blocks from a table of Slots in device memory
