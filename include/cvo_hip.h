@@ -231,8 +231,10 @@ int cvo_hip_align(cvo_hip_ctx *ctx, cvo_hip_state *state, cvo_hip_trace *trace,
  * registrations, one context each, driven concurrently by the calling thread.
  * Equivalent to calling cvo_hip_align(ctxs[i], states[i], NULL, 0, &n_iters[i])
  * for every i -- bit for bit -- but with all of them in flight at once: contexts
- * of the same device and mode share their kernel launches in groups of up to 16
- * (one grid slice per registration) on streams owned by the library; contexts
+ * of the same device and mode share their kernel launches in groups of up to 32
+ * (one grid slice per registration; up to four such groups run side by side, and a
+ * registration that stops hands its slice to the next one of the call) on streams
+ * owned by the library; contexts
  * that profile or are sharded over ranks run on their own streams.  All the
  * contexts' streams are idle when the call returns.  Returns the first
  * non-zero status, 0 if all succeeded. */
