@@ -82,7 +82,8 @@ struct List {     // LIST_XY/XX/YY: TileEntry[cap] in a; LIST_KEPT: uint2[cap] i
 // 256 pairs per call 3905 / 4188 / 4254 / 4248 / 4277 / 4105, 64 pairs 3604 / 3625 / - / 3650 / 3594 / 3571,
 // 32 pairs 2630 / 2734 / - / 2723 / 2453 / 2694, 8 x 20k 1022 / 1029 / 1028 / 1014 / 995 / 961 -> 10
 static const int kEngineBatch = [] { const char *e = getenv("CVO_HIP_ENGINE_BATCH"); const int v = e ? atoi(e) : 10; return v >= 1 && v <= 64 ? v : 10; }();
-static const int kBatch = [] { const char *e = getenv("CVO_HIP_BATCH"); const int v = e ? atoi(e) : 8; return v >= 1 && v <= 64 ? v : 8; }();
+// (an even number: a head-mode batch must leave the state's head in its first copy, cvo_kernels.hip "the head")
+static const int kBatch = [] { const char *e = getenv("CVO_HIP_BATCH"); const int v = e ? atoi(e) : 8; return v >= 1 && v <= 64 ? (v + 1) / 2 * 2 : 8; }();
 
 // The kernels of the loop read their argument blocks from a table of Slots in device memory
 // (cvo_device.h "Argument tables"): one slot for a registration on its own (cvo_hip_align), up
@@ -158,7 +159,7 @@ struct TableBuf {
 // address and on the plan -- kernels, grids, LDS sizes -- not on any argument: one capture
 // serves every frame pair (and every membership of a fused group) of the same shape.
 struct PlanGraph {
-    std::vector<TLaunch> plan;
+    std::vector<TLaunch> plan, tail;
     int iterations = 0;
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
@@ -206,6 +207,9 @@ struct cvo_hip_ctx {
     Cloud fixed, moving;
     Cloud scratch_a, scratch_b;      // cvo_hip_function_inner_product_clouds: never the registration's clouds
     DevState *st = nullptr;          // device
+    DevHead *st2 = nullptr;          // device: second copy of the state's head (head mode, cvo_kernels.hip)
+    bool head_mode = false;          // the plan of the align() in progress is a head-mode plan
+    bool allow_head = true;          // CVO_HIP_NO_HEAD
     DevState *st_host = nullptr;     // pinned [kPollSlots + 2]
     int32_t *done_mirror = nullptr;  // pinned (in the last slot): the post kernels copy `done` here
     int32_t *progress_mirror = nullptr;   // pinned, next to it: slots the post-step kernel has completed
@@ -254,6 +258,7 @@ struct cvo_hip_ctx {
     CommTable *comm_table = nullptr;     // device copy; not null = connected: the post kernels exchange
     void *mail_opened[MAX_WORLD] = {};   // peers' mailboxes opened from IPC handles (closed at destroy)
     int mail_rank = 0, mail_world = 0;
+    bool mail_broken = false;            // an exchange timed out: the ranks' sequence numbers no longer agree (see job_finish)
     cvo_hip_allreduce_fn user_allreduce = nullptr;
     void *user_allreduce_arg = nullptr;
     bool profiling = false;
@@ -261,6 +266,7 @@ struct cvo_hip_ctx {
     TableBuf table;                  // this registration's own argument table (one slot): cvo_hip_align
     PlanCache plans;                 // ... and the batches captured for it
     std::vector<TLaunch> plan;       // launches of one iteration of the align() in progress
+    std::vector<TLaunch> plan_tail;  // ... and what closes a batch of them (head mode: the flush)
     hipStream_t loop_stream = nullptr;   // stream the align() in progress runs on (a fused group's, else `stream`)
     bool warm = false;               // every device buffer of the loop has been allocated
     bool use_graphs = true;
@@ -580,6 +586,7 @@ int enqueue_filter(cvo_hip_ctx *ctx, int list, const Cloud &ca, int row_lo, int 
     a.pos_a = pos_a; a.pos_b = pos_b;
     a.seg_a = ca.seg; a.seg_b = cb.seg;
     a.st = ctx->st;
+    a.st2 = static_cast<DevState *>(ctx->st2);   // (only its head exists: head mode reads / writes nothing else of it)
     a.tiles = (TileEntry *)ctx->lists[list].a.p;
     a.subcap = ctx->lists[list].cap / NSUB;
     a.list = list;
@@ -664,6 +671,7 @@ int enqueue_process(cvo_hip_ctx *ctx, int mode, int list, DevBuf &part, const fl
     a.kept_cnt = (uint32_t *)ctx->kept_cnt.p;
     a.partials = (double *)part.p;
     a.st = ctx->st;
+    a.st2 = static_cast<DevState *>(ctx->st2);
     a.subcap = ctx->lists[list].cap / NSUB;
     a.nblk = ctx->proc_blocks;
     a.kept_wcap = ctx->lists[LIST_KEPT].cap / (uint32_t)(4 * ctx->proc_blocks);
@@ -927,6 +935,7 @@ int enqueue_step(cvo_hip_ctx *ctx, int check_done, bool do_math, cvo_hip_trace *
     if (rc) return rc;
     PostStepArgs pa{};
     pa.st = ctx->st;
+    pa.st2 = static_cast<DevState *>(ctx->st2);
     pa.prm = ctx->in_loop ? loop_params(ctx) : ctx->dprm;
     pa.trace = trace; pa.trace_cap = trace_cap;
     pa.check_done = check_done;
@@ -959,13 +968,13 @@ int enqueue_step(cvo_hip_ctx *ctx, int check_done, bool do_math, cvo_hip_trace *
 int check_overflow_and_grow(cvo_hip_ctx *ctx, bool *redo)
 {
     DevState *h = &ctx->st_host[0];
-    HIP_TRY(ctx, hipMemcpyAsync(h->cnt, reinterpret_cast<char *>(ctx->st) + offsetof(DevState, cnt),
-                                sizeof(DevState) - offsetof(DevState, cnt), hipMemcpyDeviceToHost,
+    HIP_TRY(ctx, hipMemcpyAsync(h->sub, reinterpret_cast<char *>(ctx->st) + offsetof(DevState, sub),
+                                sizeof(DevState) - offsetof(DevState, sub), hipMemcpyDeviceToHost,
                                 ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     *redo = false;
     for (int l = 0; l < LIST_N; ++l)
-        if (h->cnt[2 * l + 1]) {
+        if (h->ovf[0][l] | h->ovf[1][l]) {
             uint32_t worst = 0;
             for (int q = 0; q < NSUB; ++q) worst = std::max(worst, h->sub[l][q]);
             const double need = std::max((double)worst * NSUB, (double)ctx->lists[l].cap);
@@ -1039,9 +1048,15 @@ long long filter_items(const FilterArgs &f) { return (long long)f.gx * f.gy; }
 //   flow pass + xy build + xx / yy filters (self passes afterwards) -> kt_flow_build3, kt_self2
 //   flow pass + xy build                                            -> kt_flow_build
 //   synchronous lists                                               -> kt_filter(_group), kt_process, kt_self2
-bool plan_lone(const std::vector<RecOp> &ops, Slot &slot, std::vector<TLaunch> &plan)
+// Head mode (cvo_kernels.hip "the head"), where the scheme allows it -- asynchronous builds, step pass with the
+// twist in front, one rank: the post-step launch is gone; its argument block rides in the flow launch's entry
+// (op[q].ps), every flow / self block runs it as its head, and `tail` closes a batch with the flush.
+bool plan_lone(const std::vector<RecOp> &ops, Slot &slot, std::vector<TLaunch> &plan, std::vector<TLaunch> &tail,
+               const bool allow_head, bool *head_mode)
 {
     plan.clear();
+    tail.clear();
+    *head_mode = false;
     std::memset(&slot, 0, sizeof(slot));
     slot.active = 1;
     const long long fbmax = filter_blocks_cap();
@@ -1062,6 +1077,19 @@ bool plan_lone(const std::vector<RecOp> &ops, Slot &slot, std::vector<TLaunch> &
     }
     int q = 0;
     auto smem_of = [](int jt) { return (unsigned)filter_smem_bytes(jt); };
+    // what follows the flow side must be exactly: step pass with the twist, post-step (reduce + maths, no exchange)
+    const bool rest_fits = at + 2 == ops.size() && ops[at].kind == RecOp::PROCESS && ops[at].mode == kProcStepTwist &&
+                           ops[at + 1].kind == RecOp::POST_STEP && ops[at + 1].ps.comm == nullptr &&
+                           ops[at + 1].ps.flags == (POST_REDUCE | POST_MATH) && ops[at + 1].ps.st2 != nullptr;
+    // (acvo: flow pass and both self passes, 3 x np blocks, all run the head; with the 1024 blocks per pass
+    // of round 2 three heads per SIMD took turns at the vector ALU and an iteration was a third SLOWER,
+    // 40.5 -> 55 us at 10k x 10k -- job_begin gives acvo's passes 256 / 128 blocks now, profiles/r03_ab.txt)
+    static const bool head_acvo = getenv("CVO_HIP_NO_HEAD_ACVO") == nullptr;
+    // (CVO_HIP_HEAD_FLUSH: close every batch with the post-step part of its last slot as a launch of its
+    // own, so that the host paces without any lead -- the first version, 2 us per iteration slower)
+    static const bool head_flush = getenv("CVO_HIP_HEAD_FLUSH") != nullptr;
+    const bool head = allow_head && rest_fits && have_flow && have_build &&
+                      ((na == 2 && ns == 2 && nf == 0 && head_acvo) || (na == 0 && ns == 0 && nf == 0));
     if (have_flow && have_build && ((na == 2 && ns == 2) || nf == 2)) {
         // (op[q]: flow pass + xy build; op[q + 1], op[q + 2]: the xx / yy filters and, `six`, the self passes)
         const bool six = na == 2 && ns == 2;
@@ -1077,8 +1105,10 @@ bool plan_lone(const std::vector<RecOp> &ops, Slot &slot, std::vector<TLaunch> &
         o.n1 = (int)filter_grid_cap(filter_items(slot.op[q + 1].f), cap);
         o.n2 = (int)filter_grid_cap(filter_items(slot.op[q + 2].f), cap);
         const int jt = std::max(o.f.jt, std::max(slot.op[q + 1].f.jt, slot.op[q + 2].f.jt));
-        plan.push_back(mk_launch(six ? TK_FLOW_BUILD6 : TK_FLOW_BUILD3, q,
+        if (head) o.ps = ops[at + 1].ps;
+        plan.push_back(mk_launch(head ? TK_HFLOW_BUILD6 : (six ? TK_FLOW_BUILD6 : TK_FLOW_BUILD3), q,
                                  (unsigned)((six ? 3 : 1) * o.np + o.n0 + o.n1 + o.n2), 1, smem_of(jt)));
+        if (head && head_flush) tail.push_back(mk_launch(TK_HFLUSH, q, 1, 1));
         q += 3;
         if (six) ns = 0;
         nf = 0;
@@ -1107,7 +1137,9 @@ bool plan_lone(const std::vector<RecOp> &ops, Slot &slot, std::vector<TLaunch> &
             const long long cap = std::max<long long>(64, 2 * fbmax / fb_div);
             o.np = std::max(8, flow.nblk);
             o.n0 = (int)std::max(8u, filter_grid_cap(filter_items(build), cap));
-            plan.push_back(mk_launch(TK_FLOW_BUILD, q, (unsigned)(o.np + o.n0), 1, smem_of(build.jt)));
+            if (head) o.ps = ops[at + 1].ps;
+            plan.push_back(mk_launch(head ? TK_HFLOW_BUILD : TK_FLOW_BUILD, q, (unsigned)(o.np + o.n0), 1, smem_of(build.jt)));
+            if (head && head_flush) tail.push_back(mk_launch(TK_HFLUSH, q, 1, 1));
             ++q;
         } else if (have_flow) {
             slot.op[q].p = flow;
@@ -1132,27 +1164,15 @@ bool plan_lone(const std::vector<RecOp> &ops, Slot &slot, std::vector<TLaunch> &
         else if (op.kind == RecOp::POST_STEP) { o.ps = op.ps; plan.push_back(mk_launch(TK_POST_STEP, q, 1, 1)); }
         else if (op.kind == RecOp::PROCESS && op.mode == kProcStepTwist) {
             o.p = op.p;
-            // CVO_HIP_TAIL=1: the post-step maths rides in the same launch (last block to deliver:
-            // kt_step_twist_post).  Off by default: measured 36.4 vs 33.3 us per iteration at 10k x 10k
-            // (26.3 vs 24.4 at 3k x 3k) -- the release fence of every block plus the acquire of the last
-            // one cost more than the kernel boundary and the launch they save (profiles/r02_ab.txt)
-            static const bool tail = getenv("CVO_HIP_TAIL") != nullptr;
-            const bool fuse = tail && at + 2 == ops.size() && ops[at + 1].kind == RecOp::POST_STEP &&
-                              ops[at + 1].ps.comm == nullptr && q + 1 < MAX_OPS;
-            plan.push_back(mk_launch(fuse ? TK_STEP_TWIST_POST : TK_STEP_TWIST, q,
-                                     (unsigned)std::max(8, std::max(32, op.p.nblk) / 4), 1));
-            if (fuse) {
-                slot.op[q + 1].ps = ops[at + 1].ps;
-                q += 2;
-                at += 1;
-                continue;
-            }
+            plan.push_back(mk_launch(head ? TK_HSTEP_TWIST : TK_STEP_TWIST, q, (unsigned)std::max(8, std::max(32, op.p.nblk) / 4), 1));
+            if (head) { ++q; break; }   // (the post-step launch that follows is the head of the next flow launch)
         } else if (op.kind == RecOp::PROCESS && op.mode == PROC_STEP) {
             o.p = op.p;
             plan.push_back(mk_launch(TK_STEP, q, (unsigned)std::max(1, op.p.nblk), 1));
         } else return false;
         ++q;
     }
+    *head_mode = head;
     return q <= MAX_OPS;
 }
 
@@ -1268,25 +1288,35 @@ bool same_plan(const std::vector<TLaunch> &a, const std::vector<TLaunch> &b)
     return a.size() == b.size() && (a.empty() || std::memcmp(a.data(), b.data(), a.size() * sizeof(TLaunch)) == 0);
 }
 
-void launch_plan_eager(const Slot *tab, const std::vector<TLaunch> &plan, int iterations, hipStream_t s)
+void launch_plan_eager(const Slot *tab, const std::vector<TLaunch> &plan, const std::vector<TLaunch> &tail, int iterations,
+                       hipStream_t s)
 {
     for (int k = 0; k < iterations; ++k)
-        for (const TLaunch &l : plan) launch_table(tab, l, s);
+        for (const TLaunch &l : plan) launch_table(tab, l, s, nullptr, nullptr, k & 1);
+    for (const TLaunch &l : tail) launch_table(tab, l, s);
 }
 
 // kBatch iterations of `plan` on table `tab`: through a cached graph when allowed, else eagerly.
 int run_plan(const Slot *tab, PlanCache &cache, const std::vector<TLaunch> &plan, hipStream_t s, bool use_graph,
-             int iterations)
+             int iterations, const std::vector<TLaunch> &tail = std::vector<TLaunch>())
 {
     if (!use_graph || cache.fails >= 64) {
-        launch_plan_eager(tab, plan, iterations, s);
+        launch_plan_eager(tab, plan, tail, iterations, s);
         return hipGetLastError() == hipSuccess ? CVO_HIP_OK : CVO_HIP_ERR_HIP;
     }
     PlanGraph *hit = nullptr;
     for (auto &g : cache.graphs)
-        if (g.iterations == iterations && same_plan(g.plan, plan)) { hit = &g; break; }
+        if (g.iterations == iterations && same_plan(g.plan, plan) && same_plan(g.tail, tail)) { hit = &g; break; }
     if (hit) ++cache.hits;
     if (!hit) {
+        // The capture window needs the library's lock exclusively (cvo_lock.h).  Not getting it within its
+        // millisecond -- other host threads are inside their own entry points -- is neither a capture nor a
+        // failed one: this batch goes out eagerly, nothing is counted, the next batch tries again.
+        cvo_lock::Capture alone;   // (held: no other thread of this library is inside the runtime)
+        if (!alone.ok) {
+            launch_plan_eager(tab, plan, tail, iterations, s);
+            return hipGetLastError() == hipSuccess ? CVO_HIP_OK : CVO_HIP_ERR_HIP;
+        }
         ++cache.captures;
         if (cache.graphs.size() >= 12) {   // evict the least recently used entry
             size_t lru = 0;
@@ -1298,22 +1328,20 @@ int run_plan(const Slot *tab, PlanCache &cache, const std::vector<TLaunch> &plan
         }
         PlanGraph g;
         g.plan = plan;
+        g.tail = tail;
         g.iterations = iterations;
         // A capture can be spoilt from outside (another thread's HIP work: cvo_lock.h).  Nothing
         // has been launched then: the batch goes out eagerly and the next one tries again.
         hipError_t e = hipErrorUnknown;
-        {
-            cvo_lock::Capture alone;   // (no other thread of this library is inside the runtime)
-            if (alone.ok && hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed) == hipSuccess) {
-                launch_plan_eager(tab, plan, iterations, s);
-                e = hipStreamEndCapture(s, &g.graph);
-            }
+        if (hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed) == hipSuccess) {
+            launch_plan_eager(tab, plan, tail, iterations, s);
+            e = hipStreamEndCapture(s, &g.graph);
         }
         if (e != hipSuccess || !g.graph || hipGraphInstantiate(&g.exec, g.graph, nullptr, nullptr, 0) != hipSuccess) {
             if (g.graph) (void)hipGraphDestroy(g.graph);
             (void)hipGetLastError();
             ++cache.fails;
-            launch_plan_eager(tab, plan, iterations, s);
+            launch_plan_eager(tab, plan, tail, iterations, s);
             return hipGetLastError() == hipSuccess ? CVO_HIP_OK : CVO_HIP_ERR_HIP;
         }
         cache.fails = 0;
@@ -1349,7 +1377,8 @@ int prepare_lone_plan(cvo_hip_ctx *ctx, int trace_cap)
     int rc = record_iteration(ctx, ops, trace_cap);
     if (rc) return rc;
     Slot slot;
-    if (!plan_lone(ops, slot, ctx->plan)) return fail(ctx, CVO_HIP_ERR_INVALID, "launch plan does not fit the argument table");
+    if (!plan_lone(ops, slot, ctx->plan, ctx->plan_tail, ctx->allow_head, &ctx->head_mode))
+        return fail(ctx, CVO_HIP_ERR_INVALID, "launch plan does not fit the argument table");
     if (ctx->table.sync(&slot, loop_stream(ctx)) != 0) return fail(ctx, CVO_HIP_ERR_HIP, "argument table upload failed");
     return CVO_HIP_OK;
 }
@@ -1364,15 +1393,15 @@ int launch_batch(cvo_hip_ctx *ctx, int tag0, int trace_cap)
         if (!rc) ctx->warm = true;
         return rc;
     }
-    const int rc = run_plan(ctx->table.dev, ctx->plans, ctx->plan, loop_stream(ctx), ctx->use_graphs, kBatch);
+    const int rc = run_plan(ctx->table.dev, ctx->plans, ctx->plan, loop_stream(ctx), ctx->use_graphs, kBatch, ctx->plan_tail);
     if (rc) return fail(ctx, rc, "launching a batch of iterations failed");
     return CVO_HIP_OK;
 }
 
 int zero_counters(cvo_hip_ctx *ctx)
 {
-    HIP_TRY(ctx, hipMemsetAsync(reinterpret_cast<char *>(ctx->st) + offsetof(DevState, cnt), 0,
-                                sizeof(uint32_t) * 2 * LIST_N, ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(reinterpret_cast<char *>(ctx->st) + offsetof(DevState, ovf), 0,
+                                sizeof(uint32_t) * 16, ctx->stream));
     HIP_TRY(ctx, hipMemsetAsync(reinterpret_cast<char *>(ctx->st) + offsetof(DevState, sub), 0,
                                 sizeof(uint32_t) * LIST_N * NSUB, ctx->stream));
     return CVO_HIP_OK;
@@ -1508,6 +1537,8 @@ int cvo_hip_create(int device, void *stream, const cvo_hip_params *p, cvo_hip_ct
         ctx->own_stream = true;
     }
     if (hipMalloc((void **)&ctx->st, sizeof(DevState)) != hipSuccess) return bail(CVO_HIP_ERR_NOMEM);
+    if (hipMalloc((void **)&ctx->st2, sizeof(DevHead)) != hipSuccess) return bail(CVO_HIP_ERR_NOMEM);
+    if (getenv("CVO_HIP_NO_HEAD")) ctx->allow_head = false;
     if (hipHostMalloc((void **)&ctx->st_host, (kPollSlots + 2) * sizeof(DevState),
                       hipHostMallocDefault) != hipSuccess)
         return bail(CVO_HIP_ERR_NOMEM);
@@ -1577,7 +1608,7 @@ int cvo_hip_destroy(cvo_hip_ctx *ctx)
     for (void *p : {(void *)ctx->fixed.pos, (void *)ctx->fixed.feat, (void *)ctx->moving.pos,
                     (void *)ctx->moving.feat, (void *)ctx->fixed.seg, (void *)ctx->moving.seg,
                     (void *)ctx->scratch_a.pos, (void *)ctx->scratch_a.feat, (void *)ctx->scratch_a.seg,
-                    (void *)ctx->scratch_b.pos, (void *)ctx->scratch_b.feat, (void *)ctx->scratch_b.seg, (void *)ctx->st, ctx->part_flow.p, ctx->part_xx.p,
+                    (void *)ctx->scratch_b.pos, (void *)ctx->scratch_b.feat, (void *)ctx->scratch_b.seg, (void *)ctx->st, (void *)ctx->st2, ctx->part_flow.p, ctx->part_xx.p,
                     ctx->part_yy.p, ctx->part_step.p, (void *)ctx->trace_dev, ctx->kept_cnt.p, ctx->pos_bt.p, ctx->cand[0].p, ctx->cand[1].p, ctx->cand[2].p, ctx->cand_cnt[0].p,
                     ctx->cand_cnt[1].p, ctx->cand_cnt[2].p})
         if (p) (void)hipFree(p);
@@ -1723,6 +1754,7 @@ int cvo_hip_mailbox_create(cvo_hip_ctx *ctx, int rank, int world, void *ipc_hand
     HIP_TRY(ctx, hipDeviceSynchronize());   // (null-stream fills: the context's stream does not wait for them by itself)
     ctx->mail_rank = rank;
     ctx->mail_world = world;
+    ctx->mail_broken = false;
     if (ipc_handle_64) {
         std::memset(ipc_handle_64, 0, CVO_HIP_MAILBOX_HANDLE_BYTES);
         hipIpcMemHandle_t h;
@@ -1923,6 +1955,9 @@ struct AlignJob {
     int phase = 0;          // 0 enqueueing/polling, 1 waiting for the final state, 2 finished
     int rc = CVO_HIP_OK;
     bool in_group = false;  // runs in a fused group (on the group's stream and table)
+    bool paced = false;     // cvo_hip_align only: the calling thread has nothing else to pump and may sit in the
+                            // paced loop of job_pump (align_many's blocking fall-back must keep its round-robin going:
+                            // the other jobs -- the peer ranks of a mailbox world among them -- run dry otherwise)
 };
 
 int job_begin(AlignJob &j)
@@ -1930,6 +1965,9 @@ int job_begin(AlignJob &j)
     cvo_hip_ctx *ctx = j.ctx;
     cvo_hip_state *s = j.s;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (ctx->comm_table && ctx->mail_broken)
+        return fail(ctx, CVO_HIP_ERR_COMM, "the mailboxes of this context are unusable after a timed-out exchange: "
+                                           "call cvo_hip_mailbox_create and cvo_hip_mailbox_connect again on every rank");
     const cvo_hip_params &p = ctx->prm;
     if (p.mode == CVO_HIP_MODE_ACVO) {   // tail of acvo::set_pcd (ref src/adaptive_cvo.cpp:476-478)
         s->ell = p.ell_init;
@@ -1962,9 +2000,9 @@ int job_begin(AlignJob &j)
     HIP_TRY(ctx, hipMemcpyAsync(ctx->st, h, DEVSTATE_INIT_BYTES, hipMemcpyHostToDevice, loop_stream(ctx)));
     // small clouds (the ~3k-point clouds of the reference's front end): 2048 waves do
     // (measured 3k x 3k: 2.11 ms with 512 blocks, 2.19 with 1024; 10k x 10k the other way round)
+    const bool small_pair = (double)ctx->fixed.n * (double)ctx->moving.n <= 2.5e7;
     if (!ctx->proc_blocks_forced)
-        ctx->proc_blocks = ctx->proc_blocks_default =
-            ((double)ctx->fixed.n * (double)ctx->moving.n <= 2.5e7) ? PROC_BLOCKS / 2 : PROC_BLOCKS;
+        ctx->proc_blocks = ctx->proc_blocks_default = small_pair ? PROC_BLOCKS / 2 : PROC_BLOCKS;
     // (use_async_self below; from ~20k x 20k on a build is too long to hide beside one flow pass)
     // (the MATLAB weight exists as a classic k_process launch only)
     ctx->use_async = ctx->allow_async && !ctx->crowded && !ctx->profiling && !multi_rank(ctx) &&
@@ -1972,6 +2010,12 @@ int job_begin(AlignJob &j)
                      (double)ctx->fixed.n * (double)ctx->moving.n <= 2.0e8;
     ctx->use_async_self = ctx->use_async && ctx->allow_async_self && ctx->lone &&
                           ctx->prm.mode == CVO_HIP_MODE_ACVO;
+    // acvo with everything in one launch (flow pass + both self passes + the builds = 3 x blocks + filter blocks):
+    // a quarter of the blocks per pass do (measured one registration at a time, 1024 / 512 / 256 / 128 blocks per
+    // pass: 10k x 10k 390 / 461 / 499 / - registrations/s with the post-step launch, - / 417 / 537 / 499 in head
+    // mode; 3k x 3k - / 543 / 619 / - and - / 473 / 703 / 749 -- profiles/r03_ab.txt)
+    if (ctx->use_async_self && !ctx->proc_blocks_forced)
+        ctx->proc_blocks = ctx->proc_blocks_default = small_pair ? PROC_BLOCKS / 8 : PROC_BLOCKS / 4;
     launch_prepare(ctx->st, loop_params(ctx), loop_stream(ctx));
     HIP_TRY(ctx, hipGetLastError());
     ctx->have_tf = true;
@@ -2000,8 +2044,15 @@ int job_finish(AlignJob &j)
     cvo_hip_state *s = j.s;
     const DevState &f = ctx->st_host[0];
     ctx->have_tf = false;   // the low-level entry points need their own transform_pcd()
-    if (f.done == DONE_COMM_ERROR)
-        return fail(ctx, CVO_HIP_ERR_COMM, "mailbox all-reduce timed out: a peer rank never delivered its partial sums");
+    if (f.done == DONE_COMM_ERROR) {
+        // The rank that timed out has advanced its sequence number, a peer that left early or never launched
+        // has not, and a late store may still land in a slot of the same generation: from here on every
+        // exchange of this world would mismatch or time out.  The mailboxes are unusable until every rank
+        // has called cvo_hip_mailbox_create / _connect again; sharded calls are refused until then.
+        ctx->mail_broken = true;
+        return fail(ctx, CVO_HIP_ERR_COMM, "mailbox all-reduce timed out: a peer rank never delivered its partial sums "
+                                           "(the mailboxes must be created and connected again on every rank)");
+    }
     if (f.done == RUNNING || f.done == NEED_BIGGER_LIST)
         return fail(ctx, CVO_HIP_ERR_INVALID, "align loop ended without a verdict");
     const int executed = f.n_exec;
@@ -2047,20 +2098,47 @@ int job_pump(AlignJob &j, bool block)
     // (CVO_HIP_PACE_LEAD = slots of overlap, 0 / 1 / 2 / 3: 644 / 619 / 627 / 620 registrations/s at
     // 10k x 10k, event-paced two batches ahead: 604).
     static const bool no_pace = getenv("CVO_HIP_NO_PACE") != nullptr;
-    if (j.phase == 0 && block && !no_pace && !host_reduce(ctx) && !ctx->profiling) {
-        const int limit = (ctx->use_async ? 2 : 1) * ctx->prm.max_iter + 4 * kBatch;
+    if (j.phase == 0 && block && j.paced && !no_pace && !host_reduce(ctx) && !ctx->profiling) {
+        const int limit = (ctx->use_async ? 3 : 1) * ctx->prm.max_iter + 4 * kBatch;
+        unsigned spins = 0;
+        int idle_seen = 0;
         for (;;) {
             if (*(volatile int32_t *)ctx->done_mirror != RUNNING) break;
             const int slots = *(volatile int32_t *)ctx->progress_mirror;
-            static const int lead = [] { const char *e = getenv("CVO_HIP_PACE_LEAD"); const int v = e ? atoi(e) : 0; return v >= 0 && v <= 64 ? v : 0; }();
+            // (head mode without a flush: the post-step part of a batch's last slot runs in the head of the NEXT
+            // batch's first launch, so the next batch must be on its way before the running one ends -- it goes
+            // out when the running batch is down to its last slots; the GPU never idles between batches, and
+            // a registration that stops in those last slots leaves one batch of launches that return at once)
+            static const int lead_env = [] { const char *e = getenv("CVO_HIP_PACE_LEAD"); const int v = e ? atoi(e) : -1; return v >= 0 && v <= 64 ? v : -1; }();
+            const bool flushless = ctx->head_mode && ctx->plan_tail.empty();
+            const int lead = lead_env >= 0 ? std::max(lead_env, flushless ? 1 : 0) : (flushless ? 2 : 0);
             if (j.enq - slots <= lead) {
                 if (j.enq >= limit) break;   // cannot happen
                 const int rc = launch_batch(ctx, j.executed_base + j.enq, j.trace_cap);
                 if (rc) return finish_with(rc);
                 j.enq += kBatch;
                 ++j.batches;
+                spins = 0;
+                idle_seen = 0;
             } else {
                 __builtin_ia32_pause();
+                // The two words only move while the queued kernels run.  A fault, a stream in an error state or a
+                // post kernel that never ran would leave this thread spinning for ever: now and then ask the
+                // stream itself (a batch lasts ~0.25 ms; 2^14 pauses are about that long).
+                if ((++spins & 0x3fffu) == 0u) {
+                    const hipError_t q = hipStreamQuery(loop_stream(ctx));
+                    if (q != hipSuccess && q != hipErrorNotReady)
+                        return finish_with(fail(ctx, CVO_HIP_ERR_HIP, "the stream of the align loop reports an error"));
+                    // idle, yet the batch has not reported all its slots and nothing stopped: seen twice in a row
+                    // (the mirrors are written before a kernel ends, so once is already conclusive; twice is cheap)
+                    if (q == hipSuccess && *(volatile int32_t *)ctx->done_mirror == RUNNING &&
+                        *(volatile int32_t *)ctx->progress_mirror == slots) {
+                        if (++idle_seen >= 2)
+                            return finish_with(fail(ctx, CVO_HIP_ERR_HIP, "the align loop's stream went idle without progress"));
+                    } else {
+                        idle_seen = 0;
+                    }
+                }
             }
         }
         if (hipMemcpyAsync(&ctx->st_host[0], ctx->st, sizeof(DevState), hipMemcpyDeviceToHost,
@@ -2100,7 +2178,7 @@ int job_pump(AlignJob &j, bool block)
                              : *(volatile int32_t *)ctx->done_mirror != RUNNING)
             stop = true;
         // (slots, not iterations: asynchronous builds add a stall slot now and then)
-        if (j.enq >= (ctx->use_async ? 2 : 1) * ctx->prm.max_iter + 4 * kBatch) stop = true;   // cannot happen
+        if (j.enq >= (ctx->use_async ? 3 : 1) * ctx->prm.max_iter + 4 * kBatch) stop = true;   // cannot happen
         if (!stop) return 0;
         // everything still queued either runs or returns at once; fetch the full state
         if (hipMemcpyAsync(&ctx->st_host[0], ctx->st, sizeof(DevState), hipMemcpyDeviceToHost,
@@ -2120,7 +2198,7 @@ int job_pump(AlignJob &j, bool block)
     if (ctx->profiling) rc = drain_events(ctx, cur.k + 1, &cur);
     j.executed_base = cur.k;
     for (int l = 0; l < LIST_N && !rc; ++l)
-        if (cur.cnt[2 * l + 1]) {
+        if (cur.ovf[0][l] | cur.ovf[1][l]) {
             uint32_t worst = 0;   // appends are spread evenly: scale by the fullest sub-list
             for (int qq = 0; qq < NSUB; ++qq) worst = std::max(worst, cur.sub[l][qq]);
             const double grown =
@@ -2398,7 +2476,7 @@ struct Engine {
                 if (cur.done != NEED_BIGGER_LIST) { finish_job(j, job_finish(*j)); continue; }
                 int rc = CVO_HIP_OK;
                 for (int l = 0; l < LIST_N && !rc; ++l)
-                    if (cur.cnt[2 * l + 1]) {
+                    if (cur.ovf[0][l] | cur.ovf[1][l]) {
                         uint32_t worst = 0;
                         for (int qq = 0; qq < NSUB; ++qq) worst = std::max(worst, cur.sub[l][qq]);
                         const double grown = std::min(
@@ -2578,6 +2656,7 @@ int cvo_hip_align(cvo_hip_ctx *ctx, cvo_hip_state *s, cvo_hip_trace *trace, int 
     if (!ctx || !s) return CVO_HIP_ERR_INVALID;
     AlignJob j;
     j.ctx = ctx; j.s = s; j.trace = trace; j.trace_cap = trace_cap; j.n_iter = n_iter;
+    j.paced = true;
     int rc = job_begin(j);
     if (rc) return rc;
     while (!job_pump(j, true)) {}

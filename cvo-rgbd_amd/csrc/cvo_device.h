@@ -139,8 +139,10 @@ struct DevParams {
     double s2_d, cs2_d, dl_step;
 };
 
-// The registration state, resident in HBM for the whole align().
-struct DevState {
+// The registration state, resident in HBM for the whole align(): a HEAD (what the O(1) maths of an
+// iteration reads and writes; the post kernels take a private copy of it into registers; head mode
+// keeps two copies in HBM) and a TAIL (counters that the list kernels touch with atomics).
+struct alignas(16) DevHead {
     float R[9], T[3];
     float ell, ell_max;
     float Rt[9], t[3];          // inverse transform of the current iteration
@@ -154,7 +156,7 @@ struct DevState {
     float xmax, y0max;          // max |x - center|, max |y0 - center| (bbox bounds)
     float tauf[3];
     int32_t n_fixed;            // points of the fixed cloud as the caller counts them (acvo Ayy rule);
-    uint32_t step_ticket;       // blocks of kt_step_twist_post that have delivered their partial sums
+    uint32_t pad0_;
     // Tile-list re-use (plan_lists): list l was built with every pair closer than
     // list_r[l]; the xy list with the moving cloud at [list_Rt | list_t].
     float list_r[3];
@@ -163,16 +165,18 @@ struct DevState {
     int32_t ck_nblk[3];         // candidate list of tile list l (ProcessArgs::cand): recorded by a pass of this many
                                 // blocks over the tile list as it stands; 0 = none (tile list rebuilt / to be rebuilt)
     float list_Rt[9], list_t[3];
-    // Asynchronous xy builds (DevParams::async_xy): two buffers; FLOW consumes
-    // `xy_active`; the k_filter launch of the coming slot builds `xy_target` (-1: none)
-    // at that slot's transform; `stall`: no buffer is valid, the coming slot only builds.
-    int32_t xy_active, xy_target, stall, xy_fail;
+    // Asynchronous xy builds (DevParams::async_xy): two buffers; FLOW consumes `xy_active`; the
+    // k_filter blocks of the launch that READS this state build `xy_target` (-1: none) at the
+    // transform recorded for it (xy_Rt / xy_t[target]); `xy_fresh`: the buffer whose build ran in
+    // the previous flow launch and is judged by the next plan (head mode only, see plan_xy_async);
+    // `stall`: no buffer is valid, the slot only builds.
+    int32_t xy_active, xy_target, stall, xy_fresh;
     int32_t xy_ok[2];
     float xy_r[2];
     float tauf_build, xy_pad_;
     float xy_Rt[2][9], xy_t[2][3];
     // the same for the two self lists of acvo (rigid: only the radius matters), [l][buffer]
-    int32_t sf_active[2], sf_target[2], sf_fail[2];
+    int32_t sf_active[2], sf_target[2], sf_fresh[2];
     int32_t sf_ok[2][2];
     float sf_r[2][2];
     float sf_tauf_build[2];
@@ -180,16 +184,25 @@ struct DevState {
     float omega[3], v[3];
     double dl;
     double red[RED_N];
-    // lists: cnt[2*l] = unused, cnt[2*l+1] = overflow flag of list l
-    uint32_t cnt[2 * LIST_N];
     int32_t k;                  // iteration about to run / running
     int32_t done;               // RUNNING, DONE_*, NEED_BIGGER_LIST
     int32_t iter;               // the reference's `iter` member
     int32_t n_exec;             // loop bodies executed
-    int32_t n_slots;            // post-step launches that did something (iterations + stall slots): the host paces its batches on it
-    // entries appended to every sub-list (kept last: the host polls only the
-    // part of the state in front of it)
+    int32_t n_slots;            // slots completed (iterations + stall slots): the host paces its batches on it
+    int32_t pending;            // head mode: a slot has been started whose post-step part has not run yet
+    int32_t head_pad_[2];
+};
+struct DevState : DevHead {
+    // ---- the TAIL: one copy per registration, at a fixed address (the head exists twice in
+    // ---- head mode, see cvo_kernels.hip "Head mode"); everything below is only ever touched with
+    // ---- atomics / plain stores of single words by the kernels
+    // entries appended to every sub-list (the host polls only the part of the state in front of it)
     uint32_t sub[LIST_N][NSUB];
+    // overflow flag of list l, raised by the launch that appended past the end (the host grows the
+    // list and resumes): ovf[launch parity][l].  Classic launches use parity 0 throughout; in head
+    // mode the flow launch of slot h raises ovf[h & 1], which the step launch of the slot and the
+    // head of slot h + 1 read while the blocks of THAT launch already raise ovf[(h + 1) & 1].
+    uint32_t ovf[2][8];
     // bit k of built[l]: iteration k (mod 2048) rebuilt list l (profiling: which
     // k_filter launches did the work)
     uint32_t built[3][64];
@@ -198,8 +211,10 @@ struct DevState {
     // slot generations) -- kept last, align() re-initialises everything in front of it
     unsigned long long mail_seq;
 };
+static_assert(LIST_N <= 8, "DevState::ovf holds 8 lists");
 constexpr size_t DEVSTATE_INIT_BYTES = offsetof(DevState, mail_seq);
-constexpr size_t DEVSTATE_HEAD_BYTES = offsetof(DevState, sub);
+constexpr size_t DEVSTATE_HEAD_BYTES = sizeof(DevHead);
+static_assert(offsetof(DevState, sub) == sizeof(DevHead) && sizeof(DevHead) % 16 == 0, "the tail follows the head");
 
 // Fused launches: one launch can serve up to MAXG independent registrations
 // (blockIdx.z selects the argument block).  Every hot kernel here is latency-
@@ -215,6 +230,7 @@ struct FilterArgs {
     const float4 *seg_a;   // bounding spheres (centre, radius) of every SEG device points
     const float4 *seg_b;   // ... of the ORIGINAL positions; centres are moved with [Rt|t]
     DevState *st;          // Rt, t, center, tauf, done; sub[list][] is appended to
+    DevState *st2;         // head mode: the second copy of the state's head (else null)
     TileEntry *tiles;      // the tile list
     TileEntry *tiles_b;    // async: the second buffer (same capacity); st->xy_target / sf_target picks
     int async_xy;          // 1: the asynchronous xy build; 2, 3: the asynchronous xx / yy build
@@ -246,6 +262,7 @@ struct ProcessArgs {
     uint32_t *kept_cnt;    // [PROC_WAVES] members recorded by each PROC_FLOW wave
     double *partials;      // [nacc][nblk] (k_step_twist: [nacc][nblk / 4])
     DevState *st;
+    DevState *st2;         // head mode: the second copy of the state's head (else null)
     uint32_t subcap;       // of the tile list
     uint32_t kept_wcap;    // kept-list slice of one wave (entries)
     int nblk;              // blocks of this launch for this registration (NSUB .. PROC_BLOCKS)
@@ -294,6 +311,7 @@ struct PostFlowArgs {
 
 struct PostStepArgs {
     DevState *st;
+    DevState *st2;         // head mode: the second copy of the state's head (else null)
     const double *part_step;
     cvo_hip_trace *trace; int trace_cap;
     int flags;
@@ -373,7 +391,7 @@ CVO_HD KernConsts make_kconsts(const DevParams &p, float ell)
 // 8 u S (u = 2^-24, S = (max|x'| + max|y'|)^2); tauf = tau + 16 u S
 // keeps a factor two in hand, so every pair with d2 < tau has q < 0.
 // `identity` = the moving cloud is used untransformed (function_inner_product).
-CVO_HD void compute_filter_bounds(DevState *s, bool identity)
+CVO_HD void compute_filter_bounds(DevHead *s, bool identity)
 {
     float ymax = s->y0max;
     if (!identity) {
@@ -410,7 +428,11 @@ CVO_HD void compute_filter_bounds(DevState *s, bool identity)
 // above the float32 rounding of the coordinates and of d2 (<= ~1e-5 m here) and
 // far below the margin (>= 1 mm at ell_min): decisions change performance only.
 constexpr double LIST_LOOSE = 1.3;
-CVO_HD void plan_lists(DevState *s, const DevParams &p, const double r_now)
+// (`bulk`: where the transform records and the kernel constants are stored -- the state itself; the post
+// kernels run the plan on a private copy in registers, every lane of a wave the same, and send these few
+// large, rarely written fields straight to the shared copy instead of carrying them along: `store` =
+// this lane does)
+CVO_HD void plan_lists(DevHead *s, DevHead *bulk, const bool store, const DevParams &p, const double r_now)
 {
     const double ymax = (double)s->y0max;
     const double slack = 1.0e-4 * (1.0 + (double)s->xmax + ymax);
@@ -429,11 +451,12 @@ CVO_HD void plan_lists(DevState *s, const DevParams &p, const double r_now)
         }
         travel = sqrt(0.5 * f2) * 1.001 * ymax + sqrt(c2);
     }
+#pragma unroll
     for (int l = 0; l < 3; ++l) {
-        if (l == LIST_XY && p.async_xy) continue;   // planned by plan_xy_async
-        if (l != LIST_XY && p.async_self) continue; // planned by plan_self_async
         if (l == LIST_XY && p.async_xy) continue;   // planned by plan_xy_async (and tauf[XY] must stay
                                                     // tau + rounding slack: tauf_build is made from it)
+        if (l != LIST_XY && p.async_self) continue; // planned by plan_self_async
+        if (l != LIST_XY && p.mode != CVO_HIP_MODE_ACVO) { s->reuse[l] = 1; continue; }   // cvo has no self lists
         const double need = (r_now + (l == LIST_XY ? travel : 0.0)) * 1.0001 + slack;
         const double lr = (double)s->list_r[l];
         const bool keep = margin > 0.0 && s->list_ok[l] && need <= lr &&
@@ -447,29 +470,37 @@ CVO_HD void plan_lists(DevState *s, const DevParams &p, const double r_now)
         if (margin > 0.0)   // tauf of compute_filter_bounds is tau + rounding slack: widen tau
             s->tauf[l] = (float)(((double)s->list_r[l] * (double)s->list_r[l] +
                                   ((double)s->tauf[l] - (double)s->kc.tau)) * 1.000001 + 1e-12);
-        if (l == LIST_XY) {
-            for (int q = 0; q < 9; ++q) s->list_Rt[q] = s->Rt[q];
-            for (int q = 0; q < 3; ++q) s->list_t[q] = s->t[q];
+        if (l == LIST_XY && store) {
+            for (int q = 0; q < 9; ++q) bulk->list_Rt[q] = s->Rt[q];
+            for (int q = 0; q < 3; ++q) bulk->list_t[q] = s->t[q];
         }
     }
 }
 
 // Asynchronous xy builds.  A build needs A transform near the current one, not
-// the next one: the k_filter launch of slot s runs beside k_process<FLOW> of slot
-// s (other stream), builds the idle buffer at slot s's transform, and the plan
-// step at the end of the slot switches to it if it holds every pair for the NEW
-// transform.  The filter is then off the launch chain (3 dependent launches per
-// iteration instead of 4) and never waited for.  A build is scheduled when half
-// the margin of the list in use is gone (the new one is usable one slot later) or
-// the list is too wide; if no buffer is valid (first slot, a jump) the coming slot
-// is a STALL: nothing but the build runs, the iteration is executed one slot later.
-CVO_HD double xy_travel(const DevState *s, int b)
+// the next one.  The plan step (end of slot s in the classic launches, head of the flow
+// launch of slot s + 1 in head mode) names a buffer to build; the k_filter blocks riding in
+// a flow launch build the target named by the state that launch STARTS from, at the
+// transform the plan recorded for it (xy_Rt / xy_t[target]); a later plan step judges the
+// finished build and switches to it if it holds every pair for the transform of that moment.
+// The filter is off the launch chain and never waited for.  A build is scheduled when most
+// of the margin of the list in use is gone or the list is too wide; if no buffer is valid
+// (first slot, a jump) the coming slot is a STALL: nothing but the build runs.
+//   classic launches: the target named at the end of slot s is built by the flow launch of
+//     slot s + 1 and judged at the end of slot s + 1   (fresh = the state's xy_target, inflight = -1)
+//   head mode: the plan runs redundantly in the head of every block of the flow launch of slot
+//     s + 1 while the launch's filter blocks are already at work on the target named one slot
+//     earlier (inflight = the state's xy_target, not to be judged yet: it becomes xy_fresh);
+//     the target named now is built by the flow launch of slot s + 2 and judged at the head of
+//     slot s + 3.  One build at a time: the buffers are two.
+// No dynamic indexing below: in the post kernels the state lives in registers.
+template <int B> CVO_HD double xy_travel(const DevHead *s)
 {
     double f2 = 0.0, c2 = 0.0;
     for (int r = 0; r < 3; ++r) {
-        double dc = (double)s->t[r] - (double)s->xy_t[b][r];
+        double dc = (double)s->t[r] - (double)s->xy_t[B][r];
         for (int q = 0; q < 3; ++q) {
-            const double d = (double)s->Rt[3 * r + q] - (double)s->xy_Rt[b][3 * r + q];
+            const double d = (double)s->Rt[3 * r + q] - (double)s->xy_Rt[B][3 * r + q];
             f2 += d * d;
             dc += d * (double)s->center[q];
         }
@@ -478,103 +509,155 @@ CVO_HD double xy_travel(const DevState *s, int b)
     return sqrt(0.5 * f2) * 1.001 * (double)s->y0max + sqrt(c2);
 }
 
-CVO_HD void plan_xy_async(DevState *s, const DevParams &p, const double r_now)
+CVO_HD void plan_xy_async(DevHead *s, DevHead *bulk, const bool store, const DevParams &p, const double r_now, const int fresh,
+                          const bool fresh_failed, const int inflight)
 {
     const double slack = 1.0e-4 * (1.0 + (double)s->xmax + (double)s->y0max);
     const double margin = (double)p.list_margin;
     const double r0 = r_now * 1.0001 + slack;   // radius needed with no travel
-    const int fresh = s->xy_target;
-    if (fresh >= 0) s->xy_ok[fresh] = s->xy_fail ? 0 : 1;   // the build of the slot that just ended
-    double need[2];
-    bool valid[2];
-    for (int b = 0; b < 2; ++b) {
-        need[b] = s->xy_ok[b] ? (r_now + xy_travel(s, b)) * 1.0001 + slack : 0.0;
-        valid[b] = s->xy_ok[b] && need[b] <= (double)s->xy_r[b];
-    }
+    if (fresh == 0) s->xy_ok[0] = fresh_failed ? 0 : 1;   // the build that has just ended
+    if (fresh == 1) s->xy_ok[1] = fresh_failed ? 0 : 1;
+    // (how far the cloud has travelled since a buffer was built: two float64 square roots each, on the
+    // one chain of the post kernels -- worked out for the buffer that is looked at first, the other
+    // one only if that fails)
+    const int act = s->xy_active ? 1 : 0;
+    const int first = fresh >= 0 ? (fresh ? 1 : 0) : act;
+    double need0 = 0.0, need1 = 0.0;
+    bool valid0 = false, valid1 = false;
+    if (first == 0) { need0 = s->xy_ok[0] ? (r_now + xy_travel<0>(s)) * 1.0001 + slack : 0.0; valid0 = s->xy_ok[0] && need0 <= (double)s->xy_r[0]; }
+    else { need1 = s->xy_ok[1] ? (r_now + xy_travel<1>(s)) * 1.0001 + slack : 0.0; valid1 = s->xy_ok[1] && need1 <= (double)s->xy_r[1]; }
     int use = -1;
-    if (fresh >= 0 && valid[fresh]) use = fresh;
-    else if (valid[s->xy_active]) use = s->xy_active;
-    else if (valid[1 - s->xy_active]) use = 1 - s->xy_active;
+    if (first ? valid1 : valid0) use = first;
+    else {
+        if (first == 0) { need1 = s->xy_ok[1] ? (r_now + xy_travel<1>(s)) * 1.0001 + slack : 0.0; valid1 = s->xy_ok[1] && need1 <= (double)s->xy_r[1]; }
+        else { need0 = s->xy_ok[0] ? (r_now + xy_travel<0>(s)) * 1.0001 + slack : 0.0; valid0 = s->xy_ok[0] && need0 <= (double)s->xy_r[0]; }
+        if (first ? valid0 : valid1) use = 1 - first;
+    }
     s->stall = use < 0 ? 1 : 0;
     if (use >= 0) s->xy_active = use;
     bool build = use < 0 || !(margin > 0.0);
     if (!build) {
-        const double lr = (double)s->xy_r[use];
-        if (need[use] - r0 > (double)p.build_at * (lr - r0)) build = true;   // most of the margin is gone
-        if (lr > LIST_LOOSE * (1.0 + margin) * r0) build = true;             // far wider than needed
+        const double lr = (double)(use ? s->xy_r[1] : s->xy_r[0]);
+        const double nd = use ? need1 : need0;
+        if (nd - r0 > (double)p.build_at * (lr - r0)) build = true;   // most of the margin is gone
+        if (lr > LIST_LOOSE * (1.0 + margin) * r0) build = true;     // far wider than needed
     }
+    if (inflight >= 0) build = false;   // (its buffer is the only one that is free)
+    s->xy_fresh = inflight;
     s->xy_target = -1;
     if (build) {
         const int tgt = use < 0 ? 0 : 1 - use;
         s->xy_target = tgt;
-        s->xy_ok[tgt] = 0;
-        s->xy_r[tgt] = (float)(r0 * (1.0 + margin) * 1.000001);   // rounded up
+        const float r = (float)(r0 * (1.0 + margin) * 1.000001);   // rounded up
         // tauf[LIST_XY] of compute_filter_bounds is tau + rounding slack: widen tau
-        s->tauf_build = (float)(((double)s->xy_r[tgt] * (double)s->xy_r[tgt] +
-                                 ((double)s->tauf[LIST_XY] - (double)s->kc.tau)) * 1.000001 + 1e-12);
-        for (int q = 0; q < 9; ++q) s->xy_Rt[tgt][q] = s->Rt[q];
-        for (int q = 0; q < 3; ++q) s->xy_t[tgt][q] = s->t[q];
+        s->tauf_build = (float)(((double)r * (double)r + ((double)s->tauf[LIST_XY] - (double)s->kc.tau)) * 1.000001 + 1e-12);
+        if (tgt == 0) { s->xy_ok[0] = 0; s->xy_r[0] = r; }
+        else { s->xy_ok[1] = 0; s->xy_r[1] = r; }
+        if (store) {
+            float *dR = tgt == 0 ? bulk->xy_Rt[0] : bulk->xy_Rt[1], *dt = tgt == 0 ? bulk->xy_t[0] : bulk->xy_t[1];
+            for (int q = 0; q < 9; ++q) dR[q] = s->Rt[q];
+            for (int q = 0; q < 3; ++q) dt[q] = s->t[q];
+        }
     }
-    s->xy_fail = 0;
 }
 
 // The acvo self lists the same way (PROC_SELF then rides in the flow launch and needs
 // its lists built BEFORE that launch).  They are rigid -- the pair distances do not
 // depend on the transform -- so only ell ages them: a list built for radius
 // (1 + margin) r serves until r_now outgrows it; the next one is built ahead when
-// half of that room is gone or ell has dropped far below.
-CVO_HD void plan_self_async(DevState *s, const DevParams &p, const double r_now)
+// most of that room is gone or ell has dropped far below.
+template <int L> CVO_HD void plan_self_async_one(DevHead *s, const DevParams &p, const double r0, const double margin,
+                                                 const int fresh, const bool fresh_failed, const int inflight)
 {
-    const double slack = 1.0e-4 * (1.0 + (double)s->xmax + (double)s->y0max);
-    const double margin = (double)p.list_margin;
-    const double r0 = r_now * 1.0001 + slack;
-    for (int l = 0; l < 2; ++l) {
-        const int fresh = s->sf_target[l];
-        if (fresh >= 0) s->sf_ok[l][fresh] = s->sf_fail[l] ? 0 : 1;
-        bool valid[2];
-        for (int b = 0; b < 2; ++b) valid[b] = s->sf_ok[l][b] && r0 <= (double)s->sf_r[l][b];
-        int use = -1;
-        if (fresh >= 0 && valid[fresh]) use = fresh;
-        else if (valid[s->sf_active[l]]) use = s->sf_active[l];
-        else if (valid[1 - s->sf_active[l]]) use = 1 - s->sf_active[l];
-        if (use < 0) s->stall = 1;
-        else s->sf_active[l] = use;
-        bool build = use < 0 || !(margin > 0.0);
-        if (!build) {
-            const double lr = (double)s->sf_r[l][use];
-            const double built_for = lr / (1.0 + margin);              // the radius it was built around
-            if (r0 > built_for + (double)p.build_at * (lr - built_for)) build = true;
-            if (lr > LIST_LOOSE * (1.0 + margin) * r0) build = true;
-        }
-        s->sf_target[l] = -1;
-        if (build) {
-            const int tgt = use < 0 ? 0 : 1 - use;
-            s->sf_target[l] = tgt;
-            s->sf_ok[l][tgt] = 0;
-            s->sf_r[l][tgt] = (float)(r0 * (1.0 + margin) * 1.000001);
-            s->sf_tauf_build[l] = (float)(((double)s->sf_r[l][tgt] * (double)s->sf_r[l][tgt] +
-                                           ((double)s->tauf[LIST_XX + l] - (double)s->kc.tau)) * 1.000001 + 1e-12);
-        }
-        s->sf_fail[l] = 0;
+    if (fresh == 0) s->sf_ok[L][0] = fresh_failed ? 0 : 1;
+    if (fresh == 1) s->sf_ok[L][1] = fresh_failed ? 0 : 1;
+    const bool valid0 = s->sf_ok[L][0] && r0 <= (double)s->sf_r[L][0];
+    const bool valid1 = s->sf_ok[L][1] && r0 <= (double)s->sf_r[L][1];
+    const int act = s->sf_active[L] ? 1 : 0;
+    int use = -1;
+    if (fresh >= 0 && (fresh ? valid1 : valid0)) use = fresh ? 1 : 0;
+    else if (act ? valid1 : valid0) use = act;
+    else if (act ? valid0 : valid1) use = 1 - act;
+    if (use < 0) s->stall = 1;
+    else s->sf_active[L] = use;
+    bool build = use < 0 || !(margin > 0.0);
+    if (!build) {
+        const double lr = (double)(use ? s->sf_r[L][1] : s->sf_r[L][0]);
+        const double built_for = lr / (1.0 + margin);              // the radius it was built around
+        if (r0 > built_for + (double)p.build_at * (lr - built_for)) build = true;
+        if (lr > LIST_LOOSE * (1.0 + margin) * r0) build = true;
+    }
+    if (inflight >= 0) build = false;
+    s->sf_fresh[L] = inflight;
+    s->sf_target[L] = -1;
+    if (build) {
+        const int tgt = use < 0 ? 0 : 1 - use;
+        s->sf_target[L] = tgt;
+        const float r = (float)(r0 * (1.0 + margin) * 1.000001);
+        s->sf_tauf_build[L] = (float)(((double)r * (double)r + ((double)s->tauf[LIST_XX + L] - (double)s->kc.tau)) * 1.000001 + 1e-12);
+        if (tgt == 0) { s->sf_ok[L][0] = 0; s->sf_r[L][0] = r; }
+        else { s->sf_ok[L][1] = 0; s->sf_r[L][1] = r; }
     }
 }
 
+// What a plan step knows about the asynchronous builds besides the state (see plan_xy_async)
+struct PlanBuilds {
+    int xy_fresh, xy_inflight;
+    int sf_fresh[2], sf_inflight[2];
+    bool xy_failed, sf_failed[2];
+};
+// the classic launches: the target the state names has been built by the launches of the slot that ends
+CVO_HD PlanBuilds plan_builds_classic(const DevHead *s, bool xy_failed, bool xx_failed, bool yy_failed)
+{
+    PlanBuilds b;
+    b.xy_fresh = s->xy_target; b.xy_inflight = -1; b.xy_failed = xy_failed;
+    b.sf_fresh[0] = s->sf_target[0]; b.sf_fresh[1] = s->sf_target[1];
+    b.sf_inflight[0] = b.sf_inflight[1] = -1;
+    b.sf_failed[0] = xx_failed; b.sf_failed[1] = yy_failed;
+    return b;
+}
+// head mode: the target the state names is being built by this very launch
+CVO_HD PlanBuilds plan_builds_head(const DevHead *s, bool xy_failed, bool xx_failed, bool yy_failed)
+{
+    PlanBuilds b;
+    b.xy_fresh = s->xy_fresh; b.xy_inflight = s->xy_target; b.xy_failed = xy_failed;
+    b.sf_fresh[0] = s->sf_fresh[0]; b.sf_fresh[1] = s->sf_fresh[1];
+    b.sf_inflight[0] = s->sf_target[0]; b.sf_inflight[1] = s->sf_target[1];
+    b.sf_failed[0] = xx_failed; b.sf_failed[1] = yy_failed;
+    return b;
+}
+// first plan of an align() (k_prepare): nothing built, nothing in flight
+CVO_HD PlanBuilds plan_builds_none()
+{
+    PlanBuilds b;
+    b.xy_fresh = b.xy_inflight = -1; b.xy_failed = false;
+    b.sf_fresh[0] = b.sf_fresh[1] = b.sf_inflight[0] = b.sf_inflight[1] = -1;
+    b.sf_failed[0] = b.sf_failed[1] = false;
+    return b;
+}
+
 // Everything an iteration needs that derives from (R, T, ell).  The caller logs
-// the lists that are rebuilt (reuse[l] == 0) in DevState::built.
-CVO_HD void prepare_iteration(DevState *s, const DevParams &p)
+// the lists that are rebuilt (reuse[l] == 0) in DevState::built and zeroes the sub-list
+// counters (and, classic launches, the overflow flags) of what will be built.
+CVO_HD void prepare_iteration(DevHead *s, DevHead *bulk, const bool store, const DevParams &p, const PlanBuilds &b)
 {
     cvo_math::inverse_tf(s->R, s->T, s->Rt, s->t);
     if (!(s->kc_ell == s->ell)) {   // three float64 divisions and a log-scaled threshold: only when ell moved
-        s->kc = make_kconsts(p, s->ell);
+        const KernConsts k = make_kconsts(p, s->ell);
+        if (store) bulk->kc = k;
+        s->kc.tau = k.tau;   // (all the plan reads of it)
         s->kc_ell = s->ell;
     }
     compute_filter_bounds(s, false);
     const double r_now = sqrt((double)s->kc.tau);
-    plan_lists(s, p, r_now);
-    if (p.async_xy) plan_xy_async(s, p, r_now);
-    if (p.async_self) plan_self_async(s, p, r_now);   // (after the xy plan: it may add a stall)
-    for (int q = 0; q < 2 * LIST_N; ++q) s->cnt[q] = 0u;
-    // (the per-sub-list counters are zeroed by all threads of the calling kernel)
+    plan_lists(s, bulk, store, p, r_now);
+    if (p.async_xy) plan_xy_async(s, bulk, store, p, r_now, b.xy_fresh, b.xy_failed, b.xy_inflight);
+    if (p.async_self) {   // (after the xy plan: it may add a stall)
+        const double slack = 1.0e-4 * (1.0 + (double)s->xmax + (double)s->y0max);
+        const double r0 = r_now * 1.0001 + slack;
+        plan_self_async_one<0>(s, p, r0, (double)p.list_margin, b.sf_fresh[0], b.sf_failed[0], b.sf_inflight[0]);
+        plan_self_async_one<1>(s, p, r0, (double)p.list_margin, b.sf_fresh[1], b.sf_failed[1], b.sf_inflight[1]);
+    }
 }
 
 size_t filter_smem_bytes(int jt);
@@ -596,16 +679,21 @@ void launch_step_twist_group(const ProcessArgs *a, int n, hipStream_t s, hipEven
 constexpr int STEP_TWIST_ROWS_DIV = 4;   // k_step_twist writes nblk / 4 partial rows
 
 // One launch of an iteration through a table: which kernel, its geometry, which op[] it reads.
-enum TKernel { TK_FILTER = 0, TK_FILTER_GROUP, TK_FLOW, TK_FLOW_MATLAB, TK_STEP, TK_SELF, TK_SELF2, TK_STEP_TWIST, TK_STEP_TWIST_POST,
-               TK_FLOW_BUILD, TK_FLOW_BUILD3, TK_FLOW_BUILD6, TK_POST_FLOW, TK_POST_STEP };
+enum TKernel { TK_FILTER = 0, TK_FILTER_GROUP, TK_FLOW, TK_FLOW_MATLAB, TK_STEP, TK_SELF, TK_SELF2, TK_STEP_TWIST,
+               TK_FLOW_BUILD, TK_FLOW_BUILD3, TK_FLOW_BUILD6, TK_POST_FLOW, TK_POST_STEP,
+               TK_HFLOW_BUILD, TK_HFLOW_BUILD6, TK_HSTEP_TWIST, TK_HFLUSH };   // head mode (cvo_kernels.hip "Head mode")
+// Head-mode launches carry the slot's parity and the mode in the bits above the op index of their
+// second kernel argument: qp = q | parity << 8 | QP_HEAD.
+constexpr int QP_PARITY = 1 << 8, QP_HEAD = 1 << 9, QP_MASK = 0xff;
 struct TLaunch {
     int kernel;          // TKernel
     int q;               // op index in the slots
     unsigned gx, gz;     // grid.x, grid.z (= slots served)
     unsigned smem;       // dynamic LDS bytes
 };
+// (parity: of the slot within its batch, head-mode kernels only)
 void launch_table(const Slot *tab, const TLaunch &l, hipStream_t s, hipEvent_t ev_start = nullptr,
-                  hipEvent_t ev_stop = nullptr);
+                  hipEvent_t ev_stop = nullptr, int parity = 0);
 // geometry helpers shared with the host (what the by-value launchers compute from their arguments)
 unsigned filter_grid_cap(long long nitems, long long cap);
 long long filter_blocks_cap();

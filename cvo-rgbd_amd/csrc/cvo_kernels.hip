@@ -93,7 +93,7 @@ __device__ __forceinline__ bool spheres_near(const float4 sa, const float4 sb, f
 // the room of sub-list j with one returning atomic (32 distinct addresses: one wave
 // instruction, as before).
 __device__ __forceinline__ void flush_tiles(const TileEntry *stage, int n, int lane, unsigned rot, unsigned region,
-                                            const FilterArgs &a, int list, TileEntry *tiles)
+                                            const FilterArgs &a, int list, TileEntry *tiles, const int par)
 {
     static_assert(TILE_STAGE <= 128, "two entries per lane");
     constexpr int sh = DEAL_SHIFT, L = 1 << sh;
@@ -117,7 +117,7 @@ __device__ __forceinline__ void flush_tiles(const TileEntry *stage, int n, int l
         }
     }
     if (__ballot(over) != 0ull && lane == 0)
-        atomicOr(&a.st->cnt[2 * list + 1], 1u);   // overflow: the host grows the list and resumes
+        atomicOr(&a.st->ovf[par][list], 1u);   // overflow: the host grows the list and resumes
 }
 
 // transform_pcd as a pass of its own (ref cvo.cpp:310-315), for the launches that many registrations
@@ -137,7 +137,10 @@ __device__ __forceinline__ void pretransform_body(const FilterArgs &a, const uns
     }
 }
 
-__device__ __forceinline__ void filter_body(const FilterArgs &a, const unsigned bid, const unsigned nblocks)
+// hd: the copy of the state's head this launch starts from (a.st unless head mode); par: the launch's parity
+// (which row of DevState::ovf an overflow is flagged in; 0 unless head mode)
+__device__ __forceinline__ void filter_body(const FilterArgs &a, const unsigned bid, const unsigned nblocks,
+                                            const DevState *__restrict__ hd, const int par)
 {
     // Persistent blocks: the (column chunk, row tile) items of this registration's
     // a.gx x a.gy work grid are dealt round-robin to the gridDim.x blocks of the
@@ -161,8 +164,8 @@ __device__ __forceinline__ void filter_body(const FilterArgs &a, const unsigned 
     // (inside align() a list that is still valid is consumed again: nothing to do)
     // (async xy: this launch builds the buffer the plan step scheduled, if any)
     const int kind = a.async_xy;   // 0: synchronous list; 1: xy, 2: xx, 3: yy built ahead into the idle buffer
-    const int target = kind == 1 ? a.st->xy_target : (kind >= 2 ? a.st->sf_target[kind - 2] : 0);
-    const int done_word = a.check_done ? (a.st->done | (kind ? (target < 0) : a.st->reuse[a.list])) : 0;
+    const int target = kind == 1 ? hd->xy_target : (kind >= 2 ? hd->sf_target[kind - 2] : 0);
+    const int done_word = a.check_done ? (hd->done | (kind ? (target < 0) : hd->reuse[a.list])) : 0;
     const int out_list = kind == 1 ? (target == 1 ? (int)LIST_XYB : (int)LIST_XY)
                                    : (kind >= 2 ? self_list_id(kind - 2, target == 1 ? 1 : 0) : a.list);
     TileEntry *out_tiles = (kind && target == 1) ? a.tiles_b : a.tiles;
@@ -177,11 +180,13 @@ __device__ __forceinline__ void filter_body(const FilterArgs &a, const unsigned 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wid = tid >> 6;
-    const float *Rt = a.st->Rt;
-    const float *tt = a.st->t;
-    const float cx = a.st->center[0], cy = a.st->center[1], cz = a.st->center[2];
-    const float tauf = kind == 1 ? a.st->tauf_build
-                                 : (kind >= 2 ? a.st->sf_tauf_build[kind - 2] : a.st->tauf[a.list]);
+    // (an asynchronous xy build runs at the transform its plan step recorded for it: the state's own in
+    // the classic launches -- nothing moved since the plan --, one slot older in head mode)
+    const float *Rt = kind == 1 ? hd->xy_Rt[target == 1 ? 1 : 0] : hd->Rt;
+    const float *tt = kind == 1 ? hd->xy_t[target == 1 ? 1 : 0] : hd->t;
+    const float cx = hd->center[0], cy = hd->center[1], cz = hd->center[2];
+    const float tauf = kind == 1 ? hd->tauf_build
+                                 : (kind >= 2 ? hd->sf_tauf_build[kind - 2] : hd->tauf[a.list]);
     // ---- culling, for all the items of this block at once.  The clouds are in
     // Morton order, so the 64 rows of a wave and every run of 64 columns are
     // compact patches with precomputed bounding spheres (rigid motion moves a
@@ -341,7 +346,7 @@ __device__ __forceinline__ void filter_body(const FilterArgs &a, const unsigned 
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            flush_tiles(stage, ne, lane, sub, region, a, out_list, out_tiles);
+            flush_tiles(stage, ne, lane, sub, region, a, out_list, out_tiles, par);
             sub += (unsigned)((ne + (1 << DEAL_SHIFT) - 1) >> DEAL_SHIFT);
             __builtin_amdgcn_wave_barrier();
             ne = 0;
@@ -354,7 +359,7 @@ __device__ __forceinline__ void filter_body(const FilterArgs &a, const unsigned 
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        flush_tiles(stage, ne, lane, sub, region, a, out_list, out_tiles);
+        flush_tiles(stage, ne, lane, sub, region, a, out_list, out_tiles, par);
     }
 #ifdef CVO_FILTER_PROBE
     if (a.dbg && lane == 0) {   // probe: start, prologue end, loop end, exit clocks of every wave
@@ -374,7 +379,7 @@ __device__ __forceinline__ void filter_body(const FilterArgs &a, const unsigned 
 __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(6, 8)))
 k_filter(const Grp<FilterArgs> grp)
 {
-    filter_body(grp.a[blockIdx.z], blockIdx.x, gridDim.x);
+    filter_body(grp.a[blockIdx.z], blockIdx.x, gridDim.x, grp.a[blockIdx.z].st, 0);
 }
 
 // blocks of one registration's filter launch (persistent, see k_filter)
@@ -643,19 +648,59 @@ __device__ __forceinline__ const float4 *gather16(const void *base, unsigned byt
     return reinterpret_cast<const float4 *>(static_cast<const char *>(base) + byte_off);
 }
 
+// What a list pass takes from the state's head.  The classic launches point it at the state in global
+// memory (scalar loads where a value is needed); in head mode the block has just computed the head
+// itself (LDS) and keeps the hot part in scalar registers (proc_head_lds).
+struct ProcHead {
+    const float *Rt, *tt;          // inverse transform of the slot
+    const cvo_math::XiConsts *xi;  // PROC_STEP
+    KernConsts kc;
+    int done_word;                 // done | stall
+    int n_fixed;
+    int second;                    // the pass reads the second buffer of its (asynchronous) tile list
+    unsigned list_bad;             // the list the pass consumes overflowed while it was written
+    int ck_nblk;                   // DevState::ck_nblk of the pass's tile list
+    int par;                       // row of DevState::ovf this launch flags overflows in
+};
+
+template <int MODE>
+__device__ __forceinline__ ProcHead proc_head_global(const ProcessArgs &a, const DevState *st, const int par)
+{
+    ProcHead h;
+    h.Rt = st->Rt; h.tt = st->t; h.xi = &st->xi;
+    h.kc = st->kc;
+    // (async xy: a stall slot only builds; PROC_FLOW reads the buffer in use)
+    h.done_word = a.check_done ? (st->done | (a.async_xy ? st->stall : 0)) : 0;
+    // (acvo Ayy rule, SURVEY 8a quirk 5: the caller's count of fixed points lives in the state, so
+    // that the kernel arguments -- and with them a captured graph -- do not depend on it)
+    h.n_fixed = (MODE == PROC_SELF && a.first_counted) ? st->n_fixed : 0;
+    h.second = ((MODE == PROC_FLOW && a.async_xy && st->xy_active == 1) ||
+                (MODE == PROC_SELF && a.async_self && st->sf_active[a.async_self - 1] == 1)) ? 1 : 0;
+    // A list that overflowed while it was built holds counters past what was written (an
+    // append that does not fit is dropped, its count stays): entries from memory nobody
+    // initialised would be taken for row / column numbers.  The iteration is redone with a
+    // larger list anyway: consume nothing of it.  (Same for the kept list of PROC_STEP.  A list that
+    // was built ahead is only ever switched to after its flag was seen clear: plan_xy_async.)
+    const bool ahead = (MODE == PROC_FLOW && a.async_xy) || (MODE == PROC_SELF && a.async_self);
+    h.list_bad = ahead ? 0u : a.st->ovf[par][MODE == PROC_STEP ? (int)LIST_KEPT : a.list];
+    h.ck_nblk = st->ck_nblk[a.list];
+    h.par = par;
+    return h;
+}
+
 // One pair of the exact pass.  PROC_FLOW / PROC_SELF: membership test of
 // se_kernel (ref cvo.cpp:125-152) and the flow / self sums; returns the weight
 // (0 = not in A).  PROC_STEP: `w` is the recorded weight of a member of A.
 // CK (PROC_FLOW, WEIGHT 0): 0 as the reference writes it; 1 also hands the pair's colour weight out
 // through *ck_io (computed for every pair, inside tau or not); 2 takes it from *ck_io, no features read.
 template <int MODE, int WEIGHT = 0, int CK = 0>
-__device__ __forceinline__ float eval_pair(const ProcessArgs &a, const KernConsts &kc, unsigned i,
+__device__ __forceinline__ float eval_pair(const ProcessArgs &a, const ProcHead &hd, const KernConsts &kc, unsigned i,
                                            unsigned j, float w, double *acc,
                                            const cvo_math::XiConsts &xc, const double *etab = nullptr,
                                            const int first_counted = 0, float *ck_io = nullptr)
 {
-    const float *Rt = a.st->Rt;
-    const float *tt = a.st->t;
+    const float *Rt = hd.Rt;
+    const float *tt = hd.tt;
     float4 xi = *gather16(a.pos_a, i * 16u);
     if (a.tf_a) xi = apply_tf(Rt, tt, xi);
     float4 yj = *gather16(a.pos_b, j * 16u);
@@ -751,7 +796,7 @@ constexpr int PROC_SMEM = 4 * NACC_MAX * 8 + 4 * PAIR_QUEUE * 8 + 4 * 64 * 8;
 // PROC_SELF).  REC (PROC_FLOW): every candidate is recorded for the passes that follow (ProcessArgs::cand).
 // Returns false when the loop has stopped (nothing to reduce).
 template <int MODE, int WEIGHT, int REC>
-__device__ __forceinline__ bool expand_lists(const ProcessArgs &a, const KernConsts &kc, const unsigned bid, const int wid,
+__device__ __forceinline__ bool expand_lists(const ProcessArgs &a, const ProcHead &hd, const KernConsts &kc, const unsigned bid, const int wid,
                                              const int lane, const unsigned wave, const int done_word,
                                              const unsigned list_bad, const int in_list, const TileEntry *in_tiles,
                                              const int first_counted, const double *s_etab, uint2 *pairq_all,
@@ -788,13 +833,13 @@ __device__ __forceinline__ bool expand_lists(const ProcessArgs &a, const KernCon
             float ck = 0.0f;
             if (lane < cnt) {
                 pr = pairq[base + lane];
-                w = eval_pair<MODE, WEIGHT, REC>(a, kc, pr.x, pr.y, 0.0f, acc, a.st->xi, s_etab, first_counted, &ck);   // (xi: PROC_STEP only)
+                w = eval_pair<MODE, WEIGHT, REC>(a, hd, kc, pr.x, pr.y, 0.0f, acc, *hd.xi, s_etab, first_counted, &ck);   // (xi: PROC_STEP only)
             }
             if (REC) {   // every candidate goes on record, at the place the wave met it (its colour weight with it)
                 if (co + (unsigned)cnt <= a.kept_wcap) {
                     if (lane < cnt) a.cand[kbase + co + lane] = make_uint2(pr.x | (pr.y << 16), __float_as_uint(ck));
                 } else if (lane == 0) {
-                    atomicOr(&a.st->cnt[2 * LIST_KEPT + 1], 1u);   // slice full: grow and redo
+                    atomicOr(&a.st->ovf[hd.par][LIST_KEPT], 1u);   // slice full: grow and redo
                 }
                 co += (unsigned)cnt;
             }
@@ -814,7 +859,7 @@ __device__ __forceinline__ bool expand_lists(const ProcessArgs &a, const KernCon
                         }
                     }
                 } else if (lane == 0) {
-                    atomicOr(&a.st->cnt[2 * LIST_KEPT + 1], 1u);   // slice full: grow and redo
+                    atomicOr(&a.st->ovf[hd.par][LIST_KEPT], 1u);   // slice full: grow and redo
                 }
                 nk += add;
             }
@@ -872,7 +917,7 @@ __device__ __forceinline__ bool expand_lists(const ProcessArgs &a, const KernCon
 // wave's l-th candidate of the round -- nothing to expand, full rounds but the last, the colour weight
 // read back with the pair.  PROC_FLOW: the members of A of THIS iteration go to the kept list as always.
 template <int MODE>
-__device__ __forceinline__ bool stream_candidates(const ProcessArgs &a, const KernConsts &kc, const int lane,
+__device__ __forceinline__ bool stream_candidates(const ProcessArgs &a, const ProcHead &hd, const KernConsts &kc, const int lane,
                                                   const unsigned wave, const int done_word, const double *s_etab,
                                                   double (&acc)[NAcc<MODE>::n])
 {
@@ -887,7 +932,7 @@ __device__ __forceinline__ bool stream_candidates(const ProcessArgs &a, const Ke
         float w = 0.0f;
         if (b0 + (unsigned)lane < n) {
             float ck = __uint_as_float(e.y);
-            w = eval_pair<MODE, 0, 2>(a, kc, e.x & 0xffffu, e.x >> 16, 0.0f, acc, a.st->xi, s_etab, 0, &ck);
+            w = eval_pair<MODE, 0, 2>(a, hd, kc, e.x & 0xffffu, e.x >> 16, 0.0f, acc, *hd.xi, s_etab, 0, &ck);
         }
         const unsigned long long km = __ballot(w > 0.0f);
         if (MODE == PROC_FLOW && w > 0.0f) {   // (members <= candidates <= the slice: it cannot overflow here)
@@ -906,7 +951,7 @@ __device__ __forceinline__ bool stream_candidates(const ProcessArgs &a, const Ke
 // CAND false: the launch never keeps a candidate list (the merged launches of one registration on its
 // own, whose xy list is built beside the pass): that code is left out of the kernel
 template <int MODE, int WEIGHT = 0, bool CAND = true>
-__device__ __forceinline__ void process_body(const ProcessArgs &a, const unsigned bid, char *scratch)
+__device__ __forceinline__ void process_body(const ProcessArgs &a, const unsigned bid, char *scratch, const ProcHead &hd)
 {
     if ((int)bid >= a.nblk) return;
     constexpr int NACC = NAcc<MODE>::n;
@@ -920,21 +965,13 @@ __device__ __forceinline__ void process_body(const ProcessArgs &a, const unsigne
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const unsigned wave = bid * 4u + (unsigned)wid;   // 0 .. PROC_WAVES-1
     // first round trip: loop-control word, kernel constants, list sizes
-    // (async xy: a stall slot only builds; PROC_FLOW reads the buffer in use)
-    const int done_word = a.check_done ? (a.st->done | (a.async_xy ? a.st->stall : 0)) : 0;
-    const KernConsts kc = a.st->kc;
-    // (acvo Ayy rule, SURVEY 8a quirk 5: the caller's count of fixed points lives in the state, so
-    // that the kernel arguments -- and with them a captured graph -- do not depend on it)
-    const int first_counted = (MODE == PROC_SELF && a.first_counted) ? a.st->n_fixed : 0;
-    const bool second = (MODE == PROC_FLOW && a.async_xy && a.st->xy_active == 1) ||
-                        (MODE == PROC_SELF && a.async_self && a.st->sf_active[a.async_self - 1] == 1);
+    const int done_word = hd.done_word;
+    const KernConsts kc = hd.kc;
+    const int first_counted = hd.n_fixed;
+    const bool second = hd.second != 0;
     const int in_list = !second ? a.list : (MODE == PROC_FLOW ? (int)LIST_XYB : self_list_id(a.async_self - 1, 1));
     const TileEntry *in_tiles = second ? a.tiles_b : a.tiles;
-    // A list that overflowed while it was built holds counters past what was written (an
-    // append that does not fit is dropped, its count stays): entries from memory nobody
-    // initialised would be taken for row / column numbers.  The iteration is redone with a
-    // larger list anyway: consume nothing of it.  (Same for the kept list of PROC_STEP.)
-    const unsigned list_bad = a.st->cnt[2 * (MODE == PROC_STEP ? (int)LIST_KEPT : in_list) + 1];
+    const unsigned list_bad = hd.list_bad;
 
     double acc[NACC];
 #pragma unroll
@@ -953,16 +990,16 @@ __device__ __forceinline__ void process_body(const ProcessArgs &a, const unsigne
         if (list_bad) n = 0;
         for (unsigned off = lane; off < n; off += 64) {
             if (off >= 64) { e = a.kept_ij[base + off]; if (!packed) w = a.kept_a[base + off]; }
-            eval_pair<MODE>(a, kc, packed ? (e.x & 0xffffu) : e.x, packed ? (e.x >> 16) : e.y,
-                            packed ? __uint_as_float(e.y) : w, acc, a.st->xi);
+            eval_pair<MODE>(a, hd, kc, packed ? (e.x & 0xffffu) : e.x, packed ? (e.x >> 16) : e.y,
+                            packed ? __uint_as_float(e.y) : w, acc, *hd.xi);
         }
     } else {
         bool alive;
         if (CAND && WEIGHT == 0 && a.cand && a.kept_packed && !a.async_xy && !a.async_self) {
-            if (a.st->ck_nblk[a.list] == a.nblk) alive = stream_candidates<MODE>(a, kc, lane, wave, done_word, s_etab, acc);
-            else alive = expand_lists<MODE, WEIGHT, WEIGHT == 0 ? 1 : 0>(a, kc, bid, wid, lane, wave, done_word, list_bad, in_list, in_tiles, first_counted, s_etab, pairq_all, acc);
+            if (hd.ck_nblk == a.nblk) alive = stream_candidates<MODE>(a, hd, kc, lane, wave, done_word, s_etab, acc);
+            else alive = expand_lists<MODE, WEIGHT, WEIGHT == 0 ? 1 : 0>(a, hd, kc, bid, wid, lane, wave, done_word, list_bad, in_list, in_tiles, first_counted, s_etab, pairq_all, acc);
         } else {
-            alive = expand_lists<MODE, WEIGHT, 0>(a, kc, bid, wid, lane, wave, done_word, list_bad, in_list, in_tiles, first_counted, s_etab, pairq_all, acc);
+            alive = expand_lists<MODE, WEIGHT, 0>(a, hd, kc, bid, wid, lane, wave, done_word, list_bad, in_list, in_tiles, first_counted, s_etab, pairq_all, acc);
         }
         if (!alive) return;
     }
@@ -980,7 +1017,8 @@ template <int MODE, int WEIGHT = 0>
 __global__ void __launch_bounds__(BLOCK) k_process(const Grp<ProcessArgs> grp)
 {
     __shared__ __attribute__((aligned(16))) char scratch[PROC_SMEM];
-    process_body<MODE, WEIGHT>(grp.a[blockIdx.z], blockIdx.x, scratch);
+    const ProcessArgs &a = grp.a[blockIdx.z];
+    process_body<MODE, WEIGHT>(a, blockIdx.x, scratch, proc_head_global<MODE>(a, a.st, 0));
 }
 
 // ---------------------------------------------------------------------------
@@ -996,7 +1034,8 @@ constexpr int STEP_WAVES = STEP_BLOCK / 64;
 
 // returns true if this block delivered a row of step partial sums (false: the registration has
 // stopped, the slot is a stall, a list overflowed, or the block is surplus)
-__device__ __forceinline__ bool step_twist_body(const ProcessArgs &a)
+// hd: the copy of the state's head the slot runs on (a.st unless head mode); par: the slot's parity
+__device__ __forceinline__ bool step_twist_body(const ProcessArgs &a, DevState *hd, const int par, const bool head_mode)
 {
     const int nfat = a.nblk / (STEP_BLOCK / BLOCK);   // blocks of this registration
     if ((int)blockIdx.x >= nfat) return false;
@@ -1014,11 +1053,15 @@ __device__ __forceinline__ bool step_twist_body(const ProcessArgs &a)
     const unsigned wave = fb * 4u + ((unsigned)wid & 3u);
     // first round trip: loop control, constants, this thread's PROC_FLOW partial row,
     // the wave's first kept entries
-    const int done_word = a.check_done ? (a.st->done | (a.async_xy ? a.st->stall : 0)) : 0;
-    const KernConsts kc = a.st->kc;
-    // (async xy: the buffer being built beside this launch is k_post_step's business)
-    const unsigned ovf = (a.async_xy ? 0u : a.st->cnt[2 * LIST_XY + 1]) | a.st->cnt[2 * LIST_XX + 1] |
-                         a.st->cnt[2 * LIST_YY + 1] | a.st->cnt[2 * LIST_KEPT + 1];
+    const int done_word = a.check_done ? (hd->done | (a.async_xy ? hd->stall : 0)) : 0;
+    const KernConsts kc = hd->kc;
+    // (async xy: the buffer being built beside this launch is the next plan step's business)
+    const unsigned ovf = (a.async_xy ? 0u : a.st->ovf[par][LIST_XY]) | a.st->ovf[par][LIST_XX] |
+                         a.st->ovf[par][LIST_YY] | a.st->ovf[par][LIST_KEPT];
+    // head mode: the flags of the other parity -- raised by the flow launch of the previous slot, read
+    // by that slot's step launch and by the head of this slot's flow launch -- are cleared here, before
+    // the next flow launch raises them again (not once the loop has stopped: the host wants to see them)
+    if (head_mode && blockIdx.x == 0 && tid < 8 && hd->done == 0) a.st->ovf[par ^ 1][tid] = 0u;
     double pf[NACC_FLOW];
 #pragma unroll
     for (int k = 0; k < NACC_FLOW; ++k)
@@ -1059,7 +1102,7 @@ __device__ __forceinline__ bool step_twist_body(const ProcessArgs &a)
     __syncthreads();
     const bool overflow = s_overflow != 0;
     if (blockIdx.x == 0 && tid == 0) {
-        DevState *st = a.st;
+        DevState *st = hd;
         // nothing of an overflowed iteration is usable; the host enlarges the list
         // and resumes from the same (untouched) state
         if (overflow) {
@@ -1112,13 +1155,15 @@ __device__ __forceinline__ bool step_twist_body(const ProcessArgs &a)
     }
 
     // ---- compute_step_size sums over this wave's slice of the kept list
+    ProcHead phd;
+    phd.Rt = hd->Rt; phd.tt = hd->t;   // (eval_pair<PROC_STEP> reads nothing else of it)
     double acc[NACC];
 #pragma unroll
     for (int k = 0; k < NACC; ++k) acc[k] = 0.0;
     if (n > a.kept_wcap) n = a.kept_wcap;
     for (unsigned off = lane; off < n; off += 64) {
         if (off >= 64) { e = a.kept_ij[base + off]; if (!packed) w = a.kept_a[base + off]; }
-        eval_pair<PROC_STEP>(a, kc, packed ? (e.x & 0xffffu) : e.x, packed ? (e.x >> 16) : e.y,
+        eval_pair<PROC_STEP>(a, phd, kc, packed ? (e.x & 0xffffu) : e.x, packed ? (e.x >> 16) : e.y,
                              packed ? __uint_as_float(e.y) : w, acc, xc);
     }
     __syncthreads();   // sh is re-used
@@ -1135,7 +1180,7 @@ __device__ __forceinline__ bool step_twist_body(const ProcessArgs &a)
 
 __global__ void __launch_bounds__(STEP_BLOCK) k_step_twist(const Grp<ProcessArgs> grp)
 {
-    step_twist_body(grp.a[blockIdx.z]);
+    step_twist_body(grp.a[blockIdx.z], grp.a[blockIdx.z].st, 0, false);
 }
 
 void launch_step_twist_group(const ProcessArgs *a, int n, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop)
@@ -1232,25 +1277,49 @@ __device__ void block_reduce_partials(const double *part, int nblocks, double *s
     block_finish_partials<NACC>(s, sh, out);
 }
 
-// The head of DevState (everything in front of the sub-list counters) moves
-// between HBM and LDS cooperatively: the O(1) maths then pays LDS latency per
-// field instead of one memory round trip per dependent access.
-__device__ __forceinline__ void state_head_to_lds(const DevState *g, DevState *l)
+// ---------------------------------------------------------------------------
+// The post-step part of an iteration and the plan of the next one (ref src/cvo.cpp:291-307,380-410,
+// src/adaptive_cvo.cpp:509-545, src/LieGroup.cpp:159-186) -- "the head".
+//
+// One block: the state's head moves HBM -> LDS cooperatively (one round trip, together with the step
+// partials and the overflow flags), wave 0 takes a PRIVATE copy of it -- registers: the whole O(1)
+// chain then runs without a memory access; with the state in LDS every field of it was a dependent
+// ds_read / ds_write round trip on one lane -- runs the maths with all 64 lanes (the cubic uses them;
+// the rest is the same value in every lane), lane 0 puts the head back into LDS, and the block writes it
+// out.  Three forms:
+//   HM_CLASSIC  k_post_step / kt_post_step, a launch of its own, in place (fused groups, sharded and
+//               large registrations, the low-level entry points);
+//   HM_HEAD     "head mode" (one registration with its launches to itself): there is no post-step
+//               launch.  EVERY flow / self block of the flow launch of slot s + 1 starts with this body:
+//               it reduces the step partials of slot s in the same fixed order, runs the same maths on the
+//               same inputs -- all blocks hold the same new head, bit for bit -- and goes on with the
+//               flow pass from its own LDS copy; block 0 alone publishes the head, the trace and the
+//               host's mirrors.  Nothing is fenced and nobody waits for anybody (the ticket tail of round 2
+//               paid an L2 write-back per block): two dependent launches per iteration instead of three.
+//               The launch reads one copy of the head and block 0 writes the OTHER one (a block that
+//               starts late must still find the old head): FB_s reads copy s & 1, writes copy ~s & 1;
+//               the step launch of slot s works on the copy FB_s wrote.  Batches have an even number of
+//               slots, so the head is back in copy 0 (DevState itself) when a batch ends.
+//   HM_FLUSH    the last launch of a head-mode batch: the post-step part alone, in place, one block --
+//               the host sees `done` and the slot count without enqueueing another flow launch.
+// The filter blocks that ride in a head-mode flow launch do not run the head: they build what the
+// PREVIOUS plan named, at the transform it recorded (cvo_device.h plan_xy_async).
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void state_head_to_lds(const DevHead *g, DevHead *l)
 {
-    const uint32_t *src = reinterpret_cast<const uint32_t *>(g);
-    uint32_t *dst = reinterpret_cast<uint32_t *>(l);
-    for (int q = threadIdx.x; q < (int)(DEVSTATE_HEAD_BYTES / 4); q += BLOCK) dst[q] = src[q];
+    const uint4 *src = reinterpret_cast<const uint4 *>(g);
+    uint4 *dst = reinterpret_cast<uint4 *>(l);
+    static_assert(DEVSTATE_HEAD_BYTES / 16 <= BLOCK, "one 16-byte piece per thread");
+    if (threadIdx.x < (int)(DEVSTATE_HEAD_BYTES / 16)) dst[threadIdx.x] = src[threadIdx.x];
     __syncthreads();
 }
 
-__device__ __forceinline__ void state_head_from_lds(const DevState *l, DevState *g)
+__device__ __forceinline__ void state_head_from_lds(const DevHead *l, DevHead *g)
 {
-    const uint32_t *src = reinterpret_cast<const uint32_t *>(l);
-    uint32_t *dst = reinterpret_cast<uint32_t *>(g);
-    for (int q = threadIdx.x; q < (int)(DEVSTATE_HEAD_BYTES / 4); q += BLOCK) dst[q] = src[q];
+    const uint4 *src = reinterpret_cast<const uint4 *>(l);
+    uint4 *dst = reinterpret_cast<uint4 *>(g);
+    if (threadIdx.x < (int)(DEVSTATE_HEAD_BYTES / 16)) dst[threadIdx.x] = src[threadIdx.x];
 }
-
-__device__ void post_step_math(DevState *st, const PostStepArgs &a);
 
 // cvo_math::section_root with one lane per interior point (all 64 lanes of a
 // wave must call it with the same bracket): same arithmetic per point, same
@@ -1340,11 +1409,11 @@ __device__ bool mailbox_allreduce(const CommTable &ct, DevState *gst, double *va
 __device__ __forceinline__ void post_flow_body(const PostFlowArgs &a)
 {
     __shared__ double sh[4 * NACC_MAX];
-    __shared__ __attribute__((aligned(16))) DevState s_st;
-    // One round trip: every thread fetches a word of the state's head into LDS;
+    __shared__ __attribute__((aligned(16))) DevHead s_st;
+    // One round trip: every thread fetches a piece of the state's head into LDS;
     // the maths below runs on that copy and the head is written back at the end.
     state_head_to_lds(a.st, &s_st);
-    DevState *st = &s_st;
+    DevHead *st = &s_st;
     if (a.check_done && (st->done != 0 || (a.prm.async_xy && st->stall))) return;
     const bool acvo = a.prm.mode == CVO_HIP_MODE_ACVO;
     if (a.flags & POST_REDUCE) {
@@ -1358,8 +1427,8 @@ __device__ __forceinline__ void post_flow_body(const PostFlowArgs &a)
         // a candidate list overflowed on this rank: poison nnz so that, after the
         // all-reduce, EVERY rank takes the same "grow the list and redo" exit
         if (threadIdx.x == 0 &&
-            ((a.prm.async_xy ? 0u : st->cnt[2 * LIST_XY + 1]) | st->cnt[2 * LIST_XX + 1] |
-             st->cnt[2 * LIST_YY + 1] | st->cnt[2 * LIST_KEPT + 1]))
+            ((a.prm.async_xy ? 0u : a.st->ovf[0][LIST_XY]) | a.st->ovf[0][LIST_XX] |
+             a.st->ovf[0][LIST_YY] | a.st->ovf[0][LIST_KEPT]))
             st->red[8] = __builtin_nan("");
     }
     bool comm_ok = true;
@@ -1417,100 +1486,275 @@ __global__ void __launch_bounds__(BLOCK) k_post_flow(const Grp<PostFlowArgs> grp
     post_flow_body(grp.a[blockIdx.z]);
 }
 
+enum HeadMode { HM_CLASSIC = 0, HM_HEAD = 1, HM_FLUSH = 2 };
+
+// The maths of the head on wave 0 (all 64 lanes, every value wave-uniform).  Two stages, so that the
+// registers hold what the chain needs when it needs it: the post-step part runs on the few fields it
+// touches (read from the LDS copy in one go); the plan then takes a private copy of the head's plan
+// fields (a second batch of LDS reads, none of them on the chain before), runs in registers, and lane 0
+// puts back what changed.  The large, rarely written fields (transform records, kernel constants) go
+// straight to the LDS copy when they change (cvo_device.h `bulk`).
+// `flag[l]`: overflow flag of list l in the row the finished builds were flagged in.
+// `publisher`: this block writes the trace.
+template <int HM>
+__device__ __forceinline__ void head_math(DevHead *lds, const PostStepArgs &a, const bool run_post, const bool stalled,
+                                          const unsigned (&flag)[LIST_N], const bool publisher, const bool timed,
+                                          long long (&clk)[4])
+{
+    const DevParams &p = a.prm;
+    const bool acvo = p.mode == CVO_HIP_MODE_ACVO;
+    const bool async = p.async_xy != 0, aself = p.async_self != 0;
+    const bool lane0 = threadIdx.x == 0;
+    const bool was_pending = HM == HM_CLASSIC ? true : (lds->pending != 0);
+    // ---- stage 1: the fields of the post-step part
+    float R[9], T[3], Rt[9], t[3], omega[3], v[3];
+#pragma unroll
+    for (int q = 0; q < 9; ++q) { R[q] = lds->R[q]; Rt[q] = lds->Rt[q]; }
+#pragma unroll
+    for (int q = 0; q < 3; ++q) { T[q] = lds->T[q]; t[q] = lds->t[q]; omega[q] = lds->omega[q]; v[q] = lds->v[q]; }
+    float ell = lds->ell, ell_max = lds->ell_max;
+    const double dl = lds->dl;
+    double bcde[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) bcde[q] = lds->red[RED_STEP + q];
+    int k = lds->k, done = lds->done, iter = lds->iter, n_exec = lds->n_exec;
+    const int n_slots = lds->n_slots + (was_pending ? 1 : 0);   // head mode: a slot is complete when the head that follows it has run
+
+    bool plan = HM != HM_FLUSH;
+    if (run_post) {
+        if (timed) clk[0] = (long long)__builtin_readcyclecounter();
+        const cvo_math::CubicBracket cb = cvo_math::cubic_bracket(bcde);
+        const float step = cvo_math::finish_step(
+            cb.found, cb.found ? section_root_wave(cb, (int)threadIdx.x) : 0.0, p.min_step);
+        if (timed) clk[1] = (long long)__builtin_readcyclecounter();
+        cvo_hip_trace *tr = (publisher && lane0 && a.trace && k < a.trace_cap) ? &a.trace[k] : nullptr;
+        if (tr) {
+            for (int q = 0; q < 4; ++q) tr->bcde[q] = bcde[q];
+            tr->step = step;
+            tr->dist = __builtin_nanf("");
+        }
+        n_exec = k + 1;
+        if (lane0) {   // the transform this iteration used (what align() accumulates, ref cvo.cpp:413-415)
+#pragma unroll
+            for (int q = 0; q < 9; ++q) lds->used_Rt[q] = Rt[q];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) lds->used_t[q] = t[q];
+        }
+        // break A: both twist norms below eps (ref cvo.cpp:380 float norms,
+        // adaptive_cvo.cpp:509 double norms of the float vectors)
+        bool brk;
+        if (acvo) {
+            const double nw = sqrt((double)omega[0] * omega[0] +
+                                   ((double)omega[1] * omega[1] + (double)omega[2] * omega[2]));
+            const double nv = sqrt((double)v[0] * v[0] + ((double)v[1] * v[1] + (double)v[2] * v[2]));
+            brk = nw < (double)p.eps && nv < (double)p.eps;
+        } else {
+            brk = cvo_math::norm_fixed3(omega) < p.eps && cvo_math::norm_fixed3(v) < p.eps;
+        }
+        if (brk) {
+            iter = k;
+            done = DONE_BREAK_A;
+            if (tr) tr->exit_code = 1;
+            plan = false;
+        } else {
+            // integrate: T = R*dT + T ; R = R*dR  (ref cvo.cpp:391-399)
+            float dR[9], dT[3], RdT[3];
+            cvo_math::exp_se3(omega, v, step, dR, dT);
+            cvo_math::Mat3 Rm, dRm;
+#pragma unroll
+            for (int q = 0; q < 9; ++q) { Rm.m[q] = R[q]; dRm.m[q] = dR[q]; }
+            cvo_math::mulv(Rm, dT, RdT);
+#pragma unroll
+            for (int q = 0; q < 3; ++q) T[q] = RdT[q] + T[q];
+            const cvo_math::Mat3 Rn = cvo_math::mul(Rm, dRm);
+#pragma unroll
+            for (int q = 0; q < 9; ++q) R[q] = Rn.m[q];
+
+            const float dist = cvo_math::dist_se3(omega, v, step);
+            if (tr) tr->dist = dist;
+            if (dist < p.eps_2) {   // break B
+                iter = k;
+                done = DONE_BREAK_B;
+                if (tr) tr->exit_code = 2;
+                plan = false;
+            } else {
+                // length-scale update
+                if (acvo) {   // ref src/adaptive_cvo.cpp:538-545
+                    ell = (float)((double)ell + p.dl_step * dl);
+                    if (ell >= ell_max) {
+                        ell = (float)(ell_max * 0.7);
+                        ell_max = (float)(ell_max * 0.7);
+                    }
+                    ell = (ell < p.ell_min) ? p.ell_min : ell;
+                } else {      // ref src/cvo.cpp:408-410
+                    ell = (k > 2) ? (float)0.10 : ell;
+                    ell = (k > 9) ? (float)0.06 : ell;
+                    ell = (k > 19) ? (float)0.03 : ell;
+                }
+                if (k + 1 >= p.max_iter) {
+                    done = DONE_MAX_ITER;   // `iter` keeps its stale value
+                    plan = false;
+                }
+                k = k + 1;
+            }
+        }
+        if (timed) clk[2] = (long long)__builtin_readcyclecounter();
+    }
+    if (lane0) {   // (before the plan: its registers are free for it)
+#pragma unroll
+        for (int q = 0; q < 9; ++q) lds->R[q] = R[q];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) lds->T[q] = T[q];
+        lds->ell = ell; lds->ell_max = ell_max;
+        lds->k = k; lds->iter = iter; lds->n_exec = n_exec; lds->n_slots = n_slots;
+    }
+    int pending = 0;
+    if (plan) {
+        // ---- stage 2: the plan of the slot that begins (a stall slot: the state did not move, plan only)
+        DevHead L;
+        __builtin_memcpy(&L, lds, sizeof(DevHead));
+#pragma unroll
+        for (int q = 0; q < 9; ++q) L.R[q] = R[q];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) L.T[q] = T[q];
+        L.ell = ell;
+        // what the builds that have ended made of their lists
+        PlanBuilds pb = HM == HM_CLASSIC ? plan_builds_classic(&L, false, false, false) : plan_builds_head(&L, false, false, false);
+        pb.xy_failed = async && pb.xy_fresh >= 0 && (pb.xy_fresh ? flag[LIST_XYB] : flag[LIST_XY]) != 0u;
+        // (classic, synchronous self lists: a stall slot runs no k_step_twist / k_post_flow, which is where
+        // an overflow of the xx / yy lists is normally caught: lists built in a stall slot are checked here)
+        pb.sf_failed[0] = aself ? (pb.sf_fresh[0] >= 0 && (pb.sf_fresh[0] ? flag[LIST_XXB] : flag[LIST_XX]) != 0u)
+                                : (HM == HM_CLASSIC && stalled && flag[LIST_XX] != 0u);
+        pb.sf_failed[1] = aself ? (pb.sf_fresh[1] >= 0 && (pb.sf_fresh[1] ? flag[LIST_YYB] : flag[LIST_YY]) != 0u)
+                                : (HM == HM_CLASSIC && stalled && flag[LIST_YY] != 0u);
+        // (this iteration's flow pass has recorded or streamed the candidate list: it matches the tile list --
+        // until plan_lists schedules a rebuild)
+        if (HM == HM_CLASSIC && run_post && flag[LIST_KEPT] == 0u) {
+#pragma unroll
+            for (int l = 0; l < 3; ++l)
+                if (a.ck_nblk[l] != 0 && flag[l] == 0u) L.ck_nblk[l] = a.ck_nblk[l];
+        }
+        // (lane 0 alone stores through `bulk`; the other lanes compute the same values and drop them)
+        prepare_iteration(&L, lds, lane0, p, pb);
+        // the list built beside the slot that ended overflowed: the iteration itself was fine and is
+        // kept; park so that the host enlarges the buffers (the flags stay up for it)
+        if (pb.xy_failed || pb.sf_failed[0] || pb.sf_failed[1]) done = NEED_BIGGER_LIST;
+        if (HM == HM_HEAD) pending = (done == RUNNING) ? 1 : 0;   // (this launch starts the next slot)
+        if (lane0) {
+#pragma unroll
+            for (int q = 0; q < 9; ++q) lds->Rt[q] = L.Rt[q];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) { lds->t[q] = L.t[q]; lds->tauf[q] = L.tauf[q]; lds->list_r[q] = L.list_r[q];
+                                          lds->list_ok[q] = L.list_ok[q]; lds->reuse[q] = L.reuse[q]; lds->ck_nblk[q] = L.ck_nblk[q]; }
+            lds->kc_ell = L.kc_ell;
+            lds->xy_active = L.xy_active; lds->xy_target = L.xy_target; lds->stall = L.stall; lds->xy_fresh = L.xy_fresh;
+            lds->tauf_build = L.tauf_build;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                lds->xy_ok[q] = L.xy_ok[q]; lds->xy_r[q] = L.xy_r[q];
+                lds->sf_active[q] = L.sf_active[q]; lds->sf_target[q] = L.sf_target[q]; lds->sf_fresh[q] = L.sf_fresh[q];
+                lds->sf_ok[q][0] = L.sf_ok[q][0]; lds->sf_ok[q][1] = L.sf_ok[q][1];
+                lds->sf_r[q][0] = L.sf_r[q][0]; lds->sf_r[q][1] = L.sf_r[q][1];
+                lds->sf_tauf_build[q] = L.sf_tauf_build[q];
+            }
+        }
+    }
+    if (timed) clk[3] = (long long)__builtin_readcyclecounter();
+    if (lane0) {
+        lds->done = done;
+        if (HM != HM_CLASSIC) lds->pending = pending;
+    }
+}
+
+// The whole head of one block.  in / out: the copies of the state's head the launch reads / writes (the
+// same in the classic and flush forms); st: the state itself (the tail: sub-list counters, overflow
+// flags).  Returns true if the slot that begins may run (head mode: the loop is running, no stall).
+template <int HM>
+__device__ __forceinline__ bool head_body(const PostStepArgs &a, const DevHead *in, DevHead *out, DevHead *s_st,
+                                          double *sh /*[4 * NACC_MAX]*/, const int par, const bool publisher)
+{
+    const int tid = threadIdx.x;
+    const bool reduce = HM != HM_CLASSIC || (a.flags & POST_REDUCE) != 0;
+    const bool math = HM != HM_CLASSIC || (a.flags & POST_MATH) != 0;
+    const long long c0 = (HM == HM_CLASSIC && a.dbg) ? (long long)__builtin_readcyclecounter() : 0;
+    // one round trip: the step partials, the overflow flags of the builds that have ended (classic: row
+    // 0, where everything is flagged; head mode: the row of the previous flow launch), the state's head
+    double sp[NACC_STEP];
+    if (reduce) thread_load_partials<NACC_STEP>(a.part_step, a.nblk, sp);
+    const unsigned my_flag = a.st->ovf[HM == HM_CLASSIC ? 0 : (par ^ 1)][tid & 7];
+    state_head_to_lds(in, s_st);
+    if (a.check_done && s_st->done != 0) {
+        // the loop has stopped: head mode hands the head on, so that every later launch finds the verdict
+        // whichever copy it reads
+        if (HM == HM_HEAD && publisher) state_head_from_lds(s_st, out);
+        return false;
+    }
+    const bool async = a.prm.async_xy != 0, aself = a.prm.async_self != 0;
+    // a stall slot executed no iteration (asynchronous builds: only the plan runs)
+    const bool stalled = async && s_st->stall != 0;
+    const bool pending = HM == HM_CLASSIC ? true : (s_st->pending != 0);
+    const bool run_post = pending && !stalled;
+    const long long c1 = (HM == HM_CLASSIC && a.dbg) ? (long long)__builtin_readcyclecounter() : 0;
+    if (reduce && run_post) block_finish_partials<NACC_STEP>(sp, sh, s_st->red + RED_STEP);
+    const long long c2 = (HM == HM_CLASSIC && a.dbg) ? (long long)__builtin_readcyclecounter() : 0;
+    bool comm_ok = true;
+    if (HM == HM_CLASSIC && a.comm && !stalled) {
+        __shared__ double sh_mail[MAX_WORLD * MAIL_VALS];
+        __shared__ int sh_fail;
+        comm_ok = mailbox_allreduce(*a.comm, a.st, s_st->red + RED_STEP, RED_N - RED_STEP, sh_mail, &sh_fail);
+        if (!comm_ok && tid == 0) s_st->done = DONE_COMM_ERROR;
+    }
+    if (math && comm_ok) {
+        if (tid < 64) {   // wave 0
+            unsigned flag[LIST_N];
+#pragma unroll
+            for (int l = 0; l < LIST_N; ++l) flag[l] = (unsigned)__builtin_amdgcn_readlane((int)my_flag, l);
+            long long clk[4] = {0, 0, 0, 0};
+            head_math<HM>(s_st, a, run_post, stalled, flag, publisher, HM == HM_CLASSIC && a.dbg != nullptr, clk);
+            if (HM == HM_CLASSIC && a.dbg && tid == 0) {
+                a.dbg[0] += 1; a.dbg[1] += c1 - c0; a.dbg[2] += c2 - c1;
+                if (run_post) { a.dbg[3] += clk[1] - clk[0]; a.dbg[4] += clk[2] - clk[1]; a.dbg[5] += clk[3] - clk[2]; }
+            }
+        }
+        __syncthreads();
+        // the tile lists the coming launches rebuild are emptied; the others are kept
+        if (publisher && (s_st->done == RUNNING || s_st->done == NEED_BIGGER_LIST)) {
+            if (HM != HM_FLUSH) {
+#pragma unroll
+                for (int l = 0; l < 3; ++l) {   // synchronous lists (classic plans)
+                    if (s_st->reuse[l] || (async && l == LIST_XY) || (aself && l != LIST_XY)) continue;
+                    for (int q = tid; q < NSUB; q += BLOCK) a.st->sub[l][q] = 0u;
+                    if (tid == 0) atomicOr(&a.st->built[l][(s_st->k >> 5) & 63], 1u << (s_st->k & 31));
+                }
+                if (async && s_st->xy_target >= 0) {   // the build the plan has just named
+                    const int l = s_st->xy_target ? (int)LIST_XYB : (int)LIST_XY;
+                    for (int q = tid; q < NSUB; q += BLOCK) a.st->sub[l][q] = 0u;
+                }
+                if (aself)
+                    for (int l = 0; l < 2; ++l)
+                        if (s_st->sf_target[l] >= 0) {
+                            const int id = self_list_id(l, s_st->sf_target[l]);
+                            for (int q = tid; q < NSUB; q += BLOCK) a.st->sub[id][q] = 0u;
+                        }
+            }
+            // classic: every launch of the coming slot flags its overflows in row 0 again (a parked
+            // loop keeps the flags: the host needs them to know what to grow)
+            if (HM == HM_CLASSIC && tid < 8 && s_st->done == RUNNING) a.st->ovf[0][tid] = 0u;
+        }
+    }
+    if (publisher && tid == 0) {
+        if (math && a.progress_mirror) *a.progress_mirror = s_st->n_slots;
+        if (a.done_mirror && s_st->done != RUNNING) *a.done_mirror = s_st->done;
+    }
+    if (publisher) state_head_from_lds(s_st, out);
+    return s_st->done == RUNNING && !(async && s_st->stall != 0);
+}
+
 __device__ __forceinline__ void post_step_body(const PostStepArgs &a)
 {
     __shared__ double sh[4 * NACC_MAX];
-    __shared__ __attribute__((aligned(16))) DevState s_st;
-    const long long c0 = a.dbg ? (long long)__builtin_readcyclecounter() : 0;
-    // the step partials are requested together with the state's head: one round trip for both
-    double sp[NACC_STEP];
-    if (a.flags & POST_REDUCE) thread_load_partials<NACC_STEP>(a.part_step, a.nblk, sp);
-    state_head_to_lds(a.st, &s_st);   // (see k_post_flow)
-    DevState *st = &s_st;
-    if (a.check_done && st->done != 0) return;
-    // async xy: a stall slot executed no iteration (only the plan below runs); the
-    // list that was built beside this slot may have overflowed
-    const bool async = a.prm.async_xy != 0;
-    const bool stalled = async && st->stall != 0;
-    const int built_list = (async && st->xy_target >= 0) ? (st->xy_target ? (int)LIST_XYB : (int)LIST_XY) : -1;
-    const bool built_failed = built_list >= 0 && st->cnt[2 * built_list + 1] != 0u;
-    // (a stall slot runs no k_step_twist / k_post_flow, which is where an overflow of the
-    // xx / yy lists is normally caught: lists built in a stall slot are checked here)
-    const bool aself = a.prm.async_self != 0;
-    int sf_list[2] = {-1, -1};   // the self lists built beside this slot
-    if (aself)
-        for (int l = 0; l < 2; ++l)
-            if (st->sf_target[l] >= 0) sf_list[l] = self_list_id(l, st->sf_target[l]);
-    const bool xx_failed = aself ? (sf_list[0] >= 0 && st->cnt[2 * sf_list[0] + 1] != 0u)
-                                 : (stalled && st->cnt[2 * LIST_XX + 1] != 0u);
-    const bool yy_failed = aself ? (sf_list[1] >= 0 && st->cnt[2 * sf_list[1] + 1] != 0u)
-                                 : (stalled && st->cnt[2 * LIST_YY + 1] != 0u);
-    const int xx_flag = aself ? sf_list[0] : (int)LIST_XX, yy_flag = aself ? sf_list[1] : (int)LIST_YY;
-    __syncthreads();   // (everybody has read the flags before thread 0 changes the state)
-    if (threadIdx.x == 0) {
-        st->xy_fail = built_failed ? 1 : 0;
-        st->sf_fail[0] = (aself && xx_failed) ? 1 : 0;
-        st->sf_fail[1] = (aself && yy_failed) ? 1 : 0;
-    }
-    const long long c1 = a.dbg ? (long long)__builtin_readcyclecounter() : 0;
-    if ((a.flags & POST_REDUCE) && !stalled) block_finish_partials<NACC_STEP>(sp, sh, st->red + RED_STEP);
-    if (a.dbg && threadIdx.x == 0) {
-        a.dbg[0] += 1; a.dbg[1] += c1 - c0; a.dbg[2] += (long long)__builtin_readcyclecounter() - c1;
-    }
-    bool comm_ok = true;
-    if (a.comm && !stalled) {
-        __shared__ double sh_mail[MAX_WORLD * MAIL_VALS];
-        __shared__ int sh_fail;
-        comm_ok = mailbox_allreduce(*a.comm, a.st, st->red + RED_STEP, RED_N - RED_STEP, sh_mail, &sh_fail);
-        if (!comm_ok && threadIdx.x == 0) st->done = DONE_COMM_ERROR;
-    }
-    if ((a.flags & POST_MATH) && comm_ok) {
-        if (stalled) {
-            if (threadIdx.x == 0) prepare_iteration(st, a.prm);   // the state did not move: plan only
-        } else if (threadIdx.x < 64) {
-            post_step_math(st, a);   // wave 0: the cubic uses all its lanes
-        }
-        __syncthreads();
-        // the tile lists the next slot rebuilds are emptied; the others are kept
-        if (st->done == RUNNING) {
-            for (int l = 0; l < 3; ++l) {
-                if (st->reuse[l] || (async && l == LIST_XY) || (aself && l != LIST_XY)) continue;
-                for (int q = threadIdx.x; q < NSUB; q += BLOCK) a.st->sub[l][q] = 0u;
-                if (threadIdx.x == 0)
-                    atomicOr(&a.st->built[l][(st->k >> 5) & 63], 1u << (st->k & 31));
-            }
-            if (async && st->xy_target >= 0) {
-                const int l = st->xy_target ? (int)LIST_XYB : (int)LIST_XY;
-                for (int q = threadIdx.x; q < NSUB; q += BLOCK) a.st->sub[l][q] = 0u;
-            }
-            if (aself)   // the self builds that start with the coming slot
-                for (int l = 0; l < 2; ++l)
-                    if (st->sf_target[l] >= 0) {
-                        const int id = self_list_id(l, st->sf_target[l]);
-                        for (int q = threadIdx.x; q < NSUB; q += BLOCK) a.st->sub[id][q] = 0u;
-                    }
-            __syncthreads();
-            // the list built beside this slot overflowed: the iteration itself was fine
-            // and is kept; park so that the host enlarges the buffers
-            if (threadIdx.x == 0 && (built_failed || xx_failed || yy_failed)) {
-                st->done = NEED_BIGGER_LIST;
-                // (prepare_iteration cleared the flags: the host needs them to know what to grow)
-                if (built_failed) st->cnt[2 * built_list + 1] = 1u;
-                if (xx_failed) st->cnt[2 * xx_flag + 1] = 1u;
-                if (yy_failed) st->cnt[2 * yy_flag + 1] = 1u;
-            }
-        }
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        if (a.flags & POST_MATH) {
-            s_st.n_slots += 1;
-            if (a.progress_mirror) *a.progress_mirror = s_st.n_slots;
-        }
-        if (a.done_mirror && s_st.done != RUNNING) *a.done_mirror = s_st.done;
-    }
-    __syncthreads();
-    state_head_from_lds(&s_st, a.st);
+    __shared__ __attribute__((aligned(16))) DevHead s_st;
+    head_body<HM_CLASSIC>(a, a.st, a.st, &s_st, sh, 0, true);
 }
 
 __global__ void __launch_bounds__(BLOCK) k_post_step(const Grp<PostStepArgs> grp)
@@ -1518,103 +1762,12 @@ __global__ void __launch_bounds__(BLOCK) k_post_step(const Grp<PostStepArgs> grp
     post_step_body(grp.a[blockIdx.z]);
 }
 
-__device__ void post_step_math(DevState *st, const PostStepArgs &a)
-{
-
-    const DevParams &p = a.prm;
-    const bool acvo = p.mode == CVO_HIP_MODE_ACVO;
-    const int k = st->k;
-    // (this iteration's flow pass has recorded or streamed the candidate list: it matches the tile list --
-    // until plan_lists, below, schedules a rebuild)
-    if (threadIdx.x == 0 && st->cnt[2 * LIST_KEPT + 1] == 0u)
-        for (int l = 0; l < 3; ++l)
-            if (a.ck_nblk[l] != 0 && st->cnt[2 * l + 1] == 0u) st->ck_nblk[l] = a.ck_nblk[l];
-    double bcde[4];
-    for (int q = 0; q < 4; ++q) bcde[q] = st->red[RED_STEP + q];
-    const long long c2 = a.dbg ? (long long)__builtin_readcyclecounter() : 0;
-    const cvo_math::CubicBracket cb = cvo_math::cubic_bracket(bcde);
-    const float step = cvo_math::finish_step(
-        cb.found, cb.found ? section_root_wave(cb, (int)threadIdx.x) : 0.0, p.min_step);
-    if (threadIdx.x != 0) return;   // the rest is scalar work
-    if (a.dbg) a.dbg[3] += (long long)__builtin_readcyclecounter() - c2;
-    float omega[3], v[3];
-    for (int q = 0; q < 3; ++q) { omega[q] = st->omega[q]; v[q] = st->v[q]; }
-    cvo_hip_trace *tr = (a.trace && k < a.trace_cap) ? &a.trace[k] : nullptr;
-    if (tr) {
-        for (int q = 0; q < 4; ++q) tr->bcde[q] = bcde[q];
-        tr->step = step;
-        tr->dist = __builtin_nanf("");
-    }
-    st->n_exec = k + 1;
-    for (int q = 0; q < 9; ++q) st->used_Rt[q] = st->Rt[q];
-    for (int q = 0; q < 3; ++q) st->used_t[q] = st->t[q];
-
-    // break A: both twist norms below eps (ref cvo.cpp:380 float norms,
-    // adaptive_cvo.cpp:509 double norms of the float vectors)
-    bool brk;
-    if (acvo) {
-        const double nw = sqrt((double)omega[0] * omega[0] +
-                               ((double)omega[1] * omega[1] + (double)omega[2] * omega[2]));
-        const double nv = sqrt((double)v[0] * v[0] + ((double)v[1] * v[1] + (double)v[2] * v[2]));
-        brk = nw < (double)p.eps && nv < (double)p.eps;
-    } else {
-        brk = cvo_math::norm_fixed3(omega) < p.eps && cvo_math::norm_fixed3(v) < p.eps;
-    }
-    if (brk) {
-        st->iter = k;
-        st->done = DONE_BREAK_A;
-        if (tr) tr->exit_code = 1;
-        return;
-    }
-    // integrate: T = R*dT + T ; R = R*dR  (ref cvo.cpp:391-399)
-    const long long c3 = a.dbg ? (long long)__builtin_readcyclecounter() : 0;
-    float dR[9], dT[3], RdT[3];
-    cvo_math::exp_se3(omega, v, step, dR, dT);
-    cvo_math::Mat3 R, dRm;
-    for (int q = 0; q < 9; ++q) { R.m[q] = st->R[q]; dRm.m[q] = dR[q]; }
-    cvo_math::mulv(R, dT, RdT);
-    for (int q = 0; q < 3; ++q) st->T[q] = RdT[q] + st->T[q];
-    const cvo_math::Mat3 Rn = cvo_math::mul(R, dRm);
-    for (int q = 0; q < 9; ++q) st->R[q] = Rn.m[q];
-
-    const float dist = cvo_math::dist_se3(omega, v, step);
-    if (tr) tr->dist = dist;
-    if (dist < p.eps_2) {   // break B
-        st->iter = k;
-        st->done = DONE_BREAK_B;
-        if (tr) tr->exit_code = 2;
-        return;
-    }
-    // length-scale update
-    float ell = st->ell;
-    if (acvo) {   // ref src/adaptive_cvo.cpp:538-545
-        ell = (float)((double)ell + p.dl_step * st->dl);
-        if (ell >= st->ell_max) {
-            ell = (float)(st->ell_max * 0.7);
-            st->ell_max = (float)(st->ell_max * 0.7);
-        }
-        ell = (ell < p.ell_min) ? p.ell_min : ell;
-    } else {      // ref src/cvo.cpp:408-410
-        ell = (k > 2) ? (float)0.10 : ell;
-        ell = (k > 9) ? (float)0.06 : ell;
-        ell = (k > 19) ? (float)0.03 : ell;
-    }
-    st->ell = ell;
-    st->k = k + 1;
-    if (k + 1 >= p.max_iter) {
-        st->done = DONE_MAX_ITER;   // `iter` keeps its stale value
-        return;
-    }
-    const long long c4 = a.dbg ? (long long)__builtin_readcyclecounter() : 0;
-    prepare_iteration(st, p);
-    if (a.dbg) { a.dbg[4] += c4 - c3; a.dbg[5] += (long long)__builtin_readcyclecounter() - c4; }
-}
-
 // First iteration of an align() (or of its resumption after a list grew): no
 // list is valid, everything is rebuilt.
 __global__ void k_prepare(DevState *st, const DevParams prm)
 {
     for (int q = threadIdx.x; q < LIST_N * NSUB; q += BLOCK) (&st->sub[0][0])[q] = 0u;
+    if (threadIdx.x < 16) (&st->ovf[0][0])[threadIdx.x] = 0u;
     if (threadIdx.x == 0) {
         for (int l = 0; l < 3; ++l) {
             st->list_ok[l] = 0;
@@ -1622,14 +1775,15 @@ __global__ void k_prepare(DevState *st, const DevParams prm)
         }
         for (int l = 0; l < 2; ++l) {      // async self lists: nothing built yet
             st->sf_ok[l][0] = st->sf_ok[l][1] = 0;
-            st->sf_active[l] = 0; st->sf_target[l] = -1; st->sf_fail[l] = 0;
+            st->sf_active[l] = 0; st->sf_target[l] = -1; st->sf_fresh[l] = -1;
         }
         st->xy_ok[0] = st->xy_ok[1] = 0;   // async xy: the first slot only builds
         st->xy_active = 0;
         st->xy_target = -1;
-        st->xy_fail = 0;
+        st->xy_fresh = -1;
         st->stall = 0;
-        prepare_iteration(st, prm);
+        st->pending = 0;
+        prepare_iteration(st, st, true, prm, plan_builds_none());
     }
 }
 
@@ -1673,7 +1827,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(6, 8
 kt_filter(const Slot *__restrict__ tab, const int q)
 {
     CVO_SLOT(tab);
-    filter_body(CVO_ARG(FilterArgs, op[q].f), blockIdx.x, gridDim.x);
+    filter_body(CVO_ARG(FilterArgs, op[q].f), blockIdx.x, gridDim.x, cs->op[q].f.st, 0);
     pretransform_body(CVO_ARG(FilterArgs, op[q].f), blockIdx.x, gridDim.x);   // (after: nothing of it is live across the build)
 }
 
@@ -1682,7 +1836,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(6, 8
 kt_filter_group(const Slot *__restrict__ tab, const int q)
 {
     CVO_SLOT(tab);
-    filter_body(CVO_FILTER_ROLE((int)blockIdx.y), blockIdx.x, gridDim.x);
+    filter_body(CVO_FILTER_ROLE((int)blockIdx.y), blockIdx.x, gridDim.x, cs->op[q + (int)blockIdx.y].f.st, 0);
     if (blockIdx.y == 0) pretransform_body(CVO_FILTER_ROLE(0), blockIdx.x, gridDim.x);
 }
 
@@ -1691,7 +1845,8 @@ __global__ void __launch_bounds__(BLOCK) kt_process(const Slot *__restrict__ tab
 {
     __shared__ __attribute__((aligned(16))) char scratch[PROC_SMEM];
     CVO_SLOT(tab);
-    process_body<MODE, WEIGHT>(CVO_ARG(ProcessArgs, op[q].p), blockIdx.x, scratch);
+    const ProcessArgs &a = CVO_ARG(ProcessArgs, op[q].p);
+    process_body<MODE, WEIGHT>(a, blockIdx.x, scratch, proc_head_global<MODE>(a, a.st, 0));
 }
 
 // acvo, one registration: both self passes in one launch (blockIdx.y = xx / yy)
@@ -1699,48 +1854,18 @@ __global__ void __launch_bounds__(BLOCK) kt_self2(const Slot *__restrict__ tab, 
 {
     __shared__ __attribute__((aligned(16))) char scratch[PROC_SMEM];
     CVO_SLOT(tab);
-    process_body<PROC_SELF>(CVO_ARG(ProcessArgs, op[q + blockIdx.y].p), blockIdx.x, scratch);
+    const ProcessArgs &a = CVO_ARG(ProcessArgs, op[q + blockIdx.y].p);
+    process_body<PROC_SELF>(a, blockIdx.x, scratch, proc_head_global<PROC_SELF>(a, a.st, 0));
 }
 
-__global__ void __launch_bounds__(STEP_BLOCK) kt_step_twist(const Slot *__restrict__ tab, const int q)
+// (head mode, qp & QP_HEAD: the slot runs on the copy of the head its flow launch wrote)
+__global__ void __launch_bounds__(STEP_BLOCK) kt_step_twist(const Slot *__restrict__ tab, const int qp)
 {
     CVO_SLOT(tab);
-    step_twist_body(CVO_ARG(ProcessArgs, op[q].p));
-}
-
-// kt_step_twist + k_post_step in one launch (ref src/cvo.cpp:291-307,380-410 follow the sums of
-// :213-289 without a kernel boundary).  Every block delivers its row of step partial sums, then
-// draws a ticket (release fence + one atomic); the block that draws the last one acquires, lets
-// go of all but its first four waves and runs the post-step maths (op[q + 1].ps) on the spot:
-// two dependent launches per iteration instead of three.  A stall slot (asynchronous builds: no
-// iteration executed, no partials) leaves the plan step to block 0.
-__global__ void __launch_bounds__(STEP_BLOCK) kt_step_twist_post(const Slot *__restrict__ tab, const int q)
-{
-    CVO_SLOT(tab);
-    __shared__ int s_last;
+    const int q = qp & QP_MASK, par = (qp & QP_PARITY) ? 1 : 0;
+    const bool head_mode = (qp & QP_HEAD) != 0;
     const ProcessArgs &a = CVO_ARG(ProcessArgs, op[q].p);
-    const bool ran = step_twist_body(a);
-    DevState *st = a.st;
-    if (!ran) {
-        // (block-uniform; `done` and `stall` were written by the previous launch)
-        if (!(blockIdx.x == 0 && a.async_xy && st->done == 0 && st->stall != 0)) return;
-    } else {
-        __syncthreads();   // (the row of partials is on its way)
-        if (threadIdx.x == 0) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            const unsigned nfat = (unsigned)(a.nblk / (STEP_BLOCK / BLOCK));
-            const unsigned t = __hip_atomic_fetch_add(&st->step_ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            s_last = t == nfat - 1u;
-            if (s_last) __hip_atomic_store(&st->step_ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        __syncthreads();
-        if (!s_last) return;
-    }
-    if (threadIdx.x >= BLOCK) return;   // (waves that have ended no longer count at the barriers below)
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    const PostStepArgs ps = CVO_ARG(PostStepArgs, op[q + 1].ps);
-    post_step_body(ps);
+    step_twist_body(a, head_mode ? (par ? a.st : a.st2) : a.st, par, head_mode);
 }
 
 __global__ void __launch_bounds__(BLOCK) kt_post_flow(const Slot *__restrict__ tab, const int q)
@@ -1781,10 +1906,12 @@ __global__ void __launch_bounds__(BLOCK) kt_post_step(const Slot *__restrict__ t
         CVO_SLOT(tab);                                                                                     \
         const int np = cs->op[q].np;                                                                       \
         if ((int)blockIdx.x < np) {                                                                        \
-            process_body<PROC_FLOW, 0, false>(CVO_ARG(ProcessArgs, op[q].p), blockIdx.x, smem);                      \
+            const ProcessArgs &pa = CVO_ARG(ProcessArgs, op[q].p);                                         \
+            process_body<PROC_FLOW, 0, false>(pa, blockIdx.x, smem, proc_head_global<PROC_FLOW>(pa, pa.st, 0)); \
             return;                                                                                        \
         }                                                                                                  \
-        filter_body(CVO_ARG(FilterArgs, op[q].f), blockIdx.x - (unsigned)np, (unsigned)cs->op[q].n0);      \
+        filter_body(CVO_ARG(FilterArgs, op[q].f), blockIdx.x - (unsigned)np, (unsigned)cs->op[q].n0,       \
+                    cs->op[q].f.st, 0);                                                                    \
     }                                                                                                      \
     __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WAVES, 8)))               \
     kt_flow_build3##SUFFIX(const Slot *__restrict__ tab, const int q)                                      \
@@ -1794,13 +1921,14 @@ __global__ void __launch_bounds__(BLOCK) kt_post_step(const Slot *__restrict__ t
         int b = (int)blockIdx.x;                                                                           \
         const int np = cs->op[q].np, n0 = cs->op[q].n0, n1 = cs->op[q].n1, n2 = cs->op[q].n2;             \
         if (b < np) {                                                                                      \
-            process_body<PROC_FLOW, 0, false>(CVO_ARG(ProcessArgs, op[q].p), (unsigned)b, smem);                     \
+            const ProcessArgs &pa = CVO_ARG(ProcessArgs, op[q].p);                                         \
+            process_body<PROC_FLOW, 0, false>(pa, (unsigned)b, smem, proc_head_global<PROC_FLOW>(pa, pa.st, 0)); \
             return;                                                                                        \
         }                                                                                                  \
         b -= np;                                                                                           \
         const int role = b < n0 ? 0 : (b < n0 + n1 ? 1 : 2);                                               \
         filter_body(CVO_FILTER_ROLE(role), (unsigned)(b - (role == 0 ? 0 : (role == 1 ? n0 : n0 + n1))),   \
-                    (unsigned)(role == 0 ? n0 : (role == 1 ? n1 : n2)));                                   \
+                    (unsigned)(role == 0 ? n0 : (role == 1 ? n1 : n2)), cs->op[q + role].f.st, 0);         \
     }                                                                                                      \
     __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WAVES, 8)))               \
     kt_flow_build6##SUFFIX(const Slot *__restrict__ tab, const int q)                                      \
@@ -1810,29 +1938,136 @@ __global__ void __launch_bounds__(BLOCK) kt_post_step(const Slot *__restrict__ t
         int b = (int)blockIdx.x;                                                                           \
         const int np = cs->op[q].np;                                                                       \
         if (b < np) {                                                                                      \
-            process_body<PROC_FLOW, 0, false>(CVO_ARG(ProcessArgs, op[q].p), (unsigned)b, smem);                     \
+            const ProcessArgs &pa = CVO_ARG(ProcessArgs, op[q].p);                                         \
+            process_body<PROC_FLOW, 0, false>(pa, (unsigned)b, smem, proc_head_global<PROC_FLOW>(pa, pa.st, 0)); \
             return;                                                                                        \
         }                                                                                                  \
         b -= np;                                                                                           \
         if (b < 2 * np) {                                                                                  \
             const int w = b >= np ? 1 : 0;                                                                 \
-            process_body<PROC_SELF>(CVO_ARG(ProcessArgs, op[q + 1 + w].p), (unsigned)(b - w * np), smem);   \
+            const ProcessArgs &pa = CVO_ARG(ProcessArgs, op[q + 1 + w].p);                                 \
+            process_body<PROC_SELF>(pa, (unsigned)(b - w * np), smem, proc_head_global<PROC_SELF>(pa, pa.st, 0)); \
             return;                                                                                        \
         }                                                                                                  \
         b -= 2 * np;                                                                                       \
         const int n0 = cs->op[q].n0, n1 = cs->op[q].n1;                                                    \
         const int role = b < n0 ? 0 : (b < n0 + n1 ? 1 : 2);                                               \
         filter_body(CVO_FILTER_ROLE(role), (unsigned)(b - (role == 0 ? 0 : (role == 1 ? n0 : n0 + n1))),   \
-                    (unsigned)(role == 0 ? n0 : (role == 1 ? n1 : cs->op[q].n2)));                         \
+                    (unsigned)(role == 0 ? n0 : (role == 1 ? n1 : cs->op[q].n2)), cs->op[q + role].f.st, 0); \
     }
 CVO_MERGED_KERNELS(_w4, 4)
+
+// ---------------------------------------------------------------------------
+// Head mode (see "the head" above): the flow launch of a registration on its own, every flow / self
+// block of which starts with the post-step part of the previous slot and the plan of this one.
+// qp = op index | slot parity << 8 | QP_HEAD.
+// ---------------------------------------------------------------------------
+// What the list pass of a head-mode block takes from the head the block has just computed (LDS): the
+// hot part -- kernel constants, inverse transform -- goes to scalar registers.
+template <int MODE>
+__device__ __forceinline__ ProcHead proc_head_lds(const ProcessArgs &a, const DevHead *h, const int par, float (&rt)[12])
+{
+    auto uni = [](float x) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(x))); };
+    auto unid = [](double x) {
+        return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(x)), __builtin_amdgcn_readfirstlane(__double2loint(x)));
+    };
+    ProcHead hd;
+#pragma unroll
+    for (int q = 0; q < 9; ++q) rt[q] = uni(h->Rt[q]);
+#pragma unroll
+    for (int q = 0; q < 3; ++q) rt[9 + q] = uni(h->t[q]);
+    hd.Rt = rt; hd.tt = rt + 9; hd.xi = nullptr;
+    const KernConsts &k = h->kc;
+    hd.kc.tau = uni(k.tau); hd.kc.tau_c = uni(k.tau_c); hd.kc.sp = uni(k.sp);
+    hd.kc.inv_c = uni(k.inv_c); hd.kc.inv_d = uni(k.inv_d); hd.kc.inv_l3 = uni(k.inv_l3);
+    hd.kc.cb = uni(k.cb); hd.kc.cg = uni(k.cg); hd.kc.cd = uni(k.cd); hd.kc.cscale = uni(k.cscale);
+    hd.kc.s2_d = unid(k.s2_d); hd.kc.cs2_d = unid(k.cs2_d);
+    hd.kc.ninv_2l2 = unid(k.ninv_2l2); hd.kc.ninv_2cl2 = unid(k.ninv_2cl2);
+    hd.done_word = 0;   // (head_body has looked)
+    hd.n_fixed = (MODE == PROC_SELF && a.first_counted) ? __builtin_amdgcn_readfirstlane(h->n_fixed) : 0;
+    hd.second = ((MODE == PROC_FLOW && __builtin_amdgcn_readfirstlane(h->xy_active) == 1) ||
+                 (MODE == PROC_SELF && __builtin_amdgcn_readfirstlane(h->sf_active[a.async_self == 2 ? 1 : 0]) == 1)) ? 1 : 0;
+    hd.list_bad = 0u;   // (lists built ahead are only switched to after their flag was seen clear)
+    hd.ck_nblk = 0;
+    hd.par = par;
+    return hd;
+}
+
+#define CVO_HEAD_KERNELS(SUFFIX, WAVES)                                                                    \
+    __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WAVES, 8)))               \
+    kt_hflow_build##SUFFIX(const Slot *__restrict__ tab, const int qp)                                     \
+    {                                                                                                      \
+        extern __shared__ __attribute__((aligned(16))) char smem[];                                        \
+        __shared__ double sh[4 * NACC_MAX];                                                                \
+        __shared__ __attribute__((aligned(16))) DevHead s_st;                                              \
+        CVO_SLOT(tab);                                                                                     \
+        const int q = qp & QP_MASK, par = (qp & QP_PARITY) ? 1 : 0;                                        \
+        const int np = cs->op[q].np;                                                                       \
+        if ((int)blockIdx.x >= np) {                                                                       \
+            const FilterArgs &f = CVO_ARG(FilterArgs, op[q].f);                                            \
+            filter_body(f, blockIdx.x - (unsigned)np, (unsigned)cs->op[q].n0, par ? f.st2 : f.st, par);    \
+            return;                                                                                        \
+        }                                                                                                  \
+        const PostStepArgs ps = CVO_ARG(PostStepArgs, op[q].ps);                                           \
+        if (!head_body<HM_HEAD>(ps, par ? ps.st2 : ps.st, par ? ps.st : ps.st2, &s_st, sh, par,            \
+                                blockIdx.x == 0)) return;                                                  \
+        const ProcessArgs &pa = CVO_ARG(ProcessArgs, op[q].p);                                             \
+        float rt[12];                                                                                      \
+        process_body<PROC_FLOW, 0, false>(pa, blockIdx.x, smem, proc_head_lds<PROC_FLOW>(pa, &s_st, par, rt)); \
+    }                                                                                                      \
+    __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WAVES, 8)))               \
+    kt_hflow_build6##SUFFIX(const Slot *__restrict__ tab, const int qp)                                    \
+    {                                                                                                      \
+        extern __shared__ __attribute__((aligned(16))) char smem[];                                        \
+        __shared__ double sh[4 * NACC_MAX];                                                                \
+        __shared__ __attribute__((aligned(16))) DevHead s_st;                                              \
+        CVO_SLOT(tab);                                                                                     \
+        const int q = qp & QP_MASK, par = (qp & QP_PARITY) ? 1 : 0;                                        \
+        int b = (int)blockIdx.x;                                                                           \
+        const int np = cs->op[q].np;                                                                       \
+        if (b >= 3 * np) {                                                                                 \
+            b -= 3 * np;                                                                                   \
+            const int n0 = cs->op[q].n0, n1 = cs->op[q].n1;                                                \
+            const int role = b < n0 ? 0 : (b < n0 + n1 ? 1 : 2);                                           \
+            const FilterArgs &f = CVO_FILTER_ROLE(role);                                                   \
+            filter_body(f, (unsigned)(b - (role == 0 ? 0 : (role == 1 ? n0 : n0 + n1))),                   \
+                        (unsigned)(role == 0 ? n0 : (role == 1 ? n1 : cs->op[q].n2)), par ? f.st2 : f.st, par); \
+            return;                                                                                        \
+        }                                                                                                  \
+        const PostStepArgs ps = CVO_ARG(PostStepArgs, op[q].ps);                                           \
+        if (!head_body<HM_HEAD>(ps, par ? ps.st2 : ps.st, par ? ps.st : ps.st2, &s_st, sh, par,            \
+                                blockIdx.x == 0)) return;                                                  \
+        float rt[12];                                                                                      \
+        if (b < np) {                                                                                      \
+            const ProcessArgs &pa = CVO_ARG(ProcessArgs, op[q].p);                                         \
+            process_body<PROC_FLOW, 0, false>(pa, (unsigned)b, smem, proc_head_lds<PROC_FLOW>(pa, &s_st, par, rt)); \
+            return;                                                                                        \
+        }                                                                                                  \
+        b -= np;                                                                                           \
+        const int w = b >= np ? 1 : 0;                                                                     \
+        const ProcessArgs &pa = CVO_ARG(ProcessArgs, op[q + 1 + w].p);                                     \
+        process_body<PROC_SELF, 0, false>(pa, (unsigned)(b - w * np), smem, proc_head_lds<PROC_SELF>(pa, &s_st, par, rt)); \
+    }
+CVO_HEAD_KERNELS(_w4, 4)
+
+// the post-step part of the last slot of a head-mode batch, in place (copy 0: a batch has an even
+// number of slots), one block
+__global__ void __launch_bounds__(BLOCK) kt_head_flush(const Slot *__restrict__ tab, const int qp)
+{
+    __shared__ double sh[4 * NACC_MAX];
+    __shared__ __attribute__((aligned(16))) DevHead s_st;
+    CVO_SLOT(tab);
+    const PostStepArgs ps = CVO_ARG(PostStepArgs, op[qp & QP_MASK].ps);
+    head_body<HM_FLUSH>(ps, ps.st, ps.st, &s_st, sh, 0, true);
+}
 
 unsigned filter_grid_cap(long long nitems, long long cap) { return filter_grid_x(nitems, cap); }
 long long filter_blocks_cap() { return filter_blocks_max(); }
 
-void launch_table(const Slot *tab, const TLaunch &l, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop)
+void launch_table(const Slot *tab, const TLaunch &l, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop, int parity)
 {
     const dim3 g(l.gx, 1, l.gz);
+    const int qp = l.q | (parity ? QP_PARITY : 0) | QP_HEAD;   // head-mode launches
     if (ev_start && ev_stop && l.kernel == TK_FLOW) {   // engine profiling: the dispatch's own begin / end
         hipExtLaunchKernelGGL(kt_process<PROC_FLOW>, g, dim3(BLOCK), 0, s, ev_start, ev_stop, 0, tab, l.q);
         return;
@@ -1846,12 +2081,15 @@ void launch_table(const Slot *tab, const TLaunch &l, hipStream_t s, hipEvent_t e
     case TK_SELF: hipLaunchKernelGGL(kt_process<PROC_SELF>, g, dim3(BLOCK), 0, s, tab, l.q); break;
     case TK_SELF2: hipLaunchKernelGGL(kt_self2, dim3(l.gx, 2, l.gz), dim3(BLOCK), 0, s, tab, l.q); break;
     case TK_STEP_TWIST: hipLaunchKernelGGL(kt_step_twist, g, dim3(STEP_BLOCK), 0, s, tab, l.q); break;
-    case TK_STEP_TWIST_POST: hipLaunchKernelGGL(kt_step_twist_post, g, dim3(STEP_BLOCK), 0, s, tab, l.q); break;
     case TK_FLOW_BUILD: hipLaunchKernelGGL(kt_flow_build_w4, g, dim3(BLOCK), l.smem, s, tab, l.q); break;
     case TK_FLOW_BUILD3: hipLaunchKernelGGL(kt_flow_build3_w4, g, dim3(BLOCK), l.smem, s, tab, l.q); break;
     case TK_FLOW_BUILD6: hipLaunchKernelGGL(kt_flow_build6_w4, g, dim3(BLOCK), l.smem, s, tab, l.q); break;
     case TK_POST_FLOW: hipLaunchKernelGGL(kt_post_flow, g, dim3(BLOCK), 0, s, tab, l.q); break;
     case TK_POST_STEP: hipLaunchKernelGGL(kt_post_step, g, dim3(BLOCK), 0, s, tab, l.q); break;
+    case TK_HFLOW_BUILD: hipLaunchKernelGGL(kt_hflow_build_w4, g, dim3(BLOCK), l.smem, s, tab, qp); break;
+    case TK_HFLOW_BUILD6: hipLaunchKernelGGL(kt_hflow_build6_w4, g, dim3(BLOCK), l.smem, s, tab, qp); break;
+    case TK_HSTEP_TWIST: hipLaunchKernelGGL(kt_step_twist, g, dim3(STEP_BLOCK), 0, s, tab, qp); break;
+    case TK_HFLUSH: hipLaunchKernelGGL(kt_head_flush, g, dim3(BLOCK), 0, s, tab, l.q); break;
     default: break;
     }
 }

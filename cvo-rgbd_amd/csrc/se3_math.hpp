@@ -20,7 +20,7 @@
 #include <math.h>
 #include <string.h>
 
-#define CVO_HD __host__ __device__ inline
+#define CVO_HD __host__ __device__ inline __attribute__((always_inline))
 
 namespace cvo_math {
 

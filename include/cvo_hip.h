@@ -192,8 +192,11 @@ int cvo_hip_set_allreduce(cvo_hip_ctx *ctx, cvo_hip_allreduce_fn fn, void *user)
  *      or (ctx, NULL, ptrs (world device pointers)); after it cvo_hip_align / _flow /
  *      _step_coeffs / _function_inner_product all-reduce through the mailboxes.
  * All ranks must issue the same sequence of those calls (SPMD).  A peer that does not show up
- * within CVO_HIP_MAILBOX_TIMEOUT_S (default 5 s) ends the call with CVO_HIP_ERR_COMM.  Nobody may
- * destroy its context while a peer can still be inside such a call. */
+ * within CVO_HIP_MAILBOX_TIMEOUT_S (default 5 s) ends the call with CVO_HIP_ERR_COMM.  After
+ * CVO_HIP_ERR_COMM the mailboxes of the world are UNUSABLE (the ranks' sequence numbers no longer
+ * agree): further cvo_hip_align calls on that context are refused with CVO_HIP_ERR_COMM until
+ * steps 1-3 have been repeated on every rank.  Nobody may destroy its context while a peer can
+ * still be inside such a call. */
 #define CVO_HIP_MAILBOX_HANDLE_BYTES 64
 int cvo_hip_mailbox_create(cvo_hip_ctx *ctx, int rank, int world, void *ipc_handle_64, void **dev_ptr);
 int cvo_hip_mailbox_connect(cvo_hip_ctx *ctx, const void *ipc_handles, void *const *dev_ptrs);
