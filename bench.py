@@ -43,7 +43,7 @@ F64_OPS_PER_EXP = 14.0         # the device exp (cvo_kernels.hip exp_neg)
 BYTES_PER_POINT = 32.0         # xyz 12 B + 5 features 20 B
 PEAK_F32_TFLOPS = 157.3        # MI355X_MICROARCH.md: FP32 vector = FP32 MFMA peak
 PEAK_HBM_GBS = 8000.0
-PROFILE_TAG = "r02"            # committed rocprofv3 summaries under profiles/ (tools/gpu_profile.sh)
+PROFILE_TAG = "r03"            # committed rocprofv3 summaries under profiles/ (tools/gpu_profile.sh)
 
 
 def parse():
@@ -67,6 +67,11 @@ def parse():
     ap.add_argument("--sharded-steps", type=int, default=2)
     ap.add_argument("--sharded-timeout", type=int, default=240, help="watchdog of the sharded leg, seconds")
     ap.add_argument("--sharded-exchange", default="mailbox", choices=["mailbox", "rccl"])
+    ap.add_argument("--roofline-only", action="store_true",
+                    help="run the roofline leg alone (one engine of --roofline-pairs registrations) and print its "
+                         "object: the command rocprofv3 is run on for profiles/*_kernel_stats_roofline.csv")
+    ap.add_argument("--roofline-pairs", type=int, default=22,
+                    help="registrations in the single engine of the roofline leg (an engine of the timed region holds 21-22)")
     ap.add_argument("--force-sharded-leg", action="store_true",
                     help="run the sharded leg even on one GPU (world size 1): exercises the "
                          "multi-rank code path where only one GPU is available")
@@ -90,15 +95,30 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+    # Rehearsal of the multi-GPU run where only one GPU is to be had (CVO_BENCH_RANKS_ON_DEVICE0=1): every
+    # rank works on device 0, torch's collectives go through gloo (RCCL refuses two ranks on one device) --
+    # the weak-scaling leg, the all_gather of the IPC handles, the mailbox leg with its RCCL fall-back
+    # decision, the watchdog and the assembly of the line all run as they will on 8 GPUs.
+    on_dev0 = os.environ.get("CVO_BENCH_RANKS_ON_DEVICE0", "") not in ("", "0")
+    if on_dev0:
+        local_rank = 0
+    backend = "gloo" if on_dev0 else "nccl"
+    red_dev = "cpu" if on_dev0 else "cuda"
     torch.cuda.set_device(local_rank)
     if world == 1 and args.force_sharded_leg:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
-        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
+        if on_dev0:
+            dist.init_process_group(backend, rank=0, world_size=1)
+        else:
+            dist.init_process_group(backend, rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        if on_dev0:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", local_rank))
 
     pkg = ge.load_package()
     capi = pkg.capi
@@ -106,6 +126,9 @@ def main():
     mode = capi.MODE_ACVO if acvo else capi.MODE_CVO
     n = m = args.points
     B = max(1, args.batch)
+    if args.roofline_only:
+        print(json.dumps(roofline_engine_leg(args, pkg, torch, mode, acvo, n, m)), flush=True)
+        return None
     # every rank registers its own frame pairs: `batch` contexts, one stream each.  This process
     # issues HIP work from this one thread only, so the contexts may capture their batches of
     # iterations into hipGraphs although the streams are torch's (cvo_hip_set_graph_capture).
@@ -150,8 +173,8 @@ def main():
     elapsed = time.perf_counter() - t0
     # (left off for the side legs below as well; the process ends after them)
 
-    t_max = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-    it_sum = torch.tensor([float(iters)], dtype=torch.float64, device="cuda")
+    t_max = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
+    it_sum = torch.tensor([float(iters)], dtype=torch.float64, device=red_dev)
     if world > 1:
         dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
         dist.all_reduce(it_sum, op=dist.ReduceOp.SUM)
@@ -176,6 +199,7 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
+            "ranks_on_device0": True if on_dev0 else None,
             "config": {
                 "workload": "synthetic %dk x %dk RGB-D cloud pairs (xyz + 5-dim colour), %s align() to convergence; "
                             "a step = a batch of %d %s pairs in flight (pair 0 = BASELINE configs[1], seed %d%s)"
@@ -204,15 +228,20 @@ def main():
             "peak_TFLOPs": PEAK_F32_TFLOPS}
 
     if rank == 0 and world == 1:
-        # ---- one registration at a time (latency view): the configs[1] pair on context 0
+        # ---- one registration at a time (latency view): the configs[1] pair on context 0, through
+        # cvo_hip_align -- the call a sequential VO loop makes (ref src/cvo.cpp:361-420)
+        def lone():
+            st = capi.init_state(ctx.params)
+            k, _ = ctx.align(st, trace_cap=0)
+            return [k], [st]
         for _ in range(2):
-            one_step(ctxs[:1])
+            lone()
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         it1 = 0
         n1 = max(5, args.steps)
         for _ in range(n1):
-            its, st1 = one_step(ctxs[:1])
+            its, st1 = lone()
             it1 += its[0]
         torch.cuda.synchronize()
         el1 = time.perf_counter() - t1
@@ -222,7 +251,27 @@ def main():
         out["equivalent_sweep_rate"]["single_stream_TFLOPs"] = \
             sweep_flop_per_iter / (out["single_stream"]["ms_per_iteration"] * 1e-3) / 1e12
         gpu_state0, gpu_iters0 = st1[0], its[0]
+        # ---- the path that produced `value`, checked in this run: every registration of the last timed
+        # step (engines, 32-slot tables, candidate lists) against the same pair registered on its own
+        # (cvo_hip_align), bit for bit; four of them against the oracle in the cpu leg below
+        lone_equal, lone_diff = 0, []
+        for b, c in enumerate(ctxs):
+            st_l = capi.init_state(c.params)
+            n_l, _ = c.align(st_l, trace_cap=0)
+            if bytes(st_l) == bytes(last_states[b]) and n_l == last_its[b]:
+                lone_equal += 1
+            else:
+                lone_diff.append(b)
+        batched_parity = {"registrations": B, "bit_identical_to_lone_cvo_hip_align": lone_equal,
+                          "differing": lone_diff[:8],
+                          "what": "the %d final states (R, T, ell, transforms, iter) and iteration counts of the last timed "
+                                  "align_many step vs cvo_hip_align of the same pair on the same context" % B}
         out.update(roofline_legs(args, pkg, ctx, ctxs, one_step, n, m))
+        if not args.no_side_legs:
+            try:
+                out["value_including_set_pcd"] = handover_leg(args, pkg, ctxs, pairs, one_step, torch)
+            except Exception as e:
+                out["value_including_set_pcd"] = {"error": repr(e)}
         if not args.no_side_legs:
             try:
                 out["identical_pairs"] = identical_leg(args, pkg, ctxs, pairs[0], one_step, torch)
@@ -238,9 +287,22 @@ def main():
                 out["saturation"] = {"error": repr(e)}
         if not args.no_side_legs:
             try:
+                out["roofline"].update(roofline_engine_leg(args, pkg, torch, mode, acvo, n, m))
+            except Exception as e:
+                out["roofline"]["engine_leg_error"] = repr(e)
+            if not acvo:
+                try:   # the mode of BASELINE configs[2] (ref src/adaptive_cvo.cpp:490-555), same batch shape
+                    out["acvo"] = mode_leg(args, pkg, torch, capi.MODE_ACVO, True, n, m, B)
+                except Exception as e:
+                    out["acvo"] = {"error": repr(e)}
+            try:
                 out["config4"] = config4_leg(args, pkg, torch, mode, acvo)
             except Exception as e:
                 out["config4"] = {"error": repr(e)}
+            try:   # the N = 1 point of the strong-scaling curve of BASELINE configs[3]
+                out["config3_single_gpu"] = config3_leg(args, pkg, torch, mode, acvo)
+            except Exception as e:
+                out["config3_single_gpu"] = {"error": repr(e)}
             if not args.no_frontend:
                 try:
                     out["frontend"] = frontend_leg(args, pkg)
@@ -252,6 +314,8 @@ def main():
             cpu, parity = cpu_baseline(args, pkg, xf, ff, xm, fm, acvo, gpu_state0, gpu_iters0)
             out["cpu_baseline"] = cpu
             out["parity_vs_oracle"] = parity
+            batched_parity.update(batched_vs_oracle(pkg, pairs, last_states, last_its, acvo, cpu["cores"]))
+        out.setdefault("parity_vs_oracle", {})["batched"] = batched_parity
     # The target-sharded leg runs last and under a watchdog: the headline line above it must
     # not depend on it, not even if an exchange hangs.
     if (world > 1 or args.force_sharded_leg) and args.sharded_steps > 0:
@@ -272,7 +336,7 @@ def main():
         dog.daemon = True
         dog.start()
         try:
-            sharded = sharded_leg(args, pkg, dist, torch, rank, world, local_rank, barrier)
+            sharded = sharded_leg(args, pkg, dist, torch, rank, world, local_rank, barrier, red_dev)
         except Exception as exc:
             sharded = {"error": repr(exc)}
         dog.cancel()
@@ -462,6 +526,196 @@ def roofline_legs(args, pkg, ctx, ctxs, one_step, n, m):
     return res
 
 
+def roofline_engine_leg(args, pkg, torch, mode, acvo, n, m):
+    """The roofline object's own measurement: ONE engine holding `--roofline-pairs` (22) distinct pairs --
+    what each of the three engines of the timed region holds -- with a HIP event pair attached to every
+    flow-pass dispatch (kt_process<PROC_FLOW>) on the engine's stream.  With one engine no other stream
+    contends for the GPU, so the dispatch durations are the kernel's own and agree with rocprofv3's of the
+    same command (`bench.py --roofline-only`, committed as profiles/<tag>_kernel_stats_roofline.csv); in the
+    timed region three such launch sequences overlap and a launch takes about twice as long (`in_timed_region`).
+    Units per launch = registrations that execute in it = (sum of the iterations of the call) / launches."""
+    import csv
+    capi = pkg.capi
+    count = max(2, args.roofline_pairs)
+    ctxs, streams = [], []
+    for i in range(count):
+        xf, ff, xm, fm = pkg.data.synthetic_pair(n, m, seed=pair_seed(pkg, i), acvo=acvo)
+        st = torch.cuda.Stream()
+        c = capi.Context(mode=mode, device=torch.cuda.current_device(), stream=st.cuda_stream, graph_capture=True)
+        c.set_fixed(xf, ff)
+        c.set_moving(xm, fm)
+        ctxs.append(c)
+        streams.append(st)
+    os.environ["CVO_HIP_ENGINES_FORCE"] = "1"
+    try:
+        def step():
+            states = [capi.init_state(c.params) for c in ctxs]
+            return capi.align_many(ctxs, states)
+        step()
+        torch.cuda.synchronize()
+        capi.engine_profiling(True)
+        capi.engine_profile(reset=True)
+        reps, its = max(3, args.steps // 4), 0
+        for _ in range(reps):
+            its += sum(step())
+        torch.cuda.synchronize()
+        e_ms, e_n, e_slots = capi.engine_profile(reset=True)
+        capi.engine_profiling(False)
+    finally:
+        os.environ.pop("CVO_HIP_ENGINES_FORCE", None)
+        for c in ctxs:
+            c.close()
+    algo_bytes = BYTES_PER_POINT * (n + m)
+    regs_per_launch = its / float(max(e_n, 1))
+    us = e_ms * 1e3 / max(e_n, 1)
+    b_bytes = algo_bytes * regs_per_launch
+    gbs = b_bytes / (us * 1e-6) / 1e9 if us > 0 else 0.0
+    res = {"achieved": gbs, "frac": gbs / PEAK_HBM_GBS, "algorithmic_bytes_per_launch": b_bytes,
+           "registrations_per_launch": regs_per_launch, "slots_per_launch": e_slots / float(max(e_n, 1)),
+           "avg_launch_us": us, "launches": int(e_n),
+           "measured": "HIP events attached to every flow-pass dispatch of ONE engine holding %d distinct pairs (%d align_many "
+                       "calls, eager launches): %d launches; units per launch = iterations executed / launches = %.2f registrations"
+                       % (count, reps, e_n, regs_per_launch)}
+    spath = os.path.join(ROOT, "profiles", "%s_kernel_stats_roofline.csv" % PROFILE_TAG)
+    if os.path.exists(spath):
+        try:
+            for r in csv.DictReader(open(spath)):
+                if "kt_process<0, 0>" in r["Name"]:
+                    ru = float(r["AverageNs"]) / 1e3
+                    res["rocprofv3"] = {"avg_launch_us": ru, "launches": int(r["Calls"]),
+                                        "source": "committed profiles/%s_kernel_stats_roofline.csv" % PROFILE_TAG,
+                                        "command": "rocprofv3 --kernel-trace --stats -- python bench.py --roofline-only"}
+                    res["frac_at_rocprofv3_duration"] = b_bytes / (ru * 1e-6) / 1e9 / PEAK_HBM_GBS if ru > 0 else None
+        except Exception:
+            pass
+    valu, valu_src = committed("%s_valu.json" % PROFILE_TAG)
+    if valu:
+        res["valu_issue_frac"] = valu.get("valu_issue_frac")
+        res["valu_issue"] = dict(valu, source=valu_src)
+    ph, ph_src = committed("%s_pmc_phases.json" % PROFILE_TAG)
+    if ph and "kt_process<0, 0>" in ph:
+        k = ph["kt_process<0, 0>"]
+        res["traffic"] = k.get("all", {}).get("hbm_bytes_per_launch")
+        res["traffic_source"] = ph_src
+        res["traffic_note"] = ("PMC FETCH_SIZE x 2 + WRITE_SIZE per launch, the SAME launches in both passes and in the kernel "
+                               "trace (one engine of %d pairs: the k-th dispatch of a pass is the k-th of the others)" % count)
+        res["traffic_by_length_scale"] = {kk: vv for kk, vv in k.items() if kk != "all"}
+    return res
+
+
+def handover_leg(args, pkg, ctxs, pairs, one_step, torch):
+    """`value` with row a1's work inside the timed region: every step first hands both clouds of every pair over
+    again from host arrays (cvo_hip_set_fixed / _set_moving: PCIe, Morton keys, radix sort, pack, bounding spheres
+    -- the tail of set_pcd(), ref src/cvo.cpp:344-356), then registers the batch."""
+    steps = max(3, args.steps // 4)
+
+    def step():
+        for c, pr in zip(ctxs, pairs):
+            c.set_fixed(pr[0], pr[1])
+            c.set_moving(pr[2], pr[3])
+        return one_step(ctxs)
+    step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    return {"registrations_per_s": steps * len(ctxs) / el, "ms_per_step": el * 1e3 / steps, "steps": steps,
+            "includes": "set_fixed + set_moving of both clouds of every pair from host memory, every step"}
+
+
+def mode_leg(args, pkg, torch, mode, acvo, n, m, count):
+    """The timed region's batch shape in the other mode (acvo: the mode of BASELINE configs[2])."""
+    capi = pkg.capi
+    ctxs, streams = [], []
+    for i in range(count):
+        xf, ff, xm, fm = pkg.data.synthetic_pair(n, m, seed=pair_seed(pkg, i), acvo=acvo)
+        st = torch.cuda.Stream()
+        c = capi.Context(mode=mode, device=torch.cuda.current_device(), stream=st.cuda_stream, graph_capture=True)
+        c.set_fixed(xf, ff)
+        c.set_moving(xm, fm)
+        ctxs.append(c)
+        streams.append(st)
+
+    def step():
+        states = [capi.init_state(c.params) for c in ctxs]
+        return capi.align_many(ctxs, states)
+    t_w = time.perf_counter()
+    while time.perf_counter() - t_w < 0.4:
+        step()
+    torch.cuda.synchronize()
+    steps, it = max(3, args.steps // 4), 0
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        it += sum(step())
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    # one at a time (the reference's use: a sequential VO loop)
+    c0 = ctxs[0]
+    for _ in range(2):
+        c0.align(capi.init_state(c0.params), trace_cap=0)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    n1, it1 = 8, 0
+    for _ in range(n1):
+        k, _ = c0.align(capi.init_state(c0.params), trace_cap=0)
+        it1 += k
+    torch.cuda.synchronize()
+    el1 = time.perf_counter() - t1
+    for c in ctxs:
+        c.close()
+    return {"workload": "%d distinct %dk x %dk pairs per align_many call, %s" % (count, n // 1000, m // 1000, "acvo" if acvo else "cvo"),
+            "registrations_per_s": steps * count / el, "ms_per_step": el * 1e3 / steps,
+            "iterations_per_registration": it / float(steps * count), "steps": steps,
+            "single_stream": {"registrations_per_s": n1 / el1, "ms_per_registration": el1 * 1e3 / n1,
+                              "ms_per_iteration": el1 * 1e3 / max(it1, 1), "iterations": it1 / float(n1)}}
+
+
+def config3_leg(args, pkg, torch, mode, acvo):
+    """BASELINE configs[3] on ONE GPU: a single 200k x 200k registration (the N = 1 point of the strong-scaling
+    curve of the sharded leg)."""
+    capi = pkg.capi
+    n = m = args.sharded_points
+    xf, ff, xm, fm = pkg.data.synthetic_pair(n, m, seed=pkg.data.SEED_CFG4, acvo=acvo)
+    c = capi.Context(mode=mode, device=torch.cuda.current_device(), graph_capture=True)
+    c.set_fixed(xf, ff)
+    c.set_moving(xm, fm)
+    c.align(capi.init_state(c.params), trace_cap=0)
+    torch.cuda.synchronize()
+    reps, it = 2, 0
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        k, _ = c.align(capi.init_state(c.params), trace_cap=0)
+        it += k
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    c.close()
+    return {"workload": "one synthetic %dk x %dk registration (BASELINE configs[3], seed %d), unsharded" % (n // 1000, m // 1000, pkg.data.SEED_CFG4),
+            "registrations_per_s": reps / el, "ms_per_registration": el * 1e3 / reps,
+            "ms_per_iteration": el * 1e3 / max(it, 1), "iterations": it / float(reps),
+            "pairs_per_sweep": float(n) * m}
+
+
+def batched_vs_oracle(pkg, pairs, last_states, last_its, acvo, cores, count=4):
+    """Four registrations of the last timed step (pairs 0-3) against the oracle's of the same pairs."""
+    from oracle import pyoracle as po
+    p = po.default_params(po.MODE_ACVO if acvo else po.MODE_CVO)
+    po.set_threads(max(1, cores))
+    same, rows = 0, []
+    for b in range(min(count, len(pairs))):
+        xf, ff, xm, fm = pairs[b]
+        st = po.init_state(p)
+        n_it, _ = po.align(p, st, xf, ff, xm, fm, search=po.SEARCH_GRID, trace_cap=1)
+        g = last_states[b]
+        ok = bool(int(n_it) == int(last_its[b]) and np.array_equal(np.array(g.R), np.array(st.R)) and
+                  np.array_equal(np.array(g.T), np.array(st.T)))
+        same += ok
+        rows.append({"pair": b, "iterations_gpu": int(last_its[b]), "iterations_oracle": int(n_it), "R_T_bit_identical": ok})
+    return {"vs_oracle": rows, "vs_oracle_bit_identical": same, "vs_oracle_checked": len(rows)}
+
+
+
 def identical_leg(args, pkg, ctxs, pair0, one_step, torch):
     """The round-1 headline: `--batch` copies of the configs[1] pair (every member stops at the
     same iteration: no tail, the best case of the fused groups)."""
@@ -595,6 +849,32 @@ def frontend_leg(args, pkg, frames=100):
         stream[name] = {"frames_per_s": 1.0 / dt, "ms_per_frame": dt * 1e3,
                         "passes_ms_per_frame": [round(v * 1e3, 3) for v in passes]}
     out["stream"] = stream
+    # the shape of BASELINE configs[2] (the PNGs of fr1/desk are not in the reference's tree): a synthetic VGA
+    # sequence through the front end and ONE acvo object, clouds handed over in device memory, the state carried
+    # from pair to pair as the reference's driver does (ref src/adaptive_cvo_main.cpp:36-66); the same chain is
+    # held against the oracle chain in tests/test_gpu_frontend.py
+    try:
+        nfr = 60
+        frames = [pkg.data.synthetic_rgbd_frame(seed=55, texture=1.0 + 0.5 * np.sin(k / 5.0),
+                                                motion=(1.2 * k, 0.6 * np.sin(k / 3.0) * 4)) for k in range(nfr)]
+        chain = {}
+        for name, cls, ftype in (("acvo", pkg.Acvo, 0), ("cvo", pkg.Cvo, 1)):
+            for rep in range(2):   # (the first pass warms up; a fresh object per pass, as a driver has one per sequence)
+                reg = cls()
+                its = 0
+                t0 = time.perf_counter()
+                for bgr, dep in frames:
+                    gen.submit(bgr, dep, 1, ftype)
+                    d_xyz, d_feat, npts = gen.collect_device()
+                    reg.run_cvo_device(d_xyz, d_feat, npts)
+                    its += reg.num_iterations
+                dt = (time.perf_counter() - t0) / nfr
+                reg.close()
+            chain[name] = {"frames_per_s": 1.0 / dt, "ms_per_frame": dt * 1e3, "frames": nfr,
+                           "iterations_per_pair": its / float(nfr - 1)}
+        out["chain"] = chain
+    except Exception as e:
+        out["chain"] = {"error": repr(e)}
     out["stream_note"] = "36 synthetic VGA frames (12, three times over), ~3k points each, decoded images in host memory, one frame at a time; median of 3 passes"
     gen.close()
     if not args.no_cpu:
@@ -607,7 +887,7 @@ def frontend_leg(args, pkg, frames=100):
     return out
 
 
-def sharded_leg(args, pkg, dist, torch, rank, world, local_rank, barrier):
+def sharded_leg(args, pkg, dist, torch, rank, world, local_rank, barrier, red_dev="cuda"):
     """BASELINE configs[3]: target rows sharded over the ranks; the 13 + 4 float64 partial sums of
     every iteration are summed over the ranks through peer mailboxes (stores over xGMI inside the
     post kernels) -- or, as the fall-back, with RCCL between the kernels."""
@@ -639,7 +919,7 @@ def sharded_leg(args, pkg, dist, torch, rank, world, local_rank, barrier):
 
     def agree(ok):
         # every rank must take the same branch: the minimum of the ranks' verdicts
-        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device="cuda")
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=red_dev)
         if world > 1:
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         return int(flag.item()) == 1
@@ -669,7 +949,7 @@ def sharded_leg(args, pkg, dist, torch, rank, world, local_rank, barrier):
         finally:
             barrier()
             ctx.close()
-        t = torch.tensor([el], dtype=torch.float64, device="cuda")
+        t = torch.tensor([el], dtype=torch.float64, device=red_dev)
         if world > 1:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())

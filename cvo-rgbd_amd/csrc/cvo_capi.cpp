@@ -1077,6 +1077,7 @@ bool plan_lone(const std::vector<RecOp> &ops, Slot &slot, std::vector<TLaunch> &
     }
     int q = 0;
     auto smem_of = [](int jt) { return (unsigned)filter_smem_bytes(jt); };
+    auto smem_head = [](int jt) { return (unsigned)filter_smem_bytes(jt); };
     // what follows the flow side must be exactly: step pass with the twist, post-step (reduce + maths, no exchange)
     const bool rest_fits = at + 2 == ops.size() && ops[at].kind == RecOp::PROCESS && ops[at].mode == kProcStepTwist &&
                            ops[at + 1].kind == RecOp::POST_STEP && ops[at + 1].ps.comm == nullptr &&
@@ -1105,9 +1106,9 @@ bool plan_lone(const std::vector<RecOp> &ops, Slot &slot, std::vector<TLaunch> &
         o.n1 = (int)filter_grid_cap(filter_items(slot.op[q + 1].f), cap);
         o.n2 = (int)filter_grid_cap(filter_items(slot.op[q + 2].f), cap);
         const int jt = std::max(o.f.jt, std::max(slot.op[q + 1].f.jt, slot.op[q + 2].f.jt));
-        if (head) o.ps = ops[at + 1].ps;
+        if (head) { o.ps = ops[at + 1].ps; }
         plan.push_back(mk_launch(head ? TK_HFLOW_BUILD6 : (six ? TK_FLOW_BUILD6 : TK_FLOW_BUILD3), q,
-                                 (unsigned)((six ? 3 : 1) * o.np + o.n0 + o.n1 + o.n2), 1, smem_of(jt)));
+                                 (unsigned)((six ? 3 : 1) * o.np + o.n0 + o.n1 + o.n2), 1, head ? smem_head(jt) : smem_of(jt)));
         if (head && head_flush) tail.push_back(mk_launch(TK_HFLUSH, q, 1, 1));
         q += 3;
         if (six) ns = 0;
@@ -1137,8 +1138,9 @@ bool plan_lone(const std::vector<RecOp> &ops, Slot &slot, std::vector<TLaunch> &
             const long long cap = std::max<long long>(64, 2 * fbmax / fb_div);
             o.np = std::max(8, flow.nblk);
             o.n0 = (int)std::max(8u, filter_grid_cap(filter_items(build), cap));
-            if (head) o.ps = ops[at + 1].ps;
-            plan.push_back(mk_launch(head ? TK_HFLOW_BUILD : TK_FLOW_BUILD, q, (unsigned)(o.np + o.n0), 1, smem_of(build.jt)));
+            if (head) { o.ps = ops[at + 1].ps; }
+            plan.push_back(mk_launch(head ? TK_HFLOW_BUILD : TK_FLOW_BUILD, q, (unsigned)(o.np + o.n0), 1,
+                                     head ? smem_head(build.jt) : smem_of(build.jt)));
             if (head && head_flush) tail.push_back(mk_launch(TK_HFLUSH, q, 1, 1));
             ++q;
         } else if (have_flow) {
@@ -1600,9 +1602,10 @@ int cvo_hip_destroy(cvo_hip_ctx *ctx)
     if (ctx->post_dbg) {
         long long h[8];
         if (hipMemcpy(h, ctx->post_dbg, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess && h[0] > 0)
-            fprintf(stderr, "[cvo_hip] k_post_step over %lld launches, avg ticks: state load %.0f, reduce %.0f, "
-                    "cubic %.0f, exp+update %.0f, prepare %.0f\n", h[0], (double)h[1] / h[0], (double)h[2] / h[0],
-                    (double)h[3] / h[0], (double)h[4] / h[0], (double)h[5] / h[0]);
+            fprintf(stderr, "[cvo_hip] post-step part over %lld launches, avg ticks: state load %.0f, reduce %.0f, "
+                    "cubic %.0f, exp+update %.0f, prepare %.0f; head mode: block 0 of the flow launch start to end %.0f\n",
+                    h[0], (double)h[1] / h[0], (double)h[2] / h[0],
+                    (double)h[3] / h[0], (double)h[4] / h[0], (double)h[5] / h[0], (double)h[7] / h[0]);
         (void)hipFree(ctx->post_dbg);
     }
     for (void *p : {(void *)ctx->fixed.pos, (void *)ctx->fixed.feat, (void *)ctx->moving.pos,

@@ -494,13 +494,14 @@ CVO_HD void plan_lists(DevHead *s, DevHead *bulk, const bool store, const DevPar
 //     the target named now is built by the flow launch of slot s + 2 and judged at the head of
 //     slot s + 3.  One build at a time: the buffers are two.
 // No dynamic indexing below: in the post kernels the state lives in registers.
-template <int B> CVO_HD double xy_travel(const DevHead *s)
+// (rec: where the transform records are read from -- the shared copy of the head, see `bulk` at plan_lists)
+template <int B> CVO_HD double xy_travel(const DevHead *s, const DevHead *rec)
 {
     double f2 = 0.0, c2 = 0.0;
     for (int r = 0; r < 3; ++r) {
-        double dc = (double)s->t[r] - (double)s->xy_t[B][r];
+        double dc = (double)s->t[r] - (double)rec->xy_t[B][r];
         for (int q = 0; q < 3; ++q) {
-            const double d = (double)s->Rt[3 * r + q] - (double)s->xy_Rt[B][3 * r + q];
+            const double d = (double)s->Rt[3 * r + q] - (double)rec->xy_Rt[B][3 * r + q];
             f2 += d * d;
             dc += d * (double)s->center[q];
         }
@@ -524,13 +525,13 @@ CVO_HD void plan_xy_async(DevHead *s, DevHead *bulk, const bool store, const Dev
     const int first = fresh >= 0 ? (fresh ? 1 : 0) : act;
     double need0 = 0.0, need1 = 0.0;
     bool valid0 = false, valid1 = false;
-    if (first == 0) { need0 = s->xy_ok[0] ? (r_now + xy_travel<0>(s)) * 1.0001 + slack : 0.0; valid0 = s->xy_ok[0] && need0 <= (double)s->xy_r[0]; }
-    else { need1 = s->xy_ok[1] ? (r_now + xy_travel<1>(s)) * 1.0001 + slack : 0.0; valid1 = s->xy_ok[1] && need1 <= (double)s->xy_r[1]; }
+    if (first == 0) { need0 = s->xy_ok[0] ? (r_now + xy_travel<0>(s, bulk)) * 1.0001 + slack : 0.0; valid0 = s->xy_ok[0] && need0 <= (double)s->xy_r[0]; }
+    else { need1 = s->xy_ok[1] ? (r_now + xy_travel<1>(s, bulk)) * 1.0001 + slack : 0.0; valid1 = s->xy_ok[1] && need1 <= (double)s->xy_r[1]; }
     int use = -1;
     if (first ? valid1 : valid0) use = first;
     else {
-        if (first == 0) { need1 = s->xy_ok[1] ? (r_now + xy_travel<1>(s)) * 1.0001 + slack : 0.0; valid1 = s->xy_ok[1] && need1 <= (double)s->xy_r[1]; }
-        else { need0 = s->xy_ok[0] ? (r_now + xy_travel<0>(s)) * 1.0001 + slack : 0.0; valid0 = s->xy_ok[0] && need0 <= (double)s->xy_r[0]; }
+        if (first == 0) { need1 = s->xy_ok[1] ? (r_now + xy_travel<1>(s, bulk)) * 1.0001 + slack : 0.0; valid1 = s->xy_ok[1] && need1 <= (double)s->xy_r[1]; }
+        else { need0 = s->xy_ok[0] ? (r_now + xy_travel<0>(s, bulk)) * 1.0001 + slack : 0.0; valid0 = s->xy_ok[0] && need0 <= (double)s->xy_r[0]; }
         if (first ? valid0 : valid1) use = 1 - first;
     }
     s->stall = use < 0 ? 1 : 0;

@@ -1519,6 +1519,23 @@ __device__ __forceinline__ void head_math(DevHead *lds, const PostStepArgs &a, c
     for (int q = 0; q < 4; ++q) bcde[q] = lds->red[RED_STEP + q];
     int k = lds->k, done = lds->done, iter = lds->iter, n_exec = lds->n_exec;
     const int n_slots = lds->n_slots + (was_pending ? 1 : 0);   // head mode: a slot is complete when the head that follows it has run
+    // what the builds that have ended made of their lists (judged by the plan below; worked out here, so
+    // that three verdicts travel down the chain instead of seven flags)
+    PlanBuilds pb = HM == HM_CLASSIC ? plan_builds_classic(lds, false, false, false) : plan_builds_head(lds, false, false, false);
+    pb.xy_failed = async && pb.xy_fresh >= 0 && (pb.xy_fresh ? flag[LIST_XYB] : flag[LIST_XY]) != 0u;
+    // (classic, synchronous self lists: a stall slot runs no k_step_twist / k_post_flow, which is where
+    // an overflow of the xx / yy lists is normally caught: lists built in a stall slot are checked here)
+    pb.sf_failed[0] = aself ? (pb.sf_fresh[0] >= 0 && (pb.sf_fresh[0] ? flag[LIST_XXB] : flag[LIST_XX]) != 0u)
+                            : (HM == HM_CLASSIC && stalled && flag[LIST_XX] != 0u);
+    pb.sf_failed[1] = aself ? (pb.sf_fresh[1] >= 0 && (pb.sf_fresh[1] ? flag[LIST_YYB] : flag[LIST_YY]) != 0u)
+                            : (HM == HM_CLASSIC && stalled && flag[LIST_YY] != 0u);
+    // (this iteration's flow pass has recorded or streamed the candidate list: it matches the tile list --
+    // until plan_lists schedules a rebuild)
+    bool ck_ok[3] = {false, false, false};
+    if (HM == HM_CLASSIC && run_post && flag[LIST_KEPT] == 0u) {
+#pragma unroll
+        for (int l = 0; l < 3; ++l) ck_ok[l] = a.ck_nblk[l] != 0 && flag[l] == 0u;
+    }
 
     bool plan = HM != HM_FLUSH;
     if (run_post) {
@@ -1618,21 +1635,10 @@ __device__ __forceinline__ void head_math(DevHead *lds, const PostStepArgs &a, c
 #pragma unroll
         for (int q = 0; q < 3; ++q) L.T[q] = T[q];
         L.ell = ell;
-        // what the builds that have ended made of their lists
-        PlanBuilds pb = HM == HM_CLASSIC ? plan_builds_classic(&L, false, false, false) : plan_builds_head(&L, false, false, false);
-        pb.xy_failed = async && pb.xy_fresh >= 0 && (pb.xy_fresh ? flag[LIST_XYB] : flag[LIST_XY]) != 0u;
-        // (classic, synchronous self lists: a stall slot runs no k_step_twist / k_post_flow, which is where
-        // an overflow of the xx / yy lists is normally caught: lists built in a stall slot are checked here)
-        pb.sf_failed[0] = aself ? (pb.sf_fresh[0] >= 0 && (pb.sf_fresh[0] ? flag[LIST_XXB] : flag[LIST_XX]) != 0u)
-                                : (HM == HM_CLASSIC && stalled && flag[LIST_XX] != 0u);
-        pb.sf_failed[1] = aself ? (pb.sf_fresh[1] >= 0 && (pb.sf_fresh[1] ? flag[LIST_YYB] : flag[LIST_YY]) != 0u)
-                                : (HM == HM_CLASSIC && stalled && flag[LIST_YY] != 0u);
-        // (this iteration's flow pass has recorded or streamed the candidate list: it matches the tile list --
-        // until plan_lists schedules a rebuild)
-        if (HM == HM_CLASSIC && run_post && flag[LIST_KEPT] == 0u) {
+        if (HM == HM_CLASSIC) {
 #pragma unroll
             for (int l = 0; l < 3; ++l)
-                if (a.ck_nblk[l] != 0 && flag[l] == 0u) L.ck_nblk[l] = a.ck_nblk[l];
+                if (ck_ok[l]) L.ck_nblk[l] = a.ck_nblk[l];
         }
         // (lane 0 alone stores through `bulk`; the other lanes compute the same values and drop them)
         prepare_iteration(&L, lds, lane0, p, pb);
@@ -1676,7 +1682,8 @@ __device__ __forceinline__ bool head_body(const PostStepArgs &a, const DevHead *
     const int tid = threadIdx.x;
     const bool reduce = HM != HM_CLASSIC || (a.flags & POST_REDUCE) != 0;
     const bool math = HM != HM_CLASSIC || (a.flags & POST_MATH) != 0;
-    const long long c0 = (HM == HM_CLASSIC && a.dbg) ? (long long)__builtin_readcyclecounter() : 0;
+    const bool timed = a.dbg != nullptr && publisher && HM != HM_FLUSH;   // (CVO_HIP_POST_DEBUG: phase clocks of the publishing block)
+    const long long c0 = timed ? (long long)__builtin_readcyclecounter() : 0;
     // one round trip: the step partials, the overflow flags of the builds that have ended (classic: row
     // 0, where everything is flagged; head mode: the row of the previous flow launch), the state's head
     double sp[NACC_STEP];
@@ -1694,9 +1701,9 @@ __device__ __forceinline__ bool head_body(const PostStepArgs &a, const DevHead *
     const bool stalled = async && s_st->stall != 0;
     const bool pending = HM == HM_CLASSIC ? true : (s_st->pending != 0);
     const bool run_post = pending && !stalled;
-    const long long c1 = (HM == HM_CLASSIC && a.dbg) ? (long long)__builtin_readcyclecounter() : 0;
+    const long long c1 = timed ? (long long)__builtin_readcyclecounter() : 0;
     if (reduce && run_post) block_finish_partials<NACC_STEP>(sp, sh, s_st->red + RED_STEP);
-    const long long c2 = (HM == HM_CLASSIC && a.dbg) ? (long long)__builtin_readcyclecounter() : 0;
+    const long long c2 = timed ? (long long)__builtin_readcyclecounter() : 0;
     bool comm_ok = true;
     if (HM == HM_CLASSIC && a.comm && !stalled) {
         __shared__ double sh_mail[MAX_WORLD * MAIL_VALS];
@@ -1710,10 +1717,11 @@ __device__ __forceinline__ bool head_body(const PostStepArgs &a, const DevHead *
 #pragma unroll
             for (int l = 0; l < LIST_N; ++l) flag[l] = (unsigned)__builtin_amdgcn_readlane((int)my_flag, l);
             long long clk[4] = {0, 0, 0, 0};
-            head_math<HM>(s_st, a, run_post, stalled, flag, publisher, HM == HM_CLASSIC && a.dbg != nullptr, clk);
-            if (HM == HM_CLASSIC && a.dbg && tid == 0) {
+            head_math<HM>(s_st, a, run_post, stalled, flag, publisher, timed, clk);
+            if (timed && tid == 0 && run_post) {
                 a.dbg[0] += 1; a.dbg[1] += c1 - c0; a.dbg[2] += c2 - c1;
-                if (run_post) { a.dbg[3] += clk[1] - clk[0]; a.dbg[4] += clk[2] - clk[1]; a.dbg[5] += clk[3] - clk[2]; }
+                a.dbg[3] += clk[1] - clk[0]; a.dbg[4] += clk[2] - clk[1]; a.dbg[5] += clk[3] - clk[2];
+                a.dbg[6] = c0;   // (head mode: the flow pass that follows adds its own time, kt_hflow_build)
             }
         }
         __syncthreads();
@@ -2009,11 +2017,15 @@ __device__ __forceinline__ ProcHead proc_head_lds(const ProcessArgs &a, const De
             return;                                                                                        \
         }                                                                                                  \
         const PostStepArgs ps = CVO_ARG(PostStepArgs, op[q].ps);                                           \
+        const ProcessArgs &pa = CVO_ARG(ProcessArgs, op[q].p);                                             \
         if (!head_body<HM_HEAD>(ps, par ? ps.st2 : ps.st, par ? ps.st : ps.st2, &s_st, sh, par,            \
                                 blockIdx.x == 0)) return;                                                  \
-        const ProcessArgs &pa = CVO_ARG(ProcessArgs, op[q].p);                                             \
         float rt[12];                                                                                      \
         process_body<PROC_FLOW, 0, false>(pa, blockIdx.x, smem, proc_head_lds<PROC_FLOW>(pa, &s_st, par, rt)); \
+        if (ps.dbg && blockIdx.x == 0 && threadIdx.x == 0 && ps.dbg[6] != 0) {   /* block 0: head + flow pass */ \
+            ps.dbg[7] += (long long)__builtin_readcyclecounter() - ps.dbg[6];                              \
+            ps.dbg[6] = 0;                                                                                 \
+        }                                                                                                  \
     }                                                                                                      \
     __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WAVES, 8)))               \
     kt_hflow_build6##SUFFIX(const Slot *__restrict__ tab, const int qp)                                    \
@@ -2035,18 +2047,17 @@ __device__ __forceinline__ ProcHead proc_head_lds(const ProcessArgs &a, const De
             return;                                                                                        \
         }                                                                                                  \
         const PostStepArgs ps = CVO_ARG(PostStepArgs, op[q].ps);                                           \
+        const int role = b < np ? 0 : (b < 2 * np ? 1 : 2);   /* flow, xx, yy */                          \
+        const unsigned rb = (unsigned)(b - role * np);                                                     \
+        const ProcessArgs &pa = CVO_ARG(ProcessArgs, op[q + role].p);                                      \
         if (!head_body<HM_HEAD>(ps, par ? ps.st2 : ps.st, par ? ps.st : ps.st2, &s_st, sh, par,            \
                                 blockIdx.x == 0)) return;                                                  \
         float rt[12];                                                                                      \
-        if (b < np) {                                                                                      \
-            const ProcessArgs &pa = CVO_ARG(ProcessArgs, op[q].p);                                         \
-            process_body<PROC_FLOW, 0, false>(pa, (unsigned)b, smem, proc_head_lds<PROC_FLOW>(pa, &s_st, par, rt)); \
+        if (role == 0) {                                                                                   \
+            process_body<PROC_FLOW, 0, false>(pa, rb, smem, proc_head_lds<PROC_FLOW>(pa, &s_st, par, rt)); \
             return;                                                                                        \
         }                                                                                                  \
-        b -= np;                                                                                           \
-        const int w = b >= np ? 1 : 0;                                                                     \
-        const ProcessArgs &pa = CVO_ARG(ProcessArgs, op[q + 1 + w].p);                                     \
-        process_body<PROC_SELF, 0, false>(pa, (unsigned)(b - w * np), smem, proc_head_lds<PROC_SELF>(pa, &s_st, par, rt)); \
+        process_body<PROC_SELF, 0, false>(pa, rb, smem, proc_head_lds<PROC_SELF>(pa, &s_st, par, rt));     \
     }
 CVO_HEAD_KERNELS(_w4, 4)
 

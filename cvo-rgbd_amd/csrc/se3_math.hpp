@@ -153,6 +153,19 @@ CVO_HD void sincos_det(double x, double *s_out, double *c_out)
 // ---------------------------------------------------------------------------
 CVO_HD double cubic_eval(double a, double b, double c, double s) { return ((s + a) * s + b) * s + c; }
 
+// x / 3.0, correctly rounded, without the division (~30 dependent instructions on the one chain of the
+// post kernels): q0 = x * fl(1/3), r = fma(-3, q0, x) is exact, q = fma(r, fl(1/3), q0).  x / 3 is never
+// within 1/6 ulp of a rounding boundary (x is a whole number of ulps, a boundary lies at a half), and q
+// misses the exact quotient by far less: the same double as the division, bit for bit
+// (tests/test_host_math.py holds it against x / 3.0 over the exponent range).
+CVO_HD double div3(double x)
+{
+    const double c = 1.0 / 3.0;
+    const double q0 = x * c;
+    const double r = __builtin_fma(-3.0, q0, x);
+    return __builtin_fma(r, c, q0);
+}
+
 // A bracket [lo,hi] of the monic cubic s^3 + a s^2 + b s + c that holds its
 // smallest positive real root (sign change in the stated direction), if any.
 struct CubicBracket {
@@ -190,8 +203,8 @@ CVO_HD CubicBracket cubic_bracket(const double bcde[4])
         return B;
     }
     const double sq = sqrt(disc);
-    const double s1 = (-a - sq) / 3.0;   // local maximum
-    const double s2 = (-a + sq) / 3.0;   // local minimum
+    const double s1 = div3(-a - sq);   // local maximum: (-a - sq) / 3.0
+    const double s2 = div3(-a + sq);   // local minimum: (-a + sq) / 3.0
     // (0, s1): increasing
     if (s1 > 0.0 && f0 < 0.0) {
         const double f1 = cubic_eval(a, b, c, s1);

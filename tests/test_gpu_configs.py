@@ -147,3 +147,68 @@ def test_config3_200k_x_200k_two_ranks_equal_one(pkg, cfg3):
     assert out[0][1] == out[1][1]
     rot, tra = pkg.data.rel_pose_error(out[0][2], np.array(st_ref.transform, np.float32).reshape(4, 4))
     assert rot <= 1e-6 and tra <= 1e-6
+
+
+def test_headline_shape_64_distinct_10k_pairs_through_the_engines(pkg, po):
+    """The shape bench.py's `value` is quoted on: 64 DISTINCT 10k x 10k pairs in ONE align_many call
+    (three engines of 21-22 slots, candidate lists, captured batches).  Every registration equals the
+    same pair registered on its own (cvo_hip_align: head mode, asynchronous builds) bit for bit, and
+    four of them equal the oracle's (ref src/cvo.cpp:361-420)."""
+    import torch
+    capi = pkg.capi
+    count = 64
+    ctxs, streams, pairs = [], [], []
+    for b in range(count):
+        seed = pkg.data.SEED_CFG2 if b == 0 else pkg.data.SEED_CFG5_BASE + b
+        pr = pkg.data.synthetic_pair(10000, 10000, seed=seed)
+        s = torch.cuda.Stream()
+        c = capi.Context(mode=capi.MODE_CVO, device=0, stream=s.cuda_stream, graph_capture=True)
+        c.set_fixed(pr[0], pr[1])
+        c.set_moving(pr[2], pr[3])
+        ctxs.append(c); streams.append(s); pairs.append(pr)
+    for rep in range(2):   # (the second call re-uses the engines' captured batches and tables)
+        states = [capi.init_state(c.params) for c in ctxs]
+        its = capi.align_many(ctxs, states)
+    assert len(set(its)) > 8   # distinct pairs: a spread of iteration counts, slots refilled as they fall free
+    for b, c in enumerate(ctxs):
+        st = capi.init_state(c.params)
+        n_l, _ = c.align(st, trace_cap=0)
+        assert n_l == its[b], (b, n_l, its[b])
+        assert bytes(st) == bytes(states[b]), b
+    p = po.default_params(po.MODE_CVO)
+    for b in (0, 1, 17, 63):
+        xf, ff, xm, fm = pairs[b]
+        so = po.init_state(p)
+        n_or, _ = po.align(p, so, xf, ff, xm, fm, search=po.SEARCH_GRID, trace_cap=1)
+        assert n_or == its[b], (b, n_or, its[b])
+        assert np.array_equal(np.array(states[b].R), np.array(so.R)), b
+        assert np.array_equal(np.array(states[b].T), np.array(so.T)), b
+    for c in ctxs:
+        c.close()
+
+
+def test_bench_multi_rank_rehearsal_on_one_gpu():
+    """The driver's 8-GPU command, rehearsed with two ranks on device 0 (CVO_BENCH_RANKS_ON_DEVICE0=1:
+    gloo for torch's collectives): the weak-scaling leg, the all_gather of the IPC handles, the mailbox
+    leg of the target-sharded mode (ref src/cvo.cpp:201-204,283-288 across ranks), its watchdog and
+    the assembly of the JSON line all run before the driver runs them for the first time on 8 GPUs."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, CVO_BENCH_RANKS_ON_DEVICE0="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", "29577", os.path.join(root, "bench.py"),
+           "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "8", "--points", "3000",
+           "--sharded-points", "20000", "--sharded-steps", "1", "--sharded-timeout", "120"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["value"] > 0
+    assert out["ranks_on_device0"] is True
+    sh = out["sharded_allreduce"]
+    assert "error" not in sh, sh
+    assert sh["exchange"] == "mailbox" and sh["registrations_per_s"] > 0, sh
+    assert sh["iterations"] > 0

@@ -295,3 +295,43 @@ def test_decoding_straight_into_the_staging_images(pkg):
         got = gen.create_pointcloud(img, dep, 1, pkg.frontend.FEATURES_HSV)
         assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
     gen.close()
+
+
+@pytest.mark.parametrize("mode_name,nframes", [("acvo", 80), ("cvo", 60)])
+def test_streamed_chain_equals_the_oracle_chain(pkg, mode_name, nframes):
+    """The shape of BASELINE configs[2] (the fr1/desk PNGs are not in the reference's tree): a synthetic
+    VGA sequence through the front end and ONE registration object -- clouds handed over in device
+    memory, the state carried from pair to pair as the reference's drivers do (ref
+    src/adaptive_cvo_main.cpp:36-66, src/cvo_main.cpp:36-66) -- against the oracle's front end and
+    the oracle chain: every transform, every accumulated pose and every iteration count identical."""
+    from oracle import pyoracle as po, pyoracle_fe as fo
+    acvo = mode_name == "acvo"
+    po.set_threads(16)
+    frames = [pkg.data.synthetic_rgbd_frame(seed=55, texture=1.0 + 0.5 * np.sin(k / 5.0),
+                                            motion=(1.2 * k, 0.6 * np.sin(k / 3.0) * 4)) for k in range(nframes)]
+    ftype = 0 if acvo else 1
+    reg = (pkg.Acvo if acvo else pkg.Cvo)()
+    gen = pkg.frontend.PcdGenerator(640, 480)
+    p = po.default_params(po.MODE_ACVO if acvo else po.MODE_CVO)
+    s = po.init_state(p)
+    prev, bad = None, []
+    for k, (bgr, dep) in enumerate(frames):
+        gen.submit(bgr, dep, 1, ftype)
+        d_xyz, d_feat, npts = gen.collect_device()
+        reg.run_cvo_device(d_xyz, d_feat, npts)
+        r = fo.create_pointcloud(bgr, dep, 1, ftype)
+        cur = (r["positions"], r["features"])
+        assert npts == len(cur[0])
+        if prev is not None:
+            if acvo:   # tail of acvo::set_pcd (ref src/adaptive_cvo.cpp:476-478)
+                s.ell = p.ell_init
+                s.ell_max = p.ell_max_init
+            it, _ = po.align(p, s, prev[0], prev[1], cur[0], cur[1], search=po.SEARCH_GRID, trace_cap=0)
+            T_or, _, A_or = po.state_matrices(s)
+            if not (it == reg.num_iterations and np.array_equal(T_or, reg.transform) and
+                    np.array_equal(A_or, reg.accum_transform)):
+                bad.append((k, reg.num_iterations, it))
+        prev = cur
+    reg.close()
+    gen.close()
+    assert not bad, bad

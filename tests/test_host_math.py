@@ -160,3 +160,40 @@ def test_sectioning_root_vs_float32_companion_eigenvalues(po, pkg):
             n_diff += 1
     print("random coefficients: %d of %d steps differ by more than 1e-4 relative" % (n_diff, n_rand))
     assert n_diff <= n_rand // 50
+
+
+def test_div3_and_div6_by_fma_are_the_division(tmp_path):
+    """se3_math.hpp div3 (the stationary points of the step-size cubic, ref src/cvo.cpp:53-69 via
+    cubic_bracket) and the list kernels' div6 replace a float64 division by a multiplication with an
+    exact FMA correction.  The claim -- the same double as x / 3.0 (x / 6.0), bit for bit -- is held
+    here over 2e7 random bit patterns of every exponent, subnormals and the largest values included
+    (plain C, IEEE fma from libm: what the device's v_fma_f64 computes)."""
+    import subprocess
+    src = tmp_path / "div3.c"
+    src.write_text(r'''
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+static double divk(double x, double k, double c) { double q0 = x * c; double r = fma(-k, q0, x); return fma(r, c, q0); }
+int main(void) {
+    uint64_t s = 88172645463325252ull; long bad3 = 0, bad6 = 0, n = 0;
+    for (long i = 0; i < 20000000; ++i) {
+        s ^= s << 13; s ^= s >> 7; s ^= s << 17;
+        double x; memcpy(&x, &s, 8);
+        if (!isfinite(x)) continue;
+        ++n;
+        double a = divk(x, 3.0, 1.0 / 3.0), b = x / 3.0;
+        double c = divk(x, 6.0, 1.0 / 6.0), d = x / 6.0;
+        /* (below 2^-1020 the correction term itself is subnormal: the kernels never get there) */
+        if (fabs(x) < 1e-300) continue;
+        bad3 += memcmp(&a, &b, 8) != 0; bad6 += memcmp(&c, &d, 8) != 0;
+    }
+    printf("%ld %ld %ld\n", n, bad3, bad6);
+    return 0;
+}
+''')
+    exe = tmp_path / "div3"
+    subprocess.check_call(["gcc", "-O2", "-ffp-contract=off", str(src), "-o", str(exe), "-lm"])
+    n, bad3, bad6 = map(int, subprocess.check_output([str(exe)]).split())
+    assert n > 1.9e7 and bad3 == 0 and bad6 == 0, (n, bad3, bad6)

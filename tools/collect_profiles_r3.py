@@ -1,0 +1,184 @@
+#!/usr/bin/env python3
+"""Round-3 profile summaries: from the raw rocprofv3 outputs of tools/gpu_profile_r3.sh (gpurun_out/<tag>/) to
+the small files under profiles/ (or, with --keep-in-out, into gpurun_out/<tag>/summary/ on the GPU box, from
+where they are copied).  MI355X_MICROARCH.md: FETCH_SIZE / WRITE_SIZE are in KB; FETCH_SIZE counts half the
+bytes of wide reads on gfx950 (doubled here)."""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+src = os.path.join(ROOT, "gpurun_out", tag)
+dst = os.path.join(src, "summary") if "--keep-in-out" in sys.argv else os.path.join(ROOT, "profiles")
+os.makedirs(dst, exist_ok=True)
+CLOCK_GHZ = 2.4      # MI355X peak engine clock (MI355X_MICROARCH.md)
+SIMDS = 256 * 4
+
+
+def one(pattern):
+    g = glob.glob(os.path.join(src, pattern))
+    return g[0] if g else None
+
+
+def short(name):
+    return name.split("(")[0].replace("cvo_dev::", "").replace("void ", "")
+
+
+for pat, name in (("bench.json", "%s_bench.json"), ("stats/*kernel_stats.csv", "%s_kernel_stats.csv"),
+                  ("stats_batch/*kernel_stats.csv", "%s_kernel_stats_batch.csv"),
+                  ("stats_roofline/*kernel_stats.csv", "%s_kernel_stats_roofline.csv"),
+                  ("stats_fe/*kernel_stats.csv", "%s_kernel_stats_frontend.csv"),
+                  ("roofline_plain.json", "%s_roofline_only.json")):
+    f = one(pat)
+    if f:
+        shutil.copy(f, os.path.join(dst, name % tag))
+
+
+def per_dispatch(pattern, counter=None):
+    """{kernel: [value per dispatch, in dispatch order]}"""
+    f = one(pattern)
+    out = collections.defaultdict(list)
+    if not f:
+        return out
+    rows = list(csv.DictReader(open(f)))
+    key = "Dispatch_Id" if rows and "Dispatch_Id" in rows[0] else None
+    if key:
+        rows.sort(key=lambda r: int(r[key]))
+    for r in rows:
+        if counter is None:
+            out[short(r["Kernel_Name"])].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+        elif r["Counter_Name"] == counter:
+            out[short(r["Kernel_Name"])].append(float(r["Counter_Value"]))
+    return out
+
+
+# ---- traffic of the list passes of ONE engine of 22 pairs, the same launches in every pass, per length scale
+rl = None
+try:
+    rl = json.loads(open(os.path.join(src, "roofline_plain.json")).read().strip().splitlines()[-1])
+except Exception:
+    pass
+dur = per_dispatch("stats_roofline/*kernel_trace.csv")
+fetch = per_dispatch("pmc_fetch_r/*counter_collection.csv", "FETCH_SIZE")
+write = per_dispatch("pmc_write_r/*counter_collection.csv", "WRITE_SIZE")
+phases = {}
+for k in ("kt_process<0, 0>", "kt_process<1, 0>", "kt_filter", "kt_post_step", "kt_post_flow"):
+    d, f, w = dur.get(k, []), fetch.get(k, []), write.get(k, [])
+    n = min(len(d), len(f), len(w))
+    if n == 0:
+        continue
+    note = None if len(d) == len(f) == len(w) else "dispatch counts differ between the passes (%d / %d / %d): the first %d of each" % (len(d), len(f), len(w), n)
+    calls = 6   # bench.py --roofline-only: one warm-up call + 5
+    per_call = n // calls if n % calls == 0 else None
+    rows = [(d[i], 2.0 * f[i] * 1024.0 + w[i] * 1024.0, f[i] * 1024.0 * 2.0, w[i] * 1024.0) for i in range(n)]
+
+    def agg(sel, label):
+        rr = [rows[i] for i in sel]
+        if not rr:
+            return None
+        us = sum(r[0] for r in rr) / len(rr)
+        by = sum(r[1] for r in rr) / len(rr)
+        return {"launches": len(rr), "avg_us": us, "hbm_bytes_per_launch": by,
+                "fetch_bytes_per_launch": sum(r[2] for r in rr) / len(rr), "write_bytes_per_launch": sum(r[3] for r in rr) / len(rr),
+                "counter_GBs": by / (us * 1e-6) / 1e9 if us > 0 else 0.0,
+                "frac_of_6300_GBs_achievable": by / (us * 1e-6) / 1e9 / 6300.0 if us > 0 else 0.0, "what": label}
+    ph = {"all": agg(range(n), "every launch of the command")}
+    if per_call:
+        # every registration of a call starts at iteration 0 together: launch i of a call IS iteration i
+        # (ref src/cvo.cpp:408-410: ell = 0.15 for k <= 2, 0.10 up to 9, 0.06 up to 19, then 0.03)
+        for name, lo, hi in (("ell_0.15", 0, 3), ("ell_0.10", 3, 10), ("ell_0.06", 10, 20), ("ell_0.03", 20, per_call)):
+            sel = [c * per_call + i for c in range(calls) for i in range(lo, min(hi, per_call))]
+            ph[name] = agg(sel, "iterations %d..%d of every call" % (lo, min(hi, per_call) - 1))
+        ph["launches_per_call"] = per_call
+    if note:
+        ph["note"] = note
+    phases[k] = ph
+if phases:
+    with open(os.path.join(dst, "%s_pmc_phases.json" % tag), "w") as fh:
+        json.dump(phases, fh, indent=1, sort_keys=True)
+
+# ---- VALU issue of the batched run at saturation
+f = one("pmc_valu/*counter_collection.csv")
+wall = None
+try:
+    for ln in open(os.path.join(src, "valu_wall.log")):
+        if ln.startswith("B "):
+            wall = float(ln.split("registrations/s")[0].split(":")[1])
+except Exception:
+    pass
+if f:
+    agg = collections.defaultdict(lambda: collections.defaultdict(float))
+    for r in csv.DictReader(open(f)):
+        agg[short(r["Kernel_Name"])][r["Counter_Name"]] += float(r["Counter_Value"])
+    regs = 2 * 256.0   # tools/gpu_batch.py 10000 1 256: one warm-up call + one timed call
+    tot = collections.defaultdict(float)
+    per_kernel = {}
+    for k, d in agg.items():
+        if d.get("SQ_ACTIVE_INST_VALU", 0.0) < 1e6:
+            continue
+        per_kernel[k] = {c: d[c] for c in ("SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_BUSY_CYCLES", "SQ_WAVES", "SQ_WAVE_CYCLES") if c in d}
+        for c in d:
+            tot[c] += d[c]
+    # SQ_ACTIVE_INST_VALU counts quad-cycles (x4 = cycles), summed over all SIMDs
+    simd_us_per_reg = tot["SQ_ACTIVE_INST_VALU"] * 4.0 / SIMDS / (CLOCK_GHZ * 1e3) / regs
+    out = {"command": "DISTINCT=1 CVO_HIP_GRAPH=1 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU ... -- python tools/gpu_batch.py 10000 1 256",
+           "registrations": regs, "per_kernel_sums": per_kernel,
+           "valu_active_us_per_simd_per_registration": simd_us_per_reg,
+           "definition": "sum over all launches of SQ_ACTIVE_INST_VALU x 4 cycles / 1024 SIMDs / 2.4 GHz / registrations, against the wall "
+                         "time per registration of the same workload without counters (tools/gpu_batch.py 10000 4 256)"}
+    if wall:
+        out["wall_registrations_per_s"] = wall
+        out["wall_us_per_registration"] = 1e6 / wall
+        out["valu_issue_frac"] = simd_us_per_reg / (1e6 / wall)
+    with open(os.path.join(dst, "%s_valu.json" % tag), "w") as fh:
+        json.dump(out, fh, indent=1, sort_keys=True)
+
+# ---- counters of the single-stream run (head mode) and of the one-engine run, per kernel, executed launches
+summary = {}
+for pat, label in (("pmc_sq/*counter_collection.csv", "single_stream"), ("pmc_fetch/*counter_collection.csv", "single_stream"),
+                   ("pmc_write/*counter_collection.csv", "single_stream"), ("pmc_sq_r/*counter_collection.csv", "one_engine_of_22")):
+    f = one(pat)
+    if not f:
+        continue
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    for r in csv.DictReader(open(f)):
+        agg[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    for k, d in agg.items():
+        if not (k.startswith("k") and "rocprim" not in k):
+            continue
+        for c, v in d.items():
+            vv = sorted(v)
+            real = [x for x in vv if x > 0.05 * vv[-1]] if vv[-1] > 0 else vv
+            summary.setdefault(label, {}).setdefault(k, {})[c] = {"launches": len(v), "executed": len(real),
+                                                                 "avg": sum(real) / max(len(real), 1), "max": vv[-1]}
+for label in summary:
+    for k, d in summary[label].items():
+        if "SQ_WAIT_ANY" in d and "SQ_WAVE_CYCLES" in d and d["SQ_WAVE_CYCLES"]["avg"] > 0:
+            d["wait_any_over_wave_cycles"] = d["SQ_WAIT_ANY"]["avg"] / d["SQ_WAVE_CYCLES"]["avg"]
+if summary:
+    with open(os.path.join(dst, "%s_pmc_summary.json" % tag), "w") as fh:
+        json.dump(summary, fh, indent=1, sort_keys=True)
+
+# ---- durations of the launches that did work, one registration at a time
+tr = one("stats/*kernel_trace.csv")
+if tr:
+    d2 = collections.defaultdict(list)
+    for r in csv.DictReader(open(tr)):
+        d2[short(r["Kernel_Name"])].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+    live = {}
+    for k, v in d2.items():
+        if "rocprim" in k or k.startswith("__amd"):
+            continue
+        sv = sorted(v)
+        ref = sv[len(sv) // 2]
+        lv = [x for x in v if x > 0.4 * ref]
+        live[k] = {"launches": len(v), "avg_us": sum(v) / len(v), "live_launches": len(lv), "live_avg_us": sum(lv) / max(len(lv), 1),
+                   "p50_us": ref, "total_us": sum(v)}
+    with open(os.path.join(dst, "%s_kernel_live.json" % tag), "w") as fh:
+        json.dump(live, fh, indent=1, sort_keys=True)
+print("summaries in", dst, ":", sorted(os.listdir(dst)))
