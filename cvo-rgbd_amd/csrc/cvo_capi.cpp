@@ -231,6 +231,7 @@ struct cvo_hip_ctx {
     bool allow_async = true;
     bool crowded = false;                // set by align_many: many registrations share the launches
     DevBuf cand[3], cand_cnt[3];         // the candidate lists of the xy / xx / yy tile lists (ProcessArgs::cand, cand_cnt)
+    DevBuf cand_ck[3];                   // ... their colour weights where the record is 12 bytes wide (ProcessArgs::cand_ck)
     int ck_nblk[3] = {0, 0, 0};          // recorded plan: the pass over list l keeps a candidate list with this many blocks (0: no)
     DevBuf pos_bt;                       // crowded: the moving cloud under the iteration's transform (FilterArgs::pos_bt)
     bool lone = true;                    // this registration has its launches to itself
@@ -691,13 +692,21 @@ int enqueue_process(cvo_hip_ctx *ctx, int mode, int list, DevBuf &part, const fl
         const bool no_cand = getenv("CVO_HIP_NO_CAND") != nullptr;   // (read when a plan is recorded: tests switch it)
         const bool no_self = getenv("CVO_HIP_NO_CAND_SELF") != nullptr;
         ctx->ck_nblk[list] = 0;
+        // (clouds of more than 65536 rows would need 12-byte records: built, bit-identical, and measured SLOWER --
+        // one 200k x 200k registration 81.3 -> 91.0 ms, 100k x 100k 21.7 -> 23.8, acvo 18.9 -> 21.8: at those sizes the
+        // list passes are bound by memory requests, and the record is 12 more bytes per candidate to stream;
+        // profiles/r03_ab.txt.  Opt-in: CVO_HIP_CAND_WIDE)
+        const bool no_wide = getenv("CVO_HIP_CAND_WIDE") == nullptr;
         if (!no_cand && !(mode == PROC_SELF && no_self) && pre_transform(ctx) && !(ctx->prm.color_scale > 0.0f) &&
-            a.kept_packed) {   // (the same plans: synchronous lists)
+            (a.kept_packed || !no_wide)) {   // (the same plans: synchronous lists)
             // (an optimisation: if its memory cannot be had, the pass expands the tile list every time)
             int rc_c = ensure_buf(ctx, ctx->cand[list], (size_t)ctx->lists[LIST_KEPT].cap * sizeof(uint2));
             if (!rc_c) rc_c = ensure_buf(ctx, ctx->cand_cnt[list], PROC_WAVES * sizeof(uint32_t));
+            // (clouds of more than 65536 rows: i and j do not share a word, the weight gets an array of its own)
+            if (!rc_c && !a.kept_packed) rc_c = ensure_buf(ctx, ctx->cand_ck[list], (size_t)ctx->lists[LIST_KEPT].cap * sizeof(float));
             if (!rc_c) {
                 a.cand = (uint2 *)ctx->cand[list].p;
+                a.cand_ck = a.kept_packed ? nullptr : (float *)ctx->cand_ck[list].p;
                 a.cand_cnt = (uint32_t *)ctx->cand_cnt[list].p;
                 ctx->ck_nblk[list] = a.nblk;
             } else {
@@ -1612,7 +1621,7 @@ int cvo_hip_destroy(cvo_hip_ctx *ctx)
                     (void *)ctx->moving.feat, (void *)ctx->fixed.seg, (void *)ctx->moving.seg,
                     (void *)ctx->scratch_a.pos, (void *)ctx->scratch_a.feat, (void *)ctx->scratch_a.seg,
                     (void *)ctx->scratch_b.pos, (void *)ctx->scratch_b.feat, (void *)ctx->scratch_b.seg, (void *)ctx->st, (void *)ctx->st2, ctx->part_flow.p, ctx->part_xx.p,
-                    ctx->part_yy.p, ctx->part_step.p, (void *)ctx->trace_dev, ctx->kept_cnt.p, ctx->pos_bt.p, ctx->cand[0].p, ctx->cand[1].p, ctx->cand[2].p, ctx->cand_cnt[0].p,
+                    ctx->part_yy.p, ctx->part_step.p, (void *)ctx->trace_dev, ctx->kept_cnt.p, ctx->pos_bt.p, ctx->cand[0].p, ctx->cand[1].p, ctx->cand[2].p, ctx->cand_ck[0].p, ctx->cand_ck[1].p, ctx->cand_ck[2].p, ctx->cand_cnt[0].p,
                     ctx->cand_cnt[1].p, ctx->cand_cnt[2].p})
         if (p) (void)hipFree(p);
     for (int l = 0; l < LIST_N; ++l) {

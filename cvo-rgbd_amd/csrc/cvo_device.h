@@ -285,6 +285,8 @@ struct ProcessArgs {
                            // passes over the same tile list (st->ck_nblk[list] == nblk) stream the record instead: nothing to
                            // expand, no feature gathers, no colour exp.  PROC_SELF (acvo's xx / yy lists) likewise,
                            // the sign of the recorded weight = the row counts (Ayy rule).  Null: no candidate list.
+    float *cand_ck;        // clouds of more than 65536 rows: the record is 12 bytes wide -- cand[] = (i, j), cand_ck[] = the
+                           // colour weight -- else null: 8 bytes, cand[] = (i | j << 16, the weight's bits)
     uint32_t *cand_cnt;    // [PROC_WAVES] candidates recorded by each wave
     int need_d2;           // PROC_FLOW: accumulate sum (1/l^3 a) d2 (acvo's dl term; cvo_hip_flow reports it for both modes)
     int kept_packed;       // both clouds have <= 65536 rows: a kept entry is 8 bytes (i | j << 16, weight bits)

@@ -837,7 +837,10 @@ __device__ __forceinline__ bool expand_lists(const ProcessArgs &a, const ProcHea
             }
             if (REC) {   // every candidate goes on record, at the place the wave met it (its colour weight with it)
                 if (co + (unsigned)cnt <= a.kept_wcap) {
-                    if (lane < cnt) a.cand[kbase + co + lane] = make_uint2(pr.x | (pr.y << 16), __float_as_uint(ck));
+                    if (lane < cnt) {
+                        if (a.cand_ck) { a.cand[kbase + co + lane] = pr; a.cand_ck[kbase + co + lane] = ck; }
+                        else a.cand[kbase + co + lane] = make_uint2(pr.x | (pr.y << 16), __float_as_uint(ck));
+                    }
                 } else if (lane == 0) {
                     atomicOr(&a.st->ovf[hd.par][LIST_KEPT], 1u);   // slice full: grow and redo
                 }
@@ -923,21 +926,33 @@ __device__ __forceinline__ bool stream_candidates(const ProcessArgs &a, const Pr
 {
     const size_t base = (size_t)wave * a.kept_wcap;
     unsigned n = a.cand_cnt[wave];
+    const bool wide = a.cand_ck != nullptr;   // (12-byte records: clouds of more than 65536 rows)
     uint2 e = a.cand[base + lane];
+    float ckv = wide ? a.cand_ck[base + lane] : 0.0f;
     if (done_word != 0) return false;
     if (n > a.kept_wcap) n = a.kept_wcap;
     unsigned nk = 0;
     for (unsigned b0 = 0; b0 < n; b0 += 64u) {
-        if (b0 != 0u) e = a.cand[base + min(b0 + (unsigned)lane, a.kept_wcap - 1u)];
+        if (b0 != 0u) {
+            const size_t at = base + min(b0 + (unsigned)lane, a.kept_wcap - 1u);
+            e = a.cand[at];
+            if (wide) ckv = a.cand_ck[at];
+        }
+        const unsigned ci = wide ? e.x : (e.x & 0xffffu), cj = wide ? e.y : (e.x >> 16);
         float w = 0.0f;
         if (b0 + (unsigned)lane < n) {
-            float ck = __uint_as_float(e.y);
-            w = eval_pair<MODE, 0, 2>(a, hd, kc, e.x & 0xffffu, e.x >> 16, 0.0f, acc, *hd.xi, s_etab, 0, &ck);
+            float ck = wide ? ckv : __uint_as_float(e.y);
+            w = eval_pair<MODE, 0, 2>(a, hd, kc, ci, cj, 0.0f, acc, *hd.xi, s_etab, 0, &ck);
         }
         const unsigned long long km = __ballot(w > 0.0f);
         if (MODE == PROC_FLOW && w > 0.0f) {   // (members <= candidates <= the slice: it cannot overflow here)
             const unsigned below = __builtin_amdgcn_mbcnt_hi((unsigned)(km >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)km, 0u));
-            a.kept_ij[base + nk + below] = make_uint2(e.x, __float_as_uint(w));
+            if (a.kept_packed) {
+                a.kept_ij[base + nk + below] = make_uint2(e.x, __float_as_uint(w));
+            } else {
+                a.kept_ij[base + nk + below] = make_uint2(ci, cj);
+                a.kept_a[base + nk + below] = w;
+            }
         }
         nk += (unsigned)__popcll(km);
     }
@@ -995,7 +1010,7 @@ __device__ __forceinline__ void process_body(const ProcessArgs &a, const unsigne
         }
     } else {
         bool alive;
-        if (CAND && WEIGHT == 0 && a.cand && a.kept_packed && !a.async_xy && !a.async_self) {
+        if (CAND && WEIGHT == 0 && a.cand && !a.async_xy && !a.async_self) {
             if (hd.ck_nblk == a.nblk) alive = stream_candidates<MODE>(a, hd, kc, lane, wave, done_word, s_etab, acc);
             else alive = expand_lists<MODE, WEIGHT, WEIGHT == 0 ? 1 : 0>(a, hd, kc, bid, wid, lane, wave, done_word, list_bad, in_list, in_tiles, first_counted, s_etab, pairq_all, acc);
         } else {

@@ -817,3 +817,42 @@ def test_transform_pass_and_candidate_list_change_nothing(pkg, monkeypatch, mode
         for c in ctxs:
             c.close()
     assert all(r == res[0] for r in res)
+
+
+@pytest.mark.parametrize("mode_name", ["cvo", "acvo"])
+def test_wide_candidate_records_for_clouds_above_65536_rows(pkg, po, mode_name, monkeypatch):
+    """Clouds of more than 65 536 rows: i and j no longer share a word, the candidate record is 12 bytes
+    wide (ProcessArgs::cand_ck) and the kept list 8 + 4 (opt-in, CVO_HIP_CAND_WIDE: measured slower at
+    these sizes, profiles/r03_ab.txt).  Streaming the record changes nothing: state and
+    trace equal the run that expands the tile list in every flow pass (CVO_HIP_NO_CAND), and the first
+    iterations equal the oracle's (ref src/cvo.cpp:99-210, src/adaptive_cvo.cpp:154-272)."""
+    import torch
+    capi = pkg.capi
+    acvo = mode_name == "acvo"
+    mode = capi.MODE_ACVO if acvo else capi.MODE_CVO
+    xf, ff, xm, fm = pkg.data.synthetic_pair(70000, 66000, seed=4711, acvo=acvo)
+    prm = capi.default_params(mode)
+    prm.max_iter = 14
+    runs = []
+    monkeypatch.setenv("CVO_HIP_CAND_WIDE", "1")
+    for off in (False, True):
+        if off:
+            monkeypatch.setenv("CVO_HIP_NO_CAND", "1")
+        else:
+            monkeypatch.delenv("CVO_HIP_NO_CAND", raising=False)
+        c = capi.Context(mode=mode, device=0, stream=torch.cuda.current_stream().cuda_stream, params=prm)
+        c.set_fixed(xf, ff)
+        c.set_moving(xm, fm)
+        st = capi.init_state(c.params)
+        it, tr = c.align(st, trace_cap=64)
+        runs.append((it, bytes(st), [(t["nnz"], t["nnz_xx"], t["nnz_yy"], t["omega"], t["v"], t["step"]) for t in tr]))
+        c.close()
+    assert runs[0] == runs[1]
+    p = po.default_params(mode)
+    p.max_iter = 14
+    so = po.init_state(p)
+    n_or, tr_or = po.align(p, so, xf, ff, xm, fm, search=po.SEARCH_GRID)
+    assert n_or == runs[0][0]
+    for a, b in zip(runs[0][2], tr_or):
+        assert a[0] == b["nnz"] and a[1] == b["nnz_xx"] and a[2] == b["nnz_yy"]
+        assert a[3] == b["omega"] and a[4] == b["v"] and a[5] == b["step"]

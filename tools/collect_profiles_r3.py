@@ -67,36 +67,54 @@ dur = per_dispatch("stats_roofline/*kernel_trace.csv")
 fetch = per_dispatch("pmc_fetch_r/*counter_collection.csv", "FETCH_SIZE")
 write = per_dispatch("pmc_write_r/*counter_collection.csv", "WRITE_SIZE")
 phases = {}
-for k in ("kt_process<0, 0>", "kt_process<1, 0>", "kt_filter", "kt_post_step", "kt_post_flow"):
-    d, f, w = dur.get(k, []), fetch.get(k, []), write.get(k, [])
-    n = min(len(d), len(f), len(w))
-    if n == 0:
-        continue
-    note = None if len(d) == len(f) == len(w) else "dispatch counts differ between the passes (%d / %d / %d): the first %d of each" % (len(d), len(f), len(w), n)
-    calls = 6   # bench.py --roofline-only: one warm-up call + 5
-    per_call = n // calls if n % calls == 0 else None
-    rows = [(d[i], 2.0 * f[i] * 1024.0 + w[i] * 1024.0, f[i] * 1024.0 * 2.0, w[i] * 1024.0) for i in range(n)]
+CALLS = 6   # bench.py --roofline-only: one warm-up call + 5
+PH = (("ell_0.15", 0, 3), ("ell_0.10", 3, 10), ("ell_0.06", 10, 20), ("ell_0.03", 20, 10 ** 9))
 
-    def agg(sel, label):
-        rr = [rows[i] for i in sel]
-        if not rr:
-            return None
-        us = sum(r[0] for r in rr) / len(rr)
-        by = sum(r[1] for r in rr) / len(rr)
-        return {"launches": len(rr), "avg_us": us, "hbm_bytes_per_launch": by,
-                "fetch_bytes_per_launch": sum(r[2] for r in rr) / len(rr), "write_bytes_per_launch": sum(r[3] for r in rr) / len(rr),
-                "counter_GBs": by / (us * 1e-6) / 1e9 if us > 0 else 0.0,
-                "frac_of_6300_GBs_achievable": by / (us * 1e-6) / 1e9 / 6300.0 if us > 0 else 0.0, "what": label}
-    ph = {"all": agg(range(n), "every launch of the command")}
-    if per_call:
-        # every registration of a call starts at iteration 0 together: launch i of a call IS iteration i
+
+def by_iteration(v):
+    """A pass's dispatches of one kernel -> {iteration: [values]}.  Every registration of a call starts at
+    iteration 0 together (one engine, all 22 inserted at once), so dispatch i of a call IS iteration i; a pass
+    may end its calls with a different number of launches that return at once (the host notices the last
+    `done` a batch earlier or later), so every pass is cut into calls by its OWN count."""
+    if not v or len(v) % CALLS:
+        return None, None
+    per = len(v) // CALLS
+    it = collections.defaultdict(list)
+    for c in range(CALLS):
+        for i in range(per):
+            it[i].append(v[c * per + i])
+    return it, per
+
+
+for k in ("kt_process<0, 0>", "kt_process<1, 0>", "kt_filter", "kt_post_step", "kt_post_flow", "kt_step_twist"):
+    d, f, w = dur.get(k, []), fetch.get(k, []), write.get(k, [])
+    if not d or not f or not w:
+        continue
+    mean = lambda x: sum(x) / max(len(x), 1)
+    us, fb, wb = mean(d), 2.0 * mean(f) * 1024.0, mean(w) * 1024.0
+    ph = {"all": {"launches_trace_fetch_write_pass": [len(d), len(f), len(w)], "avg_us": us, "fetch_bytes_per_launch": fb,
+                  "write_bytes_per_launch": wb, "hbm_bytes_per_launch": fb + wb,
+                  "what": "every launch of the command, each pass averaged over its own launches (the launches that return at "
+                          "once -- queued past the last convergence -- are in all three averages)"}}
+    di, dper = by_iteration(d)
+    fi, fper = by_iteration(f)
+    wi, wper = by_iteration(w)
+    if di and fi and wi:
         # (ref src/cvo.cpp:408-410: ell = 0.15 for k <= 2, 0.10 up to 9, 0.06 up to 19, then 0.03)
-        for name, lo, hi in (("ell_0.15", 0, 3), ("ell_0.10", 3, 10), ("ell_0.06", 10, 20), ("ell_0.03", 20, per_call)):
-            sel = [c * per_call + i for c in range(calls) for i in range(lo, min(hi, per_call))]
-            ph[name] = agg(sel, "iterations %d..%d of every call" % (lo, min(hi, per_call) - 1))
-        ph["launches_per_call"] = per_call
-    if note:
-        ph["note"] = note
+        live = min(dper, fper, wper)
+        for name, lo, hi in PH:
+            its = [i for i in range(lo, min(hi, live))]
+            if not its:
+                continue
+            us_p = mean([x for i in its for x in di[i]])
+            fb_p = 2.0 * mean([x for i in its for x in fi[i]]) * 1024.0
+            wb_p = mean([x for i in its for x in wi[i]]) * 1024.0
+            gbs = (fb_p + wb_p) / (us_p * 1e-6) / 1e9 if us_p > 0 else 0.0
+            ph[name] = {"iterations": [its[0], its[-1]], "launches": len(its) * CALLS, "avg_us": us_p,
+                        "fetch_bytes_per_launch": fb_p, "write_bytes_per_launch": wb_p, "hbm_bytes_per_launch": fb_p + wb_p,
+                        "counter_GBs": gbs, "frac_of_6300_GBs_achievable": gbs / 6300.0,
+                        "what": "the SAME launches in the three passes: iterations %d..%d of each of the %d calls" % (its[0], its[-1], CALLS)}
+        ph["launches_per_call_trace_fetch_write_pass"] = [dper, fper, wper]
     phases[k] = ph
 if phases:
     with open(os.path.join(dst, "%s_pmc_phases.json" % tag), "w") as fh:

@@ -15,7 +15,7 @@ for r in range(rounds):
             if "=" in kv:
                 k, x = kv.split("=", 1); env[k] = x
         for l in loads:
-            out = subprocess.run([sys.executable, os.path.join(root, "tools", "gpu_batch.py")] + l.split(), env=env, capture_output=True, text=True).stdout
+            env.setdefault("DISTINCT", "1"); out = subprocess.run([sys.executable, os.path.join(root, "tools", "gpu_batch.py")] + l.split(), env=env, capture_output=True, text=True).stdout
             for m in re.finditer(r"B +(\d+): ([0-9.]+) registrations/s", out):
                 res.setdefault((v, l, m.group(1)), []).append(float(m.group(2)))
 for (v, l, b), xs in res.items():
