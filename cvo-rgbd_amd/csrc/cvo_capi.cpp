@@ -48,6 +48,14 @@ struct Cloud {
     int pad_axis = 0;        // where the padding rows are parked (the two clouds of a pair differ)
     int cap = 0;
     float lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};   // bounding box
+    // A hand-over from host arrays does not wait for the device (round 3): the cloud's own pinned staging and
+    // bounding-box words, an event behind the preparation; whoever needs the box or another stream's view of
+    // the arrays waits then (cloud_ready: at the next compute entry point, or when the staging is needed again)
+    void *stage = nullptr;
+    size_t stage_bytes = 0;
+    float *bbox_pin = nullptr;        // [6] pinned
+    hipEvent_t ready_ev = nullptr;
+    bool pending = false;
 };
 
 struct EventPair {
@@ -217,8 +225,6 @@ struct cvo_hip_ctx {
     int proc_blocks = PROC_BLOCKS;       // blocks of the list kernels (fewer in fused launches)
     int proc_blocks_default = PROC_BLOCKS;
     bool proc_blocks_forced = false;     // CVO_HIP_PROC_BLOCKS
-    void *upload_stage = nullptr;        // pinned staging of upload_cloud (pos | feat | seg)
-    size_t upload_stage_bytes = 0;
     DevBuf raw_xyz, raw_feat;            // upload_cloud: the caller's arrays as they came
     DevBuf sort_keys[2], sort_idx[2], sort_tmp;   // ... scratch of the device-side Morton sort
     float *bbox_dev = nullptr;           // [6] device, bounding box of a cloud handed over in device memory
@@ -364,6 +370,16 @@ DevParams make_dev_params(const cvo_hip_params &p)
 
 int ensure_buf(cvo_hip_ctx *ctx, DevBuf &b, size_t bytes);
 
+// the hand-over of `c` has completed on the device; its bounding box is on the host
+int cloud_ready(cvo_hip_ctx *ctx, Cloud &c)
+{
+    if (!c.pending) return CVO_HIP_OK;
+    c.pending = false;
+    HIP_TRY(ctx, hipEventSynchronize(c.ready_ev));
+    for (int a = 0; a < 3; ++a) { c.lo[a] = c.bbox_pin[a]; c.hi[a] = c.bbox_pin[3 + a]; }
+    return CVO_HIP_OK;
+}
+
 // The cloud into the kernels' layout (cvo_cloud.hip): Morton order -- consecutive device
 // points are spatial neighbours, so a wave's 64 rows and a 16-column MFMA tile are compact
 // patches and most (wave, tile) steps see no candidate -- packed rows, bounding spheres
@@ -373,6 +389,10 @@ int upload_cloud(cvo_hip_ctx *ctx, Cloud &c, const float *xyz, const float *feat
 {
     const int np = cloud_padded(n);
     const Cloud &other = (&c == &ctx->fixed) ? ctx->moving : ctx->fixed;
+    {   // (a hand-over of this cloud that is still on its way uses the staging and the arrays)
+        const int rcw = cloud_ready(ctx, c);
+        if (rcw) return rcw;
+    }
     if (n < 0 || (n > 0 && (!xyz || !feat))) return fail(ctx, CVO_HIP_ERR_INVALID, "null cloud");
     if (n > (1 << 26))   // (the list kernels address a cloud through 32-bit byte offsets: 32 B per point)
         return fail(ctx, CVO_HIP_ERR_INVALID, "cloud too large: at most 2^26 points");
@@ -398,22 +418,30 @@ int upload_cloud(cvo_hip_ctx *ctx, Cloud &c, const float *xyz, const float *feat
         HIP_TRY(ctx, hipHostMalloc((void **)&ctx->bbox_host, 6 * sizeof(float), hipHostMallocDefault));
         HIP_TRY(ctx, hipMalloc((void **)&ctx->bbox_dev, 6 * sizeof(float)));
     }
+    if (!c.bbox_pin) {
+        HIP_TRY(ctx, hipHostMalloc((void **)&c.bbox_pin, 6 * sizeof(float), hipHostMallocDefault));
+        HIP_TRY(ctx, hipEventCreateWithFlags(&c.ready_ev, hipEventDisableTiming));
+    }
     const float *d_xyz = xyz, *d_feat = feat;
     if (!on_device) {
-        // the arrays as they are, through pinned staging kept by the context
-        if (bytes_xyz + bytes_feat > ctx->upload_stage_bytes) {
-            if (ctx->upload_stage) (void)hipHostFree(ctx->upload_stage);
-            ctx->upload_stage = nullptr;
-            ctx->upload_stage_bytes = 0;
+        // the arrays as they are, through pinned staging kept with the cloud
+        if (bytes_xyz + bytes_feat > c.stage_bytes) {
+            if (c.stage) (void)hipHostFree(c.stage);
+            c.stage = nullptr;
+            c.stage_bytes = 0;
             const size_t want = (bytes_xyz + bytes_feat) * 5 / 4 + 4096;
-            if (hipHostMalloc(&ctx->upload_stage, want, hipHostMallocDefault) != hipSuccess)
+            if (hipHostMalloc(&c.stage, want, hipHostMallocDefault) != hipSuccess)
                 return fail(ctx, CVO_HIP_ERR_NOMEM, "hipHostMalloc(upload staging) failed");
-            ctx->upload_stage_bytes = want;
+            c.stage_bytes = want;
         }
+        // (raw_xyz / raw_feat and the sort scratch are shared by the two clouds of a context: stream order
+        // keeps one hand-over's kernels ahead of the next one's copies; growing them frees memory a queued
+        // kernel may still read, so a growth waits for the stream first)
+        if (bytes_xyz > ctx->raw_xyz.bytes || bytes_feat > ctx->raw_feat.bytes) HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         int rcb = ensure_buf(ctx, ctx->raw_xyz, bytes_xyz);
         if (!rcb) rcb = ensure_buf(ctx, ctx->raw_feat, bytes_feat);
         if (rcb) return rcb;
-        char *hs = reinterpret_cast<char *>(ctx->upload_stage);
+        char *hs = reinterpret_cast<char *>(c.stage);
         std::memcpy(hs, xyz, bytes_xyz);
         HIP_TRY(ctx, hipMemcpyAsync(ctx->raw_xyz.p, hs, bytes_xyz, hipMemcpyHostToDevice, ctx->stream));
         std::memcpy(hs + bytes_xyz, feat, bytes_feat);
@@ -425,13 +453,15 @@ int upload_cloud(cvo_hip_ctx *ctx, Cloud &c, const float *xyz, const float *feat
     // and comes back to the host (the filter geometry of align() is made from it) together
     // with the end of the preparation: one synchronisation.
     HIP_TRY(ctx, cloud_bbox_device(d_xyz, n, ctx->bbox_dev, ctx->stream));
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->bbox_host, ctx->bbox_dev, 6 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(c.bbox_pin, ctx->bbox_dev, 6 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
     int rc = CVO_HIP_OK;
+    const size_t tmp = cloud_sort_scratch_bytes(n);
+    if ((size_t)n * sizeof(uint32_t) > ctx->sort_keys[0].bytes || tmp > ctx->sort_tmp.bytes)
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));   // (see raw_xyz above)
     for (int q = 0; q < 2 && !rc; ++q) {
         rc = ensure_buf(ctx, ctx->sort_keys[q], (size_t)n * sizeof(uint32_t));
         if (!rc) rc = ensure_buf(ctx, ctx->sort_idx[q], (size_t)n * sizeof(int));
     }
-    const size_t tmp = cloud_sort_scratch_bytes(n);
     if (!rc) rc = ensure_buf(ctx, ctx->sort_tmp, tmp);
     if (rc) return rc;
     CloudPrep cp{};
@@ -442,9 +472,14 @@ int upload_cloud(cvo_hip_ctx *ctx, Cloud &c, const float *xyz, const float *feat
     cp.scratch = ctx->sort_tmp.p; cp.scratch_bytes = tmp;
     cp.pos = c.pos; cp.feat8 = c.feat; cp.seg = c.seg;
     HIP_TRY(ctx, cloud_prepare_device(cp, ctx->stream));
-    // (the staging buffer, or the caller's device arrays, may be re-used once this returns)
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    for (int a = 0; a < 3; ++a) { c.lo[a] = ctx->bbox_host[a]; c.hi[a] = ctx->bbox_host[3 + a]; }
+    HIP_TRY(ctx, hipEventRecord(c.ready_ev, ctx->stream));
+    c.pending = true;
+    // Host arrays were copied into the cloud's staging: the caller's are free at once, and the call does not
+    // wait for the device (64 x 2 hand-overs of a batch overlap each other instead of costing 0.1 ms of host
+    // time apiece).  Device arrays of the caller's are read by the queued kernels: they may be re-used
+    // once this returns, so that form waits here.
+    static const bool sync_upload = getenv("CVO_HIP_SYNC_UPLOAD") != nullptr;
+    if (on_device || sync_upload) return cloud_ready(ctx, c);
     return CVO_HIP_OK;
 }
 
@@ -539,8 +574,11 @@ void shard_ranges(const cvo_hip_ctx *ctx, int &rlo, int &rhi, int &slo, int &shi
 
 // Geometry of the MFMA pre-filter: coordinates relative to the centre of the
 // fixed cloud's bounding box; radii from the farthest bounding-box corners.
-void fill_filter_geometry(const cvo_hip_ctx *ctx, DevState *h)
+void fill_filter_geometry(cvo_hip_ctx *ctx, DevState *h)
 {
+    // (every compute entry point passes here before it queues anything: hand-overs still on their way end now)
+    (void)cloud_ready(ctx, ctx->fixed);
+    (void)cloud_ready(ctx, ctx->moving);
     const Cloud &cf = ctx->fixed.n > 0 ? ctx->fixed : ctx->moving;
     h->n_fixed = ctx->fixed.n;
     for (int a = 0; a < 3; ++a) h->center[a] = 0.5f * (cf.lo[a] + cf.hi[a]);
@@ -1629,7 +1667,12 @@ int cvo_hip_destroy(cvo_hip_ctx *ctx)
         if (ctx->lists[l].b.p) (void)hipFree(ctx->lists[l].b.p);
     }
     if (ctx->st_host) (void)hipHostFree(ctx->st_host);
-    if (ctx->upload_stage) (void)hipHostFree(ctx->upload_stage);
+    for (Cloud *c : {&ctx->fixed, &ctx->moving, &ctx->scratch_a, &ctx->scratch_b}) {
+        if (c->pending && c->ready_ev) (void)hipEventSynchronize(c->ready_ev);
+        if (c->stage) (void)hipHostFree(c->stage);
+        if (c->bbox_pin) (void)hipHostFree(c->bbox_pin);
+        if (c->ready_ev) (void)hipEventDestroy(c->ready_ev);
+    }
     for (DevBuf *b : {&ctx->raw_xyz, &ctx->raw_feat, &ctx->sort_keys[0], &ctx->sort_keys[1], &ctx->sort_idx[0],
                       &ctx->sort_idx[1], &ctx->sort_tmp})
         if (b->p) (void)hipFree(b->p);

@@ -144,7 +144,10 @@ int cvo_hip_destroy(cvo_hip_ctx *ctx);
 int cvo_hip_set_params(cvo_hip_ctx *ctx, const cvo_hip_params *p);
 
 /* Cloud hand-over: tail of set_pcd() (ref src/cvo.cpp:344-356).  At most 2^26 points per cloud
- * (CVO_HIP_ERR_INVALID beyond). */
+ * (CVO_HIP_ERR_INVALID beyond).  The arrays are copied before the call returns (they are the caller's
+ * again at once); the upload and the preparation on the device (Morton order, bounding spheres) are only
+ * queued on the context's stream -- the next call that computes with the cloud waits for them, so the
+ * hand-overs of many contexts overlap.  CVO_HIP_SYNC_UPLOAD=1: wait before returning. */
 int cvo_hip_set_fixed(cvo_hip_ctx *ctx, const float *xyz, const float *feat, int n,
                       int feat_layout);
 int cvo_hip_set_moving(cvo_hip_ctx *ctx, const float *xyz, const float *feat, int m,
