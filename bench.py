@@ -849,6 +849,29 @@ def frontend_leg(args, pkg, frames=100):
         stream[name] = {"frames_per_s": 1.0 / dt, "ms_per_frame": dt * 1e3,
                         "passes_ms_per_frame": [round(v * 1e3, 3) for v in passes]}
     out["stream"] = stream
+    # the MATLAB driver's cloud preparation (range filter + grid average) on the device against
+    # its numpy oracle, on a shipped fr1/desk cloud (~50k points -> ~700)
+    try:
+        z = np.load(os.path.join(ROOT, "tests", "golden", "desk_pcd_ds.npz"))
+        xyz0, rgb0 = z["xyz0"], z["rgb0"]
+        pkg.data.prepare_matlab_cloud(xyz0, rgb0)
+        t0 = time.perf_counter()
+        for _ in range(20):
+            g = pkg.data.prepare_matlab_cloud(xyz0, rgb0)
+        dt = (time.perf_counter() - t0) / 20
+        prep = {"ms_per_cloud": dt * 1e3, "points_in": int(len(xyz0)), "points_out": int(len(g[0])),
+                "what": "pcRangeFilter(4.0, 0.8) + gridAverage(0.05), host arrays in and out"}
+        if not args.no_cpu:
+            from oracle import matlab_prep as mp
+            t0 = time.perf_counter()
+            for _ in range(5):
+                go = mp.grid_average(*mp.pc_range_filter(xyz0, rgb0))
+            prep["cpu_ms_per_cloud"] = (time.perf_counter() - t0) / 5 * 1e3
+            prep["cpu_kind"] = "port (numpy), 1 thread"
+            prep["bit_identical_to_oracle"] = bool(np.array_equal(g[0].view(np.uint32), go[0].view(np.uint32)) and np.array_equal(g[1], go[1]))
+        out["matlab_prep"] = prep
+    except Exception as e:
+        out["matlab_prep"] = {"error": repr(e)}
     # the shape of BASELINE configs[2] (the PNGs of fr1/desk are not in the reference's tree): a synthetic VGA
     # sequence through the front end and ONE acvo object, clouds handed over in device memory, the state carried
     # from pair to pair as the reference's driver does (ref src/adaptive_cvo_main.cpp:36-66); the same chain is

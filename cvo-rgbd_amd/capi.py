@@ -17,7 +17,7 @@ SYMBOLS = [
     "cvo_hip_default_params", "cvo_hip_init_state", "cvo_hip_create", "cvo_hip_destroy",
     "cvo_hip_set_params", "cvo_hip_set_fixed", "cvo_hip_set_moving",
     "cvo_hip_set_fixed_device", "cvo_hip_set_moving_device",
-    "cvo_hip_swap_moving_to_fixed", "cvo_hip_set_shard", "cvo_hip_shard_range",
+    "cvo_hip_swap_moving_to_fixed", "cvo_hip_range_filter_grid_average", "cvo_hip_set_shard", "cvo_hip_shard_range",
     "cvo_hip_comm_unique_id", "cvo_hip_comm_init", "cvo_hip_set_allreduce",
     "cvo_hip_mailbox_create", "cvo_hip_mailbox_connect",
     "cvo_hip_transform_pcd", "cvo_hip_flow", "cvo_hip_step_coeffs", "cvo_hip_pick_step",
@@ -105,6 +105,8 @@ def lib():
     L.cvo_hip_set_fixed_device.argtypes = [vp, vp, vp, C.c_int, C.c_int]
     L.cvo_hip_set_moving_device.argtypes = [vp, vp, vp, C.c_int, C.c_int]
     L.cvo_hip_swap_moving_to_fixed.argtypes = [vp]
+    L.cvo_hip_range_filter_grid_average.argtypes = [C.c_int, fp, C.POINTER(C.c_ubyte), C.c_int, C.c_float, C.c_float,
+                                                    C.c_double, fp, C.POINTER(C.c_ubyte), C.POINTER(C.c_int)]
     L.cvo_hip_set_shard.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int]
     L.cvo_hip_shard_range.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int),
                                       C.POINTER(C.c_int)]
@@ -209,6 +211,23 @@ def dist_se3(omega, v, dt):
     out = C.c_float()
     check(lib().cvo_hip_dist_se3(fptr(omega), fptr(v), np.float32(dt), C.byref(out)))
     return out.value
+
+
+def range_filter_grid_average(xyz, rgb, max_range, min_range, grid_size, device=0):
+    """cvo_hip_range_filter_grid_average: host arrays in, host arrays out."""
+    xyz = np.ascontiguousarray(xyz, np.float32).reshape(-1, 3)
+    rgb = np.ascontiguousarray(rgb, np.uint8).reshape(-1, 3)
+    n = xyz.shape[0]
+    if rgb.shape[0] != n:
+        raise ValueError("xyz and rgb differ in length")
+    xo = np.zeros((max(n, 1), 3), np.float32)
+    co = np.zeros((max(n, 1), 3), np.uint8)
+    m = C.c_int(0)
+    check(lib().cvo_hip_range_filter_grid_average(
+        int(device), xyz.ctypes.data_as(C.POINTER(C.c_float)), rgb.ctypes.data_as(C.POINTER(C.c_ubyte)), n,
+        float(max_range), float(min_range), float(grid_size), xo.ctypes.data_as(C.POINTER(C.c_float)),
+        co.ctypes.data_as(C.POINTER(C.c_ubyte)), C.byref(m)), what="range_filter_grid_average")
+    return xo[:m.value].copy(), co[:m.value].copy()
 
 
 def shard_range(n, rank, world):

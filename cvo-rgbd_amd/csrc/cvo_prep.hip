@@ -1,0 +1,212 @@
+// cvo_prep.hip -- the cloud preparation of the reference's MATLAB driver on the device
+// (SURVEY 8 f2): pcRangeFilter (ref util/pcRangeFilter.m:5-12) followed by
+// pcdownsample(cloud, 'gridAverage', gridSize) (ref data/rgbd_dataset/rgbddataset_rkhs.m:36-39,58):
+// one point per occupied voxel of a box grid anchored at the cloud's minimum corner = the mean
+// location and the mean colour of its points, voxels in lexicographic (x, y, z) index order.
+//
+// Results are defined by the arithmetic, not by the device (oracle/matlab_prep.py is the same
+// sequence in numpy): float32 range as ((x*x + y*y) + z*z) and a correctly rounded sqrt; voxel
+// indices floor((x - min) / grid) in float64; a STABLE sort of (voxel key, point index), so
+// that every voxel's float64 sums run over its points in their original order; one division
+// by the count; colours rounded as floor(mean + 0.5).
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
+
+#include "cvo_hip.h"
+#include "cvo_lock.h"
+
+namespace {
+
+constexpr int PB = 256;
+constexpr unsigned long long KEY_DROPPED = ~0ull;
+
+// keep[i] (range filter) and the bounding box of the kept points: box[0..2] min, [3..5] max, one block
+__global__ void __launch_bounds__(1024) k_prep_keep_box(const float *xyz, int n, float max_range, float min_range, int use_range,
+                                                        unsigned char *keep, float *box, int *n_kept)
+{
+    __shared__ float s_lo[16][3], s_hi[16][3];
+    __shared__ int s_cnt[16];
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    int cnt = 0;
+    for (int i = threadIdx.x; i < n; i += 1024) {
+        const float x = xyz[3 * (size_t)i], y = xyz[3 * (size_t)i + 1], z = xyz[3 * (size_t)i + 2];
+        bool k = true;
+        if (use_range) {
+            const float r = sqrtf((x * x + y * y) + z * z);   // (-ffp-contract=off: no FMA)
+            k = !((r > max_range) || (r < min_range));
+        }
+        keep[i] = k ? 1 : 0;
+        if (k) {
+            ++cnt;
+            const float v[3] = {x, y, z};
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                lo[a] = v[a] < lo[a] ? v[a] : lo[a];
+                hi[a] = v[a] > hi[a] ? v[a] : hi[a];
+            }
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+        for (int off = 32; off > 0; off >>= 1) {
+            const float l2 = __shfl_xor(lo[a], off), h2 = __shfl_xor(hi[a], off);
+            lo[a] = l2 < lo[a] ? l2 : lo[a];
+            hi[a] = h2 > hi[a] ? h2 : hi[a];
+        }
+    for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off);
+    if ((threadIdx.x & 63) == 0) {
+        for (int a = 0; a < 3; ++a) { s_lo[threadIdx.x >> 6][a] = lo[a]; s_hi[threadIdx.x >> 6][a] = hi[a]; }
+        s_cnt[threadIdx.x >> 6] = cnt;
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        float l = INFINITY, h = -INFINITY;
+        for (int w = 0; w < 16; ++w) {
+            l = s_lo[w][threadIdx.x] < l ? s_lo[w][threadIdx.x] : l;
+            h = s_hi[w][threadIdx.x] > h ? s_hi[w][threadIdx.x] : h;
+        }
+        box[threadIdx.x] = l;
+        box[3 + threadIdx.x] = h;
+    }
+    if (threadIdx.x == 0) {
+        int t = 0;
+        for (int w = 0; w < 16; ++w) t += s_cnt[w];
+        *n_kept = t;
+    }
+}
+
+__device__ __forceinline__ long long voxel_index(float v, float lo, double grid)
+{
+    return (long long)floor(((double)v - (double)lo) / grid);
+}
+
+// key of every point: its voxel in lexicographic order, or KEY_DROPPED; grid <= 0: the point's own index
+// (no downsampling: the kept points in their original order)
+__global__ void __launch_bounds__(PB) k_prep_keys(const float *xyz, const unsigned char *keep, int n, const float *box, double grid,
+                                                  unsigned long long *keys, int *idx)
+{
+    const int i = blockIdx.x * PB + threadIdx.x;
+    if (i >= n) return;
+    idx[i] = i;
+    if (!keep[i]) { keys[i] = KEY_DROPPED; return; }
+    if (!(grid > 0.0)) { keys[i] = (unsigned long long)i; return; }
+    long long q[3], span[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        q[a] = voxel_index(xyz[3 * (size_t)i + a], box[a], grid);
+        span[a] = voxel_index(box[3 + a], box[a], grid) + 1;   // (the index is monotone in the coordinate)
+    }
+    keys[i] = (unsigned long long)((q[0] * span[1] + q[1]) * span[2] + q[2]);
+}
+
+__global__ void __launch_bounds__(PB) k_prep_heads(const unsigned long long *keys, int n, int *head)
+{
+    const int i = blockIdx.x * PB + threadIdx.x;
+    if (i >= n) return;
+    const unsigned long long k = keys[i];
+    head[i] = (k != KEY_DROPPED && (i == 0 || keys[i - 1] != k)) ? 1 : 0;
+}
+
+// one thread per voxel head: float64 sums over the voxel's points in their original order
+__global__ void __launch_bounds__(PB) k_prep_average(const float *xyz, const unsigned char *rgb, const unsigned long long *keys,
+                                                     const int *order, const int *head, const int *seg, int n,
+                                                     float *xyz_out, unsigned char *rgb_out)
+{
+    const int i = blockIdx.x * PB + threadIdx.x;
+    if (i >= n || !head[i]) return;
+    const unsigned long long k = keys[i];
+    double sx = 0.0, sy = 0.0, sz = 0.0, sr = 0.0, sg = 0.0, sb = 0.0, cnt = 0.0;
+    for (int j = i; j < n && keys[j] == k; ++j) {
+        const int p = order[j];
+        sx += (double)xyz[3 * (size_t)p]; sy += (double)xyz[3 * (size_t)p + 1]; sz += (double)xyz[3 * (size_t)p + 2];
+        sr += (double)rgb[3 * (size_t)p]; sg += (double)rgb[3 * (size_t)p + 1]; sb += (double)rgb[3 * (size_t)p + 2];
+        cnt += 1.0;
+    }
+    const int o = seg[i] - 1;   // (inclusive scan of the heads)
+    xyz_out[3 * (size_t)o] = (float)(sx / cnt);
+    xyz_out[3 * (size_t)o + 1] = (float)(sy / cnt);
+    xyz_out[3 * (size_t)o + 2] = (float)(sz / cnt);
+    const double c[3] = {sr / cnt, sg / cnt, sb / cnt};
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        double v = floor(c[a] + 0.5);
+        v = v < 0.0 ? 0.0 : (v > 255.0 ? 255.0 : v);
+        rgb_out[3 * (size_t)o + a] = (unsigned char)v;
+    }
+}
+
+struct Bufs {
+    void *p[12] = {};
+    hipStream_t s = nullptr;
+    ~Bufs()
+    {
+        for (void *q : p)
+            if (q) (void)hipFree(q);
+        if (s) (void)hipStreamDestroy(s);
+    }
+};
+
+}   // namespace
+
+extern "C" int cvo_hip_range_filter_grid_average(int device, const float *xyz, const unsigned char *rgb, int n,
+                                                 float max_range, float min_range, double grid_size,
+                                                 float *xyz_out, unsigned char *rgb_out, int *n_out)
+{
+    cvo_lock::Api api_guard;
+    if (n < 0 || !n_out || (n > 0 && (!xyz || !rgb || !xyz_out || !rgb_out))) return CVO_HIP_ERR_INVALID;
+    *n_out = 0;
+    if (n == 0) return CVO_HIP_OK;
+    if (hipSetDevice(device) != hipSuccess) { (void)hipGetLastError(); return CVO_HIP_ERR_NODEVICE; }
+    Bufs b;
+#define PREP_TRY(e) do { if ((e) != hipSuccess) { (void)hipGetLastError(); return CVO_HIP_ERR_HIP; } } while (0)
+    PREP_TRY(hipStreamCreateWithFlags(&b.s, hipStreamNonBlocking));
+    float *d_xyz, *d_box, *d_out;
+    unsigned char *d_rgb, *d_keep, *d_rgb_out;
+    unsigned long long *d_keys[2];
+    int *d_idx[2], *d_head, *d_seg, *d_cnt;
+    const size_t N = (size_t)n;
+    PREP_TRY(hipMalloc(&b.p[0], N * 12)); d_xyz = (float *)b.p[0];
+    PREP_TRY(hipMalloc(&b.p[1], N * 3)); d_rgb = (unsigned char *)b.p[1];
+    PREP_TRY(hipMalloc(&b.p[2], N + 64)); d_keep = (unsigned char *)b.p[2];
+    PREP_TRY(hipMalloc(&b.p[3], 64)); d_box = (float *)b.p[3]; d_cnt = (int *)(d_box + 8);
+    PREP_TRY(hipMalloc(&b.p[4], N * 8)); d_keys[0] = (unsigned long long *)b.p[4];
+    PREP_TRY(hipMalloc(&b.p[5], N * 8)); d_keys[1] = (unsigned long long *)b.p[5];
+    PREP_TRY(hipMalloc(&b.p[6], N * 4)); d_idx[0] = (int *)b.p[6];
+    PREP_TRY(hipMalloc(&b.p[7], N * 4)); d_idx[1] = (int *)b.p[7];
+    PREP_TRY(hipMalloc(&b.p[8], N * 4)); d_head = (int *)b.p[8];
+    PREP_TRY(hipMalloc(&b.p[9], N * 4)); d_seg = (int *)b.p[9];
+    PREP_TRY(hipMalloc(&b.p[10], N * 12 + N * 3 + 64)); d_out = (float *)b.p[10]; d_rgb_out = (unsigned char *)(d_out + 3 * N);
+    size_t sort_bytes = 0, scan_bytes = 0;
+    PREP_TRY(rocprim::radix_sort_pairs(nullptr, sort_bytes, d_keys[0], d_keys[1], d_idx[0], d_idx[1], N, 0u, 64u, b.s));
+    PREP_TRY(rocprim::inclusive_scan(nullptr, scan_bytes, d_head, d_seg, N, rocprim::plus<int>(), b.s));
+    PREP_TRY(hipMalloc(&b.p[11], (sort_bytes > scan_bytes ? sort_bytes : scan_bytes) + 64));
+    PREP_TRY(hipMemcpyAsync(d_xyz, xyz, N * 12, hipMemcpyHostToDevice, b.s));
+    PREP_TRY(hipMemcpyAsync(d_rgb, rgb, N * 3, hipMemcpyHostToDevice, b.s));
+    const int use_range = max_range > 0.0f ? 1 : 0;
+    hipLaunchKernelGGL(k_prep_keep_box, dim3(1), dim3(1024), 0, b.s, d_xyz, n, max_range, min_range, use_range, d_keep, d_box, d_cnt);
+    const int nb = (n + PB - 1) / PB;
+    hipLaunchKernelGGL(k_prep_keys, dim3(nb), dim3(PB), 0, b.s, d_xyz, d_keep, n, d_box, grid_size, d_keys[0], d_idx[0]);
+    // stable: points of one voxel stay in their original order
+    PREP_TRY(rocprim::radix_sort_pairs(b.p[11], sort_bytes, d_keys[0], d_keys[1], d_idx[0], d_idx[1], N, 0u, 64u, b.s));
+    hipLaunchKernelGGL(k_prep_heads, dim3(nb), dim3(PB), 0, b.s, d_keys[1], n, d_head);
+    PREP_TRY(rocprim::inclusive_scan(b.p[11], scan_bytes, d_head, d_seg, N, rocprim::plus<int>(), b.s));
+    hipLaunchKernelGGL(k_prep_average, dim3(nb), dim3(PB), 0, b.s, d_xyz, d_rgb, d_keys[1], d_idx[1], d_head, d_seg, n, d_out, d_rgb_out);
+    PREP_TRY(hipGetLastError());
+    int n_seg = 0;
+    PREP_TRY(hipMemcpyAsync(&n_seg, d_seg + (N - 1), sizeof(int), hipMemcpyDeviceToHost, b.s));
+    PREP_TRY(hipStreamSynchronize(b.s));
+    if (n_seg > 0) {
+        PREP_TRY(hipMemcpyAsync(xyz_out, d_out, (size_t)n_seg * 12, hipMemcpyDeviceToHost, b.s));
+        PREP_TRY(hipMemcpyAsync(rgb_out, d_rgb_out, (size_t)n_seg * 3, hipMemcpyDeviceToHost, b.s));
+        PREP_TRY(hipStreamSynchronize(b.s));
+    }
+#undef PREP_TRY
+    *n_out = n_seg;
+    return CVO_HIP_OK;
+}

@@ -93,37 +93,30 @@ def read_pcd_ascii(path):
     return xyz, rgb
 
 
-def pc_range_filter(xyz, rgb, max_range=4.0, min_range=0.8):
-    """ref util/pcRangeFilter.m:5-12: drop the points whose range (float32
-    norm) is above max_range or below min_range."""
-    xyz = np.asarray(xyz, np.float32)
-    r = np.sqrt((xyz * xyz).sum(1, dtype=np.float32))
-    keep = ~((r > np.float32(max_range)) | (r < np.float32(min_range)))
-    return xyz[keep], np.asarray(rgb)[keep]
+def prepare_matlab_cloud(xyz, rgb, max_range=4.0, min_range=0.8, grid_size=0.05, device=0):
+    """The cloud preparation of the reference's MATLAB driver (ref data/rgbd_dataset/rgbddataset_rkhs.m:
+    33-39,55-58): pcRangeFilter, then pcdownsample(..., 'gridAverage', grid_size) -- on the GPU
+    (cvo_hip_range_filter_grid_average, csrc/cvo_prep.hip; no CPU path).  max_range <= 0: no range
+    filter; grid_size <= 0: no downsampling.  Returns (xyz float32 m x 3, rgb uint8 m x 3)."""
+    from . import capi
+    return capi.range_filter_grid_average(xyz, rgb, max_range, min_range, grid_size, device=device)
 
 
-def grid_average(xyz, rgb, grid_size=0.05):
-    """Box-grid downsampling in the manner of MATLAB's
-    pcdownsample(cloud, 'gridAverage', grid_size) (ref data/rgbd_dataset/
-    rgbddataset_rkhs.m:36-39,58): one point per occupied voxel = the mean
-    location and the mean colour (rounded to uint8) of its points.  Voxels are
-    anchored at the cloud's minimum corner; MATLAB's own anchoring is not
-    documented, and no anchoring reproduces the transforms its run recorded better
-    than 2.8e-3 (tools/search_grid_anchor.py, tests/golden/grid_anchor_residuals.json;
-    DESIGN.md section 2), so the output is equivalent, not identical.
-    Voxels come out in lexicographic (x, y, z) index order."""
-    x = np.asarray(xyz, np.float64)
-    c = np.asarray(rgb, np.float64)
-    idx = np.floor((x - x.min(0)) / float(grid_size)).astype(np.int64)
-    span = idx.max(0) + 1
-    key = (idx[:, 0] * span[1] + idx[:, 1]) * span[2] + idx[:, 2]
-    _, inv = np.unique(key, return_inverse=True)
-    inv = inv.ravel()
-    n = int(inv.max()) + 1
-    cnt = np.bincount(inv, minlength=n).astype(np.float64)
-    loc = np.stack([np.bincount(inv, weights=x[:, k], minlength=n) / cnt for k in range(3)], 1)
-    col = np.stack([np.bincount(inv, weights=c[:, k], minlength=n) / cnt for k in range(c.shape[1])], 1)
-    return loc.astype(np.float32), np.clip(np.floor(col + 0.5), 0, 255).astype(np.uint8)
+def pc_range_filter(xyz, rgb, max_range=4.0, min_range=0.8, device=0):
+    """ref util/pcRangeFilter.m:5-12: drop the points whose range (float32 norm) is above max_range or
+    below min_range (GPU)."""
+    return prepare_matlab_cloud(xyz, rgb, max_range, min_range, 0.0, device=device)
+
+
+def grid_average(xyz, rgb, grid_size=0.05, device=0):
+    """Box-grid downsampling in the manner of MATLAB's pcdownsample(cloud, 'gridAverage', grid_size)
+    (ref data/rgbd_dataset/rgbddataset_rkhs.m:36-39,58): one point per occupied voxel = the mean
+    location and the mean colour (rounded to uint8) of its points (GPU).  Voxels are anchored at the
+    cloud's minimum corner; MATLAB's own anchoring is not documented, and no anchoring reproduces the
+    transforms its run recorded better than 2.8e-3 (tools/search_grid_anchor.py,
+    tests/golden/grid_anchor_residuals.json), so the output is equivalent, not
+    identical.  Voxels come out in lexicographic (x, y, z) index order."""
+    return prepare_matlab_cloud(xyz, rgb, 0.0, 0.0, grid_size, device=device)
 
 
 def cvo_features(rgb, dx=None, dy=None):

@@ -163,6 +163,18 @@ int cvo_hip_set_moving_device(cvo_hip_ctx *ctx, const float *d_xyz, const float 
                               int feat_layout);
 int cvo_hip_swap_moving_to_fixed(cvo_hip_ctx *ctx);
 
+/* The cloud preparation of the reference's MATLAB driver, on the device:
+ * pcRangeFilter (ref util/pcRangeFilter.m:5-12: points whose float32 range is above max_range or
+ * below min_range are dropped; max_range <= 0: no range filter), then
+ * pcdownsample(cloud, 'gridAverage', grid_size) (ref data/rgbd_dataset/rgbddataset_rkhs.m:36-39,58:
+ * one point per occupied voxel of a box grid anchored at the minimum corner of the kept points = the
+ * mean location and the mean colour, voxels in lexicographic (x, y, z) index order; grid_size <= 0: no
+ * downsampling, the kept points in their order).  Host arrays in and out: xyz n x 3 float32, rgb n x 3
+ * uint8; xyz_out / rgb_out must hold n points, *n_out receives the count.  Context-free. */
+int cvo_hip_range_filter_grid_average(int device, const float *xyz, const unsigned char *rgb, int n,
+                                      float max_range, float min_range, double grid_size,
+                                      float *xyz_out, unsigned char *rgb_out, int *n_out);
+
 /* Multi-GPU: this context owns target rows [row_lo,row_hi) of the fixed cloud
  * (and rows [srow_lo,srow_hi) of the moving cloud for the acvo Ayy sweep).
  * Default = everything. */

@@ -76,16 +76,19 @@ def test_rel_pose_error_is_zero_for_identical_float32_matrices(pkg):
 
 def test_range_filter_and_grid_average(pkg, desk):
     """pcRangeFilter (ref util/pcRangeFilter.m) and grid-average
-    downsampling (ref rgbddataset_rkhs.m:36-39) on a shipped cloud."""
+    downsampling (ref rgbddataset_rkhs.m:36-39) on a shipped cloud -- the oracle's numpy
+    restatement (oracle/matlab_prep.py; the product's runs on the GPU and is held to it bit for
+    bit in tests/test_gpu_matlab.py)."""
     import numpy as np
+    from oracle import matlab_prep
     xyz, rgb = desk["xyz0"], desk["rgb0"]
-    fx, fc = pkg.data.pc_range_filter(xyz, rgb, 4.0, 0.8)
+    fx, fc = matlab_prep.pc_range_filter(xyz, rgb, 4.0, 0.8)
     r = np.linalg.norm(fx.astype(np.float64), axis=1)
     assert len(fx) == len(fc) <= len(xyz) and r.min() >= 0.8 - 1e-6 and r.max() <= 4.0 + 1e-6
     # everything that was dropped is out of range
     r_all = np.linalg.norm(xyz.astype(np.float64), axis=1)
     assert len(fx) == int(((r_all <= 4.0 + 1e-7) & (r_all >= 0.8 - 1e-7)).sum())
-    gx, gc = pkg.data.grid_average(fx, fc, 0.05)
+    gx, gc = matlab_prep.grid_average(fx, fc, 0.05)
     assert gc.dtype == np.uint8 and gx.dtype == np.float32
     assert 600 <= len(gx) <= 800          # the MATLAB run registered ~700-point clouds
     # one output per occupied voxel, each inside its voxel, mass conserved
@@ -96,7 +99,7 @@ def test_range_filter_and_grid_average(pkg, desk):
     cnt = np.unique(idx, axis=0, return_counts=True)[1]
     assert cnt.sum() == len(fx)
     # one giant voxel: the centroid and the mean colour
-    g1, c1 = pkg.data.grid_average(fx, fc, 100.0)
+    g1, c1 = matlab_prep.grid_average(fx, fc, 100.0)
     assert len(g1) == 1 and np.allclose(g1[0], fx.astype(np.float64).mean(0), atol=1e-5)
     assert np.all(np.abs(c1[0].astype(np.float64) - fc.astype(np.float64).mean(0)) <= 0.5 + 1e-9)
 
@@ -111,8 +114,9 @@ def test_matlab_dense_variant_close_to_recorded_run(pkg, desk):
     import numpy as np
     from oracle import matlab_dense
     gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "matlab_transforms.json")))
-    f = pkg.data.grid_average(*pkg.data.pc_range_filter(desk["xyz0"], desk["rgb0"]))
-    m = pkg.data.grid_average(*pkg.data.pc_range_filter(desk["xyz1"], desk["rgb1"]))
+    from oracle import matlab_prep
+    f = matlab_prep.grid_average(*matlab_prep.pc_range_filter(desk["xyz0"], desk["rgb0"]))
+    m = matlab_prep.grid_average(*matlab_prep.pc_range_filter(desk["xyz1"], desk["rgb1"]))
     T, k = matlab_dense.align(f[0], f[1], m[0], m[1])
     G = np.array(gold["matlab"][1])
     assert 10 <= k <= 60
@@ -136,8 +140,9 @@ def test_matlab_weight_in_the_c_restatement_tracks_float64(pkg, desk):
     from oracle import pyoracle as po
     p = po.default_params(po.MODE_MATLAB)
     assert p.mode == po.MODE_CVO and p.color_scale == np.float32(1e-5) and p.sp_thres == np.float32(1e-3)
-    f = pkg.data.grid_average(*pkg.data.pc_range_filter(desk["xyz0"], desk["rgb0"]))
-    m = pkg.data.grid_average(*pkg.data.pc_range_filter(desk["xyz1"], desk["rgb1"]))
+    from oracle import matlab_prep
+    f = matlab_prep.grid_average(*matlab_prep.pc_range_filter(desk["xyz0"], desk["rgb0"]))
+    m = matlab_prep.grid_average(*matlab_prep.pc_range_filter(desk["xyz1"], desk["rgb1"]))
     xf, _, xm, _ = pkg.data.synthetic_pair(900, 800, seed=17)
     rng = np.random.default_rng(3)
     cf = rng.integers(0, 256, (900, 3)).astype(np.uint8)

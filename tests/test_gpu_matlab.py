@@ -81,3 +81,40 @@ def test_matlab_weight_soak(pkg):
                          capture_output=True, text=True, env=env)
     assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-1500:]
     assert "120 cases, 0 mismatches" in out.stdout
+
+
+def test_cloud_preparation_on_the_device_equals_the_oracle(pkg, desk):
+    """SURVEY 8 f2 on the GPU: pcRangeFilter + grid-average downsampling (ref util/pcRangeFilter.m:5-12,
+    data/rgbd_dataset/rgbddataset_rkhs.m:36-39,58) through cvo_hip_range_filter_grid_average against the
+    numpy oracle (oracle/matlab_prep.py), bit for bit: the five shipped fr1/desk clouds at the MATLAB
+    run's settings (4.0 / 0.8 m, 0.05 m), either step alone, random clouds of 1 ... 200 000 points with
+    other grids, and the edge cases -- nothing in range, one point, everything in one voxel."""
+    from oracle import matlab_prep as mp
+    data = pkg.data
+
+    def same(a, b):
+        assert a[0].dtype == np.float32 and a[1].dtype == np.uint8
+        assert a[0].shape == b[0].shape and a[1].shape == b[1].shape
+        assert np.array_equal(a[0].view(np.uint32), np.asarray(b[0], np.float32).view(np.uint32))
+        assert np.array_equal(a[1], b[1])
+
+    for k in range(5):
+        xyz, rgb = desk["xyz%d" % k], desk["rgb%d" % k]
+        f_or = mp.pc_range_filter(xyz, rgb, 4.0, 0.8)
+        same(data.pc_range_filter(xyz, rgb, 4.0, 0.8), f_or)
+        same(data.grid_average(f_or[0], f_or[1], 0.05), mp.grid_average(f_or[0], f_or[1], 0.05))
+        g = data.prepare_matlab_cloud(xyz, rgb, 4.0, 0.8, 0.05)
+        same(g, mp.grid_average(f_or[0], f_or[1], 0.05))
+        assert 600 <= len(g[0]) <= 800   # the MATLAB run registered ~700-point clouds
+    rng = np.random.default_rng(8)
+    for n, grid, rmax, rmin in ((1, 0.05, 4.0, 0.0), (7, 0.3, 0.0, 0.0), (1000, 0.01, 3.0, 1.0), (50000, 0.05, 4.0, 0.8),
+                                (200000, 0.02, 5.0, 0.5), (3000, 100.0, 0.0, 0.0)):
+        xyz = (rng.normal(size=(n, 3)) * [1.5, 1.0, 0.7] + [0.2, -0.1, 2.0]).astype(np.float32)
+        rgb = rng.integers(0, 256, (n, 3)).astype(np.uint8)
+        f_or = mp.pc_range_filter(xyz, rgb, rmax, rmin) if rmax > 0 else (xyz, rgb)
+        same(data.prepare_matlab_cloud(xyz, rgb, rmax, rmin, grid), mp.grid_average(f_or[0], f_or[1], grid))
+    xyz = np.full((40, 3), 9.0, np.float32)       # nothing in range
+    out = data.prepare_matlab_cloud(xyz, np.zeros((40, 3), np.uint8), 4.0, 0.8, 0.05)
+    assert out[0].shape == (0, 3) and out[1].shape == (0, 3)
+    out = data.prepare_matlab_cloud(np.zeros((0, 3), np.float32), np.zeros((0, 3), np.uint8))
+    assert out[0].shape == (0, 3)

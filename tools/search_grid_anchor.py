@@ -40,7 +40,8 @@ def grid_average(xyz, rgb, index):
     return loc.astype(np.float32), col
 
 
-clouds = [pkg.data.pc_range_filter(z["xyz%d" % k], z["rgb%d" % k]) for k in range(5)]
+from oracle import matlab_prep
+clouds = [matlab_prep.pc_range_filter(z["xyz%d" % k], z["rgb%d" % k]) for k in range(5)]
 
 
 def residuals(index, pairs=(0, 1, 2, 3)):
