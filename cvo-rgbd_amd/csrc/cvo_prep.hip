@@ -14,6 +14,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstring>
+#include <mutex>
 
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
@@ -141,16 +142,23 @@ __global__ void __launch_bounds__(PB) k_prep_average(const float *xyz, const uns
     }
 }
 
-struct Bufs {
-    void *p[12] = {};
+// One arena and one stream per device, kept for the life of the process (like the engines' streams): a
+// call costs its copies and seven launches, not a dozen allocations.
+struct Arena {
+    void *p = nullptr;
+    size_t bytes = 0;
     hipStream_t s = nullptr;
-    ~Bufs()
-    {
-        for (void *q : p)
-            if (q) (void)hipFree(q);
-        if (s) (void)hipStreamDestroy(s);
-    }
 };
+std::mutex *arena_mutex()
+{
+    static std::mutex *m = new std::mutex;   // (never destroyed: see cvo_lock.h)
+    return m;
+}
+Arena *arena_of(int device)
+{
+    static Arena *a = new Arena[64];
+    return (device >= 0 && device < 64) ? &a[device] : nullptr;
+}
 
 }   // namespace
 
@@ -163,48 +171,59 @@ extern "C" int cvo_hip_range_filter_grid_average(int device, const float *xyz, c
     *n_out = 0;
     if (n == 0) return CVO_HIP_OK;
     if (hipSetDevice(device) != hipSuccess) { (void)hipGetLastError(); return CVO_HIP_ERR_NODEVICE; }
-    Bufs b;
+    Arena *ar = arena_of(device);
+    if (!ar) return CVO_HIP_ERR_INVALID;
+    std::lock_guard<std::mutex> lock(*arena_mutex());
 #define PREP_TRY(e) do { if ((e) != hipSuccess) { (void)hipGetLastError(); return CVO_HIP_ERR_HIP; } } while (0)
-    PREP_TRY(hipStreamCreateWithFlags(&b.s, hipStreamNonBlocking));
-    float *d_xyz, *d_box, *d_out;
-    unsigned char *d_rgb, *d_keep, *d_rgb_out;
-    unsigned long long *d_keys[2];
-    int *d_idx[2], *d_head, *d_seg, *d_cnt;
+    if (!ar->s) PREP_TRY(hipStreamCreateWithFlags(&ar->s, hipStreamNonBlocking));
+    hipStream_t st = ar->s;
     const size_t N = (size_t)n;
-    PREP_TRY(hipMalloc(&b.p[0], N * 12)); d_xyz = (float *)b.p[0];
-    PREP_TRY(hipMalloc(&b.p[1], N * 3)); d_rgb = (unsigned char *)b.p[1];
-    PREP_TRY(hipMalloc(&b.p[2], N + 64)); d_keep = (unsigned char *)b.p[2];
-    PREP_TRY(hipMalloc(&b.p[3], 64)); d_box = (float *)b.p[3]; d_cnt = (int *)(d_box + 8);
-    PREP_TRY(hipMalloc(&b.p[4], N * 8)); d_keys[0] = (unsigned long long *)b.p[4];
-    PREP_TRY(hipMalloc(&b.p[5], N * 8)); d_keys[1] = (unsigned long long *)b.p[5];
-    PREP_TRY(hipMalloc(&b.p[6], N * 4)); d_idx[0] = (int *)b.p[6];
-    PREP_TRY(hipMalloc(&b.p[7], N * 4)); d_idx[1] = (int *)b.p[7];
-    PREP_TRY(hipMalloc(&b.p[8], N * 4)); d_head = (int *)b.p[8];
-    PREP_TRY(hipMalloc(&b.p[9], N * 4)); d_seg = (int *)b.p[9];
-    PREP_TRY(hipMalloc(&b.p[10], N * 12 + N * 3 + 64)); d_out = (float *)b.p[10]; d_rgb_out = (unsigned char *)(d_out + 3 * N);
     size_t sort_bytes = 0, scan_bytes = 0;
-    PREP_TRY(rocprim::radix_sort_pairs(nullptr, sort_bytes, d_keys[0], d_keys[1], d_idx[0], d_idx[1], N, 0u, 64u, b.s));
-    PREP_TRY(rocprim::inclusive_scan(nullptr, scan_bytes, d_head, d_seg, N, rocprim::plus<int>(), b.s));
-    PREP_TRY(hipMalloc(&b.p[11], (sort_bytes > scan_bytes ? sort_bytes : scan_bytes) + 64));
-    PREP_TRY(hipMemcpyAsync(d_xyz, xyz, N * 12, hipMemcpyHostToDevice, b.s));
-    PREP_TRY(hipMemcpyAsync(d_rgb, rgb, N * 3, hipMemcpyHostToDevice, b.s));
+    {
+        unsigned long long *k = nullptr;
+        int *v = nullptr;
+        PREP_TRY(rocprim::radix_sort_pairs(nullptr, sort_bytes, k, k, v, v, N, 0u, 64u, st));
+        PREP_TRY(rocprim::inclusive_scan(nullptr, scan_bytes, v, v, N, rocprim::plus<int>(), st));
+    }
+    // the arena, carved (256-byte pieces)
+    size_t off = 0;
+    auto take = [&](size_t bytes) { const size_t at = off; off += (bytes + 255) / 256 * 256; return at; };
+    const size_t o_xyz = take(N * 12), o_rgb = take(N * 3), o_keep = take(N), o_box = take(64), o_k0 = take(N * 8),
+                 o_k1 = take(N * 8), o_i0 = take(N * 4), o_i1 = take(N * 4), o_head = take(N * 4), o_seg = take(N * 4),
+                 o_out = take(N * 12), o_cout = take(N * 3), o_tmp = take(sort_bytes > scan_bytes ? sort_bytes : scan_bytes);
+    if (off > ar->bytes) {
+        if (ar->p) { (void)hipStreamSynchronize(st); (void)hipFree(ar->p); ar->p = nullptr; ar->bytes = 0; }
+        const size_t want = off + off / 4;
+        if (hipMalloc(&ar->p, want) != hipSuccess) { (void)hipGetLastError(); ar->p = nullptr; return CVO_HIP_ERR_NOMEM; }
+        ar->bytes = want;
+    }
+    char *base = (char *)ar->p;
+    float *d_xyz = (float *)(base + o_xyz), *d_box = (float *)(base + o_box), *d_out = (float *)(base + o_out);
+    int *d_cnt = (int *)(d_box + 8);
+    unsigned char *d_rgb = (unsigned char *)(base + o_rgb), *d_keep = (unsigned char *)(base + o_keep),
+                  *d_rgb_out = (unsigned char *)(base + o_cout);
+    unsigned long long *d_keys[2] = {(unsigned long long *)(base + o_k0), (unsigned long long *)(base + o_k1)};
+    int *d_idx[2] = {(int *)(base + o_i0), (int *)(base + o_i1)}, *d_head = (int *)(base + o_head), *d_seg = (int *)(base + o_seg);
+    void *d_tmp = base + o_tmp;
+    PREP_TRY(hipMemcpyAsync(d_xyz, xyz, N * 12, hipMemcpyHostToDevice, st));
+    PREP_TRY(hipMemcpyAsync(d_rgb, rgb, N * 3, hipMemcpyHostToDevice, st));
     const int use_range = max_range > 0.0f ? 1 : 0;
-    hipLaunchKernelGGL(k_prep_keep_box, dim3(1), dim3(1024), 0, b.s, d_xyz, n, max_range, min_range, use_range, d_keep, d_box, d_cnt);
+    hipLaunchKernelGGL(k_prep_keep_box, dim3(1), dim3(1024), 0, st, d_xyz, n, max_range, min_range, use_range, d_keep, d_box, d_cnt);
     const int nb = (n + PB - 1) / PB;
-    hipLaunchKernelGGL(k_prep_keys, dim3(nb), dim3(PB), 0, b.s, d_xyz, d_keep, n, d_box, grid_size, d_keys[0], d_idx[0]);
+    hipLaunchKernelGGL(k_prep_keys, dim3(nb), dim3(PB), 0, st, d_xyz, d_keep, n, d_box, grid_size, d_keys[0], d_idx[0]);
     // stable: points of one voxel stay in their original order
-    PREP_TRY(rocprim::radix_sort_pairs(b.p[11], sort_bytes, d_keys[0], d_keys[1], d_idx[0], d_idx[1], N, 0u, 64u, b.s));
-    hipLaunchKernelGGL(k_prep_heads, dim3(nb), dim3(PB), 0, b.s, d_keys[1], n, d_head);
-    PREP_TRY(rocprim::inclusive_scan(b.p[11], scan_bytes, d_head, d_seg, N, rocprim::plus<int>(), b.s));
-    hipLaunchKernelGGL(k_prep_average, dim3(nb), dim3(PB), 0, b.s, d_xyz, d_rgb, d_keys[1], d_idx[1], d_head, d_seg, n, d_out, d_rgb_out);
+    PREP_TRY(rocprim::radix_sort_pairs(d_tmp, sort_bytes, d_keys[0], d_keys[1], d_idx[0], d_idx[1], N, 0u, 64u, st));
+    hipLaunchKernelGGL(k_prep_heads, dim3(nb), dim3(PB), 0, st, d_keys[1], n, d_head);
+    PREP_TRY(rocprim::inclusive_scan(d_tmp, scan_bytes, d_head, d_seg, N, rocprim::plus<int>(), st));
+    hipLaunchKernelGGL(k_prep_average, dim3(nb), dim3(PB), 0, st, d_xyz, d_rgb, d_keys[1], d_idx[1], d_head, d_seg, n, d_out, d_rgb_out);
     PREP_TRY(hipGetLastError());
     int n_seg = 0;
-    PREP_TRY(hipMemcpyAsync(&n_seg, d_seg + (N - 1), sizeof(int), hipMemcpyDeviceToHost, b.s));
-    PREP_TRY(hipStreamSynchronize(b.s));
+    PREP_TRY(hipMemcpyAsync(&n_seg, d_seg + (N - 1), sizeof(int), hipMemcpyDeviceToHost, st));
+    PREP_TRY(hipStreamSynchronize(st));
     if (n_seg > 0) {
-        PREP_TRY(hipMemcpyAsync(xyz_out, d_out, (size_t)n_seg * 12, hipMemcpyDeviceToHost, b.s));
-        PREP_TRY(hipMemcpyAsync(rgb_out, d_rgb_out, (size_t)n_seg * 3, hipMemcpyDeviceToHost, b.s));
-        PREP_TRY(hipStreamSynchronize(b.s));
+        PREP_TRY(hipMemcpyAsync(xyz_out, d_out, (size_t)n_seg * 12, hipMemcpyDeviceToHost, st));
+        PREP_TRY(hipMemcpyAsync(rgb_out, d_rgb_out, (size_t)n_seg * 3, hipMemcpyDeviceToHost, st));
+        PREP_TRY(hipStreamSynchronize(st));
     }
 #undef PREP_TRY
     *n_out = n_seg;
