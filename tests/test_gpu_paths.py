@@ -856,3 +856,56 @@ def test_wide_candidate_records_for_clouds_above_65536_rows(pkg, po, mode_name, 
     for a, b in zip(runs[0][2], tr_or):
         assert a[0] == b["nnz"] and a[1] == b["nnz_xx"] and a[2] == b["nnz_yy"]
         assert a[3] == b["omega"] and a[4] == b["v"] and a[5] == b["step"]
+
+
+@pytest.mark.parametrize("mode_name", ["cvo", "acvo"])
+def test_head_mode_changes_nothing(pkg, po, monkeypatch, mode_name):
+    """Head mode (the post-step part of an iteration -- ref src/cvo.cpp:291-307,380-410 -- runs as
+    the head of every flow / self block of the NEXT flow launch: two dependent launches per iteration, two
+    copies of the state's head, overflow flags by launch parity, builds named a slot ahead) against the
+    same registration with the post-step maths as a launch of its own (CVO_HIP_NO_HEAD), with and without
+    captured batches, with tiny lists that overflow and grow, with list re-use off (a stall before every
+    iteration), from a far start (jumps): identical state and trace; and equal to the oracle."""
+    import torch
+    capi = pkg.capi
+    acvo = mode_name == "acvo"
+    mode = capi.MODE_ACVO if acvo else capi.MODE_CVO
+    xf, ff, xm, fm = pkg.data.synthetic_pair(3400, 3100, seed=97, acvo=acvo)
+    xm_far = (xm.astype(np.float64) + np.array([0.04, -0.03, 0.05])).astype(np.float32)
+
+    def run(env, moving, graph):
+        for k in ("CVO_HIP_NO_HEAD", "CVO_HIP_LIST_INIT", "CVO_HIP_LIST_MARGIN"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        s = torch.cuda.Stream()
+        c = capi.Context(mode=mode, device=0, stream=s.cuda_stream, graph_capture=graph)
+        c.set_fixed(xf, ff)
+        c.set_moving(moving, fm)
+        out = []
+        for _ in range(2):   # (the second align() re-uses plans, tables and both copies of the head)
+            st = capi.init_state(c.params)
+            it, tr = c.align(st, trace_cap=2000)
+            # (dist is NaN in the record of an iteration that breaks on the twist norms: compare its bits; the
+            # float64 sums depend on the order the tile entries were appended in -- 1e-16 -- and stay out)
+            out.append((it, bytes(st), [(t["nnz"], t["nnz_xx"], t["nnz_yy"], t["step"], int(np.float32(t["dist"]).view(np.uint32)),
+                                         tuple(t["omega"]), tuple(t["v"])) for t in tr]))
+        c.close()
+        assert out[0] == out[1]
+        return out[0]
+
+    for moving in (xm, xm_far):
+        ref = run({"CVO_HIP_NO_HEAD": "1"}, moving, False)
+        for env, graph in (({}, False), ({}, True), ({"CVO_HIP_LIST_INIT": "4096"}, True), ({"CVO_HIP_LIST_MARGIN": "0"}, True)):
+            got = run(env, moving, graph)
+            assert got[0] == ref[0], (env, graph)
+            assert got[1] == ref[1], (env, graph)
+            assert got[2] == ref[2], (env, graph)
+        p = po.default_params(po.MODE_ACVO if acvo else po.MODE_CVO)
+        so = po.init_state(p)
+        n_or, _ = po.align(p, so, xf, ff, moving, fm, search=po.SEARCH_GRID, trace_cap=1)
+        assert n_or == ref[0]
+        R = np.frombuffer(ref[1], np.float32, 9)
+        assert np.array_equal(R, np.array(so.R, np.float32))
+    for k in ("CVO_HIP_NO_HEAD", "CVO_HIP_LIST_INIT", "CVO_HIP_LIST_MARGIN"):
+        monkeypatch.delenv(k, raising=False)
