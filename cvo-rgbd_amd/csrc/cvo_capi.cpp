@@ -2077,6 +2077,8 @@ int job_begin(AlignJob &j)
     const int prc = prepare_buffers(ctx);
     if (prc) return prc;
     // (a member of a fused group is planned by the group: its slot is one of many)
+    ctx->head_mode = false;   // (set again by prepare_lone_plan if this align() runs a head-mode plan)
+    ctx->plan_tail.clear();
     if (!j.in_group && !ctx->profiling && !host_reduce(ctx)) {
         const int rc2 = prepare_lone_plan(ctx, j.trace_cap);
         if (rc2) return rc2;
