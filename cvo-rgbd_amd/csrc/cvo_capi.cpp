@@ -238,6 +238,8 @@ struct cvo_hip_ctx {
     bool crowded = false;                // set by align_many: many registrations share the launches
     DevBuf cand[3], cand_cnt[3];         // the candidate lists of the xy / xx / yy tile lists (ProcessArgs::cand, cand_cnt)
     DevBuf cand_ck[3];                   // ... their colour weights where the record is 12 bytes wide (ProcessArgs::cand_ck)
+    DevBuf cand_xyb, cand_cnt_xyb;       // head mode: the record of the second buffer of the xy list (ProcessArgs::cand_b)
+    DevBuf cand_sfb[2], cand_cnt_sfb[2]; // ... and of the xx / yy lists (acvo)
     int ck_nblk[3] = {0, 0, 0};          // recorded plan: the pass over list l keeps a candidate list with this many blocks (0: no)
     DevBuf pos_bt;                       // crowded: the moving cloud under the iteration's transform (FilterArgs::pos_bt)
     bool lone = true;                    // this registration has its launches to itself
@@ -756,10 +758,56 @@ int enqueue_process(cvo_hip_ctx *ctx, int mode, int list, DevBuf &part, const fl
     if (ctx->in_loop && ctx->use_async) {
         a.async_xy = 1;
         a.tiles_b = (const TileEntry *)ctx->lists[LIST_XYB].a.p;
+        // Head mode (one registration on its own, plan_lone): the flow pass keeps a candidate record per buffer of
+        // the double-buffered xy list -- the pass after a buffer is switched to expands and records, the passes
+        // over the same buffer stream (DevHead::xy_ck).  The kernels of every other plan ignore the fields.
+        const bool no_cand = getenv("CVO_HIP_NO_CAND") != nullptr || getenv("CVO_HIP_NO_CAND_ASYNC") != nullptr;
+        if (mode == PROC_FLOW && list == LIST_XY && ctx->plan_recording && ctx->lone && ctx->allow_head && !multi_rank(ctx) &&
+            !no_cand && a.kept_packed && !(ctx->prm.color_scale > 0.0f)) {
+            const size_t bytes = (size_t)ctx->lists[LIST_KEPT].cap * sizeof(uint2);
+            int rc_c = ensure_buf(ctx, ctx->cand[LIST_XY], bytes);
+            if (!rc_c) rc_c = ensure_buf(ctx, ctx->cand_xyb, bytes);
+            if (!rc_c) rc_c = ensure_buf(ctx, ctx->cand_cnt[LIST_XY], PROC_WAVES * sizeof(uint32_t));
+            if (!rc_c) rc_c = ensure_buf(ctx, ctx->cand_cnt_xyb, PROC_WAVES * sizeof(uint32_t));
+            if (!rc_c) {
+                a.cand = (uint2 *)ctx->cand[LIST_XY].p;
+                a.cand_cnt = (uint32_t *)ctx->cand_cnt[LIST_XY].p;
+                a.cand_b = (uint2 *)ctx->cand_xyb.p;
+                a.cand_cnt_b = (uint32_t *)ctx->cand_cnt_xyb.p;
+                a.cand_ck = nullptr;
+                ctx->ck_nblk[LIST_XY] = a.nblk;
+            } else {   // (an optimisation: without its memory the pass expands the tile list every time)
+                (void)hipGetLastError();
+                ctx->err = "";
+            }
+        }
     }
     if (mode == PROC_SELF && ctx->in_loop && ctx->use_async_self) {
         a.async_self = list == LIST_XX ? 1 : 2;
         a.tiles_b = (const TileEntry *)ctx->lists[list == LIST_XX ? LIST_XXB : LIST_YYB].a.p;
+        // (head mode: candidate records for both buffers of the self lists too, see the xy list above)
+        const bool no_cand = getenv("CVO_HIP_NO_CAND") != nullptr || getenv("CVO_HIP_NO_CAND_ASYNC") != nullptr ||
+                             getenv("CVO_HIP_NO_CAND_SELF") != nullptr;
+        if (ctx->plan_recording && ctx->lone && ctx->allow_head && !multi_rank(ctx) && !no_cand && a.kept_packed &&
+            !(ctx->prm.color_scale > 0.0f)) {
+            const int l = list == LIST_XX ? 0 : 1;
+            const size_t bytes = (size_t)ctx->lists[LIST_KEPT].cap * sizeof(uint2);
+            int rc_c = ensure_buf(ctx, ctx->cand[list], bytes);
+            if (!rc_c) rc_c = ensure_buf(ctx, ctx->cand_sfb[l], bytes);
+            if (!rc_c) rc_c = ensure_buf(ctx, ctx->cand_cnt[list], PROC_WAVES * sizeof(uint32_t));
+            if (!rc_c) rc_c = ensure_buf(ctx, ctx->cand_cnt_sfb[l], PROC_WAVES * sizeof(uint32_t));
+            if (!rc_c) {
+                a.cand = (uint2 *)ctx->cand[list].p;
+                a.cand_cnt = (uint32_t *)ctx->cand_cnt[list].p;
+                a.cand_b = (uint2 *)ctx->cand_sfb[l].p;
+                a.cand_cnt_b = (uint32_t *)ctx->cand_cnt_sfb[l].p;
+                a.cand_ck = nullptr;
+                ctx->ck_nblk[list] = a.nblk;
+            } else {
+                (void)hipGetLastError();
+                ctx->err = "";
+            }
+        }
     }
     const bool twist = mode == PROC_STEP && ctx->merge_twist;
     if (twist) {
@@ -1659,7 +1707,7 @@ int cvo_hip_destroy(cvo_hip_ctx *ctx)
                     (void *)ctx->moving.feat, (void *)ctx->fixed.seg, (void *)ctx->moving.seg,
                     (void *)ctx->scratch_a.pos, (void *)ctx->scratch_a.feat, (void *)ctx->scratch_a.seg,
                     (void *)ctx->scratch_b.pos, (void *)ctx->scratch_b.feat, (void *)ctx->scratch_b.seg, (void *)ctx->st, (void *)ctx->st2, ctx->part_flow.p, ctx->part_xx.p,
-                    ctx->part_yy.p, ctx->part_step.p, (void *)ctx->trace_dev, ctx->kept_cnt.p, ctx->pos_bt.p, ctx->cand[0].p, ctx->cand[1].p, ctx->cand[2].p, ctx->cand_ck[0].p, ctx->cand_ck[1].p, ctx->cand_ck[2].p, ctx->cand_cnt[0].p,
+                    ctx->part_yy.p, ctx->part_step.p, (void *)ctx->trace_dev, ctx->kept_cnt.p, ctx->pos_bt.p, ctx->cand[0].p, ctx->cand[1].p, ctx->cand[2].p, ctx->cand_ck[0].p, ctx->cand_ck[1].p, ctx->cand_ck[2].p, ctx->cand_xyb.p, ctx->cand_cnt_xyb.p, ctx->cand_sfb[0].p, ctx->cand_sfb[1].p, ctx->cand_cnt_sfb[0].p, ctx->cand_cnt_sfb[1].p, ctx->cand_cnt[0].p,
                     ctx->cand_cnt[1].p, ctx->cand_cnt[2].p})
         if (p) (void)hipFree(p);
     for (int l = 0; l < LIST_N; ++l) {

@@ -172,12 +172,15 @@ struct alignas(16) DevHead {
     // `stall`: no buffer is valid, the slot only builds.
     int32_t xy_active, xy_target, stall, xy_fresh;
     int32_t xy_ok[2];
+    int32_t xy_ck[2];           // candidate record of xy buffer b (ProcessArgs::cand / cand_b): recorded by a flow pass of this
+                                // many blocks over the buffer as it stands; 0 = none (head mode, where the list is double-buffered)
     float xy_r[2];
     float tauf_build, xy_pad_;
     float xy_Rt[2][9], xy_t[2][3];
     // the same for the two self lists of acvo (rigid: only the radius matters), [l][buffer]
     int32_t sf_active[2], sf_target[2], sf_fresh[2];
     int32_t sf_ok[2][2];
+    int32_t sf_ck[2][2];        // candidate records of the self lists' buffers, as xy_ck
     float sf_r[2][2];
     float sf_tauf_build[2];
     cvo_math::XiConsts xi;      // twist constants for the step-size pass
@@ -288,6 +291,8 @@ struct ProcessArgs {
     float *cand_ck;        // clouds of more than 65536 rows: the record is 12 bytes wide -- cand[] = (i, j), cand_ck[] = the
                            // colour weight -- else null: 8 bytes, cand[] = (i | j << 16, the weight's bits)
     uint32_t *cand_cnt;    // [PROC_WAVES] candidates recorded by each wave
+    uint2 *cand_b;         // head mode (double-buffered xy list): the record of the second buffer (8-byte form only) ...
+    uint32_t *cand_cnt_b;  // ... DevHead::xy_ck[b] says whether buffer b's record matches its tile list
     int need_d2;           // PROC_FLOW: accumulate sum (1/l^3 a) d2 (acvo's dl term; cvo_hip_flow reports it for both modes)
     int kept_packed;       // both clouds have <= 65536 rows: a kept entry is 8 bytes (i | j << 16, weight bits)
                            // in kept_ij alone instead of 8 + 4 -- the kept list is the largest HBM stream of a
@@ -554,8 +559,8 @@ CVO_HD void plan_xy_async(DevHead *s, DevHead *bulk, const bool store, const Dev
         const float r = (float)(r0 * (1.0 + margin) * 1.000001);   // rounded up
         // tauf[LIST_XY] of compute_filter_bounds is tau + rounding slack: widen tau
         s->tauf_build = (float)(((double)r * (double)r + ((double)s->tauf[LIST_XY] - (double)s->kc.tau)) * 1.000001 + 1e-12);
-        if (tgt == 0) { s->xy_ok[0] = 0; s->xy_r[0] = r; }
-        else { s->xy_ok[1] = 0; s->xy_r[1] = r; }
+        if (tgt == 0) { s->xy_ok[0] = 0; s->xy_ck[0] = 0; s->xy_r[0] = r; }   // (a new tile list: its candidate record is void)
+        else { s->xy_ok[1] = 0; s->xy_ck[1] = 0; s->xy_r[1] = r; }
         if (store) {
             float *dR = tgt == 0 ? bulk->xy_Rt[0] : bulk->xy_Rt[1], *dt = tgt == 0 ? bulk->xy_t[0] : bulk->xy_t[1];
             for (int q = 0; q < 9; ++q) dR[q] = s->Rt[q];
@@ -598,8 +603,8 @@ template <int L> CVO_HD void plan_self_async_one(DevHead *s, const DevParams &p,
         s->sf_target[L] = tgt;
         const float r = (float)(r0 * (1.0 + margin) * 1.000001);
         s->sf_tauf_build[L] = (float)(((double)r * (double)r + ((double)s->tauf[LIST_XX + L] - (double)s->kc.tau)) * 1.000001 + 1e-12);
-        if (tgt == 0) { s->sf_ok[L][0] = 0; s->sf_r[L][0] = r; }
-        else { s->sf_ok[L][1] = 0; s->sf_r[L][1] = r; }
+        if (tgt == 0) { s->sf_ok[L][0] = 0; s->sf_ck[L][0] = 0; s->sf_r[L][0] = r; }
+        else { s->sf_ok[L][1] = 0; s->sf_ck[L][1] = 0; s->sf_r[L][1] = r; }
     }
 }
 

@@ -659,8 +659,10 @@ struct ProcHead {
     int n_fixed;
     int second;                    // the pass reads the second buffer of its (asynchronous) tile list
     unsigned list_bad;             // the list the pass consumes overflowed while it was written
-    int ck_nblk;                   // DevState::ck_nblk of the pass's tile list
+    int ck_nblk;                   // DevState::ck_nblk of the pass's tile list (head mode: xy_ck of the buffer in use)
     int par;                       // row of DevState::ovf this launch flags overflows in
+    uint2 *cand;                   // the candidate record of the list (buffer) the pass reads, its per-wave counts
+    uint32_t *cand_cnt;
 };
 
 template <int MODE>
@@ -685,6 +687,7 @@ __device__ __forceinline__ ProcHead proc_head_global(const ProcessArgs &a, const
     h.list_bad = ahead ? 0u : a.st->ovf[par][MODE == PROC_STEP ? (int)LIST_KEPT : a.list];
     h.ck_nblk = st->ck_nblk[a.list];
     h.par = par;
+    h.cand = a.cand; h.cand_cnt = a.cand_cnt;
     return h;
 }
 
@@ -838,8 +841,8 @@ __device__ __forceinline__ bool expand_lists(const ProcessArgs &a, const ProcHea
             if (REC) {   // every candidate goes on record, at the place the wave met it (its colour weight with it)
                 if (co + (unsigned)cnt <= a.kept_wcap) {
                     if (lane < cnt) {
-                        if (a.cand_ck) { a.cand[kbase + co + lane] = pr; a.cand_ck[kbase + co + lane] = ck; }
-                        else a.cand[kbase + co + lane] = make_uint2(pr.x | (pr.y << 16), __float_as_uint(ck));
+                        if (a.cand_ck) { hd.cand[kbase + co + lane] = pr; a.cand_ck[kbase + co + lane] = ck; }
+                        else hd.cand[kbase + co + lane] = make_uint2(pr.x | (pr.y << 16), __float_as_uint(ck));
                     }
                 } else if (lane == 0) {
                     atomicOr(&a.st->ovf[hd.par][LIST_KEPT], 1u);   // slice full: grow and redo
@@ -910,7 +913,7 @@ __device__ __forceinline__ bool expand_lists(const ProcessArgs &a, const ProcHea
         }   // sub-lists of this block
         if (qn > 0) run_batch(0, qn);
         if (MODE == PROC_FLOW && lane == 0) a.kept_cnt[wave] = nk;
-        if (REC && lane == 0) a.cand_cnt[wave] = co;
+        if (REC && lane == 0) hd.cand_cnt[wave] = co;
         // the member count of the wave joins the sums (one lane holds it; a slice that overflowed still counts)
         if (lane == 0) acc[MODE == PROC_FLOW ? 8 : 1] = (double)nk;
         return true;
@@ -925,9 +928,9 @@ __device__ __forceinline__ bool stream_candidates(const ProcessArgs &a, const Pr
                                                   double (&acc)[NAcc<MODE>::n])
 {
     const size_t base = (size_t)wave * a.kept_wcap;
-    unsigned n = a.cand_cnt[wave];
+    unsigned n = hd.cand_cnt[wave];
     const bool wide = a.cand_ck != nullptr;   // (12-byte records: clouds of more than 65536 rows)
-    uint2 e = a.cand[base + lane];
+    uint2 e = hd.cand[base + lane];
     float ckv = wide ? a.cand_ck[base + lane] : 0.0f;
     if (done_word != 0) return false;
     if (n > a.kept_wcap) n = a.kept_wcap;
@@ -935,7 +938,7 @@ __device__ __forceinline__ bool stream_candidates(const ProcessArgs &a, const Pr
     for (unsigned b0 = 0; b0 < n; b0 += 64u) {
         if (b0 != 0u) {
             const size_t at = base + min(b0 + (unsigned)lane, a.kept_wcap - 1u);
-            e = a.cand[at];
+            e = hd.cand[at];
             if (wide) ckv = a.cand_ck[at];
         }
         const unsigned ci = wide ? e.x : (e.x & 0xffffu), cj = wide ? e.y : (e.x >> 16);
@@ -1010,7 +1013,9 @@ __device__ __forceinline__ void process_body(const ProcessArgs &a, const unsigne
         }
     } else {
         bool alive;
-        if (CAND && WEIGHT == 0 && a.cand && !a.async_xy && !a.async_self) {
+        // (lists built ahead: only the xy list of a head-mode plan keeps records, one per buffer -- cand_b)
+        if (CAND && WEIGHT == 0 && hd.cand && (MODE == PROC_FLOW ? (!a.async_xy || a.cand_b != nullptr)
+                                                                 : (!a.async_self || a.cand_b != nullptr))) {
             if (hd.ck_nblk == a.nblk) alive = stream_candidates<MODE>(a, hd, kc, lane, wave, done_word, s_etab, acc);
             else alive = expand_lists<MODE, WEIGHT, WEIGHT == 0 ? 1 : 0>(a, hd, kc, bid, wid, lane, wave, done_word, list_bad, in_list, in_tiles, first_counted, s_etab, pairq_all, acc);
         } else {
@@ -1546,6 +1551,13 @@ __device__ __forceinline__ void head_math(DevHead *lds, const PostStepArgs &a, c
                             : (HM == HM_CLASSIC && stalled && flag[LIST_YY] != 0u);
     // (this iteration's flow pass has recorded or streamed the candidate list: it matches the tile list --
     // until plan_lists schedules a rebuild)
+    // head mode: the flow pass of the slot that ended has recorded (or streamed) the candidates of the xy buffer
+    // it read -- a.ck_nblk[LIST_XY] blocks, unless its slice of the record overflowed
+    const int xy_ck_done = (HM == HM_HEAD && run_post && a.ck_nblk[LIST_XY] != 0 && flag[LIST_KEPT] == 0u) ? a.ck_nblk[LIST_XY] : 0;
+    const int xy_ck_buf = lds->xy_active ? 1 : 0;
+    const int sf_ck_done[2] = {(HM == HM_HEAD && run_post && flag[LIST_KEPT] == 0u) ? a.ck_nblk[LIST_XX] : 0,
+                               (HM == HM_HEAD && run_post && flag[LIST_KEPT] == 0u) ? a.ck_nblk[LIST_YY] : 0};
+    const int sf_ck_buf[2] = {lds->sf_active[0] ? 1 : 0, lds->sf_active[1] ? 1 : 0};
     bool ck_ok[3] = {false, false, false};
     if (HM == HM_CLASSIC && run_post && flag[LIST_KEPT] == 0u) {
 #pragma unroll
@@ -1655,6 +1667,10 @@ __device__ __forceinline__ void head_math(DevHead *lds, const PostStepArgs &a, c
             for (int l = 0; l < 3; ++l)
                 if (ck_ok[l]) L.ck_nblk[l] = a.ck_nblk[l];
         }
+        if (xy_ck_done) { if (xy_ck_buf) L.xy_ck[1] = xy_ck_done; else L.xy_ck[0] = xy_ck_done; }
+#pragma unroll
+        for (int l = 0; l < 2; ++l)
+            if (sf_ck_done[l]) { if (sf_ck_buf[l]) L.sf_ck[l][1] = sf_ck_done[l]; else L.sf_ck[l][0] = sf_ck_done[l]; }
         // (lane 0 alone stores through `bulk`; the other lanes compute the same values and drop them)
         prepare_iteration(&L, lds, lane0, p, pb);
         // the list built beside the slot that ended overflowed: the iteration itself was fine and is
@@ -1672,9 +1688,10 @@ __device__ __forceinline__ void head_math(DevHead *lds, const PostStepArgs &a, c
             lds->tauf_build = L.tauf_build;
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
-                lds->xy_ok[q] = L.xy_ok[q]; lds->xy_r[q] = L.xy_r[q];
+                lds->xy_ok[q] = L.xy_ok[q]; lds->xy_ck[q] = L.xy_ck[q]; lds->xy_r[q] = L.xy_r[q];
                 lds->sf_active[q] = L.sf_active[q]; lds->sf_target[q] = L.sf_target[q]; lds->sf_fresh[q] = L.sf_fresh[q];
                 lds->sf_ok[q][0] = L.sf_ok[q][0]; lds->sf_ok[q][1] = L.sf_ok[q][1];
+                lds->sf_ck[q][0] = L.sf_ck[q][0]; lds->sf_ck[q][1] = L.sf_ck[q][1];
                 lds->sf_r[q][0] = L.sf_r[q][0]; lds->sf_r[q][1] = L.sf_r[q][1];
                 lds->sf_tauf_build[q] = L.sf_tauf_build[q];
             }
@@ -1798,9 +1815,11 @@ __global__ void k_prepare(DevState *st, const DevParams prm)
         }
         for (int l = 0; l < 2; ++l) {      // async self lists: nothing built yet
             st->sf_ok[l][0] = st->sf_ok[l][1] = 0;
+            st->sf_ck[l][0] = st->sf_ck[l][1] = 0;
             st->sf_active[l] = 0; st->sf_target[l] = -1; st->sf_fresh[l] = -1;
         }
         st->xy_ok[0] = st->xy_ok[1] = 0;   // async xy: the first slot only builds
+        st->xy_ck[0] = st->xy_ck[1] = 0;
         st->xy_active = 0;
         st->xy_target = -1;
         st->xy_fresh = -1;
@@ -2013,6 +2032,14 @@ __device__ __forceinline__ ProcHead proc_head_lds(const ProcessArgs &a, const De
     hd.list_bad = 0u;   // (lists built ahead are only switched to after their flag was seen clear)
     hd.ck_nblk = 0;
     hd.par = par;
+    hd.cand = nullptr; hd.cand_cnt = nullptr;
+    if (a.cand_b) {   // the record of the buffer in use (xy list; acvo: xx / yy)
+        const int l = a.async_self == 2 ? 1 : 0;
+        const int ck = MODE == PROC_FLOW ? (hd.second ? h->xy_ck[1] : h->xy_ck[0]) : (hd.second ? h->sf_ck[l][1] : h->sf_ck[l][0]);
+        hd.ck_nblk = __builtin_amdgcn_readfirstlane(ck);
+        hd.cand = hd.second ? a.cand_b : a.cand;
+        hd.cand_cnt = hd.second ? a.cand_cnt_b : a.cand_cnt;
+    }
     return hd;
 }
 
@@ -2036,7 +2063,7 @@ __device__ __forceinline__ ProcHead proc_head_lds(const ProcessArgs &a, const De
         if (!head_body<HM_HEAD>(ps, par ? ps.st2 : ps.st, par ? ps.st : ps.st2, &s_st, sh, par,            \
                                 blockIdx.x == 0)) return;                                                  \
         float rt[12];                                                                                      \
-        process_body<PROC_FLOW, 0, false>(pa, blockIdx.x, smem, proc_head_lds<PROC_FLOW>(pa, &s_st, par, rt)); \
+        process_body<PROC_FLOW, 0, true>(pa, blockIdx.x, smem, proc_head_lds<PROC_FLOW>(pa, &s_st, par, rt)); \
         if (ps.dbg && blockIdx.x == 0 && threadIdx.x == 0 && ps.dbg[6] != 0) {   /* block 0: head + flow pass */ \
             ps.dbg[7] += (long long)__builtin_readcyclecounter() - ps.dbg[6];                              \
             ps.dbg[6] = 0;                                                                                 \
@@ -2069,10 +2096,10 @@ __device__ __forceinline__ ProcHead proc_head_lds(const ProcessArgs &a, const De
                                 blockIdx.x == 0)) return;                                                  \
         float rt[12];                                                                                      \
         if (role == 0) {                                                                                   \
-            process_body<PROC_FLOW, 0, false>(pa, rb, smem, proc_head_lds<PROC_FLOW>(pa, &s_st, par, rt)); \
+            process_body<PROC_FLOW, 0, true>(pa, rb, smem, proc_head_lds<PROC_FLOW>(pa, &s_st, par, rt));  \
             return;                                                                                        \
         }                                                                                                  \
-        process_body<PROC_SELF, 0, false>(pa, rb, smem, proc_head_lds<PROC_SELF>(pa, &s_st, par, rt));     \
+        process_body<PROC_SELF, 0, true>(pa, rb, smem, proc_head_lds<PROC_SELF>(pa, &s_st, par, rt));      \
     }
 CVO_HEAD_KERNELS(_w4, 4)
 
