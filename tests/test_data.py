@@ -172,3 +172,28 @@ def test_no_grid_anchoring_explains_the_recorded_matlab_run():
     assert abs(min(worst) - d["best_worst_pair_residual"]) < 1e-12 and 2.5e-3 < min(worst) < 3e-3
     assert max(worst) < 8e-3
     assert not any(max(r["residual_per_pair"]) < 1.5e-3 for r in rows)
+
+
+def test_matlab_prep_oracle_known_answers():
+    """oracle/matlab_prep.py (what the GPU's cvo_hip_range_filter_grid_average is held to) on inputs whose
+    answers can be written down: ref util/pcRangeFilter.m:5-12 keeps min_range <= |p| <= max_range; the grid
+    average of ref rgbddataset_rkhs.m:36-39 is one mean point and one mean colour per occupied voxel, voxels
+    anchored at the minimum corner and ordered lexicographically in (x, y, z)."""
+    import numpy as np
+    from oracle import matlab_prep as mp
+    xyz = np.array([[0, 0, 0.5], [0, 0, 0.8], [0, 3, 4.0], [0, 0, 5.0], [1, 1, 1]], np.float32)   # ranges .5 .8 5 5 1.73
+    rgb = (np.arange(15).reshape(5, 3) * 10).astype(np.uint8)
+    fx, fc = mp.pc_range_filter(xyz, rgb, 4.0, 0.8)
+    assert fx.tolist() == [[0, 0, 0.8], [1, 1, 1]] or np.allclose(fx, [[0, 0, 0.8], [1, 1, 1]])
+    assert fc.tolist() == [[30, 40, 50], [120, 130, 140]]
+    pts = np.array([[0.00, 0.00, 0.00], [0.04, 0.04, 0.04],      # voxel (0, 0, 0)
+                    [0.06, 0.00, 0.00],                          # voxel (1, 0, 0)
+                    [0.00, 0.00, 0.11], [0.01, 0.02, 0.14]],     # voxel (0, 0, 2)
+                   np.float32)
+    col = np.array([[10, 20, 30], [11, 21, 31], [200, 0, 0], [0, 100, 0], [0, 101, 255]], np.uint8)
+    gx, gc = mp.grid_average(pts, col, 0.05)
+    assert gx.shape == (3, 3)
+    assert np.allclose(gx, [[0.02, 0.02, 0.02], [0.005, 0.01, 0.125], [0.06, 0.0, 0.0]], atol=1e-7)   # (0,0,0) < (0,0,2) < (1,0,0)
+    assert gc.tolist() == [[11, 21, 31], [0, 101, 128], [200, 0, 0]]      # floor(mean + 0.5): 10.5 -> 11, 100.5 -> 101, 127.5 -> 128
+    e = mp.grid_average(np.zeros((0, 3), np.float32), np.zeros((0, 3), np.uint8))
+    assert e[0].shape == (0, 3) and e[1].shape == (0, 3)
