@@ -2117,8 +2117,17 @@ int job_begin(AlignJob &j)
     // a quarter of the blocks per pass do (measured one registration at a time, 1024 / 512 / 256 / 128 blocks per
     // pass: 10k x 10k 390 / 461 / 499 / - registrations/s with the post-step launch, - / 417 / 537 / 499 in head
     // mode; 3k x 3k - / 543 / 619 / - and - / 473 / 703 / 749 -- profiles/r03_ab.txt)
-    if (ctx->use_async_self && !ctx->proc_blocks_forced)
-        ctx->proc_blocks = ctx->proc_blocks_default = small_pair ? PROC_BLOCKS / 8 : PROC_BLOCKS / 4;
+    const double npairs = (double)ctx->fixed.n * (double)ctx->moving.n;
+    if (ctx->use_async_self && !ctx->proc_blocks_forced)   // (6k x 6k: 128 / 256 blocks 750 / 700; 14k x 14k 510 / 568)
+        ctx->proc_blocks = ctx->proc_blocks_default = npairs <= 6.0e7 ? PROC_BLOCKS / 8 : PROC_BLOCKS / 4;
+    // cvo in head mode: every block of the flow launch starts with the head, and with the candidate records the
+    // pass behind it is short -- fewer, longer blocks (us per iteration with 256 / 512 / 1024 blocks per pass:
+    // 2k x 2k 18.4 / 18.9 / 20.4, 4.5k 19.3 / 19.5 / 22.3, 6k 21.4 / 20.9 / 23.0, 8k 27.2 / 24.7 / 26.6,
+    // 10k 31.6 / 26.5 / 26.7, 14k 34.8 / 28.5 / 27.6 -- profiles/r03_ab.txt 17)
+    if (!ctx->proc_blocks_forced && !ctx->use_async_self && ctx->use_async && ctx->lone && ctx->allow_head &&
+        ctx->prm.mode == CVO_HIP_MODE_CVO)
+        ctx->proc_blocks = ctx->proc_blocks_default =
+            npairs <= 2.5e7 ? PROC_BLOCKS / 4 : (npairs <= 1.5e8 ? PROC_BLOCKS / 2 : PROC_BLOCKS);
     launch_prepare(ctx->st, loop_params(ctx), loop_stream(ctx));
     HIP_TRY(ctx, hipGetLastError());
     ctx->have_tf = true;
