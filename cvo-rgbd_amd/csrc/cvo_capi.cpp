@@ -916,6 +916,11 @@ DevParams loop_params(const cvo_hip_ctx *ctx)
         dp.list_margin = ((double)ctx->fixed.n * (double)ctx->moving.n <= 2.0e8) ? 0.25f : 0.15f;
     dp.async_xy = ctx->use_async ? 1 : 0;
     dp.async_self = ctx->use_async_self ? 1 : 0;
+    // Head mode: a build is named a slot earlier than it is made and costs its launch 10 us; later is better
+    // (0.7 / 0.85 / 0.9 / 0.95 of the margin gone: 10k x 10k 711 / 728 / 733 / 732 registrations/s, 14k 432 / 444 / 445 /
+    // 444, 6k 694 / 694 / 706 / 705, 3k 788 / 794 / 792 / 792; profiles/r03_ab.txt 18)
+    const bool build_at_set = getenv("CVO_HIP_BUILD_AT") != nullptr;
+    if (!build_at_set && ctx->use_async && ctx->lone && ctx->allow_head && !multi_rank(ctx)) dp.build_at = 0.9f;
     return dp;
 }
 
