@@ -1355,6 +1355,10 @@ __device__ __forceinline__ double section_root_wave(const cvo_math::CubicBracket
     double lo = B.lo, hi = B.hi;
     for (int round = 0; round < 64; ++round) {
         if ((float)lo == (float)hi) break;
+        if (round == 1) {   // (wave-uniform: every lane holds the same bracket)
+            double r;
+            if (cvo_math::section_shortcut(B, lo, hi, &r)) return r;
+        }
         const double w = hi - lo;
         const double x = cvo_math::section_point(lo, w, lane);
         const bool inside = x > lo && x < hi;
