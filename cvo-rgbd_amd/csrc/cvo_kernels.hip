@@ -1907,11 +1907,29 @@ __global__ void __launch_bounds__(BLOCK) kt_self2(const Slot *__restrict__ tab, 
 // (head mode, qp & QP_HEAD: the slot runs on the copy of the head its flow launch wrote)
 __global__ void __launch_bounds__(STEP_BLOCK) kt_step_twist(const Slot *__restrict__ tab, const int qp)
 {
-    CVO_SLOT(tab);
+    CSlot cs = (CSlot)(tab) + blockIdx.z;
     const int q = qp & QP_MASK, par = (qp & QP_PARITY) ? 1 : 0;
     const bool head_mode = (qp & QP_HEAD) != 0;
     const ProcessArgs &a = CVO_ARG(ProcessArgs, op[q].p);
-    step_twist_body(a, head_mode ? (par ? a.st : a.st2) : a.st, par, head_mode);
+    // The words of the table a block needs before it can request any data are asked for TOGETHER with the
+    // slot's switch (the table is read through the scalar cache, and every dependent read of it is a round
+    // trip of its own: switch -> block count -> state address -> state was four in a row; the empty asm
+    // pins the requests in front of the first branch).
+    {
+        const int active = cs->active;
+        const int nblk = a.nblk, check_done = a.check_done, async_xy = a.async_xy, packed = a.kept_packed;
+        const unsigned wcap = a.kept_wcap;
+        const DevState *st = a.st, *st2 = a.st2;
+        const double *fp = a.flow_part;
+        const uint32_t *kc = a.kept_cnt;
+        const uint2 *kij = a.kept_ij;
+        const float *ka = a.kept_a;
+        asm volatile("" ::"s"(active), "s"(nblk), "s"(check_done), "s"(async_xy), "s"(packed), "s"(wcap), "s"(st), "s"(st2),
+                     "s"(fp), "s"(kc), "s"(kij), "s"(ka));
+        if (active == 0) return;
+    }
+    DevState *const st_a = a.st, *const st_b = a.st2;   // (both already here: a select of values, not of addresses to read)
+    step_twist_body(a, head_mode ? (par ? st_a : st_b) : st_a, par, head_mode);
 }
 
 __global__ void __launch_bounds__(BLOCK) kt_post_flow(const Slot *__restrict__ tab, const int q)
@@ -2047,6 +2065,20 @@ __device__ __forceinline__ ProcHead proc_head_lds(const ProcessArgs &a, const De
     return hd;
 }
 
+// CVO_SLOT for the head-mode launches: the slot's switch, the role boundary and the words of the head's
+// argument block that stand in front of its first data request, asked for together (see kt_step_twist)
+#define CVO_SLOT_HEAD(tab)                                                                                    \
+    CSlot cs = (CSlot)(tab) + blockIdx.z;                                                                     \
+    const int q = qp & QP_MASK, par = (qp & QP_PARITY) ? 1 : 0;                                               \
+    {                                                                                                         \
+        const PostStepArgs &hps = CVO_ARG(PostStepArgs, op[q].ps);                                            \
+        const int active = cs->active, np_ = cs->op[q].np, hn = hps.nblk, hcd = hps.check_done;               \
+        const DevState *hst = hps.st, *hst2 = hps.st2;                                                        \
+        const double *hpart = hps.part_step;                                                                  \
+        const long long *hdbg = hps.dbg;                                                                      \
+        asm volatile("" ::"s"(active), "s"(np_), "s"(hn), "s"(hcd), "s"(hst), "s"(hst2), "s"(hpart), "s"(hdbg)); \
+        if (active == 0) return;                                                                              \
+    }
 #define CVO_HEAD_KERNELS(SUFFIX, WAVES)                                                                    \
     __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WAVES, 8)))               \
     kt_hflow_build##SUFFIX(const Slot *__restrict__ tab, const int qp)                                     \
@@ -2054,8 +2086,7 @@ __device__ __forceinline__ ProcHead proc_head_lds(const ProcessArgs &a, const De
         extern __shared__ __attribute__((aligned(16))) char smem[];                                        \
         __shared__ double sh[4 * NACC_MAX];                                                                \
         __shared__ __attribute__((aligned(16))) DevHead s_st;                                              \
-        CVO_SLOT(tab);                                                                                     \
-        const int q = qp & QP_MASK, par = (qp & QP_PARITY) ? 1 : 0;                                        \
+        CVO_SLOT_HEAD(tab);                                                                                \
         const int np = cs->op[q].np;                                                                       \
         if ((int)blockIdx.x >= np) {                                                                       \
             const FilterArgs &f = CVO_ARG(FilterArgs, op[q].f);                                            \
@@ -2079,8 +2110,7 @@ __device__ __forceinline__ ProcHead proc_head_lds(const ProcessArgs &a, const De
         extern __shared__ __attribute__((aligned(16))) char smem[];                                        \
         __shared__ double sh[4 * NACC_MAX];                                                                \
         __shared__ __attribute__((aligned(16))) DevHead s_st;                                              \
-        CVO_SLOT(tab);                                                                                     \
-        const int q = qp & QP_MASK, par = (qp & QP_PARITY) ? 1 : 0;                                        \
+        CVO_SLOT_HEAD(tab);                                                                                \
         int b = (int)blockIdx.x;                                                                           \
         const int np = cs->op[q].np;                                                                       \
         if (b >= 3 * np) {                                                                                 \
