@@ -400,27 +400,30 @@ CVO_HD KernConsts make_kconsts(const DevParams &p, float ell)
 // `identity` = the moving cloud is used untransformed (function_inner_product).
 CVO_HD void compute_filter_bounds(DevHead *s, bool identity)
 {
+    // (float32 throughout, as all of the plan below: these are bounds with 1e-6 ... 1e-4 of slack, worked out on
+    // the ONE chain of the post-step part, where a float64 operation waits twice as long for its operands as a
+    // float32 one and a float64 square root is ~25 dependent instructions instead of one; ~20 float32 operations
+    // in a row are good to 2e-6 relative)
     float ymax = s->y0max;
     if (!identity) {
         // |R^T (p - T) - c| = |(p - c) - (T + R c - c)| <= |p - c| + |T + (R - I) c|
         const float *R = s->R, *c = s->center;
-        double sh2 = 0.0;
+        float sh2 = 0.0f;
         for (int r = 0; r < 3; ++r) {
-            const double rc = (double)R[3 * r] * c[0] + (double)R[3 * r + 1] * c[1] +
-                              (double)R[3 * r + 2] * c[2];
-            const double d = (double)s->T[r] + rc - (double)c[r];
+            const float rc = R[3 * r] * c[0] + R[3 * r + 1] * c[1] + R[3 * r + 2] * c[2];
+            const float d = s->T[r] + rc - c[r];
             sh2 += d * d;
         }
-        ymax = (float)(((double)s->y0max + sqrt(sh2)) * 1.0001 + 1e-6);
+        ymax = (s->y0max + sqrtf(sh2)) * 1.0001f + 1e-6f;
     }
-    const double u16 = 16.0 / 16777216.0;
-    const double sxy = ((double)s->xmax + ymax) * ((double)s->xmax + ymax);
-    const double sxx = 4.0 * (double)s->xmax * s->xmax;
-    const double syy = 4.0 * (double)ymax * ymax;
-    const double tau = (double)s->kc.tau;
-    s->tauf[LIST_XY] = (float)((tau + u16 * sxy) * 1.000001 + 1e-12);
-    s->tauf[LIST_XX] = (float)((tau + u16 * sxx) * 1.000001 + 1e-12);
-    s->tauf[LIST_YY] = (float)((tau + u16 * syy) * 1.000001 + 1e-12);
+    const float u16 = 16.0f / 16777216.0f;
+    const float sxy = (s->xmax + ymax) * (s->xmax + ymax);
+    const float sxx = 4.0f * s->xmax * s->xmax;
+    const float syy = 4.0f * ymax * ymax;
+    const float tau = s->kc.tau;
+    s->tauf[LIST_XY] = (tau + u16 * sxy) * 1.000001f;
+    s->tauf[LIST_XX] = (tau + u16 * sxx) * 1.000001f;
+    s->tauf[LIST_YY] = (tau + u16 * syy) * 1.000001f;
 }
 
 // Tile-list re-use.  k_filter is conservative and membership in A is decided by
@@ -434,29 +437,29 @@ CVO_HD void compute_filter_bounds(DevHead *s, bool identity)
 // than needed (after ell dropped) is rebuilt as well.  All slack terms are far
 // above the float32 rounding of the coordinates and of d2 (<= ~1e-5 m here) and
 // far below the margin (>= 1 mm at ell_min): decisions change performance only.
-constexpr double LIST_LOOSE = 1.3;
+constexpr float LIST_LOOSE = 1.3f;
 // (`bulk`: where the transform records and the kernel constants are stored -- the state itself; the post
 // kernels run the plan on a private copy in registers, every lane of a wave the same, and send these few
 // large, rarely written fields straight to the shared copy instead of carrying them along: `store` =
 // this lane does)
-CVO_HD void plan_lists(DevHead *s, DevHead *bulk, const bool store, const DevParams &p, const double r_now)
+CVO_HD void plan_lists(DevHead *s, DevHead *bulk, const bool store, const DevParams &p, const float r_now)
 {
-    const double ymax = (double)s->y0max;
-    const double slack = 1.0e-4 * (1.0 + (double)s->xmax + ymax);
-    const double margin = (double)p.list_margin;
-    double travel = 0.0;
+    const float ymax = s->y0max;
+    const float slack = 1.0e-4f * (1.0f + s->xmax + ymax);
+    const float margin = p.list_margin;
+    float travel = 0.0f;
     if (s->list_ok[LIST_XY] && !p.async_xy) {
-        double f2 = 0.0, c2 = 0.0;
+        float f2 = 0.0f, c2 = 0.0f;
         for (int r = 0; r < 3; ++r) {
-            double dc = (double)s->t[r] - (double)s->list_t[r];
+            float dc = s->t[r] - s->list_t[r];
             for (int q = 0; q < 3; ++q) {
-                const double d = (double)s->Rt[3 * r + q] - (double)s->list_Rt[3 * r + q];
+                const float d = s->Rt[3 * r + q] - s->list_Rt[3 * r + q];
                 f2 += d * d;
-                dc += d * (double)s->center[q];
+                dc += d * s->center[q];
             }
             c2 += dc * dc;
         }
-        travel = sqrt(0.5 * f2) * 1.001 * ymax + sqrt(c2);
+        travel = sqrtf(0.5f * f2) * 1.001f * ymax + sqrtf(c2);
     }
 #pragma unroll
     for (int l = 0; l < 3; ++l) {
@@ -464,19 +467,18 @@ CVO_HD void plan_lists(DevHead *s, DevHead *bulk, const bool store, const DevPar
                                                     // tau + rounding slack: tauf_build is made from it)
         if (l != LIST_XY && p.async_self) continue; // planned by plan_self_async
         if (l != LIST_XY && p.mode != CVO_HIP_MODE_ACVO) { s->reuse[l] = 1; continue; }   // cvo has no self lists
-        const double need = (r_now + (l == LIST_XY ? travel : 0.0)) * 1.0001 + slack;
-        const double lr = (double)s->list_r[l];
-        const bool keep = margin > 0.0 && s->list_ok[l] && need <= lr &&
-                          lr <= LIST_LOOSE * (1.0 + margin) * (r_now * 1.0001 + slack);
+        const float need = (r_now + (l == LIST_XY ? travel : 0.0f)) * 1.0001f + slack;
+        const float lr = s->list_r[l];
+        const bool keep = margin > 0.0f && s->list_ok[l] && need <= lr &&
+                          lr <= LIST_LOOSE * (1.0f + margin) * (r_now * 1.0001f + slack);
         s->reuse[l] = keep ? 1 : 0;
         if (keep) continue;
         s->ck_nblk[l] = 0;   // a new tile list: the candidate list recorded from the old one is void
-        const double rb = (r_now * 1.0001 + slack) * (1.0 + margin);
-        s->list_r[l] = (float)(rb * 1.000001);   // rounded up: the list holds at least this radius
+        const float rb = (r_now * 1.0001f + slack) * (1.0f + margin);
+        s->list_r[l] = rb * 1.000001f;   // rounded up: the list holds at least this radius
         s->list_ok[l] = 1;
-        if (margin > 0.0)   // tauf of compute_filter_bounds is tau + rounding slack: widen tau
-            s->tauf[l] = (float)(((double)s->list_r[l] * (double)s->list_r[l] +
-                                  ((double)s->tauf[l] - (double)s->kc.tau)) * 1.000001 + 1e-12);
+        if (margin > 0.0f)   // tauf of compute_filter_bounds is tau + rounding slack: widen tau
+            s->tauf[l] = (s->list_r[l] * s->list_r[l] + (s->tauf[l] - s->kc.tau)) * 1.000001f;
         if (l == LIST_XY && store) {
             for (int q = 0; q < 9; ++q) bulk->list_Rt[q] = s->Rt[q];
             for (int q = 0; q < 3; ++q) bulk->list_t[q] = s->t[q];
@@ -502,53 +504,52 @@ CVO_HD void plan_lists(DevHead *s, DevHead *bulk, const bool store, const DevPar
 //     slot s + 3.  One build at a time: the buffers are two.
 // No dynamic indexing below: in the post kernels the state lives in registers.
 // (rec: where the transform records are read from -- the shared copy of the head, see `bulk` at plan_lists)
-template <int B> CVO_HD double xy_travel(const DevHead *s, const DevHead *rec)
+template <int B> CVO_HD float xy_travel(const DevHead *s, const DevHead *rec)
 {
-    double f2 = 0.0, c2 = 0.0;
+    float f2 = 0.0f, c2 = 0.0f;
     for (int r = 0; r < 3; ++r) {
-        double dc = (double)s->t[r] - (double)rec->xy_t[B][r];
+        float dc = s->t[r] - rec->xy_t[B][r];
         for (int q = 0; q < 3; ++q) {
-            const double d = (double)s->Rt[3 * r + q] - (double)rec->xy_Rt[B][3 * r + q];
+            const float d = s->Rt[3 * r + q] - rec->xy_Rt[B][3 * r + q];
             f2 += d * d;
-            dc += d * (double)s->center[q];
+            dc += d * s->center[q];
         }
         c2 += dc * dc;
     }
-    return sqrt(0.5 * f2) * 1.001 * (double)s->y0max + sqrt(c2);
+    return sqrtf(0.5f * f2) * 1.001f * s->y0max + sqrtf(c2);
 }
 
-CVO_HD void plan_xy_async(DevHead *s, DevHead *bulk, const bool store, const DevParams &p, const double r_now, const int fresh,
+CVO_HD void plan_xy_async(DevHead *s, DevHead *bulk, const bool store, const DevParams &p, const float r_now, const int fresh,
                           const bool fresh_failed, const int inflight)
 {
-    const double slack = 1.0e-4 * (1.0 + (double)s->xmax + (double)s->y0max);
-    const double margin = (double)p.list_margin;
-    const double r0 = r_now * 1.0001 + slack;   // radius needed with no travel
+    const float slack = 1.0e-4f * (1.0f + s->xmax + s->y0max);
+    const float margin = p.list_margin;
+    const float r0 = r_now * 1.0001f + slack;   // radius needed with no travel
     if (fresh == 0) s->xy_ok[0] = fresh_failed ? 0 : 1;   // the build that has just ended
     if (fresh == 1) s->xy_ok[1] = fresh_failed ? 0 : 1;
-    // (how far the cloud has travelled since a buffer was built: two float64 square roots each, on the
-    // one chain of the post kernels -- worked out for the buffer that is looked at first, the other
-    // one only if that fails)
+    // (how far the cloud has travelled since a buffer was built: worked out for the buffer that is looked
+    // at first, the other one only if that fails)
     const int act = s->xy_active ? 1 : 0;
     const int first = fresh >= 0 ? (fresh ? 1 : 0) : act;
-    double need0 = 0.0, need1 = 0.0;
+    float need0 = 0.0f, need1 = 0.0f;
     bool valid0 = false, valid1 = false;
-    if (first == 0) { need0 = s->xy_ok[0] ? (r_now + xy_travel<0>(s, bulk)) * 1.0001 + slack : 0.0; valid0 = s->xy_ok[0] && need0 <= (double)s->xy_r[0]; }
-    else { need1 = s->xy_ok[1] ? (r_now + xy_travel<1>(s, bulk)) * 1.0001 + slack : 0.0; valid1 = s->xy_ok[1] && need1 <= (double)s->xy_r[1]; }
+    if (first == 0) { need0 = s->xy_ok[0] ? (r_now + xy_travel<0>(s, bulk)) * 1.0001f + slack : 0.0f; valid0 = s->xy_ok[0] && need0 <= s->xy_r[0]; }
+    else { need1 = s->xy_ok[1] ? (r_now + xy_travel<1>(s, bulk)) * 1.0001f + slack : 0.0f; valid1 = s->xy_ok[1] && need1 <= s->xy_r[1]; }
     int use = -1;
     if (first ? valid1 : valid0) use = first;
     else {
-        if (first == 0) { need1 = s->xy_ok[1] ? (r_now + xy_travel<1>(s, bulk)) * 1.0001 + slack : 0.0; valid1 = s->xy_ok[1] && need1 <= (double)s->xy_r[1]; }
-        else { need0 = s->xy_ok[0] ? (r_now + xy_travel<0>(s, bulk)) * 1.0001 + slack : 0.0; valid0 = s->xy_ok[0] && need0 <= (double)s->xy_r[0]; }
+        if (first == 0) { need1 = s->xy_ok[1] ? (r_now + xy_travel<1>(s, bulk)) * 1.0001f + slack : 0.0f; valid1 = s->xy_ok[1] && need1 <= s->xy_r[1]; }
+        else { need0 = s->xy_ok[0] ? (r_now + xy_travel<0>(s, bulk)) * 1.0001f + slack : 0.0f; valid0 = s->xy_ok[0] && need0 <= s->xy_r[0]; }
         if (first ? valid0 : valid1) use = 1 - first;
     }
     s->stall = use < 0 ? 1 : 0;
     if (use >= 0) s->xy_active = use;
-    bool build = use < 0 || !(margin > 0.0);
+    bool build = use < 0 || !(margin > 0.0f);
     if (!build) {
-        const double lr = (double)(use ? s->xy_r[1] : s->xy_r[0]);
-        const double nd = use ? need1 : need0;
-        if (nd - r0 > (double)p.build_at * (lr - r0)) build = true;   // most of the margin is gone
-        if (lr > LIST_LOOSE * (1.0 + margin) * r0) build = true;     // far wider than needed
+        const float lr = use ? s->xy_r[1] : s->xy_r[0];
+        const float nd = use ? need1 : need0;
+        if (nd - r0 > p.build_at * (lr - r0)) build = true;   // most of the margin is gone
+        if (lr > LIST_LOOSE * (1.0f + margin) * r0) build = true;     // far wider than needed
     }
     if (inflight >= 0) build = false;   // (its buffer is the only one that is free)
     s->xy_fresh = inflight;
@@ -556,9 +557,9 @@ CVO_HD void plan_xy_async(DevHead *s, DevHead *bulk, const bool store, const Dev
     if (build) {
         const int tgt = use < 0 ? 0 : 1 - use;
         s->xy_target = tgt;
-        const float r = (float)(r0 * (1.0 + margin) * 1.000001);   // rounded up
+        const float r = r0 * (1.0f + margin) * 1.000001f;   // rounded up
         // tauf[LIST_XY] of compute_filter_bounds is tau + rounding slack: widen tau
-        s->tauf_build = (float)(((double)r * (double)r + ((double)s->tauf[LIST_XY] - (double)s->kc.tau)) * 1.000001 + 1e-12);
+        s->tauf_build = (r * r + (s->tauf[LIST_XY] - s->kc.tau)) * 1.000001f;
         if (tgt == 0) { s->xy_ok[0] = 0; s->xy_ck[0] = 0; s->xy_r[0] = r; }   // (a new tile list: its candidate record is void)
         else { s->xy_ok[1] = 0; s->xy_ck[1] = 0; s->xy_r[1] = r; }
         if (store) {
@@ -574,13 +575,13 @@ CVO_HD void plan_xy_async(DevHead *s, DevHead *bulk, const bool store, const Dev
 // depend on the transform -- so only ell ages them: a list built for radius
 // (1 + margin) r serves until r_now outgrows it; the next one is built ahead when
 // most of that room is gone or ell has dropped far below.
-template <int L> CVO_HD void plan_self_async_one(DevHead *s, const DevParams &p, const double r0, const double margin,
+template <int L> CVO_HD void plan_self_async_one(DevHead *s, const DevParams &p, const float r0, const float margin,
                                                  const int fresh, const bool fresh_failed, const int inflight)
 {
     if (fresh == 0) s->sf_ok[L][0] = fresh_failed ? 0 : 1;
     if (fresh == 1) s->sf_ok[L][1] = fresh_failed ? 0 : 1;
-    const bool valid0 = s->sf_ok[L][0] && r0 <= (double)s->sf_r[L][0];
-    const bool valid1 = s->sf_ok[L][1] && r0 <= (double)s->sf_r[L][1];
+    const bool valid0 = s->sf_ok[L][0] && r0 <= s->sf_r[L][0];
+    const bool valid1 = s->sf_ok[L][1] && r0 <= s->sf_r[L][1];
     const int act = s->sf_active[L] ? 1 : 0;
     int use = -1;
     if (fresh >= 0 && (fresh ? valid1 : valid0)) use = fresh ? 1 : 0;
@@ -588,12 +589,12 @@ template <int L> CVO_HD void plan_self_async_one(DevHead *s, const DevParams &p,
     else if (act ? valid0 : valid1) use = 1 - act;
     if (use < 0) s->stall = 1;
     else s->sf_active[L] = use;
-    bool build = use < 0 || !(margin > 0.0);
+    bool build = use < 0 || !(margin > 0.0f);
     if (!build) {
-        const double lr = (double)(use ? s->sf_r[L][1] : s->sf_r[L][0]);
-        const double built_for = lr / (1.0 + margin);              // the radius it was built around
-        if (r0 > built_for + (double)p.build_at * (lr - built_for)) build = true;
-        if (lr > LIST_LOOSE * (1.0 + margin) * r0) build = true;
+        const float lr = use ? s->sf_r[L][1] : s->sf_r[L][0];
+        const float built_for = lr / (1.0f + margin);              // the radius it was built around
+        if (r0 > built_for + p.build_at * (lr - built_for)) build = true;
+        if (lr > LIST_LOOSE * (1.0f + margin) * r0) build = true;
     }
     if (inflight >= 0) build = false;
     s->sf_fresh[L] = inflight;
@@ -601,8 +602,8 @@ template <int L> CVO_HD void plan_self_async_one(DevHead *s, const DevParams &p,
     if (build) {
         const int tgt = use < 0 ? 0 : 1 - use;
         s->sf_target[L] = tgt;
-        const float r = (float)(r0 * (1.0 + margin) * 1.000001);
-        s->sf_tauf_build[L] = (float)(((double)r * (double)r + ((double)s->tauf[LIST_XX + L] - (double)s->kc.tau)) * 1.000001 + 1e-12);
+        const float r = r0 * (1.0f + margin) * 1.000001f;
+        s->sf_tauf_build[L] = (r * r + (s->tauf[LIST_XX + L] - s->kc.tau)) * 1.000001f;
         if (tgt == 0) { s->sf_ok[L][0] = 0; s->sf_ck[L][0] = 0; s->sf_r[L][0] = r; }
         else { s->sf_ok[L][1] = 0; s->sf_ck[L][1] = 0; s->sf_r[L][1] = r; }
     }
@@ -657,14 +658,14 @@ CVO_HD void prepare_iteration(DevHead *s, DevHead *bulk, const bool store, const
         s->kc_ell = s->ell;
     }
     compute_filter_bounds(s, false);
-    const double r_now = sqrt((double)s->kc.tau);
+    const float r_now = sqrtf(s->kc.tau);
     plan_lists(s, bulk, store, p, r_now);
     if (p.async_xy) plan_xy_async(s, bulk, store, p, r_now, b.xy_fresh, b.xy_failed, b.xy_inflight);
     if (p.async_self) {   // (after the xy plan: it may add a stall)
-        const double slack = 1.0e-4 * (1.0 + (double)s->xmax + (double)s->y0max);
-        const double r0 = r_now * 1.0001 + slack;
-        plan_self_async_one<0>(s, p, r0, (double)p.list_margin, b.sf_fresh[0], b.sf_failed[0], b.sf_inflight[0]);
-        plan_self_async_one<1>(s, p, r0, (double)p.list_margin, b.sf_fresh[1], b.sf_failed[1], b.sf_inflight[1]);
+        const float slack = 1.0e-4f * (1.0f + s->xmax + s->y0max);
+        const float r0 = r_now * 1.0001f + slack;
+        plan_self_async_one<0>(s, p, r0, p.list_margin, b.sf_fresh[0], b.sf_failed[0], b.sf_inflight[0]);
+        plan_self_async_one<1>(s, p, r0, p.list_margin, b.sf_fresh[1], b.sf_failed[1], b.sf_inflight[1]);
     }
 }
 
