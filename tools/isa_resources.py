@@ -15,7 +15,7 @@ import tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "cvo-rgbd_amd", "csrc")
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-slp-vectorize", "-Wno-invalid-offsetof",
-         "-I" + os.path.join(ROOT, "include"), "-I" + SRC, "--offload-arch=gfx950", "-save-temps"]
+         "-I" + os.path.join(ROOT, "include"), "-I" + SRC, "--offload-arch=gfx950", "-mllvm", "-amdgpu-kernarg-preload-count=8", "-save-temps"]
 
 
 def table(asm):
@@ -49,7 +49,7 @@ def main():
     rows, keys = table(text)
     mfma = len(re.findall(r"^\s*v_mfma_", text, re.M))
     swaps = len(re.findall(r"^\s*v_permlane\d+_swap", text, re.M))
-    lines = ["# ISA resources of cvo_kernels.hip (hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fno-slp-vectorize -save-temps)",
+    lines = ["# ISA resources of cvo_kernels.hip (hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fno-slp-vectorize -mllvm -amdgpu-kernarg-preload-count=8 -save-temps)",
              "# %d v_mfma_*, %d v_permlane*_swap in the file" % (mfma, swaps),
              "# kernel | sgpr | sgpr spilled (to vector lanes, no memory) | vgpr | vgpr spilled | scratch bytes | static LDS bytes"]
     for r in rows:
