@@ -728,6 +728,21 @@ int enqueue_process(cvo_hip_ctx *ctx, int mode, int list, DevBuf &part, const fl
     a.weight = ctx->prm.color_scale > 0.0f ? 1 : 0;   // the MATLAB object's weight: its own instantiation
     static const bool no_pack = getenv("CVO_HIP_NO_PACK") != nullptr;
     a.kept_packed = (!no_pack && ctx->fixed.np <= 65536 && ctx->moving.np <= 65536) ? 1 : 0;
+    if (!a.kept_packed && !no_pack && a.weight == 0 && ctx->fixed.np <= 262144 && ctx->moving.np <= 262144) {
+        // 8 bytes for larger clouds too (ProcessArgs::kept_packed == 2): a member's weight a = ck * k is a positive
+        // float32 with sp < a <= fl(fl(c_sigma^2) fl(sigma^2)) -- the two exp are <= 1 (ref cvo.cpp:143-153 as
+        // pair_weight computes it); if those two bounds lie within 16 binades, 4 bits of exponent do
+        const bool no_pack2 = getenv("CVO_HIP_NO_PACK_WIDE") != nullptr;   // (read when a plan is recorded: tests switch it)
+        const float amax = (float)ctx->dprm.cs2_d * (float)ctx->dprm.s2_d;
+        uint32_t blo, bhi;
+        std::memcpy(&blo, &ctx->dprm.sp, sizeof(blo));
+        std::memcpy(&bhi, &amax, sizeof(bhi));
+        const uint32_t elo = blo >> 23, ehi = bhi >> 23;   // (both positive: the sign bit is clear)
+        if (!no_pack2 && ctx->dprm.sp > 0.0f && amax > ctx->dprm.sp && elo >= 1 && ehi < 255 && ehi - elo <= 15) {
+            a.kept_packed = 2;
+            a.kept_ebase = elo;
+        }
+    }
     if ((mode == PROC_FLOW && list == LIST_XY) || (mode == PROC_SELF && (list == LIST_XX || list == LIST_YY))) {
         const bool no_cand = getenv("CVO_HIP_NO_CAND") != nullptr;   // (read when a plan is recorded: tests switch it)
         const bool no_self = getenv("CVO_HIP_NO_CAND_SELF") != nullptr;
@@ -738,15 +753,15 @@ int enqueue_process(cvo_hip_ctx *ctx, int mode, int list, DevBuf &part, const fl
         // profiles/r03_ab.txt.  Opt-in: CVO_HIP_CAND_WIDE)
         const bool no_wide = getenv("CVO_HIP_CAND_WIDE") == nullptr;
         if (!no_cand && !(mode == PROC_SELF && no_self) && pre_transform(ctx) && !(ctx->prm.color_scale > 0.0f) &&
-            (a.kept_packed || !no_wide)) {   // (the same plans: synchronous lists)
+            (a.kept_packed == 1 || !no_wide)) {   // (the same plans: synchronous lists)
             // (an optimisation: if its memory cannot be had, the pass expands the tile list every time)
             int rc_c = ensure_buf(ctx, ctx->cand[list], (size_t)ctx->lists[LIST_KEPT].cap * sizeof(uint2));
             if (!rc_c) rc_c = ensure_buf(ctx, ctx->cand_cnt[list], PROC_WAVES * sizeof(uint32_t));
             // (clouds of more than 65536 rows: i and j do not share a word, the weight gets an array of its own)
-            if (!rc_c && !a.kept_packed) rc_c = ensure_buf(ctx, ctx->cand_ck[list], (size_t)ctx->lists[LIST_KEPT].cap * sizeof(float));
+            if (!rc_c && a.kept_packed != 1) rc_c = ensure_buf(ctx, ctx->cand_ck[list], (size_t)ctx->lists[LIST_KEPT].cap * sizeof(float));
             if (!rc_c) {
                 a.cand = (uint2 *)ctx->cand[list].p;
-                a.cand_ck = a.kept_packed ? nullptr : (float *)ctx->cand_ck[list].p;
+                a.cand_ck = a.kept_packed == 1 ? nullptr : (float *)ctx->cand_ck[list].p;
                 a.cand_cnt = (uint32_t *)ctx->cand_cnt[list].p;
                 ctx->ck_nblk[list] = a.nblk;
             } else {
@@ -763,7 +778,7 @@ int enqueue_process(cvo_hip_ctx *ctx, int mode, int list, DevBuf &part, const fl
         // over the same buffer stream (DevHead::xy_ck).  The kernels of every other plan ignore the fields.
         const bool no_cand = getenv("CVO_HIP_NO_CAND") != nullptr || getenv("CVO_HIP_NO_CAND_ASYNC") != nullptr;
         if (mode == PROC_FLOW && list == LIST_XY && ctx->plan_recording && ctx->lone && ctx->allow_head && !multi_rank(ctx) &&
-            !no_cand && a.kept_packed && !(ctx->prm.color_scale > 0.0f)) {
+            !no_cand && a.kept_packed == 1 && !(ctx->prm.color_scale > 0.0f)) {
             const size_t bytes = (size_t)ctx->lists[LIST_KEPT].cap * sizeof(uint2);
             int rc_c = ensure_buf(ctx, ctx->cand[LIST_XY], bytes);
             if (!rc_c) rc_c = ensure_buf(ctx, ctx->cand_xyb, bytes);
@@ -788,7 +803,7 @@ int enqueue_process(cvo_hip_ctx *ctx, int mode, int list, DevBuf &part, const fl
         // (head mode: candidate records for both buffers of the self lists too, see the xy list above)
         const bool no_cand = getenv("CVO_HIP_NO_CAND") != nullptr || getenv("CVO_HIP_NO_CAND_ASYNC") != nullptr ||
                              getenv("CVO_HIP_NO_CAND_SELF") != nullptr;
-        if (ctx->plan_recording && ctx->lone && ctx->allow_head && !multi_rank(ctx) && !no_cand && a.kept_packed &&
+        if (ctx->plan_recording && ctx->lone && ctx->allow_head && !multi_rank(ctx) && !no_cand && a.kept_packed == 1 &&
             !(ctx->prm.color_scale > 0.0f)) {
             const int l = list == LIST_XX ? 0 : 1;
             const size_t bytes = (size_t)ctx->lists[LIST_KEPT].cap * sizeof(uint2);

@@ -294,9 +294,14 @@ struct ProcessArgs {
     uint2 *cand_b;         // head mode (double-buffered xy list): the record of the second buffer (8-byte form only) ...
     uint32_t *cand_cnt_b;  // ... DevHead::xy_ck[b] says whether buffer b's record matches its tile list
     int need_d2;           // PROC_FLOW: accumulate sum (1/l^3 a) d2 (acvo's dl term; cvo_hip_flow reports it for both modes)
-    int kept_packed;       // both clouds have <= 65536 rows: a kept entry is 8 bytes (i | j << 16, weight bits)
+    int kept_packed;       // 1: both clouds have <= 65536 rows: a kept entry is 8 bytes (i | j << 16, weight bits)
                            // in kept_ij alone instead of 8 + 4 -- the kept list is the largest HBM stream of a
-                           // batched run (written by every flow pass, read back by the step pass)
+                           // batched run (written by every flow pass, read back by the step pass).
+                           // 2: clouds up to 262144 rows, 8 bytes as well: i and j in 18 bits each, and the weight --
+                           // a float32 in (sp, sigma^2 c_sigma^2], positive, within 16 binades -- as 4 bits of
+                           // exponent above kept_ebase and its 23 mantissa bits (kept_pack / kept_unpack: lossless).
+                           // 0: 8 + 4 bytes (larger clouds, parameter sets whose weights span more, the MATLAB weight)
+    unsigned kept_ebase;   // kept_packed == 2: the exponent field of the smallest weight there can be
 };
 
 // k_post flags

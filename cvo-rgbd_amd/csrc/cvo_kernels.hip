@@ -691,6 +691,25 @@ __device__ __forceinline__ ProcHead proc_head_global(const ProcessArgs &a, const
     return h;
 }
 
+// Kept-list entries (ProcessArgs::kept_packed).  `raw_w`: the entry's word of the weight array (mode 0 only).
+__device__ __forceinline__ uint2 kept_pack(const int mode, const unsigned ebase, const unsigned i, const unsigned j, const float w)
+{
+    if (mode == 1) return make_uint2(i | (j << 16), __float_as_uint(w));
+    const unsigned wb = __float_as_uint(w);
+    return make_uint2(i | (j << 18), (j >> 14) | (((wb >> 23) - ebase) << 4) | ((wb & 0x7fffffu) << 8));
+}
+__device__ __forceinline__ void kept_unpack(const int mode, const unsigned ebase, const uint2 e, const float raw_w, unsigned &i,
+                                            unsigned &j, float &w)
+{
+    if (mode == 0) { i = e.x; j = e.y; w = raw_w; }
+    else if (mode == 1) { i = e.x & 0xffffu; j = e.x >> 16; w = __uint_as_float(e.y); }
+    else {
+        i = e.x & 0x3ffffu;
+        j = (e.x >> 18) | ((e.y & 0xfu) << 14);
+        w = __uint_as_float(((((e.y >> 4) & 0xfu) + ebase) << 23) | ((e.y >> 8) & 0x7fffffu));
+    }
+}
+
 // One pair of the exact pass.  PROC_FLOW / PROC_SELF: membership test of
 // se_kernel (ref cvo.cpp:125-152) and the flow / self sums; returns the weight
 // (0 = not in A).  PROC_STEP: `w` is the recorded weight of a member of A.
@@ -858,7 +877,7 @@ __device__ __forceinline__ bool expand_lists(const ProcessArgs &a, const ProcHea
                         const unsigned below = __builtin_amdgcn_mbcnt_hi(
                             (unsigned)(km >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)km, 0u));
                         if (a.kept_packed) {
-                            a.kept_ij[kbase + nk + below] = make_uint2(pr.x | (pr.y << 16), __float_as_uint(w));
+                            a.kept_ij[kbase + nk + below] = kept_pack(a.kept_packed, a.kept_ebase, pr.x, pr.y, w);
                         } else {
                             a.kept_ij[kbase + nk + below] = pr;
                             a.kept_a[kbase + nk + below] = w;
@@ -950,8 +969,10 @@ __device__ __forceinline__ bool stream_candidates(const ProcessArgs &a, const Pr
         const unsigned long long km = __ballot(w > 0.0f);
         if (MODE == PROC_FLOW && w > 0.0f) {   // (members <= candidates <= the slice: it cannot overflow here)
             const unsigned below = __builtin_amdgcn_mbcnt_hi((unsigned)(km >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)km, 0u));
-            if (a.kept_packed) {
+            if (a.kept_packed == 1) {   // (8-byte candidate records exist for such clouds only: the same first word)
                 a.kept_ij[base + nk + below] = make_uint2(e.x, __float_as_uint(w));
+            } else if (a.kept_packed) {
+                a.kept_ij[base + nk + below] = kept_pack(a.kept_packed, a.kept_ebase, ci, cj, w);
             } else {
                 a.kept_ij[base + nk + below] = make_uint2(ci, cj);
                 a.kept_a[base + nk + below] = w;
@@ -1000,7 +1021,7 @@ __device__ __forceinline__ void process_body(const ProcessArgs &a, const unsigne
         const size_t base = (size_t)wave * a.kept_wcap;
         unsigned n = a.kept_cnt[wave];
         // the first entries are fetched together with the count
-        const bool packed = a.kept_packed != 0;
+        const int packed = a.kept_packed;
         uint2 e = a.kept_ij[base + lane];
         float w = packed ? 0.0f : a.kept_a[base + lane];
         if (done_word != 0) return;
@@ -1008,8 +1029,10 @@ __device__ __forceinline__ void process_body(const ProcessArgs &a, const unsigne
         if (list_bad) n = 0;
         for (unsigned off = lane; off < n; off += 64) {
             if (off >= 64) { e = a.kept_ij[base + off]; if (!packed) w = a.kept_a[base + off]; }
-            eval_pair<MODE>(a, hd, kc, packed ? (e.x & 0xffffu) : e.x, packed ? (e.x >> 16) : e.y,
-                            packed ? __uint_as_float(e.y) : w, acc, *hd.xi);
+            unsigned mi, mj;
+            float mw;
+            kept_unpack(packed, a.kept_ebase, e, w, mi, mj, mw);
+            eval_pair<MODE>(a, hd, kc, mi, mj, mw, acc, *hd.xi);
         }
     } else {
         bool alive;
@@ -1088,7 +1111,7 @@ __device__ __forceinline__ bool step_twist_body(const ProcessArgs &a, DevState *
         pf[k] = (tid < a.nblk) ? a.flow_part[(size_t)k * a.nblk + tid] : 0.0;
     const size_t base = (size_t)wave * a.kept_wcap;
     unsigned n = a.kept_cnt[wave];
-    const bool packed = a.kept_packed != 0;
+    const int packed = a.kept_packed;
     uint2 e = a.kept_ij[base + lane];
     float w = packed ? 0.0f : a.kept_a[base + lane];
     if (done_word != 0) return false;
@@ -1183,8 +1206,10 @@ __device__ __forceinline__ bool step_twist_body(const ProcessArgs &a, DevState *
     if (n > a.kept_wcap) n = a.kept_wcap;
     for (unsigned off = lane; off < n; off += 64) {
         if (off >= 64) { e = a.kept_ij[base + off]; if (!packed) w = a.kept_a[base + off]; }
-        eval_pair<PROC_STEP>(a, phd, kc, packed ? (e.x & 0xffffu) : e.x, packed ? (e.x >> 16) : e.y,
-                             packed ? __uint_as_float(e.y) : w, acc, xc);
+        unsigned mi, mj;
+        float mw;
+        kept_unpack(packed, a.kept_ebase, e, w, mi, mj, mw);
+        eval_pair<PROC_STEP>(a, phd, kc, mi, mj, mw, acc, xc);
     }
     __syncthreads();   // sh is re-used
     wave_sums<NACC>(acc, lane, sh + wid * NACC);

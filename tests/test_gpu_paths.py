@@ -859,6 +859,43 @@ def test_wide_candidate_records_for_clouds_above_65536_rows(pkg, po, mode_name, 
 
 
 @pytest.mark.parametrize("mode_name", ["cvo", "acvo"])
+def test_eight_byte_kept_entries_for_clouds_above_65536_rows(pkg, po, mode_name, monkeypatch):
+    """Clouds of 65 537 ... 262 144 rows: a member of A is kept in 8 bytes as well (ProcessArgs::kept_packed
+    == 2: i and j in 18 bits each, the weight -- a float32 between sp_thres and sigma^2 c_sigma^2 -- as 4 bits
+    of exponent and its mantissa; lossless).  State and trace equal the run with 8 + 4 bytes
+    (CVO_HIP_NO_PACK_WIDE) and the oracle's first iterations (ref src/cvo.cpp:143-153,213-308)."""
+    import torch
+    capi = pkg.capi
+    acvo = mode_name == "acvo"
+    mode = capi.MODE_ACVO if acvo else capi.MODE_CVO
+    xf, ff, xm, fm = pkg.data.synthetic_pair(70000, 66000, seed=1234, acvo=acvo)
+    prm = capi.default_params(mode)
+    prm.max_iter = 12
+    runs = []
+    for off in (False, True):
+        if off:
+            monkeypatch.setenv("CVO_HIP_NO_PACK_WIDE", "1")
+        else:
+            monkeypatch.delenv("CVO_HIP_NO_PACK_WIDE", raising=False)
+        c = capi.Context(mode=mode, device=0, stream=torch.cuda.current_stream().cuda_stream, params=prm)
+        c.set_fixed(xf, ff)
+        c.set_moving(xm, fm)
+        st = capi.init_state(c.params)
+        it, tr = c.align(st, trace_cap=64)
+        runs.append((it, bytes(st), [(t["nnz"], t["nnz_xx"], t["nnz_yy"], t["omega"], t["v"], t["step"]) for t in tr]))
+        c.close()
+    assert runs[0] == runs[1]
+    p = po.default_params(mode)
+    p.max_iter = 12
+    so = po.init_state(p)
+    n_or, tr_or = po.align(p, so, xf, ff, xm, fm, search=po.SEARCH_GRID)
+    assert n_or == runs[0][0]
+    for a, b in zip(runs[0][2], tr_or):
+        assert a[0] == b["nnz"] and a[1] == b["nnz_xx"] and a[2] == b["nnz_yy"]
+        assert a[3] == b["omega"] and a[4] == b["v"] and a[5] == b["step"]
+
+
+@pytest.mark.parametrize("mode_name", ["cvo", "acvo"])
 def test_head_mode_changes_nothing(pkg, po, monkeypatch, mode_name):
     """Head mode (the post-step part of an iteration -- ref src/cvo.cpp:291-307,380-410 -- runs as
     the head of every flow / self block of the NEXT flow launch: two dependent launches per iteration, two
