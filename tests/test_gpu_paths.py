@@ -819,6 +819,21 @@ def test_transform_pass_and_candidate_list_change_nothing(pkg, monkeypatch, mode
     assert all(r == res[0] for r in res)
 
 
+_ORACLE_70K = {}
+
+
+def _oracle_70k(pkg, po, acvo):
+    """The oracle's first 14 iterations on the 70 000 x 66 000 pair of the two tests below (minutes of
+    host time on a slow box: run once per mode and session)."""
+    if acvo not in _ORACLE_70K:
+        xf, ff, xm, fm = pkg.data.synthetic_pair(70000, 66000, seed=4711, acvo=acvo)
+        p = po.default_params(po.MODE_ACVO if acvo else po.MODE_CVO)
+        p.max_iter = 14
+        so = po.init_state(p)
+        _ORACLE_70K[acvo] = po.align(p, so, xf, ff, xm, fm, search=po.SEARCH_GRID)
+    return _ORACLE_70K[acvo]
+
+
 @pytest.mark.parametrize("mode_name", ["cvo", "acvo"])
 def test_wide_candidate_records_for_clouds_above_65536_rows(pkg, po, mode_name, monkeypatch):
     """Clouds of more than 65 536 rows: i and j no longer share a word, the candidate record is 12 bytes
@@ -848,10 +863,7 @@ def test_wide_candidate_records_for_clouds_above_65536_rows(pkg, po, mode_name, 
         runs.append((it, bytes(st), [(t["nnz"], t["nnz_xx"], t["nnz_yy"], t["omega"], t["v"], t["step"]) for t in tr]))
         c.close()
     assert runs[0] == runs[1]
-    p = po.default_params(mode)
-    p.max_iter = 14
-    so = po.init_state(p)
-    n_or, tr_or = po.align(p, so, xf, ff, xm, fm, search=po.SEARCH_GRID)
+    n_or, tr_or = _oracle_70k(pkg, po, acvo)
     assert n_or == runs[0][0]
     for a, b in zip(runs[0][2], tr_or):
         assert a[0] == b["nnz"] and a[1] == b["nnz_xx"] and a[2] == b["nnz_yy"]
@@ -863,14 +875,14 @@ def test_eight_byte_kept_entries_for_clouds_above_65536_rows(pkg, po, mode_name,
     """Clouds of 65 537 ... 262 144 rows: a member of A is kept in 8 bytes as well (ProcessArgs::kept_packed
     == 2: i and j in 18 bits each, the weight -- a float32 between sp_thres and sigma^2 c_sigma^2 -- as 4 bits
     of exponent and its mantissa; lossless).  State and trace equal the run with 8 + 4 bytes
-    (CVO_HIP_NO_PACK_WIDE) and the oracle's first iterations (ref src/cvo.cpp:143-153,213-308)."""
+    (CVO_HIP_NO_PACK_WIDE) and the oracle's first 14 iterations (ref src/cvo.cpp:143-153,213-308)."""
     import torch
     capi = pkg.capi
     acvo = mode_name == "acvo"
     mode = capi.MODE_ACVO if acvo else capi.MODE_CVO
-    xf, ff, xm, fm = pkg.data.synthetic_pair(70000, 66000, seed=1234, acvo=acvo)
+    xf, ff, xm, fm = pkg.data.synthetic_pair(70000, 66000, seed=4711, acvo=acvo)
     prm = capi.default_params(mode)
-    prm.max_iter = 12
+    prm.max_iter = 14
     runs = []
     for off in (False, True):
         if off:
@@ -885,10 +897,7 @@ def test_eight_byte_kept_entries_for_clouds_above_65536_rows(pkg, po, mode_name,
         runs.append((it, bytes(st), [(t["nnz"], t["nnz_xx"], t["nnz_yy"], t["omega"], t["v"], t["step"]) for t in tr]))
         c.close()
     assert runs[0] == runs[1]
-    p = po.default_params(mode)
-    p.max_iter = 12
-    so = po.init_state(p)
-    n_or, tr_or = po.align(p, so, xf, ff, xm, fm, search=po.SEARCH_GRID)
+    n_or, tr_or = _oracle_70k(pkg, po, acvo)
     assert n_or == runs[0][0]
     for a, b in zip(runs[0][2], tr_or):
         assert a[0] == b["nnz"] and a[1] == b["nnz_xx"] and a[2] == b["nnz_yy"]
