@@ -1260,7 +1260,7 @@ bool plan_lone(const std::vector<RecOp> &ops, Slot &slot, std::vector<TLaunch> &
             ++q;
         } else if (have_flow) {
             slot.op[q].p = flow;
-            plan.push_back(mk_launch(flow.weight == 1 ? TK_FLOW_MATLAB : TK_FLOW, q, (unsigned)std::max(1, flow.nblk), 1));
+            plan.push_back(mk_launch(flow.weight == 1 ? TK_FLOW_MATLAB : (flow.need_d2 ? TK_FLOW_D2 : TK_FLOW), q, (unsigned)std::max(1, flow.nblk), 1));
             ++q;
         }
     }
@@ -1364,6 +1364,11 @@ bool plan_fused(const std::vector<const std::vector<RecOp> *> &ops, const std::v
             case RecOp::POST_FLOW: o.pf = op.pf; kernel = TK_POST_FLOW; break;
             case RecOp::POST_STEP: o.ps = op.ps; kernel = TK_POST_STEP; break;
             }
+        }
+        if (kernel == TK_FLOW) {   // (TK_FLOW is built without the sum of a d2, which the cvo loop never reads)
+            bool d2 = false;
+            for (size_t i = 0; i < ops.size(); ++i) d2 = d2 || (*ops[i])[q].p.need_d2 != 0;
+            if (d2) kernel = TK_FLOW_D2;
         }
         if (kernel == TK_FLOW_BUILD) {
             gx = (unsigned)np + nfb;
@@ -2676,7 +2681,7 @@ struct Engine {
             if (engine_profile()->on) {   // eager, the flow-pass launches bracketed by events
                 for (int k = 0; k < kEngineBatch; ++k)
                     for (const TLaunch &l : plan) {
-                        if (l.kernel == TK_FLOW) {
+                        if (l.kernel == TK_FLOW || l.kernel == TK_FLOW_D2) {
                             FlowEv fe{nullptr, nullptr, live()};
                             if (hipEventCreate(&fe.a) == hipSuccess && hipEventCreate(&fe.b) == hipSuccess) {
                                 launch_table(tab.dev, l, s, fe.a, fe.b);

@@ -695,7 +695,8 @@ constexpr int STEP_TWIST_ROWS_DIV = 4;   // k_step_twist writes nblk / 4 partial
 // One launch of an iteration through a table: which kernel, its geometry, which op[] it reads.
 enum TKernel { TK_FILTER = 0, TK_FILTER_GROUP, TK_FLOW, TK_FLOW_MATLAB, TK_STEP, TK_SELF, TK_SELF2, TK_STEP_TWIST,
                TK_FLOW_BUILD, TK_FLOW_BUILD3, TK_FLOW_BUILD6, TK_POST_FLOW, TK_POST_STEP,
-               TK_HFLOW_BUILD, TK_HFLOW_BUILD6, TK_HSTEP_TWIST, TK_HFLUSH };   // head mode (cvo_kernels.hip "Head mode")
+               TK_HFLOW_BUILD, TK_HFLOW_BUILD6, TK_HSTEP_TWIST, TK_HFLUSH,
+               TK_FLOW_D2 /* TK_FLOW is built without the sum of a d2 (ProcessArgs::need_d2 == 0 in every slot); this one has it */ };   // head mode (cvo_kernels.hip "Head mode")
 // Head-mode launches carry the slot's parity and the mode in the bits above the op index of their
 // second kernel argument: qp = q | parity << 8 | QP_HEAD.
 constexpr int QP_PARITY = 1 << 8, QP_HEAD = 1 << 9, QP_MASK = 0xff;

@@ -663,6 +663,7 @@ struct ProcHead {
     int par;                       // row of DevState::ovf this launch flags overflows in
     uint2 *cand;                   // the candidate record of the list (buffer) the pass reads, its per-wave counts
     uint32_t *cand_cnt;
+    int need_d2;                   // ProcessArgs::need_d2 -- or 0 where the kernel is built for loops that never read that sum
 };
 
 template <int MODE>
@@ -688,6 +689,7 @@ __device__ __forceinline__ ProcHead proc_head_global(const ProcessArgs &a, const
     h.ck_nblk = st->ck_nblk[a.list];
     h.par = par;
     h.cand = a.cand; h.cand_cnt = a.cand_cnt;
+    h.need_d2 = a.need_d2;
     return h;
 }
 
@@ -769,7 +771,7 @@ __device__ __forceinline__ float eval_pair(const ProcessArgs &a, const ProcHead 
         acc[4] += (double)(ad * f1);
         acc[5] += (double)(ad * f2);
         acc[6] += (double)w;
-        if (a.need_d2) acc[7] += (double)((kc.inv_l3 * w) * d2);   // (the acvo dl term: nobody reads it inside a cvo loop)
+        if (hd.need_d2) acc[7] += (double)((kc.inv_l3 * w) * d2);   // (the acvo dl term: nobody reads it inside a cvo loop)
         // (acc[8], the number of members: counted per wave by the caller, not per pair here)
     } else if (MODE == PROC_STEP) {
         // Taylor vectors of y_j (ref cvo.cpp:226-238), for members of A only
@@ -1199,6 +1201,7 @@ __device__ __forceinline__ bool step_twist_body(const ProcessArgs &a, DevState *
 
     // ---- compute_step_size sums over this wave's slice of the kept list
     ProcHead phd;
+    phd.need_d2 = 0;
     phd.Rt = hd->Rt; phd.tt = hd->t;   // (eval_pair<PROC_STEP> reads nothing else of it)
     double acc[NACC];
 #pragma unroll
@@ -1911,13 +1914,29 @@ kt_filter_group(const Slot *__restrict__ tab, const int q)
     if (blockIdx.y == 0) pretransform_body(CVO_FILTER_ROLE(0), blockIdx.x, gridDim.x);
 }
 
+// kt_process<PROC_FLOW, 0> is built for loops that never read the sum of a d2 (the cvo loop: ProcessArgs::need_d2 == 0 in
+// every slot; kt_flow_d2 below is the same pass with the sum) -- two vector registers and two instructions per member
+// less, which is what lets the flow pass of a crowded engine run seven waves per SIMD instead of six (64 / 256
+// distinct pairs per call 3 671 -> 3 775 / 4 166 -> 4 280 registrations/s; with the sum in, seven waves spill more
+// and acvo loses 1.5 %: profiles/r03_ab.txt 32)
 template <int MODE, int WEIGHT = 0>
-__global__ void __launch_bounds__(BLOCK) kt_process(const Slot *__restrict__ tab, const int q)
+__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((MODE == PROC_FLOW && WEIGHT == 0) ? 7 : 1, 8)))
+kt_process(const Slot *__restrict__ tab, const int q)
 {
     __shared__ __attribute__((aligned(16))) char scratch[PROC_SMEM];
     CVO_SLOT(tab);
     const ProcessArgs &a = CVO_ARG(ProcessArgs, op[q].p);
-    process_body<MODE, WEIGHT>(a, blockIdx.x, scratch, proc_head_global<MODE>(a, a.st, 0));
+    ProcHead hd = proc_head_global<MODE>(a, a.st, 0);
+    if (MODE == PROC_FLOW && WEIGHT == 0) hd.need_d2 = 0;
+    process_body<MODE, WEIGHT>(a, blockIdx.x, scratch, hd);
+}
+
+__global__ void __launch_bounds__(BLOCK) kt_flow_d2(const Slot *__restrict__ tab, const int q)
+{
+    __shared__ __attribute__((aligned(16))) char scratch[PROC_SMEM];
+    CVO_SLOT(tab);
+    const ProcessArgs &a = CVO_ARG(ProcessArgs, op[q].p);
+    process_body<PROC_FLOW, 0>(a, blockIdx.x, scratch, proc_head_global<PROC_FLOW>(a, a.st, 0));
 }
 
 // acvo, one registration: both self passes in one launch (blockIdx.y = xx / yy)
@@ -2080,6 +2099,7 @@ __device__ __forceinline__ ProcHead proc_head_lds(const ProcessArgs &a, const De
     hd.ck_nblk = 0;
     hd.par = par;
     hd.cand = nullptr; hd.cand_cnt = nullptr;
+    hd.need_d2 = a.need_d2;
     if (a.cand_b) {   // the record of the buffer in use (xy list; acvo: xx / yy)
         const int l = a.async_self == 2 ? 1 : 0;
         const int ck = MODE == PROC_FLOW ? (hd.second ? h->xy_ck[1] : h->xy_ck[0]) : (hd.second ? h->sf_ck[l][1] : h->sf_ck[l][0]);
@@ -2180,7 +2200,7 @@ void launch_table(const Slot *tab, const TLaunch &l, hipStream_t s, hipEvent_t e
 {
     const dim3 g(l.gx, 1, l.gz);
     const int qp = l.q | (parity ? QP_PARITY : 0) | QP_HEAD;   // head-mode launches
-    if (ev_start && ev_stop && l.kernel == TK_FLOW) {   // engine profiling: the dispatch's own begin / end
+    if (ev_start && ev_stop && (l.kernel == TK_FLOW || l.kernel == TK_FLOW_D2)) {   // engine profiling: the dispatch's own begin / end
         hipExtLaunchKernelGGL(kt_process<PROC_FLOW>, g, dim3(BLOCK), 0, s, ev_start, ev_stop, 0, tab, l.q);
         return;
     }
@@ -2188,6 +2208,7 @@ void launch_table(const Slot *tab, const TLaunch &l, hipStream_t s, hipEvent_t e
     case TK_FILTER: hipLaunchKernelGGL(kt_filter, g, dim3(BLOCK), l.smem, s, tab, l.q); break;
     case TK_FILTER_GROUP: hipLaunchKernelGGL(kt_filter_group, dim3(l.gx, 3, l.gz), dim3(BLOCK), l.smem, s, tab, l.q); break;
     case TK_FLOW: hipLaunchKernelGGL(kt_process<PROC_FLOW>, g, dim3(BLOCK), 0, s, tab, l.q); break;
+    case TK_FLOW_D2: hipLaunchKernelGGL(kt_flow_d2, g, dim3(BLOCK), 0, s, tab, l.q); break;
     case TK_FLOW_MATLAB: hipLaunchKernelGGL((kt_process<PROC_FLOW, 1>), g, dim3(BLOCK), 0, s, tab, l.q); break;
     case TK_STEP: hipLaunchKernelGGL(kt_process<PROC_STEP>, g, dim3(BLOCK), 0, s, tab, l.q); break;
     case TK_SELF: hipLaunchKernelGGL(kt_process<PROC_SELF>, g, dim3(BLOCK), 0, s, tab, l.q); break;
