@@ -78,6 +78,29 @@ def parse():
     return ap.parse_args()
 
 
+def respawn_under_torchrun(gpus, torch):
+    """`python bench.py --gpus N` without a launcher: replace this process by
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py <same arguments>`
+    (the driver's command for N > 1), so that both launch conventions run the same ranks."""
+    on_dev0 = os.environ.get("CVO_BENCH_RANKS_ON_DEVICE0", "") not in ("", "0")
+    have = torch.cuda.device_count()
+    if have < gpus and not on_dev0:
+        raise SystemExit("bench.py --gpus %d: this node shows %d GPU(s) "
+                         "(CVO_BENCH_RANKS_ON_DEVICE0=1 rehearses N ranks on device 0)" % (gpus, have))
+    import socket
+    port = os.environ.get("MASTER_PORT")
+    if not port:
+        with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+            s.bind(("127.0.0.1", 0))
+            port = str(s.getsockname()[1])
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL and the mailbox handles need it
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus),
+           "--master-addr", "127.0.0.1", "--master-port", port, os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stdout.flush()
+    sys.stderr.flush()
+    os.execv(sys.executable, cmd)
+
+
 def pair_seed(pkg, i):
     return pkg.data.SEED_CFG2 if i == 0 else pkg.data.SEED_CFG5_BASE + i
 
@@ -92,9 +115,12 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # A bare `python bench.py --gpus N`: become the launcher the driver's other convention uses --
+        # one process per GPU under torch.distributed.run on this node, rendezvous on 127.0.0.1.
+        respawn_under_torchrun(args.gpus, torch)
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+        raise SystemExit("bench.py --gpus %d was started with WORLD_SIZE=%d: they must agree" % (args.gpus, world))
     # Rehearsal of the multi-GPU run where only one GPU is to be had (CVO_BENCH_RANKS_ON_DEVICE0=1): every
     # rank works on device 0, torch's collectives go through gloo (RCCL refuses two ranks on one device) --
     # the weak-scaling leg, the all_gather of the IPC handles, the mailbox leg with its RCCL fall-back

@@ -27,6 +27,7 @@
 #include <deque>
 #include <mutex>
 #include <chrono>
+#include <thread>
 #include <vector>
 
 #include "cvo_comm.h"
@@ -376,8 +377,10 @@ int ensure_buf(cvo_hip_ctx *ctx, DevBuf &b, size_t bytes);
 int cloud_ready(cvo_hip_ctx *ctx, Cloud &c)
 {
     if (!c.pending) return CVO_HIP_OK;
-    c.pending = false;
+    // (pending stays up if the wait fails: the box is still the zeros of upload_cloud, and every later entry
+    // point must fail here again instead of building its filter geometry from them)
     HIP_TRY(ctx, hipEventSynchronize(c.ready_ev));
+    c.pending = false;
     for (int a = 0; a < 3; ++a) { c.lo[a] = c.bbox_pin[a]; c.hi[a] = c.bbox_pin[3 + a]; }
     return CVO_HIP_OK;
 }
@@ -576,11 +579,12 @@ void shard_ranges(const cvo_hip_ctx *ctx, int &rlo, int &rhi, int &slo, int &shi
 
 // Geometry of the MFMA pre-filter: coordinates relative to the centre of the
 // fixed cloud's bounding box; radii from the farthest bounding-box corners.
-void fill_filter_geometry(cvo_hip_ctx *ctx, DevState *h)
+int fill_filter_geometry(cvo_hip_ctx *ctx, DevState *h)
 {
     // (every compute entry point passes here before it queues anything: hand-overs still on their way end now)
-    (void)cloud_ready(ctx, ctx->fixed);
-    (void)cloud_ready(ctx, ctx->moving);
+    int rc_ready = cloud_ready(ctx, ctx->fixed);
+    if (!rc_ready) rc_ready = cloud_ready(ctx, ctx->moving);
+    if (rc_ready) return rc_ready;
     const Cloud &cf = ctx->fixed.n > 0 ? ctx->fixed : ctx->moving;
     h->n_fixed = ctx->fixed.n;
     for (int a = 0; a < 3; ++a) h->center[a] = 0.5f * (cf.lo[a] + cf.hi[a]);
@@ -596,6 +600,18 @@ void fill_filter_geometry(cvo_hip_ctx *ctx, DevState *h)
     };
     h->xmax = radius(ctx->fixed);
     h->y0max = radius(ctx->moving);
+    return CVO_HIP_OK;
+}
+
+// The entry points that exchange partial sums through the mailboxes refuse to start once an exchange has
+// timed out: the ranks' sequence numbers no longer agree (job_finish), and another exchange would spin for
+// its whole time-out or add up mismatched slots.
+int mailboxes_usable(cvo_hip_ctx *ctx)
+{
+    if (ctx->comm_table && ctx->mail_broken)
+        return fail(ctx, CVO_HIP_ERR_COMM, "the mailboxes of this context are unusable after a timed-out exchange: "
+                                           "call cvo_hip_mailbox_create and cvo_hip_mailbox_connect again on every rank");
+    return CVO_HIP_OK;
 }
 
 bool multi_rank(const cvo_hip_ctx *ctx);
@@ -1191,6 +1207,8 @@ bool plan_lone(const std::vector<RecOp> &ops, Slot &slot, std::vector<TLaunch> &
         else break;
     }
     int q = 0;
+    const int ns_all = ns;
+    const bool self_async[2] = {ns > 0 && self[0].async_self != 0, ns > 1 && self[1].async_self != 0};
     auto smem_of = [](int jt) { return (unsigned)filter_smem_bytes(jt); };
     auto smem_head = [](int jt) { return (unsigned)filter_smem_bytes(jt); };
     // what follows the flow side must be exactly: step pass with the twist, post-step (reduce + maths, no exchange)
@@ -1206,6 +1224,19 @@ bool plan_lone(const std::vector<RecOp> &ops, Slot &slot, std::vector<TLaunch> &
     static const bool head_flush = getenv("CVO_HIP_HEAD_FLUSH") != nullptr;
     const bool head = allow_head && rest_fits && have_flow && have_build &&
                       ((na == 2 && ns == 2 && nf == 0 && head_acvo) || (na == 0 && ns == 0 && nf == 0));
+    if (!head) {
+        // The candidate records of double-buffered lists (ProcessArgs::cand_b, DevHead::xy_ck / sf_ck) belong to
+        // head mode alone: enqueue_process fills them in before the plan is known.  A plan that falls back to the
+        // classic merged launches (CVO_HIP_NO_MERGE, CVO_HIP_NO_HEAD_ACVO) must not stream them -- its post-step
+        // kernel would tie ONE record to both buffers (DevHead::ck_nblk) and a pass over the second buffer would
+        // stream the first one's pairs.
+        auto strip = [](ProcessArgs &p) {
+            if (p.cand_b) { p.cand = nullptr; p.cand_b = nullptr; p.cand_cnt = nullptr; p.cand_cnt_b = nullptr; p.cand_ck = nullptr; }
+        };
+        if (have_flow && flow.async_xy) strip(flow);
+        for (int w = 0; w < ns; ++w)
+            if (self[w].async_self) strip(self[w]);
+    }
     if (have_flow && have_build && ((na == 2 && ns == 2) || nf == 2)) {
         // (op[q]: flow pass + xy build; op[q + 1], op[q + 2]: the xx / yy filters and, `six`, the self passes)
         const bool six = na == 2 && ns == 2;
@@ -1278,7 +1309,13 @@ bool plan_lone(const std::vector<RecOp> &ops, Slot &slot, std::vector<TLaunch> &
         const RecOp &op = ops[at];
         OpArgs &o = slot.op[q];
         if (op.kind == RecOp::POST_FLOW) { o.pf = op.pf; plan.push_back(mk_launch(TK_POST_FLOW, q, 1, 1)); }
-        else if (op.kind == RecOp::POST_STEP) { o.ps = op.ps; plan.push_back(mk_launch(TK_POST_STEP, q, 1, 1)); }
+        else if (op.kind == RecOp::POST_STEP) {
+            o.ps = op.ps;
+            if (have_flow && flow.async_xy) o.ps.ck_nblk[LIST_XY] = 0;   // (no record without head mode, see above)
+            for (int w = 0; w < 2; ++w)
+                if (ns_all > w && self_async[w]) o.ps.ck_nblk[LIST_XX + w] = 0;
+            plan.push_back(mk_launch(TK_POST_STEP, q, 1, 1));
+        }
         else if (op.kind == RecOp::PROCESS && op.mode == kProcStepTwist) {
             o.p = op.p;
             plan.push_back(mk_launch(head ? TK_HSTEP_TWIST : TK_STEP_TWIST, q, (unsigned)std::max(8, std::max(32, op.p.nblk) / 4), 1));
@@ -1375,6 +1412,49 @@ bool plan_fused(const std::vector<const std::vector<RecOp> *> &ops, const std::v
             for (Slot *sl : slots) { sl->op[qs].np = np; sl->op[qs].n0 = (int)nfb; }
         }
         plan.push_back(mk_launch(kernel, (int)qs, gx, (unsigned)zdim, smem));
+    }
+    // Ticket tails (cvo_kernels.hip): a post launch that directly follows the list pass whose sums it reduces --
+    // plain reduce + maths, no exchange over ranks -- runs in the tail of that pass's launch instead: the slot entry
+    // of the pass takes the post part's argument block (OpArgs::pf / ps beside ::p), the post launch is dropped.
+    // cvo: filter, flow, step = three dependent launches per iteration instead of five; acvo (its post-flow part
+    // needs the self passes' sums too): the step side only.
+    static const int tails_env = [] { const char *e = getenv("CVO_HIP_TAILS"); return e ? atoi(e) : 0; }();   // 1 both, 2 flow only, 3 step only
+    const bool tails = tails_env != 0, tail_flow = tails_env == 1 || tails_env == 2, tail_step = tails_env == 1 || tails_env == 3;
+    if (tails) {
+        std::vector<TLaunch> folded;
+        for (size_t i = 0; i < plan.size(); ++i) {
+            const TLaunch &l = plan[i];
+            const bool has_next = i + 1 < plan.size();
+            bool fold = false;
+            if (tail_flow && has_next && l.kernel == TK_FLOW && plan[i + 1].kernel == TK_POST_FLOW) {
+                fold = true;
+                for (const auto *o : ops) {
+                    const PostFlowArgs &pf = (*o)[perm[(size_t)plan[i + 1].q]].pf;
+                    fold = fold && pf.flags == (POST_REDUCE | POST_MATH) && pf.comm == nullptr && pf.prm.mode == CVO_HIP_MODE_CVO;
+                }
+                if (fold) {
+                    for (Slot *sl : slots) sl->op[l.q].pf = sl->op[plan[i + 1].q].pf;
+                    TLaunch t = l;
+                    t.kernel = TK_FLOW_TAIL;
+                    folded.push_back(t);
+                }
+            } else if (tail_step && has_next && l.kernel == TK_STEP && plan[i + 1].kernel == TK_POST_STEP) {
+                fold = true;
+                for (const auto *o : ops) {
+                    const PostStepArgs &ps = (*o)[perm[(size_t)plan[i + 1].q]].ps;
+                    fold = fold && ps.flags == (POST_REDUCE | POST_MATH) && ps.comm == nullptr;
+                }
+                if (fold) {
+                    for (Slot *sl : slots) sl->op[l.q].ps = sl->op[plan[i + 1].q].ps;
+                    TLaunch t = l;
+                    t.kernel = TK_STEP_TAIL;
+                    folded.push_back(t);
+                }
+            }
+            if (fold) ++i;   // (the post launch is gone)
+            else folded.push_back(l);
+        }
+        plan.swap(folded);
     }
     // three filters / two self passes in a row become one launch each
     std::vector<TLaunch> merged;
@@ -1964,8 +2044,9 @@ int cvo_hip_transform_pcd(cvo_hip_ctx *ctx, const float R[9], const float T[3])
     std::memcpy(h->T, T, sizeof(h->T));
     cvo_math::inverse_tf(R, T, h->Rt, h->t);
     h->done = 0;
-    fill_filter_geometry(ctx, h);
-    int rc = push_state_fields(ctx, offsetof(DevState, R), offsetof(DevState, ell) - offsetof(DevState, R));
+    int rc = fill_filter_geometry(ctx, h);
+    if (rc) return rc;
+    rc = push_state_fields(ctx, offsetof(DevState, R), offsetof(DevState, ell) - offsetof(DevState, R));
     if (rc) return rc;
     rc = push_state_fields(ctx, offsetof(DevState, Rt), offsetof(DevState, used_Rt) - offsetof(DevState, Rt));
     if (rc) return rc;
@@ -1982,13 +2063,16 @@ int cvo_hip_flow(cvo_hip_ctx *ctx, float ell, double out13[13])
     if (!ctx || !out13) return CVO_HIP_ERR_INVALID;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (!ctx->have_tf) return fail(ctx, CVO_HIP_ERR_INVALID, "transform_pcd not called");
+    int rc = mailboxes_usable(ctx);
+    if (rc) return rc;
     DevState *h = &ctx->st_host[kPollSlots];
     h->kc = make_kconsts(ctx->dprm, ell);
     h->kc_ell = -1.0f;   // (never equal to an ell: prepare_iteration recomputes)
-    fill_filter_geometry(ctx, h);
+    rc = fill_filter_geometry(ctx, h);
+    if (rc) return rc;
     compute_filter_bounds(h, false);
-    int rc = push_state_fields(ctx, offsetof(DevState, kc),
-                               offsetof(DevState, xi) - offsetof(DevState, kc));
+    rc = push_state_fields(ctx, offsetof(DevState, kc),
+                           offsetof(DevState, xi) - offsetof(DevState, kc));
     if (rc) return rc;
     for (bool redo = true; redo;) {
         rc = zero_counters(ctx);
@@ -2017,14 +2101,17 @@ int cvo_hip_step_coeffs(cvo_hip_ctx *ctx, const float omega[3], const float v[3]
     if (!ctx || !omega || !v || !bcde) return CVO_HIP_ERR_INVALID;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (!ctx->have_tf) return fail(ctx, CVO_HIP_ERR_INVALID, "transform_pcd not called");
+    int rc = mailboxes_usable(ctx);
+    if (rc) return rc;
     DevState *h = &ctx->st_host[kPollSlots];
     h->kc = make_kconsts(ctx->dprm, ell);
     h->kc_ell = -1.0f;   // (never equal to an ell: prepare_iteration recomputes)
-    fill_filter_geometry(ctx, h);
+    rc = fill_filter_geometry(ctx, h);
+    if (rc) return rc;
     compute_filter_bounds(h, false);
     h->xi = cvo_math::make_xi_consts(omega, v);
-    int rc = push_state_fields(ctx, offsetof(DevState, kc),
-                               offsetof(DevState, omega) - offsetof(DevState, kc));
+    rc = push_state_fields(ctx, offsetof(DevState, kc),
+                           offsetof(DevState, omega) - offsetof(DevState, kc));
     if (rc) return rc;
     // stand-alone call: rebuild A (filter + PROC_FLOW records the kept weights),
     // then stream it for the coefficient sums
@@ -2093,9 +2180,10 @@ int job_begin(AlignJob &j)
     cvo_hip_ctx *ctx = j.ctx;
     cvo_hip_state *s = j.s;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    if (ctx->comm_table && ctx->mail_broken)
-        return fail(ctx, CVO_HIP_ERR_COMM, "the mailboxes of this context are unusable after a timed-out exchange: "
-                                           "call cvo_hip_mailbox_create and cvo_hip_mailbox_connect again on every rank");
+    {
+        const int rcm = mailboxes_usable(ctx);
+        if (rcm) return rcm;
+    }
     const cvo_hip_params &p = ctx->prm;
     if (p.mode == CVO_HIP_MODE_ACVO) {   // tail of acvo::set_pcd (ref src/adaptive_cvo.cpp:476-478)
         s->ell = p.ell_init;
@@ -2122,7 +2210,10 @@ int job_begin(AlignJob &j)
     h->ell = s->ell;
     h->ell_max = s->ell_max;
     h->iter = s->iter;
-    fill_filter_geometry(ctx, h);
+    {
+        const int rcg = fill_filter_geometry(ctx, h);
+        if (rcg) return rcg;
+    }
     if (p.max_iter <= 0) h->done = DONE_MAX_ITER;
     // (everything but the mailbox sequence number, which lives as long as the context)
     HIP_TRY(ctx, hipMemcpyAsync(ctx->st, h, DEVSTATE_INIT_BYTES, hipMemcpyHostToDevice, loop_stream(ctx)));
@@ -2421,6 +2512,15 @@ struct Engine {
     long long launched = 0, checked = 0;   // batches
     int zdim = 0;
     bool crowded = true, use_graph = true, dirty = true, failed = false;
+    // Phase-segregated calls (cvo_hip_align_many): a HEAVY engine takes the call's new registrations in small
+    // cohorts and carries each cohort through the first `heavy batches` of its loop -- for cvo the iterations at
+    // ell >= 0.06 (ref src/cvo.cpp:408-410), whose list passes are throughput-bound -- on many blocks per
+    // registration; the cohort is then handed to the LIGHT engines, which hold many registrations each, few
+    // blocks apiece, through their long latency-bound remainder.  A cohort in flight: its jobs and the event
+    // behind its last heavy batch.
+    bool heavy = false;
+    int cohorts_out = 0;                   // cohorts of this (heavy) engine whose event has not been seen complete
+    struct Cohort { hipEvent_t ev = nullptr; std::vector<AlignJob *> jobs; Engine *from = nullptr; };
     std::vector<TLaunch> plan;
     struct FlowEv { hipEvent_t a, b; int live; };
     std::vector<FlowEv> flow_ev;           // engine profiling: one pair per flow-pass launch
@@ -2441,7 +2541,7 @@ struct Engine {
     }
 
     int live() const { int n = 0; for (AlignJob *j : member) n += j != nullptr; return n; }
-    bool idle() const { return live() == 0 && retiring.empty() && launched == checked; }
+    bool idle() const { return live() == 0 && retiring.empty() && launched == checked && cohorts_out == 0; }
 
     static int nblk_for(int z)
     {
@@ -2496,7 +2596,12 @@ struct Engine {
         c->lone = false;
         j->in_group = true;
         int rc = CVO_HIP_OK;
-        if (j->phase == 3) {   // resuming: the state is where the overflow parked it
+        if (j->phase == 4) {
+            // adopted from a heavy engine whose last batch for it has completed (the host has seen the cohort's
+            // event): state and lists are where that batch left them in HBM, the loop simply goes on here --
+            // nothing to prepare, nothing to copy; the slot's argument blocks are recorded by replan()
+            j->phase = 0;
+        } else if (j->phase == 3) {   // resuming: the state is where the overflow parked it
             int32_t zero = 0;
             std::memcpy(&c->st_host[kPollSlots].done, &zero, sizeof(zero));
             if (hipMemcpyAsync(reinterpret_cast<char *>(c->st) + offsetof(DevState, done), &c->st_host[kPollSlots].done,
@@ -2641,6 +2746,100 @@ struct Engine {
         return moved;
     }
 
+    // one batch of kEngineBatch iterations of the current plan on this engine's stream
+    int launch_one_batch()
+    {
+        if (engine_profile()->on) {   // eager, the flow-pass launches bracketed by events
+            for (int k = 0; k < kEngineBatch; ++k)
+                for (const TLaunch &l : plan) {
+                    if (l.kernel == TK_FLOW || l.kernel == TK_FLOW_D2 || l.kernel == TK_FLOW_TAIL) {
+                        FlowEv fe{nullptr, nullptr, live()};
+                        if (hipEventCreate(&fe.a) == hipSuccess && hipEventCreate(&fe.b) == hipSuccess) {
+                            launch_table(tab.dev, l, s, fe.a, fe.b);
+                            flow_ev.push_back(fe);
+                            continue;
+                        }
+                    }
+                    launch_table(tab.dev, l, s);
+                }
+            return hipGetLastError() == hipSuccess ? CVO_HIP_OK : CVO_HIP_ERR_HIP;
+        }
+        return run_plan(tab.dev, plans, plan, s, use_graph, kEngineBatch);
+    }
+
+    // The heavy engine of a phase-segregated call.  While fewer than two cohorts are on their way it takes the
+    // next `cohort_size` registrations of the queue into slots 0 .. cohort_size - 1 (their align() begins on
+    // this stream, or resumes after a list grew), queues `heavy_batches` batches for them, and records the
+    // cohort's event behind the last one; the slots are the next cohort's at once -- its table update is
+    // ordered behind those batches on the stream.  Nothing here looks at `done`: whoever adopts a job does.
+    bool pump_heavy(std::deque<AlignJob *> &pending, std::vector<Cohort> &arriving, int cohort_size, int heavy_batches)
+    {
+        if (failed) return false;
+        if (hipSetDevice(device) != hipSuccess) { fail_all("hipSetDevice failed", pending); return true; }
+        bool moved = false;
+        if (finish_arrived(pending, false)) moved = true;   // (registrations with nothing to run: max_iter <= 0)
+        while (!pending.empty() && cohorts_out < 2) {
+            moved = true;
+            for (int z = 0; z < ENGINE_SLOTS; ++z) { member[z] = nullptr; ops[z].clear(); }
+            int n = 0;
+            {
+                const double t0 = now_ms();
+                while (!pending.empty() && n < std::min(cohort_size, (int)ENGINE_SLOTS)) {
+                    AlignJob *j = pending.front();
+                    pending.pop_front();
+                    if (insert(j, n) == CVO_HIP_OK && member[n] == j) ++n;
+                }
+                t_insert += now_ms() - t0;
+            }
+            dirty = true;
+            if (n == 0) continue;
+            {
+                const double t0 = now_ms();
+                const int rc = replan();
+                t_replan += now_ms() - t0;
+                if (rc) { fail_all("fused launch recording failed", pending); return true; }
+            }
+            Cohort c;
+            c.from = this;
+            const double t_l0 = now_ms();
+            int rc_launch = CVO_HIP_OK;
+            for (int b = 0; b < heavy_batches && rc_launch == CVO_HIP_OK; ++b) rc_launch = launch_one_batch();
+            if (rc_launch != CVO_HIP_OK || hipEventCreateWithFlags(&c.ev, hipEventDisableTiming) != hipSuccess ||
+                hipEventRecord(c.ev, s) != hipSuccess) {
+                if (c.ev) (void)hipEventDestroy(c.ev);
+                fail_all("fused launch failed", pending);
+                return true;
+            }
+            t_launch += now_ms() - t_l0;
+            n_batches[zdim >= 16 ? 4 : (zdim >= 8 ? 3 : (zdim >= 4 ? 2 : (zdim >= 2 ? 1 : 0)))] += heavy_batches;
+            for (int z = 0; z < n; ++z) { c.jobs.push_back(member[z]); member[z] = nullptr; ops[z].clear(); }
+            ++cohorts_out;
+            arriving.push_back(c);
+        }
+        return moved;
+    }
+
+    // registrations whose loop has stopped while no engine held them (found stopped when their cohort arrived):
+    // their final state starts for the host on this stream; finish_arrived does the rest
+    void retire_jobs(const std::vector<AlignJob *> &jobs)
+    {
+        if (jobs.empty()) return;
+        Retire r;
+        for (AlignJob *j : jobs) {
+            if (hipMemcpyAsync(&j->ctx->st_host[0], j->ctx->st, sizeof(DevState), hipMemcpyDeviceToHost, s) != hipSuccess)
+                finish_job(j, fail(j->ctx, CVO_HIP_ERR_HIP, "state copy failed"));
+            else
+                r.jobs.push_back(j);
+        }
+        if (r.jobs.empty()) return;
+        if (hipEventCreateWithFlags(&r.ev, hipEventDisableTiming) != hipSuccess || hipEventRecord(r.ev, s) != hipSuccess) {
+            for (AlignJob *j : r.jobs) finish_job(j, fail(j->ctx, CVO_HIP_ERR_HIP, "event failed"));
+            if (r.ev) (void)hipEventDestroy(r.ev);
+            return;
+        }
+        retiring.push_back(r);
+    }
+
     // Advance as far as possible without waiting on the GPU.  `want` = how many members this
     // engine should hold at most right now.  Returns true if anything moved.
     bool pump(std::deque<AlignJob *> &pending, int want)
@@ -2676,25 +2875,8 @@ struct Engine {
                 t_replan += now_ms() - t0;
                 if (rc) { fail_all("fused launch recording failed", pending); return true; }
             }
-            int rc_launch = CVO_HIP_OK;
             const double t_l0 = now_ms();
-            if (engine_profile()->on) {   // eager, the flow-pass launches bracketed by events
-                for (int k = 0; k < kEngineBatch; ++k)
-                    for (const TLaunch &l : plan) {
-                        if (l.kernel == TK_FLOW || l.kernel == TK_FLOW_D2) {
-                            FlowEv fe{nullptr, nullptr, live()};
-                            if (hipEventCreate(&fe.a) == hipSuccess && hipEventCreate(&fe.b) == hipSuccess) {
-                                launch_table(tab.dev, l, s, fe.a, fe.b);
-                                flow_ev.push_back(fe);
-                                continue;
-                            }
-                        }
-                        launch_table(tab.dev, l, s);
-                    }
-                if (hipGetLastError() != hipSuccess) rc_launch = CVO_HIP_ERR_HIP;
-            } else {
-                rc_launch = run_plan(tab.dev, plans, plan, s, use_graph, kEngineBatch);
-            }
+            const int rc_launch = launch_one_batch();
             if (rc_launch != CVO_HIP_OK ||
                 hipEventRecord(ev[launched % 4], s) != hipSuccess) {
                 fail_all("fused launch failed", pending);
@@ -2783,6 +2965,8 @@ void engine_release(Engine *e)
     for (long long &v : e->n_batches) v = 0;
     e->n_replans = 0;
     e->launched = e->checked = 0;
+    e->heavy = false;
+    e->cohorts_out = 0;
     e->in_use = false;
 }
 
@@ -2850,6 +3034,8 @@ int cvo_hip_align_many(cvo_hip_ctx **ctxs, cvo_hip_state **states, int *n_iters,
             // 3 x 32 and 32 waiting 3297, 4 x 32 3644 -- the longest registration starts at once)
             static const size_t max_engines = [] { const char *e = getenv("CVO_HIP_ENGINES"); const int v = e ? atoi(e) : 4; return (size_t)std::max(1, std::min(v, 8)); }();
             size_t ngroups = total > 3 * ENGINE_SLOTS ? 4 : (total >= 40 ? 3 : (total >= 8 ? 2 : 1));
+            static const int seg_from = [] { const char *e = getenv("CVO_HIP_SEGREGATE_MIN"); return e ? atoi(e) : 24; }();
+            if (seg_from > 0 && (int)total >= seg_from) ngroups = total > 2 * ENGINE_SLOTS ? 4 : 3;   // (one heavy engine + the light ones, see below)
             ngroups = std::max<size_t>(1, std::min(ngroups, max_engines));
             if (const char *e = getenv("CVO_HIP_ENGINES_FORCE")) ngroups = (size_t)std::max(1, std::min(atoi(e), 8));   // (tuning probe)
             bool graphs_ok = true;   // (capture policy: cvo_hip_set_graph_capture)
@@ -2871,6 +3057,81 @@ int cvo_hip_align_many(cvo_hip_ctx **ctxs, cvo_hip_state **states, int *n_iters,
             }
             if (engines.empty()) {   // no engine to be had: the jobs run on their own below
                 for (AlignJob *j : pending) taken[j - &jobs[0]] = 0;
+                continue;
+            }
+            // Phase-segregated call: with enough registrations to fill the GPU, the first engine is a
+            // HEAVY one -- cohorts of a few new registrations, many blocks each, through their throughput-bound first
+            // batches -- and the others LIGHT ones that adopt a cohort when its heavy batches have completed.  A
+            // registration's state and lists live in HBM and its launches take their arguments from a table, so the
+            // move is a table update on the adopting engine; what the heavy engine left queued behind the cohort
+            // belongs to the next cohort.
+            static const int seg_min = [] { const char *e = getenv("CVO_HIP_SEGREGATE_MIN"); return e ? atoi(e) : 24; }();   // (0: never)
+            static const int cohort_size = [] { const char *e = getenv("CVO_HIP_COHORT"); const int v = e ? atoi(e) : 8; return std::max(1, std::min(v, (int)ENGINE_SLOTS)); }();
+            static const int heavy_batches = [] { const char *e = getenv("CVO_HIP_HEAVY_BATCHES"); const int v = e ? atoi(e) : 2; return std::max(1, std::min(v, 16)); }();
+            static const int n_heavy_env = [] { const char *e = getenv("CVO_HIP_HEAVY_ENGINES"); const int v = e ? atoi(e) : 1; return std::max(1, std::min(v, 3)); }();
+            const bool segregate = seg_min > 0 && (int)total >= seg_min && engines.size() >= 2 && engines[0]->crowded;
+            if (segregate) {
+                const size_t n_heavy = std::min<size_t>((size_t)n_heavy_env, engines.size() - 1);
+                std::vector<Engine *> heavy(engines.begin(), engines.begin() + n_heavy), light(engines.begin() + n_heavy, engines.end());
+                for (Engine *e : heavy) { e->heavy = true; e->cohorts_out = 0; }
+                for (Engine *e : light) { e->heavy = false; e->cohorts_out = 0; }
+                std::deque<AlignJob *> light_q;            // running registrations no engine holds: the next free light slots are theirs
+                std::vector<Engine::Cohort> arriving;      // cohorts on their way through a heavy engine
+                unsigned spins = 0;
+                for (;;) {
+                    bool moved = false;
+                    for (Engine *e : heavy)
+                        if (e->pump_heavy(pending, arriving, cohort_size, heavy_batches)) moved = true;
+                    // cohorts whose heavy batches have completed
+                    std::vector<AlignJob *> stopped;
+                    for (size_t a = 0; a < arriving.size();) {
+                        const hipError_t q = hipEventQuery(arriving[a].ev);
+                        if (q == hipErrorNotReady) { ++a; continue; }
+                        for (AlignJob *j : arriving[a].jobs) {
+                            if (q != hipSuccess) { arriving[a].from->finish_job(j, fail(j->ctx, CVO_HIP_ERR_HIP, "cohort event failed")); continue; }
+                            if (*(volatile int32_t *)j->ctx->done_mirror == RUNNING) { j->phase = 4; light_q.push_back(j); }
+                            else stopped.push_back(j);   // (converged, or parked on a list that must grow, inside its heavy batches)
+                        }
+                        --arriving[a].from->cohorts_out;
+                        (void)hipEventDestroy(arriving[a].ev);
+                        arriving.erase(arriving.begin() + (long)a);
+                        moved = true;
+                    }
+                    if (!stopped.empty()) light[0]->retire_jobs(stopped);
+                    // the light engines share what is running evenly
+                    size_t held = light_q.size();
+                    for (Engine *e : light) held += (size_t)e->live();
+                    const int want = std::min<int>(gmax, (int)((held + light.size() - 1) / light.size()));
+                    for (Engine *e : light)
+                        if (e->pump(light_q, want)) moved = true;
+                    bool any = !arriving.empty() || !pending.empty() || !light_q.empty();
+                    for (Engine *e : engines) any = any || !e->idle();
+                    if (!any) break;
+                    bool alive = true;
+                    for (Engine *e : engines) alive = alive && !e->failed;
+                    if (!alive) {   // an engine died: nothing of this call can be trusted to complete
+                        for (Engine *e : engines)
+                            if (!e->failed) e->fail_all("a sibling engine failed", e->heavy ? pending : light_q);
+                        for (auto &c : arriving) {
+                            for (AlignJob *j : c.jobs)
+                                if (j->phase != 2) c.from->finish_job(j, fail(j->ctx, CVO_HIP_ERR_HIP, "engine failed"));
+                            (void)hipEventDestroy(c.ev);
+                        }
+                        arriving.clear();
+                        for (AlignJob *j : pending) { j->rc = fail(j->ctx, CVO_HIP_ERR_HIP, "engine failed"); j->phase = 2; }
+                        for (AlignJob *j : light_q) { j->rc = fail(j->ctx, CVO_HIP_ERR_HIP, "engine failed"); j->phase = 2; }
+                        pending.clear();
+                        light_q.clear();
+                        break;
+                    }
+                    if (moved) { spins = 0; continue; }
+                    // several independent things are in flight (cohort events, every light engine's batches): poll them
+                    // in turn rather than sleep on one; after a while of nothing, yield the core between polls
+                    for (int k = 0; k < 64; ++k) __builtin_ia32_pause();
+                    if (++spins > 20000u) { std::this_thread::yield(); }
+                }
+                for (Engine *e : engines) { e->heavy = false; e->cohorts_out = 0; }
+                for (Engine *e : engines) engine_release(e);
                 continue;
             }
             // the first fill is even (16 + 16 of 32, 4 + 4 of 8); later a free slot takes the next job
@@ -2946,14 +3207,17 @@ int cvo_hip_function_inner_product(cvo_hip_ctx *ctx, float ell, float *out)
         dp.tau_c = (float)(-2.0 * ctx->prm.c_ell * ctx->prm.c_ell *
                            (double)(float)std::log((double)(dp.c_sp / ctx->prm.c_sigma / ctx->prm.c_sigma)));
     }
+    int rc = mailboxes_usable(ctx);
+    if (rc) return rc;
     DevState *h = &ctx->st_host[kPollSlots];
     h->kc = make_kconsts(dp, ell);
     h->kc_ell = -1.0f;   // (never equal to an ell: prepare_iteration recomputes)
-    fill_filter_geometry(ctx, h);
+    rc = fill_filter_geometry(ctx, h);
+    if (rc) return rc;
     compute_filter_bounds(h, true);
     h->done = 0;
-    int rc = push_state_fields(ctx, offsetof(DevState, kc),
-                               offsetof(DevState, xi) - offsetof(DevState, kc));
+    rc = push_state_fields(ctx, offsetof(DevState, kc),
+                           offsetof(DevState, xi) - offsetof(DevState, kc));
     if (rc) return rc;
     rc = push_state_fields(ctx, offsetof(DevState, done), sizeof(int32_t));
     if (rc) return rc;

@@ -209,6 +209,10 @@ struct DevState : DevHead {
     // bit k of built[l]: iteration k (mod 2048) rebuilt list l (profiling: which
     // k_filter launches did the work)
     uint32_t built[3][64];
+    // Ticket tails (cvo_kernels.hip "Ticket tails"): blocks of the flow ([0]) / step ([1]) launch of this
+    // registration that have delivered their partial sums; the block that draws the last ticket runs the
+    // post part of the launch and puts the counter back to zero.
+    uint32_t ticket[2];
     // exchanges done through the mailboxes since the context was created (never reset: the
     // sequence numbers of successive align() calls must keep alternating between the two
     // slot generations) -- kept last, align() re-initialises everything in front of it
@@ -696,7 +700,8 @@ constexpr int STEP_TWIST_ROWS_DIV = 4;   // k_step_twist writes nblk / 4 partial
 enum TKernel { TK_FILTER = 0, TK_FILTER_GROUP, TK_FLOW, TK_FLOW_MATLAB, TK_STEP, TK_SELF, TK_SELF2, TK_STEP_TWIST,
                TK_FLOW_BUILD, TK_FLOW_BUILD3, TK_FLOW_BUILD6, TK_POST_FLOW, TK_POST_STEP,
                TK_HFLOW_BUILD, TK_HFLOW_BUILD6, TK_HSTEP_TWIST, TK_HFLUSH,
-               TK_FLOW_D2 /* TK_FLOW is built without the sum of a d2 (ProcessArgs::need_d2 == 0 in every slot); this one has it */ };   // head mode (cvo_kernels.hip "Head mode")
+               TK_FLOW_D2 /* TK_FLOW is built without the sum of a d2 (ProcessArgs::need_d2 == 0 in every slot); this one has it */,
+               TK_FLOW_TAIL, TK_STEP_TAIL /* the list pass with the post part that follows it in the tail of its last block (op[q].pf / .ps) */ };
 // Head-mode launches carry the slot's parity and the mode in the bits above the op index of their
 // second kernel argument: qp = q | parity << 8 | QP_HEAD.
 constexpr int QP_PARITY = 1 << 8, QP_HEAD = 1 << 9, QP_MASK = 0xff;

@@ -624,6 +624,45 @@ __device__ __forceinline__ void wave_sums(double (&v)[N], int lane, double *dst)
     if (p >= 0) dst[p] = v[0];
 }
 
+// ---------------------------------------------------------------------------
+// Ticket tails.  The O(1) part that follows a list pass (k_post_flow after the flow pass, k_post_step
+// after the step pass; ref src/cvo.cpp:201-209 and :291-307,380-410 follow their sums without a boundary)
+// runs in the TAIL of the pass's own launch: every block stores its partial sums write-through (8-byte
+// agent-scope stores: `sc1`, they leave the XCD's L2 for memory), drains them, and draws a ticket from a
+// counter of the registration; the block that draws the last one reads all partial sums back with
+// agent-scope loads (served past its L1) and runs the post part.  No fence anywhere: round 2's ticket
+// tails published with a release fence -- a write-back of the XCD's whole L2, megabytes of freshly
+// written kept list, once per BLOCK -- and were 2.2x slower than the launches they replaced.  What the
+// last block reads besides the sums: the overflow flags (raised with atomics; read with agent-scope loads,
+// because the block's own L1 holds the line from its prologue) and the state's head (not written by
+// anybody while the launch runs).  What it writes is read by the NEXT launch.
+// Returns true in the block that drew the last ticket (block-uniform); `flag`: one word of LDS that
+// nobody else uses between the two barriers.
+__device__ __forceinline__ bool draw_ticket(uint32_t *ticket, const int nblk, int *flag)
+{
+    // (the sums were stored by threads of wave 0: that wave drains its stores before its lane 0 draws)
+    if (threadIdx.x < 64) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();   // (everybody has read what `flag` overlays)
+    if (threadIdx.x == 0) {
+        const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const bool last = t == (unsigned)(nblk - 1);
+        if (last) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // for the next launch
+        *flag = last ? 1 : 0;
+    }
+    __syncthreads();
+    return *flag != 0;
+}
+
+// a partial sum / an overflow flag as the tail of a launch must read it: past this CU's L1
+template <bool COH> __device__ __forceinline__ double load_partial(const double *p)
+{
+    return COH ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *p;
+}
+template <bool COH> __device__ __forceinline__ unsigned load_flag(const uint32_t *p)
+{
+    return COH ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *p;
+}
+
 template <int MODE> struct NAcc;
 template <> struct NAcc<PROC_FLOW> { static constexpr int n = NACC_FLOW; };
 template <> struct NAcc<PROC_STEP> { static constexpr int n = NACC_STEP; };
@@ -991,10 +1030,12 @@ __device__ __forceinline__ bool stream_candidates(const ProcessArgs &a, const Pr
 
 // CAND false: the launch never keeps a candidate list (the merged launches of one registration on its
 // own, whose xy list is built beside the pass): that code is left out of the kernel
-template <int MODE, int WEIGHT = 0, bool CAND = true>
-__device__ __forceinline__ void process_body(const ProcessArgs &a, const unsigned bid, char *scratch, const ProcHead &hd)
+// TAIL ("Ticket tails" below): the block sums are stored write-through, the block draws a ticket, and the
+// call returns true in the one block of the registration that drew the last one (block-uniform).
+template <int MODE, int WEIGHT = 0, bool CAND = true, bool TAIL = false>
+__device__ __forceinline__ bool process_body(const ProcessArgs &a, const unsigned bid, char *scratch, const ProcHead &hd)
 {
-    if ((int)bid >= a.nblk) return;
+    if ((int)bid >= a.nblk) return false;
     constexpr int NACC = NAcc<MODE>::n;
     double *red = reinterpret_cast<double *>(scratch);
     uint2 *pairq_all = reinterpret_cast<uint2 *>(scratch + 4 * NACC_MAX * 8);
@@ -1026,7 +1067,7 @@ __device__ __forceinline__ void process_body(const ProcessArgs &a, const unsigne
         const int packed = a.kept_packed;
         uint2 e = a.kept_ij[base + lane];
         float w = packed ? 0.0f : a.kept_a[base + lane];
-        if (done_word != 0) return;
+        if (done_word != 0) return false;
         if (n > a.kept_wcap) n = a.kept_wcap;
         if (list_bad) n = 0;
         for (unsigned off = lane; off < n; off += 64) {
@@ -1046,7 +1087,7 @@ __device__ __forceinline__ void process_body(const ProcessArgs &a, const unsigne
         } else {
             alive = expand_lists<MODE, WEIGHT, 0>(a, hd, kc, bid, wid, lane, wave, done_word, list_bad, in_list, in_tiles, first_counted, s_etab, pairq_all, acc);
         }
-        if (!alive) return;
+        if (!alive) return false;
     }
 
     // block reduction: reduce-scatter inside each wave, then the 4 waves in order
@@ -1054,8 +1095,12 @@ __device__ __forceinline__ void process_body(const ProcessArgs &a, const unsigne
     __syncthreads();
     if (tid < NACC) {
         const double s = ((red[tid] + red[NACC + tid]) + red[2 * NACC + tid]) + red[3 * NACC + tid];
-        a.partials[(size_t)tid * a.nblk + bid] = s;   // [value][block]: coalesced for the readers
+        double *dst = &a.partials[(size_t)tid * a.nblk + bid];   // [value][block]: coalesced for the readers
+        if (TAIL) __hip_atomic_store(dst, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // write-through (sc1)
+        else *dst = s;
     }
+    if (!TAIL) return false;
+    return draw_ticket(&a.st->ticket[MODE == PROC_STEP ? 1 : 0], a.nblk, reinterpret_cast<int *>(red));
 }
 
 template <int MODE, int WEIGHT = 0>
@@ -1284,7 +1329,7 @@ void launch_process(int mode, const ProcessArgs &a, hipStream_t s, hipEvent_t ev
 // wave sums are added in wave order.
 // (two halves, so that a caller can have the loads in flight while it waits for
 // something else: thread_load_partials only issues them and adds in a fixed order)
-template <int NACC, int NPART = PROC_BLOCKS>
+template <int NACC, int NPART = PROC_BLOCKS, bool COH = false>
 __device__ __forceinline__ void thread_load_partials(const double *part, int nblocks, double (&s)[NACC])
 {
     const int tid = threadIdx.x;
@@ -1297,7 +1342,7 @@ __device__ __forceinline__ void thread_load_partials(const double *part, int nbl
     for (int u = 0; u < NPART / BLOCK; ++u) {
         const int b = tid + u * BLOCK;
 #pragma unroll
-        for (int k = 0; k < NACC; ++k) s[k] += (b < nblocks) ? part[(size_t)k * nblocks + b] : 0.0;
+        for (int k = 0; k < NACC; ++k) s[k] += (b < nblocks) ? load_partial<COH>(&part[(size_t)k * nblocks + b]) : 0.0;
     }
 }
 
@@ -1316,12 +1361,12 @@ __device__ __forceinline__ void block_finish_partials(double (&s)[NACC], double 
     __syncthreads();
 }
 
-template <int NACC, int NPART = PROC_BLOCKS>
+template <int NACC, int NPART = PROC_BLOCKS, bool COH = false>
 __device__ void block_reduce_partials(const double *part, int nblocks, double *sh /*[4*NACC_MAX]*/,
                                       double *out /*[NACC], thread 0 writes*/)
 {
     double s[NACC];
-    thread_load_partials<NACC, NPART>(part, nblocks, s);
+    thread_load_partials<NACC, NPART, COH>(part, nblocks, s);
     block_finish_partials<NACC>(s, sh, out);
 }
 
@@ -1458,6 +1503,8 @@ __device__ bool mailbox_allreduce(const CommTable &ct, DevState *gst, double *va
     return *sh_fail == 0;
 }
 
+// COH: the body runs as the tail of the flow launch ("Ticket tails")
+template <bool COH = false>
 __device__ __forceinline__ void post_flow_body(const PostFlowArgs &a)
 {
     __shared__ double sh[4 * NACC_MAX];
@@ -1469,18 +1516,18 @@ __device__ __forceinline__ void post_flow_body(const PostFlowArgs &a)
     if (a.check_done && (st->done != 0 || (a.prm.async_xy && st->stall))) return;
     const bool acvo = a.prm.mode == CVO_HIP_MODE_ACVO;
     if (a.flags & POST_REDUCE) {
-        block_reduce_partials<NACC_FLOW>(a.part_flow, a.nblk, sh, st->red + RED_FLOW);
+        block_reduce_partials<NACC_FLOW, PROC_BLOCKS, COH>(a.part_flow, a.nblk, sh, st->red + RED_FLOW);
         if (acvo) {
-            block_reduce_partials<NACC_SELF>(a.part_xx, a.nblk, sh, st->red + RED_XX);
-            block_reduce_partials<NACC_SELF>(a.part_yy, a.nblk, sh, st->red + RED_YY);
+            block_reduce_partials<NACC_SELF, PROC_BLOCKS, COH>(a.part_xx, a.nblk, sh, st->red + RED_XX);
+            block_reduce_partials<NACC_SELF, PROC_BLOCKS, COH>(a.part_yy, a.nblk, sh, st->red + RED_YY);
         } else if (threadIdx.x == 0) {
             st->red[RED_XX] = st->red[RED_XX + 1] = st->red[RED_YY] = st->red[RED_YY + 1] = 0.0;
         }
         // a candidate list overflowed on this rank: poison nnz so that, after the
         // all-reduce, EVERY rank takes the same "grow the list and redo" exit
         if (threadIdx.x == 0 &&
-            ((a.prm.async_xy ? 0u : a.st->ovf[0][LIST_XY]) | a.st->ovf[0][LIST_XX] |
-             a.st->ovf[0][LIST_YY] | a.st->ovf[0][LIST_KEPT]))
+            ((a.prm.async_xy ? 0u : load_flag<COH>(&a.st->ovf[0][LIST_XY])) | load_flag<COH>(&a.st->ovf[0][LIST_XX]) |
+             load_flag<COH>(&a.st->ovf[0][LIST_YY]) | load_flag<COH>(&a.st->ovf[0][LIST_KEPT])))
             st->red[8] = __builtin_nan("");
     }
     bool comm_ok = true;
@@ -1535,7 +1582,7 @@ __device__ __forceinline__ void post_flow_body(const PostFlowArgs &a)
 
 __global__ void __launch_bounds__(BLOCK) k_post_flow(const Grp<PostFlowArgs> grp)
 {
-    post_flow_body(grp.a[blockIdx.z]);
+    post_flow_body<false>(grp.a[blockIdx.z]);
 }
 
 enum HeadMode { HM_CLASSIC = 0, HM_HEAD = 1, HM_FLUSH = 2 };
@@ -1739,7 +1786,8 @@ __device__ __forceinline__ void head_math(DevHead *lds, const PostStepArgs &a, c
 // The whole head of one block.  in / out: the copies of the state's head the launch reads / writes (the
 // same in the classic and flush forms); st: the state itself (the tail: sub-list counters, overflow
 // flags).  Returns true if the slot that begins may run (head mode: the loop is running, no stall).
-template <int HM>
+// COH: the body runs as the tail of the step launch ("Ticket tails")
+template <int HM, bool COH = false>
 __device__ __forceinline__ bool head_body(const PostStepArgs &a, const DevHead *in, DevHead *out, DevHead *s_st,
                                           double *sh /*[4 * NACC_MAX]*/, const int par, const bool publisher)
 {
@@ -1751,8 +1799,8 @@ __device__ __forceinline__ bool head_body(const PostStepArgs &a, const DevHead *
     // one round trip: the step partials, the overflow flags of the builds that have ended (classic: row
     // 0, where everything is flagged; head mode: the row of the previous flow launch), the state's head
     double sp[NACC_STEP];
-    if (reduce) thread_load_partials<NACC_STEP>(a.part_step, a.nblk, sp);
-    const unsigned my_flag = a.st->ovf[HM == HM_CLASSIC ? 0 : (par ^ 1)][tid & 7];
+    if (reduce) thread_load_partials<NACC_STEP, PROC_BLOCKS, COH>(a.part_step, a.nblk, sp);
+    const unsigned my_flag = load_flag<COH>(&a.st->ovf[HM == HM_CLASSIC ? 0 : (par ^ 1)][tid & 7]);
     state_head_to_lds(in, s_st);
     if (a.check_done && s_st->done != 0) {
         // the loop has stopped: head mode hands the head on, so that every later launch finds the verdict
@@ -1822,16 +1870,17 @@ __device__ __forceinline__ bool head_body(const PostStepArgs &a, const DevHead *
     return s_st->done == RUNNING && !(async && s_st->stall != 0);
 }
 
+template <bool COH = false>
 __device__ __forceinline__ void post_step_body(const PostStepArgs &a)
 {
     __shared__ double sh[4 * NACC_MAX];
     __shared__ __attribute__((aligned(16))) DevHead s_st;
-    head_body<HM_CLASSIC>(a, a.st, a.st, &s_st, sh, 0, true);
+    head_body<HM_CLASSIC, COH>(a, a.st, a.st, &s_st, sh, 0, true);
 }
 
 __global__ void __launch_bounds__(BLOCK) k_post_step(const Grp<PostStepArgs> grp)
 {
-    post_step_body(grp.a[blockIdx.z]);
+    post_step_body<false>(grp.a[blockIdx.z]);
 }
 
 // First iteration of an align() (or of its resumption after a list grew): no
@@ -1982,14 +2031,39 @@ __global__ void __launch_bounds__(BLOCK) kt_post_flow(const Slot *__restrict__ t
     // (the post kernels are one long dependent chain on one lane: their arguments are fetched once,
     // up front, instead of where the chain first needs them)
     const PostFlowArgs a = CVO_ARG(PostFlowArgs, op[q].pf);
-    post_flow_body(a);
+    post_flow_body<false>(a);
 }
 
 __global__ void __launch_bounds__(BLOCK) kt_post_step(const Slot *__restrict__ tab, const int q)
 {
     CVO_SLOT(tab);
     const PostStepArgs a = CVO_ARG(PostStepArgs, op[q].ps);
-    post_step_body(a);
+    post_step_body<false>(a);
+}
+
+// The list passes of a crowded engine with their post parts as ticket tails (cvo: three dependent launches
+// per iteration -- filter, flow, step -- instead of five): op[q].p is the pass, op[q].pf / .ps the post part.
+__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(7, 8)))
+kt_flow_tail(const Slot *__restrict__ tab, const int q)
+{
+    __shared__ __attribute__((aligned(16))) char scratch[PROC_SMEM];
+    CVO_SLOT(tab);
+    const ProcessArgs &a = CVO_ARG(ProcessArgs, op[q].p);
+    ProcHead hd = proc_head_global<PROC_FLOW>(a, a.st, 0);
+    hd.need_d2 = 0;   // (the cvo loop: see kt_process<PROC_FLOW, 0>)
+    if (!process_body<PROC_FLOW, 0, true, true>(a, blockIdx.x, scratch, hd)) return;
+    const PostFlowArgs pf = CVO_ARG(PostFlowArgs, op[q].pf);
+    post_flow_body<true>(pf);
+}
+
+__global__ void __launch_bounds__(BLOCK) kt_step_tail(const Slot *__restrict__ tab, const int q)
+{
+    __shared__ __attribute__((aligned(16))) char scratch[PROC_SMEM];
+    CVO_SLOT(tab);
+    const ProcessArgs &a = CVO_ARG(ProcessArgs, op[q].p);
+    if (!process_body<PROC_STEP, 0, true, true>(a, blockIdx.x, scratch, proc_head_global<PROC_STEP>(a, a.st, 0))) return;
+    const PostStepArgs ps = CVO_ARG(PostStepArgs, op[q].ps);
+    post_step_body<true>(ps);
 }
 
 // The merged launches of a registration with its launches to itself (asynchronous list builds,
@@ -2054,7 +2128,8 @@ __global__ void __launch_bounds__(BLOCK) kt_post_step(const Slot *__restrict__ t
         if (b < 2 * np) {                                                                                  \
             const int w = b >= np ? 1 : 0;                                                                 \
             const ProcessArgs &pa = CVO_ARG(ProcessArgs, op[q + 1 + w].p);                                 \
-            process_body<PROC_SELF>(pa, (unsigned)(b - w * np), smem, proc_head_global<PROC_SELF>(pa, pa.st, 0)); \
+            /* (CAND false: the records of double-buffered lists belong to head mode, see plan_lone) */   \
+            process_body<PROC_SELF, 0, false>(pa, (unsigned)(b - w * np), smem, proc_head_global<PROC_SELF>(pa, pa.st, 0)); \
             return;                                                                                        \
         }                                                                                                  \
         b -= 2 * np;                                                                                       \
@@ -2200,8 +2275,14 @@ void launch_table(const Slot *tab, const TLaunch &l, hipStream_t s, hipEvent_t e
 {
     const dim3 g(l.gx, 1, l.gz);
     const int qp = l.q | (parity ? QP_PARITY : 0) | QP_HEAD;   // head-mode launches
+    if (ev_start && ev_stop && l.kernel == TK_FLOW_TAIL) {
+        hipExtLaunchKernelGGL(kt_flow_tail, g, dim3(BLOCK), 0, s, ev_start, ev_stop, 0, tab, l.q);
+        return;
+    }
     if (ev_start && ev_stop && (l.kernel == TK_FLOW || l.kernel == TK_FLOW_D2)) {   // engine profiling: the dispatch's own begin / end
-        hipExtLaunchKernelGGL(kt_process<PROC_FLOW>, g, dim3(BLOCK), 0, s, ev_start, ev_stop, 0, tab, l.q);
+        // (the kernel the plan names: TK_FLOW is built without the sum of a d2, acvo's plans need kt_flow_d2)
+        if (l.kernel == TK_FLOW_D2) hipExtLaunchKernelGGL(kt_flow_d2, g, dim3(BLOCK), 0, s, ev_start, ev_stop, 0, tab, l.q);
+        else hipExtLaunchKernelGGL(kt_process<PROC_FLOW>, g, dim3(BLOCK), 0, s, ev_start, ev_stop, 0, tab, l.q);
         return;
     }
     switch (l.kernel) {
@@ -2209,6 +2290,8 @@ void launch_table(const Slot *tab, const TLaunch &l, hipStream_t s, hipEvent_t e
     case TK_FILTER_GROUP: hipLaunchKernelGGL(kt_filter_group, dim3(l.gx, 3, l.gz), dim3(BLOCK), l.smem, s, tab, l.q); break;
     case TK_FLOW: hipLaunchKernelGGL(kt_process<PROC_FLOW>, g, dim3(BLOCK), 0, s, tab, l.q); break;
     case TK_FLOW_D2: hipLaunchKernelGGL(kt_flow_d2, g, dim3(BLOCK), 0, s, tab, l.q); break;
+    case TK_FLOW_TAIL: hipLaunchKernelGGL(kt_flow_tail, g, dim3(BLOCK), 0, s, tab, l.q); break;
+    case TK_STEP_TAIL: hipLaunchKernelGGL(kt_step_tail, g, dim3(BLOCK), 0, s, tab, l.q); break;
     case TK_FLOW_MATLAB: hipLaunchKernelGGL((kt_process<PROC_FLOW, 1>), g, dim3(BLOCK), 0, s, tab, l.q); break;
     case TK_STEP: hipLaunchKernelGGL(kt_process<PROC_STEP>, g, dim3(BLOCK), 0, s, tab, l.q); break;
     case TK_SELF: hipLaunchKernelGGL(kt_process<PROC_SELF>, g, dim3(BLOCK), 0, s, tab, l.q); break;

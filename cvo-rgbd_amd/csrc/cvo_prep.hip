@@ -37,8 +37,10 @@ __global__ void __launch_bounds__(1024) k_prep_keep_box(const float *xyz, int n,
     int cnt = 0;
     for (int i = threadIdx.x; i < n; i += 1024) {
         const float x = xyz[3 * (size_t)i], y = xyz[3 * (size_t)i + 1], z = xyz[3 * (size_t)i + 2];
-        bool k = true;
-        if (use_range) {
+        // (non-finite points never reach a voxel: MATLAB's pcdownsample drops invalid points, and a NaN / Inf
+        // coordinate has no voxel index -- the cast of floor(NaN) is undefined and the box would become infinite)
+        bool k = isfinite(x) && isfinite(y) && isfinite(z);
+        if (k && use_range) {
             const float r = sqrtf((x * x + y * y) + z * z);   // (-ffp-contract=off: no FMA)
             k = !((r > max_range) || (r < min_range));
         }
@@ -218,8 +220,17 @@ extern "C" int cvo_hip_range_filter_grid_average(int device, const float *xyz, c
     hipLaunchKernelGGL(k_prep_average, dim3(nb), dim3(PB), 0, st, d_xyz, d_rgb, d_keys[1], d_idx[1], d_head, d_seg, n, d_out, d_rgb_out);
     PREP_TRY(hipGetLastError());
     int n_seg = 0;
+    float box[6] = {0, 0, 0, 0, 0, 0};
     PREP_TRY(hipMemcpyAsync(&n_seg, d_seg + (N - 1), sizeof(int), hipMemcpyDeviceToHost, st));
+    PREP_TRY(hipMemcpyAsync(box, d_box, sizeof(box), hipMemcpyDeviceToHost, st));
     PREP_TRY(hipStreamSynchronize(st));
+    if (grid_size > 0.0 && n_seg > 0) {
+        // the lexicographic key (q0 * span1 + q1) * span2 + q2 must fit below KEY_DROPPED: a grid so fine
+        // that the box holds 2^63 voxels or more is refused (the keys computed above were garbage)
+        long double prod = 1.0L;
+        for (int a = 0; a < 3; ++a) prod *= std::floor(((long double)box[3 + a] - (long double)box[a]) / (long double)grid_size) + 1.0L;
+        if (!(prod < 9.0e18L)) return CVO_HIP_ERR_INVALID;
+    }
     if (n_seg > 0) {
         PREP_TRY(hipMemcpyAsync(xyz_out, d_out, (size_t)n_seg * 12, hipMemcpyDeviceToHost, st));
         PREP_TRY(hipMemcpyAsync(rgb_out, d_rgb_out, (size_t)n_seg * 3, hipMemcpyDeviceToHost, st));

@@ -170,7 +170,10 @@ int cvo_hip_swap_moving_to_fixed(cvo_hip_ctx *ctx);
  * one point per occupied voxel of a box grid anchored at the minimum corner of the kept points = the
  * mean location and the mean colour, voxels in lexicographic (x, y, z) index order; grid_size <= 0: no
  * downsampling, the kept points in their order).  Host arrays in and out: xyz n x 3 float32, rgb n x 3
- * uint8; xyz_out / rgb_out must hold n points, *n_out receives the count.  Context-free. */
+ * uint8; xyz_out / rgb_out must hold n points, *n_out receives the count.  Context-free.
+ * Points with a NaN / Inf coordinate are dropped whatever the filter (pcdownsample drops invalid points; they
+ * have no voxel).  A grid so fine that the box of the kept points spans 2^63 voxels or more is refused
+ * with CVO_HIP_ERR_INVALID. */
 int cvo_hip_range_filter_grid_average(int device, const float *xyz, const unsigned char *rgb, int n,
                                       float max_range, float min_range, double grid_size,
                                       float *xyz_out, unsigned char *rgb_out, int *n_out);

@@ -14,7 +14,7 @@ def pc_range_filter(xyz, rgb, max_range=4.0, min_range=0.8):
     """Drop the points whose range (float32 norm) is above max_range or below min_range."""
     xyz = np.asarray(xyz, np.float32)
     r = np.sqrt((xyz * xyz).sum(1, dtype=np.float32))
-    keep = ~((r > np.float32(max_range)) | (r < np.float32(min_range)))
+    keep = ~((r > np.float32(max_range)) | (r < np.float32(min_range))) & np.isfinite(xyz).all(1)
     return xyz[keep], np.asarray(rgb)[keep]
 
 
@@ -23,6 +23,8 @@ def grid_average(xyz, rgb, grid_size=0.05):
     points; voxels anchored at the cloud's minimum corner, in lexicographic (x, y, z) index order."""
     x = np.asarray(xyz, np.float64)
     c = np.asarray(rgb, np.float64)
+    ok = np.isfinite(x).all(1)   # (invalid points are dropped, as pcdownsample does)
+    x, c = x[ok], c[ok]
     if x.shape[0] == 0:
         return np.zeros((0, 3), np.float32), np.zeros((0, 3), np.uint8)
     idx = np.floor((x - x.min(0)) / float(grid_size)).astype(np.int64)

@@ -187,21 +187,30 @@ def test_headline_shape_64_distinct_10k_pairs_through_the_engines(pkg, po):
         c.close()
 
 
-def test_bench_multi_rank_rehearsal_on_one_gpu():
+@pytest.mark.parametrize("launcher", ["torchrun", "bare"])
+def test_bench_multi_rank_rehearsal_on_one_gpu(launcher):
     """The driver's 8-GPU command, rehearsed with two ranks on device 0 (CVO_BENCH_RANKS_ON_DEVICE0=1:
     gloo for torch's collectives): the weak-scaling leg, the all_gather of the IPC handles, the mailbox
     leg of the target-sharded mode (ref src/cvo.cpp:201-204,283-288 across ranks), its watchdog and
-    the assembly of the JSON line all run before the driver runs them for the first time on 8 GPUs."""
+    the assembly of the JSON line all run before the driver runs them for the first time on 8 GPUs.
+    Both launch conventions: under torch.distributed.run, and a bare `python bench.py --gpus 2`, which
+    re-executes itself under the launcher -- the same line either way."""
     import json
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, CVO_BENCH_RANKS_ON_DEVICE0="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-           "--master-addr", "127.0.0.1", "--master-port", "29577", os.path.join(root, "bench.py"),
-           "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "8", "--points", "3000",
-           "--sharded-points", "20000", "--sharded-steps", "1", "--sharded-timeout", "120"]
+    bench_args = [os.path.join(root, "bench.py"),
+                  "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "8", "--points", "3000",
+                  "--sharded-points", "20000", "--sharded-steps", "1", "--sharded-timeout", "120"]
+    if launcher == "torchrun":
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+               "--master-addr", "127.0.0.1", "--master-port", "29577"] + bench_args
+    else:
+        for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+            env.pop(k, None)
+        cmd = [sys.executable] + bench_args
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=root)
     assert r.returncode == 0, r.stderr[-2000:]
     line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]

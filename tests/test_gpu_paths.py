@@ -955,3 +955,40 @@ def test_head_mode_changes_nothing(pkg, po, monkeypatch, mode_name):
         assert np.array_equal(R, np.array(so.R, np.float32))
     for k in ("CVO_HIP_NO_HEAD", "CVO_HIP_LIST_INIT", "CVO_HIP_LIST_MARGIN"):
         monkeypatch.delenv(k, raising=False)
+
+
+@pytest.mark.parametrize("mode_name", ["cvo", "acvo"])
+def test_engine_profiling_changes_nothing(pkg, mode_name):
+    """cvo_hip_engine_profiling(1) -- eager launches of the engines' plan with an event pair on every
+    flow-pass dispatch (bench.py's roofline leg) -- must run the kernels the plan names: acvo's flow pass
+    is the one WITH the sum of a d2 (ref src/adaptive_cvo.cpp:228,271: the dl term), kt_flow_d2.  Results
+    with profiling on and off are bit-identical, and the profile has counted launches."""
+    import torch
+    capi = pkg.capi
+    acvo = mode_name == "acvo"
+    mode = capi.MODE_ACVO if acvo else capi.MODE_CVO
+    sizes = [(1500, 1700), (2500, 2300), (900, 3100), (2000, 2000), (1800, 1200), (2100, 2600)]
+    streams = [torch.cuda.Stream() for _ in sizes]
+    ctxs = []
+    for i, ((n, m), s) in enumerate(zip(sizes, streams)):
+        xf, ff, xm, fm = pkg.data.synthetic_pair(n, m, seed=140 + i, acvo=acvo)
+        c = capi.Context(mode=mode, device=0, stream=s.cuda_stream)
+        c.set_fixed(xf, ff)
+        c.set_moving(xm, fm)
+        ctxs.append(c)
+    ref = [capi.init_state(c.params) for c in ctxs]
+    ref_it = capi.align_many(ctxs, ref)
+    capi.engine_profile(reset=True)
+    capi.engine_profiling(True)
+    try:
+        st = [capi.init_state(c.params) for c in ctxs]
+        it = capi.align_many(ctxs, st)
+    finally:
+        capi.engine_profiling(False)
+    prof = capi.engine_profile(reset=True)
+    assert list(it) == list(ref_it)
+    for a, b in zip(st, ref):
+        assert bytes(a) == bytes(b)
+    assert prof[1] > 0 and prof[0] > 0.0, prof
+    for c in ctxs:
+        c.close()

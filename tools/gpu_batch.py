@@ -48,5 +48,7 @@ for B in BS:
     gc.enable()
     if os.environ.get("PER_STEP"):
         print("   per step ms:", " ".join("%.2f" % x for x in per))
-    print("B %2d: %.1f registrations/s (%.2f ms per batch, iters %s, mean %.1f, %.2f us per registration-iteration)" % (B, B * reps / dt, dt * 1e3 / reps, its[:3], float(np.mean(its)), dt * 1e6 / reps / max(1, int(np.sum(its)))))
+    import hashlib
+    dig = hashlib.sha1(b"".join(bytes(st) for st in states) + bytes(its)).hexdigest()[:12]   # (equal across variants: same results)
+    print("B %2d: %.1f registrations/s (%.2f ms per batch, iters %s, mean %.1f, %.2f us per registration-iteration) states %s" % (B, B * reps / dt, dt * 1e3 / reps, its[:3], float(np.mean(its)), dt * 1e6 / reps / max(1, int(np.sum(its))), dig))
     for c in ctxs: c.close()
