@@ -1075,6 +1075,10 @@ int enqueue_step(cvo_hip_ctx *ctx, int check_done, bool do_math, cvo_hip_trace *
     for (int l = 0; l < 3; ++l) pa.ck_nblk[l] = ctx->plan_recording ? ctx->ck_nblk[l] : 0;
     pa.nblk = ctx->merge_twist ? ctx->proc_blocks / STEP_TWIST_ROWS_DIV : ctx->proc_blocks;
     pa.part_step = (const double *)ctx->part_step.p;
+    pa.run_part = (double *)ctx->part_step.p;
+    // (resident runs, kt_run: a registration is in its light part when an iteration keeps at most this many pairs)
+    static const int run_max_nnz = [] { const char *e = getenv("CVO_HIP_RUN_MAX_NNZ"); const int v = e ? atoi(e) : 300000; return v > 0 ? v : 300000; }();
+    pa.run_max_nnz = run_max_nnz;
     pa.dbg = ctx->post_dbg;
     pa.comm = ctx->comm_table;
     if (host_reduce(ctx)) {
@@ -1333,8 +1337,10 @@ bool plan_lone(const std::vector<RecOp> &ops, Slot &slot, std::vector<TLaunch> &
 // A fused group: one launch per recorded launch, blockIdx.z = slot.  `ops[i]` = member i's
 // recorded iteration (all of the same shape), `slots[i]` its slot image; geometry = what
 // serves every member (zdim slots share the launch).
+// run_iters > 0 (cvo, synchronous lists): every iteration of the plan is followed by a resident run of up to
+// that many iterations (kt_run, cvo_kernels.hip "Resident runs").
 bool plan_fused(const std::vector<const std::vector<RecOp> *> &ops, const std::vector<Slot *> &slots, int zdim,
-                std::vector<TLaunch> &plan)
+                std::vector<TLaunch> &plan, int run_iters = 0)
 {
     plan.clear();
     if (ops.empty()) return true;
@@ -1413,49 +1419,6 @@ bool plan_fused(const std::vector<const std::vector<RecOp> *> &ops, const std::v
         }
         plan.push_back(mk_launch(kernel, (int)qs, gx, (unsigned)zdim, smem));
     }
-    // Ticket tails (cvo_kernels.hip): a post launch that directly follows the list pass whose sums it reduces --
-    // plain reduce + maths, no exchange over ranks -- runs in the tail of that pass's launch instead: the slot entry
-    // of the pass takes the post part's argument block (OpArgs::pf / ps beside ::p), the post launch is dropped.
-    // cvo: filter, flow, step = three dependent launches per iteration instead of five; acvo (its post-flow part
-    // needs the self passes' sums too): the step side only.
-    static const int tails_env = [] { const char *e = getenv("CVO_HIP_TAILS"); return e ? atoi(e) : 0; }();   // 1 both, 2 flow only, 3 step only
-    const bool tails = tails_env != 0, tail_flow = tails_env == 1 || tails_env == 2, tail_step = tails_env == 1 || tails_env == 3;
-    if (tails) {
-        std::vector<TLaunch> folded;
-        for (size_t i = 0; i < plan.size(); ++i) {
-            const TLaunch &l = plan[i];
-            const bool has_next = i + 1 < plan.size();
-            bool fold = false;
-            if (tail_flow && has_next && l.kernel == TK_FLOW && plan[i + 1].kernel == TK_POST_FLOW) {
-                fold = true;
-                for (const auto *o : ops) {
-                    const PostFlowArgs &pf = (*o)[perm[(size_t)plan[i + 1].q]].pf;
-                    fold = fold && pf.flags == (POST_REDUCE | POST_MATH) && pf.comm == nullptr && pf.prm.mode == CVO_HIP_MODE_CVO;
-                }
-                if (fold) {
-                    for (Slot *sl : slots) sl->op[l.q].pf = sl->op[plan[i + 1].q].pf;
-                    TLaunch t = l;
-                    t.kernel = TK_FLOW_TAIL;
-                    folded.push_back(t);
-                }
-            } else if (tail_step && has_next && l.kernel == TK_STEP && plan[i + 1].kernel == TK_POST_STEP) {
-                fold = true;
-                for (const auto *o : ops) {
-                    const PostStepArgs &ps = (*o)[perm[(size_t)plan[i + 1].q]].ps;
-                    fold = fold && ps.flags == (POST_REDUCE | POST_MATH) && ps.comm == nullptr;
-                }
-                if (fold) {
-                    for (Slot *sl : slots) sl->op[l.q].ps = sl->op[plan[i + 1].q].ps;
-                    TLaunch t = l;
-                    t.kernel = TK_STEP_TAIL;
-                    folded.push_back(t);
-                }
-            }
-            if (fold) ++i;   // (the post launch is gone)
-            else folded.push_back(l);
-        }
-        plan.swap(folded);
-    }
     // three filters / two self passes in a row become one launch each
     std::vector<TLaunch> merged;
     for (size_t i = 0; i < plan.size(); ++i) {
@@ -1482,6 +1445,32 @@ bool plan_fused(const std::vector<const std::vector<RecOp> *> &ops, const std::v
         }
     }
     plan.swap(merged);
+    if (run_iters > 0) {
+        // the op entries whose argument blocks a run reads: the xy filter's (the moving cloud itself), the flow
+        // pass's, the two post parts' (trace; parameters, mirrors, the step sums' array)
+        int qf = -1, qflow = -1, qpf = -1, qstep = -1, qps = -1;
+        for (size_t qs = 0; qs < nq; ++qs) {
+            const RecOp &r = (*ops[0])[perm[qs]];
+            if (r.kind == RecOp::FILTER && r.mode != kFilterAhead && r.f.list == LIST_XY && qf < 0) qf = (int)qs;
+            else if (r.kind == RecOp::PROCESS && r.mode == PROC_FLOW && qflow < 0) qflow = (int)qs;
+            else if (r.kind == RecOp::POST_FLOW && qpf < 0) qpf = (int)qs;
+            else if (r.kind == RecOp::PROCESS && r.mode == PROC_STEP && qstep < 0) qstep = (int)qs;
+            else if (r.kind == RecOp::POST_STEP && qps < 0) qps = (int)qs;
+        }
+        bool ok = qf >= 0 && qflow >= 0 && qpf >= 0 && qstep >= 0 && qps >= 0;
+        for (const auto *o : ops) {
+            if (!ok) break;
+            const RecOp &fl = (*o)[perm[(size_t)qflow]], &po = (*o)[perm[(size_t)qps]], &pfo = (*o)[perm[(size_t)qpf]];
+            ok = fl.p.cand != nullptr && fl.p.cand_ck == nullptr && fl.p.weight == 0 && fl.p.need_d2 == 0 && fl.p.nblk >= RUN_G &&
+                 po.ps.comm == nullptr && po.ps.flags == (POST_REDUCE | POST_MATH) && po.ps.prm.mode == CVO_HIP_MODE_CVO &&
+                 pfo.pf.flags == (POST_REDUCE | POST_MATH) && pfo.pf.comm == nullptr;
+        }
+        if (ok) {
+            TLaunch l = mk_launch(TK_RUN, run_ops(qf, qflow, qpf, qstep, qps), run_grid(zdim), (unsigned)zdim);
+            l.arg = run_iters;
+            plan.push_back(l);
+        }
+    }
     return true;
 }
 
@@ -2519,6 +2508,7 @@ struct Engine {
     // blocks apiece, through their long latency-bound remainder.  A cohort in flight: its jobs and the event
     // behind its last heavy batch.
     bool heavy = false;
+    int run_iters = 0;                     // > 0: every iteration of the plan is followed by a resident run of up to this many (kt_run)
     int cohorts_out = 0;                   // cohorts of this (heavy) engine whose event has not been seen complete
     struct Cohort { hipEvent_t ev = nullptr; std::vector<AlignJob *> jobs; Engine *from = nullptr; };
     std::vector<TLaunch> plan;
@@ -2670,7 +2660,7 @@ struct Engine {
             po.push_back(&ops[z]);
             ps.push_back(&slot[z]);
         }
-        if (!plan_fused(po, ps, zdim, plan)) return CVO_HIP_ERR_INVALID;
+        if (!plan_fused(po, ps, zdim, plan, run_iters)) return CVO_HIP_ERR_INVALID;
         const int nq = po.empty() ? 0 : (int)po[0]->size();
         if (tab.sync(slot, s, nq) != 0) return CVO_HIP_ERR_HIP;
         ++n_replans;
@@ -2749,10 +2739,13 @@ struct Engine {
     // one batch of kEngineBatch iterations of the current plan on this engine's stream
     int launch_one_batch()
     {
+        // (with resident runs one pass over the plan is up to 1 + run_iters iterations)
+        static const int run_reps = [] { const char *e = getenv("CVO_HIP_RUN_REPS"); const int v = e ? atoi(e) : 2; return v >= 1 && v <= 16 ? v : 2; }();
+        const int batch = run_iters > 0 ? run_reps : kEngineBatch;
         if (engine_profile()->on) {   // eager, the flow-pass launches bracketed by events
-            for (int k = 0; k < kEngineBatch; ++k)
+            for (int k = 0; k < batch; ++k)
                 for (const TLaunch &l : plan) {
-                    if (l.kernel == TK_FLOW || l.kernel == TK_FLOW_D2 || l.kernel == TK_FLOW_TAIL) {
+                    if (l.kernel == TK_FLOW || l.kernel == TK_FLOW_D2) {
                         FlowEv fe{nullptr, nullptr, live()};
                         if (hipEventCreate(&fe.a) == hipSuccess && hipEventCreate(&fe.b) == hipSuccess) {
                             launch_table(tab.dev, l, s, fe.a, fe.b);
@@ -2764,7 +2757,7 @@ struct Engine {
                 }
             return hipGetLastError() == hipSuccess ? CVO_HIP_OK : CVO_HIP_ERR_HIP;
         }
-        return run_plan(tab.dev, plans, plan, s, use_graph, kEngineBatch);
+        return run_plan(tab.dev, plans, plan, s, use_graph, batch);
     }
 
     // The heavy engine of a phase-segregated call.  While fewer than two cohorts are on their way it takes the
@@ -2967,6 +2960,7 @@ void engine_release(Engine *e)
     e->launched = e->checked = 0;
     e->heavy = false;
     e->cohorts_out = 0;
+    e->run_iters = 0;
     e->in_use = false;
 }
 
@@ -3073,8 +3067,9 @@ int cvo_hip_align_many(cvo_hip_ctx **ctxs, cvo_hip_state **states, int *n_iters,
             if (segregate) {
                 const size_t n_heavy = std::min<size_t>((size_t)n_heavy_env, engines.size() - 1);
                 std::vector<Engine *> heavy(engines.begin(), engines.begin() + n_heavy), light(engines.begin() + n_heavy, engines.end());
-                for (Engine *e : heavy) { e->heavy = true; e->cohorts_out = 0; }
-                for (Engine *e : light) { e->heavy = false; e->cohorts_out = 0; }
+                static const int run_iters_env = [] { const char *e = getenv("CVO_HIP_RUN_ITERS"); const int v = e ? atoi(e) : 0; return v >= 0 && v <= 64 ? v : 0; }();
+                for (Engine *e : heavy) { e->heavy = true; e->cohorts_out = 0; e->run_iters = 0; }
+                for (Engine *e : light) { e->heavy = false; e->cohorts_out = 0; e->run_iters = jobs[i].ctx->prm.mode == CVO_HIP_MODE_CVO ? run_iters_env : 0; }
                 std::deque<AlignJob *> light_q;            // running registrations no engine holds: the next free light slots are theirs
                 std::vector<Engine::Cohort> arriving;      // cohorts on their way through a heavy engine
                 unsigned spins = 0;
@@ -3130,9 +3125,13 @@ int cvo_hip_align_many(cvo_hip_ctx **ctxs, cvo_hip_state **states, int *n_iters,
                     for (int k = 0; k < 64; ++k) __builtin_ia32_pause();
                     if (++spins > 20000u) { std::this_thread::yield(); }
                 }
-                for (Engine *e : engines) { e->heavy = false; e->cohorts_out = 0; }
+                for (Engine *e : engines) { e->heavy = false; e->cohorts_out = 0; e->run_iters = 0; }
                 for (Engine *e : engines) engine_release(e);
                 continue;
+            }
+            {   // (tuning probe: resident runs in the engines of an unsegregated call)
+                static const int run_all = [] { const char *e = getenv("CVO_HIP_RUN_ALL"); const int v = e ? atoi(e) : 0; return v >= 0 && v <= 64 ? v : 0; }();
+                for (Engine *e : engines) e->run_iters = (run_all > 0 && e->crowded && jobs[i].ctx->prm.mode == CVO_HIP_MODE_CVO) ? run_all : 0;
             }
             // the first fill is even (16 + 16 of 32, 4 + 4 of 8); later a free slot takes the next job
             const int share = std::min<int>(gmax, (int)((total + engines.size() - 1) / engines.size()));

@@ -624,36 +624,8 @@ __device__ __forceinline__ void wave_sums(double (&v)[N], int lane, double *dst)
     if (p >= 0) dst[p] = v[0];
 }
 
-// ---------------------------------------------------------------------------
-// Ticket tails.  The O(1) part that follows a list pass (k_post_flow after the flow pass, k_post_step
-// after the step pass; ref src/cvo.cpp:201-209 and :291-307,380-410 follow their sums without a boundary)
-// runs in the TAIL of the pass's own launch: every block stores its partial sums write-through (8-byte
-// agent-scope stores: `sc1`, they leave the XCD's L2 for memory), drains them, and draws a ticket from a
-// counter of the registration; the block that draws the last one reads all partial sums back with
-// agent-scope loads (served past its L1) and runs the post part.  No fence anywhere: round 2's ticket
-// tails published with a release fence -- a write-back of the XCD's whole L2, megabytes of freshly
-// written kept list, once per BLOCK -- and were 2.2x slower than the launches they replaced.  What the
-// last block reads besides the sums: the overflow flags (raised with atomics; read with agent-scope loads,
-// because the block's own L1 holds the line from its prologue) and the state's head (not written by
-// anybody while the launch runs).  What it writes is read by the NEXT launch.
-// Returns true in the block that drew the last ticket (block-uniform); `flag`: one word of LDS that
-// nobody else uses between the two barriers.
-__device__ __forceinline__ bool draw_ticket(uint32_t *ticket, const int nblk, int *flag)
-{
-    // (the sums were stored by threads of wave 0: that wave drains its stores before its lane 0 draws)
-    if (threadIdx.x < 64) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();   // (everybody has read what `flag` overlays)
-    if (threadIdx.x == 0) {
-        const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const bool last = t == (unsigned)(nblk - 1);
-        if (last) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // for the next launch
-        *flag = last ? 1 : 0;
-    }
-    __syncthreads();
-    return *flag != 0;
-}
-
-// a partial sum / an overflow flag as the tail of a launch must read it: past this CU's L1
+// a partial sum / a flag that ANOTHER block of the running launch has written (kt_run below): an agent-scope
+// load, served past this CU's L1 -- the writer stored it write-through with an agent-scope store
 template <bool COH> __device__ __forceinline__ double load_partial(const double *p)
 {
     return COH ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *p;
@@ -703,6 +675,9 @@ struct ProcHead {
     uint2 *cand;                   // the candidate record of the list (buffer) the pass reads, its per-wave counts
     uint32_t *cand_cnt;
     int need_d2;                   // ProcessArgs::need_d2 -- or 0 where the kernel is built for loops that never read that sum
+    const float4 *pos_b;           // the column cloud and whether the slot's transform is still to be applied to it:
+    int tf_b;                      // ProcessArgs::pos_b / tf_b -- kt_run reads the moving cloud itself where the classic
+                                   // launches read the copy their filter launch has transformed
 };
 
 template <int MODE>
@@ -729,6 +704,7 @@ __device__ __forceinline__ ProcHead proc_head_global(const ProcessArgs &a, const
     h.par = par;
     h.cand = a.cand; h.cand_cnt = a.cand_cnt;
     h.need_d2 = a.need_d2;
+    h.pos_b = a.pos_b; h.tf_b = a.tf_b;
     return h;
 }
 
@@ -766,7 +742,7 @@ __device__ __forceinline__ float eval_pair(const ProcessArgs &a, const ProcHead 
     const float *tt = hd.tt;
     float4 xi = *gather16(a.pos_a, i * 16u);
     if (a.tf_a) xi = apply_tf(Rt, tt, xi);
-    float4 yj = *gather16(a.pos_b, j * 16u);
+    float4 yj = *gather16(hd.pos_b, j * 16u);
     // the features are fetched together with the positions (one memory round
     // trip per pair instead of two); ~97 % of the filtered pairs need them
     float4 fa0 = make_float4(0.f, 0.f, 0.f, 0.f), fb0 = fa0;
@@ -780,7 +756,7 @@ __device__ __forceinline__ float eval_pair(const ProcessArgs &a, const ProcHead 
         if (MODE == PROC_SELF)   // the caller's index of the row (acvo Ayy rule)
             row_index = __float_as_int(a.feat_a[(size_t)i * FEAT_STRIDE + FEAT_INDEX_SLOT]);
     }
-    if (a.tf_b) yj = apply_tf(Rt, tt, yj);
+    if (hd.tf_b) yj = apply_tf(Rt, tt, yj);
     const float e0 = xi.x - yj.x, e1 = xi.y - yj.y, e2 = xi.z - yj.z;
     float d2 = 0.0f;
     if (MODE != PROC_STEP) {
@@ -1030,12 +1006,10 @@ __device__ __forceinline__ bool stream_candidates(const ProcessArgs &a, const Pr
 
 // CAND false: the launch never keeps a candidate list (the merged launches of one registration on its
 // own, whose xy list is built beside the pass): that code is left out of the kernel
-// TAIL ("Ticket tails" below): the block sums are stored write-through, the block draws a ticket, and the
-// call returns true in the one block of the registration that drew the last one (block-uniform).
-template <int MODE, int WEIGHT = 0, bool CAND = true, bool TAIL = false>
-__device__ __forceinline__ bool process_body(const ProcessArgs &a, const unsigned bid, char *scratch, const ProcHead &hd)
+template <int MODE, int WEIGHT = 0, bool CAND = true>
+__device__ __forceinline__ void process_body(const ProcessArgs &a, const unsigned bid, char *scratch, const ProcHead &hd)
 {
-    if ((int)bid >= a.nblk) return false;
+    if ((int)bid >= a.nblk) return;
     constexpr int NACC = NAcc<MODE>::n;
     double *red = reinterpret_cast<double *>(scratch);
     uint2 *pairq_all = reinterpret_cast<uint2 *>(scratch + 4 * NACC_MAX * 8);
@@ -1067,7 +1041,7 @@ __device__ __forceinline__ bool process_body(const ProcessArgs &a, const unsigne
         const int packed = a.kept_packed;
         uint2 e = a.kept_ij[base + lane];
         float w = packed ? 0.0f : a.kept_a[base + lane];
-        if (done_word != 0) return false;
+        if (done_word != 0) return;
         if (n > a.kept_wcap) n = a.kept_wcap;
         if (list_bad) n = 0;
         for (unsigned off = lane; off < n; off += 64) {
@@ -1087,7 +1061,7 @@ __device__ __forceinline__ bool process_body(const ProcessArgs &a, const unsigne
         } else {
             alive = expand_lists<MODE, WEIGHT, 0>(a, hd, kc, bid, wid, lane, wave, done_word, list_bad, in_list, in_tiles, first_counted, s_etab, pairq_all, acc);
         }
-        if (!alive) return false;
+        if (!alive) return;
     }
 
     // block reduction: reduce-scatter inside each wave, then the 4 waves in order
@@ -1095,12 +1069,8 @@ __device__ __forceinline__ bool process_body(const ProcessArgs &a, const unsigne
     __syncthreads();
     if (tid < NACC) {
         const double s = ((red[tid] + red[NACC + tid]) + red[2 * NACC + tid]) + red[3 * NACC + tid];
-        double *dst = &a.partials[(size_t)tid * a.nblk + bid];   // [value][block]: coalesced for the readers
-        if (TAIL) __hip_atomic_store(dst, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // write-through (sc1)
-        else *dst = s;
+        a.partials[(size_t)tid * a.nblk + bid] = s;   // [value][block]: coalesced for the readers
     }
-    if (!TAIL) return false;
-    return draw_ticket(&a.st->ticket[MODE == PROC_STEP ? 1 : 0], a.nblk, reinterpret_cast<int *>(red));
 }
 
 template <int MODE, int WEIGHT = 0>
@@ -1248,6 +1218,7 @@ __device__ __forceinline__ bool step_twist_body(const ProcessArgs &a, DevState *
     ProcHead phd;
     phd.need_d2 = 0;
     phd.Rt = hd->Rt; phd.tt = hd->t;   // (eval_pair<PROC_STEP> reads nothing else of it)
+    phd.pos_b = a.pos_b; phd.tf_b = a.tf_b;
     double acc[NACC];
 #pragma unroll
     for (int k = 0; k < NACC; ++k) acc[k] = 0.0;
@@ -1329,7 +1300,7 @@ void launch_process(int mode, const ProcessArgs &a, hipStream_t s, hipEvent_t ev
 // wave sums are added in wave order.
 // (two halves, so that a caller can have the loads in flight while it waits for
 // something else: thread_load_partials only issues them and adds in a fixed order)
-template <int NACC, int NPART = PROC_BLOCKS, bool COH = false>
+template <int NACC, int NPART = PROC_BLOCKS>
 __device__ __forceinline__ void thread_load_partials(const double *part, int nblocks, double (&s)[NACC])
 {
     const int tid = threadIdx.x;
@@ -1342,7 +1313,7 @@ __device__ __forceinline__ void thread_load_partials(const double *part, int nbl
     for (int u = 0; u < NPART / BLOCK; ++u) {
         const int b = tid + u * BLOCK;
 #pragma unroll
-        for (int k = 0; k < NACC; ++k) s[k] += (b < nblocks) ? load_partial<COH>(&part[(size_t)k * nblocks + b]) : 0.0;
+        for (int k = 0; k < NACC; ++k) s[k] += (b < nblocks) ? part[(size_t)k * nblocks + b] : 0.0;
     }
 }
 
@@ -1361,12 +1332,12 @@ __device__ __forceinline__ void block_finish_partials(double (&s)[NACC], double 
     __syncthreads();
 }
 
-template <int NACC, int NPART = PROC_BLOCKS, bool COH = false>
+template <int NACC, int NPART = PROC_BLOCKS>
 __device__ void block_reduce_partials(const double *part, int nblocks, double *sh /*[4*NACC_MAX]*/,
                                       double *out /*[NACC], thread 0 writes*/)
 {
     double s[NACC];
-    thread_load_partials<NACC, NPART, COH>(part, nblocks, s);
+    thread_load_partials<NACC, NPART>(part, nblocks, s);
     block_finish_partials<NACC>(s, sh, out);
 }
 
@@ -1503,8 +1474,6 @@ __device__ bool mailbox_allreduce(const CommTable &ct, DevState *gst, double *va
     return *sh_fail == 0;
 }
 
-// COH: the body runs as the tail of the flow launch ("Ticket tails")
-template <bool COH = false>
 __device__ __forceinline__ void post_flow_body(const PostFlowArgs &a)
 {
     __shared__ double sh[4 * NACC_MAX];
@@ -1516,18 +1485,18 @@ __device__ __forceinline__ void post_flow_body(const PostFlowArgs &a)
     if (a.check_done && (st->done != 0 || (a.prm.async_xy && st->stall))) return;
     const bool acvo = a.prm.mode == CVO_HIP_MODE_ACVO;
     if (a.flags & POST_REDUCE) {
-        block_reduce_partials<NACC_FLOW, PROC_BLOCKS, COH>(a.part_flow, a.nblk, sh, st->red + RED_FLOW);
+        block_reduce_partials<NACC_FLOW>(a.part_flow, a.nblk, sh, st->red + RED_FLOW);
         if (acvo) {
-            block_reduce_partials<NACC_SELF, PROC_BLOCKS, COH>(a.part_xx, a.nblk, sh, st->red + RED_XX);
-            block_reduce_partials<NACC_SELF, PROC_BLOCKS, COH>(a.part_yy, a.nblk, sh, st->red + RED_YY);
+            block_reduce_partials<NACC_SELF>(a.part_xx, a.nblk, sh, st->red + RED_XX);
+            block_reduce_partials<NACC_SELF>(a.part_yy, a.nblk, sh, st->red + RED_YY);
         } else if (threadIdx.x == 0) {
             st->red[RED_XX] = st->red[RED_XX + 1] = st->red[RED_YY] = st->red[RED_YY + 1] = 0.0;
         }
         // a candidate list overflowed on this rank: poison nnz so that, after the
         // all-reduce, EVERY rank takes the same "grow the list and redo" exit
         if (threadIdx.x == 0 &&
-            ((a.prm.async_xy ? 0u : load_flag<COH>(&a.st->ovf[0][LIST_XY])) | load_flag<COH>(&a.st->ovf[0][LIST_XX]) |
-             load_flag<COH>(&a.st->ovf[0][LIST_YY]) | load_flag<COH>(&a.st->ovf[0][LIST_KEPT])))
+            ((a.prm.async_xy ? 0u : a.st->ovf[0][LIST_XY]) | a.st->ovf[0][LIST_XX] |
+             a.st->ovf[0][LIST_YY] | a.st->ovf[0][LIST_KEPT]))
             st->red[8] = __builtin_nan("");
     }
     bool comm_ok = true;
@@ -1582,7 +1551,7 @@ __device__ __forceinline__ void post_flow_body(const PostFlowArgs &a)
 
 __global__ void __launch_bounds__(BLOCK) k_post_flow(const Grp<PostFlowArgs> grp)
 {
-    post_flow_body<false>(grp.a[blockIdx.z]);
+    post_flow_body(grp.a[blockIdx.z]);
 }
 
 enum HeadMode { HM_CLASSIC = 0, HM_HEAD = 1, HM_FLUSH = 2 };
@@ -1783,11 +1752,50 @@ __device__ __forceinline__ void head_math(DevHead *lds, const PostStepArgs &a, c
     }
 }
 
+// What the publishing block does once the head's maths has run (all its threads): the tile lists the coming
+// launches rebuild are emptied, the others are kept ...
+template <int HM>
+__device__ __forceinline__ void head_prepare_lists(const PostStepArgs &a, const DevHead *s_st)
+{
+    const int tid = threadIdx.x;
+    const bool async = a.prm.async_xy != 0, aself = a.prm.async_self != 0;
+    if (!(s_st->done == RUNNING || s_st->done == NEED_BIGGER_LIST)) return;
+    if (HM != HM_FLUSH) {
+#pragma unroll
+        for (int l = 0; l < 3; ++l) {   // synchronous lists (classic plans)
+            if (s_st->reuse[l] || (async && l == LIST_XY) || (aself && l != LIST_XY)) continue;
+            for (int q = tid; q < NSUB; q += BLOCK) a.st->sub[l][q] = 0u;
+            if (tid == 0) atomicOr(&a.st->built[l][(s_st->k >> 5) & 63], 1u << (s_st->k & 31));
+        }
+        if (async && s_st->xy_target >= 0) {   // the build the plan has just named
+            const int l = s_st->xy_target ? (int)LIST_XYB : (int)LIST_XY;
+            for (int q = tid; q < NSUB; q += BLOCK) a.st->sub[l][q] = 0u;
+        }
+        if (aself)
+            for (int l = 0; l < 2; ++l)
+                if (s_st->sf_target[l] >= 0) {
+                    const int id = self_list_id(l, s_st->sf_target[l]);
+                    for (int q = tid; q < NSUB; q += BLOCK) a.st->sub[id][q] = 0u;
+                }
+    }
+    // classic: every launch of the coming slot flags its overflows in row 0 again (a parked
+    // loop keeps the flags: the host needs them to know what to grow)
+    if (HM == HM_CLASSIC && tid < 8 && s_st->done == RUNNING) a.st->ovf[0][tid] = 0u;
+}
+// ... and the head goes out: the host's mirrors, then the state
+__device__ __forceinline__ void head_publish(const PostStepArgs &a, const DevHead *s_st, DevHead *out, const bool math)
+{
+    if (threadIdx.x == 0) {
+        if (math && a.progress_mirror) *a.progress_mirror = s_st->n_slots;
+        if (a.done_mirror && s_st->done != RUNNING) *a.done_mirror = s_st->done;
+    }
+    state_head_from_lds(s_st, out);
+}
+
 // The whole head of one block.  in / out: the copies of the state's head the launch reads / writes (the
 // same in the classic and flush forms); st: the state itself (the tail: sub-list counters, overflow
 // flags).  Returns true if the slot that begins may run (head mode: the loop is running, no stall).
-// COH: the body runs as the tail of the step launch ("Ticket tails")
-template <int HM, bool COH = false>
+template <int HM>
 __device__ __forceinline__ bool head_body(const PostStepArgs &a, const DevHead *in, DevHead *out, DevHead *s_st,
                                           double *sh /*[4 * NACC_MAX]*/, const int par, const bool publisher)
 {
@@ -1799,8 +1807,8 @@ __device__ __forceinline__ bool head_body(const PostStepArgs &a, const DevHead *
     // one round trip: the step partials, the overflow flags of the builds that have ended (classic: row
     // 0, where everything is flagged; head mode: the row of the previous flow launch), the state's head
     double sp[NACC_STEP];
-    if (reduce) thread_load_partials<NACC_STEP, PROC_BLOCKS, COH>(a.part_step, a.nblk, sp);
-    const unsigned my_flag = load_flag<COH>(&a.st->ovf[HM == HM_CLASSIC ? 0 : (par ^ 1)][tid & 7]);
+    if (reduce) thread_load_partials<NACC_STEP>(a.part_step, a.nblk, sp);
+    const unsigned my_flag = a.st->ovf[HM == HM_CLASSIC ? 0 : (par ^ 1)][tid & 7];
     state_head_to_lds(in, s_st);
     if (a.check_done && s_st->done != 0) {
         // the loop has stopped: head mode hands the head on, so that every later launch finds the verdict
@@ -1808,7 +1816,7 @@ __device__ __forceinline__ bool head_body(const PostStepArgs &a, const DevHead *
         if (HM == HM_HEAD && publisher) state_head_from_lds(s_st, out);
         return false;
     }
-    const bool async = a.prm.async_xy != 0, aself = a.prm.async_self != 0;
+    const bool async = a.prm.async_xy != 0;
     // a stall slot executed no iteration (asynchronous builds: only the plan runs)
     const bool stalled = async && s_st->stall != 0;
     const bool pending = HM == HM_CLASSIC ? true : (s_st->pending != 0);
@@ -1837,50 +1845,22 @@ __device__ __forceinline__ bool head_body(const PostStepArgs &a, const DevHead *
             }
         }
         __syncthreads();
-        // the tile lists the coming launches rebuild are emptied; the others are kept
-        if (publisher && (s_st->done == RUNNING || s_st->done == NEED_BIGGER_LIST)) {
-            if (HM != HM_FLUSH) {
-#pragma unroll
-                for (int l = 0; l < 3; ++l) {   // synchronous lists (classic plans)
-                    if (s_st->reuse[l] || (async && l == LIST_XY) || (aself && l != LIST_XY)) continue;
-                    for (int q = tid; q < NSUB; q += BLOCK) a.st->sub[l][q] = 0u;
-                    if (tid == 0) atomicOr(&a.st->built[l][(s_st->k >> 5) & 63], 1u << (s_st->k & 31));
-                }
-                if (async && s_st->xy_target >= 0) {   // the build the plan has just named
-                    const int l = s_st->xy_target ? (int)LIST_XYB : (int)LIST_XY;
-                    for (int q = tid; q < NSUB; q += BLOCK) a.st->sub[l][q] = 0u;
-                }
-                if (aself)
-                    for (int l = 0; l < 2; ++l)
-                        if (s_st->sf_target[l] >= 0) {
-                            const int id = self_list_id(l, s_st->sf_target[l]);
-                            for (int q = tid; q < NSUB; q += BLOCK) a.st->sub[id][q] = 0u;
-                        }
-            }
-            // classic: every launch of the coming slot flags its overflows in row 0 again (a parked
-            // loop keeps the flags: the host needs them to know what to grow)
-            if (HM == HM_CLASSIC && tid < 8 && s_st->done == RUNNING) a.st->ovf[0][tid] = 0u;
-        }
+        if (publisher) head_prepare_lists<HM>(a, s_st);
     }
-    if (publisher && tid == 0) {
-        if (math && a.progress_mirror) *a.progress_mirror = s_st->n_slots;
-        if (a.done_mirror && s_st->done != RUNNING) *a.done_mirror = s_st->done;
-    }
-    if (publisher) state_head_from_lds(s_st, out);
+    if (publisher) head_publish(a, s_st, out, math);
     return s_st->done == RUNNING && !(async && s_st->stall != 0);
 }
 
-template <bool COH = false>
 __device__ __forceinline__ void post_step_body(const PostStepArgs &a)
 {
     __shared__ double sh[4 * NACC_MAX];
     __shared__ __attribute__((aligned(16))) DevHead s_st;
-    head_body<HM_CLASSIC, COH>(a, a.st, a.st, &s_st, sh, 0, true);
+    head_body<HM_CLASSIC>(a, a.st, a.st, &s_st, sh, 0, true);
 }
 
 __global__ void __launch_bounds__(BLOCK) k_post_step(const Grp<PostStepArgs> grp)
 {
-    post_step_body<false>(grp.a[blockIdx.z]);
+    post_step_body(grp.a[blockIdx.z]);
 }
 
 // First iteration of an align() (or of its resumption after a list grew): no
@@ -2031,39 +2011,14 @@ __global__ void __launch_bounds__(BLOCK) kt_post_flow(const Slot *__restrict__ t
     // (the post kernels are one long dependent chain on one lane: their arguments are fetched once,
     // up front, instead of where the chain first needs them)
     const PostFlowArgs a = CVO_ARG(PostFlowArgs, op[q].pf);
-    post_flow_body<false>(a);
+    post_flow_body(a);
 }
 
 __global__ void __launch_bounds__(BLOCK) kt_post_step(const Slot *__restrict__ tab, const int q)
 {
     CVO_SLOT(tab);
     const PostStepArgs a = CVO_ARG(PostStepArgs, op[q].ps);
-    post_step_body<false>(a);
-}
-
-// The list passes of a crowded engine with their post parts as ticket tails (cvo: three dependent launches
-// per iteration -- filter, flow, step -- instead of five): op[q].p is the pass, op[q].pf / .ps the post part.
-__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(7, 8)))
-kt_flow_tail(const Slot *__restrict__ tab, const int q)
-{
-    __shared__ __attribute__((aligned(16))) char scratch[PROC_SMEM];
-    CVO_SLOT(tab);
-    const ProcessArgs &a = CVO_ARG(ProcessArgs, op[q].p);
-    ProcHead hd = proc_head_global<PROC_FLOW>(a, a.st, 0);
-    hd.need_d2 = 0;   // (the cvo loop: see kt_process<PROC_FLOW, 0>)
-    if (!process_body<PROC_FLOW, 0, true, true>(a, blockIdx.x, scratch, hd)) return;
-    const PostFlowArgs pf = CVO_ARG(PostFlowArgs, op[q].pf);
-    post_flow_body<true>(pf);
-}
-
-__global__ void __launch_bounds__(BLOCK) kt_step_tail(const Slot *__restrict__ tab, const int q)
-{
-    __shared__ __attribute__((aligned(16))) char scratch[PROC_SMEM];
-    CVO_SLOT(tab);
-    const ProcessArgs &a = CVO_ARG(ProcessArgs, op[q].p);
-    if (!process_body<PROC_STEP, 0, true, true>(a, blockIdx.x, scratch, proc_head_global<PROC_STEP>(a, a.st, 0))) return;
-    const PostStepArgs ps = CVO_ARG(PostStepArgs, op[q].ps);
-    post_step_body<true>(ps);
+    post_step_body(a);
 }
 
 // The merged launches of a registration with its launches to itself (asynchronous list builds,
@@ -2175,6 +2130,7 @@ __device__ __forceinline__ ProcHead proc_head_lds(const ProcessArgs &a, const De
     hd.par = par;
     hd.cand = nullptr; hd.cand_cnt = nullptr;
     hd.need_d2 = a.need_d2;
+    hd.pos_b = a.pos_b; hd.tf_b = a.tf_b;
     if (a.cand_b) {   // the record of the buffer in use (xy list; acvo: xx / yy)
         const int l = a.async_self == 2 ? 1 : 0;
         const int ck = MODE == PROC_FLOW ? (hd.second ? h->xy_ck[1] : h->xy_ck[0]) : (hd.second ? h->sf_ck[l][1] : h->sf_ck[l][0]);
@@ -2268,6 +2224,248 @@ __global__ void __launch_bounds__(BLOCK) kt_head_flush(const Slot *__restrict__ 
     head_body<HM_FLUSH>(ps, ps.st, ps.st, &s_st, sh, 0, true);
 }
 
+// ---------------------------------------------------------------------------
+// Resident runs.  The light part of a registration -- a few tens of thousands of candidates per iteration, the
+// tile list and its candidate record valid for the next dozen iterations -- spends its time at the five launch
+// boundaries of an iteration and in the prologues behind them, not in its arithmetic.  kt_run executes up to
+// `iters` WHOLE iterations (ref src/cvo.cpp:366-410: transform, flow sums, twist, step sums, cubic, Exp, update,
+// length scale, stop tests) in ONE launch: RUN_G = 32 blocks per registration, all of them on one XCD (blocks
+// whose index is congruent modulo 8: observed placement, used for speed only), and between the passes a barrier
+// among those 32 on a counter of the registration plus an exchange of the blocks' partial sums -- published
+// write-through with 8-byte agent-scope stores, read back by EVERY block with agent-scope loads (0.8 us for the
+// barrier, 2.0 us with the exchange, against 2.3 us per launch boundary plus the prologue behind it:
+// profiles/r04_ab.txt 4).  Nothing else crosses blocks:
+//   * every block reduces all partial sums itself in the same fixed order and runs the O(1) maths itself -- the
+//     twist constants, then the head (cubic, Exp_SEK3, update, plan) exactly as a head-mode flow block does: all
+//     blocks hold the same head, bit for bit, in LDS, for the whole run; block 0 publishes it (state, trace, the
+//     host's mirrors) after every iteration;
+//   * a wave streams the slices of the candidate record its index names, applies the slot's transform itself
+//     (transform_pcd per pair: the transformed cloud of the classic launches would be another block's data),
+//     and keeps the members of A of an iteration in those slices' kept-list slices, which it alone reads back
+//     in the step pass.
+// A run ends when its iterations are done, the loop stops, or the plan wants a list rebuilt (the classic
+// launches of the plan do that: filter, expansion, a new record); a registration that is not in its light part
+// (too many members in its last iteration) or has no valid record does not enter.  Every block decides the same
+// from the same head.  A barrier that does not fill within its time-out ends the registration with
+// DONE_COMM_ERROR instead of hanging the GPU.
+// Co-residency: blocks are dispatched in index order and a chunk of 256 holds eight whole registrations, so at
+// most one chunk per launch can be partly resident, and what it waits for -- ordinary kernels, or chunks that are
+// whole -- ends without its help; concurrent runs of different engines need 256 blocks of room each.
+constexpr long long RUN_TIMEOUT_TICKS = 100000000LL;   // 1 s of the 100 MHz wall clock
+
+unsigned run_grid(int slots) { return (unsigned)((slots + 7) / 8 * 8 * RUN_G); }
+
+// all threads of the block; the partial sums this block publishes were stored by threads of wave 0
+__device__ __forceinline__ bool run_barrier(uint32_t *cnt, const unsigned target, int *s_ok)
+{
+    if (threadIdx.x < 64) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const long long t0 = (long long)wall_clock64();
+        int ok = 1;
+        while ((int)(__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
+            if ((long long)wall_clock64() - t0 > RUN_TIMEOUT_TICKS) { ok = 0; break; }
+            __builtin_amdgcn_s_sleep(1);
+        }
+        *s_ok = ok;
+    }
+    __syncthreads();
+    return *s_ok != 0;
+}
+
+// every block: the RUN_G blocks' partial sums [value][block], added in one fixed order, into out[0 .. N)
+template <int N>
+__device__ __forceinline__ void run_reduce(const double *part, double *out /* LDS */)
+{
+    if (threadIdx.x < 64) {
+        double v[N];
+#pragma unroll
+        for (int k = 0; k < N; ++k)
+            v[k] = ((int)threadIdx.x < RUN_G) ? load_partial<true>(&part[(size_t)k * RUN_G + threadIdx.x]) : 0.0;
+        wave_sums<N>(v, (int)threadIdx.x, out);
+    }
+    __syncthreads();
+}
+
+__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4, 8)))
+kt_run(const Slot *__restrict__ tab, const int qs, const int iters, const int nslots)
+{
+    __shared__ __attribute__((aligned(16))) char scratch[PROC_SMEM];
+    __shared__ __attribute__((aligned(16))) DevHead s_st;
+    __shared__ double tot[NACC_MAX + 4];
+    __shared__ cvo_math::XiConsts s_xi;
+    __shared__ int s_ok;
+    __shared__ unsigned s_base;
+    // eight registrations per chunk of 8 * RUN_G blocks, the blocks of one congruent modulo 8
+    const unsigned chunk = blockIdx.x / (8u * RUN_G), within = blockIdx.x % (8u * RUN_G);
+    const unsigned slot = chunk * 8u + (within & 7u), rank = within >> 3;
+    CSlot cs = (CSlot)(tab) + (slot < (unsigned)nslots ? slot : 0u);
+    if (slot >= (unsigned)nslots) return;   // (the table ends there)
+    if (cs->active == 0) return;
+    const int qf = qs & 15, qflow = (qs >> 4) & 15, qpf = (qs >> 8) & 15, qps = (qs >> 16) & 15;
+    const ProcessArgs &pa = CVO_ARG(ProcessArgs, op[qflow].p);
+    const FilterArgs &fa = CVO_ARG(FilterArgs, op[qf].f);
+    const PostFlowArgs &pf = CVO_ARG(PostFlowArgs, op[qpf].pf);
+    const PostStepArgs ps = CVO_ARG(PostStepArgs, op[qps].ps);
+    DevState *const gst = pa.st;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const ProcessArgs &a = pa;   // (the passes' arguments: the classic plan's, but on the moving cloud itself -- hd.pos_b below)
+    if (tid == 0) s_base = gst->run_base;
+    state_head_to_lds(gst, &s_st);   // (with its barrier)
+    const unsigned base = s_base;
+    // entry: a running loop in its light part, its tile list and the record of it as the plan wants them
+    {
+        const bool wide = a.cand_ck != nullptr;
+        const double nnz_last = s_st.red[RED_FLOW + 8];
+        if (s_st.done != RUNNING || a.cand == nullptr || wide || a.weight != 0 || !(nnz_last <= (double)ps.run_max_nnz) ||
+            ps.prm.mode != CVO_HIP_MODE_CVO || ps.comm != nullptr)
+            return;
+    }
+    double *red = reinterpret_cast<double *>(scratch);
+    double *s_etab_all = reinterpret_cast<double *>(scratch + 4 * NACC_MAX * 8 + 4 * PAIR_QUEUE * 8);
+    s_etab_all[tid] = c_exp2_64[tid & 63];
+    const double *s_etab = s_etab_all + wid * 64;
+    const unsigned gw = rank * 4u + (unsigned)wid;           // this wave among the registration's 4 * RUN_G
+    const unsigned nslice = 4u * (unsigned)a.nblk;           // slices of the record (waves of the pass that made it)
+    unsigned nb = 0;                                         // barriers passed
+    bool comm_ok = true;
+    auto uni = [](float x) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(x))); };
+    auto unid = [](double x) {
+        return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(x)), __builtin_amdgcn_readfirstlane(__double2loint(x)));
+    };
+    for (int it = 0; it < iters; ++it) {
+        __syncthreads();   // (the head of this iteration is complete in LDS)
+        if (s_st.done != RUNNING || s_st.reuse[LIST_XY] == 0 || s_st.ck_nblk[LIST_XY] != a.nblk) break;
+        // ---- flow pass (ref src/cvo.cpp:164-210 over the members se_kernel would keep, :99-161)
+        float rt[12];
+#pragma unroll
+        for (int q = 0; q < 9; ++q) rt[q] = uni(s_st.Rt[q]);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) rt[9 + q] = uni(s_st.t[q]);
+        ProcHead hd;
+        hd.Rt = rt; hd.tt = rt + 9; hd.xi = &s_xi;
+        {
+            const KernConsts &k = s_st.kc;
+            hd.kc.tau = uni(k.tau); hd.kc.tau_c = uni(k.tau_c); hd.kc.sp = uni(k.sp);
+            hd.kc.inv_c = uni(k.inv_c); hd.kc.inv_d = uni(k.inv_d); hd.kc.inv_l3 = uni(k.inv_l3);
+            hd.kc.cb = uni(k.cb); hd.kc.cg = uni(k.cg); hd.kc.cd = uni(k.cd); hd.kc.cscale = uni(k.cscale);
+            hd.kc.s2_d = unid(k.s2_d); hd.kc.cs2_d = unid(k.cs2_d);
+            hd.kc.ninv_2l2 = unid(k.ninv_2l2); hd.kc.ninv_2cl2 = unid(k.ninv_2cl2);
+        }
+        hd.done_word = 0; hd.n_fixed = 0; hd.second = 0; hd.list_bad = 0u; hd.ck_nblk = a.nblk; hd.par = 0;
+        hd.cand = a.cand; hd.cand_cnt = a.cand_cnt; hd.need_d2 = 0;
+        hd.pos_b = fa.pos_b; hd.tf_b = 1;
+        const KernConsts kc = hd.kc;
+        double acc[NACC_FLOW];
+#pragma unroll
+        for (int k = 0; k < NACC_FLOW; ++k) acc[k] = 0.0;
+        double members = 0.0;   // (lane 0)
+        for (unsigned sl = gw; sl < nslice; sl += 4u * RUN_G) {
+            stream_candidates<PROC_FLOW>(a, hd, kc, lane, sl, 0, s_etab, acc);
+            if (lane == 0) members += acc[8];
+            acc[8] = 0.0;
+        }
+        if (lane == 0) acc[8] = members;
+        wave_sums<NACC_FLOW>(acc, lane, red + wid * NACC_FLOW);
+        __syncthreads();
+        if (tid < NACC_FLOW) {
+            const double s = ((red[tid] + red[NACC_FLOW + tid]) + red[2 * NACC_FLOW + tid]) + red[3 * NACC_FLOW + tid];
+            __hip_atomic_store(&a.partials[(size_t)tid * RUN_G + rank], s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        ++nb;
+        if (!run_barrier(&gst->run_cnt, base + nb * (unsigned)RUN_G, &s_ok)) { comm_ok = false; break; }
+        run_reduce<NACC_FLOW>(a.partials, tot);
+        // ---- the tail of compute_flow (ref src/cvo.cpp:201-209): twist, Taylor constants; block 0: the trace record
+        if (tid == 0) {
+            float omega[3], v[3];
+            for (int q = 0; q < 3; ++q) { omega[q] = (float)tot[q]; v[q] = (float)tot[3 + q]; }
+            s_xi = cvo_math::make_xi_consts(omega, v);
+            for (int q = 0; q < NACC_FLOW; ++q) s_st.red[RED_FLOW + q] = tot[q];
+            for (int q = 0; q < 4; ++q) s_st.red[RED_XX + q] = 0.0;
+            for (int q = 0; q < 3; ++q) { s_st.omega[q] = omega[q]; s_st.v[q] = v[q]; }
+            s_st.xi = s_xi;
+            s_st.dl = 0.0;
+            if (rank == 0 && pf.trace && s_st.k < pf.trace_cap) {
+                cvo_hip_trace &tr = pf.trace[s_st.k];
+                tr.k = s_st.k;
+                tr.exit_code = 0;
+                tr.ell = s_st.ell;
+                for (int q = 0; q < 3; ++q) {
+                    tr.omega[q] = omega[q]; tr.v[q] = v[q];
+                    tr.omega_d[q] = tot[q]; tr.v_d[q] = tot[3 + q];
+                }
+                tr.sum_a = tot[6];
+                tr.dl = 0.0;
+                tr.nnz = (long long)tot[8]; tr.nnz_xx = 0; tr.nnz_yy = 0;
+            }
+        }
+        __syncthreads();
+        cvo_math::XiConsts xc;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            xc.omega[q] = uni(s_xi.omega[q]); xc.v[q] = uni(s_xi.v[q]);
+            xc.u2[q] = uni(s_xi.u2[q]); xc.u3[q] = uni(s_xi.u3[q]); xc.u4[q] = uni(s_xi.u4[q]);
+        }
+#pragma unroll
+        for (int q = 0; q < 9; ++q) {
+            xc.W2[q] = uni(s_xi.W2[q]); xc.W3[q] = uni(s_xi.W3[q]); xc.W4[q] = uni(s_xi.W4[q]);
+        }
+        // ---- compute_step_size sums (ref src/cvo.cpp:213-289) over the members this wave has just kept
+        double sacc[NACC_STEP];
+#pragma unroll
+        for (int k = 0; k < NACC_STEP; ++k) sacc[k] = 0.0;
+        for (unsigned sl = gw; sl < nslice; sl += 4u * RUN_G) {
+            const size_t kb = (size_t)sl * a.kept_wcap;
+            unsigned n = a.kept_cnt[sl];
+            if (n > a.kept_wcap) n = a.kept_wcap;
+            for (unsigned off = lane; off < n; off += 64) {
+                const uint2 e = a.kept_ij[kb + off];
+                const float w0 = a.kept_packed ? 0.0f : a.kept_a[kb + off];
+                unsigned mi, mj;
+                float mw;
+                kept_unpack(a.kept_packed, a.kept_ebase, e, w0, mi, mj, mw);
+                eval_pair<PROC_STEP>(a, hd, kc, mi, mj, mw, sacc, xc);
+            }
+        }
+        __syncthreads();   // (red is used again)
+        wave_sums<NACC_STEP>(sacc, lane, red + wid * NACC_STEP);
+        __syncthreads();
+        if (tid < NACC_STEP) {
+            const double s = ((red[tid] + red[NACC_STEP + tid]) + red[2 * NACC_STEP + tid]) + red[3 * NACC_STEP + tid];
+            __hip_atomic_store(&ps.run_part[(size_t)tid * RUN_G + rank], s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        ++nb;
+        if (!run_barrier(&gst->run_cnt, base + nb * (unsigned)RUN_G, &s_ok)) { comm_ok = false; break; }
+        run_reduce<NACC_STEP>(ps.run_part, tot);
+        if (tid < NACC_STEP) s_st.red[RED_STEP + tid] = tot[tid];
+        __syncthreads();
+        // ---- the head: cubic, break tests, Exp_SEK3, update, length scale, the plan of the next iteration
+        // (ref src/cvo.cpp:291-307,380-410), in every block; block 0 publishes
+        if (tid < 64) {
+            unsigned flag[LIST_N];
+#pragma unroll
+            for (int l = 0; l < LIST_N; ++l) flag[l] = 0u;   // (nothing is built and no slice can overflow in a run)
+            long long clk[4] = {0, 0, 0, 0};
+            head_math<HM_CLASSIC>(&s_st, ps, true, false, flag, rank == 0, false, clk);
+        }
+        __syncthreads();
+        if (rank == 0) {
+            head_prepare_lists<HM_CLASSIC>(ps, &s_st);
+            head_publish(ps, &s_st, gst, true);
+        }
+    }
+    if (!comm_ok) {   // a barrier timed out: nothing of this run can be trusted
+        if (tid == 0) {
+            gst->done = DONE_COMM_ERROR;
+            if (ps.done_mirror) *ps.done_mirror = DONE_COMM_ERROR;
+        }
+        return;
+    }
+    if (rank == 0 && tid == 0) gst->run_base = base + nb * (unsigned)RUN_G;
+}
+
 unsigned filter_grid_cap(long long nitems, long long cap) { return filter_grid_x(nitems, cap); }
 long long filter_blocks_cap() { return filter_blocks_max(); }
 
@@ -2275,10 +2473,6 @@ void launch_table(const Slot *tab, const TLaunch &l, hipStream_t s, hipEvent_t e
 {
     const dim3 g(l.gx, 1, l.gz);
     const int qp = l.q | (parity ? QP_PARITY : 0) | QP_HEAD;   // head-mode launches
-    if (ev_start && ev_stop && l.kernel == TK_FLOW_TAIL) {
-        hipExtLaunchKernelGGL(kt_flow_tail, g, dim3(BLOCK), 0, s, ev_start, ev_stop, 0, tab, l.q);
-        return;
-    }
     if (ev_start && ev_stop && (l.kernel == TK_FLOW || l.kernel == TK_FLOW_D2)) {   // engine profiling: the dispatch's own begin / end
         // (the kernel the plan names: TK_FLOW is built without the sum of a d2, acvo's plans need kt_flow_d2)
         if (l.kernel == TK_FLOW_D2) hipExtLaunchKernelGGL(kt_flow_d2, g, dim3(BLOCK), 0, s, ev_start, ev_stop, 0, tab, l.q);
@@ -2290,8 +2484,6 @@ void launch_table(const Slot *tab, const TLaunch &l, hipStream_t s, hipEvent_t e
     case TK_FILTER_GROUP: hipLaunchKernelGGL(kt_filter_group, dim3(l.gx, 3, l.gz), dim3(BLOCK), l.smem, s, tab, l.q); break;
     case TK_FLOW: hipLaunchKernelGGL(kt_process<PROC_FLOW>, g, dim3(BLOCK), 0, s, tab, l.q); break;
     case TK_FLOW_D2: hipLaunchKernelGGL(kt_flow_d2, g, dim3(BLOCK), 0, s, tab, l.q); break;
-    case TK_FLOW_TAIL: hipLaunchKernelGGL(kt_flow_tail, g, dim3(BLOCK), 0, s, tab, l.q); break;
-    case TK_STEP_TAIL: hipLaunchKernelGGL(kt_step_tail, g, dim3(BLOCK), 0, s, tab, l.q); break;
     case TK_FLOW_MATLAB: hipLaunchKernelGGL((kt_process<PROC_FLOW, 1>), g, dim3(BLOCK), 0, s, tab, l.q); break;
     case TK_STEP: hipLaunchKernelGGL(kt_process<PROC_STEP>, g, dim3(BLOCK), 0, s, tab, l.q); break;
     case TK_SELF: hipLaunchKernelGGL(kt_process<PROC_SELF>, g, dim3(BLOCK), 0, s, tab, l.q); break;
@@ -2306,6 +2498,7 @@ void launch_table(const Slot *tab, const TLaunch &l, hipStream_t s, hipEvent_t e
     case TK_HFLOW_BUILD6: hipLaunchKernelGGL(kt_hflow_build6_w4, g, dim3(BLOCK), l.smem, s, tab, qp); break;
     case TK_HSTEP_TWIST: hipLaunchKernelGGL(kt_step_twist, g, dim3(STEP_BLOCK), 0, s, tab, qp); break;
     case TK_HFLUSH: hipLaunchKernelGGL(kt_head_flush, g, dim3(BLOCK), 0, s, tab, l.q); break;
+    case TK_RUN: hipLaunchKernelGGL(kt_run, dim3(l.gx), dim3(BLOCK), 0, s, tab, l.q, l.arg, (int)l.gz); break;   // (gz: slots of the table it serves)
     default: break;
     }
 }
