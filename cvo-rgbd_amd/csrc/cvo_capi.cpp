@@ -27,7 +27,6 @@
 #include <deque>
 #include <mutex>
 #include <chrono>
-#include <thread>
 #include <vector>
 
 #include "cvo_comm.h"
@@ -1075,10 +1074,6 @@ int enqueue_step(cvo_hip_ctx *ctx, int check_done, bool do_math, cvo_hip_trace *
     for (int l = 0; l < 3; ++l) pa.ck_nblk[l] = ctx->plan_recording ? ctx->ck_nblk[l] : 0;
     pa.nblk = ctx->merge_twist ? ctx->proc_blocks / STEP_TWIST_ROWS_DIV : ctx->proc_blocks;
     pa.part_step = (const double *)ctx->part_step.p;
-    pa.run_part = (double *)ctx->part_step.p;
-    // (resident runs, kt_run: a registration is in its light part when an iteration keeps at most this many pairs)
-    static const int run_max_nnz = [] { const char *e = getenv("CVO_HIP_RUN_MAX_NNZ"); const int v = e ? atoi(e) : 300000; return v > 0 ? v : 300000; }();
-    pa.run_max_nnz = run_max_nnz;
     pa.dbg = ctx->post_dbg;
     pa.comm = ctx->comm_table;
     if (host_reduce(ctx)) {
@@ -1337,10 +1332,8 @@ bool plan_lone(const std::vector<RecOp> &ops, Slot &slot, std::vector<TLaunch> &
 // A fused group: one launch per recorded launch, blockIdx.z = slot.  `ops[i]` = member i's
 // recorded iteration (all of the same shape), `slots[i]` its slot image; geometry = what
 // serves every member (zdim slots share the launch).
-// run_iters > 0 (cvo, synchronous lists): every iteration of the plan is followed by a resident run of up to
-// that many iterations (kt_run, cvo_kernels.hip "Resident runs").
 bool plan_fused(const std::vector<const std::vector<RecOp> *> &ops, const std::vector<Slot *> &slots, int zdim,
-                std::vector<TLaunch> &plan, int run_iters = 0)
+                std::vector<TLaunch> &plan)
 {
     plan.clear();
     if (ops.empty()) return true;
@@ -1445,32 +1438,6 @@ bool plan_fused(const std::vector<const std::vector<RecOp> *> &ops, const std::v
         }
     }
     plan.swap(merged);
-    if (run_iters > 0) {
-        // the op entries whose argument blocks a run reads: the xy filter's (the moving cloud itself), the flow
-        // pass's, the two post parts' (trace; parameters, mirrors, the step sums' array)
-        int qf = -1, qflow = -1, qpf = -1, qstep = -1, qps = -1;
-        for (size_t qs = 0; qs < nq; ++qs) {
-            const RecOp &r = (*ops[0])[perm[qs]];
-            if (r.kind == RecOp::FILTER && r.mode != kFilterAhead && r.f.list == LIST_XY && qf < 0) qf = (int)qs;
-            else if (r.kind == RecOp::PROCESS && r.mode == PROC_FLOW && qflow < 0) qflow = (int)qs;
-            else if (r.kind == RecOp::POST_FLOW && qpf < 0) qpf = (int)qs;
-            else if (r.kind == RecOp::PROCESS && r.mode == PROC_STEP && qstep < 0) qstep = (int)qs;
-            else if (r.kind == RecOp::POST_STEP && qps < 0) qps = (int)qs;
-        }
-        bool ok = qf >= 0 && qflow >= 0 && qpf >= 0 && qstep >= 0 && qps >= 0;
-        for (const auto *o : ops) {
-            if (!ok) break;
-            const RecOp &fl = (*o)[perm[(size_t)qflow]], &po = (*o)[perm[(size_t)qps]], &pfo = (*o)[perm[(size_t)qpf]];
-            ok = fl.p.cand != nullptr && fl.p.cand_ck == nullptr && fl.p.weight == 0 && fl.p.need_d2 == 0 && fl.p.nblk >= RUN_G &&
-                 po.ps.comm == nullptr && po.ps.flags == (POST_REDUCE | POST_MATH) && po.ps.prm.mode == CVO_HIP_MODE_CVO &&
-                 pfo.pf.flags == (POST_REDUCE | POST_MATH) && pfo.pf.comm == nullptr;
-        }
-        if (ok) {
-            TLaunch l = mk_launch(TK_RUN, run_ops(qf, qflow, qpf, qstep, qps), run_grid(zdim), (unsigned)zdim);
-            l.arg = run_iters;
-            plan.push_back(l);
-        }
-    }
     return true;
 }
 
@@ -2501,16 +2468,6 @@ struct Engine {
     long long launched = 0, checked = 0;   // batches
     int zdim = 0;
     bool crowded = true, use_graph = true, dirty = true, failed = false;
-    // Phase-segregated calls (cvo_hip_align_many): a HEAVY engine takes the call's new registrations in small
-    // cohorts and carries each cohort through the first `heavy batches` of its loop -- for cvo the iterations at
-    // ell >= 0.06 (ref src/cvo.cpp:408-410), whose list passes are throughput-bound -- on many blocks per
-    // registration; the cohort is then handed to the LIGHT engines, which hold many registrations each, few
-    // blocks apiece, through their long latency-bound remainder.  A cohort in flight: its jobs and the event
-    // behind its last heavy batch.
-    bool heavy = false;
-    int run_iters = 0;                     // > 0: every iteration of the plan is followed by a resident run of up to this many (kt_run)
-    int cohorts_out = 0;                   // cohorts of this (heavy) engine whose event has not been seen complete
-    struct Cohort { hipEvent_t ev = nullptr; std::vector<AlignJob *> jobs; Engine *from = nullptr; };
     std::vector<TLaunch> plan;
     struct FlowEv { hipEvent_t a, b; int live; };
     std::vector<FlowEv> flow_ev;           // engine profiling: one pair per flow-pass launch
@@ -2531,7 +2488,7 @@ struct Engine {
     }
 
     int live() const { int n = 0; for (AlignJob *j : member) n += j != nullptr; return n; }
-    bool idle() const { return live() == 0 && retiring.empty() && launched == checked && cohorts_out == 0; }
+    bool idle() const { return live() == 0 && retiring.empty() && launched == checked; }
 
     static int nblk_for(int z)
     {
@@ -2586,12 +2543,7 @@ struct Engine {
         c->lone = false;
         j->in_group = true;
         int rc = CVO_HIP_OK;
-        if (j->phase == 4) {
-            // adopted from a heavy engine whose last batch for it has completed (the host has seen the cohort's
-            // event): state and lists are where that batch left them in HBM, the loop simply goes on here --
-            // nothing to prepare, nothing to copy; the slot's argument blocks are recorded by replan()
-            j->phase = 0;
-        } else if (j->phase == 3) {   // resuming: the state is where the overflow parked it
+        if (j->phase == 3) {   // resuming: the state is where the overflow parked it
             int32_t zero = 0;
             std::memcpy(&c->st_host[kPollSlots].done, &zero, sizeof(zero));
             if (hipMemcpyAsync(reinterpret_cast<char *>(c->st) + offsetof(DevState, done), &c->st_host[kPollSlots].done,
@@ -2660,7 +2612,7 @@ struct Engine {
             po.push_back(&ops[z]);
             ps.push_back(&slot[z]);
         }
-        if (!plan_fused(po, ps, zdim, plan, run_iters)) return CVO_HIP_ERR_INVALID;
+        if (!plan_fused(po, ps, zdim, plan)) return CVO_HIP_ERR_INVALID;
         const int nq = po.empty() ? 0 : (int)po[0]->size();
         if (tab.sync(slot, s, nq) != 0) return CVO_HIP_ERR_HIP;
         ++n_replans;
@@ -2739,9 +2691,7 @@ struct Engine {
     // one batch of kEngineBatch iterations of the current plan on this engine's stream
     int launch_one_batch()
     {
-        // (with resident runs one pass over the plan is up to 1 + run_iters iterations)
-        static const int run_reps = [] { const char *e = getenv("CVO_HIP_RUN_REPS"); const int v = e ? atoi(e) : 2; return v >= 1 && v <= 16 ? v : 2; }();
-        const int batch = run_iters > 0 ? run_reps : kEngineBatch;
+        const int batch = kEngineBatch;
         if (engine_profile()->on) {   // eager, the flow-pass launches bracketed by events
             for (int k = 0; k < batch; ++k)
                 for (const TLaunch &l : plan) {
@@ -2758,79 +2708,6 @@ struct Engine {
             return hipGetLastError() == hipSuccess ? CVO_HIP_OK : CVO_HIP_ERR_HIP;
         }
         return run_plan(tab.dev, plans, plan, s, use_graph, batch);
-    }
-
-    // The heavy engine of a phase-segregated call.  While fewer than two cohorts are on their way it takes the
-    // next `cohort_size` registrations of the queue into slots 0 .. cohort_size - 1 (their align() begins on
-    // this stream, or resumes after a list grew), queues `heavy_batches` batches for them, and records the
-    // cohort's event behind the last one; the slots are the next cohort's at once -- its table update is
-    // ordered behind those batches on the stream.  Nothing here looks at `done`: whoever adopts a job does.
-    bool pump_heavy(std::deque<AlignJob *> &pending, std::vector<Cohort> &arriving, int cohort_size, int heavy_batches)
-    {
-        if (failed) return false;
-        if (hipSetDevice(device) != hipSuccess) { fail_all("hipSetDevice failed", pending); return true; }
-        bool moved = false;
-        if (finish_arrived(pending, false)) moved = true;   // (registrations with nothing to run: max_iter <= 0)
-        while (!pending.empty() && cohorts_out < 2) {
-            moved = true;
-            for (int z = 0; z < ENGINE_SLOTS; ++z) { member[z] = nullptr; ops[z].clear(); }
-            int n = 0;
-            {
-                const double t0 = now_ms();
-                while (!pending.empty() && n < std::min(cohort_size, (int)ENGINE_SLOTS)) {
-                    AlignJob *j = pending.front();
-                    pending.pop_front();
-                    if (insert(j, n) == CVO_HIP_OK && member[n] == j) ++n;
-                }
-                t_insert += now_ms() - t0;
-            }
-            dirty = true;
-            if (n == 0) continue;
-            {
-                const double t0 = now_ms();
-                const int rc = replan();
-                t_replan += now_ms() - t0;
-                if (rc) { fail_all("fused launch recording failed", pending); return true; }
-            }
-            Cohort c;
-            c.from = this;
-            const double t_l0 = now_ms();
-            int rc_launch = CVO_HIP_OK;
-            for (int b = 0; b < heavy_batches && rc_launch == CVO_HIP_OK; ++b) rc_launch = launch_one_batch();
-            if (rc_launch != CVO_HIP_OK || hipEventCreateWithFlags(&c.ev, hipEventDisableTiming) != hipSuccess ||
-                hipEventRecord(c.ev, s) != hipSuccess) {
-                if (c.ev) (void)hipEventDestroy(c.ev);
-                fail_all("fused launch failed", pending);
-                return true;
-            }
-            t_launch += now_ms() - t_l0;
-            n_batches[zdim >= 16 ? 4 : (zdim >= 8 ? 3 : (zdim >= 4 ? 2 : (zdim >= 2 ? 1 : 0)))] += heavy_batches;
-            for (int z = 0; z < n; ++z) { c.jobs.push_back(member[z]); member[z] = nullptr; ops[z].clear(); }
-            ++cohorts_out;
-            arriving.push_back(c);
-        }
-        return moved;
-    }
-
-    // registrations whose loop has stopped while no engine held them (found stopped when their cohort arrived):
-    // their final state starts for the host on this stream; finish_arrived does the rest
-    void retire_jobs(const std::vector<AlignJob *> &jobs)
-    {
-        if (jobs.empty()) return;
-        Retire r;
-        for (AlignJob *j : jobs) {
-            if (hipMemcpyAsync(&j->ctx->st_host[0], j->ctx->st, sizeof(DevState), hipMemcpyDeviceToHost, s) != hipSuccess)
-                finish_job(j, fail(j->ctx, CVO_HIP_ERR_HIP, "state copy failed"));
-            else
-                r.jobs.push_back(j);
-        }
-        if (r.jobs.empty()) return;
-        if (hipEventCreateWithFlags(&r.ev, hipEventDisableTiming) != hipSuccess || hipEventRecord(r.ev, s) != hipSuccess) {
-            for (AlignJob *j : r.jobs) finish_job(j, fail(j->ctx, CVO_HIP_ERR_HIP, "event failed"));
-            if (r.ev) (void)hipEventDestroy(r.ev);
-            return;
-        }
-        retiring.push_back(r);
     }
 
     // Advance as far as possible without waiting on the GPU.  `want` = how many members this
@@ -2958,9 +2835,6 @@ void engine_release(Engine *e)
     for (long long &v : e->n_batches) v = 0;
     e->n_replans = 0;
     e->launched = e->checked = 0;
-    e->heavy = false;
-    e->cohorts_out = 0;
-    e->run_iters = 0;
     e->in_use = false;
 }
 
@@ -3028,8 +2902,6 @@ int cvo_hip_align_many(cvo_hip_ctx **ctxs, cvo_hip_state **states, int *n_iters,
             // 3 x 32 and 32 waiting 3297, 4 x 32 3644 -- the longest registration starts at once)
             static const size_t max_engines = [] { const char *e = getenv("CVO_HIP_ENGINES"); const int v = e ? atoi(e) : 4; return (size_t)std::max(1, std::min(v, 8)); }();
             size_t ngroups = total > 3 * ENGINE_SLOTS ? 4 : (total >= 40 ? 3 : (total >= 8 ? 2 : 1));
-            static const int seg_from = [] { const char *e = getenv("CVO_HIP_SEGREGATE_MIN"); return e ? atoi(e) : 24; }();
-            if (seg_from > 0 && (int)total >= seg_from) ngroups = total > 2 * ENGINE_SLOTS ? 4 : 3;   // (one heavy engine + the light ones, see below)
             ngroups = std::max<size_t>(1, std::min(ngroups, max_engines));
             if (const char *e = getenv("CVO_HIP_ENGINES_FORCE")) ngroups = (size_t)std::max(1, std::min(atoi(e), 8));   // (tuning probe)
             bool graphs_ok = true;   // (capture policy: cvo_hip_set_graph_capture)
@@ -3052,86 +2924,6 @@ int cvo_hip_align_many(cvo_hip_ctx **ctxs, cvo_hip_state **states, int *n_iters,
             if (engines.empty()) {   // no engine to be had: the jobs run on their own below
                 for (AlignJob *j : pending) taken[j - &jobs[0]] = 0;
                 continue;
-            }
-            // Phase-segregated call: with enough registrations to fill the GPU, the first engine is a
-            // HEAVY one -- cohorts of a few new registrations, many blocks each, through their throughput-bound first
-            // batches -- and the others LIGHT ones that adopt a cohort when its heavy batches have completed.  A
-            // registration's state and lists live in HBM and its launches take their arguments from a table, so the
-            // move is a table update on the adopting engine; what the heavy engine left queued behind the cohort
-            // belongs to the next cohort.
-            static const int seg_min = [] { const char *e = getenv("CVO_HIP_SEGREGATE_MIN"); return e ? atoi(e) : 24; }();   // (0: never)
-            static const int cohort_size = [] { const char *e = getenv("CVO_HIP_COHORT"); const int v = e ? atoi(e) : 8; return std::max(1, std::min(v, (int)ENGINE_SLOTS)); }();
-            static const int heavy_batches = [] { const char *e = getenv("CVO_HIP_HEAVY_BATCHES"); const int v = e ? atoi(e) : 2; return std::max(1, std::min(v, 16)); }();
-            static const int n_heavy_env = [] { const char *e = getenv("CVO_HIP_HEAVY_ENGINES"); const int v = e ? atoi(e) : 1; return std::max(1, std::min(v, 3)); }();
-            const bool segregate = seg_min > 0 && (int)total >= seg_min && engines.size() >= 2 && engines[0]->crowded;
-            if (segregate) {
-                const size_t n_heavy = std::min<size_t>((size_t)n_heavy_env, engines.size() - 1);
-                std::vector<Engine *> heavy(engines.begin(), engines.begin() + n_heavy), light(engines.begin() + n_heavy, engines.end());
-                static const int run_iters_env = [] { const char *e = getenv("CVO_HIP_RUN_ITERS"); const int v = e ? atoi(e) : 0; return v >= 0 && v <= 64 ? v : 0; }();
-                for (Engine *e : heavy) { e->heavy = true; e->cohorts_out = 0; e->run_iters = 0; }
-                for (Engine *e : light) { e->heavy = false; e->cohorts_out = 0; e->run_iters = jobs[i].ctx->prm.mode == CVO_HIP_MODE_CVO ? run_iters_env : 0; }
-                std::deque<AlignJob *> light_q;            // running registrations no engine holds: the next free light slots are theirs
-                std::vector<Engine::Cohort> arriving;      // cohorts on their way through a heavy engine
-                unsigned spins = 0;
-                for (;;) {
-                    bool moved = false;
-                    for (Engine *e : heavy)
-                        if (e->pump_heavy(pending, arriving, cohort_size, heavy_batches)) moved = true;
-                    // cohorts whose heavy batches have completed
-                    std::vector<AlignJob *> stopped;
-                    for (size_t a = 0; a < arriving.size();) {
-                        const hipError_t q = hipEventQuery(arriving[a].ev);
-                        if (q == hipErrorNotReady) { ++a; continue; }
-                        for (AlignJob *j : arriving[a].jobs) {
-                            if (q != hipSuccess) { arriving[a].from->finish_job(j, fail(j->ctx, CVO_HIP_ERR_HIP, "cohort event failed")); continue; }
-                            if (*(volatile int32_t *)j->ctx->done_mirror == RUNNING) { j->phase = 4; light_q.push_back(j); }
-                            else stopped.push_back(j);   // (converged, or parked on a list that must grow, inside its heavy batches)
-                        }
-                        --arriving[a].from->cohorts_out;
-                        (void)hipEventDestroy(arriving[a].ev);
-                        arriving.erase(arriving.begin() + (long)a);
-                        moved = true;
-                    }
-                    if (!stopped.empty()) light[0]->retire_jobs(stopped);
-                    // the light engines share what is running evenly
-                    size_t held = light_q.size();
-                    for (Engine *e : light) held += (size_t)e->live();
-                    const int want = std::min<int>(gmax, (int)((held + light.size() - 1) / light.size()));
-                    for (Engine *e : light)
-                        if (e->pump(light_q, want)) moved = true;
-                    bool any = !arriving.empty() || !pending.empty() || !light_q.empty();
-                    for (Engine *e : engines) any = any || !e->idle();
-                    if (!any) break;
-                    bool alive = true;
-                    for (Engine *e : engines) alive = alive && !e->failed;
-                    if (!alive) {   // an engine died: nothing of this call can be trusted to complete
-                        for (Engine *e : engines)
-                            if (!e->failed) e->fail_all("a sibling engine failed", e->heavy ? pending : light_q);
-                        for (auto &c : arriving) {
-                            for (AlignJob *j : c.jobs)
-                                if (j->phase != 2) c.from->finish_job(j, fail(j->ctx, CVO_HIP_ERR_HIP, "engine failed"));
-                            (void)hipEventDestroy(c.ev);
-                        }
-                        arriving.clear();
-                        for (AlignJob *j : pending) { j->rc = fail(j->ctx, CVO_HIP_ERR_HIP, "engine failed"); j->phase = 2; }
-                        for (AlignJob *j : light_q) { j->rc = fail(j->ctx, CVO_HIP_ERR_HIP, "engine failed"); j->phase = 2; }
-                        pending.clear();
-                        light_q.clear();
-                        break;
-                    }
-                    if (moved) { spins = 0; continue; }
-                    // several independent things are in flight (cohort events, every light engine's batches): poll them
-                    // in turn rather than sleep on one; after a while of nothing, yield the core between polls
-                    for (int k = 0; k < 64; ++k) __builtin_ia32_pause();
-                    if (++spins > 20000u) { std::this_thread::yield(); }
-                }
-                for (Engine *e : engines) { e->heavy = false; e->cohorts_out = 0; e->run_iters = 0; }
-                for (Engine *e : engines) engine_release(e);
-                continue;
-            }
-            {   // (tuning probe: resident runs in the engines of an unsegregated call)
-                static const int run_all = [] { const char *e = getenv("CVO_HIP_RUN_ALL"); const int v = e ? atoi(e) : 0; return v >= 0 && v <= 64 ? v : 0; }();
-                for (Engine *e : engines) e->run_iters = (run_all > 0 && e->crowded && jobs[i].ctx->prm.mode == CVO_HIP_MODE_CVO) ? run_all : 0;
             }
             // the first fill is even (16 + 16 of 32, 4 + 4 of 8); later a free slot takes the next job
             const int share = std::min<int>(gmax, (int)((total + engines.size() - 1) / engines.size()));

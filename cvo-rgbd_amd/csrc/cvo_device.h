@@ -209,9 +209,6 @@ struct DevState : DevHead {
     // bit k of built[l]: iteration k (mod 2048) rebuilt list l (profiling: which
     // k_filter launches did the work)
     uint32_t built[3][64];
-    // kt_run (cvo_kernels.hip "Resident runs"): arrivals of the registration's blocks at the barriers of its resident
-    // runs, monotonic; and the count at which the last run ended = where the next one starts counting from
-    uint32_t run_cnt, run_base;
     // exchanges done through the mailboxes since the context was created (never reset: the
     // sequence numbers of successive align() calls must keep alternating between the two
     // slot generations) -- kept last, align() re-initialises everything in front of it
@@ -339,8 +336,6 @@ struct PostStepArgs {
                                 // batch when the running one is down to its last slot instead of a whole batch ahead
     int nblk;
     const CommTable *comm; // see PostFlowArgs
-    double *run_part;      // kt_run: [NACC_STEP][RUN_G] partial sums of its step pass (the step pass's own array)
-    int run_max_nnz;       // kt_run: a registration enters a resident run only if its last iteration kept at most this many pairs
     DevParams prm;
 };
 
@@ -701,8 +696,7 @@ constexpr int STEP_TWIST_ROWS_DIV = 4;   // k_step_twist writes nblk / 4 partial
 enum TKernel { TK_FILTER = 0, TK_FILTER_GROUP, TK_FLOW, TK_FLOW_MATLAB, TK_STEP, TK_SELF, TK_SELF2, TK_STEP_TWIST,
                TK_FLOW_BUILD, TK_FLOW_BUILD3, TK_FLOW_BUILD6, TK_POST_FLOW, TK_POST_STEP,
                TK_HFLOW_BUILD, TK_HFLOW_BUILD6, TK_HSTEP_TWIST, TK_HFLUSH,
-               TK_FLOW_D2 /* TK_FLOW is built without the sum of a d2 (ProcessArgs::need_d2 == 0 in every slot); this one has it */,
-               TK_RUN /* kt_run: up to TLaunch::arg whole iterations in one launch, q = the packed op indices (run_ops) */ };
+               TK_FLOW_D2 /* TK_FLOW is built without the sum of a d2 (ProcessArgs::need_d2 == 0 in every slot); this one has it */ };   // head mode (cvo_kernels.hip "Head mode")
 // Head-mode launches carry the slot's parity and the mode in the bits above the op index of their
 // second kernel argument: qp = q | parity << 8 | QP_HEAD.
 constexpr int QP_PARITY = 1 << 8, QP_HEAD = 1 << 9, QP_MASK = 0xff;
@@ -711,16 +705,7 @@ struct TLaunch {
     int q;               // op index in the slots
     unsigned gx, gz;     // grid.x, grid.z (= slots served)
     unsigned smem;       // dynamic LDS bytes
-    int arg;             // TK_RUN: iterations per launch
 };
-// kt_run: blocks per registration (one XCD's share of a 256-block chunk) and the op indices of the classic plan's
-// launches whose argument blocks it reads, packed into its second kernel argument
-constexpr int RUN_G = 32;
-CVO_HD int run_ops(int q_filter, int q_flow, int q_post_flow, int q_step, int q_post_step)
-{
-    return q_filter | (q_flow << 4) | (q_post_flow << 8) | (q_step << 12) | (q_post_step << 16);
-}
-unsigned run_grid(int slots);   // grid.x of a kt_run launch that serves slots 0 .. slots - 1
 // (parity: of the slot within its batch, head-mode kernels only)
 void launch_table(const Slot *tab, const TLaunch &l, hipStream_t s, hipEvent_t ev_start = nullptr,
                   hipEvent_t ev_stop = nullptr, int parity = 0);

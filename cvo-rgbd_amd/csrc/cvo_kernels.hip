@@ -624,17 +624,6 @@ __device__ __forceinline__ void wave_sums(double (&v)[N], int lane, double *dst)
     if (p >= 0) dst[p] = v[0];
 }
 
-// a partial sum / a flag that ANOTHER block of the running launch has written (kt_run below): an agent-scope
-// load, served past this CU's L1 -- the writer stored it write-through with an agent-scope store
-template <bool COH> __device__ __forceinline__ double load_partial(const double *p)
-{
-    return COH ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *p;
-}
-template <bool COH> __device__ __forceinline__ unsigned load_flag(const uint32_t *p)
-{
-    return COH ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *p;
-}
-
 template <int MODE> struct NAcc;
 template <> struct NAcc<PROC_FLOW> { static constexpr int n = NACC_FLOW; };
 template <> struct NAcc<PROC_STEP> { static constexpr int n = NACC_STEP; };
@@ -675,9 +664,6 @@ struct ProcHead {
     uint2 *cand;                   // the candidate record of the list (buffer) the pass reads, its per-wave counts
     uint32_t *cand_cnt;
     int need_d2;                   // ProcessArgs::need_d2 -- or 0 where the kernel is built for loops that never read that sum
-    const float4 *pos_b;           // the column cloud and whether the slot's transform is still to be applied to it:
-    int tf_b;                      // ProcessArgs::pos_b / tf_b -- kt_run reads the moving cloud itself where the classic
-                                   // launches read the copy their filter launch has transformed
 };
 
 template <int MODE>
@@ -704,7 +690,6 @@ __device__ __forceinline__ ProcHead proc_head_global(const ProcessArgs &a, const
     h.par = par;
     h.cand = a.cand; h.cand_cnt = a.cand_cnt;
     h.need_d2 = a.need_d2;
-    h.pos_b = a.pos_b; h.tf_b = a.tf_b;
     return h;
 }
 
@@ -742,7 +727,7 @@ __device__ __forceinline__ float eval_pair(const ProcessArgs &a, const ProcHead 
     const float *tt = hd.tt;
     float4 xi = *gather16(a.pos_a, i * 16u);
     if (a.tf_a) xi = apply_tf(Rt, tt, xi);
-    float4 yj = *gather16(hd.pos_b, j * 16u);
+    float4 yj = *gather16(a.pos_b, j * 16u);
     // the features are fetched together with the positions (one memory round
     // trip per pair instead of two); ~97 % of the filtered pairs need them
     float4 fa0 = make_float4(0.f, 0.f, 0.f, 0.f), fb0 = fa0;
@@ -756,7 +741,7 @@ __device__ __forceinline__ float eval_pair(const ProcessArgs &a, const ProcHead 
         if (MODE == PROC_SELF)   // the caller's index of the row (acvo Ayy rule)
             row_index = __float_as_int(a.feat_a[(size_t)i * FEAT_STRIDE + FEAT_INDEX_SLOT]);
     }
-    if (hd.tf_b) yj = apply_tf(Rt, tt, yj);
+    if (a.tf_b) yj = apply_tf(Rt, tt, yj);
     const float e0 = xi.x - yj.x, e1 = xi.y - yj.y, e2 = xi.z - yj.z;
     float d2 = 0.0f;
     if (MODE != PROC_STEP) {
@@ -1218,7 +1203,6 @@ __device__ __forceinline__ bool step_twist_body(const ProcessArgs &a, DevState *
     ProcHead phd;
     phd.need_d2 = 0;
     phd.Rt = hd->Rt; phd.tt = hd->t;   // (eval_pair<PROC_STEP> reads nothing else of it)
-    phd.pos_b = a.pos_b; phd.tf_b = a.tf_b;
     double acc[NACC];
 #pragma unroll
     for (int k = 0; k < NACC; ++k) acc[k] = 0.0;
@@ -1752,46 +1736,6 @@ __device__ __forceinline__ void head_math(DevHead *lds, const PostStepArgs &a, c
     }
 }
 
-// What the publishing block does once the head's maths has run (all its threads): the tile lists the coming
-// launches rebuild are emptied, the others are kept ...
-template <int HM>
-__device__ __forceinline__ void head_prepare_lists(const PostStepArgs &a, const DevHead *s_st)
-{
-    const int tid = threadIdx.x;
-    const bool async = a.prm.async_xy != 0, aself = a.prm.async_self != 0;
-    if (!(s_st->done == RUNNING || s_st->done == NEED_BIGGER_LIST)) return;
-    if (HM != HM_FLUSH) {
-#pragma unroll
-        for (int l = 0; l < 3; ++l) {   // synchronous lists (classic plans)
-            if (s_st->reuse[l] || (async && l == LIST_XY) || (aself && l != LIST_XY)) continue;
-            for (int q = tid; q < NSUB; q += BLOCK) a.st->sub[l][q] = 0u;
-            if (tid == 0) atomicOr(&a.st->built[l][(s_st->k >> 5) & 63], 1u << (s_st->k & 31));
-        }
-        if (async && s_st->xy_target >= 0) {   // the build the plan has just named
-            const int l = s_st->xy_target ? (int)LIST_XYB : (int)LIST_XY;
-            for (int q = tid; q < NSUB; q += BLOCK) a.st->sub[l][q] = 0u;
-        }
-        if (aself)
-            for (int l = 0; l < 2; ++l)
-                if (s_st->sf_target[l] >= 0) {
-                    const int id = self_list_id(l, s_st->sf_target[l]);
-                    for (int q = tid; q < NSUB; q += BLOCK) a.st->sub[id][q] = 0u;
-                }
-    }
-    // classic: every launch of the coming slot flags its overflows in row 0 again (a parked
-    // loop keeps the flags: the host needs them to know what to grow)
-    if (HM == HM_CLASSIC && tid < 8 && s_st->done == RUNNING) a.st->ovf[0][tid] = 0u;
-}
-// ... and the head goes out: the host's mirrors, then the state
-__device__ __forceinline__ void head_publish(const PostStepArgs &a, const DevHead *s_st, DevHead *out, const bool math)
-{
-    if (threadIdx.x == 0) {
-        if (math && a.progress_mirror) *a.progress_mirror = s_st->n_slots;
-        if (a.done_mirror && s_st->done != RUNNING) *a.done_mirror = s_st->done;
-    }
-    state_head_from_lds(s_st, out);
-}
-
 // The whole head of one block.  in / out: the copies of the state's head the launch reads / writes (the
 // same in the classic and flush forms); st: the state itself (the tail: sub-list counters, overflow
 // flags).  Returns true if the slot that begins may run (head mode: the loop is running, no stall).
@@ -1816,7 +1760,7 @@ __device__ __forceinline__ bool head_body(const PostStepArgs &a, const DevHead *
         if (HM == HM_HEAD && publisher) state_head_from_lds(s_st, out);
         return false;
     }
-    const bool async = a.prm.async_xy != 0;
+    const bool async = a.prm.async_xy != 0, aself = a.prm.async_self != 0;
     // a stall slot executed no iteration (asynchronous builds: only the plan runs)
     const bool stalled = async && s_st->stall != 0;
     const bool pending = HM == HM_CLASSIC ? true : (s_st->pending != 0);
@@ -1845,9 +1789,36 @@ __device__ __forceinline__ bool head_body(const PostStepArgs &a, const DevHead *
             }
         }
         __syncthreads();
-        if (publisher) head_prepare_lists<HM>(a, s_st);
+        // the tile lists the coming launches rebuild are emptied; the others are kept
+        if (publisher && (s_st->done == RUNNING || s_st->done == NEED_BIGGER_LIST)) {
+            if (HM != HM_FLUSH) {
+#pragma unroll
+                for (int l = 0; l < 3; ++l) {   // synchronous lists (classic plans)
+                    if (s_st->reuse[l] || (async && l == LIST_XY) || (aself && l != LIST_XY)) continue;
+                    for (int q = tid; q < NSUB; q += BLOCK) a.st->sub[l][q] = 0u;
+                    if (tid == 0) atomicOr(&a.st->built[l][(s_st->k >> 5) & 63], 1u << (s_st->k & 31));
+                }
+                if (async && s_st->xy_target >= 0) {   // the build the plan has just named
+                    const int l = s_st->xy_target ? (int)LIST_XYB : (int)LIST_XY;
+                    for (int q = tid; q < NSUB; q += BLOCK) a.st->sub[l][q] = 0u;
+                }
+                if (aself)
+                    for (int l = 0; l < 2; ++l)
+                        if (s_st->sf_target[l] >= 0) {
+                            const int id = self_list_id(l, s_st->sf_target[l]);
+                            for (int q = tid; q < NSUB; q += BLOCK) a.st->sub[id][q] = 0u;
+                        }
+            }
+            // classic: every launch of the coming slot flags its overflows in row 0 again (a parked
+            // loop keeps the flags: the host needs them to know what to grow)
+            if (HM == HM_CLASSIC && tid < 8 && s_st->done == RUNNING) a.st->ovf[0][tid] = 0u;
+        }
     }
-    if (publisher) head_publish(a, s_st, out, math);
+    if (publisher && tid == 0) {
+        if (math && a.progress_mirror) *a.progress_mirror = s_st->n_slots;
+        if (a.done_mirror && s_st->done != RUNNING) *a.done_mirror = s_st->done;
+    }
+    if (publisher) state_head_from_lds(s_st, out);
     return s_st->done == RUNNING && !(async && s_st->stall != 0);
 }
 
@@ -2130,7 +2101,6 @@ __device__ __forceinline__ ProcHead proc_head_lds(const ProcessArgs &a, const De
     hd.par = par;
     hd.cand = nullptr; hd.cand_cnt = nullptr;
     hd.need_d2 = a.need_d2;
-    hd.pos_b = a.pos_b; hd.tf_b = a.tf_b;
     if (a.cand_b) {   // the record of the buffer in use (xy list; acvo: xx / yy)
         const int l = a.async_self == 2 ? 1 : 0;
         const int ck = MODE == PROC_FLOW ? (hd.second ? h->xy_ck[1] : h->xy_ck[0]) : (hd.second ? h->sf_ck[l][1] : h->sf_ck[l][0]);
@@ -2224,248 +2194,6 @@ __global__ void __launch_bounds__(BLOCK) kt_head_flush(const Slot *__restrict__ 
     head_body<HM_FLUSH>(ps, ps.st, ps.st, &s_st, sh, 0, true);
 }
 
-// ---------------------------------------------------------------------------
-// Resident runs.  The light part of a registration -- a few tens of thousands of candidates per iteration, the
-// tile list and its candidate record valid for the next dozen iterations -- spends its time at the five launch
-// boundaries of an iteration and in the prologues behind them, not in its arithmetic.  kt_run executes up to
-// `iters` WHOLE iterations (ref src/cvo.cpp:366-410: transform, flow sums, twist, step sums, cubic, Exp, update,
-// length scale, stop tests) in ONE launch: RUN_G = 32 blocks per registration, all of them on one XCD (blocks
-// whose index is congruent modulo 8: observed placement, used for speed only), and between the passes a barrier
-// among those 32 on a counter of the registration plus an exchange of the blocks' partial sums -- published
-// write-through with 8-byte agent-scope stores, read back by EVERY block with agent-scope loads (0.8 us for the
-// barrier, 2.0 us with the exchange, against 2.3 us per launch boundary plus the prologue behind it:
-// profiles/r04_ab.txt 4).  Nothing else crosses blocks:
-//   * every block reduces all partial sums itself in the same fixed order and runs the O(1) maths itself -- the
-//     twist constants, then the head (cubic, Exp_SEK3, update, plan) exactly as a head-mode flow block does: all
-//     blocks hold the same head, bit for bit, in LDS, for the whole run; block 0 publishes it (state, trace, the
-//     host's mirrors) after every iteration;
-//   * a wave streams the slices of the candidate record its index names, applies the slot's transform itself
-//     (transform_pcd per pair: the transformed cloud of the classic launches would be another block's data),
-//     and keeps the members of A of an iteration in those slices' kept-list slices, which it alone reads back
-//     in the step pass.
-// A run ends when its iterations are done, the loop stops, or the plan wants a list rebuilt (the classic
-// launches of the plan do that: filter, expansion, a new record); a registration that is not in its light part
-// (too many members in its last iteration) or has no valid record does not enter.  Every block decides the same
-// from the same head.  A barrier that does not fill within its time-out ends the registration with
-// DONE_COMM_ERROR instead of hanging the GPU.
-// Co-residency: blocks are dispatched in index order and a chunk of 256 holds eight whole registrations, so at
-// most one chunk per launch can be partly resident, and what it waits for -- ordinary kernels, or chunks that are
-// whole -- ends without its help; concurrent runs of different engines need 256 blocks of room each.
-constexpr long long RUN_TIMEOUT_TICKS = 100000000LL;   // 1 s of the 100 MHz wall clock
-
-unsigned run_grid(int slots) { return (unsigned)((slots + 7) / 8 * 8 * RUN_G); }
-
-// all threads of the block; the partial sums this block publishes were stored by threads of wave 0
-__device__ __forceinline__ bool run_barrier(uint32_t *cnt, const unsigned target, int *s_ok)
-{
-    if (threadIdx.x < 64) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const long long t0 = (long long)wall_clock64();
-        int ok = 1;
-        while ((int)(__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
-            if ((long long)wall_clock64() - t0 > RUN_TIMEOUT_TICKS) { ok = 0; break; }
-            __builtin_amdgcn_s_sleep(1);
-        }
-        *s_ok = ok;
-    }
-    __syncthreads();
-    return *s_ok != 0;
-}
-
-// every block: the RUN_G blocks' partial sums [value][block], added in one fixed order, into out[0 .. N)
-template <int N>
-__device__ __forceinline__ void run_reduce(const double *part, double *out /* LDS */)
-{
-    if (threadIdx.x < 64) {
-        double v[N];
-#pragma unroll
-        for (int k = 0; k < N; ++k)
-            v[k] = ((int)threadIdx.x < RUN_G) ? load_partial<true>(&part[(size_t)k * RUN_G + threadIdx.x]) : 0.0;
-        wave_sums<N>(v, (int)threadIdx.x, out);
-    }
-    __syncthreads();
-}
-
-__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4, 8)))
-kt_run(const Slot *__restrict__ tab, const int qs, const int iters, const int nslots)
-{
-    __shared__ __attribute__((aligned(16))) char scratch[PROC_SMEM];
-    __shared__ __attribute__((aligned(16))) DevHead s_st;
-    __shared__ double tot[NACC_MAX + 4];
-    __shared__ cvo_math::XiConsts s_xi;
-    __shared__ int s_ok;
-    __shared__ unsigned s_base;
-    // eight registrations per chunk of 8 * RUN_G blocks, the blocks of one congruent modulo 8
-    const unsigned chunk = blockIdx.x / (8u * RUN_G), within = blockIdx.x % (8u * RUN_G);
-    const unsigned slot = chunk * 8u + (within & 7u), rank = within >> 3;
-    CSlot cs = (CSlot)(tab) + (slot < (unsigned)nslots ? slot : 0u);
-    if (slot >= (unsigned)nslots) return;   // (the table ends there)
-    if (cs->active == 0) return;
-    const int qf = qs & 15, qflow = (qs >> 4) & 15, qpf = (qs >> 8) & 15, qps = (qs >> 16) & 15;
-    const ProcessArgs &pa = CVO_ARG(ProcessArgs, op[qflow].p);
-    const FilterArgs &fa = CVO_ARG(FilterArgs, op[qf].f);
-    const PostFlowArgs &pf = CVO_ARG(PostFlowArgs, op[qpf].pf);
-    const PostStepArgs ps = CVO_ARG(PostStepArgs, op[qps].ps);
-    DevState *const gst = pa.st;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const ProcessArgs &a = pa;   // (the passes' arguments: the classic plan's, but on the moving cloud itself -- hd.pos_b below)
-    if (tid == 0) s_base = gst->run_base;
-    state_head_to_lds(gst, &s_st);   // (with its barrier)
-    const unsigned base = s_base;
-    // entry: a running loop in its light part, its tile list and the record of it as the plan wants them
-    {
-        const bool wide = a.cand_ck != nullptr;
-        const double nnz_last = s_st.red[RED_FLOW + 8];
-        if (s_st.done != RUNNING || a.cand == nullptr || wide || a.weight != 0 || !(nnz_last <= (double)ps.run_max_nnz) ||
-            ps.prm.mode != CVO_HIP_MODE_CVO || ps.comm != nullptr)
-            return;
-    }
-    double *red = reinterpret_cast<double *>(scratch);
-    double *s_etab_all = reinterpret_cast<double *>(scratch + 4 * NACC_MAX * 8 + 4 * PAIR_QUEUE * 8);
-    s_etab_all[tid] = c_exp2_64[tid & 63];
-    const double *s_etab = s_etab_all + wid * 64;
-    const unsigned gw = rank * 4u + (unsigned)wid;           // this wave among the registration's 4 * RUN_G
-    const unsigned nslice = 4u * (unsigned)a.nblk;           // slices of the record (waves of the pass that made it)
-    unsigned nb = 0;                                         // barriers passed
-    bool comm_ok = true;
-    auto uni = [](float x) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(x))); };
-    auto unid = [](double x) {
-        return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(x)), __builtin_amdgcn_readfirstlane(__double2loint(x)));
-    };
-    for (int it = 0; it < iters; ++it) {
-        __syncthreads();   // (the head of this iteration is complete in LDS)
-        if (s_st.done != RUNNING || s_st.reuse[LIST_XY] == 0 || s_st.ck_nblk[LIST_XY] != a.nblk) break;
-        // ---- flow pass (ref src/cvo.cpp:164-210 over the members se_kernel would keep, :99-161)
-        float rt[12];
-#pragma unroll
-        for (int q = 0; q < 9; ++q) rt[q] = uni(s_st.Rt[q]);
-#pragma unroll
-        for (int q = 0; q < 3; ++q) rt[9 + q] = uni(s_st.t[q]);
-        ProcHead hd;
-        hd.Rt = rt; hd.tt = rt + 9; hd.xi = &s_xi;
-        {
-            const KernConsts &k = s_st.kc;
-            hd.kc.tau = uni(k.tau); hd.kc.tau_c = uni(k.tau_c); hd.kc.sp = uni(k.sp);
-            hd.kc.inv_c = uni(k.inv_c); hd.kc.inv_d = uni(k.inv_d); hd.kc.inv_l3 = uni(k.inv_l3);
-            hd.kc.cb = uni(k.cb); hd.kc.cg = uni(k.cg); hd.kc.cd = uni(k.cd); hd.kc.cscale = uni(k.cscale);
-            hd.kc.s2_d = unid(k.s2_d); hd.kc.cs2_d = unid(k.cs2_d);
-            hd.kc.ninv_2l2 = unid(k.ninv_2l2); hd.kc.ninv_2cl2 = unid(k.ninv_2cl2);
-        }
-        hd.done_word = 0; hd.n_fixed = 0; hd.second = 0; hd.list_bad = 0u; hd.ck_nblk = a.nblk; hd.par = 0;
-        hd.cand = a.cand; hd.cand_cnt = a.cand_cnt; hd.need_d2 = 0;
-        hd.pos_b = fa.pos_b; hd.tf_b = 1;
-        const KernConsts kc = hd.kc;
-        double acc[NACC_FLOW];
-#pragma unroll
-        for (int k = 0; k < NACC_FLOW; ++k) acc[k] = 0.0;
-        double members = 0.0;   // (lane 0)
-        for (unsigned sl = gw; sl < nslice; sl += 4u * RUN_G) {
-            stream_candidates<PROC_FLOW>(a, hd, kc, lane, sl, 0, s_etab, acc);
-            if (lane == 0) members += acc[8];
-            acc[8] = 0.0;
-        }
-        if (lane == 0) acc[8] = members;
-        wave_sums<NACC_FLOW>(acc, lane, red + wid * NACC_FLOW);
-        __syncthreads();
-        if (tid < NACC_FLOW) {
-            const double s = ((red[tid] + red[NACC_FLOW + tid]) + red[2 * NACC_FLOW + tid]) + red[3 * NACC_FLOW + tid];
-            __hip_atomic_store(&a.partials[(size_t)tid * RUN_G + rank], s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        ++nb;
-        if (!run_barrier(&gst->run_cnt, base + nb * (unsigned)RUN_G, &s_ok)) { comm_ok = false; break; }
-        run_reduce<NACC_FLOW>(a.partials, tot);
-        // ---- the tail of compute_flow (ref src/cvo.cpp:201-209): twist, Taylor constants; block 0: the trace record
-        if (tid == 0) {
-            float omega[3], v[3];
-            for (int q = 0; q < 3; ++q) { omega[q] = (float)tot[q]; v[q] = (float)tot[3 + q]; }
-            s_xi = cvo_math::make_xi_consts(omega, v);
-            for (int q = 0; q < NACC_FLOW; ++q) s_st.red[RED_FLOW + q] = tot[q];
-            for (int q = 0; q < 4; ++q) s_st.red[RED_XX + q] = 0.0;
-            for (int q = 0; q < 3; ++q) { s_st.omega[q] = omega[q]; s_st.v[q] = v[q]; }
-            s_st.xi = s_xi;
-            s_st.dl = 0.0;
-            if (rank == 0 && pf.trace && s_st.k < pf.trace_cap) {
-                cvo_hip_trace &tr = pf.trace[s_st.k];
-                tr.k = s_st.k;
-                tr.exit_code = 0;
-                tr.ell = s_st.ell;
-                for (int q = 0; q < 3; ++q) {
-                    tr.omega[q] = omega[q]; tr.v[q] = v[q];
-                    tr.omega_d[q] = tot[q]; tr.v_d[q] = tot[3 + q];
-                }
-                tr.sum_a = tot[6];
-                tr.dl = 0.0;
-                tr.nnz = (long long)tot[8]; tr.nnz_xx = 0; tr.nnz_yy = 0;
-            }
-        }
-        __syncthreads();
-        cvo_math::XiConsts xc;
-#pragma unroll
-        for (int q = 0; q < 3; ++q) {
-            xc.omega[q] = uni(s_xi.omega[q]); xc.v[q] = uni(s_xi.v[q]);
-            xc.u2[q] = uni(s_xi.u2[q]); xc.u3[q] = uni(s_xi.u3[q]); xc.u4[q] = uni(s_xi.u4[q]);
-        }
-#pragma unroll
-        for (int q = 0; q < 9; ++q) {
-            xc.W2[q] = uni(s_xi.W2[q]); xc.W3[q] = uni(s_xi.W3[q]); xc.W4[q] = uni(s_xi.W4[q]);
-        }
-        // ---- compute_step_size sums (ref src/cvo.cpp:213-289) over the members this wave has just kept
-        double sacc[NACC_STEP];
-#pragma unroll
-        for (int k = 0; k < NACC_STEP; ++k) sacc[k] = 0.0;
-        for (unsigned sl = gw; sl < nslice; sl += 4u * RUN_G) {
-            const size_t kb = (size_t)sl * a.kept_wcap;
-            unsigned n = a.kept_cnt[sl];
-            if (n > a.kept_wcap) n = a.kept_wcap;
-            for (unsigned off = lane; off < n; off += 64) {
-                const uint2 e = a.kept_ij[kb + off];
-                const float w0 = a.kept_packed ? 0.0f : a.kept_a[kb + off];
-                unsigned mi, mj;
-                float mw;
-                kept_unpack(a.kept_packed, a.kept_ebase, e, w0, mi, mj, mw);
-                eval_pair<PROC_STEP>(a, hd, kc, mi, mj, mw, sacc, xc);
-            }
-        }
-        __syncthreads();   // (red is used again)
-        wave_sums<NACC_STEP>(sacc, lane, red + wid * NACC_STEP);
-        __syncthreads();
-        if (tid < NACC_STEP) {
-            const double s = ((red[tid] + red[NACC_STEP + tid]) + red[2 * NACC_STEP + tid]) + red[3 * NACC_STEP + tid];
-            __hip_atomic_store(&ps.run_part[(size_t)tid * RUN_G + rank], s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        ++nb;
-        if (!run_barrier(&gst->run_cnt, base + nb * (unsigned)RUN_G, &s_ok)) { comm_ok = false; break; }
-        run_reduce<NACC_STEP>(ps.run_part, tot);
-        if (tid < NACC_STEP) s_st.red[RED_STEP + tid] = tot[tid];
-        __syncthreads();
-        // ---- the head: cubic, break tests, Exp_SEK3, update, length scale, the plan of the next iteration
-        // (ref src/cvo.cpp:291-307,380-410), in every block; block 0 publishes
-        if (tid < 64) {
-            unsigned flag[LIST_N];
-#pragma unroll
-            for (int l = 0; l < LIST_N; ++l) flag[l] = 0u;   // (nothing is built and no slice can overflow in a run)
-            long long clk[4] = {0, 0, 0, 0};
-            head_math<HM_CLASSIC>(&s_st, ps, true, false, flag, rank == 0, false, clk);
-        }
-        __syncthreads();
-        if (rank == 0) {
-            head_prepare_lists<HM_CLASSIC>(ps, &s_st);
-            head_publish(ps, &s_st, gst, true);
-        }
-    }
-    if (!comm_ok) {   // a barrier timed out: nothing of this run can be trusted
-        if (tid == 0) {
-            gst->done = DONE_COMM_ERROR;
-            if (ps.done_mirror) *ps.done_mirror = DONE_COMM_ERROR;
-        }
-        return;
-    }
-    if (rank == 0 && tid == 0) gst->run_base = base + nb * (unsigned)RUN_G;
-}
-
 unsigned filter_grid_cap(long long nitems, long long cap) { return filter_grid_x(nitems, cap); }
 long long filter_blocks_cap() { return filter_blocks_max(); }
 
@@ -2498,7 +2226,6 @@ void launch_table(const Slot *tab, const TLaunch &l, hipStream_t s, hipEvent_t e
     case TK_HFLOW_BUILD6: hipLaunchKernelGGL(kt_hflow_build6_w4, g, dim3(BLOCK), l.smem, s, tab, qp); break;
     case TK_HSTEP_TWIST: hipLaunchKernelGGL(kt_step_twist, g, dim3(STEP_BLOCK), 0, s, tab, qp); break;
     case TK_HFLUSH: hipLaunchKernelGGL(kt_head_flush, g, dim3(BLOCK), 0, s, tab, l.q); break;
-    case TK_RUN: hipLaunchKernelGGL(kt_run, dim3(l.gx), dim3(BLOCK), 0, s, tab, l.q, l.arg, (int)l.gz); break;   // (gz: slots of the table it serves)
     default: break;
     }
 }
