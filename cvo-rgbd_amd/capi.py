@@ -17,7 +17,7 @@ SYMBOLS = [
     "cvo_hip_default_params", "cvo_hip_init_state", "cvo_hip_create", "cvo_hip_destroy",
     "cvo_hip_set_params", "cvo_hip_set_fixed", "cvo_hip_set_moving",
     "cvo_hip_set_fixed_device", "cvo_hip_set_moving_device",
-    "cvo_hip_swap_moving_to_fixed", "cvo_hip_range_filter_grid_average", "cvo_hip_set_shard", "cvo_hip_shard_range",
+    "cvo_hip_swap_moving_to_fixed", "cvo_hip_set_pcd_many", "cvo_hip_get_device_cloud", "cvo_hip_range_filter_grid_average", "cvo_hip_set_shard", "cvo_hip_shard_range",
     "cvo_hip_comm_unique_id", "cvo_hip_comm_init", "cvo_hip_set_allreduce",
     "cvo_hip_mailbox_create", "cvo_hip_mailbox_connect",
     "cvo_hip_transform_pcd", "cvo_hip_flow", "cvo_hip_step_coeffs", "cvo_hip_pick_step",
@@ -105,6 +105,9 @@ def lib():
     L.cvo_hip_set_fixed_device.argtypes = [vp, vp, vp, C.c_int, C.c_int]
     L.cvo_hip_set_moving_device.argtypes = [vp, vp, vp, C.c_int, C.c_int]
     L.cvo_hip_swap_moving_to_fixed.argtypes = [vp]
+    pp = C.POINTER(C.c_void_p)
+    L.cvo_hip_set_pcd_many.argtypes = [pp, pp, pp, C.POINTER(C.c_int), pp, pp, C.POINTER(C.c_int), C.c_int, C.c_int]
+    L.cvo_hip_get_device_cloud.argtypes = [vp, C.c_int, fp, fp, fp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.cvo_hip_range_filter_grid_average.argtypes = [C.c_int, fp, C.POINTER(C.c_ubyte), C.c_int, C.c_float, C.c_float,
                                                     C.c_double, fp, C.POINTER(C.c_ubyte), C.POINTER(C.c_int)]
     L.cvo_hip_set_shard.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int]
@@ -295,6 +298,17 @@ class Context:
         self.n_moving = int(m)
         self._chk(self._L.cvo_hip_set_moving_device(self._ctx, d_xyz, d_feat, int(m), layout), "set_moving_device")
 
+    def device_cloud(self, which):
+        """Inspection: the device arrays of the fixed (0) / moving (1) cloud as the kernels read them."""
+        rows, pts = C.c_int(), C.c_int()
+        self._chk(self._L.cvo_hip_get_device_cloud(self._ctx, which, None, None, None, C.byref(rows), C.byref(pts)), "device_cloud")
+        pos = np.zeros((rows.value, 4), np.float32)
+        feat = np.zeros((rows.value, 8), np.float32)
+        seg = np.zeros(((rows.value + 63) // 64, 4), np.float32)
+        self._chk(self._L.cvo_hip_get_device_cloud(self._ctx, which, fptr(pos), fptr(feat), fptr(seg), C.byref(rows), C.byref(pts)),
+                  "device_cloud")
+        return {"pos": pos, "feat": feat, "seg": seg, "rows": rows.value, "points": pts.value}
+
     def swap_moving_to_fixed(self):
         self._chk(self._L.cvo_hip_swap_moving_to_fixed(self._ctx), "swap")
         self.n_fixed, self.n_moving = self.n_moving, 0
@@ -399,6 +413,57 @@ class Context:
 
     def synchronize(self):
         self._chk(self._L.cvo_hip_synchronize(self._ctx), "synchronize")
+
+
+def pinned_copy(a):
+    """A float32 copy of `a` in page-locked host memory (torch's allocator): what cvo_hip_set_pcd_many transfers from
+    where it is.  The array keeps its tensor alive."""
+    import torch
+    t = torch.from_numpy(np.ascontiguousarray(a, np.float32)).pin_memory()
+    out = t.numpy()
+    _PINNED_KEEP[id(out)] = t
+    return out
+
+
+_PINNED_KEEP = {}
+
+
+def set_pcd_many(contexts, fixed, moving, layout=FEAT_ROWMAJOR):
+    """The hand-over of a batch in one call (cvo_hip_set_pcd_many): fixed / moving = lists of (xyz, feat) per
+    context; fixed may be None (or hold None entries): those contexts keep their fixed cloud."""
+    n = len(contexts)
+    keep = []
+
+    def arr(pairs, k):
+        ptrs = (C.c_void_p * n)()
+        cnt = (C.c_int * n)()
+        for i in range(n):
+            pr = pairs[i] if pairs is not None else None
+            if pr is None:
+                ptrs[i] = None
+                cnt[i] = 0
+                continue
+            a = f32(pr[k])
+            keep.append(a)
+            ptrs[i] = a.ctypes.data
+            cnt[i] = pr[0].shape[0]
+        return ptrs, cnt
+    mx, mn = arr(moving, 0)
+    mf, _ = arr(moving, 1)
+    if fixed is not None:
+        fx, fn = arr(fixed, 0)
+        ff, _ = arr(fixed, 1)
+    else:
+        fx = ff = fn = None
+    arr_c = (C.c_void_p * n)(*[c._ctx for c in contexts])
+    pp = C.POINTER(C.c_void_p)
+    check(lib().cvo_hip_set_pcd_many(C.cast(arr_c, pp), C.cast(fx, pp) if fx is not None else None,
+                                     C.cast(ff, pp) if ff is not None else None, fn,
+                                     C.cast(mx, pp), C.cast(mf, pp), mn, layout, n), what="set_pcd_many")
+    for i, c in enumerate(contexts):
+        if fixed is not None and fixed[i] is not None:
+            c.n_fixed = fixed[i][0].shape[0]
+        c.n_moving = moving[i][0].shape[0]
 
 
 def align_many(contexts, states):

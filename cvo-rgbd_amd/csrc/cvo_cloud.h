@@ -29,6 +29,26 @@ struct CloudPrep {
 constexpr int CLOUD_PAD = 256;
 inline int cloud_padded(int n) { return n <= 0 ? 0 : (n + CLOUD_PAD - 1) / CLOUD_PAD * CLOUD_PAD; }
 
+// One cloud of a hand-over made by ONE launch (k_cloud_one, cvo_cloud.hip): a block per cloud does what
+// cloud_bbox_device + cloud_prepare_device do in ten launches -- bounding box, Morton keys, a stable radix sort
+// in LDS, packed rows, bounding spheres, padding rows -- for clouds of up to CLOUD_ONE_MAX points; the arrays
+// it writes are the same, bit for bit.
+constexpr int CLOUD_ONE_MAX = 16384;
+struct CloudJob {
+    const float *xyz;    // device: n x 3 as the caller gave them
+    const float *feat;   // device: n x 5, row- or column-major
+    int n, colmajor;
+    int np, pad_axis;    // as CloudPrep
+    float4 *pos;         // out
+    float *feat8;
+    float4 *seg;
+    float *bbox_out;     // out: min xyz, max xyz -- device or host-mapped (pinned) memory
+};
+size_t cloud_one_smem_bytes(int nmax);
+// jobs: device array; nmax: the largest n among them (sizes the LDS of the launch)
+hipError_t cloud_prepare_many(const CloudJob *d_jobs, int count, int nmax, hipStream_t s);
+hipError_t cloud_prepare_one(const CloudJob &job, hipStream_t s);
+
 size_t cloud_sort_scratch_bytes(int n);
 // bbox6 (device): min xyz, max xyz
 hipError_t cloud_bbox_device(const float *d_xyz, int n, float *d_bbox6, hipStream_t s);

@@ -163,6 +163,26 @@ int cvo_hip_set_moving_device(cvo_hip_ctx *ctx, const float *d_xyz, const float 
                               int feat_layout);
 int cvo_hip_swap_moving_to_fixed(cvo_hip_ctx *ctx);
 
+/* The hand-over of a whole batch -- the tail of set_pcd() (ref src/cvo.cpp:344-356) for `count` registration
+ * objects at once: context k receives fixed cloud k (fixed_xyz[k], fixed_feat[k], n_fixed[k] points) and moving
+ * cloud k; a null fixed_xyz (or a null entry of it) leaves that context's fixed cloud as it is (a streamed
+ * sequence: cvo_hip_swap_moving_to_fixed first).  Host arrays, the layouts of cvo_hip_set_fixed.  One transfer
+ * and ONE kernel launch serve all clouds of up to 16384 points (a block per cloud: bounding box, Morton keys,
+ * sort, packed rows, bounding spheres); larger clouds go the way of cvo_hip_set_fixed / _set_moving.  The
+ * arrays are copied into the library's own page-locked staging (by a few host threads, in pieces whose transfers
+ * overlap the staging of the next piece) and are free when the call returns.  The call does not wait for the
+ * device: a cloud's hand-over ends when the next compute entry point of its context needs it.  All contexts
+ * must be on one device. */
+int cvo_hip_set_pcd_many(cvo_hip_ctx *const *ctxs, const float *const *fixed_xyz, const float *const *fixed_feat,
+                         const int *n_fixed, const float *const *moving_xyz, const float *const *moving_feat,
+                         const int *n_moving, int feat_layout, int count);
+
+/* Inspection (tests): the device arrays of a context's cloud as the kernels read them -- which: 0 fixed,
+ * 1 moving; pos4 rows x 4 floats (x, y, z, 5th feature), feat8 rows x 8, seg4 ceil(rows / 64) x 4 (bounding
+ * spheres); any of the three may be null.  *rows = padded row count, *points = the caller's count. */
+int cvo_hip_get_device_cloud(cvo_hip_ctx *ctx, int which, float *pos4, float *feat8, float *seg4, int *rows,
+                             int *points);
+
 /* The cloud preparation of the reference's MATLAB driver, on the device:
  * pcRangeFilter (ref util/pcRangeFilter.m:5-12: points whose float32 range is above max_range or
  * below min_range are dropped; max_range <= 0: no range filter), then

@@ -992,3 +992,75 @@ def test_engine_profiling_changes_nothing(pkg, mode_name):
     assert prof[1] > 0 and prof[0] > 0.0, prof
     for c in ctxs:
         c.close()
+
+
+@pytest.mark.parametrize("n", [1, 63, 64, 65, 1000, 10000, 16384])
+def test_one_launch_hand_over_writes_the_same_device_arrays(pkg, monkeypatch, n):
+    """The tail of set_pcd() (ref src/cvo.cpp:344-356) three ways -- cvo_hip_set_fixed / _set_moving through the
+    one-launch preparation (k_cloud_one: a block sorts the cloud in LDS), the same entry points through the ten
+    launches of the first version (CVO_HIP_NO_CLOUD_ONE), and a batch through cvo_hip_set_pcd_many (pageable
+    and page-locked caller arrays, both layouts) -- leave bit-identical packed rows, features, Morton order, bounding
+    spheres and padding rows in device memory."""
+    capi = pkg.capi
+    m = max(1, n - 3)
+    xf, ff, xm, fm = pkg.data.synthetic_pair(n, m, seed=500 + n % 89)
+
+    def arrays(c):
+        out = []
+        for which in (0, 1):
+            d = c.device_cloud(which)
+            out.append((d["rows"], d["points"], d["pos"].tobytes(), d["feat"].tobytes(), d["seg"].tobytes()))
+        return out
+
+    monkeypatch.setenv("CVO_HIP_NO_CLOUD_ONE", "1")
+    c = capi.Context(mode=capi.MODE_CVO, device=0)
+    c.set_fixed(xf, ff); c.set_moving(xm, fm)
+    ref = arrays(c)
+    c.close()
+    monkeypatch.delenv("CVO_HIP_NO_CLOUD_ONE")
+    c = capi.Context(mode=capi.MODE_CVO, device=0)
+    c.set_fixed(xf, ff); c.set_moving(xm, fm)
+    assert arrays(c) == ref
+    c.close()
+    for how in ("rowmajor", "pinned", "colmajor"):
+        cs = [capi.Context(mode=capi.MODE_CVO, device=0) for _ in range(3)]
+        col = how == "colmajor"
+        conv = (lambda a: np.ascontiguousarray(a.T)) if col else (lambda a: a)
+        prep = capi.pinned_copy if how == "pinned" else (lambda a: np.ascontiguousarray(a, np.float32))
+        fixed = [(prep(xf), prep(conv(ff))) for _ in cs]
+        moving = [(prep(xm), prep(conv(fm))) for _ in cs]
+        capi.set_pcd_many(cs, fixed, moving, layout=capi.FEAT_COLMAJOR if col else capi.FEAT_ROWMAJOR)
+        for c in cs:
+            assert arrays(c) == ref, how
+        # a second batch into the same contexts, the fixed clouds kept (a streamed sequence)
+        capi.set_pcd_many(cs, None, moving, layout=capi.FEAT_COLMAJOR if col else capi.FEAT_ROWMAJOR)
+        for c in cs:
+            assert arrays(c) == ref, how
+        for c in cs:
+            c.close()
+
+
+def test_batched_hand_over_then_align_many(pkg):
+    """cvo_hip_set_pcd_many followed by cvo_hip_align_many gives what one hand-over and one align() at a time
+    give (sizes on both sides of the one-launch limit of 16384 points)."""
+    import torch
+    capi = pkg.capi
+    sizes = [(3000, 2800), (10000, 10000), (17000, 16500), (200, 16384), (5000, 64)]
+    pairs = [pkg.data.synthetic_pair(n, m, seed=700 + i) for i, (n, m) in enumerate(sizes)]
+    ref = []
+    for xf, ff, xm, fm in pairs:
+        c = capi.Context(mode=capi.MODE_CVO, device=0)
+        c.set_fixed(xf, ff); c.set_moving(xm, fm)
+        st = capi.init_state(c.params)
+        it, _ = c.align(st, trace_cap=0)
+        ref.append((it, bytes(st)))
+        c.close()
+    streams = [torch.cuda.Stream() for _ in pairs]
+    cs = [capi.Context(mode=capi.MODE_CVO, device=0, stream=s.cuda_stream) for s in streams]
+    for _ in range(2):
+        capi.set_pcd_many(cs, [(p[0], p[1]) for p in pairs], [(p[2], p[3]) for p in pairs])
+        states = [capi.init_state(c.params) for c in cs]
+        its = capi.align_many(cs, states)
+        assert [(i, bytes(s)) for i, s in zip(its, states)] == ref
+    for c in cs:
+        c.close()
