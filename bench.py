@@ -43,7 +43,7 @@ F64_OPS_PER_EXP = 14.0         # the device exp (cvo_kernels.hip exp_neg)
 BYTES_PER_POINT = 32.0         # xyz 12 B + 5 features 20 B
 PEAK_F32_TFLOPS = 157.3        # MI355X_MICROARCH.md: FP32 vector = FP32 MFMA peak
 PEAK_HBM_GBS = 8000.0
-PROFILE_TAG = "r03"            # committed rocprofv3 summaries under profiles/ (tools/gpu_profile.sh)
+PROFILE_TAG = "r04"            # committed rocprofv3 summaries under profiles/ (tools/gpu_profile.sh)
 
 
 def parse():
@@ -333,6 +333,10 @@ def main():
                 out["config3_single_gpu"] = config3_leg(args, pkg, torch, mode, acvo)
             except Exception as e:
                 out["config3_single_gpu"] = {"error": repr(e)}
+            try:   # ... and what one of eight GPUs would hold
+                out["config3_shard_of_8"] = shard_leg(args, pkg, torch, mode, acvo)
+            except Exception as e:
+                out["config3_shard_of_8"] = {"error": repr(e)}
             if not args.no_frontend:
                 try:
                     out["frontend"] = frontend_leg(args, pkg)
@@ -586,9 +590,28 @@ def roofline_engine_leg(args, pkg, torch, mode, acvo, n, m):
         capi.engine_profiling(True)
         capi.engine_profile(reset=True)
         reps, its = max(3, args.steps // 4), 0
+        # per phase of the loop (cvo: the length scale is a function of the iteration, ref src/cvo.cpp:408-410 --
+        # ell = 0.15 in iterations 0-3, 0.10 in 4-10, 0.06 in 11-20, 0.03 from 21 on; every registration of a call
+        # starts at iteration 0 together, so the i-th flow launch of a call IS iteration i)
+        phases = {}
         for _ in range(reps):
-            its += sum(step())
-        torch.cuda.synchronize()
+            capi.engine_flow_trace(reset=True)
+            its_call = step()
+            its += sum(its_call)
+            torch.cuda.synchronize()
+            dur, per, _sl = capi.engine_flow_trace(reset=True)
+            for i in range(len(dur)):
+                running = sum(1 for k in its_call if k > i)
+                if running == 0:
+                    continue
+                name = "all" if acvo else ("ell_0.15" if i < 4 else "ell_0.10" if i < 11 else "ell_0.06" if i < 21 else "ell_0.03")
+                ph = phases.setdefault(name, {"launches": 0, "us": 0.0, "registrations": 0, "period_us": 0.0, "periods": 0})
+                ph["launches"] += 1
+                ph["us"] += float(dur[i])
+                ph["registrations"] += running
+                if per[i] > 0.0 and i + 1 < len(dur):
+                    ph["period_us"] += float(per[i])
+                    ph["periods"] += 1
         e_ms, e_n, e_slots = capi.engine_profile(reset=True)
         capi.engine_profiling(False)
     finally:
@@ -623,13 +646,59 @@ def roofline_engine_leg(args, pkg, torch, mode, acvo, n, m):
         res["valu_issue_frac"] = valu.get("valu_issue_frac")
         res["valu_issue"] = dict(valu, source=valu_src)
     ph, ph_src = committed("%s_pmc_phases.json" % PROFILE_TAG)
-    if ph and "kt_process<0, 0>" in ph:
-        k = ph["kt_process<0, 0>"]
-        res["traffic"] = k.get("all", {}).get("hbm_bytes_per_launch")
+    pmc = ph.get("kt_process<0, 0>") if ph else None
+    if pmc:
+        res["traffic"] = pmc.get("all", {}).get("hbm_bytes_per_launch")
         res["traffic_source"] = ph_src
         res["traffic_note"] = ("PMC FETCH_SIZE x 2 + WRITE_SIZE per launch, the SAME launches in both passes and in the kernel "
                                "trace (one engine of %d pairs: the k-th dispatch of a pass is the k-th of the others)" % count)
-        res["traffic_by_length_scale"] = {kk: vv for kk, vv in k.items() if kk != "all"}
+        res["traffic_by_length_scale"] = {kk: vv for kk, vv in pmc.items() if kk != "all"}
+    # ---- one bound with one number per phase: the heavy iterations (ell >= 0.06) are
+    # throughput-bound -- counter bytes of the SAME launches (committed PMC passes of this command) over the
+    # duration measured live here, against what HBM delivers; the light ones (ell = 0.03) are bound by the
+    # engine's chain of dependent launches -- the live period from one flow launch to the next.
+    ACHIEVABLE_HBM_GBS = 6300.0   # MI355X_MICROARCH.md: what a streaming kernel reaches of the 8 TB/s
+
+    def phase_obj(names):
+        sel = [phases[k] for k in names if k in phases]
+        if not sel:
+            return None
+        ln = sum(p["launches"] for p in sel)
+        us = sum(p["us"] for p in sel) / max(ln, 1)
+        regs = sum(p["registrations"] for p in sel) / float(max(ln, 1))
+        prd = sum(p["period_us"] for p in sel) / max(sum(p["periods"] for p in sel), 1)
+        o = {"launches": ln, "avg_launch_us": us, "registrations_per_launch": regs, "iteration_period_us": prd,
+             "algorithmic_GBs": algo_bytes * regs / (us * 1e-6) / 1e9 if us > 0 else None}
+        if pmc:   # counter bytes per launch of the same phases, weighted by their launches in the committed passes
+            tot_b = tot_l = 0.0
+            for k in names:
+                if k in pmc and isinstance(pmc[k], dict) and pmc[k].get("launches"):
+                    tot_b += pmc[k]["hbm_bytes_per_launch"] * pmc[k]["launches"]
+                    tot_l += pmc[k]["launches"]
+            if tot_l:
+                o["counter_bytes_per_launch"] = tot_b / tot_l
+                o["counter_GBs"] = tot_b / tot_l / (us * 1e-6) / 1e9 if us > 0 else None
+                o["frac_of_achievable_hbm"] = o["counter_GBs"] / ACHIEVABLE_HBM_GBS if o["counter_GBs"] else None
+        return o
+    if acvo:
+        res["by_phase"] = {"all": phase_obj(["all"])}
+    else:
+        heavy = phase_obj(["ell_0.15", "ell_0.10", "ell_0.06"])
+        light = phase_obj(["ell_0.03"])
+        if heavy:
+            heavy["bound"] = "hbm-counter"
+            heavy["what"] = ("iterations 0-20 (ell >= 0.06): throughput-bound list passes; counter bytes (FETCH_SIZE x 2 + WRITE_SIZE of the "
+                             "same launches, committed %s) over the live duration, against %.1f TB/s achievable"
+                             % (ph_src or "profiles/%s_pmc_phases.json" % PROFILE_TAG, ACHIEVABLE_HBM_GBS / 1e3))
+        if light:
+            light["bound"] = "launch-latency"
+            light["launches_per_iteration"] = 5
+            light["chain_us"] = light["iteration_period_us"]
+            light["what"] = ("iterations 21+ (ell = 0.03): an iteration of the engine = its chain of five dependent launches (filter, "
+                             "flow, post-flow, step, post-step); chain_us = live time from one flow launch's begin to the next one's")
+        res["by_phase"] = {"heavy": heavy, "light": light,
+                           "per_length_scale": {k: phase_obj([k]) for k in sorted(phases)}}
+    res["bound_note"] = "per phase: see by_phase (heavy: hbm-counter, light: launch-latency); `frac` is the contract's algorithmic-bytes figure"
     return res
 
 
@@ -738,11 +807,92 @@ def config3_leg(args, pkg, torch, mode, acvo):
         it += k
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
+    out = {"workload": "one synthetic %dk x %dk registration (BASELINE configs[3], seed %d), unsharded" % (n // 1000, m // 1000, pkg.data.SEED_CFG4),
+           "registrations_per_s": reps / el, "ms_per_registration": el * 1e3 / reps,
+           "ms_per_iteration": el * 1e3 / max(it, 1), "iterations": it / float(reps),
+           "pairs_per_sweep": float(n) * m}
+    # ---- the roofline of this size: the heavy iterations (0-20, ell >= 0.06) are the kept list -- every member of A
+    # written by the flow pass (8 B) and read back by the step pass (8 B) -- on top of the tile list the flow pass
+    # expands (16 B per entry) and the gathers; durations by HIP events on every dispatch (profiling mode: the
+    # by-value launches of the same kernel bodies), members per iteration from the trace of the same run
+    try:
+        import copy
+        prm = copy.copy(c.params)
+        heavy_iters = 21
+        prm.max_iter = heavy_iters
+        c.set_params(prm)
+        c.set_profiling(True)
+        c.get_profile(reset=True)
+        k_h, tr = c.align(capi.init_state(c.params), trace_cap=heavy_iters)
+        torch.cuda.synchronize()
+        pr = c.get_profile(reset=True)
+        c.set_profiling(False)
+        members = [t["nnz"] for t in tr[:k_h]]
+        kept_bytes = 16.0 * float(sum(members))   # 8 B written + 8 B read per member and iteration
+        list_ms = pr["proc_flow_ms"] + pr["step_ms"]
+        algo = BYTES_PER_POINT * (n + m) * 2.0 * k_h   # two sweeps per iteration
+        gbs = kept_bytes / (list_ms * 1e-3) / 1e9 if list_ms > 0 else None
+        out["roofline"] = {
+            "bound": "hbm", "kernel": "k_process<PROC_FLOW> + k_process<PROC_STEP> (the list passes) of iterations 0-%d" % (k_h - 1),
+            "iterations": k_h, "members_of_A_per_iteration_min_max": [int(min(members)), int(max(members))] if members else None,
+            "kept_list_bytes_written_and_read": kept_bytes, "list_pass_ms": list_ms,
+            "flow_pass_ms": pr["proc_flow_ms"], "step_pass_ms": pr["step_ms"], "filter_ms": pr["flow_ms"],
+            "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS if gbs else None,
+            "achieved_algorithmic": algo / (list_ms * 1e-3) / 1e9 if list_ms > 0 else None,
+            "frac_algorithmic": algo / (list_ms * 1e-3) / 1e9 / PEAK_HBM_GBS if list_ms > 0 else None,
+            "what": "achieved = the kept list's own bytes (16 B per member and iteration: written by the flow pass, read back by the "
+                    "step pass) over the list passes' kernel time; the contract's algorithmic figure (32 B x (N + M) x 2 sweeps) beside it; "
+                    "traffic by counters: profiles/%s_pmc_big.json where committed" % PROFILE_TAG}
+        big, big_src = committed("%s_pmc_big.json" % PROFILE_TAG)
+        if big:
+            out["roofline"]["traffic"] = big
+            out["roofline"]["traffic_source"] = big_src
+    except Exception as e:
+        out["roofline"] = {"error": repr(e)}
     c.close()
-    return {"workload": "one synthetic %dk x %dk registration (BASELINE configs[3], seed %d), unsharded" % (n // 1000, m // 1000, pkg.data.SEED_CFG4),
-            "registrations_per_s": reps / el, "ms_per_registration": el * 1e3 / reps,
-            "ms_per_iteration": el * 1e3 / max(it, 1), "iterations": it / float(reps),
-            "pairs_per_sweep": float(n) * m}
+    return out
+
+
+def shard_leg(args, pkg, torch, mode, acvo, world=8):
+    """The per-GPU problem of BASELINE configs[3] on 8 GPUs, on ONE GPU: rank 0's share of the target rows
+    (25k of 200k) against the whole source cloud, as a world of one (the mailbox exchange runs -- in local memory --
+    and the sharded launch scheme with it).  What the 8-GPU run adds per iteration is two exchanges across xGMI;
+    their latency is measured by the sharded leg of a multi-GPU run (`sharded_allreduce.allreduce_latency_us`) and
+    not available here: `projected_8gpu_ms_per_iteration` = shard time + 2 x that latency where this line
+    holds one (`--gpus N` runs), else + 2 x 10 us (SURVEY 8e's estimate), labelled as such."""
+    capi = pkg.capi
+    n = m = args.sharded_points
+    xf, ff, xm, fm = pkg.data.synthetic_pair(n, m, seed=pkg.data.SEED_CFG4, acvo=acvo)
+    c = capi.Context(mode=mode, device=torch.cuda.current_device(), graph_capture=True)
+    c.set_fixed(xf, ff)
+    c.set_moving(xm, fm)
+    lo, hi = capi.shard_range(n, 0, world)
+    slo, shi = capi.shard_range(m, 0, world)
+    c.set_shard(lo, hi, slo, shi)
+    c.mailbox_create(0, 1)
+    c.mailbox_connect(ptrs=[None])
+    prm = c.params
+    import copy
+    p2 = copy.copy(prm)
+    p2.max_iter = 40   # (a shard alone does not converge to the full registration's pose: time a fixed number of iterations)
+    c.set_params(p2)
+    c.align(capi.init_state(c.params), trace_cap=0)
+    torch.cuda.synchronize()
+    reps, it = 3, 0
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        k, _ = c.align(capi.init_state(c.params), trace_cap=0)
+        it += k
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    c.close()
+    ms_it = el * 1e3 / max(it, 1)
+    return {"workload": "rows [%d, %d) of a %dk x %dk registration (one eighth of BASELINE configs[3]) on one GPU, world of one, %d iterations"
+                        % (lo, hi, n // 1000, m // 1000, it // reps),
+            "ms_per_iteration": ms_it, "iterations": it / float(reps),
+            "projected_8gpu_ms_per_iteration": ms_it + 2 * 0.010,
+            "projection": "shard time + 2 exchanges x 10 us (SURVEY 8e's estimate of one small all-reduce over xGMI; a multi-GPU run "
+                          "of this bench measures it: sharded_allreduce.allreduce_latency_us) -- a PROJECTION, not a measurement"}
 
 
 def batched_vs_oracle(pkg, pairs, last_states, last_its, acvo, cores, count=4):

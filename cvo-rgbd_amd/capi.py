@@ -23,7 +23,7 @@ SYMBOLS = [
     "cvo_hip_transform_pcd", "cvo_hip_flow", "cvo_hip_step_coeffs", "cvo_hip_pick_step",
     "cvo_hip_exp_se3", "cvo_hip_dist_se3", "cvo_hip_align", "cvo_hip_align_many",
     "cvo_hip_function_inner_product", "cvo_hip_function_inner_product_clouds",
-    "cvo_hip_engine_profiling", "cvo_hip_get_engine_profile", "cvo_hip_get_wave_load", "cvo_hip_set_graph_capture", "cvo_hip_set_profiling", "cvo_hip_get_profile", "cvo_hip_get_graph_stats", "cvo_hip_synchronize",
+    "cvo_hip_engine_profiling", "cvo_hip_get_engine_profile", "cvo_hip_get_engine_flow_trace", "cvo_hip_get_wave_load", "cvo_hip_set_graph_capture", "cvo_hip_set_profiling", "cvo_hip_get_profile", "cvo_hip_get_graph_stats", "cvo_hip_synchronize",
 ]
 
 
@@ -133,6 +133,7 @@ def lib():
                                                         C.c_int, fp]
     L.cvo_hip_engine_profiling.argtypes = [C.c_int]
     L.cvo_hip_get_engine_profile.argtypes = [dp, C.POINTER(C.c_longlong), dp, C.c_int]
+    L.cvo_hip_get_engine_flow_trace.argtypes = [fp, fp, C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_int), C.c_int]
     L.cvo_hip_get_wave_load.argtypes = [vp, C.POINTER(C.c_uint32), C.c_int, C.POINTER(C.c_int)]
     L.cvo_hip_set_graph_capture.argtypes = [vp, C.c_int]
     L.cvo_hip_set_profiling.argtypes = [vp, C.c_int]
@@ -486,6 +487,18 @@ def engine_profile(reset=True):
     ms, n, regs = C.c_double(), C.c_longlong(), C.c_double()
     check(lib().cvo_hip_get_engine_profile(C.byref(ms), C.byref(n), C.byref(regs), int(reset)), what="engine_profile")
     return ms.value, n.value, regs.value
+
+
+def engine_flow_trace(reset=True, capacity=1 << 16):
+    """Per flow-pass launch of the fused groups since the last reset: (duration us, period us, slots) arrays."""
+    dur = np.zeros(capacity, np.float32)
+    per = np.zeros(capacity, np.float32)
+    sl = np.zeros(capacity, np.int32)
+    n = C.c_int()
+    check(lib().cvo_hip_get_engine_flow_trace(fptr(dur), fptr(per), sl.ctypes.data_as(C.POINTER(C.c_int)), capacity, C.byref(n), int(reset)),
+          what="engine_flow_trace")
+    k = min(n.value, capacity)
+    return dur[:k].copy(), per[:k].copy(), sl[:k].copy()
 
 
 def comm_unique_id():

@@ -92,9 +92,9 @@ struct List {     // LIST_XY/XX/YY: TileEntry[cap] in a; LIST_KEPT: uint2[cap] i
 // flight at once and the iterations are cheaper (candidate lists): 4 / 8 / 10 / 12 / 16 / 24 per captured batch:
 // 256 pairs per call 3905 / 4188 / 4254 / 4248 / 4277 / 4105, 64 pairs 3604 / 3625 / - / 3650 / 3594 / 3571,
 // 32 pairs 2630 / 2734 / - / 2723 / 2453 / 2694, 8 x 20k 1022 / 1029 / 1028 / 1014 / 995 / 961 -> 10
-static const int kEngineBatch = [] { const char *e = getenv("CVO_HIP_ENGINE_BATCH"); const int v = e ? atoi(e) : 10; return v >= 1 && v <= 64 ? v : 10; }();
+constexpr int kEngineBatch = 10;
 // (an even number: a head-mode batch must leave the state's head in its first copy, cvo_kernels.hip "the head")
-static const int kBatch = [] { const char *e = getenv("CVO_HIP_BATCH"); const int v = e ? atoi(e) : 8; return v >= 1 && v <= 64 ? (v + 1) / 2 * 2 : 8; }();
+constexpr int kBatch = 8;
 
 // The kernels of the loop read their argument blocks from a table of Slots in device memory
 // (cvo_device.h "Argument tables"): one slot for a registration on its own (cvo_hip_align), up
@@ -170,7 +170,7 @@ struct TableBuf {
 // address and on the plan -- kernels, grids, LDS sizes -- not on any argument: one capture
 // serves every frame pair (and every membership of a fused group) of the same shape.
 struct PlanGraph {
-    std::vector<TLaunch> plan, tail;
+    std::vector<TLaunch> plan;
     int iterations = 0;
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
@@ -240,7 +240,6 @@ struct cvo_hip_ctx {
     bool allow_async = true;
     bool crowded = false;                // set by align_many: many registrations share the launches
     DevBuf cand[3], cand_cnt[3];         // the candidate lists of the xy / xx / yy tile lists (ProcessArgs::cand, cand_cnt)
-    DevBuf cand_ck[3];                   // ... their colour weights where the record is 12 bytes wide (ProcessArgs::cand_ck)
     DevBuf cand_xyb, cand_cnt_xyb;       // head mode: the record of the second buffer of the xy list (ProcessArgs::cand_b)
     DevBuf cand_sfb[2], cand_cnt_sfb[2]; // ... and of the xx / yy lists (acvo)
     int ck_nblk[3] = {0, 0, 0};          // recorded plan: the pass over list l keeps a candidate list with this many blocks (0: no)
@@ -278,7 +277,6 @@ struct cvo_hip_ctx {
     TableBuf table;                  // this registration's own argument table (one slot): cvo_hip_align
     PlanCache plans;                 // ... and the batches captured for it
     std::vector<TLaunch> plan;       // launches of one iteration of the align() in progress
-    std::vector<TLaunch> plan_tail;  // ... and what closes a batch of them (head mode: the flush)
     hipStream_t loop_stream = nullptr;   // stream the align() in progress runs on (a fused group's, else `stream`)
     bool warm = false;               // every device buffer of the loop has been allocated
     bool use_graphs = true;
@@ -304,6 +302,13 @@ int fail(cvo_hip_ctx *ctx, int code, const char *msg)
     if (ctx) ctx->err = msg;
     return code;
 }
+
+// The switches this library reads from the environment, one per mechanism: test switches (read where a plan is
+// recorded, so that a test can flip them between two registrations) and diagnostics.
+bool env_no_cand() { return getenv("CVO_HIP_NO_CAND") != nullptr; }           // no candidate records: expand the tile list every time
+bool env_no_graph() { return getenv("CVO_HIP_NO_GRAPH") != nullptr; }         // no stream captures at all
+bool env_sync_upload() { static const bool v = getenv("CVO_HIP_SYNC_UPLOAD") != nullptr; return v; }   // hand-overs wait for the device
+bool env_engine_debug() { static const bool v = getenv("CVO_HIP_ENGINE_DEBUG") != nullptr; return v; } // host-side clocks of the engines
 
 // Parameters the kernels can work with: a known mode, finite values, positive kernel scales
 // and thresholds (log of a non-positive quotient would make NaN radii and NaN twists that
@@ -361,15 +366,7 @@ DevParams make_dev_params(const cvo_hip_params &p)
     d.color_scale = p.color_scale;
     // tile-list re-use (cvo_device.h plan_lists); CVO_HIP_LIST_MARGIN=0 rebuilds every iteration
     d.build_at = 0.7f;   // (measured 0.3 / 0.5 / 0.7: 1.80 / 1.77 / 1.73 ms per 10k x 10k registration)
-    if (const char *e = getenv("CVO_HIP_BUILD_AT")) {
-        const double m = atof(e);
-        d.build_at = (m > 0.0 && m < 1.0) ? (float)m : d.build_at;
-    }
-    d.list_margin = 0.15f;
-    if (const char *e = getenv("CVO_HIP_LIST_MARGIN")) {
-        const double m = atof(e);
-        d.list_margin = (m >= 0.0 && m <= 4.0) ? (float)m : d.list_margin;
-    }
+    d.list_margin = 0.15f;   // (loop_params picks the margin of an align() by size; CVO_HIP_LIST_MARGIN overrides it there)
     return d;
 }
 
@@ -484,8 +481,7 @@ int upload_cloud(cvo_hip_ctx *ctx, Cloud &c, const float *xyz, const float *feat
         HIP_TRY(ctx, hipEventRecord(c.ready_ev, ctx->stream));
         c.wait_ev = nullptr;
         c.pending = true;
-        static const bool sync_upload1 = getenv("CVO_HIP_SYNC_UPLOAD") != nullptr;
-        if (on_device || sync_upload1) return cloud_ready(ctx, c);
+        if (on_device || env_sync_upload()) return cloud_ready(ctx, c);
         return CVO_HIP_OK;
     }
     // Larger clouds: bounding box, keys, rocPRIM's radix sort, pack, spheres as launches of their own.  The box is
@@ -518,8 +514,7 @@ int upload_cloud(cvo_hip_ctx *ctx, Cloud &c, const float *xyz, const float *feat
     // wait for the device (64 x 2 hand-overs of a batch overlap each other instead of costing 0.1 ms of host
     // time apiece).  Device arrays of the caller's are read by the queued kernels: they may be re-used
     // once this returns, so that form waits here.
-    static const bool sync_upload = getenv("CVO_HIP_SYNC_UPLOAD") != nullptr;
-    if (on_device || sync_upload) return cloud_ready(ctx, c);
+    if (on_device || env_sync_upload()) return cloud_ready(ctx, c);
     return CVO_HIP_OK;
 }
 
@@ -680,8 +675,7 @@ hipStream_t loop_stream(const cvo_hip_ctx *ctx);
 // the transformed moving cloud, and the list passes of the iteration read that.
 bool pre_transform(const cvo_hip_ctx *ctx)
 {
-    const bool off = getenv("CVO_HIP_NO_PRETF") != nullptr;   // (read when a plan is recorded: tests switch it)
-    return !off && ctx->plan_recording && ctx->in_loop && !ctx->use_async;   // (a table plan: kt_filter / kt_filter_group)
+    return ctx->plan_recording && ctx->in_loop && !ctx->use_async;   // (a table plan: kt_filter / kt_filter_group)
 }
 
 // The dense all-pairs filter of one list (with optional HIP-event bracket: this
@@ -799,42 +793,34 @@ int enqueue_process(cvo_hip_ctx *ctx, int mode, int list, DevBuf &part, const fl
     a.check_done = check_done;
     a.need_d2 = (ctx->prm.mode == CVO_HIP_MODE_ACVO || !ctx->in_loop) ? 1 : 0;
     a.weight = ctx->prm.color_scale > 0.0f ? 1 : 0;   // the MATLAB object's weight: its own instantiation
-    static const bool no_pack = getenv("CVO_HIP_NO_PACK") != nullptr;
+    const bool no_pack = getenv("CVO_HIP_NO_PACK") != nullptr;   // (test switch, read when a plan is recorded: 8 + 4 byte kept entries)
     a.kept_packed = (!no_pack && ctx->fixed.np <= 65536 && ctx->moving.np <= 65536) ? 1 : 0;
     if (!a.kept_packed && !no_pack && a.weight == 0 && ctx->fixed.np <= 262144 && ctx->moving.np <= 262144) {
         // 8 bytes for larger clouds too (ProcessArgs::kept_packed == 2): a member's weight a = ck * k is a positive
         // float32 with sp < a <= fl(fl(c_sigma^2) fl(sigma^2)) -- the two exp are <= 1 (ref cvo.cpp:143-153 as
         // pair_weight computes it); if those two bounds lie within 16 binades, 4 bits of exponent do
-        const bool no_pack2 = getenv("CVO_HIP_NO_PACK_WIDE") != nullptr;   // (read when a plan is recorded: tests switch it)
         const float amax = (float)ctx->dprm.cs2_d * (float)ctx->dprm.s2_d;
         uint32_t blo, bhi;
         std::memcpy(&blo, &ctx->dprm.sp, sizeof(blo));
         std::memcpy(&bhi, &amax, sizeof(bhi));
         const uint32_t elo = blo >> 23, ehi = bhi >> 23;   // (both positive: the sign bit is clear)
-        if (!no_pack2 && ctx->dprm.sp > 0.0f && amax > ctx->dprm.sp && elo >= 1 && ehi < 255 && ehi - elo <= 15) {
+        if (ctx->dprm.sp > 0.0f && amax > ctx->dprm.sp && elo >= 1 && ehi < 255 && ehi - elo <= 15) {
             a.kept_packed = 2;
             a.kept_ebase = elo;
         }
     }
     if ((mode == PROC_FLOW && list == LIST_XY) || (mode == PROC_SELF && (list == LIST_XX || list == LIST_YY))) {
-        const bool no_cand = getenv("CVO_HIP_NO_CAND") != nullptr;   // (read when a plan is recorded: tests switch it)
-        const bool no_self = getenv("CVO_HIP_NO_CAND_SELF") != nullptr;
+        const bool no_cand = env_no_cand();
         ctx->ck_nblk[list] = 0;
-        // (clouds of more than 65536 rows would need 12-byte records: built, bit-identical, and measured SLOWER --
-        // one 200k x 200k registration 81.3 -> 91.0 ms, 100k x 100k 21.7 -> 23.8, acvo 18.9 -> 21.8: at those sizes the
-        // list passes are bound by memory requests, and the record is 12 more bytes per candidate to stream;
-        // profiles/r03_ab.txt.  Opt-in: CVO_HIP_CAND_WIDE)
-        const bool no_wide = getenv("CVO_HIP_CAND_WIDE") == nullptr;
-        if (!no_cand && !(mode == PROC_SELF && no_self) && pre_transform(ctx) && !(ctx->prm.color_scale > 0.0f) &&
-            (a.kept_packed == 1 || !no_wide)) {   // (the same plans: synchronous lists)
+        // (clouds of up to 65536 rows: i and j share a word.  12-byte records for larger clouds were built, bit-identical,
+        // and measured SLOWER -- one 200k x 200k registration 81.3 -> 91.0 ms, 100k x 100k 21.7 -> 23.8, acvo 18.9 -> 21.8: at
+        // those sizes the list passes are bound by memory requests and the record is more bytes to stream; profiles/r03_ab.txt 8)
+        if (!no_cand && pre_transform(ctx) && !(ctx->prm.color_scale > 0.0f) && a.kept_packed == 1) {   // (the same plans: synchronous lists)
             // (an optimisation: if its memory cannot be had, the pass expands the tile list every time)
             int rc_c = ensure_buf(ctx, ctx->cand[list], (size_t)ctx->lists[LIST_KEPT].cap * sizeof(uint2));
             if (!rc_c) rc_c = ensure_buf(ctx, ctx->cand_cnt[list], PROC_WAVES * sizeof(uint32_t));
-            // (clouds of more than 65536 rows: i and j do not share a word, the weight gets an array of its own)
-            if (!rc_c && a.kept_packed != 1) rc_c = ensure_buf(ctx, ctx->cand_ck[list], (size_t)ctx->lists[LIST_KEPT].cap * sizeof(float));
             if (!rc_c) {
                 a.cand = (uint2 *)ctx->cand[list].p;
-                a.cand_ck = a.kept_packed == 1 ? nullptr : (float *)ctx->cand_ck[list].p;
                 a.cand_cnt = (uint32_t *)ctx->cand_cnt[list].p;
                 ctx->ck_nblk[list] = a.nblk;
             } else {
@@ -849,7 +835,7 @@ int enqueue_process(cvo_hip_ctx *ctx, int mode, int list, DevBuf &part, const fl
         // Head mode (one registration on its own, plan_lone): the flow pass keeps a candidate record per buffer of
         // the double-buffered xy list -- the pass after a buffer is switched to expands and records, the passes
         // over the same buffer stream (DevHead::xy_ck).  The kernels of every other plan ignore the fields.
-        const bool no_cand = getenv("CVO_HIP_NO_CAND") != nullptr || getenv("CVO_HIP_NO_CAND_ASYNC") != nullptr;
+        const bool no_cand = env_no_cand();
         if (mode == PROC_FLOW && list == LIST_XY && ctx->plan_recording && ctx->lone && ctx->allow_head && !multi_rank(ctx) &&
             !no_cand && a.kept_packed == 1 && !(ctx->prm.color_scale > 0.0f)) {
             const size_t bytes = (size_t)ctx->lists[LIST_KEPT].cap * sizeof(uint2);
@@ -862,7 +848,6 @@ int enqueue_process(cvo_hip_ctx *ctx, int mode, int list, DevBuf &part, const fl
                 a.cand_cnt = (uint32_t *)ctx->cand_cnt[LIST_XY].p;
                 a.cand_b = (uint2 *)ctx->cand_xyb.p;
                 a.cand_cnt_b = (uint32_t *)ctx->cand_cnt_xyb.p;
-                a.cand_ck = nullptr;
                 ctx->ck_nblk[LIST_XY] = a.nblk;
             } else {   // (an optimisation: without its memory the pass expands the tile list every time)
                 (void)hipGetLastError();
@@ -874,8 +859,7 @@ int enqueue_process(cvo_hip_ctx *ctx, int mode, int list, DevBuf &part, const fl
         a.async_self = list == LIST_XX ? 1 : 2;
         a.tiles_b = (const TileEntry *)ctx->lists[list == LIST_XX ? LIST_XXB : LIST_YYB].a.p;
         // (head mode: candidate records for both buffers of the self lists too, see the xy list above)
-        const bool no_cand = getenv("CVO_HIP_NO_CAND") != nullptr || getenv("CVO_HIP_NO_CAND_ASYNC") != nullptr ||
-                             getenv("CVO_HIP_NO_CAND_SELF") != nullptr;
+        const bool no_cand = env_no_cand();
         if (ctx->plan_recording && ctx->lone && ctx->allow_head && !multi_rank(ctx) && !no_cand && a.kept_packed == 1 &&
             !(ctx->prm.color_scale > 0.0f)) {
             const int l = list == LIST_XX ? 0 : 1;
@@ -889,7 +873,6 @@ int enqueue_process(cvo_hip_ctx *ctx, int mode, int list, DevBuf &part, const fl
                 a.cand_cnt = (uint32_t *)ctx->cand_cnt[list].p;
                 a.cand_b = (uint2 *)ctx->cand_sfb[l].p;
                 a.cand_cnt_b = (uint32_t *)ctx->cand_cnt_sfb[l].p;
-                a.cand_ck = nullptr;
                 ctx->ck_nblk[list] = a.nblk;
             } else {
                 (void)hipGetLastError();
@@ -999,16 +982,17 @@ DevParams loop_params(const cvo_hip_ctx *ctx)
     // candidates ((1 + margin)^2).  Measured (profiles/r02_ab.txt): up to ~14k points a side, where a
     // build is a large part of an iteration, 25 % beats 15 % (32 distinct 10k x 10k pairs 2273 ->
     // 2398 registrations/s, one at a time 1.77 -> 1.71 ms); at 20k x 20k it loses (917 -> 792).
-    const bool margin_set = getenv("CVO_HIP_LIST_MARGIN") != nullptr;   // (then make_dev_params took it)
-    if (!margin_set)
-        dp.list_margin = ((double)ctx->fixed.n * (double)ctx->moving.n <= 2.0e8) ? 0.25f : 0.15f;
+    dp.list_margin = ((double)ctx->fixed.n * (double)ctx->moving.n <= 2.0e8) ? 0.25f : 0.15f;
+    if (const char *e = getenv("CVO_HIP_LIST_MARGIN")) {   // (test switch; 0 = rebuild every iteration)
+        const double m = atof(e);
+        if (m >= 0.0 && m <= 4.0) dp.list_margin = (float)m;
+    }
     dp.async_xy = ctx->use_async ? 1 : 0;
     dp.async_self = ctx->use_async_self ? 1 : 0;
     // Head mode: a build is named a slot earlier than it is made and costs its launch 10 us; later is better
     // (0.7 / 0.85 / 0.9 / 0.95 of the margin gone: 10k x 10k 711 / 728 / 733 / 732 registrations/s, 14k 432 / 444 / 445 /
     // 444, 6k 694 / 694 / 706 / 705, 3k 788 / 794 / 792 / 792; profiles/r03_ab.txt 18)
-    const bool build_at_set = getenv("CVO_HIP_BUILD_AT") != nullptr;
-    if (!build_at_set && ctx->use_async && ctx->lone && ctx->allow_head && !multi_rank(ctx)) dp.build_at = 0.9f;
+    if (ctx->use_async && ctx->lone && ctx->allow_head && !multi_rank(ctx)) dp.build_at = 0.9f;
     return dp;
 }
 
@@ -1238,12 +1222,10 @@ long long filter_items(const FilterArgs &f) { return (long long)f.gx * f.gy; }
 //   synchronous lists                                               -> kt_filter(_group), kt_process, kt_self2
 // Head mode (cvo_kernels.hip "the head"), where the scheme allows it -- asynchronous builds, step pass with the
 // twist in front, one rank: the post-step launch is gone; its argument block rides in the flow launch's entry
-// (op[q].ps), every flow / self block runs it as its head, and `tail` closes a batch with the flush.
-bool plan_lone(const std::vector<RecOp> &ops, Slot &slot, std::vector<TLaunch> &plan, std::vector<TLaunch> &tail,
-               const bool allow_head, bool *head_mode)
+// (op[q].ps), every flow / self block runs it as its head.
+bool plan_lone(const std::vector<RecOp> &ops, Slot &slot, std::vector<TLaunch> &plan, const bool allow_head, bool *head_mode)
 {
     plan.clear();
-    tail.clear();
     *head_mode = false;
     std::memset(&slot, 0, sizeof(slot));
     slot.active = 1;
@@ -1275,20 +1257,16 @@ bool plan_lone(const std::vector<RecOp> &ops, Slot &slot, std::vector<TLaunch> &
     // (acvo: flow pass and both self passes, 3 x np blocks, all run the head; with the 1024 blocks per pass
     // of round 2 three heads per SIMD took turns at the vector ALU and an iteration was a third SLOWER,
     // 40.5 -> 55 us at 10k x 10k -- job_begin gives acvo's passes 256 / 128 blocks now, profiles/r03_ab.txt)
-    static const bool head_acvo = getenv("CVO_HIP_NO_HEAD_ACVO") == nullptr;
-    // (CVO_HIP_HEAD_FLUSH: close every batch with the post-step part of its last slot as a launch of its
-    // own, so that the host paces without any lead -- the first version, 2 us per iteration slower)
-    static const bool head_flush = getenv("CVO_HIP_HEAD_FLUSH") != nullptr;
     const bool head = allow_head && rest_fits && have_flow && have_build &&
-                      ((na == 2 && ns == 2 && nf == 0 && head_acvo) || (na == 0 && ns == 0 && nf == 0));
+                      ((na == 2 && ns == 2 && nf == 0) || (na == 0 && ns == 0 && nf == 0));
     if (!head) {
         // The candidate records of double-buffered lists (ProcessArgs::cand_b, DevHead::xy_ck / sf_ck) belong to
         // head mode alone: enqueue_process fills them in before the plan is known.  A plan that falls back to the
-        // classic merged launches (CVO_HIP_NO_MERGE, CVO_HIP_NO_HEAD_ACVO) must not stream them -- its post-step
+        // classic merged launches (CVO_HIP_NO_MERGE, CVO_HIP_NO_HEAD) must not stream them -- its post-step
         // kernel would tie ONE record to both buffers (DevHead::ck_nblk) and a pass over the second buffer would
         // stream the first one's pairs.
         auto strip = [](ProcessArgs &p) {
-            if (p.cand_b) { p.cand = nullptr; p.cand_b = nullptr; p.cand_cnt = nullptr; p.cand_cnt_b = nullptr; p.cand_ck = nullptr; }
+            if (p.cand_b) { p.cand = nullptr; p.cand_b = nullptr; p.cand_cnt = nullptr; p.cand_cnt_b = nullptr; }
         };
         if (have_flow && flow.async_xy) strip(flow);
         for (int w = 0; w < ns; ++w)
@@ -1312,7 +1290,6 @@ bool plan_lone(const std::vector<RecOp> &ops, Slot &slot, std::vector<TLaunch> &
         if (head) { o.ps = ops[at + 1].ps; }
         plan.push_back(mk_launch(head ? TK_HFLOW_BUILD6 : (six ? TK_FLOW_BUILD6 : TK_FLOW_BUILD3), q,
                                  (unsigned)((six ? 3 : 1) * o.np + o.n0 + o.n1 + o.n2), 1, head ? smem_head(jt) : smem_of(jt)));
-        if (head && head_flush) tail.push_back(mk_launch(TK_HFLUSH, q, 1, 1));
         q += 3;
         if (six) ns = 0;
         nf = 0;
@@ -1337,14 +1314,12 @@ bool plan_lone(const std::vector<RecOp> &ops, Slot &slot, std::vector<TLaunch> &
         if (have_flow && have_build) {
             OpArgs &o = slot.op[q];
             o.p = flow; o.f = build;
-            static const long long fb_div = [] { const char *e = getenv("CVO_HIP_BUILD_DIV"); return e ? std::max(1LL, atoll(e)) : 4LL; }();
-            const long long cap = std::max<long long>(64, 2 * fbmax / fb_div);
+            const long long cap = std::max<long long>(64, fbmax / 2);   // (blocks of a build riding in a flow launch: / 1 ... / 8 measured alike)
             o.np = std::max(8, flow.nblk);
             o.n0 = (int)std::max(8u, filter_grid_cap(filter_items(build), cap));
             if (head) { o.ps = ops[at + 1].ps; }
             plan.push_back(mk_launch(head ? TK_HFLOW_BUILD : TK_FLOW_BUILD, q, (unsigned)(o.np + o.n0), 1,
                                      head ? smem_head(build.jt) : smem_of(build.jt)));
-            if (head && head_flush) tail.push_back(mk_launch(TK_HFLUSH, q, 1, 1));
             ++q;
         } else if (have_flow) {
             slot.op[q].p = flow;
@@ -1400,19 +1375,17 @@ bool plan_fused(const std::vector<const std::vector<RecOp> *> &ops, const std::v
     for (const auto *o : ops)
         if (o->size() != nq) return false;
     const long long fbmax = filter_blocks_cap();
-    static const long long fb_div = [] { const char *e = getenv("CVO_HIP_BUILD_DIV"); return e ? std::max(1LL, atoll(e)) : 4LL; }();
     // acvo, synchronous lists: filter xy, flow, filter xx, self, filter yy, self are recorded in the
     // reference's order; the three filters are independent of the passes, so the slots hold them
     // first -- three filters (one launch, blockIdx.y = list), flow, two self passes (one launch) --
     // 6 launches per iteration instead of 9
     std::vector<size_t> perm(nq);
     for (size_t q = 0; q < nq; ++q) perm[q] = q;
-    static const bool regroup = getenv("CVO_HIP_NO_REGROUP") == nullptr;
     {
         const std::vector<RecOp> &r = *ops[0];
         auto is_f = [&](size_t q) { return q < nq && r[q].kind == RecOp::FILTER && r[q].mode != kFilterAhead; };
         auto is_p = [&](size_t q, int mode) { return q < nq && r[q].kind == RecOp::PROCESS && r[q].mode == mode; };
-        if (regroup && is_f(0) && is_p(1, PROC_FLOW) && is_f(2) && is_p(3, PROC_SELF) && is_f(4) && is_p(5, PROC_SELF)) {
+        if (is_f(0) && is_p(1, PROC_FLOW) && is_f(2) && is_p(3, PROC_SELF) && is_f(4) && is_p(5, PROC_SELF)) {
             const size_t order[6] = {0, 2, 4, 1, 3, 5};
             for (size_t q = 0; q < 6; ++q) perm[q] = order[q];
         }
@@ -1445,7 +1418,7 @@ bool plan_fused(const std::vector<const std::vector<RecOp> *> &ops, const std::v
                 } else if (op.mode == kFlowBuild) {
                     kernel = TK_FLOW_BUILD;
                     o.f = op.f;
-                    const long long cap = std::max<long long>(64, 2 * fbmax / (fb_div * zdim));
+                    const long long cap = std::max<long long>(64, fbmax / (2 * zdim));
                     np = std::max(np, op.p.nblk);
                     nfb = std::max(nfb, filter_grid_cap(filter_items(op.f), cap));
                     smem = std::max(smem, (unsigned)filter_smem_bytes(op.f.jt));
@@ -1504,25 +1477,23 @@ bool same_plan(const std::vector<TLaunch> &a, const std::vector<TLaunch> &b)
     return a.size() == b.size() && (a.empty() || std::memcmp(a.data(), b.data(), a.size() * sizeof(TLaunch)) == 0);
 }
 
-void launch_plan_eager(const Slot *tab, const std::vector<TLaunch> &plan, const std::vector<TLaunch> &tail, int iterations,
-                       hipStream_t s)
+void launch_plan_eager(const Slot *tab, const std::vector<TLaunch> &plan, int iterations, hipStream_t s)
 {
     for (int k = 0; k < iterations; ++k)
         for (const TLaunch &l : plan) launch_table(tab, l, s, nullptr, nullptr, k & 1);
-    for (const TLaunch &l : tail) launch_table(tab, l, s);
 }
 
 // kBatch iterations of `plan` on table `tab`: through a cached graph when allowed, else eagerly.
 int run_plan(const Slot *tab, PlanCache &cache, const std::vector<TLaunch> &plan, hipStream_t s, bool use_graph,
-             int iterations, const std::vector<TLaunch> &tail = std::vector<TLaunch>())
+             int iterations)
 {
     if (!use_graph || cache.fails >= 64) {
-        launch_plan_eager(tab, plan, tail, iterations, s);
+        launch_plan_eager(tab, plan, iterations, s);
         return hipGetLastError() == hipSuccess ? CVO_HIP_OK : CVO_HIP_ERR_HIP;
     }
     PlanGraph *hit = nullptr;
     for (auto &g : cache.graphs)
-        if (g.iterations == iterations && same_plan(g.plan, plan) && same_plan(g.tail, tail)) { hit = &g; break; }
+        if (g.iterations == iterations && same_plan(g.plan, plan)) { hit = &g; break; }
     if (hit) ++cache.hits;
     if (!hit) {
         // The capture window needs the library's lock exclusively (cvo_lock.h).  Not getting it within its
@@ -1530,7 +1501,7 @@ int run_plan(const Slot *tab, PlanCache &cache, const std::vector<TLaunch> &plan
         // failed one: this batch goes out eagerly, nothing is counted, the next batch tries again.
         cvo_lock::Capture alone;   // (held: no other thread of this library is inside the runtime)
         if (!alone.ok) {
-            launch_plan_eager(tab, plan, tail, iterations, s);
+            launch_plan_eager(tab, plan, iterations, s);
             return hipGetLastError() == hipSuccess ? CVO_HIP_OK : CVO_HIP_ERR_HIP;
         }
         ++cache.captures;
@@ -1544,20 +1515,19 @@ int run_plan(const Slot *tab, PlanCache &cache, const std::vector<TLaunch> &plan
         }
         PlanGraph g;
         g.plan = plan;
-        g.tail = tail;
         g.iterations = iterations;
         // A capture can be spoilt from outside (another thread's HIP work: cvo_lock.h).  Nothing
         // has been launched then: the batch goes out eagerly and the next one tries again.
         hipError_t e = hipErrorUnknown;
         if (hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed) == hipSuccess) {
-            launch_plan_eager(tab, plan, tail, iterations, s);
+            launch_plan_eager(tab, plan, iterations, s);
             e = hipStreamEndCapture(s, &g.graph);
         }
         if (e != hipSuccess || !g.graph || hipGraphInstantiate(&g.exec, g.graph, nullptr, nullptr, 0) != hipSuccess) {
             if (g.graph) (void)hipGraphDestroy(g.graph);
             (void)hipGetLastError();
             ++cache.fails;
-            launch_plan_eager(tab, plan, tail, iterations, s);
+            launch_plan_eager(tab, plan, iterations, s);
             return hipGetLastError() == hipSuccess ? CVO_HIP_OK : CVO_HIP_ERR_HIP;
         }
         cache.fails = 0;
@@ -1593,7 +1563,7 @@ int prepare_lone_plan(cvo_hip_ctx *ctx, int trace_cap)
     int rc = record_iteration(ctx, ops, trace_cap);
     if (rc) return rc;
     Slot slot;
-    if (!plan_lone(ops, slot, ctx->plan, ctx->plan_tail, ctx->allow_head, &ctx->head_mode))
+    if (!plan_lone(ops, slot, ctx->plan, ctx->allow_head, &ctx->head_mode))
         return fail(ctx, CVO_HIP_ERR_INVALID, "launch plan does not fit the argument table");
     if (ctx->table.sync(&slot, loop_stream(ctx)) != 0) return fail(ctx, CVO_HIP_ERR_HIP, "argument table upload failed");
     return CVO_HIP_OK;
@@ -1609,7 +1579,7 @@ int launch_batch(cvo_hip_ctx *ctx, int tag0, int trace_cap)
         if (!rc) ctx->warm = true;
         return rc;
     }
-    const int rc = run_plan(ctx->table.dev, ctx->plans, ctx->plan, loop_stream(ctx), ctx->use_graphs, kBatch, ctx->plan_tail);
+    const int rc = run_plan(ctx->table.dev, ctx->plans, ctx->plan, loop_stream(ctx), ctx->use_graphs, kBatch);
     if (rc) return fail(ctx, rc, "launching a batch of iterations failed");
     return CVO_HIP_OK;
 }
@@ -1776,10 +1746,9 @@ int cvo_hip_create(int device, void *stream, const cvo_hip_params *p, cvo_hip_ct
     // (cvo_hip_set_graph_capture, or CVO_HIP_GRAPH=1) once it knows no other thread of the
     // process uses HIP while an align() is being set up.  CVO_HIP_NO_GRAPH=1 forbids captures.
     ctx->use_graphs = ctx->own_stream || getenv("CVO_HIP_GRAPH") != nullptr;
-    if (getenv("CVO_HIP_NO_GRAPH")) ctx->use_graphs = false;
+    if (env_no_graph()) ctx->use_graphs = false;
     if (getenv("CVO_HIP_NO_MERGE")) ctx->allow_merge = false;
-    if (getenv("CVO_HIP_NO_ASYNC")) ctx->allow_async = false;
-    if (getenv("CVO_HIP_NO_ASYNC_SELF")) ctx->allow_async_self = false;
+    if (getenv("CVO_HIP_NO_ASYNC")) ctx->allow_async = ctx->allow_async_self = false;
     if (const char *e = getenv("CVO_HIP_PROC_BLOCKS")) {   // list-kernel blocks of a lone registration
         const int v = atoi(e);
         if (v == 64 || v == 128 || v == 256 || v == 512 || v == 1024) {
@@ -1809,8 +1778,6 @@ int cvo_hip_destroy(cvo_hip_ctx *ctx)
         if (q) (void)hipIpcCloseMemHandle(q);
     if (ctx->comm_table) (void)hipFree(ctx->comm_table);
     if (ctx->mailbox) (void)hipFree(ctx->mailbox);
-    if (getenv("CVO_HIP_GRAPH_DEBUG"))
-        fprintf(stderr, "[cvo_hip] graph cache: %lld hits, %lld captures\n", ctx->plans.hits, ctx->plans.captures);
     drop_graphs(ctx);
     ctx->table.destroy();
     if (ctx->post_dbg) {
@@ -1826,7 +1793,7 @@ int cvo_hip_destroy(cvo_hip_ctx *ctx)
                     (void *)ctx->moving.feat, (void *)ctx->fixed.seg, (void *)ctx->moving.seg,
                     (void *)ctx->scratch_a.pos, (void *)ctx->scratch_a.feat, (void *)ctx->scratch_a.seg,
                     (void *)ctx->scratch_b.pos, (void *)ctx->scratch_b.feat, (void *)ctx->scratch_b.seg, (void *)ctx->st, (void *)ctx->st2, ctx->part_flow.p, ctx->part_xx.p,
-                    ctx->part_yy.p, ctx->part_step.p, (void *)ctx->trace_dev, ctx->kept_cnt.p, ctx->pos_bt.p, ctx->cand[0].p, ctx->cand[1].p, ctx->cand[2].p, ctx->cand_ck[0].p, ctx->cand_ck[1].p, ctx->cand_ck[2].p, ctx->cand_xyb.p, ctx->cand_cnt_xyb.p, ctx->cand_sfb[0].p, ctx->cand_sfb[1].p, ctx->cand_cnt_sfb[0].p, ctx->cand_cnt_sfb[1].p, ctx->cand_cnt[0].p,
+                    ctx->part_yy.p, ctx->part_step.p, (void *)ctx->trace_dev, ctx->kept_cnt.p, ctx->pos_bt.p, ctx->cand[0].p, ctx->cand[1].p, ctx->cand[2].p, ctx->cand_xyb.p, ctx->cand_cnt_xyb.p, ctx->cand_sfb[0].p, ctx->cand_sfb[1].p, ctx->cand_cnt_sfb[0].p, ctx->cand_cnt_sfb[1].p, ctx->cand_cnt[0].p,
                     ctx->cand_cnt[1].p, ctx->cand_cnt[2].p})
         if (p) (void)hipFree(p);
     for (int l = 0; l < LIST_N; ++l) {
@@ -2007,10 +1974,8 @@ int cvo_hip_set_pcd_many(cvo_hip_ctx *const *ctxs, const float *const *fixed_xyz
         }
     }
     static const int max_threads = [] {   // (half the host's cores, at most 8: staging is memory-bound well before that)
-        const char *e = getenv("CVO_HIP_COPY_THREADS");
         const int hw = (int)std::thread::hardware_concurrency();
-        const int v = e ? atoi(e) : std::min(8, std::max(2, hw / 2));
-        return std::max(1, std::min(v, 16));
+        return std::min(8, std::max(2, hw / 2));
     }();
     const int nt = (int)std::max<size_t>(1, std::min<size_t>((size_t)max_threads, raw_need / ((size_t)2 << 20)));
     std::vector<std::atomic<int>> staged(piece_end.size());
@@ -2438,7 +2403,6 @@ int job_begin(AlignJob &j)
     if (prc) return prc;
     // (a member of a fused group is planned by the group: its slot is one of many)
     ctx->head_mode = false;   // (set again by prepare_lone_plan if this align() runs a head-mode plan)
-    ctx->plan_tail.clear();
     if (!j.in_group && !ctx->profiling && !host_reduce(ctx)) {
         const int rc2 = prepare_lone_plan(ctx, j.trace_cap);
         if (rc2) return rc2;
@@ -2514,8 +2478,7 @@ int job_pump(AlignJob &j, bool block)
     // queues behind them).  The ~10 us the stream idles between two batches cost less than that
     // (CVO_HIP_PACE_LEAD = slots of overlap, 0 / 1 / 2 / 3: 644 / 619 / 627 / 620 registrations/s at
     // 10k x 10k, event-paced two batches ahead: 604).
-    static const bool no_pace = getenv("CVO_HIP_NO_PACE") != nullptr;
-    if (j.phase == 0 && block && j.paced && !no_pace && !host_reduce(ctx) && !ctx->profiling) {
+    if (j.phase == 0 && block && j.paced && !host_reduce(ctx) && !ctx->profiling) {
         const int limit = (ctx->use_async ? 3 : 1) * ctx->prm.max_iter + 4 * kBatch;
         unsigned spins = 0;
         int idle_seen = 0;
@@ -2526,9 +2489,7 @@ int job_pump(AlignJob &j, bool block)
             // batch's first launch, so the next batch must be on its way before the running one ends -- it goes
             // out when the running batch is down to its last slots; the GPU never idles between batches, and
             // a registration that stops in those last slots leaves one batch of launches that return at once)
-            static const int lead_env = [] { const char *e = getenv("CVO_HIP_PACE_LEAD"); const int v = e ? atoi(e) : -1; return v >= 0 && v <= 64 ? v : -1; }();
-            const bool flushless = ctx->head_mode && ctx->plan_tail.empty();
-            const int lead = lead_env >= 0 ? std::max(lead_env, flushless ? 1 : 0) : (flushless ? 2 : 0);
+            const int lead = ctx->head_mode ? 2 : 0;
             if (j.enq - slots <= lead) {
                 if (j.enq >= limit) break;   // cannot happen
                 const int rc = launch_batch(ctx, j.executed_base + j.enq, j.trace_cap);
@@ -2667,6 +2628,11 @@ struct EngineProfile {
     bool on = false;
     double flow_ms = 0.0, flow_slots = 0.0;
     long long flow_launches = 0;
+    // the launches one by one, in launch order per engine (cvo_hip_get_engine_flow_trace): duration, the time from
+    // this launch's begin to the next flow launch's begin on the same stream (= one iteration of the engine;
+    // 0 for the last of a drain), occupied slots
+    std::vector<float> dur_us, period_us;
+    std::vector<int> slots;
 };
 EngineProfile *engine_profile()
 {
@@ -2723,14 +2689,10 @@ struct Engine {
 
     static int nblk_for(int z)
     {
-        static const int budget = [] {   // blocks of a whole fused launch (tuning knob)
-            const char *e = getenv("CVO_HIP_PROC_BUDGET");
-            const int v = e ? atoi(e) : 2048;
-            return v >= 64 ? v : 2048;
-        }();
-        // (a multiple of 32 that divides or is a multiple of NSUB: 64, 128, 256, 512, 1024)
-        static const int nmin = [] { const char *e = getenv("CVO_HIP_PROC_MIN"); const int v = e ? atoi(e) : 64; return (v == 8 || v == 16 || v == 32) ? v : 64; }();
-        int nblk = nmin;
+        // blocks of a whole fused launch (1024 / 2048 / 4096 measured: 3 806 / 3 808 / 3 615 registrations/s at 64 pairs per
+        // call, 4 398 / 4 386 / 4 326 at 256, profiles/r04_ab.txt 1); a registration gets 64, 128, 256, 512 or 1024 of them
+        constexpr int budget = 2048;
+        int nblk = 64;
         while (nblk < PROC_BLOCKS && nblk * 2 <= (budget + z / 2) / std::max(1, z)) nblk *= 2;
         return nblk;
     }
@@ -2822,7 +2784,7 @@ struct Engine {
         const bool regeom = zd != zdim;
         zdim = zd;
         const int nblk = nblk_for(zdim);
-        static const int merge_max = [] { const char *e = getenv("CVO_HIP_MERGE_MAXG"); return e ? atoi(e) : 2; }();
+        constexpr int merge_max = 2;
         std::vector<const std::vector<RecOp> *> po;
         std::vector<Slot *> ps;
         for (int z = 0; z < ENGINE_SLOTS; ++z) {
@@ -2968,7 +2930,7 @@ struct Engine {
             moved = true;
         }
         // batches kept queued per engine (the other engines fill the gap between two batches of this one)
-        static const long long depth = [] { const char *e = getenv("CVO_HIP_ENGINE_DEPTH"); const int v = e ? atoi(e) : 2; return (long long)(v >= 1 && v <= 3 ? v : 2); }();
+        constexpr long long depth = 2;   // (one batch queued per engine instead of two: -17 %, profiles/r02_ab.txt)
         while (live() > 0 && launched - checked < depth) {
             if (dirty) {
                 const double t0 = now_ms();
@@ -3044,19 +3006,25 @@ void engine_release(Engine *e)
     if (!e->flow_ev.empty()) {   // (the engine is idle: every event has completed)
         EngineProfile *pr = engine_profile();
         std::lock_guard<std::mutex> plock(pr->mu);
-        for (auto &fe : e->flow_ev) {
-            float ms = 0.f;
+        for (size_t q = 0; q < e->flow_ev.size(); ++q) {
+            auto &fe = e->flow_ev[q];
+            float ms = 0.f, gap = 0.f;
             if (hipEventSynchronize(fe.b) == hipSuccess && hipEventElapsedTime(&ms, fe.a, fe.b) == hipSuccess) {
                 pr->flow_ms += ms; pr->flow_launches++; pr->flow_slots += fe.live;
+                if (q + 1 < e->flow_ev.size() && hipEventElapsedTime(&gap, fe.a, e->flow_ev[q + 1].a) != hipSuccess) gap = 0.f;
+                if (pr->dur_us.size() < (size_t)1 << 20) {
+                    pr->dur_us.push_back(ms * 1e3f); pr->period_us.push_back(gap * 1e3f); pr->slots.push_back(fe.live);
+                }
             }
+        }
+        for (auto &fe : e->flow_ev) {
             (void)hipEventDestroy(fe.a);
             (void)hipEventDestroy(fe.b);
         }
         e->flow_ev.clear();
     }
     std::lock_guard<std::mutex> lock(*engine_mutex());
-    static const bool dbg = getenv("CVO_HIP_ENGINE_DEBUG") != nullptr;
-    if (dbg)
+    if (env_engine_debug())
         fprintf(stderr, "[cvo_hip] engine %p: batches at zdim 1/2/4/8/16: %lld %lld %lld %lld %lld, replans %lld, "
                 "graph captures %lld hits %lld; host ms: insert %.2f replan %.2f launch %.2f collect %.2f finish %.2f wait %.2f\n",
                 (void *)e, e->n_batches[0], e->n_batches[1], e->n_batches[2],
@@ -3089,9 +3057,9 @@ int cvo_hip_align_many(cvo_hip_ctx **ctxs, cvo_hip_state **states, int *n_iters,
 {
     cvo_lock::Api api_guard;
     if (count < 0 || (count > 0 && (!ctxs || !states))) return CVO_HIP_ERR_INVALID;
-    static const bool dbg_many = getenv("CVO_HIP_ENGINE_DEBUG") != nullptr;
+    const bool dbg_many = env_engine_debug();
     const double t_many0 = Engine::now_ms();
-    struct Tell { double t0; int n; ~Tell() { if (dbg_many) fprintf(stderr, "[cvo_hip] align_many(%d): %.2f ms\n", n, Engine::now_ms() - t0); } } tell{t_many0, count};
+    struct Tell { double t0; int n; ~Tell() { if (env_engine_debug()) fprintf(stderr, "[cvo_hip] align_many(%d): %.2f ms\n", n, Engine::now_ms() - t0); } } tell{t_many0, count};
     std::vector<AlignJob> jobs((size_t)count);
     for (int i = 0; i < count; ++i) {
         if (!ctxs[i] || !states[i]) return CVO_HIP_ERR_INVALID;
@@ -3109,11 +3077,7 @@ int cvo_hip_align_many(cvo_hip_ctx **ctxs, cvo_hip_state **states, int *n_iters,
     // slots as slots become free.
     static const bool no_fuse = getenv("CVO_HIP_NO_FUSE") != nullptr;
     if (!no_fuse && count > 1) {
-        static const int gmax = [] {
-            const char *e = getenv("CVO_HIP_GROUP");
-            const int v = e ? atoi(e) : ENGINE_SLOTS;
-            return std::min((int)ENGINE_SLOTS, std::max(2, v));
-        }();
+        constexpr int gmax = ENGINE_SLOTS;
         for (int i = 0; i < count; ++i) {
             if (taken[i] || jobs[i].phase != 0 || !fusable(jobs[i].ctx)) continue;
             std::deque<AlignJob *> pending;
@@ -3131,7 +3095,7 @@ int cvo_hip_align_many(cvo_hip_ctx **ctxs, cvo_hip_state **states, int *n_iters,
             // groups well filled (64 distinct pairs in engines of 32 slots: 2 x 32 2897, 3 x 22 3149,
             // 4 x 16 2822); a fourth when three tables cannot hold every job at once (128 pairs:
             // 3 x 32 and 32 waiting 3297, 4 x 32 3644 -- the longest registration starts at once)
-            static const size_t max_engines = [] { const char *e = getenv("CVO_HIP_ENGINES"); const int v = e ? atoi(e) : 4; return (size_t)std::max(1, std::min(v, 8)); }();
+            constexpr size_t max_engines = 4;   // (the runtime's hardware queues; with 8 queues and 6 engines: -40 % at 64 pairs, r04_ab.txt 1)
             size_t ngroups = total > 3 * ENGINE_SLOTS ? 4 : (total >= 40 ? 3 : (total >= 8 ? 2 : 1));
             ngroups = std::max<size_t>(1, std::min(ngroups, max_engines));
             if (const char *e = getenv("CVO_HIP_ENGINES_FORCE")) ngroups = (size_t)std::max(1, std::min(atoi(e), 8));   // (tuning probe)
@@ -3140,7 +3104,7 @@ int cvo_hip_align_many(cvo_hip_ctx **ctxs, cvo_hip_state **states, int *n_iters,
             // Asynchronous xy builds shorten the launch chain of a registration; once the GPU is
             // shared by many registrations the chain no longer matters and the extra builds cost
             // more than they save: members of large groups keep the synchronous scheme.
-            static const int crowd = [] { const char *e = getenv("CVO_HIP_CROWD"); return e ? atoi(e) : 2; }();
+            constexpr int crowd = 2;
             std::vector<Engine *> engines;
             for (size_t g = 0; g < ngroups; ++g) {
                 Engine *e = engine_checkout(jobs[i].ctx->device);
@@ -3309,7 +3273,23 @@ int cvo_hip_get_engine_profile(double *flow_ms, long long *flow_launches, double
     EngineProfile *pr = engine_profile();
     std::lock_guard<std::mutex> lock(pr->mu);
     *flow_ms = pr->flow_ms; *flow_launches = pr->flow_launches; *flow_registrations = pr->flow_slots;
-    if (reset) { pr->flow_ms = 0.0; pr->flow_launches = 0; pr->flow_slots = 0.0; }
+    if (reset) { pr->flow_ms = 0.0; pr->flow_launches = 0; pr->flow_slots = 0.0; pr->dur_us.clear(); pr->period_us.clear(); pr->slots.clear(); }
+    return CVO_HIP_OK;
+}
+
+int cvo_hip_get_engine_flow_trace(float *dur_us, float *period_us, int *slots, int capacity, int *count, int reset)
+{
+    if (!count || capacity < 0) return CVO_HIP_ERR_INVALID;
+    EngineProfile *pr = engine_profile();
+    std::lock_guard<std::mutex> lock(pr->mu);
+    const int n = (int)std::min<size_t>(pr->dur_us.size(), (size_t)capacity);
+    for (int q = 0; q < n; ++q) {
+        if (dur_us) dur_us[q] = pr->dur_us[(size_t)q];
+        if (period_us) period_us[q] = pr->period_us[(size_t)q];
+        if (slots) slots[q] = pr->slots[(size_t)q];
+    }
+    *count = (int)pr->dur_us.size();
+    if (reset) { pr->dur_us.clear(); pr->period_us.clear(); pr->slots.clear(); }
     return CVO_HIP_OK;
 }
 
@@ -3331,7 +3311,7 @@ int cvo_hip_set_graph_capture(cvo_hip_ctx *ctx, int enable)
 {
     cvo_lock::Api api_guard;
     if (!ctx) return CVO_HIP_ERR_INVALID;
-    ctx->use_graphs = enable != 0 && getenv("CVO_HIP_NO_GRAPH") == nullptr;
+    ctx->use_graphs = enable != 0 && !env_no_graph();
     if (!ctx->use_graphs) drop_graphs(ctx);
     return CVO_HIP_OK;
 }

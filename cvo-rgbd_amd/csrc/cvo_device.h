@@ -288,8 +288,8 @@ struct ProcessArgs {
                            // passes over the same tile list (st->ck_nblk[list] == nblk) stream the record instead: nothing to
                            // expand, no feature gathers, no colour exp.  PROC_SELF (acvo's xx / yy lists) likewise,
                            // the sign of the recorded weight = the row counts (Ayy rule).  Null: no candidate list.
-    float *cand_ck;        // clouds of more than 65536 rows: the record is 12 bytes wide -- cand[] = (i, j), cand_ck[] = the
-                           // colour weight -- else null: 8 bytes, cand[] = (i | j << 16, the weight's bits)
+                           // (8 bytes per candidate: clouds of up to 65536 rows -- 12-byte records for larger clouds were
+                           // built and measured slower, profiles/r03_ab.txt 8)
     uint32_t *cand_cnt;    // [PROC_WAVES] candidates recorded by each wave
     uint2 *cand_b;         // head mode (double-buffered xy list): the record of the second buffer (8-byte form only) ...
     uint32_t *cand_cnt_b;  // ... DevHead::xy_ck[b] says whether buffer b's record matches its tile list
@@ -695,7 +695,7 @@ constexpr int STEP_TWIST_ROWS_DIV = 4;   // k_step_twist writes nblk / 4 partial
 // One launch of an iteration through a table: which kernel, its geometry, which op[] it reads.
 enum TKernel { TK_FILTER = 0, TK_FILTER_GROUP, TK_FLOW, TK_FLOW_MATLAB, TK_STEP, TK_SELF, TK_SELF2, TK_STEP_TWIST,
                TK_FLOW_BUILD, TK_FLOW_BUILD3, TK_FLOW_BUILD6, TK_POST_FLOW, TK_POST_STEP,
-               TK_HFLOW_BUILD, TK_HFLOW_BUILD6, TK_HSTEP_TWIST, TK_HFLUSH,
+               TK_HFLOW_BUILD, TK_HFLOW_BUILD6, TK_HSTEP_TWIST,
                TK_FLOW_D2 /* TK_FLOW is built without the sum of a d2 (ProcessArgs::need_d2 == 0 in every slot); this one has it */ };   // head mode (cvo_kernels.hip "Head mode")
 // Head-mode launches carry the slot's parity and the mode in the bits above the op index of their
 // second kernel argument: qp = q | parity << 8 | QP_HEAD.

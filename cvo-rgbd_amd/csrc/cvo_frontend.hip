@@ -810,7 +810,6 @@ int cvo_fe_create(int device, void *stream, int width, int height, cvo_fe_ctx **
         // (submit / collect), the registration's latency-bound launch chain goes first
         int least = 0, greatest = 0;
         (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
-        if (getenv("CVO_FE_NO_PRIORITY")) least = greatest;
         if (hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, least) != hipSuccess)
             return bail(CVO_HIP_ERR_HIP);
         ctx->own_stream = true;

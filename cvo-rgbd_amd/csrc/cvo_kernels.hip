@@ -383,15 +383,7 @@ k_filter(const Grp<FilterArgs> grp)
 }
 
 // blocks of one registration's filter launch (persistent, see k_filter)
-static long long filter_blocks_max()
-{
-    static const long long v = [] {
-        const char *e = getenv("CVO_HIP_FILTER_BLOCKS");
-        const long long q = e ? atoll(e) : 2048;
-        return q >= 1 ? q : 2048;
-    }();
-    return v;
-}
+static long long filter_blocks_max() { return 2048; }   // (1024 / 2048 / 4096 persistent blocks: within 1 %, profiles/r02_ab.txt 7)
 
 // grid.x of one registration: a multiple of 8 (one eighth of the blocks per XCD /
 // row region), enough for the largest region's items up to the cap
@@ -861,10 +853,7 @@ __device__ __forceinline__ bool expand_lists(const ProcessArgs &a, const ProcHea
             }
             if (REC) {   // every candidate goes on record, at the place the wave met it (its colour weight with it)
                 if (co + (unsigned)cnt <= a.kept_wcap) {
-                    if (lane < cnt) {
-                        if (a.cand_ck) { hd.cand[kbase + co + lane] = pr; a.cand_ck[kbase + co + lane] = ck; }
-                        else hd.cand[kbase + co + lane] = make_uint2(pr.x | (pr.y << 16), __float_as_uint(ck));
-                    }
+                    if (lane < cnt) hd.cand[kbase + co + lane] = make_uint2(pr.x | (pr.y << 16), __float_as_uint(ck));
                 } else if (lane == 0) {
                     atomicOr(&a.st->ovf[hd.par][LIST_KEPT], 1u);   // slice full: grow and redo
                 }
@@ -950,35 +939,24 @@ __device__ __forceinline__ bool stream_candidates(const ProcessArgs &a, const Pr
 {
     const size_t base = (size_t)wave * a.kept_wcap;
     unsigned n = hd.cand_cnt[wave];
-    const bool wide = a.cand_ck != nullptr;   // (12-byte records: clouds of more than 65536 rows)
     uint2 e = hd.cand[base + lane];
-    float ckv = wide ? a.cand_ck[base + lane] : 0.0f;
     if (done_word != 0) return false;
     if (n > a.kept_wcap) n = a.kept_wcap;
     unsigned nk = 0;
     for (unsigned b0 = 0; b0 < n; b0 += 64u) {
-        if (b0 != 0u) {
-            const size_t at = base + min(b0 + (unsigned)lane, a.kept_wcap - 1u);
-            e = hd.cand[at];
-            if (wide) ckv = a.cand_ck[at];
-        }
-        const unsigned ci = wide ? e.x : (e.x & 0xffffu), cj = wide ? e.y : (e.x >> 16);
+        if (b0 != 0u) e = hd.cand[base + min(b0 + (unsigned)lane, a.kept_wcap - 1u)];
+        const unsigned ci = e.x & 0xffffu, cj = e.x >> 16;
         float w = 0.0f;
         if (b0 + (unsigned)lane < n) {
-            float ck = wide ? ckv : __uint_as_float(e.y);
+            float ck = __uint_as_float(e.y);
             w = eval_pair<MODE, 0, 2>(a, hd, kc, ci, cj, 0.0f, acc, *hd.xi, s_etab, 0, &ck);
         }
         const unsigned long long km = __ballot(w > 0.0f);
         if (MODE == PROC_FLOW && w > 0.0f) {   // (members <= candidates <= the slice: it cannot overflow here)
             const unsigned below = __builtin_amdgcn_mbcnt_hi((unsigned)(km >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)km, 0u));
-            if (a.kept_packed == 1) {   // (8-byte candidate records exist for such clouds only: the same first word)
-                a.kept_ij[base + nk + below] = make_uint2(e.x, __float_as_uint(w));
-            } else if (a.kept_packed) {
-                a.kept_ij[base + nk + below] = kept_pack(a.kept_packed, a.kept_ebase, ci, cj, w);
-            } else {
-                a.kept_ij[base + nk + below] = make_uint2(ci, cj);
-                a.kept_a[base + nk + below] = w;
-            }
+            // (candidate records exist for clouds of up to 65536 rows only, whose kept entries are packed the same
+            // way: the record's first word IS the entry's)
+            a.kept_ij[base + nk + below] = make_uint2(e.x, __float_as_uint(w));
         }
         nk += (unsigned)__popcll(km);
     }
@@ -1348,8 +1326,6 @@ __device__ void block_reduce_partials(const double *part, int nblocks, double *s
 //               starts late must still find the old head): FB_s reads copy s & 1, writes copy ~s & 1;
 //               the step launch of slot s works on the copy FB_s wrote.  Batches have an even number of
 //               slots, so the head is back in copy 0 (DevState itself) when a batch ends.
-//   HM_FLUSH    the last launch of a head-mode batch: the post-step part alone, in place, one block --
-//               the host sees `done` and the slot count without enqueueing another flow launch.
 // The filter blocks that ride in a head-mode flow launch do not run the head: they build what the
 // PREVIOUS plan named, at the transform it recorded (cvo_device.h plan_xy_async).
 // ---------------------------------------------------------------------------
@@ -1538,7 +1514,7 @@ __global__ void __launch_bounds__(BLOCK) k_post_flow(const Grp<PostFlowArgs> grp
     post_flow_body(grp.a[blockIdx.z]);
 }
 
-enum HeadMode { HM_CLASSIC = 0, HM_HEAD = 1, HM_FLUSH = 2 };
+enum HeadMode { HM_CLASSIC = 0, HM_HEAD = 1 };
 
 // The maths of the head on wave 0 (all 64 lanes, every value wave-uniform).  Two stages, so that the
 // registers hold what the chain needs when it needs it: the post-step part runs on the few fields it
@@ -1596,7 +1572,7 @@ __device__ __forceinline__ void head_math(DevHead *lds, const PostStepArgs &a, c
         for (int l = 0; l < 3; ++l) ck_ok[l] = a.ck_nblk[l] != 0 && flag[l] == 0u;
     }
 
-    bool plan = HM != HM_FLUSH;
+    bool plan = true;
     if (run_post) {
         if (timed) clk[0] = (long long)__builtin_readcyclecounter();
         const cvo_math::CubicBracket cb = cvo_math::cubic_bracket(bcde);
@@ -1746,7 +1722,7 @@ __device__ __forceinline__ bool head_body(const PostStepArgs &a, const DevHead *
     const int tid = threadIdx.x;
     const bool reduce = HM != HM_CLASSIC || (a.flags & POST_REDUCE) != 0;
     const bool math = HM != HM_CLASSIC || (a.flags & POST_MATH) != 0;
-    const bool timed = a.dbg != nullptr && publisher && HM != HM_FLUSH;   // (CVO_HIP_POST_DEBUG: phase clocks of the publishing block)
+    const bool timed = a.dbg != nullptr && publisher;   // (CVO_HIP_POST_DEBUG: phase clocks of the publishing block)
     const long long c0 = timed ? (long long)__builtin_readcyclecounter() : 0;
     // one round trip: the step partials, the overflow flags of the builds that have ended (classic: row
     // 0, where everything is flagged; head mode: the row of the previous flow launch), the state's head
@@ -1791,7 +1767,7 @@ __device__ __forceinline__ bool head_body(const PostStepArgs &a, const DevHead *
         __syncthreads();
         // the tile lists the coming launches rebuild are emptied; the others are kept
         if (publisher && (s_st->done == RUNNING || s_st->done == NEED_BIGGER_LIST)) {
-            if (HM != HM_FLUSH) {
+            {
 #pragma unroll
                 for (int l = 0; l < 3; ++l) {   // synchronous lists (classic plans)
                     if (s_st->reuse[l] || (async && l == LIST_XY) || (aself && l != LIST_XY)) continue;
@@ -2183,17 +2159,6 @@ __device__ __forceinline__ ProcHead proc_head_lds(const ProcessArgs &a, const De
     }
 CVO_HEAD_KERNELS(_w4, 4)
 
-// the post-step part of the last slot of a head-mode batch, in place (copy 0: a batch has an even
-// number of slots), one block
-__global__ void __launch_bounds__(BLOCK) kt_head_flush(const Slot *__restrict__ tab, const int qp)
-{
-    __shared__ double sh[4 * NACC_MAX];
-    __shared__ __attribute__((aligned(16))) DevHead s_st;
-    CVO_SLOT(tab);
-    const PostStepArgs ps = CVO_ARG(PostStepArgs, op[qp & QP_MASK].ps);
-    head_body<HM_FLUSH>(ps, ps.st, ps.st, &s_st, sh, 0, true);
-}
-
 unsigned filter_grid_cap(long long nitems, long long cap) { return filter_grid_x(nitems, cap); }
 long long filter_blocks_cap() { return filter_blocks_max(); }
 
@@ -2225,7 +2190,6 @@ void launch_table(const Slot *tab, const TLaunch &l, hipStream_t s, hipEvent_t e
     case TK_HFLOW_BUILD: hipLaunchKernelGGL(kt_hflow_build_w4, g, dim3(BLOCK), l.smem, s, tab, qp); break;
     case TK_HFLOW_BUILD6: hipLaunchKernelGGL(kt_hflow_build6_w4, g, dim3(BLOCK), l.smem, s, tab, qp); break;
     case TK_HSTEP_TWIST: hipLaunchKernelGGL(kt_step_twist, g, dim3(STEP_BLOCK), 0, s, tab, qp); break;
-    case TK_HFLUSH: hipLaunchKernelGGL(kt_head_flush, g, dim3(BLOCK), 0, s, tab, l.q); break;
     default: break;
     }
 }

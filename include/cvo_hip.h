@@ -314,6 +314,11 @@ int cvo_hip_get_profile(cvo_hip_ctx *ctx, cvo_hip_profile *out, int reset);
  * (sum over launches of the occupied slots); bench.py quotes its roofline on it. */
 int cvo_hip_engine_profiling(int enable);
 int cvo_hip_get_engine_profile(double *flow_ms, long long *flow_launches, double *flow_registrations, int reset);
+/* The same launches one by one, in launch order (one engine at a time: with several, engine after engine as they
+ * are released): kernel duration, the time from the launch's begin to the NEXT flow launch's begin on the same
+ * stream (= one iteration of the engine: the length of its dependent launch chain; 0 for the last one), occupied
+ * slots.  *count = launches recorded (may exceed `capacity`, which bounds what is copied). */
+int cvo_hip_get_engine_flow_trace(float *dur_us, float *period_us, int *slots, int capacity, int *count, int reset);
 
 /* Diagnostics: how evenly the last flow pass (cvo_hip_flow / the last iteration of align) spread
  * the members of A over its wavefronts: members_per_wave[w] = pairs kept by wave w (4 waves per

@@ -765,22 +765,20 @@ def test_graph_capture_policy_and_parameter_errors(pkg):
 
 @pytest.mark.parametrize("mode_name", ["cvo", "acvo"])
 def test_transform_pass_and_candidate_list_change_nothing(pkg, monkeypatch, mode_name):
-    """Two mechanisms of the plans whose xy filter is a launch of its own (a 16k x 15k pair, too large
-    for a build to ride in the flow launch; crowded engines), each against the plain form:
-    transform_pcd as a pass of its own (the filter launch writes [Rt|t] y for every point, the list
-    passes read it; CVO_HIP_NO_PRETF = the transform inside the list passes, per pair) and the
-    candidate list (the flow pass after a build records every pair of the tile list with its colour
-    weight, the passes over the same list stream the record; CVO_HIP_NO_CAND = expand the tile list
-    every time; CVO_HIP_NO_CAND_SELF = only for acvo's xx / yy lists).  Same iterations, same state, bit
-    for bit, in every form."""
+    """The candidate list of the plans whose xy filter is a launch of its own (a 16k x 15k pair, too large
+    for a build to ride in the flow launch; crowded engines) against the plain form: the flow pass after a
+    build records every pair of the tile list with its colour weight, the passes over the same list stream
+    the record (acvo: the xx / yy lists likewise); CVO_HIP_NO_CAND = expand the tile list every time.  Same
+    iterations, same state, bit for bit.  (transform_pcd as a pass of its own -- these plans -- against the
+    transform per pair -- a registration on its own -- is what test_align_many_equals_one_by_one compares.)"""
     import torch
     capi = pkg.capi
     acvo = mode_name == "acvo"
     mode = capi.MODE_ACVO if acvo else capi.MODE_CVO
-    forms = ({}, {"CVO_HIP_NO_CAND": "1"}, {"CVO_HIP_NO_PRETF": "1"}, {"CVO_HIP_NO_CAND_SELF": "1"})
+    forms = ({}, {"CVO_HIP_NO_CAND": "1"})
 
     def set_form(env):
-        for k in ("CVO_HIP_NO_CAND", "CVO_HIP_NO_PRETF", "CVO_HIP_NO_CAND_SELF"):
+        for k in ("CVO_HIP_NO_CAND",):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -835,47 +833,11 @@ def _oracle_70k(pkg, po, acvo):
 
 
 @pytest.mark.parametrize("mode_name", ["cvo", "acvo"])
-def test_wide_candidate_records_for_clouds_above_65536_rows(pkg, po, mode_name, monkeypatch):
-    """Clouds of more than 65 536 rows: i and j no longer share a word, the candidate record is 12 bytes
-    wide (ProcessArgs::cand_ck) and the kept list 8 + 4 (opt-in, CVO_HIP_CAND_WIDE: measured slower at
-    these sizes, profiles/r03_ab.txt).  Streaming the record changes nothing: state and
-    trace equal the run that expands the tile list in every flow pass (CVO_HIP_NO_CAND), and the first
-    iterations equal the oracle's (ref src/cvo.cpp:99-210, src/adaptive_cvo.cpp:154-272)."""
-    import torch
-    capi = pkg.capi
-    acvo = mode_name == "acvo"
-    mode = capi.MODE_ACVO if acvo else capi.MODE_CVO
-    xf, ff, xm, fm = pkg.data.synthetic_pair(70000, 66000, seed=4711, acvo=acvo)
-    prm = capi.default_params(mode)
-    prm.max_iter = 14
-    runs = []
-    monkeypatch.setenv("CVO_HIP_CAND_WIDE", "1")
-    for off in (False, True):
-        if off:
-            monkeypatch.setenv("CVO_HIP_NO_CAND", "1")
-        else:
-            monkeypatch.delenv("CVO_HIP_NO_CAND", raising=False)
-        c = capi.Context(mode=mode, device=0, stream=torch.cuda.current_stream().cuda_stream, params=prm)
-        c.set_fixed(xf, ff)
-        c.set_moving(xm, fm)
-        st = capi.init_state(c.params)
-        it, tr = c.align(st, trace_cap=64)
-        runs.append((it, bytes(st), [(t["nnz"], t["nnz_xx"], t["nnz_yy"], t["omega"], t["v"], t["step"]) for t in tr]))
-        c.close()
-    assert runs[0] == runs[1]
-    n_or, tr_or = _oracle_70k(pkg, po, acvo)
-    assert n_or == runs[0][0]
-    for a, b in zip(runs[0][2], tr_or):
-        assert a[0] == b["nnz"] and a[1] == b["nnz_xx"] and a[2] == b["nnz_yy"]
-        assert a[3] == b["omega"] and a[4] == b["v"] and a[5] == b["step"]
-
-
-@pytest.mark.parametrize("mode_name", ["cvo", "acvo"])
 def test_eight_byte_kept_entries_for_clouds_above_65536_rows(pkg, po, mode_name, monkeypatch):
     """Clouds of 65 537 ... 262 144 rows: a member of A is kept in 8 bytes as well (ProcessArgs::kept_packed
     == 2: i and j in 18 bits each, the weight -- a float32 between sp_thres and sigma^2 c_sigma^2 -- as 4 bits
     of exponent and its mantissa; lossless).  State and trace equal the run with 8 + 4 bytes
-    (CVO_HIP_NO_PACK_WIDE) and the oracle's first 14 iterations (ref src/cvo.cpp:143-153,213-308)."""
+    (CVO_HIP_NO_PACK) and the oracle's first 14 iterations (ref src/cvo.cpp:143-153,213-308)."""
     import torch
     capi = pkg.capi
     acvo = mode_name == "acvo"
@@ -886,9 +848,9 @@ def test_eight_byte_kept_entries_for_clouds_above_65536_rows(pkg, po, mode_name,
     runs = []
     for off in (False, True):
         if off:
-            monkeypatch.setenv("CVO_HIP_NO_PACK_WIDE", "1")
+            monkeypatch.setenv("CVO_HIP_NO_PACK", "1")
         else:
-            monkeypatch.delenv("CVO_HIP_NO_PACK_WIDE", raising=False)
+            monkeypatch.delenv("CVO_HIP_NO_PACK", raising=False)
         c = capi.Context(mode=mode, device=0, stream=torch.cuda.current_stream().cuda_stream, params=prm)
         c.set_fixed(xf, ff)
         c.set_moving(xm, fm)

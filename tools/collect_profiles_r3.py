@@ -68,7 +68,7 @@ fetch = per_dispatch("pmc_fetch_r/*counter_collection.csv", "FETCH_SIZE")
 write = per_dispatch("pmc_write_r/*counter_collection.csv", "WRITE_SIZE")
 phases = {}
 CALLS = 6   # bench.py --roofline-only: one warm-up call + 5
-PH = (("ell_0.15", 0, 3), ("ell_0.10", 3, 10), ("ell_0.06", 10, 20), ("ell_0.03", 20, 10 ** 9))
+PH = (("ell_0.15", 0, 4), ("ell_0.10", 4, 11), ("ell_0.06", 11, 21), ("ell_0.03", 21, 10 ** 9))
 
 
 def by_iteration(v):
@@ -100,7 +100,8 @@ for k in ("kt_process<0, 0>", "kt_process<1, 0>", "kt_filter", "kt_post_step", "
     fi, fper = by_iteration(f)
     wi, wper = by_iteration(w)
     if di and fi and wi:
-        # (ref src/cvo.cpp:408-410: ell = 0.15 for k <= 2, 0.10 up to 9, 0.06 up to 19, then 0.03)
+        # (ref src/cvo.cpp:408-410, applied at the END of iteration k: ell = 0.15 in iterations 0-3, 0.10 in 4-10, 0.06 in 11-20, then 0.03;
+        # round 3 cut one iteration early)
         live = min(dper, fper, wper)
         for name, lo, hi in PH:
             its = [i for i in range(lo, min(hi, live))]
