@@ -1,0 +1,600 @@
+// cvo_engine.cpp -- batched mode (BASELINE configs[4]): fused groups as long-lived engines with continuous
+// batching, and cvo_hip_align_many, the host loop that pumps them.
+#include "cvo_internal.h"
+
+using namespace cvo_dev;
+using namespace cvo_impl;
+
+namespace cvo_impl {
+
+// ---------------------------------------------------------------------------
+// Fused mode: up to MAXG registrations advance through ONE sequence of launches
+// (blockIdx.z = registration).  All members run the same launch sequence (same
+// mode, single rank, no per-launch events) on the leader's stream; a member
+// that has stopped keeps returning at its first load until it is dropped from
+// the launches at the next poll.
+bool fusable(const cvo_hip_ctx *c) { return !c->profiling && !multi_rank(c) && !(c->prm.color_scale > 0.0f); }
+
+// Engine profiling (cvo_hip_engine_profiling): while it is on, the engines launch eagerly and every
+// flow-pass launch (kt_process<PROC_FLOW>, the kernel with the largest share of a batched run)
+// carries a HIP event pair; the sums are read with cvo_hip_get_engine_profile.
+struct EngineProfile {
+    std::mutex mu;
+    bool on = false;
+    double flow_ms = 0.0, flow_slots = 0.0;
+    long long flow_launches = 0;
+    // the launches one by one, in launch order per engine (cvo_hip_get_engine_flow_trace): duration, the time from
+    // this launch's begin to the next flow launch's begin on the same stream (= one iteration of the engine;
+    // 0 for the last of a drain), occupied slots
+    std::vector<float> dur_us, period_us;
+    std::vector<int> slots;
+};
+EngineProfile *engine_profile()
+{
+    static EngineProfile *p = new EngineProfile;
+    return p;
+}
+
+// A fused group as a long-lived engine: a stream, a table of ENGINE_SLOTS slots and the batches
+// captured for it, all of which outlive the cvo_hip_align_many call that uses them.
+// Registrations enter a free slot and leave it when they stop -- by stream-ordered copies into
+// the table, between two batches of iterations: nothing is drained, nothing is captured again
+// (continuous batching).  Slots are kept packed at the low end; the launches serve
+// zdim = 1, 2, 4, 8, 16, 24 or 32 slots, the list kernels getting more blocks per registration the
+// fewer share the launch.  One host thread keeps several engines in flight: while one group
+// sits in its single-block post kernels or between two kernels, the other one has the GPU.
+struct Engine {
+    int device = 0;
+    hipStream_t s = nullptr;
+    TableBuf tab;
+    PlanCache plans;
+    bool in_use = false;
+
+    // state of the call in progress
+    AlignJob *member[ENGINE_SLOTS] = {};
+    std::vector<RecOp> ops[ENGINE_SLOTS];
+    Slot slot[ENGINE_SLOTS];
+    struct Retire { hipEvent_t ev = nullptr; std::vector<AlignJob *> jobs; };
+    std::vector<Retire> retiring;          // their final state is on its way to the host
+    hipEvent_t ev[4] = {};
+    long long launched = 0, checked = 0;   // batches
+    int zdim = 0;
+    bool crowded = true, use_graph = true, dirty = true, failed = false;
+    std::vector<TLaunch> plan;
+    struct FlowEv { hipEvent_t a, b; int live; };
+    std::vector<FlowEv> flow_ev;           // engine profiling: one pair per flow-pass launch
+    // diagnostics (CVO_HIP_ENGINE_DEBUG)
+    long long n_batches[5] = {}, n_replans = 0, n_inserts = 0, n_sends = 0;
+    double t_replan = 0, t_insert = 0, t_launch = 0, t_finish = 0, t_wait = 0, t_collect = 0, t_idle_at = 0;
+    static double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+    int create(int dev)
+    {
+        device = dev;
+        if (hipSetDevice(dev) != hipSuccess) return -1;
+        if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) return -1;
+        if (tab.init(ENGINE_SLOTS, s) != 0) return -1;
+        for (auto &e : ev)
+            if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return -1;
+        return 0;
+    }
+
+    int live() const { int n = 0; for (AlignJob *j : member) n += j != nullptr; return n; }
+    bool idle() const { return live() == 0 && retiring.empty() && launched == checked; }
+
+    static int nblk_for(int z)
+    {
+        // blocks of a whole fused launch (1024 / 2048 / 4096 measured: 3 806 / 3 808 / 3 615 registrations/s at 64 pairs per
+        // call, 4 398 / 4 386 / 4 326 at 256, profiles/r04_ab.txt 1); a registration gets 64, 128, 256, 512 or 1024 of them
+        constexpr int budget = 2048;
+        int nblk = 64;
+        while (nblk < PROC_BLOCKS && nblk * 2 <= (budget + z / 2) / std::max(1, z)) nblk *= 2;
+        return nblk;
+    }
+
+    void finish_job(AlignJob *j, int rc)
+    {
+        j->rc = rc;
+        j->phase = 2;
+        j->in_group = false;
+        j->ctx->loop_stream = nullptr;
+        j->ctx->crowded = false;
+        j->ctx->lone = true;
+        j->ctx->proc_blocks = j->ctx->proc_blocks_default;
+    }
+
+    void fail_all(const char *msg, std::deque<AlignJob *> &pending)
+    {
+        failed = true;
+        (void)hipStreamSynchronize(s);
+        for (AlignJob *&j : member)
+            if (j) { finish_job(j, fail(j->ctx, CVO_HIP_ERR_HIP, msg)); j = nullptr; }
+        for (auto &r : retiring) {
+            for (AlignJob *j : r.jobs) finish_job(j, fail(j->ctx, CVO_HIP_ERR_HIP, msg));
+            if (r.ev) (void)hipEventDestroy(r.ev);
+        }
+        retiring.clear();
+        for (AlignJob *j : pending) { j->rc = fail(j->ctx, CVO_HIP_ERR_HIP, msg); j->phase = 2; }
+        pending.clear();
+        for (int z = 0; z < ENGINE_SLOTS; ++z) slot[z].active = 0;
+        (void)tab.sync(slot, s, 0);
+        (void)hipStreamSynchronize(s);
+        launched = checked = 0;
+    }
+
+    // a job takes slot z: its align() begins (or resumes after its lists grew) on this stream
+    int insert(AlignJob *j, int z)
+    {
+        cvo_hip_ctx *c = j->ctx;
+        c->loop_stream = s;
+        c->crowded = crowded;
+        c->lone = false;
+        j->in_group = true;
+        int rc = CVO_HIP_OK;
+        if (j->phase == 3) {   // resuming: the state is where the overflow parked it
+            int32_t zero = 0;
+            std::memcpy(&c->st_host[kPollSlots].done, &zero, sizeof(zero));
+            if (hipMemcpyAsync(reinterpret_cast<char *>(c->st) + offsetof(DevState, done), &c->st_host[kPollSlots].done,
+                               sizeof(zero), hipMemcpyHostToDevice, s) != hipSuccess)
+                rc = fail(c, CVO_HIP_ERR_HIP, "resume failed");
+            *c->done_mirror = 0;
+            launch_prepare(c->st, loop_params(c), s);
+            j->phase = 0;
+        } else {
+            rc = job_begin(*j);
+        }
+        if (rc) { finish_job(j, rc); return rc; }
+        if (j->phase != 0) {   // max_iter <= 0: nothing to run; the state copy is already queued
+            Retire r;
+            if (hipEventCreateWithFlags(&r.ev, hipEventDisableTiming) != hipSuccess || hipEventRecord(r.ev, s) != hipSuccess) {
+                finish_job(j, fail(c, CVO_HIP_ERR_HIP, "event failed"));
+                return CVO_HIP_ERR_HIP;
+            }
+            r.jobs.push_back(j);
+            retiring.push_back(r);
+            return CVO_HIP_OK;
+        }
+        member[z] = j;
+        ops[z].clear();
+        dirty = true;
+        return CVO_HIP_OK;
+    }
+
+    // membership changed: pick zdim (1, 2, 4, 8, 16, 24, 32 >= the members), bring the members that sit
+    // above it down into free slots (the others stay where they are: a slot that moves is a slot
+    // that has to be sent again), (re)record what needs it, make the plan, send what changed
+    int replan()
+    {
+        int n = 0;
+        for (int z = 0; z < ENGINE_SLOTS; ++z) n += member[z] != nullptr;
+        int zd = 1;
+        while (zd < n) zd *= 2;
+        if (n > 16 && n <= 24) zd = 24;   // (three engines sharing 64 registrations hold 21 or 22 each)
+        for (int z = ENGINE_SLOTS - 1, hole = 0; z >= zd; --z) {
+            if (!member[z]) continue;
+            while (member[hole]) ++hole;
+            member[hole] = member[z]; member[z] = nullptr;
+            ops[hole].swap(ops[z]); ops[z].clear();
+        }
+        const bool regeom = zd != zdim;
+        zdim = zd;
+        const int nblk = nblk_for(zdim);
+        constexpr int merge_max = 2;
+        std::vector<const std::vector<RecOp> *> po;
+        std::vector<Slot *> ps;
+        for (int z = 0; z < ENGINE_SLOTS; ++z) {
+            if (!member[z]) { slot[z].active = 0; continue; }
+            cvo_hip_ctx *c = member[z]->ctx;
+            if (regeom || ops[z].empty()) {
+                c->proc_blocks = nblk;
+                // k_step_twist pays for the saved launch with a prologue in every block:
+                // a gain while launches are latency-bound, a loss once the GPU is full
+                const bool allow = c->allow_merge;
+                if (zdim > merge_max) c->allow_merge = false;
+                const int rc = record_iteration(c, ops[z], 0);
+                c->allow_merge = allow;
+                if (rc) return rc;
+            }
+            std::memset(&slot[z], 0, sizeof(Slot));
+            slot[z].active = 1;
+            po.push_back(&ops[z]);
+            ps.push_back(&slot[z]);
+        }
+        if (!plan_fused(po, ps, zdim, plan)) return CVO_HIP_ERR_INVALID;
+        const int nq = po.empty() ? 0 : (int)po[0]->size();
+        if (tab.sync(slot, s, nq) != 0) return CVO_HIP_ERR_HIP;
+        ++n_replans;
+        dirty = false;
+        return CVO_HIP_OK;
+    }
+
+    // members whose loop has stopped leave their slots; their final state starts for the host
+    void collect_stopped()
+    {
+        Retire r;
+        for (int z = 0; z < ENGINE_SLOTS; ++z) {
+            AlignJob *j = member[z];
+            if (!j || *(volatile int32_t *)j->ctx->done_mirror == RUNNING) continue;
+            if (hipMemcpyAsync(&j->ctx->st_host[0], j->ctx->st, sizeof(DevState), hipMemcpyDeviceToHost, s) != hipSuccess) {
+                finish_job(j, fail(j->ctx, CVO_HIP_ERR_HIP, "state copy failed"));
+            } else {
+                r.jobs.push_back(j);
+            }
+            member[z] = nullptr;
+            ops[z].clear();
+            dirty = true;
+        }
+        if (r.jobs.empty()) return;
+        if (hipEventCreateWithFlags(&r.ev, hipEventDisableTiming) != hipSuccess || hipEventRecord(r.ev, s) != hipSuccess) {
+            for (AlignJob *j : r.jobs) finish_job(j, fail(j->ctx, CVO_HIP_ERR_HIP, "event failed"));
+            if (r.ev) (void)hipEventDestroy(r.ev);
+            return;
+        }
+        retiring.push_back(r);
+    }
+
+    // final states that have arrived: hand the registration back, or -- a list overflowed --
+    // enlarge it and queue the registration again (it resumes at the iteration it parked at)
+    bool finish_arrived(std::deque<AlignJob *> &pending, bool block)
+    {
+        bool moved = false;
+        while (!retiring.empty()) {
+            Retire &r = retiring.front();
+            const hipError_t q = block ? hipEventSynchronize(r.ev) : hipEventQuery(r.ev);
+            if (q == hipErrorNotReady) break;
+            block = false;
+            for (AlignJob *j : r.jobs) {
+                cvo_hip_ctx *c = j->ctx;
+                const DevState &cur = c->st_host[0];
+                if (q != hipSuccess) { finish_job(j, fail(c, CVO_HIP_ERR_HIP, "state event failed")); continue; }
+                if (cur.done != NEED_BIGGER_LIST) { finish_job(j, job_finish(*j)); continue; }
+                int rc = CVO_HIP_OK;
+                for (int l = 0; l < LIST_N && !rc; ++l)
+                    if (cur.ovf[0][l] | cur.ovf[1][l]) {
+                        uint32_t worst = 0;
+                        for (int qq = 0; qq < NSUB; ++qq) worst = std::max(worst, cur.sub[l][qq]);
+                        const double grown = std::min(
+                            4.0e9, std::max((double)worst * NSUB, (double)c->lists[l].cap) * 1.5 + 1024.0);
+                        rc = ensure_list(c, l, 0, 0, grown);
+                    }
+                for (int qq = 0; qq < 3 && !rc; ++qq) {   // the two buffers of a list share one capacity
+                    const int la = qq == 0 ? LIST_XY : (qq == 1 ? LIST_XX : LIST_YY), lb = qq == 0 ? LIST_XYB : (qq == 1 ? LIST_XXB : LIST_YYB);
+                    if (!c->lists[la].cap && !c->lists[lb].cap) continue;
+                    const double both = (double)std::max(c->lists[la].cap, c->lists[lb].cap);
+                    rc = ensure_list(c, la, 0, 0, both);
+                    if (!rc && c->lists[lb].cap) rc = ensure_list(c, lb, 0, 0, both);
+                }
+                if (rc) { finish_job(j, rc); continue; }
+                j->executed_base = cur.k;
+                j->phase = 3;   // resume
+                pending.push_front(j);
+            }
+            (void)hipEventDestroy(r.ev);
+            retiring.erase(retiring.begin());
+            moved = true;
+        }
+        return moved;
+    }
+
+    // one batch of kEngineBatch iterations of the current plan on this engine's stream
+    int launch_one_batch()
+    {
+        const int batch = kEngineBatch;
+        if (engine_profile()->on) {   // eager, the flow-pass launches bracketed by events
+            for (int k = 0; k < batch; ++k)
+                for (const TLaunch &l : plan) {
+                    if (l.kernel == TK_FLOW || l.kernel == TK_FLOW_D2) {
+                        FlowEv fe{nullptr, nullptr, live()};
+                        if (hipEventCreate(&fe.a) == hipSuccess && hipEventCreate(&fe.b) == hipSuccess) {
+                            launch_table(tab.dev, l, s, fe.a, fe.b);
+                            flow_ev.push_back(fe);
+                            continue;
+                        }
+                    }
+                    launch_table(tab.dev, l, s);
+                }
+            return hipGetLastError() == hipSuccess ? CVO_HIP_OK : CVO_HIP_ERR_HIP;
+        }
+        return run_plan(tab.dev, plans, plan, s, use_graph, batch);
+    }
+
+    // Advance as far as possible without waiting on the GPU.  `want` = how many members this
+    // engine should hold at most right now.  Returns true if anything moved.
+    bool pump(std::deque<AlignJob *> &pending, int want)
+    {
+        if (failed) return false;
+        if (hipSetDevice(device) != hipSuccess) { fail_all("hipSetDevice failed", pending); return true; }
+        bool moved = false;
+        // batches that have completed: look for members that stopped
+        while (checked < launched) {
+            const hipError_t q = hipEventQuery(ev[checked % 4]);
+            if (q == hipErrorNotReady) break;
+            if (q != hipSuccess) { fail_all("fused poll failed", pending); return true; }
+            ++checked;
+            { const double t0 = now_ms(); collect_stopped(); t_collect += now_ms() - t0; }
+            moved = true;
+        }
+        { const double t0 = now_ms(); if (finish_arrived(pending, false)) moved = true; t_finish += now_ms() - t0; }
+        // free slots take the next registrations
+        while (!pending.empty() && live() < std::min(want, (int)ENGINE_SLOTS)) {
+            AlignJob *j = pending.front();
+            pending.pop_front();
+            int z = 0;
+            while (member[z]) ++z;
+            { const double t0 = now_ms(); insert(j, z); t_insert += now_ms() - t0; }
+            moved = true;
+        }
+        // batches kept queued per engine (the other engines fill the gap between two batches of this one)
+        constexpr long long depth = 2;   // (one batch queued per engine instead of two: -17 %, profiles/r02_ab.txt)
+        while (live() > 0 && launched - checked < depth) {
+            if (dirty) {
+                const double t0 = now_ms();
+                const int rc = replan();
+                t_replan += now_ms() - t0;
+                if (rc) { fail_all("fused launch recording failed", pending); return true; }
+            }
+            const double t_l0 = now_ms();
+            const int rc_launch = launch_one_batch();
+            if (rc_launch != CVO_HIP_OK ||
+                hipEventRecord(ev[launched % 4], s) != hipSuccess) {
+                fail_all("fused launch failed", pending);
+                return true;
+            }
+            t_launch += now_ms() - t_l0;
+            ++launched;
+            ++n_batches[zdim >= 16 ? 4 : (zdim >= 8 ? 3 : (zdim >= 4 ? 2 : (zdim >= 2 ? 1 : 0)))];
+            moved = true;
+        }
+        if (live() == 0 && dirty && launched == checked) {   // the last members left: empty the table
+            if (replan() != CVO_HIP_OK) { fail_all("table update failed", pending); return true; }
+        }
+        return moved;
+    }
+
+    // block until the oldest thing in flight has completed
+    void wait_oldest(std::deque<AlignJob *> &pending)
+    {
+        const double t0 = now_ms();
+        struct Acc { double &t; double t0; ~Acc() { t += now_ms() - t0; } } acc{t_wait, t0};
+        if (checked < launched) {
+            if (hipEventSynchronize(ev[checked % 4]) != hipSuccess) fail_all("fused poll failed", pending);
+        } else if (!retiring.empty()) {
+            (void)hipEventSynchronize(retiring.front().ev);
+        }
+    }
+};
+
+// engines live for the life of the process (like their streams); a call borrows them
+std::mutex *engine_mutex()
+{
+    static std::mutex *mu = new std::mutex;   // (never destroyed: see cvo_lock.h)
+    return mu;
+}
+
+Engine *engine_checkout(int device)
+{
+    static std::vector<Engine *> *all = new std::vector<Engine *>();
+    std::lock_guard<std::mutex> lock(*engine_mutex());
+    for (Engine *e : *all)
+        if (!e->in_use && e->device == device && !e->failed) { e->in_use = true; return e; }
+    // The runtime deals streams to its (four) hardware queues in the order they are created: engines
+    // whose streams share a queue run one behind the other.  An engine created alone, long after its
+    // siblings, landed on a queue one of them already had (256 pairs per call after a first call with
+    // three engines: 4 130 -> 3 370 registrations/s).  So the first call on a device creates all four
+    // streams back to back; the spares cost a table each.
+    size_t have = 0;
+    for (Engine *e : *all) have += e->device == device && !e->failed;
+    Engine *first = nullptr;
+    for (size_t k = have; k < std::max<size_t>(have + 1, 4); ++k) {
+        Engine *e = new (std::nothrow) Engine();
+        if (!e) break;
+        if (e->create(device) != 0) { (void)hipGetLastError(); delete e; break; }
+        all->push_back(e);
+        if (!first) first = e;
+    }
+    if (first) first->in_use = true;
+    return first;
+}
+
+void engine_release(Engine *e)
+{
+    if (!e->flow_ev.empty()) {   // (the engine is idle: every event has completed)
+        EngineProfile *pr = engine_profile();
+        std::lock_guard<std::mutex> plock(pr->mu);
+        for (size_t q = 0; q < e->flow_ev.size(); ++q) {
+            auto &fe = e->flow_ev[q];
+            float ms = 0.f, gap = 0.f;
+            if (hipEventSynchronize(fe.b) == hipSuccess && hipEventElapsedTime(&ms, fe.a, fe.b) == hipSuccess) {
+                pr->flow_ms += ms; pr->flow_launches++; pr->flow_slots += fe.live;
+                if (q + 1 < e->flow_ev.size() && hipEventElapsedTime(&gap, fe.a, e->flow_ev[q + 1].a) != hipSuccess) gap = 0.f;
+                if (pr->dur_us.size() < (size_t)1 << 20) {
+                    pr->dur_us.push_back(ms * 1e3f); pr->period_us.push_back(gap * 1e3f); pr->slots.push_back(fe.live);
+                }
+            }
+        }
+        for (auto &fe : e->flow_ev) {
+            (void)hipEventDestroy(fe.a);
+            (void)hipEventDestroy(fe.b);
+        }
+        e->flow_ev.clear();
+    }
+    std::lock_guard<std::mutex> lock(*engine_mutex());
+    if (env_engine_debug())
+        fprintf(stderr, "[cvo_hip] engine %p: batches at zdim 1/2/4/8/16: %lld %lld %lld %lld %lld, replans %lld, "
+                "graph captures %lld hits %lld; host ms: insert %.2f replan %.2f launch %.2f collect %.2f finish %.2f wait %.2f\n",
+                (void *)e, e->n_batches[0], e->n_batches[1], e->n_batches[2],
+                e->n_batches[3], e->n_batches[4], e->n_replans, e->plans.captures, e->plans.hits,
+                e->t_insert, e->t_replan, e->t_launch, e->t_collect, e->t_finish, e->t_wait);
+    e->t_insert = e->t_replan = e->t_launch = e->t_collect = e->t_finish = e->t_wait = 0;
+    for (long long &v : e->n_batches) v = 0;
+    e->n_replans = 0;
+    e->launched = e->checked = 0;
+    e->in_use = false;
+}
+
+
+}   // namespace cvo_impl
+
+extern "C" {
+
+int cvo_hip_align_many(cvo_hip_ctx **ctxs, cvo_hip_state **states, int *n_iters, int count)
+{
+    cvo_lock::Api api_guard;
+    if (count < 0 || (count > 0 && (!ctxs || !states))) return CVO_HIP_ERR_INVALID;
+    const bool dbg_many = env_engine_debug();
+    const double t_many0 = Engine::now_ms();
+    struct Tell { double t0; int n; ~Tell() { if (env_engine_debug()) fprintf(stderr, "[cvo_hip] align_many(%d): %.2f ms\n", n, Engine::now_ms() - t0); } } tell{t_many0, count};
+    std::vector<AlignJob> jobs((size_t)count);
+    for (int i = 0; i < count; ++i) {
+        if (!ctxs[i] || !states[i]) return CVO_HIP_ERR_INVALID;
+        for (int k = 0; k < i; ++k)
+            if (ctxs[k] == ctxs[i]) return CVO_HIP_ERR_INVALID;   // one job per context
+        jobs[i].ctx = ctxs[i];
+        jobs[i].s = states[i];
+        jobs[i].n_iter = n_iters ? &n_iters[i] : nullptr;
+    }
+    int first_err = CVO_HIP_OK;
+    std::vector<char> taken((size_t)count, 0);
+    // fused groups: same device, same mode, nothing that needs its own launches.  The jobs of
+    // a class wait in one queue; one or two engines (two from 8 jobs on: two groups fill each
+    // other's bubbles -- single-block post kernels, kernel boundaries) take them into their
+    // slots as slots become free.
+    static const bool no_fuse = getenv("CVO_HIP_NO_FUSE") != nullptr;
+    if (!no_fuse && count > 1) {
+        constexpr int gmax = ENGINE_SLOTS;
+        for (int i = 0; i < count; ++i) {
+            if (taken[i] || jobs[i].phase != 0 || !fusable(jobs[i].ctx)) continue;
+            std::deque<AlignJob *> pending;
+            for (int k = i; k < count; ++k)
+                if (!taken[k] && jobs[k].phase == 0 && fusable(jobs[k].ctx) &&
+                    jobs[k].ctx->device == jobs[i].ctx->device &&
+                    jobs[k].ctx->prm.mode == jobs[i].ctx->prm.mode)
+                    pending.push_back(&jobs[k]);
+            if (pending.size() < 2) continue;
+            for (AlignJob *j : pending) taken[j - &jobs[0]] = 1;
+            const size_t total = pending.size();
+            // how many engines share the GPU: one group alone leaves it idle in its single-block post
+            // kernels and at every kernel boundary; two fill each other's bubbles (32 pairs: 2079 ->
+            // 2428 registrations/s; three: 2273); a third pays once there are enough jobs to keep three
+            // groups well filled (64 distinct pairs in engines of 32 slots: 2 x 32 2897, 3 x 22 3149,
+            // 4 x 16 2822); a fourth when three tables cannot hold every job at once (128 pairs:
+            // 3 x 32 and 32 waiting 3297, 4 x 32 3644 -- the longest registration starts at once)
+            constexpr size_t max_engines = 4;   // (the runtime's hardware queues; with 8 queues and 6 engines: -40 % at 64 pairs, r04_ab.txt 1)
+            size_t ngroups = total > 3 * ENGINE_SLOTS ? 4 : (total >= 40 ? 3 : (total >= 8 ? 2 : 1));
+            ngroups = std::max<size_t>(1, std::min(ngroups, max_engines));
+            if (const char *e = getenv("CVO_HIP_ENGINES_FORCE")) ngroups = (size_t)std::max(1, std::min(atoi(e), 8));   // (tuning probe)
+            bool graphs_ok = true;   // (capture policy: cvo_hip_set_graph_capture)
+            for (AlignJob *j : pending) graphs_ok = graphs_ok && j->ctx->use_graphs;
+            // Asynchronous xy builds shorten the launch chain of a registration; once the GPU is
+            // shared by many registrations the chain no longer matters and the extra builds cost
+            // more than they save: members of large groups keep the synchronous scheme.
+            constexpr int crowd = 2;
+            std::vector<Engine *> engines;
+            for (size_t g = 0; g < ngroups; ++g) {
+                Engine *e = engine_checkout(jobs[i].ctx->device);
+                if (!e) break;
+                e->crowded = (int)total > crowd;
+                e->use_graph = graphs_ok;
+                e->zdim = 0;
+                e->t_idle_at = 0;
+                e->dirty = true;
+                engines.push_back(e);
+            }
+            if (engines.empty()) {   // no engine to be had: the jobs run on their own below
+                for (AlignJob *j : pending) taken[j - &jobs[0]] = 0;
+                continue;
+            }
+            // the first fill is even (16 + 16 of 32, 4 + 4 of 8); later a free slot takes the next job
+            const int share = std::min<int>(gmax, (int)((total + engines.size() - 1) / engines.size()));
+            for (;;) {
+                bool any = false, moved = false;
+                for (Engine *e : engines) {
+                    if (e->pump(pending, share)) moved = true;
+                    if (!e->idle()) any = true;
+                    else if (dbg_many && e->t_idle_at == 0) {
+                        e->t_idle_at = Engine::now_ms();
+                        fprintf(stderr, "[cvo_hip]   engine %p idle after %.2f ms\n", (void *)e, e->t_idle_at - t_many0);
+                    }
+                }
+                if (!any && pending.empty()) break;
+                bool alive = false;
+                for (Engine *e : engines) alive = alive || !e->failed;
+                if (!alive) break;
+                if (!moved)   // everybody waits for the GPU: block on the oldest thing in flight
+                    for (Engine *e : engines)
+                        if (!e->idle() && !e->failed) { e->wait_oldest(pending); break; }
+            }
+            for (Engine *e : engines) engine_release(e);
+        }
+        for (int i = 0; i < count; ++i)
+            if (jobs[i].phase == 2 && jobs[i].rc && !first_err) first_err = jobs[i].rc;
+    }
+    // the others run on their own streams and tables
+    for (int i = 0; i < count; ++i) {
+        if (taken[i] || jobs[i].phase == 2) continue;
+        jobs[i].ctx->crowded = false;
+        jobs[i].ctx->lone = true;
+        const int rc = job_begin(jobs[i]);
+        if (rc) { jobs[i].rc = rc; jobs[i].phase = 2; if (!first_err) first_err = rc; }
+    }
+    // round-robin: every pass tops up each registration's queue and looks at its
+    // poll word without blocking; when nobody moved, block on the oldest job
+    for (;;) {
+        int live = 0, moved = 0, first_live = -1;
+        for (int i = 0; i < count; ++i) {
+            if (jobs[i].phase == 2) continue;
+            const int before_phase = jobs[i].phase, before_checked = jobs[i].checked;
+            if (job_pump(jobs[i], false)) {
+                if (jobs[i].rc && !first_err) first_err = jobs[i].rc;
+                ++moved;
+                continue;
+            }
+            ++live;
+            if (first_live < 0) first_live = i;
+            if (jobs[i].phase != before_phase || jobs[i].checked != before_checked) ++moved;
+        }
+        if (live == 0) break;
+        if (!moved) {
+            if (job_pump(jobs[first_live], true) && jobs[first_live].rc && !first_err)
+                first_err = jobs[first_live].rc;
+        }
+    }
+    return first_err;
+}
+
+int cvo_hip_engine_profiling(int enable)
+{
+    EngineProfile *pr = engine_profile();
+    std::lock_guard<std::mutex> lock(pr->mu);
+    pr->on = enable != 0;
+    return CVO_HIP_OK;
+}
+
+int cvo_hip_get_engine_profile(double *flow_ms, long long *flow_launches, double *flow_registrations, int reset)
+{
+    if (!flow_ms || !flow_launches || !flow_registrations) return CVO_HIP_ERR_INVALID;
+    EngineProfile *pr = engine_profile();
+    std::lock_guard<std::mutex> lock(pr->mu);
+    *flow_ms = pr->flow_ms; *flow_launches = pr->flow_launches; *flow_registrations = pr->flow_slots;
+    if (reset) { pr->flow_ms = 0.0; pr->flow_launches = 0; pr->flow_slots = 0.0; pr->dur_us.clear(); pr->period_us.clear(); pr->slots.clear(); }
+    return CVO_HIP_OK;
+}
+
+int cvo_hip_get_engine_flow_trace(float *dur_us, float *period_us, int *slots, int capacity, int *count, int reset)
+{
+    if (!count || capacity < 0) return CVO_HIP_ERR_INVALID;
+    EngineProfile *pr = engine_profile();
+    std::lock_guard<std::mutex> lock(pr->mu);
+    const int n = (int)std::min<size_t>(pr->dur_us.size(), (size_t)capacity);
+    for (int q = 0; q < n; ++q) {
+        if (dur_us) dur_us[q] = pr->dur_us[(size_t)q];
+        if (period_us) period_us[q] = pr->period_us[(size_t)q];
+        if (slots) slots[q] = pr->slots[(size_t)q];
+    }
+    *count = (int)pr->dur_us.size();
+    if (reset) { pr->dur_us.clear(); pr->period_us.clear(); pr->slots.clear(); }
+    return CVO_HIP_OK;
+}
+
+
+}   // extern "C"

@@ -1,0 +1,370 @@
+// cvo_internal.h -- what the translation units of the host library share: the context, the growable device
+// arrays, argument tables and captured batches, the recorded launches of an iteration, the resumable align() job.
+//   cvo_capi.cpp    entry points that are not listed below (create / destroy, parameters, sharding, mailboxes, the
+//                   low-level calls of the loop body, function_inner_product, profiling getters)
+//   cvo_clouds.cpp  the cloud hand-over (tail of set_pcd(), ref src/cvo.cpp:344-356): one cloud, a batch
+//   cvo_plan.cpp    from the launches of ONE iteration (recorded, not issued) to launch plans, argument tables and
+//                   captured batches; the eager launches of the low-level entry points
+//   cvo_job.cpp     align() as a resumable job: begin / pump / finish; cvo_hip_align
+//   cvo_engine.cpp  fused groups as long-lived engines with continuous batching; cvo_hip_align_many
+#pragma once
+#include "cvo_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cmath>
+#include <cstddef>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <deque>
+#include <memory>
+#include <mutex>
+#include <new>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "cvo_cloud.h"
+#include "cvo_comm.h"
+#include "cvo_device.h"
+#include "cvo_lock.h"
+#include "se3_math.hpp"
+
+namespace cvo_impl {
+using namespace cvo_dev;
+
+
+struct Cloud {
+    float4 *pos = nullptr;   // Morton-sorted; .w = the 5th feature
+    float *feat = nullptr;   // same order: f0..f4, index in the caller's cloud (int bits), 2 pad
+    float4 *seg = nullptr;   // bounding sphere (centre, radius) of every SEG consecutive points
+    int n = 0;               // points, as the caller counts them
+    int np = 0;              // rows of the device arrays: n padded to CLOUD_PAD (cvo_cloud.h); what kernels get
+    int pad_axis = 0;        // where the padding rows are parked (the two clouds of a pair differ)
+    int cap = 0;
+    float lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};   // bounding box
+    // A hand-over from host arrays does not wait for the device (round 3): the cloud's own pinned staging and
+    // bounding-box words, an event behind the preparation; whoever needs the box or another stream's view of
+    // the arrays waits then (cloud_ready: at the next compute entry point, or when the staging is needed again)
+    void *stage = nullptr;
+    size_t stage_bytes = 0;
+    float *bbox_pin = nullptr;        // [6] pinned
+    hipEvent_t ready_ev = nullptr;
+    hipEvent_t wait_ev = nullptr;     // what `pending` waits for: ready_ev, or the event of a batched hand-over (borrowed)
+    bool pending = false;
+};
+
+struct EventPair {
+    hipEvent_t a, b;
+    int kind;      // SweepMode
+    int iter_tag;  // align() iteration the launch belongs to, -1 outside align()
+    double pairs;
+};
+
+struct FilterPlan {
+    dim3 grid;
+    int jt = 0;
+};
+
+struct DevBuf {   // a growable device array
+    void *p = nullptr;
+    size_t bytes = 0;
+};
+
+struct List {     // LIST_XY/XX/YY: TileEntry[cap] in a; LIST_KEPT: uint2[cap] in a, float[cap] in b
+    DevBuf a, b;
+    uint32_t cap = 0;   // entries, a multiple of NSUB
+};
+
+// iterations per captured batch of a registration on its own (paced submission, job_pump: measured with the next
+// batch enqueued when the running one has finished -- 6 / 8 / 12 / 16 / 24: 643 / 644 / 632 / 625 / 600 reg/s at 10k x 10k,
+// 650 / 668 / 668 / 644 / 672 at 3k x 3k, acvo 388 / 393 / 376 / 392 / 380)
+// ... and in a fused group, where a batch boundary is also where a slot that fell free is noticed and
+// refilled.  With tables of 16 slots (a batch of 64 pairs = 48 in flight + 16 waiting for a slot) shorter was
+// better (3 -> 2857, 4 -> 2917, 6 -> 2693, 8 -> 2621 registrations/s); with tables of 32 a batch of 64 is in
+// flight at once and the iterations are cheaper (candidate lists): 4 / 8 / 10 / 12 / 16 / 24 per captured batch:
+// 256 pairs per call 3905 / 4188 / 4254 / 4248 / 4277 / 4105, 64 pairs 3604 / 3625 / - / 3650 / 3594 / 3571,
+// 32 pairs 2630 / 2734 / - / 2723 / 2453 / 2694, 8 x 20k 1022 / 1029 / 1028 / 1014 / 995 / 961 -> 10
+constexpr int kEngineBatch = 10;
+// (an even number: a head-mode batch must leave the state's head in its first copy, cvo_kernels.hip "the head")
+constexpr int kBatch = 8;
+
+// The kernels of the loop read their argument blocks from a table of Slots in device memory
+// (cvo_device.h "Argument tables"): one slot for a registration on its own (cvo_hip_align), up
+// to MAXG for a fused group (cvo_hip_align_many).  The host keeps an image of what it last sent
+// per slot and sends a slot again only when its image changed -- through a small ring of
+// pinned staging buffers, ordered on the stream that runs the loop.
+constexpr int kStage = 4;
+struct TableBuf {
+    Slot *dev = nullptr;
+    int nslots = 0;
+    std::vector<Slot> image;          // what the device holds (after the queued copies)
+    Slot *stage = nullptr;            // pinned [kStage][nslots]
+    hipEvent_t stage_ev[kStage] = {};
+    bool stage_used[kStage] = {};
+    int next = 0;
+
+    // (s: the stream every later copy into the table is ordered on -- the zero fill must be too:
+    // a non-blocking stream does not wait for the null stream's memset)
+    int init(int n, hipStream_t s)
+    {
+        if (dev) return 0;
+        if (hipMalloc((void **)&dev, (size_t)n * sizeof(Slot)) != hipSuccess) { dev = nullptr; return -1; }
+        if (hipMemsetAsync(dev, 0, (size_t)n * sizeof(Slot), s) != hipSuccess) return -1;
+        if (hipHostMalloc((void **)&stage, (size_t)kStage * n * sizeof(Slot), hipHostMallocDefault) != hipSuccess) return -1;
+        for (int i = 0; i < kStage; ++i)
+            if (hipEventCreateWithFlags(&stage_ev[i], hipEventDisableTiming) != hipSuccess) return -1;
+        nslots = n;
+        image.assign((size_t)n, Slot{});
+        return 0;
+    }
+    void destroy()
+    {
+        for (int i = 0; i < kStage; ++i)
+            if (stage_ev[i]) (void)hipEventDestroy(stage_ev[i]);
+        if (stage) (void)hipHostFree(stage);
+        if (dev) (void)hipFree(dev);
+        dev = nullptr; stage = nullptr; nslots = 0;
+        image.clear();
+    }
+    // Make the device hold want[0 .. nslots): as far as the first `nq` argument blocks of the
+    // ACTIVE slots and every slot's `active` flag go.  Whatever differs travels in ONE copy (the
+    // span from the first to the last slot that changed), ordered on s -- every copy is a stop of
+    // its own between two batches of the stream.
+    int sync(const Slot *want, hipStream_t s, int nq = MAX_OPS)
+    {
+        const size_t head = offsetof(Slot, op);
+        int lo = nslots, hi = -1;
+        for (int z = 0; z < nslots; ++z) {
+            const Slot &img = image[(size_t)z];
+            bool same = std::memcmp(&img, &want[z], head) == 0;
+            if (same && want[z].active) same = std::memcmp(img.op, want[z].op, (size_t)nq * sizeof(OpArgs)) == 0;
+            if (!same) { lo = std::min(lo, z); hi = z; }
+        }
+        if (hi < 0) return 0;
+        const int b = next;
+        next = (next + 1) % kStage;
+        if (stage_used[b] && hipEventSynchronize(stage_ev[b]) != hipSuccess) return -1;   // (kStage copies ago)
+        Slot *st = stage + (size_t)b * nslots;
+        const size_t n = (size_t)(hi - lo + 1);
+        for (int z = lo; z <= hi; ++z) {
+            if (want[z].active) image[(size_t)z] = want[z];
+            else image[(size_t)z].active = 0;   // (its argument blocks stay what they were: nobody reads them)
+            st[z] = image[(size_t)z];
+        }
+        if (hipMemcpyAsync(&dev[lo], &st[lo], n * sizeof(Slot), hipMemcpyHostToDevice, s) != hipSuccess) return -1;
+        if (hipEventRecord(stage_ev[b], s) != hipSuccess) return -1;
+        stage_used[b] = true;
+        return 0;
+    }
+};
+
+// A captured batch of kBatch iterations of a launch plan (hipGraph).  It depends on the table's
+// address and on the plan -- kernels, grids, LDS sizes -- not on any argument: one capture
+// serves every frame pair (and every membership of a fused group) of the same shape.
+struct PlanGraph {
+    std::vector<TLaunch> plan;
+    int iterations = 0;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    uint64_t stamp = 0;
+};
+struct PlanCache {
+    std::vector<PlanGraph> graphs;
+    uint64_t clock = 0;
+    long long hits = 0, captures = 0;
+    int fails = 0;
+    void drop()
+    {
+        for (auto &g : graphs) {
+            if (g.exec) (void)hipGraphExecDestroy(g.exec);
+            if (g.graph) (void)hipGraphDestroy(g.graph);
+        }
+        graphs.clear();
+    }
+};
+constexpr int kPollSlots = 4;
+constexpr int kEvProcFlow = 10, kEvProcStep = 11;   // EventPair::kind of the list kernels (0..2: k_filter of list l)
+constexpr int kProcStepTwist = 100;   // RecOp::mode of a k_step_twist launch
+constexpr int kFlowBuild = 101;       // RecOp::mode of a k_flow_build launch (RecOp::f = the build's arguments)
+constexpr int kFilterAhead = 102;     // RecOp::mode of an xx / yy filter that builds ahead (rides in the flow launch)
+
+// One kernel launch of an iteration, recorded instead of launched (fused mode:
+// the launches of several registrations are merged slot by slot).
+struct RecOp {
+    enum Kind { FILTER, PROCESS, POST_FLOW, POST_STEP } kind;
+    int mode = 0;   // PROCESS: ProcMode
+    FilterArgs f{};
+    ProcessArgs p{};
+    PostFlowArgs pf{};
+    PostStepArgs ps{};
+};
+
+
+}   // namespace cvo_impl
+
+// (an internal header: the host translation units all work in these two namespaces)
+using namespace cvo_dev;
+using namespace cvo_impl;
+
+struct cvo_hip_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    cvo_hip_params prm{};
+    DevParams dprm{};
+    Cloud fixed, moving;
+    Cloud scratch_a, scratch_b;      // cvo_hip_function_inner_product_clouds: never the registration's clouds
+    DevState *st = nullptr;          // device
+    DevHead *st2 = nullptr;          // device: second copy of the state's head (head mode, cvo_kernels.hip)
+    bool head_mode = false;          // the plan of the align() in progress is a head-mode plan
+    bool allow_head = true;          // CVO_HIP_NO_HEAD
+    DevState *st_host = nullptr;     // pinned [kPollSlots + 2]
+    int32_t *done_mirror = nullptr;  // pinned (in the last slot): the post kernels copy `done` here
+    int32_t *progress_mirror = nullptr;   // pinned, next to it: slots the post-step kernel has completed
+    std::vector<RecOp> *rec = nullptr;   // not null: record launches instead of issuing them
+    int proc_blocks = PROC_BLOCKS;       // blocks of the list kernels (fewer in fused launches)
+    int proc_blocks_default = PROC_BLOCKS;
+    bool proc_blocks_forced = false;     // CVO_HIP_PROC_BLOCKS
+    DevBuf raw_xyz, raw_feat;            // upload_cloud: the caller's arrays as they came
+    DevBuf sort_keys[2], sort_idx[2], sort_tmp;   // ... scratch of the device-side Morton sort
+    float *bbox_dev = nullptr;           // [6] device, bounding box of a cloud handed over in device memory
+    float *bbox_host = nullptr;          // [6] pinned
+    // asynchronous xy builds (cvo_device.h plan_xy_async): the k_filter blocks of the xy
+    // list ride in the launch of the flow pass of the same slot (k_flow_build) and fill
+    // the idle one of two buffers
+    FilterArgs xy_build{};               // argument block of those filter blocks (this slot)
+    bool have_xy_build = false;
+    bool allow_async = true;
+    bool crowded = false;                // set by align_many: many registrations share the launches
+    DevBuf cand[3], cand_cnt[3];         // the candidate lists of the xy / xx / yy tile lists (ProcessArgs::cand, cand_cnt)
+    DevBuf cand_xyb, cand_cnt_xyb;       // head mode: the record of the second buffer of the xy list (ProcessArgs::cand_b)
+    DevBuf cand_sfb[2], cand_cnt_sfb[2]; // ... and of the xx / yy lists (acvo)
+    int ck_nblk[3] = {0, 0, 0};          // recorded plan: the pass over list l keeps a candidate list with this many blocks (0: no)
+    DevBuf pos_bt;                       // crowded: the moving cloud under the iteration's transform (FilterArgs::pos_bt)
+    bool lone = true;                    // this registration has its launches to itself
+    bool allow_async_self = true;
+    bool use_async_self = false;         // acvo, lone: self lists built ahead, PROC_SELF in the flow launch
+    bool use_async = false;              // decided per align(): single rank, not profiling
+    bool in_loop = false;                // enqueueing iterations of align()
+    bool plan_recording = false;         // ... into the RecOp list a table plan is made of (record_iteration)
+    bool merge_twist = false;            // inside align(): k_step_twist replaces k_post_flow + PROC_STEP
+    bool allow_merge = true;
+    cvo_hip_trace *cur_trace = nullptr;  // trace buffer of the iterations being enqueued
+    int cur_trace_cap = 0;
+    hipEvent_t poll_ev[kPollSlots]{};
+    DevBuf part_flow, part_xx, part_yy, part_step;   // [PROC_BLOCKS][NACC_MAX] float64
+    List lists[LIST_N];
+    DevBuf kept_cnt;                 // uint32[PROC_WAVES]
+    cvo_hip_trace *trace_dev = nullptr;
+    int trace_dev_cap = 0;
+    bool have_tf = false;
+    int row_lo = 0, row_hi = -1, srow_lo = 0, srow_hi = -1;
+    bool sharded = false;
+    cvo_comm *comm = nullptr;
+    // mailbox all-reduce (cvo_device.h Mailbox / CommTable)
+    Mailbox *mailbox = nullptr;          // this rank's own, device memory (uncached where the runtime offers it)
+    CommTable *comm_table = nullptr;     // device copy; not null = connected: the post kernels exchange
+    void *mail_opened[MAX_WORLD] = {};   // peers' mailboxes opened from IPC handles (closed at destroy)
+    int mail_rank = 0, mail_world = 0;
+    bool mail_broken = false;            // an exchange timed out: the ranks' sequence numbers no longer agree (see job_finish)
+    cvo_hip_allreduce_fn user_allreduce = nullptr;
+    void *user_allreduce_arg = nullptr;
+    bool profiling = false;
+    long long *post_dbg = nullptr;   // CVO_HIP_POST_DEBUG diagnostics
+    TableBuf table;                  // this registration's own argument table (one slot): cvo_hip_align
+    PlanCache plans;                 // ... and the batches captured for it
+    std::vector<TLaunch> plan;       // launches of one iteration of the align() in progress
+    hipStream_t loop_stream = nullptr;   // stream the align() in progress runs on (a fused group's, else `stream`)
+    bool warm = false;               // every device buffer of the loop has been allocated
+    bool use_graphs = true;
+    int iter_tag = -1;
+    std::vector<EventPair> events;
+    cvo_hip_profile prof{};
+    std::string err;
+};
+
+namespace cvo_impl {
+
+#define HIP_TRY(ctx, expr)                                                                   \
+    do {                                                                                     \
+        hipError_t e_ = (expr);                                                              \
+        if (e_ != hipSuccess) {                                                              \
+            if (ctx) (ctx)->err = std::string(#expr) + ": " + hipGetErrorString(e_);         \
+            return CVO_HIP_ERR_HIP;                                                          \
+        }                                                                                    \
+    } while (0)
+
+struct AlignJob {
+    cvo_hip_ctx *ctx = nullptr;
+    cvo_hip_state *s = nullptr;
+    cvo_hip_trace *trace = nullptr;
+    int trace_cap = 0;
+    int *n_iter = nullptr;
+    int enq = 0;            // iterations enqueued in this round
+    int batches = 0;        // batches enqueued in this round
+    int checked = 0;        // batches whose poll copy has been looked at
+    int executed_base = 0;  // iterations completed before this round (after a list grew)
+    int phase = 0;          // 0 enqueueing/polling, 1 waiting for the final state, 2 finished
+    int rc = CVO_HIP_OK;
+    bool in_group = false;  // runs in a fused group (on the group's stream and table)
+    bool paced = false;     // cvo_hip_align only: the calling thread has nothing else to pump and may sit in the
+                            // paced loop of job_pump (align_many's blocking fall-back must keep its round-robin going:
+                            // the other jobs -- the peer ranks of a mailbox world among them -- run dry otherwise)
+};
+
+// ---- cvo_capi.cpp
+int fail(cvo_hip_ctx *ctx, int code, const char *msg);
+bool env_no_cand();
+bool env_no_graph();
+bool env_sync_upload();
+bool env_engine_debug();
+const char *params_problem(const cvo_hip_params &p);
+DevParams make_dev_params(const cvo_hip_params &p);
+// ---- cvo_clouds.cpp
+int cloud_ready(cvo_hip_ctx *ctx, Cloud &c);
+int cloud_reserve(cvo_hip_ctx *ctx, Cloud &c, const float *xyz, const float *feat, int n, int layout);
+int upload_cloud(cvo_hip_ctx *ctx, Cloud &c, const float *xyz, const float *feat, int n, int layout, bool on_device = false);
+// ---- cvo_plan.cpp
+FilterPlan plan_filter(int nrows, int nb);
+int ensure_buf(cvo_hip_ctx *ctx, DevBuf &b, size_t bytes);
+int ensure_list(cvo_hip_ctx *ctx, int list, int nrows, int nb, double at_least);
+void shard_ranges(const cvo_hip_ctx *ctx, int &rlo, int &rhi, int &slo, int &shi);
+int fill_filter_geometry(cvo_hip_ctx *ctx, DevState *h);
+int mailboxes_usable(cvo_hip_ctx *ctx);
+bool host_reduce(const cvo_hip_ctx *ctx);
+bool multi_rank(const cvo_hip_ctx *ctx);
+DevParams loop_params(const cvo_hip_ctx *ctx);
+hipStream_t loop_stream(const cvo_hip_ctx *ctx);
+int enqueue_filter(cvo_hip_ctx *ctx, int list, const Cloud &ca, int row_lo, int row_hi, int tf_a, const Cloud &cb, int tf_b, int check_done);
+int enqueue_process(cvo_hip_ctx *ctx, int mode, int list, DevBuf &part, const float4 *pos_a, const float *feat_a, int tf_a,
+                    const float4 *pos_b, const float *feat_b, int tf_b, int first_counted, int check_done);
+int drain_events(cvo_hip_ctx *ctx, int n_exec = -1, const DevState *fin = nullptr);
+int reduce_over_ranks(cvo_hip_ctx *ctx, int off, int count);
+int enqueue_flow(cvo_hip_ctx *ctx, bool tf_moving, int check_done, bool do_math, cvo_hip_trace *trace, int trace_cap);
+int enqueue_step(cvo_hip_ctx *ctx, int check_done, bool do_math, cvo_hip_trace *trace, int trace_cap);
+int check_overflow_and_grow(cvo_hip_ctx *ctx, bool *redo);
+int prepare_buffers(cvo_hip_ctx *ctx);
+int enqueue_iterations(cvo_hip_ctx *ctx, int count, int tag0, int trace_cap);
+void drop_graphs(cvo_hip_ctx *ctx);
+TLaunch mk_launch(int kernel, int q, unsigned gx, unsigned gz, unsigned smem = 0);
+bool plan_lone(const std::vector<RecOp> &ops, Slot &slot, std::vector<TLaunch> &plan, const bool allow_head, bool *head_mode);
+bool plan_fused(const std::vector<const std::vector<RecOp> *> &ops, const std::vector<Slot *> &slots, int zdim, std::vector<TLaunch> &plan);
+int run_plan(const Slot *tab, PlanCache &cache, const std::vector<TLaunch> &plan, hipStream_t s, bool use_graph, int iterations);
+int record_iteration(cvo_hip_ctx *ctx, std::vector<RecOp> &ops, int trace_cap);
+int prepare_lone_plan(cvo_hip_ctx *ctx, int trace_cap);
+int launch_batch(cvo_hip_ctx *ctx, int tag0, int trace_cap);
+int zero_counters(cvo_hip_ctx *ctx);
+int push_state_fields(cvo_hip_ctx *ctx, size_t off, size_t bytes);
+int fetch_red(cvo_hip_ctx *ctx, int off, int count, double *out);
+// ---- cvo_job.cpp
+int job_begin(AlignJob &j);
+int job_finish(AlignJob &j);
+int job_pump(AlignJob &j, bool block);
+
+}   // namespace cvo_impl

@@ -1,0 +1,315 @@
+// cvo_job.cpp -- align() (ref src/cvo.cpp:361-420, src/adaptive_cvo.cpp:490-555) as a resumable job: begin / pump /
+// finish, so that one host thread can keep many registrations in flight; cvo_hip_align is one job pumped to its end.
+#include "cvo_internal.h"
+
+using namespace cvo_dev;
+using namespace cvo_impl;
+
+namespace cvo_impl {
+
+int job_begin(AlignJob &j)
+{
+    cvo_hip_ctx *ctx = j.ctx;
+    cvo_hip_state *s = j.s;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    {
+        const int rcm = mailboxes_usable(ctx);
+        if (rcm) return rcm;
+    }
+    const cvo_hip_params &p = ctx->prm;
+    if (p.mode == CVO_HIP_MODE_ACVO) {   // tail of acvo::set_pcd (ref src/adaptive_cvo.cpp:476-478)
+        s->ell = p.ell_init;
+        s->ell_max = p.ell_max_init;
+    }
+    *ctx->done_mirror = 0;
+    *ctx->progress_mirror = 0;
+    if (!j.trace) j.trace_cap = 0;
+    if (j.trace_cap > p.max_iter) j.trace_cap = p.max_iter;
+    if (j.trace_cap > ctx->trace_dev_cap) {
+        if (ctx->trace_dev) HIP_TRY(ctx, hipFree(ctx->trace_dev));
+        ctx->trace_dev = nullptr; ctx->trace_dev_cap = 0;
+        HIP_TRY(ctx, hipMalloc((void **)&ctx->trace_dev, (size_t)j.trace_cap * sizeof(cvo_hip_trace)));
+        ctx->trace_dev_cap = j.trace_cap;
+    }
+    if (j.trace_cap > 0)
+        HIP_TRY(ctx, hipMemsetAsync(ctx->trace_dev, 0, (size_t)j.trace_cap * sizeof(cvo_hip_trace),
+                                    loop_stream(ctx)));
+    // initial device state
+    DevState *h = &ctx->st_host[kPollSlots];
+    std::memset(h, 0, sizeof(*h));
+    std::memcpy(h->R, s->R, sizeof(h->R));
+    std::memcpy(h->T, s->T, sizeof(h->T));
+    h->ell = s->ell;
+    h->ell_max = s->ell_max;
+    h->iter = s->iter;
+    {
+        const int rcg = fill_filter_geometry(ctx, h);
+        if (rcg) return rcg;
+    }
+    if (p.max_iter <= 0) h->done = DONE_MAX_ITER;
+    // (everything but the mailbox sequence number, which lives as long as the context)
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->st, h, DEVSTATE_INIT_BYTES, hipMemcpyHostToDevice, loop_stream(ctx)));
+    // small clouds (the ~3k-point clouds of the reference's front end): 2048 waves do
+    // (measured 3k x 3k: 2.11 ms with 512 blocks, 2.19 with 1024; 10k x 10k the other way round)
+    const bool small_pair = (double)ctx->fixed.n * (double)ctx->moving.n <= 2.5e7;
+    if (!ctx->proc_blocks_forced)
+        ctx->proc_blocks = ctx->proc_blocks_default = small_pair ? PROC_BLOCKS / 2 : PROC_BLOCKS;
+    // (use_async_self below; from ~20k x 20k on a build is too long to hide beside one flow pass)
+    // (the MATLAB weight exists as a classic k_process launch only)
+    ctx->use_async = ctx->allow_async && !ctx->crowded && !ctx->profiling && !multi_rank(ctx) &&
+                     !(ctx->prm.color_scale > 0.0f) &&
+                     (double)ctx->fixed.n * (double)ctx->moving.n <= 2.0e8;
+    ctx->use_async_self = ctx->use_async && ctx->allow_async_self && ctx->lone &&
+                          ctx->prm.mode == CVO_HIP_MODE_ACVO;
+    // acvo with everything in one launch (flow pass + both self passes + the builds = 3 x blocks + filter blocks):
+    // a quarter of the blocks per pass do (measured one registration at a time, 1024 / 512 / 256 / 128 blocks per
+    // pass: 10k x 10k 390 / 461 / 499 / - registrations/s with the post-step launch, - / 417 / 537 / 499 in head
+    // mode; 3k x 3k - / 543 / 619 / - and - / 473 / 703 / 749 -- profiles/r03_ab.txt)
+    const double npairs = (double)ctx->fixed.n * (double)ctx->moving.n;
+    if (ctx->use_async_self && !ctx->proc_blocks_forced)   // (6k x 6k: 128 / 256 blocks 750 / 700; 14k x 14k 510 / 568)
+        ctx->proc_blocks = ctx->proc_blocks_default = npairs <= 6.0e7 ? PROC_BLOCKS / 8 : PROC_BLOCKS / 4;
+    // cvo in head mode: every block of the flow launch starts with the head, and with the candidate records the
+    // pass behind it is short -- fewer, longer blocks (us per iteration with 256 / 512 / 1024 blocks per pass:
+    // 2k x 2k 18.4 / 18.9 / 20.4, 4.5k 19.3 / 19.5 / 22.3, 6k 21.4 / 20.9 / 23.0, 8k 27.2 / 24.7 / 26.6,
+    // 10k 31.6 / 26.5 / 26.7, 14k 34.8 / 28.5 / 27.6 -- profiles/r03_ab.txt 17)
+    if (!ctx->proc_blocks_forced && !ctx->use_async_self && ctx->use_async && ctx->lone && ctx->allow_head &&
+        ctx->prm.mode == CVO_HIP_MODE_CVO)
+        ctx->proc_blocks = ctx->proc_blocks_default =
+            npairs <= 2.5e7 ? PROC_BLOCKS / 4 : (npairs <= 1.5e8 ? PROC_BLOCKS / 2 : PROC_BLOCKS);
+    launch_prepare(ctx->st, loop_params(ctx), loop_stream(ctx));
+    HIP_TRY(ctx, hipGetLastError());
+    ctx->have_tf = true;
+    const int prc = prepare_buffers(ctx);
+    if (prc) return prc;
+    // (a member of a fused group is planned by the group: its slot is one of many)
+    ctx->head_mode = false;   // (set again by prepare_lone_plan if this align() runs a head-mode plan)
+    if (!j.in_group && !ctx->profiling && !host_reduce(ctx)) {
+        const int rc2 = prepare_lone_plan(ctx, j.trace_cap);
+        if (rc2) return rc2;
+    }
+    j.enq = j.batches = j.checked = 0;
+    j.executed_base = 0;
+    j.phase = p.max_iter <= 0 ? 1 : 0;
+    if (j.phase == 1) {
+        HIP_TRY(ctx, hipMemcpyAsync(&ctx->st_host[0], ctx->st, sizeof(DevState), hipMemcpyDeviceToHost,
+                                    loop_stream(ctx)));
+        HIP_TRY(ctx, hipEventRecord(ctx->poll_ev[0], loop_stream(ctx)));
+    }
+    return CVO_HIP_OK;
+}
+
+// ref src/cvo.cpp:413-415 and the trace / state hand-back
+int job_finish(AlignJob &j)
+{
+    cvo_hip_ctx *ctx = j.ctx;
+    cvo_hip_state *s = j.s;
+    const DevState &f = ctx->st_host[0];
+    ctx->have_tf = false;   // the low-level entry points need their own transform_pcd()
+    if (f.done == DONE_COMM_ERROR) {
+        // The rank that timed out has advanced its sequence number, a peer that left early or never launched
+        // has not, and a late store may still land in a slot of the same generation: from here on every
+        // exchange of this world would mismatch or time out.  The mailboxes are unusable until every rank
+        // has called cvo_hip_mailbox_create / _connect again; sharded calls are refused until then.
+        ctx->mail_broken = true;
+        return fail(ctx, CVO_HIP_ERR_COMM, "mailbox all-reduce timed out: a peer rank never delivered its partial sums "
+                                           "(the mailboxes must be created and connected again on every rank)");
+    }
+    if (f.done == RUNNING || f.done == NEED_BIGGER_LIST)
+        return fail(ctx, CVO_HIP_ERR_INVALID, "align loop ended without a verdict");
+    const int executed = f.n_exec;
+    if (j.trace_cap > 0 && executed > 0)
+        HIP_TRY(ctx, hipMemcpy(j.trace, ctx->trace_dev,
+                               (size_t)std::min(executed, j.trace_cap) * sizeof(cvo_hip_trace),
+                               hipMemcpyDeviceToHost));
+    // accumulate the transform computed at the TOP of the last executed
+    // iteration, then refresh `transform` from the final R,T
+    if (executed > 0) cvo_math::tf_to_mat4(f.used_Rt, f.used_t, s->transform);
+    std::memcpy(s->R, f.R, sizeof(s->R));
+    std::memcpy(s->T, f.T, sizeof(s->T));
+    s->ell = f.ell;
+    s->ell_max = f.ell_max;
+    s->iter = f.iter;
+    std::memcpy(s->prev_transform, s->transform, sizeof(s->transform));
+    cvo_math::mat4_mul(s->accum_transform, s->transform, s->accum_transform);
+    float Rt[9], t[3];
+    cvo_math::inverse_tf(s->R, s->T, Rt, t);
+    cvo_math::tf_to_mat4(Rt, t, s->transform);
+    if (j.n_iter) *j.n_iter = executed;
+    if (ctx->profiling) return drain_events(ctx, executed, &f);
+    return CVO_HIP_OK;
+}
+
+// Advance a job without (block = false) or with (block = true) waiting on the
+// GPU.  Returns 1 when the job has finished (j.rc holds its status), else 0.
+// At most two batches are in flight; `done` is looked at one batch behind; a
+// list that overflows parks the loop with NEED_BIGGER_LIST before any state was
+// changed: enlarge it and resume from the same iteration.
+int job_pump(AlignJob &j, bool block)
+{
+    cvo_hip_ctx *ctx = j.ctx;
+    if (j.phase == 2) return 1;
+    auto finish_with = [&](int rc) { j.rc = rc; j.phase = 2; return 1; };
+    if (hipSetDevice(ctx->device) != hipSuccess) return finish_with(CVO_HIP_ERR_HIP);
+    // Blocking caller, launches that need no host work in between: PACED mode.  The post-step
+    // kernel mirrors its slot count and `done` into pinned memory; this thread watches the two
+    // words and enqueues the next batch when the running one has finished -- not a whole batch
+    // ahead, which left a registration that converged with (on average) a batch and a half of
+    // queued launches to return one by one (~85 us of 1.7 ms, and the next frame's hand-over
+    // queues behind them).  The ~10 us the stream idles between two batches cost less than that
+    // (CVO_HIP_PACE_LEAD = slots of overlap, 0 / 1 / 2 / 3: 644 / 619 / 627 / 620 registrations/s at
+    // 10k x 10k, event-paced two batches ahead: 604).
+    if (j.phase == 0 && block && j.paced && !host_reduce(ctx) && !ctx->profiling) {
+        const int limit = (ctx->use_async ? 3 : 1) * ctx->prm.max_iter + 4 * kBatch;
+        unsigned spins = 0;
+        int idle_seen = 0;
+        for (;;) {
+            if (*(volatile int32_t *)ctx->done_mirror != RUNNING) break;
+            const int slots = *(volatile int32_t *)ctx->progress_mirror;
+            // (head mode without a flush: the post-step part of a batch's last slot runs in the head of the NEXT
+            // batch's first launch, so the next batch must be on its way before the running one ends -- it goes
+            // out when the running batch is down to its last slots; the GPU never idles between batches, and
+            // a registration that stops in those last slots leaves one batch of launches that return at once)
+            const int lead = ctx->head_mode ? 2 : 0;
+            if (j.enq - slots <= lead) {
+                if (j.enq >= limit) break;   // cannot happen
+                const int rc = launch_batch(ctx, j.executed_base + j.enq, j.trace_cap);
+                if (rc) return finish_with(rc);
+                j.enq += kBatch;
+                ++j.batches;
+                spins = 0;
+                idle_seen = 0;
+            } else {
+                __builtin_ia32_pause();
+                // The two words only move while the queued kernels run.  A fault, a stream in an error state or a
+                // post kernel that never ran would leave this thread spinning for ever: now and then ask the
+                // stream itself (a batch lasts ~0.25 ms; 2^14 pauses are about that long).
+                if ((++spins & 0x3fffu) == 0u) {
+                    const hipError_t q = hipStreamQuery(loop_stream(ctx));
+                    if (q != hipSuccess && q != hipErrorNotReady)
+                        return finish_with(fail(ctx, CVO_HIP_ERR_HIP, "the stream of the align loop reports an error"));
+                    // idle, yet the batch has not reported all its slots and nothing stopped: seen twice in a row
+                    // (the mirrors are written before a kernel ends, so once is already conclusive; twice is cheap)
+                    if (q == hipSuccess && *(volatile int32_t *)ctx->done_mirror == RUNNING &&
+                        *(volatile int32_t *)ctx->progress_mirror == slots) {
+                        if (++idle_seen >= 2)
+                            return finish_with(fail(ctx, CVO_HIP_ERR_HIP, "the align loop's stream went idle without progress"));
+                    } else {
+                        idle_seen = 0;
+                    }
+                }
+            }
+        }
+        if (hipMemcpyAsync(&ctx->st_host[0], ctx->st, sizeof(DevState), hipMemcpyDeviceToHost,
+                           ctx->stream) != hipSuccess ||
+            hipEventRecord(ctx->poll_ev[0], ctx->stream) != hipSuccess)
+            return finish_with(fail(ctx, CVO_HIP_ERR_HIP, "state copy failed"));
+        j.phase = 1;
+    }
+    if (j.phase == 0) {
+        bool stop = false;
+        while (j.batches - j.checked < 2) {   // keep two batches queued
+            int rc = launch_batch(ctx, j.executed_base + j.enq, j.trace_cap);
+            if (rc) return finish_with(rc);
+            j.enq += kBatch;
+            const int slot = j.batches % kPollSlots;
+            // Single rank: the post kernels mirror `done` into pinned memory, an event
+            // per batch is all the polling needs.  With ranks to stay in step with, the
+            // state is copied in stream order instead: every rank must see `done` at the
+            // same batch, or their all-reduce counts would differ.
+            if (host_reduce(ctx) &&
+                hipMemcpyAsync(&ctx->st_host[slot], ctx->st, DEVSTATE_HEAD_BYTES, hipMemcpyDeviceToHost,
+                               ctx->stream) != hipSuccess)
+                return finish_with(fail(ctx, CVO_HIP_ERR_HIP, "poll copy failed"));
+            if (hipEventRecord(ctx->poll_ev[slot], ctx->stream) != hipSuccess)
+                return finish_with(fail(ctx, CVO_HIP_ERR_HIP, "poll event failed"));
+            ++j.batches;
+        }
+        // look at the oldest batch not yet examined
+        const int slot = j.checked % kPollSlots;
+        hipError_t q = block ? hipEventSynchronize(ctx->poll_ev[slot]) : hipEventQuery(ctx->poll_ev[slot]);
+        if (q == hipErrorNotReady) return 0;
+        if (q != hipSuccess) return finish_with(fail(ctx, CVO_HIP_ERR_HIP, "poll event failed"));
+        ++j.checked;
+        // (mailboxes: a rank that sees `done` one batch after its peers only queues kernels that
+        // return at their first load -- no exchange is left half done)
+        if (host_reduce(ctx) ? ctx->st_host[slot].done != RUNNING
+                             : *(volatile int32_t *)ctx->done_mirror != RUNNING)
+            stop = true;
+        // (slots, not iterations: asynchronous builds add a stall slot now and then)
+        if (j.enq >= (ctx->use_async ? 3 : 1) * ctx->prm.max_iter + 4 * kBatch) stop = true;   // cannot happen
+        if (!stop) return 0;
+        // everything still queued either runs or returns at once; fetch the full state
+        if (hipMemcpyAsync(&ctx->st_host[0], ctx->st, sizeof(DevState), hipMemcpyDeviceToHost,
+                           ctx->stream) != hipSuccess ||
+            hipEventRecord(ctx->poll_ev[0], ctx->stream) != hipSuccess)
+            return finish_with(fail(ctx, CVO_HIP_ERR_HIP, "state copy failed"));
+        j.phase = 1;
+    }
+    // phase 1: wait for the final state
+    hipError_t q = block ? hipEventSynchronize(ctx->poll_ev[0]) : hipEventQuery(ctx->poll_ev[0]);
+    if (q == hipErrorNotReady) return 0;
+    if (q != hipSuccess) return finish_with(fail(ctx, CVO_HIP_ERR_HIP, "state event failed"));
+    const DevState &cur = ctx->st_host[0];
+    if (cur.done != NEED_BIGGER_LIST) return finish_with(job_finish(j));
+    // grow the overflowed list(s) and resume from the parked iteration
+    int rc = CVO_HIP_OK;
+    if (ctx->profiling) rc = drain_events(ctx, cur.k + 1, &cur);
+    j.executed_base = cur.k;
+    for (int l = 0; l < LIST_N && !rc; ++l)
+        if (cur.ovf[0][l] | cur.ovf[1][l]) {
+            uint32_t worst = 0;   // appends are spread evenly: scale by the fullest sub-list
+            for (int qq = 0; qq < NSUB; ++qq) worst = std::max(worst, cur.sub[l][qq]);
+            const double grown =
+                std::min(4.0e9, std::max((double)worst * NSUB, (double)ctx->lists[l].cap) * 1.5 + 1024.0);
+            rc = ensure_list(ctx, l, 0, 0, grown);
+        }
+    for (int q = 0; q < 3 && !rc; ++q) {   // the two buffers of a list share one capacity
+        const int la = q == 0 ? LIST_XY : (q == 1 ? LIST_XX : LIST_YY), lb = q == 0 ? LIST_XYB : (q == 1 ? LIST_XXB : LIST_YYB);
+        if (!ctx->lists[la].cap && !ctx->lists[lb].cap) continue;
+        const double both = (double)std::max(ctx->lists[la].cap, ctx->lists[lb].cap);
+        rc = ensure_list(ctx, la, 0, 0, both);
+        if (!rc && ctx->lists[lb].cap) rc = ensure_list(ctx, lb, 0, 0, both);
+    }
+    if (rc) return finish_with(rc);
+    int32_t zero = 0;
+    if (hipMemcpyAsync(reinterpret_cast<char *>(ctx->st) + offsetof(DevState, done), &zero, sizeof(zero),
+                       hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+        hipStreamSynchronize(ctx->stream) != hipSuccess)
+        return finish_with(fail(ctx, CVO_HIP_ERR_HIP, "resume failed"));
+    *ctx->done_mirror = 0;   // (the stream is idle: nothing can be writing it)
+    *ctx->progress_mirror = 0;
+    if (hipMemset(reinterpret_cast<char *>(ctx->st) + offsetof(DevState, n_slots), 0, sizeof(int32_t)) != hipSuccess ||
+        hipDeviceSynchronize() != hipSuccess)
+        return finish_with(fail(ctx, CVO_HIP_ERR_HIP, "resume failed"));
+    launch_prepare(ctx->st, loop_params(ctx), ctx->stream);   // idempotent; re-zeroes the counters
+    if (hipGetLastError() != hipSuccess) return finish_with(fail(ctx, CVO_HIP_ERR_HIP, "resume failed"));
+    if (!ctx->profiling && !host_reduce(ctx)) {   // the lists moved: new arguments
+        rc = prepare_lone_plan(ctx, j.trace_cap);
+        if (rc) return finish_with(rc);
+    }
+    j.enq = j.batches = j.checked = 0;
+    j.phase = 0;
+    return 0;
+}
+
+
+}   // namespace cvo_impl
+
+extern "C" {
+
+int cvo_hip_align(cvo_hip_ctx *ctx, cvo_hip_state *s, cvo_hip_trace *trace, int trace_cap,
+                  int *n_iter)
+{
+    cvo_lock::Api api_guard;
+    if (!ctx || !s) return CVO_HIP_ERR_INVALID;
+    AlignJob j;
+    j.ctx = ctx; j.s = s; j.trace = trace; j.trace_cap = trace_cap; j.n_iter = n_iter;
+    j.paced = true;
+    int rc = job_begin(j);
+    if (rc) return rc;
+    while (!job_pump(j, true)) {}
+    return j.rc;
+}
+
+
+}   // extern "C"
