@@ -89,6 +89,9 @@ int cloud_reserve(cvo_hip_ctx *ctx, Cloud &c, const float *xyz, const float *fea
     }
     if (!c.bbox_pin) {
         HIP_TRY(ctx, hipHostMalloc((void **)&c.bbox_pin, 6 * sizeof(float), hipHostMallocDefault));
+        void *bbox_d = nullptr;
+        HIP_TRY(ctx, hipHostGetDevicePointer(&bbox_d, c.bbox_pin, 0));
+        c.bbox_pin_dev = (float *)bbox_d;
         HIP_TRY(ctx, hipEventCreateWithFlags(&c.ready_ev, hipEventDisableTiming));
     }
     return CVO_HIP_OK;
@@ -140,9 +143,7 @@ int upload_cloud(cvo_hip_ctx *ctx, Cloud &c, const float *xyz, const float *feat
         jb.xyz = d_xyz; jb.feat = d_feat; jb.n = n; jb.colmajor = layout == CVO_HIP_FEAT_COLMAJOR ? 1 : 0;
         jb.np = np; jb.pad_axis = c.pad_axis;
         jb.pos = c.pos; jb.feat8 = c.feat; jb.seg = c.seg;
-        void *bbox_d = nullptr;
-        HIP_TRY(ctx, hipHostGetDevicePointer(&bbox_d, c.bbox_pin, 0));
-        jb.bbox_out = (float *)bbox_d;
+        jb.bbox_out = c.bbox_pin_dev;
         HIP_TRY(ctx, cloud_prepare_one(jb, ctx->stream));
         HIP_TRY(ctx, hipEventRecord(c.ready_ev, ctx->stream));
         c.wait_ev = nullptr;
@@ -264,8 +265,11 @@ int cvo_hip_set_pcd_many(cvo_hip_ctx *const *ctxs, const float *const *fixed_xyz
     if (count < 0 || (count > 0 && (!ctxs || !moving_xyz || !moving_feat || !n_moving))) return CVO_HIP_ERR_INVALID;
     if (count == 0) return CVO_HIP_OK;
     if (fixed_xyz && (!fixed_feat || !n_fixed)) return CVO_HIP_ERR_INVALID;
-    for (int k = 0; k < count; ++k)
+    for (int k = 0; k < count; ++k) {
         if (!ctxs[k] || ctxs[k]->device != ctxs[0]->device) return CVO_HIP_ERR_INVALID;
+        for (int q = 0; q < k; ++q)
+            if (ctxs[q] == ctxs[k]) return CVO_HIP_ERR_INVALID;   // (two clouds of a batch would land in the same device arrays)
+    }
     cvo_hip_ctx *c0 = ctxs[0];
     HIP_TRY(c0, hipSetDevice(c0->device));
     Handover *ho = handover_of(c0->device);
@@ -335,9 +339,7 @@ int cvo_hip_set_pcd_many(cvo_hip_ctx *const *ctxs, const float *const *fixed_xyz
         jb.n = it.n; jb.colmajor = feat_layout == CVO_HIP_FEAT_COLMAJOR ? 1 : 0;
         jb.np = it.c->np; jb.pad_axis = it.c->pad_axis;
         jb.pos = it.c->pos; jb.feat8 = it.c->feat; jb.seg = it.c->seg;
-        void *bbox_d = nullptr;
-        HIP_TRY(it.ctx, hipHostGetDevicePointer(&bbox_d, it.c->bbox_pin, 0));
-        jb.bbox_out = (float *)bbox_d;
+        jb.bbox_out = it.c->bbox_pin_dev;
         ho->jobs_pin[q] = jb;
     }
     HIP_TRY(c0, hipMemcpyAsync(ho->jobs_dev, ho->jobs_pin, small.size() * sizeof(CloudJob), hipMemcpyHostToDevice, ho->s));

@@ -54,6 +54,7 @@ struct Cloud {
     void *stage = nullptr;
     size_t stage_bytes = 0;
     float *bbox_pin = nullptr;        // [6] pinned
+    float *bbox_pin_dev = nullptr;    // ... as the device addresses it (the one-launch preparation writes the box there)
     hipEvent_t ready_ev = nullptr;
     hipEvent_t wait_ev = nullptr;     // what `pending` waits for: ready_ev, or the event of a batched hand-over (borrowed)
     bool pending = false;

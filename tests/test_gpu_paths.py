@@ -1024,5 +1024,8 @@ def test_batched_hand_over_then_align_many(pkg):
         states = [capi.init_state(c.params) for c in cs]
         its = capi.align_many(cs, states)
         assert [(i, bytes(s)) for i, s in zip(its, states)] == ref
+    # one context twice in a batch: two clouds would land in the same device arrays -- refused
+    with pytest.raises(capi.CvoHipError):
+        capi.set_pcd_many([cs[0], cs[0]], [(pairs[0][0], pairs[0][1])] * 2, [(pairs[0][2], pairs[0][3])] * 2)
     for c in cs:
         c.close()
