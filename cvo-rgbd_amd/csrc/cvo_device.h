@@ -293,7 +293,7 @@ struct ProcessArgs {
     uint32_t *cand_cnt;    // [PROC_WAVES] candidates recorded by each wave
     uint2 *cand_b;         // head mode (double-buffered xy list): the record of the second buffer (8-byte form only) ...
     uint32_t *cand_cnt_b;  // ... DevHead::xy_ck[b] says whether buffer b's record matches its tile list
-    int need_d2;           // PROC_FLOW: accumulate sum (1/l^3 a) d2 (acvo's dl term; cvo_hip_flow reports it for both modes)
+    int need_d2;           // PROC_FLOW: accumulate sum a (trace records, cvo_hip_flow) and sum (1/l^3 a) d2 (acvo's dl term; cvo_hip_flow reports it for both modes)
     int kept_packed;       // 1: both clouds have <= 65536 rows: a kept entry is 8 bytes (i | j << 16, weight bits)
                            // in kept_ij alone instead of 8 + 4 -- the kept list is the largest HBM stream of a
                            // batched run (written by every flow pass, read back by the step pass).
@@ -696,7 +696,7 @@ constexpr int STEP_TWIST_ROWS_DIV = 4;   // k_step_twist writes nblk / 4 partial
 enum TKernel { TK_FILTER = 0, TK_FILTER_GROUP, TK_FLOW, TK_FLOW_MATLAB, TK_STEP, TK_SELF, TK_SELF2, TK_STEP_TWIST,
                TK_FLOW_BUILD, TK_FLOW_BUILD3, TK_FLOW_BUILD6, TK_POST_FLOW, TK_POST_STEP,
                TK_HFLOW_BUILD, TK_HFLOW_BUILD6, TK_HSTEP_TWIST,
-               TK_FLOW_D2 /* TK_FLOW is built without the sum of a d2 (ProcessArgs::need_d2 == 0 in every slot); this one has it */ };   // head mode (cvo_kernels.hip "Head mode")
+               TK_FLOW_D2 /* TK_FLOW is built without the sums of a and of a d2 (ProcessArgs::need_d2 == 0 in every slot); this one has them */ };   // head mode (cvo_kernels.hip "Head mode")
 // Head-mode launches carry the slot's parity and the mode in the bits above the op index of their
 // second kernel argument: qp = q | parity << 8 | QP_HEAD.
 constexpr int QP_PARITY = 1 << 8, QP_HEAD = 1 << 9, QP_MASK = 0xff;

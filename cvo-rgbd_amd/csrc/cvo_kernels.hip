@@ -633,6 +633,19 @@ __device__ __forceinline__ double div6(double x)
     return __builtin_fma(r, c, q0);
 }
 
+// the streamed lists (candidate record, kept list) are read once per pass: CVO_NT_LISTS (A/B builds) marks those loads
+// non-temporal, so that they leave the L2 to the gathered clouds
+__device__ __forceinline__ uint2 list_load(const uint2 *p)
+{
+#ifdef CVO_NT_LISTS
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    const u32x2 v = __builtin_nontemporal_load(reinterpret_cast<const u32x2 *>(p));
+    return make_uint2(v.x, v.y);
+#else
+    return *p;
+#endif
+}
+
 // a 16-byte gather at a 32-bit byte offset from a wave-uniform base (clouds of < 2^27 points): the
 // address is scalar base + vector offset, one shift per gather instead of 64-bit address arithmetic
 __device__ __forceinline__ const float4 *gather16(const void *base, unsigned byte_off)
@@ -762,8 +775,17 @@ __device__ __forceinline__ float eval_pair(const ProcessArgs &a, const ProcHead 
         acc[3] += (double)(ad * f0);
         acc[4] += (double)(ad * f1);
         acc[5] += (double)(ad * f2);
+        // (the sum of the weights goes into trace records and cvo_hip_flow's answer, the sum of a d2 is acvo's dl term:
+        // neither is read inside a cvo loop that keeps no trace -- ProcessArgs::need_d2)
+#ifdef CVO_SUM_A_ALWAYS   // (A/B builds: profiles/r04_ab.txt 12)
         acc[6] += (double)w;
-        if (hd.need_d2) acc[7] += (double)((kc.inv_l3 * w) * d2);   // (the acvo dl term: nobody reads it inside a cvo loop)
+        if (hd.need_d2) acc[7] += (double)((kc.inv_l3 * w) * d2);
+#else
+        if (hd.need_d2) {
+            acc[6] += (double)w;
+            acc[7] += (double)((kc.inv_l3 * w) * d2);
+        }
+#endif
         // (acc[8], the number of members: counted per wave by the caller, not per pair here)
     } else if (MODE == PROC_STEP) {
         // Taylor vectors of y_j (ref cvo.cpp:226-238), for members of A only
@@ -793,10 +815,29 @@ __device__ __forceinline__ float eval_pair(const ProcessArgs &a, const ProcHead 
         const double A = (double)w;
         const double b = (double)beta, g = (double)gamma;
         acc[0] += (double)(w * beta);
+#ifdef CVO_STEP_TAIL_LITERAL
+        // the source line's operations one by one (ref cvo.cpp:275-280 under C's promotion rules): 33 float64-rate
+        // instructions per member; kept for A/B builds (profiles/r04_ab.txt 11)
         acc[1] += A * (g + (double)(beta * beta) / 2.0);
         acc[2] += A * ((double)(delta + beta * gamma) + div6((double)(beta * beta * beta)));
         acc[3] += A * ((((double)(epsil + beta * delta) + 0.5 * b * b * g) + 0.5 * g * g) +
                        1 / 24.0 * b * b * b * b);
+#else
+        // The float64 part of the terms with fused operations: every float32 product of the source line is formed
+        // and promoted as written (beta*beta, beta*beta*beta, delta + beta*gamma, epsil + beta*delta); what is
+        // fused are float64 operations whose separate roundings the reference's own sum order already outweighs
+        // (a term moves by <= 3 ulp(float64), the sum of ~10^5..10^6 of them is order-dependent at 10^-13).
+        // 20 float64-rate instructions per member instead of 33: the step pass is issue-bound while the kernel is
+        // wide (profiles/r04_ab.txt 8, 11).
+        acc[1] = __builtin_fma(A, __builtin_fma((double)(beta * beta), 0.5, g), acc[1]);
+        acc[2] = __builtin_fma(A, __builtin_fma((double)(beta * beta * beta), 0x1.5555555555555p-3,
+                                                (double)(delta + beta * gamma)), acc[2]);
+        const double b2 = b * b, hg = 0.5 * g;
+        double t = __builtin_fma(b2, hg, (double)(epsil + beta * delta));
+        t = __builtin_fma(hg, g, t);
+        t = __builtin_fma(b2 * (1 / 24.0), b2, t);
+        acc[3] = __builtin_fma(A, t, acc[3]);
+#endif
     } else {
         if (CK == 2 ? row_index >= 0 : row_index >= first_counted) acc[0] += (double)((kc.inv_l3 * w) * d2);
         // (acc[1], the number of members: counted per wave by the caller)
@@ -939,12 +980,12 @@ __device__ __forceinline__ bool stream_candidates(const ProcessArgs &a, const Pr
 {
     const size_t base = (size_t)wave * a.kept_wcap;
     unsigned n = hd.cand_cnt[wave];
-    uint2 e = hd.cand[base + lane];
+    uint2 e = list_load(&hd.cand[base + lane]);
     if (done_word != 0) return false;
     if (n > a.kept_wcap) n = a.kept_wcap;
     unsigned nk = 0;
     for (unsigned b0 = 0; b0 < n; b0 += 64u) {
-        if (b0 != 0u) e = hd.cand[base + min(b0 + (unsigned)lane, a.kept_wcap - 1u)];
+        if (b0 != 0u) e = list_load(&hd.cand[base + min(b0 + (unsigned)lane, a.kept_wcap - 1u)]);
         const unsigned ci = e.x & 0xffffu, cj = e.x >> 16;
         float w = 0.0f;
         if (b0 + (unsigned)lane < n) {
@@ -956,7 +997,15 @@ __device__ __forceinline__ bool stream_candidates(const ProcessArgs &a, const Pr
             const unsigned below = __builtin_amdgcn_mbcnt_hi((unsigned)(km >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)km, 0u));
             // (candidate records exist for clouds of up to 65536 rows only, whose kept entries are packed the same
             // way: the record's first word IS the entry's)
+#ifdef CVO_NT_KEPT_ST   // (A/B builds)
+            {
+                typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+                u32x2 v; v.x = e.x; v.y = __float_as_uint(w);
+                __builtin_nontemporal_store(v, reinterpret_cast<u32x2 *>(&a.kept_ij[base + nk + below]));
+            }
+#else
             a.kept_ij[base + nk + below] = make_uint2(e.x, __float_as_uint(w));
+#endif
         }
         nk += (unsigned)__popcll(km);
     }
@@ -1002,13 +1051,13 @@ __device__ __forceinline__ void process_body(const ProcessArgs &a, const unsigne
         unsigned n = a.kept_cnt[wave];
         // the first entries are fetched together with the count
         const int packed = a.kept_packed;
-        uint2 e = a.kept_ij[base + lane];
+        uint2 e = list_load(&a.kept_ij[base + lane]);
         float w = packed ? 0.0f : a.kept_a[base + lane];
         if (done_word != 0) return;
         if (n > a.kept_wcap) n = a.kept_wcap;
         if (list_bad) n = 0;
         for (unsigned off = lane; off < n; off += 64) {
-            if (off >= 64) { e = a.kept_ij[base + off]; if (!packed) w = a.kept_a[base + off]; }
+            if (off >= 64) { e = list_load(&a.kept_ij[base + off]); if (!packed) w = a.kept_a[base + off]; }
             unsigned mi, mj;
             float mw;
             kept_unpack(packed, a.kept_ebase, e, w, mi, mj, mw);

@@ -256,7 +256,7 @@ int enqueue_process(cvo_hip_ctx *ctx, int mode, int list, DevBuf &part, const fl
         if (tf_a && pos_a == ctx->moving.pos) { a.pos_a = (const float4 *)ctx->pos_bt.p; a.tf_a = 0; }   // acvo: the yy pass
     }
     a.check_done = check_done;
-    a.need_d2 = (ctx->prm.mode == CVO_HIP_MODE_ACVO || !ctx->in_loop) ? 1 : 0;
+    a.need_d2 = (ctx->prm.mode == CVO_HIP_MODE_ACVO || !ctx->in_loop || ctx->cur_trace_cap > 0) ? 1 : 0;   // (a trace record holds the sum of the weights)
     a.weight = ctx->prm.color_scale > 0.0f ? 1 : 0;   // the MATLAB object's weight: its own instantiation
     const bool no_pack = getenv("CVO_HIP_NO_PACK") != nullptr;   // (test switch, read when a plan is recorded: 8 + 4 byte kept entries)
     a.kept_packed = (!no_pack && ctx->fixed.np <= 65536 && ctx->moving.np <= 65536) ? 1 : 0;

@@ -85,6 +85,47 @@ __global__ void __launch_bounds__(256) bench(long long *cyc, float *sink, int it
                               "v_pk_add_f32 %2, %4, %5 neg_lo:[0,1] neg_hi:[0,1]\n v_pk_mul_f32 %3, %0, %0\n"
                               "v_pk_fma_f32 %3, %1, %1, %3\n v_pk_fma_f32 %3, %2, %2, %3\n"
                               : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3) : "v"(q), "v"(q));)
+        } else if (KIND == 13) {   // v_add_f64
+            double d0 = r0, d1 = r1, d2 = r2, d3 = r3, db = 1.0000001;
+            REP8(asm volatile("v_add_f64 %0, %0, %4\n v_add_f64 %1, %1, %4\n v_add_f64 %2, %2, %4\n v_add_f64 %3, %3, %4\n"
+                              "v_add_f64 %0, %0, %4\n v_add_f64 %1, %1, %4\n v_add_f64 %2, %2, %4\n v_add_f64 %3, %3, %4\n"
+                              : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3) : "v"(db));)
+            r0 = (float)(d0 + d1 + d2 + d3);
+        } else if (KIND == 14) {   // v_mul_f64
+            double d0 = r0, d1 = r1, d2 = r2, d3 = r3, db = 1.0000001;
+            REP8(asm volatile("v_mul_f64 %0, %0, %4\n v_mul_f64 %1, %1, %4\n v_mul_f64 %2, %2, %4\n v_mul_f64 %3, %3, %4\n"
+                              "v_mul_f64 %0, %0, %4\n v_mul_f64 %1, %1, %4\n v_mul_f64 %2, %2, %4\n v_mul_f64 %3, %3, %4\n"
+                              : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3) : "v"(db));)
+            r0 = (float)(d0 + d1 + d2 + d3);
+        } else if (KIND == 15) {   // v_cvt_f64_f32
+            double d0 = 0, d1 = 0, d2 = 0, d3 = 0;
+            REP8(asm volatile("v_cvt_f64_f32 %0, %4\n v_cvt_f64_f32 %1, %5\n v_cvt_f64_f32 %2, %6\n v_cvt_f64_f32 %3, %7\n"
+                              "v_cvt_f64_f32 %0, %5\n v_cvt_f64_f32 %1, %6\n v_cvt_f64_f32 %2, %7\n v_cvt_f64_f32 %3, %4\n"
+                              : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3) : "v"(r4), "v"(r5), "v"(r6), "v"(r7));)
+            r0 = (float)(d0 + d1 + d2 + d3);
+        } else if (KIND == 16) {   // v_cvt_f32_f64
+            double d0 = r0, d1 = r1, d2 = r2, d3 = r3;
+            REP8(asm volatile("v_cvt_f32_f64 %0, %4\n v_cvt_f32_f64 %1, %5\n v_cvt_f32_f64 %2, %6\n v_cvt_f32_f64 %3, %7\n"
+                              "v_cvt_f32_f64 %0, %5\n v_cvt_f32_f64 %1, %6\n v_cvt_f32_f64 %2, %7\n v_cvt_f32_f64 %3, %4\n"
+                              : "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7) : "v"(d0), "v"(d1), "v"(d2), "v"(d3));)
+        } else if (KIND == 17) {   // 4 v_fma_f32 + 4 v_fma_f64 interleaved (do the two kinds share issue time?)
+            double d0 = r0, d1 = r1, d2 = r2, d3 = r3, db = 1.0000001, dc = 0.25;
+            REP8(asm volatile("v_fma_f64 %0, %0, %8, %9\n v_fma_f32 %4, %4, %10, %11\n v_fma_f64 %1, %1, %8, %9\n v_fma_f32 %5, %5, %10, %11\n"
+                              "v_fma_f64 %2, %2, %8, %9\n v_fma_f32 %6, %6, %10, %11\n v_fma_f64 %3, %3, %8, %9\n v_fma_f32 %7, %7, %10, %11\n"
+                              : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3), "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7) : "v"(db), "v"(dc), "v"(b), "v"(c));)
+            r0 = (float)(d0 + d1 + d2 + d3);
+        } else if (KIND == 18) {   // v_ldexp_f64 / v_rndne_f64 / v_cvt_i32_f64 mix of the exp (3 of each kind... 8 per group)
+            double d0 = r0, d1 = r1, d2 = r2, d3 = r3; int e0 = 1, e1 = 2;
+            REP8(asm volatile("v_rndne_f64 %0, %0\n v_rndne_f64 %1, %1\n v_ldexp_f64 %2, %2, %6\n v_ldexp_f64 %3, %3, %6\n"
+                              "v_cvt_i32_f64 %4, %0\n v_cvt_i32_f64 %5, %1\n v_ldexp_f64 %2, %2, %6\n v_rndne_f64 %3, %3\n"
+                              : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3), "+v"(e0), "+v"(e1) : "v"(0));)
+            r0 = (float)(d0 + d1 + d2 + d3) + e0 + e1;
+        } else if (KIND == 19) {   // v_mbcnt_lo + v_mbcnt_hi + v_lshlrev + v_and (integer ops of the list bookkeeping)
+            int e0 = threadIdx.x, e1 = 2, e2 = 3, e3 = 4;
+            REP8(asm volatile("v_mbcnt_lo_u32_b32 %0, %4, %0\n v_mbcnt_hi_u32_b32 %1, %4, %1\n v_lshlrev_b32 %2, 3, %2\n v_and_b32 %3, 63, %3\n"
+                              "v_mbcnt_lo_u32_b32 %0, %4, %0\n v_mbcnt_hi_u32_b32 %1, %4, %1\n v_lshl_add_u32 %2, %2, 3, %3\n v_and_or_b32 %3, %3, %4, %0\n"
+                              : "+v"(e0), "+v"(e1), "+v"(e2), "+v"(e3) : "v"(0x55aa55aa));)
+            r0 = (float)(e0 + e1 + e2 + e3);
         }
     }
     long long t1 = __builtin_readcyclecounter();
@@ -139,6 +180,13 @@ int main()
         run<10>("ds_read_b128 broadcast x8 + wait", 8, bpc, 256);
         run<11>("v_fma_f64", 64, bpc, 256);
         run<12>("pk pair test (6 pk inst / 2 pairs)", 48, bpc, 256);
+        run<13>("v_add_f64", 64, bpc, 256);
+        run<14>("v_mul_f64", 64, bpc, 256);
+        run<15>("v_cvt_f64_f32", 64, bpc, 256);
+        run<16>("v_cvt_f32_f64", 64, bpc, 256);
+        run<17>("4 v_fma_f64 + 4 v_fma_f32 interleaved", 64, bpc, 256);
+        run<18>("rndne/ldexp/cvt_i32 f64 mix", 64, bpc, 256);
+        run<19>("mbcnt/lshl/and integer mix", 64, bpc, 256);
     }
     return 0;
 }
