@@ -139,6 +139,7 @@ __device__ __forceinline__ void pretransform_body(const FilterArgs &a, const uns
 
 // hd: the copy of the state's head this launch starts from (a.st unless head mode); par: the launch's parity
 // (which row of DevState::ovf an overflow is flagged in; 0 unless head mode)
+template <bool PIPE = true>   // (false: the merged launches of one registration on its own, at the scalar-register ceiling)
 __device__ __forceinline__ void filter_body(const FilterArgs &a, const unsigned bid, const unsigned nblocks,
                                             const DevState *__restrict__ hd, const int par)
 {
@@ -239,7 +240,13 @@ __device__ __forceinline__ void filter_body(const FilterArgs &a, const unsigned 
     const int j0 = bx * a.jt;
     const int jn = min(a.jt, a.nb - j0);
     const int ngroups = (jn + 15) >> 4;
-    const unsigned mynear = nearmask[k * 4 + wid];
+#ifdef CVO_FILTER_NO_PF   // (A/B builds)
+    constexpr bool PF = false;
+#else
+    constexpr bool PF = PIPE;
+#endif
+    // (PF: wave-uniform, so that the loop over the column groups runs on scalar branches)
+    const unsigned mynear = PF ? (unsigned)__builtin_amdgcn_readfirstlane((int)nearmask[k * 4 + wid]) : nearmask[k * 4 + wid];
 
     // ---- prologue.  Every global load is issued before anything waits on one
     // (clamped addresses instead of control flow), so the block pays ONE memory
@@ -307,9 +314,32 @@ __device__ __forceinline__ void filter_body(const FilterArgs &a, const unsigned 
 #ifdef CVO_FILTER_PROBE
     const long long t_loop = a.dbg ? (long long)__builtin_readcyclecounter() : 0;
 #endif
-    for (int g = 0; g < ngroups; ++g) {
-        if ((g & 3) == 0 && ((mynear >> (g >> 2)) & 1u) == 0u) { g += 3; continue; }   // culled segment
-        const float b = bop[g * 64 + lane];
+    // The loop over the groups of 16 columns, software-pipelined by hand: the next LIVE group (culled segments of 64
+    // columns are skipped on scalar registers) is known one step ahead and its B operands are requested before this
+    // group's matrix instructions go out -- exactly one LDS read in flight per step, so the wait in front of the
+    // matrix instructions covers the operand of THIS step only.  (An LDS round trip per group was what a wave with
+    // one or two neighbours on its SIMD waited for most.)
+    auto next_live = [&](int g) {   // first group >= g whose segment is not culled (ngroups: none)
+        while (g < ngroups && (g & 3) == 0 && ((mynear >> (g >> 2)) & 1u) == 0u) g += 4;
+        return g;
+    };
+    int g = PF ? next_live(0) : 0;
+    float b_cur = PF ? bop[min(g, ngroups - 1) * 64 + lane] : 0.0f;
+    while (g < ngroups) {
+        float b;
+        int g_this;
+        if (PF) {
+            const int gn = next_live(g + 1);
+            b = b_cur;
+            b_cur = bop[min(gn, ngroups - 1) * 64 + lane];
+            g_this = g;
+            g = gn;
+        } else {
+            if ((g & 3) == 0 && ((mynear >> (g >> 2)) & 1u) == 0u) { g += 4; continue; }   // culled segment
+            b = bop[g * 64 + lane];
+            g_this = g;
+            ++g;
+        }
         f32x4 d[TILES_PER_WAVE];
 #pragma unroll
         for (int t = 0; t < TILES_PER_WAVE; ++t)
@@ -338,7 +368,7 @@ __device__ __forceinline__ void filter_body(const FilterArgs &a, const unsigned 
         if (has) {
             const unsigned below = __builtin_amdgcn_mbcnt_lo((unsigned)nz, 0u);
             stage[ne + below] = make_uint4(rbase + (unsigned)(lane >> 2) * 16u,
-                                           (unsigned)(j0 + g * 16) | ((unsigned)(lane & 3) << 30),
+                                           (unsigned)(j0 + g_this * 16) | ((unsigned)(lane & 3) << 30),
                                            mlo, mhi);
         }
         ne += __popcll(nz);
@@ -722,17 +752,122 @@ __device__ __forceinline__ void kept_unpack(const int mode, const unsigned ebase
 // (0 = not in A).  PROC_STEP: `w` is the recorded weight of a member of A.
 // CK (PROC_FLOW, WEIGHT 0): 0 as the reference writes it; 1 also hands the pair's colour weight out
 // through *ck_io (computed for every pair, inside tau or not); 2 takes it from *ck_io, no features read.
-template <int MODE, int WEIGHT = 0, int CK = 0>
-__device__ __forceinline__ float eval_pair(const ProcessArgs &a, const ProcHead &hd, const KernConsts &kc, unsigned i,
+// What eval_pair reads of a launch's arguments.  The list passes hand it a copy whose members are pinned in scalar
+// registers (pin_pair_src): read through the argument table, the compiler re-issues the scalar loads of the two cloud
+// addresses and the transform switches in EVERY round of a streaming loop -- cheap instructions, but each a round trip
+// through the scalar cache that the round's gathers wait for.
+// (A pointer that went through the pin is an opaque value to the compiler: without the explicit global address
+// space its loads would become flat ones.)
+#define CVO_GLOBAL __attribute__((address_space(1)))
+typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+struct PairSrc {
+    const CVO_GLOBAL char *pos_a; const float *feat_a;
+    const CVO_GLOBAL char *pos_b; const float *feat_b;
+    int tf_a, tf_b;
+};
+#ifdef CVO_NO_PIN   // (A/B builds)
+constexpr bool kPinBuild = false;
+#else
+constexpr bool kPinBuild = true;
+#endif
+#ifdef CVO_NO_PF
+constexpr bool kPrefetchBuild = false;
+#else
+constexpr bool kPrefetchBuild = true;
+#endif
+// PIN false: the kernels that play several roles per launch (the merged and head-mode launches of one registration on
+// its own) sit at the scalar-register ceiling already -- pinned values would come back as v_readlane traffic -- and
+// are bound by their launch chain, not by these loops: they keep the plain form.
+template <bool PIN, class T> __device__ __forceinline__ const CVO_GLOBAL char *pin_global(const T *p)
+{
+    unsigned long long v = (unsigned long long)p;
+    if (PIN && kPinBuild) asm volatile("" : "+s"(v));
+    return (const CVO_GLOBAL char *)v;
+}
+template <bool PIN> __device__ __forceinline__ unsigned pin_u32(unsigned v)
+{
+    if (PIN && kPinBuild) asm volatile("" : "+s"(v));
+    return v;
+}
+template <bool PIN> __device__ __forceinline__ PairSrc pin_pair_src(const ProcessArgs &a)
+{
+    PairSrc p;
+    p.pos_a = pin_global<PIN>(a.pos_a); p.pos_b = pin_global<PIN>(a.pos_b);
+    p.feat_a = a.feat_a; p.feat_b = a.feat_b;
+    p.tf_a = (int)pin_u32<PIN>((unsigned)a.tf_a); p.tf_b = (int)pin_u32<PIN>((unsigned)a.tf_b);
+    return p;
+}
+template <bool W>
+__device__ __forceinline__ float4 load_pos(const void *base, unsigned byte_off)
+{
+    return *reinterpret_cast<const float4 *>(static_cast<const char *>(base) + byte_off);   // (.w unused: the compiler narrows the load itself)
+}
+template <bool W>
+__device__ __forceinline__ float4 load_pos(const CVO_GLOBAL char *base, unsigned byte_off)
+{
+    if (W) {
+        const f32x4_t v = *reinterpret_cast<const CVO_GLOBAL f32x4_t *>(base + byte_off);
+        return make_float4(v.x, v.y, v.z, v.w);
+    }
+    typedef float f32x3_t __attribute__((ext_vector_type(3)));
+    const f32x3_t v = *reinterpret_cast<const CVO_GLOBAL f32x3_t *>(base + byte_off);   // (12 of the row's 16 bytes)
+    return make_float4(v.x, v.y, v.z, 0.0f);
+}
+__device__ __forceinline__ uint2 load8(const CVO_GLOBAL char *base, unsigned idx)
+{
+#ifdef CVO_NT_LISTS
+    const u32x2_t v = __builtin_nontemporal_load(reinterpret_cast<const CVO_GLOBAL u32x2_t *>(base) + idx);
+#else
+    const u32x2_t v = reinterpret_cast<const CVO_GLOBAL u32x2_t *>(base)[idx];
+#endif
+    return make_uint2(v.x, v.y);
+}
+__device__ __forceinline__ void store8(const CVO_GLOBAL char *base, unsigned idx, unsigned x, unsigned y)
+{
+    u32x2_t v; v.x = x; v.y = y;
+    CVO_GLOBAL u32x2_t *q = reinterpret_cast<CVO_GLOBAL u32x2_t *>(const_cast<CVO_GLOBAL char *>(base)) + idx;
+#ifdef CVO_NT_KEPT_ST
+    __builtin_nontemporal_store(v, q);
+#else
+    *q = v;
+#endif
+}
+
+// the Taylor constants of an iteration are the same for every lane: a copy in scalar registers (read once per wave; read
+// through the state's pointer inside a streaming loop they come back as loads of every round)
+__device__ __forceinline__ cvo_math::XiConsts xi_uniform(const cvo_math::XiConsts &g)
+{
+    cvo_math::XiConsts xc;
+    auto uni = [](float x) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(x))); };
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        xc.omega[q] = uni(g.omega[q]); xc.v[q] = uni(g.v[q]);
+        xc.u2[q] = uni(g.u2[q]); xc.u3[q] = uni(g.u3[q]); xc.u4[q] = uni(g.u4[q]);
+    }
+#pragma unroll
+    for (int q = 0; q < 9; ++q) {
+        xc.W2[q] = uni(g.W2[q]); xc.W3[q] = uni(g.W3[q]); xc.W4[q] = uni(g.W4[q]);
+    }
+    return xc;
+}
+
+template <int MODE, int WEIGHT = 0, int CK = 0, class ARGS = ProcessArgs>
+__device__ __forceinline__ float eval_pair(const ARGS &a, const ProcHead &hd, const KernConsts &kc, unsigned i,
                                            unsigned j, float w, double *acc,
                                            const cvo_math::XiConsts &xc, const double *etab = nullptr,
-                                           const int first_counted = 0, float *ck_io = nullptr)
+                                           const int first_counted = 0, float *ck_io = nullptr,
+                                           uint2 *pf_out = nullptr, const CVO_GLOBAL char *pf_base = nullptr, unsigned pf_idx = 0)
 {
     const float *Rt = hd.Rt;
     const float *tt = hd.tt;
-    float4 xi = *gather16(a.pos_a, i * 16u);
-    if (a.tf_a) xi = apply_tf(Rt, tt, xi);
-    float4 yj = *gather16(a.pos_b, j * 16u);
+    // (both gathers -- and the features' -- are requested before anything waits or branches)
+    constexpr bool need_w = MODE != PROC_STEP && CK != 2;
+    float4 xi = load_pos<need_w>(a.pos_a, i * 16u);
+    float4 yj = load_pos<need_w>(a.pos_b, j * 16u);
+    // (a streaming loop's next record: requested BEHIND the gathers -- loads return in order -- so that the wait for the
+    // gathers leaves it in flight while the pair is evaluated)
+    if (pf_out) *pf_out = load8(pf_base, pf_idx);
     // the features are fetched together with the positions (one memory round
     // trip per pair instead of two); ~97 % of the filtered pairs need them
     float4 fa0 = make_float4(0.f, 0.f, 0.f, 0.f), fb0 = fa0;
@@ -746,6 +881,7 @@ __device__ __forceinline__ float eval_pair(const ProcessArgs &a, const ProcHead 
         if (MODE == PROC_SELF)   // the caller's index of the row (acvo Ayy rule)
             row_index = __float_as_int(a.feat_a[(size_t)i * FEAT_STRIDE + FEAT_INDEX_SLOT]);
     }
+    if (a.tf_a) xi = apply_tf(Rt, tt, xi);
     if (a.tf_b) yj = apply_tf(Rt, tt, yj);
     const float e0 = xi.x - yj.x, e1 = xi.y - yj.y, e2 = xi.z - yj.z;
     float d2 = 0.0f;
@@ -852,7 +988,7 @@ constexpr int PROC_SMEM = 4 * NACC_MAX * 8 + 4 * PAIR_QUEUE * 8 + 4 * 64 * 8;
 // The tile list of one registration, expanded and evaluated by the block's four waves (PROC_FLOW,
 // PROC_SELF).  REC (PROC_FLOW): every candidate is recorded for the passes that follow (ProcessArgs::cand).
 // Returns false when the loop has stopped (nothing to reduce).
-template <int MODE, int WEIGHT, int REC>
+template <int MODE, int WEIGHT, int REC, bool PIPE>
 __device__ __forceinline__ bool expand_lists(const ProcessArgs &a, const ProcHead &hd, const KernConsts &kc, const unsigned bid, const int wid,
                                              const int lane, const unsigned wave, const int done_word,
                                              const unsigned list_bad, const int in_list, const TileEntry *in_tiles,
@@ -876,6 +1012,7 @@ __device__ __forceinline__ bool expand_lists(const ProcessArgs &a, const ProcHea
         TileEntry mine = tl[min(e0 + (unsigned)lane * stride, a.subcap - 1)];
         if (done_word != 0) return false;
         uint2 *pairq = pairq_all + wid * PAIR_QUEUE;
+        const PairSrc src = pin_pair_src<PIPE>(a);   // (the clouds' addresses and the transform switches in scalar registers)
         int qn = 0;   // wave-uniform: queued pairs
         unsigned nk = 0;   // wave-uniform: members of A recorded so far
         unsigned co = 0;   // wave-uniform (REC): candidates recorded so far
@@ -890,7 +1027,7 @@ __device__ __forceinline__ bool expand_lists(const ProcessArgs &a, const ProcHea
             float ck = 0.0f;
             if (lane < cnt) {
                 pr = pairq[base + lane];
-                w = eval_pair<MODE, WEIGHT, REC>(a, hd, kc, pr.x, pr.y, 0.0f, acc, *hd.xi, s_etab, first_counted, &ck);   // (xi: PROC_STEP only)
+                w = eval_pair<MODE, WEIGHT, REC>(src, hd, kc, pr.x, pr.y, 0.0f, acc, *hd.xi, s_etab, first_counted, &ck);   // (xi: PROC_STEP only)
             }
             if (REC) {   // every candidate goes on record, at the place the wave met it (its colour weight with it)
                 if (co + (unsigned)cnt <= a.kept_wcap) {
@@ -973,41 +1110,44 @@ __device__ __forceinline__ bool expand_lists(const ProcessArgs &a, const ProcHea
 // The candidate list of one registration, streamed by the wave that recorded it: lane l takes the
 // wave's l-th candidate of the round -- nothing to expand, full rounds but the last, the colour weight
 // read back with the pair.  PROC_FLOW: the members of A of THIS iteration go to the kept list as always.
-template <int MODE>
+template <int MODE, bool PIPE>
 __device__ __forceinline__ bool stream_candidates(const ProcessArgs &a, const ProcHead &hd, const KernConsts &kc, const int lane,
                                                   const unsigned wave, const int done_word, const double *s_etab,
                                                   double (&acc)[NAcc<MODE>::n])
 {
-    const size_t base = (size_t)wave * a.kept_wcap;
+    unsigned wcap = a.kept_wcap;
+    const size_t base = (size_t)wave * wcap;
     unsigned n = hd.cand_cnt[wave];
     uint2 e = list_load(&hd.cand[base + lane]);
     if (done_word != 0) return false;
-    if (n > a.kept_wcap) n = a.kept_wcap;
+    if (n > wcap) n = wcap;
     unsigned nk = 0;
+    // (the loop's addresses and switches in scalar registers: PairSrc)
+    const PairSrc src = pin_pair_src<PIPE>(a);
+    const CVO_GLOBAL char *cand_w = pin_global<PIPE>(hd.cand + base);
+    const CVO_GLOBAL char *kept_w = pin_global<PIPE>(a.kept_ij + base);
+    wcap = pin_u32<PIPE>(wcap);
+    constexpr bool PF = PIPE && kPrefetchBuild;   // the next round's records are requested behind this round's gathers
     for (unsigned b0 = 0; b0 < n; b0 += 64u) {
-        if (b0 != 0u) e = list_load(&hd.cand[base + min(b0 + (unsigned)lane, a.kept_wcap - 1u)]);
+        if (!PF && b0 != 0u) e = load8(cand_w, min(b0 + (unsigned)lane, wcap - 1u));
+        uint2 e_next = e;
+        uint2 *const pf = PF ? &e_next : nullptr;
         const unsigned ci = e.x & 0xffffu, cj = e.x >> 16;
         float w = 0.0f;
         if (b0 + (unsigned)lane < n) {
             float ck = __uint_as_float(e.y);
-            w = eval_pair<MODE, 0, 2>(a, hd, kc, ci, cj, 0.0f, acc, *hd.xi, s_etab, 0, &ck);
+            w = eval_pair<MODE, 0, 2>(src, hd, kc, ci, cj, 0.0f, acc, *hd.xi, s_etab, 0, &ck, pf, cand_w,
+                                      min(b0 + 64u + (unsigned)lane, wcap - 1u));
         }
         const unsigned long long km = __ballot(w > 0.0f);
         if (MODE == PROC_FLOW && w > 0.0f) {   // (members <= candidates <= the slice: it cannot overflow here)
             const unsigned below = __builtin_amdgcn_mbcnt_hi((unsigned)(km >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)km, 0u));
             // (candidate records exist for clouds of up to 65536 rows only, whose kept entries are packed the same
             // way: the record's first word IS the entry's)
-#ifdef CVO_NT_KEPT_ST   // (A/B builds)
-            {
-                typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-                u32x2 v; v.x = e.x; v.y = __float_as_uint(w);
-                __builtin_nontemporal_store(v, reinterpret_cast<u32x2 *>(&a.kept_ij[base + nk + below]));
-            }
-#else
-            a.kept_ij[base + nk + below] = make_uint2(e.x, __float_as_uint(w));
-#endif
+            store8(kept_w, nk + below, e.x, __float_as_uint(w));
         }
         nk += (unsigned)__popcll(km);
+        if (PF) e = e_next;
     }
     if (lane == 0) {
         if (MODE == PROC_FLOW) a.kept_cnt[wave] = nk;
@@ -1018,7 +1158,7 @@ __device__ __forceinline__ bool stream_candidates(const ProcessArgs &a, const Pr
 
 // CAND false: the launch never keeps a candidate list (the merged launches of one registration on its
 // own, whose xy list is built beside the pass): that code is left out of the kernel
-template <int MODE, int WEIGHT = 0, bool CAND = true>
+template <int MODE, int WEIGHT = 0, bool CAND = true, bool PIPE = true>
 __device__ __forceinline__ void process_body(const ProcessArgs &a, const unsigned bid, char *scratch, const ProcHead &hd)
 {
     if ((int)bid >= a.nblk) return;
@@ -1056,22 +1196,30 @@ __device__ __forceinline__ void process_body(const ProcessArgs &a, const unsigne
         if (done_word != 0) return;
         if (n > a.kept_wcap) n = a.kept_wcap;
         if (list_bad) n = 0;
+        const PairSrc src = pin_pair_src<PIPE>(a);
+        const cvo_math::XiConsts xc = xi_uniform(*hd.xi);
+        const CVO_GLOBAL char *kept_w = pin_global<PIPE>(a.kept_ij + base);
+        const unsigned ebase = pin_u32<PIPE>(a.kept_ebase), wcap = pin_u32<PIPE>(a.kept_wcap);
+        constexpr bool PF = PIPE && kPrefetchBuild;
         for (unsigned off = lane; off < n; off += 64) {
-            if (off >= 64) { e = list_load(&a.kept_ij[base + off]); if (!packed) w = a.kept_a[base + off]; }
+            if (off >= 64) { if (!PF) e = load8(kept_w, off); if (!packed) w = a.kept_a[base + off]; }
+            uint2 e_next = e;
+            uint2 *const pf = PF ? &e_next : nullptr;
             unsigned mi, mj;
             float mw;
-            kept_unpack(packed, a.kept_ebase, e, w, mi, mj, mw);
-            eval_pair<MODE>(a, hd, kc, mi, mj, mw, acc, *hd.xi);
+            kept_unpack(packed, ebase, e, w, mi, mj, mw);
+            eval_pair<MODE>(src, hd, kc, mi, mj, mw, acc, xc, nullptr, 0, nullptr, pf, kept_w, min(off + 64u, wcap - 1u));
+            if (PF) e = e_next;
         }
     } else {
         bool alive;
         // (lists built ahead: only the xy list of a head-mode plan keeps records, one per buffer -- cand_b)
         if (CAND && WEIGHT == 0 && hd.cand && (MODE == PROC_FLOW ? (!a.async_xy || a.cand_b != nullptr)
                                                                  : (!a.async_self || a.cand_b != nullptr))) {
-            if (hd.ck_nblk == a.nblk) alive = stream_candidates<MODE>(a, hd, kc, lane, wave, done_word, s_etab, acc);
-            else alive = expand_lists<MODE, WEIGHT, WEIGHT == 0 ? 1 : 0>(a, hd, kc, bid, wid, lane, wave, done_word, list_bad, in_list, in_tiles, first_counted, s_etab, pairq_all, acc);
+            if (hd.ck_nblk == a.nblk) alive = stream_candidates<MODE, PIPE>(a, hd, kc, lane, wave, done_word, s_etab, acc);
+            else alive = expand_lists<MODE, WEIGHT, WEIGHT == 0 ? 1 : 0, PIPE>(a, hd, kc, bid, wid, lane, wave, done_word, list_bad, in_list, in_tiles, first_counted, s_etab, pairq_all, acc);
         } else {
-            alive = expand_lists<MODE, WEIGHT, 0>(a, hd, kc, bid, wid, lane, wave, done_word, list_bad, in_list, in_tiles, first_counted, s_etab, pairq_all, acc);
+            alive = expand_lists<MODE, WEIGHT, 0, PIPE>(a, hd, kc, bid, wid, lane, wave, done_word, list_bad, in_list, in_tiles, first_counted, s_etab, pairq_all, acc);
         }
         if (!alive) return;
     }
@@ -1233,13 +1381,22 @@ __device__ __forceinline__ bool step_twist_body(const ProcessArgs &a, DevState *
     double acc[NACC];
 #pragma unroll
     for (int k = 0; k < NACC; ++k) acc[k] = 0.0;
-    if (n > a.kept_wcap) n = a.kept_wcap;
+    unsigned wcap = a.kept_wcap, ebase = a.kept_ebase;
+    if (n > wcap) n = wcap;
+    // (addresses and switches of the loop in scalar registers, the next entries requested behind the gathers: PairSrc)
+    const PairSrc src = pin_pair_src<true>(a);
+    const CVO_GLOBAL char *kept_w = pin_global<true>(a.kept_ij + base);
+    wcap = pin_u32<true>(wcap); ebase = pin_u32<true>(ebase);
+    constexpr bool PF = kPrefetchBuild;
     for (unsigned off = lane; off < n; off += 64) {
-        if (off >= 64) { e = a.kept_ij[base + off]; if (!packed) w = a.kept_a[base + off]; }
+        if (off >= 64) { if (!PF) e = load8(kept_w, off); if (!packed) w = a.kept_a[base + off]; }
+        uint2 e_next = e;
+        uint2 *const pf = PF ? &e_next : nullptr;
         unsigned mi, mj;
         float mw;
-        kept_unpack(packed, a.kept_ebase, e, w, mi, mj, mw);
-        eval_pair<PROC_STEP>(a, phd, kc, mi, mj, mw, acc, xc);
+        kept_unpack(packed, ebase, e, w, mi, mj, mw);
+        eval_pair<PROC_STEP>(src, phd, kc, mi, mj, mw, acc, xc, nullptr, 0, nullptr, pf, kept_w, min(off + 64u, wcap - 1u));
+        if (PF) e = e_next;
     }
     __syncthreads();   // sh is re-used
     wave_sums<NACC>(acc, lane, sh + wid * NACC);
@@ -2040,10 +2197,10 @@ __global__ void __launch_bounds__(BLOCK) kt_post_step(const Slot *__restrict__ t
         const int np = cs->op[q].np;                                                                       \
         if ((int)blockIdx.x < np) {                                                                        \
             const ProcessArgs &pa = CVO_ARG(ProcessArgs, op[q].p);                                         \
-            process_body<PROC_FLOW, 0, false>(pa, blockIdx.x, smem, proc_head_global<PROC_FLOW>(pa, pa.st, 0)); \
+            process_body<PROC_FLOW, 0, false, false>(pa, blockIdx.x, smem, proc_head_global<PROC_FLOW>(pa, pa.st, 0)); \
             return;                                                                                        \
         }                                                                                                  \
-        filter_body(CVO_ARG(FilterArgs, op[q].f), blockIdx.x - (unsigned)np, (unsigned)cs->op[q].n0,       \
+        filter_body<false>(CVO_ARG(FilterArgs, op[q].f), blockIdx.x - (unsigned)np, (unsigned)cs->op[q].n0,       \
                     cs->op[q].f.st, 0);                                                                    \
     }                                                                                                      \
     __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WAVES, 8)))               \
@@ -2055,12 +2212,12 @@ __global__ void __launch_bounds__(BLOCK) kt_post_step(const Slot *__restrict__ t
         const int np = cs->op[q].np, n0 = cs->op[q].n0, n1 = cs->op[q].n1, n2 = cs->op[q].n2;             \
         if (b < np) {                                                                                      \
             const ProcessArgs &pa = CVO_ARG(ProcessArgs, op[q].p);                                         \
-            process_body<PROC_FLOW, 0, false>(pa, (unsigned)b, smem, proc_head_global<PROC_FLOW>(pa, pa.st, 0)); \
+            process_body<PROC_FLOW, 0, false, false>(pa, (unsigned)b, smem, proc_head_global<PROC_FLOW>(pa, pa.st, 0)); \
             return;                                                                                        \
         }                                                                                                  \
         b -= np;                                                                                           \
         const int role = b < n0 ? 0 : (b < n0 + n1 ? 1 : 2);                                               \
-        filter_body(CVO_FILTER_ROLE(role), (unsigned)(b - (role == 0 ? 0 : (role == 1 ? n0 : n0 + n1))),   \
+        filter_body<false>(CVO_FILTER_ROLE(role), (unsigned)(b - (role == 0 ? 0 : (role == 1 ? n0 : n0 + n1))),   \
                     (unsigned)(role == 0 ? n0 : (role == 1 ? n1 : n2)), cs->op[q + role].f.st, 0);         \
     }                                                                                                      \
     __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WAVES, 8)))               \
@@ -2072,7 +2229,7 @@ __global__ void __launch_bounds__(BLOCK) kt_post_step(const Slot *__restrict__ t
         const int np = cs->op[q].np;                                                                       \
         if (b < np) {                                                                                      \
             const ProcessArgs &pa = CVO_ARG(ProcessArgs, op[q].p);                                         \
-            process_body<PROC_FLOW, 0, false>(pa, (unsigned)b, smem, proc_head_global<PROC_FLOW>(pa, pa.st, 0)); \
+            process_body<PROC_FLOW, 0, false, false>(pa, (unsigned)b, smem, proc_head_global<PROC_FLOW>(pa, pa.st, 0)); \
             return;                                                                                        \
         }                                                                                                  \
         b -= np;                                                                                           \
@@ -2080,13 +2237,13 @@ __global__ void __launch_bounds__(BLOCK) kt_post_step(const Slot *__restrict__ t
             const int w = b >= np ? 1 : 0;                                                                 \
             const ProcessArgs &pa = CVO_ARG(ProcessArgs, op[q + 1 + w].p);                                 \
             /* (CAND false: the records of double-buffered lists belong to head mode, see plan_lone) */   \
-            process_body<PROC_SELF, 0, false>(pa, (unsigned)(b - w * np), smem, proc_head_global<PROC_SELF>(pa, pa.st, 0)); \
+            process_body<PROC_SELF, 0, false, false>(pa, (unsigned)(b - w * np), smem, proc_head_global<PROC_SELF>(pa, pa.st, 0)); \
             return;                                                                                        \
         }                                                                                                  \
         b -= 2 * np;                                                                                       \
         const int n0 = cs->op[q].n0, n1 = cs->op[q].n1;                                                    \
         const int role = b < n0 ? 0 : (b < n0 + n1 ? 1 : 2);                                               \
-        filter_body(CVO_FILTER_ROLE(role), (unsigned)(b - (role == 0 ? 0 : (role == 1 ? n0 : n0 + n1))),   \
+        filter_body<false>(CVO_FILTER_ROLE(role), (unsigned)(b - (role == 0 ? 0 : (role == 1 ? n0 : n0 + n1))),   \
                     (unsigned)(role == 0 ? n0 : (role == 1 ? n1 : cs->op[q].n2)), cs->op[q + role].f.st, 0); \
     }
 CVO_MERGED_KERNELS(_w4, 4)
@@ -2161,7 +2318,7 @@ __device__ __forceinline__ ProcHead proc_head_lds(const ProcessArgs &a, const De
         const int np = cs->op[q].np;                                                                       \
         if ((int)blockIdx.x >= np) {                                                                       \
             const FilterArgs &f = CVO_ARG(FilterArgs, op[q].f);                                            \
-            filter_body(f, blockIdx.x - (unsigned)np, (unsigned)cs->op[q].n0, par ? f.st2 : f.st, par);    \
+            filter_body<false>(f, blockIdx.x - (unsigned)np, (unsigned)cs->op[q].n0, par ? f.st2 : f.st, par);    \
             return;                                                                                        \
         }                                                                                                  \
         const PostStepArgs ps = CVO_ARG(PostStepArgs, op[q].ps);                                           \
@@ -2169,7 +2326,7 @@ __device__ __forceinline__ ProcHead proc_head_lds(const ProcessArgs &a, const De
         if (!head_body<HM_HEAD>(ps, par ? ps.st2 : ps.st, par ? ps.st : ps.st2, &s_st, sh, par,            \
                                 blockIdx.x == 0)) return;                                                  \
         float rt[12];                                                                                      \
-        process_body<PROC_FLOW, 0, true>(pa, blockIdx.x, smem, proc_head_lds<PROC_FLOW>(pa, &s_st, par, rt)); \
+        process_body<PROC_FLOW, 0, true, false>(pa, blockIdx.x, smem, proc_head_lds<PROC_FLOW>(pa, &s_st, par, rt)); \
         if (ps.dbg && blockIdx.x == 0 && threadIdx.x == 0 && ps.dbg[6] != 0) {   /* block 0: head + flow pass */ \
             ps.dbg[7] += (long long)__builtin_readcyclecounter() - ps.dbg[6];                              \
             ps.dbg[6] = 0;                                                                                 \
@@ -2189,7 +2346,7 @@ __device__ __forceinline__ ProcHead proc_head_lds(const ProcessArgs &a, const De
             const int n0 = cs->op[q].n0, n1 = cs->op[q].n1;                                                \
             const int role = b < n0 ? 0 : (b < n0 + n1 ? 1 : 2);                                           \
             const FilterArgs &f = CVO_FILTER_ROLE(role);                                                   \
-            filter_body(f, (unsigned)(b - (role == 0 ? 0 : (role == 1 ? n0 : n0 + n1))),                   \
+            filter_body<false>(f, (unsigned)(b - (role == 0 ? 0 : (role == 1 ? n0 : n0 + n1))),                   \
                         (unsigned)(role == 0 ? n0 : (role == 1 ? n1 : cs->op[q].n2)), par ? f.st2 : f.st, par); \
             return;                                                                                        \
         }                                                                                                  \
@@ -2201,10 +2358,10 @@ __device__ __forceinline__ ProcHead proc_head_lds(const ProcessArgs &a, const De
                                 blockIdx.x == 0)) return;                                                  \
         float rt[12];                                                                                      \
         if (role == 0) {                                                                                   \
-            process_body<PROC_FLOW, 0, true>(pa, rb, smem, proc_head_lds<PROC_FLOW>(pa, &s_st, par, rt));  \
+            process_body<PROC_FLOW, 0, true, false>(pa, rb, smem, proc_head_lds<PROC_FLOW>(pa, &s_st, par, rt));  \
             return;                                                                                        \
         }                                                                                                  \
-        process_body<PROC_SELF, 0, true>(pa, rb, smem, proc_head_lds<PROC_SELF>(pa, &s_st, par, rt));      \
+        process_body<PROC_SELF, 0, true, false>(pa, rb, smem, proc_head_lds<PROC_SELF>(pa, &s_st, par, rt));      \
     }
 CVO_HEAD_KERNELS(_w4, 4)
 
