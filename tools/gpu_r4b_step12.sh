@@ -1,0 +1,6 @@
+#!/bin/bash
+# non-temporal list traffic in the heavy iterations only (iteration caps)
+cd ${GRAFT_REPO_ROOT:-$(pwd)}
+for r in 1 2; do for lib in libcvo_hip.so libcvo_hip_nt.so libcvo_hip_ntst.so libcvo_hip_ntst2.so; do for mi in 4 21; do
+  echo -n "$lib max_iter $mi: "; CVO_LIB=$lib MAX_ITER=$mi DISTINCT=1 CVO_HIP_GRAPH=1 python tools/gpu_batch.py 10000 6 64 2>/dev/null | tail -1 | cut -c1-60
+done; done; done 2>&1 | tee gpurun_out/r4b_nt_heavy.txt
