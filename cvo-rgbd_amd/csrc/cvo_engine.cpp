@@ -179,7 +179,7 @@ struct Engine {
         const bool regeom = zd != zdim;
         zdim = zd;
         const int nblk = nblk_for(zdim);
-        static const int merge_max = [] { const char *e = getenv("CVO_HIP_MERGE_MAX"); return e ? atoi(e) : 2; }();   // (tuning probe, r04_ab.txt 13)
+        constexpr int merge_max = 2;   // (4 / 8 / 16 measured alike on the round-4 kernels, 32 loses 7 %: profiles/r04_ab.txt 13)
         std::vector<const std::vector<RecOp> *> po;
         std::vector<Slot *> ps;
         for (int z = 0; z < ENGINE_SLOTS; ++z) {

@@ -131,9 +131,21 @@ def test_align_matches_oracle_synthetic(pkg, po, mode_name):
     for a, b in zip(reg.trace, tr_or):
         assert a["nnz"] == b["nnz"] and a["ell"] == b["ell"]
         assert a["omega"] == b["omega"] and a["v"] == b["v"] and a["step"] == b["step"]
+        # (the sum of the weights: only trace records read it -- the flow pass of a loop WITHOUT a trace leaves it out)
+        if "sum_a" in a and "sum_a" in b:
+            assert abs(a["sum_a"] - b["sum_a"]) <= 1e-11 * max(1.0, abs(b["sum_a"]))
     rot, tr = pkg.data.rel_pose_error(reg.transform, T_or)
     assert rot <= 1e-6 and tr <= 1e-6
     assert np.allclose(reg.accum_transform, A_or, rtol=0, atol=1e-7)
+    # the same registration without a trace (the flow pass without the sum of the weights): the same state, bit for bit
+    import torch
+    Reg = pkg.Cvo if mode == pkg.capi.MODE_CVO else pkg.Acvo
+    reg2 = Reg(device=0, stream=torch.cuda.current_stream().cuda_stream)
+    reg2.run_cvo(xf, ff)
+    reg2.run_cvo(xm, fm)
+    assert reg2.num_iterations == reg.num_iterations
+    assert np.array_equal(reg2.transform, reg.transform) and np.array_equal(reg2.accum_transform, reg.accum_transform)
+    reg2.close()
     reg.close()
 
 
