@@ -1252,6 +1252,39 @@ __global__ void __launch_bounds__(BLOCK) k_process(const Grp<ProcessArgs> grp)
 constexpr int STEP_BLOCK = 1024;
 constexpr int STEP_WAVES = STEP_BLOCK / 64;
 
+// cvo_math::make_xi_consts (se3_math.hpp; ref src/cvo.cpp:226-238) by the first twelve lanes of a wave: every element of W^2, W^3, W^4
+// and of W v, W^2 v, W^3 v with the expression the serial routine has for it (mul / mulv: (a0 b0 + a1 b1) + a2 b2, no contraction), three
+// dependent levels through LDS instead of ~200 instructions of one lane in a row.  xi and wm[9] are in LDS; all 64 lanes call it.
+__device__ __forceinline__ void xi_consts_wave(cvo_math::XiConsts *xi, float *wm, const float omega[3], const float v[3], const int lane)
+{
+    if (lane == 0) {
+        const cvo_math::Mat3 W = cvo_math::skew(omega);
+#pragma unroll
+        for (int k = 0; k < 9; ++k) wm[k] = W.m[k];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { xi->omega[k] = omega[k]; xi->v[k] = v[k]; }
+    }
+    const int r = lane < 9 ? lane / 3 : lane - 9, c = lane < 9 ? lane - 3 * (lane / 3) : 0;
+#pragma unroll
+    for (int level = 1; level <= 3; ++level) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (lane < 12) {
+            const float *A = level == 1 ? wm : (level == 2 ? xi->W2 : xi->W3);
+            const float a0 = A[3 * r], a1 = A[3 * r + 1], a2 = A[3 * r + 2];
+            const float b0 = lane < 9 ? wm[c] : xi->v[0], b1 = lane < 9 ? wm[3 + c] : xi->v[1], b2 = lane < 9 ? wm[6 + c] : xi->v[2];
+            const float o = (a0 * b0 + a1 * b1) + a2 * b2;
+            float *dst = level == 1 ? (lane < 9 ? xi->W2 + lane : xi->u2 + r)
+                                    : (level == 2 ? (lane < 9 ? xi->W3 + lane : xi->u3 + r) : (lane < 9 ? xi->W4 + lane : xi->u4 + r));
+            *dst = o;
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // returns true if this block delivered a row of step partial sums (false: the registration has
 // stopped, the slot is a stall, a list overflowed, or the block is surplus)
 // hd: the copy of the state's head the slot runs on (a.st unless head mode); par: the slot's parity
@@ -1263,6 +1296,7 @@ __device__ __forceinline__ bool step_twist_body(const ProcessArgs &a, DevState *
     __shared__ double sh[STEP_WAVES * NACC_MAX];
     __shared__ double tot[NACC_MAX + 4];
     __shared__ cvo_math::XiConsts s_xi;
+    __shared__ float s_wm[12];
     __shared__ int s_overflow;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1303,11 +1337,11 @@ __device__ __forceinline__ bool step_twist_body(const ProcessArgs &a, DevState *
         tot[tid] = t;
     }
     __syncthreads();
-    if (tid == 0) {
+    if (tid < 64) {   // (the Taylor constants by the first wave, element by element: xi_consts_wave)
         float omega[3], v[3];
         for (int q = 0; q < 3; ++q) { omega[q] = (float)tot[q]; v[q] = (float)tot[3 + q]; }
-        s_xi = cvo_math::make_xi_consts(omega, v);
-        s_overflow = ovf != 0u;
+        xi_consts_wave(&s_xi, s_wm, omega, v, lane);
+        if (tid == 0) s_overflow = ovf != 0u;
     }
     // acvo: block 0 also needs the Axx / Ayy sums for dl (ref adaptive_cvo.cpp:222-231,271)
     if (blockIdx.x == 0 && a.acvo && wid < 2) {
@@ -1672,6 +1706,13 @@ __device__ __forceinline__ void post_flow_body(const PostFlowArgs &a)
         comm_ok = mailbox_allreduce(*a.comm, a.st, st->red + RED_FLOW, RED_STEP - RED_FLOW, sh_mail, &sh_fail);
         if (!comm_ok && threadIdx.x == 0) st->done = DONE_COMM_ERROR;
     }
+    if ((a.flags & POST_MATH) && comm_ok && threadIdx.x < 64) {   // (the Taylor constants by the first wave: xi_consts_wave)
+        // (sh is free again -- the reductions above end with a block barrier --: the wave's scratch for W)
+        const double *red = st->red;
+        float omega[3], v[3];
+        for (int q = 0; q < 3; ++q) { omega[q] = (float)red[q]; v[q] = (float)red[3 + q]; }
+        if (!(red[8] != red[8])) xi_consts_wave(&st->xi, reinterpret_cast<float *>(sh), omega, v, (int)threadIdx.x);
+    }
     if ((a.flags & POST_MATH) && comm_ok && threadIdx.x == 0) {
         // nothing of an overflowed iteration is usable; the host enlarges the
         // list and resumes from the same (untouched) state
@@ -1685,7 +1726,6 @@ __device__ __forceinline__ void post_flow_body(const PostFlowArgs &a)
             st->omega[q] = omega[q];
             st->v[q] = v[q];
         }
-        if (!overflow) st->xi = cvo_math::make_xi_consts(omega, v);
         double dl = 0.0;
         const long long nnz = (long long)red[8];
         long long nnz_xx = 0, nnz_yy = 0;
