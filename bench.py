@@ -526,10 +526,13 @@ def roofline_legs(args, pkg, ctx, ctxs, one_step, n, m):
                       "peak_TFLOPs": PEAK_F32_TFLOPS,
                       "frac": (flow_flop * regs_per_launch / (b_us * 1e-6) / 1e12 / PEAK_F32_TFLOPS) if b_us > 0 else 0.0},
         "reading": "the algorithmic bytes are the two clouds; what the pass does is evaluate ~1e5-1e6 candidate pairs per "
-                   "registration at ~135 vector instructions per 64 of them (float32 geometry, two float64 exp, nine float64 "
-                   "sums). The saturated resource of the batched run is VALU issue, not a memory roof: SQ_ACTIVE_INST_VALU "
-                   "over all kernels = ~78 % of the wall time at saturation, and idle instructions added to this kernel cost "
-                   "throughput in proportion (profiles/r02_ab.txt items 24-28, DESIGN 5)",
+                   "registration at ~85 vector instructions per 64 of them (float32 geometry, a float64 exp, six float64 sums) "
+                   "and write the members of A out for the step pass. It is at neither roof: in the wide iterations vector "
+                   "issue is ~0.5 busy and the counter traffic ~0.5 of what HBM delivers (by_phase); a round of 64 candidates is "
+                   "one dependent chain (record, two gathers, arithmetic, store) and a wave waits ~3/4 of its life for it. "
+                   "Round 4 arranged the loop so that the chain holds only data dependences and the next record is in flight "
+                   "during the arithmetic (+5...+9 % batched); deeper pipelines, more waves, staged stores all lose "
+                   "(profiles/r04_ab.txt 15-20, DESIGN 4.2)",
     }
     # ---- the all-pairs test: k_filter (f32 MFMA), launches that build a list
     kf_n = prof["flow_launches"]
