@@ -852,35 +852,6 @@ __device__ __forceinline__ cvo_math::XiConsts xi_uniform(const cvo_math::XiConst
     return xc;
 }
 
-// What a pair's evaluation reads from memory: the two rows and -- where the pass looks at them -- the two feature quads and
-// the caller's index of the fixed row.  load_pair requests it all at once; eval_loaded is the arithmetic.  (Two halves, so that
-// a pass can take the rows from somewhere else than the clouds: the tiled streaming pass has them in LDS.)
-struct PairOps {
-    float4 xi, yj, fa0, fb0;
-    int row_index;
-};
-template <int MODE, int CK, class ARGS>
-__device__ __forceinline__ void load_pair(const ARGS &a, const unsigned i, const unsigned j, PairOps &o)
-{
-    constexpr bool need_w = MODE != PROC_STEP && CK != 2;
-    o.xi = load_pos<need_w>(a.pos_a, i * 16u);
-    o.yj = load_pos<need_w>(a.pos_b, j * 16u);
-    o.fa0 = make_float4(0.f, 0.f, 0.f, 0.f);
-    o.fb0 = o.fa0;
-    o.row_index = 0;
-    if (MODE != PROC_STEP && CK != 2) {
-        o.fa0 = *gather16(a.feat_a, i * (unsigned)(FEAT_STRIDE * 4));
-        o.fb0 = *gather16(a.feat_b, j * (unsigned)(FEAT_STRIDE * 4));
-        if (MODE == PROC_SELF)   // the caller's index of the row (acvo Ayy rule)
-            o.row_index = __float_as_int(a.feat_a[(size_t)i * FEAT_STRIDE + FEAT_INDEX_SLOT]);
-    }
-}
-
-template <int MODE, int WEIGHT, int CK, class ARGS>
-__device__ __forceinline__ float eval_loaded(const ARGS &a, const ProcHead &hd, const KernConsts &kc, const PairOps &o, float w,
-                                             double *acc, const cvo_math::XiConsts &xc, const double *etab, const int first_counted,
-                                             float *ck_io, const bool rows_transformed = false);
-
 template <int MODE, int WEIGHT = 0, int CK = 0, class ARGS = ProcessArgs>
 __device__ __forceinline__ float eval_pair(const ARGS &a, const ProcHead &hd, const KernConsts &kc, unsigned i,
                                            unsigned j, float w, double *acc,
@@ -888,25 +859,30 @@ __device__ __forceinline__ float eval_pair(const ARGS &a, const ProcHead &hd, co
                                            const int first_counted = 0, float *ck_io = nullptr,
                                            uint2 *pf_out = nullptr, const CVO_GLOBAL char *pf_base = nullptr, unsigned pf_idx = 0)
 {
-    PairOps o;
-    load_pair<MODE, CK>(a, i, j, o);
-    if (pf_out) *pf_out = load8(pf_base, pf_idx);   // (the next record, behind the gathers)
-    return eval_loaded<MODE, WEIGHT, CK>(a, hd, kc, o, w, acc, xc, etab, first_counted, ck_io);
-}
-
-template <int MODE, int WEIGHT, int CK, class ARGS>
-__device__ __forceinline__ float eval_loaded(const ARGS &a, const ProcHead &hd, const KernConsts &kc, const PairOps &o, float w,
-                                             double *acc, const cvo_math::XiConsts &xc, const double *etab, const int first_counted,
-                                             float *ck_io, const bool rows_transformed)
-{
     const float *Rt = hd.Rt;
     const float *tt = hd.tt;
-    float4 xi = o.xi, yj = o.yj;
-    const float4 fa0 = o.fa0, fb0 = o.fb0;
-    const float fa4 = xi.w, fb4 = yj.w;   // the 5th feature travels in pos.w
-    int row_index = o.row_index;
-    if (a.tf_a && !rows_transformed) xi = apply_tf(Rt, tt, xi);
-    if (a.tf_b && !rows_transformed) yj = apply_tf(Rt, tt, yj);
+    // (both gathers -- and the features' -- are requested before anything waits or branches)
+    constexpr bool need_w = MODE != PROC_STEP && CK != 2;
+    float4 xi = load_pos<need_w>(a.pos_a, i * 16u);
+    float4 yj = load_pos<need_w>(a.pos_b, j * 16u);
+    // (a streaming loop's next record: requested BEHIND the gathers -- loads return in order -- so that the wait for the
+    // gathers leaves it in flight while the pair is evaluated)
+    if (pf_out) *pf_out = load8(pf_base, pf_idx);
+    // the features are fetched together with the positions (one memory round
+    // trip per pair instead of two); ~97 % of the filtered pairs need them
+    float4 fa0 = make_float4(0.f, 0.f, 0.f, 0.f), fb0 = fa0;
+    float fa4 = 0.f, fb4 = 0.f;
+    int row_index = 0;
+    if (MODE != PROC_STEP && CK != 2) {
+        fa0 = *gather16(a.feat_a, i * (unsigned)(FEAT_STRIDE * 4));
+        fb0 = *gather16(a.feat_b, j * (unsigned)(FEAT_STRIDE * 4));
+        fa4 = xi.w;   // the 5th feature travels in pos.w
+        fb4 = yj.w;
+        if (MODE == PROC_SELF)   // the caller's index of the row (acvo Ayy rule)
+            row_index = __float_as_int(a.feat_a[(size_t)i * FEAT_STRIDE + FEAT_INDEX_SLOT]);
+    }
+    if (a.tf_a) xi = apply_tf(Rt, tt, xi);
+    if (a.tf_b) yj = apply_tf(Rt, tt, yj);
     const float e0 = xi.x - yj.x, e1 = xi.y - yj.y, e2 = xi.z - yj.z;
     float d2 = 0.0f;
     if (MODE != PROC_STEP) {
@@ -1008,7 +984,6 @@ __device__ __forceinline__ float eval_loaded(const ARGS &a, const ProcHead &hd, 
 // LDS of a list-kernel block: handed in, so that launches whose blocks play different
 // roles (flow pass, self passes, filter) overlay one allocation instead of adding them up
 constexpr int PROC_SMEM = 4 * NACC_MAX * 8 + 4 * PAIR_QUEUE * 8 + 4 * 64 * 8;
-constexpr int PROC_SMEM_TILED = PROC_SMEM + 4 * (8 * 32 * 16 + 64 + 4 * 64);   // + TS_SMEM_WAVE per wave (stream_candidates_tiled)
 
 // The tile list of one registration, expanded and evaluated by the block's four waves (PROC_FLOW,
 // PROC_SELF).  REC (PROC_FLOW): every candidate is recorded for the passes that follow (ProcessArgs::cand).
@@ -1034,13 +1009,7 @@ __device__ __forceinline__ bool expand_lists(const ProcessArgs &a, const ProcHea
         // entries, the first one together with the count).
         const unsigned stride = shared ? 4u * (unsigned)(a.nblk / NSUB) : 4u;
         const unsigned e0 = part * 4u + (unsigned)wid;
-#ifdef CVO_ENTRY_SINGLES   // (A/B builds: the waves of a sub-list take its entries one by one in turn)
-        auto entry_of = [&](unsigned round) { return e0 + (round * 64u + (unsigned)lane) * stride; };
-#else
-        // four entries at a time: the four result registers of one 16 x 16 tile, as a rule, stay with one wave
-        auto entry_of = [&](unsigned round) { return ((round * 16u + ((unsigned)lane >> 2)) * stride + e0) * 4u + ((unsigned)lane & 3u); };
-#endif
-        TileEntry mine = tl[min(entry_of(0u), a.subcap - 1)];
+        TileEntry mine = tl[min(e0 + (unsigned)lane * stride, a.subcap - 1)];
         if (done_word != 0) return false;
         uint2 *pairq = pairq_all + wid * PAIR_QUEUE;
         const PairSrc src = pin_pair_src<PIPE>(a);   // (the clouds' addresses and the transform switches in scalar registers)
@@ -1099,13 +1068,13 @@ __device__ __forceinline__ bool expand_lists(const ProcessArgs &a, const ProcHea
             const unsigned sub_next = sub + (unsigned)a.nblk;
             n_next = list_bad ? 0u : a.st->sub[in_list][sub_next];
             tl_next = in_tiles + (size_t)sub_next * a.subcap;
-            mine_next = tl_next[min(entry_of(0u), a.subcap - 1)];
+            mine_next = tl_next[min(e0 + (unsigned)lane * stride, a.subcap - 1)];
         }
         if (n > a.subcap) n = a.subcap;   // overflowed list: the iteration is redone anyway
-        for (unsigned round = 0;; ++round) {
-            const int cnt = (int)__popcll(__ballot(entry_of(round) < n));   // (a prefix of the lanes: the index grows with the lane)
-            if (cnt == 0) break;
-            if (round != 0u) mine = tl[min(entry_of(round), a.subcap - 1)];
+        for (unsigned eb = e0; eb < n; eb += 64u * stride) {
+            if (eb != e0) mine = tl[min(eb + (unsigned)lane * stride, a.subcap - 1)];
+            const unsigned left = (n - eb + stride - 1) / stride;   // entries of this round
+            const int cnt = (int)(left < 64u ? left : 64u);
             for (int k = 0; k < cnt; ++k) {
                 // broadcast lane k's entry and expand its mask into the queue:
                 // bit l is row (l>>4)*4 + r, column l&15 of the tile
@@ -1187,139 +1156,6 @@ __device__ __forceinline__ bool stream_candidates(const ProcessArgs &a, const Pr
     return true;
 }
 
-// ---------------------------------------------------------------------------
-// EXPERIMENT (profiles/r04_ab.txt 22; measured 9-10 % slower, removed by the next commit): the streaming flow pass with its rows in
-// LDS (north star: "LDS-tiled source blocks reused across target wavefronts").  A wave takes TS_K rounds of
-// candidate records at a time, finds the runs of records with the same 16 x 16 tile, and if the chunk has at most TS_SLOTS of
-// them it fetches each run's 32 rows once, coalesced, into its own LDS; every pair then reads its two rows from there.  A chunk
-// with more runs takes the plain gathers; after two such chunks in a row the wave stops looking.  Bit-identical.
-constexpr int TS_K = 4, TS_SLOTS = 8;
-constexpr int TS_SMEM_WAVE = TS_SLOTS * 32 * 16 + 64 + TS_K * 64;   // rows + the runs' tile numbers + a run number per record
-
-template <int MODE>
-__device__ __forceinline__ bool stream_candidates_tiled(const ProcessArgs &a, const ProcHead &hd, const KernConsts &kc, const int lane,
-                                                        const unsigned wave, const int done_word, const double *s_etab,
-                                                        double (&acc)[NAcc<MODE>::n], char *ts /* TS_SMEM_WAVE bytes of this wave */)
-{
-    static_assert(MODE == PROC_FLOW, "the flow pass");
-    float4 *tile = reinterpret_cast<float4 *>(ts);
-    unsigned *runkey = reinterpret_cast<unsigned *>(ts + TS_SLOTS * 32 * 16);
-    unsigned char *ridbuf = reinterpret_cast<unsigned char *>(ts + TS_SLOTS * 32 * 16 + 64);
-    unsigned wcap = a.kept_wcap;
-    const size_t base = (size_t)wave * wcap;
-    unsigned n = hd.cand_cnt[wave];
-    const PairSrc src = pin_pair_src<true>(a);
-    const CVO_GLOBAL char *cand_w = pin_global<true>(hd.cand + base);
-    const CVO_GLOBAL char *kept_w = pin_global<true>(a.kept_ij + base);
-    wcap = pin_u32<true>(wcap);
-    // the tile numbers of a chunk's records (the records themselves are read again, round by round, when the pairs are evaluated)
-    unsigned kx[TS_K];
-#pragma unroll
-    for (int k = 0; k < TS_K; ++k) kx[k] = load8(cand_w, min((unsigned)(k * 64 + lane), wcap - 1u)).x;
-    if (done_word != 0) return false;
-    if (n > wcap) n = wcap;
-    unsigned nk = 0;
-    bool looking = true;
-    int misses = 0;
-    const bool tf_any = (src.tf_a | src.tf_b) != 0;
-    for (unsigned c0 = 0; c0 < n; c0 += 64u * TS_K) {
-        unsigned nr = 0;
-        bool tiled = false;
-        if (looking) {
-            unsigned last = 0xffffffffu;
-#pragma unroll
-            for (int k = 0; k < TS_K; ++k) {
-                const bool valid = c0 + (unsigned)(k * 64 + lane) < n;
-                const unsigned key = ((kx[k] >> 4) & 0xfffu) | ((kx[k] >> 20) << 12);
-                unsigned prev = (unsigned)__shfl_up((int)key, 1, 64);
-                if (lane == 0) prev = last;
-                const bool st = valid && key != prev;
-                const unsigned long long m = __ballot(st);
-                const unsigned rid = nr + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u)) + (st ? 1u : 0u) - 1u;
-                if (st && rid < (unsigned)TS_SLOTS) runkey[rid] = key;
-                ridbuf[k * 64 + lane] = (unsigned char)rid;
-                nr += (unsigned)__popcll(m);
-                last = (unsigned)__builtin_amdgcn_readlane((int)key, 63);
-            }
-            tiled = nr <= (unsigned)TS_SLOTS;
-            if (tiled) misses = 0;
-            else if (++misses >= 2) looking = false;
-        }
-#pragma unroll
-        for (int k = 0; k < TS_K; ++k) kx[k] = load8(cand_w, min(c0 + (unsigned)((TS_K + k) * 64 + lane), wcap - 1u)).x;
-        if (tiled) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            // the runs' rows: lanes 0-31 one run, lanes 32-63 the next; rows 0-15 of the fixed cloud, 16-31 of the moving one
-            float4 v[TS_SLOTS / 2];
-            const int p = lane & 31;
-#pragma unroll
-            for (int t = 0; t < TS_SLOTS / 2; ++t) {
-                const unsigned slot = (unsigned)(2 * t + (lane >> 5));
-                v[t] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (slot < nr) {
-                    const unsigned key = runkey[slot];
-                    const unsigned row = p < 16 ? (key & 0xfffu) * 16u + (unsigned)p : (key >> 12) * 16u + (unsigned)(p - 16);
-                    const CVO_GLOBAL char *cloud = p < 16 ? src.pos_a : src.pos_b;
-                    v[t] = load_pos<false>(cloud, row * 16u);
-                }
-            }
-#pragma unroll
-            for (int t = 0; t < TS_SLOTS / 2; ++t) {
-                const unsigned slot = (unsigned)(2 * t + (lane >> 5));
-                if (slot < nr) {
-                    float4 q = v[t];
-                    if (tf_any) {
-                        if (p < 16 ? src.tf_a != 0 : src.tf_b != 0) q = apply_tf(hd.Rt, hd.tt, q);
-                    }
-                    tile[slot * 32u + (unsigned)p] = q;
-                }
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        }
-        uint2 e = load8(cand_w, min(c0 + (unsigned)lane, wcap - 1u));
-#pragma unroll 1
-        for (int k = 0; k < TS_K; ++k) {
-            const unsigned b0 = c0 + (unsigned)(k * 64);
-            if (b0 >= n) break;
-            const unsigned ci = e.x & 0xffffu, cj = e.x >> 16;
-            float w = 0.0f;
-            uint2 e_next = e;
-            const unsigned keep_x = e.x;
-            if (b0 + (unsigned)lane < n) {
-                float ck = __uint_as_float(e.y);
-                PairOps o;
-                if (tiled) {
-                    const unsigned rid = ridbuf[k * 64 + lane];
-                    o.xi = tile[rid * 32u + (ci & 15u)];
-                    o.yj = tile[rid * 32u + 16u + (cj & 15u)];
-                    o.fa0 = make_float4(0.f, 0.f, 0.f, 0.f); o.fb0 = o.fa0; o.row_index = 0;
-                } else {
-                    load_pair<MODE, 2>(src, ci, cj, o);
-                }
-                e_next = load8(cand_w, min(b0 + 64u + (unsigned)lane, wcap - 1u));
-                w = eval_loaded<MODE, 0, 2>(src, hd, kc, o, 0.0f, acc, *hd.xi, s_etab, 0, &ck, tiled);
-            }
-            const unsigned long long km = __ballot(w > 0.0f);
-            if (w > 0.0f) {
-                const unsigned below = __builtin_amdgcn_mbcnt_hi((unsigned)(km >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)km, 0u));
-                store8(kept_w, nk + below, keep_x, __float_as_uint(w));
-            }
-            nk += (unsigned)__popcll(km);
-            e = e_next;
-        }
-        if (tiled) __builtin_amdgcn_wave_barrier();
-    }
-    if (lane == 0) {
-        a.kept_cnt[wave] = nk;
-        acc[8] = (double)nk;
-    }
-    return true;
-}
-
 // CAND false: the launch never keeps a candidate list (the merged launches of one registration on its
 // own, whose xy list is built beside the pass): that code is left out of the kernel
 template <int MODE, int WEIGHT = 0, bool CAND = true, bool PIPE = true>
@@ -1380,15 +1216,7 @@ __device__ __forceinline__ void process_body(const ProcessArgs &a, const unsigne
         // (lists built ahead: only the xy list of a head-mode plan keeps records, one per buffer -- cand_b)
         if (CAND && WEIGHT == 0 && hd.cand && (MODE == PROC_FLOW ? (!a.async_xy || a.cand_b != nullptr)
                                                                  : (!a.async_self || a.cand_b != nullptr))) {
-#ifdef CVO_NO_TILED   // (A/B builds)
-            constexpr bool TILED = false;
-#else
-            constexpr bool TILED = PIPE && MODE == PROC_FLOW;
-#endif
-            if (hd.ck_nblk == a.nblk) {
-                if constexpr (TILED) alive = stream_candidates_tiled<MODE>(a, hd, kc, lane, wave, done_word, s_etab, acc, scratch + PROC_SMEM + wid * TS_SMEM_WAVE);
-                else alive = stream_candidates<MODE, PIPE>(a, hd, kc, lane, wave, done_word, s_etab, acc);
-            }
+            if (hd.ck_nblk == a.nblk) alive = stream_candidates<MODE, PIPE>(a, hd, kc, lane, wave, done_word, s_etab, acc);
             else alive = expand_lists<MODE, WEIGHT, WEIGHT == 0 ? 1 : 0, PIPE>(a, hd, kc, bid, wid, lane, wave, done_word, list_bad, in_list, in_tiles, first_counted, s_etab, pairq_all, acc);
         } else {
             alive = expand_lists<MODE, WEIGHT, 0, PIPE>(a, hd, kc, bid, wid, lane, wave, done_word, list_bad, in_list, in_tiles, first_counted, s_etab, pairq_all, acc);
@@ -1408,7 +1236,7 @@ __device__ __forceinline__ void process_body(const ProcessArgs &a, const unsigne
 template <int MODE, int WEIGHT = 0>
 __global__ void __launch_bounds__(BLOCK) k_process(const Grp<ProcessArgs> grp)
 {
-    __shared__ __attribute__((aligned(16))) char scratch[PROC_SMEM_TILED];
+    __shared__ __attribute__((aligned(16))) char scratch[PROC_SMEM];
     const ProcessArgs &a = grp.a[blockIdx.z];
     process_body<MODE, WEIGHT>(a, blockIdx.x, scratch, proc_head_global<MODE>(a, a.st, 0));
 }
@@ -2317,7 +2145,7 @@ template <int MODE, int WEIGHT = 0>
 __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((MODE == PROC_FLOW && WEIGHT == 0) ? 7 : 1, 8)))
 kt_process(const Slot *__restrict__ tab, const int q)
 {
-    __shared__ __attribute__((aligned(16))) char scratch[PROC_SMEM_TILED];
+    __shared__ __attribute__((aligned(16))) char scratch[PROC_SMEM];
     CVO_SLOT(tab);
     const ProcessArgs &a = CVO_ARG(ProcessArgs, op[q].p);
     ProcHead hd = proc_head_global<MODE>(a, a.st, 0);
@@ -2327,7 +2155,7 @@ kt_process(const Slot *__restrict__ tab, const int q)
 
 __global__ void __launch_bounds__(BLOCK) kt_flow_d2(const Slot *__restrict__ tab, const int q)
 {
-    __shared__ __attribute__((aligned(16))) char scratch[PROC_SMEM_TILED];
+    __shared__ __attribute__((aligned(16))) char scratch[PROC_SMEM];
     CVO_SLOT(tab);
     const ProcessArgs &a = CVO_ARG(ProcessArgs, op[q].p);
     process_body<PROC_FLOW, 0>(a, blockIdx.x, scratch, proc_head_global<PROC_FLOW>(a, a.st, 0));
@@ -2336,7 +2164,7 @@ __global__ void __launch_bounds__(BLOCK) kt_flow_d2(const Slot *__restrict__ tab
 // acvo, one registration: both self passes in one launch (blockIdx.y = xx / yy)
 __global__ void __launch_bounds__(BLOCK) kt_self2(const Slot *__restrict__ tab, const int q)
 {
-    __shared__ __attribute__((aligned(16))) char scratch[PROC_SMEM_TILED];
+    __shared__ __attribute__((aligned(16))) char scratch[PROC_SMEM];
     CVO_SLOT(tab);
     const ProcessArgs &a = CVO_ARG(ProcessArgs, op[q + blockIdx.y].p);
     process_body<PROC_SELF>(a, blockIdx.x, scratch, proc_head_global<PROC_SELF>(a, a.st, 0));
