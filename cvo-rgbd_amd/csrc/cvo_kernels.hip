@@ -1071,8 +1071,15 @@ __device__ __forceinline__ bool expand_lists(const ProcessArgs &a, const ProcHea
             mine_next = tl_next[min(e0 + (unsigned)lane * stride, a.subcap - 1)];
         }
         if (n > a.subcap) n = a.subcap;   // overflowed list: the iteration is redone anyway
+#ifdef CVO_NO_ENTRY_PF   // (A/B builds)
+        constexpr bool EPF = false;
+#else
+        constexpr bool EPF = PIPE;   // the next 64 entries are requested while these 64 are expanded and evaluated
+#endif
+        TileEntry ahead = mine;
         for (unsigned eb = e0; eb < n; eb += 64u * stride) {
-            if (eb != e0) mine = tl[min(eb + (unsigned)lane * stride, a.subcap - 1)];
+            if (eb != e0) mine = EPF ? ahead : tl[min(eb + (unsigned)lane * stride, a.subcap - 1)];
+            if (EPF && eb + 64u * stride < n) ahead = tl[min(eb + (64u + (unsigned)lane) * stride, a.subcap - 1)];
             const unsigned left = (n - eb + stride - 1) / stride;   // entries of this round
             const int cnt = (int)(left < 64u ? left : 64u);
             for (int k = 0; k < cnt; ++k) {
@@ -2141,8 +2148,11 @@ kt_filter_group(const Slot *__restrict__ tab, const int q)
 // less, which is what lets the flow pass of a crowded engine run seven waves per SIMD instead of six (64 / 256
 // distinct pairs per call 3 671 -> 3 775 / 4 166 -> 4 280 registrations/s; with the sum in, seven waves spill more
 // and acvo loses 1.5 %: profiles/r03_ab.txt 32)
+#ifndef CVO_FLOW_WAVES
+#define CVO_FLOW_WAVES 6   // (7 / 6 / 5 measured alike on the round-4 loops, profiles/r04_ab.txt 18)
+#endif
 template <int MODE, int WEIGHT = 0>
-__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((MODE == PROC_FLOW && WEIGHT == 0) ? 7 : 1, 8)))
+__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((MODE == PROC_FLOW && WEIGHT == 0) ? CVO_FLOW_WAVES : 1, 8)))
 kt_process(const Slot *__restrict__ tab, const int q)
 {
     __shared__ __attribute__((aligned(16))) char scratch[PROC_SMEM];
