@@ -302,9 +302,6 @@ struct ProcessArgs {
                            // exponent above kept_ebase and its 23 mantissa bits (kept_pack / kept_unpack: lossless).
                            // 0: 8 + 4 bytes (larger clouds, parameter sets whose weights span more, the MATLAB weight)
     unsigned kept_ebase;   // kept_packed == 2: the exponent field of the smallest weight there can be
-    unsigned cand_ebase;   // kept_packed == 2, candidate record of the xy list (round 4): i (18 bits) | j (18 bits) | the colour weight as
-                           // 4 bits of exponent above cand_ebase + 23 mantissa bits in 8 bytes; exponent code 15 = "cannot be a member"
-                           // (the colour cut failed, or the weight lies a binade below sp / sigma^2: a = ck k <= ck sigma^2 < sp)
 };
 
 // k_post flags

@@ -747,26 +747,6 @@ __device__ __forceinline__ void kept_unpack(const int mode, const unsigned ebase
     }
 }
 
-// Candidate records (ProcessArgs::cand).  Clouds of up to 65 536 rows: (i | j << 16, the colour weight's bits).  Up to 262 144 rows
-// (kept_packed == 2, the xy list): the first word is the kept entry's (i | j << 18), the second holds j's four high bits and the
-// weight in 27 bits -- see ProcessArgs::cand_ebase; a weight that cannot make a member comes back as 0.
-__device__ __forceinline__ uint2 cand_pack(const int mode, const unsigned ebase, const unsigned i, const unsigned j, const float ck)
-{
-    if (mode != 2) return make_uint2(i | (j << 16), __float_as_uint(ck));
-    const unsigned wb = __float_as_uint(ck);
-    const unsigned ef = wb >> 23;   // (ck >= 0: no sign bit)
-    const unsigned code = (ck > 0.0f && ef >= ebase) ? min(ef - ebase, 14u) : 15u;   // (host: the largest weight is within 14 binades)
-    return make_uint2(i | (j << 18), (j >> 14) | (code << 4) | ((wb & 0x7fffffu) << 8));
-}
-__device__ __forceinline__ void cand_unpack(const int mode, const unsigned ebase, const uint2 e, unsigned &i, unsigned &j, float &ck)
-{
-    if (mode != 2) { i = e.x & 0xffffu; j = e.x >> 16; ck = __uint_as_float(e.y); return; }
-    i = e.x & 0x3ffffu;
-    j = (e.x >> 18) | ((e.y & 0xfu) << 14);
-    const unsigned code = (e.y >> 4) & 0xfu;
-    ck = code == 15u ? 0.0f : __uint_as_float(((code + ebase) << 23) | (e.y >> 8));
-}
-
 // One pair of the exact pass.  PROC_FLOW / PROC_SELF: membership test of
 // se_kernel (ref cvo.cpp:125-152) and the flow / self sums; returns the weight
 // (0 = not in A).  PROC_STEP: `w` is the recorded weight of a member of A.
@@ -1051,7 +1031,7 @@ __device__ __forceinline__ bool expand_lists(const ProcessArgs &a, const ProcHea
             }
             if (REC) {   // every candidate goes on record, at the place the wave met it (its colour weight with it)
                 if (co + (unsigned)cnt <= a.kept_wcap) {
-                    if (lane < cnt) hd.cand[kbase + co + lane] = cand_pack(MODE == PROC_FLOW ? a.kept_packed : 1, a.cand_ebase, pr.x, pr.y, ck);
+                    if (lane < cnt) hd.cand[kbase + co + lane] = make_uint2(pr.x | (pr.y << 16), __float_as_uint(ck));
                 } else if (lane == 0) {
                     atomicOr(&a.st->ovf[hd.par][LIST_KEPT], 1u);   // slice full: grow and redo
                 }
@@ -1155,25 +1135,23 @@ __device__ __forceinline__ bool stream_candidates(const ProcessArgs &a, const Pr
     const CVO_GLOBAL char *kept_w = pin_global<PIPE>(a.kept_ij + base);
     wcap = pin_u32<PIPE>(wcap);
     constexpr bool PF = PIPE && kPrefetchBuild;   // the next round's records are requested behind this round's gathers
-    const int cmode = MODE == PROC_FLOW ? a.kept_packed : 1;   // (the self lists' records exist in the 16 + 16-bit form only)
-    const unsigned cbase = pin_u32<PIPE>(a.cand_ebase), kbase_e = pin_u32<PIPE>(a.kept_ebase);
     for (unsigned b0 = 0; b0 < n; b0 += 64u) {
         if (!PF && b0 != 0u) e = load8(cand_w, min(b0 + (unsigned)lane, wcap - 1u));
         uint2 e_next = e;
         uint2 *const pf = PF ? &e_next : nullptr;
-        unsigned ci, cj;
-        float ck;
-        cand_unpack(cmode, cbase, e, ci, cj, ck);
+        const unsigned ci = e.x & 0xffffu, cj = e.x >> 16;
         float w = 0.0f;
         if (b0 + (unsigned)lane < n) {
+            float ck = __uint_as_float(e.y);
             w = eval_pair<MODE, 0, 2>(src, hd, kc, ci, cj, 0.0f, acc, *hd.xi, s_etab, 0, &ck, pf, cand_w,
                                       min(b0 + 64u + (unsigned)lane, wcap - 1u));
         }
         const unsigned long long km = __ballot(w > 0.0f);
         if (MODE == PROC_FLOW && w > 0.0f) {   // (members <= candidates <= the slice: it cannot overflow here)
             const unsigned below = __builtin_amdgcn_mbcnt_hi((unsigned)(km >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)km, 0u));
-            // (the record's first word IS the kept entry's, in both packed forms)
-            store8(kept_w, nk + below, e.x, cmode == 2 ? kept_pack(2, kbase_e, ci, cj, w).y : __float_as_uint(w));
+            // (candidate records exist for clouds of up to 65536 rows only, whose kept entries are packed the same
+            // way: the record's first word IS the entry's)
+            store8(kept_w, nk + below, e.x, __float_as_uint(w));
         }
         nk += (unsigned)__popcll(km);
         if (PF) e = e_next;

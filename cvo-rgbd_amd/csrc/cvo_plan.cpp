@@ -280,19 +280,7 @@ int enqueue_process(cvo_hip_ctx *ctx, int mode, int list, DevBuf &part, const fl
         // (clouds of up to 65536 rows: i and j share a word.  12-byte records for larger clouds were built, bit-identical,
         // and measured SLOWER -- one 200k x 200k registration 81.3 -> 91.0 ms, 100k x 100k 21.7 -> 23.8, acvo 18.9 -> 21.8: at
         // those sizes the list passes are bound by memory requests and the record is more bytes to stream; profiles/r03_ab.txt 8)
-        // Round 4: clouds of 65 537 ... 262 144 rows keep an 8-byte record of the xy list too (18 + 18 bits of i and j, the colour
-        // weight in 27: ProcessArgs::cand_ebase) -- same bytes per candidate as below 65 537 rows, and the passes stream them with
-        // the next record in flight (profiles/r04_ab.txt 24).  The weight's range: (sp / sigma^2) / 2 ... c_sigma^2 within 14 binades.
-        bool big_rec = false;
-        if (a.kept_packed == 2 && mode == PROC_FLOW && !getenv("CVO_HIP_NO_BIG_CAND")) {
-            const float lo = 0.5f * (ctx->dprm.sp / (float)ctx->dprm.s2_d), hi = (float)ctx->dprm.cs2_d;
-            uint32_t blo, bhi;
-            std::memcpy(&blo, &lo, sizeof(blo));
-            std::memcpy(&bhi, &hi, sizeof(bhi));
-            const uint32_t elo = blo >> 23, ehi = bhi >> 23;
-            if (lo > 0.0f && hi > lo && elo >= 1 && ehi < 255 && ehi - elo <= 14) { big_rec = true; a.cand_ebase = elo; }
-        }
-        if (!no_cand && pre_transform(ctx) && !(ctx->prm.color_scale > 0.0f) && (a.kept_packed == 1 || big_rec)) {   // (the same plans: synchronous lists)
+        if (!no_cand && pre_transform(ctx) && !(ctx->prm.color_scale > 0.0f) && a.kept_packed == 1) {   // (the same plans: synchronous lists)
             // (an optimisation: if its memory cannot be had, the pass expands the tile list every time)
             int rc_c = ensure_buf(ctx, ctx->cand[list], (size_t)ctx->lists[LIST_KEPT].cap * sizeof(uint2));
             if (!rc_c) rc_c = ensure_buf(ctx, ctx->cand_cnt[list], PROC_WAVES * sizeof(uint32_t));
