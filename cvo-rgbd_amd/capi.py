@@ -23,7 +23,7 @@ SYMBOLS = [
     "cvo_hip_transform_pcd", "cvo_hip_flow", "cvo_hip_step_coeffs", "cvo_hip_pick_step",
     "cvo_hip_exp_se3", "cvo_hip_dist_se3", "cvo_hip_align", "cvo_hip_align_many",
     "cvo_hip_function_inner_product", "cvo_hip_function_inner_product_clouds",
-    "cvo_hip_engine_profiling", "cvo_hip_get_engine_profile", "cvo_hip_get_engine_flow_trace", "cvo_hip_get_wave_load", "cvo_hip_set_graph_capture", "cvo_hip_set_profiling", "cvo_hip_get_profile", "cvo_hip_get_graph_stats", "cvo_hip_synchronize",
+    "cvo_hip_engine_profiling", "cvo_hip_get_engine_profile", "cvo_hip_get_engine_flow_trace", "cvo_hip_get_wave_load", "cvo_hip_set_graph_capture", "cvo_hip_set_profiling", "cvo_hip_get_profile", "cvo_hip_get_graph_stats", "cvo_hip_get_run_stats", "cvo_hip_get_run_clocks", "cvo_hip_synchronize",
 ]
 
 
@@ -139,6 +139,8 @@ def lib():
     L.cvo_hip_set_profiling.argtypes = [vp, C.c_int]
     L.cvo_hip_get_profile.argtypes = [vp, C.POINTER(Profile), C.c_int]
     L.cvo_hip_get_graph_stats.argtypes = [vp, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]
+    L.cvo_hip_get_run_clocks.argtypes = [vp, C.POINTER(C.c_longlong)]
+    L.cvo_hip_get_run_stats.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.cvo_hip_synchronize.argtypes = [vp]
     for name in SYMBOLS:   # raises AttributeError if the library lacks a declared symbol
         if name not in ("cvo_hip_error_string", "cvo_hip_last_error"):
@@ -411,6 +413,18 @@ class Context:
         a, b = C.c_longlong(0), C.c_longlong(0)
         self._chk(self._L.cvo_hip_get_graph_stats(self._ctx, C.byref(a), C.byref(b)), "graph_stats")
         return a.value, b.value
+
+    def run_stats(self):
+        """(resident runs that executed iterations, runs that declined, iterations executed inside runs, candidates of the
+        record the last run looked at) of the last align()."""
+        a, b, c, d = C.c_int(0), C.c_int(0), C.c_int(0), C.c_int(0)
+        self._chk(self._L.cvo_hip_get_run_stats(self._ctx, C.byref(a), C.byref(b), C.byref(c), C.byref(d)), "run_stats")
+        return a.value, b.value, c.value, d.value
+
+    def run_clocks(self):
+        buf = (C.c_longlong * 8)()
+        self._chk(self._L.cvo_hip_get_run_clocks(self._ctx, buf), "run_clocks")
+        return list(buf)
 
     def synchronize(self):
         self._chk(self._L.cvo_hip_synchronize(self._ctx), "synchronize")

@@ -213,8 +213,13 @@ int cvo_hip_create(int device, void *stream, const cvo_hip_params *p, cvo_hip_ct
             return bail(CVO_HIP_ERR_HIP);
     ctx->done_mirror = reinterpret_cast<int32_t *>(&ctx->st_host[kPollSlots + 1]);
     ctx->progress_mirror = ctx->done_mirror + 16;   // (its own cache line)
+    ctx->run_mirror = ctx->done_mirror + 32;
+    ctx->hint_mirror = ctx->done_mirror + 48;
     *ctx->done_mirror = 0;
     *ctx->progress_mirror = 0;
+    *ctx->run_mirror = 0;
+    *ctx->hint_mirror = -1;
+    if (getenv("CVO_HIP_NO_RUN")) ctx->allow_run = false;   // (test switch: no resident runs, cvo_kernels.hip kt_run)
     // Stream capture is a process-wide affair in this runtime (cvo_lock.h): the library's own
     // entry points keep out of each other's captures, but HIP work of OTHER code in the process
     // (torch on another thread, say) cannot be kept out and would fail with "previous error
@@ -270,7 +275,7 @@ int cvo_hip_destroy(cvo_hip_ctx *ctx)
                     (void *)ctx->moving.feat, (void *)ctx->fixed.seg, (void *)ctx->moving.seg,
                     (void *)ctx->scratch_a.pos, (void *)ctx->scratch_a.feat, (void *)ctx->scratch_a.seg,
                     (void *)ctx->scratch_b.pos, (void *)ctx->scratch_b.feat, (void *)ctx->scratch_b.seg, (void *)ctx->st, (void *)ctx->st2, ctx->part_flow.p, ctx->part_xx.p,
-                    ctx->part_yy.p, ctx->part_step.p, (void *)ctx->trace_dev, ctx->kept_cnt.p, ctx->pos_bt.p, ctx->cand[0].p, ctx->cand[1].p, ctx->cand[2].p, ctx->cand_xyb.p, ctx->cand_cnt_xyb.p, ctx->cand_sfb[0].p, ctx->cand_sfb[1].p, ctx->cand_cnt_sfb[0].p, ctx->cand_cnt_sfb[1].p, ctx->cand_cnt[0].p,
+                    ctx->part_yy.p, ctx->part_step.p, ctx->run_mail.p, (void *)ctx->trace_dev, ctx->kept_cnt.p, ctx->pos_bt.p, ctx->cand[0].p, ctx->cand[1].p, ctx->cand[2].p, ctx->cand_xyb.p, ctx->cand_cnt_xyb.p, ctx->cand_sfb[0].p, ctx->cand_sfb[1].p, ctx->cand_cnt_sfb[0].p, ctx->cand_cnt_sfb[1].p, ctx->cand_cnt[0].p,
                     ctx->cand_cnt[1].p, ctx->cand_cnt[2].p})
         if (p) (void)hipFree(p);
     for (int l = 0; l < LIST_N; ++l) {
@@ -694,6 +699,24 @@ int cvo_hip_get_graph_stats(const cvo_hip_ctx *ctx, long long *launches_from_cac
     if (!ctx || !launches_from_cache || !captures) return CVO_HIP_ERR_INVALID;
     *launches_from_cache = ctx->plans.hits;
     *captures = ctx->plans.captures;
+    return CVO_HIP_OK;
+}
+
+int cvo_hip_get_run_stats(const cvo_hip_ctx *ctx, int *runs, int *declined, int *iterations, int *candidates)
+{
+    if (!ctx || !ctx->st_host) return CVO_HIP_ERR_INVALID;
+    const DevState &f = ctx->st_host[0];   // (the final state of the last align())
+    if (runs) *runs = f.run_entered;
+    if (declined) *declined = f.run_count - f.run_entered;
+    if (iterations) *iterations = f.run_iterations;
+    if (candidates) *candidates = f.run_candidates;
+    return CVO_HIP_OK;
+}
+
+int cvo_hip_get_run_clocks(const cvo_hip_ctx *ctx, long long clocks8[8])
+{
+    if (!ctx || !ctx->st_host || !clocks8) return CVO_HIP_ERR_INVALID;
+    for (int q = 0; q < 8; ++q) clocks8[q] = ctx->st_host[0].run_clk[q];
     return CVO_HIP_OK;
 }
 

@@ -106,6 +106,20 @@ struct CommTable {
     long long timeout_ticks;       // of the 100 MHz wall clock
 };
 
+// Resident runs (cvo_kernels.hip kt_run): RUN_G workgroups of RUN_BLOCK threads carry whole iterations of ONE
+// registration in one launch; between the passes they exchange their partial sums through a RunMail in device
+// memory -- every double as two 8-byte words (tag32 << 32 | half32), relaxed agent-scope atomic stores; a reader
+// polls the words themselves until the tags match (no flag, no fence; two generations: a block can be one
+// exchange ahead of the slowest reader, never two).  1.7 us per exchange among 32 blocks of one XCD
+// (tools/microbench/xcd_exchange.hip, profiles/r05_ab.txt 1).
+constexpr int RUN_G = 32;            // solver blocks of a run: blockIdx.x % 8 == 0 of a grid of 8 * RUN_G (one XCD)
+constexpr int RUN_BLOCK = 512;       // 8 waves = two per SIMD: 256 vector registers per lane, the run's candidates live there
+constexpr int RUN_WAVES = RUN_BLOCK / 64;
+constexpr int RUN_LANES = RUN_G * RUN_BLOCK;
+constexpr int RUN_R = 8;             // candidates per lane at most: RUN_LANES * RUN_R = 131 072 candidates per run
+constexpr int RUN_NV = 9;            // doubles per exchange at most (flow: 9, step: 4)
+struct RunMail { unsigned long long w[2][RUN_G][2 * RUN_NV]; };
+
 struct KernConsts {
     float tau;        // d2 < tau
     float tau_c;      // d2c < tau_c
@@ -209,10 +223,19 @@ struct DevState : DevHead {
     // bit k of built[l]: iteration k (mod 2048) rebuilt list l (profiling: which
     // k_filter launches did the work)
     uint32_t built[3][64];
+    // resident runs (kt_run) that have ended or declined since align() began: mirrored to the host, which sends the
+    // next batch when the run of the batch in flight is over
+    int32_t run_count;
+    int32_t run_entered;    // ... runs that executed at least one iteration, and the iterations executed inside runs (cvo_hip_get_run_stats)
+    int32_t run_iterations;
+    int32_t run_candidates; // candidates of the record the last run looked at
+    long long run_clk[8];   // CVO_RUN_CLOCKS builds: ticks of block 0 in entry / flow / exchange / twist / step / exchange / head / exit
     // exchanges done through the mailboxes since the context was created (never reset: the
     // sequence numbers of successive align() calls must keep alternating between the two
     // slot generations) -- kept last, align() re-initialises everything in front of it
     unsigned long long mail_seq;
+    // ... and the exchanges of resident runs (RunMail), likewise
+    unsigned long long run_seq;
 };
 static_assert(LIST_N <= 8, "DevState::ovf holds 8 lists");
 constexpr size_t DEVSTATE_INIT_BYTES = offsetof(DevState, mail_seq);
@@ -336,6 +359,11 @@ struct PostStepArgs {
                                 // batch when the running one is down to its last slot instead of a whole batch ahead
     int nblk;
     const CommTable *comm; // see PostFlowArgs
+    // resident runs (kt_run; null / 0: the plan has none)
+    RunMail *run_mail;
+    int32_t *run_mirror;   // pinned: DevState::run_count
+    int32_t *hint_mirror;  // pinned: members of A of the last executed iteration (the host picks the next batch's plan by it)
+    int run_iters;         // iterations per run at most
     DevParams prm;
 };
 
@@ -695,7 +723,7 @@ constexpr int STEP_TWIST_ROWS_DIV = 4;   // k_step_twist writes nblk / 4 partial
 // One launch of an iteration through a table: which kernel, its geometry, which op[] it reads.
 enum TKernel { TK_FILTER = 0, TK_FILTER_GROUP, TK_FLOW, TK_FLOW_MATLAB, TK_STEP, TK_SELF, TK_SELF2, TK_STEP_TWIST,
                TK_FLOW_BUILD, TK_FLOW_BUILD3, TK_FLOW_BUILD6, TK_POST_FLOW, TK_POST_STEP,
-               TK_HFLOW_BUILD, TK_HFLOW_BUILD6, TK_HSTEP_TWIST,
+               TK_HFLOW_BUILD, TK_HFLOW_BUILD6, TK_HSTEP_TWIST, TK_RUN /* q = flow op | step op << 4 */,
                TK_FLOW_D2 /* TK_FLOW is built without the sums of a and of a d2 (ProcessArgs::need_d2 == 0 in every slot); this one has them */ };   // head mode (cvo_kernels.hip "Head mode")
 // Head-mode launches carry the slot's parity and the mode in the bits above the op index of their
 // second kernel argument: qp = q | parity << 8 | QP_HEAD.

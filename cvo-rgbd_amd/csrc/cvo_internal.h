@@ -169,6 +169,7 @@ struct TableBuf {
 // address and on the plan -- kernels, grids, LDS sizes -- not on any argument: one capture
 // serves every frame pair (and every membership of a fused group) of the same shape.
 struct PlanGraph {
+    std::vector<TLaunch> pre;     // launched once in front of the iterations
     std::vector<TLaunch> plan;
     int iterations = 0;
     hipGraph_t graph = nullptr;
@@ -228,6 +229,12 @@ struct cvo_hip_ctx {
     DevState *st_host = nullptr;     // pinned [kPollSlots + 2]
     int32_t *done_mirror = nullptr;  // pinned (in the last slot): the post kernels copy `done` here
     int32_t *progress_mirror = nullptr;   // pinned, next to it: slots the post-step kernel has completed
+    int32_t *run_mirror = nullptr;        // pinned: resident runs (kt_run) that have ended since align() began
+    int32_t *hint_mirror = nullptr;       // pinned: members of A of the last executed iteration (-1: none yet)
+    DevBuf run_mail;                      // RunMail of this registration's resident runs
+    bool allow_run = true;                // CVO_HIP_NO_RUN
+    int run_nnz_max = 0;                  // a batch begins with a resident run when the last iteration had at most this many members
+    std::vector<TLaunch> plan_pre;        // launches in front of a RUN batch's iterations (the kt_run launch); empty: the plan has no run
     std::vector<RecOp> *rec = nullptr;   // not null: record launches instead of issuing them
     int proc_blocks = PROC_BLOCKS;       // blocks of the list kernels (fewer in fused launches)
     int proc_blocks_default = PROC_BLOCKS;
@@ -314,6 +321,8 @@ struct AlignJob {
     int phase = 0;          // 0 enqueueing/polling, 1 waiting for the final state, 2 finished
     int rc = CVO_HIP_OK;
     bool in_group = false;  // runs in a fused group (on the group's stream and table)
+    int runs_enq = 0;       // resident runs enqueued in this round
+    bool run_waiting = false;   // the last batch began with a resident run that has not reported its end yet
     bool paced = false;     // cvo_hip_align only: the calling thread has nothing else to pump and may sit in the
                             // paced loop of job_pump (align_many's blocking fall-back must keep its round-robin going:
                             // the other jobs -- the peer ranks of a mailbox world among them -- run dry otherwise)
@@ -354,12 +363,15 @@ int prepare_buffers(cvo_hip_ctx *ctx);
 int enqueue_iterations(cvo_hip_ctx *ctx, int count, int tag0, int trace_cap);
 void drop_graphs(cvo_hip_ctx *ctx);
 TLaunch mk_launch(int kernel, int q, unsigned gx, unsigned gz, unsigned smem = 0);
-bool plan_lone(const std::vector<RecOp> &ops, Slot &slot, std::vector<TLaunch> &plan, const bool allow_head, bool *head_mode);
+bool plan_lone(const std::vector<RecOp> &ops, Slot &slot, std::vector<TLaunch> &plan, const bool allow_head, bool *head_mode,
+               std::vector<TLaunch> *pre = nullptr);
 bool plan_fused(const std::vector<const std::vector<RecOp> *> &ops, const std::vector<Slot *> &slots, int zdim, std::vector<TLaunch> &plan);
-int run_plan(const Slot *tab, PlanCache &cache, const std::vector<TLaunch> &plan, hipStream_t s, bool use_graph, int iterations);
+int run_plan(const Slot *tab, PlanCache &cache, const std::vector<TLaunch> &plan, hipStream_t s, bool use_graph, int iterations,
+             const std::vector<TLaunch> *pre = nullptr);
 int record_iteration(cvo_hip_ctx *ctx, std::vector<RecOp> &ops, int trace_cap);
 int prepare_lone_plan(cvo_hip_ctx *ctx, int trace_cap);
-int launch_batch(cvo_hip_ctx *ctx, int tag0, int trace_cap);
+int launch_batch(cvo_hip_ctx *ctx, int tag0, int trace_cap, bool with_run = false);
+constexpr int kRunBatchSlots = 2;   // classic slots behind the resident run of a RUN batch (an even number, see kBatch)
 int zero_counters(cvo_hip_ctx *ctx);
 int push_state_fields(cvo_hip_ctx *ctx, size_t off, size_t bytes);
 int fetch_red(cvo_hip_ctx *ctx, int off, int count, double *out);

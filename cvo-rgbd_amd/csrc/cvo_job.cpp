@@ -23,6 +23,8 @@ int job_begin(AlignJob &j)
     }
     *ctx->done_mirror = 0;
     *ctx->progress_mirror = 0;
+    *ctx->run_mirror = 0;
+    *ctx->hint_mirror = -1;
     if (!j.trace) j.trace_cap = 0;
     if (j.trace_cap > p.max_iter) j.trace_cap = p.max_iter;
     if (j.trace_cap > ctx->trace_dev_cap) {
@@ -88,7 +90,14 @@ int job_begin(AlignJob &j)
         if (rc2) return rc2;
     }
     j.enq = j.batches = j.checked = 0;
+    j.runs_enq = 0;
+    j.run_waiting = false;
     j.executed_base = 0;
+    // (a batch begins with a resident run when the last iteration had at most this many members of A: the run holds
+    // RUN_LANES * RUN_R candidates in registers, about a third to a half of the candidates are members, and a run that
+    // finds more than it can hold declines, which costs its launch and one head)
+    ctx->run_nnz_max = 76000;
+    if (const char *e = getenv("CVO_HIP_RUN_NNZ")) ctx->run_nnz_max = atoi(e);   // (tuning switch)
     j.phase = p.max_iter <= 0 ? 1 : 0;
     if (j.phase == 1) {
         HIP_TRY(ctx, hipMemcpyAsync(&ctx->st_host[0], ctx->st, sizeof(DevState), hipMemcpyDeviceToHost,
@@ -164,23 +173,37 @@ int job_pump(AlignJob &j, bool block)
         int idle_seen = 0;
         for (;;) {
             if (*(volatile int32_t *)ctx->done_mirror != RUNNING) break;
+            // (the run counter first: a run publishes its slots before it reports its end)
+            const int runs = *(volatile int32_t *)ctx->run_mirror;
             const int slots = *(volatile int32_t *)ctx->progress_mirror;
             // (head mode without a flush: the post-step part of a batch's last slot runs in the head of the NEXT
             // batch's first launch, so the next batch must be on its way before the running one ends -- it goes
             // out when the running batch is down to its last slots; the GPU never idles between batches, and
             // a registration that stops in those last slots leaves one batch of launches that return at once)
             const int lead = ctx->head_mode ? 2 : 0;
-            if (j.enq - slots <= lead) {
+            bool go;
+            if (j.run_waiting) {
+                // a RUN batch: its length is the run's business; the next batch goes out when the run reports its end --
+                // the batch's kRunBatchSlots classic slots are what is left then
+                go = runs >= j.runs_enq;
+                if (go) { j.enq = slots + kRunBatchSlots; j.run_waiting = false; }
+            } else {
+                go = j.enq - slots <= lead;
+            }
+            if (go) {
                 if (j.enq >= limit) break;   // cannot happen
-                const int rc = launch_batch(ctx, j.executed_base + j.enq, j.trace_cap);
+                const int hint = *(volatile int32_t *)ctx->hint_mirror;
+                const bool with_run = ctx->head_mode && !ctx->plan_pre.empty() && hint >= 0 && hint <= ctx->run_nnz_max;
+                const int rc = launch_batch(ctx, j.executed_base + j.enq, j.trace_cap, with_run);
                 if (rc) return finish_with(rc);
-                j.enq += kBatch;
+                if (with_run) { ++j.runs_enq; j.run_waiting = true; }
+                else j.enq += kBatch;
                 ++j.batches;
                 spins = 0;
                 idle_seen = 0;
             } else {
                 __builtin_ia32_pause();
-                // The two words only move while the queued kernels run.  A fault, a stream in an error state or a
+                // The mirrors only move while the queued kernels run.  A fault, a stream in an error state or a
                 // post kernel that never ran would leave this thread spinning for ever: now and then ask the
                 // stream itself (a batch lasts ~0.25 ms; 2^14 pauses are about that long).
                 if ((++spins & 0x3fffu) == 0u) {
@@ -190,7 +213,7 @@ int job_pump(AlignJob &j, bool block)
                     // idle, yet the batch has not reported all its slots and nothing stopped: seen twice in a row
                     // (the mirrors are written before a kernel ends, so once is already conclusive; twice is cheap)
                     if (q == hipSuccess && *(volatile int32_t *)ctx->done_mirror == RUNNING &&
-                        *(volatile int32_t *)ctx->progress_mirror == slots) {
+                        *(volatile int32_t *)ctx->progress_mirror == slots && *(volatile int32_t *)ctx->run_mirror == runs) {
                         if (++idle_seen >= 2)
                             return finish_with(fail(ctx, CVO_HIP_ERR_HIP, "the align loop's stream went idle without progress"));
                     } else {
@@ -278,7 +301,11 @@ int job_pump(AlignJob &j, bool block)
         return finish_with(fail(ctx, CVO_HIP_ERR_HIP, "resume failed"));
     *ctx->done_mirror = 0;   // (the stream is idle: nothing can be writing it)
     *ctx->progress_mirror = 0;
+    *ctx->run_mirror = 0;
+    j.runs_enq = 0;
+    j.run_waiting = false;
     if (hipMemset(reinterpret_cast<char *>(ctx->st) + offsetof(DevState, n_slots), 0, sizeof(int32_t)) != hipSuccess ||
+        hipMemset(reinterpret_cast<char *>(ctx->st) + offsetof(DevState, run_count), 0, sizeof(int32_t)) != hipSuccess ||
         hipDeviceSynchronize() != hipSuccess)
         return finish_with(fail(ctx, CVO_HIP_ERR_HIP, "resume failed"));
     launch_prepare(ctx->st, loop_params(ctx), ctx->stream);   // idempotent; re-zeroes the counters

@@ -852,6 +852,93 @@ __device__ __forceinline__ cvo_math::XiConsts xi_uniform(const cvo_math::XiConst
     return xc;
 }
 
+// The sums of one member of A, shared by the list passes (eval_pair) and the resident runs (kt_run).
+// compute_flow (ref src/cvo.cpp:191-204): xi = x_i, yj = the transformed y_j, w = A_ij > 0, d2 = |x_i - y_j|^2
+__device__ __forceinline__ void pair_flow_sums(const KernConsts &kc, const float4 xi, const float4 yj, const float w, const float d2,
+                                           const int need_d2, double *acc)
+{
+    // cross(x_i, y_j), y_j - x_i ; (1/c * A_ij) * cross  (ref cvo.cpp:191-198)
+    const float c0 = xi.y * yj.z - xi.z * yj.y;
+    const float c1 = xi.z * yj.x - xi.x * yj.z;
+    const float c2 = xi.x * yj.y - xi.y * yj.x;
+    const float f0 = yj.x - xi.x, f1 = yj.y - xi.y, f2 = yj.z - xi.z;
+    const float ac = kc.inv_c * w, ad = kc.inv_d * w;
+    acc[0] += (double)(ac * c0);
+    acc[1] += (double)(ac * c1);
+    acc[2] += (double)(ac * c2);
+    acc[3] += (double)(ad * f0);
+    acc[4] += (double)(ad * f1);
+    acc[5] += (double)(ad * f2);
+    // (the sum of the weights goes into trace records and cvo_hip_flow's answer, the sum of a d2 is acvo's dl term:
+    // neither is read inside a cvo loop that keeps no trace -- ProcessArgs::need_d2)
+#ifdef CVO_SUM_A_ALWAYS   // (A/B builds: profiles/r04_ab.txt 12)
+    acc[6] += (double)w;
+    if (need_d2) acc[7] += (double)((kc.inv_l3 * w) * d2);
+#else
+    if (need_d2) {
+        acc[6] += (double)w;
+        acc[7] += (double)((kc.inv_l3 * w) * d2);
+    }
+#endif
+    // (acc[8], the number of members: counted per wave by the caller, not per pair here)
+}
+
+// compute_step_size (ref src/cvo.cpp:226-238,256-280): (e0, e1, e2) = x_i - y_j
+__device__ __forceinline__ void pair_step_sums(const KernConsts &kc, const cvo_math::XiConsts &xc, const float4 yj, const float e0,
+                                           const float e1, const float e2, const float w, double *acc)
+{
+    // Taylor vectors of y_j (ref cvo.cpp:226-238), for members of A only
+    float xiz[3], xi2z[3], xi3z[3], xi4z[3];
+    xiz[0] = (xc.omega[1] * yj.z - xc.omega[2] * yj.y) + xc.v[0];
+    xiz[1] = (xc.omega[2] * yj.x - xc.omega[0] * yj.z) + xc.v[1];
+    xiz[2] = (xc.omega[0] * yj.y - xc.omega[1] * yj.x) + xc.v[2];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        xi2z[r] = mv_row(xc.W2 + 3 * r, yj.x, yj.y, yj.z) + xc.u2[r];
+        xi3z[r] = mv_row(xc.W3 + 3 * r, yj.x, yj.y, yj.z) + xc.u3[r];
+        xi4z[r] = mv_row(xc.W4 + 3 * r, yj.x, yj.y, yj.z) + xc.u4[r];
+    }
+    const float normxiz2 = (xiz[0] * xiz[0] + xiz[1] * xiz[1]) + xiz[2] * xiz[2];
+    const float xz12 = -((xiz[0] * xi2z[0] + xiz[1] * xi2z[1]) + xiz[2] * xi2z[2]);
+    const float eps_c = ((xi2z[0] * xi2z[0] + xi2z[1] * xi2z[1]) + xi2z[2] * xi2z[2]) +
+                        2 * ((xiz[0] * xi3z[0] + xiz[1] * xi3z[1]) + xiz[2] * xi3z[2]);
+    // diff_xy = x_i - y_j is (e0,e1,e2); ref cvo.cpp:256-280
+    const float cb = kc.cb, cg = kc.cg, cd = kc.cd;
+    const float beta = ((cb * xiz[0]) * e0 + (cb * xiz[1]) * e1) + (cb * xiz[2]) * e2;
+    const float g_dot = ((2.0f * xi2z[0]) * e0 + (2.0f * xi2z[1]) * e1) + (2.0f * xi2z[2]) * e2;
+    const float gamma = cg * (normxiz2 + g_dot);
+    const float d_dot = ((-xi3z[0]) * e0 + (-xi3z[1]) * e1) + (-xi3z[2]) * e2;
+    const float delta = cd * (xz12 + d_dot);
+    const float e_dot = ((2.0f * xi4z[0]) * e0 + (2.0f * xi4z[1]) * e1) + (2.0f * xi4z[2]) * e2;
+    const float epsil = cg * (eps_c + e_dot);
+    const double A = (double)w;
+    const double b = (double)beta, g = (double)gamma;
+    acc[0] += (double)(w * beta);
+#ifdef CVO_STEP_TAIL_LITERAL
+    // the source line's operations one by one (ref cvo.cpp:275-280 under C's promotion rules): 33 float64-rate
+    // instructions per member; kept for A/B builds (profiles/r04_ab.txt 11)
+    acc[1] += A * (g + (double)(beta * beta) / 2.0);
+    acc[2] += A * ((double)(delta + beta * gamma) + div6((double)(beta * beta * beta)));
+    acc[3] += A * ((((double)(epsil + beta * delta) + 0.5 * b * b * g) + 0.5 * g * g) +
+                   1 / 24.0 * b * b * b * b);
+#else
+    // The float64 part of the terms with fused operations: every float32 product of the source line is formed
+    // and promoted as written (beta*beta, beta*beta*beta, delta + beta*gamma, epsil + beta*delta); what is
+    // fused are float64 operations whose separate roundings the reference's own sum order already outweighs
+    // (a term moves by <= 3 ulp(float64), the sum of ~10^5..10^6 of them is order-dependent at 10^-13).
+    // 20 float64-rate instructions per member instead of 33: the step pass is issue-bound while the kernel is
+    // wide (profiles/r04_ab.txt 8, 11).
+    acc[1] = __builtin_fma(A, __builtin_fma((double)(beta * beta), 0.5, g), acc[1]);
+    acc[2] = __builtin_fma(A, __builtin_fma((double)(beta * beta * beta), 0x1.5555555555555p-3,
+                                            (double)(delta + beta * gamma)), acc[2]);
+    const double b2 = b * b, hg = 0.5 * g;
+    double t = __builtin_fma(b2, hg, (double)(epsil + beta * delta));
+    t = __builtin_fma(hg, g, t);
+    t = __builtin_fma(b2 * (1 / 24.0), b2, t);
+    acc[3] = __builtin_fma(A, t, acc[3]);
+#endif
+}
+
 template <int MODE, int WEIGHT = 0, int CK = 0, class ARGS = ProcessArgs>
 __device__ __forceinline__ float eval_pair(const ARGS &a, const ProcHead &hd, const KernConsts &kc, unsigned i,
                                            unsigned j, float w, double *acc,
@@ -899,81 +986,9 @@ __device__ __forceinline__ float eval_pair(const ARGS &a, const ProcHead &hd, co
     }
     if (!(w > 0.0f)) return 0.0f;
     if (MODE == PROC_FLOW) {
-        // cross(x_i, y_j), y_j - x_i ; (1/c * A_ij) * cross  (ref cvo.cpp:191-198)
-        const float c0 = xi.y * yj.z - xi.z * yj.y;
-        const float c1 = xi.z * yj.x - xi.x * yj.z;
-        const float c2 = xi.x * yj.y - xi.y * yj.x;
-        const float f0 = yj.x - xi.x, f1 = yj.y - xi.y, f2 = yj.z - xi.z;
-        const float ac = kc.inv_c * w, ad = kc.inv_d * w;
-        acc[0] += (double)(ac * c0);
-        acc[1] += (double)(ac * c1);
-        acc[2] += (double)(ac * c2);
-        acc[3] += (double)(ad * f0);
-        acc[4] += (double)(ad * f1);
-        acc[5] += (double)(ad * f2);
-        // (the sum of the weights goes into trace records and cvo_hip_flow's answer, the sum of a d2 is acvo's dl term:
-        // neither is read inside a cvo loop that keeps no trace -- ProcessArgs::need_d2)
-#ifdef CVO_SUM_A_ALWAYS   // (A/B builds: profiles/r04_ab.txt 12)
-        acc[6] += (double)w;
-        if (hd.need_d2) acc[7] += (double)((kc.inv_l3 * w) * d2);
-#else
-        if (hd.need_d2) {
-            acc[6] += (double)w;
-            acc[7] += (double)((kc.inv_l3 * w) * d2);
-        }
-#endif
-        // (acc[8], the number of members: counted per wave by the caller, not per pair here)
+        pair_flow_sums(kc, xi, yj, w, d2, hd.need_d2, acc);
     } else if (MODE == PROC_STEP) {
-        // Taylor vectors of y_j (ref cvo.cpp:226-238), for members of A only
-        float xiz[3], xi2z[3], xi3z[3], xi4z[3];
-        xiz[0] = (xc.omega[1] * yj.z - xc.omega[2] * yj.y) + xc.v[0];
-        xiz[1] = (xc.omega[2] * yj.x - xc.omega[0] * yj.z) + xc.v[1];
-        xiz[2] = (xc.omega[0] * yj.y - xc.omega[1] * yj.x) + xc.v[2];
-#pragma unroll
-        for (int r = 0; r < 3; ++r) {
-            xi2z[r] = mv_row(xc.W2 + 3 * r, yj.x, yj.y, yj.z) + xc.u2[r];
-            xi3z[r] = mv_row(xc.W3 + 3 * r, yj.x, yj.y, yj.z) + xc.u3[r];
-            xi4z[r] = mv_row(xc.W4 + 3 * r, yj.x, yj.y, yj.z) + xc.u4[r];
-        }
-        const float normxiz2 = (xiz[0] * xiz[0] + xiz[1] * xiz[1]) + xiz[2] * xiz[2];
-        const float xz12 = -((xiz[0] * xi2z[0] + xiz[1] * xi2z[1]) + xiz[2] * xi2z[2]);
-        const float eps_c = ((xi2z[0] * xi2z[0] + xi2z[1] * xi2z[1]) + xi2z[2] * xi2z[2]) +
-                            2 * ((xiz[0] * xi3z[0] + xiz[1] * xi3z[1]) + xiz[2] * xi3z[2]);
-        // diff_xy = x_i - y_j is (e0,e1,e2); ref cvo.cpp:256-280
-        const float cb = kc.cb, cg = kc.cg, cd = kc.cd;
-        const float beta = ((cb * xiz[0]) * e0 + (cb * xiz[1]) * e1) + (cb * xiz[2]) * e2;
-        const float g_dot = ((2.0f * xi2z[0]) * e0 + (2.0f * xi2z[1]) * e1) + (2.0f * xi2z[2]) * e2;
-        const float gamma = cg * (normxiz2 + g_dot);
-        const float d_dot = ((-xi3z[0]) * e0 + (-xi3z[1]) * e1) + (-xi3z[2]) * e2;
-        const float delta = cd * (xz12 + d_dot);
-        const float e_dot = ((2.0f * xi4z[0]) * e0 + (2.0f * xi4z[1]) * e1) + (2.0f * xi4z[2]) * e2;
-        const float epsil = cg * (eps_c + e_dot);
-        const double A = (double)w;
-        const double b = (double)beta, g = (double)gamma;
-        acc[0] += (double)(w * beta);
-#ifdef CVO_STEP_TAIL_LITERAL
-        // the source line's operations one by one (ref cvo.cpp:275-280 under C's promotion rules): 33 float64-rate
-        // instructions per member; kept for A/B builds (profiles/r04_ab.txt 11)
-        acc[1] += A * (g + (double)(beta * beta) / 2.0);
-        acc[2] += A * ((double)(delta + beta * gamma) + div6((double)(beta * beta * beta)));
-        acc[3] += A * ((((double)(epsil + beta * delta) + 0.5 * b * b * g) + 0.5 * g * g) +
-                       1 / 24.0 * b * b * b * b);
-#else
-        // The float64 part of the terms with fused operations: every float32 product of the source line is formed
-        // and promoted as written (beta*beta, beta*beta*beta, delta + beta*gamma, epsil + beta*delta); what is
-        // fused are float64 operations whose separate roundings the reference's own sum order already outweighs
-        // (a term moves by <= 3 ulp(float64), the sum of ~10^5..10^6 of them is order-dependent at 10^-13).
-        // 20 float64-rate instructions per member instead of 33: the step pass is issue-bound while the kernel is
-        // wide (profiles/r04_ab.txt 8, 11).
-        acc[1] = __builtin_fma(A, __builtin_fma((double)(beta * beta), 0.5, g), acc[1]);
-        acc[2] = __builtin_fma(A, __builtin_fma((double)(beta * beta * beta), 0x1.5555555555555p-3,
-                                                (double)(delta + beta * gamma)), acc[2]);
-        const double b2 = b * b, hg = 0.5 * g;
-        double t = __builtin_fma(b2, hg, (double)(epsil + beta * delta));
-        t = __builtin_fma(hg, g, t);
-        t = __builtin_fma(b2 * (1 / 24.0), b2, t);
-        acc[3] = __builtin_fma(A, t, acc[3]);
-#endif
+        pair_step_sums(kc, xc, yj, e0, e1, e2, w, acc);
     } else {
         if (CK == 2 ? row_index >= 0 : row_index >= first_counted) acc[0] += (double)((kc.inv_l3 * w) * d2);
         // (acc[1], the number of members: counted per wave by the caller)
@@ -1965,6 +1980,48 @@ __device__ __forceinline__ void head_math(DevHead *lds, const PostStepArgs &a, c
     }
 }
 
+// What the publishing block does once the head's maths has run (all its threads): the tile lists the coming
+// launches rebuild are emptied, the others are kept ...
+template <int HM>
+__device__ __forceinline__ void head_prepare_lists(const PostStepArgs &a, const DevHead *s_st)
+{
+    const int tid = threadIdx.x;
+    const int nthr = blockDim.x;
+    const bool async = a.prm.async_xy != 0, aself = a.prm.async_self != 0;
+    if (!(s_st->done == RUNNING || s_st->done == NEED_BIGGER_LIST)) return;
+#pragma unroll
+    for (int l = 0; l < 3; ++l) {   // synchronous lists (classic plans)
+        if (s_st->reuse[l] || (async && l == LIST_XY) || (aself && l != LIST_XY)) continue;
+        for (int q = tid; q < NSUB; q += nthr) a.st->sub[l][q] = 0u;
+        if (tid == 0) atomicOr(&a.st->built[l][(s_st->k >> 5) & 63], 1u << (s_st->k & 31));
+    }
+    if (async && s_st->xy_target >= 0) {   // the build the plan has just named
+        const int l = s_st->xy_target ? (int)LIST_XYB : (int)LIST_XY;
+        for (int q = tid; q < NSUB; q += nthr) a.st->sub[l][q] = 0u;
+    }
+    if (aself)
+        for (int l = 0; l < 2; ++l)
+            if (s_st->sf_target[l] >= 0) {
+                const int id = self_list_id(l, s_st->sf_target[l]);
+                for (int q = tid; q < NSUB; q += nthr) a.st->sub[id][q] = 0u;
+            }
+    // classic: every launch of the coming slot flags its overflows in row 0 again (a parked
+    // loop keeps the flags: the host needs them to know what to grow)
+    if (HM == HM_CLASSIC && tid < 8 && s_st->done == RUNNING) a.st->ovf[0][tid] = 0u;
+}
+// ... and the head goes out: the host's mirrors, then the state
+__device__ __forceinline__ void head_publish(const PostStepArgs &a, const DevHead *s_st, DevHead *out, const bool math)
+{
+    if (threadIdx.x == 0) {
+        // (members of A of the last executed iteration: what the host picks the next batch's plan by, kt_run -- in front
+        // of the slot count the host paces its batches on)
+        if (math && a.hint_mirror) *a.hint_mirror = (int32_t)fmin(s_st->red[RED_FLOW + 8], 2.0e9);
+        if (math && a.progress_mirror) *a.progress_mirror = s_st->n_slots;
+        if (a.done_mirror && s_st->done != RUNNING) *a.done_mirror = s_st->done;
+    }
+    state_head_from_lds(s_st, out);
+}
+
 // The whole head of one block.  in / out: the copies of the state's head the launch reads / writes (the
 // same in the classic and flush forms); st: the state itself (the tail: sub-list counters, overflow
 // flags).  Returns true if the slot that begins may run (head mode: the loop is running, no stall).
@@ -1989,7 +2046,7 @@ __device__ __forceinline__ bool head_body(const PostStepArgs &a, const DevHead *
         if (HM == HM_HEAD && publisher) state_head_from_lds(s_st, out);
         return false;
     }
-    const bool async = a.prm.async_xy != 0, aself = a.prm.async_self != 0;
+    const bool async = a.prm.async_xy != 0;
     // a stall slot executed no iteration (asynchronous builds: only the plan runs)
     const bool stalled = async && s_st->stall != 0;
     const bool pending = HM == HM_CLASSIC ? true : (s_st->pending != 0);
@@ -2018,36 +2075,9 @@ __device__ __forceinline__ bool head_body(const PostStepArgs &a, const DevHead *
             }
         }
         __syncthreads();
-        // the tile lists the coming launches rebuild are emptied; the others are kept
-        if (publisher && (s_st->done == RUNNING || s_st->done == NEED_BIGGER_LIST)) {
-            {
-#pragma unroll
-                for (int l = 0; l < 3; ++l) {   // synchronous lists (classic plans)
-                    if (s_st->reuse[l] || (async && l == LIST_XY) || (aself && l != LIST_XY)) continue;
-                    for (int q = tid; q < NSUB; q += BLOCK) a.st->sub[l][q] = 0u;
-                    if (tid == 0) atomicOr(&a.st->built[l][(s_st->k >> 5) & 63], 1u << (s_st->k & 31));
-                }
-                if (async && s_st->xy_target >= 0) {   // the build the plan has just named
-                    const int l = s_st->xy_target ? (int)LIST_XYB : (int)LIST_XY;
-                    for (int q = tid; q < NSUB; q += BLOCK) a.st->sub[l][q] = 0u;
-                }
-                if (aself)
-                    for (int l = 0; l < 2; ++l)
-                        if (s_st->sf_target[l] >= 0) {
-                            const int id = self_list_id(l, s_st->sf_target[l]);
-                            for (int q = tid; q < NSUB; q += BLOCK) a.st->sub[id][q] = 0u;
-                        }
-            }
-            // classic: every launch of the coming slot flags its overflows in row 0 again (a parked
-            // loop keeps the flags: the host needs them to know what to grow)
-            if (HM == HM_CLASSIC && tid < 8 && s_st->done == RUNNING) a.st->ovf[0][tid] = 0u;
-        }
+        if (publisher) head_prepare_lists<HM>(a, s_st);
     }
-    if (publisher && tid == 0) {
-        if (math && a.progress_mirror) *a.progress_mirror = s_st->n_slots;
-        if (a.done_mirror && s_st->done != RUNNING) *a.done_mirror = s_st->done;
-    }
-    if (publisher) state_head_from_lds(s_st, out);
+    if (publisher) head_publish(a, s_st, out, math);
     return s_st->done == RUNNING && !(async && s_st->stall != 0);
 }
 
@@ -2415,6 +2445,427 @@ __device__ __forceinline__ ProcHead proc_head_lds(const ProcessArgs &a, const De
     }
 CVO_HEAD_KERNELS(_w4, 4)
 
+
+// ---------------------------------------------------------------------------
+// Resident runs (round 5): whole iterations of ONE registration in one launch.
+//
+// The narrow part of a registration on its own -- a few ten thousand candidates per iteration, the tile list and
+// its candidate record valid for the next dozen iterations -- spent its time at the two launch boundaries of an
+// iteration, in the prologues behind them and in the head's state load, not in its arithmetic (17 us per iteration
+// at 10k x 10k of which ~4 us are the two passes, profiles/r05_ab.txt 2).  kt_run executes up to `run_iters` WHOLE
+// iterations (ref src/cvo.cpp:366-410: transform, flow sums, twist, step sums, cubic, Exp, update, length scale,
+// stop tests) in ONE launch:
+//   * RUN_G = 32 blocks of 512 threads, the blocks with blockIdx.x % 8 == 0 of a grid of 256: one XCD (observed
+//     placement, used for speed only);
+//   * THE CANDIDATES LIVE IN REGISTERS for the life of the run.  The record of the tile list in use (ProcessArgs::cand,
+//     written by the classic flow pass after the last build) does not change while the list is re-used, and neither
+//     do x_i, y0_j and the colour weight of a candidate: at entry lane g takes candidates g, g + RUN_LANES, ...
+//     (a flat numbering over the record's slices: balanced whatever the slices hold), loads (i, j, ck), x_i and y0_j
+//     ONCE, and an iteration's flow pass is transform + exact test + sums on registers -- no memory access at all;
+//     the members' weights stay in registers for the step pass: no kept list either;
+//   * between the passes the 32 blocks exchange their partial sums through a RunMail (cvo_device.h): tagged 8-byte
+//     words, polled by everybody; every block adds all 32 rows in one fixed order and holds the same totals, bit for bit;
+//   * every block runs the twist constants and the head (cubic, Exp_SEK3, update, plan) itself, on its own copy of
+//     the state's head in LDS, exactly as a head-mode flow block does -- block 0 publishes (trace records, the
+//     host's mirrors) and writes the head back when the run ends.
+// A run is one launch of a head-mode plan's batch: [kt_run, HF, ST, HF, ST] (cvo_plan.cpp).  It starts where a
+// head-mode flow launch of parity 0 would (head in copy 0, the previous slot's step sums in part_step, its
+// overflow flags in row 1) and ends where a step launch of parity 1 leaves off (head in copy 0, pending, the last
+// slot's step sums as row 0 of part_step), so that classic launches and runs can follow each other in any order.
+// It declines -- returns with nothing written but the host's run counter -- unless the loop is running on a
+// candidate record that fits into the registers, and it ends after the slot whose head has named a list build
+// (the filter blocks of the next classic flow launch make it; two classic slots later the next run starts on the new
+// record), when the loop stops, or after `run_iters` iterations.  All blocks decide the same from the same inputs.
+// A poll that does not fill within RUN_TIMEOUT_TICKS ends the registration with DONE_COMM_ERROR instead of hanging.
+constexpr long long RUN_TIMEOUT_TICKS = 100000000LL;   // 1 s of the 100 MHz wall clock
+
+// One exchange: vals[0..NV) of this block (LDS, written before the call by threads < NV) -> tot[0..NV) = the sum of
+// all RUN_G blocks' values, rows added in ONE fixed order (four chains of eight, then a tree).  All threads call it.
+// seq: the exchange's number (every block counts the same).  Returns false on a time-out (block-uniform).
+template <int NV>
+__device__ __forceinline__ bool run_exchange(RunMail *mail, const unsigned rank, const unsigned long long seq, const double *vals,
+                                             double *all /* LDS [RUN_G * NV] */, double *tot /* LDS [NV] */, int *s_fail)
+{
+    const int tid = threadIdx.x;
+    const unsigned tag = (unsigned)seq;
+    unsigned long long *slot = &mail->w[seq & 1ull][0][0];
+    if (tid == 0) *s_fail = 0;
+    __syncthreads();   // (vals complete)
+    if (tid < 2 * NV) {
+        const unsigned long long bits = (unsigned long long)__double_as_longlong(vals[tid >> 1]);
+        const unsigned half = (tid & 1) ? (unsigned)(bits >> 32) : (unsigned)bits;
+        __hip_atomic_store(&slot[rank * (2 * RUN_NV) + tid], ((unsigned long long)tag << 32) | half, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+    }
+    static_assert(RUN_G * 2 * RUN_NV <= 2 * RUN_BLOCK, "two words per thread at most");
+    for (int wi = tid; wi < RUN_G * 2 * NV; wi += RUN_BLOCK) {
+        const int r = wi / (2 * NV), k = wi - r * (2 * NV);
+        const unsigned long long *src = &slot[r * (2 * RUN_NV) + k];
+        unsigned long long w = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((unsigned)(w >> 32) != tag) {
+            const long long t0 = (long long)wall_clock64();
+            do {
+                __builtin_amdgcn_s_sleep(1);
+                w = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((unsigned)(w >> 32) == tag) break;
+            } while ((long long)wall_clock64() - t0 <= RUN_TIMEOUT_TICKS);
+            if ((unsigned)(w >> 32) != tag) *s_fail = 1;
+        }
+        reinterpret_cast<unsigned *>(all)[r * (2 * NV) + k] = (unsigned)w;   // (little endian: word 2k is the low half of value k)
+    }
+    __syncthreads();
+    if (tid < NV) {
+        double c[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int q = 0; q < RUN_G / 4; ++q)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) c[u] += all[(u * (RUN_G / 4) + q) * NV + tid];
+        tot[tid] = (c[0] + c[1]) + (c[2] + c[3]);
+    }
+    __syncthreads();
+    return *s_fail == 0;
+}
+
+unsigned run_grid() { return 8u * RUN_G; }
+
+__global__ void __launch_bounds__(RUN_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
+kt_run(const Slot *__restrict__ tab, const int qs)
+{
+    if ((blockIdx.x & 7u) != 0u) return;
+    const unsigned rank = blockIdx.x >> 3;
+    CSlot cs = (CSlot)(tab);
+    if (cs->active == 0) return;
+    const int qf = qs & 15, qt = (qs >> 4) & 15;
+    const ProcessArgs &pa = CVO_ARG(ProcessArgs, op[qf].p);     // the flow pass of the plan's classic launches
+    const PostStepArgs ps = CVO_ARG(PostStepArgs, op[qf].ps);   // its head
+    const ProcessArgs &ta = CVO_ARG(ProcessArgs, op[qt].p);     // its step launch (the trace)
+    DevState *const gst = ps.st;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    __shared__ __attribute__((aligned(16))) DevHead s_st;
+    __shared__ double s_red[RUN_WAVES * NACC_MAX];
+    __shared__ double s_vals[NACC_MAX];
+    __shared__ double s_all[RUN_G * RUN_NV];
+    __shared__ double s_tot[NACC_MAX + 4];
+    __shared__ double s_etab[64];
+    __shared__ cvo_math::XiConsts s_xi;
+    __shared__ float s_wm[12];
+    __shared__ int s_fail;
+    __shared__ unsigned s_pref[PROC_WAVES + 1];
+    __shared__ unsigned s_wsum[RUN_WAVES];
+    __shared__ unsigned long long s_seq;
+
+#ifdef CVO_RUN_CLOCKS   // (A/B builds: where block 0's time goes, DevState::run_clk)
+    long long clk_t = (long long)__builtin_readcyclecounter(), clk_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define RUN_CLK(i) do { const long long n_ = (long long)__builtin_readcyclecounter(); clk_acc[i] += n_ - clk_t; clk_t = n_; } while (0)
+#else
+#define RUN_CLK(i) do { } while (0)
+#endif
+    // ---- entry: one round trip for the head, the previous slot's step sums, its overflow flags and the slice
+    // counts of both records
+    double sp[NACC_STEP];
+    thread_load_partials<NACC_STEP, PROC_BLOCKS / STEP_TWIST_ROWS_DIV>(ps.part_step, ps.nblk, sp);   // (threads >= BLOCK read rows beyond: guarded)
+    const unsigned my_flag = gst->ovf[1][tid & 7];
+    const int nsl = 4 * pa.nblk;   // slices of a record (waves of the pass that wrote it)
+    constexpr int PER = PROC_WAVES / RUN_BLOCK;   // 8 slices per thread
+    unsigned cnt_a[PER], cnt_b[PER];
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+        const int sl = tid * PER + q;
+        cnt_a[q] = (sl < nsl && pa.cand_cnt) ? pa.cand_cnt[sl] : 0u;
+        cnt_b[q] = (sl < nsl && pa.cand_cnt_b) ? pa.cand_cnt_b[sl] : 0u;
+    }
+    if (tid == 0) s_seq = gst->run_seq;
+    if (tid < 64) s_etab[tid] = c_exp2_64[tid];
+    state_head_to_lds(gst, &s_st);   // (with its barrier)
+    // block 0 alone tells the host that this run is over (whatever way it ends)
+    auto run_over = [&]() {
+        if (rank == 0 && tid == 0) {
+            const int c = gst->run_count + 1;
+            gst->run_count = c;
+            if (ps.run_mirror) *ps.run_mirror = c;
+        }
+    };
+    // what would make this launch a plain head-mode flow launch's business: a loop that has stopped, a stall slot,
+    // a build this launch's filter blocks would have to make
+    if (s_st.done != RUNNING || s_st.stall != 0 || s_st.xy_target >= 0 || pa.cand == nullptr || pa.cand_b == nullptr ||
+        ps.run_mail == nullptr) { run_over(); return; }
+    const unsigned long long seq0 = s_seq;
+    unsigned nexch = 0;
+
+    // the head of the first slot: post-step part of the slot that ended (if one is pending), plan of this one
+    {
+        const bool pending = s_st.pending != 0;
+        if (pending) {
+            // (the partial rows: BLOCK threads hold them, reduce as head_body does -- same order, same sums)
+            if (tid < BLOCK) {
+                wave_sums<NACC_STEP>(sp, lane, s_red + wid * NACC_MAX);
+            }
+            __syncthreads();
+            if (tid == 0) {
+#pragma unroll
+                for (int k = 0; k < NACC_STEP; ++k)
+                    s_st.red[RED_STEP + k] = ((s_red[k] + s_red[NACC_MAX + k]) + s_red[2 * NACC_MAX + k]) + s_red[3 * NACC_MAX + k];
+            }
+            __syncthreads();
+        }
+        if (tid < 64) {
+            unsigned flag[LIST_N];
+#pragma unroll
+            for (int l = 0; l < LIST_N; ++l) flag[l] = (unsigned)__builtin_amdgcn_readlane((int)my_flag, l);
+            long long clk[4] = {0, 0, 0, 0};
+            head_math<HM_HEAD>(&s_st, ps, pending, false, flag, rank == 0, false, clk);
+        }
+        __syncthreads();
+    }
+    // can the slot that begins run here?  (the loop is running on a buffer whose record is current and fits)
+    const int act = s_st.xy_active ? 1 : 0;
+    bool ok = s_st.done == RUNNING && s_st.stall == 0 && (act ? s_st.xy_ck[1] : s_st.xy_ck[0]) == pa.nblk;
+    // the record's slices, numbered flat: s_pref[s] = candidates in front of slice s
+    unsigned total = 0;
+    {
+        const unsigned wcap = pa.kept_wcap;
+        unsigned mine[PER], sum = 0;
+#pragma unroll
+        for (int q = 0; q < PER; ++q) {
+            const unsigned c = act ? cnt_b[q] : cnt_a[q];
+            mine[q] = sum;
+            sum += c < wcap ? c : wcap;
+        }
+        unsigned inc = sum;   // inclusive scan over the wave
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const unsigned o = (unsigned)__shfl_up((int)inc, off, 64);
+            if (lane >= off) inc += o;
+        }
+        if (lane == 63) s_wsum[wid] = inc;
+        __syncthreads();
+        unsigned base = 0;
+#pragma unroll
+        for (int w = 0; w < RUN_WAVES; ++w) {
+            const unsigned v = s_wsum[w];
+            if (w < wid) base += v;
+            total += v;
+        }
+        base += inc - sum;
+#pragma unroll
+        for (int q = 0; q < PER; ++q) s_pref[tid * PER + q] = base + mine[q];
+        if (tid == 0) s_pref[PROC_WAVES] = total;
+        __syncthreads();
+    }
+    if (rank == 0 && tid == 0) gst->run_candidates = (int32_t)total;
+    if (total > (unsigned)RUN_LANES * RUN_R || total == 0u) ok = false;
+    if (!ok) { run_over(); return; }   // (nothing has been written: the classic launches behind this one do the same head again)
+
+    // ---- the candidates of this lane: c = g + r * RUN_LANES
+    const unsigned wave_first = rank * RUN_BLOCK + (unsigned)wid * 64u;   // flat number of the wave's first candidate of round 0
+    const int rmax = wave_first < total ? (int)((total - wave_first + RUN_LANES - 1) / RUN_LANES) : 0;   // wave-uniform: rounds with any candidate
+    float cx[RUN_R][3], cy[RUN_R][3], cck[RUN_R], cw[RUN_R];
+    {
+        const uint2 *rec = act ? pa.cand_b : pa.cand;
+        const unsigned wcap = pa.kept_wcap;
+        uint2 e[RUN_R];
+#pragma unroll
+        for (int r = 0; r < RUN_R; ++r) {
+            e[r] = make_uint2(0u, 0u);
+            if (r < rmax) {
+                const unsigned c0 = wave_first + (unsigned)r * RUN_LANES;   // < total
+                // slice of c0: the last s with s_pref[s] <= c0, by two 64-way steps (s_pref is non-decreasing; PROC_WAVES = 64 * 64)
+                const unsigned coarse = s_pref[lane * 64];
+                const int k1 = __popcll(__ballot(coarse <= c0)) - 1;
+                const unsigned fine = s_pref[k1 * 64 + lane];
+                int sl = k1 * 64 + __popcll(__ballot(fine <= c0)) - 1;
+                const unsigned c = c0 + (unsigned)lane;
+                if (c < total) {
+                    while (c >= s_pref[sl + 1]) ++sl;   // (slices are a few dozen candidates long: a few steps)
+                    e[r] = rec[(size_t)sl * wcap + (c - s_pref[sl])];
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < RUN_R; ++r) {
+            cck[r] = 0.0f; cw[r] = 0.0f;
+            cx[r][0] = cx[r][1] = cx[r][2] = 0.0f;
+            cy[r][0] = cy[r][1] = cy[r][2] = 0.0f;
+            if (r < rmax) {
+                const bool have = wave_first + (unsigned)r * RUN_LANES + (unsigned)lane < total;
+                const float4 x = pa.pos_a[e[r].x & 0xffffu];
+                const float4 y = pa.pos_b[e[r].x >> 16];
+                cx[r][0] = x.x; cx[r][1] = x.y; cx[r][2] = x.z;
+                cy[r][0] = y.x; cy[r][1] = y.y; cy[r][2] = y.z;
+                cck[r] = have ? __uint_as_float(e[r].y) : 0.0f;   // (0: the pair is never a member)
+            }
+        }
+    }
+    // the row of flags the entry head has read is cleared as the slot's step launch would (nothing is flagged in a run);
+    // the counters of a build the entry head has named are zeroed as its flow launch would
+    if (rank == 0) {
+        if (tid < 8) gst->ovf[1][tid] = 0u;
+        head_prepare_lists<HM_HEAD>(ps, &s_st);
+    }
+
+    bool comm_ok = true;
+    const int need_d2 = pa.need_d2;
+    const int iters = ps.run_iters > 0 ? ps.run_iters : 1;
+    RUN_CLK(0);
+    for (int it = 0;; ++it) {
+        // ---- this slot's constants from the head in LDS: plain broadcast reads into vector registers (through scalar
+        // registers -- v_readfirstlane of every word -- the kernel spilled 200 of them and an iteration's two passes spent
+        // more time moving constants than on their pairs, profiles/r05_ab.txt 3)
+        float rt[12];
+#pragma unroll
+        for (int q = 0; q < 9; ++q) rt[q] = s_st.Rt[q];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) rt[9 + q] = s_st.t[q];
+        const KernConsts kc = s_st.kc;
+        // ---- flow pass (se_kernel's exact tests + compute_flow, ref src/cvo.cpp:125-152,164-210) on registers
+        double acc[NACC_FLOW];
+#pragma unroll
+        for (int k = 0; k < NACC_FLOW; ++k) acc[k] = 0.0;
+        unsigned nk = 0;
+#pragma unroll
+        for (int r = 0; r < RUN_R; ++r) {
+            if (r < rmax) {
+                const float4 xi = make_float4(cx[r][0], cx[r][1], cx[r][2], 0.0f);
+                const float4 yj = apply_tf(rt, rt + 9, make_float4(cy[r][0], cy[r][1], cy[r][2], 0.0f));
+                const float e0 = xi.x - yj.x, e1 = xi.y - yj.y, e2 = xi.z - yj.z;
+                const float d2 = __builtin_fmaf(e2, e2, __builtin_fmaf(e1, e1, e0 * e0));
+                const float ck = cck[r];
+                const float w = (d2 < kc.tau && ck > 0.0f) ? weight_from_ck(kc, d2, ck, s_etab) : 0.0f;
+                cw[r] = w;
+                if (w > 0.0f) pair_flow_sums(kc, xi, yj, w, d2, need_d2, acc);
+                nk += (unsigned)__popcll(__ballot(w > 0.0f));
+            }
+        }
+        if (lane == 0) acc[8] = (double)nk;
+        wave_sums<NACC_FLOW>(acc, lane, s_red + wid * NACC_MAX);
+        __syncthreads();
+        if (tid < NACC_FLOW) {
+            double t = 0.0;
+#pragma unroll
+            for (int q = 0; q < RUN_WAVES; ++q) t += s_red[q * NACC_MAX + tid];
+            s_vals[tid] = t;
+        }
+        RUN_CLK(1);
+        ++nexch;
+        if (!run_exchange<NACC_FLOW>(ps.run_mail, rank, seq0 + nexch, s_vals, s_all, s_tot, &s_fail)) { comm_ok = false; break; }
+        RUN_CLK(2);
+        // ---- the tail of compute_flow (ref src/cvo.cpp:201-209): twist, Taylor constants; block 0: the trace record
+        if (tid < 64) {
+            float omega[3], v[3];
+            for (int q = 0; q < 3; ++q) { omega[q] = (float)s_tot[q]; v[q] = (float)s_tot[3 + q]; }
+            xi_consts_wave(&s_xi, s_wm, omega, v, lane);
+            if (tid == 0) {
+                for (int q = 0; q < NACC_FLOW; ++q) s_st.red[RED_FLOW + q] = s_tot[q];
+                for (int q = 0; q < 4; ++q) s_st.red[RED_XX + q] = 0.0;
+                for (int q = 0; q < 3; ++q) { s_st.omega[q] = s_xi.omega[q]; s_st.v[q] = s_xi.v[q]; }
+                s_st.xi = s_xi;
+                s_st.dl = 0.0;
+                if (rank == 0 && ta.trace && s_st.k < ta.trace_cap) {
+                    cvo_hip_trace &tr = ta.trace[s_st.k];
+                    tr.k = s_st.k;
+                    tr.exit_code = 0;
+                    tr.ell = s_st.ell;
+                    for (int q = 0; q < 3; ++q) {
+                        tr.omega[q] = s_xi.omega[q]; tr.v[q] = s_xi.v[q];
+                        tr.omega_d[q] = s_tot[q]; tr.v_d[q] = s_tot[3 + q];
+                    }
+                    tr.sum_a = s_tot[6];
+                    tr.dl = 0.0;
+                    tr.nnz = (long long)s_tot[8]; tr.nnz_xx = 0; tr.nnz_yy = 0;
+                }
+            }
+        }
+        __syncthreads();
+        const cvo_math::XiConsts xc = s_xi;
+        RUN_CLK(3);
+        // ---- compute_step_size sums (ref src/cvo.cpp:213-289) over the members, whose weights are still in registers
+        double sacc[NACC_STEP];
+#pragma unroll
+        for (int k = 0; k < NACC_STEP; ++k) sacc[k] = 0.0;
+#pragma unroll
+        for (int r = 0; r < RUN_R; ++r) {
+            if (r < rmax) {
+                const float w = cw[r];
+                if (w > 0.0f) {
+                    const float4 yj = apply_tf(rt, rt + 9, make_float4(cy[r][0], cy[r][1], cy[r][2], 0.0f));
+                    pair_step_sums(kc, xc, yj, cx[r][0] - yj.x, cx[r][1] - yj.y, cx[r][2] - yj.z, w, sacc);
+                }
+            }
+        }
+        wave_sums<NACC_STEP>(sacc, lane, s_red + wid * NACC_MAX);
+        __syncthreads();
+        if (tid < NACC_STEP) {
+            double t = 0.0;
+#pragma unroll
+            for (int q = 0; q < RUN_WAVES; ++q) t += s_red[q * NACC_MAX + tid];
+            s_vals[tid] = t;
+        }
+        RUN_CLK(4);
+        ++nexch;
+        if (!run_exchange<NACC_STEP>(ps.run_mail, rank, seq0 + nexch, s_vals, s_all, s_tot, &s_fail)) { comm_ok = false; break; }
+        RUN_CLK(5);
+        // ---- the slot is complete but for its post-step part.  Leave here -- as a step launch would leave it -- when the
+        // head of this slot has named a build (the next classic flow launch's filter blocks make it) or the run is over
+        if (it + 1 >= iters || s_st.xy_target >= 0) {
+            if (rank == 0) {
+                // (the step sums as row 0 of the rows the next head reduces; the other rows are zero: x + 0 = x in any order)
+                for (int q = tid; q < NACC_STEP * ps.nblk; q += RUN_BLOCK) {
+                    const int k = q / ps.nblk, b = q - k * ps.nblk;
+                    const_cast<double *>(ps.part_step)[q] = b == 0 ? s_tot[k] : 0.0;
+                }
+                head_publish(ps, &s_st, gst, false);
+            }
+            break;
+        }
+        // ---- the head: cubic, break tests, Exp_SEK3, update, length scale, the plan of the next slot
+        // (ref src/cvo.cpp:291-307,380-410), in every block; block 0 publishes the mirrors
+        if (tid < NACC_STEP) s_st.red[RED_STEP + tid] = s_tot[tid];
+        __syncthreads();
+        if (tid < 64) {
+            unsigned flag[LIST_N];
+#pragma unroll
+            for (int l = 0; l < LIST_N; ++l) flag[l] = 0u;   // (nothing is built and no slice can overflow in a run)
+            long long clk[4] = {0, 0, 0, 0};
+            head_math<HM_HEAD>(&s_st, ps, true, false, flag, rank == 0, false, clk);
+        }
+        __syncthreads();
+        if (s_st.done != RUNNING || s_st.stall != 0) {
+            // the loop has stopped, or no buffer holds every pair any more (a jump): the head goes out as a head-mode flow
+            // launch would publish it (a stall slot runs no passes: the next launch's filter blocks build what it names)
+            if (rank == 0) {
+                head_prepare_lists<HM_HEAD>(ps, &s_st);
+                head_publish(ps, &s_st, gst, true);
+            }
+            break;
+        }
+        if (rank == 0 && tid == 0) {   // the host's mirrors, once per slot
+            if (ps.hint_mirror) *ps.hint_mirror = (int32_t)fmin(s_st.red[RED_FLOW + 8], 2.0e9);
+            if (ps.progress_mirror) *ps.progress_mirror = s_st.n_slots;
+        }
+        if (rank == 0) head_prepare_lists<HM_HEAD>(ps, &s_st);   // (a build this head has named: its counters)
+        RUN_CLK(6);
+    }
+    if (!comm_ok) {   // an exchange timed out: nothing of this run can be trusted
+        if (tid == 0) {
+            gst->done = DONE_COMM_ERROR;
+            if (ps.done_mirror) *ps.done_mirror = DONE_COMM_ERROR;
+        }
+    }
+    if (rank == 0 && tid == 0) {
+        gst->run_seq = seq0 + nexch;
+        gst->run_entered += 1;
+        gst->run_iterations += (int)(nexch / 2u);
+#ifdef CVO_RUN_CLOCKS
+        RUN_CLK(7);
+        for (int q = 0; q < 8; ++q) gst->run_clk[q] += clk_acc[q];
+#endif
+    }
+    __syncthreads();
+    run_over();
+}
+
 unsigned filter_grid_cap(long long nitems, long long cap) { return filter_grid_x(nitems, cap); }
 long long filter_blocks_cap() { return filter_blocks_max(); }
 
@@ -2446,6 +2897,7 @@ void launch_table(const Slot *tab, const TLaunch &l, hipStream_t s, hipEvent_t e
     case TK_HFLOW_BUILD: hipLaunchKernelGGL(kt_hflow_build_w4, g, dim3(BLOCK), l.smem, s, tab, qp); break;
     case TK_HFLOW_BUILD6: hipLaunchKernelGGL(kt_hflow_build6_w4, g, dim3(BLOCK), l.smem, s, tab, qp); break;
     case TK_HSTEP_TWIST: hipLaunchKernelGGL(kt_step_twist, g, dim3(STEP_BLOCK), 0, s, tab, qp); break;
+    case TK_RUN: hipLaunchKernelGGL(kt_run, dim3(run_grid()), dim3(RUN_BLOCK), 0, s, tab, l.q); break;
     default: break;
     }
 }

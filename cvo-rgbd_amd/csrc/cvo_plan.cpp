@@ -583,6 +583,22 @@ int enqueue_step(cvo_hip_ctx *ctx, int check_done, bool do_math, cvo_hip_trace *
     pa.part_step = (const double *)ctx->part_step.p;
     pa.dbg = ctx->post_dbg;
     pa.comm = ctx->comm_table;
+    // Resident runs (cvo_kernels.hip kt_run): one cvo registration with its launches to itself, in head mode, on
+    // candidate records (plan_lone decides whether the plan really is a head-mode plan)
+    if (ctx->plan_recording && ctx->lone && ctx->allow_head && ctx->allow_run && ctx->use_async && ctx->merge_twist &&
+        !multi_rank(ctx) && ctx->prm.mode == CVO_HIP_MODE_CVO && !(ctx->prm.color_scale > 0.0f) && !ctx->post_dbg) {
+        const bool fresh = ctx->run_mail.p == nullptr;
+        if (ensure_buf(ctx, ctx->run_mail, sizeof(RunMail)) == CVO_HIP_OK) {
+            if (fresh) HIP_TRY(ctx, hipMemsetAsync(ctx->run_mail.p, 0, sizeof(RunMail), loop_stream(ctx)));
+            pa.run_mail = (RunMail *)ctx->run_mail.p;
+            pa.run_mirror = ctx->run_mirror;
+            pa.run_iters = 64;
+        } else {   // (an optimisation: without its memory the plan has no runs)
+            (void)hipGetLastError();
+            ctx->err = "";
+        }
+    }
+    if (ctx->plan_recording && ctx->lone) pa.hint_mirror = ctx->hint_mirror;
     if (host_reduce(ctx)) {
         pa.flags = POST_REDUCE;
         emit_post_step(ctx, pa);
@@ -688,9 +704,11 @@ long long filter_items(const FilterArgs &f) { return (long long)f.gx * f.gy; }
 // Head mode (cvo_kernels.hip "the head"), where the scheme allows it -- asynchronous builds, step pass with the
 // twist in front, one rank: the post-step launch is gone; its argument block rides in the flow launch's entry
 // (op[q].ps), every flow / self block runs it as its head.
-bool plan_lone(const std::vector<RecOp> &ops, Slot &slot, std::vector<TLaunch> &plan, const bool allow_head, bool *head_mode)
+bool plan_lone(const std::vector<RecOp> &ops, Slot &slot, std::vector<TLaunch> &plan, const bool allow_head, bool *head_mode,
+               std::vector<TLaunch> *pre)
 {
     plan.clear();
+    if (pre) pre->clear();
     *head_mode = false;
     std::memset(&slot, 0, sizeof(slot));
     slot.active = 1;
@@ -783,8 +801,15 @@ bool plan_lone(const std::vector<RecOp> &ops, Slot &slot, std::vector<TLaunch> &
             o.np = std::max(8, flow.nblk);
             o.n0 = (int)std::max(8u, filter_grid_cap(filter_items(build), cap));
             if (head) { o.ps = ops[at + 1].ps; }
+            else { o.ps.run_mail = nullptr; }
             plan.push_back(mk_launch(head ? TK_HFLOW_BUILD : TK_FLOW_BUILD, q, (unsigned)(o.np + o.n0), 1,
                                      head ? smem_head(build.jt) : smem_of(build.jt)));
+            // a RUN batch begins with a resident run (kt_run reads the head's and the flow pass's arguments from this entry,
+            // the trace from the step launch's, which is the next one): candidate records on both buffers, the moving
+            // cloud read as it came
+            if (head && pre && o.ps.run_mail && flow.cand && flow.cand_b && flow.kept_packed == 1 && flow.tf_a == 0 && flow.tf_b == 1 &&
+                flow.weight == 0 && 4 * flow.nblk <= PROC_WAVES)
+                pre->push_back(mk_launch(TK_RUN, q | ((q + 1) << 4), 8u * RUN_G, 1));
             ++q;
         } else if (have_flow) {
             slot.op[q].p = flow;
@@ -942,23 +967,27 @@ bool same_plan(const std::vector<TLaunch> &a, const std::vector<TLaunch> &b)
     return a.size() == b.size() && (a.empty() || std::memcmp(a.data(), b.data(), a.size() * sizeof(TLaunch)) == 0);
 }
 
-void launch_plan_eager(const Slot *tab, const std::vector<TLaunch> &plan, int iterations, hipStream_t s)
+void launch_plan_eager(const Slot *tab, const std::vector<TLaunch> &plan, int iterations, hipStream_t s, const std::vector<TLaunch> *pre)
 {
+    if (pre)
+        for (const TLaunch &l : *pre) launch_table(tab, l, s, nullptr, nullptr, 0);
     for (int k = 0; k < iterations; ++k)
         for (const TLaunch &l : plan) launch_table(tab, l, s, nullptr, nullptr, k & 1);
 }
 
 // kBatch iterations of `plan` on table `tab`: through a cached graph when allowed, else eagerly.
 int run_plan(const Slot *tab, PlanCache &cache, const std::vector<TLaunch> &plan, hipStream_t s, bool use_graph,
-             int iterations)
+             int iterations, const std::vector<TLaunch> *pre)
 {
+    static const std::vector<TLaunch> none;
+    const std::vector<TLaunch> &front = pre ? *pre : none;
     if (!use_graph || cache.fails >= 64) {
-        launch_plan_eager(tab, plan, iterations, s);
+        launch_plan_eager(tab, plan, iterations, s, pre);
         return hipGetLastError() == hipSuccess ? CVO_HIP_OK : CVO_HIP_ERR_HIP;
     }
     PlanGraph *hit = nullptr;
     for (auto &g : cache.graphs)
-        if (g.iterations == iterations && same_plan(g.plan, plan)) { hit = &g; break; }
+        if (g.iterations == iterations && same_plan(g.plan, plan) && same_plan(g.pre, front)) { hit = &g; break; }
     if (hit) ++cache.hits;
     if (!hit) {
         // The capture window needs the library's lock exclusively (cvo_lock.h).  Not getting it within its
@@ -966,7 +995,7 @@ int run_plan(const Slot *tab, PlanCache &cache, const std::vector<TLaunch> &plan
         // failed one: this batch goes out eagerly, nothing is counted, the next batch tries again.
         cvo_lock::Capture alone;   // (held: no other thread of this library is inside the runtime)
         if (!alone.ok) {
-            launch_plan_eager(tab, plan, iterations, s);
+            launch_plan_eager(tab, plan, iterations, s, pre);
             return hipGetLastError() == hipSuccess ? CVO_HIP_OK : CVO_HIP_ERR_HIP;
         }
         ++cache.captures;
@@ -980,19 +1009,20 @@ int run_plan(const Slot *tab, PlanCache &cache, const std::vector<TLaunch> &plan
         }
         PlanGraph g;
         g.plan = plan;
+        g.pre = front;
         g.iterations = iterations;
         // A capture can be spoilt from outside (another thread's HIP work: cvo_lock.h).  Nothing
         // has been launched then: the batch goes out eagerly and the next one tries again.
         hipError_t e = hipErrorUnknown;
         if (hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed) == hipSuccess) {
-            launch_plan_eager(tab, plan, iterations, s);
+            launch_plan_eager(tab, plan, iterations, s, pre);
             e = hipStreamEndCapture(s, &g.graph);
         }
         if (e != hipSuccess || !g.graph || hipGraphInstantiate(&g.exec, g.graph, nullptr, nullptr, 0) != hipSuccess) {
             if (g.graph) (void)hipGraphDestroy(g.graph);
             (void)hipGetLastError();
             ++cache.fails;
-            launch_plan_eager(tab, plan, iterations, s);
+            launch_plan_eager(tab, plan, iterations, s, pre);
             return hipGetLastError() == hipSuccess ? CVO_HIP_OK : CVO_HIP_ERR_HIP;
         }
         cache.fails = 0;
@@ -1028,7 +1058,7 @@ int prepare_lone_plan(cvo_hip_ctx *ctx, int trace_cap)
     int rc = record_iteration(ctx, ops, trace_cap);
     if (rc) return rc;
     Slot slot;
-    if (!plan_lone(ops, slot, ctx->plan, ctx->allow_head, &ctx->head_mode))
+    if (!plan_lone(ops, slot, ctx->plan, ctx->allow_head, &ctx->head_mode, &ctx->plan_pre))
         return fail(ctx, CVO_HIP_ERR_INVALID, "launch plan does not fit the argument table");
     if (ctx->table.sync(&slot, loop_stream(ctx)) != 0) return fail(ctx, CVO_HIP_ERR_HIP, "argument table upload failed");
     return CVO_HIP_OK;
@@ -1037,14 +1067,17 @@ int prepare_lone_plan(cvo_hip_ctx *ctx, int trace_cap)
 // Launch one batch of kBatch iterations: through the context's table (graph or eager table
 // launches); profiling and the stream-level all-reduces (RCCL, caller's hook) keep the
 // classic by-value launches -- they need their own launches / host calls in between.
-int launch_batch(cvo_hip_ctx *ctx, int tag0, int trace_cap)
+// with_run: a RUN batch -- the plan's resident run, then kRunBatchSlots classic slots (job_pump asks for it when the plan has a
+// run and the registration is narrow enough)
+int launch_batch(cvo_hip_ctx *ctx, int tag0, int trace_cap, bool with_run)
 {
     if (ctx->profiling || host_reduce(ctx)) {
         const int rc = enqueue_iterations(ctx, kBatch, tag0, trace_cap);
         if (!rc) ctx->warm = true;
         return rc;
     }
-    const int rc = run_plan(ctx->table.dev, ctx->plans, ctx->plan, loop_stream(ctx), ctx->use_graphs, kBatch);
+    const int rc = with_run ? run_plan(ctx->table.dev, ctx->plans, ctx->plan, loop_stream(ctx), ctx->use_graphs, kRunBatchSlots, &ctx->plan_pre)
+                            : run_plan(ctx->table.dev, ctx->plans, ctx->plan, loop_stream(ctx), ctx->use_graphs, kBatch);
     if (rc) return fail(ctx, rc, "launching a batch of iterations failed");
     return CVO_HIP_OK;
 }

@@ -329,6 +329,14 @@ int cvo_hip_get_wave_load(cvo_hip_ctx *ctx, uint32_t *members_per_wave, int capa
 /* Diagnostics: batches of align() launched from a cached hipGraph / batches that had to be
  * captured first (a stream of frames should capture a handful of times, not per frame). */
 int cvo_hip_get_graph_stats(const cvo_hip_ctx *ctx, long long *launches_from_cache, long long *captures);
+/* Resident runs of the last cvo_hip_align (one cvo registration at a time runs the narrow part of its loop as whole
+ * iterations inside one launch, csrc/cvo_kernels.hip kt_run): launches of that kernel that executed iterations, launches
+ * that declined, iterations executed inside runs, candidate pairs of the record the last run looked at.  Diagnostics; any
+ * pointer may be null. */
+int cvo_hip_get_run_stats(const cvo_hip_ctx *ctx, int *runs, int *declined, int *iterations, int *candidates);
+/* ... and, in builds with -DCVO_RUN_CLOCKS, the ticks block 0 of the runs spent in: entry, flow pass, its exchange, twist
+ * constants, step pass, its exchange, head, exit (zeros otherwise). */
+int cvo_hip_get_run_clocks(const cvo_hip_ctx *ctx, long long clocks8[8]);
 int cvo_hip_synchronize(cvo_hip_ctx *ctx);
 
 #ifdef __cplusplus
