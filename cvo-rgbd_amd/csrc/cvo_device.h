@@ -189,7 +189,8 @@ struct alignas(16) DevHead {
     int32_t xy_ck[2];           // candidate record of xy buffer b (ProcessArgs::cand / cand_b): recorded by a flow pass of this
                                 // many blocks over the buffer as it stands; 0 = none (head mode, where the list is double-buffered)
     float xy_r[2];
-    float tauf_build, xy_pad_;
+    float tauf_build;
+    float r_last;               // sqrt(tau) of the plan before this one (0: none): scales the last iteration's member count to this one's radius
     float xy_Rt[2][9], xy_t[2][3];
     // the same for the two self lists of acvo (rigid: only the radius matters), [l][buffer]
     int32_t sf_active[2], sf_target[2], sf_fresh[2];
@@ -207,7 +208,9 @@ struct alignas(16) DevHead {
     int32_t n_exec;             // loop bodies executed
     int32_t n_slots;            // slots completed (iterations + stall slots): the host paces its batches on it
     int32_t pending;            // head mode: a slot has been started whose post-step part has not run yet
-    int32_t head_pad_[2];
+    int32_t run_hint;           // candidates expected in the record the slot that begins reads (prepare_iteration): what the host picks
+                                // the next batch's plan by (PostStepArgs::hint_mirror)
+    int32_t head_pad_;
 };
 struct DevState : DevHead {
     // ---- the TAIL: one copy per registration, at a fixed address (the head exists twice in
@@ -362,7 +365,7 @@ struct PostStepArgs {
     // resident runs (kt_run; null / 0: the plan has none)
     RunMail *run_mail;
     int32_t *run_mirror;   // pinned: DevState::run_count
-    int32_t *hint_mirror;  // pinned: members of A of the last executed iteration (the host picks the next batch's plan by it)
+    int32_t *hint_mirror;  // pinned: DevHead::run_hint (the host picks the next batch's plan by it)
     int run_iters;         // iterations per run at most
     DevParams prm;
 };
@@ -694,6 +697,17 @@ CVO_HD void prepare_iteration(DevHead *s, DevHead *bulk, const bool store, const
     const float r_now = sqrtf(s->kc.tau);
     plan_lists(s, bulk, store, p, r_now);
     if (p.async_xy) plan_xy_async(s, bulk, store, p, r_now, b.xy_fresh, b.xy_failed, b.xy_inflight);
+    {   // Candidates of the record the slot that begins will read -- what a resident run (kt_run) must hold in registers; the host
+        // picks the next batch's plan by it.  An estimate: the clouds are surfaces, so pairs within a radius go with its square
+        // (members of A per iteration at ell = 0.15 / 0.10 / 0.06 / 0.03: ratios 2.15, 2.73, 4.0), and a record of radius R holds
+        // ~1.05 (R / r)^2 candidates per member at radius r (1.64 at R = 1.25 r; profiles/r05_ab.txt 0, 4).
+        const float nnz = (float)s->red[RED_FLOW + 8];
+        const float q = s->r_last > 0.0f ? r_now / s->r_last : 1.0f;
+        const float rr = p.async_xy ? (s->xy_active ? s->xy_r[1] : s->xy_r[0]) : s->list_r[LIST_XY];
+        const float w = rr / r_now;
+        s->run_hint = (nnz > 0.0f && nnz < 1.0e9f) ? (int32_t)fminf(1.05f * nnz * (q * q) * (w * w), 2.0e9f) : 0;   // (NaN: an overflowed iteration)
+        s->r_last = r_now;
+    }
     if (p.async_self) {   // (after the xy plan: it may add a stall)
         const float slack = 1.0e-4f * (1.0f + s->xmax + s->y0max);
         const float r0 = r_now * 1.0001f + slack;

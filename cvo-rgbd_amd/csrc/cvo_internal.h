@@ -230,10 +230,10 @@ struct cvo_hip_ctx {
     int32_t *done_mirror = nullptr;  // pinned (in the last slot): the post kernels copy `done` here
     int32_t *progress_mirror = nullptr;   // pinned, next to it: slots the post-step kernel has completed
     int32_t *run_mirror = nullptr;        // pinned: resident runs (kt_run) that have ended since align() began
-    int32_t *hint_mirror = nullptr;       // pinned: members of A of the last executed iteration (-1: none yet)
+    int32_t *hint_mirror = nullptr;       // pinned: DevHead::run_hint, candidates expected in the record in use (-1: none yet)
     DevBuf run_mail;                      // RunMail of this registration's resident runs
     bool allow_run = true;                // CVO_HIP_NO_RUN
-    int run_nnz_max = 0;                  // a batch begins with a resident run when the last iteration had at most this many members
+    int run_nnz_max = 0;                  // a batch begins with a resident run when the record in use is expected to hold at most this many candidates
     std::vector<TLaunch> plan_pre;        // launches in front of a RUN batch's iterations (the kt_run launch); empty: the plan has no run
     std::vector<RecOp> *rec = nullptr;   // not null: record launches instead of issuing them
     int proc_blocks = PROC_BLOCKS;       // blocks of the list kernels (fewer in fused launches)
@@ -370,7 +370,8 @@ int run_plan(const Slot *tab, PlanCache &cache, const std::vector<TLaunch> &plan
              const std::vector<TLaunch> *pre = nullptr);
 int record_iteration(cvo_hip_ctx *ctx, std::vector<RecOp> &ops, int trace_cap);
 int prepare_lone_plan(cvo_hip_ctx *ctx, int trace_cap);
-int launch_batch(cvo_hip_ctx *ctx, int tag0, int trace_cap, bool with_run = false);
+int launch_batch(cvo_hip_ctx *ctx, int tag0, int trace_cap, bool with_run = false, int slots = kBatch);
+constexpr int kShortBatch = 4;      // classic slots of a batch while a resident run is within reach (job_pump)
 constexpr int kRunBatchSlots = 2;   // classic slots behind the resident run of a RUN batch (an even number, see kBatch)
 int zero_counters(cvo_hip_ctx *ctx);
 int push_state_fields(cvo_hip_ctx *ctx, size_t off, size_t bytes);

@@ -93,11 +93,10 @@ int job_begin(AlignJob &j)
     j.runs_enq = 0;
     j.run_waiting = false;
     j.executed_base = 0;
-    // (a batch begins with a resident run when the last iteration had at most this many members of A: the run holds
-    // RUN_LANES * RUN_R candidates in registers, about a third to a half of the candidates are members, and a run that
-    // finds more than it can hold declines, which costs its launch and one head)
-    ctx->run_nnz_max = 76000;
-    if (const char *e = getenv("CVO_HIP_RUN_NNZ")) ctx->run_nnz_max = atoi(e);   // (tuning switch)
+    // (a batch begins with a resident run when the record in use is expected to hold at most this many candidates -- DevHead::
+    // run_hint, an estimate; a run that finds more than it can hold declines, which costs its launch and one head)
+    ctx->run_nnz_max = (int)(0.95 * RUN_LANES * RUN_R);
+    if (const char *e = getenv("CVO_HIP_RUN_CAND")) ctx->run_nnz_max = atoi(e);   // (tuning switch)
     j.phase = p.max_iter <= 0 ? 1 : 0;
     if (j.phase == 1) {
         HIP_TRY(ctx, hipMemcpyAsync(&ctx->st_host[0], ctx->st, sizeof(DevState), hipMemcpyDeviceToHost,
@@ -193,11 +192,14 @@ int job_pump(AlignJob &j, bool block)
             if (go) {
                 if (j.enq >= limit) break;   // cannot happen
                 const int hint = *(volatile int32_t *)ctx->hint_mirror;
-                const bool with_run = ctx->head_mode && !ctx->plan_pre.empty() && hint >= 0 && hint <= ctx->run_nnz_max;
-                const int rc = launch_batch(ctx, j.executed_base + j.enq, j.trace_cap, with_run);
+                const bool with_run = ctx->head_mode && !ctx->plan_pre.empty() && hint > 0 && hint <= ctx->run_nnz_max;
+                // (a plan with runs whose record is within reach of one -- the length scale has dropped, the list is still the
+                // wide one -- goes out in short classic batches: a run can only start at a batch's head)
+                const bool near_run = ctx->head_mode && !ctx->plan_pre.empty() && !with_run && hint > 0 && hint <= 6 * ctx->run_nnz_max;
+                const int rc = launch_batch(ctx, j.executed_base + j.enq, j.trace_cap, with_run, near_run ? kShortBatch : kBatch);
                 if (rc) return finish_with(rc);
                 if (with_run) { ++j.runs_enq; j.run_waiting = true; }
-                else j.enq += kBatch;
+                else j.enq += near_run ? kShortBatch : kBatch;
                 ++j.batches;
                 spins = 0;
                 idle_seen = 0;

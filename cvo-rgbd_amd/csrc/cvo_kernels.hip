@@ -1959,7 +1959,7 @@ __device__ __forceinline__ void head_math(DevHead *lds, const PostStepArgs &a, c
 #pragma unroll
             for (int q = 0; q < 3; ++q) { lds->t[q] = L.t[q]; lds->tauf[q] = L.tauf[q]; lds->list_r[q] = L.list_r[q];
                                           lds->list_ok[q] = L.list_ok[q]; lds->reuse[q] = L.reuse[q]; lds->ck_nblk[q] = L.ck_nblk[q]; }
-            lds->kc_ell = L.kc_ell;
+            lds->kc_ell = L.kc_ell; lds->run_hint = L.run_hint; lds->r_last = L.r_last;
             lds->xy_active = L.xy_active; lds->xy_target = L.xy_target; lds->stall = L.stall; lds->xy_fresh = L.xy_fresh;
             lds->tauf_build = L.tauf_build;
 #pragma unroll
@@ -2013,9 +2013,9 @@ __device__ __forceinline__ void head_prepare_lists(const PostStepArgs &a, const 
 __device__ __forceinline__ void head_publish(const PostStepArgs &a, const DevHead *s_st, DevHead *out, const bool math)
 {
     if (threadIdx.x == 0) {
-        // (members of A of the last executed iteration: what the host picks the next batch's plan by, kt_run -- in front
+        // (members of A expected in the slot that begins: what the host picks the next batch's plan by, kt_run -- in front
         // of the slot count the host paces its batches on)
-        if (math && a.hint_mirror) *a.hint_mirror = (int32_t)fmin(s_st->red[RED_FLOW + 8], 2.0e9);
+        if (math && a.hint_mirror) *a.hint_mirror = s_st->run_hint;
         if (math && a.progress_mirror) *a.progress_mirror = s_st->n_slots;
         if (a.done_mirror && s_st->done != RUNNING) *a.done_mirror = s_st->done;
     }
@@ -2589,8 +2589,9 @@ kt_run(const Slot *__restrict__ tab, const int qs)
     };
     // what would make this launch a plain head-mode flow launch's business: a loop that has stopped, a stall slot,
     // a build this launch's filter blocks would have to make
+    // (... or a record that is expected to hold far more than a run's registers: decided before the head's maths, cheaply)
     if (s_st.done != RUNNING || s_st.stall != 0 || s_st.xy_target >= 0 || pa.cand == nullptr || pa.cand_b == nullptr ||
-        ps.run_mail == nullptr) { run_over(); return; }
+        ps.run_mail == nullptr || s_st.run_hint > 2 * RUN_LANES * RUN_R) { run_over(); return; }
     const unsigned long long seq0 = s_seq;
     unsigned nexch = 0;
 
@@ -2841,7 +2842,7 @@ kt_run(const Slot *__restrict__ tab, const int qs)
             break;
         }
         if (rank == 0 && tid == 0) {   // the host's mirrors, once per slot
-            if (ps.hint_mirror) *ps.hint_mirror = (int32_t)fmin(s_st.red[RED_FLOW + 8], 2.0e9);
+            if (ps.hint_mirror) *ps.hint_mirror = s_st.run_hint;
             if (ps.progress_mirror) *ps.progress_mirror = s_st.n_slots;
         }
         if (rank == 0) head_prepare_lists<HM_HEAD>(ps, &s_st);   // (a build this head has named: its counters)

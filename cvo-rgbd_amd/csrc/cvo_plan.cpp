@@ -1069,7 +1069,7 @@ int prepare_lone_plan(cvo_hip_ctx *ctx, int trace_cap)
 // classic by-value launches -- they need their own launches / host calls in between.
 // with_run: a RUN batch -- the plan's resident run, then kRunBatchSlots classic slots (job_pump asks for it when the plan has a
 // run and the registration is narrow enough)
-int launch_batch(cvo_hip_ctx *ctx, int tag0, int trace_cap, bool with_run)
+int launch_batch(cvo_hip_ctx *ctx, int tag0, int trace_cap, bool with_run, int slots)
 {
     if (ctx->profiling || host_reduce(ctx)) {
         const int rc = enqueue_iterations(ctx, kBatch, tag0, trace_cap);
@@ -1077,7 +1077,7 @@ int launch_batch(cvo_hip_ctx *ctx, int tag0, int trace_cap, bool with_run)
         return rc;
     }
     const int rc = with_run ? run_plan(ctx->table.dev, ctx->plans, ctx->plan, loop_stream(ctx), ctx->use_graphs, kRunBatchSlots, &ctx->plan_pre)
-                            : run_plan(ctx->table.dev, ctx->plans, ctx->plan, loop_stream(ctx), ctx->use_graphs, kBatch);
+                            : run_plan(ctx->table.dev, ctx->plans, ctx->plan, loop_stream(ctx), ctx->use_graphs, slots);
     if (rc) return fail(ctx, rc, "launching a batch of iterations failed");
     return CVO_HIP_OK;
 }
