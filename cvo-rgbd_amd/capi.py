@@ -422,7 +422,7 @@ class Context:
         return a.value, b.value, c.value, d.value
 
     def run_clocks(self):
-        buf = (C.c_longlong * 8)()
+        buf = (C.c_longlong * 16)()
         self._chk(self._L.cvo_hip_get_run_clocks(self._ctx, buf), "run_clocks")
         return list(buf)
 

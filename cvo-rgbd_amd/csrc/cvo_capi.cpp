@@ -713,10 +713,10 @@ int cvo_hip_get_run_stats(const cvo_hip_ctx *ctx, int *runs, int *declined, int 
     return CVO_HIP_OK;
 }
 
-int cvo_hip_get_run_clocks(const cvo_hip_ctx *ctx, long long clocks8[8])
+int cvo_hip_get_run_clocks(const cvo_hip_ctx *ctx, long long clocks16[16])
 {
-    if (!ctx || !ctx->st_host || !clocks8) return CVO_HIP_ERR_INVALID;
-    for (int q = 0; q < 8; ++q) clocks8[q] = ctx->st_host[0].run_clk[q];
+    if (!ctx || !ctx->st_host || !clocks16) return CVO_HIP_ERR_INVALID;
+    for (int q = 0; q < 16; ++q) clocks16[q] = ctx->st_host[0].run_clk[q];
     return CVO_HIP_OK;
 }
 

@@ -112,13 +112,13 @@ struct CommTable {
 // polls the words themselves until the tags match (no flag, no fence; two generations: a block can be one
 // exchange ahead of the slowest reader, never two).  1.7 us per exchange among 32 blocks of one XCD
 // (tools/microbench/xcd_exchange.hip, profiles/r05_ab.txt 1).
-constexpr int RUN_G = 32;            // solver blocks of a run: blockIdx.x % 8 == 0 of a grid of 8 * RUN_G (one XCD)
+constexpr int RUN_G = 32;            // solver blocks of a run at most (blocks 1 .. RUN_G of the launch; block 0 is the head block)
 constexpr int RUN_BLOCK = 512;       // 8 waves = two per SIMD: 256 vector registers per lane, the run's candidates live there
 constexpr int RUN_WAVES = RUN_BLOCK / 64;
 constexpr int RUN_LANES = RUN_G * RUN_BLOCK;
 constexpr int RUN_R = 8;             // candidates per lane at most: RUN_LANES * RUN_R = 131 072 candidates per run
 constexpr int RUN_NV = 9;            // doubles per exchange at most (flow: 9, step: 4)
-struct RunMail { unsigned long long w[2][RUN_G][2 * RUN_NV]; };
+struct RunMail { unsigned long long w[2][RUN_G + 1][2 * RUN_NV]; };   // (row RUN_G: the head block's verdict word)
 
 struct KernConsts {
     float tau;        // d2 < tau
@@ -232,7 +232,7 @@ struct DevState : DevHead {
     int32_t run_entered;    // ... runs that executed at least one iteration, and the iterations executed inside runs (cvo_hip_get_run_stats)
     int32_t run_iterations;
     int32_t run_candidates; // candidates of the record the last run looked at
-    long long run_clk[8];   // CVO_RUN_CLOCKS builds: ticks of block 0 in entry / flow / exchange / twist / step / exchange / head / exit
+    long long run_clk[16];  // CVO_RUN_CLOCKS builds: ticks of the first solver block by phase (tools/gpu_run_clocks.py)
     // exchanges done through the mailboxes since the context was created (never reset: the
     // sequence numbers of successive align() calls must keep alternating between the two
     // slot generations) -- kept last, align() re-initialises everything in front of it

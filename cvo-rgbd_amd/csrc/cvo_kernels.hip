@@ -1792,17 +1792,17 @@ enum HeadMode { HM_CLASSIC = 0, HM_HEAD = 1 };
 // straight to the LDS copy when they change (cvo_device.h `bulk`).
 // `flag[l]`: overflow flag of list l in the row the finished builds were flagged in.
 // `publisher`: this block writes the trace.
+// head_post: the post-step part (ref src/cvo.cpp:291-307,380-410) of the slot that ended -- cubic, stop tests, Exp_SEK3, update,
+// length scale -- on the head in LDS; leaves R, T, ell, the counters and `done` there.  `was_pending`: a slot is complete when the
+// head that follows it has run (head mode counts it then).
 template <int HM>
-__device__ __forceinline__ void head_math(DevHead *lds, const PostStepArgs &a, const bool run_post, const bool stalled,
-                                          const unsigned (&flag)[LIST_N], const bool publisher, const bool timed,
+__device__ __forceinline__ void head_post(DevHead *lds, const PostStepArgs &a, const bool run_post, const bool publisher, const bool timed,
                                           long long (&clk)[4])
 {
     const DevParams &p = a.prm;
     const bool acvo = p.mode == CVO_HIP_MODE_ACVO;
-    const bool async = p.async_xy != 0, aself = p.async_self != 0;
-    const bool lane0 = threadIdx.x == 0;
+    const bool lane0 = (threadIdx.x & 63) == 0;
     const bool was_pending = HM == HM_CLASSIC ? true : (lds->pending != 0);
-    // ---- stage 1: the fields of the post-step part
     float R[9], T[3], Rt[9], t[3], omega[3], v[3];
 #pragma unroll
     for (int q = 0; q < 9; ++q) { R[q] = lds->R[q]; Rt[q] = lds->Rt[q]; }
@@ -1815,37 +1815,11 @@ __device__ __forceinline__ void head_math(DevHead *lds, const PostStepArgs &a, c
     for (int q = 0; q < 4; ++q) bcde[q] = lds->red[RED_STEP + q];
     int k = lds->k, done = lds->done, iter = lds->iter, n_exec = lds->n_exec;
     const int n_slots = lds->n_slots + (was_pending ? 1 : 0);   // head mode: a slot is complete when the head that follows it has run
-    // what the builds that have ended made of their lists (judged by the plan below; worked out here, so
-    // that three verdicts travel down the chain instead of seven flags)
-    PlanBuilds pb = HM == HM_CLASSIC ? plan_builds_classic(lds, false, false, false) : plan_builds_head(lds, false, false, false);
-    pb.xy_failed = async && pb.xy_fresh >= 0 && (pb.xy_fresh ? flag[LIST_XYB] : flag[LIST_XY]) != 0u;
-    // (classic, synchronous self lists: a stall slot runs no k_step_twist / k_post_flow, which is where
-    // an overflow of the xx / yy lists is normally caught: lists built in a stall slot are checked here)
-    pb.sf_failed[0] = aself ? (pb.sf_fresh[0] >= 0 && (pb.sf_fresh[0] ? flag[LIST_XXB] : flag[LIST_XX]) != 0u)
-                            : (HM == HM_CLASSIC && stalled && flag[LIST_XX] != 0u);
-    pb.sf_failed[1] = aself ? (pb.sf_fresh[1] >= 0 && (pb.sf_fresh[1] ? flag[LIST_YYB] : flag[LIST_YY]) != 0u)
-                            : (HM == HM_CLASSIC && stalled && flag[LIST_YY] != 0u);
-    // (this iteration's flow pass has recorded or streamed the candidate list: it matches the tile list --
-    // until plan_lists schedules a rebuild)
-    // head mode: the flow pass of the slot that ended has recorded (or streamed) the candidates of the xy buffer
-    // it read -- a.ck_nblk[LIST_XY] blocks, unless its slice of the record overflowed
-    const int xy_ck_done = (HM == HM_HEAD && run_post && a.ck_nblk[LIST_XY] != 0 && flag[LIST_KEPT] == 0u) ? a.ck_nblk[LIST_XY] : 0;
-    const int xy_ck_buf = lds->xy_active ? 1 : 0;
-    const int sf_ck_done[2] = {(HM == HM_HEAD && run_post && flag[LIST_KEPT] == 0u) ? a.ck_nblk[LIST_XX] : 0,
-                               (HM == HM_HEAD && run_post && flag[LIST_KEPT] == 0u) ? a.ck_nblk[LIST_YY] : 0};
-    const int sf_ck_buf[2] = {lds->sf_active[0] ? 1 : 0, lds->sf_active[1] ? 1 : 0};
-    bool ck_ok[3] = {false, false, false};
-    if (HM == HM_CLASSIC && run_post && flag[LIST_KEPT] == 0u) {
-#pragma unroll
-        for (int l = 0; l < 3; ++l) ck_ok[l] = a.ck_nblk[l] != 0 && flag[l] == 0u;
-    }
-
-    bool plan = true;
     if (run_post) {
         if (timed) clk[0] = (long long)__builtin_readcyclecounter();
         const cvo_math::CubicBracket cb = cvo_math::cubic_bracket(bcde);
         const float step = cvo_math::finish_step(
-            cb.found, cb.found ? section_root_wave(cb, (int)threadIdx.x) : 0.0, p.min_step);
+            cb.found, cb.found ? section_root_wave(cb, (int)(threadIdx.x & 63)) : 0.0, p.min_step);
         if (timed) clk[1] = (long long)__builtin_readcyclecounter();
         cvo_hip_trace *tr = (publisher && lane0 && a.trace && k < a.trace_cap) ? &a.trace[k] : nullptr;
         if (tr) {
@@ -1875,7 +1849,6 @@ __device__ __forceinline__ void head_math(DevHead *lds, const PostStepArgs &a, c
             iter = k;
             done = DONE_BREAK_A;
             if (tr) tr->exit_code = 1;
-            plan = false;
         } else {
             // integrate: T = R*dT + T ; R = R*dR  (ref cvo.cpp:391-399)
             float dR[9], dT[3], RdT[3];
@@ -1896,7 +1869,6 @@ __device__ __forceinline__ void head_math(DevHead *lds, const PostStepArgs &a, c
                 iter = k;
                 done = DONE_BREAK_B;
                 if (tr) tr->exit_code = 2;
-                plan = false;
             } else {
                 // length-scale update
                 if (acvo) {   // ref src/adaptive_cvo.cpp:538-545
@@ -1911,33 +1883,65 @@ __device__ __forceinline__ void head_math(DevHead *lds, const PostStepArgs &a, c
                     ell = (k > 9) ? (float)0.06 : ell;
                     ell = (k > 19) ? (float)0.03 : ell;
                 }
-                if (k + 1 >= p.max_iter) {
-                    done = DONE_MAX_ITER;   // `iter` keeps its stale value
-                    plan = false;
-                }
+                if (k + 1 >= p.max_iter) done = DONE_MAX_ITER;   // `iter` keeps its stale value
                 k = k + 1;
             }
         }
         if (timed) clk[2] = (long long)__builtin_readcyclecounter();
     }
-    if (lane0) {   // (before the plan: its registers are free for it)
+    if (lane0) {
 #pragma unroll
         for (int q = 0; q < 9; ++q) lds->R[q] = R[q];
 #pragma unroll
         for (int q = 0; q < 3; ++q) lds->T[q] = T[q];
         lds->ell = ell; lds->ell_max = ell_max;
         lds->k = k; lds->iter = iter; lds->n_exec = n_exec; lds->n_slots = n_slots;
+        lds->done = done;
+        if (HM != HM_CLASSIC) lds->pending = 0;   // (head_plan raises it again if this launch starts the next slot)
     }
+}
+
+// head_plan: the plan of the slot that begins (cvo_device.h prepare_iteration) on a private copy of the head's plan fields
+// (registers), lane 0 puts back what changed.  The large, rarely written fields (transform records, kernel constants) go
+// straight to the LDS copy when they change (cvo_device.h `bulk`).  Follows head_post in the same wave (the loop must be running).
+// `flag[l]`: overflow flag of list l in the row the finished builds were flagged in; `ran_post`: head_post executed a slot.
+template <int HM>
+__device__ __forceinline__ void head_plan(DevHead *lds, const PostStepArgs &a, const bool ran_post, const bool stalled,
+                                          const unsigned (&flag)[LIST_N])
+{
+    const DevParams &p = a.prm;
+    const bool async = p.async_xy != 0, aself = p.async_self != 0;
+    const bool lane0 = (threadIdx.x & 63) == 0;
+    // what the builds that have ended made of their lists (judged by the plan below; worked out here, so
+    // that three verdicts travel down the chain instead of seven flags)
+    PlanBuilds pb = HM == HM_CLASSIC ? plan_builds_classic(lds, false, false, false) : plan_builds_head(lds, false, false, false);
+    pb.xy_failed = async && pb.xy_fresh >= 0 && (pb.xy_fresh ? flag[LIST_XYB] : flag[LIST_XY]) != 0u;
+    // (classic, synchronous self lists: a stall slot runs no k_step_twist / k_post_flow, which is where
+    // an overflow of the xx / yy lists is normally caught: lists built in a stall slot are checked here)
+    pb.sf_failed[0] = aself ? (pb.sf_fresh[0] >= 0 && (pb.sf_fresh[0] ? flag[LIST_XXB] : flag[LIST_XX]) != 0u)
+                            : (HM == HM_CLASSIC && stalled && flag[LIST_XX] != 0u);
+    pb.sf_failed[1] = aself ? (pb.sf_fresh[1] >= 0 && (pb.sf_fresh[1] ? flag[LIST_YYB] : flag[LIST_YY]) != 0u)
+                            : (HM == HM_CLASSIC && stalled && flag[LIST_YY] != 0u);
+    // (this iteration's flow pass has recorded or streamed the candidate list: it matches the tile list --
+    // until plan_lists schedules a rebuild)
+    // head mode: the flow pass of the slot that ended has recorded (or streamed) the candidates of the xy buffer
+    // it read -- a.ck_nblk[LIST_XY] blocks, unless its slice of the record overflowed
+    const int xy_ck_done = (HM == HM_HEAD && ran_post && a.ck_nblk[LIST_XY] != 0 && flag[LIST_KEPT] == 0u) ? a.ck_nblk[LIST_XY] : 0;
+    const int xy_ck_buf = lds->xy_active ? 1 : 0;
+    const int sf_ck_done[2] = {(HM == HM_HEAD && ran_post && flag[LIST_KEPT] == 0u) ? a.ck_nblk[LIST_XX] : 0,
+                               (HM == HM_HEAD && ran_post && flag[LIST_KEPT] == 0u) ? a.ck_nblk[LIST_YY] : 0};
+    const int sf_ck_buf[2] = {lds->sf_active[0] ? 1 : 0, lds->sf_active[1] ? 1 : 0};
+    bool ck_ok[3] = {false, false, false};
+    if (HM == HM_CLASSIC && ran_post && flag[LIST_KEPT] == 0u) {
+#pragma unroll
+        for (int l = 0; l < 3; ++l) ck_ok[l] = a.ck_nblk[l] != 0 && flag[l] == 0u;
+    }
+    int done = lds->done;
     int pending = 0;
-    if (plan) {
-        // ---- stage 2: the plan of the slot that begins (a stall slot: the state did not move, plan only)
+    {
+        // ---- the plan of the slot that begins (a stall slot: the state did not move, plan only)
         DevHead L;
         __builtin_memcpy(&L, lds, sizeof(DevHead));
-#pragma unroll
-        for (int q = 0; q < 9; ++q) L.R[q] = R[q];
-#pragma unroll
-        for (int q = 0; q < 3; ++q) L.T[q] = T[q];
-        L.ell = ell;
         if (HM == HM_CLASSIC) {
 #pragma unroll
             for (int l = 0; l < 3; ++l)
@@ -1971,13 +1975,21 @@ __device__ __forceinline__ void head_math(DevHead *lds, const PostStepArgs &a, c
                 lds->sf_r[q][0] = L.sf_r[q][0]; lds->sf_r[q][1] = L.sf_r[q][1];
                 lds->sf_tauf_build[q] = L.sf_tauf_build[q];
             }
+            lds->done = done;
+            if (HM != HM_CLASSIC) lds->pending = pending;
         }
     }
+}
+
+template <int HM>
+__device__ __forceinline__ void head_math(DevHead *lds, const PostStepArgs &a, const bool run_post, const bool stalled,
+                                          const unsigned (&flag)[LIST_N], const bool publisher, const bool timed,
+                                          long long (&clk)[4])
+{
+    head_post<HM>(lds, a, run_post, publisher, timed, clk);
+    // (one wave, LDS operations in order: the plan reads what the post-step part has just stored)
+    if (lds->done == RUNNING) head_plan<HM>(lds, a, run_post, stalled, flag);
     if (timed) clk[3] = (long long)__builtin_readcyclecounter();
-    if (lane0) {
-        lds->done = done;
-        if (HM != HM_CLASSIC) lds->pending = pending;
-    }
 }
 
 // What the publishing block does once the head's maths has run (all its threads): the tile lists the coming
@@ -2452,22 +2464,26 @@ CVO_HEAD_KERNELS(_w4, 4)
 // The narrow part of a registration on its own -- a few ten thousand candidates per iteration, the tile list and
 // its candidate record valid for the next dozen iterations -- spent its time at the two launch boundaries of an
 // iteration, in the prologues behind them and in the head's state load, not in its arithmetic (17 us per iteration
-// at 10k x 10k of which ~4 us are the two passes, profiles/r05_ab.txt 2).  kt_run executes up to `run_iters` WHOLE
+// at 10k x 10k of which ~4 us are the two passes, profiles/r05_ab.txt 0).  kt_run executes up to `run_iters` WHOLE
 // iterations (ref src/cvo.cpp:366-410: transform, flow sums, twist, step sums, cubic, Exp, update, length scale,
-// stop tests) in ONE launch:
-//   * RUN_G = 32 blocks of 512 threads, the blocks with blockIdx.x % 8 == 0 of a grid of 256: one XCD (observed
-//     placement, used for speed only);
-//   * THE CANDIDATES LIVE IN REGISTERS for the life of the run.  The record of the tile list in use (ProcessArgs::cand,
+// stop tests) in ONE launch of 1 + RUN_G blocks of 512 threads:
+//   * blocks 1 .. g are SOLVERS (g = 8, 16 or 32, as few as hold the record: an exchange costs by the block).  THE
+//     CANDIDATES LIVE IN REGISTERS for the life of the run.  The record of the tile list in use (ProcessArgs::cand,
 //     written by the classic flow pass after the last build) does not change while the list is re-used, and neither
-//     do x_i, y0_j and the colour weight of a candidate: at entry lane g takes candidates g, g + RUN_LANES, ...
+//     do x_i, y0_j and the colour weight of a candidate: at entry solver lane l takes candidates l, l + 512 g, ...
 //     (a flat numbering over the record's slices: balanced whatever the slices hold), loads (i, j, ck), x_i and y0_j
 //     ONCE, and an iteration's flow pass is transform + exact test + sums on registers -- no memory access at all;
 //     the members' weights stay in registers for the step pass: no kept list either;
-//   * between the passes the 32 blocks exchange their partial sums through a RunMail (cvo_device.h): tagged 8-byte
-//     words, polled by everybody; every block adds all 32 rows in one fixed order and holds the same totals, bit for bit;
-//   * every block runs the twist constants and the head (cubic, Exp_SEK3, update, plan) itself, on its own copy of
-//     the state's head in LDS, exactly as a head-mode flow block does -- block 0 publishes (trace records, the
-//     host's mirrors) and writes the head back when the run ends.
+//   * between the passes the solvers exchange their partial sums through a RunMail (cvo_device.h): tagged 8-byte
+//     words, polled by everybody; every block adds the g rows in one fixed order and holds the same totals, bit for bit;
+//   * every block runs the twist constants and the POST-STEP part of the head (cubic, Exp_SEK3, update, length scale,
+//     stop tests: head_post) itself, on its own copy of the state's head in LDS -- that chain is the critical path
+//     of an iteration and its result is needed everywhere;
+//   * block 0 is the HEAD BLOCK: no candidates, no row in the exchanges (it reads them).  It alone runs the PLAN of
+//     the next slot (head_plan: filter bounds, travel of the cloud against the lists' radii, builds) while the
+//     solvers are already in the slot's passes, and tells them what they need of it -- stall, build named -- in a
+//     verdict word that travels with the slot's second exchange; it writes the trace records and the host's mirrors
+//     and puts the head back when the run ends.
 // A run is one launch of a head-mode plan's batch: [kt_run, HF, ST, HF, ST] (cvo_plan.cpp).  It starts where a
 // head-mode flow launch of parity 0 would (head in copy 0, the previous slot's step sums in part_step, its
 // overflow flags in row 1) and ends where a step launch of parity 1 leaves off (head in copy 0, pending, the last
@@ -2478,29 +2494,35 @@ CVO_HEAD_KERNELS(_w4, 4)
 // record), when the loop stops, or after `run_iters` iterations.  All blocks decide the same from the same inputs.
 // A poll that does not fill within RUN_TIMEOUT_TICKS ends the registration with DONE_COMM_ERROR instead of hanging.
 constexpr long long RUN_TIMEOUT_TICKS = 100000000LL;   // 1 s of the 100 MHz wall clock
+enum { RUN_V_STALL = 1, RUN_V_BUILD = 2 };            // the head block's verdict on the slot that is running
 
-// One exchange: vals[0..NV) of this block (LDS, written before the call by threads < NV) -> tot[0..NV) = the sum of
-// all RUN_G blocks' values, rows added in ONE fixed order (four chains of eight, then a tree).  All threads call it.
-// seq: the exchange's number (every block counts the same).  Returns false on a time-out (block-uniform).
+// One exchange among the g solver blocks: vals[0..NV) of this block (LDS, written before the call by threads < NV; `row` < 0:
+// this block only reads) -> tot[0..NV) = the sum of the g rows, added in ONE fixed order (four chains, then a tree).  All
+// threads call it.  seq: the exchange's number (every block counts the same).  verdict_out (block-uniform, may be null): the
+// head block's verdict word of this exchange is waited for as well and handed out.  Returns false on a time-out (block-uniform).
 template <int NV>
-__device__ __forceinline__ bool run_exchange(RunMail *mail, const unsigned rank, const unsigned long long seq, const double *vals,
-                                             double *all /* LDS [RUN_G * NV] */, double *tot /* LDS [NV] */, int *s_fail)
+__device__ __forceinline__ bool run_exchange(RunMail *mail, const int row, const int g, const unsigned long long seq, const double *vals,
+                                             double *all /* LDS [RUN_G * NV] */, double *tot /* LDS [NV] */, int *s_fail,
+                                             unsigned *verdict_out, unsigned *s_verdict)
 {
     const int tid = threadIdx.x;
     const unsigned tag = (unsigned)seq;
     unsigned long long *slot = &mail->w[seq & 1ull][0][0];
     if (tid == 0) *s_fail = 0;
     __syncthreads();   // (vals complete)
-    if (tid < 2 * NV) {
+    if (row >= 0 && tid < 2 * NV) {
         const unsigned long long bits = (unsigned long long)__double_as_longlong(vals[tid >> 1]);
         const unsigned half = (tid & 1) ? (unsigned)(bits >> 32) : (unsigned)bits;
-        __hip_atomic_store(&slot[rank * (2 * RUN_NV) + tid], ((unsigned long long)tag << 32) | half, __ATOMIC_RELAXED,
+        __hip_atomic_store(&slot[row * (2 * RUN_NV) + tid], ((unsigned long long)tag << 32) | half, __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_AGENT);
     }
-    static_assert(RUN_G * 2 * RUN_NV <= 2 * RUN_BLOCK, "two words per thread at most");
-    for (int wi = tid; wi < RUN_G * 2 * NV; wi += RUN_BLOCK) {
-        const int r = wi / (2 * NV), k = wi - r * (2 * NV);
-        const unsigned long long *src = &slot[r * (2 * RUN_NV) + k];
+    static_assert(RUN_G * 2 * RUN_NV + 1 <= 3 * RUN_BLOCK, "a few words per thread");
+    const int nwords = g * 2 * NV + (verdict_out ? 1 : 0);
+    for (int wi = tid; wi < nwords; wi += RUN_BLOCK) {
+        const bool is_v = wi == g * 2 * NV;   // the verdict: word 0 of the row behind the solvers'
+        const int r = is_v ? RUN_G : wi / (2 * NV), k = is_v ? 0 : wi - r * (2 * NV);
+        // (the verdict's generation goes by the slot -- every second exchange carries one, their numbers have one parity)
+        const unsigned long long *src = is_v ? &mail->w[(seq >> 1) & 1ull][RUN_G][0] : &slot[r * (2 * RUN_NV) + k];
         unsigned long long w = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if ((unsigned)(w >> 32) != tag) {
             const long long t0 = (long long)wall_clock64();
@@ -2511,28 +2533,72 @@ __device__ __forceinline__ bool run_exchange(RunMail *mail, const unsigned rank,
             } while ((long long)wall_clock64() - t0 <= RUN_TIMEOUT_TICKS);
             if ((unsigned)(w >> 32) != tag) *s_fail = 1;
         }
-        reinterpret_cast<unsigned *>(all)[r * (2 * NV) + k] = (unsigned)w;   // (little endian: word 2k is the low half of value k)
+        if (is_v) *s_verdict = (unsigned)w;
+        else reinterpret_cast<unsigned *>(all)[r * (2 * NV) + k] = (unsigned)w;   // (little endian: word 2k is the low half of value k)
     }
     __syncthreads();
     if (tid < NV) {
         double c[4] = {0.0, 0.0, 0.0, 0.0};
+        const int gq = g >> 2;
+        for (int q = 0; q < gq; ++q)
 #pragma unroll
-        for (int q = 0; q < RUN_G / 4; ++q)
-#pragma unroll
-            for (int u = 0; u < 4; ++u) c[u] += all[(u * (RUN_G / 4) + q) * NV + tid];
+            for (int u = 0; u < 4; ++u) c[u] += all[(u * gq + q) * NV + tid];
         tot[tid] = (c[0] + c[1]) + (c[2] + c[3]);
     }
     __syncthreads();
+    if (verdict_out) *verdict_out = *s_verdict;
     return *s_fail == 0;
 }
 
-unsigned run_grid() { return 8u * RUN_G; }
+// The passes of a run over NR candidates per lane, straight-line: the NR chains (transform, exact test, a float64 exp, the
+// sums' terms) are independent and a lane has nothing else to hide their latency with -- two waves per SIMD --, so there is no
+// branch between them for the scheduler to stop at.  A candidate that is no member has w = 0 and every one of its terms is an
+// exact zero (0 x finite, summed into a float64: acc + 0 = acc), which is also what a lane without a candidate holds (ck = 0):
+// nothing is skipped and nothing changes.  (With a uniform branch per candidate a round cost ~1 600 ticks of a wave's time,
+// profiles/r05_ab.txt 6.)
+template <int NR>
+__device__ __forceinline__ unsigned run_flow_rounds(const float (&rt)[12], const KernConsts &kc, const float (&cx)[RUN_R][3],
+                                                     const float (&cy)[RUN_R][3], const float (&cck)[RUN_R], float (&cw)[RUN_R],
+                                                     const double *etab, const int need_d2, double (&acc)[NACC_FLOW])
+{
+    unsigned nk = 0;
+    asm volatile("; run_flow_rounds begin %0" ::"n"(NR));
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        const float4 xi = make_float4(cx[r][0], cx[r][1], cx[r][2], 0.0f);
+        const float4 yj = apply_tf(rt, rt + 9, make_float4(cy[r][0], cy[r][1], cy[r][2], 0.0f));
+        const float e0 = xi.x - yj.x, e1 = xi.y - yj.y, e2 = xi.z - yj.z;
+        const float d2 = __builtin_fmaf(e2, e2, __builtin_fmaf(e1, e1, e0 * e0));
+        const float ck = cck[r];
+        // (weight_from_ck's own comparison, as a select: the exp of a pair outside tau is formed and dropped)
+        const float a = ck * (float)(kc.s2_d * exp_neg((double)d2 * kc.ninv_2l2, etab));
+        const float w = (d2 < kc.tau && ck > 0.0f && a > kc.sp) ? a : 0.0f;
+        cw[r] = w;
+        pair_flow_sums(kc, xi, yj, w, d2, need_d2, acc);
+        nk += (unsigned)__popcll(__ballot(w > 0.0f));
+    }
+    asm volatile("; run_flow_rounds end %0" ::"n"(NR));
+    return nk;
+}
+template <int NR>
+__device__ __forceinline__ void run_step_rounds(const float (&rt)[12], const KernConsts &kc, const cvo_math::XiConsts &xc,
+                                                const float (&cx)[RUN_R][3], const float (&cy)[RUN_R][3], const float (&cw)[RUN_R],
+                                                double (&sacc)[NACC_STEP])
+{
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        const float4 yj = apply_tf(rt, rt + 9, make_float4(cy[r][0], cy[r][1], cy[r][2], 0.0f));
+        pair_step_sums(kc, xc, yj, cx[r][0] - yj.x, cx[r][1] - yj.y, cx[r][2] - yj.z, cw[r], sacc);
+    }
+}
+
+unsigned run_grid() { return 1u + RUN_G; }
 
 __global__ void __launch_bounds__(RUN_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
 kt_run(const Slot *__restrict__ tab, const int qs)
 {
-    if ((blockIdx.x & 7u) != 0u) return;
-    const unsigned rank = blockIdx.x >> 3;
+    const bool head_block = blockIdx.x == 0;
+    const int srow = (int)blockIdx.x - 1;   // a solver's row in the exchanges (-1: the head block)
     CSlot cs = (CSlot)(tab);
     if (cs->active == 0) return;
     const int qf = qs & 15, qt = (qs >> 4) & 15;
@@ -2552,12 +2618,15 @@ kt_run(const Slot *__restrict__ tab, const int qs)
     __shared__ cvo_math::XiConsts s_xi;
     __shared__ float s_wm[12];
     __shared__ int s_fail;
+    __shared__ unsigned s_verdict;
+    __shared__ double s_bak[NACC_FLOW];
+    __shared__ float s_bakf[6];
     __shared__ unsigned s_pref[PROC_WAVES + 1];
     __shared__ unsigned s_wsum[RUN_WAVES];
     __shared__ unsigned long long s_seq;
 
-#ifdef CVO_RUN_CLOCKS   // (A/B builds: where block 0's time goes, DevState::run_clk)
-    long long clk_t = (long long)__builtin_readcyclecounter(), clk_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#ifdef CVO_RUN_CLOCKS   // (A/B builds: where block 1's time goes, DevState::run_clk)
+    long long clk_t = (long long)__builtin_readcyclecounter(), clk_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #define RUN_CLK(i) do { const long long n_ = (long long)__builtin_readcyclecounter(); clk_acc[i] += n_ - clk_t; clk_t = n_; } while (0)
 #else
 #define RUN_CLK(i) do { } while (0)
@@ -2579,9 +2648,9 @@ kt_run(const Slot *__restrict__ tab, const int qs)
     if (tid == 0) s_seq = gst->run_seq;
     if (tid < 64) s_etab[tid] = c_exp2_64[tid];
     state_head_to_lds(gst, &s_st);   // (with its barrier)
-    // block 0 alone tells the host that this run is over (whatever way it ends)
+    // the head block alone tells the host that this run is over (whatever way it ends)
     auto run_over = [&]() {
-        if (rank == 0 && tid == 0) {
+        if (head_block && tid == 0) {
             const int c = gst->run_count + 1;
             gst->run_count = c;
             if (ps.run_mirror) *ps.run_mirror = c;
@@ -2595,7 +2664,7 @@ kt_run(const Slot *__restrict__ tab, const int qs)
     const unsigned long long seq0 = s_seq;
     unsigned nexch = 0;
 
-    // the head of the first slot: post-step part of the slot that ended (if one is pending), plan of this one
+    // the head of the first slot, whole, in every block: post-step part of the slot that ended (if one is pending), plan of this one
     {
         const bool pending = s_st.pending != 0;
         if (pending) {
@@ -2616,7 +2685,7 @@ kt_run(const Slot *__restrict__ tab, const int qs)
 #pragma unroll
             for (int l = 0; l < LIST_N; ++l) flag[l] = (unsigned)__builtin_amdgcn_readlane((int)my_flag, l);
             long long clk[4] = {0, 0, 0, 0};
-            head_math<HM_HEAD>(&s_st, ps, pending, false, flag, rank == 0, false, clk);
+            head_math<HM_HEAD>(&s_st, ps, pending, false, flag, head_block, false, clk);
         }
         __syncthreads();
     }
@@ -2655,13 +2724,18 @@ kt_run(const Slot *__restrict__ tab, const int qs)
         if (tid == 0) s_pref[PROC_WAVES] = total;
         __syncthreads();
     }
-    if (rank == 0 && tid == 0) gst->run_candidates = (int32_t)total;
+    if (head_block && tid == 0) gst->run_candidates = (int32_t)total;
     if (total > (unsigned)RUN_LANES * RUN_R || total == 0u) ok = false;
     if (!ok) { run_over(); return; }   // (nothing has been written: the classic launches behind this one do the same head again)
+    // as few solvers as give every lane one candidate: 8, 16 or 32 (an exchange among 8 blocks costs half of one among 32 in
+    // isolation, but a second candidate per lane costs a pass more than that saves: profiles/r05_ab.txt 1, 6)
+    const int g = total <= 8u * RUN_BLOCK ? 8 : (total <= 16u * RUN_BLOCK ? 16 : RUN_G);
+    if (srow >= g) return;
+    const unsigned lanes = (unsigned)g * RUN_BLOCK;
 
-    // ---- the candidates of this lane: c = g + r * RUN_LANES
-    const unsigned wave_first = rank * RUN_BLOCK + (unsigned)wid * 64u;   // flat number of the wave's first candidate of round 0
-    const int rmax = wave_first < total ? (int)((total - wave_first + RUN_LANES - 1) / RUN_LANES) : 0;   // wave-uniform: rounds with any candidate
+    // ---- the candidates of this lane: c = l + r * lanes
+    const unsigned wave_first = head_block ? total : (unsigned)srow * RUN_BLOCK + (unsigned)wid * 64u;   // flat number of the wave's first candidate of round 0
+    const int rmax = wave_first < total ? (int)((total - wave_first + lanes - 1) / lanes) : 0;   // wave-uniform: rounds with any candidate
     float cx[RUN_R][3], cy[RUN_R][3], cck[RUN_R], cw[RUN_R];
     {
         const uint2 *rec = act ? pa.cand_b : pa.cand;
@@ -2671,7 +2745,7 @@ kt_run(const Slot *__restrict__ tab, const int qs)
         for (int r = 0; r < RUN_R; ++r) {
             e[r] = make_uint2(0u, 0u);
             if (r < rmax) {
-                const unsigned c0 = wave_first + (unsigned)r * RUN_LANES;   // < total
+                const unsigned c0 = wave_first + (unsigned)r * lanes;   // < total
                 // slice of c0: the last s with s_pref[s] <= c0, by two 64-way steps (s_pref is non-decreasing; PROC_WAVES = 64 * 64)
                 const unsigned coarse = s_pref[lane * 64];
                 const int k1 = __popcll(__ballot(coarse <= c0)) - 1;
@@ -2690,7 +2764,7 @@ kt_run(const Slot *__restrict__ tab, const int qs)
             cx[r][0] = cx[r][1] = cx[r][2] = 0.0f;
             cy[r][0] = cy[r][1] = cy[r][2] = 0.0f;
             if (r < rmax) {
-                const bool have = wave_first + (unsigned)r * RUN_LANES + (unsigned)lane < total;
+                const bool have = wave_first + (unsigned)r * lanes + (unsigned)lane < total;
                 const float4 x = pa.pos_a[e[r].x & 0xffffu];
                 const float4 y = pa.pos_b[e[r].x >> 16];
                 cx[r][0] = x.x; cx[r][1] = x.y; cx[r][2] = x.z;
@@ -2701,7 +2775,7 @@ kt_run(const Slot *__restrict__ tab, const int qs)
     }
     // the row of flags the entry head has read is cleared as the slot's step launch would (nothing is flagged in a run);
     // the counters of a build the entry head has named are zeroed as its flow launch would
-    if (rank == 0) {
+    if (head_block) {
         if (tid < 8) gst->ovf[1][tid] = 0u;
         head_prepare_lists<HM_HEAD>(ps, &s_st);
     }
@@ -2709,6 +2783,15 @@ kt_run(const Slot *__restrict__ tab, const int qs)
     bool comm_ok = true;
     const int need_d2 = pa.need_d2;
     const int iters = ps.run_iters > 0 ? ps.run_iters : 1;
+    // the head block's verdict on the slot that begins travels with the slot's second exchange (its number is known in advance)
+    auto post_verdict = [&](const unsigned long long seq_b) {
+        if (head_block && tid == 0) {
+            const unsigned v = (s_st.stall != 0 ? (unsigned)RUN_V_STALL : 0u) | (s_st.xy_target >= 0 ? (unsigned)RUN_V_BUILD : 0u);
+            __hip_atomic_store(&ps.run_mail->w[(seq_b >> 1) & 1ull][RUN_G][0], ((seq_b & 0xffffffffull) << 32) | v, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+        }
+    };
+    post_verdict(seq0 + 2);
     RUN_CLK(0);
     for (int it = 0;; ++it) {
         // ---- this slot's constants from the head in LDS: plain broadcast reads into vector registers (through scalar
@@ -2720,97 +2803,123 @@ kt_run(const Slot *__restrict__ tab, const int qs)
 #pragma unroll
         for (int q = 0; q < 3; ++q) rt[9 + q] = s_st.t[q];
         const KernConsts kc = s_st.kc;
+        RUN_CLK(1);
         // ---- flow pass (se_kernel's exact tests + compute_flow, ref src/cvo.cpp:125-152,164-210) on registers
         double acc[NACC_FLOW];
 #pragma unroll
         for (int k = 0; k < NACC_FLOW; ++k) acc[k] = 0.0;
         unsigned nk = 0;
+        static_assert(RUN_R == 8, "the cases below");
+        switch (rmax) {   // (wave-uniform; rounds beyond the wave's last candidate would be all zeros)
+        case 0: break;
+        case 1: nk = run_flow_rounds<1>(rt, kc, cx, cy, cck, cw, s_etab, need_d2, acc); break;
+        case 2: nk = run_flow_rounds<2>(rt, kc, cx, cy, cck, cw, s_etab, need_d2, acc); break;
+        case 3: nk = run_flow_rounds<3>(rt, kc, cx, cy, cck, cw, s_etab, need_d2, acc); break;
+        case 4: nk = run_flow_rounds<4>(rt, kc, cx, cy, cck, cw, s_etab, need_d2, acc); break;
+        case 5: case 6: nk = run_flow_rounds<6>(rt, kc, cx, cy, cck, cw, s_etab, need_d2, acc); break;
+        default: nk = run_flow_rounds<8>(rt, kc, cx, cy, cck, cw, s_etab, need_d2, acc); break;
+        }
+        RUN_CLK(2);
+        if (!head_block) {
+            if (lane == 0) acc[8] = (double)nk;
+            wave_sums<NACC_FLOW>(acc, lane, s_red + wid * NACC_MAX);
+            RUN_CLK(3);
+            __syncthreads();
+            if (tid < NACC_FLOW) {
+                double t = 0.0;
 #pragma unroll
-        for (int r = 0; r < RUN_R; ++r) {
-            if (r < rmax) {
-                const float4 xi = make_float4(cx[r][0], cx[r][1], cx[r][2], 0.0f);
-                const float4 yj = apply_tf(rt, rt + 9, make_float4(cy[r][0], cy[r][1], cy[r][2], 0.0f));
-                const float e0 = xi.x - yj.x, e1 = xi.y - yj.y, e2 = xi.z - yj.z;
-                const float d2 = __builtin_fmaf(e2, e2, __builtin_fmaf(e1, e1, e0 * e0));
-                const float ck = cck[r];
-                const float w = (d2 < kc.tau && ck > 0.0f) ? weight_from_ck(kc, d2, ck, s_etab) : 0.0f;
-                cw[r] = w;
-                if (w > 0.0f) pair_flow_sums(kc, xi, yj, w, d2, need_d2, acc);
-                nk += (unsigned)__popcll(__ballot(w > 0.0f));
+                for (int q = 0; q < RUN_WAVES; ++q) t += s_red[q * NACC_MAX + tid];
+                s_vals[tid] = t;
             }
         }
-        if (lane == 0) acc[8] = (double)nk;
-        wave_sums<NACC_FLOW>(acc, lane, s_red + wid * NACC_MAX);
-        __syncthreads();
-        if (tid < NACC_FLOW) {
-            double t = 0.0;
-#pragma unroll
-            for (int q = 0; q < RUN_WAVES; ++q) t += s_red[q * NACC_MAX + tid];
-            s_vals[tid] = t;
-        }
-        RUN_CLK(1);
+        RUN_CLK(4);
         ++nexch;
-        if (!run_exchange<NACC_FLOW>(ps.run_mail, rank, seq0 + nexch, s_vals, s_all, s_tot, &s_fail)) { comm_ok = false; break; }
-        RUN_CLK(2);
-        // ---- the tail of compute_flow (ref src/cvo.cpp:201-209): twist, Taylor constants; block 0: the trace record
+        if (!run_exchange<NACC_FLOW>(ps.run_mail, srow, g, seq0 + nexch, s_vals, s_all, s_tot, &s_fail, nullptr, &s_verdict)) { comm_ok = false; break; }
+        RUN_CLK(5);
+        // ---- the tail of compute_flow (ref src/cvo.cpp:201-209): twist, Taylor constants
         if (tid < 64) {
             float omega[3], v[3];
             for (int q = 0; q < 3; ++q) { omega[q] = (float)s_tot[q]; v[q] = (float)s_tot[3 + q]; }
             xi_consts_wave(&s_xi, s_wm, omega, v, lane);
             if (tid == 0) {
-                for (int q = 0; q < NACC_FLOW; ++q) s_st.red[RED_FLOW + q] = s_tot[q];
-                for (int q = 0; q < 4; ++q) s_st.red[RED_XX + q] = 0.0;
-                for (int q = 0; q < 3; ++q) { s_st.omega[q] = s_xi.omega[q]; s_st.v[q] = s_xi.v[q]; }
-                s_st.xi = s_xi;
-                s_st.dl = 0.0;
-                if (rank == 0 && ta.trace && s_st.k < ta.trace_cap) {
-                    cvo_hip_trace &tr = ta.trace[s_st.k];
-                    tr.k = s_st.k;
-                    tr.exit_code = 0;
-                    tr.ell = s_st.ell;
-                    for (int q = 0; q < 3; ++q) {
-                        tr.omega[q] = s_xi.omega[q]; tr.v[q] = s_xi.v[q];
-                        tr.omega_d[q] = s_tot[q]; tr.v_d[q] = s_tot[3 + q];
-                    }
-                    tr.sum_a = s_tot[6];
-                    tr.dl = 0.0;
-                    tr.nnz = (long long)s_tot[8]; tr.nnz_xx = 0; tr.nnz_yy = 0;
+                if (head_block) {   // (a stall verdict voids the slot: the head then goes out with the sums it came with)
+                    for (int q = 0; q < NACC_FLOW; ++q) s_bak[q] = s_st.red[RED_FLOW + q];
+                    for (int q = 0; q < 3; ++q) { s_bakf[q] = s_st.omega[q]; s_bakf[3 + q] = s_st.v[q]; }
                 }
+                for (int q = 0; q < NACC_FLOW; ++q) s_st.red[RED_FLOW + q] = s_tot[q];
+                for (int q = 0; q < 3; ++q) { s_st.omega[q] = s_xi.omega[q]; s_st.v[q] = s_xi.v[q]; }
             }
         }
         __syncthreads();
         const cvo_math::XiConsts xc = s_xi;
-        RUN_CLK(3);
+        RUN_CLK(6);
         // ---- compute_step_size sums (ref src/cvo.cpp:213-289) over the members, whose weights are still in registers
         double sacc[NACC_STEP];
 #pragma unroll
         for (int k = 0; k < NACC_STEP; ++k) sacc[k] = 0.0;
+        switch (rmax) {
+        case 0: break;
+        case 1: run_step_rounds<1>(rt, kc, xc, cx, cy, cw, sacc); break;
+        case 2: run_step_rounds<2>(rt, kc, xc, cx, cy, cw, sacc); break;
+        case 3: run_step_rounds<3>(rt, kc, xc, cx, cy, cw, sacc); break;
+        case 4: run_step_rounds<4>(rt, kc, xc, cx, cy, cw, sacc); break;
+        case 5: case 6: run_step_rounds<6>(rt, kc, xc, cx, cy, cw, sacc); break;
+        default: run_step_rounds<8>(rt, kc, xc, cx, cy, cw, sacc); break;
+        }
+        RUN_CLK(7);
+        if (!head_block) {
+            wave_sums<NACC_STEP>(sacc, lane, s_red + wid * NACC_MAX);
+            __syncthreads();
+            if (tid < NACC_STEP) {
+                double t = 0.0;
 #pragma unroll
-        for (int r = 0; r < RUN_R; ++r) {
-            if (r < rmax) {
-                const float w = cw[r];
-                if (w > 0.0f) {
-                    const float4 yj = apply_tf(rt, rt + 9, make_float4(cy[r][0], cy[r][1], cy[r][2], 0.0f));
-                    pair_step_sums(kc, xc, yj, cx[r][0] - yj.x, cx[r][1] - yj.y, cx[r][2] - yj.z, w, sacc);
-                }
+                for (int q = 0; q < RUN_WAVES; ++q) t += s_red[q * NACC_MAX + tid];
+                s_vals[tid] = t;
             }
         }
-        wave_sums<NACC_STEP>(sacc, lane, s_red + wid * NACC_MAX);
-        __syncthreads();
-        if (tid < NACC_STEP) {
-            double t = 0.0;
-#pragma unroll
-            for (int q = 0; q < RUN_WAVES; ++q) t += s_red[q * NACC_MAX + tid];
-            s_vals[tid] = t;
-        }
-        RUN_CLK(4);
+        RUN_CLK(8);
         ++nexch;
-        if (!run_exchange<NACC_STEP>(ps.run_mail, rank, seq0 + nexch, s_vals, s_all, s_tot, &s_fail)) { comm_ok = false; break; }
-        RUN_CLK(5);
+        unsigned verdict = 0u;
+        if (!run_exchange<NACC_STEP>(ps.run_mail, srow, g, seq0 + nexch, s_vals, s_all, s_tot, &s_fail, &verdict, &s_verdict)) { comm_ok = false; break; }
+        RUN_CLK(9);
+        if (verdict & RUN_V_STALL) {
+            // no buffer holds every pair for this slot's transform (a jump): what the passes have summed is void.  The head goes
+            // out as the head-mode flow launch of a stall slot would publish it (it runs no passes: the next launch's filter
+            // blocks build what the plan has named); the head block did its list preparation when it planned
+            if (head_block) {
+                if (tid == 0) {
+                    for (int q = 0; q < NACC_FLOW; ++q) s_st.red[RED_FLOW + q] = s_bak[q];
+                    for (int q = 0; q < 3; ++q) { s_st.omega[q] = s_bakf[q]; s_st.v[q] = s_bakf[3 + q]; }
+                }
+                __syncthreads();
+                head_publish(ps, &s_st, gst, true);
+            }
+            break;
+        }
+        // ---- the slot stands.  The head block: what the slot's step launch leaves in the head, the trace record
+        if (head_block && tid == 0) {
+            for (int q = 0; q < 4; ++q) s_st.red[RED_XX + q] = 0.0;
+            s_st.xi = s_xi;
+            s_st.dl = 0.0;
+            if (ta.trace && s_st.k < ta.trace_cap) {
+                cvo_hip_trace &tr = ta.trace[s_st.k];
+                tr.k = s_st.k;
+                tr.exit_code = 0;
+                tr.ell = s_st.ell;
+                for (int q = 0; q < 3; ++q) {
+                    tr.omega[q] = s_xi.omega[q]; tr.v[q] = s_xi.v[q];
+                    tr.omega_d[q] = s_st.red[RED_FLOW + q]; tr.v_d[q] = s_st.red[RED_FLOW + 3 + q];
+                }
+                tr.sum_a = s_st.red[RED_FLOW + 6];
+                tr.dl = 0.0;
+                tr.nnz = (long long)s_st.red[RED_FLOW + 8]; tr.nnz_xx = 0; tr.nnz_yy = 0;
+            }
+        }
         // ---- the slot is complete but for its post-step part.  Leave here -- as a step launch would leave it -- when the
         // head of this slot has named a build (the next classic flow launch's filter blocks make it) or the run is over
-        if (it + 1 >= iters || s_st.xy_target >= 0) {
-            if (rank == 0) {
+        if (it + 1 >= iters || (verdict & RUN_V_BUILD)) {
+            if (head_block) {
+                __syncthreads();
                 // (the step sums as row 0 of the rows the next head reduces; the other rows are zero: x + 0 = x in any order)
                 for (int q = tid; q < NACC_STEP * ps.nblk; q += RUN_BLOCK) {
                     const int k = q / ps.nblk, b = q - k * ps.nblk;
@@ -2820,33 +2929,66 @@ kt_run(const Slot *__restrict__ tab, const int qs)
             }
             break;
         }
-        // ---- the head: cubic, break tests, Exp_SEK3, update, length scale, the plan of the next slot
-        // (ref src/cvo.cpp:291-307,380-410), in every block; block 0 publishes the mirrors
+        // ---- the post-step part of the head: cubic, break tests, Exp_SEK3, update, length scale (ref src/cvo.cpp:291-307,
+        // 380-410), in every block; then, for the passes of the next slot, its transform and -- when the length scale moved --
+        // its kernel constants (the two pieces of the plan that the passes read: the same functions, the same values)
         if (tid < NACC_STEP) s_st.red[RED_STEP + tid] = s_tot[tid];
         __syncthreads();
+        RUN_CLK(10);
         if (tid < 64) {
-            unsigned flag[LIST_N];
-#pragma unroll
-            for (int l = 0; l < LIST_N; ++l) flag[l] = 0u;   // (nothing is built and no slice can overflow in a run)
             long long clk[4] = {0, 0, 0, 0};
-            head_math<HM_HEAD>(&s_st, ps, true, false, flag, rank == 0, false, clk);
+            head_post<HM_HEAD>(&s_st, ps, true, head_block, false, clk);
+            RUN_CLK(11);
+            if (s_st.done == RUNNING) {
+                if (head_block) {
+                    unsigned flag[LIST_N];
+#pragma unroll
+                    for (int l = 0; l < LIST_N; ++l) flag[l] = 0u;   // (nothing is built and no slice can overflow in a run)
+                    head_plan<HM_HEAD>(&s_st, ps, true, false, flag);
+                } else {
+                    float Rt[9], t[3];
+                    cvo_math::inverse_tf(s_st.R, s_st.T, Rt, t);
+                    if (!(s_st.kc_ell == s_st.ell)) {
+                        const KernConsts k = make_kconsts(ps.prm, s_st.ell);
+                        if (tid == 0) { s_st.kc = k; s_st.kc_ell = s_st.ell; }
+                    }
+                    if (tid == 0) {
+#pragma unroll
+                        for (int q = 0; q < 9; ++q) s_st.Rt[q] = Rt[q];
+#pragma unroll
+                        for (int q = 0; q < 3; ++q) s_st.t[q] = t[q];
+                        s_st.pending = 1;
+                    }
+                }
+            }
         }
         __syncthreads();
-        if (s_st.done != RUNNING || s_st.stall != 0) {
-            // the loop has stopped, or no buffer holds every pair any more (a jump): the head goes out as a head-mode flow
-            // launch would publish it (a stall slot runs no passes: the next launch's filter blocks build what it names)
-            if (rank == 0) {
+        RUN_CLK(12);
+        if (s_st.done != RUNNING) {   // the loop has stopped: the final head goes out
+            if (head_block) {
                 head_prepare_lists<HM_HEAD>(ps, &s_st);
                 head_publish(ps, &s_st, gst, true);
             }
             break;
         }
-        if (rank == 0 && tid == 0) {   // the host's mirrors, once per slot
-            if (ps.hint_mirror) *ps.hint_mirror = s_st.run_hint;
-            if (ps.progress_mirror) *ps.progress_mirror = s_st.n_slots;
+        if (head_block) {
+            post_verdict(seq0 + nexch + 2);
+            if (tid == 0) {   // the host's mirrors, once per slot
+                if (ps.hint_mirror) *ps.hint_mirror = s_st.run_hint;
+                if (ps.progress_mirror) *ps.progress_mirror = s_st.n_slots;
+            }
+            head_prepare_lists<HM_HEAD>(ps, &s_st);   // (a build this head has named: its counters)
         }
-        if (rank == 0) head_prepare_lists<HM_HEAD>(ps, &s_st);   // (a build this head has named: its counters)
-        RUN_CLK(6);
+        RUN_CLK(13);
+    }
+    if (!head_block) {
+#ifdef CVO_RUN_CLOCKS
+        if (srow == 0 && tid == 0) {
+            RUN_CLK(14);
+            for (int q = 0; q < 16; ++q) gst->run_clk[q] += clk_acc[q];
+        }
+#endif
+        return;
     }
     if (!comm_ok) {   // an exchange timed out: nothing of this run can be trusted
         if (tid == 0) {
@@ -2854,14 +2996,10 @@ kt_run(const Slot *__restrict__ tab, const int qs)
             if (ps.done_mirror) *ps.done_mirror = DONE_COMM_ERROR;
         }
     }
-    if (rank == 0 && tid == 0) {
+    if (tid == 0) {
         gst->run_seq = seq0 + nexch;
         gst->run_entered += 1;
         gst->run_iterations += (int)(nexch / 2u);
-#ifdef CVO_RUN_CLOCKS
-        RUN_CLK(7);
-        for (int q = 0; q < 8; ++q) gst->run_clk[q] += clk_acc[q];
-#endif
     }
     __syncthreads();
     run_over();

@@ -809,7 +809,7 @@ bool plan_lone(const std::vector<RecOp> &ops, Slot &slot, std::vector<TLaunch> &
             // cloud read as it came
             if (head && pre && o.ps.run_mail && flow.cand && flow.cand_b && flow.kept_packed == 1 && flow.tf_a == 0 && flow.tf_b == 1 &&
                 flow.weight == 0 && 4 * flow.nblk <= PROC_WAVES)
-                pre->push_back(mk_launch(TK_RUN, q | ((q + 1) << 4), 8u * RUN_G, 1));
+                pre->push_back(mk_launch(TK_RUN, q | ((q + 1) << 4), 1u + RUN_G, 1));
             ++q;
         } else if (have_flow) {
             slot.op[q].p = flow;

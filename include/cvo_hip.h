@@ -334,9 +334,9 @@ int cvo_hip_get_graph_stats(const cvo_hip_ctx *ctx, long long *launches_from_cac
  * that declined, iterations executed inside runs, candidate pairs of the record the last run looked at.  Diagnostics; any
  * pointer may be null. */
 int cvo_hip_get_run_stats(const cvo_hip_ctx *ctx, int *runs, int *declined, int *iterations, int *candidates);
-/* ... and, in builds with -DCVO_RUN_CLOCKS, the ticks block 0 of the runs spent in: entry, flow pass, its exchange, twist
- * constants, step pass, its exchange, head, exit (zeros otherwise). */
-int cvo_hip_get_run_clocks(const cvo_hip_ctx *ctx, long long clocks8[8]);
+/* ... and, in builds with -DCVO_RUN_CLOCKS, the ticks the first solver block of the runs spent in each phase of the loop
+ * (csrc/cvo_kernels.hip kt_run: RUN_CLK; zeros otherwise). */
+int cvo_hip_get_run_clocks(const cvo_hip_ctx *ctx, long long clocks16[16]);
 int cvo_hip_synchronize(cvo_hip_ctx *ctx);
 
 #ifdef __cplusplus

@@ -9,7 +9,7 @@ import __graft_entry__ as ge
 pkg = ge.load_package(); capi = pkg.capi
 if os.environ.get("CVO_LIB"):
     capi.LIB_PATH = os.path.join(os.path.dirname(capi.LIB_PATH), os.environ["CVO_LIB"])
-names = ("entry", "flow", "exch A", "twist", "step", "exch B", "head", "exit")
+names = ("entry", "consts", "flow rounds", "wave sums", "barrier+block sum", "exch A", "twist", "step rounds", "step sums", "exch B", "pre-head", "head_post", "inverse+sync", "tail", "exit", "-")
 for n in [int(a) for a in sys.argv[1:]] or [3000, 10000]:
     xf, ff, xm, fm = pkg.data.synthetic_pair(n, n, seed=pkg.data.SEED_CFG2)
     c = capi.Context(mode=capi.MODE_CVO, device=0, stream=torch.cuda.current_stream().cuda_stream)
@@ -24,6 +24,6 @@ for n in [int(a) for a in sys.argv[1:]] or [3000, 10000]:
     print("n %d: %d iterations in %.1f us; %d runs (%d declined), %d iterations inside, last record %d candidates" % (n, n_it, dt * 1e6, runs, declined, its, cand))
     if its:
         tot = sum(clk)
-        print("   ticks of block 0 (100 MHz s_memtime? see below): total %d = %.2f per run-iteration" % (tot, tot / its))
+        print("   ticks of the first solver block (2.4 per ns): %.0f per run-iteration" % ((tot - clk[0] - clk[14]) / its))
         print("   " + ", ".join("%s %.0f" % (nm, (v / runs) if nm in ("entry", "exit") else (v / its)) for nm, v in zip(names, clk)) + "  (entry / exit per run, the others per iteration)")
     c.close()
