@@ -76,8 +76,13 @@ int job_begin(AlignJob &j)
     // 10k 31.6 / 26.5 / 26.7, 14k 34.8 / 28.5 / 27.6 -- profiles/r03_ab.txt 17)
     if (!ctx->proc_blocks_forced && !ctx->use_async_self && ctx->use_async && ctx->lone && ctx->allow_head &&
         ctx->prm.mode == CVO_HIP_MODE_CVO)
+    {
+        // (with resident runs the narrow iterations no longer run these launches: the wide ones want the blocks -- 10k x 10k
+        // 256 / 512 / 1024 blocks per pass 752 / 869 / 913 registrations/s, 6k 950 / 966 / 950, 3k 1 176 / 1 157 / 1 074: profiles/r05_ab.txt 7)
+        const bool runs = ctx->allow_run && ctx->fixed.np <= 65536 && ctx->moving.np <= 65536;
         ctx->proc_blocks = ctx->proc_blocks_default =
-            npairs <= 2.5e7 ? PROC_BLOCKS / 4 : (npairs <= 1.5e8 ? PROC_BLOCKS / 2 : PROC_BLOCKS);
+            npairs <= 2.5e7 ? PROC_BLOCKS / 4 : (npairs <= (runs ? 6.0e7 : 1.5e8) ? PROC_BLOCKS / 2 : PROC_BLOCKS);
+    }
     launch_prepare(ctx->st, loop_params(ctx), loop_stream(ctx));
     HIP_TRY(ctx, hipGetLastError());
     ctx->have_tf = true;
