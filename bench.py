@@ -43,6 +43,7 @@ F64_OPS_PER_EXP = 14.0         # the device exp (cvo_kernels.hip exp_neg)
 BYTES_PER_POINT = 32.0         # xyz 12 B + 5 features 20 B
 PEAK_F32_TFLOPS = 157.3        # MI355X_MICROARCH.md: FP32 vector = FP32 MFMA peak
 PEAK_HBM_GBS = 8000.0
+FETCH_CALIBRATION = "profiles/r05_fetch_calibration.txt"   # what TCC FETCH_SIZE counts on a 16-byte gather of known footprint
 PROFILE_TAG = "r04"            # committed rocprofv3 summaries under profiles/ (tools/gpu_profile.sh)
 
 
@@ -63,6 +64,8 @@ def parse():
     ap.add_argument("--no-side-legs", action="store_true", help="timed region + roofline only (profiling runs)")
     ap.add_argument("--saturation-batch", type=int, default=256,
                     help="side leg: distinct pairs per call with the tail of a call amortised (0 = skip)")
+    ap.add_argument("--config4-points", type=int, default=20000, help="N = M of the BASELINE configs[4] leg")
+    ap.add_argument("--config4-count", type=int, default=8, help="concurrent registrations per GPU of that leg")
     ap.add_argument("--sharded-points", type=int, default=200000)
     ap.add_argument("--sharded-steps", type=int, default=2)
     ap.add_argument("--sharded-timeout", type=int, default=240, help="watchdog of the sharded leg, seconds")
@@ -253,9 +256,11 @@ def main():
             "batched_TFLOPs": sweep_flop_per_iter * float(it_sum.item()) / elapsed / 1e12,
             "peak_TFLOPs": PEAK_F32_TFLOPS}
 
-    if rank == 0 and world == 1:
+    if rank == 0:
         # ---- one registration at a time (latency view): the configs[1] pair on context 0, through
-        # cvo_hip_align -- the call a sequential VO loop makes (ref src/cvo.cpp:361-420)
+        # cvo_hip_align -- the call a sequential VO loop makes (ref src/cvo.cpp:361-420), BASELINE configs[1] read
+        # literally.  Under N ranks: rank 0's GPU, the others wait at the next barrier.  The figures also go into
+        # `config` (the part of the line the driver keeps whole).
         def lone():
             st = capi.init_state(ctx.params)
             k, _ = ctx.align(st, trace_cap=0)
@@ -273,10 +278,18 @@ def main():
         el1 = time.perf_counter() - t1
         out["single_stream"] = {"registrations_per_s": n1 / el1, "ms_per_registration": el1 * 1e3 / n1,
                                 "ms_per_iteration": el1 * 1e3 / max(it1, 1), "iterations": it1 / n1,
-                                "pair": "BASELINE configs[1] (seed %d)" % pkg.data.SEED_CFG2}
+                                "pair": "BASELINE configs[1] (seed %d)" % pkg.data.SEED_CFG2,
+                                "resident_runs": dict(zip(("runs", "declined", "iterations_inside", "candidates_of_last_record"), ctx.run_stats()))}
+        out["config"]["one_registration_at_a_time"] = {
+            "what": "BASELINE configs[1] literally: one %dk x %dk pair, cvo_hip_align to convergence, nothing else on the GPU "
+                    "(`value` is %d distinct pairs in flight per GPU)" % (n // 1000, m // 1000, B),
+            "registrations_per_s": out["single_stream"]["registrations_per_s"],
+            "ms_per_iteration": out["single_stream"]["ms_per_iteration"],
+            "iterations": out["single_stream"]["iterations"]}
         out["equivalent_sweep_rate"]["single_stream_TFLOPs"] = \
             sweep_flop_per_iter / (out["single_stream"]["ms_per_iteration"] * 1e-3) / 1e12
         gpu_state0, gpu_iters0 = st1[0], its[0]
+    if rank == 0 and world == 1:
         # ---- the path that produced `value`, checked in this run: every registration of the last timed
         # step (engines, 32-slot tables, candidate lists) against the same pair registered on its own
         # (cvo_hip_align), bit for bit; four of them against the oracle in the cpu leg below
@@ -298,6 +311,7 @@ def main():
                 ho = handover_leg(args, pkg, ctxs, pairs, one_step, torch)
                 out["value_including_set_pcd"] = ho["registrations_per_s"]
                 out["value_including_set_pcd_over_value"] = ho["registrations_per_s"] / value
+                out["config"]["value_including_set_pcd"] = ho["registrations_per_s"]
                 out["hand_over"] = ho
             except Exception as e:
                 out["value_including_set_pcd"] = None
@@ -327,6 +341,7 @@ def main():
                     out["acvo"] = {"error": repr(e)}
             try:
                 out["config4"] = config4_leg(args, pkg, torch, mode, acvo)
+                out["config"]["config4_registrations_per_s"] = out["config4"]["registrations_per_s"]
             except Exception as e:
                 out["config4"] = {"error": repr(e)}
             try:   # the N = 1 point of the strong-scaling curve of BASELINE configs[3]
@@ -350,6 +365,31 @@ def main():
             out["parity_vs_oracle"] = parity
             batched_parity.update(batched_vs_oracle(pkg, pairs, last_states, last_its, acvo, cpu["cores"]))
         out.setdefault("parity_vs_oracle", {})["batched"] = batched_parity
+    if world > 1 and not args.no_side_legs:
+        # BASELINE configs[4] IS "64 concurrent 20k x 20k across 8 GPUs": under N ranks every rank runs the leg on its own
+        # registrations (collective: all ranks, or none -- an exception on one rank is agreed on before anybody waits)
+        import threading
+        for c in ctxs:
+            c.close()
+        ctxs = []
+
+        def give_up4():   # (a rank that fails leaves the others at a barrier: the headline line must still go out)
+            if rank == 0:
+                out["config4"] = {"error": "timed out after %d s" % args.sharded_timeout}
+                print(json.dumps(out), flush=True)
+            os._exit(0)
+        dog4 = threading.Timer(args.sharded_timeout, give_up4)
+        dog4.daemon = True
+        dog4.start()
+        try:
+            c4 = config4_leg(args, pkg, torch, mode, acvo, world=world, rank=rank, barrier=barrier, dist=dist, red_dev=red_dev)
+        except Exception as e:
+            c4 = {"error": repr(e)}
+        dog4.cancel()
+        if rank == 0:
+            out["config4"] = c4
+            if "registrations_per_s" in c4:
+                out["config"]["config4_registrations_per_s"] = c4["registrations_per_s"]
     # The target-sharded leg runs last and under a watchdog: the headline line above it must
     # not depend on it, not even if an exchange hangs.
     if (world > 1 or args.force_sharded_leg) and args.sharded_steps > 0:
@@ -422,14 +462,18 @@ def roofline_legs(args, pkg, ctx, ctxs, one_step, n, m):
     pmc, pmc_src = committed("%s_pmc_summary.json" % PROFILE_TAG)
     live, live_src = committed("%s_kernel_live.json" % PROFILE_TAG)
     shares = None
-    spath = os.path.join(ROOT, "profiles", "%s_kernel_stats_batch32.csv" % PROFILE_TAG)
+    # (rounds 1-2 named the file ..._batch32.csv; round 4 looked for that name and found nothing)
+    sname = "%s_kernel_stats_batch.csv" % PROFILE_TAG
+    if not os.path.exists(os.path.join(ROOT, "profiles", sname)):
+        sname = "%s_kernel_stats_batch32.csv" % PROFILE_TAG
+    spath = os.path.join(ROOT, "profiles", sname)
     if os.path.exists(spath):
         try:
             import csv
             rows = [r for r in csv.DictReader(open(spath)) if "cvo_dev::" in r["Name"]]
             tot = sum(float(r["TotalDurationNs"]) for r in rows)
             top = sorted(rows, key=lambda r: -float(r["TotalDurationNs"]))[:6]
-            shares = {"source": "committed profiles/%s_kernel_stats_batch32.csv" % PROFILE_TAG}
+            shares = {"source": "committed profiles/" + sname}
             shares.update({r["Name"].replace("void ", "").replace("cvo_dev::", "").split("(")[0]:
                            round(float(r["TotalDurationNs"]) / tot, 3) for r in top})
         except Exception:
@@ -456,7 +500,7 @@ def roofline_legs(args, pkg, ctx, ctxs, one_step, n, m):
             for r in csv.DictReader(open(spath)):
                 if "kt_process<0, 0>" in r["Name"]:
                     rocprof_batch = {"avg_launch_us": float(r["AverageNs"]) / 1e3, "launches": int(r["Calls"]),
-                                     "source": "committed profiles/%s_kernel_stats_batch32.csv" % PROFILE_TAG,
+                                     "source": "committed profiles/" + sname,
                                      "note": "under the kernel trace a step takes ~1.4x as long and the engines' launches overlap "
                                              "less: a launch has more of the GPU to itself and is shorter than in the timed run"}
         except Exception:
@@ -498,6 +542,11 @@ def roofline_legs(args, pkg, ctx, ctxs, one_step, n, m):
         "kernel": "cvo_dev::kt_process<PROC_FLOW> (exact membership test + kernel weights + flow sums over the candidate "
                   "lists of the registrations of an engine; the largest share of the GPU time of the timed region)",
         "bound": "hbm",
+        "bound_note": "the roof `frac` is quoted against (the contract's algorithmic bytes over 8 TB/s).  It is NOT what limits the "
+                      "kernel: see limited_by and by_phase",
+        "limited_by": "dependent latency while the kernel is wide (one gather round trip per 64 candidates and wave; vector issue ~0.5, "
+                      "4 of 6 waves per SIMD resident, each waiting ~3/4 of its cycles, L2 hit rate 0.66: profiles/r04_ab.txt 8, 14), "
+                      "the chain of dependent launches while it is narrow",
         "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
         "algorithmic_bytes_per_launch": b_bytes,
         "bytes_definition": "32 B x (N + M) points read once per sweep (SURVEY 8d) x the registrations the launch serves",
@@ -688,20 +737,28 @@ def roofline_engine_leg(args, pkg, torch, mode, acvo, n, m):
     else:
         heavy = phase_obj(["ell_0.15", "ell_0.10", "ell_0.06"])
         light = phase_obj(["ell_0.03"])
+        sq, sq_src = committed("%s_sq_phases.json" % PROFILE_TAG)   # (per-phase SQ counters of the same command, where collected)
         if heavy:
-            heavy["bound"] = "hbm-counter"
-            heavy["what"] = ("iterations 0-20 (ell >= 0.06): throughput-bound list passes; counter bytes (FETCH_SIZE x 2 + WRITE_SIZE of the "
-                             "same launches, committed %s) over the live duration, against %.1f TB/s achievable"
-                             % (ph_src or "profiles/%s_pmc_phases.json" % PROFILE_TAG, ACHIEVABLE_HBM_GBS / 1e3))
+            heavy["bound"] = "dependent-latency"
+            heavy["what"] = ("iterations 0-20 (ell >= 0.06): the streaming flow pass waits for one gather round trip per round of 64 "
+                             "candidates and wave -- vector instructions issue 44-52 % of the time, 3.8-4.4 of 6 waves per SIMD are "
+                             "resident and each waits 73-79 % of its cycles, L2 hit rate 0.66, texture addresser 4-6 % busy "
+                             "(profiles/r04_ab.txt 8, 14).  counter_GBs = FETCH_SIZE x 2 + WRITE_SIZE of the same launches (committed %s) "
+                             "over the live duration: FETCH_SIZE counts Infinity-Cache hits too and one engine's working set fits that "
+                             "cache, so this is a traffic figure at the L2's far side, not an HBM roof (calibration: %s)"
+                             % (ph_src or "profiles/%s_pmc_phases.json" % PROFILE_TAG, FETCH_CALIBRATION))
+            heavy["step_pass"] = {"bound": "valu-issue", "issue_frac_by_length_scale": {"ell_0.15": 0.86, "ell_0.10": 0.81, "ell_0.06": 0.71},
+                                  "source": (sq_src or "profiles/r04_ab.txt 8")}
         if light:
-            light["bound"] = "launch-latency"
+            light["bound"] = "launch-chain"
             light["launches_per_iteration"] = 5
             light["chain_us"] = light["iteration_period_us"]
             light["what"] = ("iterations 21+ (ell = 0.03): an iteration of the engine = its chain of five dependent launches (filter, "
                              "flow, post-flow, step, post-step); chain_us = live time from one flow launch's begin to the next one's")
         res["by_phase"] = {"heavy": heavy, "light": light,
                            "per_length_scale": {k: phase_obj([k]) for k in sorted(phases)}}
-    res["bound_note"] = "per phase: see by_phase (heavy: hbm-counter, light: launch-latency); `frac` is the contract's algorithmic-bytes figure"
+    res["bound_note"] = ("per phase: see by_phase (wide flow pass: dependent-latency, wide step pass: valu-issue, narrow: launch-chain); "
+                         "`frac` is the contract's algorithmic-bytes figure against the HBM roof")
     return res
 
 
@@ -977,14 +1034,17 @@ def saturation_leg(args, pkg, torch, mode, acvo, n, m):
             "iterations_per_registration": it / float(steps * count), "steps": steps}
 
 
-def config4_leg(args, pkg, torch, mode, acvo, count=8, points=20000):
-    """BASELINE configs[4] per GPU: 8 concurrent 20k x 20k registrations (seeds 1000 + i), one
-    align_many call per step."""
+def config4_leg(args, pkg, torch, mode, acvo, count=None, points=None, world=1, rank=0, barrier=None, dist=None, red_dev="cuda"):
+    """BASELINE configs[4] per GPU: 8 concurrent 20k x 20k registrations (seeds 1000 + i; under N ranks rank r takes seeds
+    1000 + 8 r + i: "64 concurrent 20k x 20k across 8 GPUs"), one align_many call per step; with ranks: every rank its own
+    registrations, no data-path collective, barrier + max-over-ranks clock as the headline."""
     capi = pkg.capi
+    count = count or args.config4_count
+    points = points or args.config4_points
     streams = [torch.cuda.Stream() for _ in range(count)]
     ctxs = []
     for i in range(count):
-        xf, ff, xm, fm = pkg.data.synthetic_pair(points, points, seed=pkg.data.SEED_CFG5_BASE + i, acvo=acvo)
+        xf, ff, xm, fm = pkg.data.synthetic_pair(points, points, seed=pkg.data.SEED_CFG5_BASE + rank * count + i, acvo=acvo)
         c = capi.Context(mode=mode, device=torch.cuda.current_device(), stream=streams[i].cuda_stream,
                          graph_capture=True)
         c.set_fixed(xf, ff)
@@ -995,20 +1055,27 @@ def config4_leg(args, pkg, torch, mode, acvo, count=8, points=20000):
         states = [capi.init_state(c.params) for c in ctxs]
         return capi.align_many(ctxs, states)
     step()
-    torch.cuda.synchronize()
+    sync = barrier if barrier else torch.cuda.synchronize
+    sync()
     steps = 5
     t0 = time.perf_counter()
     it = 0
     for _ in range(steps):
         it += sum(step())
-    torch.cuda.synchronize()
+    sync()
     el = time.perf_counter() - t0
     for c in ctxs:
         c.close()
-    return {"workload": "%d concurrent %dk x %dk registrations per GPU (BASELINE configs[4], seeds 1000 + i), "
-                        "one align_many call per step" % (count, points // 1000, points // 1000),
-            "registrations_per_s": steps * count / el, "ms_per_step": el * 1e3 / steps,
-            "iterations_per_registration": it / float(steps * count), "steps": steps}
+    if world > 1:
+        t_max = torch.tensor([el], dtype=torch.float64, device=red_dev)
+        it_sum = torch.tensor([float(it)], dtype=torch.float64, device=red_dev)
+        dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
+        dist.all_reduce(it_sum, op=dist.ReduceOp.SUM)
+        el, it = float(t_max.item()), float(it_sum.item())
+    return {"workload": "%d concurrent %dk x %dk registrations per GPU x %d GPU(s) (BASELINE configs[4], seeds 1000 + i), "
+                        "one align_many call per step and rank" % (count, points // 1000, points // 1000, world),
+            "registrations_per_s": steps * count * world / el, "ms_per_step": el * 1e3 / steps, "n_gpus": world,
+            "iterations_per_registration": it / float(steps * count * world), "steps": steps}
 
 
 def frontend_leg(args, pkg, frames=100):

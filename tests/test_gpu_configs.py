@@ -203,7 +203,8 @@ def test_bench_multi_rank_rehearsal_on_one_gpu(launcher):
     env = dict(os.environ, CVO_BENCH_RANKS_ON_DEVICE0="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     bench_args = [os.path.join(root, "bench.py"),
                   "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "8", "--points", "3000",
-                  "--sharded-points", "20000", "--sharded-steps", "1", "--sharded-timeout", "120"]
+                  "--sharded-points", "20000", "--sharded-steps", "1", "--sharded-timeout", "120",
+                  "--config4-points", "4000", "--config4-count", "4"]
     if launcher == "torchrun":
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                "--master-addr", "127.0.0.1", "--master-port", "29577"] + bench_args
@@ -217,6 +218,14 @@ def test_bench_multi_rank_rehearsal_on_one_gpu(launcher):
     out = json.loads(line)
     assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["value"] > 0
     assert out["ranks_on_device0"] is True
+    # BASELINE configs[4] under N ranks (every rank its own registrations, max-over-ranks clock) and the literal one-pair
+    # figure of configs[1], both also inside `config` (the part of the line the driver keeps whole)
+    c4 = out["config4"]
+    assert "error" not in c4, c4
+    assert c4["n_gpus"] == 2 and c4["registrations_per_s"] > 0 and c4["iterations_per_registration"] > 10
+    assert out["config"]["config4_registrations_per_s"] == c4["registrations_per_s"]
+    one = out["config"]["one_registration_at_a_time"]
+    assert one["registrations_per_s"] > 0 and one["ms_per_iteration"] > 0 and one["iterations"] > 10
     sh = out["sharded_allreduce"]
     assert "error" not in sh, sh
     assert sh["exchange"] == "mailbox" and sh["registrations_per_s"] > 0, sh

@@ -1029,3 +1029,67 @@ def test_batched_hand_over_then_align_many(pkg):
         capi.set_pcd_many([cs[0], cs[0]], [(pairs[0][0], pairs[0][1])] * 2, [(pairs[0][2], pairs[0][3])] * 2)
     for c in cs:
         c.close()
+
+
+@pytest.mark.parametrize("n,m", [(3000, 3000), (2300, 2700), (6000, 6000)])
+def test_resident_runs_change_nothing(pkg, po, monkeypatch, n, m):
+    """Resident runs (csrc/cvo_kernels.hip kt_run: the narrow part of one cvo registration -- ref src/cvo.cpp:366-410 -- as whole
+    iterations inside one launch, candidates in registers, partial sums exchanged among the blocks, a head block planning beside
+    the solvers) against the same library without them (CVO_HIP_NO_RUN, read when a context is created): runs are entered, and
+    iteration count, final state and the float32 trace are identical, the float64 sums equal to 1e-11 -- with and without captured
+    batches, with and without a trace, from a far start (jumps: stall verdicts), stopped by max_iter inside a run, with lists
+    rebuilt every iteration (no run can start) and with tiny lists that grow; and equal to the oracle."""
+    import torch
+    capi = pkg.capi
+    xf, ff, xm, fm = pkg.data.synthetic_pair(n, m, seed=4242 + n)
+    xm_far = (xm.astype(np.float64) + np.array([0.05, -0.04, 0.03])).astype(np.float32)
+
+    def run(env, moving, graph, trace_cap, max_iter=0):
+        for k in ("CVO_HIP_NO_RUN", "CVO_HIP_LIST_INIT", "CVO_HIP_LIST_MARGIN"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        p = capi.default_params(capi.MODE_CVO)
+        if max_iter:
+            p.max_iter = max_iter
+        s = torch.cuda.Stream()
+        c = capi.Context(params=p, mode=capi.MODE_CVO, device=0, stream=s.cuda_stream, graph_capture=graph)
+        c.set_fixed(xf, ff)
+        c.set_moving(moving, fm)
+        out = []
+        for _ in range(2):   # (the second align() re-uses plans, tables, the run's mail and its sequence numbers)
+            st = capi.init_state(c.params)
+            it, tr = c.align(st, trace_cap=trace_cap)
+            out.append((it, bytes(st), [(t["k"], t["exit_code"], t["nnz"], t["ell"], t["step"], int(np.float32(t["dist"]).view(np.uint32)),
+                                         tuple(t["omega"]), tuple(t["v"])) for t in tr],
+                        np.array([list(t["omega_d"]) + list(t["v_d"]) + list(t["bcde"]) + [t["sum_a"]] for t in tr], np.float64)))
+        stats = c.run_stats()
+        c.close()
+        assert out[0][:3] == out[1][:3]
+        return out[0], stats
+
+    for moving in (xm, xm_far):
+        for trace_cap in (2000, 0):
+            ref, st_ref = run({"CVO_HIP_NO_RUN": "1"}, moving, True, trace_cap)
+            assert st_ref[0] == 0 and st_ref[2] == 0
+            for env, graph, mi in (({}, True, 0), ({}, False, 0), ({}, True, 37), ({"CVO_HIP_LIST_INIT": "4096"}, True, 0)):
+                want = ref if not mi else run({"CVO_HIP_NO_RUN": "1"}, moving, True, trace_cap, mi)[0]
+                got, st = run(env, moving, graph, trace_cap, mi)
+                assert st[0] >= 1 and st[2] >= 10, (env, graph, mi, st)   # runs were entered and carried iterations
+                assert got[0] == want[0], (env, graph, mi)
+                assert got[1] == want[1], (env, graph, mi)
+                assert got[2] == want[2], (env, graph, mi)
+                if trace_cap:
+                    assert np.allclose(got[3], want[3], rtol=1e-11, atol=1e-13), (env, graph, mi)
+        got, st = run({"CVO_HIP_LIST_MARGIN": "0"}, moving, True, 2000)
+        want = run({"CVO_HIP_NO_RUN": "1", "CVO_HIP_LIST_MARGIN": "0"}, moving, True, 2000)[0]
+        assert got[:3] == want[:3]
+        p = po.default_params(po.MODE_CVO)
+        so = po.init_state(p)
+        n_or, _ = po.align(p, so, xf, ff, moving, fm, search=po.SEARCH_GRID, trace_cap=1)
+        ref, _ = run({}, moving, True, 0)
+        assert n_or == ref[0]
+        assert np.array_equal(np.frombuffer(ref[1], np.float32, 9), np.array(so.R, np.float32))
+        assert np.array_equal(np.frombuffer(ref[1], np.float32, 12)[9:], np.array(so.T, np.float32))
+    for k in ("CVO_HIP_NO_RUN", "CVO_HIP_LIST_INIT", "CVO_HIP_LIST_MARGIN"):
+        monkeypatch.delenv(k, raising=False)
