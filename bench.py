@@ -350,6 +350,7 @@ def main():
                 out["config3_single_gpu"] = {"error": repr(e)}
             try:   # ... and what one of eight GPUs would hold
                 out["config3_shard_of_8"] = shard_leg(args, pkg, torch, mode, acvo)
+                out["config3_projection_8gpu"] = strong_scaling_projection(out["config3_single_gpu"], out["config3_shard_of_8"])
             except Exception as e:
                 out["config3_shard_of_8"] = {"error": repr(e)}
             if not args.no_frontend:
@@ -849,6 +850,31 @@ def mode_leg(args, pkg, torch, mode, acvo, n, m, count):
                               "ms_per_iteration": el1 * 1e3 / max(it1, 1), "iterations": it1 / float(n1)}}
 
 
+def per_length_scale_ms(c, capi, torch, caps=(4, 11, 21, 40)):
+    """ms per iteration of context c's registration in each phase of the cvo length-scale schedule (ell changes at the END of
+    iterations 3, 10, 20, ref src/cvo.cpp:408-410): the registration stopped after 4 / 11 / 21 / 40 iterations (max_iter),
+    differences of the times.  The first window carries the call's fixed cost."""
+    import copy
+    base = copy.copy(c.params)
+    names = ("ell_0.15", "ell_0.10", "ell_0.06", "ell_0.03")
+    res, prev_it, prev_ms = {}, 0, 0.0
+    for cap, name in zip(caps, names):
+        p = copy.copy(base)
+        p.max_iter = cap
+        c.set_params(p)
+        c.align(capi.init_state(c.params), trace_cap=0)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        k, _ = c.align(capi.init_state(c.params), trace_cap=0)
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) * 1e3
+        if k > prev_it:
+            res[name] = {"iterations": [prev_it, k - 1], "ms_per_iteration": (ms - prev_ms) / (k - prev_it)}
+        prev_it, prev_ms = k, ms
+    c.set_params(base)
+    return res
+
+
 def config3_leg(args, pkg, torch, mode, acvo):
     """BASELINE configs[3] on ONE GPU: a single 200k x 200k registration (the N = 1 point of the strong-scaling
     curve of the sharded leg)."""
@@ -871,6 +897,11 @@ def config3_leg(args, pkg, torch, mode, acvo):
            "registrations_per_s": reps / el, "ms_per_registration": el * 1e3 / reps,
            "ms_per_iteration": el * 1e3 / max(it, 1), "iterations": it / float(reps),
            "pairs_per_sweep": float(n) * m}
+    if not acvo:
+        try:   # the same iteration windows as config3_shard_of_8 (like against like)
+            out["per_length_scale"] = per_length_scale_ms(c, capi, torch)
+        except Exception as e:
+            out["per_length_scale"] = {"error": repr(e)}
     # ---- the roofline of this size: the heavy iterations (0-20, ell >= 0.06) are the kept list -- every member of A
     # written by the flow pass (8 B) and read back by the step pass (8 B) -- on top of the tile list the flow pass
     # expands (16 B per entry) and the gathers; durations by HIP events on every dispatch (profiling mode: the
@@ -945,14 +976,58 @@ def shard_leg(args, pkg, torch, mode, acvo, world=8):
         it += k
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
-    c.close()
     ms_it = el * 1e3 / max(it, 1)
-    return {"workload": "rows [%d, %d) of a %dk x %dk registration (one eighth of BASELINE configs[3]) on one GPU, world of one, %d iterations"
-                        % (lo, hi, n // 1000, m // 1000, it // reps),
-            "ms_per_iteration": ms_it, "iterations": it / float(reps),
-            "projected_8gpu_ms_per_iteration": ms_it + 2 * 0.010,
-            "projection": "shard time + 2 exchanges x 10 us (SURVEY 8e's estimate of one small all-reduce over xGMI; a multi-GPU run "
-                          "of this bench measures it: sharded_allreduce.allreduce_latency_us) -- a PROJECTION, not a measurement"}
+    out = {"workload": "rows [%d, %d) of a %dk x %dk registration (one eighth of BASELINE configs[3]) on one GPU, world of one, %d iterations"
+                       % (lo, hi, n // 1000, m // 1000, it // reps),
+           "launches_per_iteration": "filter, flow pass, step pass with the twist and the flow-side exchange in front (every block reads its "
+                                     "rank's mailbox), post-step with the step-side exchange: 4 (5 until round 5)",
+           "ms_per_iteration": ms_it, "iterations": it / float(reps),
+           "projected_8gpu_ms_per_iteration": ms_it + 2 * 0.010,
+           "projection": "shard time + 2 exchanges x 10 us (SURVEY 8e's estimate of one small all-reduce over xGMI; a multi-GPU run "
+                         "of this bench measures it: sharded_allreduce.allreduce_latency_us) -- a PROJECTION, not a measurement"}
+    if not acvo:
+        try:
+            c.set_params(prm)
+            out["per_length_scale"] = per_length_scale_ms(c, capi, torch)
+        except Exception as e:
+            out["per_length_scale"] = {"error": repr(e)}
+    c.close()
+    return out
+
+
+def strong_scaling_projection(single, shard, exchange_us=10.0, world=8):
+    """BASELINE configs[3] on 8 GPUs from what ONE GPU can measure, like against like: per length scale, an 8-GPU iteration = the
+    slowest shard's iteration (rank 0's share, measured as a world of one over the SAME iteration window as the unsharded
+    registration) + two exchanges; a registration = the unsharded run's iterations per length scale at that pace.  The exchange
+    latency is an ASSUMPTION named in the result (a multi-GPU run of this bench measures it)."""
+    a, b = single.get("per_length_scale") or {}, shard.get("per_length_scale") or {}
+    if "error" in a or "error" in b or not a or not b:
+        return None
+    total_it = int(round(single["iterations"]))
+    table, ms_single, ms_proj, seen = {}, 0.0, 0.0, 0
+    for name in ("ell_0.15", "ell_0.10", "ell_0.06", "ell_0.03"):
+        if name not in a or name not in b:
+            continue
+        lo = a[name]["iterations"][0]
+        its = (total_it - lo) if name == "ell_0.03" else (a[name]["iterations"][1] - lo + 1)
+        its = max(its, 0)
+        one = b[name]["ms_per_iteration"] + 2.0 * exchange_us * 1e-3
+        table[name] = {"iterations_of_the_registration": its, "single_gpu_ms_per_iteration": a[name]["ms_per_iteration"],
+                       "shard_ms_per_iteration": b[name]["ms_per_iteration"], "projected_8gpu_ms_per_iteration": one,
+                       "speedup": a[name]["ms_per_iteration"] / one if one > 0 else None}
+        ms_single += its * a[name]["ms_per_iteration"]
+        ms_proj += its * one
+        seen += its
+    if not seen or ms_proj <= 0:
+        return None
+    return {"per_length_scale": table,
+            "single_gpu_registrations_per_s_from_the_same_table": 1e3 / ms_single,
+            "projected_8gpu_registrations_per_s": 1e3 / ms_proj,
+            "projected_speedup_on_%d_gpus" % world: ms_single / ms_proj,
+            "assumed_exchange_us": exchange_us,
+            "assumption": "one mailbox exchange across xGMI = %.0f us (SURVEY 8e's estimate; never measured on this pool: SCALE runs have been "
+                          "skipped) -- two per iteration; every rank's shard as slow as rank 0's; the first window carries a call's fixed cost on "
+                          "both sides.  A PROJECTION." % exchange_us}
 
 
 def batched_vs_oracle(pkg, pairs, last_states, last_its, acvo, cores, count=4):

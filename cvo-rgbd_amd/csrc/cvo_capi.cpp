@@ -377,6 +377,15 @@ int cvo_hip_mailbox_create(cvo_hip_ctx *ctx, int rank, int world, void *ipc_hand
     // sequence numbers restart with a new set of peers: empty the slots and the counter
     HIP_TRY(ctx, hipMemset(ctx->mailbox, 0, sizeof(Mailbox)));
     HIP_TRY(ctx, hipMemset(reinterpret_cast<char *>(ctx->st) + offsetof(DevState, mail_seq), 0, sizeof(unsigned long long)));
+    {   // which GPU this rank's kernels run on, for the peers to read (cvo_hip_mailbox_connect)
+        char bus[64] = {0};
+        unsigned long long id = 1469598103934665603ull;
+        if (hipDeviceGetPCIBusId(bus, sizeof(bus) - 1, ctx->device) != hipSuccess) { (void)hipGetLastError(); std::snprintf(bus, sizeof(bus), "device %d", ctx->device); }
+        for (const char *c = bus; *c; ++c) id = (id ^ (unsigned char)*c) * 1099511628211ull;
+        ctx->mail_dev_id = id | 1ull;
+        HIP_TRY(ctx, hipMemcpy(&ctx->mailbox->owner_dev, &ctx->mail_dev_id, sizeof(id), hipMemcpyHostToDevice));
+    }
+    ctx->mail_shared_device = false;
     HIP_TRY(ctx, hipDeviceSynchronize());   // (null-stream fills: the context's stream does not wait for them by itself)
     ctx->mail_rank = rank;
     ctx->mail_world = world;
@@ -431,6 +440,14 @@ int cvo_hip_mailbox_connect(cvo_hip_ctx *ctx, const void *ipc_handles, void *con
         }
         if (!p) return fail(ctx, CVO_HIP_ERR_INVALID, "null peer mailbox");
         t.peer[r] = (Mailbox *)p;
+        {   // does the peer share this rank's GPU?  (then the exchange stays in the single-block post kernels: plan side)
+            unsigned long long peer_id = 0;
+            if (hipMemcpy(&peer_id, &((Mailbox *)p)->owner_dev, sizeof(peer_id), hipMemcpyDeviceToHost) != hipSuccess) {
+                (void)hipGetLastError();
+                peer_id = ctx->mail_dev_id;   // (unknown: assume the worst)
+            }
+            if (peer_id == ctx->mail_dev_id || peer_id == 0ull) ctx->mail_shared_device = true;
+        }
     }
     CommTable *d = nullptr;
     HIP_TRY(ctx, hipMalloc((void **)&d, sizeof(CommTable)));

@@ -99,7 +99,12 @@ struct alignas(128) MailSlot {
     unsigned long long seq;
     unsigned long long pad_;
 };
-struct Mailbox { MailSlot slot[2][MAX_WORLD]; };
+struct Mailbox {
+    MailSlot slot[2][MAX_WORLD];
+    unsigned long long owner_dev;   // which GPU the owner's kernels run on (a hash of its PCI bus id, never 0), written at creation:
+                                    // ranks that SHARE a GPU must not all spin in every block of a launch (cvo_hip_mailbox_connect)
+    unsigned long long pad_[15];
+};
 struct CommTable {
     Mailbox *peer[MAX_WORLD];      // peer[rank] = this rank's own mailbox
     int rank, world;
@@ -208,9 +213,11 @@ struct alignas(16) DevHead {
     int32_t n_exec;             // loop bodies executed
     int32_t n_slots;            // slots completed (iterations + stall slots): the host paces its batches on it
     int32_t pending;            // head mode: a slot has been started whose post-step part has not run yet
+    unsigned long long mail_snap;   // DevState::mail_seq as the last single-block exchange (or k_prepare) left it: what the blocks of a
+                                // k_step_twist launch that exchanges number their exchange from (mail_seq itself moves while they start)
     int32_t run_hint;           // candidates expected in the record the slot that begins reads (prepare_iteration): what the host picks
                                 // the next batch's plan by (PostStepArgs::hint_mirror)
-    int32_t head_pad_;
+    int32_t head_pad_[3];
 };
 struct DevState : DevHead {
     // ---- the TAIL: one copy per registration, at a fixed address (the head exists twice in
@@ -320,6 +327,8 @@ struct ProcessArgs {
     uint2 *cand_b;         // head mode (double-buffered xy list): the record of the second buffer (8-byte form only) ...
     uint32_t *cand_cnt_b;  // ... DevHead::xy_ck[b] says whether buffer b's record matches its tile list
     int need_d2;           // PROC_FLOW: accumulate sum a (trace records, cvo_hip_flow) and sum (1/l^3 a) d2 (acvo's dl term; cvo_hip_flow reports it for both modes)
+    const CommTable *comm; // k_step_twist with ranks: the flow-side sums are exchanged through the mailboxes inside the launch, every
+                           // block reading its rank's own mailbox (null: one rank, or the exchange is a post kernel's / the host's)
     int kept_packed;       // 1: both clouds have <= 65536 rows: a kept entry is 8 bytes (i | j << 16, weight bits)
                            // in kept_ij alone instead of 8 + 4 -- the kept list is the largest HBM stream of a
                            // batched run (written by every flow pass, read back by the step pass).

@@ -280,6 +280,9 @@ struct cvo_hip_ctx {
     CommTable *comm_table = nullptr;     // device copy; not null = connected: the post kernels exchange
     void *mail_opened[MAX_WORLD] = {};   // peers' mailboxes opened from IPC handles (closed at destroy)
     int mail_rank = 0, mail_world = 0;
+    bool mail_shared_device = false;     // a peer's kernels run on this rank's own GPU (tests, rehearsals): the exchange inside
+                                         // k_step_twist -- every block spinning -- would keep the peer's kernels off the GPU
+    unsigned long long mail_dev_id = 0;  // this device's Mailbox::owner_dev
     bool mail_broken = false;            // an exchange timed out: the ranks' sequence numbers no longer agree (see job_finish)
     cvo_hip_allreduce_fn user_allreduce = nullptr;
     void *user_allreduce_arg = nullptr;

@@ -988,6 +988,13 @@ __device__ __forceinline__ float eval_pair(const ARGS &a, const ProcHead &hd, co
     if (MODE == PROC_FLOW) {
         pair_flow_sums(kc, xi, yj, w, d2, hd.need_d2, acc);
     } else if (MODE == PROC_STEP) {
+#ifdef CVO_PROBE_STEP_EXP   // (probe builds, profiles/r05_ab.txt 9: the least a step pass without a stored weight must do -- d2 and one exp per member)
+        {
+            const float d2p = __builtin_fmaf(e2, e2, __builtin_fmaf(e1, e1, e0 * e0));
+            const float kp = (float)(kc.s2_d * exp_neg((double)d2p * kc.ninv_2l2, etab));
+            asm volatile("" ::"v"(kp));
+        }
+#endif
         pair_step_sums(kc, xc, yj, e0, e1, e2, w, acc);
     } else {
         if (CK == 2 ? row_index >= 0 : row_index >= first_counted) acc[0] += (double)((kc.inv_l3 * w) * d2);
@@ -1166,13 +1173,19 @@ __device__ __forceinline__ bool stream_candidates(const ProcessArgs &a, const Pr
             const unsigned below = __builtin_amdgcn_mbcnt_hi((unsigned)(km >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)km, 0u));
             // (candidate records exist for clouds of up to 65536 rows only, whose kept entries are packed the same
             // way: the record's first word IS the entry's)
+#ifndef CVO_PROBE_NO_KEPT_STORE   // (probe builds, profiles/r05_ab.txt 9: what the flow pass would gain if it kept no list at all)
             store8(kept_w, nk + below, e.x, __float_as_uint(w));
+#endif
         }
         nk += (unsigned)__popcll(km);
         if (PF) e = e_next;
     }
     if (lane == 0) {
+#if defined(CVO_PROBE_NO_KEPT_STORE) || defined(CVO_PROBE_KEPT_CNT0)
+        if (MODE == PROC_FLOW) a.kept_cnt[wave] = 0u;   // (the step pass of the probe reads nothing)
+#else
         if (MODE == PROC_FLOW) a.kept_cnt[wave] = nk;
+#endif
         acc[MODE == PROC_FLOW ? 8 : 1] = (double)nk;
     }
     return true;
@@ -1189,7 +1202,11 @@ __device__ __forceinline__ void process_body(const ProcessArgs &a, const unsigne
     uint2 *pairq_all = reinterpret_cast<uint2 *>(scratch + 4 * NACC_MAX * 8);
     // every wave keeps its own copy of the exp table (no block barrier needed)
     double *s_etab_all = reinterpret_cast<double *>(scratch + 4 * NACC_MAX * 8 + 4 * PAIR_QUEUE * 8);
+#ifdef CVO_PROBE_STEP_EXP
+    s_etab_all[threadIdx.x] = c_exp2_64[threadIdx.x & 63];
+#else
     if (MODE != PROC_STEP) s_etab_all[threadIdx.x] = c_exp2_64[threadIdx.x & 63];
+#endif
     const double *s_etab = s_etab_all + ((MODE == PROC_STEP) ? 0 : (threadIdx.x >> 6) * 64);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1230,7 +1247,11 @@ __device__ __forceinline__ void process_body(const ProcessArgs &a, const unsigne
             unsigned mi, mj;
             float mw;
             kept_unpack(packed, ebase, e, w, mi, mj, mw);
+#ifdef CVO_PROBE_STEP_EXP
+            eval_pair<MODE>(src, hd, kc, mi, mj, mw, acc, xc, s_etab, 0, nullptr, pf, kept_w, min(off + 64u, wcap - 1u));
+#else
             eval_pair<MODE>(src, hd, kc, mi, mj, mw, acc, xc, nullptr, 0, nullptr, pf, kept_w, min(off + 64u, wcap - 1u));
+#endif
             if (PF) e = e_next;
         }
     } else {
@@ -1269,8 +1290,9 @@ __global__ void __launch_bounds__(BLOCK) k_process(const Grp<ProcessArgs> grp)
 // partial row each, the same fixed order in every block, so all blocks hold the same
 // twist -- and goes on to stream its slices of the kept list.  One launch, one kernel
 // boundary and one single-block bubble less per iteration.  Block 0 also leaves the
-// twist, dl and the trace record in the state for k_post_step.  Single-rank align()
-// only: with ranks to sum over, k_post_flow and PROC_STEP stay separate launches.
+// twist, dl and the trace record in the state for k_post_step.  With ranks to sum over whose
+// exchange runs through the mailboxes (ProcessArgs::comm) the flow-side sums are exchanged inside the
+// launch, by every block (round 5); the stream-level all-reduces keep k_post_flow and PROC_STEP apart.
 constexpr int STEP_BLOCK = 1024;
 constexpr int STEP_WAVES = STEP_BLOCK / 64;
 
@@ -1306,6 +1328,8 @@ __device__ __forceinline__ void xi_consts_wave(cvo_math::XiConsts *xi, float *wm
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
+
+__device__ bool mailbox_allreduce_every_block(const CommTable &ct, DevState *gst, const DevHead *hd, double *vals, int count, double *sh, int *sh_fail);
 
 // returns true if this block delivered a row of step partial sums (false: the registration has
 // stopped, the slot is a stall, a list overflowed, or the block is surplus)
@@ -1357,14 +1381,10 @@ __device__ __forceinline__ bool step_twist_body(const ProcessArgs &a, DevState *
 #pragma unroll
         for (int q = 0; q < STEP_WAVES; ++q) t += sh[q * NACC_MAX + tid];
         tot[tid] = t;
+    } else if (tid < NACC_FLOW + 4) {
+        tot[tid] = 0.0;
     }
     __syncthreads();
-    if (tid < 64) {   // (the Taylor constants by the first wave, element by element: xi_consts_wave)
-        float omega[3], v[3];
-        for (int q = 0; q < 3; ++q) { omega[q] = (float)tot[q]; v[q] = (float)tot[3 + q]; }
-        xi_consts_wave(&s_xi, s_wm, omega, v, lane);
-        if (tid == 0) s_overflow = ovf != 0u;
-    }
     // acvo: block 0 also needs the Axx / Ayy sums for dl (ref adaptive_cvo.cpp:222-231,271)
     if (blockIdx.x == 0 && a.acvo && wid < 2) {
         const double *part = wid == 0 ? a.xx_part : a.yy_part;
@@ -1374,6 +1394,30 @@ __device__ __forceinline__ bool step_twist_body(const ProcessArgs &a, DevState *
             ps[1] += part[(size_t)a.nblk + b];
         }
         wave_sums<NACC_SELF>(ps, lane, tot + NACC_FLOW + 2 * wid);   // tot[9..10] xx, tot[11..12] yy
+    }
+    if (a.comm) {
+        // With ranks to sum over (the target cloud is split, ref src/cvo.cpp:201-204 across ranks): this rank's 13 flow-side sums
+        // travel through the mailboxes INSIDE the launch -- block 0 sends, every block reads its rank's own mailbox and adds in
+        // rank order -- and the step pass goes on in the same launch: no post-flow launch, no single-block bubble.  A list that
+        // overflowed on this rank poisons nnz before the sums travel, so that every block of every rank takes the same exit.
+        __shared__ double sh_mail[MAX_WORLD * MAIL_VALS];
+        __shared__ int sh_fail;
+        __syncthreads();
+        if (blockIdx.x == 0 && tid == 0 && ovf != 0u) tot[8] = __builtin_nan("");
+        const bool comm_ok = mailbox_allreduce_every_block(*a.comm, a.st, hd, tot, RED_STEP - RED_FLOW, sh_mail, &sh_fail);
+        if (!comm_ok) {
+            if (blockIdx.x == 0 && tid == 0) {
+                hd->done = DONE_COMM_ERROR;
+                if (a.done_mirror) *a.done_mirror = DONE_COMM_ERROR;
+            }
+            return false;
+        }
+    }
+    if (tid < 64) {   // (the Taylor constants by the first wave, element by element: xi_consts_wave)
+        float omega[3], v[3];
+        for (int q = 0; q < 3; ++q) { omega[q] = (float)tot[q]; v[q] = (float)tot[3 + q]; }
+        xi_consts_wave(&s_xi, s_wm, omega, v, lane);
+        if (tid == 0) s_overflow = a.comm ? (tot[8] != tot[8]) : (ovf != 0u);
     }
     __syncthreads();
     const bool overflow = s_overflow != 0;
@@ -1652,8 +1696,10 @@ __device__ __forceinline__ double section_root_wave(const cvo_math::CubicBracket
 // slot of sender r and copies it out.  The poll is bounded (CommTable::timeout_ticks): a
 // peer that never shows up ends the registration with DONE_COMM_ERROR instead of hanging
 // the GPU.  Returns false on a time-out (block-uniform).
+// `lds_head`: the block's copy of the state's head, which it writes back afterwards: the new sequence number is left there as well
+// (DevHead::mail_snap: what a later k_step_twist launch numbers its own exchange from).
 __device__ bool mailbox_allreduce(const CommTable &ct, DevState *gst, double *vals, int count,
-                                  double *sh /*[MAX_WORLD * MAIL_VALS]*/, int *sh_fail)
+                                  double *sh /*[MAX_WORLD * MAIL_VALS]*/, int *sh_fail, DevHead *lds_head)
 {
     __syncthreads();
     const int lane = threadIdx.x;
@@ -1689,6 +1735,61 @@ __device__ bool mailbox_allreduce(const CommTable &ct, DevState *gst, double *va
         }
         if (lane == 0) {
             gst->mail_seq = seq;
+            lds_head->mail_snap = seq;
+            *sh_fail = all_ok ? 0 : 1;
+        }
+    }
+    __syncthreads();
+    return *sh_fail == 0;
+}
+
+// The same exchange inside a launch whose EVERY block needs the sums (k_step_twist with ranks; the reductions of
+// ref src/cvo.cpp:201-204 across ranks): block 0 alone sends this rank's values -- to every rank's mailbox, its own included --,
+// every block polls its rank's OWN mailbox (local memory, system-scope loads) and adds the slots up in rank order: all blocks of all
+// ranks hold the same bits.  The exchange's number comes from the head the launch runs on (DevHead::mail_snap + 1: constant while
+// the launch runs; block 0 advances DevState::mail_seq, which nobody reads in this launch).  Two generations still do: a rank
+// sends its next exchange from a later launch, after all its blocks have read this one, and the one after that only once every
+// peer has answered the next one -- which a peer does from a launch behind the one whose blocks may still be reading.
+// vals[0..count): LDS, this rank's values going in (block 0's are sent), the sums coming out.  All threads of the block call it.
+__device__ bool mailbox_allreduce_every_block(const CommTable &ct, DevState *gst, const DevHead *hd, double *vals, int count,
+                                              double *sh /*[MAX_WORLD * MAIL_VALS]*/, int *sh_fail)
+{
+    __syncthreads();
+    const int lane = threadIdx.x;
+    if (lane < 64) {
+        const unsigned long long seq = hd->mail_snap + 1ull;
+        const int gen = (int)(seq & 1ull);
+        bool ok = true;
+        if (lane < ct.world) {
+            if (blockIdx.x == 0) {
+                MailSlot *dst = &ct.peer[lane]->slot[gen][ct.rank];
+                for (int i = 0; i < count; ++i)
+                    __hip_atomic_store(&dst->v[i], vals[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the flag must not overtake the write-back)
+                __hip_atomic_store(&dst->seq, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+            const MailSlot *src = &ct.peer[ct.rank]->slot[gen][lane];
+            const long long t0 = (long long)wall_clock64();
+            while (__hip_atomic_load(&src->seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != seq) {
+                if ((long long)wall_clock64() - t0 > ct.timeout_ticks) { ok = false; break; }
+                __builtin_amdgcn_s_sleep(8);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+            for (int i = 0; i < count; ++i)
+                sh[lane * MAIL_VALS + i] = __hip_atomic_load(&src->v[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        const bool all_ok = __ballot(!ok) == 0ull;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (lane < count && all_ok) {
+            double t = 0.0;
+            for (int r = 0; r < ct.world; ++r) t += sh[r * MAIL_VALS + lane];   // rank order, in every block of every rank
+            vals[lane] = t;
+        }
+        if (lane == 0) {
+            if (blockIdx.x == 0) gst->mail_seq = seq;
             *sh_fail = all_ok ? 0 : 1;
         }
     }
@@ -1725,7 +1826,7 @@ __device__ __forceinline__ void post_flow_body(const PostFlowArgs &a)
     if (a.comm) {
         __shared__ double sh_mail[MAX_WORLD * MAIL_VALS];
         __shared__ int sh_fail;
-        comm_ok = mailbox_allreduce(*a.comm, a.st, st->red + RED_FLOW, RED_STEP - RED_FLOW, sh_mail, &sh_fail);
+        comm_ok = mailbox_allreduce(*a.comm, a.st, st->red + RED_FLOW, RED_STEP - RED_FLOW, sh_mail, &sh_fail, st);
         if (!comm_ok && threadIdx.x == 0) st->done = DONE_COMM_ERROR;
     }
     if ((a.flags & POST_MATH) && comm_ok && threadIdx.x < 64) {   // (the Taylor constants by the first wave: xi_consts_wave)
@@ -2070,7 +2171,7 @@ __device__ __forceinline__ bool head_body(const PostStepArgs &a, const DevHead *
     if (HM == HM_CLASSIC && a.comm && !stalled) {
         __shared__ double sh_mail[MAX_WORLD * MAIL_VALS];
         __shared__ int sh_fail;
-        comm_ok = mailbox_allreduce(*a.comm, a.st, s_st->red + RED_STEP, RED_N - RED_STEP, sh_mail, &sh_fail);
+        comm_ok = mailbox_allreduce(*a.comm, a.st, s_st->red + RED_STEP, RED_N - RED_STEP, sh_mail, &sh_fail, s_st);
         if (!comm_ok && tid == 0) s_st->done = DONE_COMM_ERROR;
     }
     if (math && comm_ok) {
@@ -2128,6 +2229,7 @@ __global__ void k_prepare(DevState *st, const DevParams prm)
         st->xy_fresh = -1;
         st->stall = 0;
         st->pending = 0;
+        st->mail_snap = st->mail_seq;
         prepare_iteration(st, st, true, prm, plan_builds_none());
     }
 }
@@ -2191,7 +2293,7 @@ kt_filter_group(const Slot *__restrict__ tab, const int q)
 // distinct pairs per call 3 671 -> 3 775 / 4 166 -> 4 280 registrations/s; with the sum in, seven waves spill more
 // and acvo loses 1.5 %: profiles/r03_ab.txt 32)
 #ifndef CVO_FLOW_WAVES
-#define CVO_FLOW_WAVES 6   // (7 / 6 / 5 measured alike on the round-4 loops, profiles/r04_ab.txt 18)
+#define CVO_FLOW_WAVES 5   // (7 / 6 / 5 measured alike on the round-4 loops, profiles/r04_ab.txt 18; at 6 the kernel spilled 4 vector registers)
 #endif
 template <int MODE, int WEIGHT = 0>
 __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((MODE == PROC_FLOW && WEIGHT == 0) ? CVO_FLOW_WAVES : 1, 8)))

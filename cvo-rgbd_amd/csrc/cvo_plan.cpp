@@ -353,6 +353,7 @@ int enqueue_process(cvo_hip_ctx *ctx, int mode, int list, DevBuf &part, const fl
         a.trace = ctx->cur_trace; a.trace_cap = ctx->cur_trace_cap;
         a.acvo = ctx->prm.mode == CVO_HIP_MODE_ACVO;
         a.done_mirror = ctx->done_mirror;
+        a.comm = ctx->comm_table;   // (ranks through the mailboxes: the exchange runs inside the launch)
     }
     const bool build = mode == PROC_FLOW && ctx->have_xy_build;
     ctx->have_xy_build = ctx->have_xy_build && mode != PROC_FLOW;
@@ -667,7 +668,11 @@ int prepare_buffers(cvo_hip_ctx *ctx)
 int enqueue_iterations(cvo_hip_ctx *ctx, int count, int tag0, int trace_cap)
 {
     int rc = CVO_HIP_OK;
-    ctx->merge_twist = ctx->allow_merge && !multi_rank(ctx);
+    // (k_step_twist: one rank, or ranks whose sums travel through the mailboxes -- the exchange then runs inside the launch;
+    // the stream-level all-reduces need their own launches in between; ranks that share ONE GPU -- tests, rehearsals -- keep the
+    // single-block exchange: every block of a rank's launch spinning for a peer keeps that peer's kernels off the GPU.  The test
+    // switch forces the in-launch exchange there, for clouds whose launches leave room)
+    ctx->merge_twist = ctx->allow_merge && !host_reduce(ctx) && !(ctx->comm_table && ctx->mail_shared_device && !getenv("CVO_HIP_TWIST_ON_SHARED_GPU"));
     ctx->in_loop = true;
     ctx->cur_trace = ctx->trace_dev;
     ctx->cur_trace_cap = trace_cap;

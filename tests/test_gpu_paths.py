@@ -659,14 +659,25 @@ def test_two_ranks_on_one_gpu_through_the_allreduce_hook(pkg, po, mode_name, n, 
     assert rot <= 1e-6 and tra <= 1e-6
 
 
+@pytest.mark.parametrize("in_launch", [False, True])
 @pytest.mark.parametrize("mode_name,n,m,world", [("cvo", 2600, 2300, 2), ("acvo", 1500, 2400, 2), ("cvo", 5000, 5000, 4)])
-def test_ranks_on_one_gpu_through_device_mailboxes(pkg, mode_name, n, m, world):
+def test_ranks_on_one_gpu_through_device_mailboxes(pkg, monkeypatch, mode_name, n, m, world, in_launch):
     """The peer-store all-reduce of SURVEY 8e (cvo_hip_mailbox_*): `world` contexts on this GPU,
     each with its share of the fixed rows, exchange their 13 + 4 float64 partial sums through
-    mailboxes in DEVICE memory from inside the post kernels -- the code path that runs over
+    mailboxes in DEVICE memory from inside the kernels -- the code path that runs over
     xGMI between GPUs; here every peer store lands on the same device.  All ranks stay in lock
-    step bit for bit and land on the unsharded result (same iteration count, 1e-6)."""
+    step bit for bit and land on the unsharded result (same iteration count, 1e-6).
+    in_launch: the flow-side sums are exchanged INSIDE k_step_twist, by every block (round 5: what ranks on GPUs of their own
+    run -- four launches per iteration, ref src/cvo.cpp:201-204 across ranks); ranks that share a GPU keep the single-block
+    post-flow exchange (a rank's every block spinning would keep its peers' kernels off the GPU) unless the test switch
+    asks for it, which these small clouds can afford."""
     from helpers import align_two_ranks
+    if in_launch and world > 2:
+        pytest.skip("four ranks' launches, every block spinning, do not fit one GPU side by side: what the switch is off for")
+    if in_launch:
+        monkeypatch.setenv("CVO_HIP_TWIST_ON_SHARED_GPU", "1")
+    else:
+        monkeypatch.delenv("CVO_HIP_TWIST_ON_SHARED_GPU", raising=False)
     capi = pkg.capi
     acvo = mode_name == "acvo"
     mode = capi.MODE_ACVO if acvo else capi.MODE_CVO

@@ -24,7 +24,10 @@ for B in BS:
         xf, ff, xm, fm = pkg.data.synthetic_pair(n, n, seed=(1000 + b) if os.environ.get("DISTINCT") else pkg.data.SEED_CFG2, acvo=ACVO)
         c = capi.Context(mode=capi.MODE_ACVO if ACVO else capi.MODE_CVO, device=0, stream=s.cuda_stream)
         if os.environ.get("MAX_ITER"):   # probe: stop every registration after that many iterations
-            prm = c.params; prm.max_iter = int(os.environ["MAX_ITER"]); c.set_params(prm)
+            prm = c.params; prm.max_iter = int(os.environ["MAX_ITER"])
+            if os.environ.get("NO_BREAK"):   # ... and never earlier (probes whose sums are not the real ones)
+                prm.eps = 0.0; prm.eps_2 = 0.0
+            c.set_params(prm)
         c.set_fixed(xf, ff); c.set_moving(xm, fm)
         ctxs.append(c); streams.append(s)
     def step():
