@@ -431,16 +431,12 @@ class Context:
 
 
 def pinned_copy(a):
-    """A float32 copy of `a` in page-locked host memory (torch's allocator): what cvo_hip_set_pcd_many transfers from
-    where it is.  The array keeps its tensor alive."""
+    """A float32 copy of `a` in page-locked host memory (torch's allocator).  cvo_hip_set_pcd_many stages every array into its
+    own arena whatever memory it comes from (a transfer per page-locked array measured slower than one staged copy,
+    profiles/r04_ab.txt 7): this only serves tests that hand over from such memory.  The array keeps its tensor alive (.base)."""
     import torch
     t = torch.from_numpy(np.ascontiguousarray(a, np.float32)).pin_memory()
-    out = t.numpy()
-    _PINNED_KEEP[id(out)] = t
-    return out
-
-
-_PINNED_KEEP = {}
+    return t.numpy()
 
 
 def set_pcd_many(contexts, fixed, moving, layout=FEAT_ROWMAJOR):

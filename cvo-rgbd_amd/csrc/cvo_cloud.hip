@@ -15,6 +15,8 @@
 
 #include <rocprim/device/device_radix_sort.hpp>
 
+#include <atomic>
+
 #include "cvo_cloud.h"
 
 namespace cvo_dev {
@@ -400,11 +402,15 @@ hipError_t cloud_prepare_many(const CloudJob *d_jobs, int count, int nmax, hipSt
     if (count <= 0) return hipSuccess;
     if (nmax > CLOUD_ONE_MAX) return hipErrorInvalidValue;
     const size_t smem = cloud_one_smem_bytes(nmax);
-    static bool allowed = false;
-    if (!allowed) {
-        const hipError_t e = allow_smem(k_cloud_one, cloud_one_smem_bytes(CLOUD_ONE_MAX));
-        if (e != hipSuccess) return e;
-        allowed = true;
+    {   // (an attribute of the function on the CURRENT device: once per device, whichever thread comes first)
+        static std::atomic<unsigned char> allowed[64];
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+        if (!allowed[dev].load(std::memory_order_acquire)) {
+            const hipError_t e = allow_smem(k_cloud_one, cloud_one_smem_bytes(CLOUD_ONE_MAX));
+            if (e != hipSuccess) return e;
+            allowed[dev].store(1, std::memory_order_release);
+        }
     }
     hipLaunchKernelGGL(k_cloud_one, dim3((unsigned)count), dim3(ONE_T), smem, s, d_jobs, cloud_one_cap(nmax));
     return hipGetLastError();
@@ -415,11 +421,15 @@ hipError_t cloud_prepare_one(const CloudJob &job, hipStream_t s)
     if (job.n <= 0) return hipSuccess;
     if (job.n > CLOUD_ONE_MAX) return hipErrorInvalidValue;
     const size_t smem = cloud_one_smem_bytes(job.n);
-    static bool allowed = false;
-    if (!allowed) {
-        const hipError_t e = allow_smem(k_cloud_one_value, cloud_one_smem_bytes(CLOUD_ONE_MAX));
-        if (e != hipSuccess) return e;
-        allowed = true;
+    {
+        static std::atomic<unsigned char> allowed[64];
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+        if (!allowed[dev].load(std::memory_order_acquire)) {
+            const hipError_t e = allow_smem(k_cloud_one_value, cloud_one_smem_bytes(CLOUD_ONE_MAX));
+            if (e != hipSuccess) return e;
+            allowed[dev].store(1, std::memory_order_release);
+        }
     }
     hipLaunchKernelGGL(k_cloud_one_value, dim3(1), dim3(ONE_T), smem, s, job, cloud_one_cap(job.n));
     return hipGetLastError();

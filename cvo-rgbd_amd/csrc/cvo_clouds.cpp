@@ -11,6 +11,13 @@ using namespace cvo_impl;
 
 namespace cvo_impl {
 
+static inline void cpu_relax()
+{
+#if defined(__SSE2__)
+    _mm_pause();
+#endif
+}
+
 // The caller's array into the staging arena with streaming stores: the destination is written once and read by
 // the DMA engine, never by this core -- no read-for-ownership of 41 MB of staging per batch, and the caller's
 // arrays stay in the cache that held them.  dst is 16-byte aligned (the arena's pieces are 256-byte aligned).
@@ -188,7 +195,7 @@ int upload_cloud(cvo_hip_ctx *ctx, Cloud &c, const float *xyz, const float *feat
 // ---------------------------------------------------------------------------
 // The hand-over of a batch (cvo_hip_set_pcd_many): per device one stream, one pinned staging arena, one device
 // arena for the caller's arrays as they come, a table of CloudJobs -- kept for the life of the process, like the
-// engines.  One transfer per batch (or one per array where the caller's memory is page-locked already), one
+// engines.  One transfer per batch (or one per array where the caller's memory is page-locked already -- not implemented: the staged copy measured faster, profiles/r04_ab.txt 7), one
 // launch of k_cloud_one for all clouds of up to CLOUD_ONE_MAX points, one event the clouds of the batch wait
 // for.  Larger clouds take upload_cloud's way.
 struct Handover {
@@ -271,6 +278,15 @@ int cvo_hip_set_pcd_many(cvo_hip_ctx *const *ctxs, const float *const *fixed_xyz
             if (ctxs[q] == ctxs[k]) return CVO_HIP_ERR_INVALID;   // (two clouds of a batch would land in the same device arrays)
     }
     cvo_hip_ctx *c0 = ctxs[0];
+    // (every argument of the whole batch before any context is touched: a bad cloud in the middle must not leave the
+    // earlier contexts with new counts over old rows)
+    if (feat_layout != CVO_HIP_FEAT_COLMAJOR && feat_layout != CVO_HIP_FEAT_ROWMAJOR) return fail(c0, CVO_HIP_ERR_INVALID, "unknown feature layout");
+    for (int k = 0; k < count; ++k) {
+        if (n_moving[k] < 0 || (n_moving[k] > 0 && (!moving_xyz[k] || !moving_feat[k])))
+            return fail(c0, CVO_HIP_ERR_INVALID, "batched hand-over: a moving cloud without its arrays (or a negative count)");
+        if (fixed_xyz && fixed_xyz[k] && (n_fixed[k] < 0 || (n_fixed[k] > 0 && !fixed_feat[k])))
+            return fail(c0, CVO_HIP_ERR_INVALID, "batched hand-over: a fixed cloud without its features (or a negative count)");
+    }
     HIP_TRY(c0, hipSetDevice(c0->device));
     Handover *ho = handover_of(c0->device);
     if (!ho) return fail(c0, CVO_HIP_ERR_INVALID, "device index out of range");
@@ -283,6 +299,14 @@ int cvo_hip_set_pcd_many(cvo_hip_ctx *const *ctxs, const float *const *fixed_xyz
     struct Item { cvo_hip_ctx *ctx; Cloud *c; const float *xyz, *feat; int n; size_t off_xyz, off_feat; };
     std::vector<Item> small;
     size_t raw_need = 0;
+    // A failure behind this point (out of memory on a grow, a transfer or a launch that does not go out) leaves clouds that were
+    // reserved -- new counts, zeroed box -- but never filled: they are emptied, so that the next compute entry point of their
+    // context fails on an empty cloud instead of registering stale rows.  (The state of the batch's clouds after an error is
+    // otherwise undefined: hand them over again.)
+    size_t filled = 0;   // clouds of `small` whose piece has gone out
+    auto void_unfilled = [&]() {
+        for (size_t q = filled; q < small.size(); ++q) { small[q].c->n = 0; small[q].c->np = 0; small[q].c->pending = false; small[q].c->wait_ev = nullptr; }
+    };
     for (int k = 0; k < count; ++k) {
         cvo_hip_ctx *ctx = ctxs[k];
         for (int which = 0; which < 2; ++which) {
@@ -294,11 +318,11 @@ int cvo_hip_set_pcd_many(cvo_hip_ctx *const *ctxs, const float *const *fixed_xyz
             if (which == 1) ctx->have_tf = false;
             if (n > CLOUD_ONE_MAX || n <= 0) {
                 const int rc = upload_cloud(ctx, c, xyz, feat, n, feat_layout);
-                if (rc) return rc;
+                if (rc) { void_unfilled(); return rc; }
                 continue;
             }
             const int rc = cloud_reserve(ctx, c, xyz, feat, n, feat_layout);
-            if (rc) return rc;
+            if (rc) { void_unfilled(); return rc; }
             Item it{ctx, &c, xyz, feat, n, 0, 0};
             const size_t bx = ((size_t)n * 12 + 255) & ~(size_t)255, bf = ((size_t)n * 20 + 255) & ~(size_t)255;
             it.off_xyz = raw_need; it.off_feat = raw_need + bx;   // (the staging arena mirrors the device arena)
@@ -308,14 +332,15 @@ int cvo_hip_set_pcd_many(cvo_hip_ctx *const *ctxs, const float *const *fixed_xyz
     }
     if (small.empty()) return CVO_HIP_OK;
     // the arenas are the previous batch's until its last event has completed
-    if (ho->last) HIP_TRY(c0, hipEventSynchronize(ho->last));
+    if (ho->last && hipEventSynchronize(ho->last) != hipSuccess) { void_unfilled(); return fail(c0, CVO_HIP_ERR_HIP, "batched hand-over: the previous batch's event failed"); }
     if (raw_need > ho->raw_bytes) {
-        if (ho->raw) HIP_TRY(c0, hipFree(ho->raw));
+        if (ho->raw) (void)hipFree(ho->raw);
         if (ho->stage) (void)hipHostFree(ho->stage);
         ho->raw = nullptr; ho->stage = nullptr; ho->raw_bytes = 0;
         const size_t want = raw_need + raw_need / 4;
         if (hipMalloc((void **)&ho->raw, want) != hipSuccess || hipHostMalloc((void **)&ho->stage, want, hipHostMallocDefault) != hipSuccess) {
             (void)hipGetLastError();
+            void_unfilled();
             return fail(c0, CVO_HIP_ERR_NOMEM, "hand-over arena allocation failed");
         }
         ho->raw_bytes = want;
@@ -328,6 +353,7 @@ int cvo_hip_set_pcd_many(cvo_hip_ctx *const *ctxs, const float *const *fixed_xyz
         if (hipHostMalloc((void **)&ho->jobs_pin, (size_t)want * sizeof(CloudJob), hipHostMallocDefault) != hipSuccess ||
             hipMalloc((void **)&ho->jobs_dev, (size_t)want * sizeof(CloudJob)) != hipSuccess) {
             (void)hipGetLastError();
+            void_unfilled();
             return fail(c0, CVO_HIP_ERR_NOMEM, "hand-over job table allocation failed");
         }
         ho->jobs_cap = want;
@@ -342,7 +368,11 @@ int cvo_hip_set_pcd_many(cvo_hip_ctx *const *ctxs, const float *const *fixed_xyz
         jb.bbox_out = it.c->bbox_pin_dev;
         ho->jobs_pin[q] = jb;
     }
-    HIP_TRY(c0, hipMemcpyAsync(ho->jobs_dev, ho->jobs_pin, small.size() * sizeof(CloudJob), hipMemcpyHostToDevice, ho->s));
+    if (hipMemcpyAsync(ho->jobs_dev, ho->jobs_pin, small.size() * sizeof(CloudJob), hipMemcpyHostToDevice, ho->s) != hipSuccess) {
+        (void)hipGetLastError();
+        void_unfilled();
+        return fail(c0, CVO_HIP_ERR_HIP, "batched hand-over: job table transfer failed");
+    }
     // The batch goes out in a few pieces -- the caller's arrays into the staging arena (a few host threads, a share
     // of a piece's clouds each: one thread moves ~10 GB/s, 128 clouds of 10k points are 41 MB), one transfer, one
     // launch, one event per piece -- so that the transfer of a piece runs while the next one is staged, and the
@@ -362,7 +392,7 @@ int cvo_hip_set_pcd_many(cvo_hip_ctx *const *ctxs, const float *const *fixed_xyz
         const int hw = (int)std::thread::hardware_concurrency();
         return std::min(8, std::max(2, hw / 2));
     }();
-    const int nt = (int)std::max<size_t>(1, std::min<size_t>((size_t)max_threads, raw_need / ((size_t)2 << 20)));
+    int nt = (int)std::max<size_t>(1, std::min<size_t>((size_t)max_threads, raw_need / ((size_t)2 << 20)));
     std::vector<std::atomic<int>> staged(piece_end.size());
     for (auto &a : staged) a.store(0);
     char *stage = ho->stage;
@@ -379,18 +409,26 @@ int cvo_hip_set_pcd_many(cvo_hip_ctx *const *ctxs, const float *const *fixed_xyz
         }
     };
     std::vector<std::thread> pool;
-    for (int t = 1; t < nt; ++t) pool.emplace_back(work, t);
     struct Join { std::vector<std::thread> &p; ~Join() { for (auto &th : p) if (th.joinable()) th.join(); } } join_guard{pool};
+    pool.reserve((size_t)nt);
+    try {
+        for (int t = 1; t < nt; ++t) pool.emplace_back(work, t);
+    } catch (const std::system_error &) {
+        // (no thread to be had: the helpers that did start keep their shares -- they stride by the nt they were given --, this
+        // thread takes the shares of the ones that did not)
+    }
+    const int started = (int)pool.size() + 1;
     size_t lo = 0;
     int rc_out = CVO_HIP_OK;
     for (size_t pc = 0; pc < piece_end.size() && rc_out == CVO_HIP_OK; ++pc) {
-        // (this thread's share of the piece, then the others')
-        for (size_t q = lo; q < piece_end[pc]; q += (size_t)nt) {
-            const Item &it = small[q];
-            stage_copy(stage + it.off_xyz, it.xyz, (size_t)it.n * 12);
-            stage_copy(stage + it.off_feat, it.feat, (size_t)it.n * 20);
-        }
-        while (staged[pc].load(std::memory_order_acquire) < nt - 1) __builtin_ia32_pause();
+        // (this thread's share of the piece -- and of the helpers that could not be started --, then the others')
+        for (int t = 0; t < nt; t = t == 0 ? started : t + 1)
+            for (size_t q = lo + (size_t)t; q < piece_end[pc]; q += (size_t)nt) {
+                const Item &it = small[q];
+                stage_copy(stage + it.off_xyz, it.xyz, (size_t)it.n * 12);
+                stage_copy(stage + it.off_feat, it.feat, (size_t)it.n * 20);
+            }
+        while (staged[pc].load(std::memory_order_acquire) < started - 1) cpu_relax();
         const size_t hi = piece_end[pc];
         const size_t b0 = small[lo].off_xyz, b1 = small[hi - 1].off_feat + (((size_t)small[hi - 1].n * 20 + 255) & ~(size_t)255);
         int nmax = 0;
@@ -401,12 +439,14 @@ int cvo_hip_set_pcd_many(cvo_hip_ctx *const *ctxs, const float *const *fixed_xyz
             cloud_prepare_many(ho->jobs_dev + lo, (int)(hi - lo), nmax, ho->s) != hipSuccess ||
             hipEventRecord(ev, ho->s) != hipSuccess) {
             (void)hipGetLastError();
+            void_unfilled();
             rc_out = fail(c0, CVO_HIP_ERR_HIP, "batched hand-over: transfer or launch failed");
             break;
         }
         ho->last = ev;
         for (size_t q = lo; q < hi; ++q) { small[q].c->wait_ev = ev; small[q].c->pending = true; }
         lo = hi;
+        filled = hi;
     }
     return rc_out;
 }

@@ -172,7 +172,9 @@ int cvo_hip_swap_moving_to_fixed(cvo_hip_ctx *ctx);
  * arrays are copied into the library's own page-locked staging (by a few host threads, in pieces whose transfers
  * overlap the staging of the next piece) and are free when the call returns.  The call does not wait for the
  * device: a cloud's hand-over ends when the next compute entry point of its context needs it.  All contexts
- * must be on one device. */
+ * must be on one device.  Every argument of the whole batch is checked before any context is touched; after an error further on
+ * (out of memory, a transfer or launch that does not go out) the clouds of the batch that were not filled are left EMPTY -- the
+ * next compute entry point of their context fails on them -- and the batch must be handed over again. */
 int cvo_hip_set_pcd_many(cvo_hip_ctx *const *ctxs, const float *const *fixed_xyz, const float *const *fixed_feat,
                          const int *n_fixed, const float *const *moving_xyz, const float *const *moving_feat,
                          const int *n_moving, int feat_layout, int count);

@@ -18,15 +18,32 @@ typedef unsigned long long u64;
 
 __device__ __forceinline__ double value_of(int it, int r, int k) { return (double)(it * 7 + r * 3 + k) * 0.125; }
 
+// fixed order whatever the arrival order: 8 partial chains per value (rows c, c + 8, ...), then a fixed tree
+__device__ __forceinline__ void block_sum(const double *s_val, double *s_part, double *s_tot, int G, int tid)
+{
+    if (tid < 8 * NV) {
+        const int k = tid % NV, c = tid / NV;
+        double a = 0.0;
+        for (int q = c; q < G; q += 8) a += s_val[q * NV + k];
+        s_part[c * NV + k] = a;
+    }
+    __syncthreads();
+    if (tid < NV)
+        s_tot[tid] = ((s_part[tid] + s_part[NV + tid]) + (s_part[2 * NV + tid] + s_part[3 * NV + tid])) +
+                     ((s_part[4 * NV + tid] + s_part[5 * NV + tid]) + (s_part[6 * NV + tid] + s_part[7 * NV + tid]));
+}
+
 __global__ void __launch_bounds__(TPB) k_exchange(u64 *mail, unsigned *counter, int rounds, int mode, int *errors, int *placement_ok, int G, int stride)
 {
-    if ((blockIdx.x % stride) != 0u) return;
+    const bool reducer = mode == 3 && blockIdx.x == gridDim.x - 1;
+    if (!reducer && (blockIdx.x % stride) != 0u) return;
     const int r = blockIdx.x / stride;
-    if (r >= G) return;
+    if (!reducer && r >= G) return;
     const int xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xf;
     if (threadIdx.x == 0 && xcc == (int)(blockIdx.x & 7u)) atomicAdd(placement_ok, 1);
     __shared__ double s_val[GMAX * NV];
     __shared__ double s_tot[NV];
+    __shared__ double s_part[8 * NV];
     const int tid = threadIdx.x;
     int bad = 0;
     for (int it = 0; it < rounds; ++it) {
@@ -40,11 +57,30 @@ __global__ void __launch_bounds__(TPB) k_exchange(u64 *mail, unsigned *counter, 
                 const unsigned half = (tid & 1) ? (unsigned)(bits >> 32) : (unsigned)bits;
                 __hip_atomic_store(&slot[(size_t)r * (2 * NV) + tid], ((u64)seq << 32) | half, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-            // 576 words, 512 threads: thread t polls word t (and t + 512)
-            for (int wi = tid; wi < G * 2 * NV; wi += TPB) {
-                u64 w;
-                do { w = __hip_atomic_load(&slot[wi], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while ((unsigned)(w >> 32) != seq);
-                reinterpret_cast<unsigned *>(s_val)[wi] = (unsigned)w;   // little endian: word 2k = low half of double k
+            // thread t polls words t, t + 512, ...: ALL of them requested before any is looked at (one after the other, every word is a
+            // round trip of its own: 256 blocks = 9 words per thread took 11 us)
+            {
+                constexpr int KMAX = (GMAX * 2 * NV + TPB - 1) / TPB;
+                const int nw = G * 2 * NV;
+                bool all;
+                do {
+                    u64 w[KMAX];
+#pragma unroll
+                    for (int k = 0; k < KMAX; ++k) {
+                        const int wi = tid + k * TPB;
+                        w[k] = wi < nw ? __hip_atomic_load(&slot[wi], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ((u64)seq << 32);
+                    }
+                    all = true;
+#pragma unroll
+                    for (int k = 0; k < KMAX; ++k) all = all && (unsigned)(w[k] >> 32) == seq;
+                    if (all) {
+#pragma unroll
+                        for (int k = 0; k < KMAX; ++k) {
+                            const int wi = tid + k * TPB;
+                            if (wi < nw) reinterpret_cast<unsigned *>(s_val)[wi] = (unsigned)w[k];
+                        }
+                    }
+                } while (!all);
             }
         } else if (mode == 1) {
             typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -63,6 +99,63 @@ __global__ void __launch_bounds__(TPB) k_exchange(u64 *mail, unsigned *counter, 
                 } while (v.z != seq);
                 s_val[ui] = __longlong_as_double((long long)(((u64)v.y << 32) | v.x));
             }
+        } else if (mode == 3) {
+            // two hops: rows in (LL words), the reducer (the LAST block of the grid: it holds no row) polls them all, adds in the fixed order and
+            // publishes NV totals as LL words; every block polls the totals
+            u64 *slot = mail + ((size_t)gen * (GMAX + 1)) * (2 * NV);
+            u64 *totw = slot + (size_t)GMAX * (2 * NV);
+            if (!reducer && tid < 2 * NV) {
+                const double v = value_of(it, r, tid >> 1);
+                const u64 bits = (u64)__double_as_longlong(v);
+                const unsigned half = (tid & 1) ? (unsigned)(bits >> 32) : (unsigned)bits;
+                __hip_atomic_store(&slot[(size_t)r * (2 * NV) + tid], ((u64)seq << 32) | half, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (reducer) {
+                {
+                    constexpr int KMAX = (GMAX * 2 * NV + TPB - 1) / TPB;
+                    const int nw = G * 2 * NV;
+                    bool all;
+                    do {
+                        u64 w[KMAX];
+#pragma unroll
+                        for (int k = 0; k < KMAX; ++k) {
+                            const int wi = tid + k * TPB;
+                            w[k] = wi < nw ? __hip_atomic_load(&slot[wi], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ((u64)seq << 32);
+                        }
+                        all = true;
+#pragma unroll
+                        for (int k = 0; k < KMAX; ++k) all = all && (unsigned)(w[k] >> 32) == seq;
+                        if (all) {
+#pragma unroll
+                            for (int k = 0; k < KMAX; ++k) {
+                                const int wi = tid + k * TPB;
+                                if (wi < nw) reinterpret_cast<unsigned *>(s_val)[wi] = (unsigned)w[k];
+                            }
+                        }
+                    } while (!all);
+                }
+                __syncthreads();
+                block_sum(s_val, s_part, s_tot, G, tid);
+                __syncthreads();
+                if (tid < 2 * NV) {
+                    const u64 bits = (u64)__double_as_longlong(s_tot[tid >> 1]);
+                    const unsigned half = (tid & 1) ? (unsigned)(bits >> 32) : (unsigned)bits;
+                    __hip_atomic_store(&totw[tid], ((u64)seq << 32) | half, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            } else {
+                if (tid < 2 * NV) {
+                    u64 w;
+                    do { w = __hip_atomic_load(&totw[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while ((unsigned)(w >> 32) != seq);
+                    reinterpret_cast<unsigned *>(s_tot)[tid] = (unsigned)w;
+                }
+            }
+            __syncthreads();
+            if (tid < NV) {
+                const double want = 0.125 * ((double)G * (double)(it * 7 + tid) + 3.0 * 0.5 * (double)G * (double)(G - 1));
+                if (s_tot[tid] != want) ++bad;
+            }
+            __syncthreads();
+            continue;
         } else {
             double *slot = reinterpret_cast<double *>(mail) + ((size_t)gen * G) * 16;
             if (tid < NV) __hip_atomic_store(&slot[(size_t)r * 16 + tid], value_of(it, r, tid), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -76,16 +169,10 @@ __global__ void __launch_bounds__(TPB) k_exchange(u64 *mail, unsigned *counter, 
             for (int ui = tid; ui < G * NV; ui += TPB) s_val[ui] = __hip_atomic_load(&slot[(size_t)(ui / NV) * 16 + (ui % NV)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         __syncthreads();
-        if (tid < NV) {   // fixed order: four chains, then a tree
-            double c[4] = {0.0, 0.0, 0.0, 0.0};
-            for (int q = 0; q < G / 4; ++q)
-                for (int u = 0; u < 4; ++u) c[u] += s_val[(u * (G / 4) + q) * NV + tid];
-            s_tot[tid] = (c[0] + c[1]) + (c[2] + c[3]);
-        }
+        block_sum(s_val, s_part, s_tot, G, tid);
         __syncthreads();
         if (tid < NV) {
-            double want = 0.0;
-            for (int q = 0; q < G; ++q) want += value_of(it, q, tid);
+            const double want = 0.125 * ((double)G * (double)(it * 7 + tid) + 3.0 * 0.5 * (double)G * (double)(G - 1));
             if (s_tot[tid] != want) ++bad;   // (multiples of 1/8 below 2^40: every order gives the same double)
         }
     }
@@ -96,19 +183,20 @@ int main()
 {
     const int rounds = 2000;
     u64 *mail; unsigned *cnt; int *err, *ok;
-    const size_t mail_bytes = 2 * GMAX * 16 * 16;
+    const size_t mail_bytes = 2 * (GMAX + 1) * 18 * 8 + 2 * GMAX * 16 * 16;
     hipMalloc(&mail, mail_bytes); hipMalloc(&cnt, 256); hipMalloc(&err, 4); hipMalloc(&ok, 4);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    const int shapes[][2] = {{32, 8}, {64, 4}, {128, 2}, {256, 1}, {32, 1}, {8, 32}};   // (blocks, stride): one XCD; 2, 4, 8 XCDs; 32 blocks spread over 8 XCDs; 8 blocks one per XCD...
+    const int shapes[][2] = {{32, 8}, {64, 4}, {128, 2}, {256, 1}, {32, 1}, {8, 32}, {16, 1}};   // (blocks, stride): one XCD; 2, 4, 8 XCDs; 32 blocks spread over 8 XCDs; 8 blocks one per XCD...
     for (auto &sh : shapes)
-    for (int mode = 0; mode < 3; ++mode) {
+    for (int mode = 0; mode < 4; ++mode) {
+        if (mode == 1) continue;
         const int G = sh[0], stride = sh[1];
         float best = 1e9f; int errh = 0, okh = 0;
         for (int rep = 0; rep < 3; ++rep) {
             hipMemset(mail, 0, mail_bytes); hipMemset(cnt, 0, 256); hipMemset(err, 0, 4); hipMemset(ok, 0, 4);
             hipDeviceSynchronize();
             hipEventRecord(e0);
-            hipLaunchKernelGGL(k_exchange, dim3(G * stride), dim3(TPB), 0, 0, mail, cnt, rounds, mode, err, ok, G, stride);
+            hipLaunchKernelGGL(k_exchange, dim3(G * stride + (mode == 3 ? 1 : 0)), dim3(TPB), 0, 0, mail, cnt, rounds, mode, err, ok, G, stride);
             hipEventRecord(e1);
             hipDeviceSynchronize();
             float ms; hipEventElapsedTime(&ms, e0, e1);
@@ -117,7 +205,7 @@ int main()
             hipMemcpy(&okh, ok, 4, hipMemcpyDeviceToHost);
         }
         printf("%3d blocks, every %d-th of the grid, mode %d (%s): %.3f us per exchange round, %d wrong sums, %d of %d blocks on XCD (block %% 8)\n", G, stride, mode,
-               mode == 0 ? "LL 8-byte words" : (mode == 1 ? "16-byte tagged units" : "stores + counter barrier + loads"),
+               mode == 0 ? "LL 8-byte words" : (mode == 1 ? "16-byte tagged units" : (mode == 2 ? "stores + counter barrier + loads" : "two hops: rows in, one block adds, totals out")),
                best * 1e3 / rounds, errh, okh, G);
     }
     return 0;
