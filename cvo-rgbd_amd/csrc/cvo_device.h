@@ -371,6 +371,8 @@ struct PostStepArgs {
                                 // batch when the running one is down to its last slot instead of a whole batch ahead
     int nblk;
     const CommTable *comm; // see PostFlowArgs
+    uint32_t *build_mask;  // the table's build masks (kt_filter; null: the plan has no filter launch of its own) and this slot's bit
+    uint32_t slot_bit;
     // resident runs (kt_run; null / 0: the plan has none)
     RunMail *run_mail;
     int32_t *run_mirror;   // pinned: DevState::run_count
@@ -391,6 +393,7 @@ struct PostStepArgs {
 //   * the merged launches (flow pass + self passes + list builds in one grid) read only the
 //     fields of the role a block plays, when it needs them: no scalar-register spills.
 // An empty slot (active == 0) costs one scalar load per block.
+constexpr size_t kTableHeaderBytes = 256;   // in front of a table's slots: uint32_t build_mask[3] (+ padding), see kt_filter
 constexpr int MAX_OPS = 10;   // launches of one iteration (9 for acvo in a fused group: 3 filters, flow, 2 selfs, post, step, post)
 struct OpArgs {
     ProcessArgs p;            // PROCESS; the flow pass of a merged launch
@@ -756,6 +759,7 @@ struct TLaunch {
     int q;               // op index in the slots
     unsigned gx, gz;     // grid.x, grid.z (= slots served)
     unsigned smem;       // dynamic LDS bytes
+    int list;            // TK_FILTER: which tile list it builds (its word of the table's build masks)
 };
 // (parity: of the slot within its batch, head-mode kernels only)
 void launch_table(const Slot *tab, const TLaunch &l, hipStream_t s, hipEvent_t ev_start = nullptr,

@@ -139,6 +139,7 @@ struct Engine {
                 rc = fail(c, CVO_HIP_ERR_HIP, "resume failed");
             *c->done_mirror = 0;
             launch_prepare(c->st, loop_params(c), s);
+            (void)tab.arm(s);   // (the lists are built anew: the build masks' bits of every slot up)
             j->phase = 0;
         } else {
             rc = job_begin(*j);
@@ -157,6 +158,7 @@ struct Engine {
         member[z] = j;
         ops[z].clear();
         dirty = true;
+        (void)tab.arm(s);   // (a registration begins: everything is built; the replan that follows arms again with its copy)
         return CVO_HIP_OK;
     }
 
@@ -201,6 +203,8 @@ struct Engine {
             ps.push_back(&slot[z]);
         }
         if (!plan_fused(po, ps, zdim, plan)) return CVO_HIP_ERR_INVALID;
+        for (int z = 0; z < ENGINE_SLOTS; ++z)
+            if (member[z]) set_build_masks(slot[z], plan, tab.masks(), z);
         const int nq = po.empty() ? 0 : (int)po[0]->size();
         if (tab.sync(slot, s, nq) != 0) return CVO_HIP_ERR_HIP;
         ++n_replans;

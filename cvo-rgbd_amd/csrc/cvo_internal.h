@@ -101,8 +101,12 @@ constexpr int kBatch = 8;
 // per slot and sends a slot again only when its image changed -- through a small ring of
 // pinned staging buffers, ordered on the stream that runs the loop.
 constexpr int kStage = 4;
+// (In front of the slots, in the same allocation: the table's BUILD MASKS, cvo_device.h kTableHeaderBytes -- one word per tile
+// list, bit z = slot z may have that list to build in the coming filter launch.  The post-step kernels keep their slot's bits;
+// whenever the host changes the table or starts a registration in it, it sets them all: a set bit only costs the full check.)
 struct TableBuf {
     Slot *dev = nullptr;
+    char *raw = nullptr;
     int nslots = 0;
     std::vector<Slot> image;          // what the device holds (after the queued copies)
     Slot *stage = nullptr;            // pinned [kStage][nslots]
@@ -115,8 +119,10 @@ struct TableBuf {
     int init(int n, hipStream_t s)
     {
         if (dev) return 0;
-        if (hipMalloc((void **)&dev, (size_t)n * sizeof(Slot)) != hipSuccess) { dev = nullptr; return -1; }
-        if (hipMemsetAsync(dev, 0, (size_t)n * sizeof(Slot), s) != hipSuccess) return -1;
+        if (hipMalloc((void **)&raw, kTableHeaderBytes + (size_t)n * sizeof(Slot)) != hipSuccess) { raw = nullptr; return -1; }
+        dev = reinterpret_cast<Slot *>(raw + kTableHeaderBytes);
+        if (hipMemsetAsync(raw, 0, kTableHeaderBytes + (size_t)n * sizeof(Slot), s) != hipSuccess) return -1;
+        if (arm(s) != 0) return -1;
         if (hipHostMalloc((void **)&stage, (size_t)kStage * n * sizeof(Slot), hipHostMallocDefault) != hipSuccess) return -1;
         for (int i = 0; i < kStage; ++i)
             if (hipEventCreateWithFlags(&stage_ev[i], hipEventDisableTiming) != hipSuccess) return -1;
@@ -129,10 +135,13 @@ struct TableBuf {
         for (int i = 0; i < kStage; ++i)
             if (stage_ev[i]) (void)hipEventDestroy(stage_ev[i]);
         if (stage) (void)hipHostFree(stage);
-        if (dev) (void)hipFree(dev);
-        dev = nullptr; stage = nullptr; nslots = 0;
+        if (raw) (void)hipFree(raw);
+        dev = nullptr; raw = nullptr; stage = nullptr; nslots = 0;
         image.clear();
     }
+    uint32_t *masks() const { return reinterpret_cast<uint32_t *>(raw); }
+    // every slot may have every list to build (stream-ordered): after a change of the table, at the start of a registration
+    int arm(hipStream_t s) { return hipMemsetAsync(raw, 0xff, 4 * sizeof(uint32_t), s) == hipSuccess ? 0 : -1; }
     // Make the device hold want[0 .. nslots): as far as the first `nq` argument blocks of the
     // ACTIVE slots and every slot's `active` flag go.  Whatever differs travels in ONE copy (the
     // span from the first to the last slot that changed), ordered on s -- every copy is a stop of
@@ -159,6 +168,7 @@ struct TableBuf {
             st[z] = image[(size_t)z];
         }
         if (hipMemcpyAsync(&dev[lo], &st[lo], n * sizeof(Slot), hipMemcpyHostToDevice, s) != hipSuccess) return -1;
+        if (arm(s) != 0) return -1;   // (slots may have moved: the masks' bits with them)
         if (hipEventRecord(stage_ev[b], s) != hipSuccess) return -1;
         stage_used[b] = true;
         return 0;
@@ -368,6 +378,7 @@ void drop_graphs(cvo_hip_ctx *ctx);
 TLaunch mk_launch(int kernel, int q, unsigned gx, unsigned gz, unsigned smem = 0);
 bool plan_lone(const std::vector<RecOp> &ops, Slot &slot, std::vector<TLaunch> &plan, const bool allow_head, bool *head_mode,
                std::vector<TLaunch> *pre = nullptr);
+void set_build_masks(Slot &slot, const std::vector<TLaunch> &plan, uint32_t *masks, int z);
 bool plan_fused(const std::vector<const std::vector<RecOp> *> &ops, const std::vector<Slot *> &slots, int zdim, std::vector<TLaunch> &plan);
 int run_plan(const Slot *tab, PlanCache &cache, const std::vector<TLaunch> &plan, hipStream_t s, bool use_graph, int iterations,
              const std::vector<TLaunch> *pre = nullptr);

@@ -93,6 +93,7 @@ int job_begin(AlignJob &j)
     if (!j.in_group && !ctx->profiling && !host_reduce(ctx)) {
         const int rc2 = prepare_lone_plan(ctx, j.trace_cap);
         if (rc2) return rc2;
+        if (ctx->table.arm(loop_stream(ctx)) != 0) return fail(ctx, CVO_HIP_ERR_HIP, "argument table: build masks");   // (a registration begins: everything is built)
     }
     j.enq = j.batches = j.checked = 0;
     j.runs_enq = 0;
@@ -124,6 +125,10 @@ int job_finish(AlignJob &j)
         // exchange of this world would mismatch or time out.  The mailboxes are unusable until every rank
         // has called cvo_hip_mailbox_create / _connect again; sharded calls are refused until then.
         ctx->mail_broken = true;
+        if (getenv("CVO_HIP_COMM_DEBUG"))
+            fprintf(stderr, "[cvo_hip] rank %d of %d: exchange timed out at iteration k = %d (executed %d), mail_seq %llu, mail_snap %llu, slots %d, twist in launch %d\n",
+                    ctx->mail_rank, ctx->mail_world, f.k, f.n_exec, (unsigned long long)f.mail_seq, (unsigned long long)f.mail_snap, f.n_slots,
+                    (int)(ctx->plan.size() == 4));
         return fail(ctx, CVO_HIP_ERR_COMM, "mailbox all-reduce timed out: a peer rank never delivered its partial sums "
                                            "(the mailboxes must be created and connected again on every rank)");
     }
@@ -320,6 +325,7 @@ int job_pump(AlignJob &j, bool block)
     if (!ctx->profiling && !host_reduce(ctx)) {   // the lists moved: new arguments
         rc = prepare_lone_plan(ctx, j.trace_cap);
         if (rc) return finish_with(rc);
+        if (ctx->table.arm(ctx->stream) != 0) return finish_with(fail(ctx, CVO_HIP_ERR_HIP, "argument table: build masks"));
     }
     j.enq = j.batches = j.checked = 0;
     j.phase = 0;

@@ -129,6 +129,7 @@ __device__ __forceinline__ void pretransform_body(const FilterArgs &a, const uns
     if (a.check_done && a.st->done != 0) return;
     const float *Rt = a.st->Rt;
     const float *tt = a.st->t;
+    // (nblocks: the blocks that take part -- at most one per BLOCK points, see kt_filter)
     for (unsigned j = bid * BLOCK + threadIdx.x; j < (unsigned)a.nb; j += nblocks * BLOCK) {
         const float4 y0 = a.pos_b[j];
         float4 y = apply_tf(Rt, tt, y0);
@@ -2101,6 +2102,13 @@ __device__ __forceinline__ void head_prepare_lists(const PostStepArgs &a, const 
     const int tid = threadIdx.x;
     const int nthr = blockDim.x;
     const bool async = a.prm.async_xy != 0, aself = a.prm.async_self != 0;
+    // this slot's bits of the table's build masks (kt_filter): set where the coming filter launch has that list to build
+    if (a.build_mask && tid < 3) {
+        const bool sync_list = !((async && tid == LIST_XY) || (aself && tid != LIST_XY));
+        const bool build = sync_list && s_st->done == RUNNING && s_st->reuse[tid] == 0;
+        if (build) atomicOr(&a.build_mask[tid], a.slot_bit);
+        else atomicAnd(&a.build_mask[tid], ~a.slot_bit);
+    }
     if (!(s_st->done == RUNNING || s_st->done == NEED_BIGGER_LIST)) return;
 #pragma unroll
     for (int l = 0; l < 3; ++l) {   // synchronous lists (classic plans)
@@ -2271,20 +2279,38 @@ typedef const __attribute__((address_space(4))) Slot *CSlot;
 #define CVO_FILTER_ROLE(role) (*(const FilterArgs *)(&cs->op[q + (role)].f))
 
 __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(6, 8)))
-kt_filter(const Slot *__restrict__ tab, const int q)
+kt_filter(const Slot *__restrict__ tab, const int ql)
 {
+    const int q = ql & QP_MASK, list = (ql >> 8) & 3;   // (the list rides in the launch's argument: no load in front of the mask's)
+    // The table's build mask of this list (in front of the slots, kTableHeaderBytes): bit z clear = slot z has certainly nothing to
+    // build in this launch -- what 60 of 65 filter launches of a registration find.  One word for all blocks of all slots (a scalar
+    // load that hits after the first), read BEFORE the slot's own arguments and state: a block that is not needed leaves after it,
+    // which is what lets a crowded engine give a build 256 blocks per slot instead of 64 (profiles/r05_ab.txt 10).  The
+    // first blocks of a slot stay for the transform pass that rides here (one per BLOCK points).
+    typedef const __attribute__((address_space(4))) uint32_t *CMask;   // (a scalar load, like the table's own words)
+    const CMask masks = (CMask)(reinterpret_cast<const char *>(tab) - kTableHeaderBytes);
+    const bool may_build = ((masks[list] >> blockIdx.z) & 1u) != 0u;
+    constexpr unsigned PT_BLOCKS = 64;   // (blocks that stay for the transform pass: 16 384 points in one sweep)
+    if (!may_build && blockIdx.x >= PT_BLOCKS) return;
     CVO_SLOT(tab);
-    filter_body(CVO_ARG(FilterArgs, op[q].f), blockIdx.x, gridDim.x, cs->op[q].f.st, 0);
-    pretransform_body(CVO_ARG(FilterArgs, op[q].f), blockIdx.x, gridDim.x);   // (after: nothing of it is live across the build)
+    if (may_build) filter_body(CVO_ARG(FilterArgs, op[q].f), blockIdx.x, gridDim.x, cs->op[q].f.st, 0);
+    if (blockIdx.x < PT_BLOCKS)
+        pretransform_body(CVO_ARG(FilterArgs, op[q].f), blockIdx.x, min(gridDim.x, PT_BLOCKS));   // (after: nothing of it is live across the build)
 }
 
 // acvo, synchronous lists, one registration: the three filters in one launch (blockIdx.y = list)
 __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(6, 8)))
 kt_filter_group(const Slot *__restrict__ tab, const int q)
 {
+    // (the build masks: see kt_filter; blockIdx.y = list = LIST_XY, LIST_XX, LIST_YY)
+    typedef const __attribute__((address_space(4))) uint32_t *CMask;
+    const CMask masks = (CMask)(reinterpret_cast<const char *>(tab) - kTableHeaderBytes);
+    const bool may_build = ((masks[blockIdx.y] >> blockIdx.z) & 1u) != 0u;
+    constexpr unsigned PT_BLOCKS = 64;
+    if (!may_build && (blockIdx.y != 0 || blockIdx.x >= PT_BLOCKS)) return;
     CVO_SLOT(tab);
-    filter_body(CVO_FILTER_ROLE((int)blockIdx.y), blockIdx.x, gridDim.x, cs->op[q + (int)blockIdx.y].f.st, 0);
-    if (blockIdx.y == 0) pretransform_body(CVO_FILTER_ROLE(0), blockIdx.x, gridDim.x);
+    if (may_build) filter_body(CVO_FILTER_ROLE((int)blockIdx.y), blockIdx.x, gridDim.x, cs->op[q + (int)blockIdx.y].f.st, 0);
+    if (blockIdx.y == 0 && blockIdx.x < PT_BLOCKS) pretransform_body(CVO_FILTER_ROLE(0), blockIdx.x, min(gridDim.x, PT_BLOCKS));
 }
 
 // kt_process<PROC_FLOW, 0> is built for loops that never read the sum of a d2 (the cvo loop: ProcessArgs::need_d2 == 0 in
@@ -3121,7 +3147,7 @@ void launch_table(const Slot *tab, const TLaunch &l, hipStream_t s, hipEvent_t e
         return;
     }
     switch (l.kernel) {
-    case TK_FILTER: hipLaunchKernelGGL(kt_filter, g, dim3(BLOCK), l.smem, s, tab, l.q); break;
+    case TK_FILTER: hipLaunchKernelGGL(kt_filter, g, dim3(BLOCK), l.smem, s, tab, l.q | (l.list << 8)); break;
     case TK_FILTER_GROUP: hipLaunchKernelGGL(kt_filter_group, dim3(l.gx, 3, l.gz), dim3(BLOCK), l.smem, s, tab, l.q); break;
     case TK_FLOW: hipLaunchKernelGGL(kt_process<PROC_FLOW>, g, dim3(BLOCK), 0, s, tab, l.q); break;
     case TK_FLOW_D2: hipLaunchKernelGGL(kt_flow_d2, g, dim3(BLOCK), 0, s, tab, l.q); break;

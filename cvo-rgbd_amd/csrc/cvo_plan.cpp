@@ -699,6 +699,7 @@ TLaunch mk_launch(int kernel, int q, unsigned gx, unsigned gz, unsigned smem)
 }
 
 long long filter_items(const FilterArgs &f) { return (long long)f.gx * f.gy; }
+constexpr long long kFusedFilterBlocks = 256;   // (64 / 256 / 512 per slot: profiles/r05_ab.txt 10)
 
 // One registration with the launches to itself: the flow side of an iteration is merged into
 // as few launches as its scheme allows (what enqueue_flow does for eager launches):
@@ -796,6 +797,7 @@ bool plan_lone(const std::vector<RecOp> &ops, Slot &slot, std::vector<TLaunch> &
             for (int i = 0; i < nf; ++i) {
                 slot.op[q].f = f[i];
                 plan.push_back(mk_launch(TK_FILTER, q, filter_grid_cap(filter_items(f[i]), fbmax), 1, smem_of(f[i].jt)));
+                plan.back().list = f[i].list;
                 ++q;
             }
         }
@@ -900,7 +902,9 @@ bool plan_fused(const std::vector<const std::vector<RecOp> *> &ops, const std::v
             case RecOp::FILTER: {
                 o.f = op.f;
                 kernel = TK_FILTER;
-                const long long cap = std::max<long long>(64, fbmax / (2 * zdim));
+                // (blocks per slot: the blocks of a slot that has nothing to build leave on the table's build mask, before any
+                // load of their own -- kt_filter --, so a build can have 256 of them where 64 used to be the price of 60 idle launches)
+                const long long cap = std::max<long long>(kFusedFilterBlocks, fbmax / (2 * zdim));
                 gx = std::max(gx, filter_grid_cap(filter_items(op.f), cap));
                 smem = std::max(smem, (unsigned)filter_smem_bytes(op.f.jt));
                 break;
@@ -937,6 +941,7 @@ bool plan_fused(const std::vector<const std::vector<RecOp> *> &ops, const std::v
             for (Slot *sl : slots) { sl->op[qs].np = np; sl->op[qs].n0 = (int)nfb; }
         }
         plan.push_back(mk_launch(kernel, (int)qs, gx, (unsigned)zdim, smem));
+        if (kernel == TK_FILTER) plan.back().list = first.f.list;
     }
     // three filters / two self passes in a row become one launch each
     std::vector<TLaunch> merged;
@@ -965,6 +970,19 @@ bool plan_fused(const std::vector<const std::vector<RecOp> *> &ops, const std::v
     }
     plan.swap(merged);
     return true;
+}
+
+// The post-step launches of a plan that has filter launches of its own keep their slot's bits of the table's build masks
+// (TableBuf, kt_filter): where the masks live, which bit is this slot's.
+void set_build_masks(Slot &slot, const std::vector<TLaunch> &plan, uint32_t *masks, int z)
+{
+    bool filters = false;
+    for (const TLaunch &l : plan) filters = filters || l.kernel == TK_FILTER || l.kernel == TK_FILTER_GROUP;
+    for (const TLaunch &l : plan)
+        if (l.kernel == TK_POST_STEP) {
+            slot.op[l.q].ps.build_mask = filters ? masks : nullptr;
+            slot.op[l.q].ps.slot_bit = 1u << z;
+        }
 }
 
 bool same_plan(const std::vector<TLaunch> &a, const std::vector<TLaunch> &b)
@@ -1065,6 +1083,7 @@ int prepare_lone_plan(cvo_hip_ctx *ctx, int trace_cap)
     Slot slot;
     if (!plan_lone(ops, slot, ctx->plan, ctx->allow_head, &ctx->head_mode, &ctx->plan_pre))
         return fail(ctx, CVO_HIP_ERR_INVALID, "launch plan does not fit the argument table");
+    set_build_masks(slot, ctx->plan, ctx->table.masks(), 0);
     if (ctx->table.sync(&slot, loop_stream(ctx)) != 0) return fail(ctx, CVO_HIP_ERR_HIP, "argument table upload failed");
     return CVO_HIP_OK;
 }

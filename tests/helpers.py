@@ -31,8 +31,13 @@ def align_two_ranks(pkg, mode, xf, ff, xm, fm, exchange="mailbox", timeout=300, 
 
     def rank(r):
         try:
-            s = torch.cuda.Stream()
-            c = capi.Context(mode=mode, device=0, stream=s.cuda_stream)
+            # (a stream of the library's own, created here and now: the ranks' streams are made back to back and land on hardware
+            # queues of their own.  Streams from torch's pool -- 32 of them, handed out in turn to whoever asks in the process --
+            # put two ranks on ONE hardware queue on some boxes: a rank that spins for its peer inside a kernel then keeps that
+            # peer's kernels from ever starting, and both time out.  Ranks that share a GPU exist in tests only.)
+            import os
+            s = torch.cuda.Stream() if os.environ.get("RANK_TORCH_STREAM") else None
+            c = capi.Context(mode=mode, device=0, stream=s.cuda_stream if s is not None else None)
             c.set_fixed(xf, ff)
             c.set_moving(xm, fm)
             lo, hi = capi.shard_range(n, r, world)
