@@ -213,6 +213,8 @@ int cvo_hip_create(int device, void *stream, const cvo_hip_params *p, cvo_hip_ct
             return bail(CVO_HIP_ERR_HIP);
     ctx->done_mirror = reinterpret_cast<int32_t *>(&ctx->st_host[kPollSlots + 1]);
     ctx->progress_mirror = ctx->done_mirror + 16;   // (its own cache line)
+    ctx->final_mirror = reinterpret_cast<DevHead *>(reinterpret_cast<char *>(ctx->done_mirror) + 2048);
+    static_assert(sizeof(DevState) >= 2048 + sizeof(DevHead), "the mirrors share a pinned DevState");
     ctx->run_mirror = ctx->done_mirror + 32;
     ctx->hint_mirror = ctx->done_mirror + 48;
     *ctx->done_mirror = 0;
@@ -719,10 +721,15 @@ int cvo_hip_get_graph_stats(const cvo_hip_ctx *ctx, long long *launches_from_cac
     return CVO_HIP_OK;
 }
 
-int cvo_hip_get_run_stats(const cvo_hip_ctx *ctx, int *runs, int *declined, int *iterations, int *candidates)
+int cvo_hip_get_run_stats(cvo_hip_ctx *ctx, int *runs, int *declined, int *iterations, int *candidates)
 {
     if (!ctx || !ctx->st_host) return CVO_HIP_ERR_INVALID;
-    const DevState &f = ctx->st_host[0];   // (the final state of the last align())
+    // (diagnostics: the counters live in the state's tail, which a cvo_hip_align that ended on the mirrored head has not copied)
+    DevState &f = ctx->st_host[0];
+    if (hipSetDevice(ctx->device) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess ||
+        hipMemcpy(&f.run_count, reinterpret_cast<const char *>(ctx->st) + offsetof(DevState, run_count),
+                  offsetof(DevState, mail_seq) - offsetof(DevState, run_count), hipMemcpyDeviceToHost) != hipSuccess)
+        return CVO_HIP_ERR_HIP;
     if (runs) *runs = f.run_entered;
     if (declined) *declined = f.run_count - f.run_entered;
     if (iterations) *iterations = f.run_iterations;
@@ -730,9 +737,13 @@ int cvo_hip_get_run_stats(const cvo_hip_ctx *ctx, int *runs, int *declined, int 
     return CVO_HIP_OK;
 }
 
-int cvo_hip_get_run_clocks(const cvo_hip_ctx *ctx, long long clocks16[16])
+int cvo_hip_get_run_clocks(cvo_hip_ctx *ctx, long long clocks16[16])
 {
     if (!ctx || !ctx->st_host || !clocks16) return CVO_HIP_ERR_INVALID;
+    if (hipSetDevice(ctx->device) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess ||
+        hipMemcpy(ctx->st_host[0].run_clk, reinterpret_cast<const char *>(ctx->st) + offsetof(DevState, run_clk), sizeof(ctx->st_host[0].run_clk),
+                  hipMemcpyDeviceToHost) != hipSuccess)
+        return CVO_HIP_ERR_HIP;
     for (int q = 0; q < 16; ++q) clocks16[q] = ctx->st_host[0].run_clk[q];
     return CVO_HIP_OK;
 }

@@ -371,6 +371,8 @@ struct PostStepArgs {
                                 // batch when the running one is down to its last slot instead of a whole batch ahead
     int nblk;
     const CommTable *comm; // see PostFlowArgs
+    DevHead *final_mirror; // pinned (null: none): the head of a loop that has STOPPED with a verdict goes there too, in front of the `done`
+                           // mirror: cvo_hip_align then returns without a copy behind the launches that are still queued
     uint32_t *build_mask;  // the table's build masks (kt_filter; null: the plan has no filter launch of its own) and this slot's bit
     uint32_t slot_bit;
     // resident runs (kt_run; null / 0: the plan has none)
@@ -729,7 +731,7 @@ CVO_HD void prepare_iteration(DevHead *s, DevHead *bulk, const bool store, const
 }
 
 size_t filter_smem_bytes(int jt);
-void launch_prepare(DevState *st, const DevParams &prm, hipStream_t s);
+void launch_prepare(DevState *st, const DevParams &prm, hipStream_t s, uint32_t *build_masks = nullptr);
 void launch_filter(const FilterArgs &a, dim3 grid, hipStream_t s, hipEvent_t ev_start = nullptr,
                    hipEvent_t ev_stop = nullptr);
 void launch_process(int mode, const ProcessArgs &a, hipStream_t s, hipEvent_t ev_start = nullptr,

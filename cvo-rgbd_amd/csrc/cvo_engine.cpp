@@ -138,8 +138,7 @@ struct Engine {
                                sizeof(zero), hipMemcpyHostToDevice, s) != hipSuccess)
                 rc = fail(c, CVO_HIP_ERR_HIP, "resume failed");
             *c->done_mirror = 0;
-            launch_prepare(c->st, loop_params(c), s);
-            (void)tab.arm(s);   // (the lists are built anew: the build masks' bits of every slot up)
+            launch_prepare(c->st, loop_params(c), s, tab.masks());   // (the lists are built anew: the build masks' bits up)
             j->phase = 0;
         } else {
             rc = job_begin(*j);

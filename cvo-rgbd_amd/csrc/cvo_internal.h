@@ -239,9 +239,11 @@ struct cvo_hip_ctx {
     DevState *st_host = nullptr;     // pinned [kPollSlots + 2]
     int32_t *done_mirror = nullptr;  // pinned (in the last slot): the post kernels copy `done` here
     int32_t *progress_mirror = nullptr;   // pinned, next to it: slots the post-step kernel has completed
+    DevHead *final_mirror = nullptr;      // pinned: the head of a loop that stopped with a verdict (PostStepArgs::final_mirror)
     int32_t *run_mirror = nullptr;        // pinned: resident runs (kt_run) that have ended since align() began
     int32_t *hint_mirror = nullptr;       // pinned: DevHead::run_hint, candidates expected in the record in use (-1: none yet)
     DevBuf run_mail;                      // RunMail of this registration's resident runs
+    bool plan_has_final_mirror = false;   // the plan of the align() in progress publishes its final head to final_mirror
     bool allow_run = true;                // CVO_HIP_NO_RUN
     int run_nnz_max = 0;                  // a batch begins with a resident run when the record in use is expected to hold at most this many candidates
     std::vector<TLaunch> plan_pre;        // launches in front of a RUN batch's iterations (the kt_run launch); empty: the plan has no run

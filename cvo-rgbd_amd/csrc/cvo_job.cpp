@@ -83,7 +83,9 @@ int job_begin(AlignJob &j)
         ctx->proc_blocks = ctx->proc_blocks_default =
             npairs <= 2.5e7 ? PROC_BLOCKS / 4 : (npairs <= (runs ? 6.0e7 : 1.5e8) ? PROC_BLOCKS / 2 : PROC_BLOCKS);
     }
-    launch_prepare(ctx->st, loop_params(ctx), loop_stream(ctx));
+    // (a member of a fused group: the group's table, armed by its insert; on its own: this context's table, whose build masks the
+    // prepare kernel sets -- it exists from the first align() on, and its first use arms it anyway)
+    launch_prepare(ctx->st, loop_params(ctx), loop_stream(ctx), (!j.in_group && ctx->table.raw) ? ctx->table.masks() : nullptr);
     HIP_TRY(ctx, hipGetLastError());
     ctx->have_tf = true;
     const int prc = prepare_buffers(ctx);
@@ -93,7 +95,6 @@ int job_begin(AlignJob &j)
     if (!j.in_group && !ctx->profiling && !host_reduce(ctx)) {
         const int rc2 = prepare_lone_plan(ctx, j.trace_cap);
         if (rc2) return rc2;
-        if (ctx->table.arm(loop_stream(ctx)) != 0) return fail(ctx, CVO_HIP_ERR_HIP, "argument table: build masks");   // (a registration begins: everything is built)
     }
     j.enq = j.batches = j.checked = 0;
     j.runs_enq = 0;
@@ -234,6 +235,20 @@ int job_pump(AlignJob &j, bool block)
                 }
             }
         }
+        {
+            // The loop has stopped.  With a verdict and a plan whose heads mirror the final head (one registration on its own):
+            // everything job_finish reads is in pinned memory already -- written in front of the `done` word -- and the call
+            // returns without a copy behind the launches of the batch that are still queued (they return at their first load;
+            // whatever uses the stream next is ordered behind them).  Else: the state comes by a copy in stream order.
+            const int32_t verdict = *(volatile int32_t *)ctx->done_mirror;
+            const bool mirrored = (verdict == DONE_BREAK_A || verdict == DONE_BREAK_B || verdict == DONE_MAX_ITER) && ctx->final_mirror &&
+                                  ctx->table.image.size() == 1 && ctx->plan_has_final_mirror;
+            if (mirrored) {
+                std::atomic_thread_fence(std::memory_order_acquire);
+                std::memcpy(&ctx->st_host[0], ctx->final_mirror, sizeof(DevHead));
+                if (ctx->st_host[0].done == verdict) return finish_with(job_finish(j));
+            }
+        }
         if (hipMemcpyAsync(&ctx->st_host[0], ctx->st, sizeof(DevState), hipMemcpyDeviceToHost,
                            ctx->stream) != hipSuccess ||
             hipEventRecord(ctx->poll_ev[0], ctx->stream) != hipSuccess)
@@ -320,12 +335,11 @@ int job_pump(AlignJob &j, bool block)
         hipMemset(reinterpret_cast<char *>(ctx->st) + offsetof(DevState, run_count), 0, sizeof(int32_t)) != hipSuccess ||
         hipDeviceSynchronize() != hipSuccess)
         return finish_with(fail(ctx, CVO_HIP_ERR_HIP, "resume failed"));
-    launch_prepare(ctx->st, loop_params(ctx), ctx->stream);   // idempotent; re-zeroes the counters
+    launch_prepare(ctx->st, loop_params(ctx), ctx->stream, ctx->table.raw ? ctx->table.masks() : nullptr);   // idempotent; re-zeroes the counters
     if (hipGetLastError() != hipSuccess) return finish_with(fail(ctx, CVO_HIP_ERR_HIP, "resume failed"));
     if (!ctx->profiling && !host_reduce(ctx)) {   // the lists moved: new arguments
         rc = prepare_lone_plan(ctx, j.trace_cap);
         if (rc) return finish_with(rc);
-        if (ctx->table.arm(ctx->stream) != 0) return finish_with(fail(ctx, CVO_HIP_ERR_HIP, "argument table: build masks"));
     }
     j.enq = j.batches = j.checked = 0;
     j.phase = 0;

@@ -2133,6 +2133,13 @@ __device__ __forceinline__ void head_prepare_lists(const PostStepArgs &a, const 
 // ... and the head goes out: the host's mirrors, then the state
 __device__ __forceinline__ void head_publish(const PostStepArgs &a, const DevHead *s_st, DevHead *out, const bool math)
 {
+    // a loop that has stopped with a verdict: the final head into the host's pinned copy, all of it there before the `done` word
+    const bool final_out = a.final_mirror != nullptr && (s_st->done == DONE_BREAK_A || s_st->done == DONE_BREAK_B || s_st->done == DONE_MAX_ITER);
+    if (final_out) {
+        state_head_from_lds(s_st, a.final_mirror);
+        __threadfence_system();
+        __syncthreads();
+    }
     if (threadIdx.x == 0) {
         // (members of A expected in the slot that begins: what the host picks the next batch's plan by, kt_run -- in front
         // of the slot count the host paces its batches on)
@@ -2216,8 +2223,10 @@ __global__ void __launch_bounds__(BLOCK) k_post_step(const Grp<PostStepArgs> grp
 
 // First iteration of an align() (or of its resumption after a list grew): no
 // list is valid, everything is rebuilt.
-__global__ void k_prepare(DevState *st, const DevParams prm)
+__global__ void k_prepare(DevState *st, const DevParams prm, uint32_t *build_masks)
 {
+    // (a registration begins in this table: every list is to be built, the build masks' bits of every slot go up -- kt_filter)
+    if (build_masks && threadIdx.x < 4) build_masks[threadIdx.x] = 0xffffffffu;
     for (int q = threadIdx.x; q < LIST_N * NSUB; q += BLOCK) (&st->sub[0][0])[q] = 0u;
     if (threadIdx.x < 16) (&st->ovf[0][0])[threadIdx.x] = 0u;
     if (threadIdx.x == 0) {
@@ -2242,9 +2251,9 @@ __global__ void k_prepare(DevState *st, const DevParams prm)
     }
 }
 
-void launch_prepare(DevState *st, const DevParams &prm, hipStream_t s)
+void launch_prepare(DevState *st, const DevParams &prm, hipStream_t s, uint32_t *build_masks)
 {
-    hipLaunchKernelGGL(k_prepare, dim3(1), dim3(BLOCK), 0, s, st, prm);
+    hipLaunchKernelGGL(k_prepare, dim3(1), dim3(BLOCK), 0, s, st, prm, build_masks);
 }
 
 void launch_post_flow_group(const PostFlowArgs *a, int n, hipStream_t s)

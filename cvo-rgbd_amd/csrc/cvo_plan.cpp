@@ -600,6 +600,8 @@ int enqueue_step(cvo_hip_ctx *ctx, int check_done, bool do_math, cvo_hip_trace *
         }
     }
     if (ctx->plan_recording && ctx->lone) pa.hint_mirror = ctx->hint_mirror;
+    // (one registration on its own, one rank: its final head goes to pinned memory with the verdict, job_pump)
+    if (ctx->plan_recording && ctx->lone && !multi_rank(ctx) && !getenv("CVO_HIP_NO_FINAL_MIRROR")) pa.final_mirror = ctx->final_mirror;
     if (host_reduce(ctx)) {
         pa.flags = POST_REDUCE;
         emit_post_step(ctx, pa);
@@ -1084,6 +1086,9 @@ int prepare_lone_plan(cvo_hip_ctx *ctx, int trace_cap)
     if (!plan_lone(ops, slot, ctx->plan, ctx->allow_head, &ctx->head_mode, &ctx->plan_pre))
         return fail(ctx, CVO_HIP_ERR_INVALID, "launch plan does not fit the argument table");
     set_build_masks(slot, ctx->plan, ctx->table.masks(), 0);
+    ctx->plan_has_final_mirror = false;
+    for (const TLaunch &l : ctx->plan)   // (the launches whose heads publish: the post-step launch, or the head-mode flow launch)
+        if ((l.kernel == TK_POST_STEP || l.kernel == TK_HFLOW_BUILD || l.kernel == TK_HFLOW_BUILD6) && slot.op[l.q].ps.final_mirror) ctx->plan_has_final_mirror = true;
     if (ctx->table.sync(&slot, loop_stream(ctx)) != 0) return fail(ctx, CVO_HIP_ERR_HIP, "argument table upload failed");
     return CVO_HIP_OK;
 }

@@ -335,10 +335,10 @@ int cvo_hip_get_graph_stats(const cvo_hip_ctx *ctx, long long *launches_from_cac
  * iterations inside one launch, csrc/cvo_kernels.hip kt_run): launches of that kernel that executed iterations, launches
  * that declined, iterations executed inside runs, candidate pairs of the record the last run looked at.  Diagnostics; any
  * pointer may be null. */
-int cvo_hip_get_run_stats(const cvo_hip_ctx *ctx, int *runs, int *declined, int *iterations, int *candidates);
+int cvo_hip_get_run_stats(cvo_hip_ctx *ctx, int *runs, int *declined, int *iterations, int *candidates);
 /* ... and, in builds with -DCVO_RUN_CLOCKS, the ticks the first solver block of the runs spent in each phase of the loop
  * (csrc/cvo_kernels.hip kt_run: RUN_CLK; zeros otherwise). */
-int cvo_hip_get_run_clocks(const cvo_hip_ctx *ctx, long long clocks16[16]);
+int cvo_hip_get_run_clocks(cvo_hip_ctx *ctx, long long clocks16[16]);
 int cvo_hip_synchronize(cvo_hip_ctx *ctx);
 
 #ifdef __cplusplus
