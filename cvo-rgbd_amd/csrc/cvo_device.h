@@ -117,13 +117,23 @@ struct CommTable {
 // polls the words themselves until the tags match (no flag, no fence; two generations: a block can be one
 // exchange ahead of the slowest reader, never two).  1.7 us per exchange among 32 blocks of one XCD
 // (tools/microbench/xcd_exchange.hip, profiles/r05_ab.txt 1).
-constexpr int RUN_G = 32;            // solver blocks of a run at most (blocks 1 .. RUN_G of the launch; block 0 is the head block)
+constexpr int RUN_G = 248;           // solver blocks of a run at most (blocks 1 .. RUN_G of the launch; block 0 is the head block): a block
+                                     // per compute unit and a few units to spare -- above RUN_G_SMALL a run first proves that all of it is resident
+constexpr int RUN_G_SMALL = 32;      // runs of up to this many solvers start without the entry handshake (eight of them fit the GPU side by side)
 constexpr int RUN_BLOCK = 512;       // 8 waves = two per SIMD: 256 vector registers per lane, the run's candidates live there
 constexpr int RUN_WAVES = RUN_BLOCK / 64;
 constexpr int RUN_LANES = RUN_G * RUN_BLOCK;
-constexpr int RUN_R = 8;             // candidates per lane at most: RUN_LANES * RUN_R = 131 072 candidates per run
+constexpr int RUN_R = 8;             // candidates per lane at most: RUN_LANES * RUN_R = 1 015 808 candidates per run
 constexpr int RUN_NV = 9;            // doubles per exchange at most (flow: 9, step: 4)
-struct RunMail { unsigned long long w[2][RUN_G + 1][2 * RUN_NV]; };   // (row RUN_G: the head block's verdict word)
+struct RunMail {
+    unsigned long long w[2][RUN_G + 1][2 * RUN_NV];   // (row RUN_G: the head block's verdict word)
+    // entry handshake of a large run: every block of every kt_run launch draws a ticket as its first act (launches of one registration
+    // follow each other in one stream, so launch L holds tickets [L NB, (L + 1) NB)); the head block waits until the g + 1 blocks
+    // that take part have drawn theirs -- blocks start in index order: they are then resident -- and says GO, or ABORT when that
+    // does not happen in time (another large run holds the compute units): nothing has been written, the run declines
+    unsigned long long entry_ticket;
+    unsigned long long entry_go;                      // (launch number + 1) << 32 | RUN_GO / RUN_ABORT
+};
 
 struct KernConsts {
     float tau;        // d2 < tau
@@ -155,6 +165,7 @@ struct DevParams {
     float build_at;      // ... a new build is scheduled when this fraction of the margin in use is gone
     int32_t async_self;  // acvo: the xx / yy lists are double-buffered too and PROC_SELF rides in the flow launch
     float color_scale;   // cvo_hip_params::color_scale
+    float run_cand_cap;  // > 0: the plan has resident runs (kt_run) that hold this many candidates in registers
     double s2_d, cs2_d, dl_step;
 };
 
@@ -599,7 +610,14 @@ CVO_HD void plan_xy_async(DevHead *s, DevHead *bulk, const bool store, const Dev
         const float lr = use ? s->xy_r[1] : s->xy_r[0];
         const float nd = use ? need1 : need0;
         if (nd - r0 > p.build_at * (lr - r0)) build = true;   // most of the margin is gone
-        if (lr > LIST_LOOSE * (1.0f + margin) * r0) build = true;     // far wider than needed
+        // far wider than needed (the length scale has dropped).  Where the plan has resident runs and the record of the list in use
+        // still fits one, "far" is farther: inside a run a candidate costs ~0.03 us per iteration, a rebuild ends the run and costs three
+        // classic slots and a new entry (~60 us) -- a list of up to 1.9 x the radius (3.6 x the candidates: one step of the cvo schedule,
+        // 0.15 -> 0.10 -> 0.06) serves on, the step 0.06 -> 0.03 (2 x) rebuilds
+        const float nnz = (float)s->red[RED_FLOW + 8];
+        const float w = lr / r0;
+        const bool fits = p.run_cand_cap > 0.0f && nnz > 0.0f && 1.05f * nnz * (r_now / fmaxf(s->r_last, 1.0e-9f)) * (r_now / fmaxf(s->r_last, 1.0e-9f)) * w * w <= 0.9f * p.run_cand_cap;
+        if (lr > (fits ? 1.9f : LIST_LOOSE) * (1.0f + margin) * r0) build = true;
     }
     if (inflight >= 0) build = false;   // (its buffer is the only one that is free)
     s->xy_fresh = inflight;

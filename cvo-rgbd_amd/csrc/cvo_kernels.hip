@@ -2632,15 +2632,17 @@ CVO_HEAD_KERNELS(_w4, 4)
 // A poll that does not fill within RUN_TIMEOUT_TICKS ends the registration with DONE_COMM_ERROR instead of hanging.
 constexpr long long RUN_TIMEOUT_TICKS = 100000000LL;   // 1 s of the 100 MHz wall clock
 enum { RUN_V_STALL = 1, RUN_V_BUILD = 2 };            // the head block's verdict on the slot that is running
+enum { RUN_GO = 1, RUN_ABORT = 2 };                    // ... and on a large run's entry (RunMail::entry_go)
+constexpr long long RUN_ENTRY_TICKS = 20000LL;         // 200 us: how long the head block of a large run waits for its solvers to start
 
 // One exchange among the g solver blocks: vals[0..NV) of this block (LDS, written before the call by threads < NV; `row` < 0:
 // this block only reads) -> tot[0..NV) = the sum of the g rows, added in ONE fixed order (four chains, then a tree).  All
 // threads call it.  seq: the exchange's number (every block counts the same).  verdict_out (block-uniform, may be null): the
 // head block's verdict word of this exchange is waited for as well and handed out.  Returns false on a time-out (block-uniform).
-template <int NV>
-__device__ __forceinline__ bool run_exchange(RunMail *mail, const int row, const int g, const unsigned long long seq, const double *vals,
-                                             double *all /* LDS [RUN_G * NV] */, double *tot /* LDS [NV] */, int *s_fail,
-                                             unsigned *verdict_out, unsigned *s_verdict)
+template <int NV, int KMAX>
+__device__ __forceinline__ bool run_exchange_k(RunMail *mail, const int row, const int g, const unsigned long long seq, const double *vals,
+                                             double *all /* LDS [RUN_G * NV] */, double *part /* LDS [8 * NV] */, double *tot /* LDS [NV] */,
+                                             int *s_fail, unsigned *verdict_out, unsigned *s_verdict)
 {
     const int tid = threadIdx.x;
     const unsigned tag = (unsigned)seq;
@@ -2653,38 +2655,65 @@ __device__ __forceinline__ bool run_exchange(RunMail *mail, const int row, const
         __hip_atomic_store(&slot[row * (2 * RUN_NV) + tid], ((unsigned long long)tag << 32) | half, __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_AGENT);
     }
-    static_assert(RUN_G * 2 * RUN_NV + 1 <= 3 * RUN_BLOCK, "a few words per thread");
-    const int nwords = g * 2 * NV + (verdict_out ? 1 : 0);
-    for (int wi = tid; wi < nwords; wi += RUN_BLOCK) {
-        const bool is_v = wi == g * 2 * NV;   // the verdict: word 0 of the row behind the solvers'
-        const int r = is_v ? RUN_G : wi / (2 * NV), k = is_v ? 0 : wi - r * (2 * NV);
-        // (the verdict's generation goes by the slot -- every second exchange carries one, their numbers have one parity)
-        const unsigned long long *src = is_v ? &mail->w[(seq >> 1) & 1ull][RUN_G][0] : &slot[r * (2 * RUN_NV) + k];
-        unsigned long long w = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if ((unsigned)(w >> 32) != tag) {
-            const long long t0 = (long long)wall_clock64();
-            do {
+    // thread t polls words t, t + 512, ...: ALL of a sweep requested before any is looked at (KMAX per thread: 2 up to 32 solvers,
+    // 9 at 248)
+    const int nrow = g * 2 * NV, nwords = nrow + (verdict_out ? 1 : 0);
+    {
+        const long long t0 = (long long)wall_clock64();
+        bool all_in;
+        do {
+            unsigned long long w[KMAX];
+#pragma unroll
+            for (int k = 0; k < KMAX; ++k) {
+                const int wi = tid + k * RUN_BLOCK;
+                // (the verdict: word 0 of the row behind the solvers'; its generation goes by the slot -- every second exchange
+                // carries one, their numbers have one parity)
+                const int r = wi / (2 * NV), c = wi - r * (2 * NV);
+                const unsigned long long *src = wi == nrow ? &mail->w[(seq >> 1) & 1ull][RUN_G][0] : &slot[r * (2 * RUN_NV) + c];
+                w[k] = wi < nwords ? __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ((unsigned long long)tag << 32);
+            }
+            all_in = true;
+#pragma unroll
+            for (int k = 0; k < KMAX; ++k) all_in = all_in && (unsigned)(w[k] >> 32) == tag;
+            if (all_in) {
+#pragma unroll
+                for (int k = 0; k < KMAX; ++k) {
+                    const int wi = tid + k * RUN_BLOCK;
+                    if (wi < nrow) reinterpret_cast<unsigned *>(all)[wi] = (unsigned)w[k];   // (little endian: word 2k is the low half of value k)
+                    else if (wi == nrow && verdict_out) *s_verdict = (unsigned)w[k];
+                }
+            } else if ((long long)wall_clock64() - t0 > RUN_TIMEOUT_TICKS) {
+                *s_fail = 1;
+                break;
+            } else {
                 __builtin_amdgcn_s_sleep(1);
-                w = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if ((unsigned)(w >> 32) == tag) break;
-            } while ((long long)wall_clock64() - t0 <= RUN_TIMEOUT_TICKS);
-            if ((unsigned)(w >> 32) != tag) *s_fail = 1;
-        }
-        if (is_v) *s_verdict = (unsigned)w;
-        else reinterpret_cast<unsigned *>(all)[r * (2 * NV) + k] = (unsigned)w;   // (little endian: word 2k is the low half of value k)
+            }
+        } while (!all_in);
     }
     __syncthreads();
-    if (tid < NV) {
-        double c[4] = {0.0, 0.0, 0.0, 0.0};
-        const int gq = g >> 2;
-        for (int q = 0; q < gq; ++q)
-#pragma unroll
-            for (int u = 0; u < 4; ++u) c[u] += all[(u * gq + q) * NV + tid];
-        tot[tid] = (c[0] + c[1]) + (c[2] + c[3]);
+    // one fixed order whatever the arrival order: eight chains per value (rows c, c + 8, ...), then a tree
+    if (tid < 8 * NV) {
+        const int k = tid % NV, c = tid / NV;
+        double a = 0.0;
+        for (int q = c; q < g; q += 8) a += all[q * NV + k];
+        part[c * NV + k] = a;
     }
+    __syncthreads();
+    if (tid < NV)
+        tot[tid] = ((part[tid] + part[NV + tid]) + (part[2 * NV + tid] + part[3 * NV + tid])) +
+                   ((part[4 * NV + tid] + part[5 * NV + tid]) + (part[6 * NV + tid] + part[7 * NV + tid]));
     __syncthreads();
     if (verdict_out) *verdict_out = *s_verdict;
     return *s_fail == 0;
+}
+template <int NV>
+__device__ __forceinline__ bool run_exchange(RunMail *mail, const int row, const int g, const unsigned long long seq, const double *vals,
+                                             double *all, double *part, double *tot, int *s_fail, unsigned *verdict_out, unsigned *s_verdict)
+{
+    static_assert(RUN_G_SMALL * 2 * RUN_NV + 1 <= 2 * RUN_BLOCK, "two words per thread up to RUN_G_SMALL solvers");
+    constexpr int KBIG = (RUN_G * 2 * NV + 1 + RUN_BLOCK - 1) / RUN_BLOCK;
+    if (g <= RUN_G_SMALL) return run_exchange_k<NV, 2>(mail, row, g, seq, vals, all, part, tot, s_fail, verdict_out, s_verdict);
+    return run_exchange_k<NV, KBIG>(mail, row, g, seq, vals, all, part, tot, s_fail, verdict_out, s_verdict);
 }
 
 // The passes of a run over NR candidates per lane, straight-line: the NR chains (transform, exact test, a float64 exp, the
@@ -2734,10 +2763,17 @@ unsigned run_grid() { return 1u + RUN_G; }
 __global__ void __launch_bounds__(RUN_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
 kt_run(const Slot *__restrict__ tab, const int qs)
 {
+    __shared__ unsigned long long s_ticket;
     const bool head_block = blockIdx.x == 0;
     const int srow = (int)blockIdx.x - 1;   // a solver's row in the exchanges (-1: the head block)
     CSlot cs = (CSlot)(tab);
     if (cs->active == 0) return;
+    // (every block of every launch that gets this far draws a ticket, whatever it does next: RunMail::entry_ticket)
+    {
+        RunMail *const m0 = CVO_ARG(PostStepArgs, op[qs & 15].ps).run_mail;
+        if (m0 == nullptr) return;
+        if (threadIdx.x == 0) s_ticket = __hip_atomic_fetch_add(&m0->entry_ticket, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     const int qf = qs & 15, qt = (qs >> 4) & 15;
     const ProcessArgs &pa = CVO_ARG(ProcessArgs, op[qf].p);     // the flow pass of the plan's classic launches
     const PostStepArgs ps = CVO_ARG(PostStepArgs, op[qf].ps);   // its head
@@ -2750,6 +2786,7 @@ kt_run(const Slot *__restrict__ tab, const int qs)
     __shared__ double s_red[RUN_WAVES * NACC_MAX];
     __shared__ double s_vals[NACC_MAX];
     __shared__ double s_all[RUN_G * RUN_NV];
+    __shared__ double s_part[8 * RUN_NV];
     __shared__ double s_tot[NACC_MAX + 4];
     __shared__ double s_etab[64];
     __shared__ cvo_math::XiConsts s_xi;
@@ -2864,10 +2901,42 @@ kt_run(const Slot *__restrict__ tab, const int qs)
     if (head_block && tid == 0) gst->run_candidates = (int32_t)total;
     if (total > (unsigned)RUN_LANES * RUN_R || total == 0u) ok = false;
     if (!ok) { run_over(); return; }   // (nothing has been written: the classic launches behind this one do the same head again)
-    // as few solvers as give every lane one candidate: 8, 16 or 32 (an exchange among 8 blocks costs half of one among 32 in
-    // isolation, but a second candidate per lane costs a pass more than that saves: profiles/r05_ab.txt 1, 6)
-    const int g = total <= 8u * RUN_BLOCK ? 8 : (total <= 16u * RUN_BLOCK ? 16 : RUN_G);
+    // Solvers: as few as give every lane one candidate up to 32 (an exchange among 8 blocks costs less than among 32 in isolation, but a
+    // second candidate per lane costs a pass more than that saves: profiles/r05_ab.txt 1, 6); above, the exchange grows with the blocks
+    // (2.3 / 2.9 / 3.9 us among 64 / 128 / 256) and a candidate per lane costs ~0.45 us of the two passes: up to three per lane, then the
+    // next size, the whole GPU for the widest records
+    const unsigned per = (unsigned)RUN_BLOCK;
+    const int g = total <= 8u * per ? 8 : (total <= 16u * per ? 16 : (total <= 3u * 32u * per ? 32 :
+                  (total <= 3u * 64u * per ? 64 : (total <= 3u * 128u * per ? 128 : RUN_G))));
     if (srow >= g) return;
+    if (g > RUN_G_SMALL) {
+        // ---- entry handshake of a large run (RunMail::entry_ticket): nothing is written before all of it is known to be resident
+        const unsigned long long nb = gridDim.x, launch = s_ticket / nb, base = launch * nb;
+        if (head_block && tid == 0) {
+            const long long t0 = (long long)wall_clock64();
+            unsigned go = RUN_GO;
+            while (__hip_atomic_load(&ps.run_mail->entry_ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < base + (unsigned long long)g + 1ull) {
+                if ((long long)wall_clock64() - t0 > RUN_ENTRY_TICKS) { go = RUN_ABORT; break; }
+                __builtin_amdgcn_s_sleep(2);
+            }
+            __hip_atomic_store(&ps.run_mail->entry_go, ((launch + 1ull) << 32) | go, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (launch + 1: never the zero the mail starts with)
+            s_verdict = go;
+        } else if (tid == 0) {
+            const long long t0 = (long long)wall_clock64();
+            unsigned long long w;
+            unsigned go = RUN_ABORT;
+            for (;;) {
+                w = __hip_atomic_load(&ps.run_mail->entry_go, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((w >> 32) == ((launch + 1ull) & 0xffffffffull)) { go = (unsigned)w; break; }
+                if ((long long)wall_clock64() - t0 > RUN_TIMEOUT_TICKS) break;   // (the head block started first: cannot happen)
+                __builtin_amdgcn_s_sleep(2);
+            }
+            s_verdict = go;
+        }
+        __syncthreads();
+        if (s_verdict != RUN_GO) { run_over(); return; }
+        __syncthreads();
+    }
     const unsigned lanes = (unsigned)g * RUN_BLOCK;
 
     // ---- the candidates of this lane: c = l + r * lanes
@@ -2971,7 +3040,7 @@ kt_run(const Slot *__restrict__ tab, const int qs)
         }
         RUN_CLK(4);
         ++nexch;
-        if (!run_exchange<NACC_FLOW>(ps.run_mail, srow, g, seq0 + nexch, s_vals, s_all, s_tot, &s_fail, nullptr, &s_verdict)) { comm_ok = false; break; }
+        if (!run_exchange<NACC_FLOW>(ps.run_mail, srow, g, seq0 + nexch, s_vals, s_all, s_part, s_tot, &s_fail, nullptr, &s_verdict)) { comm_ok = false; break; }
         RUN_CLK(5);
         // ---- the tail of compute_flow (ref src/cvo.cpp:201-209): twist, Taylor constants
         if (tid < 64) {
@@ -3017,7 +3086,7 @@ kt_run(const Slot *__restrict__ tab, const int qs)
         RUN_CLK(8);
         ++nexch;
         unsigned verdict = 0u;
-        if (!run_exchange<NACC_STEP>(ps.run_mail, srow, g, seq0 + nexch, s_vals, s_all, s_tot, &s_fail, &verdict, &s_verdict)) { comm_ok = false; break; }
+        if (!run_exchange<NACC_STEP>(ps.run_mail, srow, g, seq0 + nexch, s_vals, s_all, s_part, s_tot, &s_fail, &verdict, &s_verdict)) { comm_ok = false; break; }
         RUN_CLK(9);
         if (verdict & RUN_V_STALL) {
             // no buffer holds every pair for this slot's transform (a jump): what the passes have summed is void.  The head goes

@@ -459,6 +459,11 @@ DevParams loop_params(const cvo_hip_ctx *ctx)
     // (0.7 / 0.85 / 0.9 / 0.95 of the margin gone: 10k x 10k 711 / 728 / 733 / 732 registrations/s, 14k 432 / 444 / 445 /
     // 444, 6k 694 / 694 / 706 / 705, 3k 788 / 794 / 792 / 792; profiles/r03_ab.txt 18)
     if (ctx->use_async && ctx->lone && ctx->allow_head && !multi_rank(ctx)) dp.build_at = 0.9f;
+    // (plans with resident runs, the conditions of enqueue_step: what a run's registers hold -- the plan keeps a list that has become
+    // wide while its record still fits, plan_xy_async)
+    if (ctx->use_async && ctx->lone && ctx->allow_head && ctx->allow_run && !multi_rank(ctx) && ctx->prm.mode == CVO_HIP_MODE_CVO &&
+        !(ctx->prm.color_scale > 0.0f) && !ctx->post_dbg && ctx->allow_merge && ctx->fixed.np <= 65536 && ctx->moving.np <= 65536 && !env_no_cand())
+        dp.run_cand_cap = (float)RUN_LANES * (float)RUN_R;
     return dp;
 }
 
