@@ -44,7 +44,7 @@ BYTES_PER_POINT = 32.0         # xyz 12 B + 5 features 20 B
 PEAK_F32_TFLOPS = 157.3        # MI355X_MICROARCH.md: FP32 vector = FP32 MFMA peak
 PEAK_HBM_GBS = 8000.0
 FETCH_CALIBRATION = "profiles/r05_fetch_calibration.txt"   # what TCC FETCH_SIZE counts on a 16-byte gather of known footprint
-PROFILE_TAG = "r04"            # committed rocprofv3 summaries under profiles/ (tools/gpu_profile.sh)
+PROFILE_TAG = "r05"            # committed rocprofv3 summaries under profiles/ (tools/gpu_profile.sh)
 
 
 def parse():
@@ -742,8 +742,8 @@ def roofline_engine_leg(args, pkg, torch, mode, acvo, n, m):
         if heavy:
             heavy["bound"] = "dependent-latency"
             heavy["what"] = ("iterations 0-20 (ell >= 0.06): the streaming flow pass waits for one gather round trip per round of 64 "
-                             "candidates and wave -- vector instructions issue 44-52 % of the time, 3.8-4.4 of 6 waves per SIMD are "
-                             "resident and each waits 73-79 % of its cycles, L2 hit rate 0.66, texture addresser 4-6 % busy "
+                             "candidates and wave -- vector instructions issue 44-52 %% of the time, 3.8-4.4 of 6 waves per SIMD are "
+                             "resident and each waits 73-79 %% of its cycles, L2 hit rate 0.66, texture addresser 4-6 %% busy "
                              "(profiles/r04_ab.txt 8, 14).  counter_GBs = FETCH_SIZE x 2 + WRITE_SIZE of the same launches (committed %s) "
                              "over the live duration: FETCH_SIZE counts Infinity-Cache hits too and one engine's working set fits that "
                              "cache, so this is a traffic figure at the L2's far side, not an HBM roof (calibration: %s)"
