@@ -537,6 +537,7 @@ int cvo_hip_align_many(cvo_hip_ctx **ctxs, cvo_hip_state **states, int *n_iters,
         if (taken[i] || jobs[i].phase == 2) continue;
         jobs[i].ctx->crowded = false;
         jobs[i].ctx->lone = true;
+        jobs[i].paced_nb = true;   // (job_pump's paced steps, one look per call: resident runs for registrations on their own here too)
         const int rc = job_begin(jobs[i]);
         if (rc) { jobs[i].rc = rc; jobs[i].phase = 2; if (!first_err) first_err = rc; }
     }
@@ -546,7 +547,7 @@ int cvo_hip_align_many(cvo_hip_ctx **ctxs, cvo_hip_state **states, int *n_iters,
         int live = 0, moved = 0, first_live = -1;
         for (int i = 0; i < count; ++i) {
             if (jobs[i].phase == 2) continue;
-            const int before_phase = jobs[i].phase, before_checked = jobs[i].checked;
+            const int before_phase = jobs[i].phase, before_checked = jobs[i].checked + jobs[i].batches;
             if (job_pump(jobs[i], false)) {
                 if (jobs[i].rc && !first_err) first_err = jobs[i].rc;
                 ++moved;
@@ -554,7 +555,7 @@ int cvo_hip_align_many(cvo_hip_ctx **ctxs, cvo_hip_state **states, int *n_iters,
             }
             ++live;
             if (first_live < 0) first_live = i;
-            if (jobs[i].phase != before_phase || jobs[i].checked != before_checked) ++moved;
+            if (jobs[i].phase != before_phase || jobs[i].checked + jobs[i].batches != before_checked) ++moved;
         }
         if (live == 0) break;
         if (!moved) {

@@ -338,6 +338,8 @@ struct AlignJob {
     bool in_group = false;  // runs in a fused group (on the group's stream and table)
     int runs_enq = 0;       // resident runs enqueued in this round
     bool run_waiting = false;   // the last batch began with a resident run that has not reported its end yet
+    bool paced_nb = false;  // a registration on its own inside cvo_hip_align_many: the paced steps of job_pump, one look per call
+    int idle_seen = 0;      // ... and how often in a row its stream was found idle with the mirrors where they were
     bool paced = false;     // cvo_hip_align only: the calling thread has nothing else to pump and may sit in the
                             // paced loop of job_pump (align_many's blocking fall-back must keep its round-robin going:
                             // the other jobs -- the peer ranks of a mailbox world among them -- run dry otherwise)
@@ -393,6 +395,7 @@ int zero_counters(cvo_hip_ctx *ctx);
 int push_state_fields(cvo_hip_ctx *ctx, size_t off, size_t bytes);
 int fetch_red(cvo_hip_ctx *ctx, int off, int count, double *out);
 // ---- cvo_job.cpp
+void decide_scheme(cvo_hip_ctx *ctx);
 int job_begin(AlignJob &j);
 int job_finish(AlignJob &j);
 int job_pump(AlignJob &j, bool block);

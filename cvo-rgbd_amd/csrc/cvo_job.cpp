@@ -7,50 +7,10 @@ using namespace cvo_impl;
 
 namespace cvo_impl {
 
-int job_begin(AlignJob &j)
+// How this context's align() runs (decided per align() from the clouds' sizes and from who shares the launches): blocks of the
+// list kernels, asynchronous list builds.
+void decide_scheme(cvo_hip_ctx *ctx)
 {
-    cvo_hip_ctx *ctx = j.ctx;
-    cvo_hip_state *s = j.s;
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
-    {
-        const int rcm = mailboxes_usable(ctx);
-        if (rcm) return rcm;
-    }
-    const cvo_hip_params &p = ctx->prm;
-    if (p.mode == CVO_HIP_MODE_ACVO) {   // tail of acvo::set_pcd (ref src/adaptive_cvo.cpp:476-478)
-        s->ell = p.ell_init;
-        s->ell_max = p.ell_max_init;
-    }
-    *ctx->done_mirror = 0;
-    *ctx->progress_mirror = 0;
-    *ctx->run_mirror = 0;
-    *ctx->hint_mirror = -1;
-    if (!j.trace) j.trace_cap = 0;
-    if (j.trace_cap > p.max_iter) j.trace_cap = p.max_iter;
-    if (j.trace_cap > ctx->trace_dev_cap) {
-        if (ctx->trace_dev) HIP_TRY(ctx, hipFree(ctx->trace_dev));
-        ctx->trace_dev = nullptr; ctx->trace_dev_cap = 0;
-        HIP_TRY(ctx, hipMalloc((void **)&ctx->trace_dev, (size_t)j.trace_cap * sizeof(cvo_hip_trace)));
-        ctx->trace_dev_cap = j.trace_cap;
-    }
-    if (j.trace_cap > 0)
-        HIP_TRY(ctx, hipMemsetAsync(ctx->trace_dev, 0, (size_t)j.trace_cap * sizeof(cvo_hip_trace),
-                                    loop_stream(ctx)));
-    // initial device state
-    DevState *h = &ctx->st_host[kPollSlots];
-    std::memset(h, 0, sizeof(*h));
-    std::memcpy(h->R, s->R, sizeof(h->R));
-    std::memcpy(h->T, s->T, sizeof(h->T));
-    h->ell = s->ell;
-    h->ell_max = s->ell_max;
-    h->iter = s->iter;
-    {
-        const int rcg = fill_filter_geometry(ctx, h);
-        if (rcg) return rcg;
-    }
-    if (p.max_iter <= 0) h->done = DONE_MAX_ITER;
-    // (everything but the mailbox sequence number, which lives as long as the context)
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->st, h, DEVSTATE_INIT_BYTES, hipMemcpyHostToDevice, loop_stream(ctx)));
     // small clouds (the ~3k-point clouds of the reference's front end): 2048 waves do
     // (measured 3k x 3k: 2.11 ms with 512 blocks, 2.19 with 1024; 10k x 10k the other way round)
     const bool small_pair = (double)ctx->fixed.n * (double)ctx->moving.n <= 2.5e7;
@@ -83,6 +43,54 @@ int job_begin(AlignJob &j)
         ctx->proc_blocks = ctx->proc_blocks_default =
             npairs <= 2.5e7 ? PROC_BLOCKS / 4 : (npairs <= (runs ? 6.0e7 : 1.5e8) ? PROC_BLOCKS / 2 : PROC_BLOCKS);
     }
+}
+
+int job_begin(AlignJob &j)
+{
+    cvo_hip_ctx *ctx = j.ctx;
+    cvo_hip_state *s = j.s;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    {
+        const int rcm = mailboxes_usable(ctx);
+        if (rcm) return rcm;
+    }
+    const cvo_hip_params &p = ctx->prm;
+    if (p.mode == CVO_HIP_MODE_ACVO) {   // tail of acvo::set_pcd (ref src/adaptive_cvo.cpp:476-478)
+        s->ell = p.ell_init;
+        s->ell_max = p.ell_max_init;
+    }
+    *ctx->done_mirror = 0;
+    *ctx->progress_mirror = 0;
+    *ctx->run_mirror = 0;
+    *ctx->hint_mirror = -1;
+    if (ctx->final_mirror) ctx->final_mirror->done = RUNNING;   // (an old verdict must not pass for this registration's)
+    if (!j.trace) j.trace_cap = 0;
+    if (j.trace_cap > p.max_iter) j.trace_cap = p.max_iter;
+    if (j.trace_cap > ctx->trace_dev_cap) {
+        if (ctx->trace_dev) HIP_TRY(ctx, hipFree(ctx->trace_dev));
+        ctx->trace_dev = nullptr; ctx->trace_dev_cap = 0;
+        HIP_TRY(ctx, hipMalloc((void **)&ctx->trace_dev, (size_t)j.trace_cap * sizeof(cvo_hip_trace)));
+        ctx->trace_dev_cap = j.trace_cap;
+    }
+    if (j.trace_cap > 0)
+        HIP_TRY(ctx, hipMemsetAsync(ctx->trace_dev, 0, (size_t)j.trace_cap * sizeof(cvo_hip_trace),
+                                    loop_stream(ctx)));
+    // initial device state
+    DevState *h = &ctx->st_host[kPollSlots];
+    std::memset(h, 0, sizeof(*h));
+    std::memcpy(h->R, s->R, sizeof(h->R));
+    std::memcpy(h->T, s->T, sizeof(h->T));
+    h->ell = s->ell;
+    h->ell_max = s->ell_max;
+    h->iter = s->iter;
+    {
+        const int rcg = fill_filter_geometry(ctx, h);
+        if (rcg) return rcg;
+    }
+    if (p.max_iter <= 0) h->done = DONE_MAX_ITER;
+    // (everything but the mailbox sequence number, which lives as long as the context)
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->st, h, DEVSTATE_INIT_BYTES, hipMemcpyHostToDevice, loop_stream(ctx)));
+    decide_scheme(ctx);
     // (a member of a fused group: the group's table, armed by its insert; on its own: this context's table, whose build masks the
     // prepare kernel sets -- it exists from the first align() on, and its first use arms it anyway)
     launch_prepare(ctx->st, loop_params(ctx), loop_stream(ctx), (!j.in_group && ctx->table.raw) ? ctx->table.masks() : nullptr);
@@ -177,10 +185,14 @@ int job_pump(AlignJob &j, bool block)
     // queues behind them).  The ~10 us the stream idles between two batches cost less than that
     // (CVO_HIP_PACE_LEAD = slots of overlap, 0 / 1 / 2 / 3: 644 / 619 / 627 / 620 registrations/s at
     // 10k x 10k, event-paced two batches ahead: 604).
-    if (j.phase == 0 && block && j.paced && !host_reduce(ctx) && !ctx->profiling) {
+    if (j.phase == 0 && (block || j.paced_nb) && (j.paced || j.paced_nb) && !host_reduce(ctx) && !ctx->profiling) {
+        // (j.paced: cvo_hip_align, the calling thread sits here until the loop stops.  j.paced_nb: a registration on its own inside
+        // cvo_hip_align_many -- the same steps, one look per call without blocking, a short bounded wait with it: the caller has
+        // other registrations to pump)
         const int limit = (ctx->use_async ? 3 : 1) * ctx->prm.max_iter + 4 * kBatch;
         unsigned spins = 0;
         int idle_seen = 0;
+        const auto t_enter = std::chrono::steady_clock::now();
         for (;;) {
             if (*(volatile int32_t *)ctx->done_mirror != RUNNING) break;
             // (the run counter first: a run publishes its slots before it reports its end)
@@ -214,7 +226,29 @@ int job_pump(AlignJob &j, bool block)
                 ++j.batches;
                 spins = 0;
                 idle_seen = 0;
+                j.idle_seen = 0;
+                if (!j.paced) return 0;   // (one step per call: the caller's other registrations want their turn)
             } else {
+                if (!j.paced) {
+                    if (!block) return 0;
+                    if (std::chrono::steady_clock::now() - t_enter > std::chrono::microseconds(30)) {
+                        // (the caller found nobody moving and asked this job to wait: the same look at the stream as below --
+                        // an error, or idle twice in a row with the mirrors where they were, ends the job)
+                        const hipError_t q = hipStreamQuery(loop_stream(ctx));
+                        if (q != hipSuccess && q != hipErrorNotReady)
+                            return finish_with(fail(ctx, CVO_HIP_ERR_HIP, "the stream of the align loop reports an error"));
+                        if (q == hipSuccess && *(volatile int32_t *)ctx->done_mirror == RUNNING &&
+                            *(volatile int32_t *)ctx->progress_mirror == slots && *(volatile int32_t *)ctx->run_mirror == runs) {
+                            if (++j.idle_seen >= 2)
+                                return finish_with(fail(ctx, CVO_HIP_ERR_HIP, "the align loop's stream went idle without progress"));
+                        } else {
+                            j.idle_seen = 0;
+                        }
+                        return 0;
+                    }
+                    __builtin_ia32_pause();
+                    continue;
+                }
                 __builtin_ia32_pause();
                 // The mirrors only move while the queued kernels run.  A fault, a stream in an error state or a
                 // post kernel that never ran would leave this thread spinning for ever: now and then ask the

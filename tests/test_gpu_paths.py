@@ -1095,3 +1095,39 @@ def test_resident_runs_change_nothing(pkg, po, monkeypatch, n, m):
         assert np.array_equal(np.frombuffer(ref[1], np.float32, 12)[9:], np.array(so.T, np.float32))
     for k in ("CVO_HIP_NO_RUN", "CVO_HIP_LIST_INIT", "CVO_HIP_LIST_MARGIN"):
         monkeypatch.delenv(k, raising=False)
+
+
+def test_align_many_on_its_own_takes_resident_runs(pkg):
+    """A registration that cvo_hip_align_many runs on its own (a call of one; a cvo registration beside acvo ones, which do not
+    fuse with it) takes job_pump's paced steps -- resident runs included -- and ends in the state cvo_hip_align gives."""
+    capi = pkg.capi
+    n = 3000
+    pairs = [pkg.data.synthetic_pair(n, n, seed=7100 + b) for b in range(3)]
+    ref = []
+    for xf, ff, xm, fm in pairs:
+        c = capi.Context(mode=capi.MODE_CVO, device=0)
+        c.set_fixed(xf, ff); c.set_moving(xm, fm)
+        st = capi.init_state(c.params)
+        it, _ = c.align(st)
+        ref.append((it, bytes(st)))
+        c.close()
+    # a call of one
+    c = capi.Context(mode=capi.MODE_CVO, device=0)
+    c.set_fixed(pairs[0][0], pairs[0][1]); c.set_moving(pairs[0][2], pairs[0][3])
+    for _ in range(2):
+        st = capi.init_state(c.params)
+        its = capi.align_many([c], [st])
+        assert (its[0], bytes(st)) == ref[0]
+    runs, declined, iters, _ = c.run_stats()
+    assert runs >= 2 and iters >= 20, (runs, declined, iters)
+    c.close()
+    # one cvo registration beside two acvo ones (which fuse with each other, not with it)
+    cs = [capi.Context(mode=capi.MODE_CVO, device=0)] + [capi.Context(mode=capi.MODE_ACVO, device=0) for _ in range(2)]
+    for c, (xf, ff, xm, fm) in zip(cs, pairs):
+        c.set_fixed(xf, ff); c.set_moving(xm, fm)
+    sts = [capi.init_state(c.params) for c in cs]
+    its = capi.align_many(cs, sts)
+    assert (its[0], bytes(sts[0])) == ref[0]
+    assert cs[0].run_stats()[0] >= 1
+    for c in cs:
+        c.close()
