@@ -737,7 +737,9 @@ CVO_HD void prepare_iteration(DevHead *s, DevHead *bulk, const bool store, const
         const float q = s->r_last > 0.0f ? r_now / s->r_last : 1.0f;
         const float rr = p.async_xy ? (s->xy_active ? s->xy_r[1] : s->xy_r[0]) : s->list_r[LIST_XY];
         const float w = rr / r_now;
-        s->run_hint = (nnz > 0.0f && nnz < 1.0e9f) ? (int32_t)fminf(1.05f * nnz * (q * q) * (w * w), 2.0e9f) : 0;   // (NaN: an overflowed iteration)
+        // (x 1 / 0.95: the host compares with what a run holds, and an estimate wants room -- the publishing block of a head-mode
+        // flow launch replaces it by the record's count where that is known, head_body)
+        s->run_hint = (nnz > 0.0f && nnz < 1.0e9f) ? (int32_t)fminf(1.105f * nnz * (q * q) * (w * w), 2.0e9f) : 0;   // (NaN: an overflowed iteration)
         s->r_last = r_now;
     }
     if (p.async_self) {   // (after the xy plan: it may add a stall)

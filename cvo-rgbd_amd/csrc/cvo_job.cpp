@@ -109,8 +109,9 @@ int job_begin(AlignJob &j)
     j.run_waiting = false;
     j.executed_base = 0;
     // (a batch begins with a resident run when the record in use is expected to hold at most this many candidates -- DevHead::
-    // run_hint, an estimate; a run that finds more than it can hold declines, which costs its launch and one head)
-    ctx->run_nnz_max = (int)(0.95 * RUN_LANES * RUN_R);
+    // run_hint: the record's count where the last head knew it, else an estimate with 5 % of room; a run that finds more than it can
+    // hold declines, which costs its launch and one head)
+    ctx->run_nnz_max = RUN_LANES * RUN_R;
     if (const char *e = getenv("CVO_HIP_RUN_CAND")) ctx->run_nnz_max = atoi(e);   // (tuning switch)
     j.phase = p.max_iter <= 0 ? 1 : 0;
     if (j.phase == 1) {

@@ -2153,11 +2153,18 @@ __device__ __forceinline__ void head_publish(const PostStepArgs &a, const DevHea
 // The whole head of one block.  in / out: the copies of the state's head the launch reads / writes (the
 // same in the classic and flush forms); st: the state itself (the tail: sub-list counters, overflow
 // flags).  Returns true if the slot that begins may run (head mode: the loop is running, no stall).
+// `count_pa`: the flow pass of a plan with resident runs -- the publishing block counts the candidates of the record in use
+// (DevHead::run_hint, exact where the record is complete: what the host picks a RUN batch by).
 template <int HM>
 __device__ __forceinline__ bool head_body(const PostStepArgs &a, const DevHead *in, DevHead *out, DevHead *s_st,
-                                          double *sh /*[4 * NACC_MAX]*/, const int par, const bool publisher)
+                                          double *sh /*[4 * NACC_MAX]*/, const int par, const bool publisher,
+                                          const ProcessArgs *count_pa = nullptr)
 {
     const int tid = threadIdx.x;
+    __shared__ unsigned s_cand_total;
+    const bool count = HM == HM_HEAD && publisher && count_pa != nullptr && a.run_mail != nullptr && count_pa->cand_cnt != nullptr &&
+                       count_pa->cand_cnt_b != nullptr;
+    if (count && tid == 0) s_cand_total = 0u;
     const bool reduce = HM != HM_CLASSIC || (a.flags & POST_REDUCE) != 0;
     const bool math = HM != HM_CLASSIC || (a.flags & POST_MATH) != 0;
     const bool timed = a.dbg != nullptr && publisher;   // (CVO_HIP_POST_DEBUG: phase clocks of the publishing block)
@@ -2190,6 +2197,7 @@ __device__ __forceinline__ bool head_body(const PostStepArgs &a, const DevHead *
         if (!comm_ok && tid == 0) s_st->done = DONE_COMM_ERROR;
     }
     if (math && comm_ok) {
+        const int act0 = s_st->xy_active ? 1 : 0;   // (the buffer in use when the slot that ended began)
         if (tid < 64) {   // wave 0
             unsigned flag[LIST_N];
 #pragma unroll
@@ -2201,8 +2209,29 @@ __device__ __forceinline__ bool head_body(const PostStepArgs &a, const DevHead *
                 a.dbg[3] += clk[1] - clk[0]; a.dbg[4] += clk[2] - clk[1]; a.dbg[5] += clk[3] - clk[2];
                 a.dbg[6] = c0;   // (head mode: the flow pass that follows adds its own time, kt_hflow_build)
             }
+        } else if (count) {
+            // the other waves, beside the head's maths: the slices of that buffer's record (as kt_run numbers them)
+            const uint32_t *c = act0 ? count_pa->cand_cnt_b : count_pa->cand_cnt;
+            const unsigned wcap = count_pa->kept_wcap;
+            const int nsl = 4 * count_pa->nblk;
+            unsigned sum = 0u;
+            for (int sl = tid - 64; sl < nsl; sl += BLOCK - 64) {
+                const unsigned v = c[sl];
+                sum += v < wcap ? v : wcap;
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) sum += (unsigned)__shfl_xor((int)sum, off, 64);
+            if ((tid & 63) == 0) atomicAdd(&s_cand_total, sum);
         }
         __syncthreads();
+        if (count) {
+            // exact where it can be: the loop runs on that buffer still, its record is complete (a flow pass has written it) and
+            // no build is named or in flight (a run would decline: the estimate of prepare_iteration stands)
+            if (tid == 0 && s_st->done == RUNNING && s_st->stall == 0 && s_st->xy_target < 0 && s_st->xy_fresh < 0 &&
+                (s_st->xy_active ? 1 : 0) == act0 && (act0 ? s_st->xy_ck[1] : s_st->xy_ck[0]) == count_pa->nblk)
+                s_st->run_hint = (int32_t)s_cand_total;
+            __syncthreads();
+        }
         if (publisher) head_prepare_lists<HM>(a, s_st);
     }
     if (publisher) head_publish(a, s_st, out, math);
@@ -2553,7 +2582,7 @@ __device__ __forceinline__ ProcHead proc_head_lds(const ProcessArgs &a, const De
         const PostStepArgs ps = CVO_ARG(PostStepArgs, op[q].ps);                                           \
         const ProcessArgs &pa = CVO_ARG(ProcessArgs, op[q].p);                                             \
         if (!head_body<HM_HEAD>(ps, par ? ps.st2 : ps.st, par ? ps.st : ps.st2, &s_st, sh, par,            \
-                                blockIdx.x == 0)) return;                                                  \
+                                blockIdx.x == 0, &pa)) return;                                             \
         float rt[12];                                                                                      \
         process_body<PROC_FLOW, 0, true, false>(pa, blockIdx.x, smem, proc_head_lds<PROC_FLOW>(pa, &s_st, par, rt)); \
         if (ps.dbg && blockIdx.x == 0 && threadIdx.x == 0 && ps.dbg[6] != 0) {   /* block 0: head + flow pass */ \
