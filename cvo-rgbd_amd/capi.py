@@ -23,7 +23,7 @@ SYMBOLS = [
     "cvo_hip_transform_pcd", "cvo_hip_flow", "cvo_hip_step_coeffs", "cvo_hip_pick_step",
     "cvo_hip_exp_se3", "cvo_hip_dist_se3", "cvo_hip_align", "cvo_hip_align_many",
     "cvo_hip_function_inner_product", "cvo_hip_function_inner_product_clouds",
-    "cvo_hip_engine_profiling", "cvo_hip_get_engine_profile", "cvo_hip_get_engine_flow_trace", "cvo_hip_get_wave_load", "cvo_hip_set_graph_capture", "cvo_hip_set_profiling", "cvo_hip_get_profile", "cvo_hip_get_graph_stats", "cvo_hip_get_run_stats", "cvo_hip_get_run_clocks", "cvo_hip_synchronize",
+    "cvo_hip_engine_profiling", "cvo_hip_get_engine_profile", "cvo_hip_get_engine_flow_trace", "cvo_hip_get_wave_load", "cvo_hip_set_graph_capture", "cvo_hip_set_profiling", "cvo_hip_get_profile", "cvo_hip_get_graph_stats", "cvo_hip_get_run_stats", "cvo_hip_get_run_clocks", "cvo_hip_get_mirror_retries", "cvo_hip_synchronize",
 ]
 
 
@@ -140,6 +140,8 @@ def lib():
     L.cvo_hip_get_profile.argtypes = [vp, C.POINTER(Profile), C.c_int]
     L.cvo_hip_get_graph_stats.argtypes = [vp, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]
     L.cvo_hip_get_run_clocks.argtypes = [vp, C.POINTER(C.c_longlong)]
+    L.cvo_hip_get_mirror_retries.argtypes = []
+    L.cvo_hip_get_mirror_retries.restype = C.c_longlong
     L.cvo_hip_get_run_stats.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.cvo_hip_synchronize.argtypes = [vp]
     for name in SYMBOLS:   # raises AttributeError if the library lacks a declared symbol
@@ -486,6 +488,11 @@ def align_many(contexts, states):
     its = (C.c_int * n)()
     check(lib().cvo_hip_align_many(arr_c, arr_s, its, n), what="align_many")
     return list(its)
+
+
+def mirror_retries():
+    """Times (in this process) a finished registration's pinned state copy had to be read again (incomplete when `done` was seen)."""
+    return int(lib().cvo_hip_get_mirror_retries())
 
 
 def engine_profiling(enable=True):

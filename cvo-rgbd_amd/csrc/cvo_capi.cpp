@@ -748,6 +748,8 @@ int cvo_hip_get_run_clocks(cvo_hip_ctx *ctx, long long clocks16[16])
     return CVO_HIP_OK;
 }
 
+long long cvo_hip_get_mirror_retries(void) { return mirror_retries().load(std::memory_order_relaxed); }
+
 int cvo_hip_synchronize(cvo_hip_ctx *ctx)
 {
     cvo_lock::Api api_guard;

@@ -230,6 +230,12 @@ struct alignas(16) DevHead {
                                 // the next batch's plan by (PostStepArgs::hint_mirror)
     int32_t head_pad_[3];
 };
+// Check word of a head that went to the host's pinned copy (head_publish -> job_pump): every 16-byte piece mixed with its index,
+// summed; DevHead::head_pad_[0] counts as zero and then holds the sum.
+CVO_HD inline unsigned head_check_mix(unsigned x, unsigned y, unsigned z, unsigned w, unsigned piece)
+{
+    return (x * 0x9E3779B1u + y * 0x85EBCA77u + z * 0xC2B2AE3Du + w * 0x27D4EB2Fu) ^ (piece * 0x165667B1u + 0x9E3779B9u);
+}
 struct DevState : DevHead {
     // ---- the TAIL: one copy per registration, at a fixed address (the head exists twice in
     // ---- head mode, see cvo_kernels.hip "Head mode"); everything below is only ever touched with
@@ -735,7 +741,9 @@ CVO_HD void prepare_iteration(DevHead *s, DevHead *bulk, const bool store, const
         // ~1.05 (R / r)^2 candidates per member at radius r (1.64 at R = 1.25 r; profiles/r05_ab.txt 0, 4).
         const float nnz = (float)s->red[RED_FLOW + 8];
         const float q = s->r_last > 0.0f ? r_now / s->r_last : 1.0f;
-        const float rr = p.async_xy ? (s->xy_active ? s->xy_r[1] : s->xy_r[0]) : s->list_r[LIST_XY];
+        // (a build named or in flight: the record that list will give -- the host queues a RUN batch two slots ahead)
+        const int coming = p.async_xy ? (s->xy_target >= 0 ? s->xy_target : s->xy_fresh) : -1;
+        const float rr = p.async_xy ? ((coming >= 0 ? coming : s->xy_active) ? s->xy_r[1] : s->xy_r[0]) : s->list_r[LIST_XY];
         const float w = rr / r_now;
         // (x 1 / 0.95: the host compares with what a run holds, and an estimate wants room -- the publishing block of a head-mode
         // flow launch replaces it by the record's count where that is known, head_body)

@@ -389,13 +389,14 @@ int run_plan(const Slot *tab, PlanCache &cache, const std::vector<TLaunch> &plan
 int record_iteration(cvo_hip_ctx *ctx, std::vector<RecOp> &ops, int trace_cap);
 int prepare_lone_plan(cvo_hip_ctx *ctx, int trace_cap);
 int launch_batch(cvo_hip_ctx *ctx, int tag0, int trace_cap, bool with_run = false, int slots = kBatch);
-constexpr int kShortBatch = 4;      // classic slots of a batch while a resident run is within reach (job_pump)
+constexpr int kShortBatch = 2;      // classic slots of a batch of a plan that has a resident run (job_pump; an even number, see kBatch)
 constexpr int kRunBatchSlots = 2;   // classic slots behind the resident run of a RUN batch (an even number, see kBatch)
 int zero_counters(cvo_hip_ctx *ctx);
 int push_state_fields(cvo_hip_ctx *ctx, size_t off, size_t bytes);
 int fetch_red(cvo_hip_ctx *ctx, int off, int count, double *out);
 // ---- cvo_job.cpp
 void decide_scheme(cvo_hip_ctx *ctx);
+std::atomic<long long> &mirror_retries();
 int job_begin(AlignJob &j);
 int job_finish(AlignJob &j);
 int job_pump(AlignJob &j, bool block);

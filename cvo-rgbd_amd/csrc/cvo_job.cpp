@@ -45,6 +45,13 @@ void decide_scheme(cvo_hip_ctx *ctx)
     }
 }
 
+// (how often the host found the final head's pinned copy incomplete when the `done` word was there: cvo_hip_get_mirror_retries)
+std::atomic<long long> &mirror_retries()
+{
+    static std::atomic<long long> n{0};
+    return n;
+}
+
 int job_begin(AlignJob &j)
 {
     cvo_hip_ctx *ctx = j.ctx;
@@ -217,9 +224,9 @@ int job_pump(AlignJob &j, bool block)
                 if (j.enq >= limit) break;   // cannot happen
                 const int hint = *(volatile int32_t *)ctx->hint_mirror;
                 const bool with_run = ctx->head_mode && !ctx->plan_pre.empty() && hint > 0 && hint <= ctx->run_nnz_max;
-                // (a plan with runs whose record is within reach of one -- the length scale has dropped, the list is still the
-                // wide one -- goes out in short classic batches: a run can only start at a batch's head)
-                const bool near_run = ctx->head_mode && !ctx->plan_pre.empty() && !with_run && hint > 0 && hint <= 6 * ctx->run_nnz_max;
+                // (a plan with runs is launched eagerly and in the shortest batches: a run can only start at a batch's head, and the
+                // slot it may start at is two or three slots after the head that first says so)
+                const bool near_run = ctx->head_mode && !ctx->plan_pre.empty() && !with_run;
                 const int rc = launch_batch(ctx, j.executed_base + j.enq, j.trace_cap, with_run, near_run ? kShortBatch : kBatch);
                 if (rc) return finish_with(rc);
                 if (with_run) { ++j.runs_enq; j.run_waiting = true; }
@@ -279,9 +286,22 @@ int job_pump(AlignJob &j, bool block)
             const bool mirrored = (verdict == DONE_BREAK_A || verdict == DONE_BREAK_B || verdict == DONE_MAX_ITER) && ctx->final_mirror &&
                                   ctx->table.image.size() == 1 && ctx->plan_has_final_mirror;
             if (mirrored) {
-                std::atomic_thread_fence(std::memory_order_acquire);
-                std::memcpy(&ctx->st_host[0], ctx->final_mirror, sizeof(DevHead));
-                if (ctx->st_host[0].done == verdict) return finish_with(job_finish(j));
+                // (the check word: a piece of the copy that has not landed yet -- seen on this platform although the device fences
+                // at system scope between the copy and the `done` word -- is a retry; after ~50 us the copy in stream order below)
+                const auto t0 = std::chrono::steady_clock::now();
+                for (;;) {
+                    std::atomic_thread_fence(std::memory_order_acquire);
+                    std::memcpy(&ctx->st_host[0], ctx->final_mirror, sizeof(DevHead));
+                    const uint32_t *w = reinterpret_cast<const uint32_t *>(&ctx->st_host[0]);
+                    constexpr int pieces = (int)(sizeof(DevHead) / 16);
+                    uint32_t sum = 0;
+                    for (int q = 0; q < pieces; ++q)
+                        sum += head_check_mix(w[4 * q], q == pieces - 1 ? 0u : w[4 * q + 1], w[4 * q + 2], w[4 * q + 3], (unsigned)q);
+                    if (ctx->st_host[0].done == verdict && sum == (uint32_t)ctx->st_host[0].head_pad_[0]) return finish_with(job_finish(j));
+                    mirror_retries().fetch_add(1, std::memory_order_relaxed);
+                    if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(50)) break;
+                    __builtin_ia32_pause();
+                }
             }
         }
         if (hipMemcpyAsync(&ctx->st_host[0], ctx->st, sizeof(DevState), hipMemcpyDeviceToHost,

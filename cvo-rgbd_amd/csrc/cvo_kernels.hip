@@ -2136,15 +2136,32 @@ __device__ __forceinline__ void head_publish(const PostStepArgs &a, const DevHea
     // a loop that has stopped with a verdict: the final head into the host's pinned copy, all of it there before the `done` word
     const bool final_out = a.final_mirror != nullptr && (s_st->done == DONE_BREAK_A || s_st->done == DONE_BREAK_B || s_st->done == DONE_MAX_ITER);
     if (final_out) {
-        state_head_from_lds(s_st, a.final_mirror);
+        // (with a check word over the copy: the host takes the mirror only when the word matches what it has read -- a piece that
+        // lands after the `done` word is then a retry, not a wrong state; head_check_word)
+        const uint4 *src = reinterpret_cast<const uint4 *>(s_st);
+        uint4 *dst = reinterpret_cast<uint4 *>(a.final_mirror);
+        constexpr int pieces = (int)(DEVSTATE_HEAD_BYTES / 16);
+        static_assert(pieces <= 64 && offsetof(DevHead, head_pad_) == DEVSTATE_HEAD_BYTES - 12, "one wave copies the head; the check word is the last piece's second word");
+        if (threadIdx.x < 64) {
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            if ((int)threadIdx.x < pieces) v = src[threadIdx.x];
+            if ((int)threadIdx.x == pieces - 1) v.y = 0u;   // (the word itself counts as zero)
+            unsigned sum = (int)threadIdx.x < pieces ? head_check_mix(v.x, v.y, v.z, v.w, threadIdx.x) : 0u;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) sum += (unsigned)__shfl_xor((int)sum, off, 64);
+            if ((int)threadIdx.x == pieces - 1) v.y = sum;
+            if ((int)threadIdx.x < pieces) dst[threadIdx.x] = v;
+        }
         __threadfence_system();
         __syncthreads();
     }
     if (threadIdx.x == 0) {
         // (members of A expected in the slot that begins: what the host picks the next batch's plan by, kt_run -- in front
         // of the slot count the host paces its batches on)
-        if (math && a.hint_mirror) *a.hint_mirror = s_st->run_hint;
-        if (math && a.progress_mirror) *a.progress_mirror = s_st->n_slots;
+        // (not with a verdict: the host leaves on the `done` word and may have reset the other two for its next registration
+        // before a write that was issued in front of that word has landed -- writes to host memory are seen to pass each other)
+        if (math && a.hint_mirror && s_st->done == RUNNING) *a.hint_mirror = s_st->run_hint;
+        if (math && a.progress_mirror && s_st->done == RUNNING) *a.progress_mirror = s_st->n_slots;
         if (a.done_mirror && s_st->done != RUNNING) *a.done_mirror = s_st->done;
     }
     state_head_from_lds(s_st, out);
@@ -2852,18 +2869,24 @@ kt_run(const Slot *__restrict__ tab, const int qs)
     if (tid < 64) s_etab[tid] = c_exp2_64[tid];
     state_head_to_lds(gst, &s_st);   // (with its barrier)
     // the head block alone tells the host that this run is over (whatever way it ends)
+    // (not once the loop has stopped: the host leaves on the `done` word, which went out before, and may have begun the next
+    // registration -- and reset this mirror -- by now)
     auto run_over = [&]() {
         if (head_block && tid == 0) {
             const int c = gst->run_count + 1;
             gst->run_count = c;
-            if (ps.run_mirror) *ps.run_mirror = c;
+            if (ps.run_mirror && s_st.done == RUNNING) *ps.run_mirror = c;
         }
     };
     // what would make this launch a plain head-mode flow launch's business: a loop that has stopped, a stall slot,
     // a build this launch's filter blocks would have to make
     // (... or a record that is expected to hold far more than a run's registers: decided before the head's maths, cheaply)
     if (s_st.done != RUNNING || s_st.stall != 0 || s_st.xy_target >= 0 || pa.cand == nullptr || pa.cand_b == nullptr ||
-        ps.run_mail == nullptr || s_st.run_hint > 2 * RUN_LANES * RUN_R) { run_over(); return; }
+        ps.run_mail == nullptr || s_st.run_hint > 2 * RUN_LANES * RUN_R) {
+#ifdef CVO_RUN_WHY
+        if (head_block && tid == 0) gst->run_clk[s_st.done != RUNNING ? 0 : (s_st.stall != 0 ? 1 : (s_st.xy_target >= 0 ? 2 : 3))] += 1;
+#endif
+        run_over(); return; }
     const unsigned long long seq0 = s_seq;
     unsigned nexch = 0;
 
@@ -2929,6 +2952,10 @@ kt_run(const Slot *__restrict__ tab, const int qs)
     }
     if (head_block && tid == 0) gst->run_candidates = (int32_t)total;
     if (total > (unsigned)RUN_LANES * RUN_R || total == 0u) ok = false;
+#ifdef CVO_RUN_WHY
+    if (!ok && head_block && tid == 0)
+        gst->run_clk[s_st.done != RUNNING ? 4 : (s_st.stall != 0 ? 5 : ((act ? s_st.xy_ck[1] : s_st.xy_ck[0]) != pa.nblk ? 6 : (total == 0u ? 8 : 7)))] += 1;
+#endif
     if (!ok) { run_over(); return; }   // (nothing has been written: the classic launches behind this one do the same head again)
     // Solvers: as few as give every lane one candidate up to 32 (an exchange among 8 blocks costs less than among 32 in isolation, but a
     // second candidate per lane costs a pass more than that saves: profiles/r05_ab.txt 1, 6); above, the exchange grows with the blocks

@@ -302,7 +302,9 @@ int cvo_hip_function_inner_product_clouds(cvo_hip_ctx *ctx, float ell, const flo
  * for a caller-supplied stream -- eager launches, same results, a few per cent slower.  Enable
  * it when no other thread of the process issues HIP work while align() runs (or set
  * CVO_HIP_GRAPH=1); CVO_HIP_NO_GRAPH=1 disables every capture of the library.
- * cvo_hip_align_many() captures its shared launches only if every member context allows it. */
+ * cvo_hip_align_many() captures its shared launches only if every member context allows it.
+ * One cvo registration at a time captures nothing: most of its iterations run inside two or three
+ * launches (resident runs) and the few batches left are launched eagerly, which is faster there. */
 int cvo_hip_set_graph_capture(cvo_hip_ctx *ctx, int enable);
 
 /* Profiling: HIP events on the context's stream around every sweep launch. */
@@ -339,6 +341,9 @@ int cvo_hip_get_run_stats(cvo_hip_ctx *ctx, int *runs, int *declined, int *itera
 /* ... and, in builds with -DCVO_RUN_CLOCKS, the ticks the first solver block of the runs spent in each phase of the loop
  * (csrc/cvo_kernels.hip kt_run: RUN_CLK; zeros otherwise). */
 int cvo_hip_get_run_clocks(cvo_hip_ctx *ctx, long long clocks16[16]);
+/* How often (in this process) a registration that ran on its own found the final state's pinned copy incomplete when the
+ * `done` word was already there, and read it again (csrc/cvo_job.cpp job_pump: the copy carries a check word). */
+long long cvo_hip_get_mirror_retries(void);
 int cvo_hip_synchronize(cvo_hip_ctx *ctx);
 
 #ifdef __cplusplus

@@ -734,30 +734,35 @@ def test_align_many_refills_its_slots_from_the_queue(pkg, monkeypatch, graphs, j
         c.close()
 
 
-def test_graph_capture_policy_and_parameter_errors(pkg):
+@pytest.mark.parametrize("mode_name", ["acvo", "cvo"])
+def test_graph_capture_policy_and_parameter_errors(pkg, mode_name):
     """Captures are the default only on a stream the context created itself; on a caller's stream
     the loop launches eagerly until the caller opts in (cvo_hip.h: cvo_hip_set_graph_capture) --
-    same result either way.  set_params refuses a bad block and says why."""
+    same result either way.  A cvo registration on its own captures nothing whatever the policy: its plan
+    has a resident run and is launched eagerly (csrc/cvo_plan.cpp launch_batch).  set_params refuses a
+    bad block and says why."""
     import torch
     capi = pkg.capi
-    xf, ff, xm, fm = pkg.data.synthetic_pair(1800, 1700, seed=71)
+    acvo = mode_name == "acvo"
+    mode = capi.MODE_ACVO if acvo else capi.MODE_CVO
+    xf, ff, xm, fm = pkg.data.synthetic_pair(1800, 1700, seed=71, acvo=acvo)
     results = []
     for stream, opt_in in ((None, None), ("torch", None), ("torch", True), (None, False)):
         s = torch.cuda.Stream() if stream else None
-        c = capi.Context(mode=capi.MODE_CVO, device=0, stream=s.cuda_stream if s else None, graph_capture=opt_in)
+        c = capi.Context(mode=mode, device=0, stream=s.cuda_stream if s else None, graph_capture=opt_in)
         c.set_fixed(xf, ff)
         c.set_moving(xm, fm)
         for _ in range(2):
             st = capi.init_state(c.params)
             it, _ = c.align(st, trace_cap=0)
         hits, captures = c.graph_stats()
-        expect_graphs = (stream is None and opt_in is not False) or opt_in is True
+        expect_graphs = acvo and ((stream is None and opt_in is not False) or opt_in is True)
         assert (captures > 0) == expect_graphs, (stream, opt_in, hits, captures)
         if expect_graphs:
             assert captures <= 2 and hits >= captures    # the second align() re-uses the first one's batches
         results.append((it, bytes(st)))
         if stream is None and opt_in is None:
-            bad = capi.default_params(capi.MODE_CVO)
+            bad = capi.default_params(mode)
             bad.sigma = 0.0
             with pytest.raises(capi.CvoHipError, match="sigma"):
                 c.set_params(bad)
@@ -1131,3 +1136,52 @@ def test_align_many_on_its_own_takes_resident_runs(pkg):
     assert cs[0].run_stats()[0] >= 1
     for c in cs:
         c.close()
+
+
+def test_back_to_back_registrations_keep_their_run_counts_apart(pkg):
+    """Registrations on one context with nothing between them (the next begins as soon as the `done` word of the last is seen):
+    a resident run that ends the loop reports its own end a little after that word -- to a mirror the next registration has reset
+    by then; such a report must not be made (kt_run run_over), or the next registration takes it for the end of ITS first run and
+    queues batches whose runs decline one after the other.  Same final state every time, and the last registration saw its runs
+    decline at most once."""
+    capi = pkg.capi
+    xf, ff, xm, fm = pkg.data.synthetic_pair(3000, 3000, seed=1001)
+    c = capi.Context(mode=capi.MODE_CVO, device=0)
+    c.set_fixed(xf, ff); c.set_moving(xm, fm)
+    first = None
+    for _ in range(40):
+        st = capi.init_state(c.params)
+        it, _ = c.align(st, trace_cap=0)
+        if first is None:
+            first = (it, bytes(st))
+        assert (it, bytes(st)) == first
+    runs, declined, inside, _ = c.run_stats()
+    assert runs >= 1 and inside >= 20 and declined <= 1, (runs, declined, inside)
+    c.close()
+
+
+def test_final_state_from_the_pinned_copy_is_whole(pkg, monkeypatch):
+    """A registration on its own returns its final state from a pinned copy the last head writes in front of the `done` word
+    (head_publish -> job_pump).  Writes to host memory were seen to pass each other on this platform (a 16-byte piece of the
+    copy landing after the word: tools/gpu_fresh_hunt.py), so the copy carries a check word and the host re-reads until it
+    matches.  Fresh contexts (whose mirror holds zeros: a missing piece shows) against the same registrations with the state
+    fetched by a copy in stream order (CVO_HIP_NO_FINAL_MIRROR); and the check word does match (no endless re-reading)."""
+    capi = pkg.capi
+    pairs = [pkg.data.synthetic_pair(2500, 2500, seed=pkg.data.SEED_CFG5_BASE + 100 + b) for b in range(12)]
+
+    def once(pr):
+        c = capi.Context(mode=capi.MODE_CVO, device=0)
+        c.set_fixed(pr[0], pr[1]); c.set_moving(pr[2], pr[3])
+        st = capi.init_state(c.params)
+        it, _ = c.align(st, trace_cap=0)
+        c.close()
+        return it, bytes(st)
+
+    monkeypatch.setenv("CVO_HIP_NO_FINAL_MIRROR", "1")
+    ref = [once(pr) for pr in pairs]
+    monkeypatch.delenv("CVO_HIP_NO_FINAL_MIRROR")
+    before = capi.mirror_retries()
+    for _ in range(4):
+        for b, pr in enumerate(pairs):
+            assert once(pr) == ref[b], b
+    assert capi.mirror_retries() - before < 48 * 50   # (a late piece costs a few re-reads; a word that never matched ~700 each)

@@ -1,5 +1,4 @@
 #!/bin/bash
 cd ${GRAFT_REPO_ROOT:-.}
-python tools/gpu_r5_run_check.py 3000 6000 10000 2>&1 | tail -8
-python tools/gpu_single_rate.py 3000 6000 10000 14000 2>&1 | grep "^n "
-python -m pytest tests -m gpu -x -q -k "resident or on_its_own or parity or config" 2>&1 | tail -3
+python -m pytest tests -m gpu -x -q > gpurun_out/pytest_gpu.log 2>&1
+grep -v "^RCCL\|^HIP\|^ROCm\|^Hostname\|^Librccl" gpurun_out/pytest_gpu.log | tail -5
