@@ -3199,7 +3199,12 @@ kt_run(const Slot *__restrict__ tab, const int qs)
         RUN_CLK(10);
         if (tid < 64) {
             long long clk[4] = {0, 0, 0, 0};
+#ifdef CVO_RUN_CLOCKS
+            head_post<HM_HEAD>(&s_st, ps, true, head_block, true, clk);
+            clk_acc[15] += clk[1] - clk[0];   // (of head_post: the cubic and its root)
+#else
             head_post<HM_HEAD>(&s_st, ps, true, head_block, false, clk);
+#endif
             RUN_CLK(11);
             if (s_st.done == RUNNING) {
                 if (head_block) {

@@ -9,7 +9,7 @@ import __graft_entry__ as ge
 pkg = ge.load_package(); capi = pkg.capi
 if os.environ.get("CVO_LIB"):
     capi.LIB_PATH = os.path.join(os.path.dirname(capi.LIB_PATH), os.environ["CVO_LIB"])
-names = ("entry", "consts", "flow rounds", "wave sums", "barrier+block sum", "exch A", "twist", "step rounds", "step sums", "exch B", "pre-head", "head_post", "inverse+sync", "tail", "exit", "-")
+names = ("entry", "consts", "flow rounds", "wave sums", "barrier+block sum", "exch A", "twist", "step rounds", "step sums", "exch B", "pre-head", "head_post", "inverse+sync", "tail", "exit", "(of head_post: cubic+root)")
 for n in [int(a) for a in sys.argv[1:]] or [3000, 10000]:
     xf, ff, xm, fm = pkg.data.synthetic_pair(n, n, seed=pkg.data.SEED_CFG2)
     prm = capi.default_params(capi.MODE_CVO)
