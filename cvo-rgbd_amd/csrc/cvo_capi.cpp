@@ -222,6 +222,7 @@ int cvo_hip_create(int device, void *stream, const cvo_hip_params *p, cvo_hip_ct
     *ctx->run_mirror = 0;
     *ctx->hint_mirror = -1;
     if (getenv("CVO_HIP_NO_RUN")) ctx->allow_run = false;   // (test switch: no resident runs, cvo_kernels.hip kt_run)
+    ctx->head_graphs = getenv("CVO_HIP_RUN_GRAPHS") != nullptr;   // (test switch: captured batches for head-mode plans, cvo_plan.cpp launch_batch)
     // Stream capture is a process-wide affair in this runtime (cvo_lock.h): the library's own
     // entry points keep out of each other's captures, but HIP work of OTHER code in the process
     // (torch on another thread, say) cannot be kept out and would fail with "previous error

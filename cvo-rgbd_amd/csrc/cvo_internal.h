@@ -245,6 +245,7 @@ struct cvo_hip_ctx {
     DevBuf run_mail;                      // RunMail of this registration's resident runs
     bool plan_has_final_mirror = false;   // the plan of the align() in progress publishes its final head to final_mirror
     bool allow_run = true;                // CVO_HIP_NO_RUN
+    bool head_graphs = false;             // CVO_HIP_RUN_GRAPHS: head-mode plans go out as captured batches too (they launch eagerly by default)
     int run_nnz_max = 0;                  // a batch begins with a resident run when the record in use is expected to hold at most this many candidates
     std::vector<TLaunch> plan_pre;        // launches in front of a RUN batch's iterations (the kt_run launch); empty: the plan has no run
     std::vector<RecOp> *rec = nullptr;   // not null: record launches instead of issuing them

@@ -1110,11 +1110,11 @@ int launch_batch(cvo_hip_ctx *ctx, int tag0, int trace_cap, bool with_run, int s
         if (!rc) ctx->warm = true;
         return rc;
     }
-    // A plan with a resident run launches eagerly: most of its iterations run inside two or three launches, the host paces the few
-    // batches left slot by slot anyway, and every boundary between two captured batches cost ~9 us of idle stream (10k x 10k:
-    // three of them; 978 -> 1 003 registrations/s, 3k x 3k 1 190 -> 1 232: profiles/r05_ab.txt 14)
-    static const bool run_graphs = getenv("CVO_HIP_RUN_GRAPHS") != nullptr;   // (probe)
-    const bool graphs = ctx->use_graphs && (ctx->plan_pre.empty() || run_graphs);
+    // A head-mode plan (one registration with its launches to itself: two launches per iteration, or most iterations inside
+    // resident runs) launches eagerly: the host paces its batches on the slot mirror anyway, and every boundary between two
+    // captured batches cost ~9 us of idle stream (cvo 10k x 10k: three of them, 978 -> 1 003 registrations/s, 3k x 3k 1 190 -> 1 232;
+    // acvo 10k 615 -> 635, 3k 815 -> 849: profiles/r05_ab.txt 14, 16).  CVO_HIP_RUN_GRAPHS=1 (read when a context is created) brings the captured batches back.
+    const bool graphs = ctx->use_graphs && (!ctx->head_mode || ctx->head_graphs);
     const int rc = with_run ? run_plan(ctx->table.dev, ctx->plans, ctx->plan, loop_stream(ctx), graphs, kRunBatchSlots, &ctx->plan_pre)
                             : run_plan(ctx->table.dev, ctx->plans, ctx->plan, loop_stream(ctx), graphs, slots);
     if (rc) return fail(ctx, rc, "launching a batch of iterations failed");

@@ -303,8 +303,9 @@ int cvo_hip_function_inner_product_clouds(cvo_hip_ctx *ctx, float ell, const flo
  * it when no other thread of the process issues HIP work while align() runs (or set
  * CVO_HIP_GRAPH=1); CVO_HIP_NO_GRAPH=1 disables every capture of the library.
  * cvo_hip_align_many() captures its shared launches only if every member context allows it.
- * One cvo registration at a time captures nothing: most of its iterations run inside two or three
- * launches (resident runs) and the few batches left are launched eagerly, which is faster there. */
+ * One registration at a time on clouds small enough for the two-launch scheme (cvo, acvo: up to
+ * ~14k x 14k points) captures nothing: its few launches per iteration -- for cvo most iterations run
+ * inside two or three launches altogether -- go out eagerly, which is faster there. */
 int cvo_hip_set_graph_capture(cvo_hip_ctx *ctx, int enable);
 
 /* Profiling: HIP events on the context's stream around every sweep launch. */

@@ -527,11 +527,14 @@ def test_cloud_in_device_memory_equals_host_hand_over(pkg, n):
 
 
 @pytest.mark.parametrize("lo,span,max_captures", [(2900, 120, 4), (3030, 90, 10)])
-def test_stream_of_varying_clouds_reuses_its_captured_batches(pkg, lo, span, max_captures):
+def test_stream_of_varying_clouds_reuses_its_captured_batches(pkg, monkeypatch, lo, span, max_captures):
     """Frames of a real stream differ by a few points each: the device arrays are padded to
     256-row buckets and sizes stay out of the kernel arguments, so the loop's captured
     batches (hipGraph) are re-used from frame to frame -- and the results are those of
-    fresh objects."""
+    fresh objects.  (One registration at a time launches eagerly by default since round 5;
+    CVO_HIP_RUN_GRAPHS, read when a context is created, brings its captured batches back: the
+    property matters wherever batches are captured -- the engines share this code.)"""
+    monkeypatch.setenv("CVO_HIP_RUN_GRAPHS", "1")
     rng = np.random.default_rng(4)
     base = pkg.data.synthetic_pair(3200, 3200, seed=77, acvo=True)
     frames = []
@@ -549,6 +552,7 @@ def test_stream_of_varying_clouds_reuses_its_captured_batches(pkg, lo, span, max
             got.append((reg.num_iterations, reg.transform.copy()))
     hits, captures = reg.ctx.graph_stats()
     reg.close()
+    monkeypatch.delenv("CVO_HIP_RUN_GRAPHS")
     assert captures <= max_captures and hits > 3 * captures
     # each pair on fresh objects (acvo resets ell per pair, but R, T carry over: replay the chain)
     ref = pkg.Acvo()
@@ -734,36 +738,38 @@ def test_align_many_refills_its_slots_from_the_queue(pkg, monkeypatch, graphs, j
         c.close()
 
 
-@pytest.mark.parametrize("mode_name", ["acvo", "cvo"])
+@pytest.mark.parametrize("mode_name", ["matlab", "acvo", "cvo"])
 def test_graph_capture_policy_and_parameter_errors(pkg, mode_name):
     """Captures are the default only on a stream the context created itself; on a caller's stream
     the loop launches eagerly until the caller opts in (cvo_hip.h: cvo_hip_set_graph_capture) --
-    same result either way.  A cvo registration on its own captures nothing whatever the policy: its plan
-    has a resident run and is launched eagerly (csrc/cvo_plan.cpp launch_batch).  set_params refuses a
-    bad block and says why."""
+    same result either way.  That is the policy of the plans that are captured at all: one registration
+    at a time whose plan is a head-mode plan (cvo, acvo: two launches per iteration or resident runs) is
+    launched eagerly whatever the policy (csrc/cvo_plan.cpp launch_batch); the MATLAB weight's plan (classic
+    launches) shows the policy.  set_params refuses a bad block and says why."""
     import torch
     capi = pkg.capi
     acvo = mode_name == "acvo"
     mode = capi.MODE_ACVO if acvo else capi.MODE_CVO
+    prm0 = capi.default_params(capi.MODE_MATLAB) if mode_name == "matlab" else capi.default_params(mode)
     xf, ff, xm, fm = pkg.data.synthetic_pair(1800, 1700, seed=71, acvo=acvo)
     results = []
     for stream, opt_in in ((None, None), ("torch", None), ("torch", True), (None, False)):
         s = torch.cuda.Stream() if stream else None
-        c = capi.Context(mode=mode, device=0, stream=s.cuda_stream if s else None, graph_capture=opt_in)
+        c = capi.Context(mode=mode, device=0, stream=s.cuda_stream if s else None, graph_capture=opt_in, params=prm0)
         c.set_fixed(xf, ff)
         c.set_moving(xm, fm)
         for _ in range(2):
             st = capi.init_state(c.params)
             it, _ = c.align(st, trace_cap=0)
         hits, captures = c.graph_stats()
-        expect_graphs = acvo and ((stream is None and opt_in is not False) or opt_in is True)
+        expect_graphs = mode_name == "matlab" and ((stream is None and opt_in is not False) or opt_in is True)
         assert (captures > 0) == expect_graphs, (stream, opt_in, hits, captures)
         if expect_graphs:
             assert captures <= 2 and hits >= captures    # the second align() re-uses the first one's batches
         results.append((it, bytes(st)))
         if stream is None and opt_in is None:
             bad = capi.default_params(mode)
-            bad.sigma = 0.0
+            bad.sigma = 0.0   # (cvo_hip_set_params validates the block whatever the mode)
             with pytest.raises(capi.CvoHipError, match="sigma"):
                 c.set_params(bad)
         c.close()

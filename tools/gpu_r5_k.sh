@@ -1,4 +1,4 @@
 #!/bin/bash
 cd ${GRAFT_REPO_ROOT:-.}
-tools/gpu_timeline.sh 3000 | head -40
-tools/gpu_timeline.sh 6000 | head -30
+python -m pytest tests -m gpu -x -q > gpurun_out/pytest_gpu.log 2>&1
+grep -v "^RCCL\|^HIP\|^ROCm\|^Hostname\|^Librccl" gpurun_out/pytest_gpu.log | tail -5

@@ -12,10 +12,12 @@ if os.environ.get("CVO_LIB"):
 sizes = [int(a) for a in sys.argv[1:]] or [3000, 6000, 10000]
 seeds = [int(s) for s in os.environ.get("SEEDS", "%d,1001,1002" % pkg.data.SEED_CFG2).split(",")]
 reps = int(os.environ.get("REPS", "30"))
+acvo = bool(os.environ.get("ACVO"))
+mode = capi.MODE_ACVO if acvo else capi.MODE_CVO
 for n in sizes:
     for seed in seeds:
-        xf, ff, xm, fm = pkg.data.synthetic_pair(n, n, seed=seed)
-        c = capi.Context(mode=capi.MODE_CVO, device=0)
+        xf, ff, xm, fm = pkg.data.synthetic_pair(n, n, seed=seed, acvo=acvo)
+        c = capi.Context(mode=mode, device=0)
         c.set_fixed(xf, ff); c.set_moving(xm, fm)
         for _ in range(3):
             st = capi.init_state(c.params); n_it, _ = c.align(st, trace_cap=0)
