@@ -123,7 +123,10 @@ constexpr int RUN_G_SMALL = 32;      // runs of up to this many solvers start wi
 constexpr int RUN_BLOCK = 512;       // 8 waves = two per SIMD: 256 vector registers per lane, the run's candidates live there
 constexpr int RUN_WAVES = RUN_BLOCK / 64;
 constexpr int RUN_LANES = RUN_G * RUN_BLOCK;
-constexpr int RUN_R = 8;             // candidates per lane at most: RUN_LANES * RUN_R = 1 015 808 candidates per run
+constexpr int RUN_R = 8;             // candidates per lane in registers: RUN_LANES * RUN_R = 1 015 808 candidates
+constexpr int RUN_L = 8;             // ... and in LDS behind them (the widest runs only: 2 x 16 bytes per candidate, 128 KB per block)
+constexpr int RUN_CAP = RUN_LANES * (RUN_R + RUN_L);   // candidates a run holds at most: 2 031 616
+constexpr unsigned RUN_LDS_BYTES = (unsigned)RUN_L * 2u * (unsigned)RUN_BLOCK * 16u;   // dynamic LDS of kt_run
 constexpr int RUN_NV = 9;            // doubles per exchange at most (flow: 9, step: 4)
 struct RunMail {
     unsigned long long w[2][RUN_G + 1][2 * RUN_NV];   // (row RUN_G: the head block's verdict word)
@@ -228,11 +231,13 @@ struct alignas(16) DevHead {
                                 // k_step_twist launch that exchanges number their exchange from (mail_seq itself moves while they start)
     int32_t run_hint;           // candidates expected in the record the slot that begins reads (prepare_iteration): what the host picks
                                 // the next batch's plan by (PostStepArgs::hint_mirror)
-    int32_t head_pad_[3];
+    int32_t head_check_;        // the check word of a copy that went to the host's pinned mirror (head_check_mix); unused on the device
+    int32_t rec_count[2];       // candidates in the record of xy buffer b where a launch has counted them (the publishing block of a head-mode
+                                // flow launch, a resident run at entry), 0: not known -- plan_xy_async keeps a wide list whose record fits a run
 };
 // Check word of a head that went to the host's pinned copy (head_publish -> job_pump): every 16-byte piece mixed with its index,
-// summed; DevHead::head_pad_[0] counts as zero and then holds the sum.
-CVO_HD inline unsigned head_check_mix(unsigned x, unsigned y, unsigned z, unsigned w, unsigned piece)
+// summed; DevHead::head_check_ counts as zero and then holds the sum.
+CVO_HD unsigned head_check_mix(unsigned x, unsigned y, unsigned z, unsigned w, unsigned piece)
 {
     return (x * 0x9E3779B1u + y * 0x85EBCA77u + z * 0xC2B2AE3Du + w * 0x27D4EB2Fu) ^ (piece * 0x165667B1u + 0x9E3779B9u);
 }
@@ -622,7 +627,10 @@ CVO_HD void plan_xy_async(DevHead *s, DevHead *bulk, const bool store, const Dev
         // 0.15 -> 0.10 -> 0.06) serves on, the step 0.06 -> 0.03 (2 x) rebuilds
         const float nnz = (float)s->red[RED_FLOW + 8];
         const float w = lr / r0;
-        const bool fits = p.run_cand_cap > 0.0f && nnz > 0.0f && 1.05f * nnz * (r_now / fmaxf(s->r_last, 1.0e-9f)) * (r_now / fmaxf(s->r_last, 1.0e-9f)) * w * w <= 0.9f * p.run_cand_cap;
+        // (the record's count where a launch has counted it, else an estimate with room)
+        const int known = use ? s->rec_count[1] : s->rec_count[0];
+        const bool fits = p.run_cand_cap > 0.0f && (known > 0 ? (float)known <= p.run_cand_cap :
+                          (nnz > 0.0f && 1.05f * nnz * (r_now / fmaxf(s->r_last, 1.0e-9f)) * (r_now / fmaxf(s->r_last, 1.0e-9f)) * w * w <= 0.9f * p.run_cand_cap));
         if (lr > (fits ? 1.9f : LIST_LOOSE) * (1.0f + margin) * r0) build = true;
     }
     if (inflight >= 0) build = false;   // (its buffer is the only one that is free)
@@ -634,8 +642,8 @@ CVO_HD void plan_xy_async(DevHead *s, DevHead *bulk, const bool store, const Dev
         const float r = r0 * (1.0f + margin) * 1.000001f;   // rounded up
         // tauf[LIST_XY] of compute_filter_bounds is tau + rounding slack: widen tau
         s->tauf_build = (r * r + (s->tauf[LIST_XY] - s->kc.tau)) * 1.000001f;
-        if (tgt == 0) { s->xy_ok[0] = 0; s->xy_ck[0] = 0; s->xy_r[0] = r; }   // (a new tile list: its candidate record is void)
-        else { s->xy_ok[1] = 0; s->xy_ck[1] = 0; s->xy_r[1] = r; }
+        if (tgt == 0) { s->xy_ok[0] = 0; s->xy_ck[0] = 0; s->xy_r[0] = r; s->rec_count[0] = 0; }   // (a new tile list: its candidate record is void)
+        else { s->xy_ok[1] = 0; s->xy_ck[1] = 0; s->xy_r[1] = r; s->rec_count[1] = 0; }
         if (store) {
             float *dR = tgt == 0 ? bulk->xy_Rt[0] : bulk->xy_Rt[1], *dt = tgt == 0 ? bulk->xy_t[0] : bulk->xy_t[1];
             for (int q = 0; q < 9; ++q) dR[q] = s->Rt[q];
@@ -797,5 +805,6 @@ void launch_table(const Slot *tab, const TLaunch &l, hipStream_t s, hipEvent_t e
 // geometry helpers shared with the host (what the by-value launchers compute from their arguments)
 unsigned filter_grid_cap(long long nitems, long long cap);
 long long filter_blocks_cap();
+hipError_t run_allow_lds();   // (before the first kt_run launch on the current device: its dynamic LDS is above the default limit)
 
 }   // namespace cvo_dev

@@ -245,6 +245,7 @@ struct cvo_hip_ctx {
     DevBuf run_mail;                      // RunMail of this registration's resident runs
     bool plan_has_final_mirror = false;   // the plan of the align() in progress publishes its final head to final_mirror
     bool allow_run = true;                // CVO_HIP_NO_RUN
+    bool spec_first_run = true;           // the first run of a registration goes out on spec behind its first two slots (job_pump learns from each try)
     bool head_graphs = false;             // CVO_HIP_RUN_GRAPHS: head-mode plans go out as captured batches too (they launch eagerly by default)
     int run_nnz_max = 0;                  // a batch begins with a resident run when the record in use is expected to hold at most this many candidates
     std::vector<TLaunch> plan_pre;        // launches in front of a RUN batch's iterations (the kt_run launch); empty: the plan has no run
@@ -339,6 +340,7 @@ struct AlignJob {
     bool in_group = false;  // runs in a fused group (on the group's stream and table)
     int runs_enq = 0;       // resident runs enqueued in this round
     bool run_waiting = false;   // the last batch began with a resident run that has not reported its end yet
+    bool spec_pending = false;  // ... and that run was sent on spec (job_pump: the first run of a registration)
     bool paced_nb = false;  // a registration on its own inside cvo_hip_align_many: the paced steps of job_pump, one look per call
     int idle_seen = 0;      // ... and how often in a row its stream was found idle with the mirrors where they were
     bool paced = false;     // cvo_hip_align only: the calling thread has nothing else to pump and may sit in the

@@ -114,11 +114,12 @@ int job_begin(AlignJob &j)
     j.enq = j.batches = j.checked = 0;
     j.runs_enq = 0;
     j.run_waiting = false;
+    j.spec_pending = false;
     j.executed_base = 0;
     // (a batch begins with a resident run when the record in use is expected to hold at most this many candidates -- DevHead::
     // run_hint: the record's count where the last head knew it, else an estimate with 5 % of room; a run that finds more than it can
     // hold declines, which costs its launch and one head)
-    ctx->run_nnz_max = RUN_LANES * RUN_R;
+    ctx->run_nnz_max = RUN_CAP;
     if (const char *e = getenv("CVO_HIP_RUN_CAND")) ctx->run_nnz_max = atoi(e);   // (tuning switch)
     j.phase = p.max_iter <= 0 ? 1 : 0;
     if (j.phase == 1) {
@@ -216,14 +217,28 @@ int job_pump(AlignJob &j, bool block)
                 // a RUN batch: its length is the run's business; the next batch goes out when the run reports its end --
                 // the batch's kRunBatchSlots classic slots are what is left then
                 go = runs >= j.runs_enq;
-                if (go) { j.enq = slots + kRunBatchSlots; j.run_waiting = false; }
+                if (go) {
+                    // (the run that was sent on spec behind the first two slots: did it carry slots, or decline?)
+                    if (j.spec_pending) { ctx->spec_first_run = slots > kShortBatch; j.spec_pending = false; }
+                    j.enq = slots + kRunBatchSlots; j.run_waiting = false;
+                }
             } else {
                 go = j.enq - slots <= lead;
             }
             if (go) {
                 if (j.enq >= limit) break;   // cannot happen
                 const int hint = *(volatile int32_t *)ctx->hint_mirror;
-                const bool with_run = ctx->head_mode && !ctx->plan_pre.empty() && hint > 0 && hint <= ctx->run_nnz_max;
+                // A registration's first list is its widest.  Where the last registration of this context could run on it (or nothing is
+                // known and the clouds are small enough to try) the batch behind the first two slots -- the build, then the iteration
+                // whose flow pass records the list's candidates -- begins with a run ON SPEC: the hint that would say so comes two slots
+                // later.  A run that finds the record too large declines (its launch and one head: ~5 us) and the context stops trying
+                // until a first record fits again.
+                const bool run_plan_ = ctx->head_mode && !ctx->plan_pre.empty();
+                const bool first_choice = run_plan_ && j.batches == 1 && j.enq == kShortBatch && j.runs_enq == 0;
+                if (run_plan_ && j.batches == 2 && j.runs_enq == 0 && !ctx->spec_first_run && hint > 0) ctx->spec_first_run = hint <= ctx->run_nnz_max;
+                const bool spec = first_choice && ctx->spec_first_run;
+                if (spec) j.spec_pending = true;
+                const bool with_run = run_plan_ && (spec || (hint > 0 && hint <= ctx->run_nnz_max));
                 // (a plan with runs is launched eagerly and in the shortest batches: a run can only start at a batch's head, and the
                 // slot it may start at is two or three slots after the head that first says so)
                 const bool near_run = ctx->head_mode && !ctx->plan_pre.empty() && !with_run;
@@ -297,7 +312,7 @@ int job_pump(AlignJob &j, bool block)
                     uint32_t sum = 0;
                     for (int q = 0; q < pieces; ++q)
                         sum += head_check_mix(w[4 * q], q == pieces - 1 ? 0u : w[4 * q + 1], w[4 * q + 2], w[4 * q + 3], (unsigned)q);
-                    if (ctx->st_host[0].done == verdict && sum == (uint32_t)ctx->st_host[0].head_pad_[0]) return finish_with(job_finish(j));
+                    if (ctx->st_host[0].done == verdict && sum == (uint32_t)ctx->st_host[0].head_check_) return finish_with(job_finish(j));
                     mirror_retries().fetch_add(1, std::memory_order_relaxed);
                     if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(50)) break;
                     __builtin_ia32_pause();

@@ -33,6 +33,7 @@
 // reference's operation order, accumulated in float64.  The MFMA filter only
 // decides which pairs are LOOKED AT; it never decides membership in A.
 #include <algorithm>
+#include <atomic>
 #include <cstdlib>
 
 #include "cvo_device.h"
@@ -2070,7 +2071,7 @@ __device__ __forceinline__ void head_plan(DevHead *lds, const PostStepArgs &a, c
             lds->tauf_build = L.tauf_build;
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
-                lds->xy_ok[q] = L.xy_ok[q]; lds->xy_ck[q] = L.xy_ck[q]; lds->xy_r[q] = L.xy_r[q];
+                lds->xy_ok[q] = L.xy_ok[q]; lds->xy_ck[q] = L.xy_ck[q]; lds->xy_r[q] = L.xy_r[q]; lds->rec_count[q] = L.rec_count[q];
                 lds->sf_active[q] = L.sf_active[q]; lds->sf_target[q] = L.sf_target[q]; lds->sf_fresh[q] = L.sf_fresh[q];
                 lds->sf_ok[q][0] = L.sf_ok[q][0]; lds->sf_ok[q][1] = L.sf_ok[q][1];
                 lds->sf_ck[q][0] = L.sf_ck[q][0]; lds->sf_ck[q][1] = L.sf_ck[q][1];
@@ -2141,7 +2142,7 @@ __device__ __forceinline__ void head_publish(const PostStepArgs &a, const DevHea
         const uint4 *src = reinterpret_cast<const uint4 *>(s_st);
         uint4 *dst = reinterpret_cast<uint4 *>(a.final_mirror);
         constexpr int pieces = (int)(DEVSTATE_HEAD_BYTES / 16);
-        static_assert(pieces <= 64 && offsetof(DevHead, head_pad_) == DEVSTATE_HEAD_BYTES - 12, "one wave copies the head; the check word is the last piece's second word");
+        static_assert(pieces <= 64 && offsetof(DevHead, head_check_) == DEVSTATE_HEAD_BYTES - 12, "one wave copies the head; the check word is the last piece's second word");
         if (threadIdx.x < 64) {
             uint4 v = make_uint4(0u, 0u, 0u, 0u);
             if ((int)threadIdx.x < pieces) v = src[threadIdx.x];
@@ -2244,9 +2245,10 @@ __device__ __forceinline__ bool head_body(const PostStepArgs &a, const DevHead *
         if (count) {
             // exact where it can be: the loop runs on that buffer still, its record is complete (a flow pass has written it) and
             // no build is named or in flight (a run would decline: the estimate of prepare_iteration stands)
-            if (tid == 0 && s_st->done == RUNNING && s_st->stall == 0 && s_st->xy_target < 0 && s_st->xy_fresh < 0 &&
-                (s_st->xy_active ? 1 : 0) == act0 && (act0 ? s_st->xy_ck[1] : s_st->xy_ck[0]) == count_pa->nblk)
-                s_st->run_hint = (int32_t)s_cand_total;
+            if (tid == 0 && s_st->done == RUNNING && (s_st->xy_active ? 1 : 0) == act0 && (act0 ? s_st->xy_ck[1] : s_st->xy_ck[0]) == count_pa->nblk) {
+                if (act0) s_st->rec_count[1] = (int32_t)s_cand_total; else s_st->rec_count[0] = (int32_t)s_cand_total;
+                if (s_st->stall == 0 && s_st->xy_target < 0 && s_st->xy_fresh < 0) s_st->run_hint = (int32_t)s_cand_total;
+            }
             __syncthreads();
         }
         if (publisher) head_prepare_lists<HM>(a, s_st);
@@ -2287,6 +2289,7 @@ __global__ void k_prepare(DevState *st, const DevParams prm, uint32_t *build_mas
         }
         st->xy_ok[0] = st->xy_ok[1] = 0;   // async xy: the first slot only builds
         st->xy_ck[0] = st->xy_ck[1] = 0;
+        st->rec_count[0] = st->rec_count[1] = 0;
         st->xy_active = 0;
         st->xy_target = -1;
         st->xy_fresh = -1;
@@ -2804,12 +2807,71 @@ __device__ __forceinline__ void run_step_rounds(const float (&rt)[12], const Ker
     }
 }
 
+__global__ void kt_run(const Slot *__restrict__ tab, const int qs);
+// ... and over the NL candidates per lane that live in LDS behind the registers' (the widest runs: RUN_L): lane t's candidate of
+// round r as two 16-byte pieces, [x0 x1 x2 ck] at lc[(2 r) * RUN_BLOCK + t] and [y0 y1 y2 w] behind it -- every lane reads and
+// writes its own pieces only (no barrier), a wave's accesses are consecutive (no bank conflict).  The same arithmetic per pair.
+__device__ __forceinline__ unsigned run_flow_lds(const int nl, float4 *lc, const float (&rt)[12], const KernConsts &kc, const double *etab,
+                                                 const int need_d2, double (&acc)[NACC_FLOW])
+{
+    // (two rounds per trip, independent chains side by side; nl is even: the loader fills an odd last round with lanes without a candidate)
+    unsigned nk = 0;
+#pragma unroll 1
+    for (int r = 0; r < nl; r += 2) {
+        float w[2], d2[2];
+        float4 xi[2], yj[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const float4 a4 = lc[(2 * (r + u)) * RUN_BLOCK], b4 = lc[(2 * (r + u) + 1) * RUN_BLOCK];
+            xi[u] = make_float4(a4.x, a4.y, a4.z, 0.0f);
+            yj[u] = apply_tf(rt, rt + 9, make_float4(b4.x, b4.y, b4.z, 0.0f));
+            const float e0 = xi[u].x - yj[u].x, e1 = xi[u].y - yj[u].y, e2 = xi[u].z - yj[u].z;
+            d2[u] = __builtin_fmaf(e2, e2, __builtin_fmaf(e1, e1, e0 * e0));
+            const float ck = a4.w;
+            const float a = ck * (float)(kc.s2_d * exp_neg((double)d2[u] * kc.ninv_2l2, etab));
+            w[u] = (d2[u] < kc.tau && ck > 0.0f && a > kc.sp) ? a : 0.0f;
+            reinterpret_cast<float *>(&lc[(2 * (r + u) + 1) * RUN_BLOCK])[3] = w[u];
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            pair_flow_sums(kc, xi[u], yj[u], w[u], d2[u], need_d2, acc);
+            nk += (unsigned)__popcll(__ballot(w[u] > 0.0f));
+        }
+    }
+    return nk;
+}
+__device__ __forceinline__ void run_step_lds(const int nl, const float4 *lc, const float (&rt)[12], const KernConsts &kc,
+                                             const cvo_math::XiConsts &xc, double (&sacc)[NACC_STEP])
+{
+#pragma unroll 1
+    for (int r = 0; r < nl; r += 2) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const float4 a4 = lc[(2 * (r + u)) * RUN_BLOCK], b4 = lc[(2 * (r + u) + 1) * RUN_BLOCK];
+            const float4 yj = apply_tf(rt, rt + 9, make_float4(b4.x, b4.y, b4.z, 0.0f));
+            pair_step_sums(kc, xc, yj, a4.x - yj.x, a4.y - yj.y, a4.z - yj.z, b4.w, sacc);
+        }
+    }
+}
+
 unsigned run_grid() { return 1u + RUN_G; }
+// (more than 64 KB of dynamic LDS per block must be asked for, once per device)
+hipError_t run_allow_lds()
+{
+    static std::atomic<unsigned char> allowed[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (allowed[dev].load(std::memory_order_acquire)) return hipSuccess;
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kt_run), hipFuncAttributeMaxDynamicSharedMemorySize, (int)RUN_LDS_BYTES);
+    if (e == hipSuccess) allowed[dev].store(1, std::memory_order_release);
+    return e;
+}
 
 __global__ void __launch_bounds__(RUN_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
 kt_run(const Slot *__restrict__ tab, const int qs)
 {
     __shared__ unsigned long long s_ticket;
+    extern __shared__ __attribute__((aligned(16))) float4 s_lc[];   // [RUN_L][2][RUN_BLOCK]: the candidates behind the registers'
     const bool head_block = blockIdx.x == 0;
     const int srow = (int)blockIdx.x - 1;   // a solver's row in the exchanges (-1: the head block)
     CSlot cs = (CSlot)(tab);
@@ -2831,7 +2893,12 @@ kt_run(const Slot *__restrict__ tab, const int qs)
     __shared__ __attribute__((aligned(16))) DevHead s_st;
     __shared__ double s_red[RUN_WAVES * NACC_MAX];
     __shared__ double s_vals[NACC_MAX];
-    __shared__ double s_all[RUN_G * RUN_NV];
+    // (the exchanges' rows and the record's prefix sums share their LDS: the prefix sums are dead once the candidates are loaded,
+    // and every exchange begins with a barrier)
+    constexpr size_t S_ALL_BYTES = sizeof(double) * RUN_G * RUN_NV, S_PREF_BYTES = sizeof(unsigned) * (PROC_WAVES + 1);
+    __shared__ __attribute__((aligned(16))) unsigned char s_union[S_ALL_BYTES > S_PREF_BYTES ? S_ALL_BYTES : S_PREF_BYTES];
+    double *const s_all = reinterpret_cast<double *>(s_union);
+    unsigned *const s_pref = reinterpret_cast<unsigned *>(s_union);
     __shared__ double s_part[8 * RUN_NV];
     __shared__ double s_tot[NACC_MAX + 4];
     __shared__ double s_etab[64];
@@ -2841,7 +2908,6 @@ kt_run(const Slot *__restrict__ tab, const int qs)
     __shared__ unsigned s_verdict;
     __shared__ double s_bak[NACC_FLOW];
     __shared__ float s_bakf[6];
-    __shared__ unsigned s_pref[PROC_WAVES + 1];
     __shared__ unsigned s_wsum[RUN_WAVES];
     __shared__ unsigned long long s_seq;
 
@@ -2882,7 +2948,7 @@ kt_run(const Slot *__restrict__ tab, const int qs)
     // a build this launch's filter blocks would have to make
     // (... or a record that is expected to hold far more than a run's registers: decided before the head's maths, cheaply)
     if (s_st.done != RUNNING || s_st.stall != 0 || s_st.xy_target >= 0 || pa.cand == nullptr || pa.cand_b == nullptr ||
-        ps.run_mail == nullptr || s_st.run_hint > 2 * RUN_LANES * RUN_R) {
+        ps.run_mail == nullptr || s_st.run_hint > 2 * RUN_CAP) {
 #ifdef CVO_RUN_WHY
         if (head_block && tid == 0) gst->run_clk[s_st.done != RUNNING ? 0 : (s_st.stall != 0 ? 1 : (s_st.xy_target >= 0 ? 2 : 3))] += 1;
 #endif
@@ -2951,7 +3017,8 @@ kt_run(const Slot *__restrict__ tab, const int qs)
         __syncthreads();
     }
     if (head_block && tid == 0) gst->run_candidates = (int32_t)total;
-    if (total > (unsigned)RUN_LANES * RUN_R || total == 0u) ok = false;
+    if (ok && tid == 0) { if (act) s_st.rec_count[1] = (int32_t)total; else s_st.rec_count[0] = (int32_t)total; }   // (every block alike; the record is current)
+    if (total > (unsigned)RUN_CAP || total == 0u) ok = false;
 #ifdef CVO_RUN_WHY
     if (!ok && head_block && tid == 0)
         gst->run_clk[s_st.done != RUNNING ? 4 : (s_st.stall != 0 ? 5 : ((act ? s_st.xy_ck[1] : s_st.xy_ck[0]) != pa.nblk ? 6 : (total == 0u ? 8 : 7)))] += 1;
@@ -3035,6 +3102,34 @@ kt_run(const Slot *__restrict__ tab, const int qs)
             }
         }
     }
+    // ... and those behind the registers' (rounds RUN_R .. rmax - 1: only a run of all RUN_G solvers has them) into LDS
+    static_assert(RUN_L % 2 == 0, "run_flow_lds / run_step_lds take two rounds per trip");
+    const int nl = rmax > RUN_R ? ((rmax - RUN_R + 1) & ~1) : 0;   // (wave-uniform; even: a last odd round is filled with lanes without a candidate)
+    float4 *const lc = s_lc + tid;
+    {
+        const uint2 *rec = act ? pa.cand_b : pa.cand;
+        const unsigned wcap = pa.kept_wcap;
+#pragma unroll 1
+        for (int r = 0; r < nl; ++r) {
+            const unsigned c0 = wave_first + (unsigned)(RUN_R + r) * lanes;   // (< total but for the filling round)
+            const unsigned cs = c0 < total ? c0 : total - 1u;
+            const unsigned coarse = s_pref[lane * 64];
+            const int k1 = __popcll(__ballot(coarse <= cs)) - 1;
+            const unsigned fine = s_pref[k1 * 64 + lane];
+            int sl = k1 * 64 + __popcll(__ballot(fine <= cs)) - 1;
+            const unsigned c = c0 + (unsigned)lane;
+            uint2 e = make_uint2(0u, 0u);
+            const bool have = c < total;
+            if (have) {
+                while (c >= s_pref[sl + 1]) ++sl;
+                e = rec[(size_t)sl * wcap + (c - s_pref[sl])];
+            }
+            const float4 x = pa.pos_a[e.x & 0xffffu];
+            const float4 y = pa.pos_b[e.x >> 16];
+            lc[(2 * r) * RUN_BLOCK] = make_float4(x.x, x.y, x.z, have ? __uint_as_float(e.y) : 0.0f);
+            lc[(2 * r + 1) * RUN_BLOCK] = make_float4(y.x, y.y, y.z, 0.0f);
+        }
+    }
     // the row of flags the entry head has read is cleared as the slot's step launch would (nothing is flagged in a run);
     // the counters of a build the entry head has named are zeroed as its flow launch would
     if (head_block) {
@@ -3081,6 +3176,7 @@ kt_run(const Slot *__restrict__ tab, const int qs)
         case 5: case 6: nk = run_flow_rounds<6>(rt, kc, cx, cy, cck, cw, s_etab, need_d2, acc); break;
         default: nk = run_flow_rounds<8>(rt, kc, cx, cy, cck, cw, s_etab, need_d2, acc); break;
         }
+        if (nl > 0) nk += run_flow_lds(nl, lc, rt, kc, s_etab, need_d2, acc);
         RUN_CLK(2);
         if (!head_block) {
             if (lane == 0) acc[8] = (double)nk;
@@ -3128,6 +3224,7 @@ kt_run(const Slot *__restrict__ tab, const int qs)
         case 5: case 6: run_step_rounds<6>(rt, kc, xc, cx, cy, cw, sacc); break;
         default: run_step_rounds<8>(rt, kc, xc, cx, cy, cw, sacc); break;
         }
+        if (nl > 0) run_step_lds(nl, lc, rt, kc, xc, sacc);
         RUN_CLK(7);
         if (!head_block) {
             wave_sums<NACC_STEP>(sacc, lane, s_red + wid * NACC_MAX);
@@ -3303,7 +3400,7 @@ void launch_table(const Slot *tab, const TLaunch &l, hipStream_t s, hipEvent_t e
     case TK_HFLOW_BUILD: hipLaunchKernelGGL(kt_hflow_build_w4, g, dim3(BLOCK), l.smem, s, tab, qp); break;
     case TK_HFLOW_BUILD6: hipLaunchKernelGGL(kt_hflow_build6_w4, g, dim3(BLOCK), l.smem, s, tab, qp); break;
     case TK_HSTEP_TWIST: hipLaunchKernelGGL(kt_step_twist, g, dim3(STEP_BLOCK), 0, s, tab, qp); break;
-    case TK_RUN: hipLaunchKernelGGL(kt_run, dim3(run_grid()), dim3(RUN_BLOCK), 0, s, tab, l.q); break;
+    case TK_RUN: hipLaunchKernelGGL(kt_run, dim3(run_grid()), dim3(RUN_BLOCK), RUN_LDS_BYTES, s, tab, l.q); break;   // (run_allow_lds first: plan_lone's caller)
     default: break;
     }
 }

@@ -463,7 +463,7 @@ DevParams loop_params(const cvo_hip_ctx *ctx)
     // wide while its record still fits, plan_xy_async)
     if (ctx->use_async && ctx->lone && ctx->allow_head && ctx->allow_run && !multi_rank(ctx) && ctx->prm.mode == CVO_HIP_MODE_CVO &&
         !(ctx->prm.color_scale > 0.0f) && !ctx->post_dbg && ctx->allow_merge && ctx->fixed.np <= 65536 && ctx->moving.np <= 65536 && !env_no_cand())
-        dp.run_cand_cap = (float)RUN_LANES * (float)RUN_R;
+        dp.run_cand_cap = (float)RUN_CAP;
     return dp;
 }
 
@@ -1090,6 +1090,7 @@ int prepare_lone_plan(cvo_hip_ctx *ctx, int trace_cap)
     Slot slot;
     if (!plan_lone(ops, slot, ctx->plan, ctx->allow_head, &ctx->head_mode, &ctx->plan_pre))
         return fail(ctx, CVO_HIP_ERR_INVALID, "launch plan does not fit the argument table");
+    if (!ctx->plan_pre.empty() && run_allow_lds() != hipSuccess) return fail(ctx, CVO_HIP_ERR_HIP, "resident runs: the shared-memory attribute was refused");
     set_build_masks(slot, ctx->plan, ctx->table.masks(), 0);
     ctx->plan_has_final_mirror = false;
     for (const TLaunch &l : ctx->plan)   // (the launches whose heads publish: the post-step launch, or the head-mode flow launch)
