@@ -3110,24 +3110,33 @@ kt_run(const Slot *__restrict__ tab, const int qs)
         const uint2 *rec = act ? pa.cand_b : pa.cand;
         const unsigned wcap = pa.kept_wcap;
 #pragma unroll 1
-        for (int r = 0; r < nl; ++r) {
-            const unsigned c0 = wave_first + (unsigned)(RUN_R + r) * lanes;   // (< total but for the filling round)
-            const unsigned cs = c0 < total ? c0 : total - 1u;
-            const unsigned coarse = s_pref[lane * 64];
-            const int k1 = __popcll(__ballot(coarse <= cs)) - 1;
-            const unsigned fine = s_pref[k1 * 64 + lane];
-            int sl = k1 * 64 + __popcll(__ballot(fine <= cs)) - 1;
-            const unsigned c = c0 + (unsigned)lane;
-            uint2 e = make_uint2(0u, 0u);
-            const bool have = c < total;
-            if (have) {
-                while (c >= s_pref[sl + 1]) ++sl;
-                e = rec[(size_t)sl * wcap + (c - s_pref[sl])];
+        for (int r0 = 0; r0 < nl; r0 += 2) {   // (two rounds per trip: both records requested before either gather, all four gathers before a store)
+            uint2 e[2];
+            bool have[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const unsigned c0 = wave_first + (unsigned)(RUN_R + r0 + u) * lanes;   // (< total but for the filling round)
+                const unsigned cs = c0 < total ? c0 : total - 1u;
+                const unsigned coarse = s_pref[lane * 64];
+                const int k1 = __popcll(__ballot(coarse <= cs)) - 1;
+                const unsigned fine = s_pref[k1 * 64 + lane];
+                int sl = k1 * 64 + __popcll(__ballot(fine <= cs)) - 1;
+                const unsigned c = c0 + (unsigned)lane;
+                e[u] = make_uint2(0u, 0u);
+                have[u] = c < total;
+                if (have[u]) {
+                    while (c >= s_pref[sl + 1]) ++sl;
+                    e[u] = rec[(size_t)sl * wcap + (c - s_pref[sl])];
+                }
             }
-            const float4 x = pa.pos_a[e.x & 0xffffu];
-            const float4 y = pa.pos_b[e.x >> 16];
-            lc[(2 * r) * RUN_BLOCK] = make_float4(x.x, x.y, x.z, have ? __uint_as_float(e.y) : 0.0f);
-            lc[(2 * r + 1) * RUN_BLOCK] = make_float4(y.x, y.y, y.z, 0.0f);
+            float4 x[2], y[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) { x[u] = pa.pos_a[e[u].x & 0xffffu]; y[u] = pa.pos_b[e[u].x >> 16]; }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                lc[(2 * (r0 + u)) * RUN_BLOCK] = make_float4(x[u].x, x[u].y, x[u].z, have[u] ? __uint_as_float(e[u].y) : 0.0f);
+                lc[(2 * (r0 + u) + 1) * RUN_BLOCK] = make_float4(y[u].x, y[u].y, y[u].z, 0.0f);
+            }
         }
     }
     // the row of flags the entry head has read is cleared as the slot's step launch would (nothing is flagged in a run);

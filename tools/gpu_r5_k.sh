@@ -1,7 +1,5 @@
 #!/bin/bash
 cd ${GRAFT_REPO_ROOT:-.}
-python -m pytest tests -m gpu -x -q > gpurun_out/pytest_gpu.log 2>&1
-grep -v "^RCCL\|^HIP\|^ROCm\|^Hostname\|^Librccl" gpurun_out/pytest_gpu.log | tail -5
-echo "== random 300"; SOAK_SEED=80801 timeout 2400 python tools/gpu_soak.py 300 4000 2>&1 | grep -v "^RCCL\|^HIP\|^ROCm" | tail -2
-echo "== larger clouds 80 x 12000"; SOAK_SEED=80803 timeout 2400 python tools/gpu_soak.py 80 12000 2>&1 | grep -v "^RCCL\|^HIP\|^ROCm" | tail -2
-echo "== big clouds 30 x 16000"; SOAK_SEED=80804 timeout 2400 python tools/gpu_soak.py 30 16000 2>&1 | grep -v "^RCCL\|^HIP\|^ROCm" | tail -2
+MAX_ITER=11 CVO_LIB=libcvo_hip_clk.so python tools/gpu_run_clocks.py 10000 2>&1 | grep -v "^RCCL\|^HIP\|^ROCm" | cut -c1-200
+python tools/gpu_r5_run_check.py 10000 2>&1 | tail -5
+for i in 1 2; do SEEDS=20190402 python tools/gpu_single_rate.py 3000 6000 10000 2>&1 | grep "^n "; done
