@@ -222,6 +222,12 @@ int cvo_hip_create(int device, void *stream, const cvo_hip_params *p, cvo_hip_ct
     *ctx->run_mirror = 0;
     *ctx->hint_mirror = -1;
     if (getenv("CVO_HIP_NO_RUN")) ctx->allow_run = false;   // (test switch: no resident runs, cvo_kernels.hip kt_run)
+    {   // (a run's blocks must all be resident at once, one per compute unit: a partition with fewer units gets smaller runs)
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus <= 0) cus = RUN_G + 8;
+        ctx->run_g_max = std::max(8, std::min((int)RUN_G, cus - 8));
+        if (const char *e = getenv("CVO_HIP_RUN_G_MAX")) ctx->run_g_max = std::max(8, std::min((int)RUN_G, atoi(e)));   // (test switch: a smaller device)
+    }
     ctx->head_graphs = getenv("CVO_HIP_RUN_GRAPHS") != nullptr;   // (test switch: captured batches for head-mode plans, cvo_plan.cpp launch_batch)
     // Stream capture is a process-wide affair in this runtime (cvo_lock.h): the library's own
     // entry points keep out of each other's captures, but HIP work of OTHER code in the process

@@ -124,6 +124,7 @@ constexpr int RUN_BLOCK = 512;       // 8 waves = two per SIMD: 256 vector regis
 constexpr int RUN_WAVES = RUN_BLOCK / 64;
 constexpr int RUN_LANES = RUN_G * RUN_BLOCK;
 constexpr int RUN_R = 8;             // candidates per lane in registers: RUN_LANES * RUN_R = 1 015 808 candidates
+constexpr int RUN_MIRROR_ENTERED = 1 << 30;   // in the host's run mirror: the run that reported last carried slots (it did not decline)
 constexpr int RUN_L = 8;             // ... and in LDS behind them (the widest runs only: 2 x 16 bytes per candidate, 128 KB per block)
 constexpr int RUN_CAP = RUN_LANES * (RUN_R + RUN_L);   // candidates a run holds at most: 2 031 616
 constexpr unsigned RUN_LDS_BYTES = (unsigned)RUN_L * 2u * (unsigned)RUN_BLOCK * 16u;   // dynamic LDS of kt_run
@@ -402,6 +403,7 @@ struct PostStepArgs {
     int32_t *run_mirror;   // pinned: DevState::run_count
     int32_t *hint_mirror;  // pinned: DevHead::run_hint (the host picks the next batch's plan by it)
     int run_iters;         // iterations per run at most
+    int run_g_max;         // solver blocks of a run at most (RUN_G on an unpartitioned MI355X; fewer compute units: fewer, cvo_hip_create)
     DevParams prm;
 };
 

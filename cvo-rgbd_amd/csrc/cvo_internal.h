@@ -245,6 +245,7 @@ struct cvo_hip_ctx {
     DevBuf run_mail;                      // RunMail of this registration's resident runs
     bool plan_has_final_mirror = false;   // the plan of the align() in progress publishes its final head to final_mirror
     bool allow_run = true;                // CVO_HIP_NO_RUN
+    int run_g_max = RUN_G;                // solver blocks of a resident run at most: a block per compute unit, a few to spare (cvo_hip_create)
     bool spec_first_run = true;           // the first run of a registration goes out on spec behind its first two slots (job_pump learns from each try)
     bool head_graphs = false;             // CVO_HIP_RUN_GRAPHS: head-mode plans go out as captured batches too (they launch eagerly by default)
     int run_nnz_max = 0;                  // a batch begins with a resident run when the record in use is expected to hold at most this many candidates

@@ -119,7 +119,7 @@ int job_begin(AlignJob &j)
     // (a batch begins with a resident run when the record in use is expected to hold at most this many candidates -- DevHead::
     // run_hint: the record's count where the last head knew it, else an estimate with 5 % of room; a run that finds more than it can
     // hold declines, which costs its launch and one head)
-    ctx->run_nnz_max = RUN_CAP;
+    ctx->run_nnz_max = ctx->run_g_max * RUN_BLOCK * (RUN_R + RUN_L);
     if (const char *e = getenv("CVO_HIP_RUN_CAND")) ctx->run_nnz_max = atoi(e);   // (tuning switch)
     j.phase = p.max_iter <= 0 ? 1 : 0;
     if (j.phase == 1) {
@@ -205,7 +205,8 @@ int job_pump(AlignJob &j, bool block)
         for (;;) {
             if (*(volatile int32_t *)ctx->done_mirror != RUNNING) break;
             // (the run counter first: a run publishes its slots before it reports its end)
-            const int runs = *(volatile int32_t *)ctx->run_mirror;
+            const int runs_word = *(volatile int32_t *)ctx->run_mirror;
+            const int runs = runs_word & (RUN_MIRROR_ENTERED - 1);
             const int slots = *(volatile int32_t *)ctx->progress_mirror;
             // (head mode without a flush: the post-step part of a batch's last slot runs in the head of the NEXT
             // batch's first launch, so the next batch must be on its way before the running one ends -- it goes
@@ -219,7 +220,7 @@ int job_pump(AlignJob &j, bool block)
                 go = runs >= j.runs_enq;
                 if (go) {
                     // (the run that was sent on spec behind the first two slots: did it carry slots, or decline?)
-                    if (j.spec_pending) { ctx->spec_first_run = slots > kShortBatch; j.spec_pending = false; }
+                    if (j.spec_pending) { ctx->spec_first_run = (runs_word & RUN_MIRROR_ENTERED) != 0; j.spec_pending = false; }
                     j.enq = slots + kRunBatchSlots; j.run_waiting = false;
                 }
             } else {
@@ -261,7 +262,7 @@ int job_pump(AlignJob &j, bool block)
                         if (q != hipSuccess && q != hipErrorNotReady)
                             return finish_with(fail(ctx, CVO_HIP_ERR_HIP, "the stream of the align loop reports an error"));
                         if (q == hipSuccess && *(volatile int32_t *)ctx->done_mirror == RUNNING &&
-                            *(volatile int32_t *)ctx->progress_mirror == slots && *(volatile int32_t *)ctx->run_mirror == runs) {
+                            *(volatile int32_t *)ctx->progress_mirror == slots && *(volatile int32_t *)ctx->run_mirror == runs_word) {
                             if (++j.idle_seen >= 2)
                                 return finish_with(fail(ctx, CVO_HIP_ERR_HIP, "the align loop's stream went idle without progress"));
                         } else {
@@ -283,7 +284,7 @@ int job_pump(AlignJob &j, bool block)
                     // idle, yet the batch has not reported all its slots and nothing stopped: seen twice in a row
                     // (the mirrors are written before a kernel ends, so once is already conclusive; twice is cheap)
                     if (q == hipSuccess && *(volatile int32_t *)ctx->done_mirror == RUNNING &&
-                        *(volatile int32_t *)ctx->progress_mirror == slots && *(volatile int32_t *)ctx->run_mirror == runs) {
+                        *(volatile int32_t *)ctx->progress_mirror == slots && *(volatile int32_t *)ctx->run_mirror == runs_word) {
                         if (++idle_seen >= 2)
                             return finish_with(fail(ctx, CVO_HIP_ERR_HIP, "the align loop's stream went idle without progress"));
                     } else {

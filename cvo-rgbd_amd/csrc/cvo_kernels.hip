@@ -2937,11 +2937,13 @@ kt_run(const Slot *__restrict__ tab, const int qs)
     // the head block alone tells the host that this run is over (whatever way it ends)
     // (not once the loop has stopped: the host leaves on the `done` word, which went out before, and may have begun the next
     // registration -- and reset this mirror -- by now)
+    // (the mirror's word: the count, and RUN_MIRROR_ENTERED if this run carried slots)
+    bool entered = false;
     auto run_over = [&]() {
         if (head_block && tid == 0) {
             const int c = gst->run_count + 1;
             gst->run_count = c;
-            if (ps.run_mirror && s_st.done == RUNNING) *ps.run_mirror = c;
+            if (ps.run_mirror && s_st.done == RUNNING) *ps.run_mirror = c | (entered ? RUN_MIRROR_ENTERED : 0);
         }
     };
     // what would make this launch a plain head-mode flow launch's business: a loop that has stopped, a stall slot,
@@ -3029,8 +3031,11 @@ kt_run(const Slot *__restrict__ tab, const int qs)
     // (2.3 / 2.9 / 3.9 us among 64 / 128 / 256) and a candidate per lane costs ~0.45 us of the two passes: up to three per lane, then the
     // next size, the whole GPU for the widest records
     const unsigned per = (unsigned)RUN_BLOCK;
-    const int g = total <= 8u * per ? 8 : (total <= 16u * per ? 16 : (total <= 3u * 32u * per ? 32 :
-                  (total <= 3u * 64u * per ? 64 : (total <= 3u * 128u * per ? 128 : RUN_G))));
+    const int gmax = ps.run_g_max >= 8 && ps.run_g_max <= RUN_G ? ps.run_g_max : RUN_G;   // (fewer compute units: smaller runs)
+    const int gwant = total <= 8u * per ? 8 : (total <= 16u * per ? 16 : (total <= 3u * 32u * per ? 32 :
+                      (total <= 3u * 64u * per ? 64 : (total <= 3u * 128u * per ? 128 : RUN_G))));
+    const int g = gwant < gmax ? gwant : gmax;
+    if (total > (unsigned)g * per * (unsigned)(RUN_R + RUN_L)) { run_over(); return; }   // (block-uniform; nothing has been written)
     if (srow >= g) return;
     if (g > RUN_G_SMALL) {
         // ---- entry handshake of a large run (RunMail::entry_ticket): nothing is written before all of it is known to be resident
@@ -3061,6 +3066,7 @@ kt_run(const Slot *__restrict__ tab, const int qs)
         __syncthreads();
     }
     const unsigned lanes = (unsigned)g * RUN_BLOCK;
+    entered = true;   // (from here on the run executes at least one slot)
 
     // ---- the candidates of this lane: c = l + r * lanes
     const unsigned wave_first = head_block ? total : (unsigned)srow * RUN_BLOCK + (unsigned)wid * 64u;   // flat number of the wave's first candidate of round 0

@@ -463,7 +463,7 @@ DevParams loop_params(const cvo_hip_ctx *ctx)
     // wide while its record still fits, plan_xy_async)
     if (ctx->use_async && ctx->lone && ctx->allow_head && ctx->allow_run && !multi_rank(ctx) && ctx->prm.mode == CVO_HIP_MODE_CVO &&
         !(ctx->prm.color_scale > 0.0f) && !ctx->post_dbg && ctx->allow_merge && ctx->fixed.np <= 65536 && ctx->moving.np <= 65536 && !env_no_cand())
-        dp.run_cand_cap = (float)RUN_CAP;
+        dp.run_cand_cap = (float)ctx->run_g_max * (float)(RUN_BLOCK * (RUN_R + RUN_L));
     return dp;
 }
 
@@ -599,6 +599,7 @@ int enqueue_step(cvo_hip_ctx *ctx, int check_done, bool do_math, cvo_hip_trace *
             pa.run_mail = (RunMail *)ctx->run_mail.p;
             pa.run_mirror = ctx->run_mirror;
             pa.run_iters = 64;
+            pa.run_g_max = ctx->run_g_max;
         } else {   // (an optimisation: without its memory the plan has no runs)
             (void)hipGetLastError();
             ctx->err = "";

@@ -1191,3 +1191,30 @@ def test_final_state_from_the_pinned_copy_is_whole(pkg, monkeypatch):
         for b, pr in enumerate(pairs):
             assert once(pr) == ref[b], b
     assert capi.mirror_retries() - before < 48 * 50   # (a late piece costs a few re-reads; a word that never matched ~700 each)
+
+
+def test_runs_sized_for_a_smaller_device_change_nothing(pkg, monkeypatch):
+    """A resident run needs all its blocks resident at once, one per compute unit: a context sizes its runs by the device's
+    compute units (cvo_hip_create; RUN_G = 248 solver blocks on an unpartitioned MI355X).  CVO_HIP_RUN_G_MAX stands in for a
+    device with fewer: records that no longer fit are left to the launch-per-pass path, the others run on fewer, fuller blocks --
+    same iterations, same state."""
+    capi = pkg.capi
+    xf, ff, xm, fm = pkg.data.synthetic_pair(6000, 6000, seed=515)
+
+    def once():
+        c = capi.Context(mode=capi.MODE_CVO, device=0)
+        c.set_fixed(xf, ff); c.set_moving(xm, fm)
+        st = capi.init_state(c.params)
+        it, _ = c.align(st, trace_cap=0)
+        rs = c.run_stats()
+        c.close()
+        return (it, bytes(st)), rs
+
+    ref, rs_ref = once()
+    assert rs_ref[0] >= 2
+    for gmax in ("100", "24", "8"):
+        monkeypatch.setenv("CVO_HIP_RUN_G_MAX", gmax)
+        got, rs = once()
+        assert got == ref, gmax
+        assert rs[0] >= 1, (gmax, rs)   # (the narrow records still fit)
+    monkeypatch.delenv("CVO_HIP_RUN_G_MAX")

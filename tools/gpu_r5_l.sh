@@ -1,6 +1,5 @@
 #!/bin/bash
 cd ${GRAFT_REPO_ROOT:-.}
-MAX_ITER=11 CVO_LIB=libcvo_hip_clk.so python tools/gpu_run_clocks.py 10000 2>&1 | grep -v "^RCCL\|^HIP\|^ROCm" | cut -c1-260
-CVO_LIB=libcvo_hip_clk.so python tools/gpu_run_clocks.py 3000 2>&1 | grep -v "^RCCL\|^HIP\|^ROCm" | cut -c1-260
-python tools/gpu_r5_run_check.py 3000 10000 2>&1 | tail -9
-for i in 1 2; do SEEDS=20190402 python tools/gpu_single_rate.py 3000 6000 10000 2>&1 | grep "^n "; done
+python -m pytest tests -m gpu -x -q > gpurun_out/pytest_gpu.log 2>&1
+grep -v "^RCCL\|^HIP\|^ROCm\|^Hostname\|^Librccl" gpurun_out/pytest_gpu.log | tail -4
+python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
