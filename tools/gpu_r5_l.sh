@@ -1,5 +1,10 @@
 #!/bin/bash
 cd ${GRAFT_REPO_ROOT:-.}
-python -m pytest tests -m gpu -x -q > gpurun_out/pytest_gpu.log 2>&1
-grep -v "^RCCL\|^HIP\|^ROCm\|^Hostname\|^Librccl" gpurun_out/pytest_gpu.log | tail -4
-python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
+for sh in 22 16 12 8 22 18 14; do
+  echo "-- CVO_HIP_ENGINE_SHARE=$sh"
+  CVO_HIP_ENGINE_SHARE=$sh DISTINCT=1 timeout 300 python tools/gpu_batch.py 10000 8 64 2>&1 | grep "^B " | cut -c1-120
+done
+for e in 2 4; do for sh in 16 11; do
+  echo "-- engines $e share $sh"
+  CVO_HIP_ENGINES_FORCE=$e CVO_HIP_ENGINE_SHARE=$sh DISTINCT=1 timeout 300 python tools/gpu_batch.py 10000 8 64 2>&1 | grep "^B " | cut -c1-120
+done; done
