@@ -400,8 +400,10 @@ int job_pump(AlignJob &j, bool block)
     *ctx->done_mirror = 0;   // (the stream is idle: nothing can be writing it)
     *ctx->progress_mirror = 0;
     *ctx->run_mirror = 0;
+    *ctx->hint_mirror = -1;
     j.runs_enq = 0;
     j.run_waiting = false;
+    j.spec_pending = false;
     if (hipMemset(reinterpret_cast<char *>(ctx->st) + offsetof(DevState, n_slots), 0, sizeof(int32_t)) != hipSuccess ||
         hipMemset(reinterpret_cast<char *>(ctx->st) + offsetof(DevState, run_count), 0, sizeof(int32_t)) != hipSuccess ||
         hipDeviceSynchronize() != hipSuccess)
