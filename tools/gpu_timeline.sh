@@ -10,8 +10,8 @@ import os, sys
 sys.path.insert(0, "$PWD")
 import torch, __graft_entry__ as ge
 pkg = ge.load_package(); capi = pkg.capi
-xf, ff, xm, fm = pkg.data.synthetic_pair($N, $N, seed=pkg.data.SEED_CFG2)
-c = capi.Context(mode=capi.MODE_CVO, device=0)
+xf, ff, xm, fm = pkg.data.synthetic_pair($N, $N, seed=pkg.data.SEED_CFG2, acvo=bool(os.environ.get("ACVO")))
+c = capi.Context(mode=capi.MODE_ACVO if os.environ.get("ACVO") else capi.MODE_CVO, device=0)
 c.set_fixed(xf, ff); c.set_moving(xm, fm)
 for _ in range(6):
     st = capi.init_state(c.params); n_it, _ = c.align(st, trace_cap=0)
