@@ -769,7 +769,15 @@ CVO_HD void prepare_iteration(DevHead *s, DevHead *bulk, const bool store, const
 }
 
 size_t filter_smem_bytes(int jt);
-void launch_prepare(DevState *st, const DevParams &prm, hipStream_t s, uint32_t *build_masks = nullptr);
+// What the state of a registration that begins holds besides zeros (cvo_job.cpp job_begin): handed to the prepare kernel by value, which
+// zeroes the state and sets these -- one stream operation instead of a host-to-device copy and a kernel.
+struct PrepareInit {
+    int32_t on;          // 0: the state is in place already (a resumption after a list grew)
+    float R[9], T[3], ell, ell_max;
+    int32_t iter, n_fixed, done;
+    float center[3], xmax, y0max;
+};
+void launch_prepare(DevState *st, const DevParams &prm, hipStream_t s, uint32_t *build_masks = nullptr, const PrepareInit *init = nullptr);
 void launch_filter(const FilterArgs &a, dim3 grid, hipStream_t s, hipEvent_t ev_start = nullptr,
                    hipEvent_t ev_stop = nullptr);
 void launch_process(int mode, const ProcessArgs &a, hipStream_t s, hipEvent_t ev_start = nullptr,

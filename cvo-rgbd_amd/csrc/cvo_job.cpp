@@ -82,25 +82,27 @@ int job_begin(AlignJob &j)
     if (j.trace_cap > 0)
         HIP_TRY(ctx, hipMemsetAsync(ctx->trace_dev, 0, (size_t)j.trace_cap * sizeof(cvo_hip_trace),
                                     loop_stream(ctx)));
-    // initial device state
-    DevState *h = &ctx->st_host[kPollSlots];
-    std::memset(h, 0, sizeof(*h));
-    std::memcpy(h->R, s->R, sizeof(h->R));
-    std::memcpy(h->T, s->T, sizeof(h->T));
-    h->ell = s->ell;
-    h->ell_max = s->ell_max;
-    h->iter = s->iter;
+    // initial device state: zeros but for what the object carries and the filter's geometry -- by value into the prepare kernel
+    PrepareInit in{};
     {
+        DevState *h = &ctx->st_host[kPollSlots];   // (fill_filter_geometry writes a state's head)
         const int rcg = fill_filter_geometry(ctx, h);
         if (rcg) return rcg;
+        in.on = 1;
+        std::memcpy(in.R, s->R, sizeof(in.R));
+        std::memcpy(in.T, s->T, sizeof(in.T));
+        in.ell = s->ell;
+        in.ell_max = s->ell_max;
+        in.iter = s->iter;
+        in.n_fixed = h->n_fixed;
+        for (int q = 0; q < 3; ++q) in.center[q] = h->center[q];
+        in.xmax = h->xmax; in.y0max = h->y0max;
+        in.done = p.max_iter <= 0 ? DONE_MAX_ITER : RUNNING;
     }
-    if (p.max_iter <= 0) h->done = DONE_MAX_ITER;
-    // (everything but the mailbox sequence number, which lives as long as the context)
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->st, h, DEVSTATE_INIT_BYTES, hipMemcpyHostToDevice, loop_stream(ctx)));
     decide_scheme(ctx);
     // (a member of a fused group: the group's table, armed by its insert; on its own: this context's table, whose build masks the
     // prepare kernel sets -- it exists from the first align() on, and its first use arms it anyway)
-    launch_prepare(ctx->st, loop_params(ctx), loop_stream(ctx), (!j.in_group && ctx->table.raw) ? ctx->table.masks() : nullptr);
+    launch_prepare(ctx->st, loop_params(ctx), loop_stream(ctx), (!j.in_group && ctx->table.raw) ? ctx->table.masks() : nullptr, &in);
     HIP_TRY(ctx, hipGetLastError());
     ctx->have_tf = true;
     const int prc = prepare_buffers(ctx);

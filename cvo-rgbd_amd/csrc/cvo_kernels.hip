@@ -2271,8 +2271,22 @@ __global__ void __launch_bounds__(BLOCK) k_post_step(const Grp<PostStepArgs> grp
 
 // First iteration of an align() (or of its resumption after a list grew): no
 // list is valid, everything is rebuilt.
-__global__ void k_prepare(DevState *st, const DevParams prm, uint32_t *build_masks)
+__global__ void k_prepare(DevState *st, const DevParams prm, uint32_t *build_masks, const PrepareInit init)
 {
+    if (init.on) {   // a registration begins: zeros but for what the caller carries (everything in front of the mailbox sequence number)
+        static_assert(DEVSTATE_INIT_BYTES % 4 == 0, "word stores");
+        uint32_t *z = reinterpret_cast<uint32_t *>(st);
+        for (int q = threadIdx.x; q < (int)(DEVSTATE_INIT_BYTES / 4); q += BLOCK) z[q] = 0u;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (int q = 0; q < 9; ++q) st->R[q] = init.R[q];
+            for (int q = 0; q < 3; ++q) { st->T[q] = init.T[q]; st->center[q] = init.center[q]; }
+            st->ell = init.ell; st->ell_max = init.ell_max;
+            st->iter = init.iter; st->n_fixed = init.n_fixed; st->done = init.done;
+            st->xmax = init.xmax; st->y0max = init.y0max;
+        }
+        __syncthreads();
+    }
     // (a registration begins in this table: every list is to be built, the build masks' bits of every slot go up -- kt_filter)
     if (build_masks && threadIdx.x < 4) build_masks[threadIdx.x] = 0xffffffffu;
     for (int q = threadIdx.x; q < LIST_N * NSUB; q += BLOCK) (&st->sub[0][0])[q] = 0u;
@@ -2300,9 +2314,11 @@ __global__ void k_prepare(DevState *st, const DevParams prm, uint32_t *build_mas
     }
 }
 
-void launch_prepare(DevState *st, const DevParams &prm, hipStream_t s, uint32_t *build_masks)
+void launch_prepare(DevState *st, const DevParams &prm, hipStream_t s, uint32_t *build_masks, const PrepareInit *init)
 {
-    hipLaunchKernelGGL(k_prepare, dim3(1), dim3(BLOCK), 0, s, st, prm, build_masks);
+    PrepareInit in{};
+    if (init) in = *init;
+    hipLaunchKernelGGL(k_prepare, dim3(1), dim3(BLOCK), 0, s, st, prm, build_masks, in);
 }
 
 void launch_post_flow_group(const PostFlowArgs *a, int n, hipStream_t s)

@@ -1,10 +1,7 @@
 #!/bin/bash
 cd ${GRAFT_REPO_ROOT:-.}
-for sh in 22 16 12 8 22 18 14; do
-  echo "-- CVO_HIP_ENGINE_SHARE=$sh"
-  CVO_HIP_ENGINE_SHARE=$sh DISTINCT=1 timeout 300 python tools/gpu_batch.py 10000 8 64 2>&1 | grep "^B " | cut -c1-120
-done
-for e in 2 4; do for sh in 16 11; do
-  echo "-- engines $e share $sh"
-  CVO_HIP_ENGINES_FORCE=$e CVO_HIP_ENGINE_SHARE=$sh DISTINCT=1 timeout 300 python tools/gpu_batch.py 10000 8 64 2>&1 | grep "^B " | cut -c1-120
-done; done
+python -m pytest tests -m gpu -x -q > gpurun_out/pytest_gpu.log 2>&1
+grep -v "^RCCL\|^HIP\|^ROCm\|^Hostname\|^Librccl" gpurun_out/pytest_gpu.log | tail -4
+SEEDS=20190402 REPS=100 python tools/gpu_single_rate.py 3000 6000 10000 2>&1 | grep "^n " | cut -c1-150
+ACVO=1 SEEDS=20190402 REPS=100 python tools/gpu_single_rate.py 3000 2>&1 | grep "^n " | cut -c1-150
+DISTINCT=1 timeout 300 python tools/gpu_batch.py 10000 8 64 2>&1 | grep "^B " | cut -c1-120
