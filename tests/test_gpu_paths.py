@@ -1044,14 +1044,15 @@ def test_batched_hand_over_then_align_many(pkg):
         c.close()
 
 
-@pytest.mark.parametrize("n,m", [(3000, 3000), (2300, 2700), (6000, 6000)])
+@pytest.mark.parametrize("n,m", [(3000, 3000), (2300, 2700), (6000, 6000), (10000, 10000)])
 def test_resident_runs_change_nothing(pkg, po, monkeypatch, n, m):
     """Resident runs (csrc/cvo_kernels.hip kt_run: the narrow part of one cvo registration -- ref src/cvo.cpp:366-410 -- as whole
     iterations inside one launch, candidates in registers, partial sums exchanged among the blocks, a head block planning beside
     the solvers) against the same library without them (CVO_HIP_NO_RUN, read when a context is created): runs are entered, and
     iteration count, final state and the float32 trace are identical, the float64 sums equal to 1e-11 -- with and without captured
     batches, with and without a trace, from a far start (jumps: stall verdicts), stopped by max_iter inside a run, with lists
-    rebuilt every iteration (no run can start) and with tiny lists that grow; and equal to the oracle."""
+    rebuilt every iteration (no run can start) and with tiny lists that grow; and equal to the oracle.  (10k x 10k: the first run holds
+    1.8 million candidates -- eight per lane in registers, the rest in LDS -- on 248 solver blocks, sent on spec behind the first two slots.)"""
     import torch
     capi = pkg.capi
     xf, ff, xm, fm = pkg.data.synthetic_pair(n, m, seed=4242 + n)
