@@ -124,6 +124,7 @@ constexpr int RUN_BLOCK = 512;       // 8 waves = two per SIMD: 256 vector regis
 constexpr int RUN_WAVES = RUN_BLOCK / 64;
 constexpr int RUN_LANES = RUN_G * RUN_BLOCK;
 constexpr int RUN_R = 8;             // candidates per lane in registers: RUN_LANES * RUN_R = 1 015 808 candidates
+constexpr int RUN_MIRROR_ABORTED = 1 << 29;   // ... the run that reported last gave up at its entry hand-shake: something else held the compute units
 constexpr int RUN_MIRROR_ENTERED = 1 << 30;   // in the host's run mirror: the run that reported last carried slots (it did not decline)
 constexpr int RUN_L = 8;             // ... and in LDS behind them (the widest runs only: 2 x 16 bytes per candidate, 128 KB per block)
 constexpr int RUN_CAP = RUN_LANES * (RUN_R + RUN_L);   // candidates a run holds at most: 2 031 616

@@ -246,6 +246,7 @@ struct cvo_hip_ctx {
     bool plan_has_final_mirror = false;   // the plan of the align() in progress publishes its final head to final_mirror
     bool allow_run = true;                // CVO_HIP_NO_RUN
     int run_g_max = RUN_G;                // solver blocks of a resident run at most: a block per compute unit, a few to spare (cvo_hip_create)
+    int big_run_backoff = 0;              // registrations to go without runs of more than 32 solvers (one gave up at its entry hand-shake, job_pump)
     bool spec_first_run = true;           // the first run of a registration goes out on spec behind its first two slots (job_pump learns from each try)
     bool head_graphs = false;             // CVO_HIP_RUN_GRAPHS: head-mode plans go out as captured batches too (they launch eagerly by default)
     int run_nnz_max = 0;                  // a batch begins with a resident run when the record in use is expected to hold at most this many candidates
@@ -393,6 +394,7 @@ int run_plan(const Slot *tab, PlanCache &cache, const std::vector<TLaunch> &plan
 int record_iteration(cvo_hip_ctx *ctx, std::vector<RecOp> &ops, int trace_cap);
 int prepare_lone_plan(cvo_hip_ctx *ctx, int trace_cap);
 int launch_batch(cvo_hip_ctx *ctx, int tag0, int trace_cap, bool with_run = false, int slots = kBatch);
+constexpr int kBigRunBackoff = 16;   // registrations a context keeps its large runs away after one of them found the compute units taken
 constexpr int kShortBatch = 2;      // classic slots of a batch of a plan that has a resident run (job_pump; an even number, see kBatch)
 constexpr int kRunBatchSlots = 2;   // classic slots behind the resident run of a RUN batch (an even number, see kBatch)
 int zero_counters(cvo_hip_ctx *ctx);

@@ -122,6 +122,7 @@ int job_begin(AlignJob &j)
     // run_hint: the record's count where the last head knew it, else an estimate with 5 % of room; a run that finds more than it can
     // hold declines, which costs its launch and one head)
     ctx->run_nnz_max = ctx->run_g_max * RUN_BLOCK * (RUN_R + RUN_L);
+    if (ctx->big_run_backoff > 0) --ctx->big_run_backoff;
     if (const char *e = getenv("CVO_HIP_RUN_CAND")) ctx->run_nnz_max = atoi(e);   // (tuning switch)
     j.phase = p.max_iter <= 0 ? 1 : 0;
     if (j.phase == 1) {
@@ -208,7 +209,7 @@ int job_pump(AlignJob &j, bool block)
             if (*(volatile int32_t *)ctx->done_mirror != RUNNING) break;
             // (the run counter first: a run publishes its slots before it reports its end)
             const int runs_word = *(volatile int32_t *)ctx->run_mirror;
-            const int runs = runs_word & (RUN_MIRROR_ENTERED - 1);
+            const int runs = runs_word & (RUN_MIRROR_ABORTED - 1);
             const int slots = *(volatile int32_t *)ctx->progress_mirror;
             // (head mode without a flush: the post-step part of a batch's last slot runs in the head of the NEXT
             // batch's first launch, so the next batch must be on its way before the running one ends -- it goes
@@ -222,7 +223,11 @@ int job_pump(AlignJob &j, bool block)
                 go = runs >= j.runs_enq;
                 if (go) {
                     // (the run that was sent on spec behind the first two slots: did it carry slots, or decline?)
-                    if (j.spec_pending) { ctx->spec_first_run = (runs_word & RUN_MIRROR_ENTERED) != 0; j.spec_pending = false; }
+                    // (a run that gave up at its entry hand-shake: something else -- another thread's registration, most likely -- holds
+                    // the compute units.  Runs of more than 32 solvers stay away for the next registrations: each try costs its 200 us wait)
+                    if (runs_word & RUN_MIRROR_ABORTED) ctx->big_run_backoff = kBigRunBackoff;
+                    else if (j.spec_pending) ctx->spec_first_run = (runs_word & RUN_MIRROR_ENTERED) != 0;
+                    j.spec_pending = false;
                     j.enq = slots + kRunBatchSlots; j.run_waiting = false;
                 }
             } else {
@@ -239,9 +244,10 @@ int job_pump(AlignJob &j, bool block)
                 const bool run_plan_ = ctx->head_mode && !ctx->plan_pre.empty();
                 const bool first_choice = run_plan_ && j.batches == 1 && j.enq == kShortBatch && j.runs_enq == 0;
                 if (run_plan_ && j.batches == 2 && j.runs_enq == 0 && !ctx->spec_first_run && hint > 0) ctx->spec_first_run = hint <= ctx->run_nnz_max;
-                const bool spec = first_choice && ctx->spec_first_run;
+                const bool big_ok = ctx->big_run_backoff <= 0;   // (see above)
+                const bool spec = first_choice && ctx->spec_first_run && big_ok;
                 if (spec) j.spec_pending = true;
-                const bool with_run = run_plan_ && (spec || (hint > 0 && hint <= ctx->run_nnz_max));
+                const bool with_run = run_plan_ && (spec || (hint > 0 && hint <= (big_ok ? ctx->run_nnz_max : 3 * RUN_G_SMALL * RUN_BLOCK)));
                 // (a plan with runs is launched eagerly and in the shortest batches: a run can only start at a batch's head, and the
                 // slot it may start at is two or three slots after the head that first says so)
                 const bool near_run = ctx->head_mode && !ctx->plan_pre.empty() && !with_run;

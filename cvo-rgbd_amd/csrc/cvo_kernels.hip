@@ -2954,12 +2954,12 @@ kt_run(const Slot *__restrict__ tab, const int qs)
     // (not once the loop has stopped: the host leaves on the `done` word, which went out before, and may have begun the next
     // registration -- and reset this mirror -- by now)
     // (the mirror's word: the count, and RUN_MIRROR_ENTERED if this run carried slots)
-    bool entered = false;
+    bool entered = false, aborted = false;
     auto run_over = [&]() {
         if (head_block && tid == 0) {
             const int c = gst->run_count + 1;
             gst->run_count = c;
-            if (ps.run_mirror && s_st.done == RUNNING) *ps.run_mirror = c | (entered ? RUN_MIRROR_ENTERED : 0);
+            if (ps.run_mirror && s_st.done == RUNNING) *ps.run_mirror = c | (entered ? RUN_MIRROR_ENTERED : 0) | (aborted ? RUN_MIRROR_ABORTED : 0);
         }
     };
     // what would make this launch a plain head-mode flow launch's business: a loop that has stopped, a stall slot,
@@ -3078,7 +3078,7 @@ kt_run(const Slot *__restrict__ tab, const int qs)
             s_verdict = go;
         }
         __syncthreads();
-        if (s_verdict != RUN_GO) { run_over(); return; }
+        if (s_verdict != RUN_GO) { aborted = true; run_over(); return; }
         __syncthreads();
     }
     const unsigned lanes = (unsigned)g * RUN_BLOCK;
