@@ -15,6 +15,8 @@ namespace cvo_impl {
 // the launches at the next poll.
 bool fusable(const cvo_hip_ctx *c) { return !c->profiling && !multi_rank(c) && !(c->prm.color_scale > 0.0f); }
 
+
+
 // Engine profiling (cvo_hip_engine_profiling): while it is on, the engines launch eagerly and every
 // flow-pass launch (kt_process<PROC_FLOW>, the kernel with the largest share of a batched run)
 // carries a HIP event pair; the sums are read with cvo_hip_get_engine_profile.
@@ -33,6 +35,29 @@ EngineProfile *engine_profile()
 {
     static EngineProfile *p = new EngineProfile;
     return p;
+}
+
+// A FEW cvo registrations on small clouds are faster each on its own stream than sharing an engine's launches (round 5): on
+// its own a registration runs most of its iterations inside resident runs (kt_run: ~10 us per iteration on a few dozen compute
+// units when the clouds are small, several of them side by side), in a group of two or four an iteration is a chain of four or
+// five dependent launches (~40 us) whatever its members need.  Registrations per second, engines / on their own (one MI355X,
+// distinct pairs, profiles/r05_ab.txt 22): 3k x 3k 2 / 4 / 8 / 12 / 16 / 24 per call 1 027 / 1 113 / 1 832 / 2 697 / 2 823 / 4 578 against
+// 2 316 / 1 914 / 2 896 / 2 901 / 2 866 / -; 6k x 6k 2 / 4 / 8 / 12 754 / 1 378 / 1 723 / 2 325 against 1 428 / 1 686 / 2 289 / 2 094;
+// 10k x 10k 2 / 3 / 4 591 / 824 / 987 against 722 / 735 / 774.
+bool better_alone(const std::deque<AlignJob *> &pending)
+{
+    const bool off = getenv("CVO_HIP_NO_ALONE") != nullptr;   // (test switch, read per call: small calls through the engines as before)
+    if (off || engine_profile()->on) return false;   // (... or the caller is measuring the engines: cvo_hip_engine_profiling)
+    double pairs = 0.0;
+    for (const AlignJob *j : pending) {
+        const cvo_hip_ctx *c = j->ctx;
+        if (c->prm.mode != CVO_HIP_MODE_CVO || !c->allow_run || !c->allow_head || !c->allow_async || !c->allow_merge || env_no_cand() ||
+            c->fixed.np > 65536 || c->moving.np > 65536)
+            return false;
+        pairs = std::max(pairs, (double)c->fixed.n * (double)c->moving.n);
+    }
+    const size_t few = pairs <= 1.6e7 ? 16 : (pairs <= 5.0e7 ? 8 : (pairs <= 1.2e8 ? 2 : 0));
+    return pending.size() <= few;
 }
 
 // A fused group as a long-lived engine: a stream, a table of ENGINE_SLOTS slots and the batches
@@ -474,6 +499,7 @@ int cvo_hip_align_many(cvo_hip_ctx **ctxs, cvo_hip_state **states, int *n_iters,
                     jobs[k].ctx->prm.mode == jobs[i].ctx->prm.mode)
                     pending.push_back(&jobs[k]);
             if (pending.size() < 2) continue;
+            if (better_alone(pending)) continue;   // (they run on their own below, resident runs and all)
             for (AlignJob *j : pending) taken[j - &jobs[0]] = 1;
             const size_t total = pending.size();
             // how many engines share the GPU: one group alone leaves it idle in its single-block post

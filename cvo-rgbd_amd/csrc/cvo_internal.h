@@ -393,7 +393,7 @@ int run_plan(const Slot *tab, PlanCache &cache, const std::vector<TLaunch> &plan
              const std::vector<TLaunch> *pre = nullptr);
 int record_iteration(cvo_hip_ctx *ctx, std::vector<RecOp> &ops, int trace_cap);
 int prepare_lone_plan(cvo_hip_ctx *ctx, int trace_cap);
-int launch_batch(cvo_hip_ctx *ctx, int tag0, int trace_cap, bool with_run = false, int slots = kBatch);
+int launch_batch(cvo_hip_ctx *ctx, int tag0, int trace_cap, bool with_run = false, int slots = kBatch, bool small_run = false);
 constexpr int kBigRunBackoff = 16;   // registrations a context keeps its large runs away after one of them found the compute units taken
 constexpr int kShortBatch = 2;      // classic slots of a batch of a plan that has a resident run (job_pump; an even number, see kBatch)
 constexpr int kRunBatchSlots = 2;   // classic slots behind the resident run of a RUN batch (an even number, see kBatch)

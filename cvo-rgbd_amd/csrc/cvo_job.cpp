@@ -251,7 +251,8 @@ int job_pump(AlignJob &j, bool block)
                 // (a plan with runs is launched eagerly and in the shortest batches: a run can only start at a batch's head, and the
                 // slot it may start at is two or three slots after the head that first says so)
                 const bool near_run = ctx->head_mode && !ctx->plan_pre.empty() && !with_run;
-                const int rc = launch_batch(ctx, j.executed_base + j.enq, j.trace_cap, with_run, near_run ? kShortBatch : kBatch);
+                const bool small_run = with_run && !spec && hint > 0 && hint <= 3 * RUN_G_SMALL * RUN_BLOCK;   // (a launch of 33 blocks does)
+                const int rc = launch_batch(ctx, j.executed_base + j.enq, j.trace_cap, with_run, near_run ? kShortBatch : kBatch, small_run);
                 if (rc) return finish_with(rc);
                 if (with_run) { ++j.runs_enq; j.run_waiting = true; }
                 else j.enq += near_run ? kShortBatch : kBatch;

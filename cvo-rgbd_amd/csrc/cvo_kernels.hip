@@ -2896,7 +2896,10 @@ kt_run(const Slot *__restrict__ tab, const int qs)
     {
         RunMail *const m0 = CVO_ARG(PostStepArgs, op[qs & 15].ps).run_mail;
         if (m0 == nullptr) return;
-        if (threadIdx.x == 0) s_ticket = __hip_atomic_fetch_add(&m0->entry_ticket, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // (a launch adds 1 + RUN_G in all whatever its grid -- block 0 of a launch of fewer blocks draws the difference as well --, so
+        // that ticket / (1 + RUN_G) numbers the launches)
+        const unsigned long long draw = blockIdx.x == 0 ? (unsigned long long)(1 + RUN_G) - (unsigned long long)(gridDim.x - 1u) : 1ull;
+        if (threadIdx.x == 0) s_ticket = __hip_atomic_fetch_add(&m0->entry_ticket, draw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     const int qf = qs & 15, qt = (qs >> 4) & 15;
     const ProcessArgs &pa = CVO_ARG(ProcessArgs, op[qf].p);     // the flow pass of the plan's classic launches
@@ -3047,19 +3050,27 @@ kt_run(const Slot *__restrict__ tab, const int qs)
     // (2.3 / 2.9 / 3.9 us among 64 / 128 / 256) and a candidate per lane costs ~0.45 us of the two passes: up to three per lane, then the
     // next size, the whole GPU for the widest records
     const unsigned per = (unsigned)RUN_BLOCK;
-    const int gmax = ps.run_g_max >= 8 && ps.run_g_max <= RUN_G ? ps.run_g_max : RUN_G;   // (fewer compute units: smaller runs)
+    const int gdev = ps.run_g_max >= 8 && ps.run_g_max <= RUN_G ? ps.run_g_max : RUN_G;   // (fewer compute units: smaller runs)
+    const int gmax = gdev < (int)gridDim.x - 1 ? gdev : (int)gridDim.x - 1;                // (a launch for a narrow record brings fewer blocks)
     const int gwant = total <= 8u * per ? 8 : (total <= 16u * per ? 16 : (total <= 3u * 32u * per ? 32 :
                       (total <= 3u * 64u * per ? 64 : (total <= 3u * 128u * per ? 128 : RUN_G))));
     const int g = gwant < gmax ? gwant : gmax;
     if (total > (unsigned)g * per * (unsigned)(RUN_R + RUN_L)) { run_over(); return; }   // (block-uniform; nothing has been written)
     if (srow >= g) return;
-    if (g > RUN_G_SMALL) {
-        // ---- entry handshake of a large run (RunMail::entry_ticket): nothing is written before all of it is known to be resident
-        const unsigned long long nb = gridDim.x, launch = s_ticket / nb, base = launch * nb;
+    {
+        // ---- entry hand-shake (RunMail::entry_ticket): nothing is written before all of the run is known to be resident.  Every run,
+        // the small ones too: a block takes a whole compute unit (256 registers per lane, 150 KB of LDS) and spins for its peers, so
+        // runs of several registrations -- host threads, processes, the few registrations of a small cvo_hip_align_many call -- whose
+        // blocks together outnumber the compute units would keep each other's missing blocks off the GPU for ever (seen: two
+        // processes x eight 3k registrations, every exchange timing out after its second)
+        const unsigned long long nb = 1ull + RUN_G, launch = s_ticket / nb, base = launch * nb;   // (nb: what every launch draws in all)
         if (head_block && tid == 0) {
             const long long t0 = (long long)wall_clock64();
             unsigned go = RUN_GO;
-            while (__hip_atomic_load(&ps.run_mail->entry_ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < base + (unsigned long long)g + 1ull) {
+            // (ALL blocks of the launch, not the g + 1 that take part: blocks are dealt to the eight XCDs in turn and each XCD starts
+            // its share when it has room -- with other spinning kernels about, g + 1 tickets were seen drawn while a solver of
+            // the run had not started; a block that does not take part leaves at once and frees its unit)
+            while (__hip_atomic_load(&ps.run_mail->entry_ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < base + nb) {
                 if ((long long)wall_clock64() - t0 > RUN_ENTRY_TICKS) { go = RUN_ABORT; break; }
                 __builtin_amdgcn_s_sleep(2);
             }
@@ -3431,7 +3442,7 @@ void launch_table(const Slot *tab, const TLaunch &l, hipStream_t s, hipEvent_t e
     case TK_HFLOW_BUILD: hipLaunchKernelGGL(kt_hflow_build_w4, g, dim3(BLOCK), l.smem, s, tab, qp); break;
     case TK_HFLOW_BUILD6: hipLaunchKernelGGL(kt_hflow_build6_w4, g, dim3(BLOCK), l.smem, s, tab, qp); break;
     case TK_HSTEP_TWIST: hipLaunchKernelGGL(kt_step_twist, g, dim3(STEP_BLOCK), 0, s, tab, qp); break;
-    case TK_RUN: hipLaunchKernelGGL(kt_run, dim3(run_grid()), dim3(RUN_BLOCK), RUN_LDS_BYTES, s, tab, l.q); break;   // (run_allow_lds first: plan_lone's caller)
+    case TK_RUN: hipLaunchKernelGGL(kt_run, dim3(l.gx), dim3(RUN_BLOCK), RUN_LDS_BYTES, s, tab, l.q); break;   // (run_allow_lds first: plan_lone's caller)
     default: break;
     }
 }

@@ -823,8 +823,10 @@ bool plan_lone(const std::vector<RecOp> &ops, Slot &slot, std::vector<TLaunch> &
             // the trace from the step launch's, which is the next one): candidate records on both buffers, the moving
             // cloud read as it came
             if (head && pre && o.ps.run_mail && flow.cand && flow.cand_b && flow.kept_packed == 1 && flow.tf_a == 0 && flow.tf_b == 1 &&
-                flow.weight == 0 && 4 * flow.nblk <= PROC_WAVES)
+                flow.weight == 0 && 4 * flow.nblk <= PROC_WAVES) {
                 pre->push_back(mk_launch(TK_RUN, q | ((q + 1) << 4), 1u + RUN_G, 1));
+                pre->push_back(mk_launch(TK_RUN, q | ((q + 1) << 4), 1u + RUN_G_SMALL, 1));   // (for a narrow record: launch_batch picks one)
+            }
             ++q;
         } else if (have_flow) {
             slot.op[q].p = flow;
@@ -1105,7 +1107,7 @@ int prepare_lone_plan(cvo_hip_ctx *ctx, int trace_cap)
 // classic by-value launches -- they need their own launches / host calls in between.
 // with_run: a RUN batch -- the plan's resident run, then kRunBatchSlots classic slots (job_pump asks for it when the plan has a
 // run and the registration is narrow enough)
-int launch_batch(cvo_hip_ctx *ctx, int tag0, int trace_cap, bool with_run, int slots)
+int launch_batch(cvo_hip_ctx *ctx, int tag0, int trace_cap, bool with_run, int slots, bool small_run)
 {
     if (ctx->profiling || host_reduce(ctx)) {
         const int rc = enqueue_iterations(ctx, kBatch, tag0, trace_cap);
@@ -1117,7 +1119,11 @@ int launch_batch(cvo_hip_ctx *ctx, int tag0, int trace_cap, bool with_run, int s
     // captured batches cost ~9 us of idle stream (cvo 10k x 10k: three of them, 978 -> 1 003 registrations/s, 3k x 3k 1 190 -> 1 232;
     // acvo 10k 615 -> 635, 3k 815 -> 849: profiles/r05_ab.txt 14, 16).  CVO_HIP_RUN_GRAPHS=1 (read when a context is created) brings the captured batches back.
     const bool graphs = ctx->use_graphs && (!ctx->head_mode || ctx->head_graphs);
-    const int rc = with_run ? run_plan(ctx->table.dev, ctx->plans, ctx->plan, loop_stream(ctx), graphs, kRunBatchSlots, &ctx->plan_pre)
+    // (the run's launch: all blocks, or RUN_G_SMALL + 1 for a record that needs no more -- every block of the launch must have
+    // started before the run begins, kt_run's entry hand-shake)
+    std::vector<TLaunch> front;
+    if (with_run) front.push_back(ctx->plan_pre[(small_run && ctx->plan_pre.size() > 1) ? 1 : 0]);
+    const int rc = with_run ? run_plan(ctx->table.dev, ctx->plans, ctx->plan, loop_stream(ctx), graphs, kRunBatchSlots, &front)
                             : run_plan(ctx->table.dev, ctx->plans, ctx->plan, loop_stream(ctx), graphs, slots);
     if (rc) return fail(ctx, rc, "launching a batch of iterations failed");
     return CVO_HIP_OK;

@@ -1219,3 +1219,52 @@ def test_runs_sized_for_a_smaller_device_change_nothing(pkg, monkeypatch):
         assert got == ref, gmax
         assert rs[0] >= 1, (gmax, rs)   # (the narrow records still fit)
     monkeypatch.delenv("CVO_HIP_RUN_G_MAX")
+
+
+def test_runs_of_many_registrations_share_the_gpu_without_deadlock(pkg):
+    """A block of a resident run takes a whole compute unit and spins for its peers: runs of several registrations (host threads
+    here; processes and the registrations of a small cvo_hip_align_many call likewise) whose blocks together outnumber the
+    compute units must not keep each other's missing blocks off the GPU.  Every run proves at its entry that ALL blocks of its
+    launch have started (kt_run: a block that does not take part leaves at once) or declines.  Twelve threads, each its own
+    pair on its own context: every result as registered alone, no exchange times out."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "gpu_run_collide.py"), "3000", "12", "12"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    assert "12 threads x 12 registrations of 3000 x 3000: 0 mismatches" in r.stdout, r.stdout[-1500:]
+
+
+def test_small_align_many_calls_of_small_clouds_run_on_their_own(pkg, monkeypatch):
+    """A few cvo registrations on small clouds are faster each on its own stream, resident runs and all, than sharing an engine's
+    launches (csrc/cvo_engine.cpp better_alone); CVO_HIP_NO_ALONE sends them through the engines as before.  Same results."""
+    import torch
+    capi = pkg.capi
+    pairs = [pkg.data.synthetic_pair(2600 + 150 * b, 2500 + 100 * b, seed=8800 + b) for b in range(5)]
+
+    def call():
+        cs, ss = [], []
+        for xf, ff, xm, fm in pairs:
+            s = torch.cuda.Stream()
+            c = capi.Context(mode=capi.MODE_CVO, device=0, stream=s.cuda_stream)
+            c.set_fixed(xf, ff); c.set_moving(xm, fm)
+            cs.append(c); ss.append(s)
+        out = None
+        for _ in range(2):
+            states = [capi.init_state(c.params) for c in cs]
+            its = capi.align_many(cs, states)
+            got = [(i, bytes(s)) for i, s in zip(its, states)]
+            assert out is None or got == out
+            out = got
+        stats = [c.run_stats() for c in cs]
+        for c in cs:
+            c.close()
+        return out, stats
+
+    alone, st_alone = call()
+    assert all(s[0] >= 1 for s in st_alone), st_alone        # resident runs were entered
+    monkeypatch.setenv("CVO_HIP_NO_ALONE", "1")
+    fused, st_fused = call()
+    monkeypatch.delenv("CVO_HIP_NO_ALONE")
+    assert alone == fused
