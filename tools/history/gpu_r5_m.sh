@@ -1,3 +1,8 @@
 #!/bin/bash
 cd ${GRAFT_REPO_ROOT:-.}
-python -m pytest tests -m gpu -x -q -k "without_deadlock or run_on_their_own or rehearsal or engine_profiling" 2>&1 | grep -v "^RCCL\|^HIP\|^ROCm\|^Hostname\|^Librccl" | tail -4
+for n in 3000 10000; do
+echo "== acvo $n engines"
+ACVO=1 DISTINCT=1 timeout 300 python tools/gpu_batch.py $n 8 2,4,8,16 2>&1 | grep "^B " | cut -c1-70
+echo "== acvo $n no engines"
+ACVO=1 CVO_HIP_NO_FUSE=1 DISTINCT=1 timeout 300 python tools/gpu_batch.py $n 8 2,4,8,16 2>&1 | grep "^B " | cut -c1-70
+done
