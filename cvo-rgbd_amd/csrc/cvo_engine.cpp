@@ -48,15 +48,20 @@ bool better_alone(const std::deque<AlignJob *> &pending)
 {
     const bool off = getenv("CVO_HIP_NO_ALONE") != nullptr;   // (test switch, read per call: small calls through the engines as before)
     if (off || engine_profile()->on) return false;   // (... or the caller is measuring the engines: cvo_hip_engine_profiling)
+    // (acvo has no runs, but on its own an iteration is two launches against the engines' nine: acvo 3k x 3k 2 / 4 / 8 / 16 per call
+    // 507 / 1 120 / 1 336 / 2 632 against 1 318 / 1 508 / 2 063 / 1 924, 6k x 6k 369 / 841 / 1 220 / 2 190 against 857 / 1 016 / 1 214 / 1 266)
     double pairs = 0.0;
+    bool acvo = false;
     for (const AlignJob *j : pending) {
         const cvo_hip_ctx *c = j->ctx;
-        if (c->prm.mode != CVO_HIP_MODE_CVO || !c->allow_run || !c->allow_head || !c->allow_async || !c->allow_merge || env_no_cand() ||
-            c->fixed.np > 65536 || c->moving.np > 65536)
+        acvo = c->prm.mode == CVO_HIP_MODE_ACVO;   // (the members of a group share their mode)
+        if (!c->allow_head || !c->allow_async || !c->allow_merge || env_no_cand() || c->fixed.np > 65536 || c->moving.np > 65536 ||
+            (acvo ? !c->allow_async_self : !c->allow_run))
             return false;
         pairs = std::max(pairs, (double)c->fixed.n * (double)c->moving.n);
     }
-    const size_t few = pairs <= 1.6e7 ? 16 : (pairs <= 5.0e7 ? 8 : (pairs <= 1.2e8 ? 2 : 0));
+    const size_t few = acvo ? (pairs <= 1.6e7 ? 8 : (pairs <= 5.0e7 ? 4 : (pairs <= 1.2e8 ? 2 : 0)))   // (10k x 10k, 2 per call: 429 against 841)
+                            : (pairs <= 1.6e7 ? 16 : (pairs <= 5.0e7 ? 8 : (pairs <= 1.2e8 ? 2 : 0)));
     return pending.size() <= few;
 }
 
