@@ -324,6 +324,11 @@ def main():
         for c in ctxs:   # (dozens of idle streams slow every other stream's submissions down)
             c.close()
         ctxs = []
+        if not args.no_side_legs:
+            try:
+                out["small_calls"] = small_calls_leg(args, pkg, torch, mode, acvo)
+            except Exception as e:
+                out["small_calls"] = {"error": repr(e)}
         if not args.no_side_legs and args.saturation_batch > B:
             try:
                 out["saturation"] = saturation_leg(args, pkg, torch, mode, acvo, n, m)
@@ -1069,6 +1074,47 @@ def identical_leg(args, pkg, ctxs, pair0, one_step, torch):
     el = time.perf_counter() - t0
     return {"registrations_per_s": steps * len(ctxs) / el, "ms_per_step": el * 1e3 / steps,
             "iterations_per_registration": it / float(steps * len(ctxs)), "steps": steps}
+
+
+def small_calls_leg(args, pkg, torch, mode, acvo):
+    """cvo_hip_align_many with a FEW registrations per call on front-end-sized clouds (3k x 3k): the call leaves them to the
+    streams of their contexts -- each runs most of its iterations inside resident runs, several side by side (csrc/cvo_engine.cpp
+    better_alone) -- against the same calls through the engines' shared launches (CVO_HIP_NO_ALONE=1, read per call)."""
+    capi = pkg.capi
+    n = 3000
+    out = {"workload": "distinct %d x %d pairs, 2 / 4 / 8 per align_many call" % (n, n), "per_call": {}}
+    for count in (2, 4, 8):
+        ctxs, streams = [], []
+        for i in range(count):
+            xf, ff, xm, fm = pkg.data.synthetic_pair(n, n, seed=pair_seed(pkg, 100 + i), acvo=acvo)
+            s = torch.cuda.Stream()
+            c = capi.Context(mode=mode, device=torch.cuda.current_device(), stream=s.cuda_stream, graph_capture=True)
+            c.set_fixed(xf, ff)
+            c.set_moving(xm, fm)
+            ctxs.append(c)
+            streams.append(s)
+
+        def rate():
+            for _ in range(3):
+                capi.align_many(ctxs, [capi.init_state(c.params) for c in ctxs])
+            torch.cuda.synchronize()
+            reps = 12
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                capi.align_many(ctxs, [capi.init_state(c.params) for c in ctxs])
+            torch.cuda.synchronize()
+            return reps * count / (time.perf_counter() - t0)
+
+        on_their_own = rate()
+        os.environ["CVO_HIP_NO_ALONE"] = "1"
+        try:
+            through_engines = rate()
+        finally:
+            os.environ.pop("CVO_HIP_NO_ALONE", None)
+        for c in ctxs:
+            c.close()
+        out["per_call"][str(count)] = {"registrations_per_s": on_their_own, "through_the_engines": through_engines}
+    return out
 
 
 def saturation_leg(args, pkg, torch, mode, acvo, n, m):
