@@ -43,7 +43,7 @@ EngineProfile *engine_profile()
 // five dependent launches (~40 us) whatever its members need.  Registrations per second, engines / on their own (one MI355X,
 // distinct pairs, profiles/r05_ab.txt 22): 3k x 3k 2 / 4 / 8 / 12 / 16 / 24 per call 1 027 / 1 113 / 1 832 / 2 697 / 2 823 / 4 578 against
 // 2 316 / 1 914 / 2 896 / 2 901 / 2 866 / -; 6k x 6k 2 / 4 / 8 / 12 754 / 1 378 / 1 723 / 2 325 against 1 428 / 1 686 / 2 289 / 2 094;
-// 10k x 10k 2 / 3 / 4 591 / 824 / 987 against 722 / 735 / 774.
+// 10k x 10k 2 / 3 / 4 591 / 824 / 987 against 722 / 735 / 774; 12k 2 / 3 756 / 1 113 against 983 / 1 040; 14k 540 / 777 against 781 / 709.
 bool better_alone(const std::deque<AlignJob *> &pending)
 {
     const bool off = getenv("CVO_HIP_NO_ALONE") != nullptr;   // (test switch, read per call: small calls through the engines as before)
@@ -61,7 +61,7 @@ bool better_alone(const std::deque<AlignJob *> &pending)
         pairs = std::max(pairs, (double)c->fixed.n * (double)c->moving.n);
     }
     const size_t few = acvo ? (pairs <= 1.6e7 ? 8 : (pairs <= 5.0e7 ? 4 : (pairs <= 1.2e8 ? 2 : 0)))   // (10k x 10k, 2 per call: 429 against 841)
-                            : (pairs <= 1.6e7 ? 12 : (pairs <= 5.0e7 ? 8 : (pairs <= 1.2e8 ? 2 : 0)));   // (16 x 3k: 2 520-2 870 against 2 820-2 830)
+                            : (pairs <= 1.6e7 ? 12 : (pairs <= 5.0e7 ? 8 : (pairs <= 2.0e8 ? 2 : 0)));   // (16 x 3k: 2 520-2 870 against 2 820-2 830)
     return pending.size() <= few;
 }
 

@@ -1,6 +1,6 @@
 #!/bin/bash
 cd ${GRAFT_REPO_ROOT:-.}
-for i in 1 2 3; do
-python -m pytest tests -m gpu -q > gpurun_out/pytest_gpu_$i.log 2>&1
-grep -v "^RCCL\|^HIP\|^ROCm\|^Hostname\|^Librccl" gpurun_out/pytest_gpu_$i.log | tail -2
-done
+echo "== 14000 default"; DISTINCT=1 timeout 300 python tools/gpu_batch.py 14000 6 2,3 2>&1 | grep "^B " | cut -c1-70
+echo "== 14000 no engines"; CVO_HIP_NO_FUSE=1 DISTINCT=1 timeout 300 python tools/gpu_batch.py 14000 6 2,3 2>&1 | grep "^B " | cut -c1-70
+echo "== 12000 default"; DISTINCT=1 timeout 300 python tools/gpu_batch.py 12000 6 2,3 2>&1 | grep "^B " | cut -c1-70
+echo "== 12000 no engines"; CVO_HIP_NO_FUSE=1 DISTINCT=1 timeout 300 python tools/gpu_batch.py 12000 6 2,3 2>&1 | grep "^B " | cut -c1-70
