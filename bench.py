@@ -47,6 +47,184 @@ FETCH_CALIBRATION = "profiles/r05_fetch_calibration.txt"   # what TCC FETCH_SIZE
 PROFILE_TAG = "r05"            # committed rocprofv3 summaries under profiles/ (tools/gpu_profile.sh)
 
 
+COMPACT_LIMIT = 6000   # bytes: the driver keeps an 8 KB tail of stdout; the headline line must sit inside it whole
+
+
+def _num(x, digits=6):
+    """A finite number rounded to `digits` significant figures (strict JSON: no NaN / Infinity), else None."""
+    try:
+        x = float(x)
+    except (TypeError, ValueError):
+        return None
+    if x != x or x in (float("inf"), float("-inf")):
+        return None
+    if x == 0.0:
+        return 0.0
+    if x == int(x) and abs(x) < 1e15:
+        return int(x)
+    return float("%.*g" % (digits, x))
+
+
+def _get(obj, *path):
+    for key in path:
+        if not isinstance(obj, dict) or key not in obj:
+            return None
+        obj = obj[key]
+    return obj
+
+
+def compact_line(out, detail_file="bench_detail.json"):
+    """The headline object of the run: the contract's keys, `config`, `roofline`, `cpu_baseline` and
+    `parity_vs_oracle` as numbers and short names only.  Everything else the run measured (per-phase
+    tables, the side legs, the prose) is `detail_file`.  Pure function of the full object, so a CPU test
+    holds it to COMPACT_LIMIT on canned legs (tests/test_bench_line.py)."""
+    cfg = out.get("config", {}) or {}
+    one = cfg.get("one_registration_at_a_time") or {}
+    rl = out.get("roofline") or {}
+    line = {k: out.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step",
+                                    "higher_is_better", "scaling", "vs_baseline", "dtype", "data")}
+    for k in ("value", "ms_per_step"):
+        line[k] = _num(line[k], 7)
+    if out.get("ranks_on_device0"):
+        line["ranks_on_device0"] = True
+    mode = cfg.get("mode", "cvo")
+    n, m, batch = cfg.get("points_fixed"), cfg.get("points_moving"), cfg.get("batch")
+    c = {"workload": "BASELINE configs[1] shape: %s distinct synthetic %sx%s RGB-D cloud pairs (xyz + 5-dim colour) per "
+                     "align_many call, %s align() to convergence, clouds resident in HBM"
+                     % (batch, n, m, mode) if cfg.get("distinct_pairs", True) else
+                     "BASELINE configs[1]: %s copies of the synthetic %sx%s pair per align_many call, %s align() to convergence"
+                     % (batch, n, m, mode),
+         "points_fixed": n, "points_moving": m, "mode": mode, "batch": batch,
+         "iterations_per_registration": _num(out.get("iterations_per_registration"), 5),
+         "ms_per_iteration": _num(out.get("ms_per_iteration"), 5)}
+    if one:
+        o = {"registrations_per_s": _num(one.get("registrations_per_s")),
+             "ms_per_iteration": _num(one.get("ms_per_iteration"), 5),
+             "iterations": _num(one.get("iterations"), 5)}
+        rr = _get(out, "single_stream", "resident_runs")
+        if rr:
+            o["iterations_inside_resident_runs"] = _num(rr.get("iterations_inside"))
+        run = out.get("roofline_run") or {}
+        if run:
+            o["kt_run_valu_active_frac"] = _num(run.get("frac"), 4)
+            o["kt_run_us_per_iteration"] = _num(run.get("us_per_iteration"), 4)
+        ac = _get(out, "acvo", "single_stream")
+        if ac:
+            o["acvo_registrations_per_s"] = _num(ac.get("registrations_per_s"))
+            o["acvo_ms_per_iteration"] = _num(ac.get("ms_per_iteration"), 5)
+        c["one_registration_at_a_time"] = o
+    for k in ("value_including_set_pcd", "config4_registrations_per_s"):
+        if cfg.get(k) is not None:
+            c[k] = _num(cfg[k])
+    for name, path in (("acvo_batched_registrations_per_s", ("acvo", "registrations_per_s")),
+                       ("saturation_256_per_call_registrations_per_s", ("saturation", "registrations_per_s")),
+                       ("config3_200k_single_gpu_ms_per_registration", ("config3_single_gpu", "ms_per_registration")),
+                       ("config3_list_pass_hbm_frac", ("config3_single_gpu", "roofline", "frac")),
+                       ("frontend_frames_per_s", ("frontend", "frames_per_s")),
+                       ("driver_loop_cvo_frames_per_s", ("frontend", "stream", "cvo", "frames_per_s")),
+                       ("driver_loop_acvo_frames_per_s", ("frontend", "stream", "acvo", "frames_per_s"))):
+        v = _num(_get(out, *path))
+        if v is not None:
+            c[name] = v
+    sc = _get(out, "small_calls", "per_call")
+    if isinstance(sc, dict):
+        c["small_calls_3k_registrations_per_s"] = {k: _num(_get(v, "registrations_per_s") if isinstance(v, dict) else v, 5)
+                                                   for k, v in sc.items()}
+    line["config"] = c
+    if rl:
+        r = {"kernel": "cvo_dev::kt_process<PROC_FLOW>", "bound": rl.get("bound"),
+             "achieved": _num(rl.get("achieved")), "peak": _num(rl.get("peak")), "unit": rl.get("unit"),
+             "frac": _num(rl.get("frac"), 4), "traffic": _num(rl.get("traffic")),
+             "algorithmic_bytes_per_launch": _num(rl.get("algorithmic_bytes_per_launch")),
+             "registrations_per_launch": _num(rl.get("registrations_per_launch"), 4),
+             "avg_launch_us": _num(rl.get("avg_launch_us"), 5), "launches": _num(rl.get("launches")),
+             "source": "hip-events, one engine of the timed region's shape",
+             "rocprofv3_avg_launch_us": _num(_get(rl, "rocprofv3", "avg_launch_us"), 5),
+             "rocprofv3_source": (_get(rl, "rocprofv3", "source") or "").replace("committed ", "") or None,
+             "frac_at_rocprofv3_duration": _num(rl.get("frac_at_rocprofv3_duration"), 4),
+             "traffic_source": (rl.get("traffic_source") or "").replace("committed ", "") or None,
+             "valu_issue_frac": _num(rl.get("valu_issue_frac"), 4)}
+        ph = rl.get("by_phase") or {}
+        if isinstance(_get(ph, "light", "chain_us"), (int, float)):
+            r["narrow_chain_us"] = _num(ph["light"]["chain_us"], 4)
+        line["roofline"] = r
+        rf = out.get("roofline_filter") or {}
+        if rf:
+            line["roofline_filter"] = {"kernel": "cvo_dev::kt_filter", "bound": rf.get("bound"),
+                                       "achieved": _num(rf.get("achieved")), "peak": _num(rf.get("peak")),
+                                       "unit": rf.get("unit"), "frac": _num(rf.get("frac"), 4),
+                                       "avg_launch_us": _num(rf.get("avg_launch_us"), 5)}
+        run = out.get("roofline_run") or {}
+        if run:
+            line["roofline_run"] = {k: (_num(v, 5) if isinstance(v, (int, float)) else v) for k, v in run.items()
+                                    if isinstance(v, (int, float)) or k in ("kernel", "bound", "unit", "source")}
+    cpu = out.get("cpu_baseline") or {}
+    if cpu:
+        line["cpu_baseline"] = {"value": _num(cpu.get("value")), "unit": cpu.get("unit"), "cores": cpu.get("cores"),
+                                "kind": cpu.get("kind"), "ms_per_iteration": _num(cpu.get("ms_per_iteration"), 5),
+                                "sample": (cpu.get("sample") or "")[:120],
+                                "one_thread_value": _num(_get(cpu, "one_thread", "value"))}
+    par = out.get("parity_vs_oracle") or {}
+    if par:
+        b = par.get("batched") or {}
+        line["parity_vs_oracle"] = {"iterations_gpu": par.get("iterations_gpu"), "iterations_oracle": par.get("iterations_oracle"),
+                                    "R_T_bit_identical": par.get("R_T_bit_identical"), "rot": _num(par.get("rot")),
+                                    "trans": _num(par.get("trans")), "tolerance": par.get("tolerance"),
+                                    "batched_registrations": b.get("registrations"),
+                                    "batched_bit_identical_to_lone_align": b.get("bit_identical_to_lone_cvo_hip_align"),
+                                    "batched_vs_oracle_checked": b.get("vs_oracle_checked"),
+                                    "batched_vs_oracle_bit_identical": b.get("vs_oracle_bit_identical"),
+                                    "oracle": "oracle/cvo_oracle.c (parity with the reference binary unpinned)"}
+    sh = out.get("sharded_allreduce")
+    if isinstance(sh, dict):
+        line["sharded_allreduce"] = {k: (_num(v) if isinstance(v, float) else v) for k, v in sh.items()
+                                     if isinstance(v, (int, float, bool)) or k in ("error", "exchange")}
+        if "error" in sh:
+            line["sharded_allreduce"]["error"] = str(sh["error"])[:160]
+    errs = sorted(k for k, v in out.items() if isinstance(v, dict) and "error" in v and k != "sharded_allreduce")
+    if errs:
+        line["leg_errors"] = errs
+    line["detail"] = detail_file
+    text = json.dumps(line, allow_nan=False, separators=(",", ":"))
+    if len(text) > COMPACT_LIMIT:   # cannot happen with the keys above; never let a leg push the headline out
+        for k in ("sharded_allreduce", "roofline_filter", "roofline_run", "leg_errors"):
+            line.pop(k, None)
+        text = json.dumps(line, allow_nan=False, separators=(",", ":"))
+    return text
+
+
+def _strict(o):
+    """The full object as strict JSON (NaN / Infinity -> null)."""
+    if isinstance(o, dict):
+        return {str(k): _strict(v) for k, v in o.items()}
+    if isinstance(o, (list, tuple)):
+        return [_strict(v) for v in o]
+    if isinstance(o, (float, np.floating)):
+        o = float(o)
+        return o if o == o and o not in (float("inf"), float("-inf")) else None
+    if isinstance(o, np.integer):
+        return int(o)
+    if isinstance(o, np.bool_):
+        return bool(o)
+    return o
+
+
+def emit(out):
+    """Rank 0's output: the full object to bench_detail.json (repo root, and gpurun_out/ where that exists) and to
+    stderr; the compact headline as the ONE JSON line of stdout, last."""
+    full = json.dumps(_strict(out), allow_nan=False)
+    for d in (ROOT, os.path.join(ROOT, "gpurun_out")):
+        if os.path.isdir(d):
+            try:
+                with open(os.path.join(d, "bench_detail.json"), "w") as fh:
+                    fh.write(full + "\n")
+            except OSError:
+                pass
+    sys.stderr.write("bench detail: " + full + "\n")
+    sys.stderr.flush()
+    print(compact_line(out), flush=True)
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -382,7 +560,7 @@ def main():
         def give_up4():   # (a rank that fails leaves the others at a barrier: the headline line must still go out)
             if rank == 0:
                 out["config4"] = {"error": "timed out after %d s" % args.sharded_timeout}
-                print(json.dumps(out), flush=True)
+                emit(out)
             os._exit(0)
         dog4 = threading.Timer(args.sharded_timeout, give_up4)
         dog4.daemon = True
@@ -404,7 +582,7 @@ def main():
         def give_up():
             if rank == 0:
                 out["sharded_allreduce"] = {"error": "timed out after %d s" % args.sharded_timeout}
-                print(json.dumps(out), flush=True)
+                emit(out)
             os._exit(0)
 
         for c in ctxs:
@@ -423,7 +601,7 @@ def main():
         if rank == 0:
             out["sharded_allreduce"] = sharded
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        emit(out)
     for c in ctxs:
         c.close()
     if world > 1 or args.force_sharded_leg:
