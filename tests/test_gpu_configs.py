@@ -209,16 +209,27 @@ def test_bench_multi_rank_rehearsal_on_one_gpu(launcher):
         cmd = [sys.executable] + bench_args
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=root)
     assert r.returncode == 0, r.stderr[-2000:]
-    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
-    out = json.loads(line)
-    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["value"] > 0
-    assert out["ranks_on_device0"] is True
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1 and r.stdout.strip().splitlines()[-1] == lines[0]   # ONE JSON line, last
+    assert len(lines[0]) < 6000   # (inside the driver's 8 KB tail whole)
+    head = json.loads(lines[0])
+    assert head["n_gpus"] == 2 and head["scaling"] == "weak" and head["value"] > 0
+    assert head["ranks_on_device0"] is True
+    assert head["config"]["config4_registrations_per_s"] > 0
+    assert head["config"]["one_registration_at_a_time"]["registrations_per_s"] > 0
+    assert "error" not in head["sharded_allreduce"], head["sharded_allreduce"]
+    assert "leg_errors" not in head, head["leg_errors"]
+    # ... and the full object beside it
+    with open(os.path.join(root, head["detail"])) as fh:
+        out = json.load(fh)
+    assert out["value"] == pytest.approx(head["value"], rel=1e-5)
     # BASELINE configs[4] under N ranks (every rank its own registrations, max-over-ranks clock) and the literal one-pair
     # figure of configs[1], both also inside `config` (the part of the line the driver keeps whole)
     c4 = out["config4"]
     assert "error" not in c4, c4
     assert c4["n_gpus"] == 2 and c4["registrations_per_s"] > 0 and c4["iterations_per_registration"] > 10
     assert out["config"]["config4_registrations_per_s"] == c4["registrations_per_s"]
+    assert head["config"]["config4_registrations_per_s"] == pytest.approx(c4["registrations_per_s"], rel=1e-5)
     one = out["config"]["one_registration_at_a_time"]
     assert one["registrations_per_s"] > 0 and one["ms_per_iteration"] > 0 and one["iterations"] > 10
     sh = out["sharded_allreduce"]
