@@ -816,7 +816,7 @@ def roofline_engine_leg(args, pkg, torch, mode, acvo, n, m):
         c.set_moving(xm, fm)
         ctxs.append(c)
         streams.append(st)
-    os.environ["CVO_HIP_ENGINES_FORCE"] = "1"
+    ctxs[0].set_option("engines", 1)   # (a call goes by its first context's switches)
     try:
         def step():
             states = [capi.init_state(c.params) for c in ctxs]
@@ -851,7 +851,6 @@ def roofline_engine_leg(args, pkg, torch, mode, acvo, n, m):
         e_ms, e_n, e_slots = capi.engine_profile(reset=True)
         capi.engine_profiling(False)
     finally:
-        os.environ.pop("CVO_HIP_ENGINES_FORCE", None)
         for c in ctxs:
             c.close()
     algo_bytes = BYTES_PER_POINT * (n + m)
@@ -1257,7 +1256,7 @@ def identical_leg(args, pkg, ctxs, pair0, one_step, torch):
 def small_calls_leg(args, pkg, torch, mode, acvo):
     """cvo_hip_align_many with a FEW registrations per call on front-end-sized clouds (3k x 3k): the call leaves them to the
     streams of their contexts -- each runs most of its iterations inside resident runs, several side by side (csrc/cvo_engine.cpp
-    better_alone) -- against the same calls through the engines' shared launches (CVO_HIP_NO_ALONE=1, read per call)."""
+    better_alone) -- against the same calls through the engines' shared launches (option "small_calls_alone" = 0)."""
     capi = pkg.capi
     n = 3000
     out = {"workload": "distinct %d x %d pairs, 2 / 4 / 8 per align_many call" % (n, n), "per_call": {}}
@@ -1284,11 +1283,8 @@ def small_calls_leg(args, pkg, torch, mode, acvo):
             return reps * count / (time.perf_counter() - t0)
 
         on_their_own = rate()
-        os.environ["CVO_HIP_NO_ALONE"] = "1"
-        try:
-            through_engines = rate()
-        finally:
-            os.environ.pop("CVO_HIP_NO_ALONE", None)
+        ctxs[0].set_option("small_calls_alone", 0)   # (a call goes by its first context's switches)
+        through_engines = rate()
         for c in ctxs:
             c.close()
         out["per_call"][str(count)] = {"registrations_per_s": on_their_own, "through_the_engines": through_engines}

@@ -24,6 +24,7 @@ SYMBOLS = [
     "cvo_hip_exp_se3", "cvo_hip_dist_se3", "cvo_hip_align", "cvo_hip_align_many",
     "cvo_hip_function_inner_product", "cvo_hip_function_inner_product_clouds",
     "cvo_hip_engine_profiling", "cvo_hip_get_engine_profile", "cvo_hip_get_engine_flow_trace", "cvo_hip_get_wave_load", "cvo_hip_set_graph_capture", "cvo_hip_set_profiling", "cvo_hip_get_profile", "cvo_hip_get_graph_stats", "cvo_hip_get_run_stats", "cvo_hip_get_run_clocks", "cvo_hip_get_mirror_retries", "cvo_hip_synchronize",
+    "cvo_hip_set_option", "cvo_hip_get_option",
 ]
 
 
@@ -144,6 +145,8 @@ def lib():
     L.cvo_hip_get_mirror_retries.restype = C.c_longlong
     L.cvo_hip_get_run_stats.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.cvo_hip_synchronize.argtypes = [vp]
+    L.cvo_hip_set_option.argtypes = [vp, C.c_char_p, C.c_double]
+    L.cvo_hip_get_option.argtypes = [vp, C.c_char_p, C.POINTER(C.c_double)]
     for name in SYMBOLS:   # raises AttributeError if the library lacks a declared symbol
         if name not in ("cvo_hip_error_string", "cvo_hip_last_error"):
             getattr(L, name).restype = C.c_int
@@ -427,6 +430,15 @@ class Context:
         buf = (C.c_longlong * 16)()
         self._chk(self._L.cvo_hip_get_run_clocks(self._ctx, buf), "run_clocks")
         return list(buf)
+
+    def set_option(self, key, value):
+        """cvo_hip_set_option: a policy / test switch of this context by name (include/cvo_hip.h lists the keys)."""
+        self._chk(self._L.cvo_hip_set_option(self._ctx, key.encode(), float(value)), "set_option(%s)" % key)
+
+    def get_option(self, key):
+        v = C.c_double(0.0)
+        self._chk(self._L.cvo_hip_get_option(self._ctx, key.encode(), C.byref(v)), "get_option(%s)" % key)
+        return v.value
 
     def synchronize(self):
         self._chk(self._L.cvo_hip_synchronize(self._ctx), "synchronize")

@@ -23,12 +23,91 @@ int fail(cvo_hip_ctx *ctx, int code, const char *msg)
     return code;
 }
 
-// The switches this library reads from the environment, one per mechanism: test switches (read where a plan is
-// recorded, so that a test can flip them between two registrations) and diagnostics.
-bool env_no_cand() { return getenv("CVO_HIP_NO_CAND") != nullptr; }           // no candidate records: expand the tile list every time
-bool env_no_graph() { return getenv("CVO_HIP_NO_GRAPH") != nullptr; }         // no stream captures at all
-bool env_sync_upload() { static const bool v = getenv("CVO_HIP_SYNC_UPLOAD") != nullptr; return v; }   // hand-overs wait for the device
-bool env_engine_debug() { static const bool v = getenv("CVO_HIP_ENGINE_DEBUG") != nullptr; return v; } // host-side clocks of the engines
+// ---- options (cvo_hip_set_option): one table of keys; the environment variables of earlier rounds are the DEFAULTS of the
+// same options, read once per context at cvo_hip_create (env_defaults below holds the library's only getenv of this file).
+static std::atomic<bool> g_engine_debug{false};
+bool engine_debug_on() { return g_engine_debug.load(std::memory_order_relaxed); }
+
+namespace {
+struct OptDef {
+    const char *key;
+    const char *env;      // environment variable that sets its default (nullptr: none)
+    int env_kind;         // 1: a flag -- present means env_value; 2: a number -- the variable's text
+    double env_value;
+};
+const OptDef kOptions[] = {
+    {"graph_capture", "CVO_HIP_GRAPH", 1, 1.0},           {"no_graph", "CVO_HIP_NO_GRAPH", 1, 1.0},
+    {"head_graphs", "CVO_HIP_RUN_GRAPHS", 1, 1.0},        {"head_mode", "CVO_HIP_NO_HEAD", 1, 0.0},
+    {"resident_runs", "CVO_HIP_NO_RUN", 1, 0.0},          {"run_solvers_max", "CVO_HIP_RUN_G_MAX", 2, 0.0},
+    {"run_candidates_max", "CVO_HIP_RUN_CAND", 2, 0.0},   {"run_timeout_ms", nullptr, 0, 0.0},
+    {"run_fault", nullptr, 0, 0.0},                       {"merged_launches", "CVO_HIP_NO_MERGE", 1, 0.0},
+    {"async_builds", "CVO_HIP_NO_ASYNC", 1, 0.0},         {"list_pass_blocks", "CVO_HIP_PROC_BLOCKS", 2, 0.0},
+    {"post_debug", "CVO_HIP_POST_DEBUG", 1, 1.0},         {"mailbox_timeout_s", "CVO_HIP_MAILBOX_TIMEOUT_S", 2, 0.0},
+    {"candidate_records", "CVO_HIP_NO_CAND", 1, 0.0},     {"sync_upload", "CVO_HIP_SYNC_UPLOAD", 1, 1.0},
+    {"engine_debug", "CVO_HIP_ENGINE_DEBUG", 1, 1.0},     {"one_launch_hand_over", "CVO_HIP_NO_CLOUD_ONE", 1, 0.0},
+    {"small_calls_alone", "CVO_HIP_NO_ALONE", 1, 0.0},    {"fused_groups", "CVO_HIP_NO_FUSE", 1, 0.0},
+    {"engines", "CVO_HIP_ENGINES_FORCE", 2, 0.0},         {"list_init", "CVO_HIP_LIST_INIT", 2, 0.0},
+    {"kept_pack", "CVO_HIP_NO_PACK", 1, 0.0},             {"list_margin", "CVO_HIP_LIST_MARGIN", 2, 0.0},
+    {"final_mirror", "CVO_HIP_NO_FINAL_MIRROR", 1, 0.0},  {"twist_on_shared_gpu", "CVO_HIP_TWIST_ON_SHARED_GPU", 1, 1.0},
+    {"comm_debug", "CVO_HIP_COMM_DEBUG", 1, 1.0},         {"wait_policy", "CVO_HIP_WAIT_POLICY", 2, 0.0},
+};
+void env_defaults(cvo_hip_ctx *ctx)
+{
+    for (const OptDef &d : kOptions) {
+        if (!d.env) continue;
+        const char *e = getenv(d.env);
+        if (!e) continue;
+        (void)apply_option(ctx, d.key, d.env_kind == 1 ? d.env_value : atof(e));
+    }
+}
+}   // namespace
+
+// (value: 0 / 1 for switches; returns CVO_HIP_ERR_INVALID for an unknown key or a value out of range)
+int apply_option(cvo_hip_ctx *ctx, const char *key, double v)
+{
+    auto is = [&](const char *k) { return std::strcmp(key, k) == 0; };
+    const bool on = v != 0.0;
+    CtxOptions &o = ctx->opt;
+    if (is("graph_capture")) { ctx->use_graphs = on && !o.no_graph; if (!ctx->use_graphs) drop_graphs(ctx); }
+    else if (is("no_graph")) { o.no_graph = on; if (on) { ctx->use_graphs = false; drop_graphs(ctx); } }
+    else if (is("head_graphs")) ctx->head_graphs = on;
+    else if (is("head_mode")) ctx->allow_head = on;
+    else if (is("resident_runs")) ctx->allow_run = on;
+    else if (is("run_solvers_max")) {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device) != hipSuccess || cus <= 0) cus = RUN_G + 8;
+        ctx->run_g_max = v > 0.0 ? std::max(8, std::min((int)RUN_G, (int)v)) : std::max(8, std::min((int)RUN_G, cus - 8));
+    }
+    else if (is("run_candidates_max")) { if (v < 0.0) return CVO_HIP_ERR_INVALID; o.run_cand = (int)v; }
+    else if (is("run_timeout_ms")) { if (v < 0.0 || v > 6.0e4) return CVO_HIP_ERR_INVALID; o.run_timeout_ms = v; }
+    else if (is("run_fault")) { if (v < 0.0) return CVO_HIP_ERR_INVALID; o.run_fault = (int)v; }
+    else if (is("merged_launches")) ctx->allow_merge = on;
+    else if (is("async_builds")) ctx->allow_async = ctx->allow_async_self = on;
+    else if (is("list_pass_blocks")) {   // list-kernel blocks of a lone registration (0: by the clouds)
+        const int b = (int)v;
+        if (b == 0) { ctx->proc_blocks_forced = false; ctx->proc_blocks = ctx->proc_blocks_default = PROC_BLOCKS; }
+        else if (b == 64 || b == 128 || b == 256 || b == 512 || b == 1024) { ctx->proc_blocks = ctx->proc_blocks_default = b; ctx->proc_blocks_forced = true; }
+        else return CVO_HIP_ERR_INVALID;
+    }
+    else if (is("post_debug")) o.post_debug = on;
+    else if (is("mailbox_timeout_s")) { if (!(v > 0.0)) return CVO_HIP_ERR_INVALID; o.mailbox_timeout_s = v; }
+    else if (is("candidate_records")) o.no_cand = !on;
+    else if (is("sync_upload")) o.sync_upload = on;
+    else if (is("engine_debug")) { o.engine_debug = on; if (on) g_engine_debug.store(true, std::memory_order_relaxed); }
+    else if (is("one_launch_hand_over")) o.no_cloud_one = !on;
+    else if (is("small_calls_alone")) o.no_alone = !on;
+    else if (is("fused_groups")) o.no_fuse = !on;
+    else if (is("engines")) { if (v < 0.0 || v > 8.0) return CVO_HIP_ERR_INVALID; o.engines_force = (int)v; }
+    else if (is("list_init")) { if (v < 0.0) return CVO_HIP_ERR_INVALID; o.list_init = v; }
+    else if (is("kept_pack")) o.no_pack = !on;
+    else if (is("list_margin")) { if (v > 4.0) return CVO_HIP_ERR_INVALID; o.list_margin = v < 0.0 ? -1.0f : (float)v; }
+    else if (is("final_mirror")) o.no_final_mirror = !on;
+    else if (is("twist_on_shared_gpu")) o.twist_on_shared_gpu = on;
+    else if (is("comm_debug")) o.comm_debug = on;
+    else if (is("wait_policy")) { if (v < 0.0 || v > 2.0) return CVO_HIP_ERR_INVALID; o.wait_policy = (int)v; }
+    else return CVO_HIP_ERR_INVALID;
+    return CVO_HIP_OK;
+}
 
 // Parameters the kernels can work with: a known mode, finite values, positive kernel scales
 // and thresholds (log of a non-positive quotient would make NaN radii and NaN twists that
@@ -105,6 +184,7 @@ const char *cvo_hip_error_string(int status)
     case CVO_HIP_ERR_NOMEM: return "out of memory";
     case CVO_HIP_ERR_COMM: return "RCCL / all-reduce error";
     case CVO_HIP_ERR_NODEVICE: return "no usable HIP device";
+    case CVO_HIP_ERR_RUN: return "a resident run timed out and the registration could not be redone";
     default: return "unknown status";
     }
 }
@@ -201,7 +281,6 @@ int cvo_hip_create(int device, void *stream, const cvo_hip_params *p, cvo_hip_ct
     }
     if (hipMalloc((void **)&ctx->st, sizeof(DevState)) != hipSuccess) return bail(CVO_HIP_ERR_NOMEM);
     if (hipMalloc((void **)&ctx->st2, sizeof(DevHead)) != hipSuccess) return bail(CVO_HIP_ERR_NOMEM);
-    if (getenv("CVO_HIP_NO_HEAD")) ctx->allow_head = false;
     if (hipHostMalloc((void **)&ctx->st_host, (kPollSlots + 2) * sizeof(DevState),
                       hipHostMallocDefault) != hipSuccess)
         return bail(CVO_HIP_ERR_NOMEM);
@@ -221,33 +300,22 @@ int cvo_hip_create(int device, void *stream, const cvo_hip_params *p, cvo_hip_ct
     *ctx->progress_mirror = 0;
     *ctx->run_mirror = 0;
     *ctx->hint_mirror = -1;
-    if (getenv("CVO_HIP_NO_RUN")) ctx->allow_run = false;   // (test switch: no resident runs, cvo_kernels.hip kt_run)
     {   // (a run's blocks must all be resident at once, one per compute unit: a partition with fewer units gets smaller runs)
         int cus = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus <= 0) cus = RUN_G + 8;
         ctx->run_g_max = std::max(8, std::min((int)RUN_G, cus - 8));
-        if (const char *e = getenv("CVO_HIP_RUN_G_MAX")) ctx->run_g_max = std::max(8, std::min((int)RUN_G, atoi(e)));   // (test switch: a smaller device)
     }
-    ctx->head_graphs = getenv("CVO_HIP_RUN_GRAPHS") != nullptr;   // (test switch: captured batches for head-mode plans, cvo_plan.cpp launch_batch)
     // Stream capture is a process-wide affair in this runtime (cvo_lock.h): the library's own
     // entry points keep out of each other's captures, but HIP work of OTHER code in the process
     // (torch on another thread, say) cannot be kept out and would fail with "previous error
     // during capture".  So batches are captured into hipGraphs by default only on a stream the
     // library created itself; with a caller-supplied stream the caller opts in
-    // (cvo_hip_set_graph_capture, or CVO_HIP_GRAPH=1) once it knows no other thread of the
-    // process uses HIP while an align() is being set up.  CVO_HIP_NO_GRAPH=1 forbids captures.
-    ctx->use_graphs = ctx->own_stream || getenv("CVO_HIP_GRAPH") != nullptr;
-    if (env_no_graph()) ctx->use_graphs = false;
-    if (getenv("CVO_HIP_NO_MERGE")) ctx->allow_merge = false;
-    if (getenv("CVO_HIP_NO_ASYNC")) ctx->allow_async = ctx->allow_async_self = false;
-    if (const char *e = getenv("CVO_HIP_PROC_BLOCKS")) {   // list-kernel blocks of a lone registration
-        const int v = atoi(e);
-        if (v == 64 || v == 128 || v == 256 || v == 512 || v == 1024) {
-            ctx->proc_blocks = ctx->proc_blocks_default = v;
-            ctx->proc_blocks_forced = true;
-        }
-    }
-    if (getenv("CVO_HIP_POST_DEBUG")) {
+    // (cvo_hip_set_graph_capture / cvo_hip_set_option "graph_capture") once it knows no other thread of the
+    // process uses HIP while an align() is being set up.  "no_graph" forbids captures.
+    ctx->use_graphs = ctx->own_stream;
+    // every other switch: cvo_hip_set_option; the defaults the environment names, read here and nowhere else
+    env_defaults(ctx);
+    if (ctx->opt.post_debug) {
         if (hipMalloc((void **)&ctx->post_dbg, 8 * sizeof(long long)) != hipSuccess) return bail(CVO_HIP_ERR_NOMEM);
         (void)hipMemset(ctx->post_dbg, 0, 8 * sizeof(long long));
     }
@@ -421,8 +489,7 @@ int cvo_hip_mailbox_connect(cvo_hip_ctx *ctx, const void *ipc_handles, void *con
     CommTable t{};
     t.rank = ctx->mail_rank;
     t.world = ctx->mail_world;
-    double secs = 5.0;
-    if (const char *e = getenv("CVO_HIP_MAILBOX_TIMEOUT_S")) { const double v = atof(e); if (v > 0.0) secs = v; }
+    const double secs = ctx->opt.mailbox_timeout_s;   // (cvo_hip_set_option "mailbox_timeout_s")
     t.timeout_ticks = (long long)(secs * 1.0e8);   // wall_clock64(): 100 MHz
     for (int r = 0; r < t.world; ++r) {
         if (r == t.rank) { t.peer[r] = ctx->mailbox; continue; }
@@ -696,9 +763,7 @@ int cvo_hip_set_graph_capture(cvo_hip_ctx *ctx, int enable)
 {
     cvo_lock::Api api_guard;
     if (!ctx) return CVO_HIP_ERR_INVALID;
-    ctx->use_graphs = enable != 0 && !env_no_graph();
-    if (!ctx->use_graphs) drop_graphs(ctx);
-    return CVO_HIP_OK;
+    return apply_option(ctx, "graph_capture", enable ? 1.0 : 0.0);
 }
 
 int cvo_hip_set_profiling(cvo_hip_ctx *ctx, int enable)
@@ -730,12 +795,14 @@ int cvo_hip_get_graph_stats(const cvo_hip_ctx *ctx, long long *launches_from_cac
 
 int cvo_hip_get_run_stats(cvo_hip_ctx *ctx, int *runs, int *declined, int *iterations, int *candidates)
 {
-    if (!ctx || !ctx->st_host) return CVO_HIP_ERR_INVALID;
-    // (diagnostics: the counters live in the state's tail, which a cvo_hip_align that ended on the mirrored head has not copied)
-    DevState &f = ctx->st_host[0];
+    cvo_lock::Api api_guard;   // (runtime calls: not inside another thread's capture window)
+    if (!ctx || !ctx->st) return CVO_HIP_ERR_INVALID;
+    // (diagnostics: the counters live in the state's tail, which a cvo_hip_align that ended on the mirrored head has not copied;
+    // into a buffer of this call's own -- the pinned state copies belong to the align loop)
+    struct { int32_t run_count, run_entered, run_iterations, run_candidates; } f{};
+    static_assert(offsetof(DevState, run_candidates) - offsetof(DevState, run_count) == 12, "four consecutive words");
     if (hipSetDevice(ctx->device) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess ||
-        hipMemcpy(&f.run_count, reinterpret_cast<const char *>(ctx->st) + offsetof(DevState, run_count),
-                  offsetof(DevState, mail_seq) - offsetof(DevState, run_count), hipMemcpyDeviceToHost) != hipSuccess)
+        hipMemcpy(&f, reinterpret_cast<const char *>(ctx->st) + offsetof(DevState, run_count), sizeof(f), hipMemcpyDeviceToHost) != hipSuccess)
         return CVO_HIP_ERR_HIP;
     if (runs) *runs = f.run_entered;
     if (declined) *declined = f.run_count - f.run_entered;
@@ -746,12 +813,64 @@ int cvo_hip_get_run_stats(cvo_hip_ctx *ctx, int *runs, int *declined, int *itera
 
 int cvo_hip_get_run_clocks(cvo_hip_ctx *ctx, long long clocks16[16])
 {
-    if (!ctx || !ctx->st_host || !clocks16) return CVO_HIP_ERR_INVALID;
+    cvo_lock::Api api_guard;
+    if (!ctx || !ctx->st || !clocks16) return CVO_HIP_ERR_INVALID;
+    long long clk[16];
+    static_assert(sizeof(clk) == sizeof(DevState::run_clk), "run_clk");
     if (hipSetDevice(ctx->device) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess ||
-        hipMemcpy(ctx->st_host[0].run_clk, reinterpret_cast<const char *>(ctx->st) + offsetof(DevState, run_clk), sizeof(ctx->st_host[0].run_clk),
-                  hipMemcpyDeviceToHost) != hipSuccess)
+        hipMemcpy(clk, reinterpret_cast<const char *>(ctx->st) + offsetof(DevState, run_clk), sizeof(clk), hipMemcpyDeviceToHost) != hipSuccess)
         return CVO_HIP_ERR_HIP;
-    for (int q = 0; q < 16; ++q) clocks16[q] = ctx->st_host[0].run_clk[q];
+    for (int q = 0; q < 16; ++q) clocks16[q] = clk[q];
+    return CVO_HIP_OK;
+}
+
+int cvo_hip_set_option(cvo_hip_ctx *ctx, const char *key, double value)
+{
+    cvo_lock::Api api_guard;
+    if (!ctx || !key) return CVO_HIP_ERR_INVALID;
+    if (hipSetDevice(ctx->device) != hipSuccess) return CVO_HIP_ERR_HIP;
+    const int rc = apply_option(ctx, key, value);
+    if (rc) return fail(ctx, rc, "cvo_hip_set_option: unknown key or value out of range");
+    return CVO_HIP_OK;
+}
+
+int cvo_hip_get_option(const cvo_hip_ctx *ctx, const char *key, double *value)
+{
+    if (!ctx || !key || !value) return CVO_HIP_ERR_INVALID;
+    auto is = [&](const char *k) { return std::strcmp(key, k) == 0; };
+    const CtxOptions &o = ctx->opt;
+    if (is("graph_capture")) *value = ctx->use_graphs;
+    else if (is("no_graph")) *value = o.no_graph;
+    else if (is("head_graphs")) *value = ctx->head_graphs;
+    else if (is("head_mode")) *value = ctx->allow_head;
+    else if (is("resident_runs")) *value = ctx->allow_run;
+    else if (is("run_solvers_max")) *value = ctx->run_g_max;
+    else if (is("run_candidates_max")) *value = o.run_cand;
+    else if (is("run_timeout_ms")) *value = o.run_timeout_ms;
+    else if (is("run_fault")) *value = o.run_fault;
+    else if (is("merged_launches")) *value = ctx->allow_merge;
+    else if (is("async_builds")) *value = ctx->allow_async;
+    else if (is("list_pass_blocks")) *value = ctx->proc_blocks_forced ? ctx->proc_blocks : 0;
+    else if (is("post_debug")) *value = o.post_debug;
+    else if (is("mailbox_timeout_s")) *value = o.mailbox_timeout_s;
+    else if (is("candidate_records")) *value = !o.no_cand;
+    else if (is("sync_upload")) *value = o.sync_upload;
+    else if (is("engine_debug")) *value = o.engine_debug;
+    else if (is("one_launch_hand_over")) *value = !o.no_cloud_one;
+    else if (is("small_calls_alone")) *value = !o.no_alone;
+    else if (is("fused_groups")) *value = !o.no_fuse;
+    else if (is("engines")) *value = o.engines_force;
+    else if (is("list_init")) *value = o.list_init;
+    else if (is("kept_pack")) *value = !o.no_pack;
+    else if (is("list_margin")) *value = o.list_margin;
+    else if (is("final_mirror")) *value = !o.no_final_mirror;
+    else if (is("twist_on_shared_gpu")) *value = o.twist_on_shared_gpu;
+    else if (is("comm_debug")) *value = o.comm_debug;
+    else if (is("wait_policy")) *value = o.wait_policy;
+    // read-only counters
+    else if (is("run_timeouts")) *value = (double)ctx->run_timeouts;
+    else if (is("no_run_backoff")) *value = ctx->no_run_backoff;
+    else return CVO_HIP_ERR_INVALID;
     return CVO_HIP_OK;
 }
 

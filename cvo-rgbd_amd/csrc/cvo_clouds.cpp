@@ -142,7 +142,7 @@ int upload_cloud(cvo_hip_ctx *ctx, Cloud &c, const float *xyz, const float *feat
         d_feat = (const float *)ctx->raw_feat.p;
     }
     // From here on the cloud is in device memory either way.
-    const bool no_one = getenv("CVO_HIP_NO_CLOUD_ONE") != nullptr;   // (test switch, read per call: the multi-launch preparation)
+    const bool no_one = ctx->opt.no_cloud_one;   // (test switch "one_launch_hand_over" = 0: the multi-launch preparation)
     if (n <= CLOUD_ONE_MAX && !no_one) {
         // ONE launch (k_cloud_one: a block does the whole preparation, the sort in LDS); the bounding box goes
         // straight into the cloud's pinned words
@@ -155,7 +155,7 @@ int upload_cloud(cvo_hip_ctx *ctx, Cloud &c, const float *xyz, const float *feat
         HIP_TRY(ctx, hipEventRecord(c.ready_ev, ctx->stream));
         c.wait_ev = nullptr;
         c.pending = true;
-        if (on_device || env_sync_upload()) return cloud_ready(ctx, c);
+        if (on_device || ctx->opt.sync_upload) return cloud_ready(ctx, c);
         return CVO_HIP_OK;
     }
     // Larger clouds: bounding box, keys, rocPRIM's radix sort, pack, spheres as launches of their own.  The box is
@@ -188,7 +188,7 @@ int upload_cloud(cvo_hip_ctx *ctx, Cloud &c, const float *xyz, const float *feat
     // wait for the device (64 x 2 hand-overs of a batch overlap each other instead of costing 0.1 ms of host
     // time apiece).  Device arrays of the caller's are read by the queued kernels: they may be re-used
     // once this returns, so that form waits here.
-    if (on_device || env_sync_upload()) return cloud_ready(ctx, c);
+    if (on_device || ctx->opt.sync_upload) return cloud_ready(ctx, c);
     return CVO_HIP_OK;
 }
 

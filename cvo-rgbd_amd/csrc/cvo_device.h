@@ -82,7 +82,9 @@ constexpr int RED_FLOW = 0, RED_XX = 9, RED_YY = 11, RED_STEP = 13, RED_N = 17;
 
 // DevState::done values
 enum { RUNNING = 0, DONE_BREAK_A = 1, DONE_BREAK_B = 2, DONE_MAX_ITER = 3, NEED_BIGGER_LIST = 4,
-       DONE_COMM_ERROR = 5 };
+       DONE_COMM_ERROR = 5,
+       DONE_RUN_TIMEOUT = 6 };   // a resident run (kt_run) gave up on an exchange: nothing of it was written to the state but scratch (kt_run
+                                 // "what a run writes before its exit"); the host registers again without runs (cvo_job.cpp job_pump)
 
 // Peer-to-peer mailbox all-reduce: every rank owns one Mailbox in ITS OWN device
 // memory with one slot per sender (two generations: a sender may be one exchange ahead of
@@ -114,8 +116,13 @@ struct CommTable {
 // Resident runs (cvo_kernels.hip kt_run): RUN_G workgroups of RUN_BLOCK threads carry whole iterations of ONE
 // registration in one launch; between the passes they exchange their partial sums through a RunMail in device
 // memory -- every double as two 8-byte words (tag32 << 32 | half32), relaxed agent-scope atomic stores; a reader
-// polls the words themselves until the tags match (no flag, no fence; two generations: a block can be one
-// exchange ahead of the slowest reader, never two).  1.7 us per exchange among 32 blocks of one XCD
+// polls the words themselves until the tags match (no flag, no fence).  FOUR generations (seq & 3): among the solvers
+// two would do -- a solver can post exchange e + 2 only after it has read every row of e + 1, which every solver
+// posts after reading e -- but the head block only reads, and the solvers wait for it through the verdict word of
+// every SECOND (step) exchange alone: a solver that has seen the verdict of step exchange 2i knows that the head is
+// past step exchange 2i - 2, no more, and may post flow exchange 2i + 1 while the head still sweeps flow exchange
+// 2i - 1 -- same parity.  With four generations the row a solver overwrites with e + 4 is one the head left at
+// least one verdict ago.  1.7 us per exchange among 32 blocks of one XCD
 // (tools/microbench/xcd_exchange.hip, profiles/r05_ab.txt 1).
 constexpr int RUN_G = 248;           // solver blocks of a run at most (blocks 1 .. RUN_G of the launch; block 0 is the head block): a block
                                      // per compute unit and a few units to spare -- above RUN_G_SMALL a run first proves that all of it is resident
@@ -130,8 +137,9 @@ constexpr int RUN_L = 8;             // ... and in LDS behind them (the widest r
 constexpr int RUN_CAP = RUN_LANES * (RUN_R + RUN_L);   // candidates a run holds at most: 2 031 616
 constexpr unsigned RUN_LDS_BYTES = (unsigned)RUN_L * 2u * (unsigned)RUN_BLOCK * 16u;   // dynamic LDS of kt_run
 constexpr int RUN_NV = 9;            // doubles per exchange at most (flow: 9, step: 4)
+constexpr int RUN_GEN = 4;           // generations of the exchange rows (see above)
 struct RunMail {
-    unsigned long long w[2][RUN_G + 1][2 * RUN_NV];   // (row RUN_G: the head block's verdict word)
+    unsigned long long w[RUN_GEN][RUN_G + 1][2 * RUN_NV];   // (row RUN_G: the head block's verdict word)
     // entry handshake of a large run: every block of every kt_run launch draws a ticket as its first act (launches of one registration
     // follow each other in one stream, so launch L holds tickets [L NB, (L + 1) NB)); the head block waits until the g + 1 blocks
     // that take part have drawn theirs -- blocks start in index order: they are then resident -- and says GO, or ABORT when that
@@ -405,6 +413,9 @@ struct PostStepArgs {
     int32_t *hint_mirror;  // pinned: DevHead::run_hint (the host picks the next batch's plan by it)
     int run_iters;         // iterations per run at most
     int run_g_max;         // solver blocks of a run at most (RUN_G on an unpartitioned MI355X; fewer compute units: fewer, cvo_hip_create)
+    long long run_timeout_ticks;   // how long a poll of a run's exchange waits (100 MHz wall clock; cvo_hip_set_option "run_timeout_ms")
+    int run_fault;         // test switch (cvo_hip_set_option "run_fault" = n > 0): the first solver of every run leaves at the top of its n-th
+                           // iteration without a word -- what a block lost to the scheduler looks like to its peers
     DevParams prm;
 };
 

@@ -46,7 +46,7 @@ EngineProfile *engine_profile()
 // 10k x 10k 2 / 3 / 4 591 / 824 / 987 against 722 / 735 / 774; 12k 2 / 3 756 / 1 113 against 983 / 1 040; 14k 540 / 777 against 781 / 709.
 bool better_alone(const std::deque<AlignJob *> &pending)
 {
-    const bool off = getenv("CVO_HIP_NO_ALONE") != nullptr;   // (test switch, read per call: small calls through the engines as before)
+    const bool off = !pending.empty() && pending.front()->ctx->opt.no_alone;   // (test switch "small_calls_alone" = 0: small calls through the engines as before)
     if (off || engine_profile()->on) return false;   // (... or the caller is measuring the engines: cvo_hip_engine_profiling)
     // (acvo has no runs, but on its own an iteration is two launches against the engines' nine: acvo 3k x 3k 2 / 4 / 8 / 16 per call
     // 507 / 1 120 / 1 336 / 2 632 against 1 318 / 1 508 / 2 063 / 1 924, 6k x 6k 369 / 841 / 1 220 / 2 190 against 857 / 1 016 / 1 214 / 1 266)
@@ -55,7 +55,7 @@ bool better_alone(const std::deque<AlignJob *> &pending)
     for (const AlignJob *j : pending) {
         const cvo_hip_ctx *c = j->ctx;
         acvo = c->prm.mode == CVO_HIP_MODE_ACVO;   // (the members of a group share their mode)
-        if (!c->allow_head || !c->allow_async || !c->allow_merge || env_no_cand() || c->fixed.np > 65536 || c->moving.np > 65536 ||
+        if (!c->allow_head || !c->allow_async || !c->allow_merge || c->opt.no_cand || c->fixed.np > 65536 || c->moving.np > 65536 ||
             (acvo ? !c->allow_async_self : !c->allow_run))
             return false;
         pairs = std::max(pairs, (double)c->fixed.n * (double)c->moving.n);
@@ -452,7 +452,7 @@ void engine_release(Engine *e)
         e->flow_ev.clear();
     }
     std::lock_guard<std::mutex> lock(*engine_mutex());
-    if (env_engine_debug())
+    if (engine_debug_on())
         fprintf(stderr, "[cvo_hip] engine %p: batches at zdim 1/2/4/8/16: %lld %lld %lld %lld %lld, replans %lld, "
                 "graph captures %lld hits %lld; host ms: insert %.2f replan %.2f launch %.2f collect %.2f finish %.2f wait %.2f\n",
                 (void *)e, e->n_batches[0], e->n_batches[1], e->n_batches[2],
@@ -474,9 +474,9 @@ int cvo_hip_align_many(cvo_hip_ctx **ctxs, cvo_hip_state **states, int *n_iters,
 {
     cvo_lock::Api api_guard;
     if (count < 0 || (count > 0 && (!ctxs || !states))) return CVO_HIP_ERR_INVALID;
-    const bool dbg_many = env_engine_debug();
+    const bool dbg_many = engine_debug_on();
     const double t_many0 = Engine::now_ms();
-    struct Tell { double t0; int n; ~Tell() { if (env_engine_debug()) fprintf(stderr, "[cvo_hip] align_many(%d): %.2f ms\n", n, Engine::now_ms() - t0); } } tell{t_many0, count};
+    struct Tell { double t0; int n; ~Tell() { if (engine_debug_on()) fprintf(stderr, "[cvo_hip] align_many(%d): %.2f ms\n", n, Engine::now_ms() - t0); } } tell{t_many0, count};
     std::vector<AlignJob> jobs((size_t)count);
     for (int i = 0; i < count; ++i) {
         if (!ctxs[i] || !states[i]) return CVO_HIP_ERR_INVALID;
@@ -492,7 +492,7 @@ int cvo_hip_align_many(cvo_hip_ctx **ctxs, cvo_hip_state **states, int *n_iters,
     // a class wait in one queue; one or two engines (two from 8 jobs on: two groups fill each
     // other's bubbles -- single-block post kernels, kernel boundaries) take them into their
     // slots as slots become free.
-    static const bool no_fuse = getenv("CVO_HIP_NO_FUSE") != nullptr;
+    const bool no_fuse = count > 0 && ctxs[0] && ctxs[0]->opt.no_fuse;   // ("fused_groups" = 0)
     if (!no_fuse && count > 1) {
         constexpr int gmax = ENGINE_SLOTS;
         for (int i = 0; i < count; ++i) {
@@ -516,7 +516,7 @@ int cvo_hip_align_many(cvo_hip_ctx **ctxs, cvo_hip_state **states, int *n_iters,
             constexpr size_t max_engines = 4;   // (the runtime's hardware queues; with 8 queues and 6 engines: -40 % at 64 pairs, r04_ab.txt 1)
             size_t ngroups = total > 3 * ENGINE_SLOTS ? 4 : (total >= 40 ? 3 : (total >= 8 ? 2 : 1));
             ngroups = std::max<size_t>(1, std::min(ngroups, max_engines));
-            if (const char *e = getenv("CVO_HIP_ENGINES_FORCE")) ngroups = (size_t)std::max(1, std::min(atoi(e), 8));   // (tuning probe)
+            if (const int force = pending.front()->ctx->opt.engines_force) ngroups = (size_t)std::max(1, std::min(force, 8));   // (tuning probe: "engines")
             bool graphs_ok = true;   // (capture policy: cvo_hip_set_graph_capture)
             for (AlignJob *j : pending) graphs_ok = graphs_ok && j->ctx->use_graphs;
             // Asynchronous xy builds shorten the launch chain of a registration; once the GPU is

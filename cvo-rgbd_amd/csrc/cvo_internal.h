@@ -224,7 +224,38 @@ struct RecOp {
 using namespace cvo_dev;
 using namespace cvo_impl;
 
+// Policy and test switches of a context beyond the fields of cvo_hip_ctx that have always carried one (allow_head, allow_run,
+// use_graphs ...): set through cvo_hip_set_option (cvo_capi.cpp: the table of keys); their defaults come from the environment,
+// read ONCE, when the context is created.  A call that serves many contexts (cvo_hip_align_many, cvo_hip_set_pcd_many) goes by
+// its first context's.
+struct CtxOptions {
+    bool no_cand = false;             // "candidate_records" = 0: expand the tile list every time
+    bool no_graph = false;            // "no_graph": no stream captures at all, whatever graph_capture says
+    bool sync_upload = false;         // "sync_upload": hand-overs wait for the device
+    bool engine_debug = false;        // "engine_debug": host-side clocks of the engines on stderr
+    bool no_cloud_one = false;        // "one_launch_hand_over" = 0: the multi-launch cloud preparation
+    bool no_alone = false;            // "small_calls_alone" = 0: small align_many calls through the engines
+    bool no_fuse = false;             // "fused_groups" = 0: align_many runs every registration on its own stream
+    bool no_pack = false;             // "kept_pack" = 0: 8 + 4 byte kept entries
+    bool no_final_mirror = false;     // "final_mirror" = 0: the final state comes by a copy in stream order
+    bool twist_on_shared_gpu = false; // "twist_on_shared_gpu": in-launch exchange although the ranks share a GPU
+    bool comm_debug = false;          // "comm_debug"
+    bool post_debug = false;          // "post_debug" (environment only: the buffer is made at create)
+    int engines_force = 0;            // "engines": engines of an align_many call (0: by the call's size)
+    double list_init = 0.0;           // "list_init": first capacity of every list (0: by the clouds)
+    float list_margin = -1.0f;        // "list_margin": width of the tile lists (< 0: by the clouds)
+    int run_cand = 0;                 // "run_candidates_max" (0: what the runs hold)
+    double mailbox_timeout_s = 5.0;   // "mailbox_timeout_s": read by the next cvo_hip_mailbox_connect
+    double run_timeout_ms = 0.0;      // "run_timeout_ms": a resident run's exchange gives up after this long (0: 1 s)
+    int run_fault = 0;                // "run_fault" (test switch, PostStepArgs::run_fault)
+    int wait_policy = 0;              // "wait_policy": how cvo_hip_align's calling thread waits between looks at the pinned words:
+                                      // 0 spin (pause), 1 yield (sched_yield), 2 sleep (50 us naps)
+};
+
 struct cvo_hip_ctx {
+    CtxOptions opt;
+    int no_run_backoff = 0;              // registrations to go without resident runs (one of them timed out, job_pump)
+    long long run_timeouts = 0;          // resident runs of this context that gave up on an exchange (cvo_hip_get_option "run_timeouts")
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
@@ -345,6 +376,7 @@ struct AlignJob {
     bool spec_pending = false;  // ... and that run was sent on spec (job_pump: the first run of a registration)
     bool paced_nb = false;  // a registration on its own inside cvo_hip_align_many: the paced steps of job_pump, one look per call
     int idle_seen = 0;      // ... and how often in a row its stream was found idle with the mirrors where they were
+    int restarts = 0;       // times this registration was begun again without resident runs (a run of it timed out)
     bool paced = false;     // cvo_hip_align only: the calling thread has nothing else to pump and may sit in the
                             // paced loop of job_pump (align_many's blocking fall-back must keep its round-robin going:
                             // the other jobs -- the peer ranks of a mailbox world among them -- run dry otherwise)
@@ -352,10 +384,9 @@ struct AlignJob {
 
 // ---- cvo_capi.cpp
 int fail(cvo_hip_ctx *ctx, int code, const char *msg);
-bool env_no_cand();
-bool env_no_graph();
-bool env_sync_upload();
-bool env_engine_debug();
+bool engine_debug_on();
+int apply_option(cvo_hip_ctx *ctx, const char *key, double value);
+inline bool runs_allowed(const cvo_hip_ctx *ctx) { return ctx->allow_run && ctx->no_run_backoff <= 0; }
 const char *params_problem(const cvo_hip_params &p);
 DevParams make_dev_params(const cvo_hip_params &p);
 // ---- cvo_clouds.cpp
@@ -394,6 +425,7 @@ int run_plan(const Slot *tab, PlanCache &cache, const std::vector<TLaunch> &plan
 int record_iteration(cvo_hip_ctx *ctx, std::vector<RecOp> &ops, int trace_cap);
 int prepare_lone_plan(cvo_hip_ctx *ctx, int trace_cap);
 int launch_batch(cvo_hip_ctx *ctx, int tag0, int trace_cap, bool with_run = false, int slots = kBatch, bool small_run = false);
+constexpr int kNoRunBackoff = 64;    // registrations a context goes without resident runs after one of them timed out
 constexpr int kBigRunBackoff = 16;   // registrations a context keeps its large runs away after one of them found the compute units taken
 constexpr int kShortBatch = 2;      // classic slots of a batch of a plan that has a resident run (job_pump; an even number, see kBatch)
 constexpr int kRunBatchSlots = 2;   // classic slots behind the resident run of a RUN batch (an even number, see kBatch)

@@ -39,7 +39,7 @@ void decide_scheme(cvo_hip_ctx *ctx)
     {
         // (with resident runs the narrow iterations no longer run these launches: the wide ones want the blocks -- 10k x 10k
         // 256 / 512 / 1024 blocks per pass 752 / 869 / 913 registrations/s, 6k 950 / 966 / 950, 3k 1 176 / 1 157 / 1 074: profiles/r05_ab.txt 7)
-        const bool runs = ctx->allow_run && ctx->fixed.np <= 65536 && ctx->moving.np <= 65536;
+        const bool runs = runs_allowed(ctx) && ctx->fixed.np <= 65536 && ctx->moving.np <= 65536;
         ctx->proc_blocks = ctx->proc_blocks_default =
             npairs <= 2.5e7 ? PROC_BLOCKS / 4 : (npairs <= (runs ? 6.0e7 : 1.5e8) ? PROC_BLOCKS / 2 : PROC_BLOCKS);
     }
@@ -62,6 +62,7 @@ int job_begin(AlignJob &j)
         if (rcm) return rcm;
     }
     const cvo_hip_params &p = ctx->prm;
+    if (ctx->no_run_backoff > 0) --ctx->no_run_backoff;   // (a resident run of this context timed out not long ago: runs_allowed)
     if (p.mode == CVO_HIP_MODE_ACVO) {   // tail of acvo::set_pcd (ref src/adaptive_cvo.cpp:476-478)
         s->ell = p.ell_init;
         s->ell_max = p.ell_max_init;
@@ -123,7 +124,7 @@ int job_begin(AlignJob &j)
     // hold declines, which costs its launch and one head)
     ctx->run_nnz_max = ctx->run_g_max * RUN_BLOCK * (RUN_R + RUN_L);
     if (ctx->big_run_backoff > 0) --ctx->big_run_backoff;
-    if (const char *e = getenv("CVO_HIP_RUN_CAND")) ctx->run_nnz_max = atoi(e);   // (tuning switch)
+    if (ctx->opt.run_cand > 0) ctx->run_nnz_max = ctx->opt.run_cand;   // (tuning switch "run_candidates_max")
     j.phase = p.max_iter <= 0 ? 1 : 0;
     if (j.phase == 1) {
         HIP_TRY(ctx, hipMemcpyAsync(&ctx->st_host[0], ctx->st, sizeof(DevState), hipMemcpyDeviceToHost,
@@ -146,13 +147,15 @@ int job_finish(AlignJob &j)
         // exchange of this world would mismatch or time out.  The mailboxes are unusable until every rank
         // has called cvo_hip_mailbox_create / _connect again; sharded calls are refused until then.
         ctx->mail_broken = true;
-        if (getenv("CVO_HIP_COMM_DEBUG"))
+        if (ctx->opt.comm_debug)
             fprintf(stderr, "[cvo_hip] rank %d of %d: exchange timed out at iteration k = %d (executed %d), mail_seq %llu, mail_snap %llu, slots %d, twist in launch %d\n",
                     ctx->mail_rank, ctx->mail_world, f.k, f.n_exec, (unsigned long long)f.mail_seq, (unsigned long long)f.mail_snap, f.n_slots,
                     (int)(ctx->plan.size() == 4));
         return fail(ctx, CVO_HIP_ERR_COMM, "mailbox all-reduce timed out: a peer rank never delivered its partial sums "
                                            "(the mailboxes must be created and connected again on every rank)");
     }
+    if (f.done == DONE_RUN_TIMEOUT)   // (job_pump registers again without runs; this is the second time-out in a row, which cannot be a run's)
+        return fail(ctx, CVO_HIP_ERR_RUN, "a resident run timed out and the registration could not be redone without runs");
     if (f.done == RUNNING || f.done == NEED_BIGGER_LIST)
         return fail(ctx, CVO_HIP_ERR_INVALID, "align loop ended without a verdict");
     const int executed = f.n_exec;
@@ -282,11 +285,15 @@ int job_pump(AlignJob &j, bool block)
                     __builtin_ia32_pause();
                     continue;
                 }
-                __builtin_ia32_pause();
+                // (how the calling thread waits between two looks: it spins by default -- one core per concurrent cvo_hip_align, the
+                // shortest reaction --; "wait_policy" 1 gives the core away between looks, 2 naps for 50 us)
+                if (ctx->opt.wait_policy == 0) __builtin_ia32_pause();
+                else if (ctx->opt.wait_policy == 1) std::this_thread::yield();
+                else std::this_thread::sleep_for(std::chrono::microseconds(50));
                 // The mirrors only move while the queued kernels run.  A fault, a stream in an error state or a
                 // post kernel that never ran would leave this thread spinning for ever: now and then ask the
                 // stream itself (a batch lasts ~0.25 ms; 2^14 pauses are about that long).
-                if ((++spins & 0x3fffu) == 0u) {
+                if ((++spins & (ctx->opt.wait_policy == 0 ? 0x3fffu : (ctx->opt.wait_policy == 1 ? 0x3ffu : 0x7u))) == 0u) {
                     const hipError_t q = hipStreamQuery(loop_stream(ctx));
                     if (q != hipSuccess && q != hipErrorNotReady)
                         return finish_with(fail(ctx, CVO_HIP_ERR_HIP, "the stream of the align loop reports an error"));
@@ -380,6 +387,23 @@ int job_pump(AlignJob &j, bool block)
     if (q == hipErrorNotReady) return 0;
     if (q != hipSuccess) return finish_with(fail(ctx, CVO_HIP_ERR_HIP, "state event failed"));
     const DevState &cur = ctx->st_host[0];
+    if (cur.done == DONE_RUN_TIMEOUT && j.restarts == 0 && !j.in_group) {
+        // A resident run gave up on an exchange (kt_run: a block of it did not arrive within the limit -- GPU scheduling, most
+        // likely another process's kernels on the compute units).  Nothing of the run is in the state and the caller's object
+        // has not been touched: the registration is begun again, this time -- and for this context's next registrations --
+        // without runs.  Same result, bit for bit (runs change nothing); the frame is not lost.  The run's exchange rows may hold
+        // words of the exchanges some blocks were ahead by: the next run's numbers start well past them.
+        ++ctx->run_timeouts;
+        ++j.restarts;
+        ctx->no_run_backoff = kNoRunBackoff + 1;   // (job_begin takes one off)
+        const unsigned long long seq = cur.run_seq + 4096ull;
+        if (hipStreamSynchronize(loop_stream(ctx)) != hipSuccess ||
+            hipMemcpy(reinterpret_cast<char *>(ctx->st) + offsetof(DevState, run_seq), &seq, sizeof(seq), hipMemcpyHostToDevice) != hipSuccess)
+            return finish_with(fail(ctx, CVO_HIP_ERR_RUN, "a resident run timed out and the state could not be reset"));
+        const int rc = job_begin(j);
+        if (rc) return finish_with(rc);
+        return 0;
+    }
     if (cur.done != NEED_BIGGER_LIST) return finish_with(job_finish(j));
     // grow the overflowed list(s) and resume from the parked iteration
     int rc = CVO_HIP_OK;

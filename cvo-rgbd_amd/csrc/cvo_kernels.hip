@@ -1408,8 +1408,11 @@ __device__ __forceinline__ bool step_twist_body(const ProcessArgs &a, DevState *
         if (blockIdx.x == 0 && tid == 0 && ovf != 0u) tot[8] = __builtin_nan("");
         const bool comm_ok = mailbox_allreduce_every_block(*a.comm, a.st, hd, tot, RED_STEP - RED_FLOW, sh_mail, &sh_fail);
         if (!comm_ok) {
-            if (blockIdx.x == 0 && tid == 0) {
-                hd->done = DONE_COMM_ERROR;
+            // (ANY block: the limit is per block, with a clock of its own -- a block other than 0 that gives up while block 0 still
+            // gets its answer writes no step row, and the next head must not reduce a stale one without knowing; every writer stores
+            // the same value)
+            if (tid == 0) {
+                __hip_atomic_store(&hd->done, (int32_t)DONE_COMM_ERROR, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (a.done_mirror) *a.done_mirror = DONE_COMM_ERROR;
             }
             return false;
@@ -2694,7 +2697,8 @@ CVO_HEAD_KERNELS(_w4, 4)
 // candidate record that fits into the registers, and it ends after the slot whose head has named a list build
 // (the filter blocks of the next classic flow launch make it; two classic slots later the next run starts on the new
 // record), when the loop stops, or after `run_iters` iterations.  All blocks decide the same from the same inputs.
-// A poll that does not fill within RUN_TIMEOUT_TICKS ends the registration with DONE_COMM_ERROR instead of hanging.
+// A poll that does not fill within its limit (PostStepArgs::run_timeout_ticks, else RUN_TIMEOUT_TICKS) ends the run with DONE_RUN_TIMEOUT
+// instead of hanging; the host then registers the pair again without runs.
 constexpr long long RUN_TIMEOUT_TICKS = 100000000LL;   // 1 s of the 100 MHz wall clock
 enum { RUN_V_STALL = 1, RUN_V_BUILD = 2 };            // the head block's verdict on the slot that is running
 enum { RUN_GO = 1, RUN_ABORT = 2 };                    // ... and on a large run's entry (RunMail::entry_go)
@@ -2707,11 +2711,11 @@ constexpr long long RUN_ENTRY_TICKS = 20000LL;         // 200 us: how long the h
 template <int NV, int KMAX>
 __device__ __forceinline__ bool run_exchange_k(RunMail *mail, const int row, const int g, const unsigned long long seq, const double *vals,
                                              double *all /* LDS [RUN_G * NV] */, double *part /* LDS [8 * NV] */, double *tot /* LDS [NV] */,
-                                             int *s_fail, unsigned *verdict_out, unsigned *s_verdict)
+                                             int *s_fail, unsigned *verdict_out, unsigned *s_verdict, const long long timeout_ticks)
 {
     const int tid = threadIdx.x;
     const unsigned tag = (unsigned)seq;
-    unsigned long long *slot = &mail->w[seq & 1ull][0][0];
+    unsigned long long *slot = &mail->w[seq & (unsigned long long)(RUN_GEN - 1)][0][0];   // (four generations: cvo_device.h RunMail)
     if (tid == 0) *s_fail = 0;
     __syncthreads();   // (vals complete)
     if (row >= 0 && tid < 2 * NV) {
@@ -2747,7 +2751,7 @@ __device__ __forceinline__ bool run_exchange_k(RunMail *mail, const int row, con
                     if (wi < nrow) reinterpret_cast<unsigned *>(all)[wi] = (unsigned)w[k];   // (little endian: word 2k is the low half of value k)
                     else if (wi == nrow && verdict_out) *s_verdict = (unsigned)w[k];
                 }
-            } else if ((long long)wall_clock64() - t0 > RUN_TIMEOUT_TICKS) {
+            } else if ((long long)wall_clock64() - t0 > timeout_ticks) {
                 *s_fail = 1;
                 break;
             } else {
@@ -2773,12 +2777,13 @@ __device__ __forceinline__ bool run_exchange_k(RunMail *mail, const int row, con
 }
 template <int NV>
 __device__ __forceinline__ bool run_exchange(RunMail *mail, const int row, const int g, const unsigned long long seq, const double *vals,
-                                             double *all, double *part, double *tot, int *s_fail, unsigned *verdict_out, unsigned *s_verdict)
+                                             double *all, double *part, double *tot, int *s_fail, unsigned *verdict_out, unsigned *s_verdict,
+                                             const long long timeout_ticks)
 {
     static_assert(RUN_G_SMALL * 2 * RUN_NV + 1 <= 2 * RUN_BLOCK, "two words per thread up to RUN_G_SMALL solvers");
     constexpr int KBIG = (RUN_G * 2 * NV + 1 + RUN_BLOCK - 1) / RUN_BLOCK;
-    if (g <= RUN_G_SMALL) return run_exchange_k<NV, 2>(mail, row, g, seq, vals, all, part, tot, s_fail, verdict_out, s_verdict);
-    return run_exchange_k<NV, KBIG>(mail, row, g, seq, vals, all, part, tot, s_fail, verdict_out, s_verdict);
+    if (g <= RUN_G_SMALL) return run_exchange_k<NV, 2>(mail, row, g, seq, vals, all, part, tot, s_fail, verdict_out, s_verdict, timeout_ticks);
+    return run_exchange_k<NV, KBIG>(mail, row, g, seq, vals, all, part, tot, s_fail, verdict_out, s_verdict, timeout_ticks);
 }
 
 // The passes of a run over NR candidates per lane, straight-line: the NR chains (transform, exact test, a float64 exp, the
@@ -3182,6 +3187,7 @@ kt_run(const Slot *__restrict__ tab, const int qs)
     bool comm_ok = true;
     const int need_d2 = pa.need_d2;
     const int iters = ps.run_iters > 0 ? ps.run_iters : 1;
+    const long long run_timeout = ps.run_timeout_ticks > 0 ? ps.run_timeout_ticks : RUN_TIMEOUT_TICKS;
     // the head block's verdict on the slot that begins travels with the slot's second exchange (its number is known in advance)
     auto post_verdict = [&](const unsigned long long seq_b) {
         if (head_block && tid == 0) {
@@ -3193,6 +3199,7 @@ kt_run(const Slot *__restrict__ tab, const int qs)
     post_verdict(seq0 + 2);
     RUN_CLK(0);
     for (int it = 0;; ++it) {
+        if (ps.run_fault > 0 && srow == 0 && it + 1 == ps.run_fault) return;   // (test switch: a solver that is lost to its peers)
         // ---- this slot's constants from the head in LDS: plain broadcast reads into vector registers (through scalar
         // registers -- v_readfirstlane of every word -- the kernel spilled 200 of them and an iteration's two passes spent
         // more time moving constants than on their pairs, profiles/r05_ab.txt 3)
@@ -3234,7 +3241,7 @@ kt_run(const Slot *__restrict__ tab, const int qs)
         }
         RUN_CLK(4);
         ++nexch;
-        if (!run_exchange<NACC_FLOW>(ps.run_mail, srow, g, seq0 + nexch, s_vals, s_all, s_part, s_tot, &s_fail, nullptr, &s_verdict)) { comm_ok = false; break; }
+        if (!run_exchange<NACC_FLOW>(ps.run_mail, srow, g, seq0 + nexch, s_vals, s_all, s_part, s_tot, &s_fail, nullptr, &s_verdict, run_timeout)) { comm_ok = false; break; }
         RUN_CLK(5);
         // ---- the tail of compute_flow (ref src/cvo.cpp:201-209): twist, Taylor constants
         if (tid < 64) {
@@ -3281,7 +3288,7 @@ kt_run(const Slot *__restrict__ tab, const int qs)
         RUN_CLK(8);
         ++nexch;
         unsigned verdict = 0u;
-        if (!run_exchange<NACC_STEP>(ps.run_mail, srow, g, seq0 + nexch, s_vals, s_all, s_part, s_tot, &s_fail, &verdict, &s_verdict)) { comm_ok = false; break; }
+        if (!run_exchange<NACC_STEP>(ps.run_mail, srow, g, seq0 + nexch, s_vals, s_all, s_part, s_tot, &s_fail, &verdict, &s_verdict, run_timeout)) { comm_ok = false; break; }
         RUN_CLK(9);
         if (verdict & RUN_V_STALL) {
             // no buffer holds every pair for this slot's transform (a jump): what the passes have summed is void.  The head goes
@@ -3396,10 +3403,16 @@ kt_run(const Slot *__restrict__ tab, const int qs)
 #endif
         return;
     }
-    if (!comm_ok) {   // an exchange timed out: nothing of this run can be trusted
+    if (!comm_ok) {
+        // An exchange timed out: nothing this run has summed can be trusted -- and nothing of it is in the state.  WHAT A RUN WRITES
+        // BEFORE ITS EXIT: row 1 of the overflow flags cleared (they were clear: the entry head saw them), the counters of a build its
+        // heads named (the build's own launch zeroes them again), trace records (rewritten with the same values), the host's hint and
+        // progress mirrors; the head, part_step and the run counters only on the way out, below and in head_publish.  The verdict is
+        // the run's own -- no mailbox is involved, the context's exchanges with other ranks (if it has any) are intact --, and the host
+        // answers it by registering the pair again without runs (cvo_job.cpp job_pump).
         if (tid == 0) {
-            gst->done = DONE_COMM_ERROR;
-            if (ps.done_mirror) *ps.done_mirror = DONE_COMM_ERROR;
+            gst->done = DONE_RUN_TIMEOUT;
+            if (ps.done_mirror) *ps.done_mirror = DONE_RUN_TIMEOUT;
         }
     }
     if (tid == 0) {

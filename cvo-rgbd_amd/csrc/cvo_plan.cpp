@@ -66,10 +66,7 @@ int ensure_list(cvo_hip_ctx *ctx, int list, int nrows, int nb, double at_least)
         min_sub = TILE_STAGE;
     }
     if (at_least <= 0.0) {   // test hook: start from a tiny list to exercise the grow-and-redo path
-        if (const char *e = getenv("CVO_HIP_LIST_INIT")) {
-            const double v = atof(e);
-            if (v > 0.0) want = v;
-        }
+        if (ctx->opt.list_init > 0.0) want = ctx->opt.list_init;   // ("list_init")
     }
     want = std::max(want, at_least);
     want = std::min(want, 4.0e9);
@@ -258,7 +255,7 @@ int enqueue_process(cvo_hip_ctx *ctx, int mode, int list, DevBuf &part, const fl
     a.check_done = check_done;
     a.need_d2 = (ctx->prm.mode == CVO_HIP_MODE_ACVO || !ctx->in_loop || ctx->cur_trace_cap > 0) ? 1 : 0;   // (a trace record holds the sum of the weights)
     a.weight = ctx->prm.color_scale > 0.0f ? 1 : 0;   // the MATLAB object's weight: its own instantiation
-    const bool no_pack = getenv("CVO_HIP_NO_PACK") != nullptr;   // (test switch, read when a plan is recorded: 8 + 4 byte kept entries)
+    const bool no_pack = ctx->opt.no_pack;   // (test switch "kept_pack" = 0: 8 + 4 byte kept entries)
     a.kept_packed = (!no_pack && ctx->fixed.np <= 65536 && ctx->moving.np <= 65536) ? 1 : 0;
     if (!a.kept_packed && !no_pack && a.weight == 0 && ctx->fixed.np <= 262144 && ctx->moving.np <= 262144) {
         // 8 bytes for larger clouds too (ProcessArgs::kept_packed == 2): a member's weight a = ck * k is a positive
@@ -275,7 +272,7 @@ int enqueue_process(cvo_hip_ctx *ctx, int mode, int list, DevBuf &part, const fl
         }
     }
     if ((mode == PROC_FLOW && list == LIST_XY) || (mode == PROC_SELF && (list == LIST_XX || list == LIST_YY))) {
-        const bool no_cand = env_no_cand();
+        const bool no_cand = ctx->opt.no_cand;
         ctx->ck_nblk[list] = 0;
         // (clouds of up to 65536 rows: i and j share a word.  12-byte records for larger clouds were built, bit-identical,
         // and measured SLOWER -- one 200k x 200k registration 81.3 -> 91.0 ms, 100k x 100k 21.7 -> 23.8, acvo 18.9 -> 21.8: at
@@ -300,7 +297,7 @@ int enqueue_process(cvo_hip_ctx *ctx, int mode, int list, DevBuf &part, const fl
         // Head mode (one registration on its own, plan_lone): the flow pass keeps a candidate record per buffer of
         // the double-buffered xy list -- the pass after a buffer is switched to expands and records, the passes
         // over the same buffer stream (DevHead::xy_ck).  The kernels of every other plan ignore the fields.
-        const bool no_cand = env_no_cand();
+        const bool no_cand = ctx->opt.no_cand;
         if (mode == PROC_FLOW && list == LIST_XY && ctx->plan_recording && ctx->lone && ctx->allow_head && !multi_rank(ctx) &&
             !no_cand && a.kept_packed == 1 && !(ctx->prm.color_scale > 0.0f)) {
             const size_t bytes = (size_t)ctx->lists[LIST_KEPT].cap * sizeof(uint2);
@@ -324,7 +321,7 @@ int enqueue_process(cvo_hip_ctx *ctx, int mode, int list, DevBuf &part, const fl
         a.async_self = list == LIST_XX ? 1 : 2;
         a.tiles_b = (const TileEntry *)ctx->lists[list == LIST_XX ? LIST_XXB : LIST_YYB].a.p;
         // (head mode: candidate records for both buffers of the self lists too, see the xy list above)
-        const bool no_cand = env_no_cand();
+        const bool no_cand = ctx->opt.no_cand;
         if (ctx->plan_recording && ctx->lone && ctx->allow_head && !multi_rank(ctx) && !no_cand && a.kept_packed == 1 &&
             !(ctx->prm.color_scale > 0.0f)) {
             const int l = list == LIST_XX ? 0 : 1;
@@ -449,10 +446,7 @@ DevParams loop_params(const cvo_hip_ctx *ctx)
     // build is a large part of an iteration, 25 % beats 15 % (32 distinct 10k x 10k pairs 2273 ->
     // 2398 registrations/s, one at a time 1.77 -> 1.71 ms); at 20k x 20k it loses (917 -> 792).
     dp.list_margin = ((double)ctx->fixed.n * (double)ctx->moving.n <= 2.0e8) ? 0.25f : 0.15f;
-    if (const char *e = getenv("CVO_HIP_LIST_MARGIN")) {   // (test switch; 0 = rebuild every iteration)
-        const double m = atof(e);
-        if (m >= 0.0 && m <= 4.0) dp.list_margin = (float)m;
-    }
+    if (ctx->opt.list_margin >= 0.0f) dp.list_margin = ctx->opt.list_margin;   // (test switch "list_margin"; 0 = rebuild every iteration)
     dp.async_xy = ctx->use_async ? 1 : 0;
     dp.async_self = ctx->use_async_self ? 1 : 0;
     // Head mode: a build is named a slot earlier than it is made and costs its launch 10 us; later is better
@@ -462,7 +456,7 @@ DevParams loop_params(const cvo_hip_ctx *ctx)
     // (plans with resident runs, the conditions of enqueue_step: what a run's registers hold -- the plan keeps a list that has become
     // wide while its record still fits, plan_xy_async)
     if (ctx->use_async && ctx->lone && ctx->allow_head && ctx->allow_run && !multi_rank(ctx) && ctx->prm.mode == CVO_HIP_MODE_CVO &&
-        !(ctx->prm.color_scale > 0.0f) && !ctx->post_dbg && ctx->allow_merge && ctx->fixed.np <= 65536 && ctx->moving.np <= 65536 && !env_no_cand())
+        !(ctx->prm.color_scale > 0.0f) && !ctx->post_dbg && ctx->allow_merge && ctx->fixed.np <= 65536 && ctx->moving.np <= 65536 && !ctx->opt.no_cand)
         dp.run_cand_cap = (float)ctx->run_g_max * (float)(RUN_BLOCK * (RUN_R + RUN_L));
     return dp;
 }
@@ -591,7 +585,7 @@ int enqueue_step(cvo_hip_ctx *ctx, int check_done, bool do_math, cvo_hip_trace *
     pa.comm = ctx->comm_table;
     // Resident runs (cvo_kernels.hip kt_run): one cvo registration with its launches to itself, in head mode, on
     // candidate records (plan_lone decides whether the plan really is a head-mode plan)
-    if (ctx->plan_recording && ctx->lone && ctx->allow_head && ctx->allow_run && ctx->use_async && ctx->merge_twist &&
+    if (ctx->plan_recording && ctx->lone && ctx->allow_head && runs_allowed(ctx) && ctx->use_async && ctx->merge_twist &&
         !multi_rank(ctx) && ctx->prm.mode == CVO_HIP_MODE_CVO && !(ctx->prm.color_scale > 0.0f) && !ctx->post_dbg) {
         const bool fresh = ctx->run_mail.p == nullptr;
         if (ensure_buf(ctx, ctx->run_mail, sizeof(RunMail)) == CVO_HIP_OK) {
@@ -600,6 +594,8 @@ int enqueue_step(cvo_hip_ctx *ctx, int check_done, bool do_math, cvo_hip_trace *
             pa.run_mirror = ctx->run_mirror;
             pa.run_iters = 64;
             pa.run_g_max = ctx->run_g_max;
+            pa.run_timeout_ticks = (long long)(ctx->opt.run_timeout_ms * 1.0e5);   // (100 MHz; 0: the kernel's own second)
+            pa.run_fault = ctx->opt.run_fault;
         } else {   // (an optimisation: without its memory the plan has no runs)
             (void)hipGetLastError();
             ctx->err = "";
@@ -607,7 +603,7 @@ int enqueue_step(cvo_hip_ctx *ctx, int check_done, bool do_math, cvo_hip_trace *
     }
     if (ctx->plan_recording && ctx->lone) pa.hint_mirror = ctx->hint_mirror;
     // (one registration on its own, one rank: its final head goes to pinned memory with the verdict, job_pump)
-    if (ctx->plan_recording && ctx->lone && !multi_rank(ctx) && !getenv("CVO_HIP_NO_FINAL_MIRROR")) pa.final_mirror = ctx->final_mirror;
+    if (ctx->plan_recording && ctx->lone && !multi_rank(ctx) && !ctx->opt.no_final_mirror) pa.final_mirror = ctx->final_mirror;
     if (host_reduce(ctx)) {
         pa.flags = POST_REDUCE;
         emit_post_step(ctx, pa);
@@ -680,7 +676,7 @@ int enqueue_iterations(cvo_hip_ctx *ctx, int count, int tag0, int trace_cap)
     // the stream-level all-reduces need their own launches in between; ranks that share ONE GPU -- tests, rehearsals -- keep the
     // single-block exchange: every block of a rank's launch spinning for a peer keeps that peer's kernels off the GPU.  The test
     // switch forces the in-launch exchange there, for clouds whose launches leave room)
-    ctx->merge_twist = ctx->allow_merge && !host_reduce(ctx) && !(ctx->comm_table && ctx->mail_shared_device && !getenv("CVO_HIP_TWIST_ON_SHARED_GPU"));
+    ctx->merge_twist = ctx->allow_merge && !host_reduce(ctx) && !(ctx->comm_table && ctx->mail_shared_device && !ctx->opt.twist_on_shared_gpu);
     ctx->in_loop = true;
     ctx->cur_trace = ctx->trace_dev;
     ctx->cur_trace_cap = trace_cap;
@@ -1093,7 +1089,13 @@ int prepare_lone_plan(cvo_hip_ctx *ctx, int trace_cap)
     Slot slot;
     if (!plan_lone(ops, slot, ctx->plan, ctx->allow_head, &ctx->head_mode, &ctx->plan_pre))
         return fail(ctx, CVO_HIP_ERR_INVALID, "launch plan does not fit the argument table");
-    if (!ctx->plan_pre.empty() && run_allow_lds() != hipSuccess) return fail(ctx, CVO_HIP_ERR_HIP, "resident runs: the shared-memory attribute was refused");
+    if (!ctx->plan_pre.empty() && run_allow_lds() != hipSuccess) {
+        // (resident runs are an optimisation: a device or partition that refuses kt_run its LDS gets the plain head-mode plan -- the
+        // plan's classic launches are complete without the run in front of them)
+        (void)hipGetLastError();
+        ctx->plan_pre.clear();
+        ctx->allow_run = false;
+    }
     set_build_masks(slot, ctx->plan, ctx->table.masks(), 0);
     ctx->plan_has_final_mirror = false;
     for (const TLaunch &l : ctx->plan)   // (the launches whose heads publish: the post-step launch, or the head-mode flow launch)

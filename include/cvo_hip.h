@@ -40,7 +40,10 @@ typedef enum cvo_hip_status {
     CVO_HIP_ERR_HIP = -2,       /* a HIP runtime call failed */
     CVO_HIP_ERR_NOMEM = -3,
     CVO_HIP_ERR_COMM = -4,      /* RCCL failure */
-    CVO_HIP_ERR_NODEVICE = -5   /* no usable gfx950 device */
+    CVO_HIP_ERR_NODEVICE = -5,  /* no usable gfx950 device */
+    CVO_HIP_ERR_RUN = -6        /* a resident run timed out AND the registration could not be redone without runs
+                                 * (a time-out alone is not an error: the pair is registered again on the launch-per-pass
+                                 * path, same result) */
 } cvo_hip_status;
 
 /* CVO_HIP_MODE_MATLAB is accepted by cvo_hip_default_params() only: it returns mode = CVO with
@@ -307,6 +310,27 @@ int cvo_hip_function_inner_product_clouds(cvo_hip_ctx *ctx, float ell, const flo
  * ~14k x 14k points) captures nothing: its few launches per iteration -- for cvo most iterations run
  * inside two or three launches altogether -- go out eagerly, which is faster there. */
 int cvo_hip_set_graph_capture(cvo_hip_ctx *ctx, int enable);
+
+/* Policy switches of a context, by name (value: 0 / 1 for switches).  What a host program may want to set:
+ *   "graph_capture"      as cvo_hip_set_graph_capture
+ *   "head_graphs"        1: registrations that run on their own (two launches per iteration, resident runs) go out as captured
+ *                        batches as well (default 0: eager launches are faster there)
+ *   "list_pass_blocks"   blocks of the list kernels of a registration on its own: 64 / 128 / 256 / 512 / 1024, 0 = by the clouds
+ *   "mailbox_timeout_s"  how long an exchange waits for a peer rank (default 5; read by the next cvo_hip_mailbox_connect)
+ *   "wait_policy"        how the thread inside cvo_hip_align waits between two looks at the loop's pinned progress words:
+ *                        0 spin (default: one core per concurrent caller, shortest reaction), 1 sched_yield, 2 naps of 50 us
+ *   "resident_runs"      0: no resident runs (csrc/cvo_kernels.hip kt_run); "run_solvers_max": their blocks at most
+ *   "run_timeout_ms"     how long an exchange inside a resident run waits for a block of its launch (default 1000).  A run that
+ *                        times out costs that wait, not the frame: the pair is registered again without runs, and the context
+ *                        goes without runs for its next 64 registrations ("run_timeouts" counts them, read-only)
+ * and the test switches of tests/ ("head_mode", "merged_launches", "async_builds", "candidate_records", "kept_pack",
+ * "list_init", "list_margin", "final_mirror", "one_launch_hand_over", "small_calls_alone", "fused_groups", "engines",
+ * "run_candidates_max", "run_fault", "sync_upload", "no_graph", "twist_on_shared_gpu", "comm_debug", "engine_debug").
+ * The environment variables of the same switches only set the DEFAULTS, read once when a context is
+ * created.  A call that serves many contexts goes by its first context's switches.  Unknown key / bad value:
+ * CVO_HIP_ERR_INVALID. */
+int cvo_hip_set_option(cvo_hip_ctx *ctx, const char *key, double value);
+int cvo_hip_get_option(const cvo_hip_ctx *ctx, const char *key, double *value);
 
 /* Profiling: HIP events on the context's stream around every sweep launch. */
 int cvo_hip_set_profiling(cvo_hip_ctx *ctx, int enable);

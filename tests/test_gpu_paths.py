@@ -2,6 +2,7 @@
 row sharding, the RCCL hook (world size 1), list overflow + resume,
 function_inner_product, frame-to-frame state carry-over, full-size clouds."""
 import os
+import time
 
 import numpy as np
 import pytest
@@ -1268,3 +1269,97 @@ def test_small_align_many_calls_of_small_clouds_run_on_their_own(pkg, monkeypatc
     fused, st_fused = call()
     monkeypatch.delenv("CVO_HIP_NO_ALONE")
     assert alone == fused
+
+
+def test_options_by_name(pkg):
+    """cvo_hip_set_option / _get_option: the policy switches a host program sets per context (include/cvo_hip.h), the
+    environment only names their defaults at create.  Round trips, refusals, and a switch that takes effect: a registration
+    with "resident_runs" = 0 enters no run and ends in the same state."""
+    capi = pkg.capi
+    c = capi.Context(mode=capi.MODE_CVO, device=0)
+    assert c.get_option("resident_runs") == 1.0 and c.get_option("wait_policy") == 0.0
+    for key, val in (("head_graphs", 1), ("list_pass_blocks", 256), ("mailbox_timeout_s", 2.5), ("wait_policy", 1),
+                     ("run_timeout_ms", 250), ("run_solvers_max", 64), ("list_margin", 0.3), ("engines", 2)):
+        c.set_option(key, val)
+        assert c.get_option(key) == pytest.approx(val), key
+    c.set_option("list_pass_blocks", 0)
+    assert c.get_option("list_pass_blocks") == 0.0
+    for key, val in (("no_such_switch", 1), ("list_pass_blocks", 100), ("wait_policy", 7), ("mailbox_timeout_s", 0)):
+        with pytest.raises(capi.CvoHipError):
+            c.set_option(key, val)
+    with pytest.raises(capi.CvoHipError):
+        c.get_option("no_such_switch")
+    c.close()
+    xf, ff, xm, fm = pkg.data.synthetic_pair(3000, 3000, seed=4711)
+    res = []
+    for wait in (0, 1, 2):
+        for runs in (1, 0):
+            c = capi.Context(mode=capi.MODE_CVO, device=0)
+            c.set_option("resident_runs", runs)
+            c.set_option("wait_policy", wait)
+            c.set_fixed(xf, ff); c.set_moving(xm, fm)
+            st = capi.init_state(c.params)
+            it, _ = c.align(st, trace_cap=0)
+            rs = c.run_stats()
+            assert (rs[0] >= 1) == bool(runs), (runs, rs)
+            res.append((it, bytes(st)))
+            c.close()
+    assert all(r == res[0] for r in res)
+
+
+def test_a_resident_run_that_times_out_costs_its_wait_not_the_frame(pkg):
+    """Fail soft (csrc/cvo_kernels.hip kt_run "what a run writes before its exit", csrc/cvo_job.cpp job_pump): a solver block of a
+    resident run that never arrives -- the fault switch makes the first solver leave at the top of its third iteration without a
+    word -- makes its peers give up after "run_timeout_ms" with DONE_RUN_TIMEOUT; the host begins the registration again without
+    runs.  Same iterations, state and trace as a context that never had runs; the context counts the time-out, goes without runs for
+    its next registrations, and no mailbox is declared broken (a single-rank context has none).  Through cvo_hip_align and through
+    a small cvo_hip_align_many call (registrations on their own streams)."""
+    import torch
+    capi = pkg.capi
+    pairs = [pkg.data.synthetic_pair(3000, 2900 + 50 * b, seed=9100 + b) for b in range(3)]
+
+    def make(pr, **opts):
+        s = torch.cuda.Stream()
+        c = capi.Context(mode=capi.MODE_CVO, device=0, stream=s.cuda_stream)
+        for k, v in opts.items():
+            c.set_option(k, v)
+        c.set_fixed(pr[0], pr[1]); c.set_moving(pr[2], pr[3])
+        c._stream_keepalive = s
+        return c
+
+    def one(c, trace_cap=2000):
+        st = capi.init_state(c.params)
+        it, tr = c.align(st, trace_cap=trace_cap)
+        return it, bytes(st), [(t["k"], t["exit_code"], t["nnz"], t["step"], tuple(t["omega"]), tuple(t["v"])) for t in tr]
+
+    ref = []
+    for pr in pairs:
+        c = make(pr, resident_runs=0)
+        ref.append(one(c))
+        c.close()
+    # a healthy run first: nothing to report
+    c = make(pairs[0])
+    assert one(c) == ref[0] and c.run_stats()[0] >= 1 and c.get_option("run_timeouts") == 0.0
+    c.close()
+    # the fault, through cvo_hip_align
+    c = make(pairs[0], run_fault=3, run_timeout_ms=20)
+    t0 = time.perf_counter()
+    got = one(c)
+    wall = time.perf_counter() - t0
+    assert got == ref[0]
+    assert c.get_option("run_timeouts") == 1.0 and c.get_option("no_run_backoff") >= 60
+    assert wall < 1.0, wall   # (the 20 ms of the option, not the default second; no mailbox time-out of 5 s)
+    # the context's next registrations: no runs, no further time-outs, same answer
+    for _ in range(3):
+        assert one(c, 2000) == ref[0]
+    assert c.get_option("run_timeouts") == 1.0
+    c.close()
+    # ... and through a small align_many call: every registration on its own stream, every first run faulty
+    cs = [make(pr, run_fault=2, run_timeout_ms=20) for pr in pairs]
+    for rep in range(2):
+        states = [capi.init_state(c.params) for c in cs]
+        its = capi.align_many(cs, states)
+        assert [(i, bytes(s)) for i, s in zip(its, states)] == [(r[0], r[1]) for r in ref], rep
+    assert [c.get_option("run_timeouts") for c in cs] == [1.0] * len(cs)
+    for c in cs:
+        c.close()

@@ -158,4 +158,4 @@ its = capi.align_many(ctxs, states)
 bad_many = sum(1 for i, (it, s) in enumerate(zip(its, states)) if (it, bytes(s)) != refs[i])
 for c in ctxs: c.close()
 print("soak: %d cases, %d mismatches vs oracle, %d states that differ elsewhere, %d align_many differences, %.0f s" % (n_cases, bad, whole_diff, bad_many, time.time() - t0))
-sys.exit(1 if (bad or bad_many) else 0)
+sys.exit(1 if (bad or bad_many or whole_diff) else 0)
