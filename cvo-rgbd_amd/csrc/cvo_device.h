@@ -136,7 +136,8 @@ constexpr int RUN_MIRROR_ENTERED = 1 << 30;   // in the host's run mirror: the r
 constexpr int RUN_L = 8;             // ... and in LDS behind them (the widest runs only: 2 x 16 bytes per candidate, 128 KB per block)
 constexpr int RUN_CAP = RUN_LANES * (RUN_R + RUN_L);   // candidates a run holds at most: 2 031 616
 constexpr unsigned RUN_LDS_BYTES = (unsigned)RUN_L * 2u * (unsigned)RUN_BLOCK * 16u;   // dynamic LDS of kt_run
-constexpr int RUN_NV = 9;            // doubles per exchange at most (flow: 9, step: 4)
+constexpr int RUN_NV = 13;           // doubles per exchange at most (flow: 9, acvo 9 + 2 + 2; step: 4): the stride of a row of the mail
+constexpr int RUN_A = 4;             // acvo runs (kt_run_acvo): candidates per lane of each of the three records (xy, xx, yy), all in registers
 constexpr int RUN_GEN = 4;           // generations of the exchange rows (see above)
 struct RunMail {
     unsigned long long w[RUN_GEN][RUN_G + 1][2 * RUN_NV];   // (row RUN_G: the head block's verdict word)
@@ -809,7 +810,7 @@ constexpr int STEP_TWIST_ROWS_DIV = 4;   // k_step_twist writes nblk / 4 partial
 // One launch of an iteration through a table: which kernel, its geometry, which op[] it reads.
 enum TKernel { TK_FILTER = 0, TK_FILTER_GROUP, TK_FLOW, TK_FLOW_MATLAB, TK_STEP, TK_SELF, TK_SELF2, TK_STEP_TWIST,
                TK_FLOW_BUILD, TK_FLOW_BUILD3, TK_FLOW_BUILD6, TK_POST_FLOW, TK_POST_STEP,
-               TK_HFLOW_BUILD, TK_HFLOW_BUILD6, TK_HSTEP_TWIST, TK_RUN /* q = flow op | step op << 4 */,
+               TK_HFLOW_BUILD, TK_HFLOW_BUILD6, TK_HSTEP_TWIST, TK_RUN /* q = flow op | step op << 4 */, TK_RUN_ACVO /* likewise; the self passes: flow op + 1, + 2 */,
                TK_FLOW_D2 /* TK_FLOW is built without the sums of a and of a d2 (ProcessArgs::need_d2 == 0 in every slot); this one has them */ };   // head mode (cvo_kernels.hip "Head mode")
 // Head-mode launches carry the slot's parity and the mode in the bits above the op index of their
 // second kernel argument: qp = q | parity << 8 | QP_HEAD.

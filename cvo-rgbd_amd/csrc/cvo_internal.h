@@ -241,6 +241,7 @@ struct CtxOptions {
     bool twist_on_shared_gpu = false; // "twist_on_shared_gpu": in-launch exchange although the ranks share a GPU
     bool comm_debug = false;          // "comm_debug"
     bool post_debug = false;          // "post_debug" (environment only: the buffer is made at create)
+    bool no_acvo_run = false;         // "acvo_runs" = 0: resident runs for cvo registrations only (round 5's state)
     int engines_force = 0;            // "engines": engines of an align_many call (0: by the call's size)
     double list_init = 0.0;           // "list_init": first capacity of every list (0: by the clouds)
     float list_margin = -1.0f;        // "list_margin": width of the tile lists (< 0: by the clouds)
@@ -280,6 +281,7 @@ struct cvo_hip_ctx {
     int big_run_backoff = 0;              // registrations to go without runs of more than 32 solvers (one gave up at its entry hand-shake, job_pump)
     bool spec_first_run = true;           // the first run of a registration goes out on spec behind its first two slots (job_pump learns from each try)
     bool head_graphs = false;             // CVO_HIP_RUN_GRAPHS: head-mode plans go out as captured batches too (they launch eagerly by default)
+    int run_small_max = 0;                // ... and with the launch of RUN_G_SMALL + 1 blocks up to this many
     int run_nnz_max = 0;                  // a batch begins with a resident run when the record in use is expected to hold at most this many candidates
     std::vector<TLaunch> plan_pre;        // launches in front of a RUN batch's iterations (the kt_run launch); empty: the plan has no run
     std::vector<RecOp> *rec = nullptr;   // not null: record launches instead of issuing them

@@ -123,6 +123,13 @@ int job_begin(AlignJob &j)
     // run_hint: the record's count where the last head knew it, else an estimate with 5 % of room; a run that finds more than it can
     // hold declines, which costs its launch and one head)
     ctx->run_nnz_max = ctx->run_g_max * RUN_BLOCK * (RUN_R + RUN_L);
+    // (acvo: a run holds RUN_A candidates per lane of EACH of its three records, and the hint speaks of the xy record alone -- the
+    // self records of two copies of a surface hold ~1.2 x as many)
+    ctx->run_small_max = 3 * RUN_G_SMALL * RUN_BLOCK;
+    if (ctx->prm.mode == CVO_HIP_MODE_ACVO) {
+        ctx->run_nnz_max = (int)(0.8 * ctx->run_g_max * RUN_BLOCK * RUN_A);
+        ctx->run_small_max = (int)(0.8 * 2 * RUN_G_SMALL * RUN_BLOCK);
+    }
     if (ctx->big_run_backoff > 0) --ctx->big_run_backoff;
     if (ctx->opt.run_cand > 0) ctx->run_nnz_max = ctx->opt.run_cand;   // (tuning switch "run_candidates_max")
     j.phase = p.max_iter <= 0 ? 1 : 0;
@@ -250,11 +257,11 @@ int job_pump(AlignJob &j, bool block)
                 const bool big_ok = ctx->big_run_backoff <= 0;   // (see above)
                 const bool spec = first_choice && ctx->spec_first_run && big_ok;
                 if (spec) j.spec_pending = true;
-                const bool with_run = run_plan_ && (spec || (hint > 0 && hint <= (big_ok ? ctx->run_nnz_max : 3 * RUN_G_SMALL * RUN_BLOCK)));
+                const bool with_run = run_plan_ && (spec || (hint > 0 && hint <= (big_ok ? ctx->run_nnz_max : ctx->run_small_max)));
                 // (a plan with runs is launched eagerly and in the shortest batches: a run can only start at a batch's head, and the
                 // slot it may start at is two or three slots after the head that first says so)
                 const bool near_run = ctx->head_mode && !ctx->plan_pre.empty() && !with_run;
-                const bool small_run = with_run && !spec && hint > 0 && hint <= 3 * RUN_G_SMALL * RUN_BLOCK;   // (a launch of 33 blocks does)
+                const bool small_run = with_run && !spec && hint > 0 && hint <= ctx->run_small_max;   // (a launch of 33 blocks does)
                 const int rc = launch_batch(ctx, j.executed_base + j.enq, j.trace_cap, with_run, near_run ? kShortBatch : kBatch, small_run);
                 if (rc) return finish_with(rc);
                 if (with_run) { ++j.runs_enq; j.run_waiting = true; }

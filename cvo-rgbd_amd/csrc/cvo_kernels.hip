@@ -2780,7 +2780,7 @@ __device__ __forceinline__ bool run_exchange(RunMail *mail, const int row, const
                                              double *all, double *part, double *tot, int *s_fail, unsigned *verdict_out, unsigned *s_verdict,
                                              const long long timeout_ticks)
 {
-    static_assert(RUN_G_SMALL * 2 * RUN_NV + 1 <= 2 * RUN_BLOCK, "two words per thread up to RUN_G_SMALL solvers");
+    static_assert(RUN_G_SMALL * 2 * NV + 1 <= 2 * RUN_BLOCK, "two words per thread up to RUN_G_SMALL solvers");
     constexpr int KBIG = (RUN_G * 2 * NV + 1 + RUN_BLOCK - 1) / RUN_BLOCK;
     if (g <= RUN_G_SMALL) return run_exchange_k<NV, 2>(mail, row, g, seq, vals, all, part, tot, s_fail, verdict_out, s_verdict, timeout_ticks);
     return run_exchange_k<NV, KBIG>(mail, row, g, seq, vals, all, part, tot, s_fail, verdict_out, s_verdict, timeout_ticks);
@@ -2792,9 +2792,9 @@ __device__ __forceinline__ bool run_exchange(RunMail *mail, const int row, const
 // exact zero (0 x finite, summed into a float64: acc + 0 = acc), which is also what a lane without a candidate holds (ck = 0):
 // nothing is skipped and nothing changes.  (With a uniform branch per candidate a round cost ~1 600 ticks of a wave's time,
 // profiles/r05_ab.txt 6.)
-template <int NR>
-__device__ __forceinline__ unsigned run_flow_rounds(const float (&rt)[12], const KernConsts &kc, const float (&cx)[RUN_R][3],
-                                                     const float (&cy)[RUN_R][3], const float (&cck)[RUN_R], float (&cw)[RUN_R],
+template <int NR, int NA>
+__device__ __forceinline__ unsigned run_flow_rounds(const float (&rt)[12], const KernConsts &kc, const float (&cx)[NA][3],
+                                                     const float (&cy)[NA][3], const float (&cck)[NA], float (&cw)[NA],
                                                      const double *etab, const int need_d2, double (&acc)[NACC_FLOW])
 {
     unsigned nk = 0;
@@ -2816,9 +2816,9 @@ __device__ __forceinline__ unsigned run_flow_rounds(const float (&rt)[12], const
     asm volatile("; run_flow_rounds end %0" ::"n"(NR));
     return nk;
 }
-template <int NR>
+template <int NR, int NA>
 __device__ __forceinline__ void run_step_rounds(const float (&rt)[12], const KernConsts &kc, const cvo_math::XiConsts &xc,
-                                                const float (&cx)[RUN_R][3], const float (&cy)[RUN_R][3], const float (&cw)[RUN_R],
+                                                const float (&cx)[NA][3], const float (&cy)[NA][3], const float (&cw)[NA],
                                                 double (&sacc)[NACC_STEP])
 {
 #pragma unroll
@@ -2826,6 +2826,49 @@ __device__ __forceinline__ void run_step_rounds(const float (&rt)[12], const Ker
         const float4 yj = apply_tf(rt, rt + 9, make_float4(cy[r][0], cy[r][1], cy[r][2], 0.0f));
         pair_step_sums(kc, xc, yj, cx[r][0] - yj.x, cx[r][1] - yj.y, cx[r][2] - yj.z, cw[r], sacc);
     }
+}
+
+// acvo (kt_run_acvo): the xx and yy candidates of a lane (ref src/adaptive_cvo.cpp:157-158,213-265 -- se_kernel on (x, x) and on
+// the transformed (y, y), the dl sums of their rows), the arithmetic of eval_pair<PROC_SELF, 0, 2> pair for pair.
+//   xx: x never moves -- a candidate is its d2 and its colour weight (the sign: does the row count, the Ayy rule's twin); per
+//       iteration one exp, the cut, the sum.  (Its sums are a function of the length scale alone: the caller keeps them while
+//       that stands still.)
+//   yy: the reference forms |y_i - y_j|^2 from the TRANSFORMED cloud of the iteration, so its roundings -- and with them
+//       membership at the cut -- move with the transform: both points stay in registers and are transformed every time.
+template <int NR>
+__device__ __forceinline__ unsigned run_xx_rounds(const KernConsts &kc, const float (&xd2)[RUN_A], const float (&xck)[RUN_A], const double *etab,
+                                                   double &sum)
+{
+    unsigned nk = 0;
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        const float d2 = xd2[r], ck = __builtin_fabsf(xck[r]);
+        const float a = ck * (float)(kc.s2_d * exp_neg((double)d2 * kc.ninv_2l2, etab));
+        const float w = (d2 < kc.tau && ck > 0.0f && a > kc.sp) ? a : 0.0f;
+        // (a row that does not count, a pair that is no member: an exact zero)
+        sum += (double)((kc.inv_l3 * ((xck[r] < 0.0f) ? 0.0f : w)) * d2);
+        nk += (unsigned)__popcll(__ballot(w > 0.0f));
+    }
+    return nk;
+}
+template <int NR>
+__device__ __forceinline__ unsigned run_yy_rounds(const float (&rt)[12], const KernConsts &kc, const float (&ya)[RUN_A][3], const float (&yb)[RUN_A][3],
+                                                   const float (&yck)[RUN_A], const double *etab, double &sum)
+{
+    unsigned nk = 0;
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        const float4 yi = apply_tf(rt, rt + 9, make_float4(ya[r][0], ya[r][1], ya[r][2], 0.0f));
+        const float4 yj = apply_tf(rt, rt + 9, make_float4(yb[r][0], yb[r][1], yb[r][2], 0.0f));
+        const float e0 = yi.x - yj.x, e1 = yi.y - yj.y, e2 = yi.z - yj.z;
+        const float d2 = __builtin_fmaf(e2, e2, __builtin_fmaf(e1, e1, e0 * e0));
+        const float ck = __builtin_fabsf(yck[r]);
+        const float a = ck * (float)(kc.s2_d * exp_neg((double)d2 * kc.ninv_2l2, etab));
+        const float w = (d2 < kc.tau && ck > 0.0f && a > kc.sp) ? a : 0.0f;
+        sum += (double)((kc.inv_l3 * ((yck[r] < 0.0f) ? 0.0f : w)) * d2);
+        nk += (unsigned)__popcll(__ballot(w > 0.0f));
+    }
+    return nk;
 }
 
 __global__ void kt_run(const Slot *__restrict__ tab, const int qs);
@@ -2888,11 +2931,16 @@ hipError_t run_allow_lds()
     return e;
 }
 
-__global__ void __launch_bounds__(RUN_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
-kt_run(const Slot *__restrict__ tab, const int qs)
+// ACVO (kt_run_acvo, round 6): the same for an adaptive-cvo registration (ref src/adaptive_cvo.cpp:490-555) -- three candidate sets on
+// chip (xy as above; xx and yy: run_xx_rounds / run_yy_rounds), up to RUN_A per lane each and all in registers (acvo's length scale
+// falls to its floor within a few iterations: its records are narrow), 13 sums in the first exchange (the nine of the flow side,
+// sum and count of Axx, tail sum and count of Ayy), dl and the length-scale update in every block's head_post, kernel constants
+// made again in every block whenever the length scale has moved, a build of ANY of the three lists ends the run.
+template <bool ACVO>
+__device__ __forceinline__ void run_body(const Slot *__restrict__ tab, const int qs, float4 *const s_lc)
 {
     __shared__ unsigned long long s_ticket;
-    extern __shared__ __attribute__((aligned(16))) float4 s_lc[];   // [RUN_L][2][RUN_BLOCK]: the candidates behind the registers'
+    constexpr int NVF = ACVO ? 13 : NACC_FLOW;   // doubles of the flow-side exchange
     const bool head_block = blockIdx.x == 0;
     const int srow = (int)blockIdx.x - 1;   // a solver's row in the exchanges (-1: the head block)
     CSlot cs = (CSlot)(tab);
@@ -2910,21 +2958,29 @@ kt_run(const Slot *__restrict__ tab, const int qs)
     const ProcessArgs &pa = CVO_ARG(ProcessArgs, op[qf].p);     // the flow pass of the plan's classic launches
     const PostStepArgs ps = CVO_ARG(PostStepArgs, op[qf].ps);   // its head
     const ProcessArgs &ta = CVO_ARG(ProcessArgs, op[qt].p);     // its step launch (the trace)
+    const ProcessArgs &xa = CVO_ARG(ProcessArgs, op[ACVO ? qf + 1 : qf].p);   // acvo: the self passes of the plan's flow launch (xx, yy)
+    const ProcessArgs &ya = CVO_ARG(ProcessArgs, op[ACVO ? qf + 2 : qf].p);
     DevState *const gst = ps.st;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
 
     __shared__ __attribute__((aligned(16))) DevHead s_st;
     __shared__ double s_red[RUN_WAVES * NACC_MAX];
-    __shared__ double s_vals[NACC_MAX];
+    __shared__ double s_vals[NVF];
+    __shared__ double s_self[RUN_WAVES * 4];   // acvo: the waves' xx / yy sums (sum, count, tail sum, count)
+    __shared__ double s_xx_keep[2];            // acvo: this block's Axx sums ...
+    __shared__ float s_xx_ell;                 // ... and the length scale they were made at (they are a function of nothing else)
     // (the exchanges' rows and the record's prefix sums share their LDS: the prefix sums are dead once the candidates are loaded,
     // and every exchange begins with a barrier)
-    constexpr size_t S_ALL_BYTES = sizeof(double) * RUN_G * RUN_NV, S_PREF_BYTES = sizeof(unsigned) * (PROC_WAVES + 1);
+    constexpr size_t S_ALL_BYTES = sizeof(double) * RUN_G * NVF, S_PREF_BYTES = sizeof(unsigned) * (PROC_WAVES + 1);
     __shared__ __attribute__((aligned(16))) unsigned char s_union[S_ALL_BYTES > S_PREF_BYTES ? S_ALL_BYTES : S_PREF_BYTES];
     double *const s_all = reinterpret_cast<double *>(s_union);
     unsigned *const s_pref = reinterpret_cast<unsigned *>(s_union);
-    __shared__ double s_part[8 * RUN_NV];
-    __shared__ double s_tot[NACC_MAX + 4];
+    // (acvo: the prefix sums of the self records beside it -- its blocks keep no candidates in LDS and have the room)
+    __shared__ unsigned s_pref_self[ACVO ? 2 * (PROC_WAVES + 1) : 2];
+    __shared__ double s_part[8 * NVF];
+    __shared__ double s_tot[NVF + 4];
+    __shared__ double s_dl;   // acvo: dl of the slot (ref src/adaptive_cvo.cpp:271), every block's own
     __shared__ double s_etab[64];
     __shared__ cvo_math::XiConsts s_xi;
     __shared__ float s_wm[12];
@@ -2955,6 +3011,19 @@ kt_run(const Slot *__restrict__ tab, const int qs)
         cnt_a[q] = (sl < nsl && pa.cand_cnt) ? pa.cand_cnt[sl] : 0u;
         cnt_b[q] = (sl < nsl && pa.cand_cnt_b) ? pa.cand_cnt_b[sl] : 0u;
     }
+    // (acvo: the records of the self lists, both buffers of each -- the head says which is in use)
+    unsigned cxx_a[ACVO ? PER : 1], cxx_b[ACVO ? PER : 1], cyy_a[ACVO ? PER : 1], cyy_b[ACVO ? PER : 1];
+    const int nsl_x = ACVO ? 4 * xa.nblk : 0, nsl_y = ACVO ? 4 * ya.nblk : 0;
+    if constexpr (ACVO) {
+#pragma unroll
+        for (int q = 0; q < PER; ++q) {
+            const int sl = tid * PER + q;
+            cxx_a[q] = (sl < nsl_x && xa.cand_cnt) ? xa.cand_cnt[sl] : 0u;
+            cxx_b[q] = (sl < nsl_x && xa.cand_cnt_b) ? xa.cand_cnt_b[sl] : 0u;
+            cyy_a[q] = (sl < nsl_y && ya.cand_cnt) ? ya.cand_cnt[sl] : 0u;
+            cyy_b[q] = (sl < nsl_y && ya.cand_cnt_b) ? ya.cand_cnt_b[sl] : 0u;
+        }
+    }
     if (tid == 0) s_seq = gst->run_seq;
     if (tid < 64) s_etab[tid] = c_exp2_64[tid];
     state_head_to_lds(gst, &s_st);   // (with its barrier)
@@ -2974,7 +3043,16 @@ kt_run(const Slot *__restrict__ tab, const int qs)
     // a build this launch's filter blocks would have to make
     // (... or a record that is expected to hold far more than a run's registers: decided before the head's maths, cheaply)
     if (s_st.done != RUNNING || s_st.stall != 0 || s_st.xy_target >= 0 || pa.cand == nullptr || pa.cand_b == nullptr ||
-        ps.run_mail == nullptr || s_st.run_hint > 2 * RUN_CAP) {
+        ps.run_mail == nullptr || s_st.run_hint > 2 * RUN_CAP ||
+        // (a build has just ended: the plan is about to switch to a list that has no record yet; or the list in use has none)
+        // (the pass of a pending slot has recorded the list it read: the entry head is about to say so, head_plan)
+        s_st.xy_fresh >= 0 ||
+        ((s_st.xy_active ? s_st.xy_ck[1] : s_st.xy_ck[0]) != pa.nblk && !(s_st.pending != 0 && ps.ck_nblk[LIST_XY] == pa.nblk)) ||
+        (ACVO && (s_st.sf_fresh[0] >= 0 || s_st.sf_fresh[1] >= 0 || s_st.run_hint > (int)(1.25f * (float)(RUN_LANES * RUN_A)) ||
+                  ((s_st.sf_active[0] ? s_st.sf_ck[0][1] : s_st.sf_ck[0][0]) != xa.nblk && !(s_st.pending != 0 && ps.ck_nblk[LIST_XX] == xa.nblk)) ||
+                  ((s_st.sf_active[1] ? s_st.sf_ck[1][1] : s_st.sf_ck[1][0]) != ya.nblk && !(s_st.pending != 0 && ps.ck_nblk[LIST_YY] == ya.nblk)))) ||
+        (ACVO && (s_st.sf_target[0] >= 0 || s_st.sf_target[1] >= 0 || xa.cand == nullptr || xa.cand_b == nullptr || ya.cand == nullptr ||
+                  ya.cand_b == nullptr || 4 * xa.nblk > PROC_WAVES || 4 * ya.nblk > PROC_WAVES))) {
 #ifdef CVO_RUN_WHY
         if (head_block && tid == 0) gst->run_clk[s_st.done != RUNNING ? 0 : (s_st.stall != 0 ? 1 : (s_st.xy_target >= 0 ? 2 : 3))] += 1;
 #endif
@@ -3010,14 +3088,16 @@ kt_run(const Slot *__restrict__ tab, const int qs)
     // can the slot that begins run here?  (the loop is running on a buffer whose record is current and fits)
     const int act = s_st.xy_active ? 1 : 0;
     bool ok = s_st.done == RUNNING && s_st.stall == 0 && (act ? s_st.xy_ck[1] : s_st.xy_ck[0]) == pa.nblk;
-    // the record's slices, numbered flat: s_pref[s] = candidates in front of slice s
-    unsigned total = 0;
-    {
-        const unsigned wcap = pa.kept_wcap;
+    const int act_x = (ACVO && s_st.sf_active[0]) ? 1 : 0, act_y = (ACVO && s_st.sf_active[1]) ? 1 : 0;
+    if (ACVO)
+        ok = ok && (act_x ? s_st.sf_ck[0][1] : s_st.sf_ck[0][0]) == xa.nblk && (act_y ? s_st.sf_ck[1][1] : s_st.sf_ck[1][0]) == ya.nblk;
+    // a record's slices, numbered flat: s_pref[s] = candidates in front of slice s (thread t holds the counts of slices
+    // t PER .. t PER + PER - 1); returns the record's total.  Two barriers; s_pref is whole when it returns.
+    auto prefix = [&](const unsigned (&cnt)[PER], const unsigned wcap, unsigned *const dst) -> unsigned {
         unsigned mine[PER], sum = 0;
 #pragma unroll
         for (int q = 0; q < PER; ++q) {
-            const unsigned c = act ? cnt_b[q] : cnt_a[q];
+            const unsigned c = cnt[q];
             mine[q] = sum;
             sum += c < wcap ? c : wcap;
         }
@@ -3027,24 +3107,45 @@ kt_run(const Slot *__restrict__ tab, const int qs)
             const unsigned o = (unsigned)__shfl_up((int)inc, off, 64);
             if (lane >= off) inc += o;
         }
+        __syncthreads();   // (whoever still reads s_pref / s_wsum of the scan before)
         if (lane == 63) s_wsum[wid] = inc;
         __syncthreads();
-        unsigned base = 0;
+        unsigned base = 0, tot = 0;
 #pragma unroll
         for (int w = 0; w < RUN_WAVES; ++w) {
             const unsigned v = s_wsum[w];
             if (w < wid) base += v;
-            total += v;
+            tot += v;
         }
         base += inc - sum;
 #pragma unroll
-        for (int q = 0; q < PER; ++q) s_pref[tid * PER + q] = base + mine[q];
-        if (tid == 0) s_pref[PROC_WAVES] = total;
+        for (int q = 0; q < PER; ++q) dst[tid * PER + q] = base + mine[q];
+        if (tid == 0) dst[PROC_WAVES] = tot;
         __syncthreads();
+        return tot;
+    };
+    // (acvo: the counts of the self records' buffers in use; their prefix sums have arrays of their own)
+    unsigned sel_x[ACVO ? PER : 1], sel_y[ACVO ? PER : 1];
+    unsigned total_x = 0, total_y = 0;
+    if constexpr (ACVO) {
+#pragma unroll
+        for (int q = 0; q < PER; ++q) { sel_x[q] = act_x ? cxx_b[q] : cxx_a[q]; sel_y[q] = act_y ? cyy_b[q] : cyy_a[q]; }
+        total_x = prefix(reinterpret_cast<const unsigned (&)[PER]>(sel_x), xa.kept_wcap, s_pref_self);
+        total_y = prefix(reinterpret_cast<const unsigned (&)[PER]>(sel_y), ya.kept_wcap, s_pref_self + (PROC_WAVES + 1));
+    }
+    unsigned total = 0;
+    {
+        unsigned sel[PER];
+#pragma unroll
+        for (int q = 0; q < PER; ++q) sel[q] = act ? cnt_b[q] : cnt_a[q];
+        total = prefix(sel, pa.kept_wcap, s_pref);
     }
     if (head_block && tid == 0) gst->run_candidates = (int32_t)total;
     if (ok && tid == 0) { if (act) s_st.rec_count[1] = (int32_t)total; else s_st.rec_count[0] = (int32_t)total; }   // (every block alike; the record is current)
     if (total > (unsigned)RUN_CAP || total == 0u) ok = false;
+    // (acvo: the widest of the three records decides)
+    const unsigned total_max = ACVO ? (total > total_x ? (total > total_y ? total : total_y) : (total_x > total_y ? total_x : total_y)) : total;
+    if (ACVO && total_max > (unsigned)(RUN_LANES * RUN_A)) ok = false;
 #ifdef CVO_RUN_WHY
     if (!ok && head_block && tid == 0)
         gst->run_clk[s_st.done != RUNNING ? 4 : (s_st.stall != 0 ? 5 : ((act ? s_st.xy_ck[1] : s_st.xy_ck[0]) != pa.nblk ? 6 : (total == 0u ? 8 : 7)))] += 1;
@@ -3057,10 +3158,13 @@ kt_run(const Slot *__restrict__ tab, const int qs)
     const unsigned per = (unsigned)RUN_BLOCK;
     const int gdev = ps.run_g_max >= 8 && ps.run_g_max <= RUN_G ? ps.run_g_max : RUN_G;   // (fewer compute units: smaller runs)
     const int gmax = gdev < (int)gridDim.x - 1 ? gdev : (int)gridDim.x - 1;                // (a launch for a narrow record brings fewer blocks)
-    const int gwant = total <= 8u * per ? 8 : (total <= 16u * per ? 16 : (total <= 3u * 32u * per ? 32 :
-                      (total <= 3u * 64u * per ? 64 : (total <= 3u * 128u * per ? 128 : RUN_G))));
+    // (acvo: a lane's candidates come in threes and every iteration transforms five points for them: two per lane, then the next size)
+    const int gwant = ACVO ? (total_max <= 8u * per ? 8 : (total_max <= 16u * per ? 16 : (total_max <= 2u * 32u * per ? 32 :
+                              (total_max <= 2u * 64u * per ? 64 : (total_max <= 2u * 128u * per ? 128 : RUN_G)))))
+                           : (total <= 8u * per ? 8 : (total <= 16u * per ? 16 : (total <= 3u * 32u * per ? 32 :
+                              (total <= 3u * 64u * per ? 64 : (total <= 3u * 128u * per ? 128 : RUN_G)))));
     const int g = gwant < gmax ? gwant : gmax;
-    if (total > (unsigned)g * per * (unsigned)(RUN_R + RUN_L)) { run_over(); return; }   // (block-uniform; nothing has been written)
+    if (total_max > (unsigned)g * per * (unsigned)(ACVO ? RUN_A : RUN_R + RUN_L)) { run_over(); return; }   // (block-uniform; nothing has been written)
     if (srow >= g) return;
     {
         // ---- entry hand-shake (RunMail::entry_ticket): nothing is written before all of the run is known to be resident.  Every run,
@@ -3103,13 +3207,14 @@ kt_run(const Slot *__restrict__ tab, const int qs)
     // ---- the candidates of this lane: c = l + r * lanes
     const unsigned wave_first = head_block ? total : (unsigned)srow * RUN_BLOCK + (unsigned)wid * 64u;   // flat number of the wave's first candidate of round 0
     const int rmax = wave_first < total ? (int)((total - wave_first + lanes - 1) / lanes) : 0;   // wave-uniform: rounds with any candidate
-    float cx[RUN_R][3], cy[RUN_R][3], cck[RUN_R], cw[RUN_R];
+    constexpr int NRX = ACVO ? RUN_A : RUN_R;   // xy candidates of a lane in registers
+    float cx[NRX][3], cy[NRX][3], cck[NRX], cw[NRX];
     {
         const uint2 *rec = act ? pa.cand_b : pa.cand;
         const unsigned wcap = pa.kept_wcap;
-        uint2 e[RUN_R];
+        uint2 e[NRX];
 #pragma unroll
-        for (int r = 0; r < RUN_R; ++r) {
+        for (int r = 0; r < NRX; ++r) {
             e[r] = make_uint2(0u, 0u);
             if (r < rmax) {
                 const unsigned c0 = wave_first + (unsigned)r * lanes;   // < total
@@ -3126,7 +3231,7 @@ kt_run(const Slot *__restrict__ tab, const int qs)
             }
         }
 #pragma unroll
-        for (int r = 0; r < RUN_R; ++r) {
+        for (int r = 0; r < NRX; ++r) {
             cck[r] = 0.0f; cw[r] = 0.0f;
             cx[r][0] = cx[r][1] = cx[r][2] = 0.0f;
             cy[r][0] = cy[r][1] = cy[r][2] = 0.0f;
@@ -3142,7 +3247,7 @@ kt_run(const Slot *__restrict__ tab, const int qs)
     }
     // ... and those behind the registers' (rounds RUN_R .. rmax - 1: only a run of all RUN_G solvers has them) into LDS
     static_assert(RUN_L % 2 == 0, "run_flow_lds / run_step_lds take two rounds per trip");
-    const int nl = rmax > RUN_R ? ((rmax - RUN_R + 1) & ~1) : 0;   // (wave-uniform; even: a last odd round is filled with lanes without a candidate)
+    const int nl = (!ACVO && rmax > RUN_R) ? ((rmax - RUN_R + 1) & ~1) : 0;   // (wave-uniform; even: a last odd round is filled with lanes without a candidate)
     float4 *const lc = s_lc + tid;
     {
         const uint2 *rec = act ? pa.cand_b : pa.cand;
@@ -3177,6 +3282,58 @@ kt_run(const Slot *__restrict__ tab, const int qs)
             }
         }
     }
+    // ---- acvo: the lane's xx and yy candidates (the same flat numbering over their records' slices)
+    float xd2[ACVO ? RUN_A : 1], xck[ACVO ? RUN_A : 1];
+    float yya[ACVO ? RUN_A : 1][3], yyb[ACVO ? RUN_A : 1][3], yck[ACVO ? RUN_A : 1];
+    int rmax_x = 0, rmax_y = 0;
+    if constexpr (ACVO) {
+#pragma unroll
+        for (int set = 0; set < 2; ++set) {
+            const ProcessArgs &sa = set == 0 ? xa : ya;
+            const unsigned tot_s = set == 0 ? total_x : total_y;
+            const uint2 *rec = (set == 0 ? act_x : act_y) ? sa.cand_b : sa.cand;
+            const unsigned wcap = sa.kept_wcap;
+            const unsigned *const pref = s_pref_self + (set == 0 ? 0 : PROC_WAVES + 1);   // (this record's prefix sums)
+            const unsigned first_s = head_block ? tot_s : (unsigned)srow * RUN_BLOCK + (unsigned)wid * 64u;
+            const int rm = first_s < tot_s ? (int)((tot_s - first_s + lanes - 1) / lanes) : 0;
+            if (set == 0) rmax_x = rm; else rmax_y = rm;
+            uint2 e[RUN_A];
+#pragma unroll
+            for (int r = 0; r < RUN_A; ++r) {
+                e[r] = make_uint2(0u, 0u);
+                if (r < rm) {
+                    const unsigned c0 = first_s + (unsigned)r * lanes;   // < tot_s
+                    const unsigned coarse = pref[lane * 64];
+                    const int k1 = __popcll(__ballot(coarse <= c0)) - 1;
+                    const unsigned fine = pref[k1 * 64 + lane];
+                    int sl = k1 * 64 + __popcll(__ballot(fine <= c0)) - 1;
+                    const unsigned c = c0 + (unsigned)lane;
+                    if (c < tot_s) {
+                        while (c >= pref[sl + 1]) ++sl;
+                        e[r] = rec[(size_t)sl * wcap + (c - pref[sl])];
+                    }
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < RUN_A; ++r) {
+                const bool have = r < rm && first_s + (unsigned)r * lanes + (unsigned)lane < tot_s;
+                // (a lane without a candidate reads row 0 of both clouds and holds a colour weight of 0: never a member)
+                const float4 a4 = sa.pos_a[e[r].x & 0xffffu];
+                const float4 b4 = sa.pos_b[e[r].x >> 16];
+                const float ckr = have ? __uint_as_float(e[r].y) : 0.0f;   // (the sign: the row counts or not, eval_pair)
+                if (set == 0) {
+                    const float e0 = a4.x - b4.x, e1 = a4.y - b4.y, e2 = a4.z - b4.z;   // (x never moves: d2 once)
+                    xd2[r] = __builtin_fmaf(e2, e2, __builtin_fmaf(e1, e1, e0 * e0));
+                    xck[r] = ckr;
+                } else {
+                    yya[r][0] = a4.x; yya[r][1] = a4.y; yya[r][2] = a4.z;
+                    yyb[r][0] = b4.x; yyb[r][1] = b4.y; yyb[r][2] = b4.z;
+                    yck[r] = ckr;
+                }
+            }
+        }
+        if (tid == 0) { s_xx_ell = -1.0f; s_xx_keep[0] = 0.0; s_xx_keep[1] = 0.0; }   // (no Axx sums yet)
+    }
     // the row of flags the entry head has read is cleared as the slot's step launch would (nothing is flagged in a run);
     // the counters of a build the entry head has named are zeroed as its flow launch would
     if (head_block) {
@@ -3185,13 +3342,14 @@ kt_run(const Slot *__restrict__ tab, const int qs)
     }
 
     bool comm_ok = true;
-    const int need_d2 = pa.need_d2;
+    const int need_d2 = ACVO ? 1 : pa.need_d2;   // (acvo: the sum of a d2 is a term of dl)
     const int iters = ps.run_iters > 0 ? ps.run_iters : 1;
     const long long run_timeout = ps.run_timeout_ticks > 0 ? ps.run_timeout_ticks : RUN_TIMEOUT_TICKS;
     // the head block's verdict on the slot that begins travels with the slot's second exchange (its number is known in advance)
     auto post_verdict = [&](const unsigned long long seq_b) {
         if (head_block && tid == 0) {
-            const unsigned v = (s_st.stall != 0 ? (unsigned)RUN_V_STALL : 0u) | (s_st.xy_target >= 0 ? (unsigned)RUN_V_BUILD : 0u);
+            const bool build = s_st.xy_target >= 0 || (ACVO && (s_st.sf_target[0] >= 0 || s_st.sf_target[1] >= 0));
+            const unsigned v = (s_st.stall != 0 ? (unsigned)RUN_V_STALL : 0u) | (build ? (unsigned)RUN_V_BUILD : 0u);
             __hip_atomic_store(&ps.run_mail->w[(seq_b >> 1) & 1ull][RUN_G][0], ((seq_b & 0xffffffffull) << 32) | v, __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_AGENT);
         }
@@ -3215,21 +3373,58 @@ kt_run(const Slot *__restrict__ tab, const int qs)
 #pragma unroll
         for (int k = 0; k < NACC_FLOW; ++k) acc[k] = 0.0;
         unsigned nk = 0;
-        static_assert(RUN_R == 8, "the cases below");
-        switch (rmax) {   // (wave-uniform; rounds beyond the wave's last candidate would be all zeros)
-        case 0: break;
-        case 1: nk = run_flow_rounds<1>(rt, kc, cx, cy, cck, cw, s_etab, need_d2, acc); break;
-        case 2: nk = run_flow_rounds<2>(rt, kc, cx, cy, cck, cw, s_etab, need_d2, acc); break;
-        case 3: nk = run_flow_rounds<3>(rt, kc, cx, cy, cck, cw, s_etab, need_d2, acc); break;
-        case 4: nk = run_flow_rounds<4>(rt, kc, cx, cy, cck, cw, s_etab, need_d2, acc); break;
-        case 5: case 6: nk = run_flow_rounds<6>(rt, kc, cx, cy, cck, cw, s_etab, need_d2, acc); break;
-        default: nk = run_flow_rounds<8>(rt, kc, cx, cy, cck, cw, s_etab, need_d2, acc); break;
+        static_assert(RUN_R == 8 && RUN_A == 4, "the cases below");
+        if constexpr (ACVO) {
+            switch (rmax) {   // (wave-uniform; at most RUN_A rounds)
+            case 0: break;
+            case 1: nk = run_flow_rounds<1>(rt, kc, cx, cy, cck, cw, s_etab, need_d2, acc); break;
+            case 2: nk = run_flow_rounds<2>(rt, kc, cx, cy, cck, cw, s_etab, need_d2, acc); break;
+            case 3: nk = run_flow_rounds<3>(rt, kc, cx, cy, cck, cw, s_etab, need_d2, acc); break;
+            default: nk = run_flow_rounds<4>(rt, kc, cx, cy, cck, cw, s_etab, need_d2, acc); break;
+            }
+        } else {
+            switch (rmax) {   // (wave-uniform; rounds beyond the wave's last candidate would be all zeros)
+            case 0: break;
+            case 1: nk = run_flow_rounds<1>(rt, kc, cx, cy, cck, cw, s_etab, need_d2, acc); break;
+            case 2: nk = run_flow_rounds<2>(rt, kc, cx, cy, cck, cw, s_etab, need_d2, acc); break;
+            case 3: nk = run_flow_rounds<3>(rt, kc, cx, cy, cck, cw, s_etab, need_d2, acc); break;
+            case 4: nk = run_flow_rounds<4>(rt, kc, cx, cy, cck, cw, s_etab, need_d2, acc); break;
+            case 5: case 6: nk = run_flow_rounds<6>(rt, kc, cx, cy, cck, cw, s_etab, need_d2, acc); break;
+            default: nk = run_flow_rounds<8>(rt, kc, cx, cy, cck, cw, s_etab, need_d2, acc); break;
+            }
+            if (nl > 0) nk += run_flow_lds(nl, lc, rt, kc, s_etab, need_d2, acc);
         }
-        if (nl > 0) nk += run_flow_lds(nl, lc, rt, kc, s_etab, need_d2, acc);
         RUN_CLK(2);
+        // ---- acvo: Ayy of this transform, Axx when the length scale has moved (ref src/adaptive_cvo.cpp:157-158, 213-265)
+        double self[4] = {0.0, 0.0, 0.0, 0.0};   // sum xx, count xx, tail sum yy, count yy
+        bool xx_fresh = false;
+        if constexpr (ACVO) {
+            unsigned ny = 0;
+            switch (rmax_y) {
+            case 0: break;
+            case 1: ny = run_yy_rounds<1>(rt, kc, yya, yyb, yck, s_etab, self[2]); break;
+            case 2: ny = run_yy_rounds<2>(rt, kc, yya, yyb, yck, s_etab, self[2]); break;
+            case 3: ny = run_yy_rounds<3>(rt, kc, yya, yyb, yck, s_etab, self[2]); break;
+            default: ny = run_yy_rounds<4>(rt, kc, yya, yyb, yck, s_etab, self[2]); break;
+            }
+            if (lane == 0) self[3] = (double)ny;
+            xx_fresh = !(s_xx_ell == s_st.kc_ell);   // (block-uniform; every block holds the same length scale)
+            if (xx_fresh) {
+                unsigned nx = 0;
+                switch (rmax_x) {
+                case 0: break;
+                case 1: nx = run_xx_rounds<1>(kc, xd2, xck, s_etab, self[0]); break;
+                case 2: nx = run_xx_rounds<2>(kc, xd2, xck, s_etab, self[0]); break;
+                case 3: nx = run_xx_rounds<3>(kc, xd2, xck, s_etab, self[0]); break;
+                default: nx = run_xx_rounds<4>(kc, xd2, xck, s_etab, self[0]); break;
+                }
+                if (lane == 0) self[1] = (double)nx;
+            }
+        }
         if (!head_block) {
             if (lane == 0) acc[8] = (double)nk;
             wave_sums<NACC_FLOW>(acc, lane, s_red + wid * NACC_MAX);
+            if constexpr (ACVO) wave_sums<4>(self, lane, s_self + wid * 4);
             RUN_CLK(3);
             __syncthreads();
             if (tid < NACC_FLOW) {
@@ -3237,11 +3432,21 @@ kt_run(const Slot *__restrict__ tab, const int qs)
 #pragma unroll
                 for (int q = 0; q < RUN_WAVES; ++q) t += s_red[q * NACC_MAX + tid];
                 s_vals[tid] = t;
+            } else if (ACVO && tid >= 64 && tid < 68) {   // (another wave: beside the flow sums)
+                const int k = tid - 64;
+                double t = 0.0;
+#pragma unroll
+                for (int q = 0; q < RUN_WAVES; ++q) t += s_self[q * 4 + k];
+                if (k < 2) {   // Axx: made now, or the sums this block made when the length scale last moved
+                    if (xx_fresh) s_xx_keep[k] = t; else t = s_xx_keep[k];
+                }
+                s_vals[NACC_FLOW + k] = t;
             }
         }
+        if (ACVO && xx_fresh) { __syncthreads(); if (tid == 0) s_xx_ell = s_st.kc_ell; }
         RUN_CLK(4);
         ++nexch;
-        if (!run_exchange<NACC_FLOW>(ps.run_mail, srow, g, seq0 + nexch, s_vals, s_all, s_part, s_tot, &s_fail, nullptr, &s_verdict, run_timeout)) { comm_ok = false; break; }
+        if (!run_exchange<NVF>(ps.run_mail, srow, g, seq0 + nexch, s_vals, s_all, s_part, s_tot, &s_fail, nullptr, &s_verdict, run_timeout)) { comm_ok = false; break; }
         RUN_CLK(5);
         // ---- the tail of compute_flow (ref src/cvo.cpp:201-209): twist, Taylor constants
         if (tid < 64) {
@@ -3256,6 +3461,13 @@ kt_run(const Slot *__restrict__ tab, const int qs)
                 for (int q = 0; q < NACC_FLOW; ++q) s_st.red[RED_FLOW + q] = s_tot[q];
                 for (int q = 0; q < 3; ++q) { s_st.omega[q] = s_xi.omega[q]; s_st.v[q] = s_xi.v[q]; }
             }
+        } else if (ACVO && tid == 64) {
+            // dl (ref src/adaptive_cvo.cpp:222-231,271; the expression of step_twist_body), in every block: its head_post moves the
+            // length scale by it.  Kept beside the head until the slot stands (a stall verdict voids it)
+            const long long nnz = (long long)s_tot[8], nnz_xx = (long long)s_tot[NACC_FLOW + 1], nnz_yy = (long long)s_tot[NACC_FLOW + 3];
+            const double num = (s_tot[NACC_FLOW + 2] - 2.0 * s_tot[7]) + s_tot[NACC_FLOW];
+            s_dl = num / (double)(nnz_xx + nnz_yy - 2 * nnz);
+            for (int q = 0; q < 4; ++q) s_self[q] = s_tot[NACC_FLOW + q];   // (s_tot: the step exchange writes it next)
         }
         __syncthreads();
         const cvo_math::XiConsts xc = s_xi;
@@ -3264,16 +3476,26 @@ kt_run(const Slot *__restrict__ tab, const int qs)
         double sacc[NACC_STEP];
 #pragma unroll
         for (int k = 0; k < NACC_STEP; ++k) sacc[k] = 0.0;
-        switch (rmax) {
-        case 0: break;
-        case 1: run_step_rounds<1>(rt, kc, xc, cx, cy, cw, sacc); break;
-        case 2: run_step_rounds<2>(rt, kc, xc, cx, cy, cw, sacc); break;
-        case 3: run_step_rounds<3>(rt, kc, xc, cx, cy, cw, sacc); break;
-        case 4: run_step_rounds<4>(rt, kc, xc, cx, cy, cw, sacc); break;
-        case 5: case 6: run_step_rounds<6>(rt, kc, xc, cx, cy, cw, sacc); break;
-        default: run_step_rounds<8>(rt, kc, xc, cx, cy, cw, sacc); break;
+        if constexpr (ACVO) {
+            switch (rmax) {
+            case 0: break;
+            case 1: run_step_rounds<1>(rt, kc, xc, cx, cy, cw, sacc); break;
+            case 2: run_step_rounds<2>(rt, kc, xc, cx, cy, cw, sacc); break;
+            case 3: run_step_rounds<3>(rt, kc, xc, cx, cy, cw, sacc); break;
+            default: run_step_rounds<4>(rt, kc, xc, cx, cy, cw, sacc); break;
+            }
+        } else {
+            switch (rmax) {
+            case 0: break;
+            case 1: run_step_rounds<1>(rt, kc, xc, cx, cy, cw, sacc); break;
+            case 2: run_step_rounds<2>(rt, kc, xc, cx, cy, cw, sacc); break;
+            case 3: run_step_rounds<3>(rt, kc, xc, cx, cy, cw, sacc); break;
+            case 4: run_step_rounds<4>(rt, kc, xc, cx, cy, cw, sacc); break;
+            case 5: case 6: run_step_rounds<6>(rt, kc, xc, cx, cy, cw, sacc); break;
+            default: run_step_rounds<8>(rt, kc, xc, cx, cy, cw, sacc); break;
+            }
+            if (nl > 0) run_step_lds(nl, lc, rt, kc, xc, sacc);
         }
-        if (nl > 0) run_step_lds(nl, lc, rt, kc, xc, sacc);
         RUN_CLK(7);
         if (!head_block) {
             wave_sums<NACC_STEP>(sacc, lane, s_red + wid * NACC_MAX);
@@ -3305,10 +3527,11 @@ kt_run(const Slot *__restrict__ tab, const int qs)
             break;
         }
         // ---- the slot stands.  The head block: what the slot's step launch leaves in the head, the trace record
+        if (ACVO && !head_block && tid == 0) s_st.dl = s_dl;   // (what this block's head_post moves the length scale by)
         if (head_block && tid == 0) {
-            for (int q = 0; q < 4; ++q) s_st.red[RED_XX + q] = 0.0;
+            for (int q = 0; q < 4; ++q) s_st.red[RED_XX + q] = ACVO ? s_self[q] : 0.0;
             s_st.xi = s_xi;
-            s_st.dl = 0.0;
+            s_st.dl = ACVO ? s_dl : 0.0;
             if (ta.trace && s_st.k < ta.trace_cap) {
                 cvo_hip_trace &tr = ta.trace[s_st.k];
                 tr.k = s_st.k;
@@ -3319,8 +3542,9 @@ kt_run(const Slot *__restrict__ tab, const int qs)
                     tr.omega_d[q] = s_st.red[RED_FLOW + q]; tr.v_d[q] = s_st.red[RED_FLOW + 3 + q];
                 }
                 tr.sum_a = s_st.red[RED_FLOW + 6];
-                tr.dl = 0.0;
-                tr.nnz = (long long)s_st.red[RED_FLOW + 8]; tr.nnz_xx = 0; tr.nnz_yy = 0;
+                tr.dl = s_st.dl;
+                tr.nnz = (long long)s_st.red[RED_FLOW + 8];
+                tr.nnz_xx = ACVO ? (long long)s_st.red[RED_XX + 1] : 0; tr.nnz_yy = ACVO ? (long long)s_st.red[RED_YY + 1] : 0;
             }
         }
         // ---- the slot is complete but for its post-step part.  Leave here -- as a step launch would leave it -- when the
@@ -3424,6 +3648,18 @@ kt_run(const Slot *__restrict__ tab, const int qs)
     run_over();
 }
 
+__global__ void __launch_bounds__(RUN_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
+kt_run(const Slot *__restrict__ tab, const int qs)
+{
+    extern __shared__ __attribute__((aligned(16))) float4 s_lc[];   // [RUN_L][2][RUN_BLOCK]: the candidates behind the registers'
+    run_body<false>(tab, qs, s_lc);
+}
+__global__ void __launch_bounds__(RUN_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
+kt_run_acvo(const Slot *__restrict__ tab, const int qs)
+{
+    run_body<true>(tab, qs, nullptr);   // (no candidate lives in LDS: a launch without dynamic LDS)
+}
+
 unsigned filter_grid_cap(long long nitems, long long cap) { return filter_grid_x(nitems, cap); }
 long long filter_blocks_cap() { return filter_blocks_max(); }
 
@@ -3456,6 +3692,7 @@ void launch_table(const Slot *tab, const TLaunch &l, hipStream_t s, hipEvent_t e
     case TK_HFLOW_BUILD6: hipLaunchKernelGGL(kt_hflow_build6_w4, g, dim3(BLOCK), l.smem, s, tab, qp); break;
     case TK_HSTEP_TWIST: hipLaunchKernelGGL(kt_step_twist, g, dim3(STEP_BLOCK), 0, s, tab, qp); break;
     case TK_RUN: hipLaunchKernelGGL(kt_run, dim3(l.gx), dim3(RUN_BLOCK), RUN_LDS_BYTES, s, tab, l.q); break;   // (run_allow_lds first: plan_lone's caller)
+    case TK_RUN_ACVO: hipLaunchKernelGGL(kt_run_acvo, dim3(l.gx), dim3(RUN_BLOCK), 0, s, tab, l.q); break;
     default: break;
     }
 }

@@ -446,6 +446,13 @@ DevParams loop_params(const cvo_hip_ctx *ctx)
     // build is a large part of an iteration, 25 % beats 15 % (32 distinct 10k x 10k pairs 2273 ->
     // 2398 registrations/s, one at a time 1.77 -> 1.71 ms); at 20k x 20k it loses (917 -> 792).
     dp.list_margin = ((double)ctx->fixed.n * (double)ctx->moving.n <= 2.0e8) ? 0.25f : 0.15f;
+    // acvo with resident runs: its length scale sits at its floor for most of a registration -- lists of ~24 mm with 6 mm of room,
+    // used up every few iterations while the cloud still moves, and every rebuild ends a run (two launch-per-pass slots and a new
+    // entry); a candidate inside a run costs next to nothing: 50 % (3k x 3k 1 110 -> 1 187 registrations/s, 10k 712 -> 749; 80 % and
+    // 120 % lose again: the exchanges grow with the solvers the wider records need -- profiles/r06_ab.txt 2)
+    if (ctx->prm.mode == CVO_HIP_MODE_ACVO && ctx->lone && ctx->use_async_self && runs_allowed(ctx) && !ctx->opt.no_acvo_run && ctx->allow_head &&
+        (double)ctx->fixed.n * (double)ctx->moving.n <= 2.0e8)
+        dp.list_margin = 0.5f;
     if (ctx->opt.list_margin >= 0.0f) dp.list_margin = ctx->opt.list_margin;   // (test switch "list_margin"; 0 = rebuild every iteration)
     dp.async_xy = ctx->use_async ? 1 : 0;
     dp.async_self = ctx->use_async_self ? 1 : 0;
@@ -586,7 +593,8 @@ int enqueue_step(cvo_hip_ctx *ctx, int check_done, bool do_math, cvo_hip_trace *
     // Resident runs (cvo_kernels.hip kt_run): one cvo registration with its launches to itself, in head mode, on
     // candidate records (plan_lone decides whether the plan really is a head-mode plan)
     if (ctx->plan_recording && ctx->lone && ctx->allow_head && runs_allowed(ctx) && ctx->use_async && ctx->merge_twist &&
-        !multi_rank(ctx) && ctx->prm.mode == CVO_HIP_MODE_CVO && !(ctx->prm.color_scale > 0.0f) && !ctx->post_dbg) {
+        !multi_rank(ctx) && (ctx->prm.mode == CVO_HIP_MODE_CVO || (ctx->use_async_self && !ctx->opt.no_acvo_run)) &&
+        !(ctx->prm.color_scale > 0.0f) && !ctx->post_dbg) {
         const bool fresh = ctx->run_mail.p == nullptr;
         if (ensure_buf(ctx, ctx->run_mail, sizeof(RunMail)) == CVO_HIP_OK) {
             if (fresh) HIP_TRY(ctx, hipMemsetAsync(ctx->run_mail.p, 0, sizeof(RunMail), loop_stream(ctx)));
@@ -781,8 +789,19 @@ bool plan_lone(const std::vector<RecOp> &ops, Slot &slot, std::vector<TLaunch> &
         o.n2 = (int)filter_grid_cap(filter_items(slot.op[q + 2].f), cap);
         const int jt = std::max(o.f.jt, std::max(slot.op[q + 1].f.jt, slot.op[q + 2].f.jt));
         if (head) { o.ps = ops[at + 1].ps; }
+        else { o.ps.run_mail = nullptr; }
         plan.push_back(mk_launch(head ? TK_HFLOW_BUILD6 : (six ? TK_FLOW_BUILD6 : TK_FLOW_BUILD3), q,
                                  (unsigned)((six ? 3 : 1) * o.np + o.n0 + o.n1 + o.n2), 1, head ? smem_head(jt) : smem_of(jt)));
+        // acvo: a RUN batch begins with kt_run_acvo (head and flow pass from this entry, the self passes from the next two, the
+        // trace from the step launch's, op[q + 3]): candidate records on both buffers of all three lists, the clouds read as they
+        // came (x never transformed, y by the slot's transform)
+        if (head && six && pre && o.ps.run_mail && flow.cand && flow.cand_b && flow.kept_packed == 1 && flow.tf_a == 0 && flow.tf_b == 1 &&
+            flow.weight == 0 && 4 * flow.nblk <= PROC_WAVES && self[0].cand && self[0].cand_b && self[1].cand && self[1].cand_b &&
+            self[0].tf_a == 0 && self[0].tf_b == 0 && self[1].tf_a == 1 && self[1].tf_b == 1 && 4 * self[0].nblk <= PROC_WAVES &&
+            4 * self[1].nblk <= PROC_WAVES && q + 3 < 16) {
+            pre->push_back(mk_launch(TK_RUN_ACVO, q | ((q + 3) << 4), 1u + RUN_G, 1));
+            pre->push_back(mk_launch(TK_RUN_ACVO, q | ((q + 3) << 4), 1u + RUN_G_SMALL, 1));   // (for narrow records: launch_batch picks one)
+        }
         q += 3;
         if (six) ns = 0;
         nf = 0;

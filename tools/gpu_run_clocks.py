@@ -11,11 +11,13 @@ if os.environ.get("CVO_LIB"):
     capi.LIB_PATH = os.path.join(os.path.dirname(capi.LIB_PATH), os.environ["CVO_LIB"])
 names = ("entry", "consts", "flow rounds", "wave sums", "barrier+block sum", "exch A", "twist", "step rounds", "step sums", "exch B", "pre-head", "head_post", "inverse+sync", "tail", "exit", "(of head_post: cubic+root)")
 for n in [int(a) for a in sys.argv[1:]] or [3000, 10000]:
-    xf, ff, xm, fm = pkg.data.synthetic_pair(n, n, seed=pkg.data.SEED_CFG2)
-    prm = capi.default_params(capi.MODE_CVO)
+    acvo = bool(os.environ.get("ACVO"))
+    MODE = capi.MODE_ACVO if acvo else capi.MODE_CVO
+    xf, ff, xm, fm = pkg.data.synthetic_pair(n, n, seed=pkg.data.SEED_CFG2, acvo=acvo)
+    prm = capi.default_params(MODE)
     if os.environ.get("MAX_ITER"):   # (21: the run at ell = 0.06 alone)
         prm.max_iter = int(os.environ["MAX_ITER"])
-    c = capi.Context(mode=capi.MODE_CVO, device=0, stream=torch.cuda.current_stream().cuda_stream, params=prm)
+    c = capi.Context(mode=MODE, device=0, stream=torch.cuda.current_stream().cuda_stream, params=prm)
     c.set_fixed(xf, ff); c.set_moving(xm, fm)
     for _ in range(2):
         st = capi.init_state(c.params); n_it, _ = c.align(st, trace_cap=0)

@@ -11,8 +11,9 @@ capi.LIB_PATH = os.path.join(os.path.dirname(capi.LIB_PATH), os.environ.get("CVO
 n = int(sys.argv[1])
 names = ("done", "stall", "build named", "no record/hint", "done after head", "stall after head", "record not current", "too many", "empty")
 for seed in [int(a) for a in sys.argv[2:]]:
-    xf, ff, xm, fm = pkg.data.synthetic_pair(n, n, seed=seed)
-    c = capi.Context(mode=capi.MODE_CVO, device=0)
+    acvo = bool(os.environ.get("ACVO"))
+    xf, ff, xm, fm = pkg.data.synthetic_pair(n, n, seed=seed, acvo=acvo)
+    c = capi.Context(mode=capi.MODE_ACVO if acvo else capi.MODE_CVO, device=0)
     c.set_fixed(xf, ff); c.set_moving(xm, fm)
     for rep in range(int(os.environ.get("ALIGNS", "4"))):
         c0 = c.run_clocks()
@@ -22,4 +23,5 @@ for seed in [int(a) for a in sys.argv[2:]]:
               ", ".join("%s %d" % (nm, v) for nm, v in zip(names, clk) if v)))
         if rep == 0:
             print("   nnz per iteration:", " ".join("%d:%.0fk" % (t["k"], t["nnz"] / 1e3) for t in tr[:n_it:3]))
+            print("   step per iteration:", " ".join("%d:%.3f" % (t["k"], t["step"]) for t in tr[:n_it:3]))
     c.close()
