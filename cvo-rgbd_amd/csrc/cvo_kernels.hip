@@ -3159,8 +3159,11 @@ __device__ __forceinline__ void run_body(const Slot *__restrict__ tab, const int
     const int gdev = ps.run_g_max >= 8 && ps.run_g_max <= RUN_G ? ps.run_g_max : RUN_G;   // (fewer compute units: smaller runs)
     const int gmax = gdev < (int)gridDim.x - 1 ? gdev : (int)gridDim.x - 1;                // (a launch for a narrow record brings fewer blocks)
     // (acvo: a lane's candidates come in threes and every iteration transforms five points for them: two per lane, then the next size)
-    const int gwant = ACVO ? (total_max <= 8u * per ? 8 : (total_max <= 16u * per ? 16 : (total_max <= 2u * 32u * per ? 32 :
-                              (total_max <= 2u * 64u * per ? 64 : (total_max <= 2u * 128u * per ? 128 : RUN_G)))))
+#ifndef CVO_ACVO_PER_LANE
+#define CVO_ACVO_PER_LANE 3u   // (2 / 3 / 4: 10k 740 / 756 / 755 registrations/s, 6k 981 / 982 / 953, 3k alike: profiles/r06_ab.txt 3)
+#endif
+    const int gwant = ACVO ? (total_max <= 8u * per ? 8 : (total_max <= 16u * per ? 16 : (total_max <= CVO_ACVO_PER_LANE * 32u * per ? 32 :
+                              (total_max <= CVO_ACVO_PER_LANE * 64u * per ? 64 : (total_max <= CVO_ACVO_PER_LANE * 128u * per ? 128 : RUN_G)))))
                            : (total <= 8u * per ? 8 : (total <= 16u * per ? 16 : (total <= 3u * 32u * per ? 32 :
                               (total <= 3u * 64u * per ? 64 : (total <= 3u * 128u * per ? 128 : RUN_G)))));
     const int g = gwant < gmax ? gwant : gmax;
