@@ -50,7 +50,7 @@ const OptDef kOptions[] = {
     {"kept_pack", "CVO_HIP_NO_PACK", 1, 0.0},             {"list_margin", "CVO_HIP_LIST_MARGIN", 2, 0.0},
     {"final_mirror", "CVO_HIP_NO_FINAL_MIRROR", 1, 0.0},  {"twist_on_shared_gpu", "CVO_HIP_TWIST_ON_SHARED_GPU", 1, 1.0},
     {"comm_debug", "CVO_HIP_COMM_DEBUG", 1, 1.0},         {"wait_policy", "CVO_HIP_WAIT_POLICY", 2, 0.0},
-    {"acvo_runs", "CVO_HIP_NO_ACVO_RUN", 1, 0.0},
+    {"acvo_runs", "CVO_HIP_NO_ACVO_RUN", 1, 0.0},         {"alone_max", "CVO_HIP_ALONE_MAX", 2, 0.0},
 };
 void env_defaults(cvo_hip_ctx *ctx)
 {
@@ -107,6 +107,7 @@ int apply_option(cvo_hip_ctx *ctx, const char *key, double v)
     else if (is("comm_debug")) o.comm_debug = on;
     else if (is("wait_policy")) { if (v < 0.0 || v > 2.0) return CVO_HIP_ERR_INVALID; o.wait_policy = (int)v; }
     else if (is("acvo_runs")) o.no_acvo_run = !on;
+    else if (is("alone_max")) { if (v < 0.0 || v > 64.0) return CVO_HIP_ERR_INVALID; o.alone_max = (int)v; }
     else return CVO_HIP_ERR_INVALID;
     return CVO_HIP_OK;
 }
@@ -870,8 +871,10 @@ int cvo_hip_get_option(const cvo_hip_ctx *ctx, const char *key, double *value)
     else if (is("comm_debug")) *value = o.comm_debug;
     else if (is("wait_policy")) *value = o.wait_policy;
     else if (is("acvo_runs")) *value = !o.no_acvo_run;
+    else if (is("alone_max")) *value = o.alone_max;
     // read-only counters
     else if (is("run_timeouts")) *value = (double)ctx->run_timeouts;
+    else if (is("run_aborts")) *value = (double)ctx->run_aborts;
     else if (is("no_run_backoff")) *value = ctx->no_run_backoff;
     else return CVO_HIP_ERR_INVALID;
     return CVO_HIP_OK;

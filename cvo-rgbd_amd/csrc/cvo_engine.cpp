@@ -60,8 +60,12 @@ bool better_alone(const std::deque<AlignJob *> &pending)
             return false;
         pairs = std::max(pairs, (double)c->fixed.n * (double)c->moving.n);
     }
-    const size_t few = acvo ? (pairs <= 1.6e7 ? 8 : (pairs <= 5.0e7 ? 4 : (pairs <= 1.2e8 ? 2 : 0)))   // (10k x 10k, 2 per call: 429 against 841)
-                            : (pairs <= 1.6e7 ? 12 : (pairs <= 5.0e7 ? 8 : (pairs <= 2.0e8 ? 2 : 0)));   // (16 x 3k: 2 520-2 870 against 2 820-2 830)
+    // (round 6, with every registration's runs sized to its share of the compute units and acvo in runs as well -- on their own / through the
+    // engines, profiles/r06_ab.txt 4: cvo 3k 12 per call 2 758 / 2 181, 16: 2 633 / 2 652; 6k 12: 2 800 / 2 939; 10k 3: 1 140 / 761, 4: 1 277 / 826;
+    // acvo 3k 12: 2 836 / 1 653; 6k 4: 2 373 / 972, 8: 1 463 / 1 481; 10k 2 / 3 / 4: 1 316 / 455, 1 073 / 814, 1 102 / 965)
+    const size_t few = acvo ? (pairs <= 1.6e7 ? 12 : (pairs <= 5.0e7 ? 4 : (pairs <= 1.2e8 ? 4 : 0)))
+                            : (pairs <= 1.6e7 ? 12 : (pairs <= 5.0e7 ? 8 : (pairs <= 2.0e8 ? 4 : 0)));
+    if (const int force = pending.front()->ctx->opt.alone_max) return pending.size() <= (size_t)force;   // (tuning probe: "alone_max")
     return pending.size() <= few;
 }
 
@@ -563,21 +567,48 @@ int cvo_hip_align_many(cvo_hip_ctx **ctxs, cvo_hip_state **states, int *n_iters,
         for (int i = 0; i < count; ++i)
             if (jobs[i].phase == 2 && jobs[i].rc && !first_err) first_err = jobs[i].rc;
     }
-    // the others run on their own streams and tables
-    for (int i = 0; i < count; ++i) {
-        if (taken[i] || jobs[i].phase == 2) continue;
+    // the others run on their own streams and tables.  Those of them that run resident runs spin side by side, a block per compute
+    // unit: with k of them in the call each keeps its runs to (units / k) - 1 solvers, so that k (g + 1) blocks are resident together
+    // whatever their records want (four 3k registrations asked for 128-solver runs on spec: two of four entries waited out their
+    // 200 us and backed off -- 4 per call 1 808 /s against 2 210 for 2, profiles/r05_ab.txt 22), and with more than two of them no
+    // first run goes out on spec
+    int k_alone = 0;
+    for (int i = 0; i < count; ++i)
+        if (!taken[i] && jobs[i].phase != 2) ++k_alone;
+    // (at most kAloneLive of them in flight: with more, the share of each no longer holds its first records -- 12 per call were
+    // slower than 8 --; the others begin as these end)
+    constexpr int kAloneLive = 8;
+    std::vector<char> begun((size_t)count, 0);
+    auto begin_job = [&](int i) {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, jobs[i].ctx->device) != hipSuccess || cus <= 0) cus = RUN_G + 8;
+        const int share = std::min(k_alone, kAloneLive);
+        jobs[i].ctx->run_g_call = share > 1 ? std::max(8, (cus - 8) / share - 1) : RUN_G;
+        jobs[i].ctx->call_no_spec = share > 2;
         jobs[i].ctx->crowded = false;
         jobs[i].ctx->lone = true;
         jobs[i].paced_nb = true;   // (job_pump's paced steps, one look per call: resident runs for registrations on their own here too)
+        begun[(size_t)i] = 1;
         const int rc = job_begin(jobs[i]);
         if (rc) { jobs[i].rc = rc; jobs[i].phase = 2; if (!first_err) first_err = rc; }
-    }
+    };
+    auto is_alone = [&](int i) { return !taken[i]; };
     // round-robin: every pass tops up each registration's queue and looks at its
     // poll word without blocking; when nobody moved, block on the oldest job
     for (;;) {
-        int live = 0, moved = 0, first_live = -1;
+        int live = 0, moved = 0, first_live = -1, waiting = 0;
+        for (int i = 0; i < count; ++i)
+            if (is_alone(i) && begun[(size_t)i] && jobs[i].phase != 2) ++live;
+        // (the ranks of a mailbox world wait for each other: all of them begin at once, whatever their number)
+        for (int i = 0; i < count; ++i)
+            if (is_alone(i) && !begun[(size_t)i] && jobs[i].phase != 2 && (live < kAloneLive || multi_rank(jobs[i].ctx))) {
+                begin_job(i); ++moved;
+                if (jobs[i].phase != 2) ++live;
+            }
+        live = 0;
         for (int i = 0; i < count; ++i) {
             if (jobs[i].phase == 2) continue;
+            if (is_alone(i) && !begun[(size_t)i]) { ++waiting; continue; }
             const int before_phase = jobs[i].phase, before_checked = jobs[i].checked + jobs[i].batches;
             if (job_pump(jobs[i], false)) {
                 if (jobs[i].rc && !first_err) first_err = jobs[i].rc;
@@ -588,8 +619,8 @@ int cvo_hip_align_many(cvo_hip_ctx **ctxs, cvo_hip_state **states, int *n_iters,
             if (first_live < 0) first_live = i;
             if (jobs[i].phase != before_phase || jobs[i].checked + jobs[i].batches != before_checked) ++moved;
         }
-        if (live == 0) break;
-        if (!moved) {
+        if (live == 0 && waiting == 0) break;
+        if (!moved && first_live >= 0) {
             if (job_pump(jobs[first_live], true) && jobs[first_live].rc && !first_err)
                 first_err = jobs[first_live].rc;
         }

@@ -242,6 +242,7 @@ struct CtxOptions {
     bool comm_debug = false;          // "comm_debug"
     bool post_debug = false;          // "post_debug" (environment only: the buffer is made at create)
     bool no_acvo_run = false;         // "acvo_runs" = 0: resident runs for cvo registrations only (round 5's state)
+    int alone_max = 0;                // "alone_max": a call of up to this many registrations leaves them to their own streams (0: by the clouds)
     int engines_force = 0;            // "engines": engines of an align_many call (0: by the call's size)
     double list_init = 0.0;           // "list_init": first capacity of every list (0: by the clouds)
     float list_margin = -1.0f;        // "list_margin": width of the tile lists (< 0: by the clouds)
@@ -256,6 +257,7 @@ struct CtxOptions {
 struct cvo_hip_ctx {
     CtxOptions opt;
     int no_run_backoff = 0;              // registrations to go without resident runs (one of them timed out, job_pump)
+    long long run_aborts = 0;            // resident runs of this context that gave up at their entry hand-shake ("run_aborts")
     long long run_timeouts = 0;          // resident runs of this context that gave up on an exchange (cvo_hip_get_option "run_timeouts")
     int device = 0;
     hipStream_t stream = nullptr;
@@ -278,6 +280,9 @@ struct cvo_hip_ctx {
     bool plan_has_final_mirror = false;   // the plan of the align() in progress publishes its final head to final_mirror
     bool allow_run = true;                // CVO_HIP_NO_RUN
     int run_g_max = RUN_G;                // solver blocks of a resident run at most: a block per compute unit, a few to spare (cvo_hip_create)
+    int run_g_call = RUN_G;               // ... and in the call in progress: a small cvo_hip_align_many call leaves k registrations to their own streams, whose
+                                          // runs spin side by side -- k (g + 1) blocks must fit the compute units (cvo_engine.cpp)
+    bool call_no_spec = false;            // ... and with more than two of them no first run goes out on spec (a record that does not fit costs every neighbour)
     int big_run_backoff = 0;              // registrations to go without runs of more than 32 solvers (one gave up at its entry hand-shake, job_pump)
     bool spec_first_run = true;           // the first run of a registration goes out on spec behind its first two slots (job_pump learns from each try)
     bool head_graphs = false;             // CVO_HIP_RUN_GRAPHS: head-mode plans go out as captured batches too (they launch eagerly by default)

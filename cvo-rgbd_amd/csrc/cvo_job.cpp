@@ -122,12 +122,13 @@ int job_begin(AlignJob &j)
     // (a batch begins with a resident run when the record in use is expected to hold at most this many candidates -- DevHead::
     // run_hint: the record's count where the last head knew it, else an estimate with 5 % of room; a run that finds more than it can
     // hold declines, which costs its launch and one head)
-    ctx->run_nnz_max = ctx->run_g_max * RUN_BLOCK * (RUN_R + RUN_L);
+    const int g_call = std::max(8, std::min(ctx->run_g_max, ctx->run_g_call));
+    ctx->run_nnz_max = g_call * RUN_BLOCK * (RUN_R + RUN_L);
     // (acvo: a run holds RUN_A candidates per lane of EACH of its three records, and the hint speaks of the xy record alone -- the
     // self records of two copies of a surface hold ~1.2 x as many)
     ctx->run_small_max = 3 * RUN_G_SMALL * RUN_BLOCK;
     if (ctx->prm.mode == CVO_HIP_MODE_ACVO) {
-        ctx->run_nnz_max = (int)(0.8 * ctx->run_g_max * RUN_BLOCK * RUN_A);
+        ctx->run_nnz_max = (int)(0.8 * g_call * RUN_BLOCK * RUN_A);
         ctx->run_small_max = (int)(0.8 * 2 * RUN_G_SMALL * RUN_BLOCK);
     }
     if (ctx->big_run_backoff > 0) --ctx->big_run_backoff;
@@ -235,7 +236,7 @@ int job_pump(AlignJob &j, bool block)
                     // (the run that was sent on spec behind the first two slots: did it carry slots, or decline?)
                     // (a run that gave up at its entry hand-shake: something else -- another thread's registration, most likely -- holds
                     // the compute units.  Runs of more than 32 solvers stay away for the next registrations: each try costs its 200 us wait)
-                    if (runs_word & RUN_MIRROR_ABORTED) ctx->big_run_backoff = kBigRunBackoff;
+                    if (runs_word & RUN_MIRROR_ABORTED) { ctx->big_run_backoff = kBigRunBackoff; ++ctx->run_aborts; }
                     else if (j.spec_pending) ctx->spec_first_run = (runs_word & RUN_MIRROR_ENTERED) != 0;
                     j.spec_pending = false;
                     j.enq = slots + kRunBatchSlots; j.run_waiting = false;
@@ -255,7 +256,7 @@ int job_pump(AlignJob &j, bool block)
                 const bool first_choice = run_plan_ && j.batches == 1 && j.enq == kShortBatch && j.runs_enq == 0;
                 if (run_plan_ && j.batches == 2 && j.runs_enq == 0 && !ctx->spec_first_run && hint > 0) ctx->spec_first_run = hint <= ctx->run_nnz_max;
                 const bool big_ok = ctx->big_run_backoff <= 0;   // (see above)
-                const bool spec = first_choice && ctx->spec_first_run && big_ok;
+                const bool spec = first_choice && ctx->spec_first_run && big_ok && !ctx->call_no_spec;
                 if (spec) j.spec_pending = true;
                 const bool with_run = run_plan_ && (spec || (hint > 0 && hint <= (big_ok ? ctx->run_nnz_max : ctx->run_small_max)));
                 // (a plan with runs is launched eagerly and in the shortest batches: a run can only start at a batch's head, and the
@@ -472,6 +473,8 @@ int cvo_hip_align(cvo_hip_ctx *ctx, cvo_hip_state *s, cvo_hip_trace *trace, int 
     AlignJob j;
     j.ctx = ctx; j.s = s; j.trace = trace; j.trace_cap = trace_cap; j.n_iter = n_iter;
     j.paced = true;
+    ctx->run_g_call = RUN_G;   // (the GPU is this registration's: no neighbours to leave room for)
+    ctx->call_no_spec = false;
     int rc = job_begin(j);
     if (rc) return rc;
     while (!job_pump(j, true)) {}

@@ -601,7 +601,7 @@ int enqueue_step(cvo_hip_ctx *ctx, int check_done, bool do_math, cvo_hip_trace *
             pa.run_mail = (RunMail *)ctx->run_mail.p;
             pa.run_mirror = ctx->run_mirror;
             pa.run_iters = 64;
-            pa.run_g_max = ctx->run_g_max;
+            pa.run_g_max = std::max(8, std::min(ctx->run_g_max, ctx->run_g_call));
             pa.run_timeout_ticks = (long long)(ctx->opt.run_timeout_ms * 1.0e5);   // (100 MHz; 0: the kernel's own second)
             pa.run_fault = ctx->opt.run_fault;
         } else {   // (an optimisation: without its memory the plan has no runs)
@@ -799,7 +799,7 @@ bool plan_lone(const std::vector<RecOp> &ops, Slot &slot, std::vector<TLaunch> &
             flow.weight == 0 && 4 * flow.nblk <= PROC_WAVES && self[0].cand && self[0].cand_b && self[1].cand && self[1].cand_b &&
             self[0].tf_a == 0 && self[0].tf_b == 0 && self[1].tf_a == 1 && self[1].tf_b == 1 && 4 * self[0].nblk <= PROC_WAVES &&
             4 * self[1].nblk <= PROC_WAVES && q + 3 < 16) {
-            pre->push_back(mk_launch(TK_RUN_ACVO, q | ((q + 3) << 4), 1u + RUN_G, 1));
+            pre->push_back(mk_launch(TK_RUN_ACVO, q | ((q + 3) << 4), 1u + (unsigned)std::max(8, std::min((int)RUN_G, o.ps.run_g_max)), 1));   // (no more blocks than the run may use: a block that is not needed still takes a compute unit until it knows)
             pre->push_back(mk_launch(TK_RUN_ACVO, q | ((q + 3) << 4), 1u + RUN_G_SMALL, 1));   // (for narrow records: launch_batch picks one)
         }
         q += 3;
@@ -839,7 +839,7 @@ bool plan_lone(const std::vector<RecOp> &ops, Slot &slot, std::vector<TLaunch> &
             // cloud read as it came
             if (head && pre && o.ps.run_mail && flow.cand && flow.cand_b && flow.kept_packed == 1 && flow.tf_a == 0 && flow.tf_b == 1 &&
                 flow.weight == 0 && 4 * flow.nblk <= PROC_WAVES) {
-                pre->push_back(mk_launch(TK_RUN, q | ((q + 1) << 4), 1u + RUN_G, 1));
+                pre->push_back(mk_launch(TK_RUN, q | ((q + 1) << 4), 1u + (unsigned)std::max(8, std::min((int)RUN_G, o.ps.run_g_max)), 1));   // (no more blocks than the run may use: a block that is not needed still takes a compute unit until it knows)
                 pre->push_back(mk_launch(TK_RUN, q | ((q + 1) << 4), 1u + RUN_G_SMALL, 1));   // (for a narrow record: launch_batch picks one)
             }
             ++q;

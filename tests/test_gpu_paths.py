@@ -1273,6 +1273,22 @@ def test_small_align_many_calls_of_small_clouds_run_on_their_own(pkg, monkeypatc
 
     alone, st_alone = call()
     assert all(s[0] >= 1 for s in st_alone), st_alone        # resident runs were entered
+    # ... and none of them gave up at its entry hand-shake: the call sizes its registrations' runs so that all of them are resident
+    # together (k (g + 1) blocks on the device's compute units) -- 2, 4 and 8 front-end-sized registrations per call
+    big = [pkg.data.synthetic_pair(3000, 3000, seed=8900 + b) for b in range(8)]
+    for k in (2, 4, 8):
+        cs, ss = [], []
+        for xf, ff, xm, fm in big[:k]:
+            s = torch.cuda.Stream()
+            c = capi.Context(mode=capi.MODE_CVO, device=0, stream=s.cuda_stream)
+            c.set_fixed(xf, ff); c.set_moving(xm, fm)
+            cs.append(c); ss.append(s)
+        for _ in range(4):
+            capi.align_many(cs, [capi.init_state(c.params) for c in cs])
+        assert [c.get_option("run_aborts") for c in cs] == [0.0] * k, k
+        assert all(c.run_stats()[0] >= 1 for c in cs), k
+        for c in cs:
+            c.close()
     monkeypatch.setenv("CVO_HIP_NO_ALONE", "1")
     fused, st_fused = call()
     monkeypatch.delenv("CVO_HIP_NO_ALONE")
