@@ -50,7 +50,8 @@ const OptDef kOptions[] = {
     {"kept_pack", "CVO_HIP_NO_PACK", 1, 0.0},             {"list_margin", "CVO_HIP_LIST_MARGIN", 2, 0.0},
     {"final_mirror", "CVO_HIP_NO_FINAL_MIRROR", 1, 0.0},  {"twist_on_shared_gpu", "CVO_HIP_TWIST_ON_SHARED_GPU", 1, 1.0},
     {"comm_debug", "CVO_HIP_COMM_DEBUG", 1, 1.0},         {"wait_policy", "CVO_HIP_WAIT_POLICY", 2, 0.0},
-    {"acvo_runs", "CVO_HIP_NO_ACVO_RUN", 1, 0.0},         {"alone_max", "CVO_HIP_ALONE_MAX", 2, 0.0},
+    {"acvo_runs", "CVO_HIP_NO_ACVO_RUN", 1, 0.0},         {"side_builds", "CVO_HIP_SIDE", 1, 1.0},
+    {"run_build_at", "CVO_HIP_RUN_BUILD_AT", 2, 0.0},         {"alone_max", "CVO_HIP_ALONE_MAX", 2, 0.0},
 };
 void env_defaults(cvo_hip_ctx *ctx)
 {
@@ -107,6 +108,9 @@ int apply_option(cvo_hip_ctx *ctx, const char *key, double v)
     else if (is("comm_debug")) o.comm_debug = on;
     else if (is("wait_policy")) { if (v < 0.0 || v > 2.0) return CVO_HIP_ERR_INVALID; o.wait_policy = (int)v; }
     else if (is("acvo_runs")) o.no_acvo_run = !on;
+    else if (is("run_restart")) o.no_restart = !on;
+    else if (is("side_builds")) o.no_side_builds = !on;
+    else if (is("run_build_at")) { if (!(v > 0.0 && v <= 1.0)) return CVO_HIP_ERR_INVALID; o.run_build_at = (float)v; }
     else if (is("alone_max")) { if (v < 0.0 || v > 64.0) return CVO_HIP_ERR_INVALID; o.alone_max = (int)v; }
     else return CVO_HIP_ERR_INVALID;
     return CVO_HIP_OK;
@@ -299,6 +303,8 @@ int cvo_hip_create(int device, void *stream, const cvo_hip_params *p, cvo_hip_ct
     static_assert(sizeof(DevState) >= 2048 + sizeof(DevHead), "the mirrors share a pinned DevState");
     ctx->run_mirror = ctx->done_mirror + 32;
     ctx->hint_mirror = ctx->done_mirror + 48;
+    ctx->side_mirror = ctx->done_mirror + 64;
+    *ctx->side_mirror = 0;
     *ctx->done_mirror = 0;
     *ctx->progress_mirror = 0;
     *ctx->run_mirror = 0;
@@ -374,6 +380,7 @@ int cvo_hip_destroy(cvo_hip_ctx *ctx)
         if (b->p) (void)hipFree(b->p);
     if (ctx->bbox_dev) (void)hipFree(ctx->bbox_dev);
     if (ctx->bbox_host) (void)hipHostFree(ctx->bbox_host);
+    if (ctx->side_stream) { (void)hipStreamSynchronize(ctx->side_stream); (void)hipStreamDestroy(ctx->side_stream); }
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return CVO_HIP_OK;
@@ -871,6 +878,10 @@ int cvo_hip_get_option(const cvo_hip_ctx *ctx, const char *key, double *value)
     else if (is("comm_debug")) *value = o.comm_debug;
     else if (is("wait_policy")) *value = o.wait_policy;
     else if (is("acvo_runs")) *value = !o.no_acvo_run;
+    else if (is("run_restart")) *value = !o.no_restart;
+    else if (is("side_builds")) *value = !o.no_side_builds;
+    else if (is("run_build_at")) *value = o.run_build_at;
+    else if (is("side_builds_launched")) *value = (double)ctx->side_builds_launched;
     else if (is("alone_max")) *value = o.alone_max;
     // read-only counters
     else if (is("run_timeouts")) *value = (double)ctx->run_timeouts;

@@ -147,7 +147,12 @@ struct RunMail {
     // does not happen in time (another large run holds the compute units): nothing has been written, the run declines
     unsigned long long entry_ticket;
     unsigned long long entry_go;                      // (launch number + 1) << 32 | RUN_GO / RUN_ABORT
+    // side builds (round 6, kt_run "side builds"): blocks of the record pass of side builds that have ended (kt_side_record; never reset),
+    // and the requests the runs' head blocks have made (the host's side mirror carries the same number)
+    unsigned long long side_done;
+    unsigned long long side_req;
 };
+constexpr int RUN_G_SIDE = 128;      // a run of up to this many solvers has its next xy list built BESIDE it (the side kernels need compute units of their own)
 
 struct KernConsts {
     float tau;        // d2 < tau
@@ -272,6 +277,8 @@ struct DevState : DevHead {
     int32_t run_entered;    // ... runs that executed at least one iteration, and the iterations executed inside runs (cvo_hip_get_run_stats)
     int32_t run_iterations;
     int32_t run_candidates; // candidates of the record the last run looked at
+    int32_t run_last_entered, run_last_aborted;   // run_count as the last run that carried slots / gave up at its entry left it: a batch may bring two
+                            // runs, and the host looks at the mirror when both have reported (run_over)
     long long run_clk[16];  // CVO_RUN_CLOCKS builds: ticks of the first solver block by phase (tools/gpu_run_clocks.py)
     // exchanges done through the mailboxes since the context was created (never reset: the
     // sequence numbers of successive align() calls must keep alternating between the two
@@ -415,6 +422,10 @@ struct PostStepArgs {
     int run_iters;         // iterations per run at most
     int run_g_max;         // solver blocks of a run at most (RUN_G on an unpartitioned MI355X; fewer compute units: fewer, cvo_hip_create)
     long long run_timeout_ticks;   // how long a poll of a run's exchange waits (100 MHz wall clock; cvo_hip_set_option "run_timeout_ms")
+    int32_t *side_mirror;  // pinned (null: no side builds): the head block of a run that wants its next xy list built beside it writes the request's
+                           // number here; the host launches kt_side_filter + kt_side_record on the context's side stream (cvo_job.cpp job_pump)
+    float run_build_at;    // ... and with side builds a run names its builds when this fraction of the list's room is gone (DevParams::build_at:
+                           // the launch-per-pass path, whose builds take one slot)
     int run_fault;         // test switch (cvo_hip_set_option "run_fault" = n > 0): the first solver of every run leaves at the top of its n-th
                            // iteration without a word -- what a block lost to the scheduler looks like to its peers
     DevParams prm;
@@ -811,6 +822,7 @@ constexpr int STEP_TWIST_ROWS_DIV = 4;   // k_step_twist writes nblk / 4 partial
 enum TKernel { TK_FILTER = 0, TK_FILTER_GROUP, TK_FLOW, TK_FLOW_MATLAB, TK_STEP, TK_SELF, TK_SELF2, TK_STEP_TWIST,
                TK_FLOW_BUILD, TK_FLOW_BUILD3, TK_FLOW_BUILD6, TK_POST_FLOW, TK_POST_STEP,
                TK_HFLOW_BUILD, TK_HFLOW_BUILD6, TK_HSTEP_TWIST, TK_RUN /* q = flow op | step op << 4 */, TK_RUN_ACVO /* likewise; the self passes: flow op + 1, + 2 */,
+               TK_SIDE_FILTER, TK_SIDE_RECORD /* q = the flow op: the side build of a run's next xy list */,
                TK_FLOW_D2 /* TK_FLOW is built without the sums of a and of a d2 (ProcessArgs::need_d2 == 0 in every slot); this one has them */ };   // head mode (cvo_kernels.hip "Head mode")
 // Head-mode launches carry the slot's parity and the mode in the bits above the op index of their
 // second kernel argument: qp = q | parity << 8 | QP_HEAD.

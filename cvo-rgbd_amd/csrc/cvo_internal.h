@@ -241,6 +241,10 @@ struct CtxOptions {
     bool twist_on_shared_gpu = false; // "twist_on_shared_gpu": in-launch exchange although the ranks share a GPU
     bool comm_debug = false;          // "comm_debug"
     bool post_debug = false;          // "post_debug" (environment only: the buffer is made at create)
+    bool no_side_builds = true;       // "side_builds" = 1: a resident run of up to RUN_G_SIDE solvers has its next xy list built beside it (kt_run "side
+                                      // builds"; built and measured in round 6, slower than ending the run: off unless asked for, profiles/r06_ab.txt 7)
+    float run_build_at = 0.6f;        // "run_build_at": with side builds a run names its next list when this fraction of the room of the list in use is gone
+    bool no_restart = false;          // "run_restart" = 0 (diagnostics): a run that times out fails the registration with CVO_HIP_ERR_RUN, its state kept
     bool no_acvo_run = false;         // "acvo_runs" = 0: resident runs for cvo registrations only (round 5's state)
     int alone_max = 0;                // "alone_max": a call of up to this many registrations leaves them to their own streams (0: by the clouds)
     int engines_force = 0;            // "engines": engines of an align_many call (0: by the call's size)
@@ -257,6 +261,7 @@ struct CtxOptions {
 struct cvo_hip_ctx {
     CtxOptions opt;
     int no_run_backoff = 0;              // registrations to go without resident runs (one of them timed out, job_pump)
+    long long side_builds_launched = 0;  // side builds launched by this context ("side_builds_launched")
     long long run_aborts = 0;            // resident runs of this context that gave up at their entry hand-shake ("run_aborts")
     long long run_timeouts = 0;          // resident runs of this context that gave up on an exchange (cvo_hip_get_option "run_timeouts")
     int device = 0;
@@ -276,6 +281,9 @@ struct cvo_hip_ctx {
     DevHead *final_mirror = nullptr;      // pinned: the head of a loop that stopped with a verdict (PostStepArgs::final_mirror)
     int32_t *run_mirror = nullptr;        // pinned: resident runs (kt_run) that have ended since align() began
     int32_t *hint_mirror = nullptr;       // pinned: DevHead::run_hint, candidates expected in the record in use (-1: none yet)
+    int32_t *side_mirror = nullptr;       // pinned: requests for side builds the runs of the align() in progress have made (PostStepArgs::side_mirror)
+    hipStream_t side_stream = nullptr;    // ... and the stream their kernels go out on (made when a plan first has them)
+    std::vector<TLaunch> plan_side;       // ... the two launches of a side build (kt_side_filter, kt_side_record); empty: the plan has none
     DevBuf run_mail;                      // RunMail of this registration's resident runs
     bool plan_has_final_mirror = false;   // the plan of the align() in progress publishes its final head to final_mirror
     bool allow_run = true;                // CVO_HIP_NO_RUN
@@ -383,6 +391,8 @@ struct AlignJob {
     bool spec_pending = false;  // ... and that run was sent on spec (job_pump: the first run of a registration)
     bool paced_nb = false;  // a registration on its own inside cvo_hip_align_many: the paced steps of job_pump, one look per call
     int idle_seen = 0;      // ... and how often in a row its stream was found idle with the mirrors where they were
+    int side_seen = 0;      // the last request for a side build that was answered (the side mirror's word)
+    int side_launched = 0;  // side builds launched for this registration
     int restarts = 0;       // times this registration was begun again without resident runs (a run of it timed out)
     bool paced = false;     // cvo_hip_align only: the calling thread has nothing else to pump and may sit in the
                             // paced loop of job_pump (align_many's blocking fall-back must keep its round-robin going:
@@ -424,14 +434,14 @@ int enqueue_iterations(cvo_hip_ctx *ctx, int count, int tag0, int trace_cap);
 void drop_graphs(cvo_hip_ctx *ctx);
 TLaunch mk_launch(int kernel, int q, unsigned gx, unsigned gz, unsigned smem = 0);
 bool plan_lone(const std::vector<RecOp> &ops, Slot &slot, std::vector<TLaunch> &plan, const bool allow_head, bool *head_mode,
-               std::vector<TLaunch> *pre = nullptr);
+               std::vector<TLaunch> *pre = nullptr, std::vector<TLaunch> *side = nullptr);
 void set_build_masks(Slot &slot, const std::vector<TLaunch> &plan, uint32_t *masks, int z);
 bool plan_fused(const std::vector<const std::vector<RecOp> *> &ops, const std::vector<Slot *> &slots, int zdim, std::vector<TLaunch> &plan);
 int run_plan(const Slot *tab, PlanCache &cache, const std::vector<TLaunch> &plan, hipStream_t s, bool use_graph, int iterations,
              const std::vector<TLaunch> *pre = nullptr);
 int record_iteration(cvo_hip_ctx *ctx, std::vector<RecOp> &ops, int trace_cap);
 int prepare_lone_plan(cvo_hip_ctx *ctx, int trace_cap);
-int launch_batch(cvo_hip_ctx *ctx, int tag0, int trace_cap, bool with_run = false, int slots = kBatch, bool small_run = false);
+int launch_batch(cvo_hip_ctx *ctx, int tag0, int trace_cap, bool with_run = false, int slots = kBatch, bool small_run = false, bool two_runs = false);
 constexpr int kNoRunBackoff = 64;    // registrations a context goes without resident runs after one of them timed out
 constexpr int kBigRunBackoff = 16;   // registrations a context keeps its large runs away after one of them found the compute units taken
 constexpr int kShortBatch = 2;      // classic slots of a batch of a plan that has a resident run (job_pump; an even number, see kBatch)

@@ -71,6 +71,9 @@ int job_begin(AlignJob &j)
     *ctx->progress_mirror = 0;
     *ctx->run_mirror = 0;
     *ctx->hint_mirror = -1;
+    *ctx->side_mirror = 0;
+    j.side_seen = 0;
+    j.side_launched = 0;
     if (ctx->final_mirror) ctx->final_mirror->done = RUNNING;   // (an old verdict must not pass for this registration's)
     if (!j.trace) j.trace_cap = 0;
     if (j.trace_cap > p.max_iter) j.trace_cap = p.max_iter;
@@ -222,6 +225,17 @@ int job_pump(AlignJob &j, bool block)
             const int runs_word = *(volatile int32_t *)ctx->run_mirror;
             const int runs = runs_word & (RUN_MIRROR_ABORTED - 1);
             const int slots = *(volatile int32_t *)ctx->progress_mirror;
+            // a run asks for its next list to be built beside it (kt_run "side builds"): two launches on the side stream
+            if (!ctx->plan_side.empty()) {
+                const int want = *(volatile int32_t *)ctx->side_mirror;
+                if (want != 0 && want != j.side_seen) {
+                    j.side_seen = want;
+                    for (const TLaunch &l : ctx->plan_side) launch_table(ctx->table.dev, l, ctx->side_stream);
+                    if (hipGetLastError() != hipSuccess) return finish_with(fail(ctx, CVO_HIP_ERR_HIP, "launching a side build failed"));
+                    ++j.side_launched;
+                    ++ctx->side_builds_launched;
+                }
+            }
             // (head mode without a flush: the post-step part of a batch's last slot runs in the head of the NEXT
             // batch's first launch, so the next batch must be on its way before the running one ends -- it goes
             // out when the running batch is down to its last slots; the GPU never idles between batches, and
@@ -263,9 +277,12 @@ int job_pump(AlignJob &j, bool block)
                 // slot it may start at is two or three slots after the head that first says so)
                 const bool near_run = ctx->head_mode && !ctx->plan_pre.empty() && !with_run;
                 const bool small_run = with_run && !spec && hint > 0 && hint <= ctx->run_small_max;   // (a launch of 33 blocks does)
-                const int rc = launch_batch(ctx, j.executed_base + j.enq, j.trace_cap, with_run, near_run ? kShortBatch : kBatch, small_run);
+                // (two runs in a row where the record is narrow enough for side builds: RUN_G_SIDE solvers, three candidates per lane)
+                const bool two_runs = with_run && !spec && !ctx->plan_side.empty() && hint > 0 &&
+                                      hint <= (int)((ctx->prm.mode == CVO_HIP_MODE_ACVO ? 0.8 : 1.0) * RUN_G_SIDE * RUN_BLOCK * 3);
+                const int rc = launch_batch(ctx, j.executed_base + j.enq, j.trace_cap, with_run, near_run ? kShortBatch : kBatch, small_run, two_runs);
                 if (rc) return finish_with(rc);
-                if (with_run) { ++j.runs_enq; j.run_waiting = true; }
+                if (with_run) { j.runs_enq += two_runs ? 2 : 1; j.run_waiting = true; }
                 else j.enq += near_run ? kShortBatch : kBatch;
                 ++j.batches;
                 spins = 0;
@@ -395,7 +412,10 @@ int job_pump(AlignJob &j, bool block)
     if (q == hipErrorNotReady) return 0;
     if (q != hipSuccess) return finish_with(fail(ctx, CVO_HIP_ERR_HIP, "state event failed"));
     const DevState &cur = ctx->st_host[0];
-    if (cur.done == DONE_RUN_TIMEOUT && j.restarts == 0 && !j.in_group) {
+    if (ctx->opt.comm_debug)
+        fprintf(stderr, "[cvo_hip] final state: done %d, side mirror %d (seen %d, launched %d), plan_side %zu\n", cur.done, *(volatile int32_t *)ctx->side_mirror,
+                j.side_seen, j.side_launched, ctx->plan_side.size());
+    if (cur.done == DONE_RUN_TIMEOUT && j.restarts == 0 && !j.in_group && !ctx->opt.no_restart) {
         // A resident run gave up on an exchange (kt_run: a block of it did not arrive within the limit -- GPU scheduling, most
         // likely another process's kernels on the compute units).  Nothing of the run is in the state and the caller's object
         // has not been touched: the registration is begun again, this time -- and for this context's next registrations --
@@ -405,7 +425,7 @@ int job_pump(AlignJob &j, bool block)
         ++j.restarts;
         ctx->no_run_backoff = kNoRunBackoff + 1;   // (job_begin takes one off)
         const unsigned long long seq = cur.run_seq + 4096ull;
-        if (hipStreamSynchronize(loop_stream(ctx)) != hipSuccess ||
+        if ((ctx->side_stream && hipStreamSynchronize(ctx->side_stream) != hipSuccess) || hipStreamSynchronize(loop_stream(ctx)) != hipSuccess ||
             hipMemcpy(reinterpret_cast<char *>(ctx->st) + offsetof(DevState, run_seq), &seq, sizeof(seq), hipMemcpyHostToDevice) != hipSuccess)
             return finish_with(fail(ctx, CVO_HIP_ERR_RUN, "a resident run timed out and the state could not be reset"));
         const int rc = job_begin(j);
@@ -442,6 +462,8 @@ int job_pump(AlignJob &j, bool block)
     *ctx->progress_mirror = 0;
     *ctx->run_mirror = 0;
     *ctx->hint_mirror = -1;
+    *ctx->side_mirror = 0;
+    j.side_seen = 0;
     j.runs_enq = 0;
     j.run_waiting = false;
     j.spec_pending = false;

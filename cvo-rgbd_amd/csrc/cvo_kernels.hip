@@ -993,7 +993,7 @@ __device__ __forceinline__ float eval_pair(const ARGS &a, const ProcHead &hd, co
 #ifdef CVO_PROBE_STEP_EXP   // (probe builds, profiles/r05_ab.txt 9: the least a step pass without a stored weight must do -- d2 and one exp per member)
         {
             const float d2p = __builtin_fmaf(e2, e2, __builtin_fmaf(e1, e1, e0 * e0));
-            const float kp = (float)(kc.s2_d * exp_neg((double)d2p * kc.ninv_2l2, etab));
+            const float kp = (float)(kc.s2_d * exp_neg((double)d2p * kc.ninv_2l2, etab ? etab : c_exp2_64));   // (kt_step_twist passes no table)
             asm volatile("" ::"v"(kp));
         }
 #endif
@@ -1066,7 +1066,11 @@ __device__ __forceinline__ bool expand_lists(const ProcessArgs &a, const ProcHea
                 const unsigned long long km = __ballot(w > 0.0f);
                 const unsigned add = (unsigned)__popcll(km);
                 if (nk + add <= a.kept_wcap) {
+#ifndef CVO_PROBE_NO_KEPT_STORE   // (probe builds: the expansion pass without its kept-list store, profiles/r06_ab.txt 6)
                     if (w > 0.0f) {
+#else
+                    if (false) {
+#endif
                         const unsigned below = __builtin_amdgcn_mbcnt_hi(
                             (unsigned)(km >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)km, 0u));
                         if (a.kept_packed) {
@@ -2704,22 +2708,22 @@ enum { RUN_V_STALL = 1, RUN_V_BUILD = 2 };            // the head block's verdic
 enum { RUN_GO = 1, RUN_ABORT = 2 };                    // ... and on a large run's entry (RunMail::entry_go)
 constexpr long long RUN_ENTRY_TICKS = 20000LL;         // 200 us: how long the head block of a large run waits for its solvers to start
 
-// One exchange among the g solver blocks: vals[0..NV) of this block (LDS, written before the call by threads < NV; `row` < 0:
+// One exchange among the g solver blocks: this block's NV sums -- thread t < 2 NV holds sum t >> 1 in my_val and sends its half of it
+// (round 6: the threads that add the waves' rows send what they have added; no copy through LDS, no barrier in front; `row` < 0:
 // this block only reads) -> tot[0..NV) = the sum of the g rows, added in ONE fixed order (four chains, then a tree).  All
 // threads call it.  seq: the exchange's number (every block counts the same).  verdict_out (block-uniform, may be null): the
 // head block's verdict word of this exchange is waited for as well and handed out.  Returns false on a time-out (block-uniform).
 template <int NV, int KMAX>
-__device__ __forceinline__ bool run_exchange_k(RunMail *mail, const int row, const int g, const unsigned long long seq, const double *vals,
+__device__ __forceinline__ bool run_exchange_k(RunMail *mail, const int row, const int g, const unsigned long long seq, const double my_val,
                                              double *all /* LDS [RUN_G * NV] */, double *part /* LDS [8 * NV] */, double *tot /* LDS [NV] */,
                                              int *s_fail, unsigned *verdict_out, unsigned *s_verdict, const long long timeout_ticks)
 {
     const int tid = threadIdx.x;
     const unsigned tag = (unsigned)seq;
     unsigned long long *slot = &mail->w[seq & (unsigned long long)(RUN_GEN - 1)][0][0];   // (four generations: cvo_device.h RunMail)
-    if (tid == 0) *s_fail = 0;
-    __syncthreads();   // (vals complete)
+    // (*s_fail: cleared once, before the run's first exchange -- a run does not go on after a time-out)
     if (row >= 0 && tid < 2 * NV) {
-        const unsigned long long bits = (unsigned long long)__double_as_longlong(vals[tid >> 1]);
+        const unsigned long long bits = (unsigned long long)__double_as_longlong(my_val);
         const unsigned half = (tid & 1) ? (unsigned)(bits >> 32) : (unsigned)bits;
         __hip_atomic_store(&slot[row * (2 * RUN_NV) + tid], ((unsigned long long)tag << 32) | half, __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_AGENT);
@@ -2776,14 +2780,14 @@ __device__ __forceinline__ bool run_exchange_k(RunMail *mail, const int row, con
     return *s_fail == 0;
 }
 template <int NV>
-__device__ __forceinline__ bool run_exchange(RunMail *mail, const int row, const int g, const unsigned long long seq, const double *vals,
+__device__ __forceinline__ bool run_exchange(RunMail *mail, const int row, const int g, const unsigned long long seq, const double my_val,
                                              double *all, double *part, double *tot, int *s_fail, unsigned *verdict_out, unsigned *s_verdict,
                                              const long long timeout_ticks)
 {
     static_assert(RUN_G_SMALL * 2 * NV + 1 <= 2 * RUN_BLOCK, "two words per thread up to RUN_G_SMALL solvers");
     constexpr int KBIG = (RUN_G * 2 * NV + 1 + RUN_BLOCK - 1) / RUN_BLOCK;
-    if (g <= RUN_G_SMALL) return run_exchange_k<NV, 2>(mail, row, g, seq, vals, all, part, tot, s_fail, verdict_out, s_verdict, timeout_ticks);
-    return run_exchange_k<NV, KBIG>(mail, row, g, seq, vals, all, part, tot, s_fail, verdict_out, s_verdict, timeout_ticks);
+    if (g <= RUN_G_SMALL) return run_exchange_k<NV, 2>(mail, row, g, seq, my_val, all, part, tot, s_fail, verdict_out, s_verdict, timeout_ticks);
+    return run_exchange_k<NV, KBIG>(mail, row, g, seq, my_val, all, part, tot, s_fail, verdict_out, s_verdict, timeout_ticks);
 }
 
 // The passes of a run over NR candidates per lane, straight-line: the NR chains (transform, exact test, a float64 exp, the
@@ -2872,6 +2876,7 @@ __device__ __forceinline__ unsigned run_yy_rounds(const float (&rt)[12], const K
 }
 
 __global__ void kt_run(const Slot *__restrict__ tab, const int qs);
+__global__ void kt_run_side(const Slot *__restrict__ tab, const int qs);
 // ... and over the NL candidates per lane that live in LDS behind the registers' (the widest runs: RUN_L): lane t's candidate of
 // round r as two 16-byte pieces, [x0 x1 x2 ck] at lc[(2 r) * RUN_BLOCK + t] and [y0 y1 y2 w] behind it -- every lane reads and
 // writes its own pieces only (no barrier), a wave's accesses are consecutive (no bank conflict).  The same arithmetic per pair.
@@ -2926,7 +2931,8 @@ hipError_t run_allow_lds()
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
     if (allowed[dev].load(std::memory_order_acquire)) return hipSuccess;
-    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kt_run), hipFuncAttributeMaxDynamicSharedMemorySize, (int)RUN_LDS_BYTES);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kt_run), hipFuncAttributeMaxDynamicSharedMemorySize, (int)RUN_LDS_BYTES);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(kt_run_side), hipFuncAttributeMaxDynamicSharedMemorySize, (int)RUN_LDS_BYTES);
     if (e == hipSuccess) allowed[dev].store(1, std::memory_order_release);
     return e;
 }
@@ -2936,7 +2942,9 @@ hipError_t run_allow_lds()
 // falls to its floor within a few iterations: its records are narrow), 13 sums in the first exchange (the nine of the flow side,
 // sum and count of Axx, tail sum and count of Ayy), dl and the length-scale update in every block's head_post, kernel constants
 // made again in every block whenever the length scale has moved, a build of ANY of the three lists ends the run.
-template <bool ACVO>
+// SIDE: the kernels with side builds (kt_run_side, kt_run_acvo_side: kt_run "side builds"; an option) are instantiations of their own -- with
+// that code in, the compiler spilled 123 vector registers of the plain kernels instead of 19 and every run was 6 % slower.
+template <bool ACVO, bool SIDE = false>
 __device__ __forceinline__ void run_body(const Slot *__restrict__ tab, const int qs, float4 *const s_lc)
 {
     __shared__ unsigned long long s_ticket;
@@ -2966,7 +2974,6 @@ __device__ __forceinline__ void run_body(const Slot *__restrict__ tab, const int
 
     __shared__ __attribute__((aligned(16))) DevHead s_st;
     __shared__ double s_red[RUN_WAVES * NACC_MAX];
-    __shared__ double s_vals[NVF];
     __shared__ double s_self[RUN_WAVES * 4];   // acvo: the waves' xx / yy sums (sum, count, tail sum, count)
     __shared__ double s_xx_keep[2];            // acvo: this block's Axx sums ...
     __shared__ float s_xx_ell;                 // ... and the length scale they were made at (they are a function of nothing else)
@@ -2980,6 +2987,11 @@ __device__ __forceinline__ void run_body(const Slot *__restrict__ tab, const int
     __shared__ unsigned s_pref_self[ACVO ? 2 * (PROC_WAVES + 1) : 2];
     __shared__ double s_part[8 * NVF];
     __shared__ double s_tot[NVF + 4];
+    // side builds (head block): the buffer whose build is in flight beside the run (-1: none), handed = it has ended and the plan has been
+    // told (xy_fresh), the count of RunMail::side_done that says it has ended, verdict bits the coming slot gets on top of the plan's
+    __shared__ int s_side_t, s_side_handed, s_side_fail;
+    __shared__ unsigned long long s_side_expect;
+    __shared__ unsigned s_vbits;
     __shared__ double s_dl;   // acvo: dl of the slot (ref src/adaptive_cvo.cpp:271), every block's own
     __shared__ double s_etab[64];
     __shared__ cvo_math::XiConsts s_xi;
@@ -3036,7 +3048,11 @@ __device__ __forceinline__ void run_body(const Slot *__restrict__ tab, const int
         if (head_block && tid == 0) {
             const int c = gst->run_count + 1;
             gst->run_count = c;
-            if (ps.run_mirror && s_st.done == RUNNING) *ps.run_mirror = c | (entered ? RUN_MIRROR_ENTERED : 0) | (aborted ? RUN_MIRROR_ABORTED : 0);
+            // (a batch may bring two runs: the word of the second also says what the first did)
+            if (entered) gst->run_last_entered = c;
+            if (aborted) gst->run_last_aborted = c;
+            const bool e2 = entered || (c > 1 && gst->run_last_entered == c - 1), a2 = aborted || (c > 1 && gst->run_last_aborted == c - 1);
+            if (ps.run_mirror && s_st.done == RUNNING) *ps.run_mirror = c | (e2 ? RUN_MIRROR_ENTERED : 0) | (a2 ? RUN_MIRROR_ABORTED : 0);
         }
     };
     // what would make this launch a plain head-mode flow launch's business: a loop that has stopped, a stall slot,
@@ -3345,14 +3361,58 @@ __device__ __forceinline__ void run_body(const Slot *__restrict__ tab, const int
     }
 
     bool comm_ok = true;
+    if (tid == 0) s_fail = 0;   // (the barriers of the first pass lie between this and the first poll)
     const int need_d2 = ACVO ? 1 : pa.need_d2;   // (acvo: the sum of a d2 is a term of dl)
     const int iters = ps.run_iters > 0 ? ps.run_iters : 1;
     const long long run_timeout = ps.run_timeout_ticks > 0 ? ps.run_timeout_ticks : RUN_TIMEOUT_TICKS;
+    // ---- SIDE BUILDS (round 6).  A run used to end for every list build: two launch-per-pass slots (one builds beside its passes, the next
+    // expands and records) and a new entry, 45-75 us for two iterations.  A run of up to RUN_G_SIDE solvers now has its next xy list built
+    // BESIDE it: when its head names a build, the head block puts the head where the side kernels read it (the second copy of the state's
+    // head, idle during a run), zeroes the list's counters and asks the host (PostStepArgs::side_mirror) for kt_side_filter + kt_side_record
+    // on the context's side stream -- on the compute units the run does not hold --; the run iterates on (the old list holds every pair
+    // until its room is used up: the plan checks that every slot, and a build is named early, PostStepArgs::run_build_at); the plan is
+    // kept from judging the build (xy_target stays, xy_fresh does not appear) until RunMail::side_done says the record is written; the slot
+    // whose plan then switches lists is the run's last (its passes stand if the old list still held every pair for it, else they are void,
+    // as in a stall slot), and the next kt_run launch -- queued right behind -- enters on the new record.  A run never leaves with a side
+    // build in flight (side_finish): the launches behind it would build the same list again.
+    const bool side_can = SIDE && head_block && ps.side_mirror != nullptr && g <= RUN_G_SIDE && ps.st2 != nullptr;
+#ifdef CVO_SIDE_DEBUG   // (probe builds: what the side builds did, DevState::run_clk through cvo_hip_get_run_clocks)
+#define SIDE_DBG(i) do { if (head_block && tid == 0) gst->run_clk[i] += 1; } while (0)
+#else
+#define SIDE_DBG(i) do { } while (0)
+#endif
+    SIDE_DBG(side_can ? 0 : 1);
+    if (head_block && tid == 0) { s_side_t = -1; s_side_handed = 0; s_side_fail = 0; s_vbits = 0u; }
+    auto side_ended = [&]() -> bool {
+        return __hip_atomic_load(&ps.run_mail->side_done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= s_side_expect;
+    };
+    // (before the head goes out, whatever way the run ends; all threads of the head block; false: the side kernels never came)
+    auto side_finish = [&]() -> bool {
+        if (!SIDE || !side_can) return true;
+        __syncthreads();
+        if (tid == 0 && s_side_t >= 0 && !s_side_handed) {
+            const long long t0 = (long long)wall_clock64();
+            while (!side_ended()) {
+                if ((long long)wall_clock64() - t0 > (ps.run_timeout_ticks > 0 ? ps.run_timeout_ticks : RUN_TIMEOUT_TICKS)) { s_side_fail = 1; SIDE_DBG(9); break; }
+                __builtin_amdgcn_s_sleep(8);
+            }
+            if (!s_side_fail) {   // built and recorded: the next head judges it (its overflow flags, if any, are up in row 1: that head reads them)
+                const int t = s_side_t;
+                s_st.xy_fresh = t; s_st.xy_target = -1;
+                if (t) s_st.xy_ck[1] = pa.nblk; else s_st.xy_ck[0] = pa.nblk;
+                s_side_handed = 1;
+            }
+        }
+        __syncthreads();
+        return s_side_fail == 0;
+    };
     // the head block's verdict on the slot that begins travels with the slot's second exchange (its number is known in advance)
     auto post_verdict = [&](const unsigned long long seq_b) {
         if (head_block && tid == 0) {
-            const bool build = s_st.xy_target >= 0 || (ACVO && (s_st.sf_target[0] >= 0 || s_st.sf_target[1] >= 0));
-            const unsigned v = (s_st.stall != 0 ? (unsigned)RUN_V_STALL : 0u) | (build ? (unsigned)RUN_V_BUILD : 0u);
+            // (a build that is being made beside the run does not end it)
+            const bool build = (s_st.xy_target >= 0 && !(side_can && s_side_t == s_st.xy_target)) ||
+                               (ACVO && (s_st.sf_target[0] >= 0 || s_st.sf_target[1] >= 0));
+            const unsigned v = (s_st.stall != 0 ? (unsigned)RUN_V_STALL : 0u) | (build ? (unsigned)RUN_V_BUILD : 0u) | (side_can ? s_vbits : 0u);
             __hip_atomic_store(&ps.run_mail->w[(seq_b >> 1) & 1ull][RUN_G][0], ((seq_b & 0xffffffffull) << 32) | v, __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_AGENT);
         }
@@ -3424,32 +3484,30 @@ __device__ __forceinline__ void run_body(const Slot *__restrict__ tab, const int
                 if (lane == 0) self[1] = (double)nx;
             }
         }
+        double my_val = 0.0;   // (thread t < 2 NVF: sum t >> 1 of this block, what the thread sends)
         if (!head_block) {
             if (lane == 0) acc[8] = (double)nk;
             wave_sums<NACC_FLOW>(acc, lane, s_red + wid * NACC_MAX);
             if constexpr (ACVO) wave_sums<4>(self, lane, s_self + wid * 4);
             RUN_CLK(3);
             __syncthreads();
-            if (tid < NACC_FLOW) {
-                double t = 0.0;
+            const int k = tid >> 1;
+            if (k < NACC_FLOW) {
 #pragma unroll
-                for (int q = 0; q < RUN_WAVES; ++q) t += s_red[q * NACC_MAX + tid];
-                s_vals[tid] = t;
-            } else if (ACVO && tid >= 64 && tid < 68) {   // (another wave: beside the flow sums)
-                const int k = tid - 64;
-                double t = 0.0;
+                for (int q = 0; q < RUN_WAVES; ++q) my_val += s_red[q * NACC_MAX + k];
+            } else if (ACVO && k < NVF) {
+                const int ks = k - NACC_FLOW;
 #pragma unroll
-                for (int q = 0; q < RUN_WAVES; ++q) t += s_self[q * 4 + k];
-                if (k < 2) {   // Axx: made now, or the sums this block made when the length scale last moved
-                    if (xx_fresh) s_xx_keep[k] = t; else t = s_xx_keep[k];
+                for (int q = 0; q < RUN_WAVES; ++q) my_val += s_self[q * 4 + ks];
+                if (ks < 2) {   // Axx: made now, or the sums this block made when the length scale last moved (both threads of a sum store the same)
+                    if (xx_fresh) s_xx_keep[ks] = my_val; else my_val = s_xx_keep[ks];
                 }
-                s_vals[NACC_FLOW + k] = t;
             }
         }
-        if (ACVO && xx_fresh) { __syncthreads(); if (tid == 0) s_xx_ell = s_st.kc_ell; }
+        if (ACVO && xx_fresh && tid == 0) s_xx_ell = s_st.kc_ell;   // (read again behind the barriers of the exchange)
         RUN_CLK(4);
         ++nexch;
-        if (!run_exchange<NVF>(ps.run_mail, srow, g, seq0 + nexch, s_vals, s_all, s_part, s_tot, &s_fail, nullptr, &s_verdict, run_timeout)) { comm_ok = false; break; }
+        if (!run_exchange<NVF>(ps.run_mail, srow, g, seq0 + nexch, my_val, s_all, s_part, s_tot, &s_fail, nullptr, &s_verdict, run_timeout)) { comm_ok = false; SIDE_DBG(10); break; }
         RUN_CLK(5);
         // ---- the tail of compute_flow (ref src/cvo.cpp:201-209): twist, Taylor constants
         if (tid < 64) {
@@ -3500,20 +3558,19 @@ __device__ __forceinline__ void run_body(const Slot *__restrict__ tab, const int
             if (nl > 0) run_step_lds(nl, lc, rt, kc, xc, sacc);
         }
         RUN_CLK(7);
+        double my_step = 0.0;
         if (!head_block) {
             wave_sums<NACC_STEP>(sacc, lane, s_red + wid * NACC_MAX);
             __syncthreads();
-            if (tid < NACC_STEP) {
-                double t = 0.0;
+            if (tid < 2 * NACC_STEP) {
 #pragma unroll
-                for (int q = 0; q < RUN_WAVES; ++q) t += s_red[q * NACC_MAX + tid];
-                s_vals[tid] = t;
+                for (int q = 0; q < RUN_WAVES; ++q) my_step += s_red[q * NACC_MAX + (tid >> 1)];
             }
         }
         RUN_CLK(8);
         ++nexch;
         unsigned verdict = 0u;
-        if (!run_exchange<NACC_STEP>(ps.run_mail, srow, g, seq0 + nexch, s_vals, s_all, s_part, s_tot, &s_fail, &verdict, &s_verdict, run_timeout)) { comm_ok = false; break; }
+        if (!run_exchange<NACC_STEP>(ps.run_mail, srow, g, seq0 + nexch, my_step, s_all, s_part, s_tot, &s_fail, &verdict, &s_verdict, run_timeout)) { comm_ok = false; SIDE_DBG(11); break; }
         RUN_CLK(9);
         if (verdict & RUN_V_STALL) {
             // no buffer holds every pair for this slot's transform (a jump): what the passes have summed is void.  The head goes
@@ -3523,7 +3580,9 @@ __device__ __forceinline__ void run_body(const Slot *__restrict__ tab, const int
                 if (tid == 0) {
                     for (int q = 0; q < NACC_FLOW; ++q) s_st.red[RED_FLOW + q] = s_bak[q];
                     for (int q = 0; q < 3; ++q) { s_st.omega[q] = s_bakf[q]; s_st.v[q] = s_bakf[3 + q]; }
+                    s_st.stall = 1;   // (a slot made void because the plan changed lists under the solvers: the next head must take it for the stall slot it is)
                 }
+                if (!side_finish()) { comm_ok = false; break; }
                 __syncthreads();
                 head_publish(ps, &s_st, gst, true);
             }
@@ -3554,6 +3613,7 @@ __device__ __forceinline__ void run_body(const Slot *__restrict__ tab, const int
         // head of this slot has named a build (the next classic flow launch's filter blocks make it) or the run is over
         if (it + 1 >= iters || (verdict & RUN_V_BUILD)) {
             if (head_block) {
+                if (!side_finish()) { comm_ok = false; break; }
                 __syncthreads();
                 // (the step sums as row 0 of the rows the next head reduces; the other rows are zero: x + 0 = x in any order)
                 for (int q = tid; q < NACC_STEP * ps.nblk; q += RUN_BLOCK) {
@@ -3584,7 +3644,13 @@ __device__ __forceinline__ void run_body(const Slot *__restrict__ tab, const int
                     unsigned flag[LIST_N];
 #pragma unroll
                     for (int l = 0; l < LIST_N; ++l) flag[l] = 0u;   // (nothing is built and no slice can overflow in a run)
-                    head_plan<HM_HEAD>(&s_st, ps, true, false, flag);
+                    if (SIDE && side_can && ps.run_build_at > 0.0f) {   // (builds beside the run are named early: they take a few iterations)
+                        PostStepArgs psr = ps;
+                        psr.prm.build_at = ps.run_build_at;
+                        head_plan<HM_HEAD>(&s_st, psr, true, false, flag);
+                    } else {
+                        head_plan<HM_HEAD>(&s_st, ps, true, false, flag);
+                    }
                 } else {
                     float Rt[9], t[3];
                     cvo_math::inverse_tf(s_st.R, s_st.T, Rt, t);
@@ -3606,10 +3672,68 @@ __device__ __forceinline__ void run_body(const Slot *__restrict__ tab, const int
         RUN_CLK(12);
         if (s_st.done != RUNNING) {   // the loop has stopped: the final head goes out
             if (head_block) {
-                head_prepare_lists<HM_HEAD>(ps, &s_st);
+                if (!side_finish()) { comm_ok = false; break; }
+                if (!(side_can && s_side_t >= 0)) head_prepare_lists<HM_HEAD>(ps, &s_st);
                 head_publish(ps, &s_st, gst, true);
             }
             break;
+        }
+        if constexpr (SIDE) if (side_can) {   // (the head block; block-uniform)
+            // the plan that has just run and the side build
+            if (tid == 0) {
+                unsigned vb = 0u;
+                if (s_side_t >= 0) {
+                    const int t = s_side_t;
+                    if (!s_side_handed) {
+                        // (the plan took the target for built -- in the launch-per-pass path the launch that carries the plan builds it --: it
+                        // is, once the side kernels are through)
+                        if (side_ended()) {
+                            SIDE_DBG(3);
+                            s_side_handed = 1;
+                            if (t) s_st.xy_ck[1] = pa.nblk; else s_st.xy_ck[0] = pa.nblk;   // (its record is written)
+                            // a list or a record slice that overflowed: the flags are up in row 1, the head of the next launch reads them
+                            // and parks the loop as always -- the run ends with the coming slot, before its own plan would judge the build
+                            if ((__hip_atomic_load(&gst->ovf[1][LIST_KEPT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) |
+                                 __hip_atomic_load(&gst->ovf[1][t ? LIST_XYB : LIST_XY], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != 0u)
+                                vb |= (unsigned)RUN_V_BUILD;
+                        } else {
+                            s_st.xy_target = t; s_st.xy_fresh = -1;
+                        }
+                    } else {
+                        s_side_t = -1; s_side_handed = 0;   // (the plan that has just run judged it)
+                    }
+                }
+                if ((s_st.xy_active ? 1 : 0) != act) {
+                    // the plan has changed lists; the solvers hold the old one's candidates: this slot is the run's last.  Its passes stand if
+                    // the old list still holds every pair for the slot's transform (plan_xy_async's own test), else they are void
+                    const float r_now = sqrtf(s_st.kc.tau), slack = 1.0e-4f * (1.0f + s_st.xmax + s_st.y0max);
+                    const float need = (r_now + (act ? xy_travel<1>(&s_st, &s_st) : xy_travel<0>(&s_st, &s_st))) * 1.0001f + slack;
+                    const bool held = (act ? s_st.xy_ok[1] : s_st.xy_ok[0]) != 0 && need <= (act ? s_st.xy_r[1] : s_st.xy_r[0]);
+                    vb |= held ? (unsigned)RUN_V_BUILD : (unsigned)RUN_V_STALL;
+                    SIDE_DBG(held ? 4 : 5);
+                }
+                s_vbits = vb;
+            }
+            __syncthreads();
+            // a build the plan has just named: beside the run
+            if (s_side_t < 0 && s_vbits == 0u && s_st.xy_target >= 0 && s_st.stall == 0 &&
+                !(ACVO && (s_st.sf_target[0] >= 0 || s_st.sf_target[1] >= 0))) {
+                head_prepare_lists<HM_HEAD>(ps, &s_st);                      // (its counters)
+                state_head_from_lds(&s_st, static_cast<DevHead *>(ps.st2));   // (what the side kernels read: target, its transform and bound, the kernel constants)
+                __threadfence_system();
+                __syncthreads();
+                if (tid == 0) {
+                    s_side_expect = __hip_atomic_load(&ps.run_mail->side_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + (unsigned long long)cs->op[qf].np;
+                    s_side_t = s_st.xy_target; s_side_handed = 0;
+                    SIDE_DBG(2);
+                    const unsigned long long req = ps.run_mail->side_req + 1ull;
+                    ps.run_mail->side_req = req;
+                    // (a system-scope store: a plain one to host memory may sit in this device's cache until the kernel ends -- and the host
+                    // must see this one while the run goes on)
+                    __hip_atomic_store(ps.side_mirror, (int32_t)(req & 0x7fffffffull), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
+                __syncthreads();
+            }
         }
         if (head_block) {
             post_verdict(seq0 + nexch + 2);
@@ -3617,7 +3741,7 @@ __device__ __forceinline__ void run_body(const Slot *__restrict__ tab, const int
                 if (ps.hint_mirror) *ps.hint_mirror = s_st.run_hint;
                 if (ps.progress_mirror) *ps.progress_mirror = s_st.n_slots;
             }
-            head_prepare_lists<HM_HEAD>(ps, &s_st);   // (a build this head has named: its counters)
+            if (!(side_can && s_side_t >= 0)) head_prepare_lists<HM_HEAD>(ps, &s_st);   // (a build this head has named: its counters; not those of a list that is being filled)
         }
         RUN_CLK(13);
     }
@@ -3662,6 +3786,61 @@ kt_run_acvo(const Slot *__restrict__ tab, const int qs)
 {
     run_body<true>(tab, qs, nullptr);   // (no candidate lives in LDS: a launch without dynamic LDS)
 }
+__global__ void __launch_bounds__(RUN_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
+kt_run_side(const Slot *__restrict__ tab, const int qs)
+{
+    extern __shared__ __attribute__((aligned(16))) float4 s_lc[];
+    run_body<false, true>(tab, qs, s_lc);
+}
+__global__ void __launch_bounds__(RUN_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
+kt_run_acvo_side(const Slot *__restrict__ tab, const int qs)
+{
+    run_body<true, true>(tab, qs, nullptr);
+}
+
+// The side build of a run's next xy list (kt_run "side builds"): the filter over all pairs at the transform the run's plan recorded, then the
+// expansion of the tile list with its colour weights into the buffer's candidate record -- the two things the launch-per-pass path does in
+// the flow launches of two slots.  Both read the head the run's head block put into the second copy of the state's head.
+__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4, 8)))
+kt_side_filter(const Slot *__restrict__ tab, const int q)
+{
+    CSlot cs = (CSlot)(tab);
+    if (cs->active == 0) return;
+    const FilterArgs &f = CVO_ARG(FilterArgs, op[q].f);
+    filter_body<false>(f, blockIdx.x, gridDim.x, f.st2, 1);   // (overflows are flagged in row 1: the row the head of the launch after the run reads)
+}
+__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4, 8)))
+kt_side_record(const Slot *__restrict__ tab, const int q)
+{
+    __shared__ __attribute__((aligned(16))) char scratch[PROC_SMEM];
+    CSlot cs = (CSlot)(tab);
+    if (cs->active == 0) return;
+    const ProcessArgs &pa = CVO_ARG(ProcessArgs, op[q].p);
+    RunMail *const mail = CVO_ARG(PostStepArgs, op[q].ps).run_mail;
+    const DevState *h = pa.st2;
+    const int t = __builtin_amdgcn_readfirstlane(h->xy_target);
+    if (t >= 0 && mail != nullptr) {
+        // the expansion pass of the flow launch (expand_lists with its record), on the buffer that was built: what it sums and keeps besides
+        // the record goes to buffers nobody reads before they are written again (the kept list, the flow partials)
+        ProcHead hd;
+        hd.Rt = h->Rt; hd.tt = h->t; hd.xi = &h->xi;
+        hd.kc = h->kc;
+        hd.done_word = 0; hd.n_fixed = 0;
+        hd.second = t ? 1 : 0;
+        hd.list_bad = 0u;
+        hd.ck_nblk = 0;     // (no record yet: expand and record)
+        hd.par = 1;
+        hd.cand = t ? pa.cand_b : pa.cand;
+        hd.cand_cnt = t ? pa.cand_cnt_b : pa.cand_cnt;
+        hd.need_d2 = 0;
+        process_body<PROC_FLOW, 0, true, false>(pa, blockIdx.x, scratch, hd);
+    }
+    // (the record is in memory before the count that says so)
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0 && mail != nullptr)
+        __hip_atomic_fetch_add(&mail->side_done, 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
 
 unsigned filter_grid_cap(long long nitems, long long cap) { return filter_grid_x(nitems, cap); }
 long long filter_blocks_cap() { return filter_blocks_max(); }
@@ -3694,8 +3873,17 @@ void launch_table(const Slot *tab, const TLaunch &l, hipStream_t s, hipEvent_t e
     case TK_HFLOW_BUILD: hipLaunchKernelGGL(kt_hflow_build_w4, g, dim3(BLOCK), l.smem, s, tab, qp); break;
     case TK_HFLOW_BUILD6: hipLaunchKernelGGL(kt_hflow_build6_w4, g, dim3(BLOCK), l.smem, s, tab, qp); break;
     case TK_HSTEP_TWIST: hipLaunchKernelGGL(kt_step_twist, g, dim3(STEP_BLOCK), 0, s, tab, qp); break;
-    case TK_RUN: hipLaunchKernelGGL(kt_run, dim3(l.gx), dim3(RUN_BLOCK), RUN_LDS_BYTES, s, tab, l.q); break;   // (run_allow_lds first: plan_lone's caller)
-    case TK_RUN_ACVO: hipLaunchKernelGGL(kt_run_acvo, dim3(l.gx), dim3(RUN_BLOCK), 0, s, tab, l.q); break;
+    // (l.list != 0: the plan has side builds -- the kernels that carry them)
+    case TK_RUN:
+        if (l.list) hipLaunchKernelGGL(kt_run_side, dim3(l.gx), dim3(RUN_BLOCK), RUN_LDS_BYTES, s, tab, l.q);
+        else hipLaunchKernelGGL(kt_run, dim3(l.gx), dim3(RUN_BLOCK), RUN_LDS_BYTES, s, tab, l.q);   // (run_allow_lds first: plan_lone's caller)
+        break;
+    case TK_RUN_ACVO:
+        if (l.list) hipLaunchKernelGGL(kt_run_acvo_side, dim3(l.gx), dim3(RUN_BLOCK), 0, s, tab, l.q);
+        else hipLaunchKernelGGL(kt_run_acvo, dim3(l.gx), dim3(RUN_BLOCK), 0, s, tab, l.q);
+        break;
+    case TK_SIDE_FILTER: hipLaunchKernelGGL(kt_side_filter, g, dim3(BLOCK), l.smem, s, tab, l.q); break;
+    case TK_SIDE_RECORD: hipLaunchKernelGGL(kt_side_record, g, dim3(BLOCK), 0, s, tab, l.q); break;
     default: break;
     }
 }

@@ -604,6 +604,17 @@ int enqueue_step(cvo_hip_ctx *ctx, int check_done, bool do_math, cvo_hip_trace *
             pa.run_g_max = std::max(8, std::min(ctx->run_g_max, ctx->run_g_call));
             pa.run_timeout_ticks = (long long)(ctx->opt.run_timeout_ms * 1.0e5);   // (100 MHz; 0: the kernel's own second)
             pa.run_fault = ctx->opt.run_fault;
+            // side builds (kt_run): a stream of the library's own beside the caller's, made once
+            if (!ctx->opt.no_side_builds) {
+                if (!ctx->side_stream && hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking) != hipSuccess) {
+                    (void)hipGetLastError();
+                    ctx->side_stream = nullptr;
+                }
+                if (ctx->side_stream) {
+                    pa.side_mirror = ctx->side_mirror;
+                    pa.run_build_at = ctx->opt.run_build_at;
+                }
+            }
         } else {   // (an optimisation: without its memory the plan has no runs)
             (void)hipGetLastError();
             ctx->err = "";
@@ -723,10 +734,11 @@ constexpr long long kFusedFilterBlocks = 256;   // (64 / 256 / 512 per slot: pro
 // twist in front, one rank: the post-step launch is gone; its argument block rides in the flow launch's entry
 // (op[q].ps), every flow / self block runs it as its head.
 bool plan_lone(const std::vector<RecOp> &ops, Slot &slot, std::vector<TLaunch> &plan, const bool allow_head, bool *head_mode,
-               std::vector<TLaunch> *pre)
+               std::vector<TLaunch> *pre, std::vector<TLaunch> *side)
 {
     plan.clear();
     if (pre) pre->clear();
+    if (side) side->clear();
     *head_mode = false;
     std::memset(&slot, 0, sizeof(slot));
     slot.active = 1;
@@ -801,6 +813,10 @@ bool plan_lone(const std::vector<RecOp> &ops, Slot &slot, std::vector<TLaunch> &
             4 * self[1].nblk <= PROC_WAVES && q + 3 < 16) {
             pre->push_back(mk_launch(TK_RUN_ACVO, q | ((q + 3) << 4), 1u + (unsigned)std::max(8, std::min((int)RUN_G, o.ps.run_g_max)), 1));   // (no more blocks than the run may use: a block that is not needed still takes a compute unit until it knows)
             pre->push_back(mk_launch(TK_RUN_ACVO, q | ((q + 3) << 4), 1u + RUN_G_SMALL, 1));   // (for narrow records: launch_batch picks one)
+            if (side && o.ps.side_mirror && o.f.st2) {   // (the side build of the run's next xy list: the build's own blocks, the flow pass's)
+                side->push_back(mk_launch(TK_SIDE_FILTER, q, (unsigned)o.n0, 1, smem_of(o.f.jt)));
+                side->push_back(mk_launch(TK_SIDE_RECORD, q, (unsigned)o.np, 1));
+            }
         }
         q += 3;
         if (six) ns = 0;
@@ -841,6 +857,10 @@ bool plan_lone(const std::vector<RecOp> &ops, Slot &slot, std::vector<TLaunch> &
                 flow.weight == 0 && 4 * flow.nblk <= PROC_WAVES) {
                 pre->push_back(mk_launch(TK_RUN, q | ((q + 1) << 4), 1u + (unsigned)std::max(8, std::min((int)RUN_G, o.ps.run_g_max)), 1));   // (no more blocks than the run may use: a block that is not needed still takes a compute unit until it knows)
                 pre->push_back(mk_launch(TK_RUN, q | ((q + 1) << 4), 1u + RUN_G_SMALL, 1));   // (for a narrow record: launch_batch picks one)
+                if (side && o.ps.side_mirror && o.f.st2) {
+                    side->push_back(mk_launch(TK_SIDE_FILTER, q, (unsigned)o.n0, 1, smem_of(build.jt)));
+                    side->push_back(mk_launch(TK_SIDE_RECORD, q, (unsigned)o.np, 1));
+                }
             }
             ++q;
         } else if (have_flow) {
@@ -1106,15 +1126,21 @@ int prepare_lone_plan(cvo_hip_ctx *ctx, int trace_cap)
     int rc = record_iteration(ctx, ops, trace_cap);
     if (rc) return rc;
     Slot slot;
-    if (!plan_lone(ops, slot, ctx->plan, ctx->allow_head, &ctx->head_mode, &ctx->plan_pre))
+    if (!plan_lone(ops, slot, ctx->plan, ctx->allow_head, &ctx->head_mode, &ctx->plan_pre, &ctx->plan_side))
         return fail(ctx, CVO_HIP_ERR_INVALID, "launch plan does not fit the argument table");
+    if (!ctx->plan_side.empty())
+        for (TLaunch &l : ctx->plan_pre) l.list = 1;   // (launch_table: the run kernels that carry the side builds)
     if (!ctx->plan_pre.empty() && run_allow_lds() != hipSuccess) {
         // (resident runs are an optimisation: a device or partition that refuses kt_run its LDS gets the plain head-mode plan -- the
         // plan's classic launches are complete without the run in front of them)
         (void)hipGetLastError();
         ctx->plan_pre.clear();
+        ctx->plan_side.clear();
         ctx->allow_run = false;
     }
+    if (ctx->opt.comm_debug)
+        fprintf(stderr, "[cvo_hip] lone plan: %zu launches, head mode %d, pre %zu, side %zu, side mirror %p, side stream %p\n", ctx->plan.size(), (int)ctx->head_mode,
+                ctx->plan_pre.size(), ctx->plan_side.size(), (void *)ctx->side_mirror, (void *)ctx->side_stream);
     set_build_masks(slot, ctx->plan, ctx->table.masks(), 0);
     ctx->plan_has_final_mirror = false;
     for (const TLaunch &l : ctx->plan)   // (the launches whose heads publish: the post-step launch, or the head-mode flow launch)
@@ -1128,7 +1154,7 @@ int prepare_lone_plan(cvo_hip_ctx *ctx, int trace_cap)
 // classic by-value launches -- they need their own launches / host calls in between.
 // with_run: a RUN batch -- the plan's resident run, then kRunBatchSlots classic slots (job_pump asks for it when the plan has a
 // run and the registration is narrow enough)
-int launch_batch(cvo_hip_ctx *ctx, int tag0, int trace_cap, bool with_run, int slots, bool small_run)
+int launch_batch(cvo_hip_ctx *ctx, int tag0, int trace_cap, bool with_run, int slots, bool small_run, bool two_runs)
 {
     if (ctx->profiling || host_reduce(ctx)) {
         const int rc = enqueue_iterations(ctx, kBatch, tag0, trace_cap);
@@ -1144,6 +1170,8 @@ int launch_batch(cvo_hip_ctx *ctx, int tag0, int trace_cap, bool with_run, int s
     // started before the run begins, kt_run's entry hand-shake)
     std::vector<TLaunch> front;
     if (with_run) front.push_back(ctx->plan_pre[(small_run && ctx->plan_pre.size() > 1) ? 1 : 0]);
+    // (with side builds a run ends when its next list stands ready: the second launch enters on it at once, no word from the host in between)
+    if (with_run && two_runs && !ctx->plan_side.empty()) front.push_back(front[0]);
     const int rc = with_run ? run_plan(ctx->table.dev, ctx->plans, ctx->plan, loop_stream(ctx), graphs, kRunBatchSlots, &front)
                             : run_plan(ctx->table.dev, ctx->plans, ctx->plan, loop_stream(ctx), graphs, slots);
     if (rc) return fail(ctx, rc, "launching a batch of iterations failed");

@@ -1387,3 +1387,37 @@ def test_a_resident_run_that_times_out_costs_its_wait_not_the_frame(pkg):
     assert [c.get_option("run_timeouts") for c in cs] == [1.0] * len(cs)
     for c in cs:
         c.close()
+
+
+@pytest.mark.parametrize("mode_name,n", [("cvo", 3000), ("acvo", 3000), ("cvo", 6000)])
+def test_side_builds_change_nothing(pkg, mode_name, n):
+    """Side builds (csrc/cvo_kernels.hip kt_run "side builds", option "side_builds"; built and measured in round 6, off by default): a
+    resident run has its next xy list built BESIDE it -- kt_side_filter + kt_side_record on a second stream, asked for by the run's head
+    block through a pinned word, the plan kept from judging the build until its record is written, the slot whose plan switches lists the
+    run's last, the next run entering on the new record at once.  Same iterations, state and trace as with the run ending for the build
+    (ref src/cvo.cpp:110-125: the reference rebuilds its neighbour sets every iteration; which list serves is never visible in the result)."""
+    capi = pkg.capi
+    acvo = mode_name == "acvo"
+    mode = capi.MODE_ACVO if acvo else capi.MODE_CVO
+    xf, ff, xm, fm = pkg.data.synthetic_pair(n, n, seed=6100 + n, acvo=acvo)
+    xm_far = (xm.astype(np.float64) + np.array([0.03, -0.02, 0.03])).astype(np.float32)
+    for moving in (xm, xm_far):
+        res = []
+        for side in (0, 1):
+            c = capi.Context(mode=mode, device=0)
+            c.set_option("side_builds", side)
+            c.set_fixed(xf, ff); c.set_moving(moving, fm)
+            outs = []
+            for _ in range(3):
+                st = capi.init_state(c.params)
+                it, tr = c.align(st, trace_cap=2000)
+                outs.append((it, bytes(st), [(t["k"], t["exit_code"], t["nnz"], t["nnz_xx"], t["nnz_yy"], t["ell"], t["step"],
+                                              tuple(t["omega"]), tuple(t["v"])) for t in tr]))
+            assert outs[0] == outs[1] == outs[2]
+            launched = c.get_option("side_builds_launched")
+            assert (launched > 0) == bool(side), (side, launched)
+            assert c.get_option("run_timeouts") == 0.0
+            assert c.run_stats()[0] >= 1
+            res.append(outs[0])
+            c.close()
+        assert res[0] == res[1]
