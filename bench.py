@@ -44,7 +44,15 @@ BYTES_PER_POINT = 32.0         # xyz 12 B + 5 features 20 B
 PEAK_F32_TFLOPS = 157.3        # MI355X_MICROARCH.md: FP32 vector = FP32 MFMA peak
 PEAK_HBM_GBS = 8000.0
 FETCH_CALIBRATION = "profiles/r05_fetch_calibration.txt"   # what TCC FETCH_SIZE counts on a 16-byte gather of known footprint
-PROFILE_TAG = "r05"            # committed rocprofv3 summaries under profiles/ (tools/gpu_profile.sh)
+def _profile_tag():
+    """The newest round whose rocprofv3 summaries are committed under profiles/ (tools/gpu_profile_r6.sh)."""
+    for tag in ("r06", "r05"):
+        if os.path.exists(os.path.join(ROOT, "profiles", "%s_pmc_summary.json" % tag)):
+            return tag
+    return "r05"
+
+
+PROFILE_TAG = _profile_tag()
 
 
 COMPACT_LIMIT = 6000   # bytes: the driver keeps an 8 KB tail of stdout; the headline line must sit inside it whole
@@ -541,6 +549,10 @@ def main():
                     out["frontend"] = frontend_leg(args, pkg)
                 except Exception as e:   # the headline line must survive a side leg
                     out["frontend"] = {"error": repr(e)}
+        try:
+            out["roofline_run"] = roofline_run_leg(out.get("single_stream"), (out.get("acvo") or {}).get("single_stream"))
+        except Exception as e:
+            out["roofline_run"] = {"error": repr(e)}
         # (last: the OpenMP team of the CPU leg keeps spinning for a while after its last
         # parallel region and would slow the host side of everything timed after it)
         if not args.no_cpu:
@@ -943,6 +955,48 @@ def roofline_engine_leg(args, pkg, torch, mode, acvo, n, m):
     res["bound_note"] = ("per phase: see by_phase (wide flow pass: dependent-latency, wide step pass: valu-issue, narrow: launch-chain); "
                          "`frac` is the contract's algorithmic-bytes figure against the HBM roof")
     return res
+
+
+def roofline_run_leg(single_stream, acvo_single):
+    """The resident runs (csrc/cvo_kernels.hip kt_run / kt_run_acvo: 57 % of the kernel time of one registration at a time): no HBM roof
+    and no MFMA roof applies -- an iteration inside a run touches no memory at all --, so the entry says what fraction of the GPU's
+    vector issue the kernel uses while it runs (committed SQ_ACTIVE_INST_VALU x 4 cycles / (1024 SIMDs x the kernel's cycles)) and where
+    an iteration's time goes (committed ticks of a -DCVO_RUN_CLOCKS build): the two exchanges and the head's chain, not arithmetic."""
+    pmc, pmc_src = committed("%s_pmc_summary.json" % PROFILE_TAG)
+    clk, clk_src = committed("%s_run_clocks.json" % PROFILE_TAG)
+    out = {"kernel": "cvo_dev::kt_run", "bound": "latency", "unit": "fraction of vector issue", "peak": 1.0,
+           "what": "vector-issue fraction while the kernel runs; per-iteration microseconds by phase from a clocked build"}
+    k = (pmc or {}).get("single_stream", {}).get("kt_run") if pmc else None
+    if k and "SQ_ACTIVE_INST_VALU" in k and "GRBM_GUI_ACTIVE" in k:
+        cyc = k["GRBM_GUI_ACTIVE"]["avg"] / 8.0
+        out["achieved"] = out["frac"] = k.get("valu_active_frac", k["SQ_ACTIVE_INST_VALU"]["avg"] * 4.0 / (1024.0 * cyc))
+        out["avg_launch_us"] = cyc / 2400.0
+        out["launches"] = k["SQ_ACTIVE_INST_VALU"]["executed"]
+        out["source"] = pmc_src
+    ka = (pmc or {}).get("single_stream_acvo", {}).get("kt_run_acvo") if pmc else None
+    if ka and "SQ_ACTIVE_INST_VALU" in ka and "GRBM_GUI_ACTIVE" in ka:
+        out["acvo_frac"] = ka.get("valu_active_frac", ka["SQ_ACTIVE_INST_VALU"]["avg"] * 4.0 / (1024.0 * ka["GRBM_GUI_ACTIVE"]["avg"] / 8.0))
+    if clk:
+        c = clk.get("clocks", {})
+        for mode in ("cvo", "acvo"):
+            for n in ("n_3000", "n_10000"):
+                e = c.get(mode, {}).get(n)
+                if not e or "ticks_by_phase" not in e:
+                    continue
+                ph = e["ticks_by_phase"]
+                t = lambda *names: sum(ph.get(x, 0) for x in names) / 2400.0
+                key = "%s_%s" % (mode, n[2:])
+                out["us_per_iteration_" + key] = e.get("us_per_run_iteration")
+                out["by_phase_us_" + key] = {"passes": t("flow rounds", "step rounds"), "sums_and_barriers": t("wave sums", "barrier+block sum", "step sums"),
+                                             "exchanges": t("exch A", "exch B"), "twist_constants": t("twist", "consts"),
+                                             "head_chain": t("pre-head", "head_post", "inverse+sync", "tail"),
+                                             "entry_per_run": ph.get("entry", 0) / 2400.0}
+        out["clocks_source"] = clk_src
+        if "us_per_iteration_cvo_10000" in out:
+            out["us_per_iteration"] = out["us_per_iteration_cvo_10000"]
+    if single_stream:
+        out["measured_ms_per_iteration_one_at_a_time"] = single_stream.get("ms_per_iteration")
+    return out
 
 
 def handover_leg(args, pkg, ctxs, pairs, one_step, torch):

@@ -137,7 +137,10 @@ constexpr int RUN_L = 8;             // ... and in LDS behind them (the widest r
 constexpr int RUN_CAP = RUN_LANES * (RUN_R + RUN_L);   // candidates a run holds at most: 2 031 616
 constexpr unsigned RUN_LDS_BYTES = (unsigned)RUN_L * 2u * (unsigned)RUN_BLOCK * 16u;   // dynamic LDS of kt_run
 constexpr int RUN_NV = 13;           // doubles per exchange at most (flow: 9, acvo 9 + 2 + 2; step: 4): the stride of a row of the mail
-constexpr int RUN_A = 4;             // acvo runs (kt_run_acvo): candidates per lane of each of the three records (xy, xx, yy), all in registers
+#ifndef CVO_RUN_A
+#define CVO_RUN_A 4   // (3: no vector register spilled instead of 34, +1 % at 3k-10k, but 14k x 14k no longer fits its runs: -10 %; profiles/r06_ab.txt 8)
+#endif
+constexpr int RUN_A = CVO_RUN_A;             // acvo runs (kt_run_acvo): candidates per lane of each of the three records (xy, xx, yy), all in registers
 constexpr int RUN_GEN = 4;           // generations of the exchange rows (see above)
 struct RunMail {
     unsigned long long w[RUN_GEN][RUN_G + 1][2 * RUN_NV];   // (row RUN_G: the head block's verdict word)

@@ -3436,14 +3436,14 @@ __device__ __forceinline__ void run_body(const Slot *__restrict__ tab, const int
 #pragma unroll
         for (int k = 0; k < NACC_FLOW; ++k) acc[k] = 0.0;
         unsigned nk = 0;
-        static_assert(RUN_R == 8 && RUN_A == 4, "the cases below");
+        static_assert(RUN_R == 8 && RUN_A >= 3 && RUN_A <= 4, "the cases below");
         if constexpr (ACVO) {
             switch (rmax) {   // (wave-uniform; at most RUN_A rounds)
             case 0: break;
             case 1: nk = run_flow_rounds<1>(rt, kc, cx, cy, cck, cw, s_etab, need_d2, acc); break;
             case 2: nk = run_flow_rounds<2>(rt, kc, cx, cy, cck, cw, s_etab, need_d2, acc); break;
             case 3: nk = run_flow_rounds<3>(rt, kc, cx, cy, cck, cw, s_etab, need_d2, acc); break;
-            default: nk = run_flow_rounds<4>(rt, kc, cx, cy, cck, cw, s_etab, need_d2, acc); break;
+            default: nk = run_flow_rounds<RUN_A>(rt, kc, cx, cy, cck, cw, s_etab, need_d2, acc); break;
             }
         } else {
             switch (rmax) {   // (wave-uniform; rounds beyond the wave's last candidate would be all zeros)
@@ -3468,7 +3468,7 @@ __device__ __forceinline__ void run_body(const Slot *__restrict__ tab, const int
             case 1: ny = run_yy_rounds<1>(rt, kc, yya, yyb, yck, s_etab, self[2]); break;
             case 2: ny = run_yy_rounds<2>(rt, kc, yya, yyb, yck, s_etab, self[2]); break;
             case 3: ny = run_yy_rounds<3>(rt, kc, yya, yyb, yck, s_etab, self[2]); break;
-            default: ny = run_yy_rounds<4>(rt, kc, yya, yyb, yck, s_etab, self[2]); break;
+            default: ny = run_yy_rounds<RUN_A>(rt, kc, yya, yyb, yck, s_etab, self[2]); break;
             }
             if (lane == 0) self[3] = (double)ny;
             xx_fresh = !(s_xx_ell == s_st.kc_ell);   // (block-uniform; every block holds the same length scale)
@@ -3479,7 +3479,7 @@ __device__ __forceinline__ void run_body(const Slot *__restrict__ tab, const int
                 case 1: nx = run_xx_rounds<1>(kc, xd2, xck, s_etab, self[0]); break;
                 case 2: nx = run_xx_rounds<2>(kc, xd2, xck, s_etab, self[0]); break;
                 case 3: nx = run_xx_rounds<3>(kc, xd2, xck, s_etab, self[0]); break;
-                default: nx = run_xx_rounds<4>(kc, xd2, xck, s_etab, self[0]); break;
+                default: nx = run_xx_rounds<RUN_A>(kc, xd2, xck, s_etab, self[0]); break;
                 }
                 if (lane == 0) self[1] = (double)nx;
             }
@@ -3543,7 +3543,7 @@ __device__ __forceinline__ void run_body(const Slot *__restrict__ tab, const int
             case 1: run_step_rounds<1>(rt, kc, xc, cx, cy, cw, sacc); break;
             case 2: run_step_rounds<2>(rt, kc, xc, cx, cy, cw, sacc); break;
             case 3: run_step_rounds<3>(rt, kc, xc, cx, cy, cw, sacc); break;
-            default: run_step_rounds<4>(rt, kc, xc, cx, cy, cw, sacc); break;
+            default: run_step_rounds<RUN_A>(rt, kc, xc, cx, cy, cw, sacc); break;
             }
         } else {
             switch (rmax) {

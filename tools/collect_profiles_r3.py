@@ -33,7 +33,8 @@ for pat, name in (("bench.json", "%s_bench.json"), ("stats/*kernel_stats.csv", "
                   ("stats_batch/*kernel_stats.csv", "%s_kernel_stats_batch.csv"),
                   ("stats_roofline/*kernel_stats.csv", "%s_kernel_stats_roofline.csv"),
                   ("stats_fe/*kernel_stats.csv", "%s_kernel_stats_frontend.csv"),
-                  ("roofline_plain.json", "%s_roofline_only.json")):
+                  ("roofline_plain.json", "%s_roofline_only.json"), ("bench_line.json", "%s_bench_line.json"),
+                  ("stats_acvo/*kernel_stats.csv", "%s_kernel_stats_acvo.csv")):
     f = one(pat)
     if f:
         shutil.copy(f, os.path.join(dst, name % tag))
@@ -160,7 +161,8 @@ if f:
 # ---- counters of the single-stream run (head mode) and of the one-engine run, per kernel, executed launches
 summary = {}
 for pat, label in (("pmc_sq/*counter_collection.csv", "single_stream"), ("pmc_fetch/*counter_collection.csv", "single_stream"),
-                   ("pmc_write/*counter_collection.csv", "single_stream"), ("pmc_sq_r/*counter_collection.csv", "one_engine_of_22")):
+                   ("pmc_write/*counter_collection.csv", "single_stream"), ("pmc_sq_r/*counter_collection.csv", "one_engine_of_22"),
+                   ("pmc_sq_acvo/*counter_collection.csv", "single_stream_acvo")):
     f = one(pat)
     if not f:
         continue
@@ -179,6 +181,44 @@ for label in summary:
     for k, d in summary[label].items():
         if "SQ_WAIT_ANY" in d and "SQ_WAVE_CYCLES" in d and d["SQ_WAVE_CYCLES"]["avg"] > 0:
             d["wait_any_over_wave_cycles"] = d["SQ_WAIT_ANY"]["avg"] / d["SQ_WAVE_CYCLES"]["avg"]
+# (the resident runs: vector-issue fraction while the kernel runs -- SQ_ACTIVE_INST_VALU counts quad-cycles summed over all SIMDs,
+# GRBM_GUI_ACTIVE the kernel's cycles summed over the 8 XCDs)
+for label in summary:
+    for k, d in summary[label].items():
+        if k.startswith("kt_run") and "SQ_ACTIVE_INST_VALU" in d and "GRBM_GUI_ACTIVE" in d and d["GRBM_GUI_ACTIVE"]["avg"] > 0:
+            d["valu_active_frac"] = d["SQ_ACTIVE_INST_VALU"]["avg"] * 4.0 / (SIMDS * d["GRBM_GUI_ACTIVE"]["avg"] / 8.0)
+            d["avg_us"] = d["GRBM_GUI_ACTIVE"]["avg"] / 8.0 / (CLOCK_GHZ * 1e3)
+# ... and where their iterations go (tools/gpu_run_clocks.py on a -DCVO_RUN_CLOCKS build)
+import re
+clocks = {}
+for mode in ("cvo", "acvo"):
+    try:
+        lines = open(os.path.join(src, "run_clocks_%s.txt" % mode)).read().splitlines()
+    except Exception:
+        continue
+    cur = None
+    for ln in lines:
+        m = re.match(r"n (\d+): (\d+) iterations in ([0-9.]+) us; (\d+) runs \((\d+) declined\), (\d+) iterations inside, last record (\d+) candidates", ln)
+        if m:
+            cur = clocks.setdefault(mode, {}).setdefault("n_%s" % m.group(1), {"iterations": int(m.group(2)), "us": float(m.group(3)), "runs": int(m.group(4)),
+                                                                               "declined": int(m.group(5)), "iterations_inside": int(m.group(6)),
+                                                                               "last_record_candidates": int(m.group(7))})
+            continue
+        m = re.search(r"ticks of the first solver block \(2.4 per ns\): (\d+) per run-iteration", ln)
+        if m and cur is not None:
+            cur["ticks_per_run_iteration"] = int(m.group(1)); cur["us_per_run_iteration"] = int(m.group(1)) / 2400.0
+            continue
+        if cur is not None and "entry " in ln and "exch A" in ln:
+            ph = {}
+            for part in ln.strip().split(", "):
+                mm = re.match(r"(.+?) (\d+)(?:  .*)?$", part.strip())
+                if mm:
+                    ph[mm.group(1).strip()] = int(mm.group(2))
+            cur["ticks_by_phase"] = ph
+if clocks:
+    with open(os.path.join(dst, "%s_run_clocks.json" % tag), "w") as fh:
+        json.dump({"what": "tools/gpu_run_clocks.py on libcvo_hip_clk.so (-DCVO_RUN_CLOCKS): ticks of the first solver block of the resident runs of one "
+                           "registration (seed 20190402), 2.4 ticks per ns; entry / exit per run, the other phases per iteration inside a run", "clocks": clocks}, fh, indent=1, sort_keys=True)
 if summary:
     with open(os.path.join(dst, "%s_pmc_summary.json" % tag), "w") as fh:
         json.dump(summary, fh, indent=1, sort_keys=True)
