@@ -134,7 +134,7 @@ def compact_line(out, detail_file="bench_detail.json"):
         v = _num(_get(out, *path))
         if v is not None:
             c[name] = v
-    sc = _get(out, "small_calls", "per_call")
+    sc = _get(out, "small_calls", "fresh_process") or _get(out, "small_calls", "per_call")
     if isinstance(sc, dict):
         c["small_calls_3k_registrations_per_s"] = {k: _num(_get(v, "registrations_per_s") if isinstance(v, dict) else v, 5)
                                                    for k, v in sc.items()}
@@ -1342,6 +1342,22 @@ def small_calls_leg(args, pkg, torch, mode, acvo):
         for c in ctxs:
             c.close()
         out["per_call"][str(count)] = {"registrations_per_s": on_their_own, "through_the_engines": through_engines}
+    # The same calls in a process of their own (tools/gpu_small_calls.py): what a host program with a few cameras sees.  This process has
+    # created > 70 streams by now and the runtime deals streams to its 4 hardware queues in turn: two of a call's four streams then share
+    # a queue and their resident runs -- persistent kernels -- run one after the other (4 per call 3 138 /s fresh, 2 004 /s here:
+    # profiles/r06_ab.txt 9).  `per_call` keeps this process's figures; `fresh_process` is the one quoted in the compact line.
+    try:
+        import re
+        import subprocess
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gpu_small_calls.py"), str(n), "2", "4", "8"],
+                           capture_output=True, text=True, timeout=300, env=dict(os.environ, ACVO="1") if acvo else dict(os.environ))
+        fresh = {}
+        for m in re.finditer(r"(\d+) per call: on their own +([0-9.]+) /s \(entries given up (\d+)\), through the engines +([0-9.]+) /s", r.stdout):
+            fresh[m.group(1)] = {"registrations_per_s": float(m.group(2)), "through_the_engines": float(m.group(4)), "entries_given_up": int(m.group(3))}
+        if fresh:
+            out["fresh_process"] = fresh
+    except Exception as e:
+        out["fresh_process_error"] = repr(e)
     return out
 
 

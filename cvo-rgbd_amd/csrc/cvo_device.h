@@ -410,6 +410,13 @@ struct PostStepArgs {
     int32_t *done_mirror;  // see PostFlowArgs
     int ck_nblk[3];        // the pass over tile list l of this iteration ran with ProcessArgs::cand and this many blocks:
                            // its candidate list now matches the tile list (0: no candidate list)
+    // THE HOST'S MIRRORS (pinned host memory written by the kernels): done_mirror, progress_mirror, run_mirror, hint_mirror, side_mirror are
+    // SINGLE 4-byte WORDS and must stay so -- stores to host memory were seen to pass each other on this platform although the device fences
+    // at system scope in between (profiles/r05_ab.txt 15c), so nothing may be read as "written before the word that says so" except through a
+    // check of its own: the one multi-word mirror, final_mirror, carries a check word (head_check_mix) that the host verifies and re-reads
+    // on.  A plain store to host memory may also stay in the device's cache until the kernel ENDS (round 6: the first side-build request was
+    // never seen while its run was alive): a word the host must see while the kernel runs is stored at system scope (__hip_atomic_store ...
+    // __HIP_MEMORY_SCOPE_SYSTEM); progress_mirror and hint_mirror inside a run are plain -- the host reads them when the run has reported.
     int32_t *progress_mirror;   // optional host-visible copy of st->n_slots (pinned): lets the host enqueue the next
                                 // batch when the running one is down to its last slot instead of a whole batch ahead
     int nblk;
