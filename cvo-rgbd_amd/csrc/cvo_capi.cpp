@@ -50,7 +50,7 @@ const OptDef kOptions[] = {
     {"kept_pack", "CVO_HIP_NO_PACK", 1, 0.0},             {"list_margin", "CVO_HIP_LIST_MARGIN", 2, 0.0},
     {"final_mirror", "CVO_HIP_NO_FINAL_MIRROR", 1, 0.0},  {"twist_on_shared_gpu", "CVO_HIP_TWIST_ON_SHARED_GPU", 1, 1.0},
     {"comm_debug", "CVO_HIP_COMM_DEBUG", 1, 1.0},         {"wait_policy", "CVO_HIP_WAIT_POLICY", 2, 0.0},
-    {"acvo_runs", "CVO_HIP_NO_ACVO_RUN", 1, 0.0},         {"side_builds", "CVO_HIP_SIDE", 1, 1.0},
+    {"acvo_runs", "CVO_HIP_NO_ACVO_RUN", 1, 0.0},         {"tail_alone", "CVO_HIP_TAIL_ALONE", 2, 0.0},         {"side_builds", "CVO_HIP_SIDE", 1, 1.0},
     {"run_build_at", "CVO_HIP_RUN_BUILD_AT", 2, 0.0},         {"alone_max", "CVO_HIP_ALONE_MAX", 2, 0.0},
 };
 void env_defaults(cvo_hip_ctx *ctx)
@@ -108,6 +108,7 @@ int apply_option(cvo_hip_ctx *ctx, const char *key, double v)
     else if (is("comm_debug")) o.comm_debug = on;
     else if (is("wait_policy")) { if (v < 0.0 || v > 2.0) return CVO_HIP_ERR_INVALID; o.wait_policy = (int)v; }
     else if (is("acvo_runs")) o.no_acvo_run = !on;
+    else if (is("tail_alone")) { if (v < 0.0 || v > 32.0) return CVO_HIP_ERR_INVALID; o.tail_alone = (int)v; }
     else if (is("run_restart")) o.no_restart = !on;
     else if (is("side_builds")) o.no_side_builds = !on;
     else if (is("run_build_at")) { if (!(v > 0.0 && v <= 1.0)) return CVO_HIP_ERR_INVALID; o.run_build_at = (float)v; }
@@ -878,6 +879,8 @@ int cvo_hip_get_option(const cvo_hip_ctx *ctx, const char *key, double *value)
     else if (is("comm_debug")) *value = o.comm_debug;
     else if (is("wait_policy")) *value = o.wait_policy;
     else if (is("acvo_runs")) *value = !o.no_acvo_run;
+    else if (is("tail_alone")) *value = o.tail_alone;
+    else if (is("tail_handovers")) *value = (double)ctx->tail_handovers;
     else if (is("run_restart")) *value = !o.no_restart;
     else if (is("side_builds")) *value = !o.no_side_builds;
     else if (is("run_build_at")) *value = o.run_build_at;

@@ -94,6 +94,8 @@ struct Engine {
     long long launched = 0, checked = 0;   // batches
     int zdim = 0;
     bool crowded = true, use_graph = true, dirty = true, failed = false;
+    int batch_len = kEngineBatch;          // iterations per batch (shorter when the call's tail is near: what is queued must complete before anybody leaves)
+    bool wind_down = false;                // the call's tail: no further batches; the members that are left go on alone (release_members)
     std::vector<TLaunch> plan;
     struct FlowEv { hipEvent_t a, b; int live; };
     std::vector<FlowEv> flow_ev;           // engine profiling: one pair per flow-pass launch
@@ -316,7 +318,7 @@ struct Engine {
     // one batch of kEngineBatch iterations of the current plan on this engine's stream
     int launch_one_batch()
     {
-        const int batch = kEngineBatch;
+        const int batch = batch_len;
         if (engine_profile()->on) {   // eager, the flow-pass launches bracketed by events
             for (int k = 0; k < batch; ++k)
                 for (const TLaunch &l : plan) {
@@ -363,7 +365,7 @@ struct Engine {
         }
         // batches kept queued per engine (the other engines fill the gap between two batches of this one)
         constexpr long long depth = 2;   // (one batch queued per engine instead of two: -17 %, profiles/r02_ab.txt)
-        while (live() > 0 && launched - checked < depth) {
+        while (live() > 0 && launched - checked < depth && !wind_down) {
             if (dirty) {
                 const double t0 = now_ms();
                 const int rc = replan();
@@ -386,6 +388,22 @@ struct Engine {
             if (replan() != CVO_HIP_OK) { fail_all("table update failed", pending); return true; }
         }
         return moved;
+    }
+
+    // The call's tail (wind_down, every queued batch completed): the members that are still running leave -- the caller carries them on
+    // alone (job_continue_alone); their slots go out of the table with the next replan.
+    void release_members(std::vector<AlignJob *> &out)
+    {
+        if (!wind_down || launched != checked || failed) return;
+        collect_stopped();
+        for (int z = 0; z < ENGINE_SLOTS; ++z) {
+            AlignJob *j = member[z];
+            if (!j) continue;
+            out.push_back(j);
+            member[z] = nullptr;
+            ops[z].clear();
+            dirty = true;
+        }
     }
 
     // block until the oldest thing in flight has completed
@@ -492,6 +510,7 @@ int cvo_hip_align_many(cvo_hip_ctx **ctxs, cvo_hip_state **states, int *n_iters,
     }
     int first_err = CVO_HIP_OK;
     std::vector<char> taken((size_t)count, 0);
+    std::vector<AlignJob *> leavers;   // registrations that left the engines in a call's tail: they go on alone below
     // fused groups: same device, same mode, nothing that needs its own launches.  The jobs of
     // a class wait in one queue; one or two engines (two from 8 jobs on: two groups fill each
     // other's bubbles -- single-block post kernels, kernel boundaries) take them into their
@@ -534,6 +553,8 @@ int cvo_hip_align_many(cvo_hip_ctx **ctxs, cvo_hip_state **states, int *n_iters,
                 e->crowded = (int)total > crowd;
                 e->use_graph = graphs_ok;
                 e->zdim = 0;
+                e->wind_down = false;
+                e->batch_len = kEngineBatch;
                 e->t_idle_at = 0;
                 e->dirty = true;
                 engines.push_back(e);
@@ -544,9 +565,55 @@ int cvo_hip_align_many(cvo_hip_ctx **ctxs, cvo_hip_state **states, int *n_iters,
             }
             // the first fill is even (16 + 16 of 32, 4 + 4 of 8); later a free slot takes the next job
             const int share = std::min<int>(gmax, (int)((total + engines.size() - 1) / engines.size()));
+            // THE CALL'S TAIL (round 6): once the queue is empty and few registrations are left in the engines, all past their wide
+            // iterations, an iteration is a chain of five dependent launches (~40 us) for a handful of members -- 165 iterations of the
+            // longest of 64 registrations against a mean of 68.  They leave: the engines queue no further batches, and when the queued
+            // ones have completed the members go on alone, each on its context's stream, most of their iterations inside resident runs
+            // sized to their share of the compute units (below).
+            const int tail_k = pending.empty() ? 0 : pending.front()->ctx->opt.tail_alone;
+            const int narrow_from = pending.empty() ? 0 : (pending.front()->ctx->prm.mode == CVO_HIP_MODE_ACVO ? 8 : 24);
+            bool tail_ok = tail_k > 0 && !engine_profile()->on;
+            for (AlignJob *j : pending) {
+                const cvo_hip_ctx *c = j->ctx;
+                tail_ok = tail_ok && c->allow_head && c->allow_async && c->allow_merge && !c->opt.no_cand && runs_allowed(c) && c->fixed.np <= 65536 &&
+                          c->moving.np <= 65536 && (c->prm.mode == CVO_HIP_MODE_CVO || (c->allow_async_self && !c->opt.no_acvo_run)) &&
+                          (double)c->fixed.n * (double)c->moving.n <= 2.0e8;
+            }
+            int dbg_left = -1;
             for (;;) {
                 bool any = false, moved = false;
+                if (tail_ok && pending.empty() && !engines.front()->wind_down) {
+                    int left = 0;
+                    bool narrow = true, settled = true;
+                    for (Engine *e : engines) {
+                        settled = settled && e->retiring.empty();
+                        for (AlignJob *j : e->member)
+                            if (j) { ++left; narrow = narrow && *(volatile int32_t *)j->ctx->progress_mirror >= narrow_from; }
+                    }
+                    if (dbg_many && left != dbg_left) { dbg_left = left; fprintf(stderr, "[cvo_hip]   %.2f ms: %d left (narrow %d settled %d)\n", Engine::now_ms() - t_many0, left, (int)narrow, (int)settled); }
+                    (void)settled;
+                    // (batches of 3 iterations once the tail is near -- what is queued must complete before anybody leaves, 0.4-0.8 ms with two
+                    // batches of ten -- were measured: the engines lose more by the short batches than the leavers gain, profiles/r06_ab.txt 10)
+                    if (left > 0 && left <= tail_k && narrow) {
+                        for (Engine *e : engines) e->wind_down = true;
+                        if (dbg_many) {
+                            fprintf(stderr, "[cvo_hip]   tail: %d registrations left after %.2f ms, slots done:", left, Engine::now_ms() - t_many0);
+                            for (Engine *e : engines)
+                                for (AlignJob *j : e->member)
+                                    if (j) fprintf(stderr, " %d", *(volatile int32_t *)j->ctx->progress_mirror);
+                            fprintf(stderr, "\n");
+                        }
+                    }
+                }
                 for (Engine *e : engines) {
+                    if (e->wind_down) {
+                        const size_t before = leavers.size();
+                        e->release_members(leavers);
+                        if (leavers.size() != before) {
+                            moved = true;
+                            if (dbg_many) fprintf(stderr, "[cvo_hip]   tail: %zu registrations leave engine %p after %.2f ms\n", leavers.size() - before, (void *)e, Engine::now_ms() - t_many0);
+                        }
+                    }
                     if (e->pump(pending, share)) moved = true;
                     if (!e->idle()) any = true;
                     else if (dbg_many && e->t_idle_at == 0) {
@@ -562,7 +629,7 @@ int cvo_hip_align_many(cvo_hip_ctx **ctxs, cvo_hip_state **states, int *n_iters,
                     for (Engine *e : engines)
                         if (!e->idle() && !e->failed) { e->wait_oldest(pending); break; }
             }
-            for (Engine *e : engines) engine_release(e);
+            for (Engine *e : engines) { e->wind_down = false; e->batch_len = kEngineBatch; engine_release(e); }
         }
         for (int i = 0; i < count; ++i)
             if (jobs[i].phase == 2 && jobs[i].rc && !first_err) first_err = jobs[i].rc;
@@ -572,12 +639,18 @@ int cvo_hip_align_many(cvo_hip_ctx **ctxs, cvo_hip_state **states, int *n_iters,
     // whatever their records want (four 3k registrations asked for 128-solver runs on spec: two of four entries waited out their
     // 200 us and backed off -- 4 per call 1 808 /s against 2 210 for 2, profiles/r05_ab.txt 22), and with more than two of them no
     // first run goes out on spec
+    std::vector<char> cont((size_t)count, 0);
+    for (AlignJob *j : leavers) {
+        const size_t i = (size_t)(j - &jobs[0]);
+        taken[i] = 0;
+        cont[i] = 1;
+    }
     int k_alone = 0;
     for (int i = 0; i < count; ++i)
         if (!taken[i] && jobs[i].phase != 2) ++k_alone;
     // (at most kAloneLive of them in flight: with more, the share of each no longer holds its first records -- 12 per call were
     // slower than 8 --; the others begin as these end)
-    constexpr int kAloneLive = 8;
+    const int kAloneLive = std::max<int>(8, (int)leavers.size());   // (a call's tail leaves the engines together: all of it goes on at once)
     std::vector<char> begun((size_t)count, 0);
     auto begin_job = [&](int i) {
         int cus = 0;
@@ -589,7 +662,7 @@ int cvo_hip_align_many(cvo_hip_ctx **ctxs, cvo_hip_state **states, int *n_iters,
         jobs[i].ctx->lone = true;
         jobs[i].paced_nb = true;   // (job_pump's paced steps, one look per call: resident runs for registrations on their own here too)
         begun[(size_t)i] = 1;
-        const int rc = job_begin(jobs[i]);
+        const int rc = cont[(size_t)i] ? job_continue_alone(jobs[i]) : job_begin(jobs[i]);
         if (rc) { jobs[i].rc = rc; jobs[i].phase = 2; if (!first_err) first_err = rc; }
     };
     auto is_alone = [&](int i) { return !taken[i]; };

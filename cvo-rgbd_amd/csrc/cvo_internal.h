@@ -246,6 +246,8 @@ struct CtxOptions {
     float run_build_at = 0.6f;        // "run_build_at": with side builds a run names its next list when this fraction of the room of the list in use is gone
     bool no_restart = false;          // "run_restart" = 0 (diagnostics): a run that times out fails the registration with CVO_HIP_ERR_RUN, its state kept
     bool no_acvo_run = false;         // "acvo_runs" = 0: resident runs for cvo registrations only (round 5's state)
+    int tail_alone = 8;               // "tail_alone": when a cvo_hip_align_many call's queue is empty and at most this many registrations are left in its
+                                      // engines, all past their wide iterations, they leave the engines for resident runs of their own (0: never)
     int alone_max = 0;                // "alone_max": a call of up to this many registrations leaves them to their own streams (0: by the clouds)
     int engines_force = 0;            // "engines": engines of an align_many call (0: by the call's size)
     double list_init = 0.0;           // "list_init": first capacity of every list (0: by the clouds)
@@ -262,6 +264,7 @@ struct cvo_hip_ctx {
     CtxOptions opt;
     int no_run_backoff = 0;              // registrations to go without resident runs (one of them timed out, job_pump)
     long long side_builds_launched = 0;  // side builds launched by this context ("side_builds_launched")
+    long long tail_handovers = 0;        // times this context's registration left an engine for runs of its own ("tail_handovers")
     long long run_aborts = 0;            // resident runs of this context that gave up at their entry hand-shake ("run_aborts")
     long long run_timeouts = 0;          // resident runs of this context that gave up on an exchange (cvo_hip_get_option "run_timeouts")
     int device = 0;
@@ -454,6 +457,7 @@ void decide_scheme(cvo_hip_ctx *ctx);
 std::atomic<long long> &mirror_retries();
 int job_begin(AlignJob &j);
 int job_finish(AlignJob &j);
+int job_continue_alone(AlignJob &j);
 int job_pump(AlignJob &j, bool block);
 
 }   // namespace cvo_impl

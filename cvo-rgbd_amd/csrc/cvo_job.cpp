@@ -145,6 +145,58 @@ int job_begin(AlignJob &j)
     return CVO_HIP_OK;
 }
 
+// A registration that has been running in an engine (cvo_engine.cpp) goes on alone, on its context's stream: the state stays (R, T, ell, the
+// iteration count: the engine's last batch has completed and left it at an iteration's end), the lists are forgotten -- the engine's are
+// synchronous, single-buffered and without head-mode records -- and the plan of a registration on its own, resident runs and all, takes
+// over: what job_pump does after a list grew, without the growing.  The caller has seen the engine's stream idle.
+int job_continue_alone(AlignJob &j)
+{
+    cvo_hip_ctx *ctx = j.ctx;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    j.in_group = false;
+    ctx->loop_stream = nullptr;
+    ctx->crowded = false;
+    ctx->lone = true;
+    ctx->proc_blocks = ctx->proc_blocks_default;
+    if (ctx->no_run_backoff > 0) --ctx->no_run_backoff;
+    *ctx->done_mirror = 0;
+    *ctx->progress_mirror = 0;
+    *ctx->run_mirror = 0;
+    *ctx->hint_mirror = -1;
+    *ctx->side_mirror = 0;
+    if (ctx->final_mirror) ctx->final_mirror->done = RUNNING;
+    decide_scheme(ctx);
+    hipStream_t s = loop_stream(ctx);
+    HIP_TRY(ctx, hipMemsetAsync(reinterpret_cast<char *>(ctx->st) + offsetof(DevState, n_slots), 0, sizeof(int32_t), s));
+    HIP_TRY(ctx, hipMemsetAsync(reinterpret_cast<char *>(ctx->st) + offsetof(DevState, run_count), 0, 4 * sizeof(int32_t), s));
+    HIP_TRY(ctx, hipMemsetAsync(reinterpret_cast<char *>(ctx->st) + offsetof(DevState, run_last_entered), 0, 2 * sizeof(int32_t), s));
+    // (k_prepare without the registration's first state: every list to be built, the plan made anew from R, T, ell as they stand)
+    launch_prepare(ctx->st, loop_params(ctx), s, ctx->table.raw ? ctx->table.masks() : nullptr);
+    HIP_TRY(ctx, hipGetLastError());
+    const int prc = prepare_buffers(ctx);
+    if (prc) return prc;
+    ctx->head_mode = false;
+    const int rc = prepare_lone_plan(ctx, 0);
+    if (rc) return rc;
+    j.enq = j.batches = j.checked = 0;
+    j.runs_enq = 0;
+    j.run_waiting = false;
+    j.spec_pending = false;
+    j.side_seen = 0;
+    j.side_launched = 0;
+    const int g_call = std::max(8, std::min(ctx->run_g_max, ctx->run_g_call));
+    ctx->run_nnz_max = g_call * RUN_BLOCK * (RUN_R + RUN_L);
+    ctx->run_small_max = 3 * RUN_G_SMALL * RUN_BLOCK;
+    if (ctx->prm.mode == CVO_HIP_MODE_ACVO) {
+        ctx->run_nnz_max = (int)(0.8 * g_call * RUN_BLOCK * RUN_A);
+        ctx->run_small_max = (int)(0.8 * 2 * RUN_G_SMALL * RUN_BLOCK);
+    }
+    if (ctx->opt.run_cand > 0) ctx->run_nnz_max = ctx->opt.run_cand;
+    j.phase = 0;
+    ++ctx->tail_handovers;
+    return CVO_HIP_OK;
+}
+
 // ref src/cvo.cpp:413-415 and the trace / state hand-back
 int job_finish(AlignJob &j)
 {
