@@ -108,3 +108,30 @@ def test_parameters_are_validated_before_anything_touches_a_device(pkg):
     assert create(q) == -1
     m = capi.default_params(capi.MODE_MATLAB)           # the MATLAB preset is a valid CVO-mode block
     assert m.mode == capi.MODE_CVO and m.color_scale > 0 and create(m) in (0, -5)
+
+
+def test_every_option_is_documented_and_the_library_reads_the_environment_in_one_place():
+    """cvo_hip_set_option's keys (csrc/cvo_capi.cpp kOptions) are what a host program sets instead of environment variables: every key
+    and every environment default is listed in INTEGRATION.md, and the library's translation units hold ONE getenv (the table's) besides
+    the front end's own switch."""
+    import os
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = open(os.path.join(root, "cvo-rgbd_amd", "csrc", "cvo_capi.cpp")).read()
+    table = src[src.index("const OptDef kOptions[] = {"):src.index("void env_defaults(")]
+    entries = re.findall(r'\{"([a-z_0-9]+)",\s*(nullptr|"([A-Z_0-9]+)")', table)
+    assert len(entries) >= 30
+    doc = open(os.path.join(root, "INTEGRATION.md")).read()
+    for key, _, env in entries:
+        assert "`%s`" % key in doc, key
+        if env:
+            assert env in doc or env.replace("CVO_HIP", "") in doc, env
+    # every key of the table is handled by apply_option and by cvo_hip_get_option
+    for key, _, _ in entries:
+        assert src.count('is("%s")' % key) >= 2, key
+    csrc = os.path.join(root, "cvo-rgbd_amd", "csrc")
+    n = 0
+    for f in sorted(os.listdir(csrc)):
+        if f.endswith((".cpp", ".hip", ".h", ".hpp")):
+            n += len(re.findall(r"\bgetenv\s*\(", open(os.path.join(csrc, f)).read()))
+    assert n == 2, n   # cvo_capi.cpp env_defaults, cvo_frontend.hip CVO_FE_NO_GRAPH
