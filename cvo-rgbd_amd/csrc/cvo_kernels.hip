@@ -1907,7 +1907,8 @@ enum HeadMode { HM_CLASSIC = 0, HM_HEAD = 1 };
 // head that follows it has run (head mode counts it then).
 template <int HM>
 __device__ __forceinline__ void head_post(DevHead *lds, const PostStepArgs &a, const bool run_post, const bool publisher, const bool timed,
-                                          long long (&clk)[4])
+                                          long long (&clk)[4], const cvo_math::ExpPre *pre = nullptr /* the twist-only stage of Exp_SEK3, dist_se3 and
+                                          the stop test where it was formed ahead (a resident run: behind its step exchange); null: formed here */)
 {
     const DevParams &p = a.prm;
     const bool acvo = p.mode == CVO_HIP_MODE_ACVO;
@@ -1946,15 +1947,10 @@ __device__ __forceinline__ void head_post(DevHead *lds, const PostStepArgs &a, c
         }
         // break A: both twist norms below eps (ref cvo.cpp:380 float norms,
         // adaptive_cvo.cpp:509 double norms of the float vectors)
+        const cvo_math::ExpPre P = pre ? *pre : cvo_math::exp_se3_pre(omega, v);
         bool brk;
-        if (acvo) {
-            const double nw = sqrt((double)omega[0] * omega[0] +
-                                   ((double)omega[1] * omega[1] + (double)omega[2] * omega[2]));
-            const double nv = sqrt((double)v[0] * v[0] + ((double)v[1] * v[1] + (double)v[2] * v[2]));
-            brk = nw < (double)p.eps && nv < (double)p.eps;
-        } else {
-            brk = cvo_math::norm_fixed3(omega) < p.eps && cvo_math::norm_fixed3(v) < p.eps;
-        }
+        if (acvo) brk = P.nw_d < (double)p.eps && P.nv_d < (double)p.eps;
+        else brk = P.nw < p.eps && P.nv < p.eps;
         if (brk) {
             iter = k;
             done = DONE_BREAK_A;
@@ -1962,7 +1958,7 @@ __device__ __forceinline__ void head_post(DevHead *lds, const PostStepArgs &a, c
         } else {
             // integrate: T = R*dT + T ; R = R*dR  (ref cvo.cpp:391-399)
             float dR[9], dT[3], RdT[3];
-            cvo_math::exp_se3(omega, v, step, dR, dT);
+            cvo_math::exp_se3_with(P, v, step, dR, dT);
             cvo_math::Mat3 Rm, dRm;
 #pragma unroll
             for (int q = 0; q < 9; ++q) { Rm.m[q] = R[q]; dRm.m[q] = dR[q]; }
@@ -1973,7 +1969,7 @@ __device__ __forceinline__ void head_post(DevHead *lds, const PostStepArgs &a, c
 #pragma unroll
             for (int q = 0; q < 9; ++q) R[q] = Rn.m[q];
 
-            const float dist = cvo_math::dist_se3(omega, v, step);
+            const float dist = cvo_math::dist_se3_with(P, step);
             if (tr) tr->dist = dist;
             if (dist < p.eps_2) {   // break B
                 iter = k;
@@ -2713,10 +2709,12 @@ constexpr long long RUN_ENTRY_TICKS = 20000LL;         // 200 us: how long the h
 // this block only reads) -> tot[0..NV) = the sum of the g rows, added in ONE fixed order (four chains, then a tree).  All
 // threads call it.  seq: the exchange's number (every block counts the same).  verdict_out (block-uniform, may be null): the
 // head block's verdict word of this exchange is waited for as well and handed out.  Returns false on a time-out (block-uniform).
-template <int NV, int KMAX>
+// after_post(): called by every thread once the block's sums are on their way -- work that hides behind the exchange's latency.
+struct RunNoWork { __device__ __forceinline__ void operator()() const {} };
+template <int NV, int KMAX, class AFTER>
 __device__ __forceinline__ bool run_exchange_k(RunMail *mail, const int row, const int g, const unsigned long long seq, const double my_val,
                                              double *all /* LDS [RUN_G * NV] */, double *part /* LDS [8 * NV] */, double *tot /* LDS [NV] */,
-                                             int *s_fail, unsigned *verdict_out, unsigned *s_verdict, const long long timeout_ticks)
+                                             int *s_fail, unsigned *verdict_out, unsigned *s_verdict, const long long timeout_ticks, const AFTER &after_post)
 {
     const int tid = threadIdx.x;
     const unsigned tag = (unsigned)seq;
@@ -2728,6 +2726,7 @@ __device__ __forceinline__ bool run_exchange_k(RunMail *mail, const int row, con
         __hip_atomic_store(&slot[row * (2 * RUN_NV) + tid], ((unsigned long long)tag << 32) | half, __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_AGENT);
     }
+    after_post();
     // thread t polls words t, t + 512, ...: ALL of a sweep requested before any is looked at (KMAX per thread: 2 up to 32 solvers,
     // 9 at 248)
     const int nrow = g * 2 * NV, nwords = nrow + (verdict_out ? 1 : 0);
@@ -2779,15 +2778,15 @@ __device__ __forceinline__ bool run_exchange_k(RunMail *mail, const int row, con
     if (verdict_out) *verdict_out = *s_verdict;
     return *s_fail == 0;
 }
-template <int NV>
+template <int NV, class AFTER = RunNoWork>
 __device__ __forceinline__ bool run_exchange(RunMail *mail, const int row, const int g, const unsigned long long seq, const double my_val,
                                              double *all, double *part, double *tot, int *s_fail, unsigned *verdict_out, unsigned *s_verdict,
-                                             const long long timeout_ticks)
+                                             const long long timeout_ticks, const AFTER &after_post = AFTER())
 {
     static_assert(RUN_G_SMALL * 2 * NV + 1 <= 2 * RUN_BLOCK, "two words per thread up to RUN_G_SMALL solvers");
     constexpr int KBIG = (RUN_G * 2 * NV + 1 + RUN_BLOCK - 1) / RUN_BLOCK;
-    if (g <= RUN_G_SMALL) return run_exchange_k<NV, 2>(mail, row, g, seq, my_val, all, part, tot, s_fail, verdict_out, s_verdict, timeout_ticks);
-    return run_exchange_k<NV, KBIG>(mail, row, g, seq, my_val, all, part, tot, s_fail, verdict_out, s_verdict, timeout_ticks);
+    if (g <= RUN_G_SMALL) return run_exchange_k<NV, 2>(mail, row, g, seq, my_val, all, part, tot, s_fail, verdict_out, s_verdict, timeout_ticks, after_post);
+    return run_exchange_k<NV, KBIG>(mail, row, g, seq, my_val, all, part, tot, s_fail, verdict_out, s_verdict, timeout_ticks, after_post);
 }
 
 // The passes of a run over NR candidates per lane, straight-line: the NR chains (transform, exact test, a float64 exp, the
@@ -2992,6 +2991,7 @@ __device__ __forceinline__ void run_body(const Slot *__restrict__ tab, const int
     __shared__ int s_side_t, s_side_handed, s_side_fail;
     __shared__ unsigned long long s_side_expect;
     __shared__ unsigned s_vbits;
+    __shared__ cvo_math::ExpPre s_pre;   // the twist-only stage of the head's Exp_SEK3 / dist_se3 / stop test, formed behind the step exchange
     __shared__ double s_dl;   // acvo: dl of the slot (ref src/adaptive_cvo.cpp:271), every block's own
     __shared__ double s_etab[64];
     __shared__ cvo_math::XiConsts s_xi;
@@ -3570,7 +3570,15 @@ __device__ __forceinline__ void run_body(const Slot *__restrict__ tab, const int
         RUN_CLK(8);
         ++nexch;
         unsigned verdict = 0u;
-        if (!run_exchange<NACC_STEP>(ps.run_mail, srow, g, seq0 + nexch, my_step, s_all, s_part, s_tot, &s_fail, &verdict, &s_verdict, run_timeout)) { comm_ok = false; SIDE_DBG(11); break; }
+        // (the last wave forms the twist-only stage of the head's chain while the step sums travel: ~120 instructions the first wave
+        // no longer runs in a row behind the exchange, cvo_math::exp_se3_pre)
+        auto pre_work = [&]() {
+            if (wid == RUN_WAVES - 1) {
+                const cvo_math::ExpPre P = cvo_math::exp_se3_pre(s_xi.omega, s_xi.v);
+                if (lane == 0) s_pre = P;
+            }
+        };
+        if (!run_exchange<NACC_STEP>(ps.run_mail, srow, g, seq0 + nexch, my_step, s_all, s_part, s_tot, &s_fail, &verdict, &s_verdict, run_timeout, pre_work)) { comm_ok = false; SIDE_DBG(11); break; }
         RUN_CLK(9);
         if (verdict & RUN_V_STALL) {
             // no buffer holds every pair for this slot's transform (a jump): what the passes have summed is void.  The head goes
@@ -3633,10 +3641,10 @@ __device__ __forceinline__ void run_body(const Slot *__restrict__ tab, const int
         if (tid < 64) {
             long long clk[4] = {0, 0, 0, 0};
 #ifdef CVO_RUN_CLOCKS
-            head_post<HM_HEAD>(&s_st, ps, true, head_block, true, clk);
+            head_post<HM_HEAD>(&s_st, ps, true, head_block, true, clk, &s_pre);
             clk_acc[15] += clk[1] - clk[0];   // (of head_post: the cubic and its root)
 #else
-            head_post<HM_HEAD>(&s_st, ps, true, head_block, false, clk);
+            head_post<HM_HEAD>(&s_st, ps, true, head_block, false, clk, &s_pre);
 #endif
             RUN_CLK(11);
             if (s_st.done == RUNNING) {

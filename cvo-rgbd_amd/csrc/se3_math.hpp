@@ -257,7 +257,16 @@ CVO_HD bool section_shortcut(const CubicBracket &B, double lo, double hi, double
     double x = 0.5 * (lo + hi);
     for (int it = 0; it < 2; ++it) {
         const double d = (3.0 * x + 2.0 * B.a) * x + B.b;
+#if defined(__HIP_DEVICE_COMPILE__)
+        // (on the device the quotient is a reciprocal with one correction -- 2^-50 or so -- instead of the ~40 dependent instructions of
+        // a float64 division, twice on the one chain of the head: the proof below holds for ANY x, so what comes out is the float32 of
+        // the rounds' result whichever x went in; host and device may take the short cut with different x, or only one of them at all)
+        double r = __builtin_amdgcn_rcp(d);
+        r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
+        x = x - cubic_eval(B.a, B.b, B.c, x) * r;
+#else
         x = x - cubic_eval(B.a, B.b, B.c, x) / d;
+#endif
     }
     if (!(fabs(x) <= 1.0e300)) return false;   // (NaN, infinity)
     const double delta = fabs(x) * 0x1p-40, m = fabs(x) * 0x1p-44;
@@ -317,40 +326,77 @@ CVO_HD float pick_step(const double bcde[4], float min_step)
     return finish_step(B.found, B.found ? section_root(B) : 0.0, min_step);
 }
 
-// Exp_SEK3 with K = 1: dR (row-major) and dT = Jl * v.
-CVO_HD void exp_se3(const float w[3], const float v[3], float dt, float dR[9], float dT[3])
+// Exp_SEK3 with K = 1: dR (row-major) and dT = Jl * v.  In two stages (round 6): what depends on the twist alone -- the angle, the skew
+// matrix and its square, the square roots of dist_se3 and of the stop test -- and what needs the step.  Inside a resident run the
+// first stage is formed while the step-size sums are still on their way (cvo_kernels.hip kt_run); everywhere else the two stages
+// follow each other: the same operations on the same operands either way.
+struct ExpPre {
+    float theta, theta2, theta3;
+    Mat3 A, A2;
+    double root_full, root_v;   // sqrt(2 |w|^2 + |v|^2), sqrt(|v|^2) in float64 (dist_se3)
+    float nw, nv;               // float norms of the twist (the stop test of cvo, ref src/cvo.cpp:380)
+    double nw_d, nv_d;          // ... in float64 of the float vectors (acvo, ref src/adaptive_cvo.cpp:509)
+    int small;                  // theta < TOLERANCE: R = I, Jl = I
+};
+
+CVO_HD ExpPre exp_se3_pre(const float w[3], const float v[3])
 {
     const float TOLERANCE = 1e-6f;
-    const float theta = norm_fixed3(w);
+    ExpPre P;
+    P.theta = norm_fixed3(w);
+    P.small = (P.theta < TOLERANCE) ? 1 : 0;
+    P.A = skew(w);
+    P.theta2 = P.theta * P.theta;
+    P.A2 = mul(P.A, P.A);
+    P.theta3 = P.theta2 * P.theta;
+    const double w2 = (double)w[0] * w[0] + (double)w[1] * w[1] + (double)w[2] * w[2];
+    const double v2 = (double)v[0] * v[0] + (double)v[1] * v[1] + (double)v[2] * v[2];
+    P.root_full = sqrt(2.0 * w2 + v2);
+    P.root_v = sqrt(v2);
+    P.nw = P.theta;
+    P.nv = norm_fixed3(v);
+    P.nw_d = sqrt((double)w[0] * w[0] + ((double)w[1] * w[1] + (double)w[2] * w[2]));
+    P.nv_d = sqrt((double)v[0] * v[0] + ((double)v[1] * v[1] + (double)v[2] * v[2]));
+    return P;
+}
+
+CVO_HD void exp_se3_with(const ExpPre &P, const float v[3], float dt, float dR[9], float dT[3])
+{
     const Mat3 I = identity3();
     Mat3 R = I, Jl = I;   // small-angle branch: R = I, Jl = I (not dt*I)
-    if (!(theta < TOLERANCE)) {
-        const Mat3 A = skew(w);
-        const float theta2 = theta * theta;
+    if (!P.small) {
+        const float theta = P.theta;
         double sd, cd;
         sincos_det((double)(dt * theta), &sd, &cd);
         const float stheta = (float)sd;
         const float ctheta = (float)cd;
-        const float oneMinusCosTheta2 = (1 - ctheta) / theta2;
-        const Mat3 A2 = mul(A, A);
+        const float oneMinusCosTheta2 = (1 - ctheta) / P.theta2;
         const float s1 = stheta / theta;
-        const float j3 = (dt * theta - stheta) / (theta2 * theta);
+        const float j3 = (dt * theta - stheta) / P.theta3;
         for (int k = 0; k < 9; ++k) {
-            R.m[k] = (I.m[k] + s1 * A.m[k]) + oneMinusCosTheta2 * A2.m[k];
-            Jl.m[k] = (dt * I.m[k] + oneMinusCosTheta2 * A.m[k]) + j3 * A2.m[k];
+            R.m[k] = (I.m[k] + s1 * P.A.m[k]) + oneMinusCosTheta2 * P.A2.m[k];
+            Jl.m[k] = (dt * I.m[k] + oneMinusCosTheta2 * P.A.m[k]) + j3 * P.A2.m[k];
         }
     }
     for (int k = 0; k < 9; ++k) dR[k] = R.m[k];
     mulv(Jl, v, dT);
 }
 
+CVO_HD void exp_se3(const float w[3], const float v[3], float dt, float dR[9], float dT[3])
+{
+    exp_se3_with(exp_se3_pre(w, v), v, dt, dR, dT);
+}
+
 // ||logm([dR dT; 0 1])||_F for the increment produced by exp_se3(w, v, dt).
+CVO_HD float dist_se3_with(const ExpPre &P, float dt)
+{
+    if (P.theta < 1e-6f) return (float)P.root_v;
+    return (float)((double)dt * P.root_full);
+}
+
 CVO_HD float dist_se3(const float w[3], const float v[3], float dt)
 {
-    const double w2 = (double)w[0] * w[0] + (double)w[1] * w[1] + (double)w[2] * w[2];
-    const double v2 = (double)v[0] * v[0] + (double)v[1] * v[1] + (double)v[2] * v[2];
-    if (norm_fixed3(w) < 1e-6f) return (float)sqrt(v2);
-    return (float)((double)dt * sqrt(2.0 * w2 + v2));
+    return dist_se3_with(exp_se3_pre(w, v), dt);
 }
 
 // Constants of the per-point Taylor vectors in compute_step_size
