@@ -1421,3 +1421,43 @@ def test_side_builds_change_nothing(pkg, mode_name, n):
             res.append(outs[0])
             c.close()
         assert res[0] == res[1]
+
+
+@pytest.mark.parametrize("mode_name,n,count", [("acvo", 3000, 40), ("cvo", 4000, 36)])
+def test_the_tail_of_a_large_call_leaves_the_engines(pkg, mode_name, n, count):
+    """csrc/cvo_engine.cpp "the call's tail": once a cvo_hip_align_many call's queue is empty and at most `tail_alone` (8) registrations are left
+    in its engines, all past their wide iterations, they go on alone (job_continue_alone: the state stays, the lists are forgotten, the plan of
+    a registration on its own takes over -- resident runs, kt_run / kt_run_acvo).  Every registration of the call equals the same pair
+    registered on its own (cvo_hip_align) bit for bit, with the hand-over on and off; and the hand-over does happen."""
+    import torch
+    capi = pkg.capi
+    acvo = mode_name == "acvo"
+    mode = capi.MODE_ACVO if acvo else capi.MODE_CVO
+    pairs = [pkg.data.synthetic_pair(n, n - 37 * (b % 5), seed=7300 + b, acvo=acvo) for b in range(count)]
+    res = {}
+    for tail in (8, 0):
+        cs, ss = [], []
+        for xf, ff, xm, fm in pairs:
+            s = torch.cuda.Stream()
+            c = capi.Context(mode=mode, device=0, stream=s.cuda_stream, graph_capture=True)
+            c.set_fixed(xf, ff); c.set_moving(xm, fm)
+            cs.append(c); ss.append(s)
+        cs[0].set_option("tail_alone", tail)   # (a call goes by its first context's switches)
+        out = None
+        for _ in range(2):
+            states = [capi.init_state(c.params) for c in cs]
+            its = capi.align_many(cs, states)
+            got = [(i, bytes(s)) for i, s in zip(its, states)]
+            assert out is None or got == out
+            out = got
+        left = sum(c.get_option("tail_handovers") for c in cs)
+        assert (left >= 1) == (tail > 0), (tail, left)
+        if tail:   # ... against each pair on its own
+            for b, c in enumerate(cs):
+                st = capi.init_state(c.params)
+                it, _ = c.align(st, trace_cap=0)
+                assert (it, bytes(st)) == out[b], b
+        res[tail] = out
+        for c in cs:
+            c.close()
+    assert res[8] == res[0]
