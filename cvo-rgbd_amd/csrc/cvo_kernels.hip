@@ -2700,7 +2700,9 @@ CVO_HEAD_KERNELS(_w4, 4)
 // A poll that does not fill within its limit (PostStepArgs::run_timeout_ticks, else RUN_TIMEOUT_TICKS) ends the run with DONE_RUN_TIMEOUT
 // instead of hanging; the host then registers the pair again without runs.
 constexpr long long RUN_TIMEOUT_TICKS = 100000000LL;   // 1 s of the 100 MHz wall clock
-enum { RUN_V_STALL = 1, RUN_V_BUILD = 2 };            // the head block's verdict on the slot that is running
+enum { RUN_V_STALL = 1, RUN_V_BUILD = 2, RUN_V_RELOAD = 4 };   // the head block's verdict on the slot that is running (RELOAD, side builds: the plan
+                                                               // has changed lists -- the slot stands, and before the next one every block loads its
+                                                               // candidates from the other buffer's record)
 enum { RUN_GO = 1, RUN_ABORT = 2 };                    // ... and on a large run's entry (RunMail::entry_go)
 constexpr long long RUN_ENTRY_TICKS = 20000LL;         // 200 us: how long the head block of a large run waits for its solvers to start
 
@@ -2988,7 +2990,8 @@ __device__ __forceinline__ void run_body(const Slot *__restrict__ tab, const int
     __shared__ double s_tot[NVF + 4];
     // side builds (head block): the buffer whose build is in flight beside the run (-1: none), handed = it has ended and the plan has been
     // told (xy_fresh), the count of RunMail::side_done that says it has ended, verdict bits the coming slot gets on top of the plan's
-    __shared__ int s_side_t, s_side_handed, s_side_fail;
+    __shared__ int s_side_t, s_side_handed, s_side_fail, s_side_count;
+    __shared__ unsigned s_side_total;
     __shared__ unsigned long long s_side_expect;
     __shared__ unsigned s_vbits;
     __shared__ cvo_math::ExpPre s_pre;   // the twist-only stage of the head's Exp_SEK3 / dist_se3 / stop test, formed behind the step exchange
@@ -3223,11 +3226,19 @@ __device__ __forceinline__ void run_body(const Slot *__restrict__ tab, const int
     const unsigned lanes = (unsigned)g * RUN_BLOCK;
     entered = true;   // (from here on the run executes at least one slot)
 
-    // ---- the candidates of this lane: c = l + r * lanes
-    const unsigned wave_first = head_block ? total : (unsigned)srow * RUN_BLOCK + (unsigned)wid * 64u;   // flat number of the wave's first candidate of round 0
-    const int rmax = wave_first < total ? (int)((total - wave_first + lanes - 1) / lanes) : 0;   // wave-uniform: rounds with any candidate
+    // ---- the candidates of this lane: c = l + r * lanes (load_xy: at entry; with side builds again whenever the plan has changed lists --
+    // act_cur / tot_cur: the xy buffer in use and its record's candidates, s_pref: that record's prefix sums)
+    int act_cur = act;
+    unsigned tot_cur = total;
+    int rmax = 0, nl = 0;
     constexpr int NRX = ACVO ? RUN_A : RUN_R;   // xy candidates of a lane in registers
     float cx[NRX][3], cy[NRX][3], cck[NRX], cw[NRX];
+    float4 *const lc = s_lc + tid;
+    auto load_xy = [&]() {
+    const unsigned total = tot_cur;
+    const int act = act_cur;
+    const unsigned wave_first = head_block ? total : (unsigned)srow * RUN_BLOCK + (unsigned)wid * 64u;   // flat number of the wave's first candidate of round 0
+    rmax = wave_first < total ? (int)((total - wave_first + lanes - 1) / lanes) : 0;   // wave-uniform: rounds with any candidate
     {
         const uint2 *rec = act ? pa.cand_b : pa.cand;
         const unsigned wcap = pa.kept_wcap;
@@ -3266,8 +3277,7 @@ __device__ __forceinline__ void run_body(const Slot *__restrict__ tab, const int
     }
     // ... and those behind the registers' (rounds RUN_R .. rmax - 1: only a run of all RUN_G solvers has them) into LDS
     static_assert(RUN_L % 2 == 0, "run_flow_lds / run_step_lds take two rounds per trip");
-    const int nl = (!ACVO && rmax > RUN_R) ? ((rmax - RUN_R + 1) & ~1) : 0;   // (wave-uniform; even: a last odd round is filled with lanes without a candidate)
-    float4 *const lc = s_lc + tid;
+    nl = (!ACVO && rmax > RUN_R) ? ((rmax - RUN_R + 1) & ~1) : 0;   // (wave-uniform; even: a last odd round is filled with lanes without a candidate)
     {
         const uint2 *rec = act ? pa.cand_b : pa.cand;
         const unsigned wcap = pa.kept_wcap;
@@ -3301,6 +3311,8 @@ __device__ __forceinline__ void run_body(const Slot *__restrict__ tab, const int
             }
         }
     }
+    };   // load_xy
+    load_xy();
     // ---- acvo: the lane's xx and yy candidates (the same flat numbering over their records' slices)
     float xd2[ACVO ? RUN_A : 1], xck[ACVO ? RUN_A : 1];
     float yya[ACVO ? RUN_A : 1][3], yyb[ACVO ? RUN_A : 1][3], yck[ACVO ? RUN_A : 1];
@@ -3382,7 +3394,8 @@ __device__ __forceinline__ void run_body(const Slot *__restrict__ tab, const int
 #define SIDE_DBG(i) do { } while (0)
 #endif
     SIDE_DBG(side_can ? 0 : 1);
-    if (head_block && tid == 0) { s_side_t = -1; s_side_handed = 0; s_side_fail = 0; s_vbits = 0u; }
+    if (head_block && tid == 0) { s_side_t = -1; s_side_handed = 0; s_side_fail = 0; s_vbits = 0u; s_side_count = 0; s_side_total = 0u; }
+    bool reload_next = false;   // (block-uniform: the verdict of the slot that has just run said RUN_V_RELOAD)
     auto side_ended = [&]() -> bool {
         return __hip_atomic_load(&ps.run_mail->side_done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= s_side_expect;
     };
@@ -3596,6 +3609,7 @@ __device__ __forceinline__ void run_body(const Slot *__restrict__ tab, const int
             }
             break;
         }
+        if constexpr (SIDE) reload_next = (verdict & RUN_V_RELOAD) != 0u;
         // ---- the slot stands.  The head block: what the slot's step launch leaves in the head, the trace record
         if (ACVO && !head_block && tid == 0) s_st.dl = s_dl;   // (what this block's head_post moves the length scale by)
         if (head_block && tid == 0) {
@@ -3698,6 +3712,7 @@ __device__ __forceinline__ void run_body(const Slot *__restrict__ tab, const int
                         if (side_ended()) {
                             SIDE_DBG(3);
                             s_side_handed = 1;
+                            s_side_count = 1;   // (all threads count the record's candidates below)
                             if (t) s_st.xy_ck[1] = pa.nblk; else s_st.xy_ck[0] = pa.nblk;   // (its record is written)
                             // a list or a record slice that overflowed: the flags are up in row 1, the head of the next launch reads them
                             // and parks the loop as always -- the run ends with the coming slot, before its own plan would judge the build
@@ -3711,18 +3726,36 @@ __device__ __forceinline__ void run_body(const Slot *__restrict__ tab, const int
                         s_side_t = -1; s_side_handed = 0;   // (the plan that has just run judged it)
                     }
                 }
-                if ((s_st.xy_active ? 1 : 0) != act) {
+                if ((s_st.xy_active ? 1 : 0) != act_cur) {
                     // the plan has changed lists; the solvers hold the old one's candidates: this slot is the run's last.  Its passes stand if
                     // the old list still holds every pair for the slot's transform (plan_xy_async's own test), else they are void
                     const float r_now = sqrtf(s_st.kc.tau), slack = 1.0e-4f * (1.0f + s_st.xmax + s_st.y0max);
-                    const float need = (r_now + (act ? xy_travel<1>(&s_st, &s_st) : xy_travel<0>(&s_st, &s_st))) * 1.0001f + slack;
-                    const bool held = (act ? s_st.xy_ok[1] : s_st.xy_ok[0]) != 0 && need <= (act ? s_st.xy_r[1] : s_st.xy_r[0]);
-                    vb |= held ? (unsigned)RUN_V_BUILD : (unsigned)RUN_V_STALL;
-                    SIDE_DBG(held ? 4 : 5);
+                    const float need = (r_now + (act_cur ? xy_travel<1>(&s_st, &s_st) : xy_travel<0>(&s_st, &s_st))) * 1.0001f + slack;
+                    const bool held = (act_cur ? s_st.xy_ok[1] : s_st.xy_ok[0]) != 0 && need <= (act_cur ? s_st.xy_r[1] : s_st.xy_r[0]);
+                    // (... and the run goes on where the new record fits the solvers it has: every block loads its candidates anew)
+                    const bool fits = s_side_total > 0u && s_side_total <= (unsigned)g * (unsigned)RUN_BLOCK * (unsigned)(ACVO ? RUN_A : RUN_R + RUN_L);
+                    vb |= held ? (fits ? (unsigned)RUN_V_RELOAD : (unsigned)RUN_V_BUILD) : (unsigned)RUN_V_STALL;
+                    SIDE_DBG(held ? (fits ? 6 : 4) : 5);
                 }
                 s_vbits = vb;
             }
             __syncthreads();
+            if (s_side_count != 0) {   // the side build has just ended: what its record holds (all threads; s_pref is free between two exchanges)
+                const int t = s_side_t;
+                unsigned sel[PER];
+#pragma unroll
+                for (int q = 0; q < PER; ++q) {
+                    const int sl = tid * PER + q;
+                    sel[q] = sl < nsl ? (t ? pa.cand_cnt_b[sl] : pa.cand_cnt[sl]) : 0u;
+                }
+                const unsigned tot = prefix(sel, pa.kept_wcap, s_pref);
+                if (tid == 0) {
+                    s_side_total = tot;
+                    if (t) s_st.rec_count[1] = (int32_t)tot; else s_st.rec_count[0] = (int32_t)tot;
+                    s_side_count = 0;
+                }
+                __syncthreads();
+            }
             // a build the plan has just named: beside the run
             if (s_side_t < 0 && s_vbits == 0u && s_st.xy_target >= 0 && s_st.stall == 0 &&
                 !(ACVO && (s_st.sf_target[0] >= 0 || s_st.sf_target[1] >= 0))) {
@@ -3750,6 +3783,23 @@ __device__ __forceinline__ void run_body(const Slot *__restrict__ tab, const int
                 if (ps.progress_mirror) *ps.progress_mirror = s_st.n_slots;
             }
             if (!(side_can && s_side_t >= 0)) head_prepare_lists<HM_HEAD>(ps, &s_st);   // (a build this head has named: its counters; not those of a list that is being filled)
+        }
+        if constexpr (SIDE) {
+            if (reload_next) {
+                // the plan has changed lists (a side build's): this block's candidates from the other buffer's record, as at entry
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // (another kernel wrote it while this one ran)
+                act_cur ^= 1;
+                unsigned sel[PER];
+#pragma unroll
+                for (int q = 0; q < PER; ++q) {
+                    const int sl = tid * PER + q;
+                    sel[q] = sl < nsl ? (act_cur ? pa.cand_cnt_b[sl] : pa.cand_cnt[sl]) : 0u;
+                }
+                tot_cur = prefix(sel, pa.kept_wcap, s_pref);
+                load_xy();
+                reload_next = false;
+                SIDE_DBG(7);
+            }
         }
         RUN_CLK(13);
     }
