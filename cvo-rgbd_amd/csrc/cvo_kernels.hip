@@ -2965,7 +2965,14 @@ __device__ __forceinline__ void run_body(const Slot *__restrict__ tab, const int
     }
     const int qf = qs & 15, qt = (qs >> 4) & 15;
     const ProcessArgs &pa = CVO_ARG(ProcessArgs, op[qf].p);     // the flow pass of the plan's classic launches
-    const PostStepArgs ps = CVO_ARG(PostStepArgs, op[qf].ps);   // its head
+    // (its head's arguments, read from the table where they are needed: held by value -- ~60 scalar registers for the life of the kernel --
+    // kt_run spilled 7 vector registers and kt_run_acvo 35, to 32 / 80 B of scratch; by reference neither spills any: acvo 3k 1 217 -> 1 247 /s,
+    // 10k 761 -> 798, cvo +0.5 %; -DCVO_RUN_PS_VALUE brings the copy back, profiles/r06_ab.txt 13)
+#ifdef CVO_RUN_PS_VALUE
+    const PostStepArgs ps = CVO_ARG(PostStepArgs, op[qf].ps);
+#else
+    const PostStepArgs &ps = CVO_ARG(PostStepArgs, op[qf].ps);
+#endif
     const ProcessArgs &ta = CVO_ARG(ProcessArgs, op[qt].p);     // its step launch (the trace)
     const ProcessArgs &xa = CVO_ARG(ProcessArgs, op[ACVO ? qf + 1 : qf].p);   // acvo: the self passes of the plan's flow launch (xx, yy)
     const ProcessArgs &ya = CVO_ARG(ProcessArgs, op[ACVO ? qf + 2 : qf].p);
@@ -3387,7 +3394,9 @@ __device__ __forceinline__ void run_body(const Slot *__restrict__ tab, const int
     // whose plan then switches lists is the run's last (its passes stand if the old list still held every pair for it, else they are void,
     // as in a stall slot), and the next kt_run launch -- queued right behind -- enters on the new record.  A run never leaves with a side
     // build in flight (side_finish): the launches behind it would build the same list again.
-    const bool side_can = SIDE && head_block && ps.side_mirror != nullptr && g <= RUN_G_SIDE && ps.st2 != nullptr;
+    // (cvo only: with acvo's self lists planned beside it the soak found 7 of 300 registrations wrong -- the counters of a self list named while
+    // an xy build was in flight --; the option does not pay, so acvo simply does not have it, profiles/r06_ab.txt 12)
+    const bool side_can = SIDE && !ACVO && head_block && ps.side_mirror != nullptr && g <= RUN_G_SIDE && ps.st2 != nullptr;
 #ifdef CVO_SIDE_DEBUG   // (probe builds: what the side builds did, DevState::run_clk through cvo_hip_get_run_clocks)
 #define SIDE_DBG(i) do { if (head_block && tid == 0) gst->run_clk[i] += 1; } while (0)
 #else

@@ -813,10 +813,7 @@ bool plan_lone(const std::vector<RecOp> &ops, Slot &slot, std::vector<TLaunch> &
             4 * self[1].nblk <= PROC_WAVES && q + 3 < 16) {
             pre->push_back(mk_launch(TK_RUN_ACVO, q | ((q + 3) << 4), 1u + (unsigned)std::max(8, std::min((int)RUN_G, o.ps.run_g_max)), 1));   // (no more blocks than the run may use: a block that is not needed still takes a compute unit until it knows)
             pre->push_back(mk_launch(TK_RUN_ACVO, q | ((q + 3) << 4), 1u + RUN_G_SMALL, 1));   // (for narrow records: launch_batch picks one)
-            if (side && o.ps.side_mirror && o.f.st2) {   // (the side build of the run's next xy list: the build's own blocks, the flow pass's)
-                side->push_back(mk_launch(TK_SIDE_FILTER, q, (unsigned)o.n0, 1, smem_of(o.f.jt)));
-                side->push_back(mk_launch(TK_SIDE_RECORD, q, (unsigned)o.np, 1));
-            }
+            o.ps.side_mirror = nullptr;   // (side builds are cvo's alone: see kt_run's side_can)
         }
         q += 3;
         if (six) ns = 0;

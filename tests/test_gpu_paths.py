@@ -1389,7 +1389,7 @@ def test_a_resident_run_that_times_out_costs_its_wait_not_the_frame(pkg):
         c.close()
 
 
-@pytest.mark.parametrize("mode_name,n", [("cvo", 3000), ("acvo", 3000), ("cvo", 6000)])
+@pytest.mark.parametrize("mode_name,n", [("cvo", 3000), ("cvo", 4500), ("cvo", 6000)])
 def test_side_builds_change_nothing(pkg, mode_name, n):
     """Side builds (csrc/cvo_kernels.hip kt_run "side builds", option "side_builds"; built and measured in round 6, off by default): a
     resident run has its next xy list built BESIDE it -- kt_side_filter + kt_side_record on a second stream, asked for by the run's head

@@ -11,6 +11,8 @@ from oracle import pyoracle as po
 
 pkg = ge.load_package()
 capi = pkg.capi
+if os.environ.get("CVO_LIB"):   # (a second build next to the library: tools/build_variant.sh)
+    capi.LIB_PATH = os.path.join(os.path.dirname(capi.LIB_PATH), os.environ["CVO_LIB"])
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 max_pts = int(sys.argv[2]) if len(sys.argv) > 2 else 3000
 rng = np.random.default_rng(int(os.environ.get("SOAK_SEED", "12345")))
