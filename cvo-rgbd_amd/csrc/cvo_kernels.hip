@@ -3458,7 +3458,7 @@ __device__ __forceinline__ void run_body(const Slot *__restrict__ tab, const int
 #pragma unroll
         for (int k = 0; k < NACC_FLOW; ++k) acc[k] = 0.0;
         unsigned nk = 0;
-        static_assert(RUN_R == 8 && RUN_A >= 3 && RUN_A <= 4, "the cases below");
+        static_assert(RUN_R == 8 && RUN_A >= 3 && RUN_A <= 8, "the cases below");
         if constexpr (ACVO) {
             switch (rmax) {   // (wave-uniform; at most RUN_A rounds)
             case 0: break;
