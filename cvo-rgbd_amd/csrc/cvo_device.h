@@ -142,8 +142,14 @@ constexpr int RUN_NV = 13;           // doubles per exchange at most (flow: 9, a
 #endif
 constexpr int RUN_A = CVO_RUN_A;             // acvo runs (kt_run_acvo): candidates per lane of each of the three records (xy, xx, yy), all in registers
 constexpr int RUN_GEN = 4;           // generations of the exchange rows (see above)
+constexpr int RUN_CHAINS = 8;        // chains an exchange's rows are added in (rows c, c + 8, ...; then a tree over the chains): fixed -- it is the order of the sums
 struct RunMail {
     unsigned long long w[RUN_GEN][RUN_G + 1][2 * RUN_NV];   // (row RUN_G: the head block's verdict word)
+    // two-level exchanges of the runs of more than RUN_G_SMALL solvers (cvo_kernels.hip run_exchange_hier): the RUN_CHAINS partial sums of an
+    // exchange -- chain c = rows c, c + RUN_CHAINS, ... added by solver c, the same chains in the same order the one-level exchange adds --,
+    // tagged and generation-numbered like the rows (a leader posts chain sums e + 4 after it has read every row of e + 4, which a block
+    // posts after it has read the chain sums of e + 3; the head block, which only reads, is held by the verdict words as above)
+    unsigned long long p[RUN_GEN][RUN_CHAINS][2 * RUN_NV];
     // entry handshake of a large run: every block of every kt_run launch draws a ticket as its first act (launches of one registration
     // follow each other in one stream, so launch L holds tickets [L NB, (L + 1) NB)); the head block waits until the g + 1 blocks
     // that take part have drawn theirs -- blocks start in index order: they are then resident -- and says GO, or ABORT when that

@@ -216,9 +216,11 @@ struct Engine {
         const bool regeom = zd != zdim;
         zdim = zd;
         const int nblk = nblk_for(zdim);
-        constexpr int merge_max = 2;   // (4 / 8 / 16 measured alike on the round-4 kernels, 32 loses 7 %: profiles/r04_ab.txt 13)
+        int merge_max = 2;   // (4 / 8 / 16 measured alike on the round-4 kernels, 32 loses 7 %: profiles/r04_ab.txt 13)
         std::vector<const std::vector<RecOp> *> po;
         std::vector<Slot *> ps;
+        for (int z = 0; z < ENGINE_SLOTS; ++z)
+            if (member[z]) { merge_max = member[z]->ctx->opt.engine_merge_max; break; }
         for (int z = 0; z < ENGINE_SLOTS; ++z) {
             if (!member[z]) { slot[z].active = 0; continue; }
             cvo_hip_ctx *c = member[z]->ctx;
@@ -545,7 +547,7 @@ int cvo_hip_align_many(cvo_hip_ctx **ctxs, cvo_hip_state **states, int *n_iters,
             // Asynchronous xy builds shorten the launch chain of a registration; once the GPU is
             // shared by many registrations the chain no longer matters and the extra builds cost
             // more than they save: members of large groups keep the synchronous scheme.
-            constexpr int crowd = 2;
+            const int crowd = pending.front()->ctx->opt.engine_crowd;
             std::vector<Engine *> engines;
             for (size_t g = 0; g < ngroups; ++g) {
                 Engine *e = engine_checkout(jobs[i].ctx->device);
@@ -579,7 +581,7 @@ int cvo_hip_align_many(cvo_hip_ctx **ctxs, cvo_hip_state **states, int *n_iters,
                           c->moving.np <= 65536 && (c->prm.mode == CVO_HIP_MODE_CVO || (c->allow_async_self && !c->opt.no_acvo_run)) &&
                           (double)c->fixed.n * (double)c->moving.n <= 2.0e8;
             }
-            int dbg_left = -1;
+            int dbg_left = -1, dbg_narrow = -1;
             for (;;) {
                 bool any = false, moved = false;
                 if (tail_ok && pending.empty() && !engines.front()->wind_down) {
@@ -590,7 +592,7 @@ int cvo_hip_align_many(cvo_hip_ctx **ctxs, cvo_hip_state **states, int *n_iters,
                         for (AlignJob *j : e->member)
                             if (j) { ++left; narrow = narrow && *(volatile int32_t *)j->ctx->progress_mirror >= narrow_from; }
                     }
-                    if (dbg_many && left != dbg_left) { dbg_left = left; fprintf(stderr, "[cvo_hip]   %.2f ms: %d left (narrow %d settled %d)\n", Engine::now_ms() - t_many0, left, (int)narrow, (int)settled); }
+                    if (dbg_many && (left != dbg_left || (int)narrow != dbg_narrow)) { dbg_left = left; dbg_narrow = (int)narrow; fprintf(stderr, "[cvo_hip]   %.2f ms: %d left (narrow %d settled %d)\n", Engine::now_ms() - t_many0, left, (int)narrow, (int)settled); }
                     (void)settled;
                     // (batches of 3 iterations once the tail is near -- what is queued must complete before anybody leaves, 0.4-0.8 ms with two
                     // batches of ten -- were measured: the engines lose more by the short batches than the leavers gain, profiles/r06_ab.txt 10)

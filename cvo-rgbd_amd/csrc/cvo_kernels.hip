@@ -2780,7 +2780,110 @@ __device__ __forceinline__ bool run_exchange_k(RunMail *mail, const int row, con
     if (verdict_out) *verdict_out = *s_verdict;
     return *s_fail == 0;
 }
-template <int NV, class AFTER = RunNoWork>
+// The same exchange in TWO LEVELS, for the runs of more than RUN_G_SMALL solvers (round 6).  With everybody polling everybody's row an
+// exchange among g blocks moves g^2 rows through the memory system -- 249 blocks x 36-51 KB per exchange at 248 solvers, 3.3-3.8 us against 2.2
+// among 32 (tools/microbench/xcd_exchange.hip: 3.3 / 5.5 / 9.7 us among 64 / 128 / 256 blocks).  The one-level exchange adds the rows in
+// RUN_CHAINS chains (rows c, c + 8, ...) and then a tree over the chains; here solver c -- the LEADER of chain c -- alone polls the rows of its
+// chain (workgroups are dealt to the eight XCDs in turn: a chain's blocks share an XCD and its L2), adds them in the same order and posts the
+// chain's sums (RunMail::p), and every block polls the eight chain sums and does the tree: g + 8 x 249 rows instead of 249 g, the same
+// additions in the same order -- the same totals bit for bit.  Two hops instead of one.
+template <int NV, class AFTER>
+__device__ __forceinline__ bool run_exchange_hier(RunMail *mail, const int row, const int g, const unsigned long long seq, const double my_val,
+                                                  double *all /* LDS [RUN_G * NV] */, double *part /* LDS [8 * NV] */, double *tot /* LDS [NV] */,
+                                                  int *s_fail, unsigned *verdict_out, unsigned *s_verdict, const long long timeout_ticks, const AFTER &after_post)
+{
+    static_assert(RUN_CHAINS == 8 && RUN_CHAINS * 2 * NV + 1 <= RUN_BLOCK, "one word per thread at the second level");
+    constexpr int KL = ((RUN_G + RUN_CHAINS - 1) / RUN_CHAINS * 2 * NV + RUN_BLOCK - 1) / RUN_BLOCK;   // words per thread of a leader's sweep
+    const int tid = threadIdx.x;
+    const unsigned tag = (unsigned)seq;
+    const unsigned long long gen = seq & (unsigned long long)(RUN_GEN - 1);
+    unsigned long long *slot = &mail->w[gen][0][0];
+    unsigned long long *pslot = &mail->p[gen][0][0];
+    if (row >= 0 && tid < 2 * NV) {
+        const unsigned long long bits = (unsigned long long)__double_as_longlong(my_val);
+        const unsigned half = (tid & 1) ? (unsigned)(bits >> 32) : (unsigned)bits;
+        __hip_atomic_store(&slot[row * (2 * RUN_NV) + tid], ((unsigned long long)tag << 32) | half, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    after_post();
+    if (row >= 0 && row < RUN_CHAINS) {   // ---- first level: the leader of chain `row` (block-uniform)
+        const int nr = (g - row + RUN_CHAINS - 1) / RUN_CHAINS, nwords = nr * 2 * NV;   // rows row, row + 8, ... of the chain, in the order they are added
+        const long long t0 = (long long)wall_clock64();
+        bool all_in;
+        do {
+            unsigned long long w[KL];
+#pragma unroll
+            for (int k = 0; k < KL; ++k) {
+                const int wi = tid + k * RUN_BLOCK;
+                const int r = wi / (2 * NV), c = wi - r * (2 * NV);
+                w[k] = wi < nwords ? __hip_atomic_load(&slot[(row + r * RUN_CHAINS) * (2 * RUN_NV) + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                   : ((unsigned long long)tag << 32);
+            }
+            all_in = true;
+#pragma unroll
+            for (int k = 0; k < KL; ++k) all_in = all_in && (unsigned)(w[k] >> 32) == tag;
+            if (all_in) {
+#pragma unroll
+                for (int k = 0; k < KL; ++k) {
+                    const int wi = tid + k * RUN_BLOCK;
+                    if (wi < nwords) reinterpret_cast<unsigned *>(all)[wi] = (unsigned)w[k];   // (all[r * NV + k]: row `row + 8 r` of the chain)
+                }
+            } else if ((long long)wall_clock64() - t0 > timeout_ticks) {
+                *s_fail = 1;
+                break;
+            } else {
+                __builtin_amdgcn_s_sleep(1);
+            }
+        } while (!all_in);
+        __syncthreads();
+        if (tid < 2 * NV && *s_fail == 0) {   // (two threads per value: each adds the chain and sends its half of the sum)
+            const int k = tid >> 1;
+            double a = 0.0;
+            for (int r = 0; r < nr; ++r) a += all[r * NV + k];
+            const unsigned long long bits = (unsigned long long)__double_as_longlong(a);
+            const unsigned half = (tid & 1) ? (unsigned)(bits >> 32) : (unsigned)bits;
+            __hip_atomic_store(&pslot[row * (2 * RUN_NV) + tid], ((unsigned long long)tag << 32) | half, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    {   // ---- second level: everybody, the eight chain sums (and the verdict word)
+        const int nrow = RUN_CHAINS * 2 * NV, nwords = nrow + (verdict_out ? 1 : 0);
+        const long long t0 = (long long)wall_clock64();
+        bool all_in;
+        do {
+            const int wi = tid;
+            const int r = wi / (2 * NV), c = wi - r * (2 * NV);
+            const unsigned long long *src = wi == nrow ? &mail->w[(seq >> 1) & 1ull][RUN_G][0] : &pslot[r * (2 * RUN_NV) + c];
+            const unsigned long long w = wi < nwords ? __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ((unsigned long long)tag << 32);
+            all_in = (unsigned)(w >> 32) == tag;
+            if (all_in) {
+                if (wi < nrow) reinterpret_cast<unsigned *>(part)[wi] = (unsigned)w;   // (part[c * NV + k], as the one-level exchange lays it out)
+                else if (wi == nrow && verdict_out) *s_verdict = (unsigned)w;
+            } else if ((long long)wall_clock64() - t0 > timeout_ticks) {
+                *s_fail = 1;
+                break;
+            } else {
+                __builtin_amdgcn_s_sleep(1);
+            }
+        } while (!all_in);
+    }
+    __syncthreads();
+    if (tid < NV)
+        tot[tid] = ((part[tid] + part[NV + tid]) + (part[2 * NV + tid] + part[3 * NV + tid])) +
+                   ((part[4 * NV + tid] + part[5 * NV + tid]) + (part[6 * NV + tid] + part[7 * NV + tid]));
+    __syncthreads();
+    if (verdict_out) *verdict_out = *s_verdict;
+    return *s_fail == 0;
+}
+// solvers from which an exchange runs in two levels: 65 for cvo, 33 for acvo (whose flow exchange carries 13 sums against 9).  One registration at a
+// time, registrations/s at 3k / 6k / 10k / 14k points, never / from 33 / from 65 / from 129 solvers (profiles/r06_ab.txt 15):
+//   cvo  1 281 1 071 1 036 627 / 1 309 1 115 1 082 668 / 1 325 1 122 1 098 670 / 1 304 1 116 1 091 653
+//   acvo 1 249 1 054   799 774 / 1 268 1 076   849 856 / 1 258 1 090   842 845 / 1 268 1 089   808 851
+#ifndef CVO_RUN_HIER_CVO
+#define CVO_RUN_HIER_CVO 65     // (A/B builds: 9999 = never)
+#endif
+#ifndef CVO_RUN_HIER_ACVO
+#define CVO_RUN_HIER_ACVO 33
+#endif
+template <int NV, int HIER_FROM, class AFTER = RunNoWork>
 __device__ __forceinline__ bool run_exchange(RunMail *mail, const int row, const int g, const unsigned long long seq, const double my_val,
                                              double *all, double *part, double *tot, int *s_fail, unsigned *verdict_out, unsigned *s_verdict,
                                              const long long timeout_ticks, const AFTER &after_post = AFTER())
@@ -2788,6 +2891,7 @@ __device__ __forceinline__ bool run_exchange(RunMail *mail, const int row, const
     static_assert(RUN_G_SMALL * 2 * NV + 1 <= 2 * RUN_BLOCK, "two words per thread up to RUN_G_SMALL solvers");
     constexpr int KBIG = (RUN_G * 2 * NV + 1 + RUN_BLOCK - 1) / RUN_BLOCK;
     if (g <= RUN_G_SMALL) return run_exchange_k<NV, 2>(mail, row, g, seq, my_val, all, part, tot, s_fail, verdict_out, s_verdict, timeout_ticks, after_post);
+    if (g >= HIER_FROM) return run_exchange_hier<NV>(mail, row, g, seq, my_val, all, part, tot, s_fail, verdict_out, s_verdict, timeout_ticks, after_post);
     return run_exchange_k<NV, KBIG>(mail, row, g, seq, my_val, all, part, tot, s_fail, verdict_out, s_verdict, timeout_ticks, after_post);
 }
 
@@ -2950,6 +3054,7 @@ __device__ __forceinline__ void run_body(const Slot *__restrict__ tab, const int
 {
     __shared__ unsigned long long s_ticket;
     constexpr int NVF = ACVO ? 13 : NACC_FLOW;   // doubles of the flow-side exchange
+    constexpr int HIER_FROM = ACVO ? CVO_RUN_HIER_ACVO : CVO_RUN_HIER_CVO;   // (run_exchange)
     const bool head_block = blockIdx.x == 0;
     const int srow = (int)blockIdx.x - 1;   // a solver's row in the exchanges (-1: the head block)
     CSlot cs = (CSlot)(tab);
@@ -3529,7 +3634,7 @@ __device__ __forceinline__ void run_body(const Slot *__restrict__ tab, const int
         if (ACVO && xx_fresh && tid == 0) s_xx_ell = s_st.kc_ell;   // (read again behind the barriers of the exchange)
         RUN_CLK(4);
         ++nexch;
-        if (!run_exchange<NVF>(ps.run_mail, srow, g, seq0 + nexch, my_val, s_all, s_part, s_tot, &s_fail, nullptr, &s_verdict, run_timeout)) { comm_ok = false; SIDE_DBG(10); break; }
+        if (!run_exchange<NVF, HIER_FROM>(ps.run_mail, srow, g, seq0 + nexch, my_val, s_all, s_part, s_tot, &s_fail, nullptr, &s_verdict, run_timeout)) { comm_ok = false; SIDE_DBG(10); break; }
         RUN_CLK(5);
         // ---- the tail of compute_flow (ref src/cvo.cpp:201-209): twist, Taylor constants
         if (tid < 64) {
@@ -3600,7 +3705,7 @@ __device__ __forceinline__ void run_body(const Slot *__restrict__ tab, const int
                 if (lane == 0) s_pre = P;
             }
         };
-        if (!run_exchange<NACC_STEP>(ps.run_mail, srow, g, seq0 + nexch, my_step, s_all, s_part, s_tot, &s_fail, &verdict, &s_verdict, run_timeout, pre_work)) { comm_ok = false; SIDE_DBG(11); break; }
+        if (!run_exchange<NACC_STEP, HIER_FROM>(ps.run_mail, srow, g, seq0 + nexch, my_step, s_all, s_part, s_tot, &s_fail, &verdict, &s_verdict, run_timeout, pre_work)) { comm_ok = false; SIDE_DBG(11); break; }
         RUN_CLK(9);
         if (verdict & RUN_V_STALL) {
             // no buffer holds every pair for this slot's transform (a jump): what the passes have summed is void.  The head goes
