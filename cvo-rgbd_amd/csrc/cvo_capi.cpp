@@ -52,6 +52,7 @@ const OptDef kOptions[] = {
     {"comm_debug", "CVO_HIP_COMM_DEBUG", 1, 1.0},         {"wait_policy", "CVO_HIP_WAIT_POLICY", 2, 0.0},
     {"acvo_runs", "CVO_HIP_NO_ACVO_RUN", 1, 0.0},         {"tail_alone", "CVO_HIP_TAIL_ALONE", 2, 0.0},         {"side_builds", "CVO_HIP_SIDE", 1, 1.0},
     {"run_build_at", "CVO_HIP_RUN_BUILD_AT", 2, 0.0},         {"alone_max", "CVO_HIP_ALONE_MAX", 2, 0.0},
+    {"narrow_merge", "CVO_HIP_NARROW_MERGE", 1, 1.0},     {"narrow_blocks", "CVO_HIP_NARROW_BLOCKS", 2, 0.0},
     {"engine_crowd", "CVO_HIP_ENGINE_CROWD", 2, 0.0},     {"engine_merge_max", "CVO_HIP_ENGINE_MERGE_MAX", 2, 0.0},
 };
 void env_defaults(cvo_hip_ctx *ctx)
@@ -114,6 +115,8 @@ int apply_option(cvo_hip_ctx *ctx, const char *key, double v)
     else if (is("side_builds")) o.no_side_builds = !on;
     else if (is("run_build_at")) { if (!(v > 0.0 && v <= 1.0)) return CVO_HIP_ERR_INVALID; o.run_build_at = (float)v; }
     else if (is("alone_max")) { if (v < 0.0 || v > 64.0) return CVO_HIP_ERR_INVALID; o.alone_max = (int)v; }
+    else if (is("narrow_merge")) o.narrow_merge = on;
+    else if (is("narrow_blocks")) { const int b = (int)v; if (b != 0 && b != 32 && b != 64) return CVO_HIP_ERR_INVALID; o.narrow_blocks = b; }
     else if (is("engine_crowd")) { if (v < 0.0) return CVO_HIP_ERR_INVALID; o.engine_crowd = (int)std::min(v, 1.0e6); }
     else if (is("engine_merge_max")) { if (v < 0.0 || v > 32.0) return CVO_HIP_ERR_INVALID; o.engine_merge_max = (int)v; }
     else return CVO_HIP_ERR_INVALID;
@@ -874,6 +877,8 @@ int cvo_hip_get_option(const cvo_hip_ctx *ctx, const char *key, double *value)
     else if (is("small_calls_alone")) *value = !o.no_alone;
     else if (is("fused_groups")) *value = !o.no_fuse;
     else if (is("engines")) *value = o.engines_force;
+    else if (is("narrow_merge")) *value = o.narrow_merge;
+    else if (is("narrow_blocks")) *value = o.narrow_blocks;
     else if (is("engine_crowd")) *value = o.engine_crowd;
     else if (is("engine_merge_max")) *value = o.engine_merge_max;
     else if (is("list_init")) *value = o.list_init;

@@ -95,6 +95,9 @@ struct Engine {
     int zdim = 0;
     bool crowded = true, use_graph = true, dirty = true, failed = false;
     int batch_len = kEngineBatch;          // iterations per batch (shorter when the call's tail is near: what is queued must complete before anybody leaves)
+    bool narrow = false;                   // every registration of the call is past its wide iterations (align_many): replan goes by the narrow-phase options
+    bool narrow_merge = false;             // ... the step launch carries the twist whatever zdim
+    int narrow_blocks = 0;                 // ... blocks of a list pass per registration (0: by zdim as ever)
     bool wind_down = false;                // the call's tail: no further batches; the members that are left go on alone (release_members)
     std::vector<TLaunch> plan;
     struct FlowEv { hipEvent_t a, b; int live; };
@@ -215,7 +218,7 @@ struct Engine {
         }
         const bool regeom = zd != zdim;
         zdim = zd;
-        const int nblk = nblk_for(zdim);
+        const int nblk = (narrow && narrow_blocks > 0) ? std::min(narrow_blocks, nblk_for(zdim)) : nblk_for(zdim);
         int merge_max = 2;   // (4 / 8 / 16 measured alike on the round-4 kernels, 32 loses 7 %: profiles/r04_ab.txt 13)
         std::vector<const std::vector<RecOp> *> po;
         std::vector<Slot *> ps;
@@ -229,7 +232,7 @@ struct Engine {
                 // k_step_twist pays for the saved launch with a prologue in every block:
                 // a gain while launches are latency-bound, a loss once the GPU is full
                 const bool allow = c->allow_merge;
-                if (zdim > merge_max) c->allow_merge = false;
+                if (zdim > merge_max && !(narrow && narrow_merge)) c->allow_merge = false;
                 const int rc = record_iteration(c, ops[z], 0);
                 c->allow_merge = allow;
                 if (rc) return rc;
@@ -556,6 +559,9 @@ int cvo_hip_align_many(cvo_hip_ctx **ctxs, cvo_hip_state **states, int *n_iters,
                 e->use_graph = graphs_ok;
                 e->zdim = 0;
                 e->wind_down = false;
+                e->narrow = false;
+                e->narrow_merge = pending.front()->ctx->opt.narrow_merge;
+                e->narrow_blocks = pending.front()->ctx->opt.narrow_blocks;
                 e->batch_len = kEngineBatch;
                 e->t_idle_at = 0;
                 e->dirty = true;
@@ -581,10 +587,11 @@ int cvo_hip_align_many(cvo_hip_ctx **ctxs, cvo_hip_state **states, int *n_iters,
                           c->moving.np <= 65536 && (c->prm.mode == CVO_HIP_MODE_CVO || (c->allow_async_self && !c->opt.no_acvo_run)) &&
                           (double)c->fixed.n * (double)c->moving.n <= 2.0e8;
             }
+            const bool narrow_merge_ok = !pending.empty() && (pending.front()->ctx->opt.narrow_merge || pending.front()->ctx->opt.narrow_blocks > 0) && !engine_profile()->on;
             int dbg_left = -1, dbg_narrow = -1;
             for (;;) {
                 bool any = false, moved = false;
-                if (tail_ok && pending.empty() && !engines.front()->wind_down) {
+                if ((tail_ok || narrow_merge_ok) && pending.empty() && !engines.front()->wind_down) {
                     int left = 0;
                     bool narrow = true, settled = true;
                     for (Engine *e : engines) {
@@ -592,11 +599,19 @@ int cvo_hip_align_many(cvo_hip_ctx **ctxs, cvo_hip_state **states, int *n_iters,
                         for (AlignJob *j : e->member)
                             if (j) { ++left; narrow = narrow && *(volatile int32_t *)j->ctx->progress_mirror >= narrow_from; }
                     }
+                    // THE NARROW PHASE: a launch saved per iteration (the twist in front of the step pass, no post-flow launch) is a loss while the
+                    // engines' launches fill the GPU and a gain once every registration of the call is past its wide iterations
+                    if (narrow_merge_ok && narrow && left > 0 && !engines.front()->narrow)
+                        for (Engine *e : engines) {
+                            e->narrow = true;
+                            e->dirty = true;
+                            for (int z = 0; z < ENGINE_SLOTS; ++z) e->ops[z].clear();   // (recorded again by the next replan)
+                        }
                     if (dbg_many && (left != dbg_left || (int)narrow != dbg_narrow)) { dbg_left = left; dbg_narrow = (int)narrow; fprintf(stderr, "[cvo_hip]   %.2f ms: %d left (narrow %d settled %d)\n", Engine::now_ms() - t_many0, left, (int)narrow, (int)settled); }
                     (void)settled;
                     // (batches of 3 iterations once the tail is near -- what is queued must complete before anybody leaves, 0.4-0.8 ms with two
                     // batches of ten -- were measured: the engines lose more by the short batches than the leavers gain, profiles/r06_ab.txt 10)
-                    if (left > 0 && left <= tail_k && narrow) {
+                    if (tail_ok && left > 0 && left <= tail_k && narrow) {
                         for (Engine *e : engines) e->wind_down = true;
                         if (dbg_many) {
                             fprintf(stderr, "[cvo_hip]   tail: %d registrations left after %.2f ms, slots done:", left, Engine::now_ms() - t_many0);
@@ -631,7 +646,7 @@ int cvo_hip_align_many(cvo_hip_ctx **ctxs, cvo_hip_state **states, int *n_iters,
                     for (Engine *e : engines)
                         if (!e->idle() && !e->failed) { e->wait_oldest(pending); break; }
             }
-            for (Engine *e : engines) { e->wind_down = false; e->batch_len = kEngineBatch; engine_release(e); }
+            for (Engine *e : engines) { e->wind_down = false; e->narrow = false; e->batch_len = kEngineBatch; engine_release(e); }
         }
         for (int i = 0; i < count; ++i)
             if (jobs[i].phase == 2 && jobs[i].rc && !first_err) first_err = jobs[i].rc;

@@ -250,6 +250,8 @@ struct CtxOptions {
                                       // engines, all past their wide iterations, they leave the engines for resident runs of their own (0: never)
     int alone_max = 0;                // "alone_max": a call of up to this many registrations leaves them to their own streams (0: by the clouds)
     int engines_force = 0;            // "engines": engines of an align_many call (0: by the call's size)
+    int narrow_blocks = 0;            // "narrow_blocks": ... and give every registration this many blocks per list pass (0: by the engine's slots as ever)
+    bool narrow_merge = false;        // "narrow_merge": once every registration of a cvo_hip_align_many call is past its wide iterations its engines launch the step pass with the twist in front
     int engine_crowd = 2;             // "engine_crowd" (tuning probe): a call of more registrations than this keeps the synchronous list scheme in its engines
     int engine_merge_max = 2;         // "engine_merge_max" (tuning probe): engines of up to this many slots launch the step pass with the twist in front
     double list_init = 0.0;           // "list_init": first capacity of every list (0: by the clouds)
