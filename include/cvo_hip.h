@@ -325,7 +325,8 @@ int cvo_hip_set_graph_capture(cvo_hip_ctx *ctx, int enable);
  *                        goes without runs for its next 64 registrations ("run_timeouts" counts them, read-only)
  * and the test switches of tests/ ("head_mode", "merged_launches", "async_builds", "candidate_records", "kept_pack",
  * "list_init", "list_margin", "final_mirror", "one_launch_hand_over", "small_calls_alone", "fused_groups", "engines",
- * "run_candidates_max", "run_fault", "sync_upload", "no_graph", "twist_on_shared_gpu", "comm_debug", "engine_debug").
+ * "run_candidates_max", "run_fault", "sync_upload", "no_graph", "twist_on_shared_gpu", "comm_debug", "engine_debug"; the
+ * measured probes "engine_crowd", "engine_merge_max", "narrow_merge", "narrow_blocks", all off: profiles/r06_ab.txt 16).
  * The environment variables of the same switches only set the DEFAULTS, read once when a context is
  * created.  A call that serves many contexts goes by its first context's switches.  Unknown key / bad value:
  * CVO_HIP_ERR_INVALID. */
