@@ -2713,6 +2713,61 @@ constexpr long long RUN_ENTRY_TICKS = 20000LL;         // 200 us: how long the h
 // head block's verdict word of this exchange is waited for as well and handed out.  Returns false on a time-out (block-uniform).
 // after_post(): called by every thread once the block's sums are on their way -- work that hides behind the exchange's latency.
 struct RunNoWork { __device__ __forceinline__ void operator()() const {} };
+// Polling K tagged words per thread: sweeps of all K words until every tag matches.  A sweep that comes back incomplete costs a whole round
+// trip to the L2 / the memory side before the next look (0.4-0.55 us, tools/micro/pingpong.hip).  TWO sweeps in flight -- the second issued half
+// a round trip behind the first, each re-issued as soon as it has been looked at, taking turns without a register move (a move would wait for
+// the load it moves) -- look twice as often and were measured SLOWER (-DCVO_RUN_POLL_GAP=8 against 0: cvo 3k 1 298 against 1 325, 6k 1 116 / 1 138,
+// 10k 1 092 / 1 105, acvo 3k 1 232 / 1 272): the polls of 249 blocks are themselves the traffic the rows travel in.  Naps between sweeps of 0 / 1 / 4 / 12
+// units (-DCVO_RUN_POLL_SLEEP): alike up to 4, -2...-4 % at 12 (profiles/r06_ab.txt 17).
+// src(k): address of this thread's k-th word, nullptr for none.  Returns false on a time-out (this thread's; *s_fail is set).
+#ifndef CVO_RUN_POLL_GAP
+#define CVO_RUN_POLL_GAP 0   // s_sleep units (64 clocks) between the first two sweeps; 0 = one sweep in flight
+#endif
+#ifndef CVO_RUN_POLL_SLEEP
+#define CVO_RUN_POLL_SLEEP 1 // s_sleep units between two sweeps of one thread (one sweep in flight)
+#endif
+template <int K, class SRC>
+__device__ __forceinline__ bool run_poll(const SRC &src, const unsigned tag, const long long timeout_ticks, unsigned long long (&w)[K], int *s_fail)
+{
+    const unsigned long long none = (unsigned long long)tag << 32;
+    auto sweep = [&](unsigned long long (&v)[K]) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const unsigned long long *p = src(k);
+            v[k] = p ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : none;
+        }
+    };
+    auto in = [&](const unsigned long long (&v)[K]) {
+        bool ok = true;
+#pragma unroll
+        for (int k = 0; k < K; ++k) ok = ok && (unsigned)(v[k] >> 32) == tag;
+        return ok;
+    };
+    const long long t0 = (long long)wall_clock64();
+    if (CVO_RUN_POLL_GAP == 0) {
+        for (;;) {
+            sweep(w);
+            if (in(w)) return true;
+            if ((long long)wall_clock64() - t0 > timeout_ticks) { *s_fail = 1; return false; }
+            __builtin_amdgcn_s_sleep(CVO_RUN_POLL_SLEEP);
+        }
+    }
+    unsigned long long b[K];
+    sweep(w);
+    __builtin_amdgcn_s_sleep(CVO_RUN_POLL_GAP);
+    sweep(b);
+    for (;;) {
+        if (in(w)) return true;
+        if ((long long)wall_clock64() - t0 > timeout_ticks) { *s_fail = 1; return false; }
+        sweep(w);
+        if (in(b)) {
+#pragma unroll
+            for (int k = 0; k < K; ++k) w[k] = b[k];
+            return true;
+        }
+        sweep(b);
+    }
+}
 template <int NV, int KMAX, class AFTER>
 __device__ __forceinline__ bool run_exchange_k(RunMail *mail, const int row, const int g, const unsigned long long seq, const double my_val,
                                              double *all /* LDS [RUN_G * NV] */, double *part /* LDS [8 * NV] */, double *tot /* LDS [NV] */,
@@ -2732,6 +2787,23 @@ __device__ __forceinline__ bool run_exchange_k(RunMail *mail, const int row, con
     // thread t polls words t, t + 512, ...: ALL of a sweep requested before any is looked at (KMAX per thread: 2 up to 32 solvers,
     // 9 at 248)
     const int nrow = g * 2 * NV, nwords = nrow + (verdict_out ? 1 : 0);
+    if constexpr (KMAX <= 2) {   // (the runs of up to RUN_G_SMALL solvers: two sweeps in flight, run_poll)
+        unsigned long long w[KMAX];
+        auto src = [&](const int k) -> const unsigned long long * {
+            const int wi = tid + k * RUN_BLOCK;
+            if (wi >= nwords) return nullptr;
+            const int r = wi / (2 * NV), c = wi - r * (2 * NV);
+            return wi == nrow ? &mail->w[(seq >> 1) & 1ull][RUN_G][0] : &slot[r * (2 * RUN_NV) + c];
+        };
+        if (run_poll<KMAX>(src, tag, timeout_ticks, w, s_fail)) {
+#pragma unroll
+            for (int k = 0; k < KMAX; ++k) {
+                const int wi = tid + k * RUN_BLOCK;
+                if (wi < nrow) reinterpret_cast<unsigned *>(all)[wi] = (unsigned)w[k];
+                else if (wi == nrow && verdict_out) *s_verdict = (unsigned)w[k];
+            }
+        }
+    } else
     {
         const long long t0 = (long long)wall_clock64();
         bool all_in;
@@ -2807,33 +2879,20 @@ __device__ __forceinline__ bool run_exchange_hier(RunMail *mail, const int row, 
     after_post();
     if (row >= 0 && row < RUN_CHAINS) {   // ---- first level: the leader of chain `row` (block-uniform)
         const int nr = (g - row + RUN_CHAINS - 1) / RUN_CHAINS, nwords = nr * 2 * NV;   // rows row, row + 8, ... of the chain, in the order they are added
-        const long long t0 = (long long)wall_clock64();
-        bool all_in;
-        do {
-            unsigned long long w[KL];
+        unsigned long long w[KL];
+        auto src = [&](const int k) -> const unsigned long long * {
+            const int wi = tid + k * RUN_BLOCK;
+            if (wi >= nwords) return nullptr;
+            const int r = wi / (2 * NV), c = wi - r * (2 * NV);
+            return &slot[(row + r * RUN_CHAINS) * (2 * RUN_NV) + c];
+        };
+        if (run_poll<KL>(src, tag, timeout_ticks, w, s_fail)) {
 #pragma unroll
             for (int k = 0; k < KL; ++k) {
                 const int wi = tid + k * RUN_BLOCK;
-                const int r = wi / (2 * NV), c = wi - r * (2 * NV);
-                w[k] = wi < nwords ? __hip_atomic_load(&slot[(row + r * RUN_CHAINS) * (2 * RUN_NV) + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-                                   : ((unsigned long long)tag << 32);
+                if (wi < nwords) reinterpret_cast<unsigned *>(all)[wi] = (unsigned)w[k];   // (all[r * NV + k]: row `row + 8 r` of the chain)
             }
-            all_in = true;
-#pragma unroll
-            for (int k = 0; k < KL; ++k) all_in = all_in && (unsigned)(w[k] >> 32) == tag;
-            if (all_in) {
-#pragma unroll
-                for (int k = 0; k < KL; ++k) {
-                    const int wi = tid + k * RUN_BLOCK;
-                    if (wi < nwords) reinterpret_cast<unsigned *>(all)[wi] = (unsigned)w[k];   // (all[r * NV + k]: row `row + 8 r` of the chain)
-                }
-            } else if ((long long)wall_clock64() - t0 > timeout_ticks) {
-                *s_fail = 1;
-                break;
-            } else {
-                __builtin_amdgcn_s_sleep(1);
-            }
-        } while (!all_in);
+        }
         __syncthreads();
         if (tid < 2 * NV && *s_fail == 0) {   // (two threads per value: each adds the chain and sends its half of the sum)
             const int k = tid >> 1;
@@ -2846,24 +2905,16 @@ __device__ __forceinline__ bool run_exchange_hier(RunMail *mail, const int row, 
     }
     {   // ---- second level: everybody, the eight chain sums (and the verdict word)
         const int nrow = RUN_CHAINS * 2 * NV, nwords = nrow + (verdict_out ? 1 : 0);
-        const long long t0 = (long long)wall_clock64();
-        bool all_in;
-        do {
-            const int wi = tid;
-            const int r = wi / (2 * NV), c = wi - r * (2 * NV);
-            const unsigned long long *src = wi == nrow ? &mail->w[(seq >> 1) & 1ull][RUN_G][0] : &pslot[r * (2 * RUN_NV) + c];
-            const unsigned long long w = wi < nwords ? __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ((unsigned long long)tag << 32);
-            all_in = (unsigned)(w >> 32) == tag;
-            if (all_in) {
-                if (wi < nrow) reinterpret_cast<unsigned *>(part)[wi] = (unsigned)w;   // (part[c * NV + k], as the one-level exchange lays it out)
-                else if (wi == nrow && verdict_out) *s_verdict = (unsigned)w;
-            } else if ((long long)wall_clock64() - t0 > timeout_ticks) {
-                *s_fail = 1;
-                break;
-            } else {
-                __builtin_amdgcn_s_sleep(1);
-            }
-        } while (!all_in);
+        unsigned long long w[1];
+        auto src = [&](const int) -> const unsigned long long * {
+            if (tid >= nwords) return nullptr;
+            const int r = tid / (2 * NV), c = tid - r * (2 * NV);
+            return tid == nrow ? &mail->w[(seq >> 1) & 1ull][RUN_G][0] : &pslot[r * (2 * RUN_NV) + c];
+        };
+        if (run_poll<1>(src, tag, timeout_ticks, w, s_fail)) {
+            if (tid < nrow) reinterpret_cast<unsigned *>(part)[tid] = (unsigned)w[0];   // (part[c * NV + k], as the one-level exchange lays it out)
+            else if (tid == nrow && verdict_out) *s_verdict = (unsigned)w[0];
+        }
     }
     __syncthreads();
     if (tid < NV)
