@@ -3344,10 +3344,18 @@ __device__ __forceinline__ void run_body(const Slot *__restrict__ tab, const int
 #ifndef CVO_ACVO_PER_LANE
 #define CVO_ACVO_PER_LANE 3u   // (2 / 3 / 4: 10k 740 / 756 / 755 registrations/s, 6k 981 / 982 / 953, 3k alike: profiles/r06_ab.txt 3)
 #endif
+#ifndef CVO_RUN_PER_LANE_HI
+#define CVO_RUN_PER_LANE_HI_CVO 3u
+#define CVO_RUN_PER_LANE_HI_ACVO 1u   // (above 32 solvers an exchange runs in two levels and hardly grows with the blocks: acvo 6k 1 083-1 086 -> 1 096-1 102 /s, seed 1001
+                                      // 978-992 -> 1 003-1 010, the other sizes alike; cvo, whose 33-64 solvers exchange in one level, keeps 3: profiles/r06_ab.txt 19)
+#else
+#define CVO_RUN_PER_LANE_HI_CVO CVO_RUN_PER_LANE_HI
+#define CVO_RUN_PER_LANE_HI_ACVO CVO_RUN_PER_LANE_HI
+#endif
     const int gwant = ACVO ? (total_max <= 8u * per ? 8 : (total_max <= 16u * per ? 16 : (total_max <= CVO_ACVO_PER_LANE * 32u * per ? 32 :
-                              (total_max <= CVO_ACVO_PER_LANE * 64u * per ? 64 : (total_max <= CVO_ACVO_PER_LANE * 128u * per ? 128 : RUN_G)))))
+                              (total_max <= CVO_RUN_PER_LANE_HI_ACVO * 64u * per ? 64 : (total_max <= CVO_RUN_PER_LANE_HI_ACVO * 128u * per ? 128 : RUN_G)))))
                            : (total <= 8u * per ? 8 : (total <= 16u * per ? 16 : (total <= 3u * 32u * per ? 32 :
-                              (total <= 3u * 64u * per ? 64 : (total <= 3u * 128u * per ? 128 : RUN_G)))));
+                              (total <= CVO_RUN_PER_LANE_HI_CVO * 64u * per ? 64 : (total <= CVO_RUN_PER_LANE_HI_CVO * 128u * per ? 128 : RUN_G)))));
     const int g = gwant < gmax ? gwant : gmax;
     if (total_max > (unsigned)g * per * (unsigned)(ACVO ? RUN_A : RUN_R + RUN_L)) { run_over(); return; }   // (block-uniform; nothing has been written)
     if (srow >= g) return;
