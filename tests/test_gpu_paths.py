@@ -1230,6 +1230,40 @@ def test_runs_sized_for_a_smaller_device_change_nothing(pkg, monkeypatch):
     monkeypatch.delenv("CVO_HIP_RUN_G_MAX")
 
 
+@pytest.mark.parametrize("mode_name", ["cvo", "acvo"])
+def test_exchanges_in_two_levels_change_nothing(pkg, mode_name):
+    """csrc/cvo_kernels.hip run_exchange_hier (round 6): above 64 solvers (cvo; 32 for acvo) the blocks of a resident run exchange their
+    partial sums in two levels -- the leader of each of the eight chains adds its chain's rows, everybody polls the eight chain sums -- with
+    the additions of the one-level exchange in the same order.  A 10k x 10k registration (runs of 128-248 solvers: two levels) against the
+    same with its runs held to 64 solvers (cvo; one level: "run_solvers_max") and against no runs at all: same iterations, same state, same
+    float32 trace (ref src/cvo.cpp:366-410, src/adaptive_cvo.cpp:490-555: how the sums are gathered is never visible in the result)."""
+    capi = pkg.capi
+    acvo = mode_name == "acvo"
+    mode = capi.MODE_ACVO if acvo else capi.MODE_CVO
+    xf, ff, xm, fm = pkg.data.synthetic_pair(10000, 10000, seed=6700, acvo=acvo)
+    res = {}
+    # (acvo: the 32 solvers of its one-level exchanges do not hold a 10k pair's records -- 0.8 x 32 x 512 x 4 candidates: no third variant)
+    variants = (("two levels", {}), ("no runs", {"resident_runs": 0})) if acvo else \
+               (("two levels", {}), ("one level", {"run_solvers_max": 64}), ("no runs", {"resident_runs": 0}))
+    for name, opts in variants:
+        c = capi.Context(mode=mode, device=0)
+        for k, v in opts.items():
+            c.set_option(k, v)
+        c.set_fixed(xf, ff); c.set_moving(xm, fm)
+        st = capi.init_state(c.params)
+        it, tr = c.align(st, trace_cap=2000)
+        rs = c.run_stats()
+        assert c.get_option("run_timeouts") == 0.0
+        if name != "no runs":
+            assert rs[0] >= 1 and rs[2] >= 10, (name, rs)   # (runs were entered and carried iterations)
+        res[name] = (it, bytes(st), [(t["k"], t["exit_code"], t["nnz"], t["nnz_xx"], t["nnz_yy"], t["ell"], t["step"], tuple(t["omega"]),
+                                      tuple(t["v"])) for t in tr])
+        c.close()
+    assert res["two levels"] == res["no runs"]
+    if not acvo:
+        assert res["two levels"] == res["one level"]
+
+
 def test_runs_of_many_registrations_share_the_gpu_without_deadlock(pkg):
     """A block of a resident run takes a whole compute unit and spins for its peers: runs of several registrations (host threads
     here; processes and the registrations of a small cvo_hip_align_many call likewise) whose blocks together outnumber the
