@@ -885,6 +885,37 @@ __device__ __forceinline__ void pair_flow_sums(const KernConsts &kc, const float
     // (acc[8], the number of members: counted per wave by the caller, not per pair here)
 }
 
+// the float64 part of a member's step terms (ref src/cvo.cpp:275-280), shared by the one-member and the two-member forms below
+__device__ __forceinline__ void step_tail(const float w, const float beta, const float gamma, const float delta, const float epsil, double *acc)
+{
+    const double A = (double)w;
+    const double b = (double)beta, g = (double)gamma;
+    acc[0] += (double)(w * beta);
+#ifdef CVO_STEP_TAIL_LITERAL
+    // the source line's operations one by one (ref cvo.cpp:275-280 under C's promotion rules): 33 float64-rate
+    // instructions per member; kept for A/B builds (profiles/r04_ab.txt 11)
+    acc[1] += A * (g + (double)(beta * beta) / 2.0);
+    acc[2] += A * ((double)(delta + beta * gamma) + div6((double)(beta * beta * beta)));
+    acc[3] += A * ((((double)(epsil + beta * delta) + 0.5 * b * b * g) + 0.5 * g * g) +
+                   1 / 24.0 * b * b * b * b);
+#else
+    // The float64 part of the terms with fused operations: every float32 product of the source line is formed
+    // and promoted as written (beta*beta, beta*beta*beta, delta + beta*gamma, epsil + beta*delta); what is
+    // fused are float64 operations whose separate roundings the reference's own sum order already outweighs
+    // (a term moves by <= 3 ulp(float64), the sum of ~10^5..10^6 of them is order-dependent at 10^-13).
+    // 20 float64-rate instructions per member instead of 33: the step pass is issue-bound while the kernel is
+    // wide (profiles/r04_ab.txt 8, 11).
+    acc[1] = __builtin_fma(A, __builtin_fma((double)(beta * beta), 0.5, g), acc[1]);
+    acc[2] = __builtin_fma(A, __builtin_fma((double)(beta * beta * beta), 0x1.5555555555555p-3,
+                                            (double)(delta + beta * gamma)), acc[2]);
+    const double b2 = b * b, hg = 0.5 * g;
+    double t = __builtin_fma(b2, hg, (double)(epsil + beta * delta));
+    t = __builtin_fma(hg, g, t);
+    t = __builtin_fma(b2 * (1 / 24.0), b2, t);
+    acc[3] = __builtin_fma(A, t, acc[3]);
+#endif
+}
+
 // compute_step_size (ref src/cvo.cpp:226-238,256-280): (e0, e1, e2) = x_i - y_j
 __device__ __forceinline__ void pair_step_sums(const KernConsts &kc, const cvo_math::XiConsts &xc, const float4 yj, const float e0,
                                            const float e1, const float e2, const float w, double *acc)
@@ -913,32 +944,43 @@ __device__ __forceinline__ void pair_step_sums(const KernConsts &kc, const cvo_m
     const float delta = cd * (xz12 + d_dot);
     const float e_dot = ((2.0f * xi4z[0]) * e0 + (2.0f * xi4z[1]) * e1) + (2.0f * xi4z[2]) * e2;
     const float epsil = cg * (eps_c + e_dot);
-    const double A = (double)w;
-    const double b = (double)beta, g = (double)gamma;
-    acc[0] += (double)(w * beta);
-#ifdef CVO_STEP_TAIL_LITERAL
-    // the source line's operations one by one (ref cvo.cpp:275-280 under C's promotion rules): 33 float64-rate
-    // instructions per member; kept for A/B builds (profiles/r04_ab.txt 11)
-    acc[1] += A * (g + (double)(beta * beta) / 2.0);
-    acc[2] += A * ((double)(delta + beta * gamma) + div6((double)(beta * beta * beta)));
-    acc[3] += A * ((((double)(epsil + beta * delta) + 0.5 * b * b * g) + 0.5 * g * g) +
-                   1 / 24.0 * b * b * b * b);
-#else
-    // The float64 part of the terms with fused operations: every float32 product of the source line is formed
-    // and promoted as written (beta*beta, beta*beta*beta, delta + beta*gamma, epsil + beta*delta); what is
-    // fused are float64 operations whose separate roundings the reference's own sum order already outweighs
-    // (a term moves by <= 3 ulp(float64), the sum of ~10^5..10^6 of them is order-dependent at 10^-13).
-    // 20 float64-rate instructions per member instead of 33: the step pass is issue-bound while the kernel is
-    // wide (profiles/r04_ab.txt 8, 11).
-    acc[1] = __builtin_fma(A, __builtin_fma((double)(beta * beta), 0.5, g), acc[1]);
-    acc[2] = __builtin_fma(A, __builtin_fma((double)(beta * beta * beta), 0x1.5555555555555p-3,
-                                            (double)(delta + beta * gamma)), acc[2]);
-    const double b2 = b * b, hg = 0.5 * g;
-    double t = __builtin_fma(b2, hg, (double)(epsil + beta * delta));
-    t = __builtin_fma(hg, g, t);
-    t = __builtin_fma(b2 * (1 / 24.0), b2, t);
-    acc[3] = __builtin_fma(A, t, acc[3]);
-#endif
+    step_tail(w, beta, gamma, delta, epsil, acc);
+}
+
+// The same for TWO members at once (round 6; A/B builds with -DCVO_STEP_TWO, measured and not adopted: profiles/r06_ab.txt 22): the float32 part --
+// ~130 of a member's ~180 instructions -- on pairs of floats, which gfx950 executes as packed instructions (v_pk_mul_f32 / v_pk_add_f32: two IEEE
+// operations per lane and issue slot, each rounded as the single one is; the constants come from scalar registers, broadcast by the
+// instruction).  Every expression is pair_step_sums' own, operation for operation; the float64 tails follow one after the other, member 0
+// first: a lane that takes its members two at a time adds exactly what it added one at a time, in the same order.  A member with w = 0 (a
+// lane's odd last one) adds exact zeros.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void pair_step_sums2(const KernConsts &kc, const cvo_math::XiConsts &xc, const f32x2 yx, const f32x2 yy, const f32x2 yz,
+                                                const f32x2 e0, const f32x2 e1, const f32x2 e2, const f32x2 w, double *acc)
+{
+    f32x2 xiz[3], xi2z[3], xi3z[3], xi4z[3];
+    xiz[0] = (xc.omega[1] * yz - xc.omega[2] * yy) + xc.v[0];
+    xiz[1] = (xc.omega[2] * yx - xc.omega[0] * yz) + xc.v[1];
+    xiz[2] = (xc.omega[0] * yy - xc.omega[1] * yx) + xc.v[2];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        xi2z[r] = ((xc.W2[3 * r] * yx + xc.W2[3 * r + 1] * yy) + xc.W2[3 * r + 2] * yz) + xc.u2[r];
+        xi3z[r] = ((xc.W3[3 * r] * yx + xc.W3[3 * r + 1] * yy) + xc.W3[3 * r + 2] * yz) + xc.u3[r];
+        xi4z[r] = ((xc.W4[3 * r] * yx + xc.W4[3 * r + 1] * yy) + xc.W4[3 * r + 2] * yz) + xc.u4[r];
+    }
+    const f32x2 normxiz2 = (xiz[0] * xiz[0] + xiz[1] * xiz[1]) + xiz[2] * xiz[2];
+    const f32x2 xz12 = -((xiz[0] * xi2z[0] + xiz[1] * xi2z[1]) + xiz[2] * xi2z[2]);
+    const f32x2 eps_c = ((xi2z[0] * xi2z[0] + xi2z[1] * xi2z[1]) + xi2z[2] * xi2z[2]) +
+                        2.0f * ((xiz[0] * xi3z[0] + xiz[1] * xi3z[1]) + xiz[2] * xi3z[2]);
+    const float cb = kc.cb, cg = kc.cg, cd = kc.cd;
+    const f32x2 beta = ((cb * xiz[0]) * e0 + (cb * xiz[1]) * e1) + (cb * xiz[2]) * e2;
+    const f32x2 g_dot = ((2.0f * xi2z[0]) * e0 + (2.0f * xi2z[1]) * e1) + (2.0f * xi2z[2]) * e2;
+    const f32x2 gamma = cg * (normxiz2 + g_dot);
+    const f32x2 d_dot = ((-xi3z[0]) * e0 + (-xi3z[1]) * e1) + (-xi3z[2]) * e2;
+    const f32x2 delta = cd * (xz12 + d_dot);
+    const f32x2 e_dot = ((2.0f * xi4z[0]) * e0 + (2.0f * xi4z[1]) * e1) + (2.0f * xi4z[2]) * e2;
+    const f32x2 epsil = cg * (eps_c + e_dot);
+    step_tail(w.x, beta.x, gamma.x, delta.x, epsil.x, acc);
+    step_tail(w.y, beta.y, gamma.y, delta.y, epsil.y, acc);
 }
 
 template <int MODE, int WEIGHT = 0, int CK = 0, class ARGS = ProcessArgs>
@@ -1003,6 +1045,49 @@ __device__ __forceinline__ float eval_pair(const ARGS &a, const ProcHead &hd, co
         // (acc[1], the number of members: counted per wave by the caller)
     }
     return w;
+}
+
+// The step pass over one wave's slice of the kept list, two members per lane and trip (A/B builds, see process_body).  e / w: the lane's first
+// entry (and, unpacked lists, its weight), already requested by the caller.
+template <bool PF>
+__device__ __forceinline__ void step_members2(const PairSrc &src, const ProcHead &hd, const KernConsts &kc, const cvo_math::XiConsts &xc,
+                                              const CVO_GLOBAL char *kept_w, const float *kept_a, const int packed, const unsigned ebase,
+                                              const unsigned wcap, const unsigned n, const int lane, uint2 e, float w, double *acc)
+{
+    const float *Rt = hd.Rt, *tt = hd.tt;
+    uint2 eb = load8(kept_w, min((unsigned)lane + 64u, wcap - 1u));
+    for (unsigned off = lane; off < n; off += 128u) {
+        const bool two = off + 64u < n;
+        if (off >= 128u && !PF) { e = load8(kept_w, off); eb = load8(kept_w, min(off + 64u, wcap - 1u)); }
+        float wa = w, wb = 0.0f;
+        if (!packed) { wa = kept_a[off]; wb = kept_a[min(off + 64u, wcap - 1u)]; }
+        if (!two) { eb = e; wb = wa; }
+        unsigned ia, ja, ib, jb;
+        float ma, mb;
+        kept_unpack(packed, ebase, e, wa, ia, ja, ma);
+        kept_unpack(packed, ebase, eb, wb, ib, jb, mb);
+        if (!two) mb = 0.0f;
+        // (the four gathers, then the next trip's entries behind them: loads return in order)
+        const float4 xa = load_pos<false>(src.pos_a, ia * 16u), ya = load_pos<false>(src.pos_b, ja * 16u);
+        const float4 xb = load_pos<false>(src.pos_a, ib * 16u), yb = load_pos<false>(src.pos_b, jb * 16u);
+        if (PF) { e = load8(kept_w, min(off + 128u, wcap - 1u)); eb = load8(kept_w, min(off + 192u, wcap - 1u)); }
+        f32x2 px = {xa.x, xb.x}, py = {xa.y, xb.y}, pz = {xa.z, xb.z};
+        f32x2 qx = {ya.x, yb.x}, qy = {ya.y, yb.y}, qz = {ya.z, yb.z};
+        if (src.tf_a) {   // (apply_tf's expressions)
+            const f32x2 ox = ((Rt[0] * px + Rt[1] * py) + Rt[2] * pz) + tt[0];
+            const f32x2 oy = ((Rt[3] * px + Rt[4] * py) + Rt[5] * pz) + tt[1];
+            const f32x2 oz = ((Rt[6] * px + Rt[7] * py) + Rt[8] * pz) + tt[2];
+            px = ox; py = oy; pz = oz;
+        }
+        if (src.tf_b) {
+            const f32x2 ox = ((Rt[0] * qx + Rt[1] * qy) + Rt[2] * qz) + tt[0];
+            const f32x2 oy = ((Rt[3] * qx + Rt[4] * qy) + Rt[5] * qz) + tt[1];
+            const f32x2 oz = ((Rt[6] * qx + Rt[7] * qy) + Rt[8] * qz) + tt[2];
+            qx = ox; qy = oy; qz = oz;
+        }
+        const f32x2 mw = {ma, mb};
+        pair_step_sums2(kc, xc, qx, qy, qz, px - qx, py - qy, pz - qz, mw, acc);
+    }
 }
 
 // LDS of a list-kernel block: handed in, so that launches whose blocks play different
@@ -1246,6 +1331,12 @@ __device__ __forceinline__ void process_body(const ProcessArgs &a, const unsigne
         const CVO_GLOBAL char *kept_w = pin_global<PIPE>(a.kept_ij + base);
         const unsigned ebase = pin_u32<PIPE>(a.kept_ebase), wcap = pin_u32<PIPE>(a.kept_wcap);
         constexpr bool PF = PIPE && kPrefetchBuild;
+#if defined(CVO_STEP_TWO) && !defined(CVO_PROBE_STEP_EXP)
+        // (A/B builds: TWO members per lane and trip -- entries off and off + 64, the ones the lane takes in two trips of one --, the float32
+        // part of their terms through packed instructions, their float64 tails in the old order: the same partial sums bit for bit)
+        step_members2<PF>(src, hd, kc, xc, kept_w, a.kept_a + base, packed, ebase, wcap, n, lane, e, w, acc);
+        if (false)
+#endif
         for (unsigned off = lane; off < n; off += 64) {
             if (off >= 64) { if (!PF) e = load8(kept_w, off); if (!packed) w = a.kept_a[base + off]; }
             uint2 e_next = e;
